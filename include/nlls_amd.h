@@ -1,0 +1,218 @@
+/*
+ * nlls_amd.h -- C ABI of the MI355X-native Gauss-Newton / Levenberg-Marquardt inner loop
+ *               for NLLSsolver.jl (drop-in for the hot path only).
+ *
+ * The reference (NLLSsolver.jl v4.0.3, pure Julia) has no FFI of its own.  The seam this library
+ * plugs into is Julia dispatch on the linear-system type: NLLSInternal{LSType} is parametric
+ * (src/structs.jl:81-104) and the only factory is makesymmvls (src/linearsystem.jl:91-124, called
+ * from src/optimize.jl:16).  A Julia shim type `MultiVariateLSgpu` (julia/NLLSsolverAMD.jl, shown in
+ * INTEGRATION.md) overloads exactly the generic functions listed next to each entry point below and
+ * `ccall`s them.  Every function:
+ *   - returns int: 0 = NLLS_OK, negative = error (message via nlls_last_error),
+ *   - never throws / longjmps across the boundary,
+ *   - takes plain pointers + sizes; host buffers are only read/written during the call,
+ *   - takes variable indices 1-BASED exactly as NLLSsolver stores them (SimpleError2.varind,
+ *     src/residual.jl:4-7; blockindices, src/linearsystem.jl:93-102) and rebases internally,
+ *   - is synchronous on return for anything it writes to a host pointer.
+ * One context per host task; no re-entrancy (the reference is single threaded).
+ *
+ * Closed-world kinds: a HIP kernel cannot call a Julia closure, so residuals,
+ * variables and robustifiers are a registry of kinds with device implementations.  Anything else
+ * makes nlls_upload_structure return NLLS_ERR_UNSUPPORTED and the shim keeps the reference's CPU
+ * linear system (decline, not failure).
+ */
+#ifndef NLLS_AMD_H
+#define NLLS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nlls_ctx nlls_ctx;
+
+/* ---- error codes ------------------------------------------------------------------------- */
+#define NLLS_OK                 0
+#define NLLS_ERR_INVALID_ARG   (-1)
+#define NLLS_ERR_UNSUPPORTED   (-2) /* unregistered kind / structure: caller falls back to CPU path */
+#define NLLS_ERR_HIP           (-3) /* a HIP runtime call failed                                    */
+#define NLLS_ERR_NOT_READY     (-4) /* call order violated (e.g. solve before sweep)                */
+#define NLLS_ERR_NOT_SPD       (-5) /* factorisation hit a non-positive / zero pivot                */
+#define NLLS_ERR_NO_DEVICE     (-6) /* no gfx950 device visible: the product path never falls back  */
+
+/* ---- compile-time limits mirrored from src/NLLSsolver.jl:28-30 ----------------------------- */
+#define NLLS_MAX_ARGS        10
+#define NLLS_MAX_BLOCK_SZ    32
+#define NLLS_MAX_STATIC_VAR  64
+
+/* ---- variable kinds: nvars()/update() of src/variable.jl:3-32, src/robustadaptive.jl:3-23 --- */
+#define NLLS_VAR_EUCLIDEAN              1 /* EuclideanVector{N} / Number (N=1): dof N, storage N, v+d       */
+#define NLLS_VAR_ZERO_TO_INF            2 /* ZeroToInfScalar: dof 1, storage 1, max(v,floatmin)*exp(d)      */
+#define NLLS_VAR_ZERO_TO_ONE            3 /* ZeroToOneScalar: dof 1, storage 1, src/variable.jl:29-32       */
+#define NLLS_VAR_CONTAMINATED_GAUSSIAN  4 /* ContaminatedGaussian: dof 3, storage 3 = (1/s1, 1/s2, w)       */
+#define NLLS_VAR_POSE_SO3               5 /* NEW: R (3x3 col-major) + t, dof 6, storage 12,
+                                             R <- R*expm([d(1:3)]x), t <- t + d(4:6)                      */
+
+/* ---- residual kinds: computeresidual() bodies ----------------------------------------------- */
+#define NLLS_RES_BA_AFFINE        1 /* SimpleError2{2}: (pose[1:3].X, pose[4:6].X) - meas; vars (EUCL6, EUCL3);
+                                       data = meas[2]                      test/optimizeba.jl:4               */
+#define NLLS_RES_ROSENBROCK_A     2 /* a*(1-x); vars (EUCL1); data = a     test/functional.jl:5-16            */
+#define NLLS_RES_ROSENBROCK_B     3 /* b*(x^2-y); vars (EUCL1,EUCL1); data = b   test/functional.jl:18-25     */
+#define NLLS_RES_ROSENBROCK_2D    4 /* (a(1-x1), b(x1^2-x2)); vars (EUCL2); data = (a,b)  examples/rosenbrock.jl:10-20 */
+#define NLLS_RES_CURVE_EXP4       5 /* a*exp(b*t)+c*t+d - y; vars 4x EUCL1; data = (t,y)  (BASELINE config 2) */
+#define NLLS_RES_ADAPTIVE_MEAN    6 /* AbstractAdaptiveResidual: mean - data; vars (CONT_GAUSS, EUCL1);
+                                       data = value                        test/adaptivecost.jl:3-13          */
+#define NLLS_RES_BA_SO3           7 /* NEW: pinhole projection of R*X+t, normalised image plane;
+                                       vars (POSE_SO3, EUCL3); data = meas[2]                                  */
+#define NLLS_RES_BA_SO3_ADAPTIVE  8 /* NEW: as 7 with the robust kernel as variable #1 (src/residual.jl:46-47);
+                                       vars (CONT_GAUSS, POSE_SO3, EUCL3); data = meas[2]                      */
+#define NLLS_RES_KIND_COUNT       9
+
+/* ---- robust kernels: src/robust.jl:7-77 ------------------------------------------------------ */
+#define NLLS_ROBUST_NONE           0 /* NoRobust                                               */
+#define NLLS_ROBUST_HUBER          1 /* HuberKernel(w):   params[0] = width                    */
+#define NLLS_ROBUST_HUBER2O        2 /* Huber2oKernel(w): params[0] = width                    */
+#define NLLS_ROBUST_GEMAN_MCCLURE  3 /* GemanMcclureKernel(w): params[0] = width               */
+#define NLLS_ROBUST_SCALED      0x10 /* OR-ed flag: Scaled(inner, height): params[1] = height  */
+/* adaptive residual kinds ignore robust_kind: their kernel is variable #1. */
+
+/* ---- problem description --------------------------------------------------------------------- */
+/* One group per Julia cost type (one VectorRepo entry, src/VectorRepo.jl:1-7), in values(costs)
+ * order, each cost's fields struct-of-arrays. */
+typedef struct nlls_cost_group {
+    int32_t        res_kind;          /* NLLS_RES_*                                                  */
+    int32_t        robust_kind;       /* NLLS_ROBUST_* (| NLLS_ROBUST_SCALED)                        */
+    double         robust_params[4];
+    int64_t        ncost;
+    const int64_t* varind;            /* [ncost][ndeps], 1-based variable indices (varindices())     */
+    const double*  data;              /* [ncost][ndata] per-cost payload (measurement etc.)          */
+} nlls_cost_group;
+
+typedef struct nlls_info {
+    int32_t is_sparse;       /* 1: MultiVariateLSsparse/BlockSparseMatrix, 0: MultiVariateLSdense   */
+    int32_t has_schur;       /* 1: an independent variable set is eliminated before the dense solve  */
+    int64_t nvar;            /* number of variable blocks                                            */
+    int64_t nblocks;         /* number of unfixed blocks                                             */
+    int64_t ndof;            /* length of b / x                                                      */
+    int64_t nnz_data;        /* length of A.data (BSM) or ndof*ndof (dense)                          */
+    int64_t nblocks_stored;  /* number of stored blocks in the BSM                                   */
+    int64_t ncost;           /* total number of cost blocks                                          */
+    int64_t var_storage;     /* length of the packed variable vector                                 */
+    int64_t nschur_blocks;   /* number of eliminated (Schur) variable blocks                         */
+    int64_t nreduced_dof;    /* order of the dense reduced system                                    */
+    int64_t owner_path;      /* 1: deterministic owner-gather accumulate, 0: atomic scatter          */
+} nlls_info;
+
+/* flags for nlls_upload_structure */
+#define NLLS_FLAG_FORCE_ATOMIC   0x1  /* always use the generic atomic scatter accumulate            */
+#define NLLS_FLAG_NO_SCHUR       0x2  /* solve the full system densely (small problems / testing)    */
+#define NLLS_FLAG_FORCE_SPARSE   0x4  /* makesymmvls(...; formarginalization) style: BSM regardless   */
+
+/* variable-set ids for the on-device copies of problem.variables / varnext / varbest
+ * (src/problem.jl:9-12) */
+#define NLLS_VARS_CURRENT 0
+#define NLLS_VARS_NEXT    1
+#define NLLS_VARS_BEST    2
+
+/* ---- lifecycle --------------------------------------------------------------------------------
+ * replaces: GC-managed MultiVariateLSsparse/dense objects (src/linearsystem.jl:44-87).          */
+int  nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out);
+int  nlls_ctx_destroy(nlls_ctx* ctx);
+const char* nlls_last_error(const nlls_ctx* ctx);
+/* run all launches of this context on an externally owned hipStream_t (0 = the context's own) */
+int  nlls_set_stream(nlls_ctx* ctx, void* hip_stream);
+/* observation sharding for N ranks: must precede nlls_upload_structure */
+int  nlls_set_shard(nlls_ctx* ctx, int32_t rank, int32_t nranks);
+
+/* static helpers (no context): storage length / dof of a variable kind; ndeps/nres/ndata of a
+ * residual kind, and the variable kind+dim it expects in each slot. */
+int  nlls_var_storage(int32_t var_kind, int32_t var_dim);
+int  nlls_var_dof(int32_t var_kind, int32_t var_dim);
+int  nlls_res_ndeps(int32_t res_kind);
+int  nlls_res_nres(int32_t res_kind);
+int  nlls_res_ndata(int32_t res_kind);
+int  nlls_res_slot_kind(int32_t res_kind, int32_t slot, int32_t* var_kind, int32_t* var_dim);
+
+/* ---- factory ----------------------------------------------------------------------------------
+ * replaces: makesymmvls(problem, unfixed, nblocks)   src/linearsystem.jl:91-124
+ * Builds blocksizes, the sparse/dense decision (src/utils.jl:108-120), the BlockSparseMatrix
+ * pattern and offsets exactly as src/BlockSparseMatrix.jl:30-47, boffsets
+ * (src/linearsystem.jl:36-41) and all device-side work lists.
+ * blockindices[i] = 0 for a fixed variable, else its 1-based block number (linearsystem.jl:93-102). */
+int  nlls_upload_structure(nlls_ctx* ctx,
+                           int64_t nvar, const int32_t* var_kind, const int32_t* var_dim,
+                           const uint64_t* blockindices,
+                           int32_t ngroups, const nlls_cost_group* groups,
+                           int32_t flags);
+int  nlls_get_info(const nlls_ctx* ctx, nlls_info* out);
+/* parity/debug: indicestransposed of the BSM as CSC (colptr[nblocks+1], rowval, nzval; all 1-based)
+ * and boffsets[nblocks] (1-based).  Any pointer may be NULL. */
+int  nlls_get_bsm_index(const nlls_ctx* ctx, int64_t* colptr, int64_t* rowval, int64_t* nzval,
+                        int64_t* boffsets);
+
+/* ---- variables --------------------------------------------------------------------------------
+ * packed layout: variable i occupies nlls_var_storage(kind_i, dim_i) doubles, in variable order. */
+int  nlls_set_variables(nlls_ctx* ctx, int32_t which, const double* packed);
+int  nlls_get_variables(nlls_ctx* ctx, int32_t which, double* packed);
+int  nlls_swap_variables(nlls_ctx* ctx, int32_t a, int32_t b);   /* src/optimize.jl:207-214 */
+int  nlls_copy_variables(nlls_ctx* ctx, int32_t dst, int32_t src);/* deepcopy, src/optimize.jl:81,141 */
+
+/* ---- sweeps -----------------------------------------------------------------------------------
+ * replaces: zero!(linsystem) + costgradhess!(linsystem, vars, costs)
+ *           src/optimize.jl:118,167-170 -> src/cost.jl:29-54, src/residual.jl:57-111,
+ *           src/linearsystem.jl:132-175.  Evaluated at NLLS_VARS_CURRENT.  Resets the damping. */
+int  nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out);
+/* replaces: cost(vars, costs)  src/cost.jl:10-13, src/residual.jl:49-55 */
+int  nlls_sweep_cost(nlls_ctx* ctx, int32_t which, double* cost_out);
+
+/* ---- linear system access ---------------------------------------------------------------------
+ * replaces: gethessgrad (src/linearsystem.jl:180-190), initlambda (src/iterators.jl:131-137). */
+int  nlls_get_grad(nlls_ctx* ctx, double* b_out);                 /* linsystem.b            */
+int  nlls_get_bsm_data(nlls_ctx* ctx, double* data_out);          /* A.data (BSM or dense)  */
+int  nlls_max_abs_diag(nlls_ctx* ctx, double* out);               /* max_i |H_ii|           */
+int  nlls_grad_sqnorm(nlls_ctx* ctx, double* out);                /* gradient' * gradient   */
+int  nlls_grad_quadform(nlls_ctx* ctx, double* out);              /* fast_bAb(H, gradient)  */
+
+/* replaces: uniformscaling!(hessian, k)  src/iterators.jl:149,162 */
+int  nlls_damp(nlls_ctx* ctx, double delta);
+/* replaces: negate!(solve!(linsystem, options))  src/iterators.jl:152 -> src/linearsolver.jl:28-32.
+ * Solves (H + lambda I) y = b and stores x = -y on the device; x_out (length ndof) may be NULL. */
+int  nlls_solve(nlls_ctx* ctx, double* x_out);
+int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
+int  nlls_get_step(nlls_ctx* ctx, double* x_out);
+int  nlls_step_maxabs(nlls_ctx* ctx, double* out);                /* maximum(abs, linsystem.x) */
+int  nlls_step_norm(nlls_ctx* ctx, double* out);                  /* norm(linsystem.x)         */
+/* replaces: fast_bAb(hessian, x), dot(gradient, x)  src/iterators.jl:163, src/utils.jl:95-106.
+ * Uses the CURRENT damping (the reference un-damps first, src/iterators.jl:162). */
+int  nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out);
+/* replaces: update!(to, from, linsystem)  src/linearsystem.jl:206-213:
+ * vars[to] = update(vars[from], x) for unfixed variables, copy for fixed ones. */
+int  nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from);
+
+/* ---- multi-GPU --------------------------------------------------------------------------------
+ * Device buffers that must be summed across ranks.  After nlls_sweep_gradhess_local:
+ * stage 0 = [cost | reduced-block diagonal data | reduced part of b].  After nlls_schur_local:
+ * stage 1 = [S (lower, dense) | s].  Pointers are device addresses valid until the next upload. */
+int  nlls_sweep_gradhess_local(nlls_ctx* ctx);
+int  nlls_sweep_gradhess_finish(nlls_ctx* ctx, double* cost_out);
+int  nlls_sweep_cost_local(nlls_ctx* ctx, int32_t which);
+int  nlls_sweep_cost_finish(nlls_ctx* ctx, double* cost_out);
+int  nlls_solve_local(nlls_ctx* ctx);
+int  nlls_solve_finish(nlls_ctx* ctx, double* x_out);
+int  nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count);
+/* after nlls_solve_finish every rank holds x for its own eliminated blocks only;
+ * this returns the [offset,count) range of x that this rank owns plus the reduced part */
+int  nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count,
+                         int64_t* own_offset, int64_t* own_count);
+
+/* ---- profiling helper: run the accumulate kernel(s) `reps` times between two HIP events on the
+ * context's stream; returns average ms per sweep (used by bench.py for the roofline line). */
+int  nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg);
+int  nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg);
+int  nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLLS_AMD_H */

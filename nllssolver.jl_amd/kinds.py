@@ -1,0 +1,97 @@
+"""Registry of variable / residual / robustifier kinds (mirrors include/nlls_amd.h).
+
+The reference lets users write arbitrary Julia residuals differentiated by ForwardDiff
+(src/autodiff.jl:81-93); a HIP kernel cannot call those, so the accelerated path is a closed
+registry.  Anything outside it is declined (NLLS_ERR_UNSUPPORTED).
+"""
+# variable kinds: nvars()/update() of src/variable.jl:3-32, src/robustadaptive.jl:3-23
+VAR_EUCLIDEAN = 1
+VAR_ZERO_TO_INF = 2
+VAR_ZERO_TO_ONE = 3
+VAR_CONTAMINATED_GAUSSIAN = 4
+VAR_POSE_SO3 = 5
+
+# residual kinds
+RES_BA_AFFINE = 1         # test/optimizeba.jl:4
+RES_ROSENBROCK_A = 2      # test/functional.jl:5-16
+RES_ROSENBROCK_B = 3      # test/functional.jl:18-25
+RES_ROSENBROCK_2D = 4     # examples/rosenbrock.jl:10-20
+RES_CURVE_EXP4 = 5        # BASELINE.json config 2
+RES_ADAPTIVE_MEAN = 6     # test/adaptivecost.jl:3-13
+RES_BA_SO3 = 7            # new
+RES_BA_SO3_ADAPTIVE = 8   # new
+
+# robust kernels: src/robust.jl:7-77
+ROBUST_NONE = 0
+ROBUST_HUBER = 1
+ROBUST_HUBER2O = 2
+ROBUST_GEMAN_MCCLURE = 3
+ROBUST_SCALED = 0x10
+
+# (ndeps, nres, ndata, adaptive, ((slot kind, slot dim), ...))
+RES_TABLE = {
+    RES_BA_AFFINE: (2, 2, 2, False, ((VAR_EUCLIDEAN, 6), (VAR_EUCLIDEAN, 3))),
+    RES_ROSENBROCK_A: (1, 1, 1, False, ((VAR_EUCLIDEAN, 1),)),
+    RES_ROSENBROCK_B: (2, 1, 1, False, ((VAR_EUCLIDEAN, 1), (VAR_EUCLIDEAN, 1))),
+    RES_ROSENBROCK_2D: (1, 2, 2, False, ((VAR_EUCLIDEAN, 2),)),
+    RES_CURVE_EXP4: (4, 1, 2, False, ((VAR_EUCLIDEAN, 1),) * 4),
+    RES_ADAPTIVE_MEAN: (2, 1, 1, True, ((VAR_CONTAMINATED_GAUSSIAN, 3), (VAR_EUCLIDEAN, 1))),
+    RES_BA_SO3: (2, 2, 2, False, ((VAR_POSE_SO3, 6), (VAR_EUCLIDEAN, 3))),
+    RES_BA_SO3_ADAPTIVE: (3, 2, 2, True, ((VAR_CONTAMINATED_GAUSSIAN, 3), (VAR_POSE_SO3, 6), (VAR_EUCLIDEAN, 3))),
+}
+
+
+def res_ndeps(kind):
+    return RES_TABLE[kind][0]
+
+
+def res_nres(kind):
+    return RES_TABLE[kind][1]
+
+
+def res_ndata(kind):
+    return RES_TABLE[kind][2]
+
+
+def var_storage(kind, dim):
+    """Storage length of a variable (may exceed its dof, src/docstrings.jl:11-14)."""
+    return {VAR_EUCLIDEAN: dim, VAR_ZERO_TO_INF: 1, VAR_ZERO_TO_ONE: 1,
+            VAR_CONTAMINATED_GAUSSIAN: 3, VAR_POSE_SO3: 12}[kind]
+
+
+def var_dof(kind, dim):
+    """nvars(): src/variable.jl:4,9,21,28; src/robustadaptive.jl:21."""
+    return {VAR_EUCLIDEAN: dim, VAR_ZERO_TO_INF: 1, VAR_ZERO_TO_ONE: 1,
+            VAR_CONTAMINATED_GAUSSIAN: 3, VAR_POSE_SO3: 6}[kind]
+
+
+class Robustifier:
+    """A fixed-parameter robust kernel: (kind, params) as passed in nlls_cost_group."""
+
+    def __init__(self, kind=ROBUST_NONE, params=()):
+        self.kind = int(kind)
+        self.params = tuple(float(p) for p in params) + (0.0,) * (4 - len(params))
+
+    def key(self):
+        return (self.kind, self.params)
+
+
+def NoRobust():                       # src/robust.jl:7-12
+    return Robustifier(ROBUST_NONE)
+
+
+def HuberKernel(w):                   # src/robust.jl:40-45
+    return Robustifier(ROBUST_HUBER, (w,))
+
+
+def Huber2oKernel(w):                 # src/robust.jl:46
+    return Robustifier(ROBUST_HUBER2O, (w,))
+
+
+def GemanMcclureKernel(w):            # src/robust.jl:63-69
+    return Robustifier(ROBUST_GEMAN_MCCLURE, (w,))
+
+
+def Scaled(inner, height):            # src/robust.jl:22-31
+    assert not (inner.kind & ROBUST_SCALED), "nested Scaled is not a registered kernel"
+    return Robustifier(inner.kind | ROBUST_SCALED, (inner.params[0], height))

@@ -1,0 +1,140 @@
+"""Synthetic problem generators restating the reference's own test generators.
+
+create_ba_problem / perturb_ba_problem follow test/optimizeba.jl:6-47 so that the STRUCTURE
+(variable order, banded visibility, camera-major cost order, noiseless measurements) is exactly
+the reference's; random values come from numpy's PCG64 (Julia's RNG stream is not reproducible
+outside Julia), which is what "values match in distribution" means in SURVEY 8d.
+"""
+import numpy as np
+
+from . import kinds as K
+from .problem import NLLSProblem
+
+
+def ba_visibility(ncameras, nlandmarks, propvisible):
+    """visibility[c, l] = |c - t_l| <= K-th smallest, t = LinRange(2, ncameras-1, nlandmarks)
+    (test/optimizeba.jl:22-23).  Returns (camind, landmark) 1-based pairs in camera-major order."""
+    t = np.linspace(2.0, ncameras - 1.0, nlandmarks) if nlandmarks > 1 else np.array([2.0])
+    total = ncameras * nlandmarks
+    kth = int(np.ceil(total * propvisible))
+    if total <= 40_000_000:
+        vis = np.abs(np.arange(1, ncameras + 1, dtype=np.float64)[:, None] - t[None, :])
+        thr = np.partition(vis.ravel(), kth - 1)[kth - 1]
+        cam, lm = np.nonzero(vis <= thr)               # row-major nonzero == camera-major order
+        return cam + 1, lm + 1
+    # large case: bisection on the threshold using closed-form per-landmark counts
+    def count(tau):
+        lo = np.maximum(np.ceil(t - tau), 1); hi = np.minimum(np.floor(t + tau), ncameras)
+        return int(np.maximum(hi - lo + 1, 0).sum())
+    a, b = 0.0, float(ncameras)
+    for _ in range(200):
+        m = 0.5 * (a + b)
+        if count(m) >= kth:
+            b = m
+        else:
+            a = m
+        if b - a <= np.spacing(b):
+            break
+    thr = b
+    lo = np.maximum(np.ceil(t - thr), 1).astype(np.int64); hi = np.minimum(np.floor(t + thr), ncameras).astype(np.int64)
+    cnt = np.maximum(hi - lo + 1, 0)
+    lm = np.repeat(np.arange(1, nlandmarks + 1), cnt)
+    start = np.repeat(lo, cnt); pos = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    cam = start + pos
+    order = np.lexsort((lm, cam))                      # camera-major (test/optimizeba.jl:24-31)
+    return cam[order], lm[order]
+
+
+def create_ba_problem(ncameras, nlandmarks, propvisible, seed=1, robust=None, outlier_frac=0.0, outlier_sigma=0.0):
+    """test/optimizeba.jl:6-35: affine 6-dof cameras, 3-dof landmarks, 2-dim reprojection residuals."""
+    rng = np.random.default_rng(seed)
+    problem = NLLSProblem()
+    cams = rng.standard_normal((ncameras, 6)) + np.array([1.0, 0, 0, 0, 1.0, 0])      # :10-13
+    pts = rng.random((nlandmarks, 3)) + np.array([-0.5, -0.5, 10.0])                  # :16-19
+    problem.addvariables(cams)
+    problem.addvariables(pts)
+    cam, lm = ba_visibility(ncameras, nlandmarks, propvisible)
+    c, X = cams[cam - 1], pts[lm - 1]
+    meas = np.stack([(c[:, 0:3] * X).sum(1), (c[:, 3:6] * X).sum(1)], axis=1)          # generatemeasurement :4
+    if outlier_frac > 0:
+        bad = rng.random(meas.shape[0]) < outlier_frac
+        meas[bad] += rng.standard_normal((int(bad.sum()), 2)) * outlier_sigma
+    varind = np.stack([cam, lm + ncameras], axis=1)
+    problem.addcosts(K.RES_BA_AFFINE, varind, meas, robust)
+    return problem
+
+
+def perturb_ba_problem(problem, pointnoise, posenoise, seed=2):
+    """test/optimizeba.jl:38-47."""
+    rng = np.random.default_rng(seed)
+    kk, dd, off = problem.var_kind, problem.var_dim, problem.var_offsets
+    v = problem.variables
+    is_pt = (kk == K.VAR_EUCLIDEAN) & (dd == 3)
+    is_cam = (kk == K.VAR_EUCLIDEAN) & (dd == 6)
+    for mask, dim, noise in ((is_pt, 3, pointnoise), (is_cam, 6, posenoise)):
+        idx = np.nonzero(mask)[0]
+        if idx.size and noise != 0:
+            pos = (off[idx][:, None] + np.arange(dim)[None, :]).ravel()
+            v[pos] += rng.standard_normal(pos.size) * noise
+    is_pose = kk == K.VAR_POSE_SO3
+    idx = np.nonzero(is_pose)[0]
+    if idx.size and posenoise != 0:
+        from .variables import so3_exp
+        for i in idx:
+            d = rng.standard_normal(6) * posenoise
+            st = v[off[i]:off[i] + 12]
+            R = st[:9].reshape(3, 3, order="F") @ so3_exp(d[:3])
+            st[:9] = R.ravel(order="F"); st[9:] += d[3:]
+    problem._gpu = None
+    return problem
+
+
+def create_curvefit_problem(n=10_000, seed=1, noise=0.01):
+    """BASELINE config 2: n 1-dim residuals a*exp(b*t)+c*t+d - y over 4 scalar variables
+    (4 blocks of dof 1 -> MultiVariateLSdense, src/linearsystem.jl:105-106,123)."""
+    rng = np.random.default_rng(seed)
+    truth = np.array([2.0, -1.5, 0.7, 0.3])
+    t = rng.random(n) * 2.0
+    y = truth[0] * np.exp(truth[1] * t) + truth[2] * t + truth[3] + rng.standard_normal(n) * noise
+    problem = NLLSProblem()
+    for v in (1.5, -1.0, 0.0, 0.0):
+        problem.addvariable(v)
+    problem.addcosts(K.RES_CURVE_EXP4, np.tile(np.array([1, 2, 3, 4]), (n, 1)), np.stack([t, y], axis=1))
+    return problem, truth
+
+
+def create_so3_ba_problem(ncameras, nlandmarks, propvisible, seed=1, adaptive=True, outlier_frac=0.1,
+                          noise=1e-3, outlier_sigma=0.1, robust=None):
+    """BASELINE config 5: pinhole cameras with SO(3) rotations (new kind), optionally with
+    a ContaminatedGaussian adaptive kernel as variable #1 (src/residual.jl:46-47)."""
+    from .variables import so3_exp
+    rng = np.random.default_rng(seed)
+    problem = NLLSProblem()
+    first = 1
+    if adaptive:
+        from .variables import contaminated_gaussian
+        problem.addvariable(contaminated_gaussian(2 * noise, 0.5 * outlier_sigma, 0.5), K.VAR_CONTAMINATED_GAUSSIAN)
+        first = 2
+    poses = np.zeros((ncameras, 12))
+    ang = np.linspace(-0.3, 0.3, ncameras)
+    for i in range(ncameras):
+        R = so3_exp(np.array([0.05 * rng.standard_normal(), ang[i], 0.05 * rng.standard_normal()]))
+        poses[i, :9] = R.ravel(order="F")
+        poses[i, 9:] = np.array([0.2 * rng.standard_normal(), 0.2 * rng.standard_normal(), 0.1 * rng.standard_normal()])
+    pts = rng.random((nlandmarks, 3)) + np.array([-0.5, -0.5, 5.0])
+    problem.addvariables(poses, K.VAR_POSE_SO3)
+    problem.addvariables(pts)
+    cam, lm = ba_visibility(ncameras, nlandmarks, propvisible)
+    R = poses[cam - 1, :9].reshape(-1, 3, 3).transpose(0, 2, 1)      # col-major storage -> R[n, r, c]
+    Y = np.einsum("nrc,nc->nr", R, pts[lm - 1]) + poses[cam - 1, 9:]
+    meas = Y[:, :2] / Y[:, 2:3] + rng.standard_normal((cam.size, 2)) * noise
+    bad = rng.random(cam.size) < outlier_frac
+    meas[bad] += rng.standard_normal((int(bad.sum()), 2)) * outlier_sigma
+    camv = cam + (first - 1)
+    lmv = lm + ncameras + (first - 1)
+    if adaptive:
+        varind = np.stack([np.ones_like(camv), camv, lmv], axis=1)
+        problem.addcosts(K.RES_BA_SO3_ADAPTIVE, varind, meas)
+    else:
+        problem.addcosts(K.RES_BA_SO3, np.stack([camv, lmv], axis=1), meas, robust)
+    return problem
