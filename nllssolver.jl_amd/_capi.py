@@ -1,0 +1,242 @@
+"""ctypes binding of csrc/libnlls_amd.so (the C ABI of include/nlls_amd.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or no gfx950 device is
+visible, every compute entry point raises NllsError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnlls_amd.so")
+
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOT_READY, ERR_NOT_SPD, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+FLAG_FORCE_ATOMIC, FLAG_NO_SCHUR, FLAG_FORCE_SPARSE = 1, 2, 4
+VARS_CURRENT, VARS_NEXT, VARS_BEST = 0, 1, 2
+
+# every symbol include/nlls_amd.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = """nlls_ctx_create nlls_ctx_destroy nlls_last_error nlls_set_stream nlls_set_shard nlls_var_storage nlls_var_dof
+nlls_res_ndeps nlls_res_nres nlls_res_ndata nlls_res_slot_kind nlls_upload_structure nlls_get_info nlls_get_bsm_index
+nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nlls_sweep_gradhess nlls_sweep_cost
+nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_set_step
+nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
+nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
+nlls_get_reduce_buffer nlls_get_step_shard nlls_time_sweep_gradhess nlls_time_sweep_cost nlls_time_solve""".split()
+
+
+class NllsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nlls_amd error {code}: {msg}")
+        self.code = code
+
+
+class CostGroup(C.Structure):
+    _fields_ = [("res_kind", C.c_int32), ("robust_kind", C.c_int32), ("robust_params", C.c_double * 4),
+                ("ncost", C.c_int64), ("varind", C.c_void_p), ("data", C.c_void_p)]
+
+
+class Info(C.Structure):
+    _fields_ = [("is_sparse", C.c_int32), ("has_schur", C.c_int32), ("nvar", C.c_int64), ("nblocks", C.c_int64),
+                ("ndof", C.c_int64), ("nnz_data", C.c_int64), ("nblocks_stored", C.c_int64), ("ncost", C.c_int64),
+                ("var_storage", C.c_int64), ("nschur_blocks", C.c_int64), ("nreduced_dof", C.c_int64),
+                ("owner_path", C.c_int64)]
+
+
+def build(force=False):
+    """Compile libnlls_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", csrc, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", csrc, "libnlls_amd.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library or fail loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NllsError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C nllssolver.jl_amd/csrc); "
+                                           "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+        L.nlls_ctx_create.argtypes = [vp, i32, C.POINTER(vp)]
+        L.nlls_ctx_destroy.argtypes = [vp]
+        L.nlls_last_error.argtypes = [vp]; L.nlls_last_error.restype = C.c_char_p
+        L.nlls_set_stream.argtypes = [vp, vp]
+        L.nlls_set_shard.argtypes = [vp, i32, i32]
+        L.nlls_var_storage.argtypes = [i32, i32]; L.nlls_var_dof.argtypes = [i32, i32]
+        L.nlls_res_ndeps.argtypes = [i32]; L.nlls_res_nres.argtypes = [i32]; L.nlls_res_ndata.argtypes = [i32]
+        L.nlls_res_slot_kind.argtypes = [i32, i32, vp, vp]
+        L.nlls_upload_structure.argtypes = [vp, i64, vp, vp, vp, i32, vp, i32]
+        L.nlls_get_info.argtypes = [vp, vp]
+        L.nlls_get_bsm_index.argtypes = [vp, vp, vp, vp, vp]
+        L.nlls_set_variables.argtypes = [vp, i32, vp]; L.nlls_get_variables.argtypes = [vp, i32, vp]
+        L.nlls_swap_variables.argtypes = [vp, i32, i32]; L.nlls_copy_variables.argtypes = [vp, i32, i32]
+        L.nlls_sweep_gradhess.argtypes = [vp, vp]; L.nlls_sweep_cost.argtypes = [vp, i32, vp]
+        L.nlls_get_grad.argtypes = [vp, vp]; L.nlls_get_bsm_data.argtypes = [vp, vp]
+        L.nlls_max_abs_diag.argtypes = [vp, vp]; L.nlls_grad_sqnorm.argtypes = [vp, vp]; L.nlls_grad_quadform.argtypes = [vp, vp]
+        L.nlls_damp.argtypes = [vp, dbl]
+        L.nlls_solve.argtypes = [vp, vp]; L.nlls_set_step.argtypes = [vp, vp]; L.nlls_get_step.argtypes = [vp, vp]
+        L.nlls_step_maxabs.argtypes = [vp, vp]; L.nlls_step_norm.argtypes = [vp, vp]
+        L.nlls_quadform.argtypes = [vp, vp, vp]
+        L.nlls_retract.argtypes = [vp, i32, i32]
+        L.nlls_sweep_gradhess_local.argtypes = [vp]; L.nlls_sweep_gradhess_finish.argtypes = [vp, vp]
+        L.nlls_sweep_cost_local.argtypes = [vp, i32]; L.nlls_sweep_cost_finish.argtypes = [vp, vp]
+        L.nlls_solve_local.argtypes = [vp]; L.nlls_solve_finish.argtypes = [vp, vp]
+        L.nlls_get_reduce_buffer.argtypes = [vp, i32, vp, vp]
+        L.nlls_get_step_shard.argtypes = [vp, vp, vp, vp, vp]
+        L.nlls_time_sweep_gradhess.argtypes = [vp, i32, vp]; L.nlls_time_sweep_cost.argtypes = [vp, i32, vp]
+        L.nlls_time_solve.argtypes = [vp, i32, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """Owns one nlls_ctx."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        dev = np.array([device], np.int32)
+        rc = self.L.nlls_ctx_create(_p(dev), 1, C.byref(self.h))
+        if rc != OK:
+            self.h = None
+            raise NllsError(rc, "nlls_ctx_create failed: no gfx950 (MI355X) device visible -- there is no CPU fallback"
+                            if rc == ERR_NO_DEVICE else "nlls_ctx_create failed")
+        self.info = None
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.nlls_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise NllsError(rc, self.L.nlls_last_error(self.h).decode())
+        return rc
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.nlls_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def upload(self, var_kind, var_dim, blockindices, groups, flags=0):
+        """nlls_upload_structure; groups = list of dicts as produced by NLLSProblem.groups()."""
+        vk = np.ascontiguousarray(var_kind, np.int32); vd = np.ascontiguousarray(var_dim, np.int32)
+        bi = np.ascontiguousarray(blockindices, np.uint64)
+        arr = (CostGroup * max(len(groups), 1))()
+        keep = [vk, vd, bi]
+        for i, g in enumerate(groups):
+            vi = np.ascontiguousarray(g["varind"], np.int64); da = np.ascontiguousarray(g["data"], np.float64)
+            keep += [vi, da]
+            arr[i].res_kind = int(g["res_kind"]); arr[i].robust_kind = int(g.get("robust_kind", 0))
+            rp = list(g.get("robust_params", ())) + [0.0] * 4
+            for k in range(4):
+                arr[i].robust_params[k] = float(rp[k])
+            arr[i].ncost = vi.shape[0]; arr[i].varind = vi.ctypes.data; arr[i].data = da.ctypes.data
+        self._chk(self.L.nlls_upload_structure(self.h, len(vk), _p(vk), _p(vd), _p(bi), len(groups), arr, flags))
+        self.info = Info()
+        self._chk(self.L.nlls_get_info(self.h, C.byref(self.info)))
+        return self.info
+
+    def bsm_index(self):
+        nb, ns = self.info.nblocks, self.info.nblocks_stored
+        cp = np.zeros(nb + 1, np.int64); rv = np.zeros(max(ns, 1), np.int64); nz = np.zeros(max(ns, 1), np.int64)
+        bo = np.zeros(max(nb, 1), np.int64)
+        self._chk(self.L.nlls_get_bsm_index(self.h, _p(cp), _p(rv), _p(nz), _p(bo)))
+        return cp, rv[:ns], nz[:ns], bo[:nb]
+
+    def set_variables(self, packed, which=VARS_CURRENT):
+        packed = np.ascontiguousarray(packed, np.float64)
+        assert packed.size == self.info.var_storage
+        self._chk(self.L.nlls_set_variables(self.h, which, _p(packed)))
+
+    def get_variables(self, which=VARS_CURRENT):
+        out = np.zeros(self.info.var_storage)
+        self._chk(self.L.nlls_get_variables(self.h, which, _p(out)))
+        return out
+
+    def swap_variables(self, a, b):
+        self._chk(self.L.nlls_swap_variables(self.h, a, b))
+
+    def copy_variables(self, dst, src):
+        self._chk(self.L.nlls_copy_variables(self.h, dst, src))
+
+    def _scalar(self, fn, *args):
+        out = C.c_double()
+        self._chk(fn(self.h, *args, C.byref(out)))
+        return out.value
+
+    def sweep_gradhess(self):
+        return self._scalar(self.L.nlls_sweep_gradhess)
+
+    def sweep_cost(self, which=VARS_CURRENT):
+        return self._scalar(self.L.nlls_sweep_cost, which)
+
+    def get_grad(self):
+        out = np.zeros(self.info.ndof); self._chk(self.L.nlls_get_grad(self.h, _p(out))); return out
+
+    def get_bsm_data(self):
+        out = np.zeros(self.info.nnz_data); self._chk(self.L.nlls_get_bsm_data(self.h, _p(out))); return out
+
+    def max_abs_diag(self):
+        return self._scalar(self.L.nlls_max_abs_diag)
+
+    def grad_sqnorm(self):
+        return self._scalar(self.L.nlls_grad_sqnorm)
+
+    def grad_quadform(self):
+        return self._scalar(self.L.nlls_grad_quadform)
+
+    def damp(self, delta):
+        self._chk(self.L.nlls_damp(self.h, float(delta)))
+
+    def solve(self, want_x=False):
+        out = np.zeros(self.info.ndof) if want_x else None
+        self._chk(self.L.nlls_solve(self.h, _p(out)))
+        return out
+
+    def set_step(self, x):
+        x = np.ascontiguousarray(x, np.float64); assert x.size == self.info.ndof
+        self._chk(self.L.nlls_set_step(self.h, _p(x)))
+
+    def get_step(self):
+        out = np.zeros(self.info.ndof); self._chk(self.L.nlls_get_step(self.h, _p(out))); return out
+
+    def step_maxabs(self):
+        return self._scalar(self.L.nlls_step_maxabs)
+
+    def step_norm(self):
+        return self._scalar(self.L.nlls_step_norm)
+
+    def quadform(self):
+        a, b = C.c_double(), C.c_double()
+        self._chk(self.L.nlls_quadform(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def retract(self, to=VARS_NEXT, frm=VARS_CURRENT):
+        self._chk(self.L.nlls_retract(self.h, to, frm))
+
+    def time_sweep_gradhess(self, reps=10):
+        ms = C.c_float(); self._chk(self.L.nlls_time_sweep_gradhess(self.h, reps, C.byref(ms))); return ms.value
+
+    def time_sweep_cost(self, reps=10):
+        ms = C.c_float(); self._chk(self.L.nlls_time_sweep_cost(self.h, reps, C.byref(ms))); return ms.value
+
+    def time_solve(self, reps=3):
+        ms = C.c_float(); self._chk(self.L.nlls_time_solve(self.h, reps, C.byref(ms))); return ms.value

@@ -1,0 +1,264 @@
+// nlls_capi.cpp -- the extern "C" boundary declared in include/nlls_amd.h.
+#include <algorithm>
+
+#include "nlls_internal.hpp"
+
+using namespace nlls;
+
+namespace {
+int fail(nlls_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(what) + ": " + hipGetErrorString(e); return NLLS_ERR_HIP; }
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return herr(ctx, e_, #expr); } while (0)
+#define NEED_READY() do { if (!ctx) return NLLS_ERR_INVALID_ARG; if (!ctx->ready) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_upload_structure has not succeeded"); } while (0)
+#define NEED_GRAD() do { NEED_READY(); if (!ctx->have_grad) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_sweep_gradhess has not been run"); } while (0)
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != NLLS_OK) return rc_; } while (0)
+
+// copy `count` scalars starting at `slot` to the pinned mirror and wait
+int fetch_scalars(nlls_ctx* ctx, int slot, int count) {
+    HIPCHK(hipMemcpyAsync(ctx->h_scalars + slot, ctx->scalars.p + slot, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
+}
+bool valid_set(int w) { return w >= 0 && w < 3; }
+}  // namespace
+
+extern "C" {
+
+int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
+    if (!out) return NLLS_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return NLLS_ERR_NO_DEVICE;   // never falls back to a CPU path
+    int dev = (device_ids && ndev > 0) ? device_ids[0] : 0;
+    if (dev < 0 || dev >= count) return NLLS_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NLLS_ERR_HIP;
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return NLLS_ERR_NO_DEVICE;  // the code object is gfx950-only
+    nlls_ctx* c = new (std::nothrow) nlls_ctx();
+    if (!c) return NLLS_ERR_HIP;
+    c->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return NLLS_ERR_HIP; }
+    c->own_stream = true;
+    *out = c;
+    return NLLS_OK;
+}
+
+int nlls_ctx_destroy(nlls_ctx* ctx) {
+    if (!ctx) return NLLS_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+    hipStream_t s = ctx->own_stream ? ctx->stream : nullptr;
+    delete ctx;
+    if (s) (void)hipStreamDestroy(s);
+    return NLLS_OK;
+}
+
+const char* nlls_last_error(const nlls_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int nlls_set_stream(nlls_ctx* ctx, void* hip_stream) {
+    if (!ctx) return NLLS_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    if (hip_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    else { if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return NLLS_ERR_HIP; ctx->own_stream = true; }
+    return NLLS_OK;
+}
+
+int nlls_set_shard(nlls_ctx* ctx, int32_t rank, int32_t nranks) {
+    if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return NLLS_ERR_INVALID_ARG;
+    ctx->rank = rank; ctx->nranks = nranks; ctx->ready = false;
+    return NLLS_OK;
+}
+
+int nlls_var_storage(int32_t k, int32_t d) { return var_storage(k, d); }
+int nlls_var_dof(int32_t k, int32_t d) { return var_dof(k, d); }
+int nlls_res_ndeps(int32_t k) { ResDesc d; return res_desc(k, d) ? d.ndeps : NLLS_ERR_UNSUPPORTED; }
+int nlls_res_nres(int32_t k) { ResDesc d; return res_desc(k, d) ? d.nres : NLLS_ERR_UNSUPPORTED; }
+int nlls_res_ndata(int32_t k) { ResDesc d; return res_desc(k, d) ? d.ndata : NLLS_ERR_UNSUPPORTED; }
+int nlls_res_slot_kind(int32_t k, int32_t slot, int32_t* vk, int32_t* vd) {
+    ResDesc d; if (!res_desc(k, d)) return NLLS_ERR_UNSUPPORTED;
+    if (slot < 0 || slot >= d.ndeps) return NLLS_ERR_INVALID_ARG;
+    if (vk) *vk = d.sk[slot]; if (vd) *vd = d.sd[slot];
+    return NLLS_OK;
+}
+
+int nlls_upload_structure(nlls_ctx* ctx, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* blockindices,
+                          int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
+    if (!ctx || nvar < 0 || ngroups < 0 || (nvar && (!var_kind || !var_dim || !blockindices)) || (ngroups && !groups)) return NLLS_ERR_INVALID_ARG;
+    try { return build_structure(ctx, nvar, var_kind, var_dim, blockindices, ngroups, groups, flags); }
+    catch (const std::exception& e) { return fail(ctx, NLLS_ERR_HIP, std::string("host exception: ") + e.what()); }
+}
+
+int nlls_get_info(const nlls_ctx* ctx, nlls_info* out) {
+    if (!ctx || !out || !ctx->ready) return ctx ? NLLS_ERR_NOT_READY : NLLS_ERR_INVALID_ARG;
+    *out = ctx->info; return NLLS_OK;
+}
+
+int nlls_get_bsm_index(const nlls_ctx* ctx, int64_t* colptr, int64_t* rowval, int64_t* nzval, int64_t* boffsets) {
+    if (!ctx || !ctx->ready) return ctx ? NLLS_ERR_NOT_READY : NLLS_ERR_INVALID_ARG;
+    if (ctx->info.is_sparse) {
+        if (colptr) for (size_t i = 0; i < ctx->it_colptr.size(); ++i) colptr[i] = ctx->it_colptr[i] + 1;
+        if (rowval) for (size_t i = 0; i < ctx->it_rowval.size(); ++i) rowval[i] = ctx->it_rowval[i] + 1;
+        if (nzval) for (size_t i = 0; i < ctx->it_nzval.size(); ++i) nzval[i] = ctx->it_nzval[i] + 1;
+    }
+    if (boffsets) for (int64_t i = 0; i < ctx->info.nblocks; ++i) boffsets[i] = ctx->boffsets[i] + 1;
+    return NLLS_OK;
+}
+
+int nlls_set_variables(nlls_ctx* ctx, int32_t which, const double* packed) {
+    NEED_READY(); if (!valid_set(which) || !packed) return NLLS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(vars_ptr(ctx, which), packed, sizeof(double) * ctx->info.var_storage, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
+}
+int nlls_get_variables(nlls_ctx* ctx, int32_t which, double* packed) {
+    NEED_READY(); if (!valid_set(which) || !packed) return NLLS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(packed, vars_ptr(ctx, which), sizeof(double) * ctx->info.var_storage, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
+}
+int nlls_swap_variables(nlls_ctx* ctx, int32_t a, int32_t b) {
+    NEED_READY(); if (!valid_set(a) || !valid_set(b)) return NLLS_ERR_INVALID_ARG;
+    std::swap(ctx->vars_slot[a], ctx->vars_slot[b]); return NLLS_OK;
+}
+int nlls_copy_variables(nlls_ctx* ctx, int32_t dst, int32_t src) {
+    NEED_READY(); if (!valid_set(dst) || !valid_set(src)) return NLLS_ERR_INVALID_ARG;
+    if (dst != src) HIPCHK(hipMemcpyAsync(vars_ptr(ctx, dst), vars_ptr(ctx, src), sizeof(double) * ctx->info.var_storage, hipMemcpyDeviceToDevice, ctx->stream));
+    return NLLS_OK;
+}
+
+int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
+    NEED_READY();
+    TRY(enqueue_sweep_gradhess(ctx));
+    ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
+    TRY(fetch_scalars(ctx, 0, 1));
+    if (cost_out) *cost_out = ctx->h_scalars[0];
+    return NLLS_OK;
+}
+int nlls_sweep_cost(nlls_ctx* ctx, int32_t which, double* cost_out) {
+    NEED_READY(); if (!valid_set(which)) return NLLS_ERR_INVALID_ARG;
+    TRY(enqueue_sweep_cost(ctx, which));
+    TRY(fetch_scalars(ctx, 0, 1));
+    if (cost_out) *cost_out = ctx->h_scalars[0];
+    return NLLS_OK;
+}
+
+int nlls_get_grad(nlls_ctx* ctx, double* b_out) {
+    NEED_GRAD(); if (!b_out) return NLLS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(b_out, ctx->b.p, sizeof(double) * ctx->info.ndof, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
+}
+int nlls_get_bsm_data(nlls_ctx* ctx, double* data_out) {
+    NEED_GRAD(); if (!data_out) return NLLS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(data_out, ctx->A.p, sizeof(double) * ctx->info.nnz_data, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
+}
+int nlls_max_abs_diag(nlls_ctx* ctx, double* out) {
+    NEED_GRAD(); TRY(enqueue_max_abs_diag(ctx)); TRY(fetch_scalars(ctx, 3, 1));
+    if (out) *out = ctx->h_scalars[3]; return NLLS_OK;
+}
+int nlls_grad_sqnorm(nlls_ctx* ctx, double* out) {
+    NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->b.p, 6)); TRY(fetch_scalars(ctx, 6, 2));
+    if (out) *out = ctx->h_scalars[7]; return NLLS_OK;
+}
+int nlls_grad_quadform(nlls_ctx* ctx, double* out) {
+    NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->b.p, 6)); TRY(fetch_scalars(ctx, 6, 2));
+    if (out) *out = ctx->h_scalars[6]; return NLLS_OK;
+}
+
+int nlls_damp(nlls_ctx* ctx, double delta) { NEED_GRAD(); ctx->lambda += delta; return NLLS_OK; }
+
+int nlls_solve(nlls_ctx* ctx, double* x_out) {
+    NEED_GRAD();
+    TRY(enqueue_solve(ctx));
+    int32_t status[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    if (x_out) HIPCHK(hipMemcpyAsync(x_out, ctx->x.p, sizeof(double) * ctx->info.ndof, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->solved = true;
+    if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");
+    return NLLS_OK;
+}
+int nlls_set_step(nlls_ctx* ctx, const double* x) {
+    NEED_READY(); if (!x) return NLLS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(ctx->x.p, x, sizeof(double) * ctx->info.ndof, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
+}
+int nlls_get_step(nlls_ctx* ctx, double* x_out) {
+    NEED_READY(); if (!x_out) return NLLS_ERR_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(x_out, ctx->x.p, sizeof(double) * ctx->info.ndof, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
+}
+int nlls_step_maxabs(nlls_ctx* ctx, double* out) {
+    NEED_READY(); TRY(enqueue_step_stats(ctx)); TRY(fetch_scalars(ctx, 1, 2));
+    if (out) *out = ctx->h_scalars[1]; return NLLS_OK;
+}
+int nlls_step_norm(nlls_ctx* ctx, double* out) {
+    NEED_READY(); TRY(enqueue_step_stats(ctx)); TRY(fetch_scalars(ctx, 1, 2));
+    if (out) *out = std::sqrt(ctx->h_scalars[2]); return NLLS_OK;
+}
+int nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out) {
+    NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->x.p, 4)); TRY(fetch_scalars(ctx, 4, 2));
+    if (xHx_out) *xHx_out = ctx->h_scalars[4]; if (gx_out) *gx_out = ctx->h_scalars[5];
+    return NLLS_OK;
+}
+int nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from) {
+    NEED_READY(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
+    return enqueue_retract(ctx, to, from);
+}
+
+// ---- multi-GPU: local phases + reduce buffers (single rank: the buffers simply need no reduction) --------
+int nlls_sweep_gradhess_local(nlls_ctx* ctx) {
+    NEED_READY(); TRY(enqueue_sweep_gradhess(ctx));
+    ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; return NLLS_OK;
+}
+int nlls_sweep_gradhess_finish(nlls_ctx* ctx, double* cost_out) {
+    NEED_GRAD(); TRY(fetch_scalars(ctx, 0, 1)); if (cost_out) *cost_out = ctx->h_scalars[0]; return NLLS_OK;
+}
+int nlls_sweep_cost_local(nlls_ctx* ctx, int32_t which) { NEED_READY(); if (!valid_set(which)) return NLLS_ERR_INVALID_ARG; return enqueue_sweep_cost(ctx, which); }
+int nlls_sweep_cost_finish(nlls_ctx* ctx, double* cost_out) { NEED_READY(); TRY(fetch_scalars(ctx, 0, 1)); if (cost_out) *cost_out = ctx->h_scalars[0]; return NLLS_OK; }
+int nlls_solve_local(nlls_ctx* ctx) { NEED_GRAD(); return fail(ctx, NLLS_ERR_UNSUPPORTED, "split solve phases are not available yet"); }
+int nlls_solve_finish(nlls_ctx* ctx, double*) { NEED_GRAD(); return fail(ctx, NLLS_ERR_UNSUPPORTED, "split solve phases are not available yet"); }
+int nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count) {
+    NEED_READY(); if (!dev_ptr || !count) return NLLS_ERR_INVALID_ARG;
+    if (stage == 0) { *dev_ptr = ctx->scalars.p; *count = 1; return NLLS_OK; }
+    return fail(ctx, NLLS_ERR_UNSUPPORTED, "reduce stage not available yet");
+}
+int nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count, int64_t* own_offset, int64_t* own_count) {
+    NEED_READY();
+    if (dev_ptr_x) *dev_ptr_x = ctx->x.p; if (reduced_count) *reduced_count = ctx->nred;
+    if (own_offset) *own_offset = 0; if (own_count) *own_count = ctx->info.ndof;
+    return NLLS_OK;
+}
+
+// ---- timing helpers: HIP events on the context's stream around `reps` back-to-back enqueues -------------
+static int time_loop(nlls_ctx* ctx, int reps, float* ms_avg, int (*fn)(nlls_ctx*)) {
+    if (reps < 1 || !ms_avg) return NLLS_ERR_INVALID_ARG;
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    TRY(fn(ctx));   // warm-up
+    HIPCHK(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; ++i) TRY(fn(ctx));
+    HIPCHK(hipEventRecord(e1, ctx->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_avg = ms / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return NLLS_OK;
+}
+int nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+    NEED_READY(); int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c); });
+    ctx->have_grad = true; return rc;
+}
+int nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+    NEED_READY(); return time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_cost(c, NLLS_VARS_CURRENT); });
+}
+int nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+    NEED_GRAD(); return time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_solve(c); });
+}
+
+}  // extern "C"

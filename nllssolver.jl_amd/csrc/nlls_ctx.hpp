@@ -1,0 +1,168 @@
+// nlls_ctx.hpp -- context, device buffers and the work lists built at nlls_upload_structure time.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nlls_amd.h"
+#include "nlls_kinds.hpp"
+
+namespace nlls {
+
+// ---- device memory ---------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count) {
+        release(); n = count;
+        if (count == 0) { return hipSuccess; }
+        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& h) {
+        hipError_t e = alloc(h.size()); if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+// ---- accumulate work lists ----------------------------------------------------------------------
+// One tile = the share of one workgroup: a run of block rows whose A.data / b segments are staged
+// as one LDS image (light), or one (part of a) heavy row.
+struct Tile {
+    uint32_t e0, e1;        // entry range in the list
+    uint32_t row0, nrows;   // rows of the list covered (index into RowInfo)
+    int64_t  data_off;      // start of the image's A.data segment
+    uint32_t data_len;      // doubles of A.data in the image
+    uint32_t b_off, b_len;  // b segment
+    uint32_t flags;
+};
+constexpr uint32_t TILE_PARTIAL = 1;   // rows shared with other tiles: flush the image with atomics
+constexpr uint32_t TILE_DIRECT  = 2;   // segment too large for LDS: off-diagonal blocks go straight to HBM atomics
+
+struct RowInfo {
+    uint32_t diag_off;      // image-relative offset of the diagonal block
+    uint32_t b_off;         // image-relative offset of the row's part of b (>= data_len)
+};
+
+// dest word of the entry's own slot
+constexpr uint32_t DEST_NONE       = 0xFFFFFFFFu;
+constexpr uint32_t OWN_ROW_MASK    = 0xFFFFu;
+constexpr uint32_t OWN_COST_OWNER  = 1u << 16;   // this entry adds the block's cost to the total
+constexpr uint32_t OWN_KERNEL_FREE = 1u << 17;   // adaptive residual whose kernel variable is optimised
+
+struct EntryList {          // all (cost, slot) incidences of one cost group and one slot, sorted by block row
+    int slot = 0;
+    int64_t n = 0;
+    DevBuf<double>   data;  // [n][ndata]
+    DevBuf<uint32_t> voff;  // [n][ndeps] storage offsets of the block's variables
+    DevBuf<uint32_t> dest;  // [n][ndeps] see above
+    DevBuf<RowInfo>  rows;
+    DevBuf<Tile>     light, heavy;
+    int64_t nlight = 0, nheavy = 0;
+    uint32_t light_lds = 0, heavy_lds = 0;   // max image doubles over the tiles
+};
+
+struct DenseList {          // dense linear system: one entry per cost
+    int64_t n = 0;
+    DevBuf<double>   data;  // [n][ndata]
+    DevBuf<uint32_t> voff;  // [n][ndeps]
+    DevBuf<uint32_t> brow;  // [n][ndeps] dof offset of the slot's block in b, DEST_NONE if fixed
+};
+
+struct Group {
+    int res_kind = 0, ndeps = 0, ndata = 0, nres = 0, adaptive = 0;
+    RobustSpec rk{};
+    int64_t ncost = 0;
+    // cost-order arrays (cost sweep)
+    DevBuf<double>   data;      // [ncost][ndata]
+    DevBuf<uint32_t> voff;      // [ncost][ndeps]
+    DevBuf<uint32_t> fixedcost; // costs without any free variable (only their cost counts in the sweep)
+    int64_t nfixedcost = 0;
+    EntryList lists[4];
+    DenseList dense;
+};
+
+// ---- Schur / solve structures ---------------------------------------------------------------------
+struct SchurNbr {            // one off-diagonal block touching an eliminated block
+    int64_t off;             // offset in A.data
+    uint32_t rcol;           // dof offset of the neighbour in the reduced system
+    uint16_t dim;            // neighbour block size
+    uint16_t trans;          // 0: stored as (elim x nbr) [dv x du]; 1: stored as (nbr x elim) [du x dv]
+};
+struct SchurCopy {           // a reduced-reduced block copied from A.data into S
+    int64_t off; uint32_t r, c; uint16_t rows, cols;
+};
+
+}  // namespace nlls
+
+struct nlls_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int rank = 0, nranks = 1;
+
+    // ---- structure ------------------------------------------------------------------------------
+    bool ready = false;
+    nlls_info info{};
+    std::vector<int32_t> var_kind, var_dim;
+    std::vector<uint32_t> var_off;           // storage offsets (nvar+1)
+    std::vector<uint64_t> blockindices;      // as uploaded (1-based, 0 fixed)
+    std::vector<int32_t> blocksizes;         // per block
+    std::vector<int64_t> boffsets;           // 0-based dof offset per block (nblocks+1)
+    std::vector<int64_t> it_colptr, it_rowval, it_nzval;   // BSM indicestransposed, 0-based
+    std::vector<int64_t> diag_off;           // per block: offset of the diagonal block (sparse) / dense index
+    std::vector<nlls::Group> groups;
+
+    // ---- device state -----------------------------------------------------------------------------
+    nlls::DevBuf<double> vars[3];            // problem.variables / varnext / varbest (src/problem.jl:9-12)
+    int vars_slot[3] = {0, 1, 2};            // logical -> physical (swaps are pointer swaps)
+    nlls::DevBuf<double> A, b, x;
+    nlls::DevBuf<int32_t> d_var_kind, d_var_dim;
+    nlls::DevBuf<uint32_t> d_var_off, d_var_boff;   // d_var_boff: dof offset of the variable's block, DEST_NONE if fixed
+    nlls::DevBuf<int64_t> d_diag_off;        // per block
+    nlls::DevBuf<int32_t> d_blocksizes;
+    nlls::DevBuf<int64_t> d_zero_off;        // segments that must be zeroed before a sweep (shared / split rows)
+    nlls::DevBuf<uint32_t> d_zero_len;
+    int64_t nzero = 0;
+    nlls::DevBuf<uint32_t> d_zero_b_off, d_zero_b_len;
+    nlls::DevBuf<double> partials;           // per-workgroup cost partials
+    nlls::DevBuf<double> scalars;            // small device scratch for scalar results
+    double* h_scalars = nullptr;             // pinned host mirror
+    int64_t npartials = 0;
+    double lambda = 0.0;                     // accumulated uniformscaling! (src/iterators.jl:149,162)
+    bool have_grad = false;
+
+    // ---- solve ---------------------------------------------------------------------------------------
+    std::vector<uint8_t> is_elim;            // per block
+    int64_t nelim = 0, nred = 0;             // blocks eliminated / dof of the reduced system
+    nlls::DevBuf<int64_t> d_elim_ptr;        // CSR over eliminated blocks -> SchurNbr
+    nlls::DevBuf<nlls::SchurNbr> d_elim_nbr;
+    nlls::DevBuf<int64_t> d_elim_diag;       // A.data offset of C_v
+    nlls::DevBuf<uint32_t> d_elim_boff;      // dof offset in b/x
+    nlls::DevBuf<uint16_t> d_elim_dim;
+    nlls::DevBuf<uint32_t> d_elim_group;     // supernodes: runs of eliminated blocks with identical neighbour sets
+    int64_t nelim_groups = 0;
+    int max_elim_dim = 0, max_nbr_dof = 0;
+    nlls::DevBuf<nlls::SchurCopy> d_copy;    // reduced-reduced blocks
+    int64_t ncopy = 0;
+    nlls::DevBuf<nlls::SchurCopy> d_blk;     // every stored block with full-system dof offsets (quadratic forms)
+    int64_t nblk = 0;
+    nlls::DevBuf<uint32_t> d_red_boff;       // reduced dof -> dof offset in b/x
+    nlls::DevBuf<double> S, s, Lwork;        // reduced system, rhs, factor workspace
+    nlls::DevBuf<double> Yelim;              // C^-1 * [E | b] per eliminated block (reused by back-substitution)
+    nlls::DevBuf<int32_t> d_status;          // factorisation status
+    bool solved = false;
+};

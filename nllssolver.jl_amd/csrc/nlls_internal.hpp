@@ -1,0 +1,32 @@
+// nlls_internal.hpp -- declarations shared by the translation units of libnlls_amd.so
+#pragma once
+
+#include "nlls_ctx.hpp"
+
+#define NLLS_FOR_EACH_RES(X) \
+    X(NLLS_RES_BA_AFFINE) X(NLLS_RES_ROSENBROCK_A) X(NLLS_RES_ROSENBROCK_B) X(NLLS_RES_ROSENBROCK_2D) \
+    X(NLLS_RES_CURVE_EXP4) X(NLLS_RES_ADAPTIVE_MEAN) X(NLLS_RES_BA_SO3) X(NLLS_RES_BA_SO3_ADAPTIVE)
+
+namespace nlls {
+
+struct ResDesc { int ndeps, nres, ndata, adaptive; int sk[4], sd[4]; };
+bool res_desc(int kind, ResDesc& d);
+
+int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
+                    int32_t ngroups, const nlls_cost_group* groups, int32_t flags);
+int build_schur(nlls_ctx* c, int32_t flags);
+
+// sweeps (nlls_sweep.hip): enqueue on c->stream; cost lands in c->scalars[0]
+int enqueue_sweep_cost(nlls_ctx* c, int which);
+int enqueue_sweep_gradhess(nlls_ctx* c);
+// vector helpers (nlls_sweep.hip)
+int enqueue_retract(nlls_ctx* c, int to, int from);
+int enqueue_step_stats(nlls_ctx* c);          // scalars[1] = max|x|, scalars[2] = x'x
+int enqueue_max_abs_diag(nlls_ctx* c);        // scalars[3]
+int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot /* scalars[out], scalars[out+1] = v'Hv, b'v */);
+// solve (nlls_solve.hip)
+int enqueue_solve(nlls_ctx* c);
+
+inline double* vars_ptr(nlls_ctx* c, int which) { return c->vars[c->vars_slot[which]].p; }
+
+}  // namespace nlls

@@ -1,0 +1,417 @@
+// nlls_kinds.hpp -- device-side block maths for the registered kinds (gfx950 only).
+//
+// What the reference does per cost block, restated for one GPU lane:
+//   * forward-mode AD through update()   src/autodiff.jl:57-61,81-93  -> Dual<N>
+//   * variable retractions               src/variable.jl:5,10,22,29-32; src/robustadaptive.jl:12-22
+//   * robust kernels                     src/robust.jl:7-77, src/robustadaptive.jl:25-33
+//   * adaptive-kernel derivatives        src/autodiff.jl:163-165       -> Dual2 (second order, 4 vars)
+// Everything is fully unrolled over compile-time sizes so that the structural zeros / ones of the
+// dual seeds are constant-folded by the compiler (the GPU analogue of the reference's StaticInt /
+// SVector specialisation).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/nlls_amd.h"
+
+#define NLLS_DEV __device__ __forceinline__
+#define NLLS_HD __host__ __device__ __forceinline__
+
+namespace nlls {
+
+// ------------------------------------------------------------------------------------------------
+// first-order dual numbers
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct Dual {
+    double v;
+    double d[N];
+};
+
+template <int N> NLLS_DEV Dual<N> dconst(double v) { Dual<N> r; r.v = v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = 0.0; return r; }
+template <int N> NLLS_DEV Dual<N> dseed(double v, int k) { Dual<N> r; r.v = v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = (i == k) ? 1.0 : 0.0; return r; }
+template <int N> NLLS_DEV Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> NLLS_DEV Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> NLLS_DEV Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> NLLS_DEV Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; double ib = 1.0 / b.v; r.v = a.v * ib;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
+template <int N> NLLS_DEV Dual<N> operator*(const Dual<N>& a, double s) { Dual<N> r; r.v = a.v * s;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * s; return r; }
+template <int N> NLLS_DEV Dual<N> operator*(double s, const Dual<N>& a) { return a * s; }
+template <int N> NLLS_DEV Dual<N> operator+(const Dual<N>& a, double c) { Dual<N> r = a; r.v = a.v + c; return r; }
+template <int N> NLLS_DEV Dual<N> operator-(const Dual<N>& a, double c) { Dual<N> r = a; r.v = a.v - c; return r; }
+template <int N> NLLS_DEV Dual<N> operator-(double c, const Dual<N>& a) { Dual<N> r; r.v = c - a.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+template <int N> NLLS_DEV Dual<N> dexp(const Dual<N>& a) { Dual<N> r; r.v = exp(a.v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * r.v; return r; }
+NLLS_DEV double dexp(double a) { return exp(a); }
+NLLS_DEV double dval(double a) { return a; }
+template <int N> NLLS_DEV double dval(const Dual<N>& a) { return a.v; }
+NLLS_DEV double dpart(double, int) { return 0.0; }
+template <int N> NLLS_DEV double dpart(const Dual<N>& a, int i) { return a.d[i]; }
+
+template <class T> struct Lift;                // constant / seeded construction generic in T
+template <> struct Lift<double> {
+    static NLLS_DEV double c(double v) { return v; }
+    static NLLS_DEV double seed(double v, int) { return v; }
+    static NLLS_DEV double seedw(double v, int, double) { return v; }
+};
+template <int N> struct Lift<Dual<N>> {
+    static NLLS_DEV Dual<N> c(double v) { return dconst<N>(v); }
+    static NLLS_DEV Dual<N> seed(double v, int k) { return dseed<N>(v, k); }
+    static NLLS_DEV Dual<N> seedw(double v, int k, double w) { Dual<N> r = dconst<N>(v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) if (i == k) r.d[i] = w; return r; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// second-order duals over 4 variables (3 kernel dof + the cost): src/autodiff.jl:123-128,164-165
+// ------------------------------------------------------------------------------------------------
+struct Dual2 {
+    double v, g[4], h[4][4];
+};
+NLLS_DEV Dual2 d2const(double v) { Dual2 r; r.v = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.g[i] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[i][j] = 0; } return r; }
+NLLS_DEV Dual2 d2add(const Dual2& a, const Dual2& b) { Dual2 r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.g[i] = a.g[i] + b.g[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[i][j] = a.h[i][j] + b.h[i][j]; } return r; }
+NLLS_DEV Dual2 d2scale(const Dual2& a, double s) { Dual2 r; r.v = a.v * s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.g[i] = a.g[i] * s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[i][j] = a.h[i][j] * s; } return r; }
+NLLS_DEV Dual2 d2mul(const Dual2& a, const Dual2& b) { Dual2 r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.g[i] = a.g[i] * b.v + a.v * b.g[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[i][j] = a.h[i][j] * b.v + a.g[i] * b.g[j] + a.g[j] * b.g[i] + a.v * b.h[i][j]; } return r; }
+NLLS_DEV Dual2 d2chain(const Dual2& a, double f0, double f1, double f2) { Dual2 r; r.v = f0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.g[i] = f1 * a.g[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.h[i][j] = f1 * a.h[i][j] + f2 * a.g[i] * a.g[j]; } return r; }
+NLLS_DEV Dual2 d2exp(const Dual2& a) { double e = exp(a.v); return d2chain(a, e, e, e); }
+NLLS_DEV Dual2 d2log(const Dual2& a) { double i = 1.0 / a.v; return d2chain(a, log(a.v), i, -i * i); }
+NLLS_DEV Dual2 d2recip(const Dual2& a) { double i = 1.0 / a.v; return d2chain(a, i, -i * i, 2.0 * i * i * i); }
+
+// ------------------------------------------------------------------------------------------------
+// variable kinds
+// ------------------------------------------------------------------------------------------------
+NLLS_HD constexpr int var_storage(int kind, int dim) {
+    return kind == NLLS_VAR_EUCLIDEAN ? dim
+         : (kind == NLLS_VAR_ZERO_TO_INF || kind == NLLS_VAR_ZERO_TO_ONE) ? 1
+         : kind == NLLS_VAR_CONTAMINATED_GAUSSIAN ? 3
+         : kind == NLLS_VAR_POSE_SO3 ? 12 : -1;
+}
+NLLS_HD constexpr int var_dof(int kind, int dim) {   // nvars(): src/variable.jl:4,9,21,28; robustadaptive.jl:21
+    return kind == NLLS_VAR_EUCLIDEAN ? dim
+         : (kind == NLLS_VAR_ZERO_TO_INF || kind == NLLS_VAR_ZERO_TO_ONE) ? 1
+         : kind == NLLS_VAR_CONTAMINATED_GAUSSIAN ? 3
+         : kind == NLLS_VAR_POSE_SO3 ? 6 : -1;
+}
+
+NLLS_DEV double zti_update(double v, double d) { return (v > 0 ? v : DBL_MIN) * exp(d); }          // variable.jl:22
+NLLS_DEV double zto_update(double v, double d) {                                                   // variable.jl:29-32
+    double val = (v > 0 ? v : DBL_MIN) * exp(d);
+    return val < INFINITY ? val / (1 + (val - v)) : 1.0;
+}
+NLLS_DEV void so3_exp(const double* w, double* E) {   // Rodrigues, column-major 3x3 (new kind)
+    double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], A, B;
+    if (th2 < 1e-12) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; }
+    else { double th = sqrt(th2); A = sin(th) / th; B = (1.0 - cos(th)) / th2; }
+    const double K[9] = {0, w[2], -w[1], -w[2], 0, w[0], w[1], -w[0], 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double k2 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) k2 += K[r + 3 * k] * K[k + 3 * c];
+            E[r + 3 * c] = (r == c ? 1.0 : 0.0) + A * K[r + 3 * c] + B * k2;
+        }
+}
+// update(var, step): the real retraction (src/linearsystem.jl:206-213 -> src/variable.jl)
+NLLS_DEV void var_update_real(int kind, int dim, const double* in, const double* d, double* out) {
+    switch (kind) {
+    case NLLS_VAR_EUCLIDEAN: for (int i = 0; i < dim; ++i) out[i] = in[i] + d[i]; break;
+    case NLLS_VAR_ZERO_TO_INF: out[0] = zti_update(in[0], d[0]); break;
+    case NLLS_VAR_ZERO_TO_ONE: out[0] = zto_update(in[0], d[0]); break;
+    case NLLS_VAR_CONTAMINATED_GAUSSIAN: {   // robustadaptive.jl:22, then the ordering of :13-15
+        double a = zti_update(in[0], d[0]), b = zti_update(in[1], d[1]), w = zto_update(in[2], d[2]);
+        if (!(a >= b)) { double t = a; a = b; b = t; }
+        out[0] = a; out[1] = b; out[2] = w; break; }
+    case NLLS_VAR_POSE_SO3: {
+        double E[9], R[9]; so3_exp(d, E);
+        for (int i = 0; i < 9; ++i) R[i] = in[i];
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) {
+            double s = 0; for (int k = 0; k < 3; ++k) s += R[r + 3 * k] * E[k + 3 * c];
+            out[r + 3 * c] = s; }
+        for (int i = 0; i < 3; ++i) out[9 + i] = in[9 + i] + d[3 + i];
+        break; }
+    }
+}
+// update(var, dualzeros) (src/autodiff.jl:57-61): storage of the variable as T, seeded from `start`
+// (start < 0: no partials wanted for this slot).  KIND/DIM are compile-time.
+template <int KIND, int DIM, class T>
+NLLS_DEV void var_load(const double* v, int start, T* out) {
+    using L = Lift<T>;
+    if constexpr (KIND == NLLS_VAR_EUCLIDEAN) {
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) out[i] = L::seed(v[i], start < 0 ? -1 : start + i);
+    } else if constexpr (KIND == NLLS_VAR_ZERO_TO_INF) {
+        double b = v[0] > 0 ? v[0] : DBL_MIN; out[0] = L::seedw(b, start, b);
+    } else if constexpr (KIND == NLLS_VAR_ZERO_TO_ONE) {
+        double b = v[0] > 0 ? v[0] : DBL_MIN; T val = L::seedw(b, start, b); out[0] = val / (val + (1.0 - v[0]));
+    } else if constexpr (KIND == NLLS_VAR_CONTAMINATED_GAUSSIAN) {
+        var_load<NLLS_VAR_ZERO_TO_INF, 1, T>(v + 0, start < 0 ? -1 : start + 0, out + 0);
+        var_load<NLLS_VAR_ZERO_TO_INF, 1, T>(v + 1, start < 0 ? -1 : start + 1, out + 1);
+        var_load<NLLS_VAR_ZERO_TO_ONE, 1, T>(v + 2, start < 0 ? -1 : start + 2, out + 2);
+    } else if constexpr (KIND == NLLS_VAR_POSE_SO3) {
+        // R*(I + [d]x): the exact first-order behaviour of R*expm([d]x) at d = 0
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double R0 = v[r], R1 = v[r + 3], R2 = v[r + 6];
+            T c0 = L::c(R0), c1 = L::c(R1), c2 = L::c(R2);
+            if (start >= 0) {
+                c0 = c0 + L::seedw(0.0, start + 2, R1) - L::seedw(0.0, start + 1, R2);
+                c1 = c1 - L::seedw(0.0, start + 2, R0) + L::seedw(0.0, start + 0, R2);
+                c2 = c2 + L::seedw(0.0, start + 1, R0) - L::seedw(0.0, start + 0, R1);
+            }
+            out[r] = c0; out[r + 3] = c1; out[r + 6] = c2;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[9 + i] = L::seed(v[9 + i], start < 0 ? -1 : start + 3 + i);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual kinds: computeresidual() bodies, generic in the scalar type
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXST = 12;   // largest variable storage (POSE_SO3)
+
+template <int KIND> struct Res;
+
+template <> struct Res<NLLS_RES_BA_AFFINE> {   // test/optimizeba.jl:4 + src/residual.jl:13
+    static constexpr int NDEPS = 2, M = 2, NDATA = 2, ADAPT = 0;
+    static constexpr int SK[4] = {NLLS_VAR_EUCLIDEAN, NLLS_VAR_EUCLIDEAN, 0, 0};
+    static constexpr int SD[4] = {6, 3, 0, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) {
+        const T* c = sv[0]; const T* X = sv[1];
+        r[0] = c[0] * X[0] + c[1] * X[1] + c[2] * X[2] - data[0];
+        r[1] = c[3] * X[0] + c[4] * X[1] + c[5] * X[2] - data[1];
+    }
+};
+template <> struct Res<NLLS_RES_ROSENBROCK_A> {   // test/functional.jl:12
+    static constexpr int NDEPS = 1, M = 1, NDATA = 1, ADAPT = 0;
+    static constexpr int SK[4] = {NLLS_VAR_EUCLIDEAN, 0, 0, 0};
+    static constexpr int SD[4] = {1, 0, 0, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) { r[0] = (1.0 - sv[0][0]) * data[0]; }
+};
+template <> struct Res<NLLS_RES_ROSENBROCK_B> {   // test/functional.jl:24
+    static constexpr int NDEPS = 2, M = 1, NDATA = 1, ADAPT = 0;
+    static constexpr int SK[4] = {NLLS_VAR_EUCLIDEAN, NLLS_VAR_EUCLIDEAN, 0, 0};
+    static constexpr int SD[4] = {1, 1, 0, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) { r[0] = (sv[0][0] * sv[0][0] - sv[1][0]) * data[0]; }
+};
+template <> struct Res<NLLS_RES_ROSENBROCK_2D> {   // examples/rosenbrock.jl:19
+    static constexpr int NDEPS = 1, M = 2, NDATA = 2, ADAPT = 0;
+    static constexpr int SK[4] = {NLLS_VAR_EUCLIDEAN, 0, 0, 0};
+    static constexpr int SD[4] = {2, 0, 0, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) {
+        const T* x = sv[0]; r[0] = (1.0 - x[0]) * data[0]; r[1] = (x[0] * x[0] - x[1]) * data[1]; }
+};
+template <> struct Res<NLLS_RES_CURVE_EXP4> {   // BASELINE config 2
+    static constexpr int NDEPS = 4, M = 1, NDATA = 2, ADAPT = 0;
+    static constexpr int SK[4] = {NLLS_VAR_EUCLIDEAN, NLLS_VAR_EUCLIDEAN, NLLS_VAR_EUCLIDEAN, NLLS_VAR_EUCLIDEAN};
+    static constexpr int SD[4] = {1, 1, 1, 1};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) {
+        double t = data[0], y = data[1];
+        r[0] = sv[0][0] * dexp(sv[1][0] * t) + sv[2][0] * t + sv[3][0] - y; }
+};
+template <> struct Res<NLLS_RES_ADAPTIVE_MEAN> {   // test/adaptivecost.jl:11 (sv[] excludes the kernel)
+    static constexpr int NDEPS = 2, M = 1, NDATA = 1, ADAPT = 1;
+    static constexpr int SK[4] = {NLLS_VAR_CONTAMINATED_GAUSSIAN, NLLS_VAR_EUCLIDEAN, 0, 0};
+    static constexpr int SD[4] = {3, 1, 0, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) { r[0] = sv[0][0] - data[0]; }
+};
+template <class T> NLLS_DEV void pinhole(const double* data, const T* P, const T* X, T* r) {
+    T Y[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Y[i] = P[i] * X[0] + P[i + 3] * X[1] + P[i + 6] * X[2] + P[9 + i];
+    r[0] = Y[0] / Y[2] - data[0]; r[1] = Y[1] / Y[2] - data[1];
+}
+template <> struct Res<NLLS_RES_BA_SO3> {   // new kind
+    static constexpr int NDEPS = 2, M = 2, NDATA = 2, ADAPT = 0;
+    static constexpr int SK[4] = {NLLS_VAR_POSE_SO3, NLLS_VAR_EUCLIDEAN, 0, 0};
+    static constexpr int SD[4] = {6, 3, 0, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) { pinhole(data, sv[0], sv[1], r); }
+};
+template <> struct Res<NLLS_RES_BA_SO3_ADAPTIVE> {   // new kind
+    static constexpr int NDEPS = 3, M = 2, NDATA = 2, ADAPT = 1;
+    static constexpr int SK[4] = {NLLS_VAR_CONTAMINATED_GAUSSIAN, NLLS_VAR_POSE_SO3, NLLS_VAR_EUCLIDEAN, 0};
+    static constexpr int SD[4] = {3, 6, 3, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) { pinhole(data, sv[0], sv[1], r); }
+};
+
+// compile-time helpers over a residual kind
+template <int KIND> struct ResInfo {
+    using R = Res<KIND>;
+    static constexpr int NS = R::NDEPS - R::ADAPT;                     // slots seen by computeresidual
+    static constexpr int dof(int s) { return var_dof(R::SK[s], R::SD[s]); }
+    static constexpr int sto(int s) { return var_storage(R::SK[s], R::SD[s]); }
+    static constexpr int np() { int n = 0; for (int s = R::ADAPT; s < R::NDEPS; ++s) n += dof(s); return n; }
+    static constexpr int NP = np();                                    // free dof of the non-kernel slots
+    // start of slot s among the non-kernel partials
+    static constexpr int joff(int s) { int n = 0; for (int t = R::ADAPT; t < s; ++t) n += dof(t); return n; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// robust kernels
+// ------------------------------------------------------------------------------------------------
+struct RobustSpec { int kind; double p0, p1; };
+
+NLLS_DEV double robustify_fixed(const RobustSpec& k, double cost) {   // src/robust.jl:11,26,47,71
+    int base = k.kind & 0xF; double c;
+    if (base == NLLS_ROBUST_HUBER || base == NLLS_ROBUST_HUBER2O) { double w2 = k.p0 * k.p0; c = cost < w2 ? cost : sqrt(cost) * (k.p0 * 2) - w2; }
+    else if (base == NLLS_ROBUST_GEMAN_MCCLURE) { double w2 = k.p0 * k.p0; c = cost * w2 / (cost + w2); }
+    else c = cost;
+    if (k.kind & NLLS_ROBUST_SCALED) c *= k.p1;
+    return c;
+}
+NLLS_DEV void robustifydcost_fixed(const RobustSpec& k, double cost, double& rho, double& d1, double& d2) {   // src/robust.jl:12,28-31,48-55,72-77
+    int base = k.kind & 0xF;
+    if (base == NLLS_ROBUST_HUBER || base == NLLS_ROBUST_HUBER2O) {
+        double w = k.p0, w2 = w * w;
+        if (cost < w2) { rho = cost; d1 = 1; d2 = 0; }
+        else { double sq = sqrt(cost); rho = sq * (w * 2) - w2; d1 = w / sq; d2 = base == NLLS_ROBUST_HUBER2O ? (-0.5 * w) / (cost * sq) : 0.0; }
+    } else if (base == NLLS_ROBUST_GEMAN_MCCLURE) {
+        double w2 = k.p0 * k.p0, r = 1.0 / (cost + w2), w = w2 * r, ww = w * w;
+        rho = cost * w; d1 = ww; d2 = -2 * ww * r;
+    } else { rho = cost; d1 = 1; d2 = 0; }
+    if (k.kind & NLLS_ROBUST_SCALED) { rho *= k.p1; d1 *= k.p1; d2 *= k.p1; }
+}
+// ContaminatedGaussian from storage (1/s1, 1/s2, w)   src/robustadaptive.jl:12-33
+NLLS_DEV double cg_robustify(const double* st, double cost) {
+    double s1sq = st[0] * st[0], s2sq = st[1] * st[1], hd = 0.5 * (s2sq - s1sq), hs2 = 0.5 * s2sq;
+    return cost * hs2 - log(st[2] * st[0] * exp(cost * hd) + (1 - st[2]) * st[1]);
+}
+NLLS_DEV void cg_robustifydcost(const double* st, double cost, double& rho, double& d1, double& d2) {
+    double s1sq = st[0] * st[0], s2sq = st[1] * st[1], hd = 0.5 * (s2sq - s1sq), hs2 = 0.5 * s2sq;
+    double c = cost * hs2, s = st[2] * st[0] * exp(cost * hd), t = (1 - st[2]) * st[1], den = 1 / (s + t);
+    s *= hd;
+    rho = c + log(den); d1 = hs2 - s * den; d2 = -s * hd * t * den * den;
+}
+// autorobustifydkernel  src/autodiff.jl:164-165: value/gradient/hessian w.r.t. (kernel dof 1..3, cost)
+NLLS_DEV Dual2 cg_robustifydkernel(const double* st, double cost) {
+    double b0 = st[0] > 0 ? st[0] : DBL_MIN, b1 = st[1] > 0 ? st[1] : DBL_MIN, b2 = st[2] > 0 ? st[2] : DBL_MIN;
+    Dual2 is1 = d2const(b0); is1.g[0] = b0; is1.h[0][0] = b0;            // ZeroToInf: b*exp(x)
+    Dual2 is2 = d2const(b1); is2.g[1] = b1; is2.h[1][1] = b1;
+    Dual2 val = d2const(b2); val.g[2] = b2; val.h[2][2] = b2;            // ZeroToOne: val/(1+(val-v))
+    Dual2 den = val; den.v += 1.0 - st[2];
+    Dual2 w = d2mul(val, d2recip(den));
+    Dual2 c = d2const(cost); c.g[3] = 1.0;
+    Dual2 s1sq = d2mul(is1, is1), s2sq = d2mul(is2, is2);
+    Dual2 hd = d2scale(d2add(s2sq, d2scale(s1sq, -1.0)), 0.5), hs2 = d2scale(s2sq, 0.5);
+    Dual2 a = d2mul(d2mul(w, is1), d2exp(d2mul(c, hd)));
+    Dual2 omw = d2scale(w, -1.0); omw.v += 1.0;
+    Dual2 b = d2mul(omw, is2);
+    return d2add(d2mul(c, hs2), d2scale(d2log(d2add(a, b)), -1.0));
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-block evaluation  (src/residual.jl:44-111, src/autodiff.jl:81-93)
+// ------------------------------------------------------------------------------------------------
+// Residual value only: computerescost  src/residual.jl:49-55.  voff[s] = storage offset of slot s.
+template <int KIND>
+NLLS_DEV double block_cost(const double* __restrict__ vars, const uint32_t* voff, const double* data, const RobustSpec& rk) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    double sv[I::NS > 0 ? I::NS : 1][MAXST];
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+        (var_load<R::SK[S + R::ADAPT], R::SD[S + R::ADAPT], double>(vars + voff[S + R::ADAPT], -1, sv[S]), ...);
+    }(std::make_integer_sequence<int, I::NS>{});
+    double r[R::M]; R::template eval<double>(data, sv, r);
+    double s = 0;
+#pragma unroll
+    for (int m = 0; m < R::M; ++m) s += r[m] * r[m];
+    if constexpr (R::ADAPT) return 0.5 * cg_robustify(vars + voff[0], s);
+    else return 0.5 * robustify_fixed(rk, s);
+}
+
+// Everything the accumulate kernels need from one block, with ALL variables treated as free
+// (the reference's varflags specialisations only drop rows/columns of g and H; the kept entries
+// are identical -- src/residual.jl:57-111).
+template <int KIND>
+struct BlockGH {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    static constexpr int NP = I::NP, M = R::M;
+    double J[M][NP];        // jacobian
+    double g[NP];           // UN-weighted J'r (residual.jl:73)
+    double cost;            // 0.5 * rho   (residual.jl:110)
+    double dc, d2c;         // rho', rho'' (residual.jl:78 or :82-84)
+    double dck[3];          // d rho / d kernel   (adaptive, kernel optimised)
+    double d2ck[3][4];      // d2 rho / d kernel d(kernel, cost)
+
+    NLLS_DEV void compute(const double* __restrict__ vars, const uint32_t* voff, const double* data, const RobustSpec& rk, bool kernel_free) {
+        using T = Dual<NP>;
+        T sv[I::NS > 0 ? I::NS : 1][MAXST];
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            (var_load<R::SK[S + R::ADAPT], R::SD[S + R::ADAPT], T>(vars + voff[S + R::ADAPT], I::joff(S + R::ADAPT), sv[S]), ...);
+        }(std::make_integer_sequence<int, I::NS>{});
+        T r[M]; R::template eval<T>(data, sv, r);
+        double c = 0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) { c += r[m].v * r[m].v;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) J[m][j] = r[m].d[j]; }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { double s = 0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) s += r[m].d[j] * r[m].v; g[j] = s; }
+        double rho;
+        if constexpr (R::ADAPT) {
+            if (kernel_free) {                                  // residual.jl:79-88
+                Dual2 k = cg_robustifydkernel(vars + voff[0], c);
+                rho = k.v; dc = k.g[3]; d2c = k.h[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { dck[i] = k.g[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d2ck[i][j] = k.h[i][j]; }
+            } else cg_robustifydcost(vars + voff[0], c, rho, dc, d2c);   // residual.jl:76-78
+        } else robustifydcost_fixed(rk, c, rho, dc, d2c);
+        cost = 0.5 * rho;
+    }
+    // local H / g entries over the non-kernel dof (residual.jl:91-101)
+    NLLS_DEV double H(int i, int j) const { double s = 0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) s += J[m][i] * J[m][j];
+        return s * dc + (2 * d2c) * g[i] * g[j]; }
+    NLLS_DEV double G(int i) const { return g[i] * dc; }
+    // kernel border (residual.jl:86-88,103-107): d2/dkernel_k dvar_i, d2/dkernel^2, d/dkernel
+    NLLS_DEV double Hkv(int k, int i) const { return g[i] * d2ck[k][3]; }
+    NLLS_DEV double Hkk(int k, int l) const { return d2ck[k][l]; }
+    NLLS_DEV double Gk(int k) const { return dck[k]; }
+};
+
+}  // namespace nlls

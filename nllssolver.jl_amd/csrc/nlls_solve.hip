@@ -1,0 +1,453 @@
+// nlls_solve.hip -- damped normal-equation solve on the device (gfx950).
+//
+// Replaces  negate!(solve!(linsystem, options))  src/iterators.jl:152 -> src/linearsolver.jl:28-32 together
+// with the damping uniformscaling!(hessian, k) (src/iterators.jl:149) and fast_bAb / dot
+// (src/iterators.jl:163, src/utils.jl:95-106).
+//
+// The reference factors the FULL sparse system with LDLFactorizations; it has no Schur complement
+// (SURVEY F1).  This path is new: an independent set of blocks (bundle adjustment: the points) is
+// eliminated block-wise (C_v^-1 by a small Cholesky in LDS), the reduced system
+//   S = B + lambda*I - sum_v E_v' C_v^-1 E_v ,   s = b_R - sum_v E_v' C_v^-1 b_v
+// is assembled densely and factored by a blocked right-looking Cholesky whose trailing update runs on
+// the fp64 matrix cores (v_mfma_f64_16x16x4_f64); the eliminated blocks are recovered by
+// back-substitution.  Parity contract: x solves (H + lambda*I) x = -b, unique for SPD systems.
+#include <utility>
+
+#include "nlls_internal.hpp"
+
+namespace nlls {
+
+constexpr int NB = 64;          // Cholesky panel width
+constexpr int LDT = 80;         // LDS leading dimension of a 64-row operand tile (80 = 16 mod 32: conflict-free ds_read_b64)
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+NLLS_DEV double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reduced system set-up
+// ---------------------------------------------------------------------------------------------------
+// identity on the padding, the rhs as an extra ROW n of the lower triangle: factoring the bordered matrix
+// [[S, s], [s', c]] leaves y = L^-1 s in row n of the factor, so no separate forward substitution is needed.
+__global__ void schur_init_kernel(double* __restrict__ S, double* __restrict__ s, const double* __restrict__ b,
+                                  const uint32_t* __restrict__ red_boff, int n, int npad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    if (i < n) { const double v = b[red_boff[i]]; s[i] = v; }
+    else { s[i] = 0.0; S[(size_t)i + (size_t)npad * i] = (i == n) ? 1e300 : 1.0; }
+}
+__global__ void schur_copy_kernel(double* __restrict__ S, const double* __restrict__ A, const SchurCopy* __restrict__ copies, double lambda, int npad) {
+    const SchurCopy cp = copies[blockIdx.x];
+    for (int e = threadIdx.x; e < cp.rows * cp.cols; e += blockDim.x) {
+        const int i = e % cp.rows, j = e / cp.rows;
+        double v = A[cp.off + e];
+        if (cp.r == cp.c && i == j) v += lambda;
+        S[(size_t)(cp.r + i) + (size_t)npad * (cp.c + j)] = v;
+    }
+}
+__global__ void dense_to_S_kernel(double* __restrict__ S, const double* __restrict__ A, double lambda, int n, int npad) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n * n) return;
+    const int i = (int)(e % n), j = (int)(e / n);
+    S[(size_t)i + (size_t)npad * j] = A[e] + (i == j ? lambda : 0.0);
+}
+__global__ void rhs_row_kernel(double* __restrict__ S, const double* __restrict__ s, int n, int npad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) S[(size_t)n + (size_t)npad * i] = s[i];
+}
+
+// One wavefront per eliminated block v:  Y = C_v^-1 [E_v | b_v];  S -= E_v' Y_E ;  s -= E_v' y_b.
+// LDS: C (dv x dv), Ecat (dv x nd), Y (dv x (nd+1)), column map.
+__global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                        const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
+                                                        const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                        const uint16_t* __restrict__ edim, double lambda, int maxdv, int maxnd,
+                                                        double* __restrict__ S, double* __restrict__ s, int npad, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int v = blockIdx.x, lane = threadIdx.x;
+    const int dv = edim[v];
+    double* C = sm;                                   // dv*dv
+    double* E = C + maxdv * maxdv;                    // dv*nd  (col-major, column = reduced dof)
+    double* Y = E + (size_t)maxdv * maxnd;            // dv*(nd+1)
+    uint32_t* rc = reinterpret_cast<uint32_t*>(Y + (size_t)maxdv * (maxnd + 1));   // nd
+    const int64_t p0 = eptr[v], p1 = eptr[v + 1];
+    // gather
+    for (int e = lane; e < dv * dv; e += 64) { const int i = e % dv, j = e / dv; C[e] = A[ediag[v] + e] + (i == j ? lambda : 0.0); }
+    int nd = 0;
+    for (int64_t p = p0; p < p1; ++p) {
+        const SchurNbr nb = enbr[p]; const int du = nb.dim;
+        for (int e = lane; e < dv * du; e += 64) {
+            int a, c2;   // a: row in eliminated block, c2: column in neighbour
+            if (!nb.trans) { a = e % dv; c2 = e / dv; } else { c2 = e % du; a = e / du; }
+            E[a + dv * (nd + c2)] = A[nb.off + e];
+        }
+        for (int c2 = lane; c2 < du; c2 += 64) rc[nd + c2] = nb.rcol + c2;
+        nd += du;
+    }
+    for (int a = lane; a < dv; a += 64) Y[a + dv * nd] = b[eboff[v] + a];
+    __syncthreads();
+    // Cholesky of C in place (lower), lane-serial: dv <= 32
+    if (lane == 0) {
+        for (int j = 0; j < dv; ++j) {
+            double d = C[j + dv * j];
+            for (int k = 0; k < j; ++k) d -= C[j + dv * k] * C[j + dv * k];
+            if (!(d > 0)) { atomicCAS(status, 0, 1); d = 1.0; }
+            d = sqrt(d); C[j + dv * j] = d;
+            for (int i = j + 1; i < dv; ++i) { double t = C[i + dv * j]; for (int k = 0; k < j; ++k) t -= C[i + dv * k] * C[j + dv * k]; C[i + dv * j] = t / d; }
+        }
+    }
+    __syncthreads();
+    // Y(:, c) = C^-1 [E | b](:, c): one column per lane
+    for (int c2 = lane; c2 <= nd; c2 += 64) {
+        double y[NLLS_MAX_BLOCK_SZ];
+        for (int i = 0; i < dv; ++i) { double t = (c2 < nd) ? E[i + dv * c2] : Y[i + dv * nd]; for (int k = 0; k < i; ++k) t -= C[i + dv * k] * y[k]; y[i] = t / C[i + dv * i]; }
+        for (int i = dv - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < dv; ++k) t -= C[k + dv * i] * y[k]; y[i] = t / C[i + dv * i]; }
+        for (int i = 0; i < dv; ++i) Y[i + dv * c2] = y[i];
+    }
+    __syncthreads();
+    // S(rc[p], rc[q]) -= E(:,p)' Y(:,q) for p >= q ; s(rc[p]) -= E(:,p)' y_b
+    const int npairs = nd * (nd + 1) / 2;
+    for (int t = lane; t < npairs; t += 64) {
+        int p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (p * (p + 1) / 2 > t) --p;
+        while ((p + 1) * (p + 2) / 2 <= t) ++p;
+        const int q = t - p * (p + 1) / 2;
+        double acc = 0; for (int a = 0; a < dv; ++a) acc += E[a + dv * p] * Y[a + dv * q];
+        atomicAdd(&S[(size_t)rc[p] + (size_t)npad * rc[q]], -acc);
+    }
+    for (int p = lane; p < nd; p += 64) { double acc = 0; for (int a = 0; a < dv; ++a) acc += E[a + dv * p] * Y[a + dv * nd]; atomicAdd(&s[rc[p]], -acc); }
+}
+
+// x_v = C_v^-1 (b_v - E_v x_R), stored negated (negate!, src/iterators.jl:3)
+__global__ __launch_bounds__(64) void schur_backsub_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                           const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
+                                                           const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                           const uint16_t* __restrict__ edim, double lambda, int maxdv,
+                                                           const double* __restrict__ xr, double* __restrict__ x) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int v = blockIdx.x, lane = threadIdx.x; const int dv = edim[v];
+    double* C = sm; double* rhs = C + maxdv * maxdv;
+    for (int e = lane; e < dv * dv; e += 64) { const int i = e % dv, j = e / dv; C[e] = A[ediag[v] + e] + (i == j ? lambda : 0.0); }
+    // rhs[a] = b[a] - sum_p E[a,p] xr[p]: lanes over (neighbour element) with a wave reduction per row
+    double part[NLLS_MAX_BLOCK_SZ];
+    for (int a = 0; a < dv; ++a) part[a] = 0;
+    for (int64_t p = eptr[v]; p < eptr[v + 1]; ++p) {
+        const SchurNbr nb = enbr[p]; const int du = nb.dim;
+        for (int e = lane; e < dv * du; e += 64) {
+            int a, c2; if (!nb.trans) { a = e % dv; c2 = e / dv; } else { c2 = e % du; a = e / du; }
+            const double val = A[nb.off + e] * xr[nb.rcol + c2];
+            for (int aa = 0; aa < dv; ++aa) if (aa == a) part[aa] += val;
+        }
+    }
+    for (int a = 0; a < dv; ++a) { double t = wsum(part[a]); if (lane == 0) rhs[a] = b[eboff[v] + a] - t; }
+    __syncthreads();
+    if (lane == 0) {
+        for (int j = 0; j < dv; ++j) {
+            double d = C[j + dv * j]; for (int k = 0; k < j; ++k) d -= C[j + dv * k] * C[j + dv * k];
+            d = sqrt(d > 0 ? d : 1.0); C[j + dv * j] = d;
+            for (int i = j + 1; i < dv; ++i) { double t = C[i + dv * j]; for (int k = 0; k < j; ++k) t -= C[i + dv * k] * C[j + dv * k]; C[i + dv * j] = t / d; }
+        }
+        for (int i = 0; i < dv; ++i) { double t = rhs[i]; for (int k = 0; k < i; ++k) t -= C[i + dv * k] * rhs[k]; rhs[i] = t / C[i + dv * i]; }
+        for (int i = dv - 1; i >= 0; --i) { double t = rhs[i]; for (int k = i + 1; k < dv; ++k) t -= C[k + dv * i] * rhs[k]; rhs[i] = t / C[i + dv * i]; }
+        for (int i = 0; i < dv; ++i) x[eboff[v] + i] = -rhs[i];
+    }
+}
+__global__ void scatter_reduced_kernel(const double* __restrict__ xr, const uint32_t* __restrict__ red_boff, int n, double* __restrict__ x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[red_boff[i]] = -xr[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small systems (n < 64): Cholesky, else LU with partial pivoting (the reference falls back from
+// cholesky to qr, src/linearsolver.jl:20-26; any exact solver of a nonsingular system is equivalent)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void small_solve_kernel(const double* __restrict__ S, double* __restrict__ s, int n, int npad, int* __restrict__ status) {
+    __shared__ double M[64 * 65]; __shared__ double rhs[64]; __shared__ int piv; __shared__ int ok;
+    const int t = threadIdx.x;
+    for (int e = t; e < n * n; e += 64) { const int i = e % n, j = e / n; M[i + 65 * j] = (i >= j) ? S[(size_t)i + (size_t)npad * j] : S[(size_t)j + (size_t)npad * i]; }
+    if (t < n) rhs[t] = s[t];
+    if (t == 0) ok = 1;
+    __syncthreads();
+    // Cholesky (right-looking), thread = row
+    for (int j = 0; j < n; ++j) {
+        const double d = M[j + 65 * j];
+        if (!(d > 0)) { if (t == 0) ok = 0; }
+        __syncthreads();
+        if (!ok) break;
+        const double sd = sqrt(d);
+        double lij = 0;
+        if (t > j && t < n) { lij = M[t + 65 * j] / sd; }
+        __syncthreads();
+        if (t == j) M[j + 65 * j] = sd;
+        if (t > j && t < n) M[t + 65 * j] = lij;
+        __syncthreads();
+        if (t > j && t < n) for (int c2 = j + 1; c2 <= t; ++c2) M[t + 65 * c2] -= lij * M[c2 + 65 * j];
+        __syncthreads();
+    }
+    if (ok) {
+        if (t == 0) {
+            for (int i = 0; i < n; ++i) { double v = rhs[i]; for (int k = 0; k < i; ++k) v -= M[i + 65 * k] * rhs[k]; rhs[i] = v / M[i + 65 * i]; }
+            for (int i = n - 1; i >= 0; --i) { double v = rhs[i]; for (int k = i + 1; k < n; ++k) v -= M[k + 65 * i] * rhs[k]; rhs[i] = v / M[i + 65 * i]; }
+        }
+        __syncthreads();
+        if (t < n) s[t] = rhs[t];
+        return;
+    }
+    // LU with partial pivoting on a fresh symmetric copy
+    __syncthreads();
+    for (int e = t; e < n * n; e += 64) { const int i = e % n, j = e / n; M[i + 65 * j] = (i >= j) ? S[(size_t)i + (size_t)npad * j] : S[(size_t)j + (size_t)npad * i]; }
+    if (t < n) rhs[t] = s[t];
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        if (t == 0) { int p = j; double best = fabs(M[j + 65 * j]); for (int i = j + 1; i < n; ++i) { double a = fabs(M[i + 65 * j]); if (a > best) { best = a; p = i; } } piv = p; if (best == 0.0) atomicCAS(status, 0, 2); }
+        __syncthreads();
+        const int p = piv;
+        if (p != j) { if (t < n) { double a = M[j + 65 * t]; M[j + 65 * t] = M[p + 65 * t]; M[p + 65 * t] = a; } if (t == 0) { double a = rhs[j]; rhs[j] = rhs[p]; rhs[p] = a; } }
+        __syncthreads();
+        double f = 0;
+        if (t > j && t < n) { f = M[t + 65 * j] / M[j + 65 * j]; }
+        __syncthreads();
+        if (t > j && t < n) { for (int c2 = j + 1; c2 < n; ++c2) M[t + 65 * c2] -= f * M[j + 65 * c2]; rhs[t] -= f * rhs[j]; }
+        __syncthreads();
+    }
+    if (t == 0) for (int i = n - 1; i >= 0; --i) { double v = rhs[i]; for (int k = i + 1; k < n; ++k) v -= M[i + 65 * k] * rhs[k]; rhs[i] = v / M[i + 65 * i]; }
+    __syncthreads();
+    if (t < n) s[t] = rhs[t];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// blocked Cholesky of the (bordered) reduced system: S col-major, ld = npad, lower triangle
+// ---------------------------------------------------------------------------------------------------
+// diagonal block: unblocked right-looking factorisation in LDS, 256 threads
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ S, int npad, int k, int* __restrict__ status) {
+    __shared__ double M[NB * (NB + 1)];
+    double* D = S + (size_t)k * NB + (size_t)npad * k * NB;
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 256) { const int i = e % NB, j = e / NB; M[i + (NB + 1) * j] = D[(size_t)i + (size_t)npad * j]; }
+    __syncthreads();
+    for (int j = 0; j < NB; ++j) {
+        double d = M[j + (NB + 1) * j];
+        if (!(d > 0)) { if (t == 0) atomicCAS(status, 0, 1 + k * NB + j); d = 1.0; }
+        const double sd = sqrt(d);
+        __syncthreads();
+        if (t == 0) M[j + (NB + 1) * j] = sd;
+        if (t > j && t < NB) M[t + (NB + 1) * j] /= sd;
+        __syncthreads();
+        // trailing update: element (i, c), j < c <= i < NB
+        const int m = NB - 1 - j;
+        for (int e = t; e < m * m; e += 256) { const int i = j + 1 + e % m, c2 = j + 1 + e / m; if (i >= c2) M[i + (NB + 1) * c2] -= M[i + (NB + 1) * j] * M[c2 + (NB + 1) * j]; }
+        __syncthreads();
+    }
+    for (int e = t; e < NB * NB; e += 256) { const int i = e % NB, j = e / NB; if (i >= j) D[(size_t)i + (size_t)npad * j] = M[i + (NB + 1) * j]; }
+}
+// panel: X = A_ik * L_kk^-T for each 64-row block i > k; one workgroup (64 threads, thread = row) per block
+__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ S, int npad, int k) {
+    __shared__ double L[NB * (NB + 1)];
+    const double* D = S + (size_t)k * NB + (size_t)npad * k * NB;
+    const int t = threadIdx.x; const int ib = k + 1 + blockIdx.x;
+    for (int e = t; e < NB * NB; e += 64) { const int i = e % NB, j = e / NB; L[i + (NB + 1) * j] = D[(size_t)i + (size_t)npad * j]; }
+    __syncthreads();
+    double* P = S + (size_t)ib * NB + t + (size_t)npad * k * NB;   // row t of the block, stride npad between columns
+    double xr[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) xr[j] = P[(size_t)npad * j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double v = xr[j];
+#pragma unroll
+        for (int l = 0; l < j; ++l) v -= xr[l] * L[j + (NB + 1) * l];
+        xr[j] = v / L[j + (NB + 1) * j];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) P[(size_t)npad * j] = xr[j];
+}
+// trailing update on the matrix cores: C_ij -= P_i * P_j' for all k < j <= i; one 64x64 tile per workgroup,
+// 4 waves x (2x2) v_mfma_f64_16x16x4_f64 accumulators.
+__global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ S, int npad, int k, int nblk) {
+    __shared__ double Pi[NB * LDT];   // Pi[r + LDT*kk]
+    __shared__ double Pj[NB * LDT];
+    const int T = nblk - k - 1;
+    // linear tile index -> (ti >= tj)
+    int tix = blockIdx.x; int ti = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tix) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
+    const int tj = tix - ti * (ti + 1) / 2;
+    (void)T;
+    const int ib = k + 1 + ti, jb = k + 1 + tj;
+    const double* Gi = S + (size_t)ib * NB + (size_t)npad * k * NB;
+    const double* Gj = S + (size_t)jb * NB + (size_t)npad * k * NB;
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 256) { const int r = e % NB, c2 = e / NB; Pi[r + LDT * c2] = Gi[(size_t)r + (size_t)npad * c2]; Pj[r + LDT * c2] = Gj[(size_t)r + (size_t)npad * c2]; }
+    __syncthreads();
+    const int w = t >> 6, lane = t & 63;
+    const int r0 = (w & 1) * 32, c0 = (w >> 1) * 32;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = double4_t{0, 0, 0, 0};
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+    for (int kk = 0; kk < NB; kk += 4) {
+        double av[2], bv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) av[a] = Pi[r0 + 16 * a + li + LDT * (kk + lk)];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Pj[c0 + 16 * b2 + li + LDT * (kk + lk)];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b2], acc[a][b2], 0, 0, 0);
+    }
+    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4*reg
+    double* Cg = S + (size_t)ib * NB + (size_t)npad * jb * NB;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 16 * a + lk + 4 * r, col = c0 + 16 * b2 + li;
+                Cg[(size_t)row + (size_t)npad * col] -= acc[a][b2][r];
+            }
+}
+// backward substitution L' x = y, block by block from the bottom.  y is row n of the factor.
+// step 1 (one workgroup per 64-column block kb, many row blocks): partial[kb][j] = sum_{i > kb block} L[i][kb*64+j] * x[i]
+__global__ __launch_bounds__(256) void bwd_gemv_kernel(const double* __restrict__ S, int npad, int kb, int n, const double* __restrict__ x, double* __restrict__ acc) {
+    // grid.x = number of row blocks below kb; each adds its 64-vector contribution atomically
+    __shared__ double red[4][NB];
+    const int ib = kb + 1 + blockIdx.x; const int t = threadIdx.x; const int j = t & 63, q = t >> 6;
+    const double* P = S + (size_t)ib * NB + (size_t)npad * ((size_t)kb * NB + j);
+    double v = 0;
+    for (int i = q * 16; i < q * 16 + 16; ++i) { const int gi = ib * NB + i; if (gi < n) v += P[i] * x[gi]; }
+    red[q][j] = v; __syncthreads();
+    if (q == 0) atomicAdd(&acc[kb * NB + j], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+}
+// step 2: x_k = L_kk^-T (y_k - acc_k), single wave
+__global__ __launch_bounds__(64) void bwd_diag_kernel(const double* __restrict__ S, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x) {
+    __shared__ double L[NB * (NB + 1)]; __shared__ double r[NB];
+    const double* D = S + (size_t)kb * NB + (size_t)npad * kb * NB; const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 64) { const int i = e % NB, j = e / NB; L[i + (NB + 1) * j] = D[(size_t)i + (size_t)npad * j]; }
+    const int g = kb * NB + t;
+    r[t] = (g < n) ? S[(size_t)n + (size_t)npad * g] - acc[g] : 0.0;   // y lives in row n of the factor
+    __syncthreads();
+    if (t == 0) for (int i = NB - 1; i >= 0; --i) { if (kb * NB + i >= n) { r[i] = 0; continue; } double v = r[i]; for (int l = i + 1; l < NB && kb * NB + l < n; ++l) v -= L[l + (NB + 1) * i] * r[l]; r[i] = v / L[i + (NB + 1) * i]; }
+    __syncthreads();
+    if (g < n) x[g] = r[t];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fast_bAb(H + lambda I, v) and dot(b, v)   src/utils.jl:71-106, src/iterators.jl:52,163
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quadform_blocks_kernel(const double* __restrict__ A, const SchurCopy* __restrict__ blk, int64_t nblk,
+                                                              const double* __restrict__ v, double* __restrict__ partials) {
+    __shared__ double red[4];
+    double acc = 0;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nblk; q += (int64_t)gridDim.x * 256) {
+        const SchurCopy bk = blk[q]; double t = 0;
+        for (int j = 0; j < bk.cols; ++j) { double c2 = 0; for (int i = 0; i < bk.rows; ++i) c2 += A[bk.off + i + bk.rows * j] * v[bk.r + i]; t += c2 * v[bk.c + j]; }
+        acc += (bk.r == bk.c) ? t : 2.0 * t;
+    }
+    acc = wsum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void quadform_dense_kernel(const double* __restrict__ A, int n, const double* __restrict__ v, double* __restrict__ partials) {
+    __shared__ double red[4];
+    double acc = 0;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) { double c2 = 0; for (int i = 0; i < n; ++i) c2 += A[(size_t)i + (size_t)n * j] * v[i]; acc += c2 * v[j]; }
+    acc = wsum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// out[slot] = sum(partials) + lambda * v'v ; out[slot+1] = b'v
+__global__ __launch_bounds__(256) void quadform_finish_kernel(const double* __restrict__ partials, int np, const double* __restrict__ b,
+                                                              const double* __restrict__ v, int64_t n, double lambda, double* __restrict__ out, int slot) {
+    __shared__ double red[3][4];
+    double a = 0, vv = 0, bv = 0;
+    for (int i = threadIdx.x; i < np; i += 256) a += partials[i];
+    for (int64_t i = threadIdx.x; i < n; i += 256) { const double x = v[i]; vv += x * x; bv += b[i] * x; }
+    a = wsum(a); vv = wsum(vv); bv = wsum(bv);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = vv; red[2][threadIdx.x >> 6] = bv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = red[0][0] + red[0][1] + red[0][2] + red[0][3]; vv = red[1][0] + red[1][1] + red[1][2] + red[1][3]; bv = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        out[slot] = a + lambda * vv; out[slot + 1] = bv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(what) + ": " + hipGetErrorString(e); return NLLS_ERR_HIP; }
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return herr(c, e_, #expr); } while (0)
+
+int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
+    int np = 0;
+    if (c->info.is_sparse) {
+        np = (int)std::min<int64_t>((c->nblk + 255) / 256, 1024); if (np < 1) np = 1;
+        hipLaunchKernelGGL(quadform_blocks_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, c->d_blk.p, c->nblk, d_vec, c->partials.p);
+    } else {
+        np = (int)std::min<int64_t>((c->info.ndof + 255) / 256, 1024); if (np < 1) np = 1;
+        hipLaunchKernelGGL(quadform_dense_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, (int)c->info.ndof, d_vec, c->partials.p);
+    }
+    hipLaunchKernelGGL(quadform_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, np, c->b.p, d_vec, c->info.ndof, c->lambda, c->scalars.p, out_slot);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+int enqueue_solve(nlls_ctx* c) {
+    const int n = (int)c->nred; const int npad = ((n + 1 + NB - 1) / NB) * NB; const int nblk = npad / NB;
+    if (n == 0) return NLLS_OK;
+    HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (size_t)npad * npad, c->stream));
+    hipLaunchKernelGGL(schur_init_kernel, dim3((npad + 255) / 256), dim3(256), 0, c->stream, c->S.p, c->s.p, c->b.p, c->d_red_boff.p, n, npad);
+    if (c->info.is_sparse) {
+        if (c->ncopy > 0) hipLaunchKernelGGL(schur_copy_kernel, dim3((unsigned)c->ncopy), dim3(64), 0, c->stream, c->S.p, c->A.p, c->d_copy.p, c->lambda, npad);
+    } else {
+        const int64_t n2 = (int64_t)n * n;
+        hipLaunchKernelGGL(dense_to_S_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->S.p, c->A.p, c->lambda, n, npad);
+    }
+    const size_t elim_lds = sizeof(double) * ((size_t)c->max_elim_dim * c->max_elim_dim + (size_t)c->max_elim_dim * (2 * c->max_nbr_dof + 1)) + sizeof(uint32_t) * (c->max_nbr_dof + 2);
+    if (c->nelim > 0)
+        hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)c->nelim), dim3(64), elim_lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
+                           c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->lambda, c->max_elim_dim, c->max_nbr_dof, c->S.p, c->s.p, npad, c->d_status.p);
+    if (n < NB) {
+        hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s.p, n, npad, c->d_status.p);
+    } else {
+        hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S.p, c->s.p, n, npad);
+        for (int k = 0; k < nblk; ++k) {
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, c->stream, c->S.p, npad, k, c->d_status.p);
+            const int T = nblk - k - 1;
+            if (T > 0) {
+                hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(64), 0, c->stream, c->S.p, npad, k);
+                hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, npad, k, nblk);
+            }
+        }
+        // backward substitution into Lwork (acc) / s (x)
+        HIPCHK(hipMemsetAsync(c->Lwork.p, 0, sizeof(double) * npad, c->stream));
+        const int nb_real = (n + NB - 1) / NB;
+        for (int kb = nb_real - 1; kb >= 0; --kb) {
+            const int below = nb_real - 1 - kb;
+            if (below > 0) hipLaunchKernelGGL(bwd_gemv_kernel, dim3(below), dim3(256), 0, c->stream, c->S.p, npad, kb, n, c->s.p, c->Lwork.p);
+            hipLaunchKernelGGL(bwd_diag_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, npad, kb, n, c->Lwork.p, c->s.p);
+        }
+    }
+    // x = -solution
+    hipLaunchKernelGGL(scatter_reduced_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->s.p, c->d_red_boff.p, n, c->x.p);
+    if (c->nelim > 0) {
+        const size_t lds = sizeof(double) * ((size_t)c->max_elim_dim * c->max_elim_dim + c->max_elim_dim);
+        hipLaunchKernelGGL(schur_backsub_kernel, dim3((unsigned)c->nelim), dim3(64), lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
+                           c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->lambda, c->max_elim_dim, c->s.p, c->x.p);
+    }
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+}  // namespace nlls

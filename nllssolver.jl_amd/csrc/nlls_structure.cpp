@@ -1,0 +1,374 @@
+// nlls_structure.cpp -- host-side symbolic phase of nlls_upload_structure.
+//
+// Replaces makesymmvls (src/linearsystem.jl:91-124): block sizes, the sparse/dense decision
+// (src/utils.jl:108-120), the BlockSparseMatrix pattern + offsets in the reference's exact layout
+// (src/BlockSparseMatrix.jl:30-47), boffsets (src/linearsystem.jl:36-41) -- and builds the device
+// work lists the reference has no counterpart for: per-(cost type, slot) entry lists sorted by
+// block row, LDS-image tiles, and the Schur elimination lists.
+#include <algorithm>
+#include <numeric>
+#include <unordered_map>
+
+#include "nlls_ctx.hpp"
+#include "nlls_internal.hpp"
+
+namespace nlls {
+
+bool res_desc(int kind, ResDesc& d) {
+    switch (kind) {
+#define X(K) case K: d.ndeps = Res<K>::NDEPS; d.nres = Res<K>::M; d.ndata = Res<K>::NDATA; d.adaptive = Res<K>::ADAPT; \
+        for (int i = 0; i < 4; ++i) { d.sk[i] = Res<K>::SK[i]; d.sd[i] = Res<K>::SD[i]; } return true;
+        NLLS_FOR_EACH_RES(X)
+#undef X
+    }
+    return false;
+}
+
+static int fail(nlls_ctx* c, int code, const std::string& msg) { c->err = msg; return code; }
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(c, NLLS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+// tiling parameters (see DESIGN.md "accumulate kernel")
+constexpr uint32_t LIGHT_MAX_ENTRIES = 256;    // one entry per lane of a 256-thread workgroup
+constexpr uint32_t LIGHT_IMG_MAX     = 6144;   // doubles of LDS image (48 KiB) -> 3 workgroups per CU
+constexpr uint32_t HEAVY_ROW_ENTRIES = 128;    // rows with more entries get a workgroup of their own
+constexpr uint32_t HEAVY_MAX_ENTRIES = 4096;   // entries per heavy tile; longer rows are split (PARTIAL)
+
+int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
+                    int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
+    c->ready = false; c->solved = false; c->have_grad = false; c->lambda = 0;
+    c->groups.clear();
+    // ---- variables ------------------------------------------------------------------------------
+    c->var_kind.assign(var_kind, var_kind + nvar); c->var_dim.assign(var_dim, var_dim + nvar);
+    c->var_off.assign(nvar + 1, 0);
+    uint64_t off = 0;
+    for (int64_t i = 0; i < nvar; ++i) {
+        int st = var_storage(var_kind[i], var_dim[i]);
+        if (st <= 0 || var_dof(var_kind[i], var_dim[i]) > NLLS_MAX_BLOCK_SZ) return fail(c, NLLS_ERR_UNSUPPORTED, "unregistered variable kind / block larger than MAX_BLOCK_SZ");
+        c->var_off[i] = (uint32_t)off; off += st;
+        if (off > 0xFFFFFFF0ull) return fail(c, NLLS_ERR_UNSUPPORTED, "variable storage exceeds 32-bit offsets");
+    }
+    c->var_off[nvar] = (uint32_t)off;
+    c->blockindices.assign(bi, bi + nvar);
+    int64_t nb = 0; for (int64_t i = 0; i < nvar; ++i) nb = std::max<int64_t>(nb, (int64_t)bi[i]);
+    c->blocksizes.assign(nb, 0);
+    for (int64_t i = 0; i < nvar; ++i) if (bi[i]) c->blocksizes[bi[i] - 1] = var_dof(var_kind[i], var_dim[i]);   // linearsystem.jl:96-102
+    c->boffsets.assign(nb + 1, 0);
+    for (int64_t k = 0; k < nb; ++k) { if (c->blocksizes[k] <= 0) return fail(c, NLLS_ERR_INVALID_ARG, "blockindices are not a dense 1..nblocks numbering"); c->boffsets[k + 1] = c->boffsets[k] + c->blocksizes[k]; }
+    const int64_t ndof = c->boffsets[nb];
+    // ---- groups: validate ------------------------------------------------------------------------
+    std::vector<ResDesc> desc(ngroups);
+    int64_t ncost_total = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        if (!res_desc(groups[g].res_kind, desc[g])) return fail(c, NLLS_ERR_UNSUPPORTED, "unregistered residual kind");
+        int base = groups[g].robust_kind & 0xF;
+        if (base > NLLS_ROBUST_GEMAN_MCCLURE || (groups[g].robust_kind & ~0x1F)) return fail(c, NLLS_ERR_UNSUPPORTED, "unregistered robust kernel");
+        const ResDesc& d = desc[g];
+        for (int64_t k = 0; k < groups[g].ncost; ++k) for (int s = 0; s < d.ndeps; ++s) {
+            int64_t v = groups[g].varind[k * d.ndeps + s];
+            if (v < 1 || v > nvar) return fail(c, NLLS_ERR_INVALID_ARG, "varind out of range");
+            if (var_kind[v - 1] != d.sk[s] || (d.sk[s] == NLLS_VAR_EUCLIDEAN && var_dim[v - 1] != d.sd[s]))
+                return fail(c, NLLS_ERR_UNSUPPORTED, "variable kind does not match the residual's slot");
+            for (int t = 0; t < s; ++t) if (groups[g].varind[k * d.ndeps + t] == v) return fail(c, NLLS_ERR_UNSUPPORTED, "a cost block lists the same variable twice");
+        }
+        ncost_total += groups[g].ncost;
+    }
+    // ---- sparsity: triu(V*V' .> 0) over the unfixed rows (linearsystem.jl:108-110) -------------------
+    bool sparse = false;
+    std::vector<uint64_t> keys;
+    if ((ndof >= 40 || (flags & NLLS_FLAG_FORCE_SPARSE)) && nb > 0) {
+        size_t cap = 0; for (int g = 0; g < ngroups; ++g) cap += (size_t)groups[g].ncost * (desc[g].ndeps * (desc[g].ndeps + 1) / 2);
+        keys.reserve(cap);
+        for (int g = 0; g < ngroups; ++g) { const int nd = desc[g].ndeps;
+            for (int64_t k = 0; k < groups[g].ncost; ++k) for (int s = 0; s < nd; ++s) {
+                uint64_t a = bi[groups[g].varind[k * nd + s] - 1]; if (!a) continue;
+                for (int t = 0; t <= s; ++t) { uint64_t b = bi[groups[g].varind[k * nd + t] - 1]; if (!b) continue;
+                    uint64_t hi = std::max(a, b), lo = std::min(a, b); keys.push_back((hi - 1) * (uint64_t)nb + (lo - 1)); } } }
+        std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        int64_t bnnz = 0; for (uint64_t k : keys) bnnz += (int64_t)c->blocksizes[k / nb] * c->blocksizes[k % nb];   // utils.jl:110-120
+        sparse = (flags & NLLS_FLAG_FORCE_SPARSE) || (bnnz * 64) < (25 * ndof * (ndof - 40));                        // utils.jl:108
+    }
+    c->it_colptr.clear(); c->it_rowval.clear(); c->it_nzval.clear(); c->diag_off.assign(nb, -1);
+    int64_t nnz_data = 0;
+    if (sparse) {   // BlockSparseMatrix constructor, BlockSparseMatrix.jl:30-47 (0-based here)
+        c->it_colptr.assign(nb + 1, 0); c->it_rowval.resize(keys.size()); c->it_nzval.resize(keys.size());
+        size_t q = 0; int64_t start = 0;
+        for (int64_t row = 0; row < nb; ++row) {
+            c->it_colptr[row] = (int64_t)q;
+            while (q < keys.size() && (int64_t)(keys[q] / nb) == row) {
+                int64_t col = keys[q] % nb; c->it_rowval[q] = col; c->it_nzval[q] = start;
+                if (col == row) c->diag_off[row] = start;
+                start += (int64_t)c->blocksizes[row] * c->blocksizes[col]; ++q; }
+        }
+        c->it_colptr[nb] = (int64_t)q; nnz_data = start;
+        if (nnz_data > 0xFFFFFFF0ll) return fail(c, NLLS_ERR_UNSUPPORTED, "A.data exceeds 32-bit offsets");
+    } else {
+        nnz_data = ndof * ndof;
+        for (int64_t k = 0; k < nb; ++k) c->diag_off[k] = c->boffsets[k] + ndof * c->boffsets[k];
+    }
+    std::vector<uint64_t>().swap(keys);
+    auto block_off = [&](int64_t row, int64_t col) -> int64_t {   // offset of block(A, row, col), row >= col
+        const int64_t* b0 = c->it_rowval.data() + c->it_colptr[row]; const int64_t* b1 = c->it_rowval.data() + c->it_colptr[row + 1];
+        const int64_t* it = std::lower_bound(b0, b1, col);
+        return (it != b1 && *it == col) ? c->it_nzval[it - c->it_rowval.data()] : -1;
+    };
+    // segment [segs[row], segs[row+1]) of every block row: rows are laid out back to back
+    std::vector<int64_t> segs(nb + 1, 0);
+    if (sparse) { int64_t cur = 0; for (int64_t row = 0; row < nb; ++row) { segs[row] = cur;
+            for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) cur += (int64_t)c->blocksizes[row] * c->blocksizes[c->it_rowval[q]]; }
+        segs[nb] = nnz_data; }
+
+    // ---- info ----------------------------------------------------------------------------------------
+    nlls_info& I = c->info; memset(&I, 0, sizeof I);
+    I.is_sparse = sparse; I.nvar = nvar; I.nblocks = nb; I.ndof = ndof; I.nnz_data = nnz_data; I.nblocks_stored = (int64_t)c->it_rowval.size();
+    I.ncost = ncost_total; I.var_storage = c->var_off[nvar];
+
+    // ---- device buffers ----------------------------------------------------------------------------------
+    HIPCHK(hipSetDevice(c->device));
+    for (int k = 0; k < 3; ++k) { HIPCHK(c->vars[k].alloc(std::max<size_t>(I.var_storage, 1))); HIPCHK(hipMemset(c->vars[k].p, 0, sizeof(double) * std::max<size_t>(I.var_storage, 1))); c->vars_slot[k] = k; }
+    HIPCHK(c->A.alloc(std::max<int64_t>(nnz_data, 1))); HIPCHK(hipMemset(c->A.p, 0, sizeof(double) * std::max<int64_t>(nnz_data, 1)));
+    HIPCHK(c->b.alloc(std::max<int64_t>(ndof, 1))); HIPCHK(hipMemset(c->b.p, 0, sizeof(double) * std::max<int64_t>(ndof, 1)));
+    HIPCHK(c->x.alloc(std::max<int64_t>(ndof, 1))); HIPCHK(hipMemset(c->x.p, 0, sizeof(double) * std::max<int64_t>(ndof, 1)));
+    HIPCHK(c->d_var_kind.upload(c->var_kind)); HIPCHK(c->d_var_dim.upload(c->var_dim)); HIPCHK(c->d_var_off.upload(c->var_off));
+    { std::vector<uint32_t> vb(nvar); for (int64_t i = 0; i < nvar; ++i) vb[i] = bi[i] ? (uint32_t)c->boffsets[bi[i] - 1] : DEST_NONE; HIPCHK(c->d_var_boff.upload(vb)); }
+    HIPCHK(c->d_diag_off.upload(c->diag_off)); HIPCHK(c->d_blocksizes.upload(c->blocksizes));
+    if (!c->h_scalars) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), 64 * sizeof(double)));
+    HIPCHK(c->scalars.alloc(64));
+
+    // ---- per-group lists ---------------------------------------------------------------------------------
+    c->groups.resize(ngroups);
+    std::vector<int32_t> row_nlists(nb, 0);         // how many entry lists touch a row
+    struct HostList { std::vector<int64_t> cost; std::vector<int64_t> rowptr; std::vector<int64_t> rows; };   // entries sorted by row
+    std::vector<std::vector<HostList>> hl(ngroups);
+    int64_t npartials = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        Group& G = c->groups[g]; const ResDesc& d = desc[g]; const nlls_cost_group& in = groups[g];
+        G.res_kind = in.res_kind; G.ndeps = d.ndeps; G.ndata = d.ndata; G.nres = d.nres; G.adaptive = d.adaptive; G.ncost = in.ncost;
+        G.rk.kind = in.robust_kind; G.rk.p0 = in.robust_params[0]; G.rk.p1 = in.robust_params[1];
+        // cost-order arrays
+        { std::vector<double> hd(in.data, in.data + in.ncost * d.ndata); HIPCHK(G.data.upload(hd));
+          std::vector<uint32_t> hv((size_t)in.ncost * d.ndeps);
+          for (int64_t k = 0; k < in.ncost * d.ndeps; ++k) hv[k] = c->var_off[in.varind[k] - 1];
+          HIPCHK(G.voff.upload(hv)); }
+        std::vector<uint32_t> fixedcost;
+        for (int64_t k = 0; k < in.ncost; ++k) { bool any = false; for (int s = 0; s < d.ndeps; ++s) any |= bi[in.varind[k * d.ndeps + s] - 1] != 0; if (!any) fixedcost.push_back((uint32_t)k); }
+        G.nfixedcost = (int64_t)fixedcost.size(); HIPCHK(G.fixedcost.upload(fixedcost));
+        npartials += (G.nfixedcost + 255) / 256;
+        hl[g].resize(d.ndeps);
+        if (!sparse) continue;
+        for (int s = 0; s < d.ndeps; ++s) {
+            HostList& L = hl[g][s];
+            // counting sort of the incidences (cost, s) by block row
+            std::vector<int64_t> cnt(nb + 1, 0);
+            for (int64_t k = 0; k < in.ncost; ++k) { uint64_t r = bi[in.varind[k * d.ndeps + s] - 1]; if (r) cnt[r]++; }
+            for (int64_t r = 0; r < nb; ++r) if (cnt[r + 1]) { L.rows.push_back(r); row_nlists[r]++; }
+            std::vector<int64_t> pos(nb + 2, 0); for (int64_t r = 1; r <= nb; ++r) pos[r + 1] = pos[r] + cnt[r];
+            L.cost.resize(pos[nb + 1]);
+            L.rowptr.resize(L.rows.size() + 1);
+            for (size_t i = 0; i < L.rows.size(); ++i) L.rowptr[i] = pos[L.rows[i] + 1];
+            L.rowptr[L.rows.size()] = pos[nb + 1];
+            for (int64_t k = 0; k < in.ncost; ++k) { uint64_t r = bi[in.varind[k * d.ndeps + s] - 1]; if (r) L.cost[pos[r]++] = k; }
+        }
+    }
+    // ---- tiles ------------------------------------------------------------------------------------------------
+    std::vector<int64_t> zero_off; std::vector<uint32_t> zero_len, zero_b_off, zero_b_len;
+    std::vector<uint8_t> row_zero(nb, 0);
+    bool all_owner = true;
+    if (sparse) for (int g = 0; g < ngroups; ++g) {
+        Group& G = c->groups[g]; const ResDesc& d = desc[g]; const nlls_cost_group& in = groups[g];
+        for (int s = 0; s < d.ndeps; ++s) {
+            HostList& L = hl[g][s]; EntryList& E = G.lists[s]; E.slot = s; E.n = (int64_t)L.cost.size();
+            if (E.n == 0) continue;
+            if (E.n > 0xFFFFFFF0ll) return fail(c, NLLS_ERR_UNSUPPORTED, "entry list exceeds 32-bit indices");
+            const size_t nrows = L.rows.size();
+            std::vector<RowInfo> rinfo(nrows);
+            std::vector<Tile> light, heavy;
+            std::vector<uint32_t> dest((size_t)E.n * d.ndeps, DEST_NONE);
+            std::vector<int64_t> entry_base(E.n, 0);   // image base (A.data offset) of the entry's tile, -1 => DIRECT (absolute)
+            const bool force_atomic = (flags & NLLS_FLAG_FORCE_ATOMIC) != 0;
+            auto close_light = [&](size_t r0, size_t r1, bool partial) {
+                Tile t{}; t.e0 = (uint32_t)L.rowptr[r0]; t.e1 = (uint32_t)L.rowptr[r1]; t.row0 = (uint32_t)r0; t.nrows = (uint32_t)(r1 - r0);
+                int64_t br0 = L.rows[r0], br1 = L.rows[r1 - 1];
+                t.data_off = segs[br0]; t.data_len = (uint32_t)(segs[br1 + 1] - segs[br0]);
+                t.b_off = (uint32_t)c->boffsets[br0]; t.b_len = (uint32_t)(c->boffsets[br1 + 1] - c->boffsets[br0]);
+                t.flags = partial ? TILE_PARTIAL : 0;
+                for (size_t r = r0; r < r1; ++r) { int64_t br = L.rows[r];
+                    rinfo[r].diag_off = (uint32_t)(c->diag_off[br] - t.data_off); rinfo[r].b_off = t.data_len + (uint32_t)(c->boffsets[br] - c->boffsets[br0]);
+                    if (partial) row_zero[br] = 1;
+                    for (int64_t e = L.rowptr[r]; e < L.rowptr[r + 1]; ++e) { entry_base[e] = t.data_off; dest[(size_t)e * d.ndeps + s] = (uint32_t)(r - r0); } }
+                E.light_lds = std::max(E.light_lds, t.data_len + t.b_len);
+                light.push_back(t); if (partial) all_owner = false;
+            };
+            size_t r = 0;
+            while (r < nrows) {
+                int64_t br = L.rows[r]; int64_t ne = L.rowptr[r + 1] - L.rowptr[r]; int64_t seglen = segs[br + 1] - segs[br];
+                bool is_heavy = ne > HEAVY_ROW_ENTRIES || seglen + c->blocksizes[br] > LIGHT_IMG_MAX;
+                if (is_heavy) {
+                    bool direct = seglen + c->blocksizes[br] > LIGHT_IMG_MAX;
+                    bool split = ne > HEAVY_MAX_ENTRIES; bool shared = row_nlists[br] > 1 || force_atomic;
+                    for (int64_t e0 = L.rowptr[r]; e0 < L.rowptr[r + 1]; e0 += HEAVY_MAX_ENTRIES) {
+                        Tile t{}; t.e0 = (uint32_t)e0; t.e1 = (uint32_t)std::min<int64_t>(e0 + HEAVY_MAX_ENTRIES, L.rowptr[r + 1]); t.row0 = (uint32_t)r; t.nrows = 1;
+                        t.data_off = segs[br]; t.data_len = direct ? 0u : (uint32_t)seglen; t.b_off = (uint32_t)c->boffsets[br]; t.b_len = (uint32_t)c->blocksizes[br];
+                        t.flags = (direct ? TILE_DIRECT : 0) | ((split || shared || direct) ? TILE_PARTIAL : 0);
+                        heavy.push_back(t);
+                        E.heavy_lds = std::max(E.heavy_lds, t.data_len);
+                        for (int64_t e = t.e0; e < t.e1; ++e) { entry_base[e] = direct ? 0 : t.data_off; dest[(size_t)e * d.ndeps + s] = 0; }
+                        if (t.flags & TILE_PARTIAL) { row_zero[br] = 1; all_owner = false; }
+                    }
+                    rinfo[r].diag_off = (uint32_t)(c->diag_off[br] - segs[br]); rinfo[r].b_off = 0;
+                    ++r; continue;
+                }
+                // light run: consecutive block rows present in this list
+                size_t r1 = r; uint32_t ents = 0; int64_t img = 0; bool partial = force_atomic;
+                while (r1 < nrows) {
+                    int64_t brr = L.rows[r1]; int64_t nee = L.rowptr[r1 + 1] - L.rowptr[r1]; int64_t sl = segs[brr + 1] - segs[brr] + c->blocksizes[brr];
+                    if (r1 > r && brr != L.rows[r1 - 1] + 1) break;
+                    if (nee > HEAVY_ROW_ENTRIES || sl > LIGHT_IMG_MAX) break;
+                    if (r1 > r && (ents + nee > LIGHT_MAX_ENTRIES || img + sl > LIGHT_IMG_MAX || r1 - r >= 0xFFFF)) break;
+                    bool sh = row_nlists[brr] > 1;
+                    if (r1 > r && sh != partial && !force_atomic) break;      // keep exclusive and shared rows in separate tiles
+                    partial = sh || force_atomic; ents += (uint32_t)nee; img += sl; ++r1;
+                }
+                close_light(r, r1, partial); r = r1;
+            }
+            // off-diagonal destinations + flags
+            for (size_t rr = 0; rr < nrows; ++rr) { int64_t br = L.rows[rr];
+                for (int64_t e = L.rowptr[rr]; e < L.rowptr[rr + 1]; ++e) { int64_t k = L.cost[e];
+                    uint32_t own = dest[(size_t)e * d.ndeps + s] & OWN_ROW_MASK;
+                    bool first_free = true; for (int t = 0; t < s; ++t) if (bi[in.varind[k * d.ndeps + t] - 1]) first_free = false;
+                    if (first_free) own |= OWN_COST_OWNER;
+                    if (d.adaptive && bi[in.varind[k * d.ndeps] - 1]) own |= OWN_KERNEL_FREE;
+                    dest[(size_t)e * d.ndeps + s] = own;
+                    for (int t = 0; t < d.ndeps; ++t) { if (t == s) continue; uint64_t bt = bi[in.varind[k * d.ndeps + t] - 1];
+                        if (!bt || (int64_t)bt - 1 > br) continue;
+                        int64_t bo = block_off(br, (int64_t)bt - 1); if (bo < 0) return fail(c, NLLS_ERR_INVALID_ARG, "internal: block missing from the pattern");
+                        dest[(size_t)e * d.ndeps + t] = (uint32_t)(bo - entry_base[e]); } } }
+            // upload the list
+            { std::vector<double> hd((size_t)E.n * d.ndata); std::vector<uint32_t> hv((size_t)E.n * d.ndeps);
+              for (int64_t e = 0; e < E.n; ++e) { int64_t k = L.cost[e];
+                  for (int q = 0; q < d.ndata; ++q) hd[(size_t)e * d.ndata + q] = in.data[k * d.ndata + q];
+                  for (int q = 0; q < d.ndeps; ++q) hv[(size_t)e * d.ndeps + q] = c->var_off[in.varind[k * d.ndeps + q] - 1]; }
+              HIPCHK(E.data.upload(hd)); HIPCHK(E.voff.upload(hv)); HIPCHK(E.dest.upload(dest)); HIPCHK(E.rows.upload(rinfo)); }
+            E.nlight = (int64_t)light.size(); E.nheavy = (int64_t)heavy.size();
+            HIPCHK(E.light.upload(light)); HIPCHK(E.heavy.upload(heavy));
+            npartials += E.nlight + E.nheavy;
+            std::vector<int64_t>().swap(L.cost);
+        }
+    }
+    if (sparse) {
+        for (int64_t r = 0; r < nb; ++r) if (row_zero[r]) { zero_off.push_back(segs[r]); zero_len.push_back((uint32_t)(segs[r + 1] - segs[r])); zero_b_off.push_back((uint32_t)c->boffsets[r]); zero_b_len.push_back((uint32_t)c->blocksizes[r]); }
+    } else {
+        // dense linear system: one entry per cost with at least one free variable
+        for (int g = 0; g < ngroups; ++g) {
+            Group& G = c->groups[g]; const ResDesc& d = desc[g]; const nlls_cost_group& in = groups[g];
+            std::vector<double> hd; std::vector<uint32_t> hv, hb;
+            for (int64_t k = 0; k < in.ncost; ++k) { bool any = false; for (int s = 0; s < d.ndeps; ++s) any |= bi[in.varind[k * d.ndeps + s] - 1] != 0; if (!any) continue;
+                for (int q = 0; q < d.ndata; ++q) hd.push_back(in.data[k * d.ndata + q]);
+                for (int s = 0; s < d.ndeps; ++s) { int64_t v = in.varind[k * d.ndeps + s] - 1; hv.push_back(c->var_off[v]); hb.push_back(bi[v] ? (uint32_t)c->boffsets[bi[v] - 1] : DEST_NONE); } }
+            G.dense.n = (int64_t)(hv.size() / std::max(d.ndeps, 1));
+            HIPCHK(G.dense.data.upload(hd)); HIPCHK(G.dense.voff.upload(hv)); HIPCHK(G.dense.brow.upload(hb));
+            npartials += (G.dense.n + 255) / 256 + 1;
+        }
+        all_owner = false;
+    }
+    c->nzero = (int64_t)zero_off.size();
+    HIPCHK(c->d_zero_off.upload(zero_off)); HIPCHK(c->d_zero_len.upload(zero_len)); HIPCHK(c->d_zero_b_off.upload(zero_b_off)); HIPCHK(c->d_zero_b_len.upload(zero_b_len));
+    for (int g = 0; g < ngroups; ++g) npartials += (c->groups[g].ncost + 255) / 256 + 1;
+    c->npartials = npartials + 16;
+    HIPCHK(c->partials.alloc(c->npartials));
+    I.owner_path = all_owner ? 1 : 0;
+
+    int rc = build_schur(c, flags);
+    if (rc != NLLS_OK) return rc;
+    c->ready = true;
+    return NLLS_OK;
+}
+
+// ---- Schur structures --------------------------------------------------------------------------------------
+// The reference factors the FULL sparse system with LDLFactorizations (src/linearsolver.jl:29); there is no
+// Schur complement in it.  Here an independent set of blocks (no two share a stored block) is
+// eliminated first -- the same fill-reducing choice a minimum-degree ordering makes for bundle adjustment --
+// and the remaining blocks form the dense reduced system.
+int build_schur(nlls_ctx* c, int32_t flags) {
+    const nlls_info& I0 = c->info; const int64_t nb = I0.nblocks, ndof = I0.ndof;
+    c->is_elim.assign(nb, 0); c->nelim = 0; c->nelim_groups = 0; c->max_elim_dim = 0; c->max_nbr_dof = 0;
+    std::vector<int64_t> red_of(nb, -1);     // dof offset in the reduced system
+    if (I0.is_sparse && !(flags & NLLS_FLAG_NO_SCHUR) && nb > 1) {
+        // adjacency counts
+        std::vector<int32_t> deg(nb, 0);
+        for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q]; if (col != row) { deg[row]++; deg[col]++; } }
+        // candidate class = the (block size) class with the most blocks; greedy independent set inside it,
+        // lowest degree first (stable by index)
+        std::unordered_map<int, int64_t> classcount; for (int64_t k = 0; k < nb; ++k) classcount[c->blocksizes[k]]++;
+        int best = -1; int64_t bestn = 0; for (auto& kv : classcount) if (kv.second > bestn || (kv.second == bestn && kv.first < best)) { best = kv.first; bestn = kv.second; }
+        std::vector<std::vector<int32_t>> adj;   // only needed to test independence: use marks over rows
+        std::vector<uint8_t> blocked(nb, 0);
+        // neighbours of a block = cols of its row + rows having it as col -> build transposed lists once
+        std::vector<int64_t> tptr(nb + 1, 0); for (int64_t q = 0; q < (int64_t)c->it_rowval.size(); ++q) tptr[c->it_rowval[q] + 1]++;
+        for (int64_t k = 0; k < nb; ++k) tptr[k + 1] += tptr[k];
+        std::vector<int64_t> trow(c->it_rowval.size()); { std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
+            for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) trow[cur[c->it_rowval[q]]++] = row; }
+        std::vector<int64_t> order; for (int64_t k = 0; k < nb; ++k) if (c->blocksizes[k] == best) order.push_back(k);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return deg[a] < deg[b]; });
+        for (int64_t v : order) { if (blocked[v]) continue; c->is_elim[v] = 1; c->nelim++;
+            for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) blocked[c->it_rowval[q]] = 1;
+            for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) blocked[trow[q]] = 1; }
+        // not worth it unless most blocks go
+        if (c->nelim * 2 < nb) { std::fill(c->is_elim.begin(), c->is_elim.end(), 0); c->nelim = 0; }
+        if (c->nelim) {
+            int64_t ro = 0; for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) { red_of[k] = ro; ro += c->blocksizes[k]; }
+            c->nred = ro;
+            std::vector<int64_t> eptr; std::vector<SchurNbr> enbr; std::vector<int64_t> ediag; std::vector<uint32_t> eboff; std::vector<uint16_t> edim;
+            std::vector<uint32_t> egroup;
+            eptr.push_back(0);
+            std::vector<SchurNbr> prev;
+            for (int64_t v = 0; v < nb; ++v) if (c->is_elim[v]) {
+                std::vector<SchurNbr> nb_list;
+                for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) { int64_t u = c->it_rowval[q]; if (u == v) continue;
+                    nb_list.push_back(SchurNbr{c->it_nzval[q], (uint32_t)red_of[u], (uint16_t)c->blocksizes[u], 0}); }
+                for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) { int64_t w = trow[q]; if (w == v) continue;
+                    // block (w, v) stored in row w: find its offset
+                    const int64_t* b0 = c->it_rowval.data() + c->it_colptr[w]; const int64_t* b1 = c->it_rowval.data() + c->it_colptr[w + 1];
+                    const int64_t* it = std::lower_bound(b0, b1, v);
+                    nb_list.push_back(SchurNbr{c->it_nzval[it - c->it_rowval.data()], (uint32_t)red_of[w], (uint16_t)c->blocksizes[w], 1}); }
+                std::sort(nb_list.begin(), nb_list.end(), [](const SchurNbr& a, const SchurNbr& b) { return a.rcol < b.rcol; });
+                int nd = 0; for (auto& n : nb_list) nd += n.dim;
+                c->max_nbr_dof = std::max(c->max_nbr_dof, nd); c->max_elim_dim = std::max(c->max_elim_dim, (int)c->blocksizes[v]);
+                // supernode: same neighbour columns as the previous eliminated block
+                bool same = !egroup.empty() && prev.size() == nb_list.size();
+                if (same) for (size_t i = 0; i < prev.size(); ++i) if (prev[i].rcol != nb_list[i].rcol) { same = false; break; }
+                if (!same) egroup.push_back((uint32_t)ediag.size());
+                prev = nb_list;
+                for (auto& n : nb_list) enbr.push_back(n);
+                eptr.push_back((int64_t)enbr.size()); ediag.push_back(c->diag_off[v]); eboff.push_back((uint32_t)c->boffsets[v]); edim.push_back((uint16_t)c->blocksizes[v]);
+            }
+            egroup.push_back((uint32_t)ediag.size());
+            { size_t lds = sizeof(double) * ((size_t)c->max_elim_dim * c->max_elim_dim + (size_t)c->max_elim_dim * (2 * c->max_nbr_dof + 1)) + 4 * (c->max_nbr_dof + 2);
+              if (lds > 60 * 1024) return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated block with too many neighbours for the LDS-staged Schur kernel (retry with NLLS_FLAG_NO_SCHUR)"); }
+            c->nelim_groups = (int64_t)egroup.size() - 1;
+            if (hipSuccess != c->d_elim_ptr.upload(eptr) || hipSuccess != c->d_elim_nbr.upload(enbr) || hipSuccess != c->d_elim_diag.upload(ediag) ||
+                hipSuccess != c->d_elim_boff.upload(eboff) || hipSuccess != c->d_elim_dim.upload(edim) || hipSuccess != c->d_elim_group.upload(egroup)) return fail(c, NLLS_ERR_HIP, "schur upload");
+        }
+    }
+    if (!c->nelim) { int64_t ro = 0; for (int64_t k = 0; k < nb; ++k) { red_of[k] = ro; ro += c->blocksizes[k]; } c->nred = ro; }
+    // reduced-reduced blocks to copy into S
+    std::vector<SchurCopy> copies; std::vector<uint32_t> red_boff(c->nred);
+    for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) for (int i = 0; i < c->blocksizes[k]; ++i) red_boff[red_of[k] + i] = (uint32_t)(c->boffsets[k] + i);
+    if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) { if (c->is_elim[row]) continue;
+        for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q]; if (c->is_elim[col]) continue;
+            copies.push_back(SchurCopy{c->it_nzval[q], (uint32_t)red_of[row], (uint32_t)red_of[col], (uint16_t)c->blocksizes[row], (uint16_t)c->blocksizes[col]}); } }
+    c->ncopy = (int64_t)copies.size();
+    { std::vector<SchurCopy> blks;
+      if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q];
+          blks.push_back(SchurCopy{c->it_nzval[q], (uint32_t)c->boffsets[row], (uint32_t)c->boffsets[col], (uint16_t)c->blocksizes[row], (uint16_t)c->blocksizes[col]}); }
+      c->nblk = (int64_t)blks.size(); if (hipSuccess != c->d_blk.upload(blks)) return fail(c, NLLS_ERR_HIP, "block list upload"); }
+    if (hipSuccess != c->d_copy.upload(copies) || hipSuccess != c->d_red_boff.upload(red_boff)) return fail(c, NLLS_ERR_HIP, "schur upload");
+    const int64_t n = c->nred; const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
+    if (hipSuccess != c->S.alloc((size_t)std::max<int64_t>(npad * npad, 1)) || hipSuccess != c->s.alloc((size_t)std::max<int64_t>(npad, 1)) ||
+        hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 64 + 64 * 64 * 2, 1)) || hipSuccess != c->d_status.alloc(4)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
+    c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
+    (void)ndof;
+    return NLLS_OK;
+}
+
+}  // namespace nlls

@@ -1,0 +1,485 @@
+// nlls_sweep.hip -- the residual+Jacobian sweep and the block-sparse J'J / J'r accumulation (gfx950).
+//
+// Replaces, per outer iteration:
+//   zero!(linsystem); costgradhess!(linsystem, vars, costs)   src/optimize.jl:118,167-170
+//     -> per block src/cost.jl:29-52, src/residual.jl:57-111, src/autodiff.jl:81-93
+//     -> updatesymlinearsystem!                                src/linearsystem.jl:132-175
+//   cost(vars, costs)                                          src/cost.jl:10-13
+//   update!(to, from, linsystem)                               src/linearsystem.jl:206-213
+//
+// Accumulate design ("owner image"): A.data is block-ROW-major (src/BlockSparseMatrix.jl:37-44), so all
+// blocks a variable's row owns -- (row, col<row) and the diagonal -- are one contiguous run of A.data,
+// and consecutive rows are back to back.  Every (cost, slot) incidence is an *entry* in a list sorted by
+// the block row of that slot's variable.  A workgroup takes a tile of consecutive rows, keeps their
+// A.data / b segment as an LDS image, lets one lane per entry evaluate the block (dual numbers in
+// registers) and add its contributions into the image with LDS atomics, then streams the image to HBM
+// with plain coalesced stores: each byte of A.data is written exactly once, no zero! pass, no HBM
+// atomics.  Rows with many entries (cameras) get a workgroup each, accumulate the diagonal block + b in
+// registers and reduce with wavefront shuffles.  Rows that several lists share, or that are split over
+// workgroups, fall back to flushing the (already LDS-reduced) image with HBM atomics.
+#include <utility>
+
+#include "nlls_internal.hpp"
+
+namespace nlls {
+
+constexpr int TPB = 256;
+
+template <int N, class F>
+NLLS_DEV void static_for(F&& f) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
+NLLS_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+NLLS_DEV double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+// deterministic workgroup sum (fixed tree); result valid in thread 0
+NLLS_DEV double block_sum(double v, double* red /* >= TPB/64 doubles of LDS */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+NLLS_DEV double block_max(double v, double* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, red[i]);
+    return t;
+}
+
+// element (i of slot SA, j of slot SB) of the block's local Hessian / gradient (residual.jl:91-107)
+template <int KIND, int SA, int SB>
+NLLS_DEV double h_elem(const BlockGH<KIND>& B, int i, int j) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    constexpr bool KA = R::ADAPT && SA == 0, KB = R::ADAPT && SB == 0;
+    if constexpr (KA && KB) return B.Hkk(i, j);
+    else if constexpr (KA) return B.Hkv(i, I::joff(SB) + j);
+    else if constexpr (KB) return B.Hkv(j, I::joff(SA) + i);
+    else return B.H(I::joff(SA) + i, I::joff(SB) + j);
+}
+template <int KIND, int SA>
+NLLS_DEV double g_elem(const BlockGH<KIND>& B, int i) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    if constexpr (R::ADAPT && SA == 0) return B.Gk(i); else return B.G(I::joff(SA) + i);
+}
+
+// ================================================================================================
+// cost sweep   src/cost.jl:10-13 -> src/residual.jl:49-55
+// ================================================================================================
+template <int KIND>
+__global__ __launch_bounds__(TPB) void cost_kernel(const double* __restrict__ vars, const double* __restrict__ data,
+                                                   const uint32_t* __restrict__ voff, const uint32_t* __restrict__ index,
+                                                   int64_t n, RobustSpec rk, double* __restrict__ partials) {
+    using R = Res<KIND>;
+    __shared__ double red[TPB / 64];
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const int64_t k = index ? index[i] : i;
+        double d[R::NDATA]; uint32_t vo[R::NDEPS];
+#pragma unroll
+        for (int q = 0; q < R::NDATA; ++q) d[q] = data[k * R::NDATA + q];
+#pragma unroll
+        for (int q = 0; q < R::NDEPS; ++q) vo[q] = voff[k * R::NDEPS + q];
+        acc += block_cost<KIND>(vars, vo, d, rk);
+    }
+    double t = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// final deterministic reduction of the per-workgroup partials
+__global__ __launch_bounds__(TPB) void reduce_partials_kernel(const double* __restrict__ partials, int64_t n, double* __restrict__ out) {
+    __shared__ double red[TPB / 64];
+    double acc = 0;
+    for (int64_t i = threadIdx.x; i < n; i += TPB) acc += partials[i];
+    double t = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+// ================================================================================================
+// accumulate: light tiles (many rows per workgroup, one entry per lane)
+// ================================================================================================
+template <int KIND, int SLOT>
+__global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
+                                                       const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ edest,
+                                                       const RowInfo* __restrict__ rows, const Tile* __restrict__ tiles, RobustSpec rk,
+                                                       double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    constexpr int DS = I::dof(SLOT);
+    extern __shared__ __attribute__((aligned(16))) double img[];
+    __shared__ double red[TPB / 64];
+    const Tile t = tiles[blockIdx.x];
+    const uint32_t imglen = t.data_len + t.b_len;
+    for (uint32_t i = threadIdx.x; i < imglen; i += TPB) img[i] = 0.0;
+    __syncthreads();
+    double mycost = 0;
+    for (uint32_t e = t.e0 + threadIdx.x; e < t.e1; e += TPB) {
+        double d[R::NDATA]; uint32_t vo[R::NDEPS], ds[R::NDEPS];
+#pragma unroll
+        for (int q = 0; q < R::NDATA; ++q) d[q] = edata[(size_t)e * R::NDATA + q];
+#pragma unroll
+        for (int q = 0; q < R::NDEPS; ++q) { vo[q] = evoff[(size_t)e * R::NDEPS + q]; ds[q] = edest[(size_t)e * R::NDEPS + q]; }
+        const uint32_t own = ds[SLOT];
+        BlockGH<KIND> B; B.compute(vars, vo, d, rk, (own & OWN_KERNEL_FREE) != 0);
+        if (own & OWN_COST_OWNER) mycost += B.cost;
+        const RowInfo ri = rows[t.row0 + (own & OWN_ROW_MASK)];
+        // diagonal block (full, both triangles: linearsystem.jl:140) and b (linearsystem.jl:159-170)
+#pragma unroll
+        for (int j = 0; j < DS; ++j)
+#pragma unroll
+            for (int i = 0; i < DS; ++i) atomicAdd(&img[ri.diag_off + i + DS * j], h_elem<KIND, SLOT, SLOT>(B, i, j));
+#pragma unroll
+        for (int i = 0; i < DS; ++i) atomicAdd(&img[ri.b_off + i], g_elem<KIND, SLOT>(B, i));
+        // off-diagonal blocks this row owns: block(A, row(SLOT), row(T)) += H[SLOT range, T range]  (linearsystem.jl:148-149)
+        static_for<R::NDEPS>([&](auto Tc) {
+            constexpr int T = decltype(Tc)::value;
+            if constexpr (T != SLOT) {
+                constexpr int DT = I::dof(T);
+                if (ds[T] != DEST_NONE) {
+#pragma unroll
+                    for (int j = 0; j < DT; ++j)
+#pragma unroll
+                        for (int i = 0; i < DS; ++i) atomicAdd(&img[ds[T] + i + DS * j], h_elem<KIND, SLOT, T>(B, i, j));
+                }
+            }
+        });
+    }
+    double tc = block_sum(mycost, red);    // contains the barrier that completes the image
+    if (threadIdx.x == 0) partials[blockIdx.x] = tc;
+    __syncthreads();
+    if (t.flags & TILE_PARTIAL) {
+        for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) { double v = img[i]; if (v != 0.0) atomicAdd(&A[t.data_off + i], v); }
+        for (uint32_t i = threadIdx.x; i < t.b_len; i += TPB) { double v = img[t.data_len + i]; if (v != 0.0) atomicAdd(&b[t.b_off + i], v); }
+    } else {
+        double* dst = A + t.data_off;
+        for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) dst[i] = img[i];
+        for (uint32_t i = threadIdx.x; i < t.b_len; i += TPB) b[t.b_off + i] = img[t.data_len + i];
+    }
+}
+
+// ================================================================================================
+// accumulate: heavy tiles (one row, or a slice of one, per workgroup)
+// ================================================================================================
+template <int KIND, int SLOT>
+__global__ __launch_bounds__(TPB) void gh_heavy_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
+                                                       const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ edest,
+                                                       const RowInfo* __restrict__ rows, const Tile* __restrict__ tiles, RobustSpec rk,
+                                                       double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    constexpr int DS = I::dof(SLOT);
+    constexpr int NTRI = DS * (DS + 1) / 2, NACC = NTRI + DS + 1;   // lower triangle + b + cost
+    extern __shared__ __attribute__((aligned(16))) double img[];
+    __shared__ double red[TPB / 64][NACC];
+    const Tile t = tiles[blockIdx.x];
+    const bool direct = (t.flags & TILE_DIRECT) != 0;
+    for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) img[i] = 0.0;
+    __syncthreads();
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    for (uint32_t e = t.e0 + threadIdx.x; e < t.e1; e += TPB) {
+        double d[R::NDATA]; uint32_t vo[R::NDEPS], ds[R::NDEPS];
+#pragma unroll
+        for (int q = 0; q < R::NDATA; ++q) d[q] = edata[(size_t)e * R::NDATA + q];
+#pragma unroll
+        for (int q = 0; q < R::NDEPS; ++q) { vo[q] = evoff[(size_t)e * R::NDEPS + q]; ds[q] = edest[(size_t)e * R::NDEPS + q]; }
+        const uint32_t own = ds[SLOT];
+        BlockGH<KIND> B; B.compute(vars, vo, d, rk, (own & OWN_KERNEL_FREE) != 0);
+        if (own & OWN_COST_OWNER) acc[NACC - 1] += B.cost;
+        {
+            int q = 0;
+#pragma unroll
+            for (int j = 0; j < DS; ++j)
+#pragma unroll
+                for (int i = j; i < DS; ++i) acc[q++] += h_elem<KIND, SLOT, SLOT>(B, i, j);
+#pragma unroll
+            for (int i = 0; i < DS; ++i) acc[NTRI + i] += g_elem<KIND, SLOT>(B, i);
+        }
+        static_for<R::NDEPS>([&](auto Tc) {
+            constexpr int T = decltype(Tc)::value;
+            if constexpr (T != SLOT) {
+                constexpr int DT = I::dof(T);
+                if (ds[T] != DEST_NONE) {
+#pragma unroll
+                    for (int j = 0; j < DT; ++j)
+#pragma unroll
+                        for (int i = 0; i < DS; ++i) {
+                            const double v = h_elem<KIND, SLOT, T>(B, i, j);
+                            if (direct) atomicAdd(&A[(size_t)ds[T] + i + DS * j], v); else atomicAdd(&img[ds[T] + i + DS * j], v);
+                        }
+                }
+            }
+        });
+    }
+    // fixed-tree reduction of the row's diagonal block, b and cost
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) { double v = wave_sum(acc[i]); if (lane == 0) red[w][i] = v; }
+    __syncthreads();
+    const RowInfo ri = rows[t.row0];   // diag_off: offset of the diagonal block inside the row's segment
+    if (threadIdx.x < NACC) {
+        double v = 0;
+        for (int k = 0; k < TPB / 64; ++k) v += red[k][threadIdx.x];
+        if ((int)threadIdx.x == NACC - 1) partials[blockIdx.x] = v;
+        else if ((int)threadIdx.x >= NTRI) {
+            const int i = threadIdx.x - NTRI;
+            if (t.flags & TILE_PARTIAL) atomicAdd(&b[t.b_off + i], v); else b[t.b_off + i] = v;
+        } else {
+            int q = threadIdx.x, j = 0; while (q >= DS - j) { q -= DS - j; ++j; } const int i = j + q;   // unpack (i >= j)
+            if (direct) { double* dg = A + t.data_off + ri.diag_off; atomicAdd(&dg[i + DS * j], v); if (i != j) atomicAdd(&dg[j + DS * i], v); }
+            else { img[ri.diag_off + i + DS * j] = v; if (i != j) img[ri.diag_off + j + DS * i] = v; }   // only registers feed the diagonal block
+        }
+    }
+    __syncthreads();
+    if (direct) return;
+    if (t.flags & TILE_PARTIAL) {
+        for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) { double v = img[i]; if (v != 0.0) atomicAdd(&A[t.data_off + i], v); }
+    } else {
+        double* dst = A + t.data_off;
+        for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) dst[i] = img[i];
+    }
+}
+
+// ================================================================================================
+// accumulate: dense linear system (MultiVariateLSdense, src/linearsystem.jl:73-87; BlockDenseMatrix.jl)
+// ================================================================================================
+template <int KIND>
+__global__ __launch_bounds__(TPB) void gh_dense_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
+                                                       const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ ebrow,
+                                                       int64_t n, RobustSpec rk, int ndof, int use_lds,
+                                                       double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    extern __shared__ __attribute__((aligned(16))) double img[];
+    __shared__ double red[TPB / 64];
+    const int imglen = use_lds ? ndof * ndof + ndof : 0;
+    for (int i = threadIdx.x; i < imglen; i += TPB) img[i] = 0.0;
+    __syncthreads();
+    double* HA = use_lds ? img : A;
+    double* Hb = use_lds ? img + ndof * ndof : b;
+    double mycost = 0;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        double d[R::NDATA]; uint32_t vo[R::NDEPS], br[R::NDEPS];
+#pragma unroll
+        for (int q = 0; q < R::NDATA; ++q) d[q] = edata[(size_t)e * R::NDATA + q];
+#pragma unroll
+        for (int q = 0; q < R::NDEPS; ++q) { vo[q] = evoff[(size_t)e * R::NDEPS + q]; br[q] = ebrow[(size_t)e * R::NDEPS + q]; }
+        bool kfree = false; if constexpr (R::ADAPT) kfree = br[0] != DEST_NONE;
+        BlockGH<KIND> B; B.compute(vars, vo, d, rk, kfree);
+        mycost += B.cost;
+        static_for<R::NDEPS>([&](auto Sc) {
+            constexpr int S = decltype(Sc)::value; constexpr int DS = I::dof(S);
+            if (br[S] != DEST_NONE) {
+#pragma unroll
+                for (int i = 0; i < DS; ++i) atomicAdd(&Hb[br[S] + i], g_elem<KIND, S>(B, i));
+#pragma unroll
+                for (int j = 0; j < DS; ++j)
+#pragma unroll
+                    for (int i = 0; i < DS; ++i) atomicAdd(&HA[(br[S] + i) + (size_t)ndof * (br[S] + j)], h_elem<KIND, S, S>(B, i, j));
+                static_for<S>([&](auto Tc) {   // j < i in slot order; stored in the block-lower triangle (linearsystem.jl:148-152)
+                    constexpr int T = decltype(Tc)::value; constexpr int DT = I::dof(T);
+                    if (br[T] != DEST_NONE) {
+#pragma unroll
+                        for (int j = 0; j < DT; ++j)
+#pragma unroll
+                            for (int i = 0; i < DS; ++i) {
+                                const double v = h_elem<KIND, S, T>(B, i, j);
+                                if (br[S] >= br[T]) atomicAdd(&HA[(br[S] + i) + (size_t)ndof * (br[T] + j)], v);
+                                else atomicAdd(&HA[(br[T] + j) + (size_t)ndof * (br[S] + i)], v);
+                            }
+                    }
+                });
+            }
+        });
+    }
+    double tc = block_sum(mycost, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tc;
+    __syncthreads();
+    if (use_lds) {
+        for (int i = threadIdx.x; i < ndof * ndof; i += TPB) { double v = img[i]; if (v != 0.0) atomicAdd(&A[i], v); }
+        for (int i = threadIdx.x; i < ndof; i += TPB) { double v = img[ndof * ndof + i]; if (v != 0.0) atomicAdd(&b[i], v); }
+    }
+}
+// gethessian(::MultiVariateLSdense) = symmetrifyfull: mirror the lower triangle  BlockDenseMatrix.jl:24-34
+__global__ void symmetrize_dense_kernel(double* __restrict__ A, int n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * n) return;
+    const int r = (int)(i % n), c = (int)(i / n);
+    if (r > c) A[c + (size_t)n * r] = A[i];
+}
+
+__global__ void zero_ranges_kernel(double* __restrict__ A, const int64_t* __restrict__ off, const uint32_t* __restrict__ len,
+                                   double* __restrict__ b, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ blen) {
+    const int64_t o = off[blockIdx.x]; const uint32_t l = len[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < l; i += blockDim.x) A[o + i] = 0.0;
+    const uint32_t bo = boff[blockIdx.x], bl = blen[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < bl; i += blockDim.x) b[bo + i] = 0.0;
+}
+
+// ================================================================================================
+// vector helpers
+// ================================================================================================
+// update!(to, from, linsystem)   src/linearsystem.jl:206-213
+__global__ void retract_kernel(const int32_t* __restrict__ kind, const int32_t* __restrict__ dim, const uint32_t* __restrict__ voff,
+                               const uint32_t* __restrict__ vboff, int64_t nvar, const double* __restrict__ from,
+                               const double* __restrict__ x, double* __restrict__ to) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvar) return;
+    const int k = kind[i], d = dim[i]; const uint32_t o = voff[i], bo = vboff[i];
+    if (bo == DEST_NONE) { const int st = var_storage(k, d); for (int q = 0; q < st; ++q) to[o + q] = from[o + q]; return; }
+    double in[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], out[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], st[NLLS_MAX_BLOCK_SZ];
+    const int ns = var_storage(k, d), nd = var_dof(k, d);
+    for (int q = 0; q < ns; ++q) in[q] = from[o + q];
+    for (int q = 0; q < nd; ++q) st[q] = x[bo + q];
+    var_update_real(k, d, in, st, out);
+    for (int q = 0; q < ns; ++q) to[o + q] = out[q];
+}
+// maximum(abs, x) and x'x   (src/optimize.jl:149, src/iterators.jl:160; NaN propagates like Julia's maximum)
+__global__ __launch_bounds__(TPB) void step_stats_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+    __shared__ double red[TPB / 64];
+    double m = 0, s = 0; bool nan = false;
+    for (int64_t i = threadIdx.x; i < n; i += TPB) { double v = x[i]; nan |= (v != v); m = fmax(m, fabs(v)); s += v * v; }
+    double mm = block_max(m, red);
+    double ss = block_sum(s, red);
+    double nn = block_max(nan ? 1.0 : 0.0, red);
+    if (threadIdx.x == 0) { out[1] = nn > 0 ? NAN : mm; out[2] = ss; }
+}
+// initlambda's max |H_ii|   src/iterators.jl:131-137
+__global__ __launch_bounds__(TPB) void max_abs_diag_kernel(const double* __restrict__ A, const int64_t* __restrict__ diag_off,
+                                                           const int32_t* __restrict__ bs, int64_t nb, int64_t ld_dense, double* __restrict__ out) {
+    __shared__ double red[TPB / 64];
+    double m = 0;
+    for (int64_t k = threadIdx.x; k < nb; k += TPB) {
+        const int n = bs[k]; const int64_t o = diag_off[k]; const int64_t ld = ld_dense ? ld_dense : n;
+        for (int i = 0; i < n; ++i) m = fmax(m, fabs(A[o + i + ld * i]));
+    }
+    double mm = block_max(m, red);
+    if (threadIdx.x == 0) out[3] = mm;
+}
+
+// ================================================================================================
+// host-side enqueue
+// ================================================================================================
+static int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(what) + ": " + hipGetErrorString(e); return NLLS_ERR_HIP; }
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return herr(c, e_, #expr); } while (0)
+
+template <int KIND>
+static int launch_cost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if (G.ncost > 0) {
+        int grid = (int)std::min<int64_t>((G.ncost + TPB - 1) / TPB, 2048);
+        hipLaunchKernelGGL(cost_kernel<KIND>, dim3(grid), dim3(TPB), 0, c->stream, vars, G.data.p, G.voff.p, (const uint32_t*)nullptr, G.ncost, G.rk, c->partials.p + pbase);
+        pbase += grid;
+    }
+    return NLLS_OK;
+}
+template <int KIND>
+static int launch_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if (G.nfixedcost > 0) {
+        int grid = (int)std::min<int64_t>((G.nfixedcost + TPB - 1) / TPB, 2048);
+        hipLaunchKernelGGL(cost_kernel<KIND>, dim3(grid), dim3(TPB), 0, c->stream, vars, G.data.p, G.voff.p, G.fixedcost.p, G.nfixedcost, G.rk, c->partials.p + pbase);
+        pbase += grid;
+    }
+    return NLLS_OK;
+}
+template <int KIND, int SLOT>
+static void launch_gh_slot(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if constexpr (SLOT < Res<KIND>::NDEPS) {
+        const EntryList& E = G.lists[SLOT];
+        if (E.nlight > 0) {
+            hipLaunchKernelGGL((gh_light_kernel<KIND, SLOT>), dim3((unsigned)E.nlight), dim3(TPB), E.light_lds * sizeof(double), c->stream,
+                               vars, E.data.p, E.voff.p, E.dest.p, E.rows.p, E.light.p, G.rk, c->A.p, c->b.p, c->partials.p + pbase);
+            pbase += E.nlight;
+        }
+        if (E.nheavy > 0) {
+            hipLaunchKernelGGL((gh_heavy_kernel<KIND, SLOT>), dim3((unsigned)E.nheavy), dim3(TPB), E.heavy_lds * sizeof(double), c->stream,
+                               vars, E.data.p, E.voff.p, E.dest.p, E.rows.p, E.heavy.p, G.rk, c->A.p, c->b.p, c->partials.p + pbase);
+            pbase += E.nheavy;
+        }
+    }
+}
+template <int KIND>
+static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if (c->info.is_sparse) {
+        launch_gh_slot<KIND, 0>(c, G, vars, pbase); launch_gh_slot<KIND, 1>(c, G, vars, pbase);
+        launch_gh_slot<KIND, 2>(c, G, vars, pbase); launch_gh_slot<KIND, 3>(c, G, vars, pbase);
+    } else if (G.dense.n > 0) {
+        const int ndof = (int)c->info.ndof; const int use_lds = ndof <= 64;
+        int grid = (int)std::min<int64_t>((G.dense.n + TPB - 1) / TPB, 1024);
+        hipLaunchKernelGGL(gh_dense_kernel<KIND>, dim3(grid), dim3(TPB), use_lds ? (size_t)(ndof * ndof + ndof) * sizeof(double) : 0, c->stream,
+                           vars, G.dense.data.p, G.dense.voff.p, G.dense.brow.p, G.dense.n, G.rk, ndof, use_lds, c->A.p, c->b.p, c->partials.p + pbase);
+        pbase += grid;
+    }
+    return launch_fixedcost<KIND>(c, G, vars, pbase);
+}
+
+int enqueue_sweep_cost(nlls_ctx* c, int which) {
+    const double* vars = vars_ptr(c, which); int64_t pbase = 0;
+    for (const Group& G : c->groups) {
+        switch (G.res_kind) {
+#define X(K) case K: launch_cost<K>(c, G, vars, pbase); break;
+            NLLS_FOR_EACH_RES(X)
+#undef X
+        }
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, pbase, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+int enqueue_sweep_gradhess(nlls_ctx* c) {
+    const double* vars = vars_ptr(c, NLLS_VARS_CURRENT); int64_t pbase = 0;
+    if (!c->info.is_sparse) {
+        HIPCHK(hipMemsetAsync(c->A.p, 0, sizeof(double) * std::max<int64_t>(c->info.nnz_data, 1), c->stream));
+        HIPCHK(hipMemsetAsync(c->b.p, 0, sizeof(double) * std::max<int64_t>(c->info.ndof, 1), c->stream));
+    } else if (c->nzero > 0) {
+        hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)c->nzero), dim3(64), 0, c->stream, c->A.p, c->d_zero_off.p, c->d_zero_len.p, c->b.p, c->d_zero_b_off.p, c->d_zero_b_len.p);
+    }
+    for (const Group& G : c->groups) {
+        switch (G.res_kind) {
+#define X(K) case K: launch_gh<K>(c, G, vars, pbase); break;
+            NLLS_FOR_EACH_RES(X)
+#undef X
+        }
+    }
+    if (!c->info.is_sparse && c->info.ndof > 0) {
+        const int64_t n2 = c->info.ndof * c->info.ndof;
+        hipLaunchKernelGGL(symmetrize_dense_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->A.p, (int)c->info.ndof);
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, pbase, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+int enqueue_retract(nlls_ctx* c, int to, int from) {
+    const int64_t nvar = c->info.nvar; if (nvar == 0) return NLLS_OK;
+    hipLaunchKernelGGL(retract_kernel, dim3((unsigned)((nvar + 255) / 256)), dim3(256), 0, c->stream, c->d_var_kind.p, c->d_var_dim.p, c->d_var_off.p,
+                       c->d_var_boff.p, nvar, vars_ptr(c, from), c->x.p, vars_ptr(c, to));
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+int enqueue_step_stats(nlls_ctx* c) {
+    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(TPB), 0, c->stream, c->x.p, c->info.ndof, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+int enqueue_max_abs_diag(nlls_ctx* c) {
+    hipLaunchKernelGGL(max_abs_diag_kernel, dim3(1), dim3(TPB), 0, c->stream, c->A.p, c->d_diag_off.p, c->d_blocksizes.p, c->info.nblocks,
+                       c->info.is_sparse ? (int64_t)0 : c->info.ndof, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+}  // namespace nlls

@@ -1,0 +1,152 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the
+same seeded inputs.  Tolerances (fp64): the GPU sums in a different order than the sequential reference
+(SURVEY.md "fp64 reduction order"), so values agree to ~1e-12 relative, not bit for bit; index arrays
+(the BlockSparseMatrix layout) must agree exactly."""
+import numpy as np
+import pytest
+
+import nllssolver_jl_amd as N
+from nllssolver_jl_amd import kinds as K
+from nllssolver_jl_amd import synthetic, _capi
+from nllssolver_jl_amd.variables import contaminated_gaussian
+from oracle import oracle as O
+from tests.helpers import oracle_problem, blockindices
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-11      # accumulate / cost sweeps
+RTOL_X = 1e-7     # solve: conditioning of the damped normal equations enters
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def check_problem(problem, unfixed=None, flags=0, lam_scale=1e-6, expect_sparse=None, expect_schur=None):
+    bi = blockindices(problem, unfixed)
+    op = oracle_problem(problem)
+    ols = op.linear_system(bi, flags & _capi.FLAG_FORCE_SPARSE)
+    ctx = _capi.Context()
+    info = ctx.upload(problem.var_kind, problem.var_dim, bi, problem.groups(), flags)
+    # ---- structure: exact
+    assert info.is_sparse == ols.info.is_sparse and info.ndof == ols.info.ndof and info.nnz_data == ols.info.nnz_data
+    if expect_sparse is not None:
+        assert info.is_sparse == expect_sparse
+    if expect_schur is not None:
+        assert info.has_schur == expect_schur
+    if info.is_sparse:
+        for g, o in zip(ctx.bsm_index(), ols.bsm_index()):
+            assert np.array_equal(g, o)
+    # ---- sweeps
+    ctx.set_variables(problem.variables)
+    c_gpu = ctx.sweep_gradhess()
+    c_ora = ols.costgradhess()
+    assert np.isclose(c_gpu, c_ora, rtol=RTOL, atol=1e-300)
+    A_gpu, b_gpu = ctx.get_bsm_data(), ctx.get_grad()
+    A_ora = ols.data.copy()
+    if not info.is_sparse:   # the device mirrors the lower triangle at the end of the sweep (gethessian)
+        n = info.ndof; M = A_ora.reshape(n, n).T; M = np.tril(M) + np.tril(M, -1).T; A_ora = M.T.ravel()
+    assert rel(A_gpu, A_ora) < RTOL, "A.data mismatch"
+    assert rel(b_gpu, ols.b) < RTOL, "b mismatch"
+    assert np.isclose(ctx.sweep_cost(), op.cost(), rtol=RTOL, atol=1e-300)
+    assert ctx.sweep_cost() == ctx.sweep_cost()                      # run-to-run deterministic (fixed reduction tree)
+    assert np.isclose(ctx.max_abs_diag(), ols.max_abs_diag(), rtol=1e-13)
+    # ---- damped solve, quadratic form, retraction
+    lam = ols.max_abs_diag() * lam_scale
+    ctx.damp(lam)
+    x_gpu = ctx.solve(want_x=True)
+    assert ols.solve(lam) == 0
+    assert rel(x_gpu, ols.x) < RTOL_X, f"x mismatch {rel(x_gpu, ols.x)}"
+    xHx, gx = ctx.quadform()
+    assert np.isclose(xHx, ols.quadform(x_gpu, lam), rtol=1e-9)
+    assert np.isclose(gx, float(ols.b @ x_gpu), rtol=1e-9)
+    assert np.isclose(ctx.step_maxabs(), np.max(np.abs(x_gpu)), rtol=1e-14)
+    assert np.isclose(ctx.step_norm(), np.linalg.norm(x_gpu), rtol=1e-12)
+    ctx.retract(_capi.VARS_NEXT, _capi.VARS_CURRENT)
+    op.set_variables(problem.variables, O.VARS_NEXT)     # varnext starts as a deepcopy (src/optimize.jl:80-82)
+    op.update(ols, O.VARS_NEXT, O.VARS_CURRENT, step=x_gpu)
+    v_gpu, v_ora = ctx.get_variables(_capi.VARS_NEXT), op.get_variables(O.VARS_NEXT)
+    assert rel(v_gpu, v_ora) < 1e-13
+    ctx.close()
+    return info
+
+
+def test_ba_sparse_small():          # test/optimizeba.jl:71 shape (10 x 50 @ 0.3 -> sparse path)
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 50, 0.3, seed=1), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.ndof == 210 and info.owner_path == 1
+
+
+def test_ba_dense_small():           # test/optimizeba.jl:51 shape (3 x 5 -> 33 dof -> dense path)
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(3, 5, 1.0, seed=1), 1e-3, 1e-3)
+    check_problem(p, expect_sparse=0, expect_schur=0)
+
+
+def test_ba_heavy_camera_rows():     # cameras with > 128 observations take the register-accumulate path
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(40, 3000, 0.12, seed=3), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.nreduced_dof == 240
+
+
+def test_ba_blocked_cholesky():      # reduced system larger than one 64-wide panel -> MFMA trailing updates
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(60, 1500, 0.1, seed=4), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.nreduced_dof == 360
+
+
+def test_ba_force_atomic_and_no_schur():
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(12, 80, 0.3, seed=5), 1e-3, 1e-3)
+    info = check_problem(p, flags=_capi.FLAG_FORCE_ATOMIC)
+    assert info.owner_path == 0
+    info = check_problem(p, flags=_capi.FLAG_NO_SCHUR, expect_schur=0)
+    assert info.nreduced_dof == info.ndof
+
+
+def test_ba_fixed_variables():       # varflags path: some cameras and points fixed (src/cost.jl:27-52)
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 60, 0.4, seed=6), 1e-3, 1e-3)
+    unfixed = np.ones(p.nvariables, bool); unfixed[[0, 3, 15, 16, 40]] = False
+    check_problem(p, unfixed=unfixed, expect_sparse=1)
+
+
+def test_ba_huber():                 # BASELINE config 4 robustifier
+    p = synthetic.create_ba_problem(10, 60, 0.4, seed=7, robust=N.HuberKernel(0.01), outlier_frac=0.2, outlier_sigma=0.1)
+    p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
+    check_problem(p, expect_sparse=1)
+    p2 = synthetic.create_ba_problem(10, 60, 0.4, seed=7, robust=N.Scaled(N.Huber2oKernel(0.01), 2.0), outlier_frac=0.2, outlier_sigma=0.1)
+    check_problem(synthetic.perturb_ba_problem(p2, 1e-3, 1e-3), lam_scale=1e-2)
+    p3 = synthetic.create_ba_problem(10, 60, 0.4, seed=7, robust=N.GemanMcclureKernel(0.05), outlier_frac=0.2, outlier_sigma=0.1)
+    check_problem(synthetic.perturb_ba_problem(p3, 1e-3, 1e-3), lam_scale=1e-1)
+
+
+def test_rosenbrock_and_curvefit():  # dense 2-dof and 4-dof systems (BASELINE configs 1-2)
+    p = N.NLLSProblem(); p.addvariable(-0.5); p.addvariable(2.5)
+    p.addcosts(K.RES_ROSENBROCK_A, [[1]], [[1.0]], N.Scaled(N.Huber2oKernel(1.6), 1.0))
+    p.addcosts(K.RES_ROSENBROCK_B, [[1, 2]], [[10.0]])
+    check_problem(p, expect_sparse=0, lam_scale=1e-3)
+    q = N.NLLSProblem(); q.addvariable([-0.5, 2.5]); q.addcosts(K.RES_ROSENBROCK_2D, [[1]], [[1.0, 10.0]])
+    check_problem(q, expect_sparse=0, lam_scale=1e-3)
+    c, _ = synthetic.create_curvefit_problem(10_000, seed=1)
+    check_problem(c, expect_sparse=0)
+
+
+def test_adaptive_mean():            # test/adaptivecost.jl shape: kernel variable + two means
+    rng = np.random.default_rng(1)
+    pts = np.concatenate([rng.standard_normal(800), rng.standard_normal(200) * 10.0])
+    p = N.NLLSProblem()
+    p.addvariable(contaminated_gaussian(0.5, 5.0, 0.6), K.VAR_CONTAMINATED_GAUSSIAN); p.addvariable(0.0); p.addvariable(0.0)
+    vi = np.empty((2000, 2), np.int64); da = np.empty((2000, 1))
+    vi[:, 0] = 1; vi[0::2, 1] = 2; vi[1::2, 1] = 3; da[0::2, 0] = pts - 1; da[1::2, 0] = pts + 1
+    p.addcosts(K.RES_ADAPTIVE_MEAN, vi, da)
+    check_problem(p, expect_sparse=0, lam_scale=1e-3)
+    check_problem(p, unfixed=[False, True, True], lam_scale=1e-3)     # kernel fixed: robustifydcost path
+    check_problem(p, unfixed=[True, False, True], lam_scale=1e-3)
+
+
+def test_so3_ba():                   # BASELINE config 5 shapes (new kinds)
+    p = synthetic.create_so3_ba_problem(8, 60, 0.5, seed=2, adaptive=False, robust=N.HuberKernel(0.05))
+    check_problem(synthetic.perturb_ba_problem(p, 1e-3, 1e-3), expect_sparse=1, lam_scale=1e-4)
+    q = synthetic.create_so3_ba_problem(8, 60, 0.5, seed=2, adaptive=True)
+    check_problem(synthetic.perturb_ba_problem(q, 1e-3, 1e-3), expect_sparse=1, lam_scale=1e-4)
+    unfixed = np.ones(q.nvariables, bool); unfixed[0] = False        # adaptive kernel held fixed
+    check_problem(q, unfixed=unfixed, expect_sparse=1, lam_scale=1e-4)
