@@ -16,10 +16,12 @@ __all__ = ["kinds", "NLLSProblem", "NoRobust", "HuberKernel", "Huber2oKernel", "
 
 def __getattr__(name):
     # lazily expose the device-backed API so that host-only use (tests -m "not gpu") needs no .so
-    if name in ("optimize", "NLLSOptions", "NLLSResult", "cost", "optimizesingles"):
-        from . import optimize as _o
-        return getattr(_o, name)
+    import importlib
+    if name in ("optimize", "NLLSOptions", "NLLSResult", "cost", "NLLSIterator", "newton", "levenbergmarquardt", "dogleg",
+                "gradientdescent"):
+        return getattr(importlib.import_module(__name__ + ".optimizer"), name)
     if name in ("MultiVariateLSgpu", "makesymmvls"):
-        from . import linearsystem as _l
-        return getattr(_l, name)
+        return getattr(importlib.import_module(__name__ + ".linearsystem"), name)
+    if name in ("nullcallback", "printoutcallback", "storecostscallback", "CostTrajectory"):
+        return getattr(importlib.import_module(__name__ + ".callbacks"), name)
     raise AttributeError(name)

@@ -8,7 +8,7 @@
 // (SURVEY F1).  This path is new: an independent set of blocks (bundle adjustment: the points) is
 // eliminated block-wise (C_v^-1 by a small Cholesky in LDS), the reduced system
 //   S = B + lambda*I - sum_v E_v' C_v^-1 E_v ,   s = b_R - sum_v E_v' C_v^-1 b_v
-// is assembled densely and factored by a blocked right-looking Cholesky whose trailing update runs on
+// is assembled densely and factored by a blocked right-looking LDL' whose trailing update runs on
 // the fp64 matrix cores (v_mfma_f64_16x16x4_f64); the eliminated blocks are recovered by
 // back-substitution.  Parity contract: x solves (H + lambda*I) x = -b, unique for SPD systems.
 #include <utility>
@@ -90,22 +90,24 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
     }
     for (int a = lane; a < dv; a += 64) Y[a + dv * nd] = b[eboff[v] + a];
     __syncthreads();
-    // Cholesky of C in place (lower), lane-serial: dv <= 32
+    // LDL' of C in place (unit lower L below the diagonal, D on it), lane-serial: dv <= 32.  No positivity is
+    // required (the reference's LDLFactorizations has none either); only an exactly zero pivot fails.
     if (lane == 0) {
         for (int j = 0; j < dv; ++j) {
             double d = C[j + dv * j];
-            for (int k = 0; k < j; ++k) d -= C[j + dv * k] * C[j + dv * k];
-            if (!(d > 0)) { atomicCAS(status, 0, 1); d = 1.0; }
-            d = sqrt(d); C[j + dv * j] = d;
-            for (int i = j + 1; i < dv; ++i) { double t = C[i + dv * j]; for (int k = 0; k < j; ++k) t -= C[i + dv * k] * C[j + dv * k]; C[i + dv * j] = t / d; }
+            for (int k = 0; k < j; ++k) d -= C[j + dv * k] * C[j + dv * k] * C[k + dv * k];
+            if (d == 0.0 || d != d) { atomicCAS(status, 0, 1); d = 1.0; }
+            C[j + dv * j] = d;
+            for (int i = j + 1; i < dv; ++i) { double t = C[i + dv * j]; for (int k = 0; k < j; ++k) t -= C[i + dv * k] * C[j + dv * k] * C[k + dv * k]; C[i + dv * j] = t / d; }
         }
     }
     __syncthreads();
     // Y(:, c) = C^-1 [E | b](:, c): one column per lane
     for (int c2 = lane; c2 <= nd; c2 += 64) {
         double y[NLLS_MAX_BLOCK_SZ];
-        for (int i = 0; i < dv; ++i) { double t = (c2 < nd) ? E[i + dv * c2] : Y[i + dv * nd]; for (int k = 0; k < i; ++k) t -= C[i + dv * k] * y[k]; y[i] = t / C[i + dv * i]; }
-        for (int i = dv - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < dv; ++k) t -= C[k + dv * i] * y[k]; y[i] = t / C[i + dv * i]; }
+        for (int i = 0; i < dv; ++i) { double t = (c2 < nd) ? E[i + dv * c2] : Y[i + dv * nd]; for (int k = 0; k < i; ++k) t -= C[i + dv * k] * y[k]; y[i] = t; }
+        for (int i = 0; i < dv; ++i) y[i] /= C[i + dv * i];
+        for (int i = dv - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < dv; ++k) t -= C[k + dv * i] * y[k]; y[i] = t; }
         for (int i = 0; i < dv; ++i) Y[i + dv * c2] = y[i];
     }
     __syncthreads();
@@ -147,12 +149,14 @@ __global__ __launch_bounds__(64) void schur_backsub_kernel(const double* __restr
     __syncthreads();
     if (lane == 0) {
         for (int j = 0; j < dv; ++j) {
-            double d = C[j + dv * j]; for (int k = 0; k < j; ++k) d -= C[j + dv * k] * C[j + dv * k];
-            d = sqrt(d > 0 ? d : 1.0); C[j + dv * j] = d;
-            for (int i = j + 1; i < dv; ++i) { double t = C[i + dv * j]; for (int k = 0; k < j; ++k) t -= C[i + dv * k] * C[j + dv * k]; C[i + dv * j] = t / d; }
+            double d = C[j + dv * j]; for (int k = 0; k < j; ++k) d -= C[j + dv * k] * C[j + dv * k] * C[k + dv * k];
+            if (d == 0.0 || d != d) d = 1.0;
+            C[j + dv * j] = d;
+            for (int i = j + 1; i < dv; ++i) { double t = C[i + dv * j]; for (int k = 0; k < j; ++k) t -= C[i + dv * k] * C[j + dv * k] * C[k + dv * k]; C[i + dv * j] = t / d; }
         }
-        for (int i = 0; i < dv; ++i) { double t = rhs[i]; for (int k = 0; k < i; ++k) t -= C[i + dv * k] * rhs[k]; rhs[i] = t / C[i + dv * i]; }
-        for (int i = dv - 1; i >= 0; --i) { double t = rhs[i]; for (int k = i + 1; k < dv; ++k) t -= C[k + dv * i] * rhs[k]; rhs[i] = t / C[i + dv * i]; }
+        for (int i = 0; i < dv; ++i) { double t = rhs[i]; for (int k = 0; k < i; ++k) t -= C[i + dv * k] * rhs[k]; rhs[i] = t; }
+        for (int i = 0; i < dv; ++i) rhs[i] /= C[i + dv * i];
+        for (int i = dv - 1; i >= 0; --i) { double t = rhs[i]; for (int k = i + 1; k < dv; ++k) t -= C[k + dv * i] * rhs[k]; rhs[i] = t; }
         for (int i = 0; i < dv; ++i) x[eboff[v] + i] = -rhs[i];
     }
 }
@@ -222,8 +226,10 @@ __global__ __launch_bounds__(64) void small_solve_kernel(const double* __restric
 // ---------------------------------------------------------------------------------------------------
 // blocked Cholesky of the (bordered) reduced system: S col-major, ld = npad, lower triangle
 // ---------------------------------------------------------------------------------------------------
-// diagonal block: unblocked right-looking factorisation in LDS, 256 threads
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ S, int npad, int k, int* __restrict__ status) {
+// diagonal block: unblocked right-looking LDL' in LDS, 256 threads.  On exit the block holds the unit-lower
+// L below the diagonal and D on it.  (LDL' rather than LL': the damped reduced system of a gauge-free
+// bundle adjustment is only barely definite; like the reference's LDLFactorizations, no pivot sign is required.)
+__global__ __launch_bounds__(256) void ldlt_diag_kernel(double* __restrict__ S, int npad, int k, int* __restrict__ status) {
     __shared__ double M[NB * (NB + 1)];
     double* D = S + (size_t)k * NB + (size_t)npad * k * NB;
     const int t = threadIdx.x;
@@ -231,27 +237,28 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ S,
     __syncthreads();
     for (int j = 0; j < NB; ++j) {
         double d = M[j + (NB + 1) * j];
-        if (!(d > 0)) { if (t == 0) atomicCAS(status, 0, 1 + k * NB + j); d = 1.0; }
-        const double sd = sqrt(d);
-        __syncthreads();
-        if (t == 0) M[j + (NB + 1) * j] = sd;
-        if (t > j && t < NB) M[t + (NB + 1) * j] /= sd;
-        __syncthreads();
-        // trailing update: element (i, c), j < c <= i < NB
+        if (d == 0.0 || d != d) { if (t == 0) atomicCAS(status, 0, 1 + k * NB + j); d = 1.0; }
+        const double id = 1.0 / d;
+        // trailing update with the un-scaled column u: M(i,c) -= u_i * u_c / d, j < c <= i
         const int m = NB - 1 - j;
-        for (int e = t; e < m * m; e += 256) { const int i = j + 1 + e % m, c2 = j + 1 + e / m; if (i >= c2) M[i + (NB + 1) * c2] -= M[i + (NB + 1) * j] * M[c2 + (NB + 1) * j]; }
+        for (int e = t; e < m * m; e += 256) { const int i = j + 1 + e % m, c2 = j + 1 + e / m; if (i >= c2) M[i + (NB + 1) * c2] -= M[i + (NB + 1) * j] * M[c2 + (NB + 1) * j] * id; }
+        __syncthreads();
+        if (t > j && t < NB) M[t + (NB + 1) * j] *= id;
+        if (t == 0) M[j + (NB + 1) * j] = d;
         __syncthreads();
     }
     for (int e = t; e < NB * NB; e += 256) { const int i = e % NB, j = e / NB; if (i >= j) D[(size_t)i + (size_t)npad * j] = M[i + (NB + 1) * j]; }
 }
-// panel: X = A_ik * L_kk^-T for each 64-row block i > k; one workgroup (64 threads, thread = row) per block
-__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ S, int npad, int k) {
+// panel: W = A_ik * L_kk^-T (unit diagonal) and L_ik = W * D_k^-1 for each 64-row block i > k; one workgroup
+// (64 threads, thread = row) per block.  L goes back into S, W (= L*D) into the panel workspace for the update.
+__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ S, double* __restrict__ W, int npad, int k) {
     __shared__ double L[NB * (NB + 1)];
     const double* D = S + (size_t)k * NB + (size_t)npad * k * NB;
     const int t = threadIdx.x; const int ib = k + 1 + blockIdx.x;
     for (int e = t; e < NB * NB; e += 64) { const int i = e % NB, j = e / NB; L[i + (NB + 1) * j] = D[(size_t)i + (size_t)npad * j]; }
     __syncthreads();
     double* P = S + (size_t)ib * NB + t + (size_t)npad * k * NB;   // row t of the block, stride npad between columns
+    double* Wr = W + (size_t)ib * NB + t;
     double xr[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) xr[j] = P[(size_t)npad * j];
@@ -260,14 +267,14 @@ __global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ S, 
         double v = xr[j];
 #pragma unroll
         for (int l = 0; l < j; ++l) v -= xr[l] * L[j + (NB + 1) * l];
-        xr[j] = v / L[j + (NB + 1) * j];
+        xr[j] = v;
     }
 #pragma unroll
-    for (int j = 0; j < NB; ++j) P[(size_t)npad * j] = xr[j];
+    for (int j = 0; j < NB; ++j) { Wr[(size_t)npad * j] = xr[j]; P[(size_t)npad * j] = xr[j] / L[j + (NB + 1) * j]; }
 }
-// trailing update on the matrix cores: C_ij -= P_i * P_j' for all k < j <= i; one 64x64 tile per workgroup,
+// trailing update on the matrix cores: C_ij -= W_i * L_j' (W = L*D) for all k < j <= i; one 64x64 tile per workgroup,
 // 4 waves x (2x2) v_mfma_f64_16x16x4_f64 accumulators.
-__global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ S, int npad, int k, int nblk) {
+__global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ S, const double* __restrict__ W, int npad, int k, int nblk) {
     __shared__ double Pi[NB * LDT];   // Pi[r + LDT*kk]
     __shared__ double Pj[NB * LDT];
     const int T = nblk - k - 1;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ S
     const int tj = tix - ti * (ti + 1) / 2;
     (void)T;
     const int ib = k + 1 + ti, jb = k + 1 + tj;
-    const double* Gi = S + (size_t)ib * NB + (size_t)npad * k * NB;
+    const double* Gi = W + (size_t)ib * NB;                       // W = L*D rows of block i
     const double* Gj = S + (size_t)jb * NB + (size_t)npad * k * NB;
     const int t = threadIdx.x;
     for (int e = t; e < NB * NB; e += 256) { const int r = e % NB, c2 = e / NB; Pi[r + LDT * c2] = Gi[(size_t)r + (size_t)npad * c2]; Pj[r + LDT * c2] = Gj[(size_t)r + (size_t)npad * c2]; }
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ S
                 Cg[(size_t)row + (size_t)npad * col] -= acc[a][b2][r];
             }
 }
-// backward substitution L' x = y, block by block from the bottom.  y is row n of the factor.
+// backward substitution L' x = z (unit diagonal), block by block from the bottom.  z = D^-1 L^-1 s is row n of the factor.
 // step 1 (one workgroup per 64-column block kb, many row blocks): partial[kb][j] = sum_{i > kb block} L[i][kb*64+j] * x[i]
 __global__ __launch_bounds__(256) void bwd_gemv_kernel(const double* __restrict__ S, int npad, int kb, int n, const double* __restrict__ x, double* __restrict__ acc) {
     // grid.x = number of row blocks below kb; each adds its 64-vector contribution atomically
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(64) void bwd_diag_kernel(const double* __restrict__
     const int g = kb * NB + t;
     r[t] = (g < n) ? S[(size_t)n + (size_t)npad * g] - acc[g] : 0.0;   // y lives in row n of the factor
     __syncthreads();
-    if (t == 0) for (int i = NB - 1; i >= 0; --i) { if (kb * NB + i >= n) { r[i] = 0; continue; } double v = r[i]; for (int l = i + 1; l < NB && kb * NB + l < n; ++l) v -= L[l + (NB + 1) * i] * r[l]; r[i] = v / L[i + (NB + 1) * i]; }
+    if (t == 0) for (int i = NB - 1; i >= 0; --i) { if (kb * NB + i >= n) { r[i] = 0; continue; } double v = r[i]; for (int l = i + 1; l < NB && kb * NB + l < n; ++l) v -= L[l + (NB + 1) * i] * r[l]; r[i] = v; }
     __syncthreads();
     if (g < n) x[g] = r[t];
 }
@@ -423,20 +430,21 @@ int enqueue_solve(nlls_ctx* c) {
     } else {
         hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S.p, c->s.p, n, npad);
         for (int k = 0; k < nblk; ++k) {
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, c->stream, c->S.p, npad, k, c->d_status.p);
+            hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(256), 0, c->stream, c->S.p, npad, k, c->d_status.p);
             const int T = nblk - k - 1;
             if (T > 0) {
-                hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(64), 0, c->stream, c->S.p, npad, k);
-                hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, npad, k, nblk);
+                hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(64), 0, c->stream, c->S.p, c->Lwork.p, npad, k);
+                hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, c->Lwork.p, npad, k, nblk);
             }
         }
         // backward substitution into Lwork (acc) / s (x)
-        HIPCHK(hipMemsetAsync(c->Lwork.p, 0, sizeof(double) * npad, c->stream));
+        double* acc = c->Lwork.p + (size_t)npad * NB;
+        HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * npad, c->stream));
         const int nb_real = (n + NB - 1) / NB;
         for (int kb = nb_real - 1; kb >= 0; --kb) {
             const int below = nb_real - 1 - kb;
-            if (below > 0) hipLaunchKernelGGL(bwd_gemv_kernel, dim3(below), dim3(256), 0, c->stream, c->S.p, npad, kb, n, c->s.p, c->Lwork.p);
-            hipLaunchKernelGGL(bwd_diag_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, npad, kb, n, c->Lwork.p, c->s.p);
+            if (below > 0) hipLaunchKernelGGL(bwd_gemv_kernel, dim3(below), dim3(256), 0, c->stream, c->S.p, npad, kb, n, c->s.p, acc);
+            hipLaunchKernelGGL(bwd_diag_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, npad, kb, n, acc, c->s.p);
         }
     }
     // x = -solution

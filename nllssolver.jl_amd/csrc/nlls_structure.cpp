@@ -365,7 +365,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     if (hipSuccess != c->d_copy.upload(copies) || hipSuccess != c->d_red_boff.upload(red_boff)) return fail(c, NLLS_ERR_HIP, "schur upload");
     const int64_t n = c->nred; const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
     if (hipSuccess != c->S.alloc((size_t)std::max<int64_t>(npad * npad, 1)) || hipSuccess != c->s.alloc((size_t)std::max<int64_t>(npad, 1)) ||
-        hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 64 + 64 * 64 * 2, 1)) || hipSuccess != c->d_status.alloc(4)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
+        hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 64 + npad, 1)) || hipSuccess != c->d_status.alloc(4)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
     (void)ndof;
     return NLLS_OK;

@@ -1,0 +1,175 @@
+"""optimize! and its result/option structs: a behavioural mirror of src/optimize.jl:5-17,78-180 and
+src/structs.jl:5-107 on the host, driving the device-resident linear system."""
+import enum
+import math
+import time
+
+import numpy as np
+
+from . import iterators as It
+from ._capi import VARS_BEST, VARS_CURRENT, VARS_NEXT
+from .callbacks import nullcallback
+from .linearsystem import makesymmvls
+
+
+class NLLSIterator(enum.IntEnum):                   # src/structs.jl:5
+    newton = 0
+    levenbergmarquardt = 1
+    dogleg = 2
+    gradientdescent = 3
+
+
+newton, levenbergmarquardt, dogleg, gradientdescent = NLLSIterator
+
+
+class NLLSOptions:                                   # src/structs.jl:22-35
+    def __init__(self, maxiters=100, reldcost=1e-15, absdcost=1e-15, dstep=1e-15, maxfails=3, maxtime=30.0,
+                 iterator=levenbergmarquardt, callback=None, iteratordata=None):
+        self.reldcost, self.absdcost, self.dstep = reldcost, absdcost, dstep
+        self.maxfails, self.maxiters = maxfails, maxiters
+        self.maxtime = int(round(maxtime * 1e9))     # nanoseconds
+        self.iterator, self.callback, self.iteratordata = NLLSIterator(iterator), callback, iteratordata
+
+
+class NLLSResult:                                    # src/structs.jl:37-79
+    def __init__(self, d):
+        self.startcost, self.bestcost = d.startcost, d.bestcost
+        self.timetotal, self.timeinit = d.timetotal * 1e-9, d.timeinit * 1e-9
+        self.timecost, self.timegradient, self.timesolver = d.timecost * 1e-9, d.timegradient * 1e-9, d.timesolver * 1e-9
+        self.termination, self.niterations = d.converged, d.iternum
+        self.costcomputations, self.gradientcomputations, self.linearsolvers = d.costcomputations, d.gradientcomputations, d.linearsolvers
+
+    def __str__(self):
+        other = self.timetotal - self.timecost - self.timegradient - self.timesolver - self.timeinit
+        tt = max(self.timetotal, 1e-300)
+        s = ("NLLSsolver optimization took %f seconds and %d iterations to reduce the cost from %e to %e (a %.2f%% reduction), using:\n"
+             "   %d cost computations in %f seconds (%.2f%% of total time),\n"
+             "   %d gradient computations in %f seconds (%.2f%% of total time),\n"
+             "   %d linear solver computations in %f seconds (%.2f%% of total time),\n"
+             "   %f seconds for initialization (%.2f%% of total time), and\n"
+             "   %f seconds for other stuff (%.2f%% of total time).\n") % (
+            self.timetotal, self.niterations, self.startcost, self.bestcost, 100 * (1 - self.bestcost / self.startcost) if self.startcost else 0.0,
+            self.costcomputations, self.timecost, 100 * self.timecost / tt, self.gradientcomputations, self.timegradient, 100 * self.timegradient / tt,
+            self.linearsolvers, self.timesolver, 100 * self.timesolver / tt, self.timeinit, 100 * self.timeinit / tt, other, 100 * other / tt)
+        reasons = ["Cost is infinite.", "Cost is NaN.", "Relative decrease in cost below threshold.", "Absolute decrease in cost below threshold.",
+                   "Step contains an infinite value.", "Step contains a NaN.", "Step size below threshold.",
+                   "Too many consecutive iterations increasing the cost.", "Maximum number of outer iterations reached.",
+                   "Maximum allowed computation time exceeded."]
+        if self.termination:
+            s += "Reason(s) for termination:\n"
+            for bit, r in enumerate(reasons):
+                if self.termination & (1 << bit):
+                    s += "   " + r + "\n"
+            if self.termination >> 16:
+                s += "   Terminated by user-defined callback, with flags: " + bin(self.termination >> 16)[2:] + "\n"
+        return s
+
+
+class NLLSInternal:                                  # src/structs.jl:81-104
+    def __init__(self, linsystem, starttime):
+        self.startcost = self.bestcost = 0.0
+        self.starttime = starttime
+        self.timetotal = self.timeinit = self.timecost = self.timegradient = self.timesolver = 0
+        self.iternum = self.costcomputations = self.gradientcomputations = self.linearsolvers = self.converged = 0
+        self.linsystem = linsystem
+
+
+_ITER = {
+    newton: (It.NewtonData, It.iterate_newton),
+    levenbergmarquardt: (It.LevMarData, It.iterate_levmar),
+    dogleg: (It.DoglegData, It.iterate_dogleg),
+    gradientdescent: (It.GradientDescentData, It.iterate_gradientdescent),
+}
+
+
+def convertunfixed(unfixed, problem):                # src/optimize.jl:19-22
+    n = problem.nvariables
+    if unfixed is None:
+        return np.ones(n, bool)
+    if isinstance(unfixed, (int, np.integer)) and not isinstance(unfixed, (bool, np.bool_)):
+        m = np.zeros(n, bool); m[int(unfixed) - 1] = True   # 1-based single variable index
+        return m
+    if isinstance(unfixed, tuple) and len(unfixed) == 2 and not isinstance(unfixed[0], (bool, np.bool_)):
+        kind, dim = unfixed                          # "variable type": (kind, dim)
+        return (problem.var_kind == kind) & (problem.var_dim == dim)
+    return np.asarray(unfixed, dtype=bool)
+
+
+def optimizeinternal(problem, options, data, iteratedata, iterate, callback):   # src/optimize.jl:109-180
+    ls = data.linsystem
+    data.startcost = -math.inf                       # preoptimization, src/iterators.jl:7
+    fails = 0
+    data.iternum = 0
+    stoptime = data.starttime + options.maxtime
+    data.timeinit += time.perf_counter_ns() - data.starttime
+    cost = It._timed(data, "timegradient", ls.costgradhess)      # :118
+    data.gradientcomputations += 1
+    data.bestcost = cost
+    data.startcost = max(cost, data.startcost)
+    have_best = False
+    while True:
+        data.iternum += 1
+        cost = float(iterate(iteratedata, data, problem, options))   # :126
+        cost, terminate = callback(cost, problem, data, iteratedata)   # :128
+        dcost = data.bestcost - cost
+        if dcost >= 0:
+            data.bestcost = cost
+            fails = 0
+        else:
+            dcost = cost
+            fails += 1
+            if fails == 1:                           # :137-144 store the current best variables
+                if have_best:
+                    ls.swap(VARS_CURRENT, VARS_BEST)
+                else:
+                    ls.copy(VARS_BEST, VARS_CURRENT); have_best = True
+        ls.swap(VARS_CURRENT, VARS_NEXT)             # updatefromnext!  :207-209
+        maxstep = ls.step_maxabs()                   # :149
+        converged = 0
+        converged |= int(math.isinf(cost)) << 0
+        converged |= int(math.isnan(cost)) << 1
+        converged |= int(dcost < data.bestcost * options.reldcost) << 2
+        converged |= int(dcost < options.absdcost) << 3
+        converged |= int(math.isinf(maxstep)) << 4
+        converged |= int(math.isnan(maxstep)) << 5
+        converged |= int(maxstep < options.dstep) << 6
+        converged |= int(fails > options.maxfails) << 7
+        converged |= int(data.iternum >= options.maxiters) << 8
+        converged |= int(time.perf_counter_ns() > stoptime) << 9
+        converged |= int(terminate) << 16
+        data.converged = converged
+        if converged != 0:
+            break
+        It._timed(data, "timegradient", ls.costgradhess)   # :167-170
+        data.gradientcomputations += 1
+    if not (data.bestcost >= cost):
+        ls.swap(VARS_CURRENT, VARS_BEST)             # updatefrombest!  :173-176
+    data.timetotal += time.perf_counter_ns() - data.starttime
+    return data
+
+
+def optimize(problem, options=None, unfixed=None, callback=nullcallback, flags=0, device=0, stream=None):
+    """optimize!(problem, options, unfixed, callback) -> NLLSResult   src/optimize.jl:5-17,57.
+    Variables are optimised in place: problem.variables holds the best values on return."""
+    options = options or NLLSOptions()
+    starttime = time.perf_counter_ns()
+    assert problem.nvariables > 0
+    unfixed = convertunfixed(unfixed, problem)
+    ls = makesymmvls(problem, unfixed, flags, device, stream)       # :16
+    data = NLLSInternal(ls, starttime)
+    mk, iterate = _ITER[options.iterator]
+    try:
+        optimizeinternal(problem, options, data, mk(), iterate, callback or nullcallback)
+        problem.variables[:] = ls.variables(VARS_CURRENT)
+    finally:
+        ls.close()
+    return NLLSResult(data)
+
+
+def cost(problem, device=0):
+    """cost(problem)   src/cost.jl:9"""
+    ls = makesymmvls(problem, np.ones(problem.nvariables, bool), 0, device)
+    try:
+        return ls.cost(VARS_CURRENT)
+    finally:
+        ls.close()
