@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/s (+ residual-blocks/s) on the synthetic bundle adjustment of BASELINE.json
+(configs[3]: 1k cameras x 100k points x ~1M 2-dim reprojection residuals, Huber-robustified).
+
+A "step" is one Levenberg-Marquardt outer iteration of the hot path: damped solve(s) + retraction + cost
+sweep(s) (src/iterators.jl:139-172) followed by the gradient sweep that builds the next linear system
+(src/optimize.jl:167-170).  Inputs are resident in HBM before the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU, RCCL).
+
+Prints ONE JSON line on rank 0 with the contract fields plus "roofline" (accumulate sweep vs the HBM roof,
+timed live with HIP events on the library's stream) and "cpu_baseline" (the CPU oracle -- a port, not the
+Julia reference, which cannot run here -- timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+CONFIGS = {
+    # name: (ncameras, npoints, propvisible)            BASELINE.json configs[2], configs[3]
+    "ba_100x10k": (100, 10_000, 0.1),
+    "ba_1kx100k": (1000, 100_000, 0.01),
+}
+
+
+def algorithmic_bytes_per_sweep(nobs, var_storage, nnz_data, ndof, M=2, ndeps=2):
+    """unique reads + unique writes of one gradient sweep."""
+    return nobs * (8 * M + 8 * ndeps) + 8 * var_storage + 8 * (nnz_data + ndof)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ba_1kx100k", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import nllssolver_jl_amd as N
+    from nllssolver_jl_amd import synthetic, iterators as It
+    from nllssolver_jl_amd import optimizer as Opt
+    from nllssolver_jl_amd._capi import VARS_CURRENT, VARS_NEXT
+    from nllssolver_jl_amd.dist import ShardedLS
+
+    ncam, npts, prop = CONFIGS[args.workload]
+    problem = synthetic.create_ba_problem(ncam, npts, prop, seed=1, robust=N.HuberKernel(0.01),
+                                          outlier_frac=0.05, outlier_sigma=0.05)
+    problem = synthetic.perturb_ba_problem(problem, 1e-3, 1e-3)
+    nobs = problem.ncosts()
+    start_vars = problem.variables.copy()
+
+    ls = ShardedLS(problem, np.ones(problem.nvariables, bool), device=local_rank, rank=rank, world=world, dist=dist)
+    info = ls.info
+    # never terminate early inside the timed region: exactly K outer iterations
+    options = N.NLLSOptions(maxiters=10 ** 9, reldcost=-np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
+
+    def fresh_loop():
+        ls.ctx.set_variables(start_vars, VARS_CURRENT)
+        ls.ctx.copy_variables(VARS_NEXT, VARS_CURRENT)
+        data = Opt.NLLSInternal(ls, time.perf_counter_ns())
+        loop = Opt.OuterLoop(problem, options, data, It.LevMarData(), It.iterate_levmar, N.nullcallback)
+        loop.start()
+        return loop
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loop = fresh_loop()
+    for _ in range(args.warmup):
+        loop.iteration()
+    loop = fresh_loop()                     # same start point for the timed region
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loop.iteration()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    data = loop.data
+    final_cost, start_cost = data.bestcost, data.startcost
+
+    # ---- roofline of the accumulate sweep (dominant HBM-bound kernels), timed with HIP events on the library's stream
+    reps = 20
+    sweep_ms = ls.ctx.time_sweep_gradhess(reps)
+    cost_ms = ls.ctx.time_sweep_cost(reps)
+    ls.ctx.damp(1e-3 * ls.ctx.max_abs_diag())
+    solve_ms = ls.ctx.time_solve(3)
+    alg_bytes = algorithmic_bytes_per_sweep(ls.local_nobs, info.var_storage, ls.local_nnz_data, ls.local_ndof_written)
+    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # filled from a separate rocprofv3 --pmc pass
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_sweep")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "gh_light_kernel<BA_AFFINE,point rows> + gh_heavy_kernel<BA_AFFINE,camera rows> (one gradient sweep)",
+                "algorithmic_bytes_per_launch": int(alg_bytes), "ms_per_launch": round(sweep_ms, 4),
+                "cost_sweep_ms": round(cost_ms, 4), "solve_ms": round(solve_ms, 4)}
+
+    # ---- CPU baseline: the oracle's own optimize! loop on a bounded sample of the same workload (rank 0, N = 1)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        problem.variables[:] = start_vars
+        op = O.OracleProblem(problem.var_kind, problem.var_dim, problem.groups()); op.set_variables(problem.variables)
+        r = op.optimize(maxiters=args.cpu_iters, reldcost=-1e300, absdcost=-1e300, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
+        t_iter = r.timecost + r.timegradient + r.timesolver        # excludes the one-off symbolic analysis
+        cpu = {"value": round(r.niterations / t_iter, 4), "unit": "LM iters/s", "cores": 1, "kind": "port",
+               "sample": f"{r.niterations} LM iterations of the same {args.workload} problem ({nobs} residual blocks); "
+                         f"gradient {r.timegradient:.2f}s, cost {r.timecost:.2f}s, solver {r.timesolver:.2f}s, "
+                         f"one-off setup {r.timetotal - t_iter:.2f}s excluded",
+               "residual_blocks_per_s": round(nobs * r.gradientcomputations / max(r.timegradient, 1e-9), 1),
+               "host_cores_available": os.cpu_count()}
+
+    if rank == 0:
+        out = {
+            "metric": "LM iterations/s on synthetic BA (1k cams x 100k pts x ~1M obs)" if args.workload == "ba_1kx100k"
+                      else f"LM iterations/s on synthetic BA ({args.workload})",
+            "value": round(args.steps / elapsed, 3), "unit": "LM iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "ncameras": ncam, "npoints": npts, "nobs": nobs, "robust": "Huber(0.01)",
+                       "outliers": "5% of measurements + N(0,0.05^2), seed 1", "ndof": int(info.ndof),
+                       "reduced_dof": int(info.nreduced_dof), "sharding": "none" if world == 1 else f"by point over {world} ranks"},
+            "residual_blocks_per_s": round(nobs * args.steps / elapsed, 1),
+            "sweep_residual_blocks_per_s": round(ls.local_nobs * world / (sweep_ms * 1e-3), 1),
+            "lm": {"start_cost": start_cost, "final_cost": final_cost, "linear_solves": data.linearsolvers,
+                   "cost_sweeps": data.costcomputations, "gradient_sweeps": data.gradientcomputations},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    ls.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""Observation sharding across the GPUs of one node, one process per GPU.
+
+Residual blocks are partitioned BY ELIMINATED VARIABLE (bundle adjustment: by point): a rank owns a
+contiguous range of points and every cost block that touches them, so the point block-rows of A.data
+(99.8 % of its bytes) are written by exactly one rank and never communicated.  What is summed over ranks
+(torch.distributed: RCCL over xGMI on the GPU box, gloo in the CPU tests):
+  stage 0  after the gradient sweep : [cost | reduced-block rows of A.data | reduced part of b]   (~0.3 MB)
+  stage 1  after local elimination  : [S (dense, lower) | s]  -- the real collective of this path
+  stage 2  after back-substitution  : x  (each rank contributes its own points)                    (~2.4 MB)
+plus one scalar per cost sweep.
+"""
+import numpy as np
+
+from . import _capi
+from .linearsystem import MultiVariateLSgpu
+
+
+class _DevArray:
+    """Wraps a raw device pointer for torch.as_tensor via __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class ShardedLS(MultiVariateLSgpu):
+    """MultiVariateLSgpu whose sweeps/solves are sharded over `world` ranks."""
+
+    def __init__(self, problem, unfixed, flags=0, device=0, rank=0, world=1, dist=None, host_staged=False):
+        self.rank, self.world, self.dist, self.host_staged = rank, world, dist, host_staged
+        self._pre_upload = (rank, world)
+        super().__init__(problem, unfixed, flags, device)
+        nobs = problem.ncosts()
+        if world == 1:
+            self.local_nobs, self.local_nnz_data, self.local_ndof_written = nobs, self.info.nnz_data, self.info.ndof
+        else:
+            sh = self.ctx.shard_info()
+            self.local_nobs, self.local_nnz_data, self.local_ndof_written = sh["local_ncost"], sh["local_nnz_data"], sh["local_ndof"]
+
+    def _make_context(self, device):
+        ctx = _capi.Context(device)
+        rank, world = self._pre_upload
+        if world > 1:
+            ctx.set_shard(rank, world)
+        return ctx
+
+    # ---- collectives ------------------------------------------------------------------------------
+    def _allreduce(self, stage):
+        import torch
+        ptr, n = self.ctx.reduce_buffer(stage)
+        if n == 0:
+            return
+        t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+        if self.host_staged:       # gloo on host copies: lets two ranks share one GPU in tests
+            h = t.cpu(); self.dist.all_reduce(h); t.copy_(h)
+        else:
+            self.dist.all_reduce(t)
+        torch.cuda.synchronize()
+
+    def costgradhess(self):
+        if self.world == 1:
+            return super().costgradhess()
+        self._x = None
+        self.ctx.sweep_gradhess_local()
+        self._allreduce(0)
+        return self.ctx.sweep_gradhess_finish()
+
+    def cost(self, which=_capi.VARS_NEXT):
+        if self.world == 1:
+            return super().cost(which)
+        self.ctx.sweep_cost_local(which)
+        self._allreduce(0)
+        return self.ctx.sweep_cost_finish()
+
+    def solve(self):
+        if self.world == 1:
+            return super().solve()
+        self._x = None
+        self.ctx.solve_local()
+        self._allreduce(1)
+        self.ctx.solve_finish()
+        self._allreduce(2)
+
+
+def partition_by_weight(weights, nparts):
+    """Contiguous ranges [start_k, start_{k+1}) over len(weights) items with balanced weight sums
+    (the same rule csrc/nlls_structure.cpp uses to split the eliminated blocks over ranks)."""
+    w = np.asarray(weights, dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(w)])
+    total = cum[-1]
+    bounds = [0]
+    for k in range(1, nparts):
+        target = (total * k) // nparts
+        bounds.append(int(np.searchsorted(cum, target, side="left")))
+    bounds.append(len(w))
+    return np.maximum.accumulate(np.array(bounds, dtype=np.int64))

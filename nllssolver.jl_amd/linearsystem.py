@@ -15,13 +15,16 @@ class MultiVariateLSgpu:
         # blockindices: linearsystem.jl:93-102
         self.blockindices = np.zeros(problem.nvariables, np.uint64)
         self.blockindices[unfixed] = np.arange(1, int(unfixed.sum()) + 1, dtype=np.uint64)
-        self.ctx = _capi.Context(device)
+        self.ctx = self._make_context(device)
         if stream is not None:
             self.ctx.set_stream(stream)
         self.info = self.ctx.upload(problem.var_kind, problem.var_dim, self.blockindices, problem.groups(), flags)
         self.ctx.set_variables(problem.variables, VARS_CURRENT)
         self.ctx.copy_variables(VARS_NEXT, VARS_CURRENT)        # setupiterator: varnext = deepcopy(variables)
         self._x = None
+
+    def _make_context(self, device):
+        return _capi.Context(device)
 
     # ---- the generic functions of SURVEY 8b -------------------------------------------------------
     def costgradhess(self):

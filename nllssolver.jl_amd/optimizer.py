@@ -95,36 +95,51 @@ def convertunfixed(unfixed, problem):                # src/optimize.jl:19-22
     return np.asarray(unfixed, dtype=bool)
 
 
-def optimizeinternal(problem, options, data, iteratedata, iterate, callback):   # src/optimize.jl:109-180
-    ls = data.linsystem
-    data.startcost = -math.inf                       # preoptimization, src/iterators.jl:7
-    fails = 0
-    data.iternum = 0
-    stoptime = data.starttime + options.maxtime
-    data.timeinit += time.perf_counter_ns() - data.starttime
-    cost = It._timed(data, "timegradient", ls.costgradhess)      # :118
-    data.gradientcomputations += 1
-    data.bestcost = cost
-    data.startcost = max(cost, data.startcost)
-    have_best = False
-    while True:
+class OuterLoop:
+    """State of optimizeinternal! (src/optimize.jl:109-180), split so that bench.py can time exactly K outer
+    iterations: start() = :111-121, iteration() = one pass of the while-loop body :124-171."""
+
+    def __init__(self, problem, options, data, iteratedata, iterate, callback):
+        self.problem, self.options, self.data = problem, options, data
+        self.iteratedata, self.iterate, self.callback = iteratedata, iterate, callback
+        self.fails = 0
+        self.have_best = False
+        self.cost = math.nan
+
+    def start(self):
+        data, ls = self.data, self.data.linsystem
+        data.startcost = -math.inf                       # preoptimization, src/iterators.jl:7
+        self.fails = 0
+        data.iternum = 0
+        self.stoptime = data.starttime + self.options.maxtime
+        data.timeinit += time.perf_counter_ns() - data.starttime
+        cost = It._timed(data, "timegradient", ls.costgradhess)      # :118
+        data.gradientcomputations += 1
+        data.bestcost = cost
+        data.startcost = max(cost, data.startcost)
+        self.cost = cost
+
+    def iteration(self, regrad=True):
+        """One outer iteration; returns the termination flags (0 = keep going).  With regrad the linear
+        problem for the next iteration is built unless terminating (:167-170)."""
+        data, ls, options = self.data, self.data.linsystem, self.options
         data.iternum += 1
-        cost = float(iterate(iteratedata, data, problem, options))   # :126
-        cost, terminate = callback(cost, problem, data, iteratedata)   # :128
+        cost = float(self.iterate(self.iteratedata, data, self.problem, options))   # :126
+        cost, terminate = self.callback(cost, self.problem, data, self.iteratedata)   # :128
         dcost = data.bestcost - cost
         if dcost >= 0:
             data.bestcost = cost
-            fails = 0
+            self.fails = 0
         else:
             dcost = cost
-            fails += 1
-            if fails == 1:                           # :137-144 store the current best variables
-                if have_best:
+            self.fails += 1
+            if self.fails == 1:                          # :137-144 store the current best variables
+                if self.have_best:
                     ls.swap(VARS_CURRENT, VARS_BEST)
                 else:
-                    ls.copy(VARS_BEST, VARS_CURRENT); have_best = True
-        ls.swap(VARS_CURRENT, VARS_NEXT)             # updatefromnext!  :207-209
-        maxstep = ls.step_maxabs()                   # :149
+                    ls.copy(VARS_BEST, VARS_CURRENT); self.have_best = True
+        ls.swap(VARS_CURRENT, VARS_NEXT)                 # updatefromnext!  :207-209
+        maxstep = ls.step_maxabs()                       # :149
         converged = 0
         converged |= int(math.isinf(cost)) << 0
         converged |= int(math.isnan(cost)) << 1
@@ -133,19 +148,31 @@ def optimizeinternal(problem, options, data, iteratedata, iterate, callback):   
         converged |= int(math.isinf(maxstep)) << 4
         converged |= int(math.isnan(maxstep)) << 5
         converged |= int(maxstep < options.dstep) << 6
-        converged |= int(fails > options.maxfails) << 7
+        converged |= int(self.fails > options.maxfails) << 7
         converged |= int(data.iternum >= options.maxiters) << 8
-        converged |= int(time.perf_counter_ns() > stoptime) << 9
+        converged |= int(time.perf_counter_ns() > self.stoptime) << 9
         converged |= int(terminate) << 16
         data.converged = converged
-        if converged != 0:
-            break
-        It._timed(data, "timegradient", ls.costgradhess)   # :167-170
-        data.gradientcomputations += 1
-    if not (data.bestcost >= cost):
-        ls.swap(VARS_CURRENT, VARS_BEST)             # updatefrombest!  :173-176
-    data.timetotal += time.perf_counter_ns() - data.starttime
-    return data
+        self.cost = cost
+        if converged == 0 and regrad:
+            It._timed(data, "timegradient", ls.costgradhess)   # :167-170
+            data.gradientcomputations += 1
+        return converged
+
+    def finish(self):
+        data, ls = self.data, self.data.linsystem
+        if not (data.bestcost >= self.cost):
+            ls.swap(VARS_CURRENT, VARS_BEST)             # updatefrombest!  :173-176
+        data.timetotal += time.perf_counter_ns() - data.starttime
+        return data
+
+
+def optimizeinternal(problem, options, data, iteratedata, iterate, callback):   # src/optimize.jl:109-180
+    loop = OuterLoop(problem, options, data, iteratedata, iterate, callback)
+    loop.start()
+    while loop.iteration() == 0:
+        pass
+    return loop.finish()
 
 
 def optimize(problem, options=None, unfixed=None, callback=nullcallback, flags=0, device=0, stream=None):
