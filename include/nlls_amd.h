@@ -102,12 +102,16 @@ typedef struct nlls_info {
     int64_t nschur_blocks;   /* number of eliminated (Schur) variable blocks                         */
     int64_t nreduced_dof;    /* order of the dense reduced system                                    */
     int64_t owner_path;      /* 1: deterministic owner-gather accumulate, 0: atomic scatter          */
+    int64_t solve_mode;      /* 0 small (one wave), 1 dense blocked LDL' (MFMA), 2 bordered band      */
+    int64_t bandwidth;       /* half bandwidth (dof) of the banded part of the reduced system         */
+    int64_t nborder_dof;     /* dof ordered last in the reduced system (dense border)                 */
 } nlls_info;
 
 /* flags for nlls_upload_structure */
 #define NLLS_FLAG_FORCE_ATOMIC   0x1  /* always use the generic atomic scatter accumulate            */
 #define NLLS_FLAG_NO_SCHUR       0x2  /* solve the full system densely (small problems / testing)    */
 #define NLLS_FLAG_FORCE_SPARSE   0x4  /* makesymmvls(...; formarginalization) style: BSM regardless   */
+#define NLLS_FLAG_NO_BAND        0x8  /* never use the bordered-band solver (dense MFMA path instead)  */
 
 /* variable-set ids for the on-device copies of problem.variables / varnext / varbest
  * (src/problem.jl:9-12) */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnlls_amd.so")
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOT_READY, ERR_NOT_SPD, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
-FLAG_FORCE_ATOMIC, FLAG_NO_SCHUR, FLAG_FORCE_SPARSE = 1, 2, 4
+FLAG_FORCE_ATOMIC, FLAG_NO_SCHUR, FLAG_FORCE_SPARSE, FLAG_NO_BAND = 1, 2, 4, 8
 VARS_CURRENT, VARS_NEXT, VARS_BEST = 0, 1, 2
 
 # every symbol include/nlls_amd.h declares (checked by tests/test_capi_symbols.py)
@@ -41,7 +41,7 @@ class Info(C.Structure):
     _fields_ = [("is_sparse", C.c_int32), ("has_schur", C.c_int32), ("nvar", C.c_int64), ("nblocks", C.c_int64),
                 ("ndof", C.c_int64), ("nnz_data", C.c_int64), ("nblocks_stored", C.c_int64), ("ncost", C.c_int64),
                 ("var_storage", C.c_int64), ("nschur_blocks", C.c_int64), ("nreduced_dof", C.c_int64),
-                ("owner_path", C.c_int64)]
+                ("owner_path", C.c_int64), ("solve_mode", C.c_int64), ("bandwidth", C.c_int64), ("nborder_dof", C.c_int64)]
 
 
 def build(force=False):

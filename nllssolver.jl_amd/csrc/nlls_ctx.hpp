@@ -101,6 +101,7 @@ struct SchurNbr {            // one off-diagonal block touching an eliminated bl
     uint16_t dim;            // neighbour block size
     uint16_t trans;          // 0: stored as (elim x nbr) [dv x du]; 1: stored as (nbr x elim) [du x dv]
 };
+constexpr int SOLVE_SMALL = 0, SOLVE_DENSE = 1, SOLVE_BAND = 2;
 struct SchurCopy {           // a reduced-reduced block copied from A.data into S
     int64_t off; uint32_t r, c; uint16_t rows, cols;
 };
@@ -156,6 +157,9 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_elim_group;     // supernodes: runs of eliminated blocks with identical neighbour sets
     int64_t nelim_groups = 0;
     int max_elim_dim = 0, max_nbr_dof = 0;
+    bool elim_use_acc = false; size_t elim_lds = 0;
+    int64_t n_band = 0; int nbd = 0, bw = 0;   // reduced ordering: [banded part | border dof | rhs]
+    int solve_mode = 0, band_CH = 0, band_H = 0;
     nlls::DevBuf<nlls::SchurCopy> d_copy;    // reduced-reduced blocks
     int64_t ncopy = 0;
     nlls::DevBuf<nlls::SchurCopy> d_blk;     // every stored block with full-system dof offsets (quadratic forms)

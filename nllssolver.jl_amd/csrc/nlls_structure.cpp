@@ -288,86 +288,133 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
 // The reference factors the FULL sparse system with LDLFactorizations (src/linearsolver.jl:29); there is no
 // Schur complement in it.  Here an independent set of blocks (no two share a stored block) is
 // eliminated first -- the same fill-reducing choice a minimum-degree ordering makes for bundle adjustment --
-// and the remaining blocks form the dense reduced system.
+// and the remaining blocks form the reduced system, ordered [banded part | border blocks | rhs row].
 int build_schur(nlls_ctx* c, int32_t flags) {
-    const nlls_info& I0 = c->info; const int64_t nb = I0.nblocks, ndof = I0.ndof;
+    const nlls_info& I0 = c->info; const int64_t nb = I0.nblocks;
     c->is_elim.assign(nb, 0); c->nelim = 0; c->nelim_groups = 0; c->max_elim_dim = 0; c->max_nbr_dof = 0;
     std::vector<int64_t> red_of(nb, -1);     // dof offset in the reduced system
+    // transposed block lists: for a block v, the rows w > v that store block (w, v)
+    std::vector<int64_t> tptr(nb + 1, 0), trow, tq;
+    if (I0.is_sparse) {
+        for (int64_t q = 0; q < (int64_t)c->it_rowval.size(); ++q) tptr[c->it_rowval[q] + 1]++;
+        for (int64_t k = 0; k < nb; ++k) tptr[k + 1] += tptr[k];
+        trow.resize(c->it_rowval.size()); tq.resize(c->it_rowval.size());
+        std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
+        for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t p = cur[c->it_rowval[q]]++; trow[p] = row; tq[p] = q; }
+    }
     if (I0.is_sparse && !(flags & NLLS_FLAG_NO_SCHUR) && nb > 1) {
-        // adjacency counts
         std::vector<int32_t> deg(nb, 0);
         for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q]; if (col != row) { deg[row]++; deg[col]++; } }
-        // candidate class = the (block size) class with the most blocks; greedy independent set inside it,
-        // lowest degree first (stable by index)
+        // candidate class = the block size with the most blocks; greedy independent set inside it, lowest degree first
         std::unordered_map<int, int64_t> classcount; for (int64_t k = 0; k < nb; ++k) classcount[c->blocksizes[k]]++;
         int best = -1; int64_t bestn = 0; for (auto& kv : classcount) if (kv.second > bestn || (kv.second == bestn && kv.first < best)) { best = kv.first; bestn = kv.second; }
-        std::vector<std::vector<int32_t>> adj;   // only needed to test independence: use marks over rows
         std::vector<uint8_t> blocked(nb, 0);
-        // neighbours of a block = cols of its row + rows having it as col -> build transposed lists once
-        std::vector<int64_t> tptr(nb + 1, 0); for (int64_t q = 0; q < (int64_t)c->it_rowval.size(); ++q) tptr[c->it_rowval[q] + 1]++;
-        for (int64_t k = 0; k < nb; ++k) tptr[k + 1] += tptr[k];
-        std::vector<int64_t> trow(c->it_rowval.size()); { std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
-            for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) trow[cur[c->it_rowval[q]]++] = row; }
         std::vector<int64_t> order; for (int64_t k = 0; k < nb; ++k) if (c->blocksizes[k] == best) order.push_back(k);
         std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return deg[a] < deg[b]; });
         for (int64_t v : order) { if (blocked[v]) continue; c->is_elim[v] = 1; c->nelim++;
             for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) blocked[c->it_rowval[q]] = 1;
             for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) blocked[trow[q]] = 1; }
-        // not worth it unless most blocks go
-        if (c->nelim * 2 < nb) { std::fill(c->is_elim.begin(), c->is_elim.end(), 0); c->nelim = 0; }
-        if (c->nelim) {
-            int64_t ro = 0; for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) { red_of[k] = ro; ro += c->blocksizes[k]; }
-            c->nred = ro;
-            std::vector<int64_t> eptr; std::vector<SchurNbr> enbr; std::vector<int64_t> ediag; std::vector<uint32_t> eboff; std::vector<uint16_t> edim;
-            std::vector<uint32_t> egroup;
-            eptr.push_back(0);
-            std::vector<SchurNbr> prev;
-            for (int64_t v = 0; v < nb; ++v) if (c->is_elim[v]) {
-                std::vector<SchurNbr> nb_list;
-                for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) { int64_t u = c->it_rowval[q]; if (u == v) continue;
-                    nb_list.push_back(SchurNbr{c->it_nzval[q], (uint32_t)red_of[u], (uint16_t)c->blocksizes[u], 0}); }
-                for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) { int64_t w = trow[q]; if (w == v) continue;
-                    // block (w, v) stored in row w: find its offset
-                    const int64_t* b0 = c->it_rowval.data() + c->it_colptr[w]; const int64_t* b1 = c->it_rowval.data() + c->it_colptr[w + 1];
-                    const int64_t* it = std::lower_bound(b0, b1, v);
-                    nb_list.push_back(SchurNbr{c->it_nzval[it - c->it_rowval.data()], (uint32_t)red_of[w], (uint16_t)c->blocksizes[w], 1}); }
-                std::sort(nb_list.begin(), nb_list.end(), [](const SchurNbr& a, const SchurNbr& b) { return a.rcol < b.rcol; });
-                int nd = 0; for (auto& n : nb_list) nd += n.dim;
-                c->max_nbr_dof = std::max(c->max_nbr_dof, nd); c->max_elim_dim = std::max(c->max_elim_dim, (int)c->blocksizes[v]);
-                // supernode: same neighbour columns as the previous eliminated block
-                bool same = !egroup.empty() && prev.size() == nb_list.size();
-                if (same) for (size_t i = 0; i < prev.size(); ++i) if (prev[i].rcol != nb_list[i].rcol) { same = false; break; }
-                if (!same) egroup.push_back((uint32_t)ediag.size());
-                prev = nb_list;
-                for (auto& n : nb_list) enbr.push_back(n);
-                eptr.push_back((int64_t)enbr.size()); ediag.push_back(c->diag_off[v]); eboff.push_back((uint32_t)c->boffsets[v]); edim.push_back((uint16_t)c->blocksizes[v]);
-            }
-            egroup.push_back((uint32_t)ediag.size());
-            { size_t lds = sizeof(double) * ((size_t)c->max_elim_dim * c->max_elim_dim + (size_t)c->max_elim_dim * (2 * c->max_nbr_dof + 1)) + 4 * (c->max_nbr_dof + 2);
-              if (lds > 60 * 1024) return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated block with too many neighbours for the LDS-staged Schur kernel (retry with NLLS_FLAG_NO_SCHUR)"); }
-            c->nelim_groups = (int64_t)egroup.size() - 1;
-            if (hipSuccess != c->d_elim_ptr.upload(eptr) || hipSuccess != c->d_elim_nbr.upload(enbr) || hipSuccess != c->d_elim_diag.upload(ediag) ||
-                hipSuccess != c->d_elim_boff.upload(eboff) || hipSuccess != c->d_elim_dim.upload(edim) || hipSuccess != c->d_elim_group.upload(egroup)) return fail(c, NLLS_ERR_HIP, "schur upload");
-        }
+        if (c->nelim * 2 < nb) { std::fill(c->is_elim.begin(), c->is_elim.end(), 0); c->nelim = 0; }   // not worth it unless most blocks go
     }
-    if (!c->nelim) { int64_t ro = 0; for (int64_t k = 0; k < nb; ++k) { red_of[k] = ro; ro += c->blocksizes[k]; } c->nred = ro; }
+    // ---- reduced ordering: blocks coupled to a large share of the system go last (border) so that they cause no fill
+    std::vector<uint8_t> is_border(nb, 0);
+    {
+        std::vector<int64_t> cnt(nb, 0); int64_t nR = 0;
+        for (int64_t v = 0; v < nb; ++v) { if (!c->is_elim[v]) { nR++; continue; }
+            for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) if (c->it_rowval[q] != v) cnt[c->it_rowval[q]]++;
+            for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) if (trow[q] != v) cnt[trow[q]]++; }
+        std::vector<int64_t> rcnt(nb, 0);
+        if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) { if (c->is_elim[row]) continue;
+            for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q]; if (col != row && !c->is_elim[col]) { rcnt[row]++; rcnt[col]++; } } }
+        int64_t bd = 0;
+        for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) {
+            bool big = (c->nelim >= 64 && cnt[k] * 4 > c->nelim) || (nR >= 64 && rcnt[k] * 4 > nR);
+            if (big && bd + c->blocksizes[k] <= 15) { is_border[k] = 1; bd += c->blocksizes[k]; } }
+        int64_t ro = 0;
+        for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && !is_border[k]) { red_of[k] = ro; ro += c->blocksizes[k]; }
+        c->n_band = ro;
+        for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && is_border[k]) { red_of[k] = ro; ro += c->blocksizes[k]; }
+        c->nred = ro; c->nbd = (int)(ro - c->n_band);
+    }
+    int64_t bw = 0;   // half bandwidth (in dof) of the non-border part of S
+    std::vector<int64_t> eptr; std::vector<SchurNbr> enbr; std::vector<int64_t> ediag; std::vector<uint32_t> eboff; std::vector<uint16_t> edim; std::vector<uint32_t> egroup;
+    eptr.push_back(0);
+    if (c->nelim) {
+        std::vector<SchurNbr> prev; uint32_t glen = 0;
+        for (int64_t v = 0; v < nb; ++v) if (c->is_elim[v]) {
+            std::vector<SchurNbr> nl;
+            for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) { int64_t u = c->it_rowval[q]; if (u == v) continue;
+                nl.push_back(SchurNbr{c->it_nzval[q], (uint32_t)red_of[u], (uint16_t)c->blocksizes[u], 0}); }
+            for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) { int64_t w = trow[q]; if (w == v) continue;
+                nl.push_back(SchurNbr{c->it_nzval[tq[q]], (uint32_t)red_of[w], (uint16_t)c->blocksizes[w], 1}); }
+            std::sort(nl.begin(), nl.end(), [](const SchurNbr& a, const SchurNbr& b) { return a.rcol < b.rcol; });
+            int nd = 0; int64_t lo = -1, hi = -1;
+            for (auto& n : nl) { nd += n.dim; if ((int64_t)n.rcol < c->n_band) { if (lo < 0) lo = n.rcol; hi = n.rcol + n.dim - 1; } }
+            if (lo >= 0) bw = std::max(bw, hi - lo);
+            c->max_nbr_dof = std::max(c->max_nbr_dof, nd); c->max_elim_dim = std::max(c->max_elim_dim, (int)c->blocksizes[v]);
+            // supernode: same neighbour columns and own size as the previous eliminated block
+            bool same = !edim.empty() && glen < 128 && prev.size() == nl.size() && edim.back() == (uint16_t)c->blocksizes[v];
+            if (same) for (size_t i = 0; i < prev.size(); ++i) if (prev[i].rcol != nl[i].rcol || prev[i].dim != nl[i].dim) { same = false; break; }
+            if (!same) { egroup.push_back((uint32_t)ediag.size()); glen = 0; }
+            ++glen; prev = nl;
+            for (auto& n : nl) enbr.push_back(n);
+            eptr.push_back((int64_t)enbr.size()); ediag.push_back(c->diag_off[v]); eboff.push_back((uint32_t)c->boffsets[v]); edim.push_back((uint16_t)c->blocksizes[v]);
+        }
+        egroup.push_back((uint32_t)ediag.size());
+        c->nelim_groups = (int64_t)egroup.size() - 1;
+        // LDS budget of the elimination kernel: C, E, Y, pair accumulators, column map
+        const size_t nd = c->max_nbr_dof, dv = c->max_elim_dim;
+        size_t base = sizeof(double) * (dv * dv + dv * nd + dv * (nd + 1)) + 4 * (nd + 2);
+        size_t accb = sizeof(double) * (nd * (nd + 1) / 2 + nd);
+        if (base > 60 * 1024) return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated block with too many neighbours for the LDS-staged Schur kernel (retry with NLLS_FLAG_NO_SCHUR)");
+        c->elim_use_acc = (base + accb <= 64 * 1024);
+        c->elim_lds = base + (c->elim_use_acc ? accb : 0);
+        if (!c->elim_use_acc) { egroup.resize(ediag.size() + 1); for (size_t i = 0; i <= ediag.size(); ++i) egroup[i] = (uint32_t)i; c->nelim_groups = (int64_t)ediag.size(); }
+        if (hipSuccess != c->d_elim_ptr.upload(eptr) || hipSuccess != c->d_elim_nbr.upload(enbr) || hipSuccess != c->d_elim_diag.upload(ediag) ||
+            hipSuccess != c->d_elim_boff.upload(eboff) || hipSuccess != c->d_elim_dim.upload(edim) || hipSuccess != c->d_elim_group.upload(egroup)) return fail(c, NLLS_ERR_HIP, "schur upload");
+    }
     // reduced-reduced blocks to copy into S
     std::vector<SchurCopy> copies; std::vector<uint32_t> red_boff(c->nred);
     for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) for (int i = 0; i < c->blocksizes[k]; ++i) red_boff[red_of[k] + i] = (uint32_t)(c->boffsets[k] + i);
     if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) { if (c->is_elim[row]) continue;
         for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q]; if (c->is_elim[col]) continue;
-            copies.push_back(SchurCopy{c->it_nzval[q], (uint32_t)red_of[row], (uint32_t)red_of[col], (uint16_t)c->blocksizes[row], (uint16_t)c->blocksizes[col]}); } }
+            // S is addressed by its lower triangle in REDUCED order: transpose the block if the border reordering flipped it
+            SchurCopy cp{c->it_nzval[q], (uint32_t)red_of[row], (uint32_t)red_of[col], (uint16_t)c->blocksizes[row], (uint16_t)c->blocksizes[col]};
+            copies.push_back(cp);
+            if (red_of[row] < c->n_band && red_of[col] < c->n_band && row != col) bw = std::max<int64_t>(bw, std::llabs(red_of[row] - red_of[col]) + std::max(c->blocksizes[row], c->blocksizes[col]) - 1);
+            if (row == col) bw = std::max<int64_t>(bw, c->blocksizes[row] - 1);
+        } }
     c->ncopy = (int64_t)copies.size();
     { std::vector<SchurCopy> blks;
       if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q];
           blks.push_back(SchurCopy{c->it_nzval[q], (uint32_t)c->boffsets[row], (uint32_t)c->boffsets[col], (uint16_t)c->blocksizes[row], (uint16_t)c->blocksizes[col]}); }
       c->nblk = (int64_t)blks.size(); if (hipSuccess != c->d_blk.upload(blks)) return fail(c, NLLS_ERR_HIP, "block list upload"); }
     if (hipSuccess != c->d_copy.upload(copies) || hipSuccess != c->d_red_boff.upload(red_boff)) return fail(c, NLLS_ERR_HIP, "schur upload");
-    const int64_t n = c->nred; const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
-    if (hipSuccess != c->S.alloc((size_t)std::max<int64_t>(npad * npad, 1)) || hipSuccess != c->s.alloc((size_t)std::max<int64_t>(npad, 1)) ||
-        hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 64 + npad, 1)) || hipSuccess != c->d_status.alloc(4)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
+    // ---- choose the reduced-system solver ----------------------------------------------------------------------
+    const int64_t n = c->nred;
+    c->bw = (int)bw; c->solve_mode = SOLVE_DENSE;
+    if (n < 64) c->solve_mode = SOLVE_SMALL;
+    else if (!I0.is_sparse) c->solve_mode = SOLVE_DENSE;
+    else if (c->n_band >= 128 && !(flags & NLLS_FLAG_NO_BAND)) {
+        // bordered-band LDL' in one persistent workgroup: needs the LDS ring + prefetch registers to fit
+        const int H = (int)bw + 1 + c->nbd + 1;
+        for (int CH : {32, 16, 8}) {
+            const int PFC = ((int)bw + 1 + CH - 1) / CH + 1, RC = (PFC + 1) * CH;
+            const size_t lds = sizeof(double) * ((size_t)RC * H + (size_t)(c->nbd + 1) * (c->nbd + 2) + 2 * CH + 256 + 8);
+            const int T = (int)(bw * (bw + 1) / 2 + bw * (c->nbd + 1) + (c->nbd + 1) * (c->nbd + 2) / 2);
+            if (H <= 255 && lds <= 150 * 1024 && CH * H <= 12 * 256 && T <= 40 * 256) { c->solve_mode = SOLVE_BAND; c->band_CH = CH; c->band_H = H; break; }
+        }
+    }
+    if (c->solve_mode == SOLVE_BAND) {
+        const size_t sz = (size_t)c->band_H * c->n_band + (size_t)(c->nbd + 1) * (c->nbd + 1);
+        if (hipSuccess != c->S.alloc(sz) || hipSuccess != c->Lwork.alloc(sz) || hipSuccess != c->s.alloc((size_t)n + 64) || hipSuccess != c->d_status.alloc(4)) return fail(c, NLLS_ERR_HIP, "band system alloc");
+    } else {
+        const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
+        if (hipSuccess != c->S.alloc((size_t)std::max<int64_t>(npad * npad, 1)) || hipSuccess != c->s.alloc((size_t)std::max<int64_t>(npad, 1)) ||
+            hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 64 + npad, 1)) || hipSuccess != c->d_status.alloc(4)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
+    }
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
-    (void)ndof;
+    c->info.solve_mode = c->solve_mode; c->info.bandwidth = c->bw; c->info.nborder_dof = c->nbd;
     return NLLS_OK;
 }
 

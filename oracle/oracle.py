@@ -33,7 +33,7 @@ class Info(C.Structure):
     _fields_ = [("is_sparse", C.c_int32), ("has_schur", C.c_int32), ("nvar", C.c_int64), ("nblocks", C.c_int64),
                 ("ndof", C.c_int64), ("nnz_data", C.c_int64), ("nblocks_stored", C.c_int64), ("ncost", C.c_int64),
                 ("var_storage", C.c_int64), ("nschur_blocks", C.c_int64), ("nreduced_dof", C.c_int64),
-                ("owner_path", C.c_int64)]
+                ("owner_path", C.c_int64), ("solve_mode", C.c_int64), ("bandwidth", C.c_int64), ("nborder_dof", C.c_int64)]
 
 
 class Options(C.Structure):

@@ -150,3 +150,17 @@ def test_so3_ba():                   # BASELINE config 5 shapes (new kinds)
     check_problem(synthetic.perturb_ba_problem(q, 1e-3, 1e-3), expect_sparse=1, lam_scale=1e-4)
     unfixed = np.ones(q.nvariables, bool); unfixed[0] = False        # adaptive kernel held fixed
     check_problem(q, unfixed=unfixed, expect_sparse=1, lam_scale=1e-4)
+
+
+def test_ba_band_solver():           # narrow-band reduced system -> persistent-workgroup bordered-band LDL'
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(120, 4000, 0.06, seed=8), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.solve_mode == 2 and info.nreduced_dof == 720 and 0 < info.bandwidth < 128
+    info = check_problem(p, flags=_capi.FLAG_NO_BAND, expect_schur=1)      # same system through the dense MFMA path
+    assert info.solve_mode == 1
+
+
+def test_so3_adaptive_band_with_border():   # the kernel variable couples to every camera: ordered last as a border
+    q = synthetic.create_so3_ba_problem(100, 3000, 0.08, seed=4, adaptive=True)
+    info = check_problem(synthetic.perturb_ba_problem(q, 1e-3, 1e-3), expect_sparse=1, lam_scale=1e-4)
+    assert info.solve_mode == 2 and info.nborder_dof == 3
