@@ -110,6 +110,7 @@ def main():
     cost_ms = ls.ctx.time_sweep_cost(reps)
     ls.ctx.damp(1e-3 * ls.ctx.max_abs_diag())
     solve_ms = ls.ctx.time_solve(3)
+    solve_stats = ls.ctx.solve_stats()
     alg_bytes = algorithmic_bytes_per_sweep(ls.local_nobs, info.var_storage, ls.local_nnz_data, ls.local_ndof_written)
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
     traffic = None
@@ -123,7 +124,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "gh_light_kernel<BA_AFFINE,point rows> + gh_heavy_kernel<BA_AFFINE,camera rows> (one gradient sweep)",
                 "algorithmic_bytes_per_launch": int(alg_bytes), "ms_per_launch": round(sweep_ms, 4),
-                "cost_sweep_ms": round(cost_ms, 4), "solve_ms": round(solve_ms, 4)}
+                "cost_sweep_ms": round(cost_ms, 4), "solve_ms": round(solve_ms, 4), "solve_stats": solve_stats}
 
     # ---- CPU baseline: the oracle's own optimize! loop on a bounded sample of the same workload (rank 0, N = 1)
     cpu = None

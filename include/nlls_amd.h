@@ -183,6 +183,9 @@ int  nlls_damp(nlls_ctx* ctx, double delta);
 /* replaces: negate!(solve!(linsystem, options))  src/iterators.jl:152 -> src/linearsolver.jl:28-32.
  * Solves (H + lambda I) y = b and stores x = -y on the device; x_out (length ndof) may be NULL. */
 int  nlls_solve(nlls_ctx* ctx, double* x_out);
+/* diagnostics of the last solve: [0] factorisation status (0 ok), [1] band factor shader cycles,
+ * [2] band backward-pass cycles, [3] solve mode, [4] number of elimination supernodes, [5] bandwidth */
+int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
 int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
 int  nlls_get_step(nlls_ctx* ctx, double* x_out);
 int  nlls_step_maxabs(nlls_ctx* ctx, double* out);                /* maximum(abs, linsystem.x) */

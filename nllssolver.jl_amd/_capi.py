@@ -20,7 +20,7 @@ VARS_CURRENT, VARS_NEXT, VARS_BEST = 0, 1, 2
 SYMBOLS = """nlls_ctx_create nlls_ctx_destroy nlls_last_error nlls_set_stream nlls_set_shard nlls_var_storage nlls_var_dof
 nlls_res_ndeps nlls_res_nres nlls_res_ndata nlls_res_slot_kind nlls_upload_structure nlls_get_info nlls_get_bsm_index
 nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nlls_sweep_gradhess nlls_sweep_cost
-nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_set_step
+nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
 nlls_get_reduce_buffer nlls_get_step_shard nlls_time_sweep_gradhess nlls_time_sweep_cost nlls_time_solve""".split()
@@ -82,6 +82,7 @@ def lib():
         L.nlls_get_grad.argtypes = [vp, vp]; L.nlls_get_bsm_data.argtypes = [vp, vp]
         L.nlls_max_abs_diag.argtypes = [vp, vp]; L.nlls_grad_sqnorm.argtypes = [vp, vp]; L.nlls_grad_quadform.argtypes = [vp, vp]
         L.nlls_damp.argtypes = [vp, dbl]
+        L.nlls_get_solve_stats.argtypes = [vp, vp, i32]
         L.nlls_solve.argtypes = [vp, vp]; L.nlls_set_step.argtypes = [vp, vp]; L.nlls_get_step.argtypes = [vp, vp]
         L.nlls_step_maxabs.argtypes = [vp, vp]; L.nlls_step_norm.argtypes = [vp, vp]
         L.nlls_quadform.argtypes = [vp, vp, vp]
@@ -210,6 +211,11 @@ class Context:
         out = np.zeros(self.info.ndof) if want_x else None
         self._chk(self.L.nlls_solve(self.h, _p(out)))
         return out
+
+    def solve_stats(self):
+        out = np.zeros(6, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 6))
+        return dict(status=int(out[0]), band_factor_cycles=int(out[1]), band_backward_cycles=int(out[2]), solve_mode=int(out[3]),
+                    elim_supernodes=int(out[4]), bandwidth=int(out[5]))
 
     def set_step(self, x):
         x = np.ascontiguousarray(x, np.float64); assert x.size == self.info.ndof

@@ -182,6 +182,15 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
     if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");
     return NLLS_OK;
 }
+int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
+    NEED_READY(); if (!out || n < 1) return NLLS_ERR_INVALID_ARG;
+    int32_t status[16] = {0};
+    HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int64_t vals[6] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw};
+    for (int i = 0; i < n && i < 6; ++i) out[i] = vals[i];
+    return NLLS_OK;
+}
 int nlls_set_step(nlls_ctx* ctx, const double* x) {
     NEED_READY(); if (!x) return NLLS_ERR_INVALID_ARG;
     HIPCHK(hipMemcpyAsync(ctx->x.p, x, sizeof(double) * ctx->info.ndof, hipMemcpyHostToDevice, ctx->stream));

@@ -155,11 +155,13 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_elim_boff;      // dof offset in b/x
     nlls::DevBuf<uint16_t> d_elim_dim;
     nlls::DevBuf<uint32_t> d_elim_group;     // supernodes: runs of eliminated blocks with identical neighbour sets
-    int64_t nelim_groups = 0;
+    int64_t nelim_groups = 0, n_fast_groups = 0, n_slow_groups = 0;
+    nlls::DevBuf<uint32_t> d_fast_groups, d_slow_groups;
+    int fast_dv = 0, fast_maxk = 0;
     int max_elim_dim = 0, max_nbr_dof = 0;
     bool elim_use_acc = false; size_t elim_lds = 0;
     int64_t n_band = 0; int nbd = 0, bw = 0;   // reduced ordering: [banded part | border dof | rhs]
-    int solve_mode = 0, band_CH = 0, band_H = 0;
+    int solve_mode = 0, band_CH = 0, band_H = 0, band_SEG = 0, band_NSEG = 0;
     nlls::DevBuf<nlls::SchurCopy> d_copy;    // reduced-reduced blocks
     int64_t ncopy = 0;
     nlls::DevBuf<nlls::SchurCopy> d_blk;     // every stored block with full-system dof offsets (quadratic forms)

@@ -82,33 +82,40 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
                                                         const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
                                                         const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
                                                         const uint16_t* __restrict__ edim, const uint32_t* __restrict__ egroup,
-                                                        double lambda, int maxdv, int maxnd, int use_acc,
+                                                        const uint32_t* __restrict__ glist, double lambda, int maxdv, int maxnd, int use_acc,
                                                         SLayout L, double* __restrict__ s, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x;
     double* C = sm;                                   // dv*dv
     double* E = C + maxdv * maxdv;                    // dv*nd  (col-major, column = reduced dof)
     double* Y = E + (size_t)maxdv * maxnd;            // dv*(nd+1)
-    uint32_t* rc = reinterpret_cast<uint32_t*>(Y + (size_t)maxdv * (maxnd + 1));   // nd (+pad)
-    double* acc = reinterpret_cast<double*>(rc + ((maxnd + 2 + 1) & ~1));           // pairs + nd
-    const uint32_t v0 = egroup[blockIdx.x], v1 = egroup[blockIdx.x + 1];
+    int64_t* csrc = reinterpret_cast<int64_t*>(Y + (size_t)maxdv * (maxnd + 1));   // nd: A.data offset of E(0, column)
+    int64_t* nbo = csrc + maxnd;                                                    // neighbour block offsets (<= nd)
+    uint32_t* rc = reinterpret_cast<uint32_t*>(nbo + maxnd);                        // nd: reduced column
+    uint32_t* cstr = rc + maxnd;                                                    // nd: stride between rows of E in A.data
+    uint32_t* nbi = cstr + maxnd;                                                   // neighbour rcol | dim << 24 | trans << 31
+    double* acc = reinterpret_cast<double*>(nbi + maxnd + (maxnd & 1));             // pairs + nd
+    const uint32_t g = glist[blockIdx.x];
+    const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
     int nd = 0, npairs = 0;
     for (uint32_t v = v0; v < v1; ++v) {
         const int dv = edim[v];
         const int64_t p0 = eptr[v], p1 = eptr[v + 1];
         __syncthreads();
+        // gather: neighbour descriptors first (one coalesced load), then every element of [C | E | b] in parallel
+        // through per-column (offset, stride) descriptors -- two memory latencies per block instead of one per neighbour
+        const int nnb = (int)(p1 - p0);
+        for (int p = lane; p < nnb; p += 64) { const SchurNbr nb = enbr[p0 + p]; nbo[p] = nb.off; nbi[p] = nb.rcol | ((uint32_t)nb.dim << 24) | ((uint32_t)nb.trans << 31); }
         for (int e = lane; e < dv * dv; e += 64) { const int i = e % dv, j = e / dv; C[e] = A[ediag[v] + e] + (i == j ? lambda : 0.0); }
+        __syncthreads();
         int ndv = 0;
-        for (int64_t p = p0; p < p1; ++p) {
-            const SchurNbr nb = enbr[p]; const int du = nb.dim;
-            for (int e = lane; e < dv * du; e += 64) {
-                int a, c2;   // a: row in eliminated block, c2: column in neighbour
-                if (!nb.trans) { a = e % dv; c2 = e / dv; } else { c2 = e % du; a = e / du; }
-                E[a + dv * (ndv + c2)] = A[nb.off + e];
-            }
-            if (v == v0) for (int c2 = lane; c2 < du; c2 += 64) rc[ndv + c2] = nb.rcol + c2;
+        for (int p = 0; p < nnb; ++p) {
+            const uint32_t info = nbi[p]; const int du = (info >> 24) & 127, tr = info >> 31;
+            for (int c2 = lane; c2 < du; c2 += 64) { csrc[ndv + c2] = nbo[p] + (tr ? c2 : (int64_t)dv * c2); cstr[ndv + c2] = tr ? du : 1; if (v == v0) rc[ndv + c2] = (info & 0xFFFFFF) + c2; }
             ndv += du;
         }
+        __syncthreads();
+        for (int e = lane; e < dv * ndv; e += 64) { const int a2 = e % dv, c2 = e / dv; E[e] = A[csrc[c2] + (int64_t)a2 * cstr[c2]]; }
         for (int a = lane; a < dv; a += 64) Y[a + dv * ndv] = b[eboff[v] + a];
         if (v == v0) { nd = ndv; npairs = nd * (nd + 1) / 2; if (use_acc) for (int t = lane; t < npairs + nd; t += 64) acc[t] = 0.0; }
         __syncthreads();
@@ -124,13 +131,12 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
             }
         }
         __syncthreads();
-        // Y(:, c) = C^-1 [E | b](:, c): one column per lane
+        // Y(:, c) = C^-1 [E | b](:, c): one column per lane, solved in place in LDS
         for (int c2 = lane; c2 <= nd; c2 += 64) {
-            double y[NLLS_MAX_BLOCK_SZ];
-            for (int i = 0; i < dv; ++i) { double t = (c2 < nd) ? E[i + dv * c2] : Y[i + dv * nd]; for (int k = 0; k < i; ++k) t -= C[i + dv * k] * y[k]; y[i] = t; }
+            double* y = Y + dv * c2;
+            for (int i = 0; i < dv; ++i) { double t = (c2 < nd) ? E[i + dv * c2] : y[i]; for (int k = 0; k < i; ++k) t -= C[i + dv * k] * y[k]; y[i] = t; }
             for (int i = 0; i < dv; ++i) y[i] /= C[i + dv * i];
             for (int i = dv - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < dv; ++k) t -= C[k + dv * i] * y[k]; y[i] = t; }
-            for (int i = 0; i < dv; ++i) Y[i + dv * c2] = y[i];
         }
         __syncthreads();
         // pair (p >= q): E(:,p)' Y(:,q); walk (p, q) incrementally from the lane's first pair
@@ -160,6 +166,115 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
     }
 }
 
+// Fast path of the elimination for supernodes whose members (a) have the compile-time block size DV and (b) store
+// their off-diagonal blocks back to back in their own block row, in reduced-column order, followed by the diagonal
+// block -- the layout every bundle-adjustment point row has (src/BlockSparseMatrix.jl:37-44).  Lane c owns column c
+// of [E | b]: it loads its DV entries plus C_v straight into registers (one memory latency per block, the next
+// block's loads are issued before the current one is consumed), factors C_v redundantly in registers (no LDS, no
+// barrier), and the pair products are accumulated in REGISTERS (static pair list per lane), flushed once per run.
+template <int DV, int MAXK>
+__global__ __launch_bounds__(64) void schur_elim_fast_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                             const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
+                                                             const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                             const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist, double lambda,
+                                                             SLayout L, double* __restrict__ s, int* __restrict__ status) {
+    __shared__ double Es[2][DV * 128], Ys[2][DV * 128];   // columns of E and Y (nd + 1 <= 128)
+    __shared__ uint32_t rc[128];
+    const int lane = threadIdx.x;
+    const uint32_t g = glist[blockIdx.x];
+    const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
+    // structure of the run (identical for all members): reduced column of every E column
+    const int64_t p0 = eptr[v0]; const int nnb = (int)(eptr[v0 + 1] - p0);
+    int nd = 0;
+    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = lane; c2 < nb.dim; c2 += 64) rc[nd + c2] = nb.rcol + c2; nd += nb.dim; }
+    const int npairs = nd * (nd + 1) / 2;
+    // static pair list: lane's k-th pair is t = lane + 64 k  ->  (p, q), p >= q
+    uint32_t pq[MAXK]; double acc[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int t = lane + 64 * k; int p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (p * (p + 1) / 2 > t) --p;
+        while ((p + 1) * (p + 2) / 2 <= t) ++p;
+        pq[k] = (t < npairs) ? ((uint32_t)p << 16 | (uint32_t)(t - p * (p + 1) / 2)) : 0xFFFFFFFFu; acc[k] = 0.0;
+    }
+    double accs[2] = {0.0, 0.0};                          // column p = lane + 64 u < nd: sum of E(:,p)' y_b
+    // software pipeline: registers hold the NEXT block's columns (lane owns columns lane and lane + 64) and diagonal block
+    double en[2][DV], cn[DV * DV];
+    auto issue = [&](uint32_t v) {
+        const int64_t seg = ediag[v] - (int64_t)DV * nd;   // the off-diagonal blocks sit right before the diagonal block
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int col = lane + 64 * u;
+#pragma unroll
+            for (int a2 = 0; a2 < DV; ++a2) en[u][a2] = (col < nd) ? A[seg + (int64_t)DV * col + a2] : ((col == nd) ? b[eboff[v] + a2] : 0.0); }
+#pragma unroll
+        for (int e = 0; e < DV * DV; ++e) cn[e] = A[ediag[v] + e];
+    };
+    issue(v0);
+    int buf = 0;
+    for (uint32_t v = v0; v < v1; ++v, buf ^= 1) {
+        double e[2][DV], C[DV * DV];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int a2 = 0; a2 < DV; ++a2) e[u][a2] = en[u][a2];
+#pragma unroll
+        for (int q = 0; q < DV * DV; ++q) C[q] = cn[q];
+        if (v + 1 < v1) issue(v + 1);
+        // LDL' of C + lambda*I in registers (every lane, redundantly)
+#pragma unroll
+        for (int j = 0; j < DV; ++j) {
+            double d = C[j + DV * j] + lambda;
+#pragma unroll
+            for (int k = 0; k < j; ++k) d -= C[j + DV * k] * C[j + DV * k] * C[k + DV * k];
+            if (d == 0.0 || d != d) { if (lane == 0) atomicCAS(status, 0, 1); d = 1.0; }
+            C[j + DV * j] = d;
+#pragma unroll
+            for (int i = j + 1; i < DV; ++i) { double t = C[i + DV * j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) t -= C[i + DV * k] * C[j + DV * k] * C[k + DV * k];
+                C[i + DV * j] = t / d; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col = lane + 64 * u;
+            double y[DV];
+#pragma unroll
+            for (int i = 0; i < DV; ++i) { double t = e[u][i];
+#pragma unroll
+                for (int k = 0; k < i; ++k) t -= C[i + DV * k] * y[k]; y[i] = t; }
+#pragma unroll
+            for (int i = 0; i < DV; ++i) y[i] /= C[i + DV * i];
+#pragma unroll
+            for (int i = DV - 1; i >= 0; --i) { double t = y[i];
+#pragma unroll
+                for (int k = i + 1; k < DV; ++k) t -= C[k + DV * i] * y[k]; y[i] = t; }
+            if (col <= nd) {
+#pragma unroll
+                for (int a2 = 0; a2 < DV; ++a2) { Es[buf][a2 + DV * col] = e[u][a2]; Ys[buf][a2 + DV * col] = y[a2]; }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS writes have landed (single-wave workgroup)
+        __builtin_amdgcn_wave_barrier();
+        const double* Eb = Es[buf]; const double* Yb = Ys[buf];
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) if (pq[k] != 0xFFFFFFFFu) {
+            const int p = pq[k] >> 16, q = pq[k] & 0xFFFF; double a2 = 0;
+#pragma unroll
+            for (int a3 = 0; a3 < DV; ++a3) a2 += Eb[a3 + DV * p] * Yb[a3 + DV * q];
+            acc[k] += a2;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (lane + 64 * u < nd) { double a2 = 0;
+#pragma unroll
+            for (int a3 = 0; a3 < DV; ++a3) a2 += e[u][a3] * Yb[a3 + DV * nd];
+            accs[u] += a2; }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) if (pq[k] != 0xFFFFFFFFu) atomicAdd(L.at(rc[pq[k] >> 16], rc[pq[k] & 0xFFFF]), -acc[k]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (lane + 64 * u < nd) atomicAdd(&s[rc[lane + 64 * u]], -accs[u]);
+}
+
 // x_v = C_v^-1 (b_v - E_v x_R), stored negated (negate!, src/iterators.jl:3)
 __global__ __launch_bounds__(64) void schur_backsub_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                            const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
@@ -170,18 +285,16 @@ __global__ __launch_bounds__(64) void schur_backsub_kernel(const double* __restr
     const int v = blockIdx.x, lane = threadIdx.x; const int dv = edim[v];
     double* C = sm; double* rhs = C + maxdv * maxdv;
     for (int e = lane; e < dv * dv; e += 64) { const int i = e % dv, j = e / dv; C[e] = A[ediag[v] + e] + (i == j ? lambda : 0.0); }
-    // rhs[a] = b[a] - sum_p E[a,p] xr[p]: lanes over (neighbour element) with a wave reduction per row
-    double part[NLLS_MAX_BLOCK_SZ];
-    for (int a = 0; a < dv; ++a) part[a] = 0;
+    // rhs[a] = b[a] - sum_p E[a,p] xr[p]: lanes over the neighbour blocks' elements, summed with LDS atomics
+    for (int a = lane; a < dv; a += 64) rhs[a] = b[eboff[v] + a];
+    __syncthreads();
     for (int64_t p = eptr[v]; p < eptr[v + 1]; ++p) {
         const SchurNbr nb = enbr[p]; const int du = nb.dim;
         for (int e = lane; e < dv * du; e += 64) {
             int a, c2; if (!nb.trans) { a = e % dv; c2 = e / dv; } else { c2 = e % du; a = e / du; }
-            const double val = A[nb.off + e] * xr[nb.rcol + c2];
-            for (int aa = 0; aa < dv; ++aa) if (aa == a) part[aa] += val;
+            atomicAdd(&rhs[a], -A[nb.off + e] * xr[nb.rcol + c2]);
         }
     }
-    for (int a = 0; a < dv; ++a) { double t = wsum(part[a]); if (lane == 0) rhs[a] = b[eboff[v] + a] - t; }
     __syncthreads();
     if (lane == 0) {
         for (int j = 0; j < dv; ++j) {
@@ -391,42 +504,51 @@ __global__ __launch_bounds__(64) void bwd_diag_kernel(const double* __restrict__
 // ring; all 256 lanes share the rank-1 update of the window (one barrier per pivot); columns stream in from HBM
 // in chunks that are prefetched into registers one chunk ahead, and the factor streams out for the backward pass.
 // ---------------------------------------------------------------------------------------------------
-struct BandArgs { const double* Sb; double* Lb; double* xr; int n_band, bw, nbd, H, CH, PFC, RC; int* status; };
+struct BandArgs { const double* Sb; double* Lb; double* xr; int n_band, bw, nbd, H, CH, PFC, RC, SEG, Bp, Hp; int* status; };
 
-template <int ITMAX>
+// SEG: entries per update segment, NSEG: segments per lane.  In LDS a column's band part (bw+1 entries) is followed
+// by SEG zeros (Bp = bw+1+SEG), so every segment is exactly SEG long and the rank-1 update is branch-free with
+// immediate LDS offsets: a segment that runs past the entries pivot j touches reads zeros as sources, so the extra
+// destinations (real entries of the column, or its zero pad) are rewritten unchanged.
+template <int SEG, int NSEG>
 __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_band = a.n_band, bw = a.bw, nbd = a.nbd, H = a.H, CH = a.CH, RC = a.RC, nbr = nbd + 1;
-    double* W = sm;                               // RC * H ring of columns
-    double* Cl = W + (size_t)RC * H;              // nbr x nbr border corner (col-major, lower), last row = rhs
+    const int n_band = a.n_band, bw = a.bw, nbd = a.nbd, H = a.H, CH = a.CH, RC = a.RC, nbr = nbd + 1, Bp = a.Bp, Hp = a.Hp;
+    double* W = sm;                               // RC * Hp ring of columns: [band part padded to Bp | border rows | rhs]
+    double* Cl = W + (size_t)RC * Hp;             // nbr x nbr border corner (col-major, lower), last row = rhs
     double* xb = Cl + nbr * nbr;                  // nbr
     double* bsum = xb + nbr;                      // 2 * CH   (backward pass)
     volatile double* xs = bsum + 2 * CH;          // ring of 256 solved unknowns (backward pass)
     const double* corner_g = a.Sb + (size_t)n_band * H;
     for (int e = tid; e < nbr * nbr; e += 256) Cl[e] = corner_g[e];
-    // ---- per-lane update items: (dc, e, s1, s2): W[col j+dc][e] -= col_j[s1] * col_j[s2] / d ; dc = 0 -> corner Cl[e]
-    uint32_t items[ITMAX]; int nit = 0;
-    {
-        int it = 0;
-        for (int dc = 1; dc <= bw; ++dc) {
-            for (int e = 0; e <= bw - dc; ++e, ++it) if ((it & 255) == tid && nit < ITMAX) items[nit++] = (uint32_t)dc | ((uint32_t)e << 8) | ((uint32_t)(dc + e) << 16) | ((uint32_t)dc << 24);
-            for (int r = 0; r < nbr; ++r, ++it) if ((it & 255) == tid && nit < ITMAX) items[nit++] = (uint32_t)dc | ((uint32_t)(bw + 1 + r) << 8) | ((uint32_t)(bw + 1 + r) << 16) | ((uint32_t)dc << 24);
-        }
-        for (int r2 = 0; r2 < nbr; ++r2) for (int r = r2; r < nbr; ++r, ++it)
-            if ((it & 255) == tid && nit < ITMAX) items[nit++] = 0u | ((uint32_t)(r + nbr * r2) << 8) | ((uint32_t)(bw + 1 + r) << 16) | ((uint32_t)(bw + 1 + r2) << 24);
+    for (int e = tid; e < RC * Hp; e += 256) W[e] = 0.0;
+    // ---- this lane's update segments: column offset dc (1..bw), first entry e0 (multiple of SEG)
+    int seg_dc[NSEG], seg_e0[NSEG];
+#pragma unroll
+    for (int q = 0; q < NSEG; ++q) {
+        int want = tid + 256 * q, dc = 1; seg_dc[q] = 0; seg_e0[q] = 0;
+        while (dc <= bw) { const int ns = (bw - dc + 1 + SEG - 1) / SEG; if (want < ns) { seg_dc[q] = dc; seg_e0[q] = want * SEG; break; } want -= ns; ++dc; }
     }
-    // ---- initial window: chunks 0 .. PFC-1
+    const int ncorner = nbr * (nbr + 1) / 2;
+    int cr = 0, cr2 = 0;                          // this lane's corner element (r >= r2), lanes < ncorner
+    { int it = tid; while (cr2 < nbr && it >= nbr - cr2) { it -= nbr - cr2; ++cr2; } cr = cr2 + it; }
+    __syncthreads();
+    // ---- initial window: chunks 0 .. PFC-1 (global layout: H entries per column; LDS: Hp with the band part padded)
     const int chunk_elems = CH * H;
+    auto lds_index = [&](int c0, int idx) { const int cc = idx / H, e = idx - cc * H; return (size_t)((c0 + cc) % RC) * Hp + (e <= bw ? e : Bp + (e - bw - 1)); };
     for (int m = 0; m < a.PFC; ++m) {
         const int c0 = m * CH;
-        for (int idx = tid; idx < chunk_elems; idx += 256) { const int c2 = c0 + idx / H; W[(size_t)(c0 % RC) * H + idx] = (c2 < n_band) ? a.Sb[(size_t)c0 * H + idx] : 0.0; }
+        for (int idx = tid; idx < chunk_elems; idx += 256) { const int c2 = c0 + idx / H; W[lds_index(c0, idx)] = (c2 < n_band) ? a.Sb[(size_t)c0 * H + idx] : 0.0; }
     }
     double pf[12];
     int sj = 0, jc = 0, mchunk = 0;                            // j % RC, j % CH, j / CH
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();   // diagnostics only (nlls_get_solve_stats)
     for (int j = 0; j < n_band; ++j) {
-        __syncthreads();                                       // the previous pivot's updates are complete
-        const double* col = W + (size_t)sj * H;
+        // the previous pivot's LDS updates are complete.  Raw barrier behind an LDS-only wait: a __syncthreads()
+        // would also drain vmcnt, i.e. put the factor stores and the chunk prefetch on the per-pivot critical path.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const double* col = W + (size_t)sj * Hp;
         double d = col[0];
         if (d == 0.0 || d != d) { if (tid == 0) atomicCAS(a.status, 0, 1 + j); d = 1.0; }
         const double id = 1.0 / d;
@@ -436,23 +558,38 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
             for (int k = 0; k < 12; ++k) { const int idx = tid + 256 * k; const int c2 = c0 + idx / H;
                 pf[k] = (idx < chunk_elems && c2 < n_band) ? a.Sb[(size_t)c0 * H + idx] : 0.0; }
         }
+        // band part of the rank-1 update: W[col j+dc][e] -= col_j[dc+e] * col_j[dc] / d
 #pragma unroll
-        for (int k = 0; k < ITMAX; ++k) if (k < nit) {
-            const uint32_t itv = items[k]; const int dc = itv & 255, e = (itv >> 8) & 255, s1 = (itv >> 16) & 255, s2 = itv >> 24;
-            const double upd = col[s1] * col[s2] * id;
-            if (dc == 0) Cl[e] -= upd;
-            else if (j + dc < n_band) { int sl = sj + dc; if (sl >= RC) sl -= RC; W[(size_t)sl * H + e] -= upd; }
+        for (int q = 0; q < NSEG; ++q) if (seg_dc[q]) {
+            const int dc = seg_dc[q], e0 = seg_e0[q];
+            const double l = col[dc] * id;
+            int sl = sj + dc; if (sl >= RC) sl -= RC;
+            double* dst = W + (size_t)sl * Hp + e0; const double* src = col + dc + e0;
+            double sv[SEG], dv[SEG];
+#pragma unroll
+            for (int m = 0; m < SEG; ++m) { sv[m] = src[m]; dv[m] = dst[m]; }
+#pragma unroll
+            for (int m = 0; m < SEG; ++m) dst[m] = dv[m] - sv[m] * l;
         }
-        for (int e = tid; e < H; e += 256) a.Lb[(size_t)j * H + e] = (e == 0) ? d : col[e] * id;   // factor column: D on top, L below
+        // border rows + rhs of column j+dc (lanes 0..bw-1), border corner (lanes < ncorner)
+        if (tid < bw) {
+            const int dc = tid + 1; const double l = col[dc] * id;
+            int sl = sj + dc; if (sl >= RC) sl -= RC;
+            double* dst = W + (size_t)sl * Hp + Bp;
+            for (int r = 0; r < nbr; ++r) dst[r] -= col[Bp + r] * l;
+        }
+        if (tid < ncorner) Cl[cr + nbr * cr2] -= col[Bp + cr] * col[Bp + cr2] * id;
+        for (int e = tid; e < H; e += 256) a.Lb[(size_t)j * H + e] = (e == 0) ? d : col[e <= bw ? e : Bp + (e - bw - 1)] * id;   // factor column: D on top, L below
         if (jc == CH - 1) {                                    // land the prefetched chunk: its ring slots held columns < j
             const int c0 = (mchunk + a.PFC) * CH;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int idx = tid + 256 * k; if (idx < chunk_elems) W[(size_t)(c0 % RC) * H + idx] = pf[k]; }
+            for (int k = 0; k < 12; ++k) { const int idx = tid + 256 * k; if (idx < chunk_elems) W[lds_index(c0, idx)] = pf[k]; }
         }
         if (++sj == RC) sj = 0;
         if (++jc == CH) { jc = 0; ++mchunk; }
     }
     __syncthreads();
+    const unsigned long long t_factor = __builtin_amdgcn_s_memtime();
     // ---- border corner: LDL' of the nbd x nbd block with the rhs row riding along, then the border unknowns
     if (tid == 0) {
         for (int j = 0; j < nbd; ++j) {
@@ -503,6 +640,7 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
         if (m > 0) border_part(m - 1, tid, 256);
         __syncthreads();
     }
+    if (tid == 0) { a.status[2] = (int)((t_factor - t_begin) >> 10); a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_factor) >> 10); }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -531,13 +669,23 @@ __global__ __launch_bounds__(256) void quadform_dense_kernel(const double* __res
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// partial (v'v, b'v) per workgroup
+__global__ __launch_bounds__(256) void dot2_partial_kernel(const double* __restrict__ b, const double* __restrict__ v, int64_t n, double* __restrict__ part) {
+    __shared__ double red[2][4];
+    double vv = 0, bv = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double x = v[i]; vv += x * x; bv += b[i] * x; }
+    vv = wsum(vv); bv = wsum(bv);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = vv; red[1][threadIdx.x >> 6] = bv; }
+    __syncthreads();
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; part[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
+}
 // out[slot] = sum(partials) + lambda * v'v ; out[slot+1] = b'v
-__global__ __launch_bounds__(256) void quadform_finish_kernel(const double* __restrict__ partials, int np, const double* __restrict__ b,
-                                                              const double* __restrict__ v, int64_t n, double lambda, double* __restrict__ out, int slot) {
+__global__ __launch_bounds__(256) void quadform_finish_kernel(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
+                                                              double lambda, double* __restrict__ out, int slot) {
     __shared__ double red[3][4];
     double a = 0, vv = 0, bv = 0;
     for (int i = threadIdx.x; i < np; i += 256) a += partials[i];
-    for (int64_t i = threadIdx.x; i < n; i += 256) { const double x = v[i]; vv += x * x; bv += b[i] * x; }
+    for (int i = threadIdx.x; i < np2; i += 256) { vv += part2[2 * i]; bv += part2[2 * i + 1]; }
     a = wsum(a); vv = wsum(vv); bv = wsum(bv);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = vv; red[2][threadIdx.x >> 6] = bv; }
     __syncthreads();
@@ -562,7 +710,10 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
         np = (int)std::min<int64_t>((c->info.ndof + 255) / 256, 1024); if (np < 1) np = 1;
         hipLaunchKernelGGL(quadform_dense_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, (int)c->info.ndof, d_vec, c->partials.p);
     }
-    hipLaunchKernelGGL(quadform_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, np, c->b.p, d_vec, c->info.ndof, c->lambda, c->scalars.p, out_slot);
+    const int np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 256));
+    double* part2 = c->partials.p + 1024;
+    hipLaunchKernelGGL(dot2_partial_kernel, dim3(np2), dim3(256), 0, c->stream, c->b.p, d_vec, c->info.ndof, part2);
+    hipLaunchKernelGGL(quadform_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, np, part2, np2, c->lambda, c->scalars.p, out_slot);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
@@ -587,22 +738,35 @@ int enqueue_solve(nlls_ctx* c) {
         const int64_t n2 = (int64_t)n * n;
         hipLaunchKernelGGL(dense_to_S_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->S.p, c->A.p, c->lambda, n, npad);
     }
-    if (c->nelim > 0)
-        hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)c->nelim_groups), dim3(64), c->elim_lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
-                           c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->lambda, c->max_elim_dim, c->max_nbr_dof,
-                           c->elim_use_acc ? 1 : 0, L, c->s.p, c->d_status.p);
+    if (c->nelim > 0) {
+        if (c->n_slow_groups > 0)
+            hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)c->n_slow_groups), dim3(64), c->elim_lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
+                               c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->d_slow_groups.p, c->lambda, c->max_elim_dim, c->max_nbr_dof,
+                               c->elim_use_acc ? 1 : 0, L, c->s.p, c->d_status.p);
+        if (c->n_fast_groups > 0) {
+#define LAUNCH_FAST(DV, MAXK) hipLaunchKernelGGL((schur_elim_fast_kernel<DV, MAXK>), dim3((unsigned)c->n_fast_groups), dim3(64), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->lambda, L, c->s.p, c->d_status.p)
+            const int maxk = c->fast_maxk;
+            if (c->fast_dv == 3) { if (maxk <= 12) LAUNCH_FAST(3, 12); else if (maxk <= 24) LAUNCH_FAST(3, 24); else LAUNCH_FAST(3, 40); }
+            else if (c->fast_dv == 2) { if (maxk <= 12) LAUNCH_FAST(2, 12); else if (maxk <= 24) LAUNCH_FAST(2, 24); else LAUNCH_FAST(2, 40); }
+            else if (c->fast_dv == 1) { if (maxk <= 12) LAUNCH_FAST(1, 12); else if (maxk <= 24) LAUNCH_FAST(1, 24); else LAUNCH_FAST(1, 40); }
+#undef LAUNCH_FAST
+        }
+    }
     if (c->solve_mode == SOLVE_SMALL) {
         hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s.p, n, npad, c->d_status.p);
     } else if (band) {
         hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s.p);
-        BandArgs a{c->S.p, c->Lwork.p, c->s.p, L.n_band, L.bw, L.nbd, L.H, c->band_CH, 0, 0, c->d_status.p};
-        a.PFC = (L.bw + 1 + a.CH - 1) / a.CH + 1; a.RC = (a.PFC + 1) * a.CH;
+        BandArgs a{}; a.Sb = c->S.p; a.Lb = c->Lwork.p; a.xr = c->s.p; a.n_band = L.n_band; a.bw = L.bw; a.nbd = L.nbd; a.H = L.H; a.CH = c->band_CH; a.status = c->d_status.p;
+        a.PFC = (L.bw + 1 + a.CH - 1) / a.CH + 1; a.RC = (a.PFC + 1) * a.CH; a.SEG = c->band_SEG;
+        a.Bp = L.bw + 1 + a.SEG; a.Hp = a.Bp + L.nbd + 1;   // SEG zero entries behind the band part keep the update branch-free
         const int nbr = L.nbd + 1;
-        const size_t lds = sizeof(double) * ((size_t)a.RC * L.H + (size_t)nbr * nbr + nbr + 2 * a.CH + 256 + 8);
-        const int T = L.bw * (L.bw + 1) / 2 + L.bw * nbr + nbr * (nbr + 1) / 2; const int per = (T + 255) / 256;
-        if (per <= 12) hipLaunchKernelGGL(band_ldlt_solve_kernel<12>, dim3(1), dim3(256), lds, c->stream, a);
-        else if (per <= 24) hipLaunchKernelGGL(band_ldlt_solve_kernel<24>, dim3(1), dim3(256), lds, c->stream, a);
-        else hipLaunchKernelGGL(band_ldlt_solve_kernel<40>, dim3(1), dim3(256), lds, c->stream, a);
+        const size_t lds = sizeof(double) * ((size_t)a.RC * a.Hp + (size_t)nbr * nbr + nbr + 2 * a.CH + 256 + 8);
+        if (c->band_SEG == 8 && c->band_NSEG == 1) hipLaunchKernelGGL((band_ldlt_solve_kernel<8, 1>), dim3(1), dim3(256), lds, c->stream, a);
+        else if (c->band_SEG == 10 && c->band_NSEG == 1) hipLaunchKernelGGL((band_ldlt_solve_kernel<10, 1>), dim3(1), dim3(256), lds, c->stream, a);
+        else if (c->band_SEG == 12 && c->band_NSEG == 1) hipLaunchKernelGGL((band_ldlt_solve_kernel<12, 1>), dim3(1), dim3(256), lds, c->stream, a);
+        else if (c->band_SEG == 8 && c->band_NSEG == 2) hipLaunchKernelGGL((band_ldlt_solve_kernel<8, 2>), dim3(1), dim3(256), lds, c->stream, a);
+        else hipLaunchKernelGGL((band_ldlt_solve_kernel<12, 2>), dim3(1), dim3(256), lds, c->stream, a);
     } else {
         hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s.p);
         for (int k = 0; k < nblk; ++k) {

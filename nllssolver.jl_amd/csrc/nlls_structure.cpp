@@ -274,7 +274,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     c->nzero = (int64_t)zero_off.size();
     HIPCHK(c->d_zero_off.upload(zero_off)); HIPCHK(c->d_zero_len.upload(zero_len)); HIPCHK(c->d_zero_b_off.upload(zero_b_off)); HIPCHK(c->d_zero_b_len.upload(zero_b_len));
     for (int g = 0; g < ngroups; ++g) npartials += (c->groups[g].ncost + 255) / 256 + 1;
-    c->npartials = npartials + 16;
+    c->npartials = std::max<int64_t>(npartials + 16, 4096);
     HIPCHK(c->partials.alloc(c->npartials));
     I.owner_path = all_owner ? 1 : 0;
 
@@ -362,14 +362,37 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         }
         egroup.push_back((uint32_t)ediag.size());
         c->nelim_groups = (int64_t)egroup.size() - 1;
+        // fast-path eligibility: small compile-time block size, few neighbour dof, and the member's off-diagonal
+        // blocks stored back to back right before its diagonal block, in reduced-column order
+        std::vector<uint32_t> fastg, slowg; int fast_dv = 0; int fast_maxk = 0;
+        { std::unordered_map<int, int64_t> dvcount; for (auto d : edim) dvcount[d]++;
+          int64_t bestc = 0; for (auto& kv : dvcount) if (kv.first <= 3 && kv.second > bestc) { bestc = kv.second; fast_dv = kv.first; } }
+        for (size_t gi = 0; gi + 1 < egroup.size(); ++gi) {
+            bool ok = fast_dv > 0;
+            int ndg = 0;
+            for (uint32_t v = egroup[gi]; ok && v < egroup[gi + 1]; ++v) {
+                if (edim[v] != fast_dv) { ok = false; break; }
+                int nd = 0; int64_t expect = -1;
+                for (int64_t p = eptr[v]; p < eptr[v + 1]; ++p) { const SchurNbr& n = enbr[p];
+                    if (n.trans) { ok = false; break; }
+                    if (expect >= 0 && n.off != expect) { ok = false; break; }
+                    expect = n.off + (int64_t)fast_dv * n.dim; nd += n.dim; }
+                if (ok && eptr[v + 1] > eptr[v] && expect != ediag[v]) ok = false;
+                if (nd + 1 > 71) ok = false;
+                ndg = nd;
+            }
+            if (ok) { fastg.push_back((uint32_t)gi); fast_maxk = std::max(fast_maxk, (ndg * (ndg + 1) / 2 + 63) / 64); } else slowg.push_back((uint32_t)gi);
+        }
+        c->n_fast_groups = (int64_t)fastg.size(); c->n_slow_groups = (int64_t)slowg.size(); c->fast_dv = fast_dv; c->fast_maxk = fast_maxk;
+        if (hipSuccess != c->d_fast_groups.upload(fastg) || hipSuccess != c->d_slow_groups.upload(slowg)) return fail(c, NLLS_ERR_HIP, "group list upload");
         // LDS budget of the elimination kernel: C, E, Y, pair accumulators, column map
         const size_t nd = c->max_nbr_dof, dv = c->max_elim_dim;
-        size_t base = sizeof(double) * (dv * dv + dv * nd + dv * (nd + 1)) + 4 * (nd + 2);
+        size_t base = sizeof(double) * (dv * dv + dv * nd + dv * (nd + 1)) + 16 * nd + 12 * nd + 16;
         size_t accb = sizeof(double) * (nd * (nd + 1) / 2 + nd);
         if (base > 60 * 1024) return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated block with too many neighbours for the LDS-staged Schur kernel (retry with NLLS_FLAG_NO_SCHUR)");
         c->elim_use_acc = (base + accb <= 64 * 1024);
         c->elim_lds = base + (c->elim_use_acc ? accb : 0);
-        if (!c->elim_use_acc) { egroup.resize(ediag.size() + 1); for (size_t i = 0; i <= ediag.size(); ++i) egroup[i] = (uint32_t)i; c->nelim_groups = (int64_t)ediag.size(); }
+        if (!c->elim_use_acc && c->n_slow_groups > 0) return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated blocks with too many neighbour dof for the LDS accumulators (retry with NLLS_FLAG_NO_SCHUR)");
         if (hipSuccess != c->d_elim_ptr.upload(eptr) || hipSuccess != c->d_elim_nbr.upload(enbr) || hipSuccess != c->d_elim_diag.upload(ediag) ||
             hipSuccess != c->d_elim_boff.upload(eboff) || hipSuccess != c->d_elim_dim.upload(edim) || hipSuccess != c->d_elim_group.upload(egroup)) return fail(c, NLLS_ERR_HIP, "schur upload");
     }
@@ -398,20 +421,27 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     else if (c->n_band >= 128 && !(flags & NLLS_FLAG_NO_BAND)) {
         // bordered-band LDL' in one persistent workgroup: needs the LDS ring + prefetch registers to fit
         const int H = (int)bw + 1 + c->nbd + 1;
-        for (int CH : {32, 16, 8}) {
+        // update segments: (SEG entries) x (NSEG per lane) must cover the band triangle with 256 lanes
+        int SEG = 0, NSEG = 0;
+        for (auto cfg : {std::pair<int, int>{8, 1}, {10, 1}, {12, 1}, {8, 2}, {12, 2}}) {
+            int64_t ns = 0; for (int64_t dc = 1; dc <= bw; ++dc) ns += (bw - dc + 1 + cfg.first - 1) / cfg.first;
+            if (ns <= 256 * cfg.second) { SEG = cfg.first; NSEG = cfg.second; break; }
+        }
+        if (SEG) for (int CH : {32, 16, 8}) {
             const int PFC = ((int)bw + 1 + CH - 1) / CH + 1, RC = (PFC + 1) * CH;
-            const size_t lds = sizeof(double) * ((size_t)RC * H + (size_t)(c->nbd + 1) * (c->nbd + 2) + 2 * CH + 256 + 8);
-            const int T = (int)(bw * (bw + 1) / 2 + bw * (c->nbd + 1) + (c->nbd + 1) * (c->nbd + 2) / 2);
-            if (H <= 255 && lds <= 150 * 1024 && CH * H <= 12 * 256 && T <= 40 * 256) { c->solve_mode = SOLVE_BAND; c->band_CH = CH; c->band_H = H; break; }
+            const int Bp = (int)bw + 1 + SEG, Hp = Bp + c->nbd + 1;
+            const size_t lds = sizeof(double) * ((size_t)RC * Hp + (size_t)(c->nbd + 1) * (c->nbd + 2) + 2 * CH + 256 + 8);
+            if (H <= 255 && bw >= 1 && lds <= 150 * 1024 && CH * H <= 12 * 256 && (size_t)RC * Hp >= (size_t)2 * CH * H) {
+                c->solve_mode = SOLVE_BAND; c->band_CH = CH; c->band_H = H; c->band_SEG = SEG; c->band_NSEG = NSEG; break; }
         }
     }
     if (c->solve_mode == SOLVE_BAND) {
         const size_t sz = (size_t)c->band_H * c->n_band + (size_t)(c->nbd + 1) * (c->nbd + 1);
-        if (hipSuccess != c->S.alloc(sz) || hipSuccess != c->Lwork.alloc(sz) || hipSuccess != c->s.alloc((size_t)n + 64) || hipSuccess != c->d_status.alloc(4)) return fail(c, NLLS_ERR_HIP, "band system alloc");
+        if (hipSuccess != c->S.alloc(sz) || hipSuccess != c->Lwork.alloc(sz) || hipSuccess != c->s.alloc((size_t)n + 64) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "band system alloc");
     } else {
         const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
         if (hipSuccess != c->S.alloc((size_t)std::max<int64_t>(npad * npad, 1)) || hipSuccess != c->s.alloc((size_t)std::max<int64_t>(npad, 1)) ||
-            hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 64 + npad, 1)) || hipSuccess != c->d_status.alloc(4)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
+            hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 64 + npad, 1)) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
     }
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
     c->info.solve_mode = c->solve_mode; c->info.bandwidth = c->bw; c->info.nborder_dof = c->nbd;

@@ -347,27 +347,44 @@ __global__ void retract_kernel(const int32_t* __restrict__ kind, const int32_t* 
     var_update_real(k, d, in, st, out);
     for (int q = 0; q < ns; ++q) to[o + q] = out[q];
 }
-// maximum(abs, x) and x'x   (src/optimize.jl:149, src/iterators.jl:160; NaN propagates like Julia's maximum)
-__global__ __launch_bounds__(TPB) void step_stats_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+// maximum(abs, x) and x'x   (src/optimize.jl:149, src/iterators.jl:160; NaN propagates like Julia's maximum).
+// Two stages: per-workgroup partials (max, nan flag, sum of squares), then one small finishing workgroup.
+constexpr int RED_BLOCKS = 256;
+__global__ __launch_bounds__(TPB) void step_stats_partial_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ part) {
     __shared__ double red[TPB / 64];
     double m = 0, s = 0; bool nan = false;
-    for (int64_t i = threadIdx.x; i < n; i += TPB) { double v = x[i]; nan |= (v != v); m = fmax(m, fabs(v)); s += v * v; }
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) { double v = x[i]; nan |= (v != v); m = fmax(m, fabs(v)); s += v * v; }
     double mm = block_max(m, red);
     double ss = block_sum(s, red);
     double nn = block_max(nan ? 1.0 : 0.0, red);
-    if (threadIdx.x == 0) { out[1] = nn > 0 ? NAN : mm; out[2] = ss; }
+    if (threadIdx.x == 0) { part[3 * blockIdx.x] = mm; part[3 * blockIdx.x + 1] = nn; part[3 * blockIdx.x + 2] = ss; }
+}
+__global__ __launch_bounds__(TPB) void step_stats_finish_kernel(const double* __restrict__ part, int nb, double* __restrict__ out) {
+    __shared__ double red[TPB / 64];
+    double m = 0, s = 0, nn = 0;
+    for (int i = threadIdx.x; i < nb; i += TPB) { m = fmax(m, part[3 * i]); nn = fmax(nn, part[3 * i + 1]); s += part[3 * i + 2]; }
+    double mm = block_max(m, red); double ss = block_sum(s, red); double n2 = block_max(nn, red);
+    if (threadIdx.x == 0) { out[1] = n2 > 0 ? NAN : mm; out[2] = ss; }
 }
 // initlambda's max |H_ii|   src/iterators.jl:131-137
-__global__ __launch_bounds__(TPB) void max_abs_diag_kernel(const double* __restrict__ A, const int64_t* __restrict__ diag_off,
-                                                           const int32_t* __restrict__ bs, int64_t nb, int64_t ld_dense, double* __restrict__ out) {
+__global__ __launch_bounds__(TPB) void max_abs_diag_partial_kernel(const double* __restrict__ A, const int64_t* __restrict__ diag_off,
+                                                                   const int32_t* __restrict__ bs, int64_t nb, int64_t ld_dense, double* __restrict__ part) {
     __shared__ double red[TPB / 64];
     double m = 0;
-    for (int64_t k = threadIdx.x; k < nb; k += TPB) {
+    for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < nb; k += (int64_t)gridDim.x * TPB) {
         const int n = bs[k]; const int64_t o = diag_off[k]; const int64_t ld = ld_dense ? ld_dense : n;
+        if (o < 0) continue;
         for (int i = 0; i < n; ++i) m = fmax(m, fabs(A[o + i + ld * i]));
     }
     double mm = block_max(m, red);
-    if (threadIdx.x == 0) out[3] = mm;
+    if (threadIdx.x == 0) part[blockIdx.x] = mm;
+}
+__global__ __launch_bounds__(TPB) void max_finish_kernel(const double* __restrict__ part, int nb, double* __restrict__ out, int slot) {
+    __shared__ double red[TPB / 64];
+    double m = 0;
+    for (int i = threadIdx.x; i < nb; i += TPB) m = fmax(m, part[i]);
+    double mm = block_max(m, red);
+    if (threadIdx.x == 0) out[slot] = mm;
 }
 
 // ================================================================================================
@@ -471,13 +488,17 @@ int enqueue_retract(nlls_ctx* c, int to, int from) {
     return NLLS_OK;
 }
 int enqueue_step_stats(nlls_ctx* c) {
-    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(TPB), 0, c->stream, c->x.p, c->info.ndof, c->scalars.p);
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + TPB - 1) / TPB, RED_BLOCKS));
+    hipLaunchKernelGGL(step_stats_partial_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->x.p, c->info.ndof, c->partials.p);
+    hipLaunchKernelGGL(step_stats_finish_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, nb, c->scalars.p);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
 int enqueue_max_abs_diag(nlls_ctx* c) {
-    hipLaunchKernelGGL(max_abs_diag_kernel, dim3(1), dim3(TPB), 0, c->stream, c->A.p, c->d_diag_off.p, c->d_blocksizes.p, c->info.nblocks,
-                       c->info.is_sparse ? (int64_t)0 : c->info.ndof, c->scalars.p);
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.nblocks + TPB - 1) / TPB, RED_BLOCKS));
+    hipLaunchKernelGGL(max_abs_diag_partial_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->A.p, c->d_diag_off.p, c->d_blocksizes.p, c->info.nblocks,
+                       c->info.is_sparse ? (int64_t)0 : c->info.ndof, c->partials.p);
+    hipLaunchKernelGGL(max_finish_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, nb, c->scalars.p, 3);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }

@@ -164,3 +164,9 @@ def test_so3_adaptive_band_with_border():   # the kernel variable couples to eve
     q = synthetic.create_so3_ba_problem(100, 3000, 0.08, seed=4, adaptive=True)
     info = check_problem(synthetic.perturb_ba_problem(q, 1e-3, 1e-3), expect_sparse=1, lam_scale=1e-4)
     assert info.solve_mode == 2 and info.nborder_dof == 3
+
+
+def test_ba_wide_points_fast_elimination():   # points seen by 11-12 cameras: more E columns than lanes (two per lane)
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(150, 3000, 0.075, seed=9), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.solve_mode == 2 and info.bandwidth >= 64
