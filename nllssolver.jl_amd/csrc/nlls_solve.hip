@@ -498,57 +498,75 @@ __global__ __launch_bounds__(64) void bwd_diag_kernel(const double* __restrict__
 
 // ---------------------------------------------------------------------------------------------------
 // bordered-band LDL' + both triangular solves in ONE persistent workgroup (narrow-band reduced systems,
-// e.g. the camera chain of sequential bundle adjustment: 6000 dof, half bandwidth 66).
-// A banded factorisation is a chain of n dependent pivots, so it is latency- not throughput-bound: the whole
-// active window (columns j..j+bw, each with its band part, the border rows and the rhs entry) lives in an LDS
-// ring; all 256 lanes share the rank-1 update of the window (one barrier per pivot); columns stream in from HBM
-// in chunks that are prefetched into registers one chunk ahead, and the factor streams out for the backward pass.
+// e.g. the camera chain of sequential bundle adjustment: 6000 dof, half bandwidth 65).
+// A banded factorisation is a chain of n dependent pivots: latency- not throughput-bound.  Design:
+//  * the active window (columns j+1..j+bw) lives in REGISTERS: lane t, slot q owns SEG consecutive entries of one
+//    window column for that column's whole life (bw pivots), so the rank-1 update costs one LDS read + one FMA per
+//    entry and no LDS write; only the next pivot column is published to LDS (double-buffered), one barrier per pivot;
+//  * border rows (dense rows ordered last) and the rhs ride along as extra rows (tiny LDS arrays);
+//  * columns stream in from HBM through an LDS ring, prefetched into registers one chunk ahead behind an LDS-only
+//    barrier (a __syncthreads() would drain vmcnt and put HBM latency on the per-pivot critical path);
+//  * the backward pass runs in "axpy" form on ONE wave: each lane keeps the partially reduced unknowns of its rows
+//    in registers, x_i is broadcast with v_readlane, no cross-lane reduction; waves 1-3 stage the factor.
 // ---------------------------------------------------------------------------------------------------
-struct BandArgs { const double* Sb; double* Lb; double* xr; int n_band, bw, nbd, H, CH, PFC, RC, SEG, Bp, Hp; int* status; };
+struct BandArgs { const double* Sb; double* Lb; double* xr; int n_band, bw, nbd, H, CH, PFC, RC, NSC; int* status; };
 
-// SEG: entries per update segment, NSEG: segments per lane.  In LDS a column's band part (bw+1 entries) is followed
-// by SEG zeros (Bp = bw+1+SEG), so every segment is exactly SEG long and the rank-1 update is branch-free with
-// immediate LDS offsets: a segment that runs past the entries pivot j touches reads zeros as sources, so the extra
-// destinations (real entries of the column, or its zero pad) are rewritten unchanged.
-template <int SEG, int NSEG>
+template <int SEG, int NSLOT>
 __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_band = a.n_band, bw = a.bw, nbd = a.nbd, H = a.H, CH = a.CH, RC = a.RC, nbr = nbd + 1, Bp = a.Bp, Hp = a.Hp;
-    double* W = sm;                               // RC * Hp ring of columns: [band part padded to Bp | border rows | rhs]
-    double* Cl = W + (size_t)RC * Hp;             // nbr x nbr border corner (col-major, lower), last row = rhs
+    const int n_band = a.n_band, bw = a.bw, nbd = a.nbd, H = a.H, CH = a.CH, RC = a.RC, nbr = nbd + 1, NSC = a.NSC;
+    const int RCW = bw + 1;                       // window columns (the pivot column + bw columns it updates)
+    const int PV = 2 * NSC * SEG + 2 * SEG;       // published pivot column: band entries, then zeros (covers dc + e0 + SEG of any slot)
+    double* W = sm;                               // RC * H landing ring of columns in global layout [band | border | rhs]
+    double* piv = W + (size_t)RC * H;             // 2 * PV   published pivot columns (double-buffered)
+    const int BWS = RCW + 1;                      // one spare slot: the entering column is written while the pivot's is still read
+    double* Bw = piv + 2 * PV;                    // BWS * nbr  border rows + rhs of the window columns (slot = column % BWS)
+    double* Cl = Bw + (size_t)BWS * nbr;          // nbr x nbr border corner (col-major, lower), last row = rhs
     double* xb = Cl + nbr * nbr;                  // nbr
-    double* bsum = xb + nbr;                      // 2 * CH   (backward pass)
-    volatile double* xs = bsum + 2 * CH;          // ring of 256 solved unknowns (backward pass)
     const double* corner_g = a.Sb + (size_t)n_band * H;
     for (int e = tid; e < nbr * nbr; e += 256) Cl[e] = corner_g[e];
-    for (int e = tid; e < RC * Hp; e += 256) W[e] = 0.0;
-    // ---- this lane's update segments: column offset dc (1..bw), first entry e0 (multiple of SEG)
-    int seg_dc[NSEG], seg_e0[NSEG];
+    for (int e = tid; e < 2 * PV; e += 256) piv[e] = 0.0;
+    // ---- ownership: pair id = tid + 256 q -> (window column slot cs, segment s)
+    int own_cs[NSLOT], own_s[NSLOT];
 #pragma unroll
-    for (int q = 0; q < NSEG; ++q) {
-        int want = tid + 256 * q, dc = 1; seg_dc[q] = 0; seg_e0[q] = 0;
-        while (dc <= bw) { const int ns = (bw - dc + 1 + SEG - 1) / SEG; if (want < ns) { seg_dc[q] = dc; seg_e0[q] = want * SEG; break; } want -= ns; ++dc; }
-    }
+    for (int q = 0; q < NSLOT; ++q) { const int pid = tid + 256 * q; own_cs[q] = (pid < RCW * NSC) ? pid / NSC : -1; own_s[q] = pid % NSC; }
     const int ncorner = nbr * (nbr + 1) / 2;
     int cr = 0, cr2 = 0;                          // this lane's corner element (r >= r2), lanes < ncorner
     { int it = tid; while (cr2 < nbr && it >= nbr - cr2) { it -= nbr - cr2; ++cr2; } cr = cr2 + it; }
-    __syncthreads();
-    // ---- initial window: chunks 0 .. PFC-1 (global layout: H entries per column; LDS: Hp with the band part padded)
+    // ---- initial landing ring: chunks 0 .. PFC-1
     const int chunk_elems = CH * H;
-    auto lds_index = [&](int c0, int idx) { const int cc = idx / H, e = idx - cc * H; return (size_t)((c0 + cc) % RC) * Hp + (e <= bw ? e : Bp + (e - bw - 1)); };
     for (int m = 0; m < a.PFC; ++m) {
         const int c0 = m * CH;
-        for (int idx = tid; idx < chunk_elems; idx += 256) { const int c2 = c0 + idx / H; W[lds_index(c0, idx)] = (c2 < n_band) ? a.Sb[(size_t)c0 * H + idx] : 0.0; }
+        for (int idx = tid; idx < chunk_elems; idx += 256) { const int c2 = c0 + idx / H; W[(size_t)(c0 % RC) * H + idx] = (c2 < n_band) ? a.Sb[(size_t)c0 * H + idx] : 0.0; }
     }
+    __syncthreads();
+    // ---- initial window: columns 0..bw into registers / Bw, column 0 published
+    double reg[NSLOT][SEG];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) {
+        const int cs = own_cs[q];                 // column c = cs for the first window
+#pragma unroll
+        for (int m = 0; m < SEG; ++m) { const int e = own_s[q] * SEG + m; reg[q][m] = (cs >= 0 && e <= bw && cs < n_band) ? W[(size_t)(cs % RC) * H + e] : 0.0; }
+        if (cs == 0) {
+#pragma unroll
+            for (int m = 0; m < SEG; ++m) piv[own_s[q] * SEG + m] = reg[q][m];
+        }
+    }
+    for (int e = tid; e < RCW * nbr; e += 256) { const int c2 = e / nbr, r = e - c2 * nbr; Bw[e] = (c2 < n_band) ? W[(size_t)(c2 % RC) * H + bw + 1 + r] : 0.0; }
     double pf[12];
-    int sj = 0, jc = 0, mchunk = 0;                            // j % RC, j % CH, j / CH
+    int jb = 0, jc = 0, mchunk = 0, pb = 0;                     // j % BWS, j % CH, j / CH, pivot buffer
+    int wnew = RCW % RC;                                        // ring slot of column j + RCW
+    int dcq[NSLOT], e0q[NSLOT];                                 // per slot: column offset from the pivot, first entry
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) { dcq[q] = own_cs[q] >= 0 ? own_cs[q] : -(1 << 28); e0q[q] = own_s[q] * SEG; }
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();   // diagnostics only (nlls_get_solve_stats)
     for (int j = 0; j < n_band; ++j) {
-        // the previous pivot's LDS updates are complete.  Raw barrier behind an LDS-only wait: a __syncthreads()
-        // would also drain vmcnt, i.e. put the factor stores and the chunk prefetch on the per-pivot critical path.
+        // the pivot column j is published.  Raw barrier behind an LDS-only wait (see header).
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const double* col = W + (size_t)sj * Hp;
+        const double* col = piv + pb * PV;        // band entries of column j (entry 0 = d), zeros behind
+        double* nxt = piv + (pb ^ 1) * PV;
+        const double* bcol = Bw + (size_t)jb * nbr;   // border rows + rhs of column j
         double d = col[0];
         if (d == 0.0 || d != d) { if (tid == 0) atomicCAS(a.status, 0, 1 + j); d = 1.0; }
         const double id = 1.0 / d;
@@ -558,35 +576,49 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
             for (int k = 0; k < 12; ++k) { const int idx = tid + 256 * k; const int c2 = c0 + idx / H;
                 pf[k] = (idx < chunk_elems && c2 < n_band) ? a.Sb[(size_t)c0 * H + idx] : 0.0; }
         }
-        // band part of the rank-1 update: W[col j+dc][e] -= col_j[dc+e] * col_j[dc] / d
+        // ---- rank-1 update of the register window:  (column j+dc)[e] -= col[dc+e] * col[dc] / d   (branch-free:
+        //      an inactive slot multiplies by 0; sources past the band part are the zero pad of the published column)
 #pragma unroll
-        for (int q = 0; q < NSEG; ++q) if (seg_dc[q]) {
-            const int dc = seg_dc[q], e0 = seg_e0[q];
-            const double l = col[dc] * id;
-            int sl = sj + dc; if (sl >= RC) sl -= RC;
-            double* dst = W + (size_t)sl * Hp + e0; const double* src = col + dc + e0;
-            double sv[SEG], dv[SEG];
+        for (int q = 0; q < NSLOT; ++q) {
+            const int dc = dcq[q], e0 = e0q[q];
+            const int dci = dc > 0 ? dc : 0;
+            const double cdc = col[dci];
+            const double l = (dc > 0 && e0 <= bw - dc) ? cdc * id : 0.0;
+            const double* src = col + dci + e0;
 #pragma unroll
-            for (int m = 0; m < SEG; ++m) { sv[m] = src[m]; dv[m] = dst[m]; }
+            for (int m = 0; m < SEG; ++m) reg[q][m] = fma(-src[m], l, reg[q][m]);
+            if (dc == 1) {                                      // next pivot column: publish
 #pragma unroll
-            for (int m = 0; m < SEG; ++m) dst[m] = dv[m] - sv[m] * l;
+                for (int m = 0; m < SEG; ++m) nxt[e0 + m] = reg[q][m];
+            }
+            if (dc == 0) {                                      // the pivot column's slot now takes column j + RCW
+                const bool have = j + RCW < n_band; const double* wsrc = W + (size_t)wnew * H + e0;
+#pragma unroll
+                for (int m = 0; m < SEG; ++m) reg[q][m] = (have && e0 + m <= bw) ? wsrc[m] : 0.0;
+            }
+            dcq[q] = (dc == 0) ? bw : dc - 1;
         }
-        // border rows + rhs of column j+dc (lanes 0..bw-1), border corner (lanes < ncorner)
+        // ---- border rows + rhs of the window columns (lanes 0..bw-1), border corner (lanes < ncorner)
         if (tid < bw) {
             const int dc = tid + 1; const double l = col[dc] * id;
-            int sl = sj + dc; if (sl >= RC) sl -= RC;
-            double* dst = W + (size_t)sl * Hp + Bp;
-            for (int r = 0; r < nbr; ++r) dst[r] -= col[Bp + r] * l;
+            int cs = jb + dc; if (cs >= BWS) cs -= BWS;
+            double* dst = Bw + (size_t)cs * nbr;
+            for (int r = 0; r < nbr; ++r) dst[r] -= bcol[r] * l;
         }
-        if (tid < ncorner) Cl[cr + nbr * cr2] -= col[Bp + cr] * col[Bp + cr2] * id;
-        for (int e = tid; e < H; e += 256) a.Lb[(size_t)j * H + e] = (e == 0) ? d : col[e <= bw ? e : Bp + (e - bw - 1)] * id;   // factor column: D on top, L below
-        if (jc == CH - 1) {                                    // land the prefetched chunk: its ring slots held columns < j
+        if (tid < ncorner) Cl[cr + nbr * cr2] -= bcol[cr] * bcol[cr2] * id;
+        // ---- factor column j: D on top, L below (fire and forget)
+        if (tid < H) a.Lb[(size_t)j * H + tid] = (tid == 0) ? d : (tid <= bw ? col[tid] : bcol[tid - bw - 1]) * id;
+        // the spare border slot takes column j + RCW (first touched at the next pivot)
+        if (tid >= 64 && tid < 64 + nbr) { int cs = jb + RCW; if (cs >= BWS) cs -= BWS; Bw[(size_t)cs * nbr + (tid - 64)] = (j + RCW < n_band) ? W[(size_t)wnew * H + bw + 1 + (tid - 64)] : 0.0; }
+        if (jc == CH - 1) {                                    // land the prefetched chunk: its ring slots held columns already in registers
             const int c0 = (mchunk + a.PFC) * CH;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int idx = tid + 256 * k; if (idx < chunk_elems) W[lds_index(c0, idx)] = pf[k]; }
+            for (int k = 0; k < 12; ++k) { const int idx = tid + 256 * k; if (idx < chunk_elems) W[(size_t)(c0 % RC) * H + idx] = pf[k]; }
         }
-        if (++sj == RC) sj = 0;
+        if (++jb == BWS) jb = 0;
+        if (++wnew == RC) wnew = 0;
         if (++jc == CH) { jc = 0; ++mchunk; }
+        pb ^= 1;
     }
     __syncthreads();
     const unsigned long long t_factor = __builtin_amdgcn_s_memtime();
@@ -603,41 +635,59 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
     }
     __threadfence();
     __syncthreads();
-    // ---- backward pass  L' x = z  over the banded part, chunk by chunk from the bottom: wave 0 walks the columns,
-    //      waves 1-3 stage the next chunk of the factor (and its border contribution) meanwhile
-    double* Lc = W;                                            // 2 * chunk_elems
+    // ---- backward pass  L' x = z  (unit diagonal), rows n_band-1 .. 0, in axpy form on wave 0.
+    // Lane l keeps the partially reduced unknown of its rows r = l (mod 64) in registers, one per 64-row block
+    // (block index mod 3: the window [i-bw, i] spans at most three blocks for bw <= 127).  Waves 1-3 stage the factor
+    // columns (global layout) into the ring W, one chunk ahead; one barrier per chunk of CH rows.
     const int M = (n_band + CH - 1) / CH;
     auto stage = [&](int m, int t0, int nt) {
-        double* dst = Lc + (size_t)(m & 1) * chunk_elems; const size_t g0 = (size_t)m * CH * H;
-        const int ncol = min(CH, n_band - m * CH);
+        if (m < 0) return;
+        const int c0 = m * CH; const int ncol = min(CH, n_band - c0);
+        double* dst = W + (size_t)(c0 % RC) * H; const size_t g0 = (size_t)c0 * H;
         for (int idx = t0; idx < ncol * H; idx += nt) dst[idx] = a.Lb[g0 + idx];
     };
-    auto border_part = [&](int m, int t0, int nt) {
-        const double* src = Lc + (size_t)(m & 1) * chunk_elems; const int ncol = min(CH, n_band - m * CH);
-        for (int jj = t0; jj < ncol; jj += nt) { double v = 0; for (int r = 0; r < nbd; ++r) v += src[(size_t)jj * H + bw + 1 + r] * xb[r]; bsum[(m & 1) * CH + jj] = v; }
-    };
-    stage(M - 1, tid, 256);
+    const int PFB = a.PFC;                                     // chunks that must be resident below the current one
+    for (int m = M - 1; m >= M - PFB && m >= 0; --m) stage(m, tid, 256);
     __syncthreads();
-    border_part(M - 1, tid, 256);
-    __syncthreads();
+    // za/zb/zc: this lane's rows in blocks B, B-1, B-2 of the current row i (rotated when i crosses a 64-row block)
+    double za = 0, zb = 0, zc = 0;
+    auto zinit = [&](int ringslot) { const double* c2 = W + (size_t)ringslot * H; double v = c2[bw + 1 + nbd]; for (int q = 0; q < nbd; ++q) v -= c2[bw + 1 + q] * xb[q]; return v; };
+    if (wave == 0) {   // rows [n_band-1-bw, n_band-1] start as z = rhs entry - border part; later rows are initialised when they enter the window
+        const int Btop = (n_band - 1) >> 6;
+        for (int r = n_band - 1; r >= max(0, n_band - 1 - bw); --r) if ((r & 63) == lane) { const double v = zinit(r % RC); const int k = Btop - (r >> 6); if (k == 0) za = v; else if (k == 1) zb = v; else zc = v; }
+    }
+    int rin_slot = ((n_band - 2 - bw) % RC + RC) % RC;          // ring slot of the row entering the window next (i - 1 - bw)
     for (int m = M - 1; m >= 0; --m) {
         if (wave == 0) {
-            const double* src = Lc + (size_t)(m & 1) * chunk_elems; const int ncol = min(CH, n_band - m * CH);
-            for (int jj = ncol - 1; jj >= 0; --jj) {
-                const int j = m * CH + jj; const double* lc = src + (size_t)jj * H;
-                double part = 0;
-                for (int e = 1 + lane; e <= bw; e += 64) if (j + e < n_band) part += lc[e] * xs[(j + e) & 255];
-                part = wsum(part);
-                part = __shfl(part, 0, 64);
-                const double xj = lc[bw + 1 + nbd] - part - bsum[(m & 1) * CH + jj];
-                if (lane == 0) { xs[j & 255] = xj; a.xr[j] = xj; }
-                __builtin_amdgcn_wave_barrier();
+            const int hi = min(n_band, (m + 1) * CH) - 1;
+            int i = hi;
+            while (i >= m * CH) {
+                const int B = i >> 6; const int lo = max(m * CH, B << 6);       // rows [lo, i] share block B
+                // per-lane LDS offsets of L(i, r_k), r_k = 64 (B - k) + lane: they decrease by one entry per step
+                int e_a = i - ((B << 6) + lane), e_b = e_a + 64, e_c = e_a + 128;
+                const int ra = (B << 6) + lane, rb = ra - 64, rc3 = ra - 128;
+                const double* pa = W + (size_t)((ra % RC + RC) % RC) * H + e_a;
+                const double* pbp = W + (size_t)((rb % RC + RC) % RC) * H + e_b;
+                const double* pc = W + (size_t)((rc3 % RC + RC) % RC) * H + e_c;
+                for (; i >= lo; --i) {
+                    const int li = i & 63;
+                    const double xi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(za), li), __builtin_amdgcn_readlane(__double2loint(za), li));
+                    if (lane == li) a.xr[i] = xi;
+                    const double la = (e_a >= 1 && e_a <= bw) ? *pa : 0.0;
+                    const double lb = (e_b <= bw && rb >= 0) ? *pbp : 0.0;
+                    const double lc = (e_c <= bw && rc3 >= 0) ? *pc : 0.0;
+                    za = fma(-la, xi, za); zb = fma(-lb, xi, zb); zc = fma(-lc, xi, zc);
+                    // the row entering the window at the next step: rin = i - 1 - bw
+                    const int rin = i - 1 - bw;
+                    if (rin >= 0 && (rin & 63) == lane) { const double v = zinit(rin_slot); const int k = B - (rin >> 6); if (k == 0) za = v; else if (k == 1) zb = v; else zc = v; }
+                    if (--rin_slot < 0) rin_slot = RC - 1;
+                    --e_a; --e_b; --e_c; --pa; --pbp; --pc;
+                }
+                if (i >= 0 && (i >> 6) != B) { za = zb; zb = zc; zc = 0.0; }   // crossed into block B-1
             }
-        } else if (m > 0) {
-            stage(m - 1, tid - 64, 192);
+        } else {
+            stage(m - PFB, tid - 64, 192);
         }
-        __syncthreads();
-        if (m > 0) border_part(m - 1, tid, 256);
         __syncthreads();
     }
     if (tid == 0) { a.status[2] = (int)((t_factor - t_begin) >> 10); a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_factor) >> 10); }
@@ -758,15 +808,16 @@ int enqueue_solve(nlls_ctx* c) {
     } else if (band) {
         hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s.p);
         BandArgs a{}; a.Sb = c->S.p; a.Lb = c->Lwork.p; a.xr = c->s.p; a.n_band = L.n_band; a.bw = L.bw; a.nbd = L.nbd; a.H = L.H; a.CH = c->band_CH; a.status = c->d_status.p;
-        a.PFC = (L.bw + 1 + a.CH - 1) / a.CH + 1; a.RC = (a.PFC + 1) * a.CH; a.SEG = c->band_SEG;
-        a.Bp = L.bw + 1 + a.SEG; a.Hp = a.Bp + L.nbd + 1;   // SEG zero entries behind the band part keep the update branch-free
+        a.PFC = (L.bw + 1 + a.CH - 1) / a.CH + 1; a.RC = (a.PFC + 1) * a.CH; a.NSC = (L.bw + 1 + c->band_SEG - 1) / c->band_SEG;
         const int nbr = L.nbd + 1;
-        const size_t lds = sizeof(double) * ((size_t)a.RC * a.Hp + (size_t)nbr * nbr + nbr + 2 * a.CH + 256 + 8);
-        if (c->band_SEG == 8 && c->band_NSEG == 1) hipLaunchKernelGGL((band_ldlt_solve_kernel<8, 1>), dim3(1), dim3(256), lds, c->stream, a);
-        else if (c->band_SEG == 10 && c->band_NSEG == 1) hipLaunchKernelGGL((band_ldlt_solve_kernel<10, 1>), dim3(1), dim3(256), lds, c->stream, a);
-        else if (c->band_SEG == 12 && c->band_NSEG == 1) hipLaunchKernelGGL((band_ldlt_solve_kernel<12, 1>), dim3(1), dim3(256), lds, c->stream, a);
-        else if (c->band_SEG == 8 && c->band_NSEG == 2) hipLaunchKernelGGL((band_ldlt_solve_kernel<8, 2>), dim3(1), dim3(256), lds, c->stream, a);
-        else hipLaunchKernelGGL((band_ldlt_solve_kernel<12, 2>), dim3(1), dim3(256), lds, c->stream, a);
+        const size_t lds = sizeof(double) * ((size_t)a.RC * L.H + 2 * (size_t)(2 * a.NSC * c->band_SEG + 2 * c->band_SEG) + (size_t)(L.bw + 2) * nbr + (size_t)nbr * nbr + nbr + 8);
+#define LAUNCH_BAND(SEG, NSLOT) hipLaunchKernelGGL((band_ldlt_solve_kernel<SEG, NSLOT>), dim3(1), dim3(256), lds, c->stream, a)
+        if (c->band_SEG == 10 && c->band_NSEG == 2) LAUNCH_BAND(10, 2);
+        else if (c->band_SEG == 8 && c->band_NSEG == 1) LAUNCH_BAND(8, 1);
+        else if (c->band_SEG == 12 && c->band_NSEG == 2) LAUNCH_BAND(12, 2);
+        else if (c->band_SEG == 12 && c->band_NSEG == 4) LAUNCH_BAND(12, 4);
+        else LAUNCH_BAND(16, 4);
+#undef LAUNCH_BAND
     } else {
         hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s.p);
         for (int k = 0; k < nblk; ++k) {

@@ -421,17 +421,17 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     else if (c->n_band >= 128 && !(flags & NLLS_FLAG_NO_BAND)) {
         // bordered-band LDL' in one persistent workgroup: needs the LDS ring + prefetch registers to fit
         const int H = (int)bw + 1 + c->nbd + 1;
-        // update segments: (SEG entries) x (NSEG per lane) must cover the band triangle with 256 lanes
+        // register window: (bw+1) columns x ceil((bw+1)/SEG) segments, NSLOT segments per lane of a 256-lane workgroup
         int SEG = 0, NSEG = 0;
-        for (auto cfg : {std::pair<int, int>{8, 1}, {10, 1}, {12, 1}, {8, 2}, {12, 2}}) {
-            int64_t ns = 0; for (int64_t dc = 1; dc <= bw; ++dc) ns += (bw - dc + 1 + cfg.first - 1) / cfg.first;
-            if (ns <= 256 * cfg.second) { SEG = cfg.first; NSEG = cfg.second; break; }
+        for (auto cfg : {std::pair<int, int>{8, 1}, {10, 2}, {12, 2}, {12, 4}, {16, 4}}) {
+            const int64_t nsc = (bw + 1 + cfg.first - 1) / cfg.first;
+            if ((bw + 1) * nsc <= 256 * cfg.second) { SEG = cfg.first; NSEG = cfg.second; break; }
         }
-        if (SEG) for (int CH : {32, 16, 8}) {
+        if (SEG && bw <= 127) for (int CH : {32, 16, 8}) {
             const int PFC = ((int)bw + 1 + CH - 1) / CH + 1, RC = (PFC + 1) * CH;
-            const int Bp = (int)bw + 1 + SEG, Hp = Bp + c->nbd + 1;
-            const size_t lds = sizeof(double) * ((size_t)RC * Hp + (size_t)(c->nbd + 1) * (c->nbd + 2) + 2 * CH + 256 + 8);
-            if (H <= 255 && bw >= 1 && lds <= 150 * 1024 && CH * H <= 12 * 256 && (size_t)RC * Hp >= (size_t)2 * CH * H) {
+            const int nbr = c->nbd + 1, NSC = ((int)bw + 1 + SEG - 1) / SEG;
+            const size_t lds = sizeof(double) * ((size_t)RC * H + 2 * (size_t)(2 * NSC * SEG + 2 * SEG) + (size_t)(bw + 2) * nbr + (size_t)nbr * nbr + nbr + 8);
+            if (H <= 255 && bw >= 1 && lds <= 150 * 1024 && CH * H <= 12 * 256) {
                 c->solve_mode = SOLVE_BAND; c->band_CH = CH; c->band_H = H; c->band_SEG = SEG; c->band_NSEG = NSEG; break; }
         }
     }
