@@ -39,6 +39,8 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     c->device = dev;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return NLLS_ERR_HIP; }
     c->own_stream = true;
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return NLLS_ERR_HIP; }
     *out = c;
     return NLLS_OK;
 }
@@ -48,6 +50,9 @@ int nlls_ctx_destroy(nlls_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     hipStream_t s = ctx->own_stream ? ctx->stream : nullptr;
     delete ctx;
     if (s) (void)hipStreamDestroy(s);
@@ -259,6 +264,7 @@ static int time_loop(nlls_ctx* ctx, int reps, float* ms_avg, int (*fn)(nlls_ctx*
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return NLLS_OK;
 }
+
 int nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
     NEED_READY(); int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c); });
     ctx->have_grad = true; return rc;

@@ -50,6 +50,7 @@ struct Tile {
 };
 constexpr uint32_t TILE_PARTIAL = 1;   // rows shared with other tiles: flush the image with atomics
 constexpr uint32_t TILE_DIRECT  = 2;   // segment too large for LDS: off-diagonal blocks go straight to HBM atomics
+constexpr uint32_t TILE_NOZERO  = 4;   // exclusive rows + unique off-diagonal destinations: every image entry is written, no zero fill
 
 struct RowInfo {
     uint32_t diag_off;      // image-relative offset of the diagonal block
@@ -61,6 +62,8 @@ constexpr uint32_t DEST_NONE       = 0xFFFFFFFFu;
 constexpr uint32_t OWN_ROW_MASK    = 0xFFFFu;
 constexpr uint32_t OWN_COST_OWNER  = 1u << 16;   // this entry adds the block's cost to the total
 constexpr uint32_t OWN_KERNEL_FREE = 1u << 17;   // adaptive residual whose kernel variable is optimised
+constexpr uint32_t OWN_COPY_SHIFT  = 18;         // which of the ACC_COPIES diagonal accumulators of its row the entry adds to
+constexpr uint32_t ACC_COPIES      = 4;          // (spreads the LDS atomics of a row's entries over distinct addresses)
 
 struct EntryList {          // all (cost, slot) incidences of one cost group and one slot, sorted by block row
     int slot = 0;
@@ -71,6 +74,7 @@ struct EntryList {          // all (cost, slot) incidences of one cost group and
     DevBuf<RowInfo>  rows;
     DevBuf<Tile>     light, heavy;
     int64_t nlight = 0, nheavy = 0;
+    bool unique_dest = false;
     uint32_t light_lds = 0, heavy_lds = 0;   // max image doubles over the tiles
 };
 
@@ -112,6 +116,8 @@ struct nlls_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr;           // side stream: heavy-row tiles run beside the light-row tiles
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     int rank = 0, nranks = 1;
 

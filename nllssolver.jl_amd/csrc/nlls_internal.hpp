@@ -27,6 +27,7 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot /* scalars[o
 // solve (nlls_solve.hip)
 int enqueue_solve(nlls_ctx* c);
 
+
 inline double* vars_ptr(nlls_ctx* c, int which) { return c->vars[c->vars_slot[which]].p; }
 
 }  // namespace nlls

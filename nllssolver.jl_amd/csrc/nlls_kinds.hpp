@@ -373,11 +373,24 @@ struct BlockGH {
     double dck[3];          // d rho / d kernel   (adaptive, kernel optimised)
     double d2ck[3][4];      // d2 rho / d kernel d(kernel, cost)
 
+    // raw storage of the block's variables (one row per getvars() slot, kernel included), so that callers can issue
+    // the gathers of several blocks before evaluating any of them
+    static constexpr int NSLOTS = R::NDEPS;
+    static NLLS_DEV void load(const double* __restrict__ vars, const uint32_t* voff, double (*st)[MAXST]) {
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+#pragma unroll
+                for (int q = 0; q < var_storage(R::SK[S], R::SD[S]); ++q) st[S][q] = vars[voff[S] + q]; }(), ...);
+        }(std::make_integer_sequence<int, R::NDEPS>{});
+    }
     NLLS_DEV void compute(const double* __restrict__ vars, const uint32_t* voff, const double* data, const RobustSpec& rk, bool kernel_free) {
+        double st[R::NDEPS][MAXST]; load(vars, voff, st); compute_st(st, data, rk, kernel_free);
+    }
+    NLLS_DEV void compute_st(const double (*st)[MAXST], const double* data, const RobustSpec& rk, bool kernel_free) {
         using T = Dual<NP>;
         T sv[I::NS > 0 ? I::NS : 1][MAXST];
         [&]<int... S>(std::integer_sequence<int, S...>) {
-            (var_load<R::SK[S + R::ADAPT], R::SD[S + R::ADAPT], T>(vars + voff[S + R::ADAPT], I::joff(S + R::ADAPT), sv[S]), ...);
+            (var_load<R::SK[S + R::ADAPT], R::SD[S + R::ADAPT], T>(st[S + R::ADAPT], I::joff(S + R::ADAPT), sv[S]), ...);
         }(std::make_integer_sequence<int, I::NS>{});
         T r[M]; R::template eval<T>(data, sv, r);
         double c = 0;
@@ -392,13 +405,13 @@ struct BlockGH {
         double rho;
         if constexpr (R::ADAPT) {
             if (kernel_free) {                                  // residual.jl:79-88
-                Dual2 k = cg_robustifydkernel(vars + voff[0], c);
+                Dual2 k = cg_robustifydkernel(st[0], c);
                 rho = k.v; dc = k.g[3]; d2c = k.h[3][3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { dck[i] = k.g[i];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) d2ck[i][j] = k.h[i][j]; }
-            } else cg_robustifydcost(vars + voff[0], c, rho, dc, d2c);   // residual.jl:76-78
+            } else cg_robustifydcost(st[0], c, rho, dc, d2c);   // residual.jl:76-78
         } else robustifydcost_fixed(rk, c, rho, dc, d2c);
         cost = 0.5 * rho;
     }

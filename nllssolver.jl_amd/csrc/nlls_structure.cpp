@@ -32,7 +32,7 @@ static int fail(nlls_ctx* c, int code, const std::string& msg) { c->err = msg; r
 constexpr uint32_t LIGHT_MAX_ENTRIES = 256;    // one entry per lane of a 256-thread workgroup
 constexpr uint32_t LIGHT_IMG_MAX     = 6144;   // doubles of LDS image (48 KiB) -> 3 workgroups per CU
 constexpr uint32_t HEAVY_ROW_ENTRIES = 128;    // rows with more entries get a workgroup of their own
-constexpr uint32_t HEAVY_MAX_ENTRIES = 4096;   // entries per heavy tile; longer rows are split (PARTIAL)
+constexpr uint32_t HEAVY_MAX_ENTRIES = 1024;   // entries per heavy tile (4 per lane, loaded as one batch); longer rows are split (PARTIAL)
 
 int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
@@ -196,7 +196,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
                     rinfo[r].diag_off = (uint32_t)(c->diag_off[br] - t.data_off); rinfo[r].b_off = t.data_len + (uint32_t)(c->boffsets[br] - c->boffsets[br0]);
                     if (partial) row_zero[br] = 1;
                     for (int64_t e = L.rowptr[r]; e < L.rowptr[r + 1]; ++e) { entry_base[e] = t.data_off; dest[(size_t)e * d.ndeps + s] = (uint32_t)(r - r0); } }
-                E.light_lds = std::max(E.light_lds, t.data_len + t.b_len);
+                { const uint32_t dsz = (uint32_t)c->blocksizes[br0]; const uint32_t per_row = ACC_COPIES * (dsz * (dsz + 1) / 2 + dsz);
+                  E.light_lds = std::max(E.light_lds, t.data_len + t.b_len + t.nrows * per_row); }
                 light.push_back(t); if (partial) all_owner = false;
             };
             size_t r = 0;
@@ -221,7 +222,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
                 // light run: consecutive block rows present in this list
                 size_t r1 = r; uint32_t ents = 0; int64_t img = 0; bool partial = force_atomic;
                 while (r1 < nrows) {
-                    int64_t brr = L.rows[r1]; int64_t nee = L.rowptr[r1 + 1] - L.rowptr[r1]; int64_t sl = segs[brr + 1] - segs[brr] + c->blocksizes[brr];
+                    int64_t brr = L.rows[r1]; int64_t nee = L.rowptr[r1 + 1] - L.rowptr[r1]; const int64_t dsz = c->blocksizes[brr];
+                    int64_t sl = segs[brr + 1] - segs[brr] + dsz + ACC_COPIES * (dsz * (dsz + 1) / 2 + dsz);
                     if (r1 > r && brr != L.rows[r1 - 1] + 1) break;
                     if (nee > HEAVY_ROW_ENTRIES || sl > LIGHT_IMG_MAX) break;
                     if (r1 > r && (ents + nee > LIGHT_MAX_ENTRIES || img + sl > LIGHT_IMG_MAX || r1 - r >= 0xFFFF)) break;
@@ -237,12 +239,22 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
                     uint32_t own = dest[(size_t)e * d.ndeps + s] & OWN_ROW_MASK;
                     bool first_free = true; for (int t = 0; t < s; ++t) if (bi[in.varind[k * d.ndeps + t] - 1]) first_free = false;
                     if (first_free) own |= OWN_COST_OWNER;
+                    own |= (uint32_t)((e - L.rowptr[rr]) & (ACC_COPIES - 1)) << OWN_COPY_SHIFT;
                     if (d.adaptive && bi[in.varind[k * d.ndeps] - 1]) own |= OWN_KERNEL_FREE;
                     dest[(size_t)e * d.ndeps + s] = own;
                     for (int t = 0; t < d.ndeps; ++t) { if (t == s) continue; uint64_t bt = bi[in.varind[k * d.ndeps + t] - 1];
                         if (!bt || (int64_t)bt - 1 > br) continue;
                         int64_t bo = block_off(br, (int64_t)bt - 1); if (bo < 0) return fail(c, NLLS_ERR_INVALID_ARG, "internal: block missing from the pattern");
                         dest[(size_t)e * d.ndeps + t] = (uint32_t)(bo - entry_base[e]); } } }
+            // are the off-diagonal destinations unique (each stored block written by exactly one entry)?  Then the
+            // kernel uses plain LDS stores for them and exclusive tiles need not zero their image.
+            bool unique = true;
+            { std::vector<uint32_t> tmp;
+              for (size_t rr = 0; rr < nrows && unique; ++rr) { tmp.clear();
+                  for (int64_t e = L.rowptr[rr]; e < L.rowptr[rr + 1]; ++e) for (int t = 0; t < d.ndeps; ++t) if (t != s && dest[(size_t)e * d.ndeps + t] != DEST_NONE) tmp.push_back(dest[(size_t)e * d.ndeps + t]);
+                  std::sort(tmp.begin(), tmp.end()); for (size_t i = 1; i < tmp.size(); ++i) if (tmp[i] == tmp[i - 1]) { unique = false; break; } } }
+            E.unique_dest = unique;
+            if (unique) for (auto& tl : light) if (!(tl.flags & TILE_PARTIAL)) tl.flags |= TILE_NOZERO;
             // upload the list
             { std::vector<double> hd((size_t)E.n * d.ndata); std::vector<uint32_t> hv((size_t)E.n * d.ndeps);
               for (int64_t e = 0; e < E.n; ++e) { int64_t k = L.cost[e];

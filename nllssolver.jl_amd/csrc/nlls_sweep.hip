@@ -35,6 +35,24 @@ NLLS_DEV double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
+// wavefront sum on the VALU (DPP row shifts + row broadcasts, gfx9): the total lands in lane 63.  18 VALU
+// instructions per value; the ds_bpermute form (__shfl_down) costs an LDS round trip per step.
+template <int CTRL, int ROWMASK>
+NLLS_DEV double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, true);
+    const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);
+    return v + __hiloint2double(shi, slo);
+}
+NLLS_DEV double wave_sum_dpp63(double v) {
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds its row's sum
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's sum
+    return v;
+}
 NLLS_DEV double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
@@ -117,14 +135,19 @@ template <int KIND, int SLOT>
 __global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
                                                        const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ edest,
                                                        const RowInfo* __restrict__ rows, const Tile* __restrict__ tiles, RobustSpec rk,
-                                                       double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+                                                       int unique_dest, double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
     using R = Res<KIND>; using I = ResInfo<KIND>;
     constexpr int DS = I::dof(SLOT);
+    constexpr int NSYM = DS * (DS + 1) / 2, NACC = NSYM + DS;   // lower triangle of the diagonal block + b, per accumulator copy
     extern __shared__ __attribute__((aligned(16))) double img[];
     __shared__ double red[TPB / 64];
     const Tile t = tiles[blockIdx.x];
     const uint32_t imglen = t.data_len + t.b_len;
-    for (uint32_t i = threadIdx.x; i < imglen; i += TPB) img[i] = 0.0;
+    double* acc = img + imglen;                                 // [nrows][ACC_COPIES][NACC]
+    const uint32_t acclen = t.nrows * ACC_COPIES * NACC;
+    // exclusive rows whose off-diagonal blocks each have exactly one writer are fully overwritten: no zero fill
+    if (!(t.flags & TILE_NOZERO)) for (uint32_t i = threadIdx.x; i < imglen; i += TPB) img[i] = 0.0;
+    for (uint32_t i = threadIdx.x; i < acclen; i += TPB) acc[i] = 0.0;
     __syncthreads();
     double mycost = 0;
     for (uint32_t e = t.e0 + threadIdx.x; e < t.e1; e += TPB) {
@@ -136,30 +159,54 @@ __global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict_
         const uint32_t own = ds[SLOT];
         BlockGH<KIND> B; B.compute(vars, vo, d, rk, (own & OWN_KERNEL_FREE) != 0);
         if (own & OWN_COST_OWNER) mycost += B.cost;
-        const RowInfo ri = rows[t.row0 + (own & OWN_ROW_MASK)];
-        // diagonal block (full, both triangles: linearsystem.jl:140) and b (linearsystem.jl:159-170)
+        // diagonal block (lower triangle; mirrored at the flush) and b: LDS atomics into one of ACC_COPIES accumulators of
+        // the row, chosen by the entry's rank in its row, so that neighbouring lanes of a row hit different addresses
+        double* ar = acc + ((size_t)(own & OWN_ROW_MASK) * ACC_COPIES + ((own >> OWN_COPY_SHIFT) & (ACC_COPIES - 1))) * NACC;
+        {
+            int q = 0;
 #pragma unroll
-        for (int j = 0; j < DS; ++j)
+            for (int j = 0; j < DS; ++j)
 #pragma unroll
-            for (int i = 0; i < DS; ++i) atomicAdd(&img[ri.diag_off + i + DS * j], h_elem<KIND, SLOT, SLOT>(B, i, j));
+                for (int i = j; i < DS; ++i) atomicAdd(&ar[q++], h_elem<KIND, SLOT, SLOT>(B, i, j));
 #pragma unroll
-        for (int i = 0; i < DS; ++i) atomicAdd(&img[ri.b_off + i], g_elem<KIND, SLOT>(B, i));
+            for (int i = 0; i < DS; ++i) atomicAdd(&ar[NSYM + i], g_elem<KIND, SLOT>(B, i));
+        }
         // off-diagonal blocks this row owns: block(A, row(SLOT), row(T)) += H[SLOT range, T range]  (linearsystem.jl:148-149)
         static_for<R::NDEPS>([&](auto Tc) {
             constexpr int T = decltype(Tc)::value;
             if constexpr (T != SLOT) {
                 constexpr int DT = I::dof(T);
                 if (ds[T] != DEST_NONE) {
+                    if (unique_dest) {
 #pragma unroll
-                    for (int j = 0; j < DT; ++j)
+                        for (int j = 0; j < DT; ++j)
 #pragma unroll
-                        for (int i = 0; i < DS; ++i) atomicAdd(&img[ds[T] + i + DS * j], h_elem<KIND, SLOT, T>(B, i, j));
+                            for (int i = 0; i < DS; ++i) img[ds[T] + i + DS * j] = h_elem<KIND, SLOT, T>(B, i, j);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < DT; ++j)
+#pragma unroll
+                            for (int i = 0; i < DS; ++i) atomicAdd(&img[ds[T] + i + DS * j], h_elem<KIND, SLOT, T>(B, i, j));
+                    }
                 }
             }
         });
     }
-    double tc = block_sum(mycost, red);    // contains the barrier that completes the image
+    double tc = block_sum(mycost, red);    // contains the barrier that completes the image and the accumulators
     if (threadIdx.x == 0) partials[blockIdx.x] = tc;
+    __syncthreads();
+    // fold the accumulator copies into the image: full diagonal block (both triangles, linearsystem.jl:140) and b
+    for (uint32_t w = threadIdx.x; w < t.nrows * NACC; w += TPB) {
+        const uint32_t r = w / NACC, q = w - r * NACC;
+        const double* ar = acc + (size_t)r * ACC_COPIES * NACC + q;
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < (int)ACC_COPIES; ++k) v += ar[k * NACC];
+        const RowInfo ri = rows[t.row0 + r];
+        if ((int)q >= NSYM) img[ri.b_off + (q - NSYM)] = v;
+        else { int qq = q, j = 0; while (qq >= DS - j) { qq -= DS - j; ++j; } const int i = j + qq;
+               img[ri.diag_off + i + DS * j] = v; if (i != j) img[ri.diag_off + j + DS * i] = v; }
+    }
     __syncthreads();
     if (t.flags & TILE_PARTIAL) {
         for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) { double v = img[i]; if (v != 0.0) atomicAdd(&A[t.data_off + i], v); }
@@ -191,44 +238,56 @@ __global__ __launch_bounds__(TPB) void gh_heavy_kernel(const double* __restrict_
     double acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-    for (uint32_t e = t.e0 + threadIdx.x; e < t.e1; e += TPB) {
-        double d[R::NDATA]; uint32_t vo[R::NDEPS], ds[R::NDEPS];
+    // entries in batches of U per lane: all U entry records are loaded first, then all U variable gathers are in
+    // flight together (two memory round trips per batch instead of per entry: the row's wave is latency-bound)
+    constexpr int U = 4;
+    for (uint32_t base = t.e0; base < t.e1; base += TPB * U) {
+        double d[U][R::NDATA]; uint32_t vo[U][R::NDEPS], ds[U][R::NDEPS]; bool ok[U];
 #pragma unroll
-        for (int q = 0; q < R::NDATA; ++q) d[q] = edata[(size_t)e * R::NDATA + q];
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = base + u * TPB + threadIdx.x; ok[u] = e < t.e1; const uint32_t ee = ok[u] ? e : t.e0;
 #pragma unroll
-        for (int q = 0; q < R::NDEPS; ++q) { vo[q] = evoff[(size_t)e * R::NDEPS + q]; ds[q] = edest[(size_t)e * R::NDEPS + q]; }
-        const uint32_t own = ds[SLOT];
-        BlockGH<KIND> B; B.compute(vars, vo, d, rk, (own & OWN_KERNEL_FREE) != 0);
-        if (own & OWN_COST_OWNER) acc[NACC - 1] += B.cost;
-        {
-            int q = 0;
+            for (int q = 0; q < R::NDATA; ++q) d[u][q] = edata[(size_t)ee * R::NDATA + q];
 #pragma unroll
-            for (int j = 0; j < DS; ++j)
-#pragma unroll
-                for (int i = j; i < DS; ++i) acc[q++] += h_elem<KIND, SLOT, SLOT>(B, i, j);
-#pragma unroll
-            for (int i = 0; i < DS; ++i) acc[NTRI + i] += g_elem<KIND, SLOT>(B, i);
+            for (int q = 0; q < R::NDEPS; ++q) { vo[u][q] = evoff[(size_t)ee * R::NDEPS + q]; ds[u][q] = edest[(size_t)ee * R::NDEPS + q]; }
         }
-        static_for<R::NDEPS>([&](auto Tc) {
-            constexpr int T = decltype(Tc)::value;
-            if constexpr (T != SLOT) {
-                constexpr int DT = I::dof(T);
-                if (ds[T] != DEST_NONE) {
+        double st[U][R::NDEPS][MAXST];
 #pragma unroll
-                    for (int j = 0; j < DT; ++j)
+        for (int u = 0; u < U; ++u) BlockGH<KIND>::load(vars, vo[u], st[u]);
 #pragma unroll
-                        for (int i = 0; i < DS; ++i) {
-                            const double v = h_elem<KIND, SLOT, T>(B, i, j);
-                            if (direct) atomicAdd(&A[(size_t)ds[T] + i + DS * j], v); else atomicAdd(&img[ds[T] + i + DS * j], v);
-                        }
-                }
+        for (int u = 0; u < U; ++u) if (ok[u]) {
+            BlockGH<KIND> B; B.compute_st(st[u], d[u], rk, (ds[u][SLOT] & OWN_KERNEL_FREE) != 0);
+            if (ds[u][SLOT] & OWN_COST_OWNER) acc[NACC - 1] += B.cost;
+            {
+                int q = 0;
+#pragma unroll
+                for (int j = 0; j < DS; ++j)
+#pragma unroll
+                    for (int i = j; i < DS; ++i) acc[q++] += h_elem<KIND, SLOT, SLOT>(B, i, j);
+#pragma unroll
+                for (int i = 0; i < DS; ++i) acc[NTRI + i] += g_elem<KIND, SLOT>(B, i);
             }
-        });
+            static_for<R::NDEPS>([&](auto Tc) {
+                constexpr int T = decltype(Tc)::value;
+                if constexpr (T != SLOT) {
+                    constexpr int DT = I::dof(T);
+                    if (ds[u][T] != DEST_NONE) {
+#pragma unroll
+                        for (int j = 0; j < DT; ++j)
+#pragma unroll
+                            for (int i = 0; i < DS; ++i) {
+                                const double v = h_elem<KIND, SLOT, T>(B, i, j);
+                                if (direct) atomicAdd(&A[(size_t)ds[u][T] + i + DS * j], v); else atomicAdd(&img[ds[u][T] + i + DS * j], v);
+                            }
+                    }
+                }
+            });
+        }
     }
     // fixed-tree reduction of the row's diagonal block, b and cost
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) { double v = wave_sum(acc[i]); if (lane == 0) red[w][i] = v; }
+    for (int i = 0; i < NACC; ++i) { double v = wave_sum_dpp63(acc[i]); if (lane == 63) red[w][i] = v; }
     __syncthreads();
     const RowInfo ri = rows[t.row0];   // diag_off: offset of the diagonal block inside the row's segment
     if (threadIdx.x < NACC) {
@@ -417,7 +476,7 @@ static void launch_gh_slot(nlls_ctx* c, const Group& G, const double* vars, int6
         const EntryList& E = G.lists[SLOT];
         if (E.nlight > 0) {
             hipLaunchKernelGGL((gh_light_kernel<KIND, SLOT>), dim3((unsigned)E.nlight), dim3(TPB), E.light_lds * sizeof(double), c->stream,
-                               vars, E.data.p, E.voff.p, E.dest.p, E.rows.p, E.light.p, G.rk, c->A.p, c->b.p, c->partials.p + pbase);
+                               vars, E.data.p, E.voff.p, E.dest.p, E.rows.p, E.light.p, G.rk, E.unique_dest ? 1 : 0, c->A.p, c->b.p, c->partials.p + pbase);
             pbase += E.nlight;
         }
         if (E.nheavy > 0) {

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Runs only the accumulate (gradient) sweep and the cost sweep of a BA workload a few times: a short target for
+rocprofv3 --pmc passes (HBM traffic, LDS conflicts) and quick A/B timing of the sweep kernels."""
+import argparse, os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nllssolver_jl_amd as N
+from nllssolver_jl_amd import synthetic, _capi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ncam", type=int, default=1000); ap.add_argument("--npts", type=int, default=100000)
+ap.add_argument("--prop", type=float, default=0.01); ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--flags", type=int, default=0)
+a = ap.parse_args()
+p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(a.ncam, a.npts, a.prop, seed=1, robust=N.HuberKernel(0.01),
+                                                             outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+ctx = _capi.Context(0)
+info = ctx.upload(p.var_kind, p.var_dim, np.arange(1, p.nvariables + 1, dtype=np.uint64), p.groups(), a.flags)
+ctx.set_variables(p.variables)
+ms = ctx.time_sweep_gradhess(a.reps); msc = ctx.time_sweep_cost(a.reps)
+nobs = p.ncosts()
+alg = nobs * 32 + 8 * info.var_storage + 8 * (info.nnz_data + info.ndof)
+print(json.dumps({"nobs": nobs, "sweep_ms": ms, "cost_ms": msc, "alg_bytes": alg, "GBps": alg / ms / 1e6, "owner_path": info.owner_path}))
