@@ -197,10 +197,17 @@ int  nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out);
  * vars[to] = update(vars[from], x) for unfixed variables, copy for fixed ones. */
 int  nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from);
 
-/* ---- multi-GPU --------------------------------------------------------------------------------
- * Device buffers that must be summed across ranks.  After nlls_sweep_gradhess_local:
- * stage 0 = [cost | reduced-block diagonal data | reduced part of b].  After nlls_schur_local:
- * stage 1 = [S (lower, dense) | s].  Pointers are device addresses valid until the next upload. */
+/* ---- multi-GPU ----------------------------------------------------------------------
+ * One process per GPU; nlls_set_shard(rank, nranks) BEFORE nlls_upload_structure.  Every rank uploads the
+ * SAME full problem; the library keeps only the cost blocks this rank owns (a cost belongs to the rank
+ * that owns its eliminated variable: contiguous ranges of eliminated blocks balanced by cost count).
+ * Device buffers the caller sums over ranks (RCCL all-reduce over xGMI; pointers stay valid until the next
+ * upload):
+ *   stage 0  after nlls_sweep_gradhess_local : [cost | reduced-block rows of A.data | reduced part of b]
+ *   stage 1  after nlls_solve_local          : [S | s]   the reduced system
+ *   stage 2  after nlls_solve_finish         : x         (each rank holds its own eliminated blocks, rank 0 the rest)
+ * With nranks > 1, nlls_sweep_cost, nlls_quadform, nlls_grad_sqnorm, nlls_grad_quadform return this rank's
+ * PARTIAL sums and nlls_max_abs_diag its partial maximum: the caller reduces those scalars itself. */
 int  nlls_sweep_gradhess_local(nlls_ctx* ctx);
 int  nlls_sweep_gradhess_finish(nlls_ctx* ctx, double* cost_out);
 int  nlls_sweep_cost_local(nlls_ctx* ctx, int32_t which);
@@ -208,10 +215,10 @@ int  nlls_sweep_cost_finish(nlls_ctx* ctx, double* cost_out);
 int  nlls_solve_local(nlls_ctx* ctx);
 int  nlls_solve_finish(nlls_ctx* ctx, double* x_out);
 int  nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count);
-/* after nlls_solve_finish every rank holds x for its own eliminated blocks only;
- * this returns the [offset,count) range of x that this rank owns plus the reduced part */
 int  nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count,
                          int64_t* own_offset, int64_t* own_count);
+/* [0] rank, [1] nranks, [2] cost blocks owned, [3] doubles of A.data this rank writes, [4] dof of b it writes */
+int  nlls_get_shard_info(nlls_ctx* ctx, int64_t* out, int32_t n);
 
 /* ---- profiling helper: run the accumulate kernel(s) `reps` times between two HIP events on the
  * context's stream; returns average ms per sweep (used by bench.py for the roofline line). */

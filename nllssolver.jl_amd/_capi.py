@@ -23,7 +23,7 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_time_sweep_gradhess nlls_time_sweep_cost nlls_time_solve""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_time_sweep_gradhess nlls_time_sweep_cost nlls_time_solve""".split()
 
 
 class NllsError(RuntimeError):
@@ -92,6 +92,7 @@ def lib():
         L.nlls_solve_local.argtypes = [vp]; L.nlls_solve_finish.argtypes = [vp, vp]
         L.nlls_get_reduce_buffer.argtypes = [vp, i32, vp, vp]
         L.nlls_get_step_shard.argtypes = [vp, vp, vp, vp, vp]
+        L.nlls_get_shard_info.argtypes = [vp, vp, i32]
         L.nlls_time_sweep_gradhess.argtypes = [vp, i32, vp]; L.nlls_time_sweep_cost.argtypes = [vp, i32, vp]
         L.nlls_time_solve.argtypes = [vp, i32, vp]
         _lib = L
@@ -237,6 +238,31 @@ class Context:
 
     def retract(self, to=VARS_NEXT, frm=VARS_CURRENT):
         self._chk(self.L.nlls_retract(self.h, to, frm))
+
+    # ---- sharding ------------------------------------------------------------------------------------------
+    def set_shard(self, rank, nranks):
+        self._chk(self.L.nlls_set_shard(self.h, rank, nranks))
+
+    def shard_info(self):
+        out = np.zeros(5, np.int64); self._chk(self.L.nlls_get_shard_info(self.h, _p(out), 5))
+        return dict(rank=int(out[0]), nranks=int(out[1]), local_ncost=int(out[2]), local_nnz_data=int(out[3]), local_ndof=int(out[4]))
+
+    def sweep_gradhess_local(self):
+        self._chk(self.L.nlls_sweep_gradhess_local(self.h))
+
+    def sweep_gradhess_finish(self):
+        return self._scalar(self.L.nlls_sweep_gradhess_finish)
+
+    def solve_local(self):
+        self._chk(self.L.nlls_solve_local(self.h))
+
+    def solve_finish(self):
+        self._chk(self.L.nlls_solve_finish(self.h, None))
+
+    def reduce_buffer(self, stage):
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.nlls_get_reduce_buffer(self.h, stage, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
 
     def time_sweep_gradhess(self, reps=10):
         ms = C.c_float(); self._chk(self.L.nlls_time_sweep_gradhess(self.h, reps, C.byref(ms))); return ms.value

@@ -226,27 +226,55 @@ int nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from) {
     return enqueue_retract(ctx, to, from);
 }
 
-// ---- multi-GPU: local phases + reduce buffers (single rank: the buffers simply need no reduction) --------
+// ---- multi-GPU: local phases + reduce buffers.  Under nlls_set_shard(rank, nranks > 1):
+//   nlls_sweep_cost / nlls_quadform / nlls_max_abs_diag / nlls_grad_* return this rank's PARTIAL values (the caller
+//   sums, or takes the max of, them over ranks); the *_local / *_finish pairs bracket the buffer reductions.
 int nlls_sweep_gradhess_local(nlls_ctx* ctx) {
     NEED_READY(); TRY(enqueue_sweep_gradhess(ctx));
-    ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; return NLLS_OK;
+    ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
+    if (ctx->nranks > 1) TRY(enqueue_pack_reduce0(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
 }
 int nlls_sweep_gradhess_finish(nlls_ctx* ctx, double* cost_out) {
-    NEED_GRAD(); TRY(fetch_scalars(ctx, 0, 1)); if (cost_out) *cost_out = ctx->h_scalars[0]; return NLLS_OK;
+    NEED_GRAD();
+    if (ctx->nranks > 1) TRY(enqueue_unpack_reduce0(ctx));
+    TRY(fetch_scalars(ctx, 0, 1)); if (cost_out) *cost_out = ctx->h_scalars[0]; return NLLS_OK;
 }
 int nlls_sweep_cost_local(nlls_ctx* ctx, int32_t which) { NEED_READY(); if (!valid_set(which)) return NLLS_ERR_INVALID_ARG; return enqueue_sweep_cost(ctx, which); }
 int nlls_sweep_cost_finish(nlls_ctx* ctx, double* cost_out) { NEED_READY(); TRY(fetch_scalars(ctx, 0, 1)); if (cost_out) *cost_out = ctx->h_scalars[0]; return NLLS_OK; }
-int nlls_solve_local(nlls_ctx* ctx) { NEED_GRAD(); return fail(ctx, NLLS_ERR_UNSUPPORTED, "split solve phases are not available yet"); }
-int nlls_solve_finish(nlls_ctx* ctx, double*) { NEED_GRAD(); return fail(ctx, NLLS_ERR_UNSUPPORTED, "split solve phases are not available yet"); }
+int nlls_solve_local(nlls_ctx* ctx) {
+    NEED_GRAD(); TRY(enqueue_solve_local(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
+}
+int nlls_solve_finish(nlls_ctx* ctx, double* x_out) {
+    NEED_GRAD(); TRY(enqueue_solve_finish(ctx));
+    int32_t status[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    if (x_out) HIPCHK(hipMemcpyAsync(x_out, ctx->x.p, sizeof(double) * ctx->info.ndof, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->solved = true;
+    if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a zero pivot (code " + std::to_string(status[0]) + ")");
+    return NLLS_OK;
+}
 int nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count) {
     NEED_READY(); if (!dev_ptr || !count) return NLLS_ERR_INVALID_ARG;
-    if (stage == 0) { *dev_ptr = ctx->scalars.p; *count = 1; return NLLS_OK; }
-    return fail(ctx, NLLS_ERR_UNSUPPORTED, "reduce stage not available yet");
+    if (stage == 0) { *dev_ptr = ctx->redbuf.p; *count = ctx->redbuf_len; return NLLS_OK; }                                   // after sweep_gradhess_local
+    if (stage == 1) { *dev_ptr = ctx->S.p; *count = (int64_t)ctx->s_elems + ctx->nred; return NLLS_OK; }                      // after solve_local: [S | s]
+    if (stage == 2) { *dev_ptr = ctx->x.p; *count = ctx->info.ndof; return NLLS_OK; }                                         // after solve_finish: x
+    return fail(ctx, NLLS_ERR_INVALID_ARG, "unknown reduce stage");
 }
 int nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count, int64_t* own_offset, int64_t* own_count) {
     NEED_READY();
     if (dev_ptr_x) *dev_ptr_x = ctx->x.p; if (reduced_count) *reduced_count = ctx->nred;
     if (own_offset) *own_offset = 0; if (own_count) *own_count = ctx->info.ndof;
+    return NLLS_OK;
+}
+int nlls_get_shard_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
+    NEED_READY(); if (!out || n < 1) return NLLS_ERR_INVALID_ARG;
+    const int64_t vals[5] = {ctx->rank, ctx->nranks, ctx->local_ncost, ctx->local_nnz_data, ctx->local_ndof};
+    for (int i = 0; i < n && i < 5; ++i) out[i] = vals[i];
     return NLLS_OK;
 }
 

@@ -152,6 +152,16 @@ struct nlls_ctx {
     double lambda = 0.0;                     // accumulated uniformscaling! (src/iterators.jl:149,162)
     bool have_grad = false;
 
+    // ---- sharding ------------------------------------------------------------------------------------
+    bool elim_selected = false;
+    std::vector<int32_t> owner_of_block;
+    int64_t local_ncost = 0, local_nnz_data = 0, local_ndof = 0;
+    int64_t nred_ranges = 0, redbuf_len = 0;  // stage-0 reduce buffer: [cost | reduced rows of A.data | reduced part of b]
+    nlls::DevBuf<int64_t> d_red_off; nlls::DevBuf<uint32_t> d_red_len, d_red_dst, d_red_which;
+    nlls::DevBuf<double> redbuf;
+    nlls::DevBuf<double> d_dof_mask;         // 1 for dof this rank accounts for in global reductions (quadratic forms, max diag)
+    nlls::DevBuf<uint8_t> d_blk_mask, d_row_mask;
+    size_t s_elems = 0;                      // S occupies S.p[0, s_elems); the rhs vector s follows it (one reduce buffer)
     // ---- solve ---------------------------------------------------------------------------------------
     std::vector<uint8_t> is_elim;            // per block
     int64_t nelim = 0, nred = 0;             // blocks eliminated / dof of the reduced system
@@ -173,7 +183,8 @@ struct nlls_ctx {
     nlls::DevBuf<nlls::SchurCopy> d_blk;     // every stored block with full-system dof offsets (quadratic forms)
     int64_t nblk = 0;
     nlls::DevBuf<uint32_t> d_red_boff;       // reduced dof -> dof offset in b/x
-    nlls::DevBuf<double> S, s, Lwork;        // reduced system, rhs, factor workspace
+    nlls::DevBuf<double> S, Lwork;           // reduced system (+ rhs vector in its tail), factor workspace
+    double* s_ptr() const { return S.p + s_elems; }
     nlls::DevBuf<double> Yelim;              // C^-1 * [E | b] per eliminated block (reused by back-substitution)
     nlls::DevBuf<int32_t> d_status;          // factorisation status
     bool solved = false;

@@ -14,6 +14,7 @@ bool res_desc(int kind, ResDesc& d);
 
 int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags);
+int select_elimination(nlls_ctx* c, int32_t flags);
 int build_schur(nlls_ctx* c, int32_t flags);
 
 // sweeps (nlls_sweep.hip): enqueue on c->stream; cost lands in c->scalars[0]
@@ -26,6 +27,10 @@ int enqueue_max_abs_diag(nlls_ctx* c);        // scalars[3]
 int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot /* scalars[out], scalars[out+1] = v'Hv, b'v */);
 // solve (nlls_solve.hip)
 int enqueue_solve(nlls_ctx* c);
+int enqueue_solve_local(nlls_ctx* c);
+int enqueue_solve_finish(nlls_ctx* c);
+int enqueue_pack_reduce0(nlls_ctx* c);      // [cost | reduced rows | reduced b] -> redbuf
+int enqueue_unpack_reduce0(nlls_ctx* c);
 
 
 inline double* vars_ptr(nlls_ctx* c, int which) { return c->vars[c->vars_slot[which]].p; }

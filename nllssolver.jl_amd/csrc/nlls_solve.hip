@@ -309,9 +309,9 @@ __global__ __launch_bounds__(64) void schur_backsub_kernel(const double* __restr
         for (int i = 0; i < dv; ++i) x[eboff[v] + i] = -rhs[i];
     }
 }
-__global__ void scatter_reduced_kernel(const double* __restrict__ xr, const uint32_t* __restrict__ red_boff, int n, double* __restrict__ x) {
+__global__ void scatter_reduced_kernel(const double* __restrict__ xr, const uint32_t* __restrict__ red_boff, int n, double* __restrict__ x, int write) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[red_boff[i]] = -xr[i];
+    if (i < n) x[red_boff[i]] = write ? -xr[i] : 0.0;   // under sharding only rank 0 contributes the reduced part to the sum of x
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -697,10 +697,11 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
 // fast_bAb(H + lambda I, v) and dot(b, v)   src/utils.jl:71-106, src/iterators.jl:52,163
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void quadform_blocks_kernel(const double* __restrict__ A, const SchurCopy* __restrict__ blk, int64_t nblk,
-                                                              const double* __restrict__ v, double* __restrict__ partials) {
+                                                              const double* __restrict__ v, const uint8_t* __restrict__ mask, double* __restrict__ partials) {
     __shared__ double red[4];
     double acc = 0;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nblk; q += (int64_t)gridDim.x * 256) {
+        if (mask && !mask[q]) continue;
         const SchurCopy bk = blk[q]; double t = 0;
         for (int j = 0; j < bk.cols; ++j) { double c2 = 0; for (int i = 0; i < bk.rows; ++i) c2 += A[bk.off + i + bk.rows * j] * v[bk.r + i]; t += c2 * v[bk.c + j]; }
         acc += (bk.r == bk.c) ? t : 2.0 * t;
@@ -720,10 +721,10 @@ __global__ __launch_bounds__(256) void quadform_dense_kernel(const double* __res
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 // partial (v'v, b'v) per workgroup
-__global__ __launch_bounds__(256) void dot2_partial_kernel(const double* __restrict__ b, const double* __restrict__ v, int64_t n, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void dot2_partial_kernel(const double* __restrict__ b, const double* __restrict__ v, const double* __restrict__ mask, int64_t n, double* __restrict__ part) {
     __shared__ double red[2][4];
     double vv = 0, bv = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double x = v[i]; vv += x * x; bv += b[i] * x; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double m = mask ? mask[i] : 1.0; const double x = v[i]; vv += m * x * x; bv += m * b[i] * x; }
     vv = wsum(vv); bv = wsum(bv);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = vv; red[1][threadIdx.x >> 6] = bv; }
     __syncthreads();
@@ -755,14 +756,14 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
     int np = 0;
     if (c->info.is_sparse) {
         np = (int)std::min<int64_t>((c->nblk + 255) / 256, 1024); if (np < 1) np = 1;
-        hipLaunchKernelGGL(quadform_blocks_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, c->d_blk.p, c->nblk, d_vec, c->partials.p);
+        hipLaunchKernelGGL(quadform_blocks_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, c->d_blk.p, c->nblk, d_vec, c->nranks > 1 ? c->d_blk_mask.p : (const uint8_t*)nullptr, c->partials.p);
     } else {
         np = (int)std::min<int64_t>((c->info.ndof + 255) / 256, 1024); if (np < 1) np = 1;
         hipLaunchKernelGGL(quadform_dense_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, (int)c->info.ndof, d_vec, c->partials.p);
     }
     const int np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 256));
     double* part2 = c->partials.p + 1024;
-    hipLaunchKernelGGL(dot2_partial_kernel, dim3(np2), dim3(256), 0, c->stream, c->b.p, d_vec, c->info.ndof, part2);
+    hipLaunchKernelGGL(dot2_partial_kernel, dim3(np2), dim3(256), 0, c->stream, c->b.p, d_vec, c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr, c->info.ndof, part2);
     hipLaunchKernelGGL(quadform_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, np, part2, np2, c->lambda, c->scalars.p, out_slot);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
@@ -774,28 +775,32 @@ static SLayout make_layout(nlls_ctx* c) {
     return L;
 }
 
-int enqueue_solve(nlls_ctx* c) {
+// local phase: assemble this rank's share of [S | s] (rank 0 also contributes the reduced-reduced blocks,
+// lambda*I and b_R); under sharding the buffer is then summed over ranks
+int enqueue_solve_local(nlls_ctx* c) {
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
-    const SLayout L = make_layout(c); const int npad = L.npad, nblk = npad / NB;
-    const bool band = c->solve_mode == SOLVE_BAND;
+    const SLayout L = make_layout(c); const int npad = L.npad;
+    const bool band = c->solve_mode == SOLVE_BAND; const bool lead = c->nranks == 1 || c->rank == 0;
     HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 4, c->stream));
-    const size_t s_elems = band ? (size_t)L.H * L.n_band + (size_t)(L.nbd + 1) * (L.nbd + 1) : (size_t)npad * npad;
-    HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * s_elems, c->stream));
-    hipLaunchKernelGGL(schur_init_kernel, dim3((std::max(npad, n) + 255) / 256), dim3(256), 0, c->stream, L, c->s.p, c->b.p, c->d_red_boff.p);
-    if (c->info.is_sparse) {
-        if (c->ncopy > 0) hipLaunchKernelGGL(schur_copy_kernel, dim3((unsigned)c->ncopy), dim3(64), 0, c->stream, L, c->A.p, c->d_copy.p, c->lambda);
-    } else {
-        const int64_t n2 = (int64_t)n * n;
-        hipLaunchKernelGGL(dense_to_S_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->S.p, c->A.p, c->lambda, n, npad);
+    HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
+    if (c->nranks > 1) HIPCHK(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->info.ndof, c->stream));
+    if (lead) {
+        hipLaunchKernelGGL(schur_init_kernel, dim3((std::max(npad, n) + 255) / 256), dim3(256), 0, c->stream, L, c->s_ptr(), c->b.p, c->d_red_boff.p);
+        if (c->info.is_sparse) {
+            if (c->ncopy > 0) hipLaunchKernelGGL(schur_copy_kernel, dim3((unsigned)c->ncopy), dim3(64), 0, c->stream, L, c->A.p, c->d_copy.p, c->lambda);
+        } else {
+            const int64_t n2 = (int64_t)n * n;
+            hipLaunchKernelGGL(dense_to_S_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->S.p, c->A.p, c->lambda, n, npad);
+        }
     }
-    if (c->nelim > 0) {
+    if (c->nelim_groups > 0) {
         if (c->n_slow_groups > 0)
             hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)c->n_slow_groups), dim3(64), c->elim_lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
                                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->d_slow_groups.p, c->lambda, c->max_elim_dim, c->max_nbr_dof,
-                               c->elim_use_acc ? 1 : 0, L, c->s.p, c->d_status.p);
+                               c->elim_use_acc ? 1 : 0, L, c->s_ptr(), c->d_status.p);
         if (c->n_fast_groups > 0) {
 #define LAUNCH_FAST(DV, MAXK) hipLaunchKernelGGL((schur_elim_fast_kernel<DV, MAXK>), dim3((unsigned)c->n_fast_groups), dim3(64), 0, c->stream, c->A.p, c->b.p, \
-                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->lambda, L, c->s.p, c->d_status.p)
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->lambda, L, c->s_ptr(), c->d_status.p)
             const int maxk = c->fast_maxk;
             if (c->fast_dv == 3) { if (maxk <= 12) LAUNCH_FAST(3, 12); else if (maxk <= 24) LAUNCH_FAST(3, 24); else LAUNCH_FAST(3, 40); }
             else if (c->fast_dv == 2) { if (maxk <= 12) LAUNCH_FAST(2, 12); else if (maxk <= 24) LAUNCH_FAST(2, 24); else LAUNCH_FAST(2, 40); }
@@ -803,11 +808,20 @@ int enqueue_solve(nlls_ctx* c) {
 #undef LAUNCH_FAST
         }
     }
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+// finish: factor the (summed) reduced system, solve it, back-substitute this rank's eliminated blocks
+int enqueue_solve_finish(nlls_ctx* c) {
+    const int n = (int)c->nred; if (n == 0) return NLLS_OK;
+    const SLayout L = make_layout(c); const int npad = L.npad, nblk = npad / NB;
+    const bool band = c->solve_mode == SOLVE_BAND;
     if (c->solve_mode == SOLVE_SMALL) {
-        hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s.p, n, npad, c->d_status.p);
+        hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s_ptr(), n, npad, c->d_status.p);
     } else if (band) {
-        hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s.p);
-        BandArgs a{}; a.Sb = c->S.p; a.Lb = c->Lwork.p; a.xr = c->s.p; a.n_band = L.n_band; a.bw = L.bw; a.nbd = L.nbd; a.H = L.H; a.CH = c->band_CH; a.status = c->d_status.p;
+        hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s_ptr());
+        BandArgs a{}; a.Sb = c->S.p; a.Lb = c->Lwork.p; a.xr = c->s_ptr(); a.n_band = L.n_band; a.bw = L.bw; a.nbd = L.nbd; a.H = L.H; a.CH = c->band_CH; a.status = c->d_status.p;
         a.PFC = (L.bw + 1 + a.CH - 1) / a.CH + 1; a.RC = (a.PFC + 1) * a.CH; a.NSC = (L.bw + 1 + c->band_SEG - 1) / c->band_SEG;
         const int nbr = L.nbd + 1;
         const size_t lds = sizeof(double) * ((size_t)a.RC * L.H + 2 * (size_t)(2 * a.NSC * c->band_SEG + 2 * c->band_SEG) + (size_t)(L.bw + 2) * nbr + (size_t)nbr * nbr + nbr + 8);
@@ -819,7 +833,7 @@ int enqueue_solve(nlls_ctx* c) {
         else LAUNCH_BAND(16, 4);
 #undef LAUNCH_BAND
     } else {
-        hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s.p);
+        hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s_ptr());
         for (int k = 0; k < nblk; ++k) {
             hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(256), 0, c->stream, c->S.p, npad, k, c->d_status.p);
             const int T = nblk - k - 1;
@@ -834,19 +848,25 @@ int enqueue_solve(nlls_ctx* c) {
         const int nb_real = (n + NB - 1) / NB;
         for (int kb = nb_real - 1; kb >= 0; --kb) {
             const int below = nb_real - 1 - kb;
-            if (below > 0) hipLaunchKernelGGL(bwd_gemv_kernel, dim3(below), dim3(256), 0, c->stream, c->S.p, npad, kb, n, c->s.p, acc);
-            hipLaunchKernelGGL(bwd_diag_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, npad, kb, n, acc, c->s.p);
+            if (below > 0) hipLaunchKernelGGL(bwd_gemv_kernel, dim3(below), dim3(256), 0, c->stream, c->S.p, npad, kb, n, c->s_ptr(), acc);
+            hipLaunchKernelGGL(bwd_diag_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, npad, kb, n, acc, c->s_ptr());
         }
     }
     // x = -solution
-    hipLaunchKernelGGL(scatter_reduced_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->s.p, c->d_red_boff.p, n, c->x.p);
-    if (c->nelim > 0) {
+    hipLaunchKernelGGL(scatter_reduced_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->s_ptr(), c->d_red_boff.p, n, c->x.p, (c->nranks == 1 || c->rank == 0) ? 1 : 0);
+    const int64_t nel_local = (int64_t)(c->d_elim_diag.n);
+    if (nel_local > 0) {
         const size_t lds = sizeof(double) * ((size_t)c->max_elim_dim * c->max_elim_dim + c->max_elim_dim);
-        hipLaunchKernelGGL(schur_backsub_kernel, dim3((unsigned)c->nelim), dim3(64), lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
-                           c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->lambda, c->max_elim_dim, c->s.p, c->x.p);
+        hipLaunchKernelGGL(schur_backsub_kernel, dim3((unsigned)nel_local), dim3(64), lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
+                           c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->lambda, c->max_elim_dim, c->s_ptr(), c->x.p);
     }
     HIPCHK(hipGetLastError());
     return NLLS_OK;
+}
+
+int enqueue_solve(nlls_ctx* c) {
+    int rc = enqueue_solve_local(c); if (rc != NLLS_OK) return rc;
+    return enqueue_solve_finish(c);
 }
 
 }  // namespace nlls

@@ -135,6 +135,31 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     if (!c->h_scalars) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), 64 * sizeof(double)));
     HIPCHK(c->scalars.alloc(64));
 
+    // ---- observation sharding: costs are owned by the rank that owns their eliminated block ----------
+    c->elim_selected = false;
+    const int nranks = c->nranks, rank = c->rank;
+    std::vector<int32_t> owner_of_block(nb, 0);           // eliminated blocks: owning rank; reduced blocks: 0
+    std::vector<std::vector<uint8_t>> mine(ngroups);
+    for (int g = 0; g < ngroups; ++g) mine[g].assign(groups[g].ncost, 1);
+    c->local_ncost = ncost_total;
+    if (nranks > 1) {
+        if (!sparse) return fail(c, NLLS_ERR_UNSUPPORTED, "sharding needs the block-sparse path");
+        c->info = I;
+        int rc0 = select_elimination(c, flags); if (rc0 != NLLS_OK) return rc0;
+        if (!c->nelim) return fail(c, NLLS_ERR_UNSUPPORTED, "sharding needs an eliminated (Schur) variable set to partition by");
+        // weight of an eliminated block = number of cost blocks touching it; contiguous ranges of equal weight
+        std::vector<int64_t> w(nb, 0);
+        for (int g = 0; g < ngroups; ++g) { const int nd = desc[g].ndeps;
+            for (int64_t k = 0; k < groups[g].ncost; ++k) for (int s = 0; s < nd; ++s) { uint64_t r = bi[groups[g].varind[k * nd + s] - 1]; if (r && c->is_elim[r - 1]) w[r - 1]++; } }
+        int64_t total = 0; for (int64_t k = 0; k < nb; ++k) if (c->is_elim[k]) total += w[k];
+        { int64_t cum = 0; for (int64_t k = 0; k < nb; ++k) if (c->is_elim[k]) { int r = (int)std::min<int64_t>(nranks - 1, total ? (cum * nranks) / total : 0); owner_of_block[k] = r; cum += w[k]; } }
+        c->local_ncost = 0;
+        for (int g = 0; g < ngroups; ++g) { const int nd = desc[g].ndeps;
+            for (int64_t k = 0; k < groups[g].ncost; ++k) { int own = (int)(k % nranks);
+                for (int s = 0; s < nd; ++s) { uint64_t r = bi[groups[g].varind[k * nd + s] - 1]; if (r && c->is_elim[r - 1]) { own = owner_of_block[r - 1]; break; } }
+                mine[g][k] = own == rank; c->local_ncost += mine[g][k]; } }
+    }
+    c->owner_of_block = owner_of_block;
     // ---- per-group lists ---------------------------------------------------------------------------------
     c->groups.resize(ngroups);
     std::vector<int32_t> row_nlists(nb, 0);         // how many entry lists touch a row
@@ -146,12 +171,17 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
         G.res_kind = in.res_kind; G.ndeps = d.ndeps; G.ndata = d.ndata; G.nres = d.nres; G.adaptive = d.adaptive; G.ncost = in.ncost;
         G.rk.kind = in.robust_kind; G.rk.p0 = in.robust_params[0]; G.rk.p1 = in.robust_params[1];
         // cost-order arrays
-        { std::vector<double> hd(in.data, in.data + in.ncost * d.ndata); HIPCHK(G.data.upload(hd));
-          std::vector<uint32_t> hv((size_t)in.ncost * d.ndeps);
-          for (int64_t k = 0; k < in.ncost * d.ndeps; ++k) hv[k] = c->var_off[in.varind[k] - 1];
-          HIPCHK(G.voff.upload(hv)); }
         std::vector<uint32_t> fixedcost;
-        for (int64_t k = 0; k < in.ncost; ++k) { bool any = false; for (int s = 0; s < d.ndeps; ++s) any |= bi[in.varind[k * d.ndeps + s] - 1] != 0; if (!any) fixedcost.push_back((uint32_t)k); }
+        { std::vector<double> hd; std::vector<uint32_t> hv; hd.reserve((size_t)in.ncost * d.ndata); hv.reserve((size_t)in.ncost * d.ndeps);
+          int64_t nl = 0;
+          for (int64_t k = 0; k < in.ncost; ++k) { if (!mine[g][k]) continue;
+              for (int q = 0; q < d.ndata; ++q) hd.push_back(in.data[k * d.ndata + q]);
+              bool any = false;
+              for (int s = 0; s < d.ndeps; ++s) { hv.push_back(c->var_off[in.varind[k * d.ndeps + s] - 1]); any |= bi[in.varind[k * d.ndeps + s] - 1] != 0; }
+              if (!any) fixedcost.push_back((uint32_t)nl);
+              ++nl; }
+          G.ncost = nl;
+          HIPCHK(G.data.upload(hd)); HIPCHK(G.voff.upload(hv)); }
         G.nfixedcost = (int64_t)fixedcost.size(); HIPCHK(G.fixedcost.upload(fixedcost));
         npartials += (G.nfixedcost + 255) / 256;
         hl[g].resize(d.ndeps);
@@ -160,14 +190,14 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
             HostList& L = hl[g][s];
             // counting sort of the incidences (cost, s) by block row
             std::vector<int64_t> cnt(nb + 1, 0);
-            for (int64_t k = 0; k < in.ncost; ++k) { uint64_t r = bi[in.varind[k * d.ndeps + s] - 1]; if (r) cnt[r]++; }
+            for (int64_t k = 0; k < in.ncost; ++k) { if (!mine[g][k]) continue; uint64_t r = bi[in.varind[k * d.ndeps + s] - 1]; if (r) cnt[r]++; }
             for (int64_t r = 0; r < nb; ++r) if (cnt[r + 1]) { L.rows.push_back(r); row_nlists[r]++; }
             std::vector<int64_t> pos(nb + 2, 0); for (int64_t r = 1; r <= nb; ++r) pos[r + 1] = pos[r] + cnt[r];
             L.cost.resize(pos[nb + 1]);
             L.rowptr.resize(L.rows.size() + 1);
             for (size_t i = 0; i < L.rows.size(); ++i) L.rowptr[i] = pos[L.rows[i] + 1];
             L.rowptr[L.rows.size()] = pos[nb + 1];
-            for (int64_t k = 0; k < in.ncost; ++k) { uint64_t r = bi[in.varind[k * d.ndeps + s] - 1]; if (r) L.cost[pos[r]++] = k; }
+            for (int64_t k = 0; k < in.ncost; ++k) { if (!mine[g][k]) continue; uint64_t r = bi[in.varind[k * d.ndeps + s] - 1]; if (r) L.cost[pos[r]++] = k; }
         }
     }
     // ---- tiles ------------------------------------------------------------------------------------------------
@@ -267,6 +297,16 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
             std::vector<int64_t>().swap(L.cost);
         }
     }
+    std::vector<int64_t> red_off; std::vector<uint32_t> red_len, red_dst, red_which;   // stage-0 reduce ranges
+    if (sparse && nranks > 1) {
+        uint32_t dst = 1;   // slot 0 carries the cost
+        for (int64_t r = 0; r < nb; ++r) if (!c->is_elim[r]) { row_zero[r] = 1;
+            red_off.push_back(segs[r]); red_len.push_back((uint32_t)(segs[r + 1] - segs[r])); red_dst.push_back(dst); red_which.push_back(0); dst += (uint32_t)(segs[r + 1] - segs[r]);
+            red_off.push_back(c->boffsets[r]); red_len.push_back((uint32_t)c->blocksizes[r]); red_dst.push_back(dst); red_which.push_back(1); dst += (uint32_t)c->blocksizes[r]; }
+        c->nred_ranges = (int64_t)red_off.size(); c->redbuf_len = dst;
+        HIPCHK(c->d_red_off.upload(red_off)); HIPCHK(c->d_red_len.upload(red_len)); HIPCHK(c->d_red_dst.upload(red_dst)); HIPCHK(c->d_red_which.upload(red_which));
+        HIPCHK(c->redbuf.alloc(dst));
+    } else { c->nred_ranges = 0; c->redbuf_len = 0; }
     if (sparse) {
         for (int64_t r = 0; r < nb; ++r) if (row_zero[r]) { zero_off.push_back(segs[r]); zero_len.push_back((uint32_t)(segs[r + 1] - segs[r])); zero_b_off.push_back((uint32_t)c->boffsets[r]); zero_b_len.push_back((uint32_t)c->blocksizes[r]); }
     } else {
@@ -290,29 +330,26 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     HIPCHK(c->partials.alloc(c->npartials));
     I.owner_path = all_owner ? 1 : 0;
 
+    { int64_t lw = 0, ld = 0;
+      for (int64_t r = 0; r < nb; ++r) if (nranks == 1 || !c->is_elim[r] || owner_of_block[r] == rank) { lw += sparse ? segs[r + 1] - segs[r] : 0; ld += c->blocksizes[r]; }
+      c->local_nnz_data = sparse ? lw : nnz_data; c->local_ndof = ld; }
     int rc = build_schur(c, flags);
     if (rc != NLLS_OK) return rc;
     c->ready = true;
     return NLLS_OK;
 }
 
-// ---- Schur structures --------------------------------------------------------------------------------------
-// The reference factors the FULL sparse system with LDLFactorizations (src/linearsolver.jl:29); there is no
-// Schur complement in it (SURVEY F1).  Here an independent set of blocks (no two share a stored block) is
-// eliminated first -- the same fill-reducing choice a minimum-degree ordering makes for bundle adjustment --
-// and the remaining blocks form the reduced system, ordered [banded part | border blocks | rhs row].
-int build_schur(nlls_ctx* c, int32_t flags) {
+// Choice of the eliminated (Schur) set: an independent set of blocks -- no two share a stored block.
+int select_elimination(nlls_ctx* c, int32_t flags) {
     const nlls_info& I0 = c->info; const int64_t nb = I0.nblocks;
-    c->is_elim.assign(nb, 0); c->nelim = 0; c->nelim_groups = 0; c->max_elim_dim = 0; c->max_nbr_dof = 0;
-    std::vector<int64_t> red_of(nb, -1);     // dof offset in the reduced system
-    // transposed block lists: for a block v, the rows w > v that store block (w, v)
-    std::vector<int64_t> tptr(nb + 1, 0), trow, tq;
+    c->is_elim.assign(nb, 0); c->nelim = 0; c->elim_selected = true;
+    std::vector<int64_t> tptr(nb + 1, 0), trow;
     if (I0.is_sparse) {
         for (int64_t q = 0; q < (int64_t)c->it_rowval.size(); ++q) tptr[c->it_rowval[q] + 1]++;
         for (int64_t k = 0; k < nb; ++k) tptr[k + 1] += tptr[k];
-        trow.resize(c->it_rowval.size()); tq.resize(c->it_rowval.size());
+        trow.resize(c->it_rowval.size());
         std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
-        for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t p = cur[c->it_rowval[q]]++; trow[p] = row; tq[p] = q; }
+        for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) trow[cur[c->it_rowval[q]]++] = row;
     }
     if (I0.is_sparse && !(flags & NLLS_FLAG_NO_SCHUR) && nb > 1) {
         std::vector<int32_t> deg(nb, 0);
@@ -328,6 +365,28 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) blocked[trow[q]] = 1; }
         if (c->nelim * 2 < nb) { std::fill(c->is_elim.begin(), c->is_elim.end(), 0); c->nelim = 0; }   // not worth it unless most blocks go
     }
+    return NLLS_OK;
+}
+
+// ---- Schur structures --------------------------------------------------------------------------------------
+// The reference factors the FULL sparse system with LDLFactorizations (src/linearsolver.jl:29); there is no
+// Schur complement in it (SURVEY F1).  Here an independent set of blocks (no two share a stored block) is
+// eliminated first -- the same fill-reducing choice a minimum-degree ordering makes for bundle adjustment --
+// and the remaining blocks form the reduced system, ordered [banded part | border blocks | rhs row].
+int build_schur(nlls_ctx* c, int32_t flags) {
+    const nlls_info& I0 = c->info; const int64_t nb = I0.nblocks;
+    c->nelim_groups = 0; c->max_elim_dim = 0; c->max_nbr_dof = 0;
+    std::vector<int64_t> red_of(nb, -1);     // dof offset in the reduced system
+    // transposed block lists: for a block v, the rows w > v that store block (w, v)
+    std::vector<int64_t> tptr(nb + 1, 0), trow, tq;
+    if (I0.is_sparse) {
+        for (int64_t q = 0; q < (int64_t)c->it_rowval.size(); ++q) tptr[c->it_rowval[q] + 1]++;
+        for (int64_t k = 0; k < nb; ++k) tptr[k + 1] += tptr[k];
+        trow.resize(c->it_rowval.size()); tq.resize(c->it_rowval.size());
+        std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
+        for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t p = cur[c->it_rowval[q]]++; trow[p] = row; tq[p] = q; }
+    }
+    if (!c->elim_selected) { int rc0 = select_elimination(c, flags); if (rc0 != NLLS_OK) return rc0; }
     // ---- reduced ordering: blocks coupled to a large share of the system go last (border) so that they cause no fill
     std::vector<uint8_t> is_border(nb, 0);
     {
@@ -349,11 +408,18 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         c->nred = ro; c->nbd = (int)(ro - c->n_band);
     }
     int64_t bw = 0;   // half bandwidth (in dof) of the non-border part of S
+    if (c->nranks > 1) for (int64_t v = 0; v < nb; ++v) if (c->is_elim[v]) {   // all ranks must agree on the layout of S
+        int64_t lo = -1, hi = -1;
+        auto upd = [&](int64_t u) { const int64_t r0 = red_of[u]; if (r0 < c->n_band) { lo = lo < 0 ? r0 : std::min(lo, r0); hi = std::max(hi, r0 + c->blocksizes[u] - 1); } };
+        for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) if (c->it_rowval[q] != v) upd(c->it_rowval[q]);
+        for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) if (trow[q] != v) upd(trow[q]);
+        if (lo >= 0) bw = std::max(bw, hi - lo);
+    }
     std::vector<int64_t> eptr; std::vector<SchurNbr> enbr; std::vector<int64_t> ediag; std::vector<uint32_t> eboff; std::vector<uint16_t> edim; std::vector<uint32_t> egroup;
     eptr.push_back(0);
     if (c->nelim) {
         std::vector<SchurNbr> prev; uint32_t glen = 0;
-        for (int64_t v = 0; v < nb; ++v) if (c->is_elim[v]) {
+        for (int64_t v = 0; v < nb; ++v) if (c->is_elim[v] && (c->nranks == 1 || c->owner_of_block[v] == c->rank)) {
             std::vector<SchurNbr> nl;
             for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) { int64_t u = c->it_rowval[q]; if (u == v) continue;
                 nl.push_back(SchurNbr{c->it_nzval[q], (uint32_t)red_of[u], (uint16_t)c->blocksizes[u], 0}); }
@@ -423,7 +489,15 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     { std::vector<SchurCopy> blks;
       if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q];
           blks.push_back(SchurCopy{c->it_nzval[q], (uint32_t)c->boffsets[row], (uint32_t)c->boffsets[col], (uint16_t)c->blocksizes[row], (uint16_t)c->blocksizes[col]}); }
-      c->nblk = (int64_t)blks.size(); if (hipSuccess != c->d_blk.upload(blks)) return fail(c, NLLS_ERR_HIP, "block list upload"); }
+      c->nblk = (int64_t)blks.size(); if (hipSuccess != c->d_blk.upload(blks)) return fail(c, NLLS_ERR_HIP, "block list upload");
+      // ownership masks for global reductions under sharding: eliminated rows count on their owner, reduced rows on rank 0
+      std::vector<uint8_t> rowmask(nb, 1), blkmask; std::vector<double> dofmask(I0.ndof, 1.0);
+      if (c->nranks > 1) {
+          for (int64_t r = 0; r < nb; ++r) { const bool own = c->is_elim[r] ? c->owner_of_block[r] == c->rank : c->rank == 0; rowmask[r] = own;
+              for (int i = 0; i < c->blocksizes[r]; ++i) dofmask[c->boffsets[r] + i] = own ? 1.0 : 0.0; }
+          for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) blkmask.push_back(rowmask[row]);
+      }
+      if (hipSuccess != c->d_row_mask.upload(rowmask) || hipSuccess != c->d_blk_mask.upload(blkmask) || hipSuccess != c->d_dof_mask.upload(dofmask)) return fail(c, NLLS_ERR_HIP, "mask upload"); }
     if (hipSuccess != c->d_copy.upload(copies) || hipSuccess != c->d_red_boff.upload(red_boff)) return fail(c, NLLS_ERR_HIP, "schur upload");
     // ---- choose the reduced-system solver ----------------------------------------------------------------------
     const int64_t n = c->nred;
@@ -449,10 +523,12 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     }
     if (c->solve_mode == SOLVE_BAND) {
         const size_t sz = (size_t)c->band_H * c->n_band + (size_t)(c->nbd + 1) * (c->nbd + 1);
-        if (hipSuccess != c->S.alloc(sz) || hipSuccess != c->Lwork.alloc(sz) || hipSuccess != c->s.alloc((size_t)n + 64) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "band system alloc");
+        c->s_elems = sz;
+        if (hipSuccess != c->S.alloc(sz + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(sz) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "band system alloc");
     } else {
         const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
-        if (hipSuccess != c->S.alloc((size_t)std::max<int64_t>(npad * npad, 1)) || hipSuccess != c->s.alloc((size_t)std::max<int64_t>(npad, 1)) ||
+        c->s_elems = (size_t)std::max<int64_t>(npad * npad, 1);
+        if (hipSuccess != c->S.alloc(c->s_elems + (size_t)npad + 64) ||
             hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 64 + npad, 1)) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
     }
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;

@@ -427,12 +427,12 @@ __global__ __launch_bounds__(TPB) void step_stats_finish_kernel(const double* __
 }
 // initlambda's max |H_ii|   src/iterators.jl:131-137
 __global__ __launch_bounds__(TPB) void max_abs_diag_partial_kernel(const double* __restrict__ A, const int64_t* __restrict__ diag_off,
-                                                                   const int32_t* __restrict__ bs, int64_t nb, int64_t ld_dense, double* __restrict__ part) {
+                                                                   const int32_t* __restrict__ bs, const uint8_t* __restrict__ rowmask, int64_t nb, int64_t ld_dense, double* __restrict__ part) {
     __shared__ double red[TPB / 64];
     double m = 0;
     for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < nb; k += (int64_t)gridDim.x * TPB) {
         const int n = bs[k]; const int64_t o = diag_off[k]; const int64_t ld = ld_dense ? ld_dense : n;
-        if (o < 0) continue;
+        if (o < 0 || (rowmask && !rowmask[k])) continue;
         for (int i = 0; i < n; ++i) m = fmax(m, fabs(A[o + i + ld * i]));
     }
     double mm = block_max(m, red);
@@ -444,6 +444,20 @@ __global__ __launch_bounds__(TPB) void max_finish_kernel(const double* __restric
     for (int i = threadIdx.x; i < nb; i += TPB) m = fmax(m, part[i]);
     double mm = block_max(m, red);
     if (threadIdx.x == 0) out[slot] = mm;
+}
+
+// stage-0 reduce buffer of the sharded sweep: [cost | reduced rows of A.data | reduced part of b]
+__global__ void pack_reduce0_kernel(const double* __restrict__ A, const double* __restrict__ b, const int64_t* __restrict__ off, const uint32_t* __restrict__ len,
+                                    const uint32_t* __restrict__ dst, const uint32_t* __restrict__ which, const double* __restrict__ scalars, double* __restrict__ buf) {
+    const double* src = (which[blockIdx.x] ? b : A) + off[blockIdx.x]; double* d = buf + dst[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < len[blockIdx.x]; i += blockDim.x) d[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) buf[0] = scalars[0];
+}
+__global__ void unpack_reduce0_kernel(double* __restrict__ A, double* __restrict__ b, const int64_t* __restrict__ off, const uint32_t* __restrict__ len,
+                                      const uint32_t* __restrict__ dst, const uint32_t* __restrict__ which, double* __restrict__ scalars, const double* __restrict__ buf) {
+    double* d = (which[blockIdx.x] ? b : A) + off[blockIdx.x]; const double* src = buf + dst[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < len[blockIdx.x]; i += blockDim.x) d[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) scalars[0] = buf[0];
 }
 
 // ================================================================================================
@@ -539,6 +553,20 @@ int enqueue_sweep_gradhess(nlls_ctx* c) {
     return NLLS_OK;
 }
 
+int enqueue_pack_reduce0(nlls_ctx* c) {
+    if (c->nred_ranges > 0)
+        hipLaunchKernelGGL(pack_reduce0_kernel, dim3((unsigned)c->nred_ranges), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_red_off.p, c->d_red_len.p,
+                           c->d_red_dst.p, c->d_red_which.p, c->scalars.p, c->redbuf.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+int enqueue_unpack_reduce0(nlls_ctx* c) {
+    if (c->nred_ranges > 0)
+        hipLaunchKernelGGL(unpack_reduce0_kernel, dim3((unsigned)c->nred_ranges), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_red_off.p, c->d_red_len.p,
+                           c->d_red_dst.p, c->d_red_which.p, c->scalars.p, c->redbuf.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
 int enqueue_retract(nlls_ctx* c, int to, int from) {
     const int64_t nvar = c->info.nvar; if (nvar == 0) return NLLS_OK;
     hipLaunchKernelGGL(retract_kernel, dim3((unsigned)((nvar + 255) / 256)), dim3(256), 0, c->stream, c->d_var_kind.p, c->d_var_dim.p, c->d_var_off.p,
@@ -555,8 +583,8 @@ int enqueue_step_stats(nlls_ctx* c) {
 }
 int enqueue_max_abs_diag(nlls_ctx* c) {
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.nblocks + TPB - 1) / TPB, RED_BLOCKS));
-    hipLaunchKernelGGL(max_abs_diag_partial_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->A.p, c->d_diag_off.p, c->d_blocksizes.p, c->info.nblocks,
-                       c->info.is_sparse ? (int64_t)0 : c->info.ndof, c->partials.p);
+    hipLaunchKernelGGL(max_abs_diag_partial_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->A.p, c->d_diag_off.p, c->d_blocksizes.p,
+                       c->nranks > 1 ? c->d_row_mask.p : (const uint8_t*)nullptr, c->info.nblocks, c->info.is_sparse ? (int64_t)0 : c->info.ndof, c->partials.p);
     hipLaunchKernelGGL(max_finish_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, nb, c->scalars.p, 3);
     HIPCHK(hipGetLastError());
     return NLLS_OK;

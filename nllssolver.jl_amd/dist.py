@@ -23,18 +23,17 @@ class _DevArray:
 
 
 class ShardedLS(MultiVariateLSgpu):
-    """MultiVariateLSgpu whose sweeps/solves are sharded over `world` ranks."""
+    """MultiVariateLSgpu whose sweeps/solves are sharded over `world` ranks (one process per GPU).
+
+    dist: torch.distributed (initialised by the caller: "nccl" = RCCL on the GPU box).  host_staged=True routes the
+    buffer reductions through host copies (gloo), which lets several ranks share ONE GPU in tests."""
 
     def __init__(self, problem, unfixed, flags=0, device=0, rank=0, world=1, dist=None, host_staged=False):
         self.rank, self.world, self.dist, self.host_staged = rank, world, dist, host_staged
         self._pre_upload = (rank, world)
         super().__init__(problem, unfixed, flags, device)
-        nobs = problem.ncosts()
-        if world == 1:
-            self.local_nobs, self.local_nnz_data, self.local_ndof_written = nobs, self.info.nnz_data, self.info.ndof
-        else:
-            sh = self.ctx.shard_info()
-            self.local_nobs, self.local_nnz_data, self.local_ndof_written = sh["local_ncost"], sh["local_nnz_data"], sh["local_ndof"]
+        sh = self.ctx.shard_info()
+        self.local_nobs, self.local_nnz_data, self.local_ndof_written = sh["local_ncost"], sh["local_nnz_data"], sh["local_ndof"]
 
     def _make_context(self, device):
         ctx = _capi.Context(device)
@@ -44,7 +43,7 @@ class ShardedLS(MultiVariateLSgpu):
         return ctx
 
     # ---- collectives ------------------------------------------------------------------------------
-    def _allreduce(self, stage):
+    def _allreduce_buffer(self, stage):
         import torch
         ptr, n = self.ctx.reduce_buffer(stage)
         if n == 0:
@@ -56,29 +55,48 @@ class ShardedLS(MultiVariateLSgpu):
             self.dist.all_reduce(t)
         torch.cuda.synchronize()
 
+    def _allreduce_scalars(self, values, op="sum"):
+        import torch
+        t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if self.host_staged else "cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.cpu()]
+
     def costgradhess(self):
         if self.world == 1:
             return super().costgradhess()
         self._x = None
         self.ctx.sweep_gradhess_local()
-        self._allreduce(0)
+        self._allreduce_buffer(0)
         return self.ctx.sweep_gradhess_finish()
 
     def cost(self, which=_capi.VARS_NEXT):
-        if self.world == 1:
-            return super().cost(which)
-        self.ctx.sweep_cost_local(which)
-        self._allreduce(0)
-        return self.ctx.sweep_cost_finish()
+        c = super().cost(which)                    # this rank's cost blocks only
+        return c if self.world == 1 else self._allreduce_scalars([c])[0]
 
     def solve(self):
         if self.world == 1:
             return super().solve()
         self._x = None
         self.ctx.solve_local()
-        self._allreduce(1)
+        self._allreduce_buffer(1)
         self.ctx.solve_finish()
-        self._allreduce(2)
+        self._allreduce_buffer(2)
+
+    def initlambda(self):
+        m = self.ctx.max_abs_diag()
+        if self.world > 1:
+            m = self._allreduce_scalars([m], "max")[0]
+        return m * 1e-6
+
+    def quadform(self):
+        a, g = self.ctx.quadform()
+        return (a, g) if self.world == 1 else tuple(self._allreduce_scalars([a, g]))
+
+    @property
+    def b(self):
+        if self.world > 1:
+            raise NotImplementedError("the full gradient is not assembled under sharding (Levenberg-Marquardt / Newton only)")
+        return self.ctx.get_grad()
 
 
 def partition_by_weight(weights, nparts):

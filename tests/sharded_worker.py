@@ -1,0 +1,65 @@
+"""Worker of tests/test_gpu_sharded.py: rank `r` of `w` on ONE GPU, gloo + host-staged reductions.
+Checks the sharded sweep / solve / LM against the unsharded device path on the same problem."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nllssolver_jl_amd as N
+    from nllssolver_jl_amd import synthetic, _capi, iterators as It, optimizer as Opt
+    from nllssolver_jl_amd.dist import ShardedLS
+    from nllssolver_jl_amd.linearsystem import MultiVariateLSgpu
+
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(40, 2000, 0.15, seed=21, robust=N.HuberKernel(0.05),
+                                                                 outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    unfixed = np.ones(p.nvariables, bool)
+    ref = MultiVariateLSgpu(p, unfixed)                       # unsharded reference on the same device
+    sh = ShardedLS(p, unfixed, rank=rank, world=world, dist=dist, host_staged=True)
+    info = sh.ctx.shard_info()
+    counts = [None] * world
+    dist.all_gather_object(counts, info["local_ncost"])
+    assert sum(counts) == p.ncosts(), (counts, p.ncosts())      # every cost block owned exactly once
+    assert max(counts) - min(counts) <= 0.1 * p.ncosts() / world + 64, counts
+
+    c_ref, c_sh = ref.costgradhess(), sh.costgradhess()
+    assert np.isclose(c_ref, c_sh, rtol=1e-12), (c_ref, c_sh)
+    assert np.isclose(ref.cost(_capi.VARS_CURRENT), sh.cost(_capi.VARS_CURRENT), rtol=1e-12)
+    lam = ref.initlambda(); assert np.isclose(lam, sh.initlambda(), rtol=1e-13)
+    ref.uniformscaling(lam); sh.uniformscaling(lam)
+    ref.solve(); sh.solve()
+    x_ref, x_sh = ref.x, sh.x
+    assert np.max(np.abs(x_ref - x_sh)) < 1e-8 * np.max(np.abs(x_ref)), np.max(np.abs(x_ref - x_sh))
+    q_ref, q_sh = ref.quadform(), sh.quadform()
+    assert np.allclose(q_ref, q_sh, rtol=1e-9), (q_ref, q_sh)
+    assert np.isclose(ref.step_maxabs(), sh.step_maxabs(), rtol=1e-9)
+
+    # a few full LM iterations through the host loop on both
+    def run(ls, iters=4):
+        opts = N.NLLSOptions(maxiters=iters)
+        data = Opt.NLLSInternal(ls, 0)
+        loop = Opt.OuterLoop(p, opts, data, It.LevMarData(), It.iterate_levmar, N.nullcallback)
+        loop.start()
+        while loop.iteration() == 0:
+            pass
+        return data.bestcost, ls.variables(_capi.VARS_CURRENT)
+    ref2 = MultiVariateLSgpu(p, unfixed); sh2 = ShardedLS(p, unfixed, rank=rank, world=world, dist=dist, host_staged=True)
+    cr, vr = run(ref2); cs, vs = run(sh2)
+    assert np.isclose(cr, cs, rtol=1e-9), (cr, cs)
+    for o in (ref, sh, ref2, sh2):
+        o.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: sharded == unsharded (cost {cs:.6e}, owned {info['local_ncost']} of {p.ncosts()} cost blocks)")
+
+
+if __name__ == "__main__":
+    main()

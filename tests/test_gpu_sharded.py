@@ -1,0 +1,27 @@
+"""N > 1 path on real kernels: two ranks share the single GPU of the test box (gloo + host-staged reductions;
+RCCL itself refuses two ranks on one device) and must reproduce the unsharded result."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_matches_unsharded(world):
+    port = str(29500 + world)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill(); out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+        assert "sharded == unsharded" in out
