@@ -694,6 +694,270 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Blocked bordered-band LDL' (block = 16 columns) -- the factorisation half of the band solver for bw <= 80.
+// Per block column J:
+//   * wave 0 holds EVERY row of the block column (diagonal tile, the NBW sub-diagonal tiles, the border/rhs tile:
+//     <= 128 rows, two per lane) in registers and runs the 16 pivots there: the pivot row is broadcast with
+//     v_readlane (the diagonal tile is kept fully symmetric, so row k of it supplies all multipliers), no LDS
+//     traffic and no barrier inside the block;
+//   * the panel (L and W = L*D) goes to LDS once, then all four waves apply the rank-16 trailing update tile by
+//     tile on the fp64 matrix cores: C(16x16) -= W_I(16x16) * L_K(16x16)', four v_mfma_f64_16x16x4_f64 per tile;
+//   * waves 1-3 stream the next tile column in from HBM (registers one block ahead) and the factor out (band layout,
+//     consumed by band_backward_kernel) while wave 0 factors.
+// Tiles live in an LDS ring indexed by (block column mod (NBW+2), tile row), rows padded to 17 doubles.
+// ---------------------------------------------------------------------------------------------------
+struct BlkArgs { const double* Sb; double* Lb; double* corner_out; int n_band, bw, nbd, H, NBW; int* status; };
+
+NLLS_DEV double readlane_d(double x, int k) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
+}
+
+// The four roles of a block step are separate NON-inlined functions: each gets its own register allocation, and the
+// compiler cannot hoist one role's loop invariants (lane predicates = 64-bit scalar masks) across the others, which
+// spilled scalar registers when everything was one body.
+struct BlkLds { double* tiles; double* corner; double* Lp; double* Wp; double* dvec; int TW, TR, NBW, H, bw, n_band, nJ; };
+constexpr int BLK_P = 17, BLK_TS = 16 * BLK_P;                // padded tile row, doubles per tile
+NLLS_DEV double* blk_tile(const BlkLds& S, int K, int ti) { return S.tiles + ((size_t)(K % S.TW) * S.TR + ti) * BLK_TS; }
+
+// wave 0: rows of block column J in registers (two per lane), 16 pivots with v_readlane broadcast of the pivot row,
+// panel columns leave for LDS as they become final
+__device__ __forceinline__ void blk_factor(const BlkLds& S, int J, int* status) {
+    constexpr int P = BLK_P;
+    const int lane = threadIdx.x & 63;
+    double a0[16], a1[16];
+    const int r0 = lane, r1 = 64 + lane; const bool w0 = (r0 >> 4) < S.TR, w1 = (r1 >> 4) < S.TR;
+    {
+        const double* t0 = blk_tile(S, J, w0 ? (r0 >> 4) : 0) + (r0 & 15) * P;
+        const double* t1 = blk_tile(S, J, w1 ? (r1 >> 4) : 0) + (r1 & 15) * P;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { a0[c] = w0 ? t0[c] : 0.0; a1[c] = w1 ? t1[c] : 0.0; }
+    }
+    double* W0 = S.Wp + (w0 ? r0 : 0) * P; double* L0 = S.Lp + (w0 ? r0 : 0) * P;
+    double* W1 = S.Wp + (w1 ? r1 : 0) * P; double* L1 = S.Lp + (w1 ? r1 : 0) * P;
+    auto pivot = [&](double v, int k, double& dk, double& rdk) {
+        dk = v; if (dk == 0.0 || dk != dk) { if (lane == 0) atomicCAS(status, 0, 1 + 16 * J + k); dk = 1.0; }
+        rdk = __builtin_amdgcn_rcp(dk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);   // Newton: full fp64 accuracy, short chain
+    };
+    double dk, rdk; pivot(readlane_d(a0[0], 0), 0, dk, rdk);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double l0 = a0[k] * rdk, l1 = a1[k] * rdk;
+        if (w0) { W0[k] = a0[k]; L0[k] = l0; }
+        if (w1) { W1[k] = a1[k]; L1[k] = l1; }
+        if (lane == 0) S.dvec[k] = dk;
+        // rows at or above the pivot inside the diagonal tile take no update: mask the multiplier with integer ops
+        const int mk = (k - lane) >> 31;   // all ones iff lane > k
+        const double m0 = __hiloint2double(__double2hiint(l0) & mk, __double2loint(l0) & mk);
+        double dkn = 1.0, rdkn = 1.0;
+        if (k + 1 < 16) {   // column k+1 first, so that the next pivot's reciprocal chain overlaps the rest of this update
+            const double u = readlane_d(a0[k + 1], k); a0[k + 1] = fma(-m0, u, a0[k + 1]); a1[k + 1] = fma(-l1, u, a1[k + 1]);
+            pivot(readlane_d(a0[k + 1], k + 1), k + 1, dkn, rdkn);
+        }
+#pragma unroll
+        for (int c = k + 2; c < 16; ++c) { const double u = readlane_d(a0[c], k); a0[c] = fma(-m0, u, a0[c]); a1[c] = fma(-l1, u, a1[c]); }
+        dk = dkn; rdk = rdkn;
+    }
+}
+// tile column K <- band layout in HBM (identity behind the last column); threads t0, t0+nt, ...  Gather form: every
+// word of the TR tiles is computed from its (row, column), so the ring slot needs no zero fill and one pass suffices.
+__device__ __forceinline__ void blk_land(const BlkLds& S, const double* __restrict__ Sb, int K, int t0, int nt) {
+    constexpr int P = BLK_P;
+    double* base = blk_tile(S, K, 0);
+    const int H = S.H, nwords = S.TR * 16 * 16;
+    for (int w = t0; w < nwords; w += nt) {
+        const int ti = w >> 8, r = (w >> 4) & 15, cc = w & 15;
+        int c = 16 * K + cc, e;
+        if (ti <= S.NBW) { e = 16 * ti + r - cc; if (e < 0) { c = 16 * K + r; e = -e; } }     // upper part of the diagonal tile: mirror
+        else e = S.bw + 1 + r;                                                              // border tile: row r = border index
+        double val = 0.0;
+        if (e < H && (ti > S.NBW || e <= S.bw)) val = (c < S.n_band) ? Sb[(size_t)c * H + e] : (e == 0 ? 1.0 : 0.0);
+        base[(size_t)ti * BLK_TS + r * P + cc] = val;
+    }
+}
+// rank-16 trailing update on the matrix cores: tile-updates u = w0, w0+nw, ... of (K = 1..NBW: pi = K..NBW and the border
+// tile row) plus the border corner
+struct BlkUpd { int K[8], pi[8], trow[8]; };                   // this wave's tile-updates (same list at every block step)
+__device__ __forceinline__ void blk_update_list(const BlkLds& S, int w0, int nw, BlkUpd& U) {
+    const int NBW = S.NBW, nup = NBW * (NBW + 1) / 2 + NBW + 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int u = w0 + q * nw; U.K[q] = -1; U.pi[q] = 0; U.trow[q] = 0;
+        if (u < nup - 1) { int uu = u, K = 1; while (uu >= NBW - K + 2) { uu -= NBW - K + 2; ++K; }
+            U.K[q] = K; U.pi[q] = (uu == NBW - K + 1) ? NBW + 1 : K + uu; U.trow[q] = (uu == NBW - K + 1) ? NBW + 1 : uu; }
+        else if (u == nup - 1) { U.K[q] = 0; U.pi[q] = NBW + 1; }    // K = 0 marks the border corner
+    }
+}
+__device__ __forceinline__ void blk_update(const BlkLds& S, int J, int jslot, const BlkUpd& U) {
+    constexpr int P = BLK_P, MAXU = 8;
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    double* Ct[MAXU]; double4_t acc[MAXU], acc2[MAXU]; double wv[MAXU][4], lv[MAXU][4]; bool ok[MAXU];
+    // all operand loads first, then the MFMAs, then the stores: the LDS latency of one tile hides behind the others
+#pragma unroll
+    for (int q = 0; q < MAXU; ++q) {
+        const int K = U.K[q]; ok[q] = K >= 0 && (K == 0 || J + K < S.nJ);
+        int sl = jslot + (K > 0 ? K : 0); if (sl >= S.TW) sl -= S.TW;
+        Ct[q] = (K > 0) ? S.tiles + ((size_t)sl * S.TR + U.trow[q]) * BLK_TS : S.corner;
+        const double* Wt = S.Wp + (size_t)U.pi[q] * 16 * P; const double* Lt = S.Lp + (size_t)(K > 0 ? K : S.NBW + 1) * 16 * P;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { wv[q][kk] = -Wt[li * P + 4 * kk + lk]; lv[q][kk] = Lt[li * P + 4 * kk + lk]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = Ct[q][(lk + 4 * r) * P + li];
+        acc2[q] = double4_t{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int q = 0; q < MAXU; ++q) {
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][0], lv[q][0], acc[q], 0, 0, 0);
+        acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][1], lv[q][1], acc2[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXU; ++q) {
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][2], lv[q][2], acc[q], 0, 0, 0);
+        acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][3], lv[q][3], acc2[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXU; ++q) if (ok[q]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[q][(lk + 4 * r) * P + li] = acc[q][r] + acc2[q][r];
+    }
+}
+// factor block column J -> HBM in band layout: entry 0 = D, 1..bw = L, then border rows + rhs
+__device__ __forceinline__ void blk_export(const BlkLds& S, const double* __restrict__ Lsrc, const double* __restrict__ dsrc, double* __restrict__ Lb, int J, int t0, int nt) {
+    constexpr int P = BLK_P;
+    const int H = S.H, col_elems = 16 * H;
+    int cc = t0 / H, e = t0 - cc * H;
+    const int dcc = nt / H, de = nt - dcc * H;
+    for (int idx = t0; idx < col_elems; idx += nt) {
+        const int c = 16 * J + cc;
+        if (c < S.n_band) {
+            double v;
+            if (e == 0) v = dsrc[cc];
+            else if (e <= S.bw) { const int rr = cc + e; v = ((rr >> 4) <= S.NBW) ? Lsrc[rr * P + cc] : 0.0; }
+            else v = Lsrc[((S.NBW + 1) * 16 + (e - S.bw - 1)) * P + cc];
+            Lb[(size_t)c * H + e] = v;
+        }
+        cc += dcc; e += de; if (e >= H) { e -= H; ++cc; }
+    }
+}
+
+__global__ __launch_bounds__(256) void band_blocked_factor_kernel(BlkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int P = BLK_P, TS = BLK_TS;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int n_band = a.n_band, nbd = a.nbd, H = a.H, NBW = a.NBW, nbr = nbd + 1;
+    BlkLds S; S.TW = NBW + 2; S.TR = NBW + 2; S.NBW = NBW; S.H = H; S.bw = a.bw; S.n_band = n_band; S.nJ = (n_band + 15) >> 4;
+    S.tiles = sm;                                             // [TW][TR][TS]
+    S.corner = S.tiles + (size_t)S.TW * S.TR * TS;            // [TS] border x border (row/col = border index, rhs = nbd)
+    S.Lp = S.corner + TS;                                     // [TR*16][P]
+    S.Wp = S.Lp + (size_t)S.TR * 16 * P;                      // [TR*16][P]
+    S.dvec = S.Wp + (size_t)S.TR * 16 * P;                    // [16]
+    const int nJ = S.nJ;
+    for (int i = tid; i < S.TW * S.TR * TS + TS; i += 256) S.tiles[i] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < nbr * nbr; e += 256) { const int i = e % nbr, j = e / nbr; if (i >= j) { const double v = a.Sb[(size_t)n_band * H + e]; S.corner[i * P + j] = v; S.corner[j * P + i] = v; } }
+    for (int K = 0; K <= NBW && K < nJ; ++K) blk_land(S, a.Sb, K, tid, 256);
+    double* Lc = S.dvec + 16;                                 // copy of the previous block's L panel and D (exported by the helpers)
+    double* dc = Lc + (size_t)S.TR * 16 * P;
+    BlkUpd U; blk_update_list(S, wave, 4, U);
+    int jslot = 0;                                            // J % TW
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();   // diagnostics only (nlls_get_solve_stats)
+    for (int J = 0; J < nJ; ++J) {
+        __syncthreads();                                      // (A) block column J is final
+        if (wave == 0) blk_factor(S, J, a.status);
+        else {
+            // helpers, hidden behind wave 0's factorisation: land tile column J+NBW+1 into the ring slot of column J-1
+            // (HBM latency), export block J-1 from its copy
+            if (J + NBW + 1 < nJ) blk_land(S, a.Sb, J + NBW + 1, tid - 64, 192);
+            if (J > 0) blk_export(S, Lc, dc, a.Lb, J - 1, tid - 64, 192);
+        }
+        __syncthreads();                                      // (B) panel in LDS
+        if (wave > 0) {
+            for (int i = tid - 64; i < S.TR * 16 * P; i += 192) Lc[i] = S.Lp[i];
+            if (tid - 64 < 16) dc[tid - 64] = S.dvec[tid - 64];
+        }
+        blk_update(S, J, jslot, U);
+        if (++jslot == S.TW) jslot = 0;
+    }
+    __syncthreads();
+    blk_export(S, S.Lp, S.dvec, a.Lb, nJ - 1, tid, 256);
+    __syncthreads();
+    for (int e = tid; e < nbr * nbr; e += 256) { const int i = e % nbr, j = e / nbr; a.corner_out[e] = S.corner[i * P + j]; }
+    if (tid == 0) a.status[2] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+}
+
+// Border corner + backward pass of the band solver (factor in band layout from band_blocked_factor_kernel).
+__global__ __launch_bounds__(256) void band_backward_kernel(BandArgs a, const double* __restrict__ corner_in) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_band = a.n_band, bw = a.bw, nbd = a.nbd, H = a.H, CH = a.CH, RC = a.RC, nbr = nbd + 1;
+    double* W = sm;                               // RC * H ring of factor columns
+    double* Cl = W + (size_t)RC * H;              // nbr x nbr border corner (col-major, lower), last row = rhs
+    double* xb = Cl + nbr * nbr;                  // nbr
+    for (int e = tid; e < nbr * nbr; e += 256) Cl[e] = corner_in[e];
+    __syncthreads();
+    const unsigned long long t_factor = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+        for (int j = 0; j < nbd; ++j) {
+            double d = Cl[j + nbr * j];
+            if (d == 0.0 || d != d) { atomicCAS(a.status, 0, 1 + n_band + j); d = 1.0; }
+            for (int c2 = j + 1; c2 < nbd; ++c2) { const double f = Cl[c2 + nbr * j] / d; for (int i = c2; i < nbr; ++i) Cl[i + nbr * c2] -= Cl[i + nbr * j] * f; }
+            for (int i = j + 1; i < nbr; ++i) Cl[i + nbr * j] /= d;
+            Cl[j + nbr * j] = d;
+        }
+        for (int r = nbd - 1; r >= 0; --r) { double v = Cl[nbd + nbr * r]; for (int r2 = r + 1; r2 < nbd; ++r2) v -= Cl[r2 + nbr * r] * xb[r2]; xb[r] = v; a.xr[n_band + r] = v; }
+    }
+    __syncthreads();
+    const int M = (n_band + CH - 1) / CH;
+    auto stage = [&](int m, int t0, int nt) {
+        if (m < 0) return;
+        const int c0 = m * CH; const int ncol = min(CH, n_band - c0);
+        double* dst = W + (size_t)(c0 % RC) * H; const size_t g0 = (size_t)c0 * H;
+        for (int idx = t0; idx < ncol * H; idx += nt) dst[idx] = a.Lb[g0 + idx];
+    };
+    const int PFB = a.PFC;
+    for (int m = M - 1; m >= M - PFB && m >= 0; --m) stage(m, tid, 256);
+    __syncthreads();
+    double za = 0, zb = 0, zc = 0;
+    auto zinit = [&](int ringslot) { const double* c2 = W + (size_t)ringslot * H; double v = c2[bw + 1 + nbd]; for (int q = 0; q < nbd; ++q) v -= c2[bw + 1 + q] * xb[q]; return v; };
+    if (wave == 0) {
+        const int Btop = (n_band - 1) >> 6;
+        for (int r = n_band - 1; r >= max(0, n_band - 1 - bw); --r) if ((r & 63) == lane) { const double v = zinit(r % RC); const int k = Btop - (r >> 6); if (k == 0) za = v; else if (k == 1) zb = v; else zc = v; }
+    }
+    int rin_slot = ((n_band - 2 - bw) % RC + RC) % RC;
+    for (int m = M - 1; m >= 0; --m) {
+        if (wave == 0) {
+            const int hi = min(n_band, (m + 1) * CH) - 1;
+            int i = hi;
+            while (i >= m * CH) {
+                const int B = i >> 6; const int lo = max(m * CH, B << 6);
+                int e_a = i - ((B << 6) + lane), e_b = e_a + 64, e_c = e_a + 128;
+                const int ra = (B << 6) + lane, rb = ra - 64, rc3 = ra - 128;
+                const double* pa = W + (size_t)((ra % RC + RC) % RC) * H + e_a;
+                const double* pbp = W + (size_t)((rb % RC + RC) % RC) * H + e_b;
+                const double* pc = W + (size_t)((rc3 % RC + RC) % RC) * H + e_c;
+                for (; i >= lo; --i) {
+                    const int li = i & 63;
+                    const double xi = readlane_d(za, li);
+                    if (lane == li) a.xr[i] = xi;
+                    const double la = (e_a >= 1 && e_a <= bw) ? *pa : 0.0;
+                    const double lb = (e_b <= bw && rb >= 0) ? *pbp : 0.0;
+                    const double lc = (e_c <= bw && rc3 >= 0) ? *pc : 0.0;
+                    za = fma(-la, xi, za); zb = fma(-lb, xi, zb); zc = fma(-lc, xi, zc);
+                    const int rin = i - 1 - bw;
+                    if (rin >= 0 && (rin & 63) == lane) { const double v = zinit(rin_slot); const int k = B - (rin >> 6); if (k == 0) za = v; else if (k == 1) zb = v; else zc = v; }
+                    if (--rin_slot < 0) rin_slot = RC - 1;
+                    --e_a; --e_b; --e_c; --pa; --pbp; --pc;
+                }
+                if (i >= 0 && (i >> 6) != B) { za = zb; zb = zc; zc = 0.0; }
+            }
+        } else {
+            stage(m - PFB, tid - 64, 192);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_factor) >> 10);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // fast_bAb(H + lambda I, v) and dot(b, v)   src/utils.jl:71-106, src/iterators.jl:52,163
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void quadform_blocks_kernel(const double* __restrict__ A, const SchurCopy* __restrict__ blk, int64_t nblk,
@@ -825,6 +1089,15 @@ int enqueue_solve_finish(nlls_ctx* c) {
         a.PFC = (L.bw + 1 + a.CH - 1) / a.CH + 1; a.RC = (a.PFC + 1) * a.CH; a.NSC = (L.bw + 1 + c->band_SEG - 1) / c->band_SEG;
         const int nbr = L.nbd + 1;
         const size_t lds = sizeof(double) * ((size_t)a.RC * L.H + 2 * (size_t)(2 * a.NSC * c->band_SEG + 2 * c->band_SEG) + (size_t)(L.bw + 2) * nbr + (size_t)nbr * nbr + nbr + 8);
+        const int NBW = (L.bw + 15) / 16;                // tile rows below the diagonal tile that a block column reaches
+        const size_t blk_lds = sizeof(double) * ((size_t)(NBW + 2) * (NBW + 2) * 272 + 272 + 3 * (size_t)(NBW + 2) * 16 * 17 + 32 + 8);
+        if (c->band_blocked && NBW <= 5 && (NBW + 2) * 16 <= 128 && L.H <= 96 && blk_lds <= 160 * 1024) {
+            BlkArgs bkl{}; bkl.Sb = c->S.p; bkl.Lb = c->Lwork.p; bkl.corner_out = c->Lwork.p + (size_t)L.H * L.n_band; bkl.n_band = L.n_band; bkl.bw = L.bw; bkl.nbd = L.nbd;
+            bkl.H = L.H; bkl.NBW = NBW; bkl.status = c->d_status.p;
+            hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(256), blk_lds, c->stream, bkl);
+            const size_t lds_b = sizeof(double) * ((size_t)a.RC * L.H + (size_t)nbr * nbr + nbr + 8);
+            hipLaunchKernelGGL(band_backward_kernel, dim3(1), dim3(256), lds_b, c->stream, a, (const double*)bkl.corner_out);
+        } else
 #define LAUNCH_BAND(SEG, NSLOT) hipLaunchKernelGGL((band_ldlt_solve_kernel<SEG, NSLOT>), dim3(1), dim3(256), lds, c->stream, a)
         if (c->band_SEG == 10 && c->band_NSEG == 2) LAUNCH_BAND(10, 2);
         else if (c->band_SEG == 8 && c->band_NSEG == 1) LAUNCH_BAND(8, 1);
