@@ -916,38 +916,42 @@ __global__ __launch_bounds__(256) void band_backward_kernel(BandArgs a, const do
     const int PFB = a.PFC;
     for (int m = M - 1; m >= M - PFB && m >= 0; --m) stage(m, tid, 256);
     __syncthreads();
-    double za = 0, zb = 0, zc = 0;
-    auto zinit = [&](int ringslot) { const double* c2 = W + (size_t)ringslot * H; double v = c2[bw + 1 + nbd]; for (int q = 0; q < nbd; ++q) v -= c2[bw + 1 + q] * xb[q]; return v; };
-    if (wave == 0) {
-        const int Btop = (n_band - 1) >> 6;
-        for (int r = n_band - 1; r >= max(0, n_band - 1 - bw); --r) if ((r & 63) == lane) { const double v = zinit(r % RC); const int k = Btop - (r >> 6); if (k == 0) za = v; else if (k == 1) zb = v; else zc = v; }
-    }
-    int rin_slot = ((n_band - 2 - bw) % RC + RC) % RC;
+    // Blocked axpy-form backward pass on wave 0: 16 rows per step.  Lane l holds the partially reduced unknowns of rows
+    // top - l (slot 0) and top - 64 - l (slot 1), top = last row of the current block; the block's own unknowns are lanes
+    // 0..15 of slot 0.  Step k broadcasts x of row top-k with v_readlane and every lane subtracts L(top-k, its row) * x:
+    // for a lane those are 16 consecutive entries of ITS factor column (band layout), read once per block.
+    const int nJb = (n_band + 15) >> 4;
+    const int NR = 16 * ((bw + 16 + 15) / 16);                  // rows (relative to top) kept live: the band reach, rounded up
+    auto col = [&](int r) { return W + (size_t)((r % RC + RC) % RC) * H; };
+    auto zinit = [&](int r) { if (r < 0 || r >= n_band) return 0.0; const double* c2 = col(r); double v = c2[bw + 1 + nbd]; for (int q = 0; q < nbd; ++q) v -= c2[bw + 1 + q] * xb[q]; return v; };
+    double z0 = 0, z1 = 0;
+    if (wave == 0) { const int top = 16 * (nJb - 1) + 15; z0 = (lane < NR) ? zinit(top - lane) : 0.0; z1 = (64 + lane < NR) ? zinit(top - 64 - lane) : 0.0; }
+    const int BPC = CH / 16;                                    // blocks per staging chunk
     for (int m = M - 1; m >= 0; --m) {
         if (wave == 0) {
-            const int hi = min(n_band, (m + 1) * CH) - 1;
-            int i = hi;
-            while (i >= m * CH) {
-                const int B = i >> 6; const int lo = max(m * CH, B << 6);
-                int e_a = i - ((B << 6) + lane), e_b = e_a + 64, e_c = e_a + 128;
-                const int ra = (B << 6) + lane, rb = ra - 64, rc3 = ra - 128;
-                const double* pa = W + (size_t)((ra % RC + RC) % RC) * H + e_a;
-                const double* pbp = W + (size_t)((rb % RC + RC) % RC) * H + e_b;
-                const double* pc = W + (size_t)((rc3 % RC + RC) % RC) * H + e_c;
-                for (; i >= lo; --i) {
-                    const int li = i & 63;
-                    const double xi = readlane_d(za, li);
-                    if (lane == li) a.xr[i] = xi;
-                    const double la = (e_a >= 1 && e_a <= bw) ? *pa : 0.0;
-                    const double lb = (e_b <= bw && rb >= 0) ? *pbp : 0.0;
-                    const double lc = (e_c <= bw && rc3 >= 0) ? *pc : 0.0;
-                    za = fma(-la, xi, za); zb = fma(-lb, xi, zb); zc = fma(-lc, xi, zc);
-                    const int rin = i - 1 - bw;
-                    if (rin >= 0 && (rin & 63) == lane) { const double v = zinit(rin_slot); const int k = B - (rin >> 6); if (k == 0) za = v; else if (k == 1) zb = v; else zc = v; }
-                    if (--rin_slot < 0) rin_slot = RC - 1;
-                    --e_a; --e_b; --e_c; --pa; --pbp; --pc;
+            for (int Jb = min(nJb, (m + 1) * BPC) - 1; Jb >= m * BPC; --Jb) {
+                const int top = 16 * Jb + 15;
+                const int r0 = top - lane, r1 = top - 64 - lane;
+                const bool v0 = r0 >= 0 && r0 < n_band, v1 = r1 >= 0 && r1 < n_band;
+                const double* c0 = col(v0 ? r0 : 0); const double* c1 = col(v1 ? r1 : 0);
+                // entries e = lane - k (slot 0) and 64 + lane - k (slot 1), k = 0..15, of this lane's columns
+                double l0[16], l1[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int e0 = lane - k, e1 = 64 + lane - k;
+                    l0[k] = (v0 && e0 >= 1 && e0 <= bw && top - k < n_band) ? c0[e0] : 0.0;
+                    l1[k] = (v1 && e1 <= bw && top - k < n_band) ? c1[e1] : 0.0;
                 }
-                if (i >= 0 && (i >> 6) != B) { za = zb; zb = zc; zc = 0.0; }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const double xk = readlane_d(z0, k); z0 = fma(-l0[k], xk, z0); z1 = fma(-l1[k], xk, z1); }
+                if (lane < 16 && v0) a.xr[r0] = z0;             // rows of the block: final (a lane is never updated by its own or later rows)
+                // shift the window down by one block: lane l <- lane l + 16; slot 0 refills from slot 1; rows entering the reach get z = rhs - border part
+                const double s0 = __shfl_down(z0, 16, 64), s1 = __shfl_down(z1, 16, 64), t1 = __shfl(z1, (lane + 16) & 63, 64);
+                z0 = (lane < 48) ? s0 : t1;
+                z1 = (lane < 48) ? s1 : 0.0;
+                const int ntop = top - 16;
+                if (lane >= NR - 16 && lane < NR && lane < 64) z0 = zinit(ntop - lane);
+                if (64 + lane >= NR - 16 && 64 + lane < NR) z1 = zinit(ntop - 64 - lane);
             }
         } else {
             stage(m - PFB, tid - 64, 192);
@@ -1095,8 +1099,10 @@ int enqueue_solve_finish(nlls_ctx* c) {
             BlkArgs bkl{}; bkl.Sb = c->S.p; bkl.Lb = c->Lwork.p; bkl.corner_out = c->Lwork.p + (size_t)L.H * L.n_band; bkl.n_band = L.n_band; bkl.bw = L.bw; bkl.nbd = L.nbd;
             bkl.H = L.H; bkl.NBW = NBW; bkl.status = c->d_status.p;
             hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(256), blk_lds, c->stream, bkl);
-            const size_t lds_b = sizeof(double) * ((size_t)a.RC * L.H + (size_t)nbr * nbr + nbr + 8);
-            hipLaunchKernelGGL(band_backward_kernel, dim3(1), dim3(256), lds_b, c->stream, a, (const double*)bkl.corner_out);
+            BandArgs ab = a;   // the backward pass keeps NR = 16*ceil((bw+16)/16) rows in reach: its own ring depth
+            { const int NR = 16 * ((L.bw + 16 + 15) / 16); ab.PFC = (NR + ab.CH - 1) / ab.CH + 1; ab.RC = (ab.PFC + 1) * ab.CH; }
+            const size_t lds_b = sizeof(double) * ((size_t)ab.RC * L.H + (size_t)nbr * nbr + nbr + 8);
+            hipLaunchKernelGGL(band_backward_kernel, dim3(1), dim3(256), lds_b, c->stream, ab, (const double*)bkl.corner_out);
         } else
 #define LAUNCH_BAND(SEG, NSLOT) hipLaunchKernelGGL((band_ldlt_solve_kernel<SEG, NSLOT>), dim3(1), dim3(256), lds, c->stream, a)
         if (c->band_SEG == 10 && c->band_NSEG == 2) LAUNCH_BAND(10, 2);
