@@ -173,7 +173,8 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_elim_group;     // supernodes: runs of eliminated blocks with identical neighbour sets
     int64_t nelim_groups = 0, n_fast_groups = 0, n_slow_groups = 0;
     nlls::DevBuf<uint32_t> d_fast_groups, d_slow_groups;
-    int fast_dv = 0, fast_maxk = 0;
+    int fast_dv = 0, fast_maxk = 0, fast_maxk_narrow = 0;
+    int64_t n_fast_narrow = 0;               // fast supernodes with nd + 1 <= 64 come first in d_fast_groups
     int max_elim_dim = 0, max_nbr_dof = 0;
     bool elim_use_acc = false; size_t elim_lds = 0;
     int64_t n_band = 0; int nbd = 0, bw = 0;   // reduced ordering: [banded part | border dof | rhs]

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
 // of [E | b]: it loads its DV entries plus C_v straight into registers (one memory latency per block, the next
 // block's loads are issued before the current one is consumed), factors C_v redundantly in registers (no LDS, no
 // barrier), and the pair products are accumulated in REGISTERS (static pair list per lane), flushed once per run.
-template <int DV, int MAXK>
+template <int DV, int MAXK, int NCOL>
 __global__ __launch_bounds__(64) void schur_elim_fast_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                              const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
                                                              const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
@@ -197,13 +197,15 @@ __global__ __launch_bounds__(64) void schur_elim_fast_kernel(const double* __res
         while ((p + 1) * (p + 2) / 2 <= t) ++p;
         pq[k] = (t < npairs) ? ((uint32_t)p << 16 | (uint32_t)(t - p * (p + 1) / 2)) : 0xFFFFFFFFu; acc[k] = 0.0;
     }
-    double accs[2] = {0.0, 0.0};                          // column p = lane + 64 u < nd: sum of E(:,p)' y_b
+    double accs[NCOL];
+#pragma unroll
+    for (int u = 0; u < NCOL; ++u) accs[u] = 0.0;                          // column p = lane + 64 u < nd: sum of E(:,p)' y_b
     // software pipeline: registers hold the NEXT block's columns (lane owns columns lane and lane + 64) and diagonal block
-    double en[2][DV], cn[DV * DV];
+    double en[NCOL][DV], cn[DV * DV];
     auto issue = [&](uint32_t v) {
         const int64_t seg = ediag[v] - (int64_t)DV * nd;   // the off-diagonal blocks sit right before the diagonal block
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const int col = lane + 64 * u;
+        for (int u = 0; u < NCOL; ++u) { const int col = lane + 64 * u;
 #pragma unroll
             for (int a2 = 0; a2 < DV; ++a2) en[u][a2] = (col < nd) ? A[seg + (int64_t)DV * col + a2] : ((col == nd) ? b[eboff[v] + a2] : 0.0); }
 #pragma unroll
@@ -212,9 +214,9 @@ __global__ __launch_bounds__(64) void schur_elim_fast_kernel(const double* __res
     issue(v0);
     int buf = 0;
     for (uint32_t v = v0; v < v1; ++v, buf ^= 1) {
-        double e[2][DV], C[DV * DV];
+        double e[NCOL][DV], C[DV * DV];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < NCOL; ++u)
 #pragma unroll
             for (int a2 = 0; a2 < DV; ++a2) e[u][a2] = en[u][a2];
 #pragma unroll
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(64) void schur_elim_fast_kernel(const double* __res
                 C[i + DV * j] = t / d; }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NCOL; ++u) {
             const int col = lane + 64 * u;
             double y[DV];
 #pragma unroll
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64) void schur_elim_fast_kernel(const double* __res
             acc[k] += a2;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) if (lane + 64 * u < nd) { double a2 = 0;
+        for (int u = 0; u < NCOL; ++u) if (lane + 64 * u < nd) { double a2 = 0;
 #pragma unroll
             for (int a3 = 0; a3 < DV; ++a3) a2 += e[u][a3] * Yb[a3 + DV * nd];
             accs[u] += a2; }
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(64) void schur_elim_fast_kernel(const double* __res
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) if (pq[k] != 0xFFFFFFFFu) atomicAdd(L.at(rc[pq[k] >> 16], rc[pq[k] & 0xFFFF]), -acc[k]);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) if (lane + 64 * u < nd) atomicAdd(&s[rc[lane + 64 * u]], -accs[u]);
+    for (int u = 0; u < NCOL; ++u) if (lane + 64 * u < nd) atomicAdd(&s[rc[lane + 64 * u]], -accs[u]);
 }
 
 // x_v = C_v^-1 (b_v - E_v x_R), stored negated (negate!, src/iterators.jl:3)
@@ -1066,15 +1068,19 @@ int enqueue_solve_local(nlls_ctx* c) {
             hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)c->n_slow_groups), dim3(64), c->elim_lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
                                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->d_slow_groups.p, c->lambda, c->max_elim_dim, c->max_nbr_dof,
                                c->elim_use_acc ? 1 : 0, L, c->s_ptr(), c->d_status.p);
+        // supernodes whose [E | b] fits one column per lane (nd + 1 <= 64) and wider ones (two per lane)
+#define LAUNCH_FAST(DV, MAXK, NCOL, N, LIST) hipLaunchKernelGGL((schur_elim_fast_kernel<DV, MAXK, NCOL>), dim3((unsigned)(N)), dim3(64), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, LIST, c->lambda, L, c->s_ptr(), c->d_status.p)
+#define LAUNCH_FAST_DV(DV) do { \
+            if (c->n_fast_narrow > 0) { if (c->fast_maxk_narrow <= 12) LAUNCH_FAST(DV, 12, 1, c->n_fast_narrow, c->d_fast_groups.p); \
+                                        else if (c->fast_maxk_narrow <= 24) LAUNCH_FAST(DV, 24, 1, c->n_fast_narrow, c->d_fast_groups.p); \
+                                        else LAUNCH_FAST(DV, 32, 1, c->n_fast_narrow, c->d_fast_groups.p); } \
+            if (c->n_fast_groups > c->n_fast_narrow) LAUNCH_FAST(DV, 40, 2, c->n_fast_groups - c->n_fast_narrow, c->d_fast_groups.p + c->n_fast_narrow); } while (0)
         if (c->n_fast_groups > 0) {
-#define LAUNCH_FAST(DV, MAXK) hipLaunchKernelGGL((schur_elim_fast_kernel<DV, MAXK>), dim3((unsigned)c->n_fast_groups), dim3(64), 0, c->stream, c->A.p, c->b.p, \
-                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->lambda, L, c->s_ptr(), c->d_status.p)
-            const int maxk = c->fast_maxk;
-            if (c->fast_dv == 3) { if (maxk <= 12) LAUNCH_FAST(3, 12); else if (maxk <= 24) LAUNCH_FAST(3, 24); else LAUNCH_FAST(3, 40); }
-            else if (c->fast_dv == 2) { if (maxk <= 12) LAUNCH_FAST(2, 12); else if (maxk <= 24) LAUNCH_FAST(2, 24); else LAUNCH_FAST(2, 40); }
-            else if (c->fast_dv == 1) { if (maxk <= 12) LAUNCH_FAST(1, 12); else if (maxk <= 24) LAUNCH_FAST(1, 24); else LAUNCH_FAST(1, 40); }
-#undef LAUNCH_FAST
+            if (c->fast_dv == 3) LAUNCH_FAST_DV(3); else if (c->fast_dv == 2) LAUNCH_FAST_DV(2); else if (c->fast_dv == 1) LAUNCH_FAST_DV(1);
         }
+#undef LAUNCH_FAST_DV
+#undef LAUNCH_FAST
     }
     HIPCHK(hipGetLastError());
     return NLLS_OK;
