@@ -36,7 +36,7 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return NLLS_ERR_NO_DEVICE;  // the code object is gfx950-only
     nlls_ctx* c = new (std::nothrow) nlls_ctx();
     if (!c) return NLLS_ERR_HIP;
-    c->device = dev;
+    c->device = dev; c->num_cus = prop.multiProcessorCount;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return NLLS_ERR_HIP; }
     c->own_stream = true;
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||

@@ -146,6 +146,7 @@ struct nlls_ctx {
     int64_t nzero = 0;
     nlls::DevBuf<uint32_t> d_zero_b_off, d_zero_b_len;
     nlls::DevBuf<double> partials;           // per-workgroup cost partials
+    int num_cus = 256;
     nlls::DevBuf<double> scalars;            // small device scratch for scalar results
     double* h_scalars = nullptr;             // pinned host mirror
     int64_t npartials = 0;

@@ -383,6 +383,14 @@ struct BlockGH {
                 for (int q = 0; q < var_storage(R::SK[S], R::SD[S]); ++q) st[S][q] = vars[voff[S] + q]; }(), ...);
         }(std::make_integer_sequence<int, R::NDEPS>{});
     }
+    // forces the gathered values into registers at this point of the program, i.e. places their s_waitcnt here
+    static NLLS_DEV void pin(double (*st)[MAXST]) {
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+#pragma unroll
+                for (int q = 0; q < var_storage(R::SK[S], R::SD[S]); ++q) { double v = st[S][q]; asm volatile("" : "+v"(v)); st[S][q] = v; } }(), ...);
+        }(std::make_integer_sequence<int, R::NDEPS>{});
+    }
     NLLS_DEV void compute(const double* __restrict__ vars, const uint32_t* voff, const double* data, const RobustSpec& rk, bool kernel_free) {
         double st[R::NDEPS][MAXST]; load(vars, voff, st); compute_st(st, data, rk, kernel_free);
     }

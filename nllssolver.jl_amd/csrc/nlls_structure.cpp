@@ -32,7 +32,7 @@ static int fail(nlls_ctx* c, int code, const std::string& msg) { c->err = msg; r
 constexpr uint32_t LIGHT_MAX_ENTRIES = 256;    // one entry per lane of a 256-thread workgroup
 constexpr uint32_t LIGHT_IMG_MAX     = 6144;   // doubles of LDS image (48 KiB) -> 3 workgroups per CU
 constexpr uint32_t HEAVY_ROW_ENTRIES = 128;    // rows with more entries get a workgroup of their own
-constexpr uint32_t HEAVY_MAX_ENTRIES = 1024;   // entries per heavy tile (4 per lane, loaded as one batch); longer rows are split (PARTIAL)
+constexpr uint32_t HEAVY_MAX_ENTRIES = 1024;   // entries per heavy tile (two wavefronts x 8 pipeline stages); longer rows are split (PARTIAL)
 
 int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {

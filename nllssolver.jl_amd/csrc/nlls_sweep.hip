@@ -30,6 +30,8 @@ NLLS_DEV void static_for(F&& f) {
     [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
 }
 
+// this file is compiled with -fno-honor-nans (see the Makefile): NaN tests must look at the bits
+NLLS_DEV bool is_nan_bits(double v) { return (__double_as_longlong(v) & 0x7fffffffffffffffLL) > 0x7ff0000000000000LL; }
 NLLS_DEV double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -131,6 +133,10 @@ __global__ __launch_bounds__(TPB) void reduce_partials_kernel(const double* __re
 // ================================================================================================
 // accumulate: light tiles (many rows per workgroup, one entry per lane)
 // ================================================================================================
+// workgroup barrier that only waits for this wavefront's LDS / scalar traffic: __syncthreads() would also drain
+// vmcnt, i.e. stall on the global loads and stores that are deliberately left in flight across it
+NLLS_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int KIND, int SLOT>
 __global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
                                                        const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ edest,
@@ -139,26 +145,35 @@ __global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict_
     using R = Res<KIND>; using I = ResInfo<KIND>;
     constexpr int DS = I::dof(SLOT);
     constexpr int NSYM = DS * (DS + 1) / 2, NACC = NSYM + DS;   // lower triangle of the diagonal block + b, per accumulator copy
-    extern __shared__ __attribute__((aligned(16))) double img[];
+    extern __shared__ __attribute__((aligned(16))) double img_raw[];
     __shared__ double red[TPB / 64];
     const Tile t = tiles[blockIdx.x];
+    // the image is shifted by one double when its A.data segment starts on an odd index, so that 16-byte aligned
+    // LDS reads pair up with 16-byte aligned HBM stores at the flush
+    const uint32_t odd = (uint32_t)(t.data_off & 1);
+    double* img = img_raw + odd;
     const uint32_t imglen = t.data_len + t.b_len;
     double* acc = img + imglen;                                 // [nrows][ACC_COPIES][NACC]
     const uint32_t acclen = t.nrows * ACC_COPIES * NACC;
+    // this lane's entry (a light tile holds at most TPB entries) and the row record its first fold item needs: issued
+    // before the LDS set-up so that their HBM latency overlaps it
+    const uint32_t e = t.e0 + threadIdx.x; const bool ok = e < t.e1; const uint32_t ee = ok ? e : t.e0;
+    double d[R::NDATA]; uint32_t vo[R::NDEPS], ds[R::NDEPS];
+#pragma unroll
+    for (int q = 0; q < R::NDATA; ++q) d[q] = edata[(size_t)ee * R::NDATA + q];
+#pragma unroll
+    for (int q = 0; q < R::NDEPS; ++q) { vo[q] = evoff[(size_t)ee * R::NDEPS + q]; ds[q] = edest[(size_t)ee * R::NDEPS + q]; }
+    const uint32_t nfold = t.nrows * NACC;
+    const RowInfo ri0 = rows[t.row0 + (threadIdx.x < nfold ? threadIdx.x / NACC : 0)];
     // exclusive rows whose off-diagonal blocks each have exactly one writer are fully overwritten: no zero fill
     if (!(t.flags & TILE_NOZERO)) for (uint32_t i = threadIdx.x; i < imglen; i += TPB) img[i] = 0.0;
     for (uint32_t i = threadIdx.x; i < acclen; i += TPB) acc[i] = 0.0;
-    __syncthreads();
+    lds_barrier();
     double mycost = 0;
-    for (uint32_t e = t.e0 + threadIdx.x; e < t.e1; e += TPB) {
-        double d[R::NDATA]; uint32_t vo[R::NDEPS], ds[R::NDEPS];
-#pragma unroll
-        for (int q = 0; q < R::NDATA; ++q) d[q] = edata[(size_t)e * R::NDATA + q];
-#pragma unroll
-        for (int q = 0; q < R::NDEPS; ++q) { vo[q] = evoff[(size_t)e * R::NDEPS + q]; ds[q] = edest[(size_t)e * R::NDEPS + q]; }
+    if (ok) {
         const uint32_t own = ds[SLOT];
         BlockGH<KIND> B; B.compute(vars, vo, d, rk, (own & OWN_KERNEL_FREE) != 0);
-        if (own & OWN_COST_OWNER) mycost += B.cost;
+        if (own & OWN_COST_OWNER) mycost = B.cost;
         // diagonal block (lower triangle; mirrored at the flush) and b: LDS atomics into one of ACC_COPIES accumulators of
         // the row, chosen by the entry's rank in its row, so that neighbouring lanes of a row hit different addresses
         double* ar = acc + ((size_t)(own & OWN_ROW_MASK) * ACC_COPIES + ((own >> OWN_COPY_SHIFT) & (ACC_COPIES - 1))) * NACC;
@@ -192,28 +207,39 @@ __global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict_
             }
         });
     }
-    double tc = block_sum(mycost, red);    // contains the barrier that completes the image and the accumulators
-    if (threadIdx.x == 0) partials[blockIdx.x] = tc;
-    __syncthreads();
+    // deterministic cost sum: fixed DPP tree per wavefront, then four partials in order
+    mycost = wave_sum_dpp63(mycost);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = mycost;
+    lds_barrier();                     // completes the image, the accumulators and red[]
+    if (threadIdx.x == 0) { double tc = 0;
+#pragma unroll
+        for (int k = 0; k < TPB / 64; ++k) tc += red[k];
+        partials[blockIdx.x] = tc; }
     // fold the accumulator copies into the image: full diagonal block (both triangles, linearsystem.jl:140) and b
-    for (uint32_t w = threadIdx.x; w < t.nrows * NACC; w += TPB) {
+    for (uint32_t w = threadIdx.x; w < nfold; w += TPB) {
         const uint32_t r = w / NACC, q = w - r * NACC;
         const double* ar = acc + (size_t)r * ACC_COPIES * NACC + q;
         double v = 0;
 #pragma unroll
         for (int k = 0; k < (int)ACC_COPIES; ++k) v += ar[k * NACC];
-        const RowInfo ri = rows[t.row0 + r];
+        const RowInfo ri = w < TPB ? ri0 : rows[t.row0 + r];
         if ((int)q >= NSYM) img[ri.b_off + (q - NSYM)] = v;
         else { int qq = q, j = 0; while (qq >= DS - j) { qq -= DS - j; ++j; } const int i = j + qq;
                img[ri.diag_off + i + DS * j] = v; if (i != j) img[ri.diag_off + j + DS * i] = v; }
     }
-    __syncthreads();
+    lds_barrier();
     if (t.flags & TILE_PARTIAL) {
         for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) { double v = img[i]; if (v != 0.0) atomicAdd(&A[t.data_off + i], v); }
         for (uint32_t i = threadIdx.x; i < t.b_len; i += TPB) { double v = img[t.data_len + i]; if (v != 0.0) atomicAdd(&b[t.b_off + i], v); }
     } else {
+        // 16 bytes per lane: LDS index `odd + 2k` and HBM index `data_off + odd + 2k` are both even
         double* dst = A + t.data_off;
-        for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) dst[i] = img[i];
+        const uint32_t npair = (t.data_len - odd) >> 1;
+        const double2* src2 = reinterpret_cast<const double2*>(img + odd);
+        double2* dst2 = reinterpret_cast<double2*>(dst + odd);
+        for (uint32_t k = threadIdx.x; k < npair; k += TPB) dst2[k] = src2[k];
+        if (threadIdx.x == 0 && odd) dst[0] = img[0];
+        if (threadIdx.x == 1 && odd + 2 * npair < t.data_len) dst[t.data_len - 1] = img[t.data_len - 1];
         for (uint32_t i = threadIdx.x; i < t.b_len; i += TPB) b[t.b_off + i] = img[t.data_len + i];
     }
 }
@@ -221,43 +247,42 @@ __global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict_
 // ================================================================================================
 // accumulate: heavy tiles (one row, or a slice of one, per workgroup)
 // ================================================================================================
+constexpr int HTPB = 128;  // two wavefronts per heavy tile, each walking every other 64-entry slice of the row through its own pipeline
 template <int KIND, int SLOT>
-__global__ __launch_bounds__(TPB) void gh_heavy_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
-                                                       const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ edest,
-                                                       const RowInfo* __restrict__ rows, const Tile* __restrict__ tiles, RobustSpec rk,
-                                                       double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+__global__ __launch_bounds__(HTPB) void gh_heavy_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
+                                                        const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ edest,
+                                                        const RowInfo* __restrict__ rows, const Tile* __restrict__ tiles, RobustSpec rk,
+                                                        double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
     using R = Res<KIND>; using I = ResInfo<KIND>;
     constexpr int DS = I::dof(SLOT);
     constexpr int NTRI = DS * (DS + 1) / 2, NACC = NTRI + DS + 1;   // lower triangle + b + cost
     extern __shared__ __attribute__((aligned(16))) double img[];
-    __shared__ double red[TPB / 64][NACC];
     const Tile t = tiles[blockIdx.x];
     const bool direct = (t.flags & TILE_DIRECT) != 0;
-    for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) img[i] = 0.0;
+    const RowInfo ri = rows[t.row0];   // diag_off: offset of the diagonal block inside the row's segment
+    for (uint32_t i = threadIdx.x; i < t.data_len; i += HTPB) img[i] = 0.0;
     __syncthreads();
     double acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-    // entries in batches of U per lane: all U entry records are loaded first, then all U variable gathers are in
-    // flight together (two memory round trips per batch instead of per entry: the row's wave is latency-bound)
-    constexpr int U = 4;
-    for (uint32_t base = t.e0; base < t.e1; base += TPB * U) {
-        double d[U][R::NDATA]; uint32_t vo[U][R::NDEPS], ds[U][R::NDEPS]; bool ok[U];
+    // The row's entries are walked 64 at a time (one per lane) through a three-deep software pipeline: while entry i
+    // is evaluated, the variable gathers of entry i+1 and the entry record of i+2 are in flight.  One wavefront per
+    // SIMD is resident, so this pipeline -- not occupancy -- is what hides the HBM and L2 latency.
+    struct Rec { double d[R::NDATA]; uint32_t vo[R::NDEPS], ds[R::NDEPS]; bool ok; };
+    auto load_rec = [&](uint32_t e, Rec& r) {
+        r.ok = e < t.e1; const uint32_t ee = r.ok ? e : t.e0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = base + u * TPB + threadIdx.x; ok[u] = e < t.e1; const uint32_t ee = ok[u] ? e : t.e0;
+        for (int q = 0; q < R::NDATA; ++q) r.d[q] = edata[(size_t)ee * R::NDATA + q];
 #pragma unroll
-            for (int q = 0; q < R::NDATA; ++q) d[u][q] = edata[(size_t)ee * R::NDATA + q];
-#pragma unroll
-            for (int q = 0; q < R::NDEPS; ++q) { vo[u][q] = evoff[(size_t)ee * R::NDEPS + q]; ds[u][q] = edest[(size_t)ee * R::NDEPS + q]; }
-        }
-        double st[U][R::NDEPS][MAXST];
-#pragma unroll
-        for (int u = 0; u < U; ++u) BlockGH<KIND>::load(vars, vo[u], st[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) if (ok[u]) {
-            BlockGH<KIND> B; B.compute_st(st[u], d[u], rk, (ds[u][SLOT] & OWN_KERNEL_FREE) != 0);
-            if (ds[u][SLOT] & OWN_COST_OWNER) acc[NACC - 1] += B.cost;
+        for (int q = 0; q < R::NDEPS; ++q) { r.vo[q] = evoff[(size_t)ee * R::NDEPS + q]; r.ds[q] = edest[(size_t)ee * R::NDEPS + q]; }
+    };
+    using St = double[R::NDEPS][MAXST];
+    auto stage = [&](uint32_t e2, const Rec& cur, const St& cst, const Rec& nxt, St& nst, Rec& nn) {
+        load_rec(e2, nn);                                        // entry record two stages ahead
+        BlockGH<KIND>::load(vars, nxt.vo, nst);                  // gathers one stage ahead
+        if (cur.ok) {
+            BlockGH<KIND> B; B.compute_st(cst, cur.d, rk, (cur.ds[SLOT] & OWN_KERNEL_FREE) != 0);
+            if (cur.ds[SLOT] & OWN_COST_OWNER) acc[NACC - 1] += B.cost;
             {
                 int q = 0;
 #pragma unroll
@@ -271,45 +296,54 @@ __global__ __launch_bounds__(TPB) void gh_heavy_kernel(const double* __restrict_
                 constexpr int T = decltype(Tc)::value;
                 if constexpr (T != SLOT) {
                     constexpr int DT = I::dof(T);
-                    if (ds[u][T] != DEST_NONE) {
+                    if (cur.ds[T] != DEST_NONE) {
 #pragma unroll
                         for (int j = 0; j < DT; ++j)
 #pragma unroll
                             for (int i = 0; i < DS; ++i) {
                                 const double v = h_elem<KIND, SLOT, T>(B, i, j);
-                                if (direct) atomicAdd(&A[(size_t)ds[u][T] + i + DS * j], v); else atomicAdd(&img[ds[u][T] + i + DS * j], v);
+                                if (direct) atomicAdd(&A[(size_t)cur.ds[T] + i + DS * j], v); else atomicAdd(&img[cur.ds[T] + i + DS * j], v);
                             }
                     }
                 }
             });
         }
+    };
+    Rec r0, r1, r2; St s0, s1, s2;
+    load_rec(t.e0 + threadIdx.x, r0);
+    load_rec(t.e0 + HTPB + threadIdx.x, r1);
+    BlockGH<KIND>::load(vars, r0.vo, s0);
+    for (uint32_t base = t.e0; base < t.e1; base += 3 * HTPB) {   // roles rotate through the three register sets
+        stage(base + 2 * HTPB + threadIdx.x, r0, s0, r1, s1, r2);
+        stage(base + 3 * HTPB + threadIdx.x, r1, s1, r2, s2, r0);
+        stage(base + 4 * HTPB + threadIdx.x, r2, s2, r0, s0, r1);
     }
-    // fixed-tree reduction of the row's diagonal block, b and cost
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // fixed-order reduction of the row's diagonal block, b and cost through a transposed LDS image: thread v sums the
+    // HTPB lane-partials of accumulator v (row pitch HTPB+1 doubles: conflict-free both ways) and then owns its destination
+    __shared__ double hred[NACC][HTPB + 1];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) { double v = wave_sum_dpp63(acc[i]); if (lane == 63) red[w][i] = v; }
+    for (int i = 0; i < NACC; ++i) hred[i][threadIdx.x] = acc[i];
     __syncthreads();
-    const RowInfo ri = rows[t.row0];   // diag_off: offset of the diagonal block inside the row's segment
-    if (threadIdx.x < NACC) {
-        double v = 0;
-        for (int k = 0; k < TPB / 64; ++k) v += red[k][threadIdx.x];
-        if ((int)threadIdx.x == NACC - 1) partials[blockIdx.x] = v;
-        else if ((int)threadIdx.x >= NTRI) {
-            const int i = threadIdx.x - NTRI;
-            if (t.flags & TILE_PARTIAL) atomicAdd(&b[t.b_off + i], v); else b[t.b_off + i] = v;
-        } else {
-            int q = threadIdx.x, j = 0; while (q >= DS - j) { q -= DS - j; ++j; } const int i = j + q;   // unpack (i >= j)
-            if (direct) { double* dg = A + t.data_off + ri.diag_off; atomicAdd(&dg[i + DS * j], v); if (i != j) atomicAdd(&dg[j + DS * i], v); }
-            else { img[ri.diag_off + i + DS * j] = v; if (i != j) img[ri.diag_off + j + DS * i] = v; }   // only registers feed the diagonal block
+    for (int v = threadIdx.x; v < NACC; v += HTPB) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int k = 0; k < HTPB; k += 4) { s0 += hred[v][k]; s1 += hred[v][k + 1]; s2 += hred[v][k + 2]; s3 += hred[v][k + 3]; }
+        const double sum = (s0 + s1) + (s2 + s3);
+        if (v == NACC - 1) partials[blockIdx.x] = sum;
+        else if (v >= NTRI) { const int i = v - NTRI; if (t.flags & TILE_PARTIAL) atomicAdd(&b[t.b_off + i], sum); else b[t.b_off + i] = sum; }
+        else {
+            int q = v, j = 0; while (q >= DS - j) { q -= DS - j; ++j; } const int i = j + q;   // unpack (i >= j)
+            if (direct) { double* dg = A + t.data_off + ri.diag_off; atomicAdd(&dg[i + DS * j], sum); if (i != j) atomicAdd(&dg[j + DS * i], sum); }
+            else { img[ri.diag_off + i + DS * j] = sum; if (i != j) img[ri.diag_off + j + DS * i] = sum; }   // only registers feed the diagonal block
         }
     }
     __syncthreads();
     if (direct) return;
     if (t.flags & TILE_PARTIAL) {
-        for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) { double v = img[i]; if (v != 0.0) atomicAdd(&A[t.data_off + i], v); }
+        for (uint32_t i = threadIdx.x; i < t.data_len; i += HTPB) { double v = img[i]; if (v != 0.0) atomicAdd(&A[t.data_off + i], v); }
     } else {
         double* dst = A + t.data_off;
-        for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) dst[i] = img[i];
+        for (uint32_t i = threadIdx.x; i < t.data_len; i += HTPB) dst[i] = img[i];
     }
 }
 
@@ -412,7 +446,7 @@ constexpr int RED_BLOCKS = 256;
 __global__ __launch_bounds__(TPB) void step_stats_partial_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ part) {
     __shared__ double red[TPB / 64];
     double m = 0, s = 0; bool nan = false;
-    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) { double v = x[i]; nan |= (v != v); m = fmax(m, fabs(v)); s += v * v; }
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) { double v = x[i]; nan |= is_nan_bits(v); m = fmax(m, fabs(v)); s += v * v; }
     double mm = block_max(m, red);
     double ss = block_sum(s, red);
     double nn = block_max(nan ? 1.0 : 0.0, red);
@@ -423,7 +457,7 @@ __global__ __launch_bounds__(TPB) void step_stats_finish_kernel(const double* __
     double m = 0, s = 0, nn = 0;
     for (int i = threadIdx.x; i < nb; i += TPB) { m = fmax(m, part[3 * i]); nn = fmax(nn, part[3 * i + 1]); s += part[3 * i + 2]; }
     double mm = block_max(m, red); double ss = block_sum(s, red); double n2 = block_max(nn, red);
-    if (threadIdx.x == 0) { out[1] = n2 > 0 ? NAN : mm; out[2] = ss; }
+    if (threadIdx.x == 0) { out[1] = n2 > 0 ? __longlong_as_double(0x7ff8000000000000LL) : mm; out[2] = ss; }
 }
 // initlambda's max |H_ii|   src/iterators.jl:131-137
 __global__ __launch_bounds__(TPB) void max_abs_diag_partial_kernel(const double* __restrict__ A, const int64_t* __restrict__ diag_off,
@@ -489,12 +523,12 @@ static void launch_gh_slot(nlls_ctx* c, const Group& G, const double* vars, int6
     if constexpr (SLOT < Res<KIND>::NDEPS) {
         const EntryList& E = G.lists[SLOT];
         if (E.nlight > 0) {
-            hipLaunchKernelGGL((gh_light_kernel<KIND, SLOT>), dim3((unsigned)E.nlight), dim3(TPB), E.light_lds * sizeof(double), c->stream,
+            hipLaunchKernelGGL((gh_light_kernel<KIND, SLOT>), dim3((unsigned)E.nlight), dim3(TPB), (E.light_lds + 2) * sizeof(double), c->stream,
                                vars, E.data.p, E.voff.p, E.dest.p, E.rows.p, E.light.p, G.rk, E.unique_dest ? 1 : 0, c->A.p, c->b.p, c->partials.p + pbase);
             pbase += E.nlight;
         }
         if (E.nheavy > 0) {
-            hipLaunchKernelGGL((gh_heavy_kernel<KIND, SLOT>), dim3((unsigned)E.nheavy), dim3(TPB), E.heavy_lds * sizeof(double), c->stream,
+            hipLaunchKernelGGL((gh_heavy_kernel<KIND, SLOT>), dim3((unsigned)E.nheavy), dim3(HTPB), E.heavy_lds * sizeof(double), c->stream,
                                vars, E.data.p, E.voff.p, E.dest.p, E.rows.p, E.heavy.p, G.rk, c->A.p, c->b.p, c->partials.p + pbase);
             pbase += E.nheavy;
         }
