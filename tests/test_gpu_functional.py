@@ -136,3 +136,25 @@ def test_so3_adaptive_ba_converges():               # BASELINE config 5 shape, s
     res = N.optimize(p, N.NLLSOptions(maxiters=30))
     assert res.bestcost < res.startcost
     assert np.isclose(res.bestcost, ores.bestcost, rtol=1e-6)
+
+
+def test_sweep_total_is_never_stale():
+    """The sweep's total cost is a fixed-order sum of per-workgroup partials: bit-identical from run to run, and never
+    built from a previous sweep's partials (two variable sets are alternated so that a stale one would show)."""
+    from nllssolver_jl_amd import _capi
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(200, 20000, 0.05, seed=3, robust=N.HuberKernel(0.01),
+                                                                 outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    ctx = _capi.Context(0)
+    ctx.upload(p.var_kind, p.var_dim, np.arange(1, p.nvariables + 1, dtype=np.uint64), p.groups(), 0)
+    va = p.variables.copy(); vb = va + 1e-3 * np.random.default_rng(0).standard_normal(va.size)
+    o = oracle_problem(p)
+    expect = []
+    for v in (va, vb):
+        ctx.set_variables(v); o.set_variables(v)
+        cg, cc = ctx.sweep_gradhess(), ctx.sweep_cost()
+        assert cg == pytest.approx(o.cost(), rel=1e-11) and cc == pytest.approx(cg, rel=1e-12)
+        expect.append((cg, cc))
+    for it in range(150):
+        ctx.set_variables((va, vb)[it & 1])
+        assert (ctx.sweep_gradhess(), ctx.sweep_cost()) == expect[it & 1], f"iteration {it}"
+    ctx.close()
