@@ -701,11 +701,13 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
 //   * wave 0 holds EVERY row of the block column (diagonal tile, the NBW sub-diagonal tiles, the border/rhs tile:
 //     <= 128 rows, two per lane) in registers and runs the 16 pivots there: the pivot row is broadcast with
 //     v_readlane (the diagonal tile is kept fully symmetric, so row k of it supplies all multipliers), no LDS
-//     traffic and no barrier inside the block;
-//   * the panel (L and W = L*D) goes to LDS once, then all four waves apply the rank-16 trailing update tile by
-//     tile on the fp64 matrix cores: C(16x16) -= W_I(16x16) * L_K(16x16)', four v_mfma_f64_16x16x4_f64 per tile;
-//   * waves 1-3 stream the next tile column in from HBM (registers one block ahead) and the factor out (band layout,
-//     consumed by band_backward_kernel) while wave 0 factors.
+//     traffic and no barrier inside the block.  The panel W = L*D and 1/D go to LDS (two buffers, by block parity);
+//   * the rank-16 trailing update runs tile by tile on the fp64 matrix cores, C(16x16) -= W_I * (W_K / D)', four
+//     v_mfma_f64_16x16x4_f64 per tile, and is split by urgency (look-ahead): only the tiles of block column J+1 are
+//     updated between the factorisations of J and J+1 (all four waves, one or two tiles each); the tiles of columns
+//     J+2..J+NBW and the border corner are updated by waves 1-3 WHILE wave 0 factors block J+1;
+//   * waves 1-3 also stream the next tile column in from HBM and the previous block's factor out (band layout,
+//     consumed by band_backward_kernel) behind wave 0's factorisation.
 // Tiles live in an LDS ring indexed by (block column mod (NBW+2), tile row), rows padded to 17 doubles.
 // ---------------------------------------------------------------------------------------------------
 struct BlkArgs { const double* Sb; double* Lb; double* corner_out; int n_band, bw, nbd, H, NBW; int* status; };
@@ -714,94 +716,140 @@ NLLS_DEV double readlane_d(double x, int k) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
 }
 
-// The four roles of a block step are separate NON-inlined functions: each gets its own register allocation, and the
-// compiler cannot hoist one role's loop invariants (lane predicates = 64-bit scalar masks) across the others, which
-// spilled scalar registers when everything was one body.
-struct BlkLds { double* tiles; double* corner; double* Lp; double* Wp; double* dvec; int TW, TR, NBW, H, bw, n_band, nJ; };
+struct BlkLds { double* tiles; double* corner; double* Wp; double* dvec; double* Li; int TW, TR, NBW, H, bw, n_band, nJ; };
 constexpr int BLK_P = 17, BLK_TS = 16 * BLK_P;                // padded tile row, doubles per tile
 NLLS_DEV double* blk_tile(const BlkLds& S, int K, int ti) { return S.tiles + ((size_t)(K % S.TW) * S.TR + ti) * BLK_TS; }
+NLLS_DEV double* blk_panel(const BlkLds& S, int J) { return S.Wp + (size_t)(J & 1) * S.TR * 16 * BLK_P; }   // W of block J
+NLLS_DEV double* blk_d(const BlkLds& S, int J) { return S.dvec + (J & 1) * 32; }                               // D[16], 1/D[16]
 
-// wave 0: rows of block column J in registers (two per lane), 16 pivots with v_readlane broadcast of the pivot row,
-// panel columns leave for LDS as they become final
+// wave 0: LDL' of the 16x16 diagonal tile of block column J, entirely on the matrix cores.  The tile sits in the
+// accumulator layout of v_mfma_f64_16x16x4_f64 (register r of lane (li, lk) = A[lk + 4r][li]); it is kept fully
+// symmetric, so row k -- ONE register, the 16 lanes with lk = k % 4 -- is the pivot column w.  With every other lane
+// zeroed that register is directly a valid A operand (A[i][kk = k % 4] = w_i) and B operand (B[kk][j] = w_j / -d_k):
+// one MFMA applies the whole rank-1 update, no cross-lane traffic except the two v_readlanes that fetch d_k.
+// A second accumulator starts as the identity and takes the same column operations (transposed): it ends as inv(L),
+// so the sub-diagonal tiles need no substitution, W_T = T * inv(L)' is a matrix-core product (blk_panel_tile).
+// Serial chain per pivot: readlane d -> v_rcp_f64 + two Newton steps -> scale -> MFMA.
 __device__ __forceinline__ void blk_factor(const BlkLds& S, int J, int* status) {
     constexpr int P = BLK_P;
-    const int lane = threadIdx.x & 63;
-    double a0[16], a1[16];
-    const int r0 = lane, r1 = 64 + lane; const bool w0 = (r0 >> 4) < S.TR, w1 = (r1 >> 4) < S.TR;
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    double4_t A, Bt;                                          // Bt[n][j]: transpose of the identity rows' tile
     {
-        const double* t0 = blk_tile(S, J, w0 ? (r0 >> 4) : 0) + (r0 & 15) * P;
-        const double* t1 = blk_tile(S, J, w1 ? (r1 >> 4) : 0) + (r1 & 15) * P;
+        const double* t0 = blk_tile(S, J, 0);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { a0[c] = w0 ? t0[c] : 0.0; a1[c] = w1 ? t1[c] : 0.0; }
+        for (int r = 0; r < 4; ++r) { A[r] = t0[(lk + 4 * r) * P + li]; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
     }
-    double* W0 = S.Wp + (w0 ? r0 : 0) * P; double* L0 = S.Lp + (w0 ? r0 : 0) * P;
-    double* W1 = S.Wp + (w1 ? r1 : 0) * P; double* L1 = S.Lp + (w1 ? r1 : 0) * P;
-    auto pivot = [&](double v, int k, double& dk, double& rdk) {
-        dk = v; if (dk == 0.0 || dk != dk) { if (lane == 0) atomicCAS(status, 0, 1 + 16 * J + k); dk = 1.0; }
-        rdk = __builtin_amdgcn_rcp(dk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);   // Newton: full fp64 accuracy, short chain
-    };
-    double dk, rdk; pivot(readlane_d(a0[0], 0), 0, dk, rdk);
+    double* db = blk_d(S, J);
+    int badk = 16;                                            // first pivot of this block that is zero or NaN
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const double l0 = a0[k] * rdk, l1 = a1[k] * rdk;
-        if (w0) { W0[k] = a0[k]; L0[k] = l0; }
-        if (w1) { W1[k] = a1[k]; L1[k] = l1; }
-        if (lane == 0) S.dvec[k] = dk;
-        // rows at or above the pivot inside the diagonal tile take no update: mask the multiplier with integer ops
-        const int mk = (k - lane) >> 31;   // all ones iff lane > k
-        const double m0 = __hiloint2double(__double2hiint(l0) & mk, __double2loint(l0) & mk);
-        double dkn = 1.0, rdkn = 1.0;
-        if (k + 1 < 16) {   // column k+1 first, so that the next pivot's reciprocal chain overlaps the rest of this update
-            const double u = readlane_d(a0[k + 1], k); a0[k + 1] = fma(-m0, u, a0[k + 1]); a1[k + 1] = fma(-l1, u, a1[k + 1]);
-            pivot(readlane_d(a0[k + 1], k + 1), k + 1, dkn, rdkn);
+        constexpr int dummy = 0; (void)dummy;
+        const int q = k & 3, r = k >> 2;
+        const double w = A[r], bt = Bt[r];                    // row k of both tiles lives in the lanes with lk == q
+        const double dk = readlane_d(w, 16 * q + k);
+        double rdk = __builtin_amdgcn_rcp(dk);
+        // operands that do not depend on 1/d: w masked to the rows below the pivot, and the lane masks
+        const bool rowq = lk == q;
+        const double am = (rowq && li > k) ? w : 0.0;
+        const double bm = rowq ? bt : 0.0;
+        rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);   // Newton: full fp64 accuracy
+        if (!(fabs(dk) > 0.0)) badk = badk < k ? badk : k;
+        db[k] = dk; db[16 + k] = rdk;                         // every lane, same value
+        if (k < 15) {
+            A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);      // A[i][j]  -= w_i w_j / d     (i, j > k)
+            Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);    // Bt[j][i] -= w_j B[i][k] / d (j > k)
         }
-#pragma unroll
-        for (int c = k + 2; c < 16; ++c) { const double u = readlane_d(a0[c], k); a0[c] = fma(-m0, u, a0[c]); a1[c] = fma(-l1, u, a1[c]); }
-        dk = dkn; rdk = rdkn;
     }
+    double* Wb = blk_panel(S, J);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { Wb[(lk + 4 * r) * P + li] = A[r]; S.Li[li * P + (lk + 4 * r)] = Bt[r]; }   // Li[j][n] = Bt[n][j] = inv(L)'[j][n]
+    if (badk < 16 && lane == 0) atomicCAS(status, 0, 1 + 16 * J + badk);
+}
+// panel tile ti (1..NBW sub-diagonal, NBW+1 border) of block J:  W = T * inv(L)'  -> panel rows 16*ti..16*ti+15
+__device__ __forceinline__ void blk_panel_tile(const BlkLds& S, int J, int ti) {
+    constexpr int P = BLK_P;
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const double* T = blk_tile(S, J, ti); double* Wt = blk_panel(S, J) + (size_t)ti * 16 * P;
+    double av[4], bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { av[kk] = T[li * P + 4 * kk + lk]; bv[kk] = S.Li[(4 * kk + lk) * P + li]; }
+    double4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[(lk + 4 * r) * P + li] = acc[r] + acc2[r];
 }
 // tile column K <- band layout in HBM (identity behind the last column); threads t0, t0+nt, ...  Gather form: every
 // word of the TR tiles is computed from its (row, column), so the ring slot needs no zero fill and one pass suffices.
-__device__ __forceinline__ void blk_land(const BlkLds& S, const double* __restrict__ Sb, int K, int t0, int nt) {
-    constexpr int P = BLK_P;
-    double* base = blk_tile(S, K, 0);
+// Two halves: blk_land_load issues the HBM loads into registers, blk_land_store puts them into the ring slot; whatever
+// runs between the two hides the HBM latency.
+constexpr int BLK_T = 512, BLK_HELP = BLK_T - 64;             // threads of the factor kernel; wave 0 factors, the rest help
+constexpr int BLK_LANDW = 5;                                  // words per helper thread: ceil(8 tiles * 256 / 448)
+__device__ __forceinline__ void blk_land_load(const BlkLds& S, const double* __restrict__ Sb, int K, int t0, int nt, double (&val)[BLK_LANDW]) {
     const int H = S.H, nwords = S.TR * 16 * 16;
-    for (int w = t0; w < nwords; w += nt) {
-        const int ti = w >> 8, r = (w >> 4) & 15, cc = w & 15;
-        int c = 16 * K + cc, e;
-        if (ti <= S.NBW) { e = 16 * ti + r - cc; if (e < 0) { c = 16 * K + r; e = -e; } }     // upper part of the diagonal tile: mirror
-        else e = S.bw + 1 + r;                                                              // border tile: row r = border index
-        double val = 0.0;
-        if (e < H && (ti > S.NBW || e <= S.bw)) val = (c < S.n_band) ? Sb[(size_t)c * H + e] : (e == 0 ? 1.0 : 0.0);
-        base[(size_t)ti * BLK_TS + r * P + cc] = val;
+#pragma unroll
+    for (int q = 0; q < BLK_LANDW; ++q) {
+        const int w = t0 + q * nt; val[q] = 0.0;
+        if (w < nwords) {
+            const int ti = w >> 8, r = (w >> 4) & 15, cc = w & 15;
+            int c = 16 * K + cc, e;
+            if (ti <= S.NBW) { e = 16 * ti + r - cc; if (e < 0) { c = 16 * K + r; e = -e; } }     // upper part of the diagonal tile: mirror
+            else e = S.bw + 1 + r;                                                              // border tile: row r = border index
+            if (e < H && (ti > S.NBW || e <= S.bw)) val[q] = (c < S.n_band) ? Sb[(size_t)c * H + e] : (e == 0 ? 1.0 : 0.0);
+        }
     }
 }
-// rank-16 trailing update on the matrix cores: tile-updates u = w0, w0+nw, ... of (K = 1..NBW: pi = K..NBW and the border
-// tile row) plus the border corner
-struct BlkUpd { int K[8], pi[8], trow[8]; };                   // this wave's tile-updates (same list at every block step)
-__device__ __forceinline__ void blk_update_list(const BlkLds& S, int w0, int nw, BlkUpd& U) {
+__device__ __forceinline__ void blk_land_store(const BlkLds& S, int K, int t0, int nt, const double (&val)[BLK_LANDW]) {
+    constexpr int P = BLK_P;
+    double* base = blk_tile(S, K, 0);
+    const int nwords = S.TR * 16 * 16;
+#pragma unroll
+    for (int q = 0; q < BLK_LANDW; ++q) {
+        const int w = t0 + q * nt;
+        if (w < nwords) { const int ti = w >> 8, r = (w >> 4) & 15, cc = w & 15; base[(size_t)ti * BLK_TS + r * P + cc] = val[q]; }
+    }
+}
+__device__ __forceinline__ void blk_land(const BlkLds& S, const double* __restrict__ Sb, int K, int t0, int nt) {
+    for (int w0 = t0; w0 < S.TR * 256; w0 += nt * BLK_LANDW) { double v[BLK_LANDW]; blk_land_load(S, Sb, K, w0, nt, v); blk_land_store(S, K, w0, nt, v); }
+}
+// Tile-updates of one block step, numbered u = 0..nup-1: first the NBW+1 tiles of block column J+1 (K = 1: tile rows
+// 1..NBW and the border row), then K = 2..NBW (tile rows K..NBW and the border row), last the border corner (K = 0).
+// A wave's share of a range of them is the same at every block step, so it is unpacked once.
+template <int MAXU> struct BlkUpd { int K[MAXU], pi[MAXU], trow[MAXU]; };
+template <int MAXU>
+__device__ __forceinline__ void blk_update_list(const BlkLds& S, int first, int count, int w0, int nw, BlkUpd<MAXU>& U) {
     const int NBW = S.NBW, nup = NBW * (NBW + 1) / 2 + NBW + 1;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int u = w0 + q * nw; U.K[q] = -1; U.pi[q] = 0; U.trow[q] = 0;
+    for (int q = 0; q < MAXU; ++q) {
+        const int u = first + w0 + q * nw; U.K[q] = -1; U.pi[q] = 0; U.trow[q] = 0;
+        if (w0 < 0 || w0 + q * nw >= count) continue;
         if (u < nup - 1) { int uu = u, K = 1; while (uu >= NBW - K + 2) { uu -= NBW - K + 2; ++K; }
             U.K[q] = K; U.pi[q] = (uu == NBW - K + 1) ? NBW + 1 : K + uu; U.trow[q] = (uu == NBW - K + 1) ? NBW + 1 : uu; }
         else if (u == nup - 1) { U.K[q] = 0; U.pi[q] = NBW + 1; }    // K = 0 marks the border corner
     }
 }
-__device__ __forceinline__ void blk_update(const BlkLds& S, int J, int jslot, const BlkUpd& U) {
-    constexpr int P = BLK_P, MAXU = 8;
+// apply this wave's tile-updates of block J (panel W and 1/D of block J in LDS) on the matrix cores
+template <int MAXU>
+__device__ __forceinline__ void blk_update(const BlkLds& S, int J, const BlkUpd<MAXU>& U) {
+    constexpr int P = BLK_P;
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const double* Wb = blk_panel(S, J); const double* rd = blk_d(S, J) + 16;
+    int jslot = J % S.TW;
     double* Ct[MAXU]; double4_t acc[MAXU], acc2[MAXU]; double wv[MAXU][4], lv[MAXU][4]; bool ok[MAXU];
+    double rdk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) rdk[kk] = rd[4 * kk + lk];
     // all operand loads first, then the MFMAs, then the stores: the LDS latency of one tile hides behind the others
 #pragma unroll
     for (int q = 0; q < MAXU; ++q) {
         const int K = U.K[q]; ok[q] = K >= 0 && (K == 0 || J + K < S.nJ);
         int sl = jslot + (K > 0 ? K : 0); if (sl >= S.TW) sl -= S.TW;
         Ct[q] = (K > 0) ? S.tiles + ((size_t)sl * S.TR + U.trow[q]) * BLK_TS : S.corner;
-        const double* Wt = S.Wp + (size_t)U.pi[q] * 16 * P; const double* Lt = S.Lp + (size_t)(K > 0 ? K : S.NBW + 1) * 16 * P;
+        const double* Wt = Wb + (size_t)U.pi[q] * 16 * P; const double* Lt = Wb + (size_t)(K > 0 ? K : S.NBW + 1) * 16 * P;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { wv[q][kk] = -Wt[li * P + 4 * kk + lk]; lv[q][kk] = Lt[li * P + 4 * kk + lk]; }
+        for (int kk = 0; kk < 4; ++kk) { wv[q][kk] = -Wt[li * P + 4 * kk + lk]; lv[q][kk] = Lt[li * P + 4 * kk + lk] * rdk[kk]; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[q][r] = Ct[q][(lk + 4 * r) * P + li];
         acc2[q] = double4_t{0, 0, 0, 0};
@@ -822,9 +870,10 @@ __device__ __forceinline__ void blk_update(const BlkLds& S, int J, int jslot, co
         for (int r = 0; r < 4; ++r) Ct[q][(lk + 4 * r) * P + li] = acc[q][r] + acc2[q][r];
     }
 }
-// factor block column J -> HBM in band layout: entry 0 = D, 1..bw = L, then border rows + rhs
-__device__ __forceinline__ void blk_export(const BlkLds& S, const double* __restrict__ Lsrc, const double* __restrict__ dsrc, double* __restrict__ Lb, int J, int t0, int nt) {
+// factor block column J -> HBM in band layout: entry 0 = D, 1..bw = L = W/D, then border rows + rhs
+__device__ __forceinline__ void blk_export(const BlkLds& S, double* __restrict__ Lb, int J, int t0, int nt) {
     constexpr int P = BLK_P;
+    const double* Wsrc = blk_panel(S, J); const double* dsrc = blk_d(S, J);
     const int H = S.H, col_elems = 16 * H;
     int cc = t0 / H, e = t0 - cc * H;
     const int dcc = nt / H, de = nt - dcc * H;
@@ -833,15 +882,15 @@ __device__ __forceinline__ void blk_export(const BlkLds& S, const double* __rest
         if (c < S.n_band) {
             double v;
             if (e == 0) v = dsrc[cc];
-            else if (e <= S.bw) { const int rr = cc + e; v = ((rr >> 4) <= S.NBW) ? Lsrc[rr * P + cc] : 0.0; }
-            else v = Lsrc[((S.NBW + 1) * 16 + (e - S.bw - 1)) * P + cc];
+            else if (e <= S.bw) { const int rr = cc + e; v = ((rr >> 4) <= S.NBW) ? Wsrc[rr * P + cc] * dsrc[16 + cc] : 0.0; }
+            else v = Wsrc[((S.NBW + 1) * 16 + (e - S.bw - 1)) * P + cc] * dsrc[16 + cc];
             Lb[(size_t)c * H + e] = v;
         }
         cc += dcc; e += de; if (e >= H) { e -= H; ++cc; }
     }
 }
 
-__global__ __launch_bounds__(256) void band_blocked_factor_kernel(BlkArgs a) {
+__global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int P = BLK_P, TS = BLK_TS;
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -849,40 +898,41 @@ __global__ __launch_bounds__(256) void band_blocked_factor_kernel(BlkArgs a) {
     BlkLds S; S.TW = NBW + 2; S.TR = NBW + 2; S.NBW = NBW; S.H = H; S.bw = a.bw; S.n_band = n_band; S.nJ = (n_band + 15) >> 4;
     S.tiles = sm;                                             // [TW][TR][TS]
     S.corner = S.tiles + (size_t)S.TW * S.TR * TS;            // [TS] border x border (row/col = border index, rhs = nbd)
-    S.Lp = S.corner + TS;                                     // [TR*16][P]
-    S.Wp = S.Lp + (size_t)S.TR * 16 * P;                      // [TR*16][P]
-    S.dvec = S.Wp + (size_t)S.TR * 16 * P;                    // [16]
+    S.Wp = S.corner + TS;                                     // [2][TR*16][P]
+    S.dvec = S.Wp + 2 * (size_t)S.TR * 16 * P;                // [2][32]
+    S.Li = S.dvec + 64;                                       // [48][P]: inv(L)' of the current block (16 rows) + spare rows for idle lanes
     const int nJ = S.nJ;
-    for (int i = tid; i < S.TW * S.TR * TS + TS; i += 256) S.tiles[i] = 0.0;
+    for (int i = tid; i < S.TW * S.TR * TS + TS; i += BLK_T) S.tiles[i] = 0.0;
     __syncthreads();
-    for (int e = tid; e < nbr * nbr; e += 256) { const int i = e % nbr, j = e / nbr; if (i >= j) { const double v = a.Sb[(size_t)n_band * H + e]; S.corner[i * P + j] = v; S.corner[j * P + i] = v; } }
-    for (int K = 0; K <= NBW && K < nJ; ++K) blk_land(S, a.Sb, K, tid, 256);
-    double* Lc = S.dvec + 16;                                 // copy of the previous block's L panel and D (exported by the helpers)
-    double* dc = Lc + (size_t)S.TR * 16 * P;
-    BlkUpd U; blk_update_list(S, wave, 4, U);
-    int jslot = 0;                                            // J % TW
+    for (int e = tid; e < nbr * nbr; e += BLK_T) { const int i = e % nbr, j = e / nbr; if (i >= j) { const double v = a.Sb[(size_t)n_band * H + e]; S.corner[i * P + j] = v; S.corner[j * P + i] = v; } }
+    for (int K = 0; K <= NBW && K < nJ; ++K) blk_land(S, a.Sb, K, tid, BLK_T);
+    // urgent tile-updates (block column J+1): NBW+1 of them over the four waves; deferred ones (the rest): over waves 1-3
+    const int nup = NBW * (NBW + 1) / 2 + NBW + 1, nurgent = NBW + 1;
+    constexpr int NW = BLK_T / 64;
+    BlkUpd<1> Uu; blk_update_list<1>(S, 0, nurgent, wave, NW, Uu);
+    BlkUpd<3> Ud; blk_update_list<3>(S, nurgent, nup - nurgent, wave - 1, NW - 1, Ud);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();   // diagnostics only (nlls_get_solve_stats)
     for (int J = 0; J < nJ; ++J) {
         __syncthreads();                                      // (A) block column J is final
         if (wave == 0) blk_factor(S, J, a.status);
         else {
-            // helpers, hidden behind wave 0's factorisation: land tile column J+NBW+1 into the ring slot of column J-1
-            // (HBM latency), export block J-1 from its copy
-            if (J + NBW + 1 < nJ) blk_land(S, a.Sb, J + NBW + 1, tid - 64, 192);
-            if (J > 0) blk_export(S, Lc, dc, a.Lb, J - 1, tid - 64, 192);
+            // helpers, hidden behind wave 0's factorisation: the deferred tile-updates of block J-1, tile column
+            // J+NBW+1 into the ring slot of column J-1 (HBM latency), block J-1's factor out
+            double lv[BLK_LANDW]; const bool landing = J + NBW + 1 < nJ;
+            if (landing) blk_land_load(S, a.Sb, J + NBW + 1, tid - 64, BLK_HELP, lv);
+            if (J > 0) { blk_update<3>(S, J - 1, Ud); blk_export(S, a.Lb, J - 1, tid - 64, BLK_HELP); }
+            if (landing) blk_land_store(S, J + NBW + 1, tid - 64, BLK_HELP, lv);
         }
-        __syncthreads();                                      // (B) panel in LDS
-        if (wave > 0) {
-            for (int i = tid - 64; i < S.TR * 16 * P; i += 192) Lc[i] = S.Lp[i];
-            if (tid - 64 < 16) dc[tid - 64] = S.dvec[tid - 64];
-        }
-        blk_update(S, J, jslot, U);
-        if (++jslot == S.TW) jslot = 0;
+        __syncthreads();                                      // (B) diagonal tile factored, deferred updates of J-1 done
+        if (wave > 0 && wave <= NBW + 1) blk_panel_tile(S, J, wave);
+        __syncthreads();                                      // (C) panel J in LDS
+        blk_update<1>(S, J, Uu);
     }
     __syncthreads();
-    blk_export(S, S.Lp, S.dvec, a.Lb, nJ - 1, tid, 256);
+    if (wave > 0) blk_update<3>(S, nJ - 1, Ud);               // the last block's share of the border corner
+    blk_export(S, a.Lb, nJ - 1, tid, BLK_T);
     __syncthreads();
-    for (int e = tid; e < nbr * nbr; e += 256) { const int i = e % nbr, j = e / nbr; a.corner_out[e] = S.corner[i * P + j]; }
+    for (int e = tid; e < nbr * nbr; e += BLK_T) { const int i = e % nbr, j = e / nbr; a.corner_out[e] = S.corner[i * P + j]; }
     if (tid == 0) a.status[2] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 
@@ -1100,11 +1150,11 @@ int enqueue_solve_finish(nlls_ctx* c) {
         const int nbr = L.nbd + 1;
         const size_t lds = sizeof(double) * ((size_t)a.RC * L.H + 2 * (size_t)(2 * a.NSC * c->band_SEG + 2 * c->band_SEG) + (size_t)(L.bw + 2) * nbr + (size_t)nbr * nbr + nbr + 8);
         const int NBW = (L.bw + 15) / 16;                // tile rows below the diagonal tile that a block column reaches
-        const size_t blk_lds = sizeof(double) * ((size_t)(NBW + 2) * (NBW + 2) * 272 + 272 + 3 * (size_t)(NBW + 2) * 16 * 17 + 32 + 8);
+        const size_t blk_lds = sizeof(double) * ((size_t)(NBW + 2) * (NBW + 2) * 272 + 272 + 2 * (size_t)(NBW + 2) * 16 * 17 + 64 + 48 * 17 + 8);
         if (c->band_blocked && NBW <= 5 && (NBW + 2) * 16 <= 128 && L.H <= 96 && blk_lds <= 160 * 1024) {
             BlkArgs bkl{}; bkl.Sb = c->S.p; bkl.Lb = c->Lwork.p; bkl.corner_out = c->Lwork.p + (size_t)L.H * L.n_band; bkl.n_band = L.n_band; bkl.bw = L.bw; bkl.nbd = L.nbd;
             bkl.H = L.H; bkl.NBW = NBW; bkl.status = c->d_status.p;
-            hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(256), blk_lds, c->stream, bkl);
+            hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(BLK_T), blk_lds, c->stream, bkl);
             BandArgs ab = a;   // the backward pass keeps NR = 16*ceil((bw+16)/16) rows in reach: its own ring depth
             { const int NR = 16 * ((L.bw + 16 + 15) / 16); ab.PFC = (NR + ab.CH - 1) / ab.CH + 1; ab.RC = (ab.PFC + 1) * ab.CH; }
             const size_t lds_b = sizeof(double) * ((size_t)ab.RC * L.H + (size_t)nbr * nbr + nbr + 8);
