@@ -721,6 +721,7 @@ constexpr int BLK_P = 17, BLK_TS = 16 * BLK_P;                // padded tile row
 NLLS_DEV double* blk_tile(const BlkLds& S, int K, int ti) { return S.tiles + ((size_t)(K % S.TW) * S.TR + ti) * BLK_TS; }
 NLLS_DEV double* blk_panel(const BlkLds& S, int J) { return S.Wp + (size_t)(J & 1) * S.TR * 16 * BLK_P; }   // W of block J
 NLLS_DEV double* blk_d(const BlkLds& S, int J) { return S.dvec + (J & 1) * 32; }                               // D[16], 1/D[16]
+NLLS_DEV double* blk_li(const BlkLds& S, int J) { return S.Li + (J & 1) * 16 * BLK_P; }                         // inv(L_JJ)'
 
 // wave 0: LDL' of the 16x16 diagonal tile of block column J, entirely on the matrix cores.  The tile sits in the
 // accumulator layout of v_mfma_f64_16x16x4_f64 (register r of lane (li, lk) = A[lk + 4r][li]); it is kept fully
@@ -761,8 +762,9 @@ __device__ __forceinline__ void blk_factor(const BlkLds& S, int J, int* status) 
         }
     }
     double* Wb = blk_panel(S, J);
+    double* Lij = blk_li(S, J);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { Wb[(lk + 4 * r) * P + li] = A[r]; S.Li[li * P + (lk + 4 * r)] = Bt[r]; }   // Li[j][n] = Bt[n][j] = inv(L)'[j][n]
+    for (int r = 0; r < 4; ++r) { Wb[(lk + 4 * r) * P + li] = A[r]; Lij[li * P + (lk + 4 * r)] = Bt[r]; }   // Li[j][n] = Bt[n][j] = inv(L)'[j][n]
     if (badk < 16 && lane == 0) atomicCAS(status, 0, 1 + 16 * J + badk);
 }
 // panel tile ti (1..NBW sub-diagonal, NBW+1 border) of block J:  W = T * inv(L)'  -> panel rows 16*ti..16*ti+15
@@ -771,8 +773,9 @@ __device__ __forceinline__ void blk_panel_tile(const BlkLds& S, int J, int ti) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const double* T = blk_tile(S, J, ti); double* Wt = blk_panel(S, J) + (size_t)ti * 16 * P;
     double av[4], bv[4];
+    const double* Lij = blk_li(S, J);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) { av[kk] = T[li * P + 4 * kk + lk]; bv[kk] = S.Li[(4 * kk + lk) * P + li]; }
+    for (int kk = 0; kk < 4; ++kk) { av[kk] = T[li * P + 4 * kk + lk]; bv[kk] = Lij[(4 * kk + lk) * P + li]; }
     double4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
@@ -870,23 +873,24 @@ __device__ __forceinline__ void blk_update(const BlkLds& S, int J, const BlkUpd<
         for (int r = 0; r < 4; ++r) Ct[q][(lk + 4 * r) * P + li] = acc[q][r] + acc2[q][r];
     }
 }
-// factor block column J -> HBM in band layout: entry 0 = D, 1..bw = L = W/D, then border rows + rhs
-__device__ __forceinline__ void blk_export(const BlkLds& S, double* __restrict__ Lb, int J, int t0, int nt) {
+// factor block column J -> HBM, tile layout (consumed by band_backward_tiles_kernel).  Per block, blk_fsize() doubles,
+// every tile row-major and UNPADDED (the backward pass copies a block into LDS linearly):
+//   [0, 256)                inv(L_JJ)' transposed: [n][j]
+//   [256 K, 256 (K+1))      L tile K = 1..NBW  [i'][c]: L(16 (J+K) + i', 16 J + c) = W / D
+//   then 16                 the rhs row  z = (L^-1 b) / D
+//   then nbd x 16           border rows of L
+NLLS_HD int blk_fsize(int NBW, int nbd) { return (NBW + 1) * 256 + (nbd + 1) * 16; }
+__device__ __forceinline__ void blk_export(const BlkLds& S, const double* __restrict__ Lisrc, double* __restrict__ Lt, int nbd, int J, int t0, int nt) {
     constexpr int P = BLK_P;
-    const double* Wsrc = blk_panel(S, J); const double* dsrc = blk_d(S, J);
-    const int H = S.H, col_elems = 16 * H;
-    int cc = t0 / H, e = t0 - cc * H;
-    const int dcc = nt / H, de = nt - dcc * H;
-    for (int idx = t0; idx < col_elems; idx += nt) {
-        const int c = 16 * J + cc;
-        if (c < S.n_band) {
-            double v;
-            if (e == 0) v = dsrc[cc];
-            else if (e <= S.bw) { const int rr = cc + e; v = ((rr >> 4) <= S.NBW) ? Wsrc[rr * P + cc] * dsrc[16 + cc] : 0.0; }
-            else v = Wsrc[((S.NBW + 1) * 16 + (e - S.bw - 1)) * P + cc] * dsrc[16 + cc];
-            Lb[(size_t)c * H + e] = v;
-        }
-        cc += dcc; e += de; if (e >= H) { e -= H; ++cc; }
+    const double* Wsrc = blk_panel(S, J); const double* rd = blk_d(S, J) + 16;
+    const int fs = blk_fsize(S.NBW, nbd), nt256 = (S.NBW + 1) * 256;
+    double* dst = Lt + (size_t)J * fs;
+    for (int idx = t0; idx < fs; idx += nt) {
+        double v;
+        if (idx < 256) v = Lisrc[(idx & 15) * P + (idx >> 4)];
+        else if (idx < nt256) { const int K = idx >> 8, i = (idx >> 4) & 15, c2 = idx & 15; v = Wsrc[(16 * K + i) * P + c2] * rd[c2]; }
+        else { const int q0 = (idx - nt256) >> 4, q = q0 == 0 ? nbd : q0 - 1, c2 = idx & 15; v = Wsrc[((S.NBW + 1) * 16 + q) * P + c2] * rd[c2]; }
+        dst[idx] = v;
     }
 }
 
@@ -900,7 +904,7 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs a) {
     S.corner = S.tiles + (size_t)S.TW * S.TR * TS;            // [TS] border x border (row/col = border index, rhs = nbd)
     S.Wp = S.corner + TS;                                     // [2][TR*16][P]
     S.dvec = S.Wp + 2 * (size_t)S.TR * 16 * P;                // [2][32]
-    S.Li = S.dvec + 64;                                       // [48][P]: inv(L)' of the current block (16 rows) + spare rows for idle lanes
+    S.Li = S.dvec + 64;                                       // [2][16][P]: inv(L_JJ)' by block parity
     const int nJ = S.nJ;
     for (int i = tid; i < S.TW * S.TR * TS + TS; i += BLK_T) S.tiles[i] = 0.0;
     __syncthreads();
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs a) {
             // J+NBW+1 into the ring slot of column J-1 (HBM latency), block J-1's factor out
             double lv[BLK_LANDW]; const bool landing = J + NBW + 1 < nJ;
             if (landing) blk_land_load(S, a.Sb, J + NBW + 1, tid - 64, BLK_HELP, lv);
-            if (J > 0) { blk_update<3>(S, J - 1, Ud); blk_export(S, a.Lb, J - 1, tid - 64, BLK_HELP); }
+            if (J > 0) { blk_update<3>(S, J - 1, Ud); blk_export(S, blk_li(S, J - 1), a.Lb, nbd, J - 1, tid - 64, BLK_HELP); }
             if (landing) blk_land_store(S, J + NBW + 1, tid - 64, BLK_HELP, lv);
         }
         __syncthreads();                                      // (B) diagonal tile factored, deferred updates of J-1 done
@@ -930,23 +934,37 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs a) {
     }
     __syncthreads();
     if (wave > 0) blk_update<3>(S, nJ - 1, Ud);               // the last block's share of the border corner
-    blk_export(S, a.Lb, nJ - 1, tid, BLK_T);
+    blk_export(S, blk_li(S, nJ - 1), a.Lb, nbd, nJ - 1, tid, BLK_T);
     __syncthreads();
     for (int e = tid; e < nbr * nbr; e += BLK_T) { const int i = e % nbr, j = e / nbr; a.corner_out[e] = S.corner[i * P + j]; }
     if (tid == 0) a.status[2] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 
-// Border corner + backward pass of the band solver (factor in band layout from band_blocked_factor_kernel).
-__global__ __launch_bounds__(256) void band_backward_kernel(BandArgs a, const double* __restrict__ corner_in) {
+// Border corner + backward pass of the blocked band solver (factor in tile layout from band_blocked_factor_kernel).
+//   x_J = inv(L_JJ)' * ( z_J - Lbd_J' xb - sum_{K=1..NBW} L_{J+K,J}' x_{J+K} ),   J = nJ-1 .. 0
+// Every product is a 16x16 tile times a 16-vector and runs on the fp64 matrix cores with the vector replicated over
+// the N dimension: x of a block leaves the MFMA in accumulator layout (register m of lane (li, lk) = x[4m + lk]),
+// which is exactly the B-operand layout (B[kk = lk][.] = x[4m + kk]) of the products that consume it, so the
+// unknowns never leave wave 0's registers.  Only the products with the newest block and the inv(L)' product are on
+// the serial chain (two dependent MFMA rounds each); the other tiles' products are issued before x_{J+1} exists.
+// Waves 1-3 copy the factor HBM -> LDS with global_load_lds_dwordx4 (no registers, BWD_AHEAD blocks ahead, block B by
+// wave 1 + B % 3); a wave retires a block with a counted s_waitcnt just before the barrier that hands it to wave 0.
+struct BwdArgs { double* Lt; const double* corner_in; double* xr; int n_band, nbd, NBW; int* status; };
+constexpr int BWD_AHEAD = 9, BWD_RING = BWD_AHEAD + 1;         // ring slots = blocks in LDS
+NLLS_HD int bwd_slot(int NBW) { return (NBW + 1) * 256 + 128; } // doubles copied per block: the tiles, then z (+ whatever follows)
+template <int NBW>
+__global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_band = a.n_band, bw = a.bw, nbd = a.nbd, H = a.H, CH = a.CH, RC = a.RC, nbr = nbd + 1;
-    double* W = sm;                               // RC * H ring of factor columns
-    double* Cl = W + (size_t)RC * H;              // nbr x nbr border corner (col-major, lower), last row = rhs
+    constexpr int SLOT = (NBW + 1) * 256 + 128, NI = SLOT / 128; // NI wave-wide 16-byte copies per block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int n_band = a.n_band, nbd = a.nbd, nbr = nbd + 1;
+    const int nJ = (n_band + 15) >> 4, fs = blk_fsize(NBW, nbd);
+    double* ring = sm;                            // [BWD_RING + 1][SLOT]; the extra slot takes the copies of blocks that do not exist
+    double* Cl = ring + (size_t)(BWD_RING + 1) * SLOT;   // nbr x nbr border corner (col-major, lower), last row = rhs
     double* xb = Cl + nbr * nbr;                  // nbr
-    for (int e = tid; e < nbr * nbr; e += 256) Cl[e] = corner_in[e];
+    for (int e = tid; e < nbr * nbr; e += 256) Cl[e] = a.corner_in[e];
     __syncthreads();
-    const unsigned long long t_factor = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     if (tid == 0) {
         for (int j = 0; j < nbd; ++j) {
             double d = Cl[j + nbr * j];
@@ -958,59 +976,70 @@ __global__ __launch_bounds__(256) void band_backward_kernel(BandArgs a, const do
         for (int r = nbd - 1; r >= 0; --r) { double v = Cl[nbd + nbr * r]; for (int r2 = r + 1; r2 < nbd; ++r2) v -= Cl[r2 + nbr * r] * xb[r2]; xb[r] = v; a.xr[n_band + r] = v; }
     }
     __syncthreads();
-    const int M = (n_band + CH - 1) / CH;
-    auto stage = [&](int m, int t0, int nt) {
-        if (m < 0) return;
-        const int c0 = m * CH; const int ncol = min(CH, n_band - c0);
-        double* dst = W + (size_t)(c0 % RC) * H; const size_t g0 = (size_t)c0 * H;
-        for (int idx = t0; idx < ncol * H; idx += nt) dst[idx] = a.Lb[g0 + idx];
-    };
-    const int PFB = a.PFC;
-    for (int m = M - 1; m >= M - PFB && m >= 0; --m) stage(m, tid, 256);
-    __syncthreads();
-    // Blocked axpy-form backward pass on wave 0: 16 rows per step.  Lane l holds the partially reduced unknowns of rows
-    // top - l (slot 0) and top - 64 - l (slot 1), top = last row of the current block; the block's own unknowns are lanes
-    // 0..15 of slot 0.  Step k broadcasts x of row top-k with v_readlane and every lane subtracts L(top-k, its row) * x:
-    // for a lane those are 16 consecutive entries of ITS factor column (band layout), read once per block.
-    const int nJb = (n_band + 15) >> 4;
-    const int NR = 16 * ((bw + 16 + 15) / 16);                  // rows (relative to top) kept live: the band reach, rounded up
-    auto col = [&](int r) { return W + (size_t)((r % RC + RC) % RC) * H; };
-    auto zinit = [&](int r) { if (r < 0 || r >= n_band) return 0.0; const double* c2 = col(r); double v = c2[bw + 1 + nbd]; for (int q = 0; q < nbd; ++q) v -= c2[bw + 1 + q] * xb[q]; return v; };
-    double z0 = 0, z1 = 0;
-    if (wave == 0) { const int top = 16 * (nJb - 1) + 15; z0 = (lane < NR) ? zinit(top - lane) : 0.0; z1 = (64 + lane < NR) ? zinit(top - 64 - lane) : 0.0; }
-    const int BPC = CH / 16;                                    // blocks per staging chunk
-    for (int m = M - 1; m >= 0; --m) {
-        if (wave == 0) {
-            for (int Jb = min(nJb, (m + 1) * BPC) - 1; Jb >= m * BPC; --Jb) {
-                const int top = 16 * Jb + 15;
-                const int r0 = top - lane, r1 = top - 64 - lane;
-                const bool v0 = r0 >= 0 && r0 < n_band, v1 = r1 >= 0 && r1 < n_band;
-                const double* c0 = col(v0 ? r0 : 0); const double* c1 = col(v1 ? r1 : 0);
-                // entries e = lane - k (slot 0) and 64 + lane - k (slot 1), k = 0..15, of this lane's columns
-                double l0[16], l1[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int e0 = lane - k, e1 = 64 + lane - k;
-                    l0[k] = (v0 && e0 >= 1 && e0 <= bw && top - k < n_band) ? c0[e0] : 0.0;
-                    l1[k] = (v1 && e1 <= bw && top - k < n_band) ? c1[e1] : 0.0;
-                }
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { const double xk = readlane_d(z0, k); z0 = fma(-l0[k], xk, z0); z1 = fma(-l1[k], xk, z1); }
-                if (lane < 16 && v0) a.xr[r0] = z0;             // rows of the block: final (a lane is never updated by its own or later rows)
-                // shift the window down by one block: lane l <- lane l + 16; slot 0 refills from slot 1; rows entering the reach get z = rhs - border part
-                const double s0 = __shfl_down(z0, 16, 64), s1 = __shfl_down(z1, 16, 64), t1 = __shfl(z1, (lane + 16) & 63, 64);
-                z0 = (lane < 48) ? s0 : t1;
-                z1 = (lane < 48) ? s1 : 0.0;
-                const int ntop = top - 16;
-                if (lane >= NR - 16 && lane < NR && lane < 64) z0 = zinit(ntop - lane);
-                if (64 + lane >= NR - 16 && 64 + lane < NR) z1 = zinit(ntop - 64 - lane);
-            }
-        } else {
-            stage(m - PFB, tid - 64, 192);
+    if (nbd > 0) {                                // fold the border unknowns into z, in place:  z_J -= Lbd_J' xb
+        for (int idx = tid; idx < nJ * 16; idx += 256) {
+            double* p = a.Lt + (size_t)(idx >> 4) * fs + (NBW + 1) * 256; const int c2 = idx & 15;
+            double v = p[c2]; for (int q = 0; q < nbd; ++q) v -= p[16 + q * 16 + c2] * xb[q]; p[c2] = v;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (tid == 0) a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_factor) >> 10);
+    // block B -> ring slot B % BWD_RING (blocks that do not exist: block 0 -> the spare slot, so that every issue is NI copies)
+    auto issue = [&](int B) {
+        const double* src = a.Lt + (size_t)(B >= 0 ? B : 0) * fs + 2 * lane;
+        double* dst = ring + (size_t)(B >= 0 ? B % BWD_RING : BWD_RING) * SLOT;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) __builtin_amdgcn_global_load_lds(src + 128 * i, (__attribute__((address_space(3))) void*)(dst + 128 * i), 16, 0, 0);
+    };
+    if (wave > 0) {
+        for (int B = nJ - 1; B > nJ - 1 - BWD_AHEAD; --B) if (1 + ((B % 3) + 3) % 3 == wave) issue(B);
+        if (1 + (nJ - 1) % 3 == wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");   // block nJ-1 has landed
+    }
+    double4_t xk[5];                              // x of blocks J+1 .. J+5, accumulator layout
+#pragma unroll
+    for (int K = 0; K < 5; ++K) xk[K] = double4_t{0, 0, 0, 0};
+    for (int J = nJ - 1; J >= 0; --J) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block J is in LDS; the slot of block J+1 is free
+        if (wave == 0) {
+            const double* B0 = ring + (size_t)(J % BWD_RING) * SLOT;
+            // v_mfma_f64_16x16x4_f64 occupies the pipe for 64 cycles and hands its accumulator on after as many: four
+            // accumulators (one per k-slice m) taken round-robin never wait for each other, and leave three vector
+            // adds per register at the end.  Far tiles first (their x is old), the newest block's tile last.
+            double4_t acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = double4_t{0, 0, 0, 0};
+#pragma unroll
+            for (int K = NBW; K >= 1; --K) {
+                const double* T = B0 + K * 256;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)                                           // A[c = li][kk = lk] = L_K[4m + lk][c]
+                    acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(4 * m + lk) * 16 + li], xk[K - 1][m], acc[m], 0, 0, 0);
+            }
+            double4_t t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = B0[(NBW + 1) * 256 + lk + 4 * r] - ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]));
+            double4_t xp[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)                                               // A[j = li][kk = lk] = inv(L)'[j][4m + lk]
+                xp[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(B0[(4 * m + lk) * 16 + li], t[m], double4_t{0, 0, 0, 0}, 0, 0, 0);
+            double4_t xn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xn[r] = (xp[0][r] + xp[1][r]) + (xp[2][r] + xp[3][r]);
+            if (li == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int row = 16 * J + lk + 4 * r; if (row < n_band) a.xr[row] = xn[r]; }
+            }
+#pragma unroll
+            for (int K = 4; K >= 1; --K) xk[K] = xk[K - 1];
+            xk[0] = xn;
+        } else {
+            const int B = J - BWD_AHEAD;          // goes into the slot block J+1 has just left
+            if (1 + ((B % 3) + 3) % 3 == wave) issue(B);
+            if (J >= 1 && 1 + (J - 1) % 3 == wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");   // block J-1 has landed
+        }
+    }
+    if (tid == 0) a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1150,15 +1179,21 @@ int enqueue_solve_finish(nlls_ctx* c) {
         const int nbr = L.nbd + 1;
         const size_t lds = sizeof(double) * ((size_t)a.RC * L.H + 2 * (size_t)(2 * a.NSC * c->band_SEG + 2 * c->band_SEG) + (size_t)(L.bw + 2) * nbr + (size_t)nbr * nbr + nbr + 8);
         const int NBW = (L.bw + 15) / 16;                // tile rows below the diagonal tile that a block column reaches
-        const size_t blk_lds = sizeof(double) * ((size_t)(NBW + 2) * (NBW + 2) * 272 + 272 + 2 * (size_t)(NBW + 2) * 16 * 17 + 64 + 48 * 17 + 8);
+        const size_t blk_lds = sizeof(double) * ((size_t)(NBW + 2) * (NBW + 2) * 272 + 272 + 2 * (size_t)(NBW + 2) * 16 * 17 + 64 + 32 * 17 + 8);
         if (c->band_blocked && NBW <= 5 && (NBW + 2) * 16 <= 128 && L.H <= 96 && blk_lds <= 160 * 1024) {
-            BlkArgs bkl{}; bkl.Sb = c->S.p; bkl.Lb = c->Lwork.p; bkl.corner_out = c->Lwork.p + (size_t)L.H * L.n_band; bkl.n_band = L.n_band; bkl.bw = L.bw; bkl.nbd = L.nbd;
+            const int nJb = (L.n_band + 15) / 16, fsz = blk_fsize(NBW, L.nbd);
+            BlkArgs bkl{}; bkl.Sb = c->S.p; bkl.Lb = c->Lwork.p; bkl.corner_out = c->Lwork.p + (size_t)nJb * fsz + 128; bkl.n_band = L.n_band; bkl.bw = L.bw; bkl.nbd = L.nbd;
             bkl.H = L.H; bkl.NBW = NBW; bkl.status = c->d_status.p;
             hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(BLK_T), blk_lds, c->stream, bkl);
-            BandArgs ab = a;   // the backward pass keeps NR = 16*ceil((bw+16)/16) rows in reach: its own ring depth
-            { const int NR = 16 * ((L.bw + 16 + 15) / 16); ab.PFC = (NR + ab.CH - 1) / ab.CH + 1; ab.RC = (ab.PFC + 1) * ab.CH; }
-            const size_t lds_b = sizeof(double) * ((size_t)ab.RC * L.H + (size_t)nbr * nbr + nbr + 8);
-            hipLaunchKernelGGL(band_backward_kernel, dim3(1), dim3(256), lds_b, c->stream, ab, (const double*)bkl.corner_out);
+            BwdArgs bw2{}; bw2.Lt = c->Lwork.p; bw2.corner_in = bkl.corner_out; bw2.xr = c->s_ptr(); bw2.n_band = L.n_band; bw2.nbd = L.nbd; bw2.NBW = NBW; bw2.status = c->d_status.p;
+            const size_t lds_b = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBW) + (size_t)nbr * nbr + nbr + 8);
+            switch (NBW) {
+                case 1: hipLaunchKernelGGL(band_backward_tiles_kernel<1>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
+                case 2: hipLaunchKernelGGL(band_backward_tiles_kernel<2>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
+                case 3: hipLaunchKernelGGL(band_backward_tiles_kernel<3>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
+                case 4: hipLaunchKernelGGL(band_backward_tiles_kernel<4>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
+                default: hipLaunchKernelGGL(band_backward_tiles_kernel<5>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
+            }
         } else
 #define LAUNCH_BAND(SEG, NSLOT) hipLaunchKernelGGL((band_ldlt_solve_kernel<SEG, NSLOT>), dim3(1), dim3(256), lds, c->stream, a)
         if (c->band_SEG == 10 && c->band_NSEG == 2) LAUNCH_BAND(10, 2);

@@ -526,7 +526,9 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     if (c->solve_mode == SOLVE_BAND) {
         const size_t sz = (size_t)c->band_H * c->n_band + (size_t)(c->nbd + 1) * (c->nbd + 1);
         c->s_elems = sz;
-        if (hipSuccess != c->S.alloc(sz + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(sz) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "band system alloc");
+        // the blocked factor kernel exports tiles: (NBW + 1) 16x16 tiles + the border/rhs rows per 16-column block
+        const size_t nbw = ((size_t)bw + 15) / 16, tsz = (((size_t)c->n_band + 15) / 16) * ((nbw + 1) * 256 + (size_t)(c->nbd + 1) * 16) + 128 + (size_t)(c->nbd + 1) * (c->nbd + 1);
+        if (hipSuccess != c->S.alloc(sz + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(std::max(sz, tsz)) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "band system alloc");
     } else {
         const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
         c->s_elems = (size_t)std::max<int64_t>(npad * npad, 1);
