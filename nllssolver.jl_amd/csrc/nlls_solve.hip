@@ -166,125 +166,227 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
     }
 }
 
+// (C_v + lambda I)^-1 of every eliminated block of the compile-time size DV, once per solve: the elimination and the
+// back-substitution of the fast path then need no factorisation, no division and no dependent chain per member.
+template <int DV>
+__global__ __launch_bounds__(256) void schur_cinv_kernel(const double* __restrict__ A, const int64_t* __restrict__ ediag, const uint16_t* __restrict__ edim,
+                                                         int64_t nel, double lambda, double* __restrict__ Cinv, int* __restrict__ status) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nel || edim[v] != DV) return;
+    double C[DV * DV];
+#pragma unroll
+    for (int j = 0; j < DV; ++j)
+#pragma unroll
+        for (int i = j; i < DV; ++i) C[i + DV * j] = A[ediag[v] + i + DV * j];
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {                            // LDL'
+        double d = C[j + DV * j] + lambda;
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= C[j + DV * k] * C[j + DV * k] * C[k + DV * k];
+        if (d == 0.0 || d != d) { atomicCAS(status, 0, 1); d = 1.0; }
+        C[j + DV * j] = d;
+#pragma unroll
+        for (int i = j + 1; i < DV; ++i) { double t = C[i + DV * j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= C[i + DV * k] * C[j + DV * k] * C[k + DV * k];
+            C[i + DV * j] = t / d; }
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < DV; ++c2) {                          // column c2 of the inverse
+        double y[DV];
+#pragma unroll
+        for (int i = 0; i < DV; ++i) { double t = (i == c2) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) t -= C[i + DV * k] * y[k]; y[i] = t; }
+#pragma unroll
+        for (int i = 0; i < DV; ++i) y[i] /= C[i + DV * i];
+#pragma unroll
+        for (int i = DV - 1; i >= 0; --i) { double t = y[i];
+#pragma unroll
+            for (int k = i + 1; k < DV; ++k) t -= C[k + DV * i] * y[k]; y[i] = t; }
+#pragma unroll
+        for (int i = 0; i < DV; ++i) Cinv[v * (DV * DV) + i + DV * c2] = y[i];
+    }
+}
+
+// x_v = (C_v + lambda I)^-1 (b_v - E_v x_R), stored negated, for the members of fast-path supernodes: one wavefront per
+// supernode, four members at a time (16 lanes each).  A lane owns columns l, l + 16, ... of E_v -- the same reduced
+// columns for every member of the supernode, so their x_R entries stay in registers -- and the 16 partial sums per
+// component meet in lane 15 of the row through DPP row shifts.
+template <int CTRL>
+NLLS_DEV double row_shr_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return v + __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true));
+}
+template <int DV>
+__global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                                const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
+                                                                const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                                const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
+                                                                const double* __restrict__ Cinv, const double* __restrict__ xr, double* __restrict__ x) {
+    constexpr int MAXC = (72 + 15) / 16;                      // columns per lane (nd <= 72)
+    __shared__ uint32_t rc[80];
+    const int lane = threadIdx.x, l = lane & 15, gsub = lane >> 4;
+    const uint32_t g = glist[blockIdx.x];
+    const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
+    const int64_t p0 = eptr[v0]; const int nnb = (int)(eptr[v0 + 1] - p0);
+    int nd = 0;
+    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = lane; c2 < nb.dim; c2 += 64) rc[nd + c2] = nb.rcol + c2; nd += nb.dim; }
+    __syncthreads();
+    double xw[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) { const int col = l + 16 * k; xw[k] = col < nd ? xr[rc[col]] : 0.0; }
+    for (uint32_t vb = v0; vb < v1; vb += 4) {
+        const uint32_t v = vb + gsub; const bool live = v < v1; const uint32_t vv = live ? v : v0;
+        const int64_t seg = ediag[vv] - (int64_t)DV * nd;
+        double acc[DV];
+#pragma unroll
+        for (int a2 = 0; a2 < DV; ++a2) acc[a2] = 0.0;
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { const int col = l + 16 * k;
+            if (col < nd) {
+#pragma unroll
+                for (int a2 = 0; a2 < DV; ++a2) acc[a2] = fma(A[seg + (int64_t)DV * col + a2], xw[k], acc[a2]); } }
+#pragma unroll
+        for (int a2 = 0; a2 < DV; ++a2) { double t = acc[a2]; t = row_shr_add<0x111>(t); t = row_shr_add<0x112>(t); t = row_shr_add<0x114>(t); t = row_shr_add<0x118>(t); acc[a2] = t; }
+        if (live && l == 15) {
+            double r[DV];
+#pragma unroll
+            for (int a2 = 0; a2 < DV; ++a2) r[a2] = b[eboff[v] + a2] - acc[a2];
+#pragma unroll
+            for (int i = 0; i < DV; ++i) { double t = 0;
+#pragma unroll
+                for (int j = 0; j < DV; ++j) t = fma(Cinv[(int64_t)v * (DV * DV) + i + DV * j], r[j], t);
+                x[eboff[v] + i] = -t; }
+        }
+    }
+}
+
 // Fast path of the elimination for supernodes whose members (a) have the compile-time block size DV and (b) store
 // their off-diagonal blocks back to back in their own block row, in reduced-column order, followed by the diagonal
-// block -- the layout every bundle-adjustment point row has (src/BlockSparseMatrix.jl:37-44).  Lane c owns column c
-// of [E | b]: it loads its DV entries plus C_v straight into registers (one memory latency per block, the next
-// block's loads are issued before the current one is consumed), factors C_v redundantly in registers (no LDS, no
-// barrier), and the pair products are accumulated in REGISTERS (static pair list per lane), flushed once per run.
-template <int DV, int MAXK, int NCOL>
-__global__ __launch_bounds__(64) void schur_elim_fast_kernel(const double* __restrict__ A, const double* __restrict__ b,
-                                                             const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
-                                                             const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
-                                                             const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist, double lambda,
-                                                             SLayout L, double* __restrict__ s, int* __restrict__ status) {
-    __shared__ double Es[2][DV * 128], Ys[2][DV * 128];   // columns of E and Y (nd + 1 <= 128)
-    __shared__ uint32_t rc[128];
-    const int lane = threadIdx.x;
+// block -- the layout every bundle-adjustment point row has (src/BlockSparseMatrix.jl:37-44).
+// One 256-thread workgroup per supernode.  Per member v: thread c <= nd owns column c of [E | b] -- it loads its DV
+// entries straight into registers (a few members ahead), multiplies by (C_v + lambda I)^-1 from schur_cinv_kernel,
+// y_c = (C_v + lambda I)^-1 e_c -- and publishes e_c, y_c in LDS,
+// component-major, two buffers so that one barrier per member suffices.  The rank-DV update S -= E' Y is register
+// tiled: thread t owns a 4x4 tile of pairs (p, q), reads four columns of E and four of Y (2 x DV 32-byte LDS reads)
+// and does 16 DV-term dot products; a few more threads take the rhs column.  The tiles are flushed once per supernode
+// with HBM atomics (supernodes of different points overlap in S).
+constexpr int ELIM_PF = 4;                                    // members in flight per solver thread
+constexpr int ELIM_NDP = 76;                                  // columns of [E | b] rounded up to a multiple of 4 (nd + 1 <= 72)
+template <int DV>
+__global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                               const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
+                                                               const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                               const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
+                                                               const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
+    __shared__ __attribute__((aligned(16))) double Es[2][DV][ELIM_NDP], Ys[2][DV][ELIM_NDP];
+    __shared__ uint32_t rc[ELIM_NDP];
+    const int tid = threadIdx.x;
     const uint32_t g = glist[blockIdx.x];
     const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
     // structure of the run (identical for all members): reduced column of every E column
     const int64_t p0 = eptr[v0]; const int nnb = (int)(eptr[v0 + 1] - p0);
     int nd = 0;
-    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = lane; c2 < nb.dim; c2 += 64) rc[nd + c2] = nb.rcol + c2; nd += nb.dim; }
-    const int npairs = nd * (nd + 1) / 2;
-    // static pair list: lane's k-th pair is t = lane + 64 k  ->  (p, q), p >= q
-    uint32_t pq[MAXK]; double acc[MAXK];
+    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = tid; c2 < nb.dim; c2 += 256) rc[nd + c2] = nb.rcol + c2; nd += nb.dim; }
+    for (int i = tid; i < 2 * DV * ELIM_NDP; i += 256) { (&Es[0][0][0])[i] = 0.0; (&Ys[0][0][0])[i] = 0.0; }
+    __syncthreads();
+    // this thread's tile: t < ntile -> (tp, tq), tq <= tp, pairs (4 tp + i, 4 tq + j); ntile <= t < ntile + T -> (tp, rhs column)
+    const int T = (nd + 3) >> 2, ntile = T * (T + 1) / 2;
+    // (tiles live on waves 1-3: wave 0 is the solver and runs one member ahead of them)
+    const int tt = tid - 64;
+    int tp = 0, tq = 0; bool rhs_tile = false, has_tile = tt >= 0 && tt < ntile + T;
+    if (has_tile && tt < ntile) { tp = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5); while (tp * (tp + 1) / 2 > tt) --tp; while ((tp + 1) * (tp + 2) / 2 <= tt) ++tp; tq = tt - tp * (tp + 1) / 2; }
+    else if (has_tile) { tp = tt - ntile; rhs_tile = true; }
+    double acc[4][4];
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-        const int t = lane + 64 * k; int p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-        while (p * (p + 1) / 2 > t) --p;
-        while ((p + 1) * (p + 2) / 2 <= t) ++p;
-        pq[k] = (t < npairs) ? ((uint32_t)p << 16 | (uint32_t)(t - p * (p + 1) / 2)) : 0xFFFFFFFFu; acc[k] = 0.0;
-    }
-    double accs[NCOL];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int u = 0; u < NCOL; ++u) accs[u] = 0.0;                          // column p = lane + 64 u < nd: sum of E(:,p)' y_b
-    // software pipeline: registers hold the NEXT block's columns (lane owns columns lane and lane + 64) and diagonal block
-    double en[NCOL][DV], cn[DV * DV];
-    auto issue = [&](uint32_t v) {
-        const int64_t seg = ediag[v] - (int64_t)DV * nd;   // the off-diagonal blocks sit right before the diagonal block
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    // software pipeline: registers hold the columns and the inverse diagonal blocks (schur_cinv_kernel) of the next
+    // ELIM_PF members (HBM latency is a multiple of a member's processing time, one member ahead is not enough)
+    const bool solver = tid <= nd;
+    double en[ELIM_PF][DV], cn[ELIM_PF][DV * DV];
+    // (the diagonal block is the same for every thread: its loads stay outside divergent code so that they are scalar)
+    auto issue = [&](uint32_t v, int slot) {
+        const int64_t dg = ediag[v], seg = dg - (int64_t)DV * nd;   // the off-diagonal blocks sit right before the diagonal block
+        if (solver) {
 #pragma unroll
-        for (int u = 0; u < NCOL; ++u) { const int col = lane + 64 * u;
+            for (int a2 = 0; a2 < DV; ++a2) en[slot][a2] = (tid < nd) ? A[seg + (int64_t)DV * tid + a2] : b[eboff[v] + a2];
+        }
 #pragma unroll
-            for (int a2 = 0; a2 < DV; ++a2) en[u][a2] = (col < nd) ? A[seg + (int64_t)DV * col + a2] : ((col == nd) ? b[eboff[v] + a2] : 0.0); }
+        for (int j = 0; j < DV; ++j)
 #pragma unroll
-        for (int e = 0; e < DV * DV; ++e) cn[e] = A[ediag[v] + e];
+            for (int i = j; i < DV; ++i) cn[slot][i + DV * j] = Cinv[(int64_t)v * (DV * DV) + i + DV * j];   // symmetric: lower triangle
     };
-    issue(v0);
+#pragma unroll
+    for (int u = 0; u < ELIM_PF; ++u) if (v0 + u < v1) issue(v0 + u, u);
     int buf = 0;
-    for (uint32_t v = v0; v < v1; ++v, buf ^= 1) {
-        double e[NCOL][DV], C[DV * DV];
+    for (uint32_t vb = v0; vb < v1; vb += ELIM_PF) {
 #pragma unroll
-        for (int u = 0; u < NCOL; ++u)
+        for (int u = 0; u < ELIM_PF; ++u) {
+            const uint32_t v = vb + u;
+            if (v >= v1) break;
+            double e[DV], C[DV * DV];
 #pragma unroll
-            for (int a2 = 0; a2 < DV; ++a2) e[u][a2] = en[u][a2];
+            for (int a2 = 0; a2 < DV; ++a2) e[a2] = en[u][a2];
 #pragma unroll
-        for (int q = 0; q < DV * DV; ++q) C[q] = cn[q];
-        if (v + 1 < v1) issue(v + 1);
-        // LDL' of C + lambda*I in registers (every lane, redundantly)
+            for (int j = 0; j < DV; ++j)
 #pragma unroll
-        for (int j = 0; j < DV; ++j) {
-            double d = C[j + DV * j] + lambda;
+                for (int i = j; i < DV; ++i) C[i + DV * j] = cn[u][i + DV * j];
+            if (v + ELIM_PF < v1) issue(v + ELIM_PF, u);
+            if (solver) {
+                double y[DV];                                  // y = (C_v + lambda I)^-1 e
 #pragma unroll
-            for (int k = 0; k < j; ++k) d -= C[j + DV * k] * C[j + DV * k] * C[k + DV * k];
-            if (d == 0.0 || d != d) { if (lane == 0) atomicCAS(status, 0, 1); d = 1.0; }
-            C[j + DV * j] = d;
+                for (int i = 0; i < DV; ++i) { double t = 0;
 #pragma unroll
-            for (int i = j + 1; i < DV; ++i) { double t = C[i + DV * j];
+                    for (int j = 0; j < DV; ++j) t = fma(i >= j ? C[i + DV * j] : C[j + DV * i], e[j], t);
+                    y[i] = t; }
 #pragma unroll
-                for (int k = 0; k < j; ++k) t -= C[i + DV * k] * C[j + DV * k] * C[k + DV * k];
-                C[i + DV * j] = t / d; }
-        }
-#pragma unroll
-        for (int u = 0; u < NCOL; ++u) {
-            const int col = lane + 64 * u;
-            double y[DV];
-#pragma unroll
-            for (int i = 0; i < DV; ++i) { double t = e[u][i];
-#pragma unroll
-                for (int k = 0; k < i; ++k) t -= C[i + DV * k] * y[k]; y[i] = t; }
-#pragma unroll
-            for (int i = 0; i < DV; ++i) y[i] /= C[i + DV * i];
-#pragma unroll
-            for (int i = DV - 1; i >= 0; --i) { double t = y[i];
-#pragma unroll
-                for (int k = i + 1; k < DV; ++k) t -= C[k + DV * i] * y[k]; y[i] = t; }
-            if (col <= nd) {
-#pragma unroll
-                for (int a2 = 0; a2 < DV; ++a2) { Es[buf][a2 + DV * col] = e[u][a2]; Ys[buf][a2 + DV * col] = y[a2]; }
+                for (int a2 = 0; a2 < DV; ++a2) { Es[buf][a2][tid] = e[a2]; Ys[buf][a2][tid] = y[a2]; }
             }
+            __syncthreads();                                   // member v published; the other buffer is free for v + 1
+            if (has_tile) {
+                double ep[DV][4], yq[DV][4];
+#pragma unroll
+                for (int a2 = 0; a2 < DV; ++a2) {
+                    const double4_t ev = *reinterpret_cast<const double4_t*>(&Es[buf][a2][4 * tp]);
+                    ep[a2][0] = ev[0]; ep[a2][1] = ev[1]; ep[a2][2] = ev[2]; ep[a2][3] = ev[3];
+                    if (!rhs_tile) { const double4_t yv = *reinterpret_cast<const double4_t*>(&Ys[buf][a2][4 * tq]); yq[a2][0] = yv[0]; yq[a2][1] = yv[1]; yq[a2][2] = yv[2]; yq[a2][3] = yv[3]; }
+                    else { yq[a2][0] = Ys[buf][a2][nd]; yq[a2][1] = yq[a2][2] = yq[a2][3] = 0.0; }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        double t = acc[i][j];
+#pragma unroll
+                        for (int a2 = 0; a2 < DV; ++a2) t = fma(ep[a2][i], yq[a2][j], t);
+                        acc[i][j] = t;
+                    }
+            }
+            buf ^= 1;
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS writes have landed (single-wave workgroup)
-        __builtin_amdgcn_wave_barrier();
-        const double* Eb = Es[buf]; const double* Yb = Ys[buf];
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) if (pq[k] != 0xFFFFFFFFu) {
-            const int p = pq[k] >> 16, q = pq[k] & 0xFFFF; double a2 = 0;
-#pragma unroll
-            for (int a3 = 0; a3 < DV; ++a3) a2 += Eb[a3 + DV * p] * Yb[a3 + DV * q];
-            acc[k] += a2;
-        }
-#pragma unroll
-        for (int u = 0; u < NCOL; ++u) if (lane + 64 * u < nd) { double a2 = 0;
-#pragma unroll
-            for (int a3 = 0; a3 < DV; ++a3) a2 += e[u][a3] * Yb[a3 + DV * nd];
-            accs[u] += a2; }
     }
+    if (has_tile) {
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) if (pq[k] != 0xFFFFFFFFu) atomicAdd(L.at(rc[pq[k] >> 16], rc[pq[k] & 0xFFFF]), -acc[k]);
+        for (int i = 0; i < 4; ++i) {
+            const int p = 4 * tp + i; if (p >= nd) continue;
+            if (rhs_tile) { atomicAdd(&s[rc[p]], -acc[i][0]); continue; }
 #pragma unroll
-    for (int u = 0; u < NCOL; ++u) if (lane + 64 * u < nd) atomicAdd(&s[rc[lane + 64 * u]], -accs[u]);
+            for (int j = 0; j < 4; ++j) { const int q = 4 * tq + j; if (q <= p) atomicAdd(L.at(rc[p], rc[q]), -acc[i][j]); }
+        }
+    }
 }
 
 // x_v = C_v^-1 (b_v - E_v x_R), stored negated (negate!, src/iterators.jl:3)
 __global__ __launch_bounds__(64) void schur_backsub_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                            const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
                                                            const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
-                                                           const uint16_t* __restrict__ edim, double lambda, int maxdv,
+                                                           const uint16_t* __restrict__ edim, const uint32_t* __restrict__ vlist, double lambda, int maxdv,
                                                            const double* __restrict__ xr, double* __restrict__ x) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int v = blockIdx.x, lane = threadIdx.x; const int dv = edim[v];
+    const int v = vlist ? (int)vlist[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x; const int dv = edim[v];
     double* C = sm; double* rhs = C + maxdv * maxdv;
     for (int e = lane; e < dv * dv; e += 64) { const int i = e % dv, j = e / dv; C[e] = A[ediag[v] + e] + (i == j ? lambda : 0.0); }
     // rhs[a] = b[a] - sum_p E[a,p] xr[p]: lanes over the neighbour blocks' elements, summed with LDS atomics
@@ -1147,19 +1249,14 @@ int enqueue_solve_local(nlls_ctx* c) {
             hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)c->n_slow_groups), dim3(64), c->elim_lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
                                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->d_slow_groups.p, c->lambda, c->max_elim_dim, c->max_nbr_dof,
                                c->elim_use_acc ? 1 : 0, L, c->s_ptr(), c->d_status.p);
-        // supernodes whose [E | b] fits one column per lane (nd + 1 <= 64) and wider ones (two per lane)
-#define LAUNCH_FAST(DV, MAXK, NCOL, N, LIST) hipLaunchKernelGGL((schur_elim_fast_kernel<DV, MAXK, NCOL>), dim3((unsigned)(N)), dim3(64), 0, c->stream, c->A.p, c->b.p, \
-                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, LIST, c->lambda, L, c->s_ptr(), c->d_status.p)
-#define LAUNCH_FAST_DV(DV) do { \
-            if (c->n_fast_narrow > 0) { if (c->fast_maxk_narrow <= 12) LAUNCH_FAST(DV, 12, 1, c->n_fast_narrow, c->d_fast_groups.p); \
-                                        else if (c->fast_maxk_narrow <= 24) LAUNCH_FAST(DV, 24, 1, c->n_fast_narrow, c->d_fast_groups.p); \
-                                        else LAUNCH_FAST(DV, 32, 1, c->n_fast_narrow, c->d_fast_groups.p); } \
-            if (c->n_fast_groups > c->n_fast_narrow) LAUNCH_FAST(DV, 40, 2, c->n_fast_groups - c->n_fast_narrow, c->d_fast_groups.p + c->n_fast_narrow); } while (0)
+#define LAUNCH_TILED(DV) do { const int64_t nel = (int64_t)c->d_elim_diag.n; \
+            hipLaunchKernelGGL((schur_cinv_kernel<DV>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, c->stream, c->A.p, c->d_elim_diag.p, c->d_elim_dim.p, nel, c->lambda, c->Cinv.p, c->d_status.p); \
+            hipLaunchKernelGGL((schur_elim_tiled_kernel<DV>), dim3((unsigned)c->n_fast_groups), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, L, c->s_ptr()); } while (0)
         if (c->n_fast_groups > 0) {
-            if (c->fast_dv == 3) LAUNCH_FAST_DV(3); else if (c->fast_dv == 2) LAUNCH_FAST_DV(2); else if (c->fast_dv == 1) LAUNCH_FAST_DV(1);
+            if (c->fast_dv == 3) LAUNCH_TILED(3); else if (c->fast_dv == 2) LAUNCH_TILED(2); else if (c->fast_dv == 1) LAUNCH_TILED(1);
         }
-#undef LAUNCH_FAST_DV
-#undef LAUNCH_FAST
+#undef LAUNCH_TILED
     }
     HIPCHK(hipGetLastError());
     return NLLS_OK;
@@ -1227,8 +1324,16 @@ int enqueue_solve_finish(nlls_ctx* c) {
     const int64_t nel_local = (int64_t)(c->d_elim_diag.n);
     if (nel_local > 0) {
         const size_t lds = sizeof(double) * ((size_t)c->max_elim_dim * c->max_elim_dim + c->max_elim_dim);
-        hipLaunchKernelGGL(schur_backsub_kernel, dim3((unsigned)nel_local), dim3(64), lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
-                           c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->lambda, c->max_elim_dim, c->s_ptr(), c->x.p);
+        // members of fast-path supernodes reuse the inverses of schur_cinv_kernel; the rest factor their own block
+        const int64_t nslow = c->n_fast_groups > 0 ? (int64_t)c->d_slow_blocks.n : nel_local;
+        if (nslow > 0)
+            hipLaunchKernelGGL(schur_backsub_kernel, dim3((unsigned)nslow), dim3(64), lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
+                               c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->n_fast_groups > 0 ? c->d_slow_blocks.p : (const uint32_t*)nullptr,
+                               c->lambda, c->max_elim_dim, c->s_ptr(), c->x.p);
+#define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p, \
+                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p)
+        if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); }
+#undef LAUNCH_BSF
     }
     HIPCHK(hipGetLastError());
     return NLLS_OK;

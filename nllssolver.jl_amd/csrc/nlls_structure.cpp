@@ -464,7 +464,9 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         c->n_fast_narrow = (int64_t)fastg.size(); c->fast_maxk_narrow = fast_maxk;
         fastg.insert(fastg.end(), fastw.begin(), fastw.end());
         c->n_fast_groups = (int64_t)fastg.size(); c->n_slow_groups = (int64_t)slowg.size(); c->fast_dv = fast_dv; c->fast_maxk = fast_maxk;
-        if (hipSuccess != c->d_fast_groups.upload(fastg) || hipSuccess != c->d_slow_groups.upload(slowg)) return fail(c, NLLS_ERR_HIP, "group list upload");
+        std::vector<uint32_t> slowb; for (uint32_t gi : slowg) for (uint32_t v = egroup[gi]; v < egroup[gi + 1]; ++v) slowb.push_back(v);
+        if (hipSuccess != c->d_fast_groups.upload(fastg) || hipSuccess != c->d_slow_groups.upload(slowg) || hipSuccess != c->d_slow_blocks.upload(slowb) ||
+            hipSuccess != c->Cinv.alloc(std::max<size_t>(1, ediag.size() * (size_t)std::max(1, fast_dv * fast_dv)))) return fail(c, NLLS_ERR_HIP, "group list upload");
         // LDS budget of the elimination kernel: C, E, Y, pair accumulators, column map
         const size_t nd = c->max_nbr_dof, dv = c->max_elim_dim;
         size_t base = sizeof(double) * (dv * dv + dv * nd + dv * (nd + 1)) + 16 * nd + 12 * nd + 16;
