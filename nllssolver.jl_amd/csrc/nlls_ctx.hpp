@@ -182,6 +182,7 @@ struct nlls_ctx {
     int64_t n_band = 0; int nbd = 0, bw = 0;   // reduced ordering: [banded part | border dof | rhs]
     int solve_mode = 0, band_CH = 0, band_H = 0, band_SEG = 0, band_NSEG = 0;
     bool band_blocked = true;                // blocked (MFMA) band factorisation when the bandwidth allows
+    bool band_twisted = true;               // factor the band from both ends at once (two workgroups) when the layout allows
     nlls::DevBuf<nlls::SchurCopy> d_copy;    // reduced-reduced blocks
     int64_t ncopy = 0;
     nlls::DevBuf<nlls::SchurCopy> d_blk;     // every stored block with full-system dof offsets (quadratic forms)

@@ -812,13 +812,17 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
 //     consumed by band_backward_kernel) behind wave 0's factorisation.
 // Tiles live in an LDS ring indexed by (block column mod (NBW+2), tile row), rows padded to 17 doubles.
 // ---------------------------------------------------------------------------------------------------
-struct BlkArgs { const double* Sb; double* Lb; double* corner_out; int n_band, bw, nbd, H, NBW; int* status; };
+// rev / nJs / sep_out: twisted (two-sided) factorisation -- one workgroup takes the band from the top, a second one from
+// the bottom (rev = 1: it sees the matrix with rows and columns reversed, still a band), each stops after nJs blocks,
+// and what they have accumulated on the separator in between goes to sep_out (band_sep_solve_kernel).
+struct BlkArgs { const double* Sb; double* Lb; double* corner_out; double* sep_out; int n_band, bw, nbd, H, NBW, rev, nJs; int* status; };
+struct BlkArgs2 { BlkArgs c[2]; };
 
 NLLS_DEV double readlane_d(double x, int k) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
 }
 
-struct BlkLds { double* tiles; double* corner; double* Wp; double* dvec; double* Li; int TW, TR, NBW, H, bw, n_band, nJ; };
+struct BlkLds { double* tiles; double* corner; double* Wp; double* dvec; double* Li; int TW, TR, NBW, H, bw, n_band, nJ, rev; };
 constexpr int BLK_P = 17, BLK_TS = 16 * BLK_P;                // padded tile row, doubles per tile
 NLLS_DEV double* blk_tile(const BlkLds& S, int K, int ti) { return S.tiles + ((size_t)(K % S.TW) * S.TR + ti) * BLK_TS; }
 NLLS_DEV double* blk_panel(const BlkLds& S, int J) { return S.Wp + (size_t)(J & 1) * S.TR * 16 * BLK_P; }   // W of block J
@@ -902,7 +906,11 @@ __device__ __forceinline__ void blk_land_load(const BlkLds& S, const double* __r
             int c = 16 * K + cc, e;
             if (ti <= S.NBW) { e = 16 * ti + r - cc; if (e < 0) { c = 16 * K + r; e = -e; } }     // upper part of the diagonal tile: mirror
             else e = S.bw + 1 + r;                                                              // border tile: row r = border index
-            if (e < H && (ti > S.NBW || e <= S.bw)) val[q] = (c < S.n_band) ? Sb[(size_t)c * H + e] : (e == 0 ? 1.0 : 0.0);
+            if (e < H && (ti > S.NBW || e <= S.bw)) {
+                if (!S.rev) val[q] = (c < S.n_band) ? Sb[(size_t)c * H + e] : (e == 0 ? 1.0 : 0.0);
+                else if (ti > S.NBW) val[q] = (c < S.n_band) ? Sb[(size_t)(S.n_band - 1 - c) * H + e] : 0.0;          // border / rhs rows of reversed column c
+                else val[q] = (c + e < S.n_band) ? Sb[(size_t)(S.n_band - 1 - c - e) * H + e] : ((e == 0 && c >= S.n_band) ? 1.0 : 0.0);   // R(c + e, c) = S(n-1-c, n-1-c-e)
+            }
         }
     }
 }
@@ -996,18 +1004,19 @@ __device__ __forceinline__ void blk_export(const BlkLds& S, const double* __rest
     }
 }
 
-__global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs a) {
+__global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 args) {
+    const BlkArgs a = args.c[blockIdx.x];
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int P = BLK_P, TS = BLK_TS;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int n_band = a.n_band, nbd = a.nbd, H = a.H, NBW = a.NBW, nbr = nbd + 1;
-    BlkLds S; S.TW = NBW + 2; S.TR = NBW + 2; S.NBW = NBW; S.H = H; S.bw = a.bw; S.n_band = n_band; S.nJ = (n_band + 15) >> 4;
+    BlkLds S; S.TW = NBW + 2; S.TR = NBW + 2; S.NBW = NBW; S.H = H; S.bw = a.bw; S.n_band = n_band; S.nJ = (n_band + 15) >> 4; S.rev = a.rev;
     S.tiles = sm;                                             // [TW][TR][TS]
     S.corner = S.tiles + (size_t)S.TW * S.TR * TS;            // [TS] border x border (row/col = border index, rhs = nbd)
     S.Wp = S.corner + TS;                                     // [2][TR*16][P]
     S.dvec = S.Wp + 2 * (size_t)S.TR * 16 * P;                // [2][32]
     S.Li = S.dvec + 64;                                       // [2][16][P]: inv(L_JJ)' by block parity
-    const int nJ = S.nJ;
+    const int nJ = S.nJ, nJs = a.nJs;                         // blocks of the matrix; blocks this workgroup factors
     for (int i = tid; i < S.TW * S.TR * TS + TS; i += BLK_T) S.tiles[i] = 0.0;
     __syncthreads();
     for (int e = tid; e < nbr * nbr; e += BLK_T) { const int i = e % nbr, j = e / nbr; if (i >= j) { const double v = a.Sb[(size_t)n_band * H + e]; S.corner[i * P + j] = v; S.corner[j * P + i] = v; } }
@@ -1018,7 +1027,7 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs a) {
     BlkUpd<1> Uu; blk_update_list<1>(S, 0, nurgent, wave, NW, Uu);
     BlkUpd<3> Ud; blk_update_list<3>(S, nurgent, nup - nurgent, wave - 1, NW - 1, Ud);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();   // diagnostics only (nlls_get_solve_stats)
-    for (int J = 0; J < nJ; ++J) {
+    for (int J = 0; J < nJs; ++J) {
         __syncthreads();                                      // (A) block column J is final
         if (wave == 0) blk_factor(S, J, a.status);
         else {
@@ -1035,11 +1044,59 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs a) {
         blk_update<1>(S, J, Uu);
     }
     __syncthreads();
-    if (wave > 0) blk_update<3>(S, nJ - 1, Ud);               // the last block's share of the border corner
-    blk_export(S, blk_li(S, nJ - 1), a.Lb, nbd, nJ - 1, tid, BLK_T);
+    if (wave > 0) blk_update<3>(S, nJs - 1, Ud);              // the last block's deferred updates (border corner, separator)
+    blk_export(S, blk_li(S, nJs - 1), a.Lb, nbd, nJs - 1, tid, BLK_T);
     __syncthreads();
+    if (a.sep_out) {
+        // the NBW tile columns behind the last factored block, with everything this side has subtracted from them:
+        // dense [16 NBW][16 NBW] (lower block triangle), then the rhs row
+        const int SW = 16 * NBW;
+        for (int idx = tid; idx < NBW * NBW * 256; idx += BLK_T) {
+            const int t2 = idx >> 8, r = (idx >> 4) & 15, cc = idx & 15, Kc = t2 / NBW, ti = t2 % NBW;
+            if (Kc + ti < NBW) a.sep_out[(size_t)(16 * (Kc + ti) + r) * SW + 16 * Kc + cc] = blk_tile(S, nJs + Kc, ti)[r * P + cc];
+        }
+        for (int idx = tid; idx < SW; idx += BLK_T) a.sep_out[(size_t)SW * SW + idx] = blk_tile(S, nJs + (idx >> 4), NBW + 1)[nbd * P + (idx & 15)];
+    }
     for (int e = tid; e < nbr * nbr; e += BLK_T) { const int i = e % nbr, j = e / nbr; a.corner_out[e] = S.corner[i * P + j]; }
-    if (tid == 0) a.status[2] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+    if (tid == 0 && blockIdx.x == 0) a.status[2] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+}
+
+// Separator of the twisted factorisation: the columns [cA, cA + ws) between the two sides.  Its matrix is what the top
+// side left (sepA), plus what the bottom side left (sepB, in reversed indices), minus the original entries, which both
+// sides had loaded; same for the rhs row.  Small and dense (ws <= 16 NBW <= 80): LDL' and both substitutions in LDS.
+__global__ __launch_bounds__(256) void band_sep_solve_kernel(const double* __restrict__ Sb, const double* __restrict__ sepA, const double* __restrict__ sepB,
+                                                             int cA, int ws, int SW, int bw, int nbd, int H, double* __restrict__ xr, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, LD = ws + 1;
+    double* M = sm;                 // [ws][LD] lower triangle, row-major
+    double* z = M + (size_t)ws * LD;
+    for (int idx = tid; idx < ws * ws; idx += 256) {
+        const int i = idx / ws, j = idx % ws;
+        if (i >= j) M[i * LD + j] = sepA[(size_t)i * SW + j] + sepB[(size_t)(ws - 1 - j) * SW + (ws - 1 - i)] - ((i - j <= bw) ? Sb[(size_t)(cA + j) * H + (i - j)] : 0.0);
+    }
+    for (int i = tid; i < ws; i += 256) z[i] = sepA[(size_t)SW * SW + i] + sepB[(size_t)SW * SW + (ws - 1 - i)] - Sb[(size_t)(cA + i) * H + bw + 1 + nbd];
+    __syncthreads();
+    for (int k = 0; k < ws; ++k) {                            // right-looking LDL': column k scaled, then the trailing update
+        const double d = M[k * LD + k];
+        if (tid == 0 && (d == 0.0 || d != d)) atomicCAS(status, 0, 1 + cA + k);
+        const double rd = 1.0 / d;
+        const int m = ws - 1 - k;                             // rows below
+        for (int idx = tid; idx < m * (m + 1) / 2; idx += 256) {
+            int ii = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5); while (ii * (ii + 1) / 2 > idx) --ii; while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
+            const int jj = idx - ii * (ii + 1) / 2, i = k + 1 + ii, j = k + 1 + jj;
+            M[i * LD + j] -= M[i * LD + k] * M[j * LD + k] * rd;
+        }
+        __syncthreads();
+        for (int i = k + 1 + tid; i < ws; i += 256) M[i * LD + k] *= rd;   // L(i, k)
+        __syncthreads();
+    }
+    if (tid < 64) {                                            // one wavefront: forward, diagonal, backward
+        for (int k = 0; k < ws; ++k) { const double zk = z[k]; for (int i = k + 1 + tid; i < ws; i += 64) z[i] -= M[i * LD + k] * zk; __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+        for (int i = tid; i < ws; i += 64) z[i] /= M[i * LD + i];
+        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+        for (int k = ws - 1; k >= 0; --k) { const double xk = z[k]; for (int i = tid; i < k; i += 64) z[i] -= M[k * LD + i] * xk; __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+        for (int i = tid; i < ws; i += 64) xr[cA + i] = z[i];
+    }
 }
 
 // Border corner + backward pass of the blocked band solver (factor in tile layout from band_blocked_factor_kernel).
@@ -1051,16 +1108,20 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs a) {
 // the serial chain (two dependent MFMA rounds each); the other tiles' products are issued before x_{J+1} exists.
 // Waves 1-3 copy the factor HBM -> LDS with global_load_lds_dwordx4 (no registers, BWD_AHEAD blocks ahead, block B by
 // wave 1 + B % 3); a wave retires a block with a counted s_waitcnt just before the barrier that hands it to wave 0.
-struct BwdArgs { double* Lt; const double* corner_in; double* xr; int n_band, nbd, NBW; int* status; };
+// rev / nJs / xnext: the two sides of the twisted factorisation (a side's unknowns behind its last block are the separator's,
+// xnext = their index in xr seen from this side; -1: nothing behind the last block)
+struct BwdArgs { double* Lt; const double* corner_in; double* xr; int n_band, nbd, NBW, rev, nJs, xnext, nxnext; int* status; };
+struct BwdArgs2 { BwdArgs c[2]; };
 constexpr int BWD_AHEAD = 9, BWD_RING = BWD_AHEAD + 1;         // ring slots = blocks in LDS
 NLLS_HD int bwd_slot(int NBW) { return (NBW + 1) * 256 + 128; } // doubles copied per block: the tiles, then z (+ whatever follows)
 template <int NBW>
-__global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args) {
+    const BwdArgs a = args.c[blockIdx.x];
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int SLOT = (NBW + 1) * 256 + 128, NI = SLOT / 128; // NI wave-wide 16-byte copies per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int n_band = a.n_band, nbd = a.nbd, nbr = nbd + 1;
-    const int nJ = (n_band + 15) >> 4, fs = blk_fsize(NBW, nbd);
+    const int nJ = a.nJs, fs = blk_fsize(NBW, nbd);           // blocks of this side
     double* ring = sm;                            // [BWD_RING + 1][SLOT]; the extra slot takes the copies of blocks that do not exist
     double* Cl = ring + (size_t)(BWD_RING + 1) * SLOT;   // nbr x nbr border corner (col-major, lower), last row = rhs
     double* xb = Cl + nbr * nbr;                  // nbr
@@ -1100,7 +1161,13 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs a) {
     }
     double4_t xk[5];                              // x of blocks J+1 .. J+5, accumulator layout
 #pragma unroll
-    for (int K = 0; K < 5; ++K) xk[K] = double4_t{0, 0, 0, 0};
+    for (int K = 0; K < 5; ++K) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {             // behind the last block: the separator's unknowns (twisted factorisation), else nothing
+            const int i = 16 * K + 4 * m + lk;
+            xk[K][m] = (a.xnext >= 0 && i < a.nxnext) ? a.xr[a.rev ? a.xnext - i : a.xnext + i] : 0.0;
+        }
+    }
     for (int J = nJ - 1; J >= 0; --J) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block J is in LDS; the slot of block J+1 is free
         if (wave == 0) {
@@ -1130,7 +1197,7 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs a) {
             for (int r = 0; r < 4; ++r) xn[r] = (xp[0][r] + xp[1][r]) + (xp[2][r] + xp[3][r]);
             if (li == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const int row = 16 * J + lk + 4 * r; if (row < n_band) a.xr[row] = xn[r]; }
+                for (int r = 0; r < 4; ++r) { const int row = 16 * J + lk + 4 * r; if (row < n_band) a.xr[a.rev ? n_band - 1 - row : row] = xn[r]; }
             }
 #pragma unroll
             for (int K = 4; K >= 1; --K) xk[K] = xk[K - 1];
@@ -1141,7 +1208,7 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs a) {
             if (J >= 1 && 1 + (J - 1) % 3 == wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");   // block J-1 has landed
         }
     }
-    if (tid == 0) a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+    if (tid == 0 && blockIdx.x == 0) a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1279,17 +1346,35 @@ int enqueue_solve_finish(nlls_ctx* c) {
         const size_t blk_lds = sizeof(double) * ((size_t)(NBW + 2) * (NBW + 2) * 272 + 272 + 2 * (size_t)(NBW + 2) * 16 * 17 + 64 + 32 * 17 + 8);
         if (c->band_blocked && NBW <= 5 && (NBW + 2) * 16 <= 128 && L.H <= 96 && blk_lds <= 160 * 1024) {
             const int nJb = (L.n_band + 15) / 16, fsz = blk_fsize(NBW, L.nbd);
-            BlkArgs bkl{}; bkl.Sb = c->S.p; bkl.Lb = c->Lwork.p; bkl.corner_out = c->Lwork.p + (size_t)nJb * fsz + 128; bkl.n_band = L.n_band; bkl.bw = L.bw; bkl.nbd = L.nbd;
-            bkl.H = L.H; bkl.NBW = NBW; bkl.status = c->d_status.p;
-            hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(BLK_T), blk_lds, c->stream, bkl);
-            BwdArgs bw2{}; bw2.Lt = c->Lwork.p; bw2.corner_in = bkl.corner_out; bw2.xr = c->s_ptr(); bw2.n_band = L.n_band; bw2.nbd = L.nbd; bw2.NBW = NBW; bw2.status = c->d_status.p;
+            // twisted (two-sided) factorisation: two workgroups, one from each end of the band, meet at a separator of
+            // ws columns, bw <= ws <= 16 NBW, so that the sides do not touch each other
+            const int kk = (L.n_band - L.bw) / 16, ws = L.n_band - 16 * kk;
+            const bool twisted = c->band_twisted && L.nbd == 0 && ws >= L.bw && ws <= 16 * NBW && kk >= 4 * (NBW + 2);
+            const int JA = twisted ? (kk + 1) / 2 : nJb, JB = twisted ? kk / 2 : 0, cA = 16 * JA;
+            double* corner = c->Lwork.p + (size_t)nJb * fsz + 128;
+            double* sepA = corner + 2 * nbr * nbr; double* sepB = sepA + (size_t)(16 * NBW) * (16 * NBW) + 16 * NBW;
+            BlkArgs2 bkl{};
+            for (int sd = 0; sd < (twisted ? 2 : 1); ++sd) {
+                BlkArgs& q = bkl.c[sd]; q.Sb = c->S.p; q.Lb = c->Lwork.p + (size_t)(sd ? JA : 0) * fsz; q.corner_out = corner + sd * nbr * nbr;
+                q.sep_out = twisted ? (sd ? sepB : sepA) : nullptr; q.n_band = L.n_band; q.bw = L.bw; q.nbd = L.nbd; q.H = L.H; q.NBW = NBW; q.rev = sd; q.nJs = sd ? JB : JA; q.status = c->d_status.p;
+            }
+            hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(twisted ? 2 : 1), dim3(BLK_T), blk_lds, c->stream, bkl);
+            if (twisted)
+                hipLaunchKernelGGL(band_sep_solve_kernel, dim3(1), dim3(256), sizeof(double) * ((size_t)ws * (ws + 1) + ws + 8), c->stream, (const double*)c->S.p, (const double*)sepA, (const double*)sepB,
+                                   cA, ws, 16 * NBW, L.bw, L.nbd, L.H, c->s_ptr(), c->d_status.p);
+            BwdArgs2 bw2{};
+            for (int sd = 0; sd < (twisted ? 2 : 1); ++sd) {
+                BwdArgs& q = bw2.c[sd]; q.Lt = c->Lwork.p + (size_t)(sd ? JA : 0) * fsz; q.corner_in = corner; q.xr = c->s_ptr(); q.n_band = L.n_band; q.nbd = L.nbd; q.NBW = NBW;
+                q.rev = sd; q.nJs = sd ? JB : JA; q.xnext = twisted ? (sd ? cA + ws - 1 : cA) : -1; q.nxnext = ws; q.status = c->d_status.p;
+            }
             const size_t lds_b = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBW) + (size_t)nbr * nbr + nbr + 8);
+            const dim3 gb(twisted ? 2 : 1);
             switch (NBW) {
-                case 1: hipLaunchKernelGGL(band_backward_tiles_kernel<1>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
-                case 2: hipLaunchKernelGGL(band_backward_tiles_kernel<2>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
-                case 3: hipLaunchKernelGGL(band_backward_tiles_kernel<3>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
-                case 4: hipLaunchKernelGGL(band_backward_tiles_kernel<4>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
-                default: hipLaunchKernelGGL(band_backward_tiles_kernel<5>, dim3(1), dim3(256), lds_b, c->stream, bw2); break;
+                case 1: hipLaunchKernelGGL(band_backward_tiles_kernel<1>, gb, dim3(256), lds_b, c->stream, bw2); break;
+                case 2: hipLaunchKernelGGL(band_backward_tiles_kernel<2>, gb, dim3(256), lds_b, c->stream, bw2); break;
+                case 3: hipLaunchKernelGGL(band_backward_tiles_kernel<3>, gb, dim3(256), lds_b, c->stream, bw2); break;
+                case 4: hipLaunchKernelGGL(band_backward_tiles_kernel<4>, gb, dim3(256), lds_b, c->stream, bw2); break;
+                default: hipLaunchKernelGGL(band_backward_tiles_kernel<5>, gb, dim3(256), lds_b, c->stream, bw2); break;
             }
         } else
 #define LAUNCH_BAND(SEG, NSLOT) hipLaunchKernelGGL((band_ldlt_solve_kernel<SEG, NSLOT>), dim3(1), dim3(256), lds, c->stream, a)

@@ -505,7 +505,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     if (hipSuccess != c->d_copy.upload(copies) || hipSuccess != c->d_red_boff.upload(red_boff)) return fail(c, NLLS_ERR_HIP, "schur upload");
     // ---- choose the reduced-system solver ----------------------------------------------------------------------
     const int64_t n = c->nred;
-    c->bw = (int)bw; c->solve_mode = SOLVE_DENSE;
+    c->bw = (int)bw; c->solve_mode = SOLVE_DENSE; c->band_twisted = !(flags & NLLS_FLAG_NO_TWIST);
     if (n < 64) c->solve_mode = SOLVE_SMALL;
     else if (!I0.is_sparse) c->solve_mode = SOLVE_DENSE;
     else if (c->n_band >= 128 && !(flags & NLLS_FLAG_NO_BAND)) {
@@ -529,7 +529,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         const size_t sz = (size_t)c->band_H * c->n_band + (size_t)(c->nbd + 1) * (c->nbd + 1);
         c->s_elems = sz;
         // the blocked factor kernel exports tiles: (NBW + 1) 16x16 tiles + the border/rhs rows per 16-column block
-        const size_t nbw = ((size_t)bw + 15) / 16, tsz = (((size_t)c->n_band + 15) / 16) * ((nbw + 1) * 256 + (size_t)(c->nbd + 1) * 16) + 128 + (size_t)(c->nbd + 1) * (c->nbd + 1);
+        const size_t nbw = ((size_t)bw + 15) / 16, tsz = (((size_t)c->n_band + 15) / 16) * ((nbw + 1) * 256 + (size_t)(c->nbd + 1) * 16) + 256 + 2 * (size_t)(c->nbd + 1) * (c->nbd + 1) + 2 * (256 * nbw * nbw + 16 * nbw);
         if (hipSuccess != c->S.alloc(sz + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(std::max(sz, tsz)) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "band system alloc");
     } else {
         const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row

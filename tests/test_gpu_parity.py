@@ -156,6 +156,8 @@ def test_ba_band_solver():           # narrow-band reduced system -> persistent-
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(120, 4000, 0.06, seed=8), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)
     assert info.solve_mode == 2 and info.nreduced_dof == 720 and 0 < info.bandwidth < 128
+    info = check_problem(p, flags=_capi.FLAG_NO_TWIST, expect_schur=1)     # one-sided factorisation (the default meets in the middle)
+    assert info.solve_mode == 2
     info = check_problem(p, flags=_capi.FLAG_NO_BAND, expect_schur=1)      # same system through the dense MFMA path
     assert info.solve_mode == 1
 
