@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
 // rev / nJs / sep_out: twisted (two-sided) factorisation -- one workgroup takes the band from the top, a second one from
 // the bottom (rev = 1: it sees the matrix with rows and columns reversed, still a band), each stops after nJs blocks,
 // and what they have accumulated on the separator in between goes to sep_out (band_sep_solve_kernel).
-struct BlkArgs { const double* Sb; double* Lb; double* corner_out; double* sep_out; int n_band, bw, nbd, H, NBW, rev, nJs; int* status; };
+struct BlkArgs { const double* Sb; double* Lb; double* corner_out; double* sep_out; int n_band, bw, nbd, H, NBW, rev, nJs, timing; int* status; };
 struct BlkArgs2 { BlkArgs c[2]; };
 
 NLLS_DEV double readlane_d(double x, int k) {
@@ -1020,7 +1020,13 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
     for (int i = tid; i < S.TW * S.TR * TS + TS; i += BLK_T) S.tiles[i] = 0.0;
     __syncthreads();
     for (int e = tid; e < nbr * nbr; e += BLK_T) { const int i = e % nbr, j = e / nbr; if (i >= j) { const double v = a.Sb[(size_t)n_band * H + e]; S.corner[i * P + j] = v; S.corner[j * P + i] = v; } }
-    for (int K = 0; K <= NBW && K < nJ; ++K) blk_land(S, a.Sb, K, tid, BLK_T);
+    {   // the first NBW + 1 tile columns: all HBM loads in flight together, then the LDS stores
+        double pv[6][BLK_LANDW];
+#pragma unroll
+        for (int K = 0; K < 6; ++K) if (K <= NBW && K < nJ) blk_land_load(S, a.Sb, K, tid, BLK_T, pv[K]);
+#pragma unroll
+        for (int K = 0; K < 6; ++K) if (K <= NBW && K < nJ) blk_land_store(S, K, tid, BLK_T, pv[K]);
+    }
     // urgent tile-updates (block column J+1): NBW+1 of them over the four waves; deferred ones (the rest): over waves 1-3
     const int nup = NBW * (NBW + 1) / 2 + NBW + 1, nurgent = NBW + 1;
     constexpr int NW = BLK_T / 64;
@@ -1058,45 +1064,24 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
         for (int idx = tid; idx < SW; idx += BLK_T) a.sep_out[(size_t)SW * SW + idx] = blk_tile(S, nJs + (idx >> 4), NBW + 1)[nbd * P + (idx & 15)];
     }
     for (int e = tid; e < nbr * nbr; e += BLK_T) { const int i = e % nbr, j = e / nbr; a.corner_out[e] = S.corner[i * P + j]; }
-    if (tid == 0 && blockIdx.x == 0) a.status[2] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+    if (tid == 0 && blockIdx.x == 0 && a.timing) a.status[2] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 
 // Separator of the twisted factorisation: the columns [cA, cA + ws) between the two sides.  Its matrix is what the top
 // side left (sepA), plus what the bottom side left (sepB, in reversed indices), minus the original entries, which both
-// sides had loaded; same for the rhs row.  Small and dense (ws <= 16 NBW <= 80): LDL' and both substitutions in LDS.
-__global__ __launch_bounds__(256) void band_sep_solve_kernel(const double* __restrict__ Sb, const double* __restrict__ sepA, const double* __restrict__ sepB,
-                                                             int cA, int ws, int SW, int bw, int nbd, int H, double* __restrict__ xr, int* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int tid = threadIdx.x, LD = ws + 1;
-    double* M = sm;                 // [ws][LD] lower triangle, row-major
-    double* z = M + (size_t)ws * LD;
-    for (int idx = tid; idx < ws * ws; idx += 256) {
-        const int i = idx / ws, j = idx % ws;
-        if (i >= j) M[i * LD + j] = sepA[(size_t)i * SW + j] + sepB[(size_t)(ws - 1 - j) * SW + (ws - 1 - i)] - ((i - j <= bw) ? Sb[(size_t)(cA + j) * H + (i - j)] : 0.0);
+// sides had loaded; same for the rhs row.  It is written out as a (dense) band system of its own, Hs = ws + 1 entries per
+// column, and goes through the same blocked factor / backward kernels (five blocks).
+__global__ __launch_bounds__(256) void band_sep_combine_kernel(const double* __restrict__ Sb, const double* __restrict__ sepA, const double* __restrict__ sepB,
+                                                               int cA, int ws, int SW, int bw, int nbd, int H, double* __restrict__ Ssep) {
+    const int Hs = ws + 1;                                    // entries 0..ws-1: the column from its diagonal down; entry ws: the rhs row
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < ws * Hs; idx += gridDim.x * 256) {
+        const int j = idx / Hs, e = idx % Hs, i = j + e;
+        double v = 0.0;
+        if (e == ws) v = sepA[(size_t)SW * SW + j] + sepB[(size_t)SW * SW + (ws - 1 - j)] - Sb[(size_t)(cA + j) * H + bw + 1 + nbd];
+        else if (i < ws) v = sepA[(size_t)i * SW + j] + sepB[(size_t)(ws - 1 - j) * SW + (ws - 1 - i)] - ((e <= bw) ? Sb[(size_t)(cA + j) * H + e] : 0.0);
+        Ssep[idx] = v;
     }
-    for (int i = tid; i < ws; i += 256) z[i] = sepA[(size_t)SW * SW + i] + sepB[(size_t)SW * SW + (ws - 1 - i)] - Sb[(size_t)(cA + i) * H + bw + 1 + nbd];
-    __syncthreads();
-    for (int k = 0; k < ws; ++k) {                            // right-looking LDL': column k scaled, then the trailing update
-        const double d = M[k * LD + k];
-        if (tid == 0 && (d == 0.0 || d != d)) atomicCAS(status, 0, 1 + cA + k);
-        const double rd = 1.0 / d;
-        const int m = ws - 1 - k;                             // rows below
-        for (int idx = tid; idx < m * (m + 1) / 2; idx += 256) {
-            int ii = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5); while (ii * (ii + 1) / 2 > idx) --ii; while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
-            const int jj = idx - ii * (ii + 1) / 2, i = k + 1 + ii, j = k + 1 + jj;
-            M[i * LD + j] -= M[i * LD + k] * M[j * LD + k] * rd;
-        }
-        __syncthreads();
-        for (int i = k + 1 + tid; i < ws; i += 256) M[i * LD + k] *= rd;   // L(i, k)
-        __syncthreads();
-    }
-    if (tid < 64) {                                            // one wavefront: forward, diagonal, backward
-        for (int k = 0; k < ws; ++k) { const double zk = z[k]; for (int i = k + 1 + tid; i < ws; i += 64) z[i] -= M[i * LD + k] * zk; __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
-        for (int i = tid; i < ws; i += 64) z[i] /= M[i * LD + i];
-        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-        for (int k = ws - 1; k >= 0; --k) { const double xk = z[k]; for (int i = tid; i < k; i += 64) z[i] -= M[k * LD + i] * xk; __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
-        for (int i = tid; i < ws; i += 64) xr[cA + i] = z[i];
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) Ssep[(size_t)ws * Hs] = 0.0;   // the 1 x 1 "corner" (rhs x rhs), unused
 }
 
 // Border corner + backward pass of the blocked band solver (factor in tile layout from band_blocked_factor_kernel).
@@ -1110,7 +1095,7 @@ __global__ __launch_bounds__(256) void band_sep_solve_kernel(const double* __res
 // wave 1 + B % 3); a wave retires a block with a counted s_waitcnt just before the barrier that hands it to wave 0.
 // rev / nJs / xnext: the two sides of the twisted factorisation (a side's unknowns behind its last block are the separator's,
 // xnext = their index in xr seen from this side; -1: nothing behind the last block)
-struct BwdArgs { double* Lt; const double* corner_in; double* xr; int n_band, nbd, NBW, rev, nJs, xnext, nxnext; int* status; };
+struct BwdArgs { double* Lt; const double* corner_in; double* xr; int n_band, nbd, NBW, rev, nJs, xnext, nxnext, timing; int* status; };
 struct BwdArgs2 { BwdArgs c[2]; };
 constexpr int BWD_AHEAD = 9, BWD_RING = BWD_AHEAD + 1;         // ring slots = blocks in LDS
 NLLS_HD int bwd_slot(int NBW) { return (NBW + 1) * 256 + 128; } // doubles copied per block: the tiles, then z (+ whatever follows)
@@ -1208,7 +1193,7 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args)
             if (J >= 1 && 1 + (J - 1) % 3 == wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");   // block J-1 has landed
         }
     }
-    if (tid == 0 && blockIdx.x == 0) a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+    if (tid == 0 && blockIdx.x == 0 && a.timing) a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1356,16 +1341,32 @@ int enqueue_solve_finish(nlls_ctx* c) {
             BlkArgs2 bkl{};
             for (int sd = 0; sd < (twisted ? 2 : 1); ++sd) {
                 BlkArgs& q = bkl.c[sd]; q.Sb = c->S.p; q.Lb = c->Lwork.p + (size_t)(sd ? JA : 0) * fsz; q.corner_out = corner + sd * nbr * nbr;
-                q.sep_out = twisted ? (sd ? sepB : sepA) : nullptr; q.n_band = L.n_band; q.bw = L.bw; q.nbd = L.nbd; q.H = L.H; q.NBW = NBW; q.rev = sd; q.nJs = sd ? JB : JA; q.status = c->d_status.p;
+                q.sep_out = twisted ? (sd ? sepB : sepA) : nullptr; q.n_band = L.n_band; q.bw = L.bw; q.nbd = L.nbd; q.H = L.H; q.NBW = NBW; q.rev = sd; q.nJs = sd ? JB : JA; q.timing = 1; q.status = c->d_status.p;
             }
             hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(twisted ? 2 : 1), dim3(BLK_T), blk_lds, c->stream, bkl);
-            if (twisted)
-                hipLaunchKernelGGL(band_sep_solve_kernel, dim3(1), dim3(256), sizeof(double) * ((size_t)ws * (ws + 1) + ws + 8), c->stream, (const double*)c->S.p, (const double*)sepA, (const double*)sepB,
-                                   cA, ws, 16 * NBW, L.bw, L.nbd, L.H, c->s_ptr(), c->d_status.p);
+            if (twisted) {
+                // the separator: a dense ws x ws system in band layout (bandwidth ws - 1), same kernels, one workgroup
+                double* Ssep = sepB + (size_t)(16 * NBW) * (16 * NBW) + 16 * NBW; double* Lsep = Ssep + (size_t)ws * (ws + 1) + 8;
+                const int nJs2 = (ws + 15) / 16, NBWs = (ws - 1 + 15) / 16;
+                hipLaunchKernelGGL(band_sep_combine_kernel, dim3(8), dim3(256), 0, c->stream, (const double*)c->S.p, (const double*)sepA, (const double*)sepB, cA, ws, 16 * NBW, L.bw, L.nbd, L.H, Ssep);
+                BlkArgs2 bs{}; BlkArgs& q = bs.c[0]; q.Sb = Ssep; q.Lb = Lsep; q.corner_out = Lsep + (size_t)nJs2 * blk_fsize(NBWs, 0) + 128; q.sep_out = nullptr;
+                q.n_band = ws; q.bw = ws - 1; q.nbd = 0; q.H = ws + 1; q.NBW = NBWs; q.rev = 0; q.nJs = nJs2; q.status = c->d_status.p;
+                const size_t lds_s = sizeof(double) * ((size_t)(NBWs + 2) * (NBWs + 2) * 272 + 272 + 2 * (size_t)(NBWs + 2) * 16 * 17 + 64 + 32 * 17 + 8);
+                hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(BLK_T), lds_s, c->stream, bs);
+                BwdArgs2 b2{}; BwdArgs& r = b2.c[0]; r.Lt = Lsep; r.corner_in = q.corner_out; r.xr = c->s_ptr() + cA; r.n_band = ws; r.nbd = 0; r.NBW = NBWs; r.rev = 0; r.nJs = nJs2; r.xnext = -1; r.nxnext = 0; r.status = c->d_status.p;
+                const size_t lds_sb = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBWs) + 16);
+                switch (NBWs) {
+                    case 1: hipLaunchKernelGGL(band_backward_tiles_kernel<1>, dim3(1), dim3(256), lds_sb, c->stream, b2); break;
+                    case 2: hipLaunchKernelGGL(band_backward_tiles_kernel<2>, dim3(1), dim3(256), lds_sb, c->stream, b2); break;
+                    case 3: hipLaunchKernelGGL(band_backward_tiles_kernel<3>, dim3(1), dim3(256), lds_sb, c->stream, b2); break;
+                    case 4: hipLaunchKernelGGL(band_backward_tiles_kernel<4>, dim3(1), dim3(256), lds_sb, c->stream, b2); break;
+                    default: hipLaunchKernelGGL(band_backward_tiles_kernel<5>, dim3(1), dim3(256), lds_sb, c->stream, b2); break;
+                }
+            }
             BwdArgs2 bw2{};
             for (int sd = 0; sd < (twisted ? 2 : 1); ++sd) {
                 BwdArgs& q = bw2.c[sd]; q.Lt = c->Lwork.p + (size_t)(sd ? JA : 0) * fsz; q.corner_in = corner; q.xr = c->s_ptr(); q.n_band = L.n_band; q.nbd = L.nbd; q.NBW = NBW;
-                q.rev = sd; q.nJs = sd ? JB : JA; q.xnext = twisted ? (sd ? cA + ws - 1 : cA) : -1; q.nxnext = ws; q.status = c->d_status.p;
+                q.rev = sd; q.nJs = sd ? JB : JA; q.xnext = twisted ? (sd ? cA + ws - 1 : cA) : -1; q.nxnext = ws; q.timing = 1; q.status = c->d_status.p;
             }
             const size_t lds_b = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBW) + (size_t)nbr * nbr + nbr + 8);
             const dim3 gb(twisted ? 2 : 1);

@@ -529,7 +529,8 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         const size_t sz = (size_t)c->band_H * c->n_band + (size_t)(c->nbd + 1) * (c->nbd + 1);
         c->s_elems = sz;
         // the blocked factor kernel exports tiles: (NBW + 1) 16x16 tiles + the border/rhs rows per 16-column block
-        const size_t nbw = ((size_t)bw + 15) / 16, tsz = (((size_t)c->n_band + 15) / 16) * ((nbw + 1) * 256 + (size_t)(c->nbd + 1) * 16) + 256 + 2 * (size_t)(c->nbd + 1) * (c->nbd + 1) + 2 * (256 * nbw * nbw + 16 * nbw);
+        const size_t nbw = ((size_t)bw + 15) / 16, tsz = (((size_t)c->n_band + 15) / 16) * ((nbw + 1) * 256 + (size_t)(c->nbd + 1) * 16) + 256 + 2 * (size_t)(c->nbd + 1) * (c->nbd + 1) + 2 * (256 * nbw * nbw + 16 * nbw)
+                                                    + (16 * nbw) * (16 * nbw + 1) + 8 + (nbw + 1) * ((nbw + 1) * 256 + 16) + 256;   // separator: band system + its factor tiles
         if (hipSuccess != c->S.alloc(sz + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(std::max(sz, tsz)) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "band system alloc");
     } else {
         const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
