@@ -983,26 +983,38 @@ __device__ __forceinline__ void blk_update(const BlkLds& S, int J, const BlkUpd<
         for (int r = 0; r < 4; ++r) Ct[q][(lk + 4 * r) * P + li] = acc[q][r] + acc2[q][r];
     }
 }
-// factor block column J -> HBM, tile layout (consumed by band_backward_tiles_kernel).  Per block, blk_fsize() doubles,
-// every tile row-major and UNPADDED (the backward pass copies a block into LDS linearly):
-//   [0, 256)                inv(L_JJ)' transposed: [n][j]
-//   [256 K, 256 (K+1))      L tile K = 1..NBW  [i'][c]: L(16 (J+K) + i', 16 J + c) = W / D
-//   then 16                 the rhs row  z = (L^-1 b) / D
-//   then nbd x 16           border rows of L
-NLLS_HD int blk_fsize(int NBW, int nbd) { return (NBW + 1) * 256 + (nbd + 1) * 16; }
-__device__ __forceinline__ void blk_export(const BlkLds& S, const double* __restrict__ Lisrc, double* __restrict__ Lt, int nbd, int J, int t0, int nt) {
+// factor block column J -> HBM (consumed by band_backward_tiles_kernel).  The backward pass needs
+//   x_J = inv(L_JJ)' ( z_J - Lbd_J' xb - sum_K L_{J+K,J}' x_{J+K} ),
+// so the tiles are exported PRE-MULTIPLIED by inv(L_JJ):  M_K = L_{J+K,J} inv(L_JJ)  (then x_J = zh_J - sum_K M_K' x_{J+K},
+// one matrix-vector stage per block instead of two dependent ones).  The products run on the matrix cores of the helper
+// waves, off wave 0's critical path.  Per block, blk_fsize() doubles, tiles row-major and unpadded:
+//   [256 (K-1), 256 K)      M_K, K = 1..NBW   [i'][c]
+//   then 16                 zh = inv(L_JJ)' z,  z = (L^-1 b) / D the rhs row
+//   then nbd x 16           border rows, Mbd = Lbd inv(L_JJ)
+NLLS_HD int blk_fsize(int NBW, int nbd) { return NBW * 256 + (nbd + 1) * 16; }
+// one wavefront: tile ti (1..NBW, or NBW+1 = the border / rhs tile) of block J
+__device__ __forceinline__ void blk_export_tile(const BlkLds& S, double* __restrict__ Lt, int nbd, int J, int ti) {
     constexpr int P = BLK_P;
-    const double* Wsrc = blk_panel(S, J); const double* rd = blk_d(S, J) + 16;
-    const int fs = blk_fsize(S.NBW, nbd), nt256 = (S.NBW + 1) * 256;
-    double* dst = Lt + (size_t)J * fs;
-    for (int idx = t0; idx < fs; idx += nt) {
-        double v;
-        if (idx < 256) v = Lisrc[(idx & 15) * P + (idx >> 4)];
-        else if (idx < nt256) { const int K = idx >> 8, i = (idx >> 4) & 15, c2 = idx & 15; v = Wsrc[(16 * K + i) * P + c2] * rd[c2]; }
-        else { const int q0 = (idx - nt256) >> 4, q = q0 == 0 ? nbd : q0 - 1, c2 = idx & 15; v = Wsrc[((S.NBW + 1) * 16 + q) * P + c2] * rd[c2]; }
-        dst[idx] = v;
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const double* Wt = blk_panel(S, J) + (size_t)ti * 16 * P; const double* rd = blk_d(S, J) + 16; const double* Lij = blk_li(S, J);
+    double4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    double av[4], bv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { av[m] = Wt[li * P + 4 * m + lk] * rd[4 * m + lk]; bv[m] = Lij[li * P + 4 * m + lk]; }   // A[i][n] = L[i][n]; B[n][c] = inv(L)'[c][n]
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+    double* dst = Lt + (size_t)J * blk_fsize(S.NBW, nbd);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = lk + 4 * r; const double v = acc[r] + acc2[r];
+        if (ti <= S.NBW) dst[(ti - 1) * 256 + i * 16 + li] = v;
+        else if (i == nbd) dst[S.NBW * 256 + li] = v;                      // rhs row -> zh
+        else if (i < nbd) dst[S.NBW * 256 + 16 + i * 16 + li] = v;         // border rows
     }
 }
+NLLS_DEV int blk_export_wave(int wave) { return wave < 4 ? wave : wave - 1; }   // waves 1,2,3,5,6,7 -> tiles 1..6 (wave 4 shares wave 0's SIMD)
 
 __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 args) {
     const BlkArgs a = args.c[blockIdx.x];
@@ -1041,7 +1053,7 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
             // J+NBW+1 into the ring slot of column J-1 (HBM latency), block J-1's factor out
             double lv[BLK_LANDW]; const bool landing = J + NBW + 1 < nJ;
             if (landing) blk_land_load(S, a.Sb, J + NBW + 1, tid - 64, BLK_HELP, lv);
-            if (J > 0) { blk_update<3>(S, J - 1, Ud); blk_export(S, blk_li(S, J - 1), a.Lb, nbd, J - 1, tid - 64, BLK_HELP); }
+            if (J > 0) { blk_update<3>(S, J - 1, Ud); if (wave != 4 && blk_export_wave(wave) <= NBW + 1) blk_export_tile(S, a.Lb, nbd, J - 1, blk_export_wave(wave)); }
             if (landing) blk_land_store(S, J + NBW + 1, tid - 64, BLK_HELP, lv);
         }
         __syncthreads();                                      // (B) diagonal tile factored, deferred updates of J-1 done
@@ -1051,7 +1063,7 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
     }
     __syncthreads();
     if (wave > 0) blk_update<3>(S, nJs - 1, Ud);              // the last block's deferred updates (border corner, separator)
-    blk_export(S, blk_li(S, nJs - 1), a.Lb, nbd, nJs - 1, tid, BLK_T);
+    if (wave > 0 && wave != 4 && blk_export_wave(wave) <= NBW + 1) blk_export_tile(S, a.Lb, nbd, nJs - 1, blk_export_wave(wave));
     __syncthreads();
     if (a.sep_out) {
         // the NBW tile columns behind the last factored block, with everything this side has subtracted from them:
@@ -1084,31 +1096,31 @@ __global__ __launch_bounds__(256) void band_sep_combine_kernel(const double* __r
     if (blockIdx.x == 0 && threadIdx.x == 0) Ssep[(size_t)ws * Hs] = 0.0;   // the 1 x 1 "corner" (rhs x rhs), unused
 }
 
-// Border corner + backward pass of the blocked band solver (factor in tile layout from band_blocked_factor_kernel).
-//   x_J = inv(L_JJ)' * ( z_J - Lbd_J' xb - sum_{K=1..NBW} L_{J+K,J}' x_{J+K} ),   J = nJ-1 .. 0
-// Every product is a 16x16 tile times a 16-vector and runs on the fp64 matrix cores with the vector replicated over
-// the N dimension: x of a block leaves the MFMA in accumulator layout (register m of lane (li, lk) = x[4m + lk]),
-// which is exactly the B-operand layout (B[kk = lk][.] = x[4m + kk]) of the products that consume it, so the
-// unknowns never leave wave 0's registers.  Only the products with the newest block and the inv(L)' product are on
-// the serial chain (two dependent MFMA rounds each); the other tiles' products are issued before x_{J+1} exists.
+// Border corner + backward pass of the blocked band solver (pre-multiplied tiles from band_blocked_factor_kernel):
+//   x_J = zh_J - Mbd_J' xb - sum_{K=1..NBW} M_K' x_{J+K},   J = nJs-1 .. 0
+// Wave 0, lane (c, g) = (lane % 16, lane / 16): it forms the part of entry c that comes from rows g, g+4, g+8, g+12 of
+// every tile (4 NBW multiply-adds) and parks it in LDS; the four parts of an entry are summed by whoever needs the
+// entry next -- lane (c, g) of the next block needs x[g + 4 q], q = 0..3, i.e. 16 parts -- so one LDS round trip per
+// block is the whole serial chain, and the far tiles' products (their x is older) are computed while it is in flight.
 // Waves 1-3 copy the factor HBM -> LDS with global_load_lds_dwordx4 (no registers, BWD_AHEAD blocks ahead, block B by
 // wave 1 + B % 3); a wave retires a block with a counted s_waitcnt just before the barrier that hands it to wave 0.
-// rev / nJs / xnext: the two sides of the twisted factorisation (a side's unknowns behind its last block are the separator's,
-// xnext = their index in xr seen from this side; -1: nothing behind the last block)
+// rev / nJs / xnext: the two sides of the twisted factorisation (a side's unknowns behind its last block are the
+// separator's, xnext = their index in xr seen from this side; -1: nothing behind the last block).
 struct BwdArgs { double* Lt; const double* corner_in; double* xr; int n_band, nbd, NBW, rev, nJs, xnext, nxnext, timing; int* status; };
 struct BwdArgs2 { BwdArgs c[2]; };
 constexpr int BWD_AHEAD = 9, BWD_RING = BWD_AHEAD + 1;         // ring slots = blocks in LDS
-NLLS_HD int bwd_slot(int NBW) { return (NBW + 1) * 256 + 128; } // doubles copied per block: the tiles, then z (+ whatever follows)
+NLLS_HD int bwd_slot(int NBW) { return NBW * 256 + 128; }      // doubles copied per block: the tiles, then zh (+ whatever follows)
 template <int NBW>
 __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args) {
     const BwdArgs a = args.c[blockIdx.x];
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    constexpr int SLOT = (NBW + 1) * 256 + 128, NI = SLOT / 128; // NI wave-wide 16-byte copies per block
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    constexpr int SLOT = NBW * 256 + 128, NI = SLOT / 128;     // NI wave-wide 16-byte copies per block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const int n_band = a.n_band, nbd = a.nbd, nbr = nbd + 1;
     const int nJ = a.nJs, fs = blk_fsize(NBW, nbd);           // blocks of this side
     double* ring = sm;                            // [BWD_RING + 1][SLOT]; the extra slot takes the copies of blocks that do not exist
-    double* Cl = ring + (size_t)(BWD_RING + 1) * SLOT;   // nbr x nbr border corner (col-major, lower), last row = rhs
+    double* red = ring + (size_t)(BWD_RING + 1) * SLOT;   // [2][16][4]: the four parts of the 16 entries of a block, by block parity
+    double* Cl = red + 128;                       // nbr x nbr border corner (col-major, lower), last row = rhs
     double* xb = Cl + nbr * nbr;                  // nbr
     for (int e = tid; e < nbr * nbr; e += 256) Cl[e] = a.corner_in[e];
     __syncthreads();
@@ -1124,9 +1136,9 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args)
         for (int r = nbd - 1; r >= 0; --r) { double v = Cl[nbd + nbr * r]; for (int r2 = r + 1; r2 < nbd; ++r2) v -= Cl[r2 + nbr * r] * xb[r2]; xb[r] = v; a.xr[n_band + r] = v; }
     }
     __syncthreads();
-    if (nbd > 0) {                                // fold the border unknowns into z, in place:  z_J -= Lbd_J' xb
+    if (nbd > 0) {                                // fold the border unknowns into zh, in place:  zh_J -= Mbd_J' xb
         for (int idx = tid; idx < nJ * 16; idx += 256) {
-            double* p = a.Lt + (size_t)(idx >> 4) * fs + (NBW + 1) * 256; const int c2 = idx & 15;
+            double* p = a.Lt + (size_t)(idx >> 4) * fs + NBW * 256; const int c2 = idx & 15;
             double v = p[c2]; for (int q = 0; q < nbd; ++q) v -= p[16 + q * 16 + c2] * xb[q]; p[c2] = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1144,55 +1156,67 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args)
         for (int B = nJ - 1; B > nJ - 1 - BWD_AHEAD; --B) if (1 + ((B % 3) + 3) % 3 == wave) issue(B);
         if (1 + (nJ - 1) % 3 == wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");   // block nJ-1 has landed
     }
-    double4_t xk[5];                              // x of blocks J+1 .. J+5, accumulator layout
+    // at the top of iteration J: xq[K][q] = x_{J+2+K}[g + 4 q].  Behind the last block: the separator's unknowns (twisted
+    // factorisation), else nothing; xfirst = the block right behind the end (what the first iteration gets for x_{J+1})
+    auto behind = [&](int i) { return (a.xnext >= 0 && i < a.nxnext) ? a.xr[a.rev ? a.xnext - i : a.xnext + i] : 0.0; };
+    double xq[NBW][4], xfirst[4];
 #pragma unroll
-    for (int K = 0; K < 5; ++K) {
+    for (int q = 0; q < 4; ++q) xfirst[q] = behind(g + 4 * q);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {             // behind the last block: the separator's unknowns (twisted factorisation), else nothing
-            const int i = 16 * K + 4 * m + lk;
-            xk[K][m] = (a.xnext >= 0 && i < a.nxnext) ? a.xr[a.rev ? a.xnext - i : a.xnext + i] : 0.0;
+    for (int K = 0; K < NBW; ++K)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xq[K][q] = behind(16 * (K + 1) + g + 4 * q);
+    double zq[4] = {0, 0, 0, 0};                  // zh of the block whose parts are in flight, entries g + 4 q
+    auto finish = [&](int Jp, double (&xnew)[4]) {           // x of block Jp from its four parts in LDS
+        const double* rp = red + (Jp & 1) * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double4_t p4 = *reinterpret_cast<const double4_t*>(rp + 4 * (g + 4 * q));
+            xnew[q] = zq[q] - ((p4[0] + p4[1]) + (p4[2] + p4[3]));
         }
-    }
+        if (c == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int row = 16 * Jp + g + 4 * q; if (row < n_band) a.xr[a.rev ? n_band - 1 - row : row] = xnew[q]; }
+        }
+    };
     for (int J = nJ - 1; J >= 0; --J) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block J is in LDS; the slot of block J+1 is free
         if (wave == 0) {
             const double* B0 = ring + (size_t)(J % BWD_RING) * SLOT;
-            // v_mfma_f64_16x16x4_f64 occupies the pipe for 64 cycles and hands its accumulator on after as many: four
-            // accumulators (one per k-slice m) taken round-robin never wait for each other, and leave three vector
-            // adds per register at the end.  Far tiles first (their x is old), the newest block's tile last.
-            double4_t acc[4];
+            // far tiles (K >= 2): their x is complete -- this hides the LDS round trip of block J+1's parts
+            double far = 0.0;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = double4_t{0, 0, 0, 0};
+            for (int K = NBW; K >= 2; --K)
 #pragma unroll
-            for (int K = NBW; K >= 1; --K) {
-                const double* T = B0 + K * 256;
+                for (int q = 0; q < 4; ++q) far = fma(B0[(K - 1) * 256 + (g + 4 * q) * 16 + c], xq[K - 2][q], far);
+            double zn[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m)                                           // A[c = li][kk = lk] = L_K[4m + lk][c]
-                    acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(4 * m + lk) * 16 + li], xk[K - 1][m], acc[m], 0, 0, 0);
-            }
-            double4_t t;
+            for (int q = 0; q < 4; ++q) zn[q] = B0[NBW * 256 + g + 4 * q];
+            double xnew[4];
+            if (J < nJ - 1) finish(J + 1, xnew);
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = B0[(NBW + 1) * 256 + lk + 4 * r] - ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]));
-            double4_t xp[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)                                               // A[j = li][kk = lk] = inv(L)'[j][4m + lk]
-                xp[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(B0[(4 * m + lk) * 16 + li], t[m], double4_t{0, 0, 0, 0}, 0, 0, 0);
-            double4_t xn;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xn[r] = (xp[0][r] + xp[1][r]) + (xp[2][r] + xp[3][r]);
-            if (li == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const int row = 16 * J + lk + 4 * r; if (row < n_band) a.xr[a.rev ? n_band - 1 - row : row] = xn[r]; }
+                for (int q = 0; q < 4; ++q) xnew[q] = xfirst[q];   // nothing in flight yet: block J+1 is behind the end
             }
 #pragma unroll
-            for (int K = 4; K >= 1; --K) xk[K] = xk[K - 1];
-            xk[0] = xn;
+            for (int K = NBW - 1; K >= 1; --K)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xq[K][q] = xq[K - 1][q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xq[0][q] = xnew[q];
+            double part = far;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part = fma(B0[(g + 4 * q) * 16 + c], xq[0][q], part);
+            red[(J & 1) * 64 + 4 * c + g] = part;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zq[q] = zn[q];
         } else {
             const int B = J - BWD_AHEAD;          // goes into the slot block J+1 has just left
             if (1 + ((B % 3) + 3) % 3 == wave) issue(B);
             if (J >= 1 && 1 + (J - 1) % 3 == wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");   // block J-1 has landed
         }
     }
+    if (wave == 0 && nJ > 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); double x0[4]; finish(0, x0); }
     if (tid == 0 && blockIdx.x == 0 && a.timing) a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 
@@ -1354,7 +1378,7 @@ int enqueue_solve_finish(nlls_ctx* c) {
                 const size_t lds_s = sizeof(double) * ((size_t)(NBWs + 2) * (NBWs + 2) * 272 + 272 + 2 * (size_t)(NBWs + 2) * 16 * 17 + 64 + 32 * 17 + 8);
                 hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(BLK_T), lds_s, c->stream, bs);
                 BwdArgs2 b2{}; BwdArgs& r = b2.c[0]; r.Lt = Lsep; r.corner_in = q.corner_out; r.xr = c->s_ptr() + cA; r.n_band = ws; r.nbd = 0; r.NBW = NBWs; r.rev = 0; r.nJs = nJs2; r.xnext = -1; r.nxnext = 0; r.status = c->d_status.p;
-                const size_t lds_sb = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBWs) + 16);
+                const size_t lds_sb = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBWs) + 128 + 16);
                 switch (NBWs) {
                     case 1: hipLaunchKernelGGL(band_backward_tiles_kernel<1>, dim3(1), dim3(256), lds_sb, c->stream, b2); break;
                     case 2: hipLaunchKernelGGL(band_backward_tiles_kernel<2>, dim3(1), dim3(256), lds_sb, c->stream, b2); break;
@@ -1368,7 +1392,7 @@ int enqueue_solve_finish(nlls_ctx* c) {
                 BwdArgs& q = bw2.c[sd]; q.Lt = c->Lwork.p + (size_t)(sd ? JA : 0) * fsz; q.corner_in = corner; q.xr = c->s_ptr(); q.n_band = L.n_band; q.nbd = L.nbd; q.NBW = NBW;
                 q.rev = sd; q.nJs = sd ? JB : JA; q.xnext = twisted ? (sd ? cA + ws - 1 : cA) : -1; q.nxnext = ws; q.timing = 1; q.status = c->d_status.p;
             }
-            const size_t lds_b = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBW) + (size_t)nbr * nbr + nbr + 8);
+            const size_t lds_b = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBW) + 128 + (size_t)nbr * nbr + nbr + 8);
             const dim3 gb(twisted ? 2 : 1);
             switch (NBW) {
                 case 1: hipLaunchKernelGGL(band_backward_tiles_kernel<1>, gb, dim3(256), lds_b, c->stream, bw2); break;
