@@ -198,6 +198,7 @@ int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
 }
 int nlls_set_step(nlls_ctx* ctx, const double* x) {
     NEED_READY(); if (!x) return NLLS_ERR_INVALID_ARG;
+    ctx->tE_valid = false;                        // the step is no longer the one the back-substitution produced
     HIPCHK(hipMemcpyAsync(ctx->x.p, x, sizeof(double) * ctx->info.ndof, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;

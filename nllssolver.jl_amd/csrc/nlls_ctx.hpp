@@ -174,6 +174,10 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_elim_group;     // supernodes: runs of eliminated blocks with identical neighbour sets
     int64_t nelim_groups = 0, n_fast_groups = 0, n_slow_groups = 0;
     nlls::DevBuf<uint32_t> d_fast_groups, d_slow_groups, d_slow_blocks;   // d_slow_blocks: members of the slow supernodes
+    nlls::DevBuf<uint32_t> d_fast_members;   // members of the fast supernodes
+    nlls::DevBuf<uint8_t> d_blk_slowmask;    // d_blk entries NOT in rows of fast members (and owned by this rank)
+    nlls::DevBuf<double> tE;                 // E_v s of the last solve per fast member (s = reduced solution): reused by the quadratic form
+    bool tE_valid = false; int64_t n_fast_members = 0;
     nlls::DevBuf<double> Cinv;               // (C_v + lambda I)^-1 of the fast-path members, fast_dv^2 doubles per eliminated block
     int fast_dv = 0, fast_maxk = 0, fast_maxk_narrow = 0;
     int64_t n_fast_narrow = 0;               // fast supernodes with nd + 1 <= 64 come first in d_fast_groups

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
                                                                 const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
                                                                 const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
                                                                 const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
-                                                                const double* __restrict__ Cinv, const double* __restrict__ xr, double* __restrict__ x) {
+                                                                const double* __restrict__ Cinv, const double* __restrict__ xr, double* __restrict__ x, double* __restrict__ tE) {
     constexpr int MAXC = (72 + 15) / 16;                      // columns per lane (nd <= 72)
     __shared__ uint32_t rc[80];
     const int lane = threadIdx.x, l = lane & 15, gsub = lane >> 4;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
         if (live && l == 15) {
             double r[DV];
 #pragma unroll
-            for (int a2 = 0; a2 < DV; ++a2) r[a2] = b[eboff[v] + a2] - acc[a2];
+            for (int a2 = 0; a2 < DV; ++a2) { r[a2] = b[eboff[v] + a2] - acc[a2]; tE[(int64_t)v * DV + a2] = acc[a2]; }
 #pragma unroll
             for (int i = 0; i < DV; ++i) { double t = 0;
 #pragma unroll
@@ -1238,6 +1238,31 @@ __global__ __launch_bounds__(256) void quadform_blocks_kernel(const double* __re
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// rows of fast-path members, for the step x of the last solve: x' A x restricted to row v is
+//   2 x_v' (E_v x_R) + x_v' C_v x_v,   E_v x_R = -E_v s  -- and E_v s is what schur_backsub_fast_kernel left in tE
+template <int DV>
+__global__ __launch_bounds__(256) void quadform_points_kernel(const double* __restrict__ A, const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                              const uint32_t* __restrict__ members, int64_t nm, const double* __restrict__ tE,
+                                                              const double* __restrict__ x, double* __restrict__ partials) {
+    __shared__ double red[4];
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nm; i += (int64_t)gridDim.x * 256) {
+        const uint32_t v = members[i];
+        double xv[DV], t = 0;
+#pragma unroll
+        for (int a2 = 0; a2 < DV; ++a2) { xv[a2] = x[eboff[v] + a2]; t -= 2.0 * xv[a2] * tE[(int64_t)v * DV + a2]; }
+#pragma unroll
+        for (int j = 0; j < DV; ++j) { double c2 = 0;
+#pragma unroll
+            for (int i2 = 0; i2 < DV; ++i2) c2 += A[ediag[v] + i2 + DV * j] * xv[i2];
+            t += c2 * xv[j]; }
+        acc += t;
+    }
+    acc = wsum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
 __global__ __launch_bounds__(256) void quadform_dense_kernel(const double* __restrict__ A, int n, const double* __restrict__ v, double* __restrict__ partials) {
     __shared__ double red[4];
     double acc = 0;
@@ -1282,8 +1307,19 @@ static int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::str
 int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
     int np = 0;
     if (c->info.is_sparse) {
-        np = (int)std::min<int64_t>((c->nblk + 255) / 256, 1024); if (np < 1) np = 1;
-        hipLaunchKernelGGL(quadform_blocks_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, c->d_blk.p, c->nblk, d_vec, c->nranks > 1 ? c->d_blk_mask.p : (const uint8_t*)nullptr, c->partials.p);
+        // the step of the last solve: the rows of fast-path members come from E_v s, which the back-substitution kept
+        const bool reuse = d_vec == c->x.p && c->tE_valid && c->n_fast_members > 0;
+        np = (int)std::min<int64_t>((c->nblk + 255) / 256, 768); if (np < 1) np = 1;
+        hipLaunchKernelGGL(quadform_blocks_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, c->d_blk.p, c->nblk, d_vec,
+                           reuse ? c->d_blk_slowmask.p : (c->nranks > 1 ? c->d_blk_mask.p : (const uint8_t*)nullptr), c->partials.p);
+        if (reuse) {
+            const int np3 = (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256));
+#define LAUNCH_QP(DV) hipLaunchKernelGGL((quadform_points_kernel<DV>), dim3(np3), dim3(256), 0, c->stream, c->A.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_fast_members.p, \
+                c->n_fast_members, c->tE.p, d_vec, c->partials.p + np)
+            if (c->fast_dv == 3) LAUNCH_QP(3); else if (c->fast_dv == 2) LAUNCH_QP(2); else LAUNCH_QP(1);
+#undef LAUNCH_QP
+            np += np3;
+        }
     } else {
         np = (int)std::min<int64_t>((c->info.ndof + 255) / 256, 1024); if (np < 1) np = 1;
         hipLaunchKernelGGL(quadform_dense_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, (int)c->info.ndof, d_vec, c->partials.p);
@@ -1441,8 +1477,8 @@ int enqueue_solve_finish(nlls_ctx* c) {
                                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->n_fast_groups > 0 ? c->d_slow_blocks.p : (const uint32_t*)nullptr,
                                c->lambda, c->max_elim_dim, c->s_ptr(), c->x.p);
 #define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p, \
-                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p)
-        if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); }
+                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p)
+        if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; }
 #undef LAUNCH_BSF
     }
     HIPCHK(hipGetLastError());

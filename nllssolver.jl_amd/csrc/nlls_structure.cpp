@@ -416,6 +416,8 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         if (lo >= 0) bw = std::max(bw, hi - lo);
     }
     std::vector<int64_t> eptr; std::vector<SchurNbr> enbr; std::vector<int64_t> ediag; std::vector<uint32_t> eboff; std::vector<uint16_t> edim; std::vector<uint32_t> egroup;
+    std::vector<int64_t> erow;                 // block row of each (local) eliminated member
+    std::vector<uint8_t> row_fast(nb, 0);      // block rows whose members take the fast elimination path
     eptr.push_back(0);
     if (c->nelim) {
         std::vector<SchurNbr> prev; uint32_t glen = 0;
@@ -436,7 +438,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             if (!same) { egroup.push_back((uint32_t)ediag.size()); glen = 0; }
             ++glen; prev = nl;
             for (auto& n : nl) enbr.push_back(n);
-            eptr.push_back((int64_t)enbr.size()); ediag.push_back(c->diag_off[v]); eboff.push_back((uint32_t)c->boffsets[v]); edim.push_back((uint16_t)c->blocksizes[v]);
+            erow.push_back(v); eptr.push_back((int64_t)enbr.size()); ediag.push_back(c->diag_off[v]); eboff.push_back((uint32_t)c->boffsets[v]); edim.push_back((uint16_t)c->blocksizes[v]);
         }
         egroup.push_back((uint32_t)ediag.size());
         c->nelim_groups = (int64_t)egroup.size() - 1;
@@ -465,6 +467,9 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         fastg.insert(fastg.end(), fastw.begin(), fastw.end());
         c->n_fast_groups = (int64_t)fastg.size(); c->n_slow_groups = (int64_t)slowg.size(); c->fast_dv = fast_dv; c->fast_maxk = fast_maxk;
         std::vector<uint32_t> slowb; for (uint32_t gi : slowg) for (uint32_t v = egroup[gi]; v < egroup[gi + 1]; ++v) slowb.push_back(v);
+        std::vector<uint32_t> fastb; for (uint32_t gi : fastg) for (uint32_t v = egroup[gi]; v < egroup[gi + 1]; ++v) { fastb.push_back(v); row_fast[erow[v]] = 1; }
+        c->n_fast_members = (int64_t)fastb.size();
+        if (hipSuccess != c->d_fast_members.upload(fastb) || hipSuccess != c->tE.alloc(std::max<size_t>(1, ediag.size() * (size_t)std::max(1, fast_dv)))) return fail(c, NLLS_ERR_HIP, "fast member upload");
         if (hipSuccess != c->d_fast_groups.upload(fastg) || hipSuccess != c->d_slow_groups.upload(slowg) || hipSuccess != c->d_slow_blocks.upload(slowb) ||
             hipSuccess != c->Cinv.alloc(std::max<size_t>(1, ediag.size() * (size_t)std::max(1, fast_dv * fast_dv)))) return fail(c, NLLS_ERR_HIP, "group list upload");
         // LDS budget of the elimination kernel: C, E, Y, pair accumulators, column map
@@ -501,7 +506,11 @@ int build_schur(nlls_ctx* c, int32_t flags) {
               for (int i = 0; i < c->blocksizes[r]; ++i) dofmask[c->boffsets[r] + i] = own ? 1.0 : 0.0; }
           for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) blkmask.push_back(rowmask[row]);
       }
-      if (hipSuccess != c->d_row_mask.upload(rowmask) || hipSuccess != c->d_blk_mask.upload(blkmask) || hipSuccess != c->d_dof_mask.upload(dofmask)) return fail(c, NLLS_ERR_HIP, "mask upload"); }
+      // blocks that quadform_points_kernel covers (rows of fast-path members) are skipped by the block kernel when E x is at hand
+      std::vector<uint8_t> slowmask;
+      if (I0.is_sparse && c->n_fast_members > 0) for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) slowmask.push_back((uint8_t)(rowmask[row] && !row_fast[row]));
+      if (hipSuccess != c->d_row_mask.upload(rowmask) || hipSuccess != c->d_blk_mask.upload(blkmask) || hipSuccess != c->d_dof_mask.upload(dofmask) ||
+          hipSuccess != c->d_blk_slowmask.upload(slowmask)) return fail(c, NLLS_ERR_HIP, "mask upload"); }
     if (hipSuccess != c->d_copy.upload(copies) || hipSuccess != c->d_red_boff.upload(red_boff)) return fail(c, NLLS_ERR_HIP, "schur upload");
     // ---- choose the reduced-system solver ----------------------------------------------------------------------
     const int64_t n = c->nred;

@@ -15,7 +15,7 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__('datetime').timedelta(seconds=90))
     import nllssolver_jl_amd as N
     from nllssolver_jl_amd import synthetic, kinds as K
     from nllssolver_jl_amd.dist import partition_by_weight

@@ -13,7 +13,7 @@ def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__('datetime').timedelta(seconds=90))
     import nllssolver_jl_amd as N
     from nllssolver_jl_amd import synthetic, _capi, iterators as It, optimizer as Opt
     from nllssolver_jl_amd.dist import ShardedLS

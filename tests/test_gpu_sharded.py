@@ -3,6 +3,7 @@ RCCL itself refuses two ranks on one device) and must reproduce the unsharded re
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -16,11 +17,15 @@ def test_sharded_matches_unsharded(world):
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
+    deadline = time.monotonic() + 150          # all ranks share one deadline: a rank that died leaves the others in a collective
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=300)
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.monotonic()))
         except subprocess.TimeoutExpired:
-            p.kill(); out, _ = p.communicate()
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            out, _ = p.communicate()
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
