@@ -179,11 +179,18 @@ int nlls_damp(nlls_ctx* ctx, double delta) { NEED_GRAD(); ctx->lambda += delta; 
 int nlls_solve(nlls_ctx* ctx, double* x_out) {
     NEED_GRAD();
     TRY(enqueue_solve(ctx));
+    // what the iterators ask about the step next -- max |x|, |x|, x'Hx, g'x (src/optimize.jl:149, src/iterators.jl:160-163) --
+    // is computed behind the solve and comes back with the same synchronisation; the queries then answer from the host
+    ctx->step_cached = false;
+    const bool precompute = ctx->nranks == 1;
+    if (precompute) { TRY(enqueue_step_stats(ctx)); TRY(enqueue_quadform(ctx, ctx->x.p, 4)); }
     int32_t status[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    if (precompute) HIPCHK(hipMemcpyAsync(ctx->h_scalars + 1, ctx->scalars.p + 1, sizeof(double) * 9, hipMemcpyDeviceToHost, ctx->stream));
     if (x_out) HIPCHK(hipMemcpyAsync(x_out, ctx->x.p, sizeof(double) * ctx->info.ndof, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->solved = true;
+    if (precompute) { ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9]; }
     if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");
     return NLLS_OK;
 }
@@ -198,7 +205,7 @@ int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
 }
 int nlls_set_step(nlls_ctx* ctx, const double* x) {
     NEED_READY(); if (!x) return NLLS_ERR_INVALID_ARG;
-    ctx->tE_valid = false;                        // the step is no longer the one the back-substitution produced
+    ctx->tE_valid = false; ctx->step_cached = false;   // the step is no longer the one the last solve produced
     HIPCHK(hipMemcpyAsync(ctx->x.p, x, sizeof(double) * ctx->info.ndof, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
@@ -210,15 +217,19 @@ int nlls_get_step(nlls_ctx* ctx, double* x_out) {
     return NLLS_OK;
 }
 int nlls_step_maxabs(nlls_ctx* ctx, double* out) {
-    NEED_READY(); TRY(enqueue_step_stats(ctx)); TRY(fetch_scalars(ctx, 1, 2));
+    NEED_READY(); if (ctx->step_cached) { if (out) *out = ctx->c_maxabs; return NLLS_OK; }
+    TRY(enqueue_step_stats(ctx)); TRY(fetch_scalars(ctx, 1, 2));
     if (out) *out = ctx->h_scalars[1]; return NLLS_OK;
 }
 int nlls_step_norm(nlls_ctx* ctx, double* out) {
-    NEED_READY(); TRY(enqueue_step_stats(ctx)); TRY(fetch_scalars(ctx, 1, 2));
+    NEED_READY(); if (ctx->step_cached) { if (out) *out = std::sqrt(ctx->c_sumsq); return NLLS_OK; }
+    TRY(enqueue_step_stats(ctx)); TRY(fetch_scalars(ctx, 1, 2));
     if (out) *out = std::sqrt(ctx->h_scalars[2]); return NLLS_OK;
 }
 int nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out) {
-    NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->x.p, 4)); TRY(fetch_scalars(ctx, 4, 2));
+    NEED_GRAD();
+    if (ctx->step_cached) { if (xHx_out) *xHx_out = ctx->c_xAx + ctx->lambda * ctx->c_xx; if (gx_out) *gx_out = ctx->c_gx; return NLLS_OK; }   // damping may have changed since
+    TRY(enqueue_quadform(ctx, ctx->x.p, 4)); TRY(fetch_scalars(ctx, 4, 2));
     if (xHx_out) *xHx_out = ctx->h_scalars[4]; if (gx_out) *gx_out = ctx->h_scalars[5];
     return NLLS_OK;
 }

@@ -1295,6 +1295,7 @@ __global__ __launch_bounds__(256) void quadform_finish_kernel(const double* __re
     if (threadIdx.x == 0) {
         a = red[0][0] + red[0][1] + red[0][2] + red[0][3]; vv = red[1][0] + red[1][1] + red[1][2] + red[1][3]; bv = red[2][0] + red[2][1] + red[2][2] + red[2][3];
         out[slot] = a + lambda * vv; out[slot + 1] = bv;
+        if (slot == 4) { out[8] = a; out[9] = vv; }             // the step's raw parts: x'Ax and x'x (nlls_solve caches them)
     }
 }
 

@@ -564,7 +564,7 @@ int enqueue_sweep_cost(nlls_ctx* c, int which) {
 }
 
 int enqueue_sweep_gradhess(nlls_ctx* c) {
-    c->tE_valid = false;                          // A changes: what the last back-substitution kept of it is stale
+    c->tE_valid = false; c->step_cached = false;  // A and b change: what the last solve kept of them is stale
     const double* vars = vars_ptr(c, NLLS_VARS_CURRENT); int64_t pbase = 0;
     if (!c->info.is_sparse) {
         HIPCHK(hipMemsetAsync(c->A.p, 0, sizeof(double) * std::max<int64_t>(c->info.nnz_data, 1), c->stream));
