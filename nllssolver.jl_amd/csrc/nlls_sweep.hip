@@ -137,17 +137,21 @@ __global__ __launch_bounds__(TPB) void reduce_partials_kernel(const double* __re
 // vmcnt, i.e. stall on the global loads and stores that are deliberately left in flight across it
 NLLS_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// arguments of one entry list's accumulate pass (light or heavy tiles of it)
+struct GhArgs {
+    const double* vars; const double* edata; const uint32_t* evoff; const uint32_t* edest; const RowInfo* rows; const Tile* tiles;
+    RobustSpec rk; int unique_dest; uint32_t ntiles; double* A; double* b; double* partials;
+};
 template <int KIND, int SLOT>
-__global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
-                                                       const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ edest,
-                                                       const RowInfo* __restrict__ rows, const Tile* __restrict__ tiles, RobustSpec rk,
-                                                       int unique_dest, double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+__device__ __forceinline__ void gh_light_body(const GhArgs& g, uint32_t tile, double* img_raw) {
     using R = Res<KIND>; using I = ResInfo<KIND>;
     constexpr int DS = I::dof(SLOT);
     constexpr int NSYM = DS * (DS + 1) / 2, NACC = NSYM + DS;   // lower triangle of the diagonal block + b, per accumulator copy
-    extern __shared__ __attribute__((aligned(16))) double img_raw[];
     __shared__ double red[TPB / 64];
-    const Tile t = tiles[blockIdx.x];
+    const double* __restrict__ vars = g.vars; const double* __restrict__ edata = g.edata; const uint32_t* __restrict__ evoff = g.evoff;
+    const uint32_t* __restrict__ edest = g.edest; const RowInfo* __restrict__ rows = g.rows; const RobustSpec rk = g.rk; const int unique_dest = g.unique_dest;
+    double* __restrict__ A = g.A; double* __restrict__ b = g.b; double* __restrict__ partials = g.partials;
+    const Tile t = g.tiles[tile];
     // the image is shifted by one double when its A.data segment starts on an odd index, so that 16-byte aligned
     // LDS reads pair up with 16-byte aligned HBM stores at the flush
     const uint32_t odd = (uint32_t)(t.data_off & 1);
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict_
     if (threadIdx.x == 0) { double tc = 0;
 #pragma unroll
         for (int k = 0; k < TPB / 64; ++k) tc += red[k];
-        partials[blockIdx.x] = tc; }
+        partials[tile] = tc; }
     // fold the accumulator copies into the image: full diagonal block (both triangles, linearsystem.jl:140) and b
     for (uint32_t w = threadIdx.x; w < nfold; w += TPB) {
         const uint32_t r = w / NACC, q = w - r * NACC;
@@ -244,30 +248,42 @@ __global__ __launch_bounds__(TPB) void gh_light_kernel(const double* __restrict_
     }
 }
 
+template <int KIND, int SLOT>
+__global__ __launch_bounds__(TPB) void gh_light_kernel(GhArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    gh_light_body<KIND, SLOT>(g, blockIdx.x, dyn_lds);
+}
+
 // ================================================================================================
 // accumulate: heavy tiles (one row, or a slice of one, per workgroup)
 // ================================================================================================
 constexpr int HTPB = 128;  // two wavefronts per heavy tile, each walking every other 64-entry slice of the row through its own pipeline
-template <int KIND, int SLOT>
-__global__ __launch_bounds__(HTPB) void gh_heavy_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
-                                                        const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ edest,
-                                                        const RowInfo* __restrict__ rows, const Tile* __restrict__ tiles, RobustSpec rk,
-                                                        double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+constexpr int HROWS = TPB / HTPB;   // heavy tiles per workgroup
+constexpr int HCHUNK = 14;          // accumulators reduced per pass through the transposed LDS image
+NLLS_HD size_t gh_heavy_lds(uint32_t heavy_img) { return (size_t)HROWS * heavy_img + (size_t)HCHUNK * (TPB + 1); }   // doubles
+template <int KIND, int SLOT, int DEPTH>   // DEPTH: stages of the register pipeline (3 alone; 2 when fused: other workgroups on the CU hide latency, registers are scarce)
+__device__ __forceinline__ void gh_heavy_body(const GhArgs& g, uint32_t wg, uint32_t heavy_img, double* dyn) {
     using R = Res<KIND>; using I = ResInfo<KIND>;
     constexpr int DS = I::dof(SLOT);
     constexpr int NTRI = DS * (DS + 1) / 2, NACC = NTRI + DS + 1;   // lower triangle + b + cost
-    extern __shared__ __attribute__((aligned(16))) double img[];
-    const Tile t = tiles[blockIdx.x];
+    const double* __restrict__ vars = g.vars; const double* __restrict__ edata = g.edata; const uint32_t* __restrict__ evoff = g.evoff;
+    const uint32_t* __restrict__ edest = g.edest; const RobustSpec rk = g.rk;
+    double* __restrict__ A = g.A; double* __restrict__ b = g.b;
+    const int half = threadIdx.x / HTPB, ht = threadIdx.x % HTPB;
+    const uint32_t tile = wg * HROWS + half; const bool live = tile < g.ntiles;
+    double* img = dyn + (size_t)half * heavy_img;
+    double (*hred)[TPB + 1] = reinterpret_cast<double (*)[TPB + 1]>(dyn + (size_t)HROWS * heavy_img);
+    Tile t{}; if (live) t = g.tiles[tile];                     // a workgroup's spare half walks an empty tile (same barriers)
     const bool direct = (t.flags & TILE_DIRECT) != 0;
-    const RowInfo ri = rows[t.row0];   // diag_off: offset of the diagonal block inside the row's segment
-    for (uint32_t i = threadIdx.x; i < t.data_len; i += HTPB) img[i] = 0.0;
+    RowInfo ri{}; if (live) ri = g.rows[t.row0];              // diag_off: offset of the diagonal block inside the row's segment
+    for (uint32_t i = ht; i < t.data_len; i += HTPB) img[i] = 0.0;
     __syncthreads();
     double acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-    // The row's entries are walked 64 at a time (one per lane) through a three-deep software pipeline: while entry i
-    // is evaluated, the variable gathers of entry i+1 and the entry record of i+2 are in flight.  One wavefront per
-    // SIMD is resident, so this pipeline -- not occupancy -- is what hides the HBM and L2 latency.
+    // The row's entries are walked 128 at a time (one per lane) through a three-deep software pipeline: while entry i
+    // is evaluated, the variable gathers of entry i+1 and the entry record of i+2 are in flight.  All workgroups of the
+    // launch are resident at once, so this pipeline -- not occupancy -- is what hides the HBM and L2 latency.
     struct Rec { double d[R::NDATA]; uint32_t vo[R::NDEPS], ds[R::NDEPS]; bool ok; };
     auto load_rec = [&](uint32_t e, Rec& r) {
         r.ok = e < t.e1; const uint32_t ee = r.ok ? e : t.e0;
@@ -309,42 +325,112 @@ __global__ __launch_bounds__(HTPB) void gh_heavy_kernel(const double* __restrict
             });
         }
     };
-    Rec r0, r1, r2; St s0, s1, s2;
-    load_rec(t.e0 + threadIdx.x, r0);
-    load_rec(t.e0 + HTPB + threadIdx.x, r1);
-    BlockGH<KIND>::load(vars, r0.vo, s0);
-    for (uint32_t base = t.e0; base < t.e1; base += 3 * HTPB) {   // roles rotate through the three register sets
-        stage(base + 2 * HTPB + threadIdx.x, r0, s0, r1, s1, r2);
-        stage(base + 3 * HTPB + threadIdx.x, r1, s1, r2, s2, r0);
-        stage(base + 4 * HTPB + threadIdx.x, r2, s2, r0, s0, r1);
-    }
-    // fixed-order reduction of the row's diagonal block, b and cost through a transposed LDS image: thread v sums the
-    // HTPB lane-partials of accumulator v (row pitch HTPB+1 doubles: conflict-free both ways) and then owns its destination
-    __shared__ double hred[NACC][HTPB + 1];
+    if constexpr (DEPTH == 3) {
+        if (live) {
+            Rec r0, r1, r2; St s0, s1, s2;
+            load_rec(t.e0 + ht, r0);
+            load_rec(t.e0 + HTPB + ht, r1);
+            BlockGH<KIND>::load(vars, r0.vo, s0);
+#pragma unroll 1
+            for (uint32_t base = t.e0; base < t.e1; base += 3 * HTPB) {   // roles rotate through the three register sets
+                stage(base + 2 * HTPB + ht, r0, s0, r1, s1, r2);
+                stage(base + 3 * HTPB + ht, r1, s1, r2, s2, r0);
+                stage(base + 4 * HTPB + ht, r2, s2, r0, s0, r1);
+            }
+        }
+    } else {
+        // two register sets: entry record and gathers of entry i+1 are requested back to back while entry i is evaluated
+        auto stage2 = [&](uint32_t e1, const Rec& cur, const St& cst, Rec& nxt, St& nst) {
+            load_rec(e1, nxt);
+            BlockGH<KIND>::load(vars, nxt.vo, nst);
+            Rec dummy;                                               // stage() wants a record two ahead: none here
+            (void)dummy;
+            if (cur.ok) {
+                BlockGH<KIND> B; B.compute_st(cst, cur.d, rk, (cur.ds[SLOT] & OWN_KERNEL_FREE) != 0);
+                if (cur.ds[SLOT] & OWN_COST_OWNER) acc[NACC - 1] += B.cost;
+                int q = 0;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) hred[i][threadIdx.x] = acc[i];
-    __syncthreads();
-    for (int v = threadIdx.x; v < NACC; v += HTPB) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                for (int j = 0; j < DS; ++j)
 #pragma unroll
-        for (int k = 0; k < HTPB; k += 4) { s0 += hred[v][k]; s1 += hred[v][k + 1]; s2 += hred[v][k + 2]; s3 += hred[v][k + 3]; }
-        const double sum = (s0 + s1) + (s2 + s3);
-        if (v == NACC - 1) partials[blockIdx.x] = sum;
-        else if (v >= NTRI) { const int i = v - NTRI; if (t.flags & TILE_PARTIAL) atomicAdd(&b[t.b_off + i], sum); else b[t.b_off + i] = sum; }
-        else {
-            int q = v, j = 0; while (q >= DS - j) { q -= DS - j; ++j; } const int i = j + q;   // unpack (i >= j)
-            if (direct) { double* dg = A + t.data_off + ri.diag_off; atomicAdd(&dg[i + DS * j], sum); if (i != j) atomicAdd(&dg[j + DS * i], sum); }
-            else { img[ri.diag_off + i + DS * j] = sum; if (i != j) img[ri.diag_off + j + DS * i] = sum; }   // only registers feed the diagonal block
+                    for (int i = j; i < DS; ++i) acc[q++] += h_elem<KIND, SLOT, SLOT>(B, i, j);
+#pragma unroll
+                for (int i = 0; i < DS; ++i) acc[NTRI + i] += g_elem<KIND, SLOT>(B, i);
+                static_for<R::NDEPS>([&](auto Tc) {
+                    constexpr int T = decltype(Tc)::value;
+                    if constexpr (T != SLOT) {
+                        constexpr int DT = I::dof(T);
+                        if (cur.ds[T] != DEST_NONE) {
+#pragma unroll
+                            for (int j = 0; j < DT; ++j)
+#pragma unroll
+                                for (int i = 0; i < DS; ++i) {
+                                    const double v = h_elem<KIND, SLOT, T>(B, i, j);
+                                    if (direct) atomicAdd(&A[(size_t)cur.ds[T] + i + DS * j], v); else atomicAdd(&img[cur.ds[T] + i + DS * j], v);
+                                }
+                        }
+                    }
+                });
+            }
+        };
+        if (live) {
+            Rec r0, r1; St s0, s1;
+            load_rec(t.e0 + ht, r0);
+            BlockGH<KIND>::load(vars, r0.vo, s0);
+#pragma unroll 1
+            for (uint32_t base = t.e0; base < t.e1; base += 2 * HTPB) {
+                stage2(base + HTPB + ht, r0, s0, r1, s1);
+                stage2(base + 2 * HTPB + ht, r1, s1, r0, s0);
+            }
         }
     }
-    __syncthreads();
-    if (direct) return;
+    // fixed-order reduction of the row's diagonal block, b and cost through a transposed LDS image, HCHUNK accumulators per
+    // pass: thread v of the row sums the HTPB lane-partials of accumulator v (row pitch TPB+1 doubles: conflict-free both
+    // ways) and then owns its destination
+#pragma unroll
+    for (int c0 = 0; c0 < NACC; c0 += HCHUNK) {
+#pragma unroll
+        for (int i = 0; i < HCHUNK; ++i) if (c0 + i < NACC) hred[i][threadIdx.x] = acc[c0 + i];
+        __syncthreads();
+        if (ht < HCHUNK && c0 + ht < NACC && live) {
+            const int v = c0 + ht; const double* hr = &hred[ht][half * HTPB];
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 4
+            for (int k = 0; k < HTPB; k += 4) { s0 += hr[k]; s1 += hr[k + 1]; s2 += hr[k + 2]; s3 += hr[k + 3]; }   // (the later chunks' accumulators are still live: modest unroll)
+            const double sum = (s0 + s1) + (s2 + s3);
+            if (v == NACC - 1) g.partials[tile] = sum;
+            else if (v >= NTRI) { const int i = v - NTRI; if (t.flags & TILE_PARTIAL) atomicAdd(&b[t.b_off + i], sum); else b[t.b_off + i] = sum; }
+            else {
+                int q = v, j = 0; while (q >= DS - j) { q -= DS - j; ++j; } const int i = j + q;   // unpack (i >= j)
+                if (direct) { double* dg = A + t.data_off + ri.diag_off; atomicAdd(&dg[i + DS * j], sum); if (i != j) atomicAdd(&dg[j + DS * i], sum); }
+                else { img[ri.diag_off + i + DS * j] = sum; if (i != j) img[ri.diag_off + j + DS * i] = sum; }   // only registers feed the diagonal block
+            }
+        }
+        __syncthreads();
+    }
+    if (direct || !live) return;
     if (t.flags & TILE_PARTIAL) {
-        for (uint32_t i = threadIdx.x; i < t.data_len; i += HTPB) { double v = img[i]; if (v != 0.0) atomicAdd(&A[t.data_off + i], v); }
+        for (uint32_t i = ht; i < t.data_len; i += HTPB) { double v = img[i]; if (v != 0.0) atomicAdd(&A[t.data_off + i], v); }
     } else {
         double* dst = A + t.data_off;
-        for (uint32_t i = threadIdx.x; i < t.data_len; i += HTPB) dst[i] = img[i];
+        for (uint32_t i = ht; i < t.data_len; i += HTPB) dst[i] = img[i];
     }
+}
+template <int KIND, int SLOT>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void gh_heavy_kernel(GhArgs g, uint32_t heavy_img) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    gh_heavy_body<KIND, SLOT, 3>(g, blockIdx.x, heavy_img, dyn_lds);
+}
+// One launch for a cost group whose entry lists split cleanly into one list of light tiles (bundle adjustment: the point
+// rows) and one of heavy tiles (the camera rows): the heavy workgroups come first in the grid and are compute / latency
+// bound with almost no HBM traffic, the light ones are bound by the A.data stream -- side by side they overlap instead
+// of running back to back.
+template <int KIND, int LSLOT, int HSLOT>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void gh_fused_kernel(GhArgs gl, GhArgs gh, uint32_t heavy_img, uint32_t nhw) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    // the heavy workgroups come first: their lifetime is the longest.  (Spreading them through the grid, or alternating
+    // them with light ones at the front, measured slower: 114 and 57 us against 49.)
+    if (blockIdx.x < nhw) gh_heavy_body<KIND, HSLOT, 2>(gh, blockIdx.x, heavy_img, dyn_lds);
+    else gh_light_body<KIND, LSLOT>(gl, blockIdx.x - nhw, dyn_lds);
 }
 
 // ================================================================================================
@@ -518,27 +604,56 @@ static int launch_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int
     }
     return NLLS_OK;
 }
+template <int KIND>
+static GhArgs gh_args(nlls_ctx* c, const Group& G, const EntryList& E, const double* vars, bool heavy, double* partials) {
+    GhArgs g{}; g.vars = vars; g.edata = E.data.p; g.evoff = E.voff.p; g.edest = E.dest.p; g.rows = E.rows.p; g.tiles = heavy ? E.heavy.p : E.light.p;
+    g.rk = G.rk; g.unique_dest = E.unique_dest ? 1 : 0; g.ntiles = (uint32_t)(heavy ? E.nheavy : E.nlight); g.A = c->A.p; g.b = c->b.p; g.partials = partials;
+    return g;
+}
 template <int KIND, int SLOT>
 static void launch_gh_slot(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
     if constexpr (SLOT < Res<KIND>::NDEPS) {
         const EntryList& E = G.lists[SLOT];
         if (E.nlight > 0) {
             hipLaunchKernelGGL((gh_light_kernel<KIND, SLOT>), dim3((unsigned)E.nlight), dim3(TPB), (E.light_lds + 2) * sizeof(double), c->stream,
-                               vars, E.data.p, E.voff.p, E.dest.p, E.rows.p, E.light.p, G.rk, E.unique_dest ? 1 : 0, c->A.p, c->b.p, c->partials.p + pbase);
+                               gh_args<KIND>(c, G, E, vars, false, c->partials.p + pbase));
             pbase += E.nlight;
         }
         if (E.nheavy > 0) {
-            hipLaunchKernelGGL((gh_heavy_kernel<KIND, SLOT>), dim3((unsigned)E.nheavy), dim3(HTPB), E.heavy_lds * sizeof(double), c->stream,
-                               vars, E.data.p, E.voff.p, E.dest.p, E.rows.p, E.heavy.p, G.rk, c->A.p, c->b.p, c->partials.p + pbase);
+            hipLaunchKernelGGL((gh_heavy_kernel<KIND, SLOT>), dim3((unsigned)((E.nheavy + HROWS - 1) / HROWS)), dim3(TPB), gh_heavy_lds(E.heavy_lds) * sizeof(double), c->stream,
+                               gh_args<KIND>(c, G, E, vars, true, c->partials.p + pbase), E.heavy_lds);
             pbase += E.nheavy;
         }
     }
 }
+// two-slot kinds whose lists split into {light only, heavy only}: one fused launch
+template <int KIND>
+static bool launch_gh_fused(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if constexpr (Res<KIND>::NDEPS == 2) {
+        const EntryList& E0 = G.lists[0]; const EntryList& E1 = G.lists[1];
+        int ls = -1;
+        if (E0.nlight > 0 && E0.nheavy == 0 && E1.nheavy > 0 && E1.nlight == 0) ls = 0;
+        else if (E1.nlight > 0 && E1.nheavy == 0 && E0.nheavy > 0 && E0.nlight == 0) ls = 1;
+        if (ls < 0) return false;
+        const EntryList& EL = ls == 0 ? E0 : E1; const EntryList& EH = ls == 0 ? E1 : E0;
+        const size_t lds = std::max<size_t>(EL.light_lds + 2, gh_heavy_lds(EH.heavy_lds)) * sizeof(double);
+        if (lds > ((size_t)EL.light_lds + 2) * sizeof(double) + 4096) return false;    // the heavy role must not cost the light one occupancy
+        const unsigned nhw = (unsigned)((EH.nheavy + HROWS - 1) / HROWS);
+        const GhArgs gl = gh_args<KIND>(c, G, EL, vars, false, c->partials.p + pbase), gh = gh_args<KIND>(c, G, EH, vars, true, c->partials.p + pbase + EL.nlight);
+        if (ls == 0) hipLaunchKernelGGL((gh_fused_kernel<KIND, 0, 1>), dim3(nhw + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw);
+        else         hipLaunchKernelGGL((gh_fused_kernel<KIND, 1, 0>), dim3(nhw + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw);
+        pbase += EL.nlight + EH.nheavy;
+        return true;
+    }
+    return false;
+}
 template <int KIND>
 static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
     if (c->info.is_sparse) {
-        launch_gh_slot<KIND, 0>(c, G, vars, pbase); launch_gh_slot<KIND, 1>(c, G, vars, pbase);
-        launch_gh_slot<KIND, 2>(c, G, vars, pbase); launch_gh_slot<KIND, 3>(c, G, vars, pbase);
+        if (!launch_gh_fused<KIND>(c, G, vars, pbase)) {
+            launch_gh_slot<KIND, 0>(c, G, vars, pbase); launch_gh_slot<KIND, 1>(c, G, vars, pbase);
+            launch_gh_slot<KIND, 2>(c, G, vars, pbase); launch_gh_slot<KIND, 3>(c, G, vars, pbase);
+        }
     } else if (G.dense.n > 0) {
         const int ndof = (int)c->info.ndof; const int use_lds = ndof <= 64;
         int grid = (int)std::min<int64_t>((G.dense.n + TPB - 1) / TPB, 1024);
