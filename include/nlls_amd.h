@@ -166,7 +166,9 @@ int  nlls_copy_variables(nlls_ctx* ctx, int32_t dst, int32_t src);/* deepcopy, s
 /* ---- sweeps -----------------------------------------------------------------------------------
  * replaces: zero!(linsystem) + costgradhess!(linsystem, vars, costs)
  *           src/optimize.jl:118,167-170 -> src/cost.jl:29-54, src/residual.jl:57-111,
- *           src/linearsystem.jl:132-175.  Evaluated at NLLS_VARS_CURRENT.  Resets the damping. */
+ *           src/linearsystem.jl:132-175.  Evaluated at NLLS_VARS_CURRENT.  Resets the damping.
+ * cost_out == NULL: the cost is not wanted (the outer loop discards it between iterations, src/optimize.jl:167-170):
+ * the sweep is only enqueued -- no cost reduction, no synchronisation; the next synchronising call waits for it. */
 int  nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out);
 /* replaces: cost(vars, costs)  src/cost.jl:10-13, src/residual.jl:49-55 */
 int  nlls_sweep_cost(nlls_ctx* ctx, int32_t which, double* cost_out);
@@ -224,6 +226,7 @@ int  nlls_get_shard_info(nlls_ctx* ctx, int64_t* out, int32_t n);
 /* ---- profiling helper: run the accumulate kernel(s) `reps` times between two HIP events on the
  * context's stream; returns average ms per sweep (used by bench.py for the roofline line). */
 int  nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg);
+int  nlls_time_sweep_accumulate(nlls_ctx* ctx, int32_t reps, float* ms_avg);   /* the accumulate launches alone (what nlls_sweep_gradhess(ctx, NULL) enqueues) */
 int  nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg);
 int  nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);
 

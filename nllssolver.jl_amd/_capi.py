@@ -23,7 +23,7 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_time_sweep_gradhess nlls_time_sweep_cost nlls_time_solve""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve""".split()
 
 
 class NllsError(RuntimeError):
@@ -93,7 +93,7 @@ def lib():
         L.nlls_get_reduce_buffer.argtypes = [vp, i32, vp, vp]
         L.nlls_get_step_shard.argtypes = [vp, vp, vp, vp, vp]
         L.nlls_get_shard_info.argtypes = [vp, vp, i32]
-        L.nlls_time_sweep_gradhess.argtypes = [vp, i32, vp]; L.nlls_time_sweep_cost.argtypes = [vp, i32, vp]
+        L.nlls_time_sweep_gradhess.argtypes = [vp, i32, vp]; L.nlls_time_sweep_cost.argtypes = [vp, i32, vp]; L.nlls_time_sweep_accumulate.argtypes = [vp, i32, vp]
         L.nlls_time_solve.argtypes = [vp, i32, vp]
         _lib = L
     return _lib
@@ -184,7 +184,9 @@ class Context:
         self._chk(fn(self.h, *args, C.byref(out)))
         return out.value
 
-    def sweep_gradhess(self):
+    def sweep_gradhess(self, want_cost=True):
+        if not want_cost:                          # enqueue only: no cost reduction, no synchronisation
+            self._chk(self.L.nlls_sweep_gradhess(self.h, None)); return None
         return self._scalar(self.L.nlls_sweep_gradhess)
 
     def sweep_cost(self, which=VARS_CURRENT):
@@ -266,6 +268,9 @@ class Context:
 
     def time_sweep_gradhess(self, reps=10):
         ms = C.c_float(); self._chk(self.L.nlls_time_sweep_gradhess(self.h, reps, C.byref(ms))); return ms.value
+
+    def time_sweep_accumulate(self, reps=10):
+        ms = C.c_float(); self._chk(self.L.nlls_time_sweep_accumulate(self.h, reps, C.byref(ms))); return ms.value
 
     def time_sweep_cost(self, reps=10):
         ms = C.c_float(); self._chk(self.L.nlls_time_sweep_cost(self.h, reps, C.byref(ms))); return ms.value

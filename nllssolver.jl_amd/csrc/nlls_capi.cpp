@@ -135,10 +135,13 @@ int nlls_copy_variables(nlls_ctx* ctx, int32_t dst, int32_t src) {
 
 int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
     NEED_READY();
-    TRY(enqueue_sweep_gradhess(ctx));
+    // cost_out == NULL: the caller does not want the cost (the outer loop between iterations, src/optimize.jl:167-170
+    // discards it) -- the sweep is then only enqueued: no partial-sum kernel, no synchronisation
+    TRY(enqueue_sweep_gradhess(ctx, cost_out != nullptr));
     ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
+    if (!cost_out) return NLLS_OK;
     TRY(fetch_scalars(ctx, 0, 1));
-    if (cost_out) *cost_out = ctx->h_scalars[0];
+    *cost_out = ctx->h_scalars[0];
     return NLLS_OK;
 }
 int nlls_sweep_cost(nlls_ctx* ctx, int32_t which, double* cost_out) {
@@ -307,6 +310,10 @@ static int time_loop(nlls_ctx* ctx, int reps, float* ms_avg, int (*fn)(nlls_ctx*
 
 int nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
     NEED_READY(); int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c); });
+    ctx->have_grad = true; return rc;
+}
+int nlls_time_sweep_accumulate(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+    NEED_READY(); int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c, false); });
     ctx->have_grad = true; return rc;
 }
 int nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg) {

@@ -19,7 +19,7 @@ int build_schur(nlls_ctx* c, int32_t flags);
 
 // sweeps (nlls_sweep.hip): enqueue on c->stream; cost lands in c->scalars[0]
 int enqueue_sweep_cost(nlls_ctx* c, int which);
-int enqueue_sweep_gradhess(nlls_ctx* c);
+int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost = true);
 // vector helpers (nlls_sweep.hip)
 int enqueue_retract(nlls_ctx* c, int to, int from);
 int enqueue_step_stats(nlls_ctx* c);          // scalars[1] = max|x|, scalars[2] = x'x

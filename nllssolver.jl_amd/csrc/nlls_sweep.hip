@@ -678,7 +678,7 @@ int enqueue_sweep_cost(nlls_ctx* c, int which) {
     return NLLS_OK;
 }
 
-int enqueue_sweep_gradhess(nlls_ctx* c) {
+int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost) {
     c->tE_valid = false; c->step_cached = false;  // A and b change: what the last solve kept of them is stale
     const double* vars = vars_ptr(c, NLLS_VARS_CURRENT); int64_t pbase = 0;
     if (!c->info.is_sparse) {
@@ -698,7 +698,7 @@ int enqueue_sweep_gradhess(nlls_ctx* c) {
         const int64_t n2 = c->info.ndof * c->info.ndof;
         hipLaunchKernelGGL(symmetrize_dense_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->A.p, (int)c->info.ndof);
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, pbase, c->scalars.p);
+    if (want_cost) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, pbase, c->scalars.p);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }

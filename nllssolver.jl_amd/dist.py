@@ -61,9 +61,9 @@ class ShardedLS(MultiVariateLSgpu):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
         return [float(v) for v in t.cpu()]
 
-    def costgradhess(self):
+    def costgradhess(self, want_cost=True):
         if self.world == 1:
-            return super().costgradhess()
+            return super().costgradhess(want_cost)
         self._x = None
         self.ctx.sweep_gradhess_local()
         self._allreduce_buffer(0)

@@ -27,10 +27,11 @@ class MultiVariateLSgpu:
         return _capi.Context(device)
 
     # ---- the generic functions of SURVEY 8b -------------------------------------------------------
-    def costgradhess(self):
-        """zero!(linsystem); costgradhess!(linsystem, vars, costs)   src/optimize.jl:118,167-170"""
+    def costgradhess(self, want_cost=True):
+        """zero!(linsystem); costgradhess!(linsystem, vars, costs)   src/optimize.jl:118,167-170.
+        want_cost=False (the outer loop between iterations discards the value): enqueue only."""
         self._x = None
-        return self.ctx.sweep_gradhess()
+        return self.ctx.sweep_gradhess(want_cost)
 
     def cost(self, which=VARS_NEXT):
         """cost(vars, costs)   src/cost.jl:10-13"""

@@ -155,7 +155,7 @@ class OuterLoop:
         data.converged = converged
         self.cost = cost
         if converged == 0 and regrad:
-            It._timed(data, "timegradient", ls.costgradhess)   # :167-170
+            It._timed(data, "timegradient", lambda: ls.costgradhess(want_cost=False))   # :167-170 (the value is discarded there too)
             data.gradientcomputations += 1
         return converged
 
