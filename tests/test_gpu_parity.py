@@ -172,3 +172,20 @@ def test_ba_wide_points_fast_elimination():   # points seen by 11-12 cameras: mo
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(150, 3000, 0.075, seed=9), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)
     assert info.solve_mode == 2 and info.bandwidth >= 64
+
+
+@pytest.mark.parametrize("ncam,npts,prop,seed", [
+    (70, 1500, 0.05, 11),      # bandwidth ~ 3 cameras: NBW = 2, short band
+    (97, 2500, 0.04, 12),      # reduced size not a multiple of 16
+    (160, 4000, 0.03, 13),     # NBW = 2..3, both sides of the twisted factorisation several blocks long
+    (240, 5000, 0.045, 14),    # ~11 cameras per point: NBW = 5, the widest band the blocked path takes
+    (300, 6000, 0.012, 15),    # ~4 cameras per point, long band
+])
+def test_band_solver_shapes(ncam, npts, prop, seed):
+    """The blocked band path over bandwidths, lengths and remainders (twisted and one-sided); x against the oracle."""
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed, robust=N.HuberKernel(0.01),
+                                                                 outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.nreduced_dof == 6 * ncam
+    if info.solve_mode == 2:
+        check_problem(p, flags=_capi.FLAG_NO_TWIST, expect_schur=1)
