@@ -822,9 +822,10 @@ NLLS_DEV double readlane_d(double x, int k) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
 }
 
-struct BlkLds { double* tiles; double* corner; double* Wp; double* dvec; double* Li; int TW, TR, NBW, H, bw, n_band, nJ, rev; };
+struct BlkLds { double* tiles; double* corner; double* Wp; double* dvec; double* Li; double* dummy; int TW, TR, NBW, H, bw, n_band, nJ, rev; };
 constexpr int BLK_P = 17, BLK_TS = 16 * BLK_P;                // padded tile row, doubles per tile
-NLLS_DEV double* blk_tile(const BlkLds& S, int K, int ti) { return S.tiles + ((size_t)(K % S.TW) * S.TR + ti) * BLK_TS; }
+NLLS_DEV double* blk_tile(const BlkLds& S, int K, int ti) { return S.tiles + ((size_t)(K % S.TW) * S.TR + ti) * BLK_TS; }          // (modulo: cold paths only)
+NLLS_DEV double* blk_slot_tile(const BlkLds& S, int slot, int ti) { return S.tiles + ((size_t)slot * S.TR + ti) * BLK_TS; }   // slot = column % TW, kept incrementally
 NLLS_DEV double* blk_panel(const BlkLds& S, int J) { return S.Wp + (size_t)(J & 1) * S.TR * 16 * BLK_P; }   // W of block J
 NLLS_DEV double* blk_d(const BlkLds& S, int J) { return S.dvec + (J & 1) * 32; }                               // D[16], 1/D[16]
 NLLS_DEV double* blk_li(const BlkLds& S, int J) { return S.Li + (J & 1) * 16 * BLK_P; }                         // inv(L_JJ)'
@@ -837,12 +838,12 @@ NLLS_DEV double* blk_li(const BlkLds& S, int J) { return S.Li + (J & 1) * 16 * B
 // A second accumulator starts as the identity and takes the same column operations (transposed): it ends as inv(L),
 // so the sub-diagonal tiles need no substitution, W_T = T * inv(L)' is a matrix-core product (blk_panel_tile).
 // Serial chain per pivot: readlane d -> v_rcp_f64 + two Newton steps -> scale -> MFMA.
-__device__ __forceinline__ void blk_factor(const BlkLds& S, int J, int* status) {
+__device__ __forceinline__ void blk_factor(const BlkLds& S, int J, int jslot, int* status) {
     constexpr int P = BLK_P;
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     double4_t A, Bt;                                          // Bt[n][j]: transpose of the identity rows' tile
     {
-        const double* t0 = blk_tile(S, J, 0);
+        const double* t0 = blk_slot_tile(S, jslot, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { A[r] = t0[(lk + 4 * r) * P + li]; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
     }
@@ -874,10 +875,10 @@ __device__ __forceinline__ void blk_factor(const BlkLds& S, int J, int* status) 
     if (badk < 16 && lane == 0) atomicCAS(status, 0, 1 + 16 * J + badk);
 }
 // panel tile ti (1..NBW sub-diagonal, NBW+1 border) of block J:  W = T * inv(L)'  -> panel rows 16*ti..16*ti+15
-__device__ __forceinline__ void blk_panel_tile(const BlkLds& S, int J, int ti) {
+__device__ __forceinline__ void blk_panel_tile(const BlkLds& S, int J, int jslot, int ti) {
     constexpr int P = BLK_P;
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    const double* T = blk_tile(S, J, ti); double* Wt = blk_panel(S, J) + (size_t)ti * 16 * P;
+    const double* T = blk_slot_tile(S, jslot, ti); double* Wt = blk_panel(S, J) + (size_t)ti * 16 * P;
     double av[4], bv[4];
     const double* Lij = blk_li(S, J);
 #pragma unroll
@@ -902,7 +903,7 @@ __device__ __forceinline__ void blk_land_load(const BlkLds& S, const double* __r
     for (int q = 0; q < BLK_LANDW; ++q) {
         const int w = t0 + q * nt; val[q] = 0.0;
         if (w < nwords) {
-            const int ti = w >> 8, r = (w >> 4) & 15, cc = w & 15;
+            const int ti = w >> 8, cc = (w >> 4) & 15, r = w & 15;     // r fastest: 16 lanes read 16 consecutive band entries
             int c = 16 * K + cc, e;
             if (ti <= S.NBW) { e = 16 * ti + r - cc; if (e < 0) { c = 16 * K + r; e = -e; } }     // upper part of the diagonal tile: mirror
             else e = S.bw + 1 + r;                                                              // border tile: row r = border index
@@ -914,57 +915,95 @@ __device__ __forceinline__ void blk_land_load(const BlkLds& S, const double* __r
         }
     }
 }
-__device__ __forceinline__ void blk_land_store(const BlkLds& S, int K, int t0, int nt, const double (&val)[BLK_LANDW]) {
+__device__ __forceinline__ void blk_land_store(const BlkLds& S, int slot, int t0, int nt, const double (&val)[BLK_LANDW]) {
     constexpr int P = BLK_P;
-    double* base = blk_tile(S, K, 0);
+    double* base = blk_slot_tile(S, slot, 0);
     const int nwords = S.TR * 16 * 16;
 #pragma unroll
     for (int q = 0; q < BLK_LANDW; ++q) {
         const int w = t0 + q * nt;
-        if (w < nwords) { const int ti = w >> 8, r = (w >> 4) & 15, cc = w & 15; base[(size_t)ti * BLK_TS + r * P + cc] = val[q]; }
+        if (w < nwords) { const int ti = w >> 8, cc = (w >> 4) & 15, r = w & 15; base[(size_t)ti * BLK_TS + r * P + cc] = val[q]; }
     }
 }
 __device__ __forceinline__ void blk_land(const BlkLds& S, const double* __restrict__ Sb, int K, int t0, int nt) {
-    for (int w0 = t0; w0 < S.TR * 256; w0 += nt * BLK_LANDW) { double v[BLK_LANDW]; blk_land_load(S, Sb, K, w0, nt, v); blk_land_store(S, K, w0, nt, v); }
+    for (int w0 = t0; w0 < S.TR * 256; w0 += nt * BLK_LANDW) { double v[BLK_LANDW]; blk_land_load(S, Sb, K, w0, nt, v); blk_land_store(S, K % S.TW, w0, nt, v); }
+}
+// The same landing for an INTERIOR tile column (every entry it reads exists: 16 K + 15 + bw < n_band), from a per-thread
+// plan made once: a word's LDS offset, its offset in the band array for column 0 and the (signed) stride per column do
+// not depend on K.  This is what runs at (almost) every block step; the general form above handles the ends.
+struct BlkLandPlan { int loff[BLK_LANDW]; long long goff[BLK_LANDW]; long long gstep; unsigned on; };
+__device__ __forceinline__ void blk_land_plan(const BlkLds& S, int t0, int nt, BlkLandPlan& Pl) {
+    constexpr int P = BLK_P;
+    const int H = S.H, nwords = S.TR * 16 * 16;
+    Pl.on = 0; Pl.gstep = S.rev ? -16LL * H : 16LL * H;
+#pragma unroll
+    for (int q = 0; q < BLK_LANDW; ++q) {
+        const int w = t0 + q * nt; Pl.loff[q] = 0; Pl.goff[q] = 0;
+        if (w >= nwords) continue;
+        const int ti = w >> 8, cc = (w >> 4) & 15, r = w & 15;
+        int c = cc, e;
+        if (ti <= S.NBW) { e = 16 * ti + r - cc; if (e < 0) { c = r; e = -e; } } else e = S.bw + 1 + r;
+        Pl.loff[q] = ti * BLK_TS + r * P + cc;
+        if (e < H && (ti > S.NBW || e <= S.bw)) {
+            Pl.on |= 1u << q;
+            Pl.goff[q] = !S.rev ? (long long)c * H + e : (ti > S.NBW ? (long long)(S.n_band - 1 - c) * H + e : (long long)(S.n_band - 1 - c - e) * H + e);
+        }
+    }
+}
+__device__ __forceinline__ void blk_land_load_fast(const double* __restrict__ Sb, int K, const BlkLandPlan& Pl, double (&val)[BLK_LANDW]) {
+    const double* col = Sb + K * Pl.gstep;
+#pragma unroll
+    for (int q = 0; q < BLK_LANDW; ++q) val[q] = (Pl.on >> q & 1) ? col[Pl.goff[q]] : 0.0;
+}
+__device__ __forceinline__ void blk_land_store_fast(const BlkLds& S, int slot, int t0, int nt, const BlkLandPlan& Pl, const double (&val)[BLK_LANDW]) {
+    double* base = blk_slot_tile(S, slot, 0);
+    const int nwords = S.TR * 16 * 16;
+#pragma unroll
+    for (int q = 0; q < BLK_LANDW; ++q) if (t0 + q * nt < nwords) base[Pl.loff[q]] = val[q];
 }
 // Tile-updates of one block step, numbered u = 0..nup-1: first the NBW+1 tiles of block column J+1 (K = 1: tile rows
 // 1..NBW and the border row), then K = 2..NBW (tile rows K..NBW and the border row), last the border corner (K = 0).
 // A wave's share of a range of them is the same at every block step, so it is unpacked once.
-template <int MAXU> struct BlkUpd { int K[MAXU], pi[MAXU], trow[MAXU]; };
+template <int MAXU> struct BlkUpd { int K[MAXU], woff[MAXU], loff[MAXU], toff[MAXU]; };   // K < 0: none; offsets in doubles
 template <int MAXU>
 __device__ __forceinline__ void blk_update_list(const BlkLds& S, int first, int count, int w0, int nw, BlkUpd<MAXU>& U) {
+    constexpr int P = BLK_P;
     const int NBW = S.NBW, nup = NBW * (NBW + 1) / 2 + NBW + 1;
 #pragma unroll
     for (int q = 0; q < MAXU; ++q) {
-        const int u = first + w0 + q * nw; U.K[q] = -1; U.pi[q] = 0; U.trow[q] = 0;
+        const int u = first + w0 + q * nw; U.K[q] = -1; U.woff[q] = 0; U.loff[q] = 0; U.toff[q] = 0;
         if (w0 < 0 || w0 + q * nw >= count) continue;
-        if (u < nup - 1) { int uu = u, K = 1; while (uu >= NBW - K + 2) { uu -= NBW - K + 2; ++K; }
-            U.K[q] = K; U.pi[q] = (uu == NBW - K + 1) ? NBW + 1 : K + uu; U.trow[q] = (uu == NBW - K + 1) ? NBW + 1 : uu; }
-        else if (u == nup - 1) { U.K[q] = 0; U.pi[q] = NBW + 1; }    // K = 0 marks the border corner
+        int K = 0, pi = NBW + 1, trow = 0;                            // K = 0 marks the border corner
+        if (u < nup - 1) { int uu = u; K = 1; while (uu >= NBW - K + 2) { uu -= NBW - K + 2; ++K; }
+            pi = (uu == NBW - K + 1) ? NBW + 1 : K + uu; trow = (uu == NBW - K + 1) ? NBW + 1 : uu; }
+        else if (u != nup - 1) continue;
+        U.K[q] = K; U.woff[q] = pi * 16 * P; U.loff[q] = (K > 0 ? K : NBW + 1) * 16 * P; U.toff[q] = trow * BLK_TS;
     }
 }
-// apply this wave's tile-updates of block J (panel W and 1/D of block J in LDS) on the matrix cores
+// apply this wave's tile-updates of block J (panel W and 1/D of block J in LDS; jslot = J % TW) on the matrix cores.
+// A tile-update that does not exist at this step works on a spare tile: no predicated stores, no branches.
 template <int MAXU>
-__device__ __forceinline__ void blk_update(const BlkLds& S, int J, const BlkUpd<MAXU>& U) {
+__device__ __forceinline__ void blk_update(const BlkLds& S, int J, int jslot, const BlkUpd<MAXU>& U) {
     constexpr int P = BLK_P;
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const double* Wb = blk_panel(S, J); const double* rd = blk_d(S, J) + 16;
-    int jslot = J % S.TW;
-    double* Ct[MAXU]; double4_t acc[MAXU], acc2[MAXU]; double wv[MAXU][4], lv[MAXU][4]; bool ok[MAXU];
+    double* Ct[MAXU]; double4_t acc[MAXU], acc2[MAXU]; double wv[MAXU][4], lv[MAXU][4];
     double rdk[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) rdk[kk] = rd[4 * kk + lk];
+    const int lo = li * P + lk, co = lk * P + li;
     // all operand loads first, then the MFMAs, then the stores: the LDS latency of one tile hides behind the others
 #pragma unroll
     for (int q = 0; q < MAXU; ++q) {
-        const int K = U.K[q]; ok[q] = K >= 0 && (K == 0 || J + K < S.nJ);
-        int sl = jslot + (K > 0 ? K : 0); if (sl >= S.TW) sl -= S.TW;
-        Ct[q] = (K > 0) ? S.tiles + ((size_t)sl * S.TR + U.trow[q]) * BLK_TS : S.corner;
-        const double* Wt = Wb + (size_t)U.pi[q] * 16 * P; const double* Lt = Wb + (size_t)(K > 0 ? K : S.NBW + 1) * 16 * P;
+        const int K = U.K[q]; const bool ok = K >= 0 && (K == 0 || J + K < S.nJ);
+        int sl = jslot + (K > 0 ? K : 0); sl -= sl >= S.TW ? S.TW : 0;
+        double* ct = (K > 0) ? S.tiles + (size_t)sl * S.TR * BLK_TS + U.toff[q] : S.corner;
+        Ct[q] = (ok ? ct : S.dummy) + co;
+        const double* Wt = Wb + U.woff[q] + lo; const double* Lt = Wb + U.loff[q] + lo;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { wv[q][kk] = -Wt[li * P + 4 * kk + lk]; lv[q][kk] = Lt[li * P + 4 * kk + lk] * rdk[kk]; }
+        for (int kk = 0; kk < 4; ++kk) { wv[q][kk] = -Wt[4 * kk]; lv[q][kk] = Lt[4 * kk] * rdk[kk]; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[q][r] = Ct[q][(lk + 4 * r) * P + li];
+        for (int r = 0; r < 4; ++r) acc[q][r] = Ct[q][4 * r * P];
         acc2[q] = double4_t{0, 0, 0, 0};
     }
 #pragma unroll
@@ -978,9 +1017,9 @@ __device__ __forceinline__ void blk_update(const BlkLds& S, int J, const BlkUpd<
         acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][3], lv[q][3], acc2[q], 0, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < MAXU; ++q) if (ok[q]) {
+    for (int q = 0; q < MAXU; ++q) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ct[q][(lk + 4 * r) * P + li] = acc[q][r] + acc2[q][r];
+        for (int r = 0; r < 4; ++r) Ct[q][4 * r * P] = acc[q][r] + acc2[q][r];
     }
 }
 // factor block column J -> HBM (consumed by band_backward_tiles_kernel).  The backward pass needs
@@ -1028,6 +1067,7 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
     S.Wp = S.corner + TS;                                     // [2][TR*16][P]
     S.dvec = S.Wp + 2 * (size_t)S.TR * 16 * P;                // [2][32]
     S.Li = S.dvec + 64;                                       // [2][16][P]: inv(L_JJ)' by block parity
+    S.dummy = S.Li + 2 * 16 * P;                              // [TS] spare tile: target of the tile-updates that do not exist at a step
     const int nJ = S.nJ, nJs = a.nJs;                         // blocks of the matrix; blocks this workgroup factors
     for (int i = tid; i < S.TW * S.TR * TS + TS; i += BLK_T) S.tiles[i] = 0.0;
     __syncthreads();
@@ -1037,7 +1077,7 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
 #pragma unroll
         for (int K = 0; K < 6; ++K) if (K <= NBW && K < nJ) blk_land_load(S, a.Sb, K, tid, BLK_T, pv[K]);
 #pragma unroll
-        for (int K = 0; K < 6; ++K) if (K <= NBW && K < nJ) blk_land_store(S, K, tid, BLK_T, pv[K]);
+        for (int K = 0; K < 6; ++K) if (K <= NBW && K < nJ) blk_land_store(S, K, tid, BLK_T, pv[K]);   // slot = column (K < TW)
     }
     // urgent tile-updates (block column J+1): NBW+1 of them over the four waves; deferred ones (the rest): over waves 1-3
     const int nup = NBW * (NBW + 1) / 2 + NBW + 1, nurgent = NBW + 1;
@@ -1045,24 +1085,28 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
     BlkUpd<1> Uu; blk_update_list<1>(S, 0, nurgent, wave, NW, Uu);
     BlkUpd<3> Ud; blk_update_list<3>(S, nurgent, nup - nurgent, wave - 1, NW - 1, Ud);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();   // diagnostics only (nlls_get_solve_stats)
+    int jslot = 0;                                            // J % TW, kept incrementally (no integer division in the loop)
+    BlkLandPlan plan; blk_land_plan(S, tid - 64, BLK_HELP, plan);
     for (int J = 0; J < nJs; ++J) {
+        const int pslot = jslot == 0 ? S.TW - 1 : jslot - 1;  // slot of column J-1 = slot of column J+NBW+1
         __syncthreads();                                      // (A) block column J is final
-        if (wave == 0) blk_factor(S, J, a.status);
+        if (wave == 0) blk_factor(S, J, jslot, a.status);
         else {
             // helpers, hidden behind wave 0's factorisation: the deferred tile-updates of block J-1, tile column
             // J+NBW+1 into the ring slot of column J-1 (HBM latency), block J-1's factor out
-            double lv[BLK_LANDW]; const bool landing = J + NBW + 1 < nJ;
-            if (landing) blk_land_load(S, a.Sb, J + NBW + 1, tid - 64, BLK_HELP, lv);
-            if (J > 0) { blk_update<3>(S, J - 1, Ud); if (wave != 4 && blk_export_wave(wave) <= NBW + 1) blk_export_tile(S, a.Lb, nbd, J - 1, blk_export_wave(wave)); }
-            if (landing) blk_land_store(S, J + NBW + 1, tid - 64, BLK_HELP, lv);
+            double lv[BLK_LANDW]; const int Kl = J + NBW + 1; const bool landing = Kl < nJ, interior = 16 * Kl + 15 + S.bw < n_band;
+            if (landing) { if (interior) blk_land_load_fast(a.Sb, Kl, plan, lv); else blk_land_load(S, a.Sb, Kl, tid - 64, BLK_HELP, lv); }
+            if (J > 0) { blk_update<3>(S, J - 1, pslot, Ud); if (wave != 4 && blk_export_wave(wave) <= NBW + 1) blk_export_tile(S, a.Lb, nbd, J - 1, blk_export_wave(wave)); }
+            if (landing) blk_land_store_fast(S, pslot, tid - 64, BLK_HELP, plan, lv);
         }
         __syncthreads();                                      // (B) diagonal tile factored, deferred updates of J-1 done
-        if (wave > 0 && wave <= NBW + 1) blk_panel_tile(S, J, wave);
+        if (wave > 0 && wave <= NBW + 1) blk_panel_tile(S, J, jslot, wave);
         __syncthreads();                                      // (C) panel J in LDS
-        blk_update<1>(S, J, Uu);
+        blk_update<1>(S, J, jslot, Uu);
+        if (++jslot == S.TW) jslot = 0;
     }
     __syncthreads();
-    if (wave > 0) blk_update<3>(S, nJs - 1, Ud);              // the last block's deferred updates (border corner, separator)
+    if (wave > 0) blk_update<3>(S, nJs - 1, (nJs - 1) % S.TW, Ud);   // the last block's deferred updates (border corner, separator)
     if (wave > 0 && wave != 4 && blk_export_wave(wave) <= NBW + 1) blk_export_tile(S, a.Lb, nbd, nJs - 1, blk_export_wave(wave));
     __syncthreads();
     if (a.sep_out) {
@@ -1389,7 +1433,7 @@ int enqueue_solve_finish(nlls_ctx* c) {
         const int nbr = L.nbd + 1;
         const size_t lds = sizeof(double) * ((size_t)a.RC * L.H + 2 * (size_t)(2 * a.NSC * c->band_SEG + 2 * c->band_SEG) + (size_t)(L.bw + 2) * nbr + (size_t)nbr * nbr + nbr + 8);
         const int NBW = (L.bw + 15) / 16;                // tile rows below the diagonal tile that a block column reaches
-        const size_t blk_lds = sizeof(double) * ((size_t)(NBW + 2) * (NBW + 2) * 272 + 272 + 2 * (size_t)(NBW + 2) * 16 * 17 + 64 + 32 * 17 + 8);
+        const size_t blk_lds = sizeof(double) * ((size_t)(NBW + 2) * (NBW + 2) * 272 + 272 + 2 * (size_t)(NBW + 2) * 16 * 17 + 64 + 32 * 17 + 272 + 8);
         if (c->band_blocked && NBW <= 5 && (NBW + 2) * 16 <= 128 && L.H <= 96 && blk_lds <= 160 * 1024) {
             const int nJb = (L.n_band + 15) / 16, fsz = blk_fsize(NBW, L.nbd);
             // twisted (two-sided) factorisation: two workgroups, one from each end of the band, meet at a separator of
@@ -1412,7 +1456,7 @@ int enqueue_solve_finish(nlls_ctx* c) {
                 hipLaunchKernelGGL(band_sep_combine_kernel, dim3(8), dim3(256), 0, c->stream, (const double*)c->S.p, (const double*)sepA, (const double*)sepB, cA, ws, 16 * NBW, L.bw, L.nbd, L.H, Ssep);
                 BlkArgs2 bs{}; BlkArgs& q = bs.c[0]; q.Sb = Ssep; q.Lb = Lsep; q.corner_out = Lsep + (size_t)nJs2 * blk_fsize(NBWs, 0) + 128; q.sep_out = nullptr;
                 q.n_band = ws; q.bw = ws - 1; q.nbd = 0; q.H = ws + 1; q.NBW = NBWs; q.rev = 0; q.nJs = nJs2; q.status = c->d_status.p;
-                const size_t lds_s = sizeof(double) * ((size_t)(NBWs + 2) * (NBWs + 2) * 272 + 272 + 2 * (size_t)(NBWs + 2) * 16 * 17 + 64 + 32 * 17 + 8);
+                const size_t lds_s = sizeof(double) * ((size_t)(NBWs + 2) * (NBWs + 2) * 272 + 272 + 2 * (size_t)(NBWs + 2) * 16 * 17 + 64 + 32 * 17 + 272 + 8);
                 hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(BLK_T), lds_s, c->stream, bs);
                 BwdArgs2 b2{}; BwdArgs& r = b2.c[0]; r.Lt = Lsep; r.corner_in = q.corner_out; r.xr = c->s_ptr() + cA; r.n_band = ws; r.nbd = 0; r.NBW = NBWs; r.rev = 0; r.nJs = nJs2; r.xnext = -1; r.nxnext = 0; r.status = c->d_status.p;
                 const size_t lds_sb = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBWs) + 128 + 16);
