@@ -52,6 +52,26 @@ __global__ void schur_init_kernel(SLayout L, double* __restrict__ s, const doubl
     if (i < L.n) { s[i] = b[red_boff[i]]; return; }
     if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
 }
+// schur_init + schur_copy + the status reset in one launch (sparse systems): the first ninit workgroups initialise s (and
+// the padding of the dense layout), the rest copy one reduced-reduced block each
+__global__ __launch_bounds__(256) void schur_prepare_kernel(SLayout L, double* __restrict__ s, const double* __restrict__ b, const uint32_t* __restrict__ red_boff,
+                                                            const double* __restrict__ A, const SchurCopy* __restrict__ copies, double lambda, int ninit, int* __restrict__ status) {
+    if (blockIdx.x == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
+    if ((int)blockIdx.x < ninit) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < L.n) { s[i] = b[red_boff[i]]; return; }
+        if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+        return;
+    }
+    const SchurCopy cp = copies[blockIdx.x - ninit];
+    for (int e = threadIdx.x; e < cp.rows * cp.cols; e += 256) {
+        const int i = e % cp.rows, j = e / cp.rows;
+        double v = A[cp.off + e];
+        if (cp.r == cp.c) { if (i < j) continue; if (i == j) v += lambda; *L.at(cp.r + i, cp.c + j) = v; }
+        else if (cp.r > cp.c) *L.at(cp.r + i, cp.c + j) = v;
+        else *L.at(cp.c + j, cp.r + i) = v;          // the border reordering flipped this block: store its transpose
+    }
+}
 __global__ void schur_copy_kernel(SLayout L, const double* __restrict__ A, const SchurCopy* __restrict__ copies, double lambda) {
     const SchurCopy cp = copies[blockIdx.x];
     for (int e = threadIdx.x; e < cp.rows * cp.cols; e += blockDim.x) {
@@ -223,10 +243,15 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
                                                                 const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
                                                                 const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
                                                                 const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
-                                                                const double* __restrict__ Cinv, const double* __restrict__ xr, double* __restrict__ x, double* __restrict__ tE) {
+                                                                const double* __restrict__ Cinv, const double* __restrict__ xr, double* __restrict__ x, double* __restrict__ tE,
+                                                                uint32_t ngroups, const uint32_t* __restrict__ red_boff, int nred, int write_red) {
     constexpr int MAXC = (72 + 15) / 16;                      // columns per lane (nd <= 72)
     __shared__ uint32_t rc[80];
     const int lane = threadIdx.x, l = lane & 15, gsub = lane >> 4;
+    if (blockIdx.x >= ngroups) {                              // the workgroups behind the supernodes scatter the reduced part: x_R = -s
+        for (int i = (blockIdx.x - ngroups) * 64 + lane; i < nred; i += (gridDim.x - ngroups) * 64) x[red_boff[i]] = write_red ? -xr[i] : 0.0;
+        return;
+    }
     const uint32_t g = glist[blockIdx.x];
     const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
     const int64_t p0 = eptr[v0]; const int nnb = (int)(eptr[v0 + 1] - p0);
@@ -1389,10 +1414,15 @@ int enqueue_solve_local(nlls_ctx* c) {
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
     const SLayout L = make_layout(c); const int npad = L.npad;
     const bool band = c->solve_mode == SOLVE_BAND; const bool lead = c->nranks == 1 || c->rank == 0;
-    HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 4, c->stream));
+    const bool one_prepare = lead && c->info.is_sparse && c->ncopy > 0;      // status reset, s and the reduced-reduced blocks in one launch
+    if (!one_prepare) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
     if (c->nranks > 1) HIPCHK(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->info.ndof, c->stream));
-    if (lead) {
+    if (one_prepare) {
+        const int ninit = (std::max(npad, n) + 255) / 256;
+        hipLaunchKernelGGL(schur_prepare_kernel, dim3((unsigned)(ninit + c->ncopy)), dim3(256), 0, c->stream, L, c->s_ptr(), c->b.p, c->d_red_boff.p,
+                           c->A.p, c->d_copy.p, c->lambda, ninit, c->d_status.p);
+    } else if (lead) {
         hipLaunchKernelGGL(schur_init_kernel, dim3((std::max(npad, n) + 255) / 256), dim3(256), 0, c->stream, L, c->s_ptr(), c->b.p, c->d_red_boff.p);
         if (c->info.is_sparse) {
             if (c->ncopy > 0) hipLaunchKernelGGL(schur_copy_kernel, dim3((unsigned)c->ncopy), dim3(64), 0, c->stream, L, c->A.p, c->d_copy.p, c->lambda);
@@ -1510,8 +1540,9 @@ int enqueue_solve_finish(nlls_ctx* c) {
             hipLaunchKernelGGL(bwd_diag_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, npad, kb, n, acc, c->s_ptr());
         }
     }
-    // x = -solution
-    hipLaunchKernelGGL(scatter_reduced_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->s_ptr(), c->d_red_boff.p, n, c->x.p, (c->nranks == 1 || c->rank == 0) ? 1 : 0);
+    // x = -solution (folded into the fast back-substitution launch when there is one)
+    const int write_red = (c->nranks == 1 || c->rank == 0) ? 1 : 0;
+    if (c->n_fast_groups == 0) hipLaunchKernelGGL(scatter_reduced_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->s_ptr(), c->d_red_boff.p, n, c->x.p, write_red);
     const int64_t nel_local = (int64_t)(c->d_elim_diag.n);
     if (nel_local > 0) {
         const size_t lds = sizeof(double) * ((size_t)c->max_elim_dim * c->max_elim_dim + c->max_elim_dim);
@@ -1521,8 +1552,8 @@ int enqueue_solve_finish(nlls_ctx* c) {
             hipLaunchKernelGGL(schur_backsub_kernel, dim3((unsigned)nslow), dim3(64), lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
                                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->n_fast_groups > 0 ? c->d_slow_blocks.p : (const uint32_t*)nullptr,
                                c->lambda, c->max_elim_dim, c->s_ptr(), c->x.p);
-#define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p, \
-                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p)
+#define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + 32), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p, \
+                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red)
         if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; }
 #undef LAUNCH_BSF
     }

@@ -519,6 +519,7 @@ __global__ void retract_kernel(const int32_t* __restrict__ kind, const int32_t* 
     if (i >= nvar) return;
     const int k = kind[i], d = dim[i]; const uint32_t o = voff[i], bo = vboff[i];
     if (bo == DEST_NONE) { const int st = var_storage(k, d); for (int q = 0; q < st; ++q) to[o + q] = from[o + q]; return; }
+    if (k == NLLS_VAR_EUCLIDEAN) { for (int q = 0; q < d; ++q) to[o + q] = from[o + q] + x[bo + q]; return; }   // v + delta (src/variable.jl:5): no staging arrays
     double in[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], out[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], st[NLLS_MAX_BLOCK_SZ];
     const int ns = var_storage(k, d), nd = var_dof(k, d);
     for (int q = 0; q < ns; ++q) in[q] = from[o + q];
