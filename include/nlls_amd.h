@@ -199,6 +199,10 @@ int  nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out);
 /* replaces: update!(to, from, linsystem)  src/linearsystem.jl:206-213:
  * vars[to] = update(vars[from], x) for unfixed variables, copy for fixed ones. */
 int  nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from);
+/* One Levenberg-Marquardt trial (src/iterators.jl:149-157) in one call and one synchronisation:
+ * nlls_damp(dlambda); nlls_solve; nlls_retract(to, from); nlls_sweep_cost(to) -> *cost_out.  Same kernels in the same
+ * order; the step statistics and the quadratic form of the step are answered from the host afterwards.  Single GPU only. */
+int  nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, double* cost_out);
 
 /* ---- multi-GPU ----------------------------------------------------------------------
  * One process per GPU; nlls_set_shard(rank, nranks) BEFORE nlls_upload_structure.  Every rank uploads the

@@ -23,7 +23,7 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_lm_trial nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve""".split()
 
 
 class NllsError(RuntimeError):
@@ -86,7 +86,7 @@ def lib():
         L.nlls_solve.argtypes = [vp, vp]; L.nlls_set_step.argtypes = [vp, vp]; L.nlls_get_step.argtypes = [vp, vp]
         L.nlls_step_maxabs.argtypes = [vp, vp]; L.nlls_step_norm.argtypes = [vp, vp]
         L.nlls_quadform.argtypes = [vp, vp, vp]
-        L.nlls_retract.argtypes = [vp, i32, i32]
+        L.nlls_retract.argtypes = [vp, i32, i32]; L.nlls_lm_trial.argtypes = [vp, C.c_double, i32, i32, vp]
         L.nlls_sweep_gradhess_local.argtypes = [vp]; L.nlls_sweep_gradhess_finish.argtypes = [vp, vp]
         L.nlls_sweep_cost_local.argtypes = [vp, i32]; L.nlls_sweep_cost_finish.argtypes = [vp, vp]
         L.nlls_solve_local.argtypes = [vp]; L.nlls_solve_finish.argtypes = [vp, vp]
@@ -214,6 +214,12 @@ class Context:
         out = np.zeros(self.info.ndof) if want_x else None
         self._chk(self.L.nlls_solve(self.h, _p(out)))
         return out
+
+    def lm_trial(self, dlambda, to=VARS_NEXT, frm=VARS_CURRENT):
+        """damp + solve + retract + cost sweep in one call / one synchronisation; returns the trial cost."""
+        out = C.c_double()
+        self._chk(self.L.nlls_lm_trial(self.h, float(dlambda), to, frm, C.byref(out)))
+        return out.value
 
     def solve_stats(self):
         out = np.zeros(6, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 6))

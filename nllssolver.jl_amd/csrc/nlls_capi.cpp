@@ -197,6 +197,27 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
     if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");
     return NLLS_OK;
 }
+// One Levenberg-Marquardt trial in one call and one synchronisation (src/iterators.jl:149-157): uniformscaling!(H, dlambda),
+// solve!, negate!, update!(to, from, x), cost(to).  Same kernels, same order as the separate entry points.
+int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, double* cost_out) {
+    NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
+    if (ctx->nranks != 1) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_lm_trial is the single-GPU fast path; sharded runs use the *_local / *_finish pairs");
+    ctx->lambda += dlambda;
+    ctx->step_cached = false;
+    TRY(enqueue_solve(ctx));
+    TRY(enqueue_step_stats(ctx)); TRY(enqueue_quadform(ctx, ctx->x.p, 4));
+    TRY(enqueue_retract(ctx, to, from));
+    TRY(enqueue_sweep_cost(ctx, to));
+    int32_t status[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 10, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->solved = true;
+    ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9];
+    if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");
+    if (cost_out) *cost_out = ctx->h_scalars[0];
+    return NLLS_OK;
+}
 int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
     NEED_READY(); if (!out || n < 1) return NLLS_ERR_INVALID_ARG;
     int32_t status[16] = {0};

@@ -73,6 +73,12 @@ class ShardedLS(MultiVariateLSgpu):
         c = super().cost(which)                    # this rank's cost blocks only
         return c if self.world == 1 else self._allreduce_scalars([c])[0]
 
+    def lm_trial(self, dlambda):
+        if self.world == 1:
+            return super().lm_trial(dlambda)
+        self.uniformscaling(dlambda); self.solve(); self.update(_capi.VARS_NEXT, _capi.VARS_CURRENT)   # sharded: the separate steps
+        return self.cost(_capi.VARS_NEXT)
+
     def solve(self):
         if self.world == 1:
             return super().solve()

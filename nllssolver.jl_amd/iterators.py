@@ -56,13 +56,19 @@ def iterate_levmar(lmd, data, problem, options):    # src/iterators.jl:139-172
     lastlambda = 0.0
     mu = 2.0
     while True:
-        ls.uniformscaling(lmd.lambda_ - lastlambda)  # :149
-        lastlambda = lmd.lambda_
-        _timed(data, "timesolver", ls.solve)         # :152
-        data.linearsolvers += 1
-        ls.update(VARS_NEXT, VARS_CURRENT)           # :155
-        cost_ = _timed(data, "timecost", lambda: ls.cost(VARS_NEXT))   # :157
-        data.costcomputations += 1
+        if hasattr(ls, "lm_trial"):                   # :149-157 in one library call (same kernels, one synchronisation)
+            cost_ = _timed(data, "timesolver", lambda: ls.lm_trial(lmd.lambda_ - lastlambda))
+            lastlambda = lmd.lambda_
+            data.linearsolvers += 1
+            data.costcomputations += 1
+        else:
+            ls.uniformscaling(lmd.lambda_ - lastlambda)  # :149
+            lastlambda = lmd.lambda_
+            _timed(data, "timesolver", ls.solve)         # :152
+            data.linearsolvers += 1
+            ls.update(VARS_NEXT, VARS_CURRENT)           # :155
+            cost_ = _timed(data, "timecost", lambda: ls.cost(VARS_NEXT))   # :157
+            data.costcomputations += 1
         if not (cost_ > data.bestcost) or ls.step_maxabs() < options.dstep:   # :160
             ls.uniformscaling(-lastlambda)           # :162
             xHx, gx = ls.quadform()

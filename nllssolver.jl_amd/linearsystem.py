@@ -46,6 +46,12 @@ class MultiVariateLSgpu:
         self._x = None
         self.ctx.solve()
 
+    def lm_trial(self, dlambda):
+        """uniformscaling!(H, dlambda); solve!; update!(next, current); cost(next)   src/iterators.jl:149-157, fused
+        into one call of the library (one synchronisation).  Returns the trial cost."""
+        self._x = None
+        return self.ctx.lm_trial(dlambda, VARS_NEXT, VARS_CURRENT)
+
     def update(self, to=VARS_NEXT, frm=VARS_CURRENT):
         """update!(to, from, linsystem)   src/linearsystem.jl:206-213"""
         self.ctx.retract(to, frm)
