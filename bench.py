@@ -52,10 +52,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # NLLS_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on ONE GPU (all ranks on device 0, reductions staged through
+    # the host); the real run is one rank per GPU over RCCL
+    backend = os.environ.get("NLLS_BENCH_BACKEND", "nccl")
+    host_staged = backend != "nccl"
+    if host_staged:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_staged:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import nllssolver_jl_amd as N
@@ -71,7 +80,7 @@ def main():
     nobs = problem.ncosts()
     start_vars = problem.variables.copy()
 
-    ls = ShardedLS(problem, np.ones(problem.nvariables, bool), device=local_rank, rank=rank, world=world, dist=dist)
+    ls = ShardedLS(problem, np.ones(problem.nvariables, bool), device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged)
     info = ls.info
     # never terminate early inside the timed region: exactly K outer iterations
     options = N.NLLSOptions(maxiters=10 ** 9, reldcost=-np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
@@ -100,7 +109,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_staged else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
     data = loop.data
     final_cost, start_cost = data.bestcost, data.startcost
 
@@ -116,7 +125,7 @@ def main():
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # filled from a separate rocprofv3 --pmc pass
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1:     # the counters were collected on the unsharded sweep
         try:
             traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_sweep")
         except Exception:
