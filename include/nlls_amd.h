@@ -199,6 +199,15 @@ int  nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out);
 /* replaces: update!(to, from, linsystem)  src/linearsystem.jl:206-213:
  * vars[to] = update(vars[from], x) for unfixed variables, copy for fixed ones. */
 int  nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from);
+/* replaces: optimizesingles!(problem, options, indices)  src/optimize.jl:60-76,183-205.
+ * Every listed variable (1-based) is optimised on its own, all others fixed, against the cost blocks that depend on it:
+ * variable i owns the entries cptr[i] .. cptr[i+1]-1 (cptr[0] = 0) of (cgroup = index of the nlls_cost_group at upload,
+ * cindex = 0-based position of the block inside that group, cslot = which of the block's variables it is).  No block may
+ * contain two listed variables (the subproblems are solved side by side, one thread each).  Levenberg-Marquardt with the
+ * outer loop and termination rules of src/optimize.jl:109-180; operates on NLLS_VARS_CURRENT in place;
+ * iters_out (nsel, may be NULL) receives the iterations each variable took.  Variables of at most 6 dof. */
+int  nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices, const int64_t* cptr, const int32_t* cgroup, const int64_t* cindex,
+                           const int32_t* cslot, int32_t maxiters, int32_t maxfails, double reldcost, double absdcost, double dstep, int64_t* iters_out);
 /* One Levenberg-Marquardt trial (src/iterators.jl:149-157) in one call and one synchronisation:
  * nlls_damp(dlambda); nlls_solve; nlls_retract(to, from); nlls_sweep_cost(to) -> *cost_out.  Same kernels in the same
  * order; the step statistics and the quadratic form of the step are answered from the host afterwards.  Single GPU only. */

@@ -17,7 +17,7 @@ __all__ = ["kinds", "NLLSProblem", "NoRobust", "HuberKernel", "Huber2oKernel", "
 def __getattr__(name):
     # lazily expose the device-backed API so that host-only use (tests -m "not gpu") needs no .so
     import importlib
-    if name in ("optimize", "NLLSOptions", "NLLSResult", "cost", "NLLSIterator", "newton", "levenbergmarquardt", "dogleg",
+    if name in ("optimize", "optimizesingles", "NLLSOptions", "NLLSResult", "cost", "NLLSIterator", "newton", "levenbergmarquardt", "dogleg",
                 "gradientdescent"):
         return getattr(importlib.import_module(__name__ + ".optimizer"), name)
     if name in ("MultiVariateLSgpu", "makesymmvls"):

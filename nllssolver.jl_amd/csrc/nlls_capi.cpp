@@ -218,6 +218,42 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     if (cost_out) *cost_out = ctx->h_scalars[0];
     return NLLS_OK;
 }
+// optimizesingles!(problem, options, indices)  src/optimize.jl:60-76,183-205
+int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices, const int64_t* cptr, const int32_t* cgroup, const int64_t* cindex,
+                          const int32_t* cslot, int32_t maxiters, int32_t maxfails, double reldcost, double absdcost, double dstep, int64_t* iters_out) {
+    NEED_READY();
+    if (nsel < 0 || (nsel > 0 && (!varindices || !cptr))) return NLLS_ERR_INVALID_ARG;
+    if (ctx->nranks != 1) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles runs unsharded");
+    if (nsel == 0) return NLLS_OK;
+    const int64_t nc = cptr[nsel];
+    if (cptr[0] != 0 || nc < 0 || (nc > 0 && (!cgroup || !cindex || !cslot))) return NLLS_ERR_INVALID_ARG;
+    std::vector<int64_t> sel(nsel); std::vector<uint32_t> cidx((size_t)nc);
+    for (int64_t i = 0; i < nsel; ++i) {
+        const int64_t v = varindices[i] - 1;
+        if (v < 0 || v >= ctx->info.nvar || cptr[i + 1] < cptr[i]) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: bad variable index or cost list");
+        if (var_dof(ctx->var_kind[v], ctx->var_dim[v]) > 6) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles: variable with more than 6 degrees of freedom");
+        sel[i] = v;
+    }
+    for (int64_t e = 0; e < nc; ++e) {
+        if (cgroup[e] < 0 || cgroup[e] >= (int32_t)ctx->groups.size()) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: bad cost group");
+        const Group& G = ctx->groups[cgroup[e]];
+        if (cindex[e] < 0 || cindex[e] >= G.ncost || cslot[e] < 0 || cslot[e] >= G.ndeps) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: bad cost index or slot");
+        if (G.adaptive && cslot[e] == 0) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles: the adaptive kernel variable cannot be optimised on its own");
+        cidx[e] = (uint32_t)cindex[e];
+    }
+    std::vector<unsigned char> gbuf(singles_group_size() * ctx->groups.size());
+    for (size_t g = 0; g < ctx->groups.size(); ++g) singles_group_fill(gbuf.data() + g * singles_group_size(), ctx->groups[g]);
+    DevBuf<int64_t> d_sel, d_cptr, d_iters; DevBuf<int32_t> d_cgroup, d_cslot; DevBuf<uint32_t> d_cidx; DevBuf<unsigned char> d_groups;
+    std::vector<int64_t> cp(cptr, cptr + nsel + 1); std::vector<int32_t> cg(cgroup, cgroup + nc), cs(cslot, cslot + nc);
+    HIPCHK(d_sel.upload(sel)); HIPCHK(d_cptr.upload(cp)); HIPCHK(d_cgroup.upload(cg)); HIPCHK(d_cslot.upload(cs)); HIPCHK(d_cidx.upload(cidx));
+    HIPCHK(d_groups.upload(gbuf)); HIPCHK(d_iters.alloc((size_t)nsel));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->have_grad = false; ctx->solved = false; ctx->step_cached = false; ctx->tE_valid = false;   // the variables change under the linear system
+    TRY(enqueue_optimize_singles(ctx, nsel, d_sel.p, d_cptr.p, d_cgroup.p, d_cidx.p, d_cslot.p, d_groups.p, maxiters, maxfails, reldcost, absdcost, dstep, d_iters.p));
+    if (iters_out) HIPCHK(hipMemcpyAsync(iters_out, d_iters.p, sizeof(int64_t) * nsel, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NLLS_OK;
+}
 int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
     NEED_READY(); if (!out || n < 1) return NLLS_ERR_INVALID_ARG;
     int32_t status[16] = {0};

@@ -193,6 +193,31 @@ def optimize(problem, options=None, unfixed=None, callback=nullcallback, flags=0
     return NLLSResult(data)
 
 
+def optimizesingles(problem, options=None, indices=None, kind=None, dim=None, device=0):
+    """optimizesingles!(problem, options, indices | type)   src/optimize.jl:60-76,183-205: every listed variable is
+    optimised on its own (all others fixed) against the cost blocks that depend on it.  `indices` 1-based, or select by
+    variable kind (and dimension), like the reference's `type` argument.  Levenberg-Marquardt only (the default
+    iterator); one GPU thread per variable.  Returns the iterations each variable took."""
+    options = options or NLLSOptions()
+    assert options.iterator == levenbergmarquardt, "optimizesingles on the device implements the Levenberg-Marquardt iterator"
+    if indices is None:
+        sel = problem.var_kind == kind
+        if dim is not None:
+            sel &= problem.var_dim == dim
+        indices = np.nonzero(sel)[0] + 1
+    indices = np.asarray(indices, dtype=np.int64)
+    # "sorted in order of variable size" (src/optimize.jl:67): the order does not matter for independent subproblems
+    cptr, cgroup, cindex, cslot = problem.costlists(indices)
+    ls = makesymmvls(problem, np.ones(problem.nvariables, bool), 0, device)
+    try:
+        iters = ls.ctx.optimize_singles(indices, cptr, cgroup, cindex, cslot, options.maxiters, options.maxfails,
+                                        options.reldcost, options.absdcost, options.dstep)
+        problem.variables[:] = ls.variables(VARS_CURRENT)
+    finally:
+        ls.close()
+    return iters
+
+
 def cost(problem, device=0):
     """cost(problem)   src/cost.jl:9"""
     ls = makesymmvls(problem, np.ones(problem.nvariables, bool), 0, device)

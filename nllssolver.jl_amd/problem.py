@@ -179,6 +179,26 @@ class NLLSProblem:
         np.cumsum(counts, out=colptr[1:]); colptr[1:] += 1
         return colptr, rowval
 
+    def costlists(self, indices):
+        """For each variable in `indices` (1-based): the cost blocks that depend on it, as the CSR lists
+        (cptr, cgroup, cindex, cslot) that nlls_optimize_singles takes -- sparse(getvarcostmap(problem)') restricted to
+        the listed variables, src/optimize.jl:62.  Raises if a block holds two listed variables (the subproblems would
+        not be independent)."""
+        indices = np.asarray(indices, dtype=np.int64)
+        pos = np.full(self.nvariables + 1, -1, np.int64); pos[indices] = np.arange(indices.size)
+        owners, groups, cidx, slots = [], [], [], []
+        for gi, g in enumerate(self.costs.values()):
+            vi, _ = g.arrays()
+            hit = pos[vi]                                       # (n x ndeps): position in `indices` or -1
+            assert np.all((hit >= 0).sum(axis=1) <= 1), "a cost block depends on two of the listed variables"
+            k, s = np.nonzero(hit >= 0)
+            owners.append(hit[k, s]); groups.append(np.full(k.size, gi, np.int32)); cidx.append(k.astype(np.int64)); slots.append(s.astype(np.int32))
+        owners = np.concatenate(owners) if owners else np.zeros(0, np.int64)
+        order = np.argsort(owners, kind="stable")
+        cptr = np.zeros(indices.size + 1, np.int64); np.cumsum(np.bincount(owners, minlength=indices.size), out=cptr[1:])
+        cat = lambda xs, dt: (np.concatenate(xs)[order] if xs else np.zeros(0, dt))
+        return cptr, cat(groups, np.int32), cat(cidx, np.int64), cat(slots, np.int32)
+
     def reordercostsforschur(self, schurvars):
         """reordercostsforschur!(problem, schurvars): group each cost type's blocks by the Schur
         variable they touch (0 = none).  Returns {key: run indices (1-based)}.

@@ -158,3 +158,48 @@ def test_sweep_total_is_never_stale():
         ctx.set_variables((va, vb)[it & 1])
         assert (ctx.sweep_gradhess(), ctx.sweep_cost()) == expect[it & 1], f"iteration {it}"
     ctx.close()
+
+
+def _oracle_optimizesingles(problem, indices, **opts):
+    """optimizesingles! on the CPU oracle: one sub-problem per variable -- the cost blocks that depend on it, only that
+    variable free (src/optimize.jl:183-205) -- through the oracle's own optimize loop."""
+    from oracle import oracle as O
+    cptr, cgroup, cindex, cslot = problem.costlists(indices)
+    out = problem.variables.copy()
+    gl = list(problem.costs.values())
+    voff = np.concatenate([[0], np.cumsum([K.var_storage(k, d) for k, d in zip(problem.var_kind, problem.var_dim)])])
+    for t, v in enumerate(indices):
+        groups = []
+        for gi in sorted(set(cgroup[cptr[t]:cptr[t + 1]].tolist())):
+            sel = cindex[cptr[t]:cptr[t + 1]][cgroup[cptr[t]:cptr[t + 1]] == gi]
+            vi, da = gl[gi].arrays()
+            d = dict(gl[gi].as_dict()); d["varind"] = np.ascontiguousarray(vi[sel]); d["data"] = np.ascontiguousarray(da[sel])
+            groups.append(d)
+        op = O.OracleProblem(problem.var_kind, problem.var_dim, groups); op.set_variables(problem.variables)
+        bi = np.zeros(problem.nvariables, np.uint64); bi[v - 1] = 1
+        op.optimize(bi, **opts)
+        res = op.get_variables()
+        out[voff[v - 1]:voff[v]] = res[voff[v - 1]:voff[v]]
+    return out
+
+
+def test_optimizesingles_points():            # test/optimizeba.jl:56-62: landmarks only, then cost < 1e-15
+    p = synthetic.create_ba_problem(3, 5, 1.0, seed=1)
+    p = synthetic.perturb_ba_problem(p, 0.003, 0.0)               # perturb the points only
+    pts = np.nonzero((p.var_kind == K.VAR_EUCLIDEAN) & (p.var_dim == 3))[0] + 1
+    expect = _oracle_optimizesingles(p, pts)
+    iters = N.optimizesingles(p, N.NLLSOptions(), kind=K.VAR_EUCLIDEAN, dim=3)
+    assert iters.size == pts.size and np.all(iters >= 1)
+    assert N.cost(p) < 1e-15
+    assert np.max(np.abs(p.variables - expect)) < 1e-9
+
+
+def test_optimizesingles_robust_matches_oracle():   # robustified blocks, non-zero optimum per point
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(12, 120, 0.4, seed=5, robust=N.HuberKernel(0.01),
+                                                                 outlier_frac=0.1, outlier_sigma=0.05), 3e-3, 0.0)
+    pts = np.nonzero((p.var_kind == K.VAR_EUCLIDEAN) & (p.var_dim == 3))[0] + 1
+    c0 = N.cost(p)
+    expect = _oracle_optimizesingles(p, pts)
+    N.optimizesingles(p, N.NLLSOptions(), indices=pts)
+    assert N.cost(p) < c0
+    assert np.max(np.abs(p.variables - expect)) < 1e-7
