@@ -30,6 +30,7 @@ CONFIGS = {
     # name: (ncameras, npoints, propvisible)            BASELINE.json configs[2], configs[3]
     "ba_100x10k": (100, 10_000, 0.1),
     "ba_1kx100k": (1000, 100_000, 0.01),
+    "ba_10kx1M": (10_000, 1_000_000, 0.001),            # 10x config 4 (not in BASELINE.json): 10M residual blocks, A.data 1.5 GB
 }
 
 

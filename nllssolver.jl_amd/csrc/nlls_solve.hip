@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
 //     updated between the factorisations of J and J+1 (all four waves, one or two tiles each); the tiles of columns
 //     J+2..J+NBW and the border corner are updated by waves 1-3 WHILE wave 0 factors block J+1;
 //   * waves 1-3 also stream the next tile column in from HBM and the previous block's factor out (band layout,
-//     consumed by band_backward_kernel) behind wave 0's factorisation.
+//     consumed by band_backward_tiles_kernel) behind wave 0's factorisation.
 // Tiles live in an LDS ring indexed by (block column mod (NBW+2), tile row), rows padded to 17 doubles.
 // ---------------------------------------------------------------------------------------------------
 // rev / nJs / sep_out: twisted (two-sided) factorisation -- one workgroup takes the band from the top, a second one from
@@ -950,8 +950,6 @@ __device__ __forceinline__ void blk_land_store(const BlkLds& S, int slot, int t0
         if (w < nwords) { const int ti = w >> 8, cc = (w >> 4) & 15, r = w & 15; base[(size_t)ti * BLK_TS + r * P + cc] = val[q]; }
     }
 }
-__device__ __forceinline__ void blk_land(const BlkLds& S, const double* __restrict__ Sb, int K, int t0, int nt) {
-    for (int w0 = t0; w0 < S.TR * 256; w0 += nt * BLK_LANDW) { double v[BLK_LANDW]; blk_land_load(S, Sb, K, w0, nt, v); blk_land_store(S, K % S.TW, w0, nt, v); }
 }
 // The same landing for an INTERIOR tile column (every entry it reads exists: 16 K + 15 + bw < n_band), from a per-thread
 // plan made once: a word's LDS offset, its offset in the band array for column 0 and the (signed) stride per column do
