@@ -950,7 +950,6 @@ __device__ __forceinline__ void blk_land_store(const BlkLds& S, int slot, int t0
         if (w < nwords) { const int ti = w >> 8, cc = (w >> 4) & 15, r = w & 15; base[(size_t)ti * BLK_TS + r * P + cc] = val[q]; }
     }
 }
-}
 // The same landing for an INTERIOR tile column (every entry it reads exists: 16 K + 15 + bw < n_band), from a per-thread
 // plan made once: a word's LDS offset, its offset in the band array for column 0 and the (signed) stride per column do
 // not depend on K.  This is what runs at (almost) every block step; the general form above handles the ends.
