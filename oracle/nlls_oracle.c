@@ -802,7 +802,8 @@ int oracle_solve_damped(oracle_ls* ls, double lambda) { /* iterators.jl:149-152,
         for (int64_t c = 0; c < n; ++c) for (int64_t q = ls->h_cp[c] - 1; q < ls->h_cp[c + 1] - 1; ++q) if (ls->h_rv[q] - 1 == c) ls->h_nz[q] += lambda;
         if (!ls->have_fac) { /* ldl_analyze once, linearsystem.jl:68 */
             int64_t nnz = ls->h_nnz; ls->Ap0 = (int64_t*)malloc(sizeof(int64_t) * (n + 1)); ls->Ai0 = (int64_t*)malloc(sizeof(int64_t) * nnz);
-            for (int64_t j = 0; j <= n; ++j) ls->Ap0[j] = ls->h_cp[j] - 1; for (int64_t q = 0; q < nnz; ++q) ls->Ai0[q] = ls->h_rv[q] - 1;
+            for (int64_t j = 0; j <= n; ++j) ls->Ap0[j] = ls->h_cp[j] - 1;
+            for (int64_t q = 0; q < nnz; ++q) ls->Ai0[q] = ls->h_rv[q] - 1;
             /* block-level minimum degree, expanded to scalars */
             int64_t nb = ls->nblocks; int64_t* bcp = (int64_t*)calloc(nb + 1, sizeof(int64_t));
             for (int64_t row = 0; row < nb; ++row) for (int64_t q = ls->it_cp[row] - 1; q < ls->it_cp[row + 1] - 1; ++q) { int64_t col = ls->it_rv[q] - 1; if (col != row) { bcp[row + 1]++; bcp[col + 1]++; } }
