@@ -830,9 +830,10 @@ __global__ __launch_bounds__(256) void band_ldlt_solve_kernel(BandArgs a) {
 //     v_readlane (the diagonal tile is kept fully symmetric, so row k of it supplies all multipliers), no LDS
 //     traffic and no barrier inside the block.  The panel W = L*D and 1/D go to LDS (two buffers, by block parity);
 //   * the rank-16 trailing update runs tile by tile on the fp64 matrix cores, C(16x16) -= W_I * (W_K / D)', four
-//     v_mfma_f64_16x16x4_f64 per tile, and is split by urgency (look-ahead): only the tiles of block column J+1 are
-//     updated between the factorisations of J and J+1 (all four waves, one or two tiles each); the tiles of columns
-//     J+2..J+NBW and the border corner are updated by waves 1-3 WHILE wave 0 factors block J+1;
+//     v_mfma_f64_16x16x4_f64 per tile, and is split by urgency (look-ahead): between the factorisations of J and J+1
+//     wave 0 forms only W_1 and updates only the DIAGONAL tile of block column J+1; every other tile-update of block J
+//     (the rest of column J+1, columns J+2..J+NBW, the border corner) is done by the helper waves WHILE wave 0
+//     factors block J+1;
 //   * waves 1-3 also stream the next tile column in from HBM and the previous block's factor out (band layout,
 //     consumed by band_backward_tiles_kernel) behind wave 0's factorisation.
 // Tiles live in an LDS ring indexed by (block column mod (NBW+2), tile row), rows padded to 17 doubles.
@@ -1101,34 +1102,36 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
 #pragma unroll
         for (int K = 0; K < 6; ++K) if (K <= NBW && K < nJ) blk_land_store(S, K, tid, BLK_T, pv[K]);   // slot = column (K < TW)
     }
-    // urgent tile-updates (block column J+1): NBW+1 of them over the four waves; deferred ones (the rest): over waves 1-3
-    const int nup = NBW * (NBW + 1) / 2 + NBW + 1, nurgent = NBW + 1;
+    // Tile-updates of a block step (blk_update_list numbering): u = 0 is the DIAGONAL tile of block column J+1 -- the only
+    // one the next factorisation waits for: wave 0 applies it itself, right after the panel tile it needs (W_1), and goes
+    // on to factor J+1.  All the others -- the rest of column J+1 (needed by the panel step of J+1, one factorisation
+    // later), columns J+2..J+NBW and the border corner -- are done by the helper waves while wave 0 factors J+1.
+    const int nup = NBW * (NBW + 1) / 2 + NBW + 1;
     constexpr int NW = BLK_T / 64;
-    BlkUpd<1> Uu; blk_update_list<1>(S, 0, nurgent, wave, NW, Uu);
-    BlkUpd<3> Ud; blk_update_list<3>(S, nurgent, nup - nurgent, wave - 1, NW - 1, Ud);
+    BlkUpd<1> U0; blk_update_list<1>(S, 0, 1, wave == 0 ? 0 : -1, 1, U0);
+    BlkUpd<3> Uh; blk_update_list<3>(S, 1, nup - 1, wave - 1, NW - 1, Uh);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();   // diagnostics only (nlls_get_solve_stats)
     int jslot = 0;                                            // J % TW, kept incrementally (no integer division in the loop)
     BlkLandPlan plan; blk_land_plan(S, tid - 64, BLK_HELP, plan);
+    __syncthreads();                                          // the first tile columns have landed
     for (int J = 0; J < nJs; ++J) {
         const int pslot = jslot == 0 ? S.TW - 1 : jslot - 1;  // slot of column J-1 = slot of column J+NBW+1
-        __syncthreads();                                      // (A) block column J is final
         if (wave == 0) blk_factor(S, J, jslot, a.status);
         else {
-            // helpers, hidden behind wave 0's factorisation: the deferred tile-updates of block J-1, tile column
-            // J+NBW+1 into the ring slot of column J-1 (HBM latency), block J-1's factor out
+            // helpers, behind wave 0's factorisation: block J-1's remaining tile-updates, tile column J+NBW+1 into the
+            // ring slot of column J-1 (HBM latency), block J-1's factor out
             double lv[BLK_LANDW]; const int Kl = J + NBW + 1; const bool landing = Kl < nJ, interior = 16 * Kl + 15 + S.bw < n_band;
             if (landing) { if (interior) blk_land_load_fast(a.Sb, Kl, plan, lv); else blk_land_load(S, a.Sb, Kl, tid - 64, BLK_HELP, lv); }
-            if (J > 0) { blk_update<3>(S, J - 1, pslot, Ud); if (wave != 4 && blk_export_wave(wave) <= NBW + 1) blk_export_tile(S, a.Lb, nbd, J - 1, blk_export_wave(wave)); }
+            if (J > 0) { blk_update<3>(S, J - 1, pslot, Uh); if (wave != 4 && blk_export_wave(wave) <= NBW + 1) blk_export_tile(S, a.Lb, nbd, J - 1, blk_export_wave(wave)); }
             if (landing) blk_land_store_fast(S, pslot, tid - 64, BLK_HELP, plan, lv);
         }
-        __syncthreads();                                      // (B) diagonal tile factored, deferred updates of J-1 done
-        if (wave > 0 && wave <= NBW + 1) blk_panel_tile(S, J, jslot, wave);
-        __syncthreads();                                      // (C) panel J in LDS
-        blk_update<1>(S, J, jslot, Uu);
+        __syncthreads();                                      // (B) diagonal tile factored; block J-1's updates all applied: column J is final
+        if (wave == 0) { blk_panel_tile(S, J, jslot, 1); blk_update<1>(S, J, jslot, U0); }   // W_1, then the diagonal tile of column J+1
+        else if (wave <= NBW) blk_panel_tile(S, J, jslot, wave + 1);                          // W_2 .. W_{NBW+1}
+        __syncthreads();                                      // (C) panel J in LDS; the next diagonal tile is ready
         if (++jslot == S.TW) jslot = 0;
     }
-    __syncthreads();
-    if (wave > 0) blk_update<3>(S, nJs - 1, (nJs - 1) % S.TW, Ud);   // the last block's deferred updates (border corner, separator)
+    if (wave > 0) blk_update<3>(S, nJs - 1, (nJs - 1) % S.TW, Uh);   // the last block's remaining updates (border corner, separator)
     if (wave > 0 && wave != 4 && blk_export_wave(wave) <= NBW + 1) blk_export_tile(S, a.Lb, nbd, nJs - 1, blk_export_wave(wave));
     __syncthreads();
     if (a.sep_out) {
