@@ -383,6 +383,26 @@ struct BlockGH {
                 for (int q = 0; q < var_storage(R::SK[S], R::SD[S]); ++q) st[S][q] = vars[voff[S] + q]; }(), ...);
         }(std::make_integer_sequence<int, R::NDEPS>{});
     }
+    // the same without slot SKIP (a heavy tile's own variable is the same for every entry: gathered once per tile)
+    template <int SKIP>
+    static NLLS_DEV void load_skip(const double* __restrict__ vars, const uint32_t* voff, double (*st)[MAXST]) {
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+                if constexpr (S != SKIP) {
+#pragma unroll
+                    for (int q = 0; q < var_storage(R::SK[S], R::SD[S]); ++q) st[S][q] = vars[voff[S] + q]; } }(), ...);
+        }(std::make_integer_sequence<int, R::NDEPS>{});
+    }
+    template <int ONLY>
+    static NLLS_DEV void load_only(const double* __restrict__ vars, const uint32_t* voff, double (*st)[MAXST]) {
+#pragma unroll
+        for (int q = 0; q < var_storage(R::SK[ONLY], R::SD[ONLY]); ++q) st[ONLY][q] = vars[voff[ONLY] + q];
+    }
+    template <int ONLY>
+    static NLLS_DEV void copy_only(const double (*from)[MAXST], double (*st)[MAXST]) {
+#pragma unroll
+        for (int q = 0; q < var_storage(R::SK[ONLY], R::SD[ONLY]); ++q) st[ONLY][q] = from[ONLY][q];
+    }
     // forces the gathered values into registers at this point of the program, i.e. places their s_waitcnt here
     static NLLS_DEV void pin(double (*st)[MAXST]) {
         [&]<int... S>(std::integer_sequence<int, S...>) {

@@ -262,7 +262,7 @@ constexpr int HTPB = 128;  // two wavefronts per heavy tile, each walking every 
 constexpr int HROWS = TPB / HTPB;   // heavy tiles per workgroup
 constexpr int HCHUNK = 14;          // accumulators reduced per pass through the transposed LDS image
 NLLS_HD size_t gh_heavy_lds(uint32_t heavy_img) { return (size_t)HROWS * heavy_img + (size_t)HCHUNK * (TPB + 1); }   // doubles
-template <int KIND, int SLOT, int DEPTH>   // DEPTH: stages of the register pipeline (3 alone; 2 when fused: other workgroups on the CU hide latency, registers are scarce)
+template <int KIND, int SLOT, int DEPTH>   // DEPTH: stages of the register pipeline (3 alone; 2 when fused: measured equal there, and 3 would spill)
 __device__ __forceinline__ void gh_heavy_body(const GhArgs& g, uint32_t wg, uint32_t heavy_img, double* dyn) {
     using R = Res<KIND>; using I = ResInfo<KIND>;
     constexpr int DS = I::dof(SLOT);
@@ -296,7 +296,7 @@ __device__ __forceinline__ void gh_heavy_body(const GhArgs& g, uint32_t wg, uint
     using St = double[R::NDEPS][MAXST];
     auto stage = [&](uint32_t e2, const Rec& cur, const St& cst, const Rec& nxt, St& nst, Rec& nn) {
         load_rec(e2, nn);                                        // entry record two stages ahead
-        BlockGH<KIND>::load(vars, nxt.vo, nst);                  // gathers one stage ahead
+        BlockGH<KIND>::template load_skip<SLOT>(vars, nxt.vo, nst);   // gathers one stage ahead (the row's own variable is already there)
         if (cur.ok) {
             BlockGH<KIND> B; B.compute_st(cst, cur.d, rk, (cur.ds[SLOT] & OWN_KERNEL_FREE) != 0);
             if (cur.ds[SLOT] & OWN_COST_OWNER) acc[NACC - 1] += B.cost;
@@ -332,6 +332,7 @@ __device__ __forceinline__ void gh_heavy_body(const GhArgs& g, uint32_t wg, uint
             load_rec(t.e0 + ht, r0);
             load_rec(t.e0 + HTPB + ht, r1);
             BlockGH<KIND>::load(vars, r0.vo, s0);
+            BlockGH<KIND>::template copy_only<SLOT>(s0, s1); BlockGH<KIND>::template copy_only<SLOT>(s0, s2);   // the row's own variable: once per tile
 #pragma unroll 1
             for (uint32_t base = t.e0; base < t.e1; base += 3 * HTPB) {   // roles rotate through the three register sets
                 stage(base + 2 * HTPB + ht, r0, s0, r1, s1, r2);
@@ -343,7 +344,7 @@ __device__ __forceinline__ void gh_heavy_body(const GhArgs& g, uint32_t wg, uint
         // two register sets: entry record and gathers of entry i+1 are requested back to back while entry i is evaluated
         auto stage2 = [&](uint32_t e1, const Rec& cur, const St& cst, Rec& nxt, St& nst) {
             load_rec(e1, nxt);
-            BlockGH<KIND>::load(vars, nxt.vo, nst);
+            BlockGH<KIND>::template load_skip<SLOT>(vars, nxt.vo, nst);
             Rec dummy;                                               // stage() wants a record two ahead: none here
             (void)dummy;
             if (cur.ok) {
@@ -377,6 +378,7 @@ __device__ __forceinline__ void gh_heavy_body(const GhArgs& g, uint32_t wg, uint
             Rec r0, r1; St s0, s1;
             load_rec(t.e0 + ht, r0);
             BlockGH<KIND>::load(vars, r0.vo, s0);
+            BlockGH<KIND>::template copy_only<SLOT>(s0, s1);
 #pragma unroll 1
             for (uint32_t base = t.e0; base < t.e1; base += 2 * HTPB) {
                 stage2(base + HTPB + ht, r0, s0, r1, s1);
@@ -385,19 +387,29 @@ __device__ __forceinline__ void gh_heavy_body(const GhArgs& g, uint32_t wg, uint
         }
     }
     // fixed-order reduction of the row's diagonal block, b and cost through a transposed LDS image, HCHUNK accumulators per
-    // pass: thread v of the row sums the HTPB lane-partials of accumulator v (row pitch TPB+1 doubles: conflict-free both
-    // ways) and then owns its destination
+    // pass: HSUB neighbouring lanes share one accumulator (each sums HTPB/HSUB lane-partials, row pitch TPB+1 doubles),
+    // a fixed xor tree joins them, and the first lane of the group owns the destination
+    constexpr int HSUB = 8;
+    static_assert(HCHUNK * HSUB <= HTPB && (HTPB % (4 * HSUB)) == 0);
 #pragma unroll
     for (int c0 = 0; c0 < NACC; c0 += HCHUNK) {
 #pragma unroll
         for (int i = 0; i < HCHUNK; ++i) if (c0 + i < NACC) hred[i][threadIdx.x] = acc[c0 + i];
         __syncthreads();
-        if (ht < HCHUNK && c0 + ht < NACC && live) {
-            const int v = c0 + ht; const double* hr = &hred[ht][half * HTPB];
+        const int hv = ht / HSUB, hp = ht % HSUB;
+        const bool mine = hv < HCHUNK && c0 + hv < NACC;
+        double sum = 0;
+        if (mine) {
+            const double* hr = &hred[hv][half * HTPB + hp * (HTPB / HSUB)];
             double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll 4
-            for (int k = 0; k < HTPB; k += 4) { s0 += hr[k]; s1 += hr[k + 1]; s2 += hr[k + 2]; s3 += hr[k + 3]; }   // (the later chunks' accumulators are still live: modest unroll)
-            const double sum = (s0 + s1) + (s2 + s3);
+#pragma unroll
+            for (int k = 0; k < HTPB / HSUB; k += 4) { s0 += hr[k]; s1 += hr[k + 1]; s2 += hr[k + 2]; s3 += hr[k + 3]; }
+            sum = (s0 + s1) + (s2 + s3);
+        }
+#pragma unroll
+        for (int m = 1; m < HSUB; m <<= 1) sum += __shfl_xor(sum, m);     // groups are aligned runs of HSUB lanes
+        if (mine && hp == 0 && live) {
+            const int v = c0 + hv;
             if (v == NACC - 1) g.partials[tile] = sum;
             else if (v >= NTRI) { const int i = v - NTRI; if (t.flags & TILE_PARTIAL) atomicAdd(&b[t.b_off + i], sum); else b[t.b_off + i] = sum; }
             else {
