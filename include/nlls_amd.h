@@ -235,6 +235,10 @@ int  nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count
                          int64_t* own_offset, int64_t* own_count);
 /* [0] rank, [1] nranks, [2] cost blocks owned, [3] doubles of A.data this rank writes, [4] dof of b it writes */
 int  nlls_get_shard_info(nlls_ctx* ctx, int64_t* out, int32_t n);
+/* this rank's share of the gradient b (length ndof): the rows of the eliminated blocks it owns, the reduced rows on
+ * rank 0, zeros elsewhere -- the sum over ranks is the full gradient that gethessgrad (src/linearsystem.jl:190) hands to
+ * the dogleg / gradient-descent iterators (src/iterators.jl:48,191).  nranks == 1: identical to nlls_get_grad. */
+int  nlls_get_grad_owned(nlls_ctx* ctx, double* b_out);
 
 /* ---- profiling helper: run the accumulate kernel(s) `reps` times between two HIP events on the
  * context's stream; returns average ms per sweep (used by bench.py for the roofline line). */

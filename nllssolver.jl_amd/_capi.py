@@ -23,7 +23,7 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve""".split()
 
 
 class NllsError(RuntimeError):
@@ -79,7 +79,7 @@ def lib():
         L.nlls_set_variables.argtypes = [vp, i32, vp]; L.nlls_get_variables.argtypes = [vp, i32, vp]
         L.nlls_swap_variables.argtypes = [vp, i32, i32]; L.nlls_copy_variables.argtypes = [vp, i32, i32]
         L.nlls_sweep_gradhess.argtypes = [vp, vp]; L.nlls_sweep_cost.argtypes = [vp, i32, vp]
-        L.nlls_get_grad.argtypes = [vp, vp]; L.nlls_get_bsm_data.argtypes = [vp, vp]
+        L.nlls_get_grad.argtypes = [vp, vp]; L.nlls_get_bsm_data.argtypes = [vp, vp]; L.nlls_get_grad_owned.argtypes = [vp, vp]
         L.nlls_max_abs_diag.argtypes = [vp, vp]; L.nlls_grad_sqnorm.argtypes = [vp, vp]; L.nlls_grad_quadform.argtypes = [vp, vp]
         L.nlls_damp.argtypes = [vp, dbl]
         L.nlls_get_solve_stats.argtypes = [vp, vp, i32]
@@ -195,6 +195,9 @@ class Context:
 
     def get_grad(self):
         out = np.zeros(self.info.ndof); self._chk(self.L.nlls_get_grad(self.h, _p(out))); return out
+
+    def get_grad_owned(self):
+        out = np.zeros(self.info.ndof); self._chk(self.L.nlls_get_grad_owned(self.h, _p(out))); return out
 
     def get_bsm_data(self):
         out = np.zeros(self.info.nnz_data); self._chk(self.L.nlls_get_bsm_data(self.h, _p(out))); return out

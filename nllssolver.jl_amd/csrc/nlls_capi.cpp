@@ -343,6 +343,15 @@ int nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count,
     if (own_offset) *own_offset = 0; if (own_count) *own_count = ctx->info.ndof;
     return NLLS_OK;
 }
+int nlls_get_grad_owned(nlls_ctx* ctx, double* b_out) {
+    TRY(nlls_get_grad(ctx, b_out));
+    if (ctx->nranks > 1) {
+        std::vector<double> mask((size_t)ctx->info.ndof);
+        HIPCHK(hipMemcpy(mask.data(), ctx->d_dof_mask.p, sizeof(double) * mask.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < mask.size(); ++i) if (mask[i] == 0.0) b_out[i] = 0.0;
+    }
+    return NLLS_OK;
+}
 int nlls_get_shard_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
     NEED_READY(); if (!out || n < 1) return NLLS_ERR_INVALID_ARG;
     const int64_t vals[5] = {ctx->rank, ctx->nranks, ctx->local_ncost, ctx->local_nnz_data, ctx->local_ndof};

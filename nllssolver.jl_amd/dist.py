@@ -7,7 +7,7 @@ contiguous range of points and every cost block that touches them, so the point 
   stage 0  after the gradient sweep : [cost | reduced-block rows of A.data | reduced part of b]   (~0.3 MB)
   stage 1  after local elimination  : [S (dense, lower) | s]  -- the real collective of this path
   stage 2  after back-substitution  : x  (each rank contributes its own points)                    (~2.4 MB)
-plus one scalar per cost sweep.
+plus one scalar per cost sweep; dogleg / gradient descent also sum the gradient b once per iteration (~2.4 MB).
 """
 import numpy as np
 
@@ -98,11 +98,22 @@ class ShardedLS(MultiVariateLSgpu):
         a, g = self.ctx.quadform()
         return (a, g) if self.world == 1 else tuple(self._allreduce_scalars([a, g]))
 
+    def grad_quadform(self):
+        g = self.ctx.grad_quadform()               # this rank's rows of H against the (complete) gradient
+        return g if self.world == 1 else self._allreduce_scalars([g])[0]
+
     @property
     def b(self):
-        if self.world > 1:
-            raise NotImplementedError("the full gradient is not assembled under sharding (Levenberg-Marquardt / Newton only)")
-        return self.ctx.get_grad()
+        """The full gradient on every rank (dogleg, gradient descent: src/iterators.jl:48,191): each rank contributes the
+        rows it owns (nlls_get_grad_owned), one sum over ranks."""
+        if self.world == 1:
+            return self.ctx.get_grad()
+        import torch
+        t = torch.from_numpy(self.ctx.get_grad_owned())
+        if not self.host_staged:
+            t = t.cuda()
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
 
 
 def partition_by_weight(weights, nparts):

@@ -96,7 +96,7 @@ def iterate_dogleg(dd, data, problem, options):     # src/iterators.jl:47-115
     t0 = time.perf_counter_ns()
     gradient = ls.b
     gnorm2 = float(gradient @ gradient)
-    a = gnorm2 / (ls.ctx.grad_quadform() + FLOATMIN)
+    a = gnorm2 / (ls.grad_quadform() + FLOATMIN)
     dd.cauchy = -a * gradient
     alpha2 = a * a * gnorm2
     alpha = math.sqrt(alpha2)

@@ -64,6 +64,10 @@ class MultiVariateLSgpu:
         """(fast_bAb(hessian, x), dot(gradient, x))   src/iterators.jl:163"""
         return self.ctx.quadform()
 
+    def grad_quadform(self):
+        """fast_bAb(hessian, gradient)   src/iterators.jl:52"""
+        return self.ctx.grad_quadform()
+
     def step_maxabs(self):
         return self.ctx.step_maxabs()
 

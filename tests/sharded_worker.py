@@ -42,11 +42,16 @@ def main():
     assert np.allclose(q_ref, q_sh, rtol=1e-9), (q_ref, q_sh)
     assert np.isclose(ref.step_maxabs(), sh.step_maxabs(), rtol=1e-9)
 
-    # a few full LM iterations through the host loop on both
-    def run(ls, iters=4):
+    # the full gradient is assembled from the ranks' own rows (dogleg / gradient descent need it on every rank)
+    b_ref, b_sh = ref.b, sh.b
+    assert np.max(np.abs(b_ref - b_sh)) < 1e-10 * np.max(np.abs(b_ref)), np.max(np.abs(b_ref - b_sh))
+    assert np.isclose(ref.grad_quadform(), sh.grad_quadform(), rtol=1e-9)
+
+    # a few full iterations through the host loop on both: Levenberg-Marquardt, then dogleg
+    def run(ls, iters=4, itdata=It.LevMarData, itfn=It.iterate_levmar):
         opts = N.NLLSOptions(maxiters=iters)
         data = Opt.NLLSInternal(ls, 0)
-        loop = Opt.OuterLoop(p, opts, data, It.LevMarData(), It.iterate_levmar, N.nullcallback)
+        loop = Opt.OuterLoop(p, opts, data, itdata(), itfn, N.nullcallback)
         loop.start()
         while loop.iteration() == 0:
             pass
@@ -54,7 +59,10 @@ def main():
     ref2 = MultiVariateLSgpu(p, unfixed); sh2 = ShardedLS(p, unfixed, rank=rank, world=world, dist=dist, host_staged=True)
     cr, vr = run(ref2); cs, vs = run(sh2)
     assert np.isclose(cr, cs, rtol=1e-9), (cr, cs)
-    for o in (ref, sh, ref2, sh2):
+    ref3 = MultiVariateLSgpu(p, unfixed); sh3 = ShardedLS(p, unfixed, rank=rank, world=world, dist=dist, host_staged=True)
+    cd_r, _ = run(ref3, 4, It.DoglegData, It.iterate_dogleg); cd_s, _ = run(sh3, 4, It.DoglegData, It.iterate_dogleg)
+    assert cd_r < 0.9 * c_ref and np.isclose(cd_r, cd_s, rtol=1e-8), (c_ref, cd_r, cd_s)
+    for o in (ref, sh, ref2, sh2, ref3, sh3):
         o.close()
     dist.barrier()
     dist.destroy_process_group()
