@@ -261,30 +261,60 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
     double xw[MAXC];
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) { const int col = l + 16 * k; xw[k] = col < nd ? xr[rc[col]] : 0.0; }
-    for (uint32_t vb = v0; vb < v1; vb += 4) {
-        const uint32_t v = vb + gsub; const bool live = v < v1; const uint32_t vv = live ? v : v0;
-        const int64_t seg = ediag[vv] - (int64_t)DV * nd;
+    // The members of a supernode are consecutive block rows (constant stride in A.data, b and x: nlls_structure.cpp), so
+    // nothing is looked up per member.  Four members per step, one per 16 lanes; the loads of the next step are issued
+    // before this one is reduced (two register sets), and the results wait in LDS until the loop is over -- a store
+    // between the loads would make every wait a full vmcnt(0) and serialise the steps again.
+    __shared__ double xs[128 * DV], ts[128 * DV];
+    const int64_t dg0 = ediag[v0], dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = eboff[v0];
+    struct Step { double a[MAXC][DV], bv[DV], ci[DV * DV]; };
+    auto load = [&](uint32_t vb, Step& S) {
+        const uint32_t v = vb + gsub; const uint32_t m = v < v1 ? v - v0 : 0u;
+        const int64_t seg = dg0 + (int64_t)m * dstride - (int64_t)DV * nd;
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { const int col = l + 16 * k;
+#pragma unroll
+            for (int a2 = 0; a2 < DV; ++a2) S.a[k][a2] = col < nd ? A[seg + (int64_t)DV * col + a2] : 0.0; }
+        if (l == 15) {
+#pragma unroll
+            for (int a2 = 0; a2 < DV; ++a2) S.bv[a2] = b[eb0 + m * DV + a2];
+#pragma unroll
+            for (int q = 0; q < DV * DV; ++q) S.ci[q] = Cinv[(int64_t)(v0 + m) * (DV * DV) + q];
+        }
+    };
+    auto reduce = [&](uint32_t vb, const Step& S) {
+        const uint32_t v = vb + gsub; const bool live = v < v1;
         double acc[DV];
 #pragma unroll
         for (int a2 = 0; a2 < DV; ++a2) acc[a2] = 0.0;
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) { const int col = l + 16 * k;
-            if (col < nd) {
+        for (int k = 0; k < MAXC; ++k)
 #pragma unroll
-                for (int a2 = 0; a2 < DV; ++a2) acc[a2] = fma(A[seg + (int64_t)DV * col + a2], xw[k], acc[a2]); } }
+            for (int a2 = 0; a2 < DV; ++a2) acc[a2] = fma(S.a[k][a2], xw[k], acc[a2]);
 #pragma unroll
         for (int a2 = 0; a2 < DV; ++a2) { double t = acc[a2]; t = row_shr_add<0x111>(t); t = row_shr_add<0x112>(t); t = row_shr_add<0x114>(t); t = row_shr_add<0x118>(t); acc[a2] = t; }
         if (live && l == 15) {
             double r[DV];
 #pragma unroll
-            for (int a2 = 0; a2 < DV; ++a2) { r[a2] = b[eboff[v] + a2] - acc[a2]; tE[(int64_t)v * DV + a2] = acc[a2]; }
+            for (int a2 = 0; a2 < DV; ++a2) { r[a2] = S.bv[a2] - acc[a2]; ts[(v - v0) * DV + a2] = acc[a2]; }
 #pragma unroll
             for (int i = 0; i < DV; ++i) { double t = 0;
 #pragma unroll
-                for (int j = 0; j < DV; ++j) t = fma(Cinv[(int64_t)v * (DV * DV) + i + DV * j], r[j], t);
-                x[eboff[v] + i] = -t; }
+                for (int j = 0; j < DV; ++j) t = fma(S.ci[i + DV * j], r[j], t);
+                xs[(v - v0) * DV + i] = -t; }
         }
+    };
+    Step S0, S1;
+    load(v0, S0);
+#pragma unroll 1
+    for (uint32_t vb = v0; vb < v1; vb += 8) {
+        if (vb + 4 < v1) load(vb + 4, S1);
+        reduce(vb, S0);
+        if (vb + 4 < v1) { if (vb + 8 < v1) load(vb + 8, S0); reduce(vb + 4, S1); }
     }
+    __syncthreads();
+    const uint32_t nout = (v1 - v0) * DV;                     // x and tE of the supernode's members are contiguous
+    for (uint32_t i = lane; i < nout; i += 64) { x[eb0 + i] = xs[i]; tE[(int64_t)v0 * DV + i] = ts[i]; }
 }
 
 // Fast path of the elimination for supernodes whose members (a) have the compile-time block size DV and (b) store
@@ -333,11 +363,13 @@ __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __r
     const bool solver = tid <= nd;
     double en[ELIM_PF][DV], cn[ELIM_PF][DV * DV];
     // (the diagonal block is the same for every thread: its loads stay outside divergent code so that they are scalar)
+    // (the members of a supernode are consecutive block rows: constant stride in A.data and in b, nlls_structure.cpp)
+    const int64_t dg0 = ediag[v0], dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = eboff[v0];
     auto issue = [&](uint32_t v, int slot) {
-        const int64_t dg = ediag[v], seg = dg - (int64_t)DV * nd;   // the off-diagonal blocks sit right before the diagonal block
+        const int64_t dg = dg0 + (int64_t)(v - v0) * dstride, seg = dg - (int64_t)DV * nd;   // the off-diagonal blocks sit right before the diagonal block
         if (solver) {
 #pragma unroll
-            for (int a2 = 0; a2 < DV; ++a2) en[slot][a2] = (tid < nd) ? A[seg + (int64_t)DV * tid + a2] : b[eboff[v] + a2];
+            for (int a2 = 0; a2 < DV; ++a2) en[slot][a2] = (tid < nd) ? A[seg + (int64_t)DV * tid + a2] : b[eb0 + (v - v0) * DV + a2];
         }
 #pragma unroll
         for (int j = 0; j < DV; ++j)

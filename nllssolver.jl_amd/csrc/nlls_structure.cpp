@@ -435,6 +435,10 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             // supernode: same neighbour columns and own size as the previous eliminated block
             bool same = !edim.empty() && glen < 128 && prev.size() == nl.size() && edim.back() == (uint16_t)c->blocksizes[v];
             if (same) for (size_t i = 0; i < prev.size(); ++i) if (prev[i].rcol != nl[i].rcol || prev[i].dim != nl[i].dim) { same = false; break; }
+            // ... and its block row follows the previous member's directly in A.data and b: the kernels then step through a
+            // supernode with a constant stride instead of looking every member's offsets up (a dependent load per member)
+            if (same) { const int64_t dv = c->blocksizes[v];
+                if (c->diag_off[v] != ediag.back() + dv * dv + dv * nd || (int64_t)c->boffsets[v] != (int64_t)eboff.back() + dv) same = false; }
             if (!same) { egroup.push_back((uint32_t)ediag.size()); glen = 0; }
             ++glen; prev = nl;
             for (auto& n : nl) enbr.push_back(n);
