@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
 // with HBM atomics (supernodes of different points overlap in S).
 constexpr int ELIM_PF = 4;                                    // members in flight per solver thread
 constexpr int ELIM_NDP = 76;                                  // columns of [E | b] rounded up to a multiple of 4 (nd + 1 <= 72)
-template <int DV>
+template <int DV, int NC>   // NC: columns of [E | b] per lane of the solver wave (1: nd + 1 <= 64; 2: up to ELIM_NDP - 4)
 __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                                const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
                                                                const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
@@ -358,51 +358,76 @@ __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __r
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    // software pipeline: registers hold the columns and the inverse diagonal blocks (schur_cinv_kernel) of the next
-    // ELIM_PF members (HBM latency is a multiple of a member's processing time, one member ahead is not enough)
-    const bool solver = tid <= nd;
-    double en[ELIM_PF][DV], cn[ELIM_PF][DV * DV];
-    // (the diagonal block is the same for every thread: its loads stay outside divergent code so that they are scalar)
     // (the members of a supernode are consecutive block rows: constant stride in A.data and in b, nlls_structure.cpp)
     const int64_t dg0 = ediag[v0], dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = eboff[v0];
-    auto issue = [&](uint32_t v, int slot) {
-        const int64_t dg = dg0 + (int64_t)(v - v0) * dstride, seg = dg - (int64_t)DV * nd;   // the off-diagonal blocks sit right before the diagonal block
-        if (solver) {
+    auto member_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // LDS only: loads stay in flight
+    if (tid < 64) {
+        // ---- solver wave.  Software pipeline: registers hold the column and the inverse diagonal block (schur_cinv_kernel)
+        // of the next ELIM_PF members (HBM latency is a multiple of a member's processing time).  What keeps the pipeline
+        // alive in the compiled code: (a) every load is unconditional -- lanes beyond the last column and steps beyond the
+        // last member re-load a valid address -- so that a load writes the register it is consumed from and its wait sits at
+        // the use, one round later (a conditional load becomes a copy plus vmcnt(0) at the end of the round); (b) the
+        // inverse, although the same for every lane, does NOT come through scalar loads: they share lgkmcnt with the LDS
+        // traffic and return out of order, so the LDS wait of every member would also wait for the scalar load issued a
+        // moment ago for the member four ahead (`vz` hides the uniformity from the compiler).
+        uint32_t vz = 0; asm volatile("" : "+v"(vz));
+        double en[ELIM_PF][NC][DV], cn[ELIM_PF][DV * DV];
+        auto issue = [&](uint32_t v, int slot) {
+            const uint32_t m = (v < v1 ? v : v1 - 1) - v0;
 #pragma unroll
-            for (int a2 = 0; a2 < DV; ++a2) en[slot][a2] = (tid < nd) ? A[seg + (int64_t)DV * tid + a2] : b[eb0 + (v - v0) * DV + a2];
-        }
+            for (int k = 0; k < NC; ++k) {
+                const int col = tid + 64 * k < nd ? tid + 64 * k : nd;
+                const double* src = col < nd ? A + (dg0 + (int64_t)m * dstride - (int64_t)DV * nd + (int64_t)DV * col) : b + (eb0 + m * DV);
 #pragma unroll
-        for (int j = 0; j < DV; ++j)
-#pragma unroll
-            for (int i = j; i < DV; ++i) cn[slot][i + DV * j] = Cinv[(int64_t)v * (DV * DV) + i + DV * j];   // symmetric: lower triangle
-    };
-#pragma unroll
-    for (int u = 0; u < ELIM_PF; ++u) if (v0 + u < v1) issue(v0 + u, u);
-    int buf = 0;
-    for (uint32_t vb = v0; vb < v1; vb += ELIM_PF) {
-#pragma unroll
-        for (int u = 0; u < ELIM_PF; ++u) {
-            const uint32_t v = vb + u;
-            if (v >= v1) break;
-            double e[DV], C[DV * DV];
-#pragma unroll
-            for (int a2 = 0; a2 < DV; ++a2) e[a2] = en[u][a2];
+                for (int a2 = 0; a2 < DV; ++a2) en[slot][k][a2] = src[a2];
+            }
 #pragma unroll
             for (int j = 0; j < DV; ++j)
 #pragma unroll
-                for (int i = j; i < DV; ++i) C[i + DV * j] = cn[u][i + DV * j];
-            if (v + ELIM_PF < v1) issue(v + ELIM_PF, u);
-            if (solver) {
-                double y[DV];                                  // y = (C_v + lambda I)^-1 e
+                for (int i = j; i < DV; ++i) cn[slot][i + DV * j] = Cinv[(int64_t)(v0 + m) * (DV * DV) + i + DV * j + vz];   // symmetric: lower triangle
+        };
 #pragma unroll
-                for (int i = 0; i < DV; ++i) { double t = 0;
+        for (int u = 0; u < ELIM_PF; ++u) issue(v0 + u, u);
+        int buf = 0;
+#pragma unroll 1
+        for (uint32_t vb = v0; vb < v1; vb += ELIM_PF) {
 #pragma unroll
-                    for (int j = 0; j < DV; ++j) t = fma(i >= j ? C[i + DV * j] : C[j + DV * i], e[j], t);
-                    y[i] = t; }
+            for (int u = 0; u < ELIM_PF; ++u) {
+                const uint32_t v = vb + u;
+                if (v >= v1) break;
+                double e[NC][DV], C[DV * DV];
 #pragma unroll
-                for (int a2 = 0; a2 < DV; ++a2) { Es[buf][a2][tid] = e[a2]; Ys[buf][a2][tid] = y[a2]; }
+                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                    for (int a2 = 0; a2 < DV; ++a2) e[k][a2] = en[u][k][a2];
+#pragma unroll
+                for (int j = 0; j < DV; ++j)
+#pragma unroll
+                    for (int i = j; i < DV; ++i) C[i + DV * j] = cn[u][i + DV * j];
+                issue(v + ELIM_PF, u);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    double y[DV];                              // y = (C_v + lambda I)^-1 e
+#pragma unroll
+                    for (int i = 0; i < DV; ++i) { double t = 0;
+#pragma unroll
+                        for (int j = 0; j < DV; ++j) t = fma(i >= j ? C[i + DV * j] : C[j + DV * i], e[k][j], t);
+                        y[i] = t; }
+                    if (tid + 64 * k <= nd) {
+#pragma unroll
+                        for (int a2 = 0; a2 < DV; ++a2) { Es[buf][a2][tid + 64 * k] = e[k][a2]; Ys[buf][a2][tid + 64 * k] = y[a2]; }
+                    }
+                }
+                member_barrier();                              // member v published; the other buffer is free for v + 1
+                buf ^= 1;
             }
-            __syncthreads();                                   // member v published; the other buffer is free for v + 1
+        }
+    } else {
+        // ---- tile waves: one barrier per member, then this thread's 4x4 tile of the rank-DV update
+        int buf = 0;
+#pragma unroll 1
+        for (uint32_t v = v0; v < v1; ++v) {
+            member_barrier();
             if (has_tile) {
                 double ep[DV][4], yq[DV][4];
 #pragma unroll
@@ -425,15 +450,27 @@ __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __r
             buf ^= 1;
         }
     }
+    // Flush.  The register tiles go through a packed column-major LDS image of the supernode's lower triangle, so that
+    // the lanes of one atomic instruction cover consecutive rows of one column of S -- consecutive addresses when the
+    // supernode's columns are consecutive (a camera range) -- instead of one cache line per lane.
+    constexpr int NDMAX = NC == 1 ? 63 : ELIM_NDP - 5;
+    __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
+    double* const irhs = img + NDMAX * (NDMAX + 1) / 2;
+    auto colstart = [nd](int q) { return q * nd - q * (q - 1) / 2 - q; };   // + p addresses (p, q), p >= q
     if (has_tile) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = 4 * tp + i; if (p >= nd) continue;
-            if (rhs_tile) { atomicAdd(&s[rc[p]], -acc[i][0]); continue; }
+            if (rhs_tile) { irhs[p] = acc[i][0]; continue; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int q = 4 * tq + j; if (q <= p) atomicAdd(L.at(rc[p], rc[q]), -acc[i][j]); }
+            for (int j = 0; j < 4; ++j) { const int q = 4 * tq + j; if (q <= p) img[colstart(q) + p] = acc[i][j]; }
         }
     }
+    __syncthreads();
+    const int wv = tid >> 6, ln = tid & 63;
+    for (int q = wv; q < nd; q += 4)
+        for (int p = q + ln; p < nd; p += 64) atomicAdd(L.at(rc[p], rc[q]), -img[colstart(q) + p]);
+    if (tid < nd) atomicAdd(&s[rc[tid]], -irhs[tid]);
 }
 
 // x_v = C_v^-1 (b_v - E_v x_R), stored negated (negate!, src/iterators.jl:3)
@@ -1470,8 +1507,11 @@ int enqueue_solve_local(nlls_ctx* c) {
                                c->elim_use_acc ? 1 : 0, L, c->s_ptr(), c->d_status.p);
 #define LAUNCH_TILED(DV) do { const int64_t nel = (int64_t)c->d_elim_diag.n; \
             hipLaunchKernelGGL((schur_cinv_kernel<DV>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, c->stream, c->A.p, c->d_elim_diag.p, c->d_elim_dim.p, nel, c->lambda, c->Cinv.p, c->d_status.p); \
-            hipLaunchKernelGGL((schur_elim_tiled_kernel<DV>), dim3((unsigned)c->n_fast_groups), dim3(256), 0, c->stream, c->A.p, c->b.p, \
-                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, L, c->s_ptr()); } while (0)
+            const int64_t nnar = c->n_fast_narrow, nwid = c->n_fast_groups - c->n_fast_narrow;   /* d_fast_groups: the narrow supernodes first */ \
+            if (nnar > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1>), dim3((unsigned)nnar), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, L, c->s_ptr()); \
+            if (nwid > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 2>), dim3((unsigned)nwid), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p + nnar, c->Cinv.p, L, c->s_ptr()); } while (0)
         if (c->n_fast_groups > 0) {
             if (c->fast_dv == 3) LAUNCH_TILED(3); else if (c->fast_dv == 2) LAUNCH_TILED(2); else if (c->fast_dv == 1) LAUNCH_TILED(1);
         }
