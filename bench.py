@@ -59,13 +59,18 @@ def main():
     host_staged = backend != "nccl"
     if host_staged:
         local_rank = 0
-    if world > 1:
+    # NLLS_BENCH_FORCE_DIST=1: one rank, but through the sharded route (local phase / RCCL all-reduce / finish): what the
+    # collectives and their synchronisations cost before any work is actually divided
+    force_dist = world == 1 and os.environ.get("NLLS_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if host_staged:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import nllssolver_jl_amd as N
@@ -81,7 +86,7 @@ def main():
     nobs = problem.ncosts()
     start_vars = problem.variables.copy()
 
-    ls = ShardedLS(problem, np.ones(problem.nvariables, bool), device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged)
+    ls = ShardedLS(problem, np.ones(problem.nvariables, bool), device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged, force_collectives=force_dist)
     info = ls.info
     # never terminate early inside the timed region: exactly K outer iterations
     options = N.NLLSOptions(maxiters=10 ** 9, reldcost=-np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
@@ -161,7 +166,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "ncameras": ncam, "npoints": npts, "nobs": nobs, "robust": "Huber(0.01)",
                        "outliers": "5% of measurements + N(0,0.05^2), seed 1", "ndof": int(info.ndof),
-                       "reduced_dof": int(info.nreduced_dof), "sharding": "none" if world == 1 else f"by point over {world} ranks"},
+                       "reduced_dof": int(info.nreduced_dof), "sharding": ("none" if not force_dist else "none (one rank through the sharded route: NLLS_BENCH_FORCE_DIST)") if world == 1 else f"by point over {world} ranks"},
             "residual_blocks_per_s": round(nobs * args.steps / elapsed, 1),
             "sweep_residual_blocks_per_s": round(ls.local_nobs * world / (sweep_ms * 1e-3), 1),
             "lm": {"start_cost": start_cost, "final_cost": final_cost, "linear_solves": data.linearsolvers,

@@ -222,6 +222,9 @@ int  nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doub
  *   stage 0  after nlls_sweep_gradhess_local : [cost | reduced-block rows of A.data | reduced part of b]
  *   stage 1  after nlls_solve_local          : [S | s]   the reduced system
  *   stage 2  after nlls_solve_finish         : x         (each rank holds its own eliminated blocks, rank 0 the rest)
+ * nlls_sweep_gradhess_local and nlls_solve_local only ENQUEUE on the context's stream (nlls_set_stream): their buffers are
+ * complete in stream order -- issue the collective on that stream, or synchronise it first.  nlls_sweep_gradhess_finish
+ * with cost_out = NULL does not synchronise either; nlls_solve_finish does (it reports the factorisation status).
  * With nranks > 1, nlls_sweep_cost, nlls_quadform, nlls_grad_sqnorm, nlls_grad_quadform return this rank's
  * PARTIAL sums and nlls_max_abs_diag its partial maximum: the caller reduces those scalars itself. */
 int  nlls_sweep_gradhess_local(nlls_ctx* ctx);
@@ -230,6 +233,10 @@ int  nlls_sweep_cost_local(nlls_ctx* ctx, int32_t which);
 int  nlls_sweep_cost_finish(nlls_ctx* ctx, double* cost_out);
 int  nlls_solve_local(nlls_ctx* ctx);
 int  nlls_solve_finish(nlls_ctx* ctx, double* x_out);
+/* after the stage-2 reduction (x complete): update!(to, from, x), cost(to), fast_bAb(H, x), dot(g, x), max|x|, |x|^2 of one
+ * Levenberg-Marquardt trial (src/iterators.jl:155-163) with one synchronisation.  out[5] = [cost, x'Hx, g'x, max|x|, |x|^2];
+ * the first three are this rank's partial sums. */
+int  nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out);
 int  nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count);
 int  nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count,
                          int64_t* own_offset, int64_t* own_count);

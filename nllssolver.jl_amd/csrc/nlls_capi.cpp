@@ -218,6 +218,20 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     if (cost_out) *cost_out = ctx->h_scalars[0];
     return NLLS_OK;
 }
+// The part of one Levenberg-Marquardt trial that follows the solve (src/iterators.jl:155-163), for sharded runs: with the
+// step x complete on this rank (after the stage-2 reduction) -- update!(to, from, x), cost(to), fast_bAb(H, x), dot(g, x),
+// maximum(abs, x), |x|^2 -- in one enqueue and one synchronisation.  out = [cost, x'Hx, g'x, max|x|, |x|^2]; under
+// nlls_set_shard the first three are this rank's PARTIAL sums (the caller adds them over ranks), the last two are global.
+int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
+    NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from || !out) return NLLS_ERR_INVALID_ARG;
+    TRY(enqueue_step_stats(ctx)); TRY(enqueue_quadform(ctx, ctx->x.p, 4));
+    TRY(enqueue_retract(ctx, to, from));
+    TRY(enqueue_sweep_cost(ctx, to));
+    HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 10, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    out[0] = ctx->h_scalars[0]; out[1] = ctx->h_scalars[8]; out[2] = ctx->h_scalars[5]; out[3] = ctx->h_scalars[1]; out[4] = ctx->h_scalars[2];
+    return NLLS_OK;
+}
 // optimizesingles!(problem, options, indices)  src/optimize.jl:60-76,183-205
 int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices, const int64_t* cptr, const int32_t* cgroup, const int64_t* cindex,
                           const int32_t* cslot, int32_t maxiters, int32_t maxfails, double reldcost, double absdcost, double dstep, int64_t* iters_out) {
@@ -305,20 +319,19 @@ int nlls_sweep_gradhess_local(nlls_ctx* ctx) {
     NEED_READY(); TRY(enqueue_sweep_gradhess(ctx));
     ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
     if (ctx->nranks > 1) TRY(enqueue_pack_reduce0(ctx));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return NLLS_OK;
+    return NLLS_OK;                                  // enqueue only: the reduce buffer is complete in stream order
 }
 int nlls_sweep_gradhess_finish(nlls_ctx* ctx, double* cost_out) {
     NEED_GRAD();
     if (ctx->nranks > 1) TRY(enqueue_unpack_reduce0(ctx));
-    TRY(fetch_scalars(ctx, 0, 1)); if (cost_out) *cost_out = ctx->h_scalars[0]; return NLLS_OK;
+    if (!cost_out) return NLLS_OK;                   // cost not wanted (src/optimize.jl:169 discards it): no synchronisation
+    TRY(fetch_scalars(ctx, 0, 1)); *cost_out = ctx->h_scalars[0]; return NLLS_OK;
 }
 int nlls_sweep_cost_local(nlls_ctx* ctx, int32_t which) { NEED_READY(); if (!valid_set(which)) return NLLS_ERR_INVALID_ARG; return enqueue_sweep_cost(ctx, which); }
 int nlls_sweep_cost_finish(nlls_ctx* ctx, double* cost_out) { NEED_READY(); TRY(fetch_scalars(ctx, 0, 1)); if (cost_out) *cost_out = ctx->h_scalars[0]; return NLLS_OK; }
 int nlls_solve_local(nlls_ctx* ctx) {
     NEED_GRAD(); TRY(enqueue_solve_local(ctx));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return NLLS_OK;
+    return NLLS_OK;                                  // enqueue only, as above
 }
 int nlls_solve_finish(nlls_ctx* ctx, double* x_out) {
     NEED_GRAD(); TRY(enqueue_solve_finish(ctx));

@@ -28,10 +28,20 @@ class ShardedLS(MultiVariateLSgpu):
     dist: torch.distributed (initialised by the caller: "nccl" = RCCL on the GPU box).  host_staged=True routes the
     buffer reductions through host copies (gloo), which lets several ranks share ONE GPU in tests."""
 
-    def __init__(self, problem, unfixed, flags=0, device=0, rank=0, world=1, dist=None, host_staged=False):
+    def __init__(self, problem, unfixed, flags=0, device=0, rank=0, world=1, dist=None, host_staged=False, force_collectives=False):
         self.rank, self.world, self.dist, self.host_staged = rank, world, dist, host_staged
+        # force_collectives: take the local / reduce / finish route even with one rank (rehearses the RCCL plumbing on one GPU)
+        self.sharded = world > 1 or (force_collectives and dist is not None)
+        self._trial = None                         # ((x'Hx, g'x), max|x|, |x|) of the last lm_trial, until the step changes
         self._pre_upload = (rank, world)
         super().__init__(problem, unfixed, flags, device)
+        self._tstream = None
+        if self.sharded and not host_staged:
+            # RCCL mode: the library works on a torch stream, and the collectives are issued under that stream -- kernels and
+            # all-reduces are then ordered by the stream itself and no device-wide synchronisation is needed between them
+            import torch
+            self._tstream = torch.cuda.Stream()
+            self.ctx.set_stream(self._tstream.cuda_stream)
         sh = self.ctx.shard_info()
         self.local_nobs, self.local_nnz_data, self.local_ndof_written = sh["local_ncost"], sh["local_nnz_data"], sh["local_ndof"]
 
@@ -48,41 +58,52 @@ class ShardedLS(MultiVariateLSgpu):
         ptr, n = self.ctx.reduce_buffer(stage)
         if n == 0:
             return
-        t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
         if self.host_staged:       # gloo on host copies: lets two ranks share one GPU in tests
+            torch.cuda.synchronize()                   # the local phase was only enqueued (on the library's own stream)
+            t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
             h = t.cpu(); self.dist.all_reduce(h); t.copy_(h)
+            torch.cuda.synchronize()
         else:
-            self.dist.all_reduce(t)
-        torch.cuda.synchronize()
+            with torch.cuda.stream(self._tstream):
+                self.dist.all_reduce(torch.as_tensor(_DevArray(ptr, n), device="cuda"))
 
     def _allreduce_scalars(self, values, op="sum"):
         import torch
-        t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if self.host_staged else "cuda")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
-        return [float(v) for v in t.cpu()]
+        op = self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM
+        if self.host_staged:
+            t = torch.tensor(list(values), dtype=torch.float64); self.dist.all_reduce(t, op=op)
+        else:
+            with torch.cuda.stream(self._tstream):
+                t = torch.tensor(list(values), dtype=torch.float64).cuda(non_blocking=True); self.dist.all_reduce(t, op=op); t = t.cpu()
+        return [float(v) for v in t]
 
     def costgradhess(self, want_cost=True):
-        if self.world == 1:
+        if not self.sharded:
             return super().costgradhess(want_cost)
-        self._x = None
+        self._x = None; self._trial = None
         self.ctx.sweep_gradhess_local()
         self._allreduce_buffer(0)
-        return self.ctx.sweep_gradhess_finish()
+        return self.ctx.sweep_gradhess_finish(want_cost)
 
     def cost(self, which=_capi.VARS_NEXT):
         c = super().cost(which)                    # this rank's cost blocks only
-        return c if self.world == 1 else self._allreduce_scalars([c])[0]
+        return c if not self.sharded else self._allreduce_scalars([c])[0]
 
     def lm_trial(self, dlambda):
-        if self.world == 1:
+        if not self.sharded:
             return super().lm_trial(dlambda)
-        self.uniformscaling(dlambda); self.solve(); self.update(_capi.VARS_NEXT, _capi.VARS_CURRENT)   # sharded: the separate steps
-        return self.cost(_capi.VARS_NEXT)
+        # sharded: damp, solve (two buffer reductions), then retraction + cost sweep + step statistics in one call and ONE
+        # three-scalar reduction; what the iterator asks next (quadform, step_maxabs) is answered from here
+        self.uniformscaling(dlambda); self.solve()
+        out = self.ctx.trial_local(_capi.VARS_NEXT, _capi.VARS_CURRENT)
+        c, a, g = self._allreduce_scalars(out[:3])
+        self._trial = ((a, g), float(out[3]), float(np.sqrt(out[4])))
+        return c
 
     def solve(self):
-        if self.world == 1:
+        if not self.sharded:
             return super().solve()
-        self._x = None
+        self._x = None; self._trial = None
         self.ctx.solve_local()
         self._allreduce_buffer(1)
         self.ctx.solve_finish()
@@ -90,30 +111,49 @@ class ShardedLS(MultiVariateLSgpu):
 
     def initlambda(self):
         m = self.ctx.max_abs_diag()
-        if self.world > 1:
+        if self.sharded:
             m = self._allreduce_scalars([m], "max")[0]
         return m * 1e-6
 
+    @property
+    def x(self):
+        return MultiVariateLSgpu.x.fget(self)
+
+    @x.setter
+    def x(self, value):
+        self._trial = None
+        MultiVariateLSgpu.x.fset(self, value)
+
+    def step_maxabs(self):
+        return self._trial[1] if self._trial else super().step_maxabs()
+
+    def step_norm(self):
+        return self._trial[2] if self._trial else super().step_norm()
+
     def quadform(self):
+        if self._trial:
+            return self._trial[0]
         a, g = self.ctx.quadform()
-        return (a, g) if self.world == 1 else tuple(self._allreduce_scalars([a, g]))
+        return (a, g) if not self.sharded else tuple(self._allreduce_scalars([a, g]))
 
     def grad_quadform(self):
         g = self.ctx.grad_quadform()               # this rank's rows of H against the (complete) gradient
-        return g if self.world == 1 else self._allreduce_scalars([g])[0]
+        return g if not self.sharded else self._allreduce_scalars([g])[0]
 
     @property
     def b(self):
         """The full gradient on every rank (dogleg, gradient descent: src/iterators.jl:48,191): each rank contributes the
         rows it owns (nlls_get_grad_owned), one sum over ranks."""
-        if self.world == 1:
+        if not self.sharded:
             return self.ctx.get_grad()
         import torch
         t = torch.from_numpy(self.ctx.get_grad_owned())
-        if not self.host_staged:
-            t = t.cuda()
-        self.dist.all_reduce(t)
-        return t.cpu().numpy()
+        if self.host_staged:
+            self.dist.all_reduce(t)
+            return t.numpy()
+        with torch.cuda.stream(self._tstream):
+            t = t.cuda(); self.dist.all_reduce(t); t = t.cpu()
+        return t.numpy()
 
 
 def partition_by_weight(weights, nparts):

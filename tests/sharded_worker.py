@@ -11,9 +11,18 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    backend = sys.argv[4] if len(sys.argv) > 4 else "gloo"     # "nccl": RCCL plumbing with ONE rank (device buffers, no host staging)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__('datetime').timedelta(seconds=90))
+    if backend == "nccl":
+        assert world == 1
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), timeout=__import__('datetime').timedelta(seconds=90))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__('datetime').timedelta(seconds=90))
+    staged = backend != "nccl"
+    mk = lambda: ShardedLS(p, unfixed, rank=rank, world=world, dist=dist, host_staged=staged, force_collectives=True)
     import nllssolver_jl_amd as N
     from nllssolver_jl_amd import synthetic, _capi, iterators as It, optimizer as Opt
     from nllssolver_jl_amd.dist import ShardedLS
@@ -23,7 +32,7 @@ def main():
                                                                  outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
     unfixed = np.ones(p.nvariables, bool)
     ref = MultiVariateLSgpu(p, unfixed)                       # unsharded reference on the same device
-    sh = ShardedLS(p, unfixed, rank=rank, world=world, dist=dist, host_staged=True)
+    sh = mk()
     info = sh.ctx.shard_info()
     counts = [None] * world
     dist.all_gather_object(counts, info["local_ncost"])
@@ -56,10 +65,10 @@ def main():
         while loop.iteration() == 0:
             pass
         return data.bestcost, ls.variables(_capi.VARS_CURRENT)
-    ref2 = MultiVariateLSgpu(p, unfixed); sh2 = ShardedLS(p, unfixed, rank=rank, world=world, dist=dist, host_staged=True)
+    ref2 = MultiVariateLSgpu(p, unfixed); sh2 = mk()
     cr, vr = run(ref2); cs, vs = run(sh2)
     assert np.isclose(cr, cs, rtol=1e-9), (cr, cs)
-    ref3 = MultiVariateLSgpu(p, unfixed); sh3 = ShardedLS(p, unfixed, rank=rank, world=world, dist=dist, host_staged=True)
+    ref3 = MultiVariateLSgpu(p, unfixed); sh3 = mk()
     cd_r, _ = run(ref3, 4, It.DoglegData, It.iterate_dogleg); cd_s, _ = run(sh3, 4, It.DoglegData, It.iterate_dogleg)
     assert cd_r < 0.9 * c_ref and np.isclose(cd_r, cd_s, rtol=1e-8), (c_ref, cd_r, cd_s)
     for o in (ref, sh, ref2, sh2, ref3, sh3):
