@@ -1258,7 +1258,9 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args)
     const int nJ = a.nJs, fs = blk_fsize(NBW, nbd);           // blocks of this side
     double* ring = sm;                            // [BWD_RING + 1][SLOT]; the extra slot takes the copies of blocks that do not exist
     double* red = ring + (size_t)(BWD_RING + 1) * SLOT;   // [2][16][4]: the four parts of the 16 entries of a block, by block parity
-    double* Cl = red + 128;                       // nbr x nbr border corner (col-major, lower), last row = rhs
+    double* xs = red + 128;                       // [8][16]: x of the last blocks (ring by block index), read by the helper waves
+    double* farp = xs + 128;                      // [2][64]: the far tiles' (K >= 3) share of a block's parts, by block parity
+    double* Cl = farp + 128;                      // nbr x nbr border corner (col-major, lower), last row = rhs
     double* xb = Cl + nbr * nbr;                  // nbr
     for (int e = tid; e < nbr * nbr; e += 256) Cl[e] = a.corner_in[e];
     __syncthreads();
@@ -1290,20 +1292,34 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args)
 #pragma unroll
         for (int i = 0; i < NI; ++i) __builtin_amdgcn_global_load_lds(src + 128 * i, (__attribute__((address_space(3))) void*)(dst + 128 * i), 16, 0, 0);
     };
+    // x behind the last block (the separator's unknowns under the twisted factorisation, else zeros) into the xs ring
+    for (int i = tid; i < 16 * NBW; i += 256) { const int blk = nJ + (i >> 4);
+        xs[(blk & 7) * 16 + (i & 15)] = (a.xnext >= 0 && i < a.nxnext) ? a.xr[a.rev ? a.xnext - i : a.xnext + i] : 0.0; }
+    __syncthreads();
+    // The far tiles (K >= 3) of block B only need x of blocks B+3.., known two iterations before wave 0 gets to block B:
+    // the wave that copied block B in forms their share of the parts right after the copy has landed (x from the xs ring)
+    // and leaves it in farp -- wave 0's chain per block is then two tiles, not NBW.
+    auto far3 = [&](int B) {
+        if constexpr (NBW >= 3) {
+            const double* Bt = ring + (size_t)(B % BWD_RING) * SLOT;
+            double f = 0.0;
+#pragma unroll
+            for (int K = NBW; K >= 3; --K)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f = fma(Bt[(K - 1) * 256 + (g + 4 * q) * 16 + c], xs[((B + K) & 7) * 16 + g + 4 * q], f);
+            farp[(B & 1) * 64 + lane] = f;
+        }
+    };
     if (wave > 0) {
         for (int B = nJ - 1; B > nJ - 1 - BWD_AHEAD; --B) if (1 + ((B % 3) + 3) % 3 == wave) issue(B);
-        if (1 + (nJ - 1) % 3 == wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");   // block nJ-1 has landed
+        if (1 + (nJ - 1) % 3 == wave) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory"); far3(nJ - 1); }   // block nJ-1 has landed
     }
-    // at the top of iteration J: xq[K][q] = x_{J+2+K}[g + 4 q].  Behind the last block: the separator's unknowns (twisted
+    // at the top of iteration J: xq[0][q] = x_{J+2}[g + 4 q].  Behind the last block: the separator's unknowns (twisted
     // factorisation), else nothing; xfirst = the block right behind the end (what the first iteration gets for x_{J+1})
     auto behind = [&](int i) { return (a.xnext >= 0 && i < a.nxnext) ? a.xr[a.rev ? a.xnext - i : a.xnext + i] : 0.0; };
-    double xq[NBW][4], xfirst[4];
+    double xq[1][4], xfirst[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xfirst[q] = behind(g + 4 * q);
-#pragma unroll
-    for (int K = 0; K < NBW; ++K)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xq[K][q] = behind(16 * (K + 1) + g + 4 * q);
+    for (int q = 0; q < 4; ++q) { xfirst[q] = behind(g + 4 * q); xq[0][q] = behind(16 + g + 4 * q); }
     double zq[4] = {0, 0, 0, 0};                  // zh of the block whose parts are in flight, entries g + 4 q
     auto finish = [&](int Jp, double (&xnew)[4]) {           // x of block Jp from its four parts in LDS
         const double* rp = red + (Jp & 1) * 64;
@@ -1312,49 +1328,58 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args)
             const double4_t p4 = *reinterpret_cast<const double4_t*>(rp + 4 * (g + 4 * q));
             xnew[q] = zq[q] - ((p4[0] + p4[1]) + (p4[2] + p4[3]));
         }
-        if (c == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int row = 16 * Jp + g + 4 * q; if (row < n_band) a.xr[a.rev ? n_band - 1 - row : row] = xnew[q]; }
-        }
+    };
+    // x leaves for HBM from the xs ring, by a helper wave and two iterations late: a global store in wave 0's loop would put
+    // a vmcnt(0) -- the store's full HBM latency -- in front of its next LDS read (the compiler orders LDS reads behind
+    // every outstanding vector-memory operation in a kernel that uses global_load_lds)
+    auto store_x = [&](int Jp, const double* xv16) {          // lanes 0..15
+        const int row = 16 * Jp + lane; if (lane < 16 && row < n_band) a.xr[a.rev ? n_band - 1 - row : row] = xv16[lane];
     };
     for (int J = nJ - 1; J >= 0; --J) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block J is in LDS; the slot of block J+1 is free
         if (wave == 0) {
             const double* B0 = ring + (size_t)(J % BWD_RING) * SLOT;
-            // far tiles (K >= 2): their x is complete -- this hides the LDS round trip of block J+1's parts
-            double far = 0.0;
+            // every LDS read of the iteration is issued up front (nothing below reads LDS behind a write): the parts of
+            // block J+1, the two near tiles, zh and the helpers' share for the far tiles
+            const double* rp = red + ((J + 1) & 1) * 64;
+            double4_t p4[4]; double m1[4], m2[4], zn[4];
 #pragma unroll
-            for (int K = NBW; K >= 2; --K)
+            for (int q = 0; q < 4; ++q) p4[q] = *reinterpret_cast<const double4_t*>(rp + 4 * (g + 4 * q));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) far = fma(B0[(K - 1) * 256 + (g + 4 * q) * 16 + c], xq[K - 2][q], far);
-            double zn[4];
+            for (int q = 0; q < 4; ++q) m1[q] = B0[(g + 4 * q) * 16 + c];
+            double far = NBW >= 3 ? farp[(J & 1) * 64 + lane] : 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) zn[q] = B0[NBW * 256 + g + 4 * q];
+            for (int q = 0; q < 4; ++q) { m2[q] = NBW >= 2 ? B0[256 + (g + 4 * q) * 16 + c] : 0.0; zn[q] = B0[NBW * 256 + g + 4 * q]; }
             double xnew[4];
-            if (J < nJ - 1) finish(J + 1, xnew);
-            else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xnew[q] = xfirst[q];   // nothing in flight yet: block J+1 is behind the end
+            for (int q = 0; q < 4; ++q) xnew[q] = J < nJ - 1 ? zq[q] - ((p4[q][0] + p4[q][1]) + (p4[q][2] + p4[q][3])) : xfirst[q];   // x_{J+1} (behind the end at first)
+            // tile K = 2 (its x is complete) is summed beside the LDS round trip; behind x_{J+1} the chain is two fused
+            // multiply-adds deep (two accumulators) and one addition
+#pragma unroll
+            for (int q = 0; q < 4; ++q) far = fma(m2[q], xq[0][q], far);
+            const double pa = fma(m1[1], xnew[1], fma(m1[0], xnew[0], far)), pb = fma(m1[3], xnew[3], m1[2] * xnew[2]);
+            red[(J & 1) * 64 + 4 * c + g] = pa + pb;
+            if (c == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xs[((J + 1) & 7) * 16 + g + 4 * q] = xnew[q];
             }
 #pragma unroll
-            for (int K = NBW - 1; K >= 1; --K)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) xq[K][q] = xq[K - 1][q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xq[0][q] = xnew[q];
-            double part = far;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) part = fma(B0[(g + 4 * q) * 16 + c], xq[0][q], part);
-            red[(J & 1) * 64 + 4 * c + g] = part;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) zq[q] = zn[q];
+            for (int q = 0; q < 4; ++q) { xq[0][q] = xnew[q]; zq[q] = zn[q]; }
         } else {
+            if (wave == 1 + J % 3 && J + 2 <= nJ - 1) store_x(J + 2, xs + ((J + 2) & 7) * 16);   // published during iteration J+1
             const int B = J - BWD_AHEAD;          // goes into the slot block J+1 has just left
             if (1 + ((B % 3) + 3) % 3 == wave) issue(B);
-            if (J >= 1 && 1 + (J - 1) % 3 == wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");   // block J-1 has landed
+            if (J >= 1 && 1 + (J - 1) % 3 == wave) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory"); far3(J - 1); }   // block J-1 has landed
         }
     }
-    if (wave == 0 && nJ > 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); double x0[4]; finish(0, x0); }
+    if (wave == 0 && nJ > 0) {                    // the last two blocks: x_1 is in the ring (iteration 0), x_0 comes out now
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); double x0[4]; finish(0, x0);
+        if (c == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int row = g + 4 * q; if (row < n_band) a.xr[a.rev ? n_band - 1 - row : row] = x0[q]; }
+        }
+        if (nJ > 1) store_x(1, xs + 16);
+    }
     if (tid == 0 && blockIdx.x == 0 && a.timing) a.status[3] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 
@@ -1561,7 +1586,7 @@ int enqueue_solve_finish(nlls_ctx* c) {
                 const size_t lds_s = sizeof(double) * ((size_t)(NBWs + 2) * (NBWs + 2) * 272 + 272 + 2 * (size_t)(NBWs + 2) * 16 * 17 + 64 + 32 * 17 + 272 + 8);
                 hipLaunchKernelGGL(band_blocked_factor_kernel, dim3(1), dim3(BLK_T), lds_s, c->stream, bs);
                 BwdArgs2 b2{}; BwdArgs& r = b2.c[0]; r.Lt = Lsep; r.corner_in = q.corner_out; r.xr = c->s_ptr() + cA; r.n_band = ws; r.nbd = 0; r.NBW = NBWs; r.rev = 0; r.nJs = nJs2; r.xnext = -1; r.nxnext = 0; r.status = c->d_status.p;
-                const size_t lds_sb = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBWs) + 128 + 16);
+                const size_t lds_sb = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBWs) + 384 + 16);
                 switch (NBWs) {
                     case 1: hipLaunchKernelGGL(band_backward_tiles_kernel<1>, dim3(1), dim3(256), lds_sb, c->stream, b2); break;
                     case 2: hipLaunchKernelGGL(band_backward_tiles_kernel<2>, dim3(1), dim3(256), lds_sb, c->stream, b2); break;
@@ -1575,7 +1600,7 @@ int enqueue_solve_finish(nlls_ctx* c) {
                 BwdArgs& q = bw2.c[sd]; q.Lt = c->Lwork.p + (size_t)(sd ? JA : 0) * fsz; q.corner_in = corner; q.xr = c->s_ptr(); q.n_band = L.n_band; q.nbd = L.nbd; q.NBW = NBW;
                 q.rev = sd; q.nJs = sd ? JB : JA; q.xnext = twisted ? (sd ? cA + ws - 1 : cA) : -1; q.nxnext = ws; q.timing = 1; q.status = c->d_status.p;
             }
-            const size_t lds_b = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBW) + 128 + (size_t)nbr * nbr + nbr + 8);
+            const size_t lds_b = sizeof(double) * ((size_t)(BWD_RING + 1) * bwd_slot(NBW) + 384 + (size_t)nbr * nbr + nbr + 8);
             const dim3 gb(twisted ? 2 : 1);
             switch (NBW) {
                 case 1: hipLaunchKernelGGL(band_backward_tiles_kernel<1>, gb, dim3(256), lds_b, c->stream, bw2); break;
