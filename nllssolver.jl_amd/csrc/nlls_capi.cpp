@@ -186,7 +186,7 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
     // is computed behind the solve and comes back with the same synchronisation; the queries then answer from the host
     ctx->step_cached = false;
     const bool precompute = ctx->nranks == 1;
-    if (precompute) { TRY(enqueue_step_stats(ctx)); TRY(enqueue_quadform(ctx, ctx->x.p, 4)); }
+    if (precompute) { TRY(enqueue_post_solve(ctx)); }
     int32_t status[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     if (precompute) HIPCHK(hipMemcpyAsync(ctx->h_scalars + 1, ctx->scalars.p + 1, sizeof(double) * 9, hipMemcpyDeviceToHost, ctx->stream));
@@ -205,7 +205,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     ctx->lambda += dlambda;
     ctx->step_cached = false;
     TRY(enqueue_solve(ctx));
-    TRY(enqueue_step_stats(ctx)); TRY(enqueue_quadform(ctx, ctx->x.p, 4));
+    TRY(enqueue_post_solve(ctx));
     TRY(enqueue_retract(ctx, to, from));
     TRY(enqueue_sweep_cost(ctx, to));
     int32_t status[4] = {0, 0, 0, 0};
@@ -224,7 +224,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
 // nlls_set_shard the first three are this rank's PARTIAL sums (the caller adds them over ranks), the last two are global.
 int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
     NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from || !out) return NLLS_ERR_INVALID_ARG;
-    TRY(enqueue_step_stats(ctx)); TRY(enqueue_quadform(ctx, ctx->x.p, 4));
+    TRY(enqueue_post_solve(ctx));
     TRY(enqueue_retract(ctx, to, from));
     TRY(enqueue_sweep_cost(ctx, to));
     HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 10, hipMemcpyDeviceToHost, ctx->stream));

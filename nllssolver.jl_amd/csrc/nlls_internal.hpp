@@ -30,6 +30,7 @@ int enqueue_optimize_singles(nlls_ctx* c, int64_t nsel, const int64_t* d_selvar,
 size_t singles_group_size();
 void singles_group_fill(void* dst, const Group& G);
 int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot /* scalars[out], scalars[out+1] = v'Hv, b'v */);
+int enqueue_post_solve(nlls_ctx* c);          // enqueue_step_stats + enqueue_quadform(x, 4) for the step of the last solve, fewer launches
 // solve (nlls_solve.hip)
 int enqueue_solve(nlls_ctx* c);
 int enqueue_solve_local(nlls_ctx* c);

@@ -1386,11 +1386,12 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args)
 // ---------------------------------------------------------------------------------------------------
 // fast_bAb(H + lambda I, v) and dot(b, v)   src/utils.jl:71-106, src/iterators.jl:52,163
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void quadform_blocks_kernel(const double* __restrict__ A, const SchurCopy* __restrict__ blk, int64_t nblk,
-                                                              const double* __restrict__ v, const uint8_t* __restrict__ mask, double* __restrict__ partials) {
+// (bodies take a virtual workgroup index / count, so that post_solve_kernel can run several of them in one launch)
+__device__ __forceinline__ void quadform_blocks_body(const double* __restrict__ A, const SchurCopy* __restrict__ blk, int64_t nblk,
+                                                     const double* __restrict__ v, const uint8_t* __restrict__ mask, double* __restrict__ partials, int bid, int nb) {
     __shared__ double red[4];
     double acc = 0;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nblk; q += (int64_t)gridDim.x * 256) {
+    for (int64_t q = (int64_t)bid * 256 + threadIdx.x; q < nblk; q += (int64_t)nb * 256) {
         if (mask && !mask[q]) continue;
         const SchurCopy bk = blk[q]; double t = 0;
         for (int j = 0; j < bk.cols; ++j) { double c2 = 0; for (int i = 0; i < bk.rows; ++i) c2 += A[bk.off + i + bk.rows * j] * v[bk.r + i]; t += c2 * v[bk.c + j]; }
@@ -1399,17 +1400,21 @@ __global__ __launch_bounds__(256) void quadform_blocks_kernel(const double* __re
     acc = wsum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) partials[bid] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void quadform_blocks_kernel(const double* __restrict__ A, const SchurCopy* __restrict__ blk, int64_t nblk,
+                                                              const double* __restrict__ v, const uint8_t* __restrict__ mask, double* __restrict__ partials) {
+    quadform_blocks_body(A, blk, nblk, v, mask, partials, (int)blockIdx.x, (int)gridDim.x);
 }
 // rows of fast-path members, for the step x of the last solve: x' A x restricted to row v is
 //   2 x_v' (E_v x_R) + x_v' C_v x_v,   E_v x_R = -E_v s  -- and E_v s is what schur_backsub_fast_kernel left in tE
 template <int DV>
-__global__ __launch_bounds__(256) void quadform_points_kernel(const double* __restrict__ A, const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
-                                                              const uint32_t* __restrict__ members, int64_t nm, const double* __restrict__ tE,
-                                                              const double* __restrict__ x, double* __restrict__ partials) {
+__device__ __forceinline__ void quadform_points_body(const double* __restrict__ A, const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                     const uint32_t* __restrict__ members, int64_t nm, const double* __restrict__ tE,
+                                                     const double* __restrict__ x, double* __restrict__ partials, int bid, int nb) {
     __shared__ double red[4];
     double acc = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nm; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < nm; i += (int64_t)nb * 256) {
         const uint32_t v = members[i];
         double xv[DV], t = 0;
 #pragma unroll
@@ -1424,7 +1429,64 @@ __global__ __launch_bounds__(256) void quadform_points_kernel(const double* __re
     acc = wsum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) partials[bid] = red[0] + red[1] + red[2] + red[3];
+}
+template <int DV>
+__global__ __launch_bounds__(256) void quadform_points_kernel(const double* __restrict__ A, const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                              const uint32_t* __restrict__ members, int64_t nm, const double* __restrict__ tE,
+                                                              const double* __restrict__ x, double* __restrict__ partials) {
+    quadform_points_body<DV>(A, ediag, eboff, members, nm, tE, x, partials, (int)blockIdx.x, (int)gridDim.x);
+}
+// Everything the iterators ask about the step x of the last solve -- maximum(abs, x), |x|^2 (src/optimize.jl:149,
+// src/callbacks.jl:47), fast_bAb(H, x) and dot(g, x) (src/iterators.jl:163) -- in ONE launch plus one finishing workgroup
+// (six launches before; a launch boundary costs ~5 us here).  Workgroups [0, np): blocks of H outside the fast-path rows;
+// [np, np + np3): the fast-path rows from E_v s; [np + np3, np + np3 + np2): one pass over x and b.
+struct PostSolveArgs { const double* A; const SchurCopy* blk; int64_t nblk; const uint8_t* blkmask; const int64_t* ediag; const uint32_t* eboff;
+                       const uint32_t* members; int64_t nm; const double* tE; const double* x; const double* b; const double* dofmask; int64_t ndof;
+                       double* partials; double* part2; int np, np3, np2; };
+template <int DV>
+__global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) {
+    const int bid = (int)blockIdx.x;
+    if (bid < a.np) { quadform_blocks_body(a.A, a.blk, a.nblk, a.x, a.blkmask, a.partials, bid, a.np); return; }
+    if (bid < a.np + a.np3) { quadform_points_body<DV>(a.A, a.ediag, a.eboff, a.members, a.nm, a.tE, a.x, a.partials + a.np, bid - a.np, a.np3); return; }
+    __shared__ double red[5][4];
+    const int b2 = bid - a.np - a.np3;
+    double m = 0, ss = 0, vv = 0, bv = 0, nan = 0;
+    for (int64_t i = (int64_t)b2 * 256 + threadIdx.x; i < a.ndof; i += (int64_t)a.np2 * 256) {
+        const double x = a.x[i], w = a.dofmask ? a.dofmask[i] : 1.0;
+        if (x != x) nan = 1.0;
+        m = fmax(m, fabs(x)); ss += x * x; vv += w * x * x; bv += w * a.b[i] * x;
+    }
+    ss = wsum(ss); vv = wsum(vv); bv = wsum(bv);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o)); nan = fmax(nan, __shfl_xor(nan, o)); }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red[0][w] = m; red[1][w] = nan; red[2][w] = ss; red[3][w] = vv; red[4][w] = bv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = a.part2 + 5 * b2;
+        o[0] = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3])); o[1] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+        o[2] = red[2][0] + red[2][1] + red[2][2] + red[2][3]; o[3] = red[3][0] + red[3][1] + red[3][2] + red[3][3]; o[4] = red[4][0] + red[4][1] + red[4][2] + red[4][3];
+    }
+}
+// out[1] = max|x| (NaN if any entry is), out[2] = x'x, out[4] = x'(H + lambda I)x, out[5] = g'x, out[8] = x'Hx, out[9] = (masked) x'x
+__global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
+                                                                double lambda, double* __restrict__ out) {
+    __shared__ double red[6][4];
+    double a = 0, m = 0, nan = 0, ss = 0, vv = 0, bv = 0;
+    for (int i = threadIdx.x; i < np; i += 256) a += partials[i];
+    for (int i = threadIdx.x; i < np2; i += 256) { m = fmax(m, part2[5 * i]); nan = fmax(nan, part2[5 * i + 1]); ss += part2[5 * i + 2]; vv += part2[5 * i + 3]; bv += part2[5 * i + 4]; }
+    a = wsum(a); ss = wsum(ss); vv = wsum(vv); bv = wsum(bv);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o)); nan = fmax(nan, __shfl_xor(nan, o)); }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red[0][w] = a; red[1][w] = m; red[2][w] = nan; red[3][w] = ss; red[4][w] = vv; red[5][w] = bv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = red[0][0] + red[0][1] + red[0][2] + red[0][3]; ss = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+        vv = red[4][0] + red[4][1] + red[4][2] + red[4][3]; bv = red[5][0] + red[5][1] + red[5][2] + red[5][3];
+        m = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3])); nan = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+        out[1] = nan > 0 ? __longlong_as_double(0x7ff8000000000000LL) : m; out[2] = ss;
+        out[4] = a + lambda * vv; out[5] = bv; out[8] = a; out[9] = vv;
+    }
 }
 __global__ __launch_bounds__(256) void quadform_dense_kernel(const double* __restrict__ A, int n, const double* __restrict__ v, double* __restrict__ partials) {
     __shared__ double red[4];
@@ -1492,6 +1554,28 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
     double* part2 = c->partials.p + 1024;
     hipLaunchKernelGGL(dot2_partial_kernel, dim3(np2), dim3(256), 0, c->stream, c->b.p, d_vec, c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr, c->info.ndof, part2);
     hipLaunchKernelGGL(quadform_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, np, part2, np2, c->lambda, c->scalars.p, out_slot);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+// step statistics + quadratic form of the step of the last solve (what nlls_solve / nlls_lm_trial / nlls_trial_local
+// precompute): one launch + one finishing workgroup on sparse systems, the separate kernels otherwise
+int enqueue_post_solve(nlls_ctx* c) {
+    if (!c->info.is_sparse) { int rc = enqueue_step_stats(c); if (rc != NLLS_OK) return rc; return enqueue_quadform(c, c->x.p, 4); }
+    const bool reuse = c->tE_valid && c->n_fast_members > 0;
+    PostSolveArgs a{};
+    a.A = c->A.p; a.blk = c->d_blk.p; a.nblk = c->nblk; a.blkmask = reuse ? c->d_blk_slowmask.p : (c->nranks > 1 ? c->d_blk_mask.p : (const uint8_t*)nullptr);
+    a.ediag = c->d_elim_diag.p; a.eboff = c->d_elim_boff.p; a.members = c->d_fast_members.p; a.nm = c->n_fast_members; a.tE = c->tE.p;
+    a.x = c->x.p; a.b = c->b.p; a.dofmask = c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr; a.ndof = c->info.ndof;
+    a.np = (int)std::max<int64_t>(1, std::min<int64_t>((c->nblk + 255) / 256, 768));
+    a.np3 = reuse ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
+    a.np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 256));
+    a.partials = c->partials.p; a.part2 = c->partials.p + 1024;
+    const dim3 grid((unsigned)(a.np + a.np3 + a.np2));
+    if (c->fast_dv == 3) hipLaunchKernelGGL((post_solve_kernel<3>), grid, dim3(256), 0, c->stream, a);
+    else if (c->fast_dv == 2) hipLaunchKernelGGL((post_solve_kernel<2>), grid, dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((post_solve_kernel<1>), grid, dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
