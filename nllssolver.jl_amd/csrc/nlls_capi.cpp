@@ -188,12 +188,12 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
     const bool precompute = ctx->nranks == 1;
     if (precompute) { TRY(enqueue_post_solve(ctx)); }
     int32_t status[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
-    if (precompute) HIPCHK(hipMemcpyAsync(ctx->h_scalars + 1, ctx->scalars.p + 1, sizeof(double) * 9, hipMemcpyDeviceToHost, ctx->stream));
+    if (precompute) HIPCHK(hipMemcpyAsync(ctx->h_scalars + 1, ctx->scalars.p + 1, sizeof(double) * 10, hipMemcpyDeviceToHost, ctx->stream));   // ... and the status in [10]
+    else HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     if (x_out) HIPCHK(hipMemcpyAsync(x_out, ctx->x.p, sizeof(double) * ctx->info.ndof, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->solved = true;
-    if (precompute) { ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9]; }
+    if (precompute) { status[0] = (int32_t)ctx->h_scalars[10]; ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9]; }
     if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");
     return NLLS_OK;
 }
@@ -208,10 +208,9 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     TRY(enqueue_post_solve(ctx));
     TRY(enqueue_retract(ctx, to, from));
     TRY(enqueue_sweep_cost(ctx, to));
-    int32_t status[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 10, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));   // scalars and, in [10], the factorisation status
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int32_t status[1] = {(int32_t)ctx->h_scalars[10]};
     ctx->solved = true;
     ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9];
     if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");

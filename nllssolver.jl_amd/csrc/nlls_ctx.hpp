@@ -178,6 +178,7 @@ struct nlls_ctx {
     nlls::DevBuf<uint8_t> d_blk_slowmask;    // d_blk entries NOT in rows of fast members (and owned by this rank)
     nlls::DevBuf<double> tE;                 // E_v s of the last solve per fast member (s = reduced solution): reused by the quadratic form
     bool tE_valid = false; int64_t n_fast_members = 0;
+    bool S_zeroed = false;                   // the last solve's back-substitution left S zero-filled for the next one (saves the memset launches)
     bool step_cached = false; double c_maxabs = 0, c_sumsq = 0, c_gx = 0, c_xAx = 0, c_xx = 0;   // host copies of the last solve's step statistics
     nlls::DevBuf<double> Cinv;               // (C_v + lambda I)^-1 of the fast-path members, fast_dv^2 doubles per eliminated block
     int fast_dv = 0, fast_maxk = 0, fast_maxk_narrow = 0;

@@ -244,12 +244,15 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
                                                                 const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
                                                                 const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
                                                                 const double* __restrict__ Cinv, const double* __restrict__ xr, double* __restrict__ x, double* __restrict__ tE,
-                                                                uint32_t ngroups, const uint32_t* __restrict__ red_boff, int nred, int write_red) {
+                                                                uint32_t ngroups, const uint32_t* __restrict__ red_boff, int nred, int write_red,
+                                                                double* __restrict__ Szero, int64_t nzero) {
     constexpr int MAXC = (72 + 15) / 16;                      // columns per lane (nd <= 72)
     __shared__ uint32_t rc[80];
     const int lane = threadIdx.x, l = lane & 15, gsub = lane >> 4;
     if (blockIdx.x >= ngroups) {                              // the workgroups behind the supernodes scatter the reduced part: x_R = -s
         for (int i = (blockIdx.x - ngroups) * 64 + lane; i < nred; i += (gridDim.x - ngroups) * 64) x[red_boff[i]] = write_red ? -xr[i] : 0.0;
+        // ... and leave the reduced system's storage zero-filled for the next solve (nothing reads S any more)
+        for (int64_t i = (int64_t)(blockIdx.x - ngroups) * 64 + lane; i < nzero; i += (int64_t)(gridDim.x - ngroups) * 64) Szero[i] = 0.0;
         return;
     }
     const uint32_t g = glist[blockIdx.x];
@@ -1468,9 +1471,10 @@ __global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) {
         o[2] = red[2][0] + red[2][1] + red[2][2] + red[2][3]; o[3] = red[3][0] + red[3][1] + red[3][2] + red[3][3]; o[4] = red[4][0] + red[4][1] + red[4][2] + red[4][3];
     }
 }
-// out[1] = max|x| (NaN if any entry is), out[2] = x'x, out[4] = x'(H + lambda I)x, out[5] = g'x, out[8] = x'Hx, out[9] = (masked) x'x
+// out[1] = max|x| (NaN if any entry is), out[2] = x'x, out[4] = x'(H + lambda I)x, out[5] = g'x, out[8] = x'Hx, out[9] = (masked) x'x,
+// out[10] = factorisation status
 __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
-                                                                double lambda, double* __restrict__ out) {
+                                                                double lambda, double* __restrict__ out, const int* __restrict__ status) {
     __shared__ double red[6][4];
     double a = 0, m = 0, nan = 0, ss = 0, vv = 0, bv = 0;
     for (int i = threadIdx.x; i < np; i += 256) a += partials[i];
@@ -1486,6 +1490,7 @@ __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __
         m = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3])); nan = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
         out[1] = nan > 0 ? __longlong_as_double(0x7ff8000000000000LL) : m; out[2] = ss;
         out[4] = a + lambda * vv; out[5] = bv; out[8] = a; out[9] = vv;
+        out[10] = (double)status[0];                             // the factorisation status rides home with the scalars (one copy)
     }
 }
 __global__ __launch_bounds__(256) void quadform_dense_kernel(const double* __restrict__ A, int n, const double* __restrict__ v, double* __restrict__ partials) {
@@ -1558,10 +1563,16 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
     return NLLS_OK;
 }
 
+__global__ void status_to_scalar_kernel(const int* __restrict__ status, double* __restrict__ out) { *out = (double)status[0]; }
 // step statistics + quadratic form of the step of the last solve (what nlls_solve / nlls_lm_trial / nlls_trial_local
 // precompute): one launch + one finishing workgroup on sparse systems, the separate kernels otherwise
 int enqueue_post_solve(nlls_ctx* c) {
-    if (!c->info.is_sparse) { int rc = enqueue_step_stats(c); if (rc != NLLS_OK) return rc; return enqueue_quadform(c, c->x.p, 4); }
+    if (!c->info.is_sparse) {
+        int rc = enqueue_step_stats(c); if (rc != NLLS_OK) return rc;
+        rc = enqueue_quadform(c, c->x.p, 4); if (rc != NLLS_OK) return rc;
+        hipLaunchKernelGGL(status_to_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_status.p, c->scalars.p + 10);
+        return NLLS_OK;
+    }
     const bool reuse = c->tE_valid && c->n_fast_members > 0;
     PostSolveArgs a{};
     a.A = c->A.p; a.blk = c->d_blk.p; a.nblk = c->nblk; a.blkmask = reuse ? c->d_blk_slowmask.p : (c->nranks > 1 ? c->d_blk_mask.p : (const uint8_t*)nullptr);
@@ -1575,7 +1586,7 @@ int enqueue_post_solve(nlls_ctx* c) {
     if (c->fast_dv == 3) hipLaunchKernelGGL((post_solve_kernel<3>), grid, dim3(256), 0, c->stream, a);
     else if (c->fast_dv == 2) hipLaunchKernelGGL((post_solve_kernel<2>), grid, dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((post_solve_kernel<1>), grid, dim3(256), 0, c->stream, a);
-    hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p);
+    hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p, c->d_status.p);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
@@ -1594,7 +1605,8 @@ int enqueue_solve_local(nlls_ctx* c) {
     const bool band = c->solve_mode == SOLVE_BAND; const bool lead = c->nranks == 1 || c->rank == 0;
     const bool one_prepare = lead && c->info.is_sparse && c->ncopy > 0;      // status reset, s and the reduced-reduced blocks in one launch
     if (!one_prepare) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
+    if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
+    c->S_zeroed = false;
     if (c->nranks > 1) HIPCHK(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->info.ndof, c->stream));
     if (one_prepare) {
         const int ninit = (std::max(npad, n) + 255) / 256;
@@ -1733,9 +1745,12 @@ int enqueue_solve_finish(nlls_ctx* c) {
             hipLaunchKernelGGL(schur_backsub_kernel, dim3((unsigned)nslow), dim3(64), lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
                                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->n_fast_groups > 0 ? c->d_slow_blocks.p : (const uint32_t*)nullptr,
                                c->lambda, c->max_elim_dim, c->s_ptr(), c->x.p);
-#define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + 32), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p, \
-                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red)
-        if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; }
+        // (single rank, one_prepare path: s is rewritten in full by schur_prepare_kernel, so only S itself has to be zero)
+        const bool zero_S = c->nranks == 1 && c->solve_mode == SOLVE_BAND && c->info.is_sparse && c->ncopy > 0;
+        const unsigned nextra = zero_S ? 160 : 32;
+#define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + nextra), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p, \
+                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red, c->S.p, zero_S ? (int64_t)c->s_elems : (int64_t)0)
+        if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; c->S_zeroed = zero_S; }
 #undef LAUNCH_BSF
     }
     HIPCHK(hipGetLastError());

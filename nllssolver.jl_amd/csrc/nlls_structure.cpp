@@ -133,6 +133,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     { std::vector<uint32_t> vb(nvar); for (int64_t i = 0; i < nvar; ++i) vb[i] = bi[i] ? (uint32_t)c->boffsets[bi[i] - 1] : DEST_NONE; HIPCHK(c->d_var_boff.upload(vb)); }
     HIPCHK(c->d_diag_off.upload(c->diag_off)); HIPCHK(c->d_blocksizes.upload(c->blocksizes));
     if (!c->h_scalars) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), 64 * sizeof(double)));
+    c->S_zeroed = false;
     HIPCHK(c->scalars.alloc(64));
 
     // ---- observation sharding: costs are owned by the rank that owns their eliminated block ----------
