@@ -43,13 +43,16 @@ struct SLayout {
         if (j < n_band) return S + (size_t)j * H + bw + 1 + (i - n_band);
         return S + (size_t)n_band * H + (i - n_band) + (size_t)(nbd + 1) * (j - n_band);
     }
+    // entry i of the reduced right-hand side while the system is assembled: the factorisations carry it as row n of S
+    // (band and dense layouts); only the one-wave solver of tiny systems reads it from the vector s
+    NLLS_DEV double* rhs(double* s, int i) const { return mode == SOLVE_SMALL ? s + i : at(n, i); }
 };
 
 // identity on the padding of the dense layout; the rhs as row n: factoring the bordered matrix
 // [[S, s], [s', c]] leaves z = D^-1 L^-1 s in row n of the factor, so no separate forward substitution is needed.
 __global__ void schur_init_kernel(SLayout L, double* __restrict__ s, const double* __restrict__ b, const uint32_t* __restrict__ red_boff) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < L.n) { s[i] = b[red_boff[i]]; return; }
+    if (i < L.n) { *L.rhs(s, i) = b[red_boff[i]]; return; }
     if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
 }
 // schur_init + schur_copy + the status reset in one launch (sparse systems): the first ninit workgroups initialise s (and
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) void schur_prepare_kernel(SLayout L, double* _
     if (blockIdx.x == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
     if ((int)blockIdx.x < ninit) {
         const int i = blockIdx.x * 256 + threadIdx.x;
-        if (i < L.n) { s[i] = b[red_boff[i]]; return; }
+        if (i < L.n) { *L.rhs(s, i) = b[red_boff[i]]; return; }
         if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
         return;
     }
@@ -87,10 +90,6 @@ __global__ void dense_to_S_kernel(double* __restrict__ S, const double* __restri
     if (e >= (int64_t)n * n) return;
     const int i = (int)(e % n), j = (int)(e / n);
     S[(size_t)i + (size_t)npad * j] = A[e] + (i == j ? lambda : 0.0);
-}
-__global__ void rhs_row_kernel(SLayout L, const double* __restrict__ s) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < L.n) *L.at(L.n, i) = s[i];
 }
 
 // One wavefront per SUPERNODE = run of eliminated blocks with identical neighbour columns (bundle adjustment:
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
             }
         }
         for (int p = lane; p < nd; p += 64) { double a2 = 0; for (int a = 0; a < dv; ++a) a2 += E[a + dv * p] * Y[a + dv * nd];
-            if (use_acc) acc[npairs + p] += a2; else atomicAdd(&s[rc[p]], -a2); }
+            if (use_acc) acc[npairs + p] += a2; else atomicAdd(L.rhs(s, rc[p]), -a2); }
     }
     if (use_acc) {
         int t = lane;
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
         while ((p + 1) * (p + 2) / 2 <= t) ++p;
         int q = t - p * (p + 1) / 2;
         for (; t < npairs; t += 64) { atomicAdd(L.at(rc[p], rc[q]), -acc[t]); q += 64; while (q > p) { q -= p + 1; ++p; } }
-        for (int p2 = lane; p2 < nd; p2 += 64) atomicAdd(&s[rc[p2]], -acc[npairs + p2]);
+        for (int p2 = lane; p2 < nd; p2 += 64) atomicAdd(L.rhs(s, rc[p2]), -acc[npairs + p2]);
     }
 }
 
@@ -473,7 +472,7 @@ __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __r
     const int wv = tid >> 6, ln = tid & 63;
     for (int q = wv; q < nd; q += 4)
         for (int p = q + ln; p < nd; p += 64) atomicAdd(L.at(rc[p], rc[q]), -img[colstart(q) + p]);
-    if (tid < nd) atomicAdd(&s[rc[tid]], -irhs[tid]);
+    if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 
 // x_v = C_v^-1 (b_v - E_v x_R), stored negated (negate!, src/iterators.jl:3)
@@ -1650,7 +1649,6 @@ int enqueue_solve_finish(nlls_ctx* c) {
     if (c->solve_mode == SOLVE_SMALL) {
         hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s_ptr(), n, npad, c->d_status.p);
     } else if (band) {
-        hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s_ptr());
         BandArgs a{}; a.Sb = c->S.p; a.Lb = c->Lwork.p; a.xr = c->s_ptr(); a.n_band = L.n_band; a.bw = L.bw; a.nbd = L.nbd; a.H = L.H; a.CH = c->band_CH; a.status = c->d_status.p;
         a.PFC = (L.bw + 1 + a.CH - 1) / a.CH + 1; a.RC = (a.PFC + 1) * a.CH; a.NSC = (L.bw + 1 + c->band_SEG - 1) / c->band_SEG;
         const int nbr = L.nbd + 1;
@@ -1714,7 +1712,6 @@ int enqueue_solve_finish(nlls_ctx* c) {
         else LAUNCH_BAND(16, 4);
 #undef LAUNCH_BAND
     } else {
-        hipLaunchKernelGGL(rhs_row_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, L, c->s_ptr());
         for (int k = 0; k < nblk; ++k) {
             hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(256), 0, c->stream, c->S.p, npad, k, c->d_status.p);
             const int T = nblk - k - 1;
