@@ -1,0 +1,47 @@
+"""BASELINE.json's configurations at their FULL sizes: the HIP path through the C ABI against the CPU oracle on the same
+seeded inputs (the oracle needs a few seconds per sweep / solve at 1M residual blocks), plus size-independent properties:
+the Levenberg-Marquardt step satisfies x'(H + lambda I)x = -g'x, the cost sweep is bit-reproducible, and a noise-free
+problem is driven to cost < 1e-15 per the reference's own criterion (test/optimizeba.jl:62,68,75)."""
+import numpy as np
+import pytest
+
+import nllssolver_jl_amd as N
+from nllssolver_jl_amd import synthetic, _capi
+from tests.test_gpu_parity import check_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ncam,npts,prop", [(100, 10000, 0.1),        # BASELINE config 3: ~100k residual blocks
+                                             (1000, 100000, 0.01)])    # BASELINE config 4: ~1M residual blocks (bench.py's workload)
+def test_full_size_sweeps_and_solve_against_oracle(ncam, npts, prop):
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=1, robust=N.HuberKernel(0.01),
+                                                                 outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)           # structure exact; cost, A.data, b, x, x'Hx, retraction vs oracle
+    assert info.nreduced_dof == 6 * ncam and info.ndof == 6 * ncam + 3 * npts
+
+
+def test_config4_step_identity_and_reproducibility():
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(1000, 100000, 0.01, seed=1, robust=N.HuberKernel(0.01),
+                                                                 outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    ctx = _capi.Context()
+    ctx.upload(p.var_kind, p.var_dim, np.arange(1, p.nvariables + 1, dtype=np.uint64), p.groups(), 0)
+    ctx.set_variables(p.variables)
+    c0 = ctx.sweep_gradhess()
+    assert ctx.sweep_cost(_capi.VARS_CURRENT) == c0 == ctx.sweep_cost(_capi.VARS_CURRENT)      # cost(problem) == the sweep's total, bit for bit
+    lam = ctx.max_abs_diag() * 1e-6
+    ctx.damp(lam)
+    x = ctx.solve(want_x=True)
+    xHx, gx = ctx.quadform()                                            # x'(H + lambda I)x and g'x
+    assert abs(xHx + gx) < 1e-9 * abs(gx), (xHx, gx)                    # (H + lambda I) x = -g  =>  x'(H + lambda I) x = -g'x
+    x2 = ctx.solve(want_x=True)
+    assert np.max(np.abs(x - x2)) < 1e-9 * np.max(np.abs(x))            # (the elimination sums with atomics: not bit-identical)
+    ctx.close()
+
+
+def test_config4_noise_free_optimum():
+    """test/optimizeba.jl:62-75 at full size: noiseless measurements, perturbed start -> cost < 1e-15 (per residual block)."""
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(1000, 100000, 0.01, seed=3), 1e-3, 1e-3)
+    res = N.optimize(p, N.NLLSOptions(maxiters=30))
+    assert res.bestcost < 1e-15 * p.ncosts(), res.bestcost
+    assert res.niterations <= 30
