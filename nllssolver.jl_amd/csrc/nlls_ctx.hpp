@@ -183,6 +183,7 @@ struct nlls_ctx {
     nlls::DevBuf<double> Cinv;               // (C_v + lambda I)^-1 of the fast-path members, fast_dv^2 doubles per eliminated block
     int fast_dv = 0, fast_maxk = 0, fast_maxk_narrow = 0;
     int64_t n_fast_narrow = 0;               // fast supernodes with nd + 1 <= 64 come first in d_fast_groups
+    int64_t n_fast_n60 = 0;                  // ... and among them those with nd <= 60 (two tile waves suffice) first of all
     int max_elim_dim = 0, max_nbr_dof = 0;
     bool elim_use_acc = false; size_t elim_lds = 0;
     int64_t n_band = 0; int nbd = 0, bw = 0;   // reduced ordering: [banded part | border dof | rhs]

@@ -331,30 +331,32 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
 // with HBM atomics (supernodes of different points overlap in S).
 constexpr int ELIM_PF = 4;                                    // members in flight per solver thread
 constexpr int ELIM_NDP = 76;                                  // columns of [E | b] rounded up to a multiple of 4 (nd + 1 <= 72)
-template <int DV, int NC>   // NC: columns of [E | b] per lane of the solver wave (1: nd + 1 <= 64; 2: up to ELIM_NDP - 4)
-__global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __restrict__ A, const double* __restrict__ b,
+// NC: columns of [E | b] per lane of the solver wave (1: nd + 1 <= 64; 2: up to ELIM_NDP - 4).  TW: tile waves -- two hold
+// the 4x4 tiles of nd <= 60 (120 tiles on 128 lanes: the bundle-adjustment point seen by ten cameras), three the rest.
+template <int DV, int NC, int TW>
+__global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                                const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
                                                                const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
                                                                const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
                                                                const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
     __shared__ __attribute__((aligned(16))) double Es[2][DV][ELIM_NDP], Ys[2][DV][ELIM_NDP];
     __shared__ uint32_t rc[ELIM_NDP];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x; constexpr int NT = 64 * (1 + TW);
     const uint32_t g = glist[blockIdx.x];
     const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
     // structure of the run (identical for all members): reduced column of every E column
     const int64_t p0 = eptr[v0]; const int nnb = (int)(eptr[v0 + 1] - p0);
     int nd = 0;
-    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = tid; c2 < nb.dim; c2 += 256) rc[nd + c2] = nb.rcol + c2; nd += nb.dim; }
-    for (int i = tid; i < 2 * DV * ELIM_NDP; i += 256) { (&Es[0][0][0])[i] = 0.0; (&Ys[0][0][0])[i] = 0.0; }
+    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = tid; c2 < nb.dim; c2 += NT) rc[nd + c2] = nb.rcol + c2; nd += nb.dim; }
+    for (int i = tid; i < 2 * DV * ELIM_NDP; i += NT) { (&Es[0][0][0])[i] = 0.0; (&Ys[0][0][0])[i] = 0.0; }
     __syncthreads();
-    // this thread's tile: t < ntile -> (tp, tq), tq <= tp, pairs (4 tp + i, 4 tq + j); ntile <= t < ntile + T -> (tp, rhs column)
+    // this thread's tile: t < ntile -> (tp, tq), tq <= tp, pairs (4 tp + i, 4 tq + j).  (The rhs column E' y_b is summed by the
+    // solver wave, which has every column of E in registers: the tile waves then carry no half-empty tiles.)
     const int T = (nd + 3) >> 2, ntile = T * (T + 1) / 2;
     // (tiles live on waves 1-3: wave 0 is the solver and runs one member ahead of them)
     const int tt = tid - 64;
-    int tp = 0, tq = 0; bool rhs_tile = false, has_tile = tt >= 0 && tt < ntile + T;
-    if (has_tile && tt < ntile) { tp = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5); while (tp * (tp + 1) / 2 > tt) --tp; while ((tp + 1) * (tp + 2) / 2 <= tt) ++tp; tq = tt - tp * (tp + 1) / 2; }
-    else if (has_tile) { tp = tt - ntile; rhs_tile = true; }
+    int tp = 0, tq = 0; const bool has_tile = tt >= 0 && tt < ntile;
+    if (has_tile) { tp = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5); while (tp * (tp + 1) / 2 > tt) --tp; while ((tp + 1) * (tp + 2) / 2 <= tt) ++tp; tq = tt - tp * (tp + 1) / 2; }
     double acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -363,6 +365,9 @@ __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __r
     // (the members of a supernode are consecutive block rows: constant stride in A.data and in b, nlls_structure.cpp)
     const int64_t dg0 = ediag[v0], dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = eboff[v0];
     auto member_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // LDS only: loads stay in flight
+    constexpr int NDMAX = NC == 1 ? 63 : ELIM_NDP - 5;
+    __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
+    double* const irhs = img + NDMAX * (NDMAX + 1) / 2; double* const rhs_out = irhs;   // (the flush image: used after the member loop)
     if (tid < 64) {
         // ---- solver wave.  Software pipeline: registers hold the column and the inverse diagonal block (schur_cinv_kernel)
         // of the next ELIM_PF members (HBM latency is a multiple of a member's processing time).  What keeps the pipeline
@@ -374,6 +379,10 @@ __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __r
         // moment ago for the member four ahead (`vz` hides the uniformity from the compiler).
         uint32_t vz = 0; asm volatile("" : "+v"(vz));
         double en[ELIM_PF][NC][DV], cn[ELIM_PF][DV * DV];
+        double racc[NC];                                          // entry tid (+ 64) of the rhs column E' y_b
+#pragma unroll
+        for (int k = 0; k < NC; ++k) racc[k] = 0.0;
+        const int kb = nd >> 6, lb = nd & 63;                     // where the rhs column sits: lane lb, slot kb
         auto issue = [&](uint32_t v, int slot) {
             const uint32_t m = (v < v1 ? v : v1 - 1) - v0;
 #pragma unroll
@@ -407,23 +416,32 @@ __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __r
 #pragma unroll
                     for (int i = j; i < DV; ++i) C[i + DV * j] = cn[u][i + DV * j];
                 issue(v + ELIM_PF, u);
+                double y[NC][DV];                              // y = (C_v + lambda I)^-1 e
 #pragma unroll
                 for (int k = 0; k < NC; ++k) {
-                    double y[DV];                              // y = (C_v + lambda I)^-1 e
 #pragma unroll
                     for (int i = 0; i < DV; ++i) { double t = 0;
 #pragma unroll
                         for (int j = 0; j < DV; ++j) t = fma(i >= j ? C[i + DV * j] : C[j + DV * i], e[k][j], t);
-                        y[i] = t; }
+                        y[k][i] = t; }
                     if (tid + 64 * k <= nd) {
 #pragma unroll
-                        for (int a2 = 0; a2 < DV; ++a2) { Es[buf][a2][tid + 64 * k] = e[k][a2]; Ys[buf][a2][tid + 64 * k] = y[a2]; }
+                        for (int a2 = 0; a2 < DV; ++a2) { Es[buf][a2][tid + 64 * k] = e[k][a2]; Ys[buf][a2][tid + 64 * k] = y[k][a2]; }
                     }
+                }
+#pragma unroll
+                for (int a2 = 0; a2 < DV; ++a2) {              // the rhs column: y_b broadcast from its lane
+                    const double ysel = (NC == 2 && kb == 1) ? +y[NC - 1][a2] : +y[0][a2];
+                    const double yb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ysel), lb), __builtin_amdgcn_readlane(__double2loint(ysel), lb));
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) racc[k] = fma(e[k][a2], yb, racc[k]);
                 }
                 member_barrier();                              // member v published; the other buffer is free for v + 1
                 buf ^= 1;
             }
         }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) if (tid + 64 * k < nd) rhs_out[tid + 64 * k] = racc[k];
     } else {
         // ---- tile waves: one barrier per member, then this thread's 4x4 tile of the rank-DV update
         int buf = 0;
@@ -436,8 +454,7 @@ __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __r
                 for (int a2 = 0; a2 < DV; ++a2) {
                     const double4_t ev = *reinterpret_cast<const double4_t*>(&Es[buf][a2][4 * tp]);
                     ep[a2][0] = ev[0]; ep[a2][1] = ev[1]; ep[a2][2] = ev[2]; ep[a2][3] = ev[3];
-                    if (!rhs_tile) { const double4_t yv = *reinterpret_cast<const double4_t*>(&Ys[buf][a2][4 * tq]); yq[a2][0] = yv[0]; yq[a2][1] = yv[1]; yq[a2][2] = yv[2]; yq[a2][3] = yv[3]; }
-                    else { yq[a2][0] = Ys[buf][a2][nd]; yq[a2][1] = yq[a2][2] = yq[a2][3] = 0.0; }
+                    const double4_t yv = *reinterpret_cast<const double4_t*>(&Ys[buf][a2][4 * tq]); yq[a2][0] = yv[0]; yq[a2][1] = yv[1]; yq[a2][2] = yv[2]; yq[a2][3] = yv[3];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -455,22 +472,18 @@ __global__ __launch_bounds__(256) void schur_elim_tiled_kernel(const double* __r
     // Flush.  The register tiles go through a packed column-major LDS image of the supernode's lower triangle, so that
     // the lanes of one atomic instruction cover consecutive rows of one column of S -- consecutive addresses when the
     // supernode's columns are consecutive (a camera range) -- instead of one cache line per lane.
-    constexpr int NDMAX = NC == 1 ? 63 : ELIM_NDP - 5;
-    __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
-    double* const irhs = img + NDMAX * (NDMAX + 1) / 2;
     auto colstart = [nd](int q) { return q * nd - q * (q - 1) / 2 - q; };   // + p addresses (p, q), p >= q
     if (has_tile) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = 4 * tp + i; if (p >= nd) continue;
-            if (rhs_tile) { irhs[p] = acc[i][0]; continue; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const int q = 4 * tq + j; if (q <= p) img[colstart(q) + p] = acc[i][j]; }
         }
     }
     __syncthreads();
     const int wv = tid >> 6, ln = tid & 63;
-    for (int q = wv; q < nd; q += 4)
+    for (int q = wv; q < nd; q += NT / 64)
         for (int p = q + ln; p < nd; p += 64) atomicAdd(L.at(rc[p], rc[q]), -img[colstart(q) + p]);
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
@@ -1627,11 +1640,13 @@ int enqueue_solve_local(nlls_ctx* c) {
                                c->elim_use_acc ? 1 : 0, L, c->s_ptr(), c->d_status.p);
 #define LAUNCH_TILED(DV) do { const int64_t nel = (int64_t)c->d_elim_diag.n; \
             hipLaunchKernelGGL((schur_cinv_kernel<DV>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, c->stream, c->A.p, c->d_elim_diag.p, c->d_elim_dim.p, nel, c->lambda, c->Cinv.p, c->d_status.p); \
-            const int64_t nnar = c->n_fast_narrow, nwid = c->n_fast_groups - c->n_fast_narrow;   /* d_fast_groups: the narrow supernodes first */ \
-            if (nnar > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1>), dim3((unsigned)nnar), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+            const int64_t n60 = c->n_fast_n60, nnar = c->n_fast_narrow - c->n_fast_n60, nwid = c->n_fast_groups - c->n_fast_narrow;   /* d_fast_groups: nd <= 60, then the other narrow supernodes, then the wide ones */ \
+            if (n60 > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1, 2>), dim3((unsigned)n60), dim3(192), 0, c->stream, c->A.p, c->b.p, \
                 c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, L, c->s_ptr()); \
-            if (nwid > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 2>), dim3((unsigned)nwid), dim3(256), 0, c->stream, c->A.p, c->b.p, \
-                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p + nnar, c->Cinv.p, L, c->s_ptr()); } while (0)
+            if (nnar > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1, 3>), dim3((unsigned)nnar), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p + n60, c->Cinv.p, L, c->s_ptr()); \
+            if (nwid > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 2, 3>), dim3((unsigned)nwid), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p + c->n_fast_narrow, c->Cinv.p, L, c->s_ptr()); } while (0)
         if (c->n_fast_groups > 0) {
             if (c->fast_dv == 3) LAUNCH_TILED(3); else if (c->fast_dv == 2) LAUNCH_TILED(2); else if (c->fast_dv == 1) LAUNCH_TILED(1);
         }

@@ -449,7 +449,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         c->nelim_groups = (int64_t)egroup.size() - 1;
         // fast-path eligibility: small compile-time block size, few neighbour dof, and the member's off-diagonal
         // blocks stored back to back right before its diagonal block, in reduced-column order
-        std::vector<uint32_t> fastg, fastw, slowg; int fast_dv = 0; int fast_maxk = 0;
+        std::vector<uint32_t> fastg60, fastg, fastw, slowg; int fast_dv = 0; int fast_maxk = 0;
         { std::unordered_map<int, int64_t> dvcount; for (auto d : edim) dvcount[d]++;
           int64_t bestc = 0; for (auto& kv : dvcount) if (kv.first <= 3 && kv.second > bestc) { bestc = kv.second; fast_dv = kv.first; } }
         for (size_t gi = 0; gi + 1 < egroup.size(); ++gi) {
@@ -466,8 +466,10 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 if (nd + 1 > 71) ok = false;
                 ndg = nd;
             }
-            if (ok) { (ndg + 1 <= 64 ? fastg : fastw).push_back((uint32_t)gi); if (ndg + 1 <= 64) fast_maxk = std::max(fast_maxk, (ndg * (ndg + 1) / 2 + 63) / 64); } else slowg.push_back((uint32_t)gi);
+            if (ok) { (ndg <= 60 ? fastg60 : ndg + 1 <= 64 ? fastg : fastw).push_back((uint32_t)gi); if (ndg + 1 <= 64) fast_maxk = std::max(fast_maxk, (ndg * (ndg + 1) / 2 + 63) / 64); } else slowg.push_back((uint32_t)gi);
         }
+        c->n_fast_n60 = (int64_t)fastg60.size();
+        fastg.insert(fastg.begin(), fastg60.begin(), fastg60.end());
         c->n_fast_narrow = (int64_t)fastg.size(); c->fast_maxk_narrow = fast_maxk;
         fastg.insert(fastg.end(), fastw.begin(), fastw.end());
         c->n_fast_groups = (int64_t)fastg.size(); c->n_slow_groups = (int64_t)slowg.size(); c->fast_dv = fast_dv; c->fast_maxk = fast_maxk;
