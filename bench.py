@@ -170,7 +170,11 @@ def main():
             "residual_blocks_per_s": round(nobs * args.steps / elapsed, 1),
             "sweep_residual_blocks_per_s": round(ls.local_nobs * world / (sweep_ms * 1e-3), 1),
             "lm": {"start_cost": start_cost, "final_cost": final_cost, "linear_solves": data.linearsolvers,
-                   "cost_sweeps": data.costcomputations, "gradient_sweeps": data.gradientcomputations},
+                   "cost_sweeps": data.costcomputations, "gradient_sweeps": data.gradientcomputations,
+                   # an outer iteration that rejects a step solves again with more damping (src/iterators.jl:149-172): at the
+                   # optimiser's noise floor (from about the 12th iteration of this problem) that happens often, so the rate
+                   # of LM trials (damped solve + retraction + cost sweep) is the figure that does not depend on --steps
+                   "lm_trials_per_s": round(data.linearsolvers / elapsed, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
