@@ -1001,6 +1001,41 @@ __device__ __forceinline__ void blk_panel_tile(const BlkLds& S, int J, int jslot
 #pragma unroll
     for (int r = 0; r < 4; ++r) Wt[(lk + 4 * r) * P + li] = acc[r] + acc2[r];
 }
+// wave 0 between two factorisations: panel tile W_1 = T_1 inv(L)' and, straight from the registers, the update of the
+// diagonal tile of block column J+1, C -= W_1 (W_1 / D)'.  The panel product is formed TRANSPOSED (operands swapped:
+// inv(L) T_1'), because the accumulator layout of W_1' -- register r of lane (li, lk) = W_1[li][lk + 4 r] -- is exactly
+// the operand layout the update needs (A[i][k] = W_1[i][k], B[k][j] = W_1[j][k] / d_k): no LDS round trip between the
+// two.  W_1 still goes to the panel in LDS (normal layout) for the helpers' tile-updates.
+__device__ __forceinline__ void blk_panel_update_diag(const BlkLds& S, int J, int jslot) {
+    constexpr int P = BLK_P;
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const double* T = blk_slot_tile(S, jslot, 1); double* Wt = blk_panel(S, J) + (size_t)16 * P;
+    const double* Lij = blk_li(S, J); const double* rd = blk_d(S, J) + 16;
+    double av[4], bv[4], rdk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { av[kk] = T[li * P + 4 * kk + lk]; bv[kk] = Lij[(4 * kk + lk) * P + li]; rdk[kk] = rd[4 * kk + lk]; }
+    int sl = jslot + 1; sl -= sl >= S.TW ? S.TW : 0;
+    double* Ct = ((J + 1 < S.nJ) ? S.tiles + (size_t)sl * S.TR * BLK_TS : S.dummy) + lk * P + li;
+    double4_t c, c2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = Ct[4 * r * P];
+    double4_t a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[0], av[0], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[1], av[1], a2, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[2], av[2], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[3], av[3], a2, 0, 0, 0);
+    double w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = a1[r] + a2[r];            // W_1[li][lk + 4 r]
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-w[0], w[0] * rdk[0], c, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w[1], w[1] * rdk[1], c2, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-w[2], w[2] * rdk[2], c, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w[3], w[3] * rdk[3], c2, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[li * P + lk + 4 * r] = w[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ct[4 * r * P] = c[r] + c2[r];
+}
 // tile column K <- band layout in HBM (identity behind the last column); threads t0, t0+nt, ...  Gather form: every
 // word of the TR tiles is computed from its (row, column), so the ring slot needs no zero fill and one pass suffices.
 // Two halves: blk_land_load issues the HBM loads into registers, blk_land_store puts them into the ring slot; whatever
@@ -1192,7 +1227,6 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
     // later), columns J+2..J+NBW and the border corner -- are done by the helper waves while wave 0 factors J+1.
     const int nup = NBW * (NBW + 1) / 2 + NBW + 1;
     constexpr int NW = BLK_T / 64;
-    BlkUpd<1> U0; blk_update_list<1>(S, 0, 1, wave == 0 ? 0 : -1, 1, U0);
     BlkUpd<3> Uh; blk_update_list<3>(S, 1, nup - 1, wave - 1, NW - 1, Uh);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();   // diagnostics only (nlls_get_solve_stats)
     int jslot = 0;                                            // J % TW, kept incrementally (no integer division in the loop)
@@ -1210,7 +1244,7 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
             if (landing) blk_land_store_fast(S, pslot, tid - 64, BLK_HELP, plan, lv);
         }
         __syncthreads();                                      // (B) diagonal tile factored; block J-1's updates all applied: column J is final
-        if (wave == 0) { blk_panel_tile(S, J, jslot, 1); blk_update<1>(S, J, jslot, U0); }   // W_1, then the diagonal tile of column J+1
+        if (wave == 0) blk_panel_update_diag(S, J, jslot);                                     // W_1 and, from the registers, the diagonal tile of column J+1
         else if (wave <= NBW) blk_panel_tile(S, J, jslot, wave + 1);                          // W_2 .. W_{NBW+1}
         __syncthreads();                                      // (C) panel J in LDS; the next diagonal tile is ready
         if (++jslot == S.TW) jslot = 0;
