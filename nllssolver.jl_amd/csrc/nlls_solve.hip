@@ -948,14 +948,14 @@ NLLS_DEV double* blk_li(const BlkLds& S, int J) { return S.Li + (J & 1) * 16 * B
 // A second accumulator starts as the identity and takes the same column operations (transposed): it ends as inv(L),
 // so the sub-diagonal tiles need no substitution, W_T = T * inv(L)' is a matrix-core product (blk_panel_tile).
 // Serial chain per pivot: readlane d -> v_rcp_f64 + two Newton steps -> scale -> MFMA.
-__device__ __forceinline__ void blk_factor(const BlkLds& S, int J, int jslot, int* status) {
+__device__ __forceinline__ void blk_factor(const BlkLds& S, int J, int jslot, int* status, const double4_t* Ain) {
     constexpr int P = BLK_P;
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     double4_t A, Bt;                                          // Bt[n][j]: transpose of the identity rows' tile
     {
         const double* t0 = blk_slot_tile(S, jslot, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { A[r] = t0[(lk + 4 * r) * P + li]; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
+        for (int r = 0; r < 4; ++r) { A[r] = Ain ? (*Ain)[r] : t0[(lk + 4 * r) * P + li]; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }   // (wave 0 made this tile final itself, one phase ago: it is still in its registers)
     }
     double* db = blk_d(S, J);
     int badk = 16;                                            // first pivot of this block that is zero or NaN
@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void blk_panel_tile(const BlkLds& S, int J, int jslot
 // inv(L) T_1'), because the accumulator layout of W_1' -- register r of lane (li, lk) = W_1[li][lk + 4 r] -- is exactly
 // the operand layout the update needs (A[i][k] = W_1[i][k], B[k][j] = W_1[j][k] / d_k): no LDS round trip between the
 // two.  W_1 still goes to the panel in LDS (normal layout) for the helpers' tile-updates.
-__device__ __forceinline__ void blk_panel_update_diag(const BlkLds& S, int J, int jslot) {
+__device__ __forceinline__ void blk_panel_update_diag(const BlkLds& S, int J, int jslot, double4_t& diag_out) {
     constexpr int P = BLK_P;
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const double* T = blk_slot_tile(S, jslot, 1); double* Wt = blk_panel(S, J) + (size_t)16 * P;
@@ -1034,7 +1034,7 @@ __device__ __forceinline__ void blk_panel_update_diag(const BlkLds& S, int J, in
 #pragma unroll
     for (int r = 0; r < 4; ++r) Wt[li * P + lk + 4 * r] = w[r];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ct[4 * r * P] = c[r] + c2[r];
+    for (int r = 0; r < 4; ++r) { diag_out[r] = c[r] + c2[r]; Ct[4 * r * P] = diag_out[r]; }
 }
 // tile column K <- band layout in HBM (identity behind the last column); threads t0, t0+nt, ...  Gather form: every
 // word of the TR tiles is computed from its (row, column), so the ring slot needs no zero fill and one pass suffices.
@@ -1230,11 +1230,12 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
     BlkUpd<3> Uh; blk_update_list<3>(S, 1, nup - 1, wave - 1, NW - 1, Uh);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();   // diagnostics only (nlls_get_solve_stats)
     int jslot = 0;                                            // J % TW, kept incrementally (no integer division in the loop)
+    double4_t diag = {0, 0, 0, 0};                            // wave 0: the next diagonal tile, from its update to its factorisation
     BlkLandPlan plan; blk_land_plan(S, tid - 64, BLK_HELP, plan);
     __syncthreads();                                          // the first tile columns have landed
     for (int J = 0; J < nJs; ++J) {
         const int pslot = jslot == 0 ? S.TW - 1 : jslot - 1;  // slot of column J-1 = slot of column J+NBW+1
-        if (wave == 0) blk_factor(S, J, jslot, a.status);
+        if (wave == 0) blk_factor(S, J, jslot, a.status, J > 0 ? &diag : nullptr);
         else {
             // helpers, behind wave 0's factorisation: block J-1's remaining tile-updates, tile column J+NBW+1 into the
             // ring slot of column J-1 (HBM latency), block J-1's factor out
@@ -1244,7 +1245,7 @@ __global__ __launch_bounds__(BLK_T) void band_blocked_factor_kernel(BlkArgs2 arg
             if (landing) blk_land_store_fast(S, pslot, tid - 64, BLK_HELP, plan, lv);
         }
         __syncthreads();                                      // (B) diagonal tile factored; block J-1's updates all applied: column J is final
-        if (wave == 0) blk_panel_update_diag(S, J, jslot);                                     // W_1 and, from the registers, the diagonal tile of column J+1
+        if (wave == 0) blk_panel_update_diag(S, J, jslot, diag);                                     // W_1 and, from the registers, the diagonal tile of column J+1
         else if (wave <= NBW) blk_panel_tile(S, J, jslot, wave + 1);                          // W_2 .. W_{NBW+1}
         __syncthreads();                                      // (C) panel J in LDS; the next diagonal tile is ready
         if (++jslot == S.TW) jslot = 0;
