@@ -205,8 +205,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     ctx->lambda += dlambda;
     ctx->step_cached = false;
     TRY(enqueue_solve(ctx));
-    TRY(enqueue_post_solve(ctx));
-    TRY(enqueue_retract(ctx, to, from));
+    TRY(enqueue_post_solve(ctx, to, from));        // step statistics, quadratic form and the retraction in one launch
     TRY(enqueue_sweep_cost(ctx, to));
     HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));   // scalars and, in [10], the factorisation status
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -223,8 +222,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
 // nlls_set_shard the first three are this rank's PARTIAL sums (the caller adds them over ranks), the last two are global.
 int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
     NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from || !out) return NLLS_ERR_INVALID_ARG;
-    TRY(enqueue_post_solve(ctx));
-    TRY(enqueue_retract(ctx, to, from));
+    TRY(enqueue_post_solve(ctx, to, from));        // step statistics, quadratic form and the retraction in one launch
     TRY(enqueue_sweep_cost(ctx, to));
     HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 10, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

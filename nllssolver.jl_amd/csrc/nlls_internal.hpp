@@ -30,7 +30,24 @@ int enqueue_optimize_singles(nlls_ctx* c, int64_t nsel, const int64_t* d_selvar,
 size_t singles_group_size();
 void singles_group_fill(void* dst, const Group& G);
 int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot /* scalars[out], scalars[out+1] = v'Hv, b'v */);
-int enqueue_post_solve(nlls_ctx* c);          // enqueue_step_stats + enqueue_quadform(x, 4) for the step of the last solve, fewer launches
+int enqueue_post_solve(nlls_ctx* c, int retract_to = -1, int retract_from = -1);   // enqueue_step_stats + enqueue_quadform(x, 4) for the step of the last solve, fewer launches; optionally the retraction rides along
+
+#if defined(__HIPCC__)
+// to[var i] = update(from[var i], x[its block])   (src/linearsystem.jl:206-213); fixed variables are copied
+__device__ __forceinline__ void retract_one(const int32_t* __restrict__ kind, const int32_t* __restrict__ dim, const uint32_t* __restrict__ voff,
+                                            const uint32_t* __restrict__ vboff, int64_t i, const double* __restrict__ from,
+                                            const double* __restrict__ x, double* __restrict__ to) {
+    const int k = kind[i], d = dim[i]; const uint32_t o = voff[i], bo = vboff[i];
+    if (bo == DEST_NONE) { const int st = var_storage(k, d); for (int q = 0; q < st; ++q) to[o + q] = from[o + q]; return; }
+    if (k == NLLS_VAR_EUCLIDEAN) { for (int q = 0; q < d; ++q) to[o + q] = from[o + q] + x[bo + q]; return; }   // v + delta (src/variable.jl:5): no staging arrays
+    double in[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], out[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], st[NLLS_MAX_BLOCK_SZ];
+    const int ns = var_storage(k, d), nd = var_dof(k, d);
+    for (int q = 0; q < ns; ++q) in[q] = from[o + q];
+    for (int q = 0; q < nd; ++q) st[q] = x[bo + q];
+    var_update_real(k, d, in, st, out);
+    for (int q = 0; q < ns; ++q) to[o + q] = out[q];
+}
+#endif
 // solve (nlls_solve.hip)
 int enqueue_solve(nlls_ctx* c);
 int enqueue_solve_local(nlls_ctx* c);

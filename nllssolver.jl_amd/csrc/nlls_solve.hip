@@ -1493,12 +1493,18 @@ __global__ __launch_bounds__(256) void quadform_points_kernel(const double* __re
 // [np, np + np3): the fast-path rows from E_v s; [np + np3, np + np3 + np2): one pass over x and b.
 struct PostSolveArgs { const double* A; const SchurCopy* blk; int64_t nblk; const uint8_t* blkmask; const int64_t* ediag; const uint32_t* eboff;
                        const uint32_t* members; int64_t nm; const double* tE; const double* x; const double* b; const double* dofmask; int64_t ndof;
-                       double* partials; double* part2; int np, np3, np2; };
+                       double* partials; double* part2; int np, np3, np2;
+                       int nretract; const int32_t* vkind; const int32_t* vdim; const uint32_t* voff; const uint32_t* vboff; int64_t nvar; const double* vfrom; double* vto; };
 template <int DV>
 __global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) {
     const int bid = (int)blockIdx.x;
     if (bid < a.np) { quadform_blocks_body(a.A, a.blk, a.nblk, a.x, a.blkmask, a.partials, bid, a.np); return; }
     if (bid < a.np + a.np3) { quadform_points_body<DV>(a.A, a.ediag, a.eboff, a.members, a.nm, a.tE, a.x, a.partials + a.np, bid - a.np, a.np3); return; }
+    if (bid >= a.np + a.np3 + a.np2) {                          // the retraction of the LM trial (update!, src/iterators.jl:155): one thread per variable
+        const int64_t i = (int64_t)(bid - a.np - a.np3 - a.np2) * 256 + threadIdx.x;
+        if (i < a.nvar) retract_one(a.vkind, a.vdim, a.voff, a.vboff, i, a.vfrom, a.x, a.vto);
+        return;
+    }
     __shared__ double red[5][4];
     const int b2 = bid - a.np - a.np3;
     double m = 0, ss = 0, vv = 0, bv = 0, nan = 0;
@@ -1613,8 +1619,9 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
 __global__ void status_to_scalar_kernel(const int* __restrict__ status, double* __restrict__ out) { *out = (double)status[0]; }
 // step statistics + quadratic form of the step of the last solve (what nlls_solve / nlls_lm_trial / nlls_trial_local
 // precompute): one launch + one finishing workgroup on sparse systems, the separate kernels otherwise
-int enqueue_post_solve(nlls_ctx* c) {
+int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from) {
     if (!c->info.is_sparse) {
+        if (retract_to >= 0) { int rc0 = enqueue_retract(c, retract_to, retract_from); if (rc0 != NLLS_OK) return rc0; }
         int rc = enqueue_step_stats(c); if (rc != NLLS_OK) return rc;
         rc = enqueue_quadform(c, c->x.p, 4); if (rc != NLLS_OK) return rc;
         hipLaunchKernelGGL(status_to_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_status.p, c->scalars.p + 10);
@@ -1629,7 +1636,12 @@ int enqueue_post_solve(nlls_ctx* c) {
     a.np3 = reuse ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
     a.np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 256));
     a.partials = c->partials.p; a.part2 = c->partials.p + 1024;
-    const dim3 grid((unsigned)(a.np + a.np3 + a.np2));
+    a.nretract = 0;
+    if (retract_to >= 0 && c->info.nvar > 0) {
+        a.nretract = (int)((c->info.nvar + 255) / 256); a.vkind = c->d_var_kind.p; a.vdim = c->d_var_dim.p; a.voff = c->d_var_off.p; a.vboff = c->d_var_boff.p;
+        a.nvar = c->info.nvar; a.vfrom = vars_ptr(c, retract_from); a.vto = vars_ptr(c, retract_to);
+    }
+    const dim3 grid((unsigned)(a.np + a.np3 + a.np2 + a.nretract));
     if (c->fast_dv == 3) hipLaunchKernelGGL((post_solve_kernel<3>), grid, dim3(256), 0, c->stream, a);
     else if (c->fast_dv == 2) hipLaunchKernelGGL((post_solve_kernel<2>), grid, dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((post_solve_kernel<1>), grid, dim3(256), 0, c->stream, a);

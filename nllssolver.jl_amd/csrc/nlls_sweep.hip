@@ -529,16 +529,7 @@ __global__ void retract_kernel(const int32_t* __restrict__ kind, const int32_t* 
                                const uint32_t* __restrict__ vboff, int64_t nvar, const double* __restrict__ from,
                                const double* __restrict__ x, double* __restrict__ to) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvar) return;
-    const int k = kind[i], d = dim[i]; const uint32_t o = voff[i], bo = vboff[i];
-    if (bo == DEST_NONE) { const int st = var_storage(k, d); for (int q = 0; q < st; ++q) to[o + q] = from[o + q]; return; }
-    if (k == NLLS_VAR_EUCLIDEAN) { for (int q = 0; q < d; ++q) to[o + q] = from[o + q] + x[bo + q]; return; }   // v + delta (src/variable.jl:5): no staging arrays
-    double in[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], out[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], st[NLLS_MAX_BLOCK_SZ];
-    const int ns = var_storage(k, d), nd = var_dof(k, d);
-    for (int q = 0; q < ns; ++q) in[q] = from[o + q];
-    for (int q = 0; q < nd; ++q) st[q] = x[bo + q];
-    var_update_real(k, d, in, st, out);
-    for (int q = 0; q < ns; ++q) to[o + q] = out[q];
+    if (i < nvar) retract_one(kind, dim, voff, vboff, i, from, x, to);
 }
 // maximum(abs, x) and x'x   (src/optimize.jl:149, src/iterators.jl:160; NaN propagates like Julia's maximum).
 // Two stages: per-workgroup partials (max, nan flag, sum of squares), then one small finishing workgroup.
