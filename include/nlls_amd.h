@@ -109,7 +109,8 @@ typedef struct nlls_info {
 
 /* flags for nlls_upload_structure */
 #define NLLS_FLAG_FORCE_ATOMIC   0x1  /* always use the generic atomic scatter accumulate            */
-#define NLLS_FLAG_NO_SCHUR       0x2  /* solve the full system densely (small problems / testing)    */
+#define NLLS_FLAG_NO_SCHUR       0x2  /* solve the full system densely (small problems / testing); taken automatically when an
+                                         eliminated block has more neighbour dof than the Schur kernels stage in LDS */
 #define NLLS_FLAG_FORCE_SPARSE   0x4  /* makesymmvls(...; formarginalization) style: BSM regardless   */
 #define NLLS_FLAG_NO_BAND        0x8  /* never use the bordered-band solver (dense MFMA path instead)  */
 #define NLLS_FLAG_NO_TWIST       0x10 /* band solver: factor from the top only (one workgroup), testing */

@@ -91,7 +91,13 @@ int nlls_res_slot_kind(int32_t k, int32_t slot, int32_t* vk, int32_t* vd) {
 int nlls_upload_structure(nlls_ctx* ctx, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* blockindices,
                           int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
     if (!ctx || nvar < 0 || ngroups < 0 || (nvar && (!var_kind || !var_dim || !blockindices)) || (ngroups && !groups)) return NLLS_ERR_INVALID_ARG;
-    try { return build_structure(ctx, nvar, var_kind, var_dim, blockindices, ngroups, groups, flags); }
+    try {
+        int rc = build_structure(ctx, nvar, var_kind, var_dim, blockindices, ngroups, groups, flags);
+        // an eliminated block with more neighbours than the Schur kernels stage in LDS: solve the full system instead of failing
+        if (rc == NLLS_ERR_UNSUPPORTED && !(flags & NLLS_FLAG_NO_SCHUR) && ctx->err.find("NLLS_FLAG_NO_SCHUR") != std::string::npos)
+            rc = build_structure(ctx, nvar, var_kind, var_dim, blockindices, ngroups, groups, flags | NLLS_FLAG_NO_SCHUR);
+        return rc;
+    }
     catch (const std::exception& e) { return fail(ctx, NLLS_ERR_HIP, std::string("host exception: ") + e.what()); }
 }
 

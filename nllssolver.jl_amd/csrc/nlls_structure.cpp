@@ -377,6 +377,13 @@ int select_elimination(nlls_ctx* c, int32_t flags) {
 int build_schur(nlls_ctx* c, int32_t flags) {
     const nlls_info& I0 = c->info; const int64_t nb = I0.nblocks;
     c->nelim_groups = 0; c->max_elim_dim = 0; c->max_nbr_dof = 0;
+    // (a re-upload -- or the retry without Schur elimination after an unsupported shape -- must not see the previous
+    // attempt's supernode lists: the solve dispatches on these counters)
+    c->n_fast_groups = 0; c->n_slow_groups = 0; c->n_fast_members = 0; c->n_fast_narrow = 0; c->n_fast_n60 = 0; c->fast_dv = 0;
+    c->tE_valid = false; c->S_zeroed = false; c->step_cached = false;
+    // (the solve also dispatches on the SIZE of these lists: an upload without elimination must not inherit them)
+    c->d_elim_ptr.release(); c->d_elim_nbr.release(); c->d_elim_diag.release(); c->d_elim_boff.release(); c->d_elim_dim.release(); c->d_elim_group.release();
+    c->d_fast_groups.release(); c->d_slow_groups.release(); c->d_slow_blocks.release(); c->d_fast_members.release(); c->Cinv.release(); c->tE.release();
     std::vector<int64_t> red_of(nb, -1);     // dof offset in the reduced system
     // transposed block lists: for a block v, the rows w > v that store block (w, v)
     std::vector<int64_t> tptr(nb + 1, 0), trow, tq;

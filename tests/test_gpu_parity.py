@@ -189,3 +189,39 @@ def test_band_solver_shapes(ncam, npts, prop, seed):
     assert info.nreduced_dof == 6 * ncam
     if info.solve_mode == 2:
         check_problem(p, flags=_capi.FLAG_NO_TWIST, expect_schur=1)
+
+
+@pytest.mark.parametrize("seed", list(range(100, 140)))
+def test_randomized_ba_against_oracle(seed):
+    """Seeded random shapes: cameras, points, visibility, robustifier, outliers and fixed variables drawn per case --
+    sweeps (exact structure, cost, A.data, b), damped solve, quadratic form and retraction against the oracle."""
+    rng = np.random.default_rng(seed)
+    ncam = int(rng.integers(4, 60)); npts = int(rng.integers(20, 1500)); prop = float(rng.uniform(0.05, 0.6))
+    prop = max(prop, 3.5 / ncam)                                        # well posed: every point is seen by at least three cameras
+    kind = int(rng.integers(0, 4))
+    robust = [None, N.HuberKernel(float(rng.uniform(0.005, 0.1))), N.GemanMcclureKernel(float(rng.uniform(0.02, 0.2))),
+              N.Scaled(N.Huber2oKernel(float(rng.uniform(0.005, 0.1))), float(rng.uniform(0.5, 3.0)))][kind]
+    kw = dict(robust=robust, outlier_frac=float(rng.uniform(0.0, 0.3)), outlier_sigma=0.1) if robust is not None else {}
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed, **kw), 1e-3, 1e-3)
+    unfixed = None
+    if rng.random() < 0.5:                                              # fix a few cameras and points (varflags path)
+        unfixed = np.ones(p.nvariables, bool)
+        unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 20), replace=False)] = False
+    check_problem(p, unfixed=unfixed, lam_scale=[1e-6, 1e-4, 1e-1, 1e-2][kind])
+
+
+def test_reupload_on_one_context():
+    """A context is re-used for different structures (Schur, full system, Schur again): nothing of an earlier upload may leak
+    into the solve of a later one."""
+    p1 = synthetic.perturb_ba_problem(synthetic.create_ba_problem(40, 900, 0.1, seed=31), 1e-3, 1e-3)
+    p2 = synthetic.perturb_ba_problem(synthetic.create_ba_problem(12, 80, 0.3, seed=32), 1e-3, 1e-3)
+    ctx = _capi.Context()
+    for p, flags in ((p1, 0), (p2, _capi.FLAG_NO_SCHUR), (p1, 0), (p2, 0), (p1, _capi.FLAG_NO_BAND)):
+        bi = np.arange(1, p.nvariables + 1, dtype=np.uint64)
+        info = ctx.upload(p.var_kind, p.var_dim, bi, p.groups(), flags)
+        ctx.set_variables(p.variables)
+        ctx.sweep_gradhess(); lam = ctx.max_abs_diag() * 1e-4; ctx.damp(lam)
+        x = ctx.solve(want_x=True)
+        ols = oracle_problem(p).linear_system(bi, 0); ols.costgradhess(); assert ols.solve(lam) == 0
+        assert rel(x, ols.x) < RTOL_X, (flags, rel(x, ols.x))
+    ctx.close()
