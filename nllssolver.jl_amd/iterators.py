@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-from ._capi import VARS_CURRENT, VARS_NEXT
+from ._capi import VARS_CURRENT, VARS_NEXT, NllsError, ERR_NOT_SPD
 
 FLOATMIN = sys.float_info.min
 
@@ -57,7 +57,14 @@ def iterate_levmar(lmd, data, problem, options):    # src/iterators.jl:139-172
     mu = 2.0
     while True:
         if hasattr(ls, "lm_trial"):                   # :149-157 in one library call (same kernels, one synchronisation)
-            cost_ = _timed(data, "timesolver", lambda: ls.lm_trial(lmd.lambda_ - lastlambda))
+            try:
+                cost_ = _timed(data, "timesolver", lambda: ls.lm_trial(lmd.lambda_ - lastlambda))
+            except NllsError as e:
+                # A zero / NaN pivot of the damped system (an exactly singular direction at a tiny lambda): the reference's
+                # LDLFactorizations would throw here; the device path treats it as a rejected trial -- more damping, again.
+                if e.code != ERR_NOT_SPD or not math.isfinite(lmd.lambda_ * mu):
+                    raise
+                cost_ = math.inf
             lastlambda = lmd.lambda_
             data.linearsolvers += 1
             data.costcomputations += 1
