@@ -225,3 +225,19 @@ def test_reupload_on_one_context():
         ols = oracle_problem(p).linear_system(bi, 0); ols.costgradhess(); assert ols.solve(lam) == 0
         assert rel(x, ols.x) < RTOL_X, (flags, rel(x, ols.x))
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(300, 316)))
+def test_randomized_so3_against_oracle(seed):
+    """BASELINE config 5 kinds (SO(3) poses, pinhole projection, optional ContaminatedGaussian kernel variable) over
+    seeded random shapes -- border ordering, band / dense reduced systems, 6-dof camera blocks against 3-dof points."""
+    rng = np.random.default_rng(seed)
+    ncam = int(rng.integers(6, 120)); npts = int(rng.integers(60, 2500)); prop = max(float(rng.uniform(0.04, 0.5)), 4.0 / ncam)
+    adaptive = bool(rng.integers(0, 2))
+    robust = None if adaptive else [None, N.HuberKernel(0.05), N.GemanMcclureKernel(0.1)][int(rng.integers(0, 3))]
+    p = synthetic.create_so3_ba_problem(ncam, npts, prop, seed=seed, adaptive=adaptive, robust=robust)
+    p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
+    unfixed = None
+    if rng.random() < 0.3:
+        unfixed = np.ones(p.nvariables, bool); unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 25), replace=False)] = False
+    check_problem(p, unfixed=unfixed, expect_sparse=1, lam_scale=1e-4 if robust is None or adaptive else 1e-1)
