@@ -28,7 +28,11 @@ def main():
     from nllssolver_jl_amd.dist import ShardedLS
     from nllssolver_jl_amd.linearsystem import MultiVariateLSgpu
 
-    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(40, 2000, 0.15, seed=21, robust=N.HuberKernel(0.05),
+    seed = int(sys.argv[5]) if len(sys.argv) > 5 else 21
+    rng = np.random.default_rng(seed)
+    ncr = int(rng.integers(12, 90))             # (sharding partitions by eliminated block: stay within what the Schur kernels take)
+    shape = (40, 2000, 0.15) if seed == 21 else (ncr, int(rng.integers(300, 4000)), float(rng.uniform(4.0, 10.0)) / ncr)
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(*shape, seed=seed, robust=N.HuberKernel(0.05),
                                                                  outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
     unfixed = np.ones(p.nvariables, bool)
     ref = MultiVariateLSgpu(p, unfixed)                       # unsharded reference on the same device

@@ -11,11 +11,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (1, "nccl")])
-def test_sharded_matches_unsharded(world, backend):
+@pytest.mark.parametrize("world,backend,seed", [(2, "gloo", 21), (3, "gloo", 21), (1, "nccl", 21), (2, "gloo", 401), (3, "gloo", 402), (2, "gloo", 403)])
+def test_sharded_matches_unsharded(world, backend, seed):
     """(1, "nccl"): the local / reduce / finish route over RCCL with device buffers, one rank -- the plumbing bench.py --gpus N uses."""
-    port = str(29500 + world)
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port, backend],
+    port = str(29500 + world + seed % 50)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port, backend, str(seed)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     deadline = time.monotonic() + 150          # all ranks share one deadline: a rank that died leaves the others in a collective
