@@ -223,3 +223,21 @@ def test_randomized_optimize_matches_oracle(seed):
         assert res.bestcost < 1e-15 * p.ncosts() and ores.bestcost < 1e-15 * p.ncosts(), (res.bestcost, ores.bestcost)
     else:
         assert np.isclose(res.bestcost, ores.bestcost, rtol=1e-6), (res.bestcost, ores.bestcost)
+
+
+@pytest.mark.parametrize("seed", list(range(500, 508)))
+def test_randomized_optimizesingles_matches_oracle(seed):
+    """optimizesingles! (src/optimize.jl:60-76) over seeded random shapes, plain and robustified, all points or a random subset."""
+    rng = np.random.default_rng(seed)
+    ncam = int(rng.integers(4, 40)); npts = int(rng.integers(30, 900)); prop = max(float(rng.uniform(0.1, 0.6)), 3.0 / ncam)
+    robust = bool(rng.integers(0, 2))
+    kw = dict(robust=N.HuberKernel(float(rng.uniform(0.005, 0.05))), outlier_frac=0.1, outlier_sigma=0.05) if robust else {}
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed, **kw), 3e-3, 0.0)   # points only
+    pts = np.nonzero((p.var_kind == K.VAR_EUCLIDEAN) & (p.var_dim == 3))[0] + 1
+    if rng.random() < 0.5:
+        pts = np.sort(rng.choice(pts, size=max(1, pts.size // 3), replace=False))
+    c0 = N.cost(p)
+    expect = _oracle_optimizesingles(p, pts)
+    N.optimizesingles(p, N.NLLSOptions(), indices=pts)
+    assert N.cost(p) <= c0
+    assert np.max(np.abs(p.variables - expect)) < 1e-7
