@@ -241,3 +241,25 @@ def test_randomized_so3_against_oracle(seed):
     if rng.random() < 0.3:
         unfixed = np.ones(p.nvariables, bool); unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 25), replace=False)] = False
     check_problem(p, unfixed=unfixed, expect_sparse=1, lam_scale=1e-4 if robust is None or adaptive else 1e-1)
+
+
+@pytest.mark.parametrize("seed", list(range(600, 616)))
+def test_randomized_band_shapes(seed):
+    """Long camera chains with 3-11 cameras per point: the blocked band solver over seeded random lengths, bandwidths
+    (NBW 1..5), separator widths and remainders, twisted and one-sided, against the oracle's sparse LDL'."""
+    rng = np.random.default_rng(seed)
+    ncam = int(rng.integers(50, 420)); cpp = float(rng.uniform(3.0, 11.0)); npts = int(rng.integers(10 * ncam, 30 * ncam))
+    kw = dict(robust=N.HuberKernel(0.01), outlier_frac=0.05, outlier_sigma=0.05) if rng.random() < 0.5 else {}
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, cpp / ncam, seed=seed, **kw), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.nreduced_dof == 6 * ncam
+    if info.solve_mode == 2 and rng.random() < 0.5:
+        check_problem(p, flags=_capi.FLAG_NO_TWIST, expect_schur=1)
+
+
+@pytest.mark.parametrize("seed", list(range(700, 706)))
+def test_randomized_dense_curvefit(seed):
+    """BASELINE config 2 shape (scalar residuals over four scalar variables -> BlockDenseMatrix path) at seeded random sizes."""
+    rng = np.random.default_rng(seed)
+    c, _ = synthetic.create_curvefit_problem(int(rng.integers(50, 30_000)), seed=seed)
+    check_problem(c, expect_sparse=0)
