@@ -207,7 +207,8 @@ def test_randomized_ba_against_oracle(seed):
     if rng.random() < 0.5:                                              # fix a few cameras and points (varflags path)
         unfixed = np.ones(p.nvariables, bool)
         unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 20), replace=False)] = False
-    check_problem(p, unfixed=unfixed, lam_scale=[1e-6, 1e-4, 1e-1, 1e-2][kind])
+    flags = [0, 0, _capi.FLAG_FORCE_ATOMIC, _capi.FLAG_NO_BAND, _capi.FLAG_NO_TWIST, _capi.FLAG_FORCE_SPARSE][int(rng.integers(0, 6))]
+    check_problem(p, unfixed=unfixed, flags=flags, lam_scale=[1e-6, 1e-4, 1e-1, 1e-2][kind])
 
 
 def test_reupload_on_one_context():
