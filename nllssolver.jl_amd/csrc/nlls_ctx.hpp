@@ -176,6 +176,7 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_fast_groups, d_slow_groups, d_slow_blocks;   // d_slow_blocks: members of the slow supernodes
     nlls::DevBuf<uint32_t> d_fast_members;   // members of the fast supernodes
     nlls::DevBuf<uint8_t> d_blk_slowmask;    // d_blk entries NOT in rows of fast members (and owned by this rank)
+    nlls::DevBuf<nlls::SchurCopy> d_blk_slow; int64_t nblk_slow = 0;   // the same as a compact list
     nlls::DevBuf<double> tE;                 // E_v s of the last solve per fast member (s = reduced solution): reused by the quadratic form
     bool tE_valid = false; int64_t n_fast_members = 0;
     bool S_zeroed = false;                   // the last solve's back-substitution left S zero-filled for the next one (saves the memset launches)

@@ -1629,10 +1629,10 @@ int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from) {
     }
     const bool reuse = c->tE_valid && c->n_fast_members > 0;
     PostSolveArgs a{};
-    a.A = c->A.p; a.blk = c->d_blk.p; a.nblk = c->nblk; a.blkmask = reuse ? c->d_blk_slowmask.p : (c->nranks > 1 ? c->d_blk_mask.p : (const uint8_t*)nullptr);
+    a.A = c->A.p; a.blk = reuse ? c->d_blk_slow.p : c->d_blk.p; a.nblk = reuse ? c->nblk_slow : c->nblk; a.blkmask = reuse ? (const uint8_t*)nullptr : (c->nranks > 1 ? c->d_blk_mask.p : (const uint8_t*)nullptr);
     a.ediag = c->d_elim_diag.p; a.eboff = c->d_elim_boff.p; a.members = c->d_fast_members.p; a.nm = c->n_fast_members; a.tE = c->tE.p;
     a.x = c->x.p; a.b = c->b.p; a.dofmask = c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr; a.ndof = c->info.ndof;
-    a.np = (int)std::max<int64_t>(1, std::min<int64_t>((c->nblk + 255) / 256, 768));
+    a.np = (int)std::max<int64_t>(1, std::min<int64_t>((a.nblk + 255) / 256, 768));
     a.np3 = reuse ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
     a.np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 256));
     a.partials = c->partials.p; a.part2 = c->partials.p + 1024;

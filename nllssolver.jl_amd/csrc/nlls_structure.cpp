@@ -523,8 +523,12 @@ int build_schur(nlls_ctx* c, int32_t flags) {
       // blocks that quadform_points_kernel covers (rows of fast-path members) are skipped by the block kernel when E x is at hand
       std::vector<uint8_t> slowmask;
       if (I0.is_sparse && c->n_fast_members > 0) for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) slowmask.push_back((uint8_t)(rowmask[row] && !row_fast[row]));
+      // ... as a compact list (bundle adjustment: the camera blocks, ~1e3 of ~1e6), so that the kernel does not walk a mask over all blocks
+      std::vector<SchurCopy> slowblks;
+      for (size_t q = 0; q < slowmask.size(); ++q) if (slowmask[q]) slowblks.push_back(blks[q]);
+      c->nblk_slow = (int64_t)slowblks.size();
       if (hipSuccess != c->d_row_mask.upload(rowmask) || hipSuccess != c->d_blk_mask.upload(blkmask) || hipSuccess != c->d_dof_mask.upload(dofmask) ||
-          hipSuccess != c->d_blk_slowmask.upload(slowmask)) return fail(c, NLLS_ERR_HIP, "mask upload"); }
+          hipSuccess != c->d_blk_slowmask.upload(slowmask) || hipSuccess != c->d_blk_slow.upload(slowblks)) return fail(c, NLLS_ERR_HIP, "mask upload"); }
     if (hipSuccess != c->d_copy.upload(copies) || hipSuccess != c->d_red_boff.upload(red_boff)) return fail(c, NLLS_ERR_HIP, "schur upload");
     // ---- choose the reduced-system solver ----------------------------------------------------------------------
     const int64_t n = c->nred;
