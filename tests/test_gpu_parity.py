@@ -264,3 +264,16 @@ def test_randomized_dense_curvefit(seed):
     rng = np.random.default_rng(seed)
     c, _ = synthetic.create_curvefit_problem(int(rng.integers(50, 30_000)), seed=seed)
     check_problem(c, expect_sparse=0)
+
+
+@pytest.mark.parametrize("seed", list(range(800, 810)))
+def test_randomized_tiny_dense_ba(seed):
+    """test/optimizeba.jl:51 shape (a handful of cameras and points, everything visible): the BlockDenseMatrix path and
+    the one-wave / small dense solvers over seeded random tiny sizes, some variables fixed."""
+    rng = np.random.default_rng(seed)
+    ncam = int(rng.integers(2, 7)); npts = int(rng.integers(4, 30))
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, 1.0, seed=seed), 1e-3, 1e-3)
+    unfixed = None
+    if rng.random() < 0.5:
+        unfixed = np.ones(p.nvariables, bool); unfixed[rng.choice(p.nvariables, size=int(rng.integers(1, 3)), replace=False)] = False
+    check_problem(p, unfixed=unfixed, lam_scale=1e-4)
