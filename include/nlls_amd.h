@@ -237,7 +237,9 @@ int  nlls_solve_finish(nlls_ctx* ctx, double* x_out);
 /* after the stage-2 reduction (x complete): update!(to, from, x), cost(to), fast_bAb(H, x), dot(g, x), max|x|, |x|^2 of one
  * Levenberg-Marquardt trial (src/iterators.jl:155-163) with one synchronisation.  out[5] = [cost, x'Hx, g'x, max|x|, |x|^2];
  * the first three are this rank's partial sums. */
-int  nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out);
+int  nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out);   /* also reports a failed factorisation of the solve before it */
+/* nlls_solve_finish without the synchronisation: for the step of an LM trial, whose status nlls_trial_local reports */
+int  nlls_solve_finish_async(nlls_ctx* ctx);
 int  nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count);
 int  nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count,
                          int64_t* own_offset, int64_t* own_count);

@@ -23,7 +23,7 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve""".split()
 
 
 class NllsError(RuntimeError):
@@ -91,7 +91,7 @@ def lib():
         L.nlls_sweep_gradhess_local.argtypes = [vp]; L.nlls_sweep_gradhess_finish.argtypes = [vp, vp]
         L.nlls_sweep_cost_local.argtypes = [vp, i32]; L.nlls_sweep_cost_finish.argtypes = [vp, vp]
         L.nlls_solve_local.argtypes = [vp]; L.nlls_solve_finish.argtypes = [vp, vp]
-        L.nlls_get_reduce_buffer.argtypes = [vp, i32, vp, vp]; L.nlls_trial_local.argtypes = [vp, i32, i32, vp]
+        L.nlls_get_reduce_buffer.argtypes = [vp, i32, vp, vp]; L.nlls_trial_local.argtypes = [vp, i32, i32, vp]; L.nlls_solve_finish_async.argtypes = [vp]
         L.nlls_get_step_shard.argtypes = [vp, vp, vp, vp, vp]
         L.nlls_get_shard_info.argtypes = [vp, vp, i32]
         L.nlls_time_sweep_gradhess.argtypes = [vp, i32, vp]; L.nlls_time_sweep_cost.argtypes = [vp, i32, vp]; L.nlls_time_sweep_accumulate.argtypes = [vp, i32, vp]
@@ -271,6 +271,9 @@ class Context:
 
     def sweep_gradhess_local(self):
         self._chk(self.L.nlls_sweep_gradhess_local(self.h))
+
+    def solve_finish_async(self):
+        self._chk(self.L.nlls_solve_finish_async(self.h))
 
     def trial_local(self, to=VARS_NEXT, frm=VARS_CURRENT):
         out = np.zeros(5); self._chk(self.L.nlls_trial_local(self.h, to, frm, _p(out))); return out

@@ -230,9 +230,10 @@ int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
     NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from || !out) return NLLS_ERR_INVALID_ARG;
     TRY(enqueue_post_solve(ctx, to, from));        // step statistics, quadratic form and the retraction in one launch
     TRY(enqueue_sweep_cost(ctx, to));
-    HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 10, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));   // [10]: the factorisation status
     HIPCHK(hipStreamSynchronize(ctx->stream));
     out[0] = ctx->h_scalars[0]; out[1] = ctx->h_scalars[8]; out[2] = ctx->h_scalars[5]; out[3] = ctx->h_scalars[1]; out[4] = ctx->h_scalars[2];
+    if ((int32_t)ctx->h_scalars[10] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a zero pivot (code " + std::to_string((int32_t)ctx->h_scalars[10]) + ")");
     return NLLS_OK;
 }
 // optimizesingles!(problem, options, indices)  src/optimize.jl:60-76,183-205
@@ -345,6 +346,9 @@ int nlls_solve_finish(nlls_ctx* ctx, double* x_out) {
     ctx->solved = true;
     if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a zero pivot (code " + std::to_string(status[0]) + ")");
     return NLLS_OK;
+}
+int nlls_solve_finish_async(nlls_ctx* ctx) {          // enqueue only: the status comes home with nlls_trial_local's scalars
+    NEED_GRAD(); TRY(enqueue_solve_finish(ctx)); ctx->solved = true; ctx->step_cached = false; return NLLS_OK;
 }
 int nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count) {
     NEED_READY(); if (!dev_ptr || !count) return NLLS_ERR_INVALID_ARG;

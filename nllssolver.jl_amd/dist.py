@@ -94,19 +94,22 @@ class ShardedLS(MultiVariateLSgpu):
             return super().lm_trial(dlambda)
         # sharded: damp, solve (two buffer reductions), then retraction + cost sweep + step statistics in one call and ONE
         # three-scalar reduction; what the iterator asks next (quadform, step_maxabs) is answered from here
-        self.uniformscaling(dlambda); self.solve()
+        self.uniformscaling(dlambda); self.solve(_in_trial=True)
         out = self.ctx.trial_local(_capi.VARS_NEXT, _capi.VARS_CURRENT)
         c, a, g = self._allreduce_scalars(out[:3])
         self._trial = ((a, g), float(out[3]), float(np.sqrt(out[4])))
         return c
 
-    def solve(self):
+    def solve(self, _in_trial=False):
         if not self.sharded:
             return super().solve()
         self._x = None; self._trial = None
         self.ctx.solve_local()
         self._allreduce_buffer(1)
-        self.ctx.solve_finish()
+        if _in_trial and not self.host_staged:
+            self.ctx.solve_finish_async()              # no synchronisation: nlls_trial_local reports the factorisation status
+        else:
+            self.ctx.solve_finish()
         self._allreduce_buffer(2)
 
     def initlambda(self):
