@@ -45,3 +45,11 @@ def test_config4_noise_free_optimum():
     res = N.optimize(p, N.NLLSOptions(maxiters=30))
     assert res.bestcost < 1e-15 * p.ncosts(), res.bestcost
     assert res.niterations <= 30
+
+
+def test_config5_full_size_so3_adaptive_against_oracle():
+    """BASELINE config 5 at full size: 500 SO(3) cameras x 50k points, ~500k pinhole residual blocks (prop 0.02),
+    ContaminatedGaussian adaptive kernel as a shared variable (the border of the reduced system)."""
+    p = synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(500, 50000, 0.02, seed=1, adaptive=True), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
+    assert info.nreduced_dof == 6 * 500 + 3 and info.nborder_dof == 3
