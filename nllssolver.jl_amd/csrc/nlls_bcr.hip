@@ -1,0 +1,506 @@
+// nlls_bcr.hip -- the bordered-band reduced system by BLOCK CYCLIC REDUCTION (gfx950).
+//
+// Same contract as the rest of the solve (src/linearsolver.jl:28-32, src/iterators.jl:149-153): x solves S x = s.
+// The banded reduced camera system of a bundle adjustment (6000 dof, half bandwidth 65) is a chain of n dependent
+// pivots for any left-to-right LDL'; the twisted two-sided kernel of round 1 still ran 2 x 185 block steps on two of
+// the 256 CUs.  Here the band is cut into N blocks of b = 16 NT >= bw columns -- a block tridiagonal matrix with a
+// few border rows (dense rows ordered last, and the right-hand side as one more row) -- and reduced level by level:
+// every second block of the active chain is eliminated at once (the blocks of one level do not touch each other),
+// its two neighbours receive the Schur complement and become neighbours of each other.  log2 N levels instead of
+// N steps; inside a level every block, and every tile of every update, is independent work for the whole chip.
+// This is LDL' of S in the odd-even (nested dissection) ordering: no pivoting needed for the definite systems
+// Levenberg-Marquardt produces, and no atomics anywhere -- the result is bit-reproducible.
+//
+// Per level, for an eliminated block i with active neighbours l and r:
+//   panel   (bcr_panel_kernel, two workgroups per block)   right-looking LDL' of the 16NT-column panel
+//            [ D_i ; X ],  X = [ A_il' ; A_ri ; border rows ; rhs row ]   ->  W = L Delta (D part and X rows), 1/Delta
+//            16x16 tiles on v_mfma_f64_16x16x4_f64: the diagonal tile is factored in the accumulator layout together
+//            with inv(L_JJ), the sub-diagonal tiles are matrix products, the next diagonal tile stays in wave 0's
+//            registers (look-ahead), everything else is done by the other seven waves behind wave 0's factorisation;
+//   update  (bcr_update_kernel, one wavefront per output tile)   D_l, D_r, the border/rhs rows of l and r, the new
+//            coupling A_rl = -W_r Delta^-1 W_l' and the border corner's share, each  sum_J W_P,J Delta_J^-1 W_Q,J';
+//   the factor is exported pre-multiplied by inv(L_JJ) (M = L inv(L_JJ)), so that the backward pass
+//   (bcr_backward_kernel, levels in reverse) is matrix-vector products only:
+//            x_i,J = zh_J - sum_X M_X,J' x_X - sum_{K>J} M_KJ' x_i,K .
+#include <algorithm>
+
+#include "nlls_bcr.hpp"
+
+namespace nlls {
+
+typedef double bdouble4_t __attribute__((ext_vector_type(4)));
+constexpr int BP = 17, BTS = 16 * BP;             // LDS tile: 16 rows padded to 17 doubles
+constexpr int BCR_T = 512;                        // threads of the panel kernel: wave 0 factors, seven waves help
+constexpr int BCR_MAXNT = 5;
+
+#define BCR_DEV __device__ __forceinline__
+
+BCR_DEV double bcr_readlane(double x, int k) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
+}
+BCR_DEV int bcr_dtile(int I, int K) { return I * (I + 1) / 2 + K; }      // lower tiles of a block, I >= K
+
+// ---------------------------------------------------------------------------------------------------
+// band storage -> block tridiagonal tiles.  Tiles are 16x16 row-major ([row][col], 256 doubles):
+//   D[k]  : NT(NT+1)/2 lower tiles of block k (diagonal tiles full and symmetric); columns >= n_band: identity
+//   A[k]  : NT x NT tiles of S(block k, block k-1)
+//   BR[k] : NT tiles, rows 0..nbd-1 the border rows, row nbd the right-hand side, for the columns of block k
+//   cp[0] : the border corner (rows/cols = border index; row nbd = the border part of the rhs), full symmetric
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bcr_convert_kernel(BcrGeom g, const double* __restrict__ Sb) {
+    const int NT = g.NT, ND = NT * (NT + 1) / 2, per = ND + NT * NT + NT, b = 16 * NT;
+    const int bid = blockIdx.x;
+    const int a = threadIdx.x & 15, bc = threadIdx.x >> 4;      // a = row inside the tile (fastest: consecutive band entries), bc = column
+    if (bid == g.N * per) {
+        const int nbr = g.nbd + 1; double v = 0.0;
+        if (a < nbr && bc < nbr) { const int hi = a > bc ? a : bc, lo = a > bc ? bc : a; v = Sb[(size_t)g.n_band * g.H + hi + nbr * lo]; }
+        g.ws[g.ocp + a * 16 + bc] = v;
+        return;
+    }
+    const int k = bid / per, t = bid % per;
+    double v = 0.0; double* dst;
+    if (t < ND) {
+        int I = 0; while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int K = t - I * (I + 1) / 2;
+        int row = b * k + 16 * I + a, col = b * k + 16 * K + bc;
+        if (row < col) { const int tmp = row; row = col; col = tmp; }
+        if (row < g.n_band) { const int e = row - col; if (e <= g.bw) v = Sb[(size_t)col * g.H + e]; }
+        else v = (row == col) ? 1.0 : 0.0;
+        dst = g.ws + g.oD + ((size_t)k * ND + t) * 256;
+    } else if (t < ND + NT * NT) {
+        const int tt = t - ND, P = tt / NT, Q = tt % NT;
+        if (k > 0) { const int row = b * k + 16 * P + a, col = b * (k - 1) + 16 * Q + bc, e = row - col; if (row < g.n_band && e <= g.bw) v = Sb[(size_t)col * g.H + e]; }
+        dst = g.ws + g.oA + ((size_t)k * NT * NT + tt) * 256;
+    } else {
+        const int K = t - ND - NT * NT, col = b * k + 16 * K + bc;
+        if (col < g.n_band && a <= g.nbd) v = Sb[(size_t)col * g.H + g.bw + 1 + a];
+        dst = g.ws + g.oBR + ((size_t)k * NT + K) * 256;
+    }
+    dst[a * 16 + bc] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// panel kernel: device functions (tile layouts as in band_blocked_factor_kernel, nlls_solve.hip)
+// ---------------------------------------------------------------------------------------------------
+// LDL' of one 16x16 diagonal tile on the matrix cores.  The tile sits in the accumulator layout of
+// v_mfma_f64_16x16x4_f64 (register r of lane (li, lk) = T[lk + 4r][li]) and is kept symmetric, so row k -- one register,
+// the 16 lanes with lk = k % 4 -- is the pivot column: with every other lane zeroed it is directly the A operand
+// (A[i][kk] = w_i) and, scaled by -1/d, the B operand: one MFMA is the whole rank-1 update.  A second accumulator starts
+// as the identity and ends as inv(L).  Out: Wd (row-major, LDS) = the factored tile (L Delta below, Delta on the
+// diagonal), Lid = inv(L)' ([k][j] = inv(L)[j][k]), dd[0..15] = Delta, dd[16..31] = 1 / Delta.
+BCR_DEV void bcr_factor(const double* T0, const bdouble4_t* Ain, double* Wd, double* Lid, double* dd, int* status, int pivbase, bool report) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    bdouble4_t A, Bt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { A[r] = Ain ? (*Ain)[r] : T0[(lk + 4 * r) * BP + li]; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
+    int badk = 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int q = k & 3, r = k >> 2;
+        const double w = A[r], bt = Bt[r];
+        const double dk = bcr_readlane(w, 16 * q + k);
+        double rdk = __builtin_amdgcn_rcp(dk);
+        const bool rowq = lk == q;
+        const double am = (rowq && li > k) ? w : 0.0;
+        const double bm = rowq ? bt : 0.0;
+        rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
+        if (!(fabs(dk) > 0.0)) badk = badk < k ? badk : k;
+        dd[k] = dk; dd[16 + k] = rdk;
+        if (k < 15) {
+            A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
+            Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { Wd[(lk + 4 * r) * BP + li] = A[r]; Lid[li * BP + (lk + 4 * r)] = Bt[r]; }
+    if (report && badk < 16 && lane == 0) atomicCAS(status, 0, 1 + pivbase + badk);
+}
+// W = T inv(L)'   (one wavefront, one tile)
+BCR_DEV void bcr_panel_tile(const double* T, const double* Lid, double* Wt) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    double av[4], bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { av[kk] = T[li * BP + 4 * kk + lk]; bv[kk] = Lid[(4 * kk + lk) * BP + li]; }
+    bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[(lk + 4 * r) * BP + li] = acc[r] + acc2[r];
+}
+// wave 0 between two factorisations: W_1 = T_1 inv(L)' formed TRANSPOSED (its accumulator layout is the operand layout
+// of the update), then  C -= W_1 (W_1 / Delta)'  on the next diagonal tile, which stays in registers.
+BCR_DEV void bcr_panel_update_diag(const double* T, const double* Lid, const double* rd, double* Wt, const double* Ct0, bdouble4_t& diag_out) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    double av[4], bv[4], rdk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { av[kk] = T[li * BP + 4 * kk + lk]; bv[kk] = Lid[(4 * kk + lk) * BP + li]; rdk[kk] = rd[4 * kk + lk]; }
+    const double* Ct = Ct0 + lk * BP + li;
+    bdouble4_t c, c2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = Ct[4 * r * BP];
+    bdouble4_t a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[0], av[0], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[1], av[1], a2, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[2], av[2], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[3], av[3], a2, 0, 0, 0);
+    double w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = a1[r] + a2[r];            // W_1[li][lk + 4 r]
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-w[0], w[0] * rdk[0], c, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w[1], w[1] * rdk[1], c2, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-w[2], w[2] * rdk[2], c, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w[3], w[3] * rdk[3], c2, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[li * BP + lk + 4 * r] = w[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) diag_out[r] = c[r] + c2[r];
+}
+// up to MAXU tile-updates  C -= W_I (W_K / Delta)'  by one wavefront: all operand loads, then the MFMAs, then the stores
+template <int MAXU>
+BCR_DEV void bcr_update_batch(int n, double* (&C)[MAXU], const double* (&Wi)[MAXU], const double* (&Wk)[MAXU], const double* rd) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int lo = li * BP + lk, co = lk * BP + li;
+    double rdk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) rdk[kk] = rd[4 * kk + lk];
+    bdouble4_t acc[MAXU], acc2[MAXU]; double wv[MAXU][4], lv[MAXU][4];
+#pragma unroll
+    for (int q = 0; q < MAXU; ++q) if (q < n) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { wv[q][kk] = -Wi[q][lo + 4 * kk]; lv[q][kk] = Wk[q][lo + 4 * kk] * rdk[kk]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = C[q][co + 4 * r * BP];
+        acc2[q] = bdouble4_t{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int q = 0; q < MAXU; ++q) if (q < n) {
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][0], lv[q][0], acc[q], 0, 0, 0);
+        acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][1], lv[q][1], acc2[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXU; ++q) if (q < n) {
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][2], lv[q][2], acc[q], 0, 0, 0);
+        acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][3], lv[q][3], acc2[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXU; ++q) if (q < n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[q][co + 4 * r * BP] = acc[q][r] + acc2[q][r];
+    }
+}
+// export of one panel tile:  M = (W / Delta) inv(L_JJ)  row-major to dstM (backward pass);  W itself in the MFMA operand
+// order (lane, kk) -> W[li][4 kk + lk] to dstW (update kernel), when wanted
+BCR_DEV void bcr_export_tile(const double* Wt, const double* rd, const double* Lid, double* __restrict__ dstM, double* __restrict__ dstW) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    double wv[4], av[4], bv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { wv[m] = Wt[li * BP + 4 * m + lk]; av[m] = wv[m] * rd[4 * m + lk]; bv[m] = Lid[li * BP + 4 * m + lk]; }
+    bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dstM[(lk + 4 * r) * 16 + li] = acc[r] + acc2[r];
+    if (dstW) *reinterpret_cast<bdouble4_t*>(dstW + 4 * lane) = bdouble4_t{wv[0], wv[1], wv[2], wv[3]};
+}
+
+struct BcrPanelArgs { BcrGeom g; const BcrElim* jobs; int* status; };
+
+// Two workgroups per eliminated block: part 0 carries the X rows of the left neighbour (A_il'), part 1 those of the right
+// neighbour (A_ri) and the border / rhs rows; both factor D_i (identical arithmetic, identical bits).
+__global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const BcrGeom& g = a.g;
+    const BcrElim job = a.jobs[blockIdx.x >> 1]; const int part = blockIdx.x & 1;
+    if (part == 0 && job.l < 0) return;
+    const int NT = g.NT, ND = NT * (NT + 1) / 2, RXT = 2 * NT + 1, PR = 2 * NT + 1;
+    const int RXr = part == 0 ? NT : (job.r >= 0 ? NT : 0), RX = part == 0 ? NT : RXr + 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* Dt = sm;                                  // [ND] lower tiles of D_i
+    double* Xt = Dt + ND * BTS;                       // [RX][NT]
+    double* Wp = Xt + (NT + 1) * NT * BTS;            // [2][PR][16][BP]: panel W of block column J, by parity; rows 0..NT-1 the D part, NT.. the X rows
+    double* dvec = Wp + 2 * PR * 16 * BP;             // [2][32]
+    double* Li = dvec + 64;                           // [2][16][BP]
+    // ---- landing
+    {
+        const double* Dg = g.ws + g.oD + (size_t)job.i * ND * 256;
+        for (int w = tid; w < ND * 256; w += BCR_T) Dt[(w >> 8) * BTS + ((w >> 4) & 15) * BP + (w & 15)] = Dg[w];
+        if (part == 0) {
+            const double* Ag = g.ws + g.oA + (size_t)job.i * NT * NT * 256;          // rows: block i, columns: block l -- transposed in
+            for (int w = tid; w < NT * NT * 256; w += BCR_T) {
+                const int tx = w >> 8, R = tx / NT, K = tx - R * NT, bb = (w >> 4) & 15, aa = w & 15;
+                Xt[(R * NT + K) * BTS + aa * BP + bb] = Ag[(size_t)(K * NT + R) * 256 + bb * 16 + aa];
+            }
+        } else {
+            if (RXr) {
+                const double* Ag = g.ws + g.oA + (size_t)job.r * NT * NT * 256;      // rows: block r, columns: block i
+                for (int w = tid; w < NT * NT * 256; w += BCR_T) Xt[(w >> 8) * BTS + ((w >> 4) & 15) * BP + (w & 15)] = Ag[w];
+            }
+            const double* Bg = g.ws + g.oBR + (size_t)job.i * NT * 256;
+            for (int w = tid; w < NT * 256; w += BCR_T) Xt[(RXr * NT + (w >> 8)) * BTS + ((w >> 4) & 15) * BP + (w & 15)] = Bg[w];
+        }
+    }
+    __syncthreads();
+    double* const Mdg = g.ws + g.oMd + (size_t)job.i * (NT * (NT - 1) / 2) * 256;
+    double* const Mxg = g.ws + g.oMx + (size_t)job.i * RXT * NT * 256;
+    double* const Wxg = g.ws + g.oWx + (size_t)job.i * RXT * NT * 256;
+    double* const rdg = g.ws + g.ord + (size_t)job.i * 16 * NT;
+    // tile-updates of block column Jp (panel Jp complete) other than the next diagonal tile, dealt over nh waves
+    auto updates = [&](int Jp, int hw, int nh) {
+        const double* Wprev = Wp + (Jp & 1) * PR * 16 * BP; const double* rd = dvec + (Jp & 1) * 32 + 16;
+        const int m = NT - 1 - Jp; if (m <= 0) return;
+        const int nDj = m * (m + 1) / 2 - 1, ntot = nDj + RX * m;
+        for (int u0 = hw; u0 < ntot; u0 += 3 * nh) {
+            double* C[3]; const double* Wi[3]; const double* Wk[3]; int n = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int u = u0 + q * nh; C[q] = nullptr; Wi[q] = nullptr; Wk[q] = nullptr;
+                if (u >= ntot) continue;
+                n = q + 1;
+                if (u < nDj) { int up = u + 1, K = Jp + 1, cnt = m; while (up >= cnt) { up -= cnt; --cnt; ++K; }
+                    const int I = K + up; C[q] = Dt + bcr_dtile(I, K) * BTS; Wi[q] = Wprev + I * 16 * BP; Wk[q] = Wprev + K * 16 * BP; }
+                else { const int v = u - nDj, R = v / m, K = Jp + 1 + (v - R * m);
+                    C[q] = Xt + (R * NT + K) * BTS; Wi[q] = Wprev + (NT + R) * 16 * BP; Wk[q] = Wprev + K * 16 * BP; }
+            }
+            bcr_update_batch<3>(n, C, Wi, Wk, rd);
+        }
+    };
+    auto exports = [&](int Jp, int hw, int nh) {
+        const double* Wprev = Wp + (Jp & 1) * PR * 16 * BP; const double* rd = dvec + (Jp & 1) * 32 + 16; const double* Lid = Li + (Jp & 1) * 16 * BP;
+        const int nDe = part == 1 ? NT - 1 - Jp : 0, ne = nDe + RX;
+        for (int e = hw; e < ne; e += nh) {
+            if (e < nDe) { const int I = Jp + 1 + e; bcr_export_tile(Wprev + I * 16 * BP, rd, Lid, Mdg + (size_t)(I * (I - 1) / 2 + Jp) * 256, nullptr); }
+            else { const int R = e - nDe, Rg = part == 0 ? R : (R < RXr ? NT + R : 2 * NT);
+                bcr_export_tile(Wprev + (NT + R) * 16 * BP, rd, Lid, Mxg + (size_t)(Rg * NT + Jp) * 256, Wxg + (size_t)(Rg * NT + Jp) * 256); }
+        }
+        if (part == 1 && hw == 0 && lane < 16) rdg[16 * Jp + lane] = rd[lane];
+    };
+    bdouble4_t diag = {0, 0, 0, 0};
+    for (int J = 0; J < NT; ++J) {
+        double* Wb = Wp + (J & 1) * PR * 16 * BP; double* Lid = Li + (J & 1) * 16 * BP; double* db = dvec + (J & 1) * 32;
+        if (wave == 0) bcr_factor(Dt + bcr_dtile(J, J) * BTS, J > 0 ? &diag : nullptr, Wb + J * 16 * BP, Lid, db, a.status, 16 * NT * job.i + 16 * J, part == 1);
+        else if (J > 0) { updates(J - 1, wave - 1, 7); exports(J - 1, wave - 1, 7); }
+        __syncthreads();                                  // diagonal tile factored; block column J final
+        if (J + 1 < NT) {
+            if (wave == 0) bcr_panel_update_diag(Dt + bcr_dtile(J + 1, J) * BTS, Lid, db + 16, Wb + (J + 1) * 16 * BP, Dt + bcr_dtile(J + 1, J + 1) * BTS, diag);
+            else {
+                const int nD = NT - J - 2;
+                for (int p = wave - 1; p < nD + RX; p += 7) {
+                    if (p < nD) bcr_panel_tile(Dt + bcr_dtile(J + 2 + p, J) * BTS, Lid, Wb + (J + 2 + p) * 16 * BP);
+                    else bcr_panel_tile(Xt + ((p - nD) * NT + J) * BTS, Lid, Wb + (NT + p - nD) * 16 * BP);
+                }
+            }
+        } else {
+            for (int p = wave; p < RX; p += 8) bcr_panel_tile(Xt + (p * NT + J) * BTS, Lid, Wb + (NT + p) * 16 * BP);
+        }
+        __syncthreads();                                  // panel J in LDS
+    }
+    exports(NT - 1, wave, 8);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Schur update of a level: one wavefront per output tile, operands straight from the exported panels (L2 / MALL)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs, int NT) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6); if (j >= njobs) return;
+    const BcrUpd u = jobs[j];
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    for (uint32_t c = 0; c < u.nc; ++c) {
+        const double* A = ws + u.a[c] + 4 * lane; const double* B = ws + u.b[c] + 4 * lane; const double* rd = ws + u.rd[c] + lk;
+        for (int J = 0; J < NT; ++J) {
+            const bdouble4_t av = *reinterpret_cast<const bdouble4_t*>(A + 256 * J), bv = *reinterpret_cast<const bdouble4_t*>(B + 256 * J);
+            const double r0 = rd[16 * J], r1 = rd[16 * J + 4], r2 = rd[16 * J + 8], r3 = rd[16 * J + 12];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0] * r0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1] * r1, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2] * r2, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3] * r3, acc2, 0, 0, 0);
+        }
+    }
+    double* dst = ws + u.dst + lk * 16 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = acc[r] + acc2[r];
+        if (u.mode == 0) dst[64 * r] -= v; else dst[64 * r] = (u.mode == 1) ? -v : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward pass of one level: one workgroup per block eliminated at that level
+// ---------------------------------------------------------------------------------------------------
+struct BcrBackArgs { BcrGeom g; const BcrElim* jobs; double* xr; int root; int* status; };
+__global__ __launch_bounds__(256) void bcr_backward_kernel(BcrBackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const BcrGeom& g = a.g;
+    const BcrElim job = a.jobs[blockIdx.x];
+    const int NT = g.NT, RXT = 2 * NT + 1, NO = NT * (NT - 1) / 2, b = 16 * NT, nbd = g.nbd, nbr = nbd + 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, gq = lane >> 4;
+    double* xs = sm;                               // [RXT][16]
+    double* red = xs + RXT * 16;                   // [NT][4][16]
+    double* tt = red + NT * 64;                    // [NT][16]
+    double* xi = tt + NT * 16;                     // [NT][16]
+    double* Mdl = xi + NT * 16;                    // [NO][256]
+    double* Cl = Mdl + NO * 256;                   // [16][16] corner (root only)
+    double* xb = Cl + 256;                         // [16]
+    if (a.root) {
+        if (nbd > 0) {
+            // corner = cp[0] - sum_i cp[1 + i], blocks in index order (fixed order: reproducible)
+            double v = g.ws[g.ocp + tid];
+            for (int i = 0; i < g.N; ++i) v -= g.ws[g.ocp + (size_t)(1 + i) * 256 + tid];
+            Cl[tid] = v;
+            __syncthreads();
+            if (tid == 0) {                        // LDL' of the nbd x nbd corner with the rhs row riding along (rows/cols of Cl: [row][col])
+                for (int j = 0; j < nbd; ++j) {
+                    double d = Cl[j * 16 + j];
+                    if (d == 0.0 || d != d) { atomicCAS(a.status, 0, 1 + g.n_band + j); d = 1.0; }
+                    for (int c2 = j + 1; c2 < nbd; ++c2) { const double f = Cl[c2 * 16 + j] / d; for (int i = c2; i < nbr; ++i) Cl[i * 16 + c2] -= Cl[i * 16 + j] * f; }
+                    for (int i = j + 1; i < nbr; ++i) Cl[i * 16 + j] /= d;
+                    Cl[j * 16 + j] = d;
+                }
+                for (int r = nbd - 1; r >= 0; --r) { double v2 = Cl[nbd * 16 + r]; for (int r2 = r + 1; r2 < nbd; ++r2) v2 -= Cl[r2 * 16 + r] * xb[r2]; xb[r] = v2; }
+            }
+            __syncthreads();
+            if (tid < nbd) { g.ws[g.oxb + tid] = xb[tid]; a.xr[g.n_band + tid] = xb[tid]; }
+        }
+    } else if (tid < nbd) xb[tid] = g.ws[g.oxb + tid];
+    __syncthreads();
+    for (int t = tid; t < RXT * 16; t += 256) {
+        const int R = t >> 4, q = t & 15; double v = 0.0;
+        if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) v = a.xr[row]; } }
+        else if (R < 2 * NT) { if (job.r >= 0) { const int row = b * job.r + 16 * (R - NT) + q; if (row < g.n_band) v = a.xr[row]; } }
+        else v = q < nbd ? xb[q] : (q == nbd ? -1.0 : 0.0);      // the rhs row is a border row whose unknown is -1
+        xs[t] = v;
+    }
+    {
+        const double* Mdg = g.ws + g.oMd + (size_t)job.i * NO * 256;
+        for (int w = tid; w < NO * 256; w += 256) Mdl[w] = Mdg[w];
+    }
+    __syncthreads();
+    const double* Mxg = g.ws + g.oMx + (size_t)job.i * RXT * NT * 256;
+    for (int J = wave; J < NT; J += 4) {
+        double acc = 0.0;
+        for (int R = 0; R < RXT; ++R) {
+            if (R < NT ? job.l < 0 : (R < 2 * NT && job.r < 0)) continue;
+            const double* M = Mxg + (size_t)(R * NT + J) * 256 + c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = fma(M[(gq + 4 * q) * 16], xs[16 * R + gq + 4 * q], acc);
+        }
+        red[(J * 4 + gq) * 16 + c] = acc;
+    }
+    __syncthreads();
+    if (tid < NT * 16) { const int J = tid >> 4, cc = tid & 15; tt[tid] = -((red[(J * 4 + 0) * 16 + cc] + red[(J * 4 + 1) * 16 + cc]) + (red[(J * 4 + 2) * 16 + cc] + red[(J * 4 + 3) * 16 + cc])); }
+    __syncthreads();
+    // the block's own triangle: x_J = t_J - sum_{K > J} M_KJ' x_K, J = NT-1 .. 0 (wave 0; one barrier per step)
+    for (int J = NT - 1; J >= 0; --J) {
+        if (wave == 0) {
+            double s = 0.0;
+            for (int K = J + 1; K < NT; ++K) {
+                const double* M = Mdl + (K * (K - 1) / 2 + J) * 256 + c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s = fma(M[(gq + 4 * q) * 16], xi[16 * K + gq + 4 * q], s);
+            }
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            if (gq == 0) {
+                const double x = tt[16 * J + c] - s; xi[16 * J + c] = x;
+                const int row = b * job.i + 16 * J + c; if (row < g.n_band) a.xr[row] = x;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------
+bool BcrSolver::supports(int64_t n_band, int bw, int nbd) {
+    return bw >= 1 && (bw + 15) / 16 <= BCR_MAXNT && nbd <= 15 && n_band >= 1 && n_band < (int64_t)1 << 30;
+}
+
+int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* err) {
+    release();
+    n_band = (int)n_band_; bw = bw_; nbd = nbd_; H = H_;
+    NT = std::max(1, (bw + 15) / 16); const int b = 16 * NT; N = (n_band + b - 1) / b;
+    const int ND = NT * (NT + 1) / 2, NO = NT * (NT - 1) / 2, RXT = 2 * NT + 1;
+    size_t off = 0;
+    auto take = [&](size_t doubles) { const size_t o = off; off += (doubles + 31) & ~(size_t)31; return o; };
+    geom = BcrGeom{};
+    geom.oD = take((size_t)N * ND * 256); geom.oA = take((size_t)N * NT * NT * 256); geom.oBR = take((size_t)N * NT * 256);
+    geom.oWx = take((size_t)N * RXT * NT * 256); geom.oMx = take((size_t)N * RXT * NT * 256); geom.oMd = take((size_t)N * std::max(NO, 1) * 256);
+    geom.ord = take((size_t)N * 16 * NT); geom.ocp = take((size_t)(N + 1) * 256); geom.oxb = take(32);
+    if (off >= ((size_t)1 << 32)) { if (err) *err = "block cyclic reduction workspace exceeds 32-bit tile offsets"; return NLLS_ERR_UNSUPPORTED; }
+    geom.NT = NT; geom.N = N; geom.nbd = nbd; geom.n_band = n_band; geom.bw = bw; geom.H = H;
+    std::vector<BcrElim> elims; std::vector<BcrUpd> upds;
+    std::vector<int> active(N); for (int k = 0; k < N; ++k) active[k] = k;
+    auto wx = [&](int src, int P) { return (uint32_t)(geom.oWx + ((size_t)src * RXT + P) * NT * 256); };
+    auto rdo = [&](int src) { return (uint32_t)(geom.ord + (size_t)src * 16 * NT); };
+    while (active.size() > 1) {
+        BcrLevel lv; lv.elim_off = elims.size(); lv.upd_off = upds.size();
+        for (size_t idx = 1; idx < active.size(); idx += 2)
+            elims.push_back(BcrElim{active[idx], active[idx - 1], idx + 1 < active.size() ? active[idx + 1] : -1, 0});
+        for (size_t idx = 0; idx < active.size(); idx += 2) {
+            const int j = active[idx];
+            int src[2], so[2], ns = 0;
+            if (idx >= 1) { src[ns] = active[idx - 1]; so[ns] = NT; ++ns; }               // j is the right neighbour of the block eliminated on its left
+            if (idx + 1 < active.size()) { src[ns] = active[idx + 1]; so[ns] = 0; ++ns; }  // ... and the left neighbour of the one on its right
+            if (!ns) continue;
+            for (int I = 0; I < NT; ++I) for (int K = 0; K <= I; ++K) {
+                BcrUpd u{}; u.dst = (uint32_t)(geom.oD + ((size_t)j * ND + I * (I + 1) / 2 + K) * 256); u.mode = 0; u.nc = ns;
+                for (int s = 0; s < ns; ++s) { u.a[s] = wx(src[s], so[s] + I); u.b[s] = wx(src[s], so[s] + K); u.rd[s] = rdo(src[s]); }
+                upds.push_back(u);
+            }
+            for (int K = 0; K < NT; ++K) {
+                BcrUpd u{}; u.dst = (uint32_t)(geom.oBR + ((size_t)j * NT + K) * 256); u.mode = 0; u.nc = ns;
+                for (int s = 0; s < ns; ++s) { u.a[s] = wx(src[s], 2 * NT); u.b[s] = wx(src[s], so[s] + K); u.rd[s] = rdo(src[s]); }
+                upds.push_back(u);
+            }
+        }
+        for (size_t e = lv.elim_off; e < elims.size(); ++e) {
+            const BcrElim& el = elims[e];
+            if (el.r >= 0) for (int P = 0; P < NT; ++P) for (int Q = 0; Q < NT; ++Q) {     // the new coupling (rows: block r, columns: block l)
+                BcrUpd u{}; u.dst = (uint32_t)(geom.oA + ((size_t)el.r * NT * NT + P * NT + Q) * 256); u.mode = 1; u.nc = 1;
+                u.a[0] = wx(el.i, NT + P); u.b[0] = wx(el.i, Q); u.rd[0] = rdo(el.i); upds.push_back(u);
+            }
+            if (nbd > 0) { BcrUpd u{}; u.dst = (uint32_t)(geom.ocp + (size_t)(1 + el.i) * 256); u.mode = 2; u.nc = 1; u.a[0] = u.b[0] = wx(el.i, 2 * NT); u.rd[0] = rdo(el.i); upds.push_back(u); }
+        }
+        lv.nelim = (int)(elims.size() - lv.elim_off); lv.nupd = (int)(upds.size() - lv.upd_off);
+        levels.push_back(lv);
+        std::vector<int> next; for (size_t idx = 0; idx < active.size(); idx += 2) next.push_back(active[idx]);
+        active.swap(next);
+    }
+    {   // the root block
+        BcrLevel lv; lv.elim_off = elims.size(); lv.upd_off = upds.size();
+        elims.push_back(BcrElim{active[0], -1, -1, 0});
+        if (nbd > 0) { BcrUpd u{}; u.dst = (uint32_t)(geom.ocp + (size_t)(1 + active[0]) * 256); u.mode = 2; u.nc = 1; u.a[0] = u.b[0] = wx(active[0], 2 * NT); u.rd[0] = rdo(active[0]); upds.push_back(u); }
+        lv.nelim = 1; lv.nupd = (int)(upds.size() - lv.upd_off);
+        levels.push_back(lv);
+    }
+    if (hipSuccess != ws.alloc(off) || hipSuccess != d_elim.upload(elims) || hipSuccess != d_upd.upload(upds)) { if (err) *err = "block cyclic reduction workspace alloc"; return NLLS_ERR_HIP; }
+    if (hipSuccess != hipMemset(ws.p, 0, off * sizeof(double))) { if (err) *err = "workspace memset"; return NLLS_ERR_HIP; }
+    geom.ws = ws.p;
+    panel_lds = sizeof(double) * ((size_t)(ND + (NT + 1) * NT) * BTS + 2 * (size_t)RXT * 16 * BP + 64 + 2 * 16 * BP);
+    back_lds = sizeof(double) * ((size_t)RXT * 16 + NT * 64 + 2 * NT * 16 + (size_t)NO * 256 + 256 + 16);
+    launches = 1; for (auto& lv : levels) launches += 2 + (lv.nupd > 0);
+    ready = true;
+    return NLLS_OK;
+}
+
+int BcrSolver::enqueue(hipStream_t st, const double* Sb, double* xr, int* status) const {
+    const int ND = NT * (NT + 1) / 2, per = ND + NT * NT + NT;
+    hipLaunchKernelGGL(bcr_convert_kernel, dim3((unsigned)(N * per + 1)), dim3(256), 0, st, geom, Sb);
+    for (const BcrLevel& lv : levels) {
+        BcrPanelArgs pa{geom, d_elim.p + lv.elim_off, status};
+        hipLaunchKernelGGL(bcr_panel_kernel, dim3((unsigned)(2 * lv.nelim)), dim3(BCR_T), panel_lds, st, pa);
+        if (lv.nupd > 0) hipLaunchKernelGGL(bcr_update_kernel, dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, geom.ws, d_upd.p + lv.upd_off, lv.nupd, NT);
+    }
+    for (size_t li = levels.size(); li-- > 0;) {
+        const BcrLevel& lv = levels[li];
+        BcrBackArgs ba{geom, d_elim.p + lv.elim_off, xr, li + 1 == levels.size() ? 1 : 0, status};
+        hipLaunchKernelGGL(bcr_backward_kernel, dim3((unsigned)lv.nelim), dim3(256), back_lds, st, ba);
+    }
+    return hipGetLastError() == hipSuccess ? NLLS_OK : NLLS_ERR_HIP;
+}
+
+}  // namespace nlls

@@ -1,0 +1,41 @@
+// nlls_bcr.hpp -- block cyclic reduction solver for the bordered-band reduced system (see nlls_bcr.hip)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "nlls_ctx.hpp"
+
+namespace nlls {
+
+struct BcrElim { int32_t i, l, r, pad; };          // block i is eliminated between its active neighbours l and r (-1: none)
+// one 16x16 output tile of a level's Schur update:  dst (-)= sum_c  Wx[a_c] Delta_c^-1 Wx[b_c]'   (offsets in doubles into the workspace)
+struct BcrUpd { uint32_t dst, mode, nc, pad; uint32_t a[2], b[2], rd[2]; };
+struct BcrLevel { int nelim = 0, nupd = 0; size_t elim_off = 0, upd_off = 0; };
+
+// workspace geometry handed to the kernels
+struct BcrGeom {
+    double* ws; size_t oD, oA, oBR, oWx, oMx, oMd, ord, ocp, oxb;
+    int NT, N, nbd, n_band, bw, H;
+};
+
+struct BcrSolver {
+    int n_band = 0, bw = 0, nbd = 0, H = 0, NT = 0, N = 0;
+    bool ready = false;
+    std::vector<BcrLevel> levels;                 // elimination levels, the root block last
+    DevBuf<double> ws; DevBuf<BcrElim> d_elim; DevBuf<BcrUpd> d_upd;
+    BcrGeom geom{};
+    size_t panel_lds = 0, back_lds = 0;
+    int launches = 0;
+
+    static bool supports(int64_t n_band, int bw, int nbd);
+    int build(int64_t n_band, int bw, int nbd, int H, std::string* err);
+    // Sb: band storage [S | corner] as assembled by the Schur elimination (SLayout, mode SOLVE_BAND); xr: n_band + nbd unknowns out
+    int enqueue(hipStream_t st, const double* Sb, double* xr, int* status) const;
+    void release() { ws.release(); d_elim.release(); d_upd.release(); levels.clear(); ready = false; }
+};
+
+}  // namespace nlls
