@@ -190,9 +190,9 @@ BCR_DEV void bcr_update_batch(int n, double* (&C)[MAXU], const double* (&Wi)[MAX
         for (int r = 0; r < 4; ++r) C[q][co + 4 * r * BP] = acc[q][r] + acc2[q][r];
     }
 }
-// export of one panel tile:  M = (W / Delta) inv(L_JJ)  row-major to dstM (backward pass);  W itself in the MFMA operand
-// order (lane, kk) -> W[li][4 kk + lk] to dstW (update kernel), when wanted
-BCR_DEV void bcr_export_tile(const double* Wt, const double* rd, const double* Lid, double* __restrict__ dstM, double* __restrict__ dstW) {
+// export of one panel tile:  M = (W / Delta) inv(L_JJ)  row-major to dstM (backward pass);  W and L = W / Delta in the MFMA
+// operand order (lane, kk) -> [li][4 kk + lk] to dstW / dstL (update kernel), when wanted
+BCR_DEV void bcr_export_tile(const double* Wt, const double* rd, const double* Lid, double* __restrict__ dstM, double* __restrict__ dstW, double* __restrict__ dstL) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     double wv[4], av[4], bv[4];
 #pragma unroll
@@ -204,7 +204,10 @@ BCR_DEV void bcr_export_tile(const double* Wt, const double* rd, const double* L
     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) dstM[(lk + 4 * r) * 16 + li] = acc[r] + acc2[r];
-    if (dstW) *reinterpret_cast<bdouble4_t*>(dstW + 4 * lane) = bdouble4_t{wv[0], wv[1], wv[2], wv[3]};
+    if (dstW) {
+        *reinterpret_cast<bdouble4_t*>(dstW + 4 * lane) = bdouble4_t{wv[0], wv[1], wv[2], wv[3]};
+        *reinterpret_cast<bdouble4_t*>(dstL + 4 * lane) = bdouble4_t{av[0], av[1], av[2], av[3]};
+    }
 }
 
 struct BcrPanelArgs { BcrGeom g; const BcrElim* jobs; int* status; };
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     double* const Mdg = g.ws + g.oMd + (size_t)job.i * (NT * (NT - 1) / 2) * 256;
     double* const Mxg = g.ws + g.oMx + (size_t)job.i * RXT * NT * 256;
     double* const Wxg = g.ws + g.oWx + (size_t)job.i * RXT * NT * 256;
-    double* const rdg = g.ws + g.ord + (size_t)job.i * 16 * NT;
+    double* const Lxg = g.ws + g.oLx + (size_t)job.i * RXT * NT * 256;
     // tile-updates of block column Jp (panel Jp complete) other than the next diagonal tile, dealt over nh waves
     auto updates = [&](int Jp, int hw, int nh) {
         const double* Wprev = Wp + (Jp & 1) * PR * 16 * BP; const double* rd = dvec + (Jp & 1) * 32 + 16;
@@ -272,11 +275,10 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
         const double* Wprev = Wp + (Jp & 1) * PR * 16 * BP; const double* rd = dvec + (Jp & 1) * 32 + 16; const double* Lid = Li + (Jp & 1) * 16 * BP;
         const int nDe = part == 1 ? NT - 1 - Jp : 0, ne = nDe + RX;
         for (int e = hw; e < ne; e += nh) {
-            if (e < nDe) { const int I = Jp + 1 + e; bcr_export_tile(Wprev + I * 16 * BP, rd, Lid, Mdg + (size_t)(I * (I - 1) / 2 + Jp) * 256, nullptr); }
+            if (e < nDe) { const int I = Jp + 1 + e; bcr_export_tile(Wprev + I * 16 * BP, rd, Lid, Mdg + (size_t)(I * (I - 1) / 2 + Jp) * 256, nullptr, nullptr); }
             else { const int R = e - nDe, Rg = part == 0 ? R : (R < RXr ? NT + R : 2 * NT);
-                bcr_export_tile(Wprev + (NT + R) * 16 * BP, rd, Lid, Mxg + (size_t)(Rg * NT + Jp) * 256, Wxg + (size_t)(Rg * NT + Jp) * 256); }
+                bcr_export_tile(Wprev + (NT + R) * 16 * BP, rd, Lid, Mxg + (size_t)(Rg * NT + Jp) * 256, Wxg + (size_t)(Rg * NT + Jp) * 256, Lxg + (size_t)(Rg * NT + Jp) * 256); }
         }
-        if (part == 1 && hw == 0 && lane < 16) rdg[16 * Jp + lane] = rd[lane];
     };
     bdouble4_t diag = {0, 0, 0, 0};
     for (int J = 0; J < NT; ++J) {
@@ -302,29 +304,44 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Schur update of a level: one wavefront per output tile, operands straight from the exported panels (L2 / MALL)
+// Schur update of a level: one wavefront per output tile, operands straight from the exported panels (L2 / MALL):
+//   dst (-)= sum_c  sum_J  Wx[a_c][J] Lx[b_c][J]'          (Lx = Wx / Delta)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs, int NT) {
+template <int NT>
+__global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6); if (j >= njobs) return;
     const BcrUpd u = jobs[j];
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-    for (uint32_t c = 0; c < u.nc; ++c) {
-        const double* A = ws + u.a[c] + 4 * lane; const double* B = ws + u.b[c] + 4 * lane; const double* rd = ws + u.rd[c] + lk;
-        for (int J = 0; J < NT; ++J) {
-            const bdouble4_t av = *reinterpret_cast<const bdouble4_t*>(A + 256 * J), bv = *reinterpret_cast<const bdouble4_t*>(B + 256 * J);
-            const double r0 = rd[16 * J], r1 = rd[16 * J + 4], r2 = rd[16 * J + 8], r3 = rd[16 * J + 12];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0] * r0, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1] * r1, acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2] * r2, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3] * r3, acc2, 0, 0, 0);
-        }
+    // every operand load of the job is issued before the first MFMA (one memory round trip per job); a job with one
+    // contribution reads the same tiles twice and counts the second pass with weight 0
+    bdouble4_t av[2][NT], bv[2][NT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int cc = c < (int)u.nc ? c : 0;
+        const double* A = ws + u.a[cc] + 4 * lane; const double* B = ws + u.b[cc] + 4 * lane;
+#pragma unroll
+        for (int J = 0; J < NT; ++J) { av[c][J] = *reinterpret_cast<const bdouble4_t*>(A + 256 * J); bv[c][J] = *reinterpret_cast<const bdouble4_t*>(B + 256 * J); }
     }
     double* dst = ws + u.dst + lk * 16 + li;
+    double old[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) old[r] = u.mode == 0 ? dst[64 * r] : 0.0;
+    bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (c >= (int)u.nc) break;
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[c][J][0], bv[c][J][0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[c][J][1], bv[c][J][1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[c][J][2], bv[c][J][2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[c][J][3], bv[c][J][3], acc2, 0, 0, 0);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const double v = acc[r] + acc2[r];
-        if (u.mode == 0) dst[64 * r] -= v; else dst[64 * r] = (u.mode == 1) ? -v : v;
+        dst[64 * r] = u.mode == 2 ? v : old[r] - v;
     }
 }
 
@@ -332,11 +349,15 @@ __global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws
 // backward pass of one level: one workgroup per block eliminated at that level
 // ---------------------------------------------------------------------------------------------------
 struct BcrBackArgs { BcrGeom g; const BcrElim* jobs; double* xr; int root; int* status; };
-__global__ __launch_bounds__(256) void bcr_backward_kernel(BcrBackArgs a) {
+// NT wavefronts: wave J owns the 16 unknowns of tile column J.  Every load of the factor is issued before anything is
+// waited for (one memory round trip per level); the unknowns of the neighbours (and of the border) go through LDS.
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BcrGeom& g = a.g;
     const BcrElim job = a.jobs[blockIdx.x];
-    const int NT = g.NT, RXT = 2 * NT + 1, NO = NT * (NT - 1) / 2, b = 16 * NT, nbd = g.nbd, nbr = nbd + 1;
+    constexpr int RXT = 2 * NT + 1, NO = NT * (NT - 1) / 2, b = 16 * NT, NTH = 64 * NT;
+    const int nbd = g.nbd, nbr = nbd + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, gq = lane >> 4;
     double* xs = sm;                               // [RXT][16]
     double* red = xs + RXT * 16;                   // [NT][4][16]
@@ -345,14 +366,24 @@ __global__ __launch_bounds__(256) void bcr_backward_kernel(BcrBackArgs a) {
     double* Mdl = xi + NT * 16;                    // [NO][256]
     double* Cl = Mdl + NO * 256;                   // [16][16] corner (root only)
     double* xb = Cl + 256;                         // [16]
+    // this wave's column of the X part of the factor: rows gq, gq + 4, .. of every tile (absent neighbours: block i's own tiles, weight 0)
+    const double* Mxg = g.ws + g.oMx + (size_t)job.i * RXT * NT * 256 + (size_t)wave * 256 + c;
+    double mx[RXT][4];
+#pragma unroll
+    for (int R = 0; R < RXT; ++R) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mx[R][q] = Mxg[(size_t)R * NT * 256 + (gq + 4 * q) * 16];
+    }
+    {
+        const double* Mdg = g.ws + g.oMd + (size_t)job.i * NO * 256;
+        for (int w = tid; w < NO * 256; w += NTH) Mdl[w] = Mdg[w];
+    }
     if (a.root) {
         if (nbd > 0) {
             // corner = cp[0] - sum_i cp[1 + i], blocks in index order (fixed order: reproducible)
-            double v = g.ws[g.ocp + tid];
-            for (int i = 0; i < g.N; ++i) v -= g.ws[g.ocp + (size_t)(1 + i) * 256 + tid];
-            Cl[tid] = v;
+            for (int e = tid; e < 256; e += NTH) { double v = g.ws[g.ocp + e]; for (int i = 0; i < g.N; ++i) v -= g.ws[g.ocp + (size_t)(1 + i) * 256 + e]; Cl[e] = v; }
             __syncthreads();
-            if (tid == 0) {                        // LDL' of the nbd x nbd corner with the rhs row riding along (rows/cols of Cl: [row][col])
+            if (tid == 0) {                        // LDL' of the nbd x nbd corner with the rhs row riding along (Cl[row][col])
                 for (int j = 0; j < nbd; ++j) {
                     double d = Cl[j * 16 + j];
                     if (d == 0.0 || d != d) { atomicCAS(a.status, 0, 1 + g.n_band + j); d = 1.0; }
@@ -367,28 +398,22 @@ __global__ __launch_bounds__(256) void bcr_backward_kernel(BcrBackArgs a) {
         }
     } else if (tid < nbd) xb[tid] = g.ws[g.oxb + tid];
     __syncthreads();
-    for (int t = tid; t < RXT * 16; t += 256) {
+    for (int t = tid; t < RXT * 16; t += NTH) {
         const int R = t >> 4, q = t & 15; double v = 0.0;
         if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) v = a.xr[row]; } }
         else if (R < 2 * NT) { if (job.r >= 0) { const int row = b * job.r + 16 * (R - NT) + q; if (row < g.n_band) v = a.xr[row]; } }
         else v = q < nbd ? xb[q] : (q == nbd ? -1.0 : 0.0);      // the rhs row is a border row whose unknown is -1
         xs[t] = v;
     }
-    {
-        const double* Mdg = g.ws + g.oMd + (size_t)job.i * NO * 256;
-        for (int w = tid; w < NO * 256; w += 256) Mdl[w] = Mdg[w];
-    }
     __syncthreads();
-    const double* Mxg = g.ws + g.oMx + (size_t)job.i * RXT * NT * 256;
-    for (int J = wave; J < NT; J += 4) {
+    {
         double acc = 0.0;
-        for (int R = 0; R < RXT; ++R) {
-            if (R < NT ? job.l < 0 : (R < 2 * NT && job.r < 0)) continue;
-            const double* M = Mxg + (size_t)(R * NT + J) * 256 + c;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = fma(M[(gq + 4 * q) * 16], xs[16 * R + gq + 4 * q], acc);
+        for (int R = 0; R < RXT; ++R) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = fma(mx[R][q], xs[16 * R + gq + 4 * q], acc);
         }
-        red[(J * 4 + gq) * 16 + c] = acc;
+        red[(wave * 4 + gq) * 16 + c] = acc;
     }
     __syncthreads();
     if (tid < NT * 16) { const int J = tid >> 4, cc = tid & 15; tt[tid] = -((red[(J * 4 + 0) * 16 + cc] + red[(J * 4 + 1) * 16 + cc]) + (red[(J * 4 + 2) * 16 + cc] + red[(J * 4 + 3) * 16 + cc])); }
@@ -428,52 +453,54 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     auto take = [&](size_t doubles) { const size_t o = off; off += (doubles + 31) & ~(size_t)31; return o; };
     geom = BcrGeom{};
     geom.oD = take((size_t)N * ND * 256); geom.oA = take((size_t)N * NT * NT * 256); geom.oBR = take((size_t)N * NT * 256);
-    geom.oWx = take((size_t)N * RXT * NT * 256); geom.oMx = take((size_t)N * RXT * NT * 256); geom.oMd = take((size_t)N * std::max(NO, 1) * 256);
-    geom.ord = take((size_t)N * 16 * NT); geom.ocp = take((size_t)(N + 1) * 256); geom.oxb = take(32);
+    geom.oWx = take((size_t)N * RXT * NT * 256); geom.oLx = take((size_t)N * RXT * NT * 256); geom.oMx = take((size_t)N * RXT * NT * 256);
+    geom.oMd = take((size_t)N * std::max(NO, 1) * 256); geom.ocp = take((size_t)(N + 1) * 256); geom.oxb = take(32);
     if (off >= ((size_t)1 << 32)) { if (err) *err = "block cyclic reduction workspace exceeds 32-bit tile offsets"; return NLLS_ERR_UNSUPPORTED; }
     geom.NT = NT; geom.N = N; geom.nbd = nbd; geom.n_band = n_band; geom.bw = bw; geom.H = H;
     std::vector<BcrElim> elims; std::vector<BcrUpd> upds;
     std::vector<int> active(N); for (int k = 0; k < N; ++k) active[k] = k;
     auto wx = [&](int src, int P) { return (uint32_t)(geom.oWx + ((size_t)src * RXT + P) * NT * 256); };
-    auto rdo = [&](int src) { return (uint32_t)(geom.ord + (size_t)src * 16 * NT); };
+    auto lx = [&](int src, int P) { return (uint32_t)(geom.oLx + ((size_t)src * RXT + P) * NT * 256); };
+    auto corner_job = [&](int i) { BcrUpd u{}; u.dst = (uint32_t)(geom.ocp + (size_t)(1 + i) * 256); u.mode = 2; u.nc = 1; u.a[0] = wx(i, 2 * NT); u.b[0] = lx(i, 2 * NT); upds.push_back(u); };
     while (active.size() > 1) {
+        // the larger independent set of the chain goes: positions 0, 2, 4, ... of an odd-length chain (m -> (m - 1) / 2), else 1, 3, ...
+        const size_t m = active.size(), first = (m & 1) ? 0 : 1;
         BcrLevel lv; lv.elim_off = elims.size(); lv.upd_off = upds.size();
-        for (size_t idx = 1; idx < active.size(); idx += 2)
-            elims.push_back(BcrElim{active[idx], active[idx - 1], idx + 1 < active.size() ? active[idx + 1] : -1, 0});
-        for (size_t idx = 0; idx < active.size(); idx += 2) {
+        for (size_t idx = first; idx < m; idx += 2)
+            elims.push_back(BcrElim{active[idx], idx >= 1 ? active[idx - 1] : -1, idx + 1 < m ? active[idx + 1] : -1, 0});
+        for (size_t idx = 1 - first; idx < m; idx += 2) {        // the survivors: both chain neighbours (where they exist) are eliminated now
             const int j = active[idx];
             int src[2], so[2], ns = 0;
-            if (idx >= 1) { src[ns] = active[idx - 1]; so[ns] = NT; ++ns; }               // j is the right neighbour of the block eliminated on its left
-            if (idx + 1 < active.size()) { src[ns] = active[idx + 1]; so[ns] = 0; ++ns; }  // ... and the left neighbour of the one on its right
-            if (!ns) continue;
+            if (idx >= 1) { src[ns] = active[idx - 1]; so[ns] = NT; ++ns; }        // j is the right neighbour of the block eliminated on its left
+            if (idx + 1 < m) { src[ns] = active[idx + 1]; so[ns] = 0; ++ns; }      // ... and the left neighbour of the one on its right
             for (int I = 0; I < NT; ++I) for (int K = 0; K <= I; ++K) {
                 BcrUpd u{}; u.dst = (uint32_t)(geom.oD + ((size_t)j * ND + I * (I + 1) / 2 + K) * 256); u.mode = 0; u.nc = ns;
-                for (int s = 0; s < ns; ++s) { u.a[s] = wx(src[s], so[s] + I); u.b[s] = wx(src[s], so[s] + K); u.rd[s] = rdo(src[s]); }
+                for (int s = 0; s < ns; ++s) { u.a[s] = wx(src[s], so[s] + I); u.b[s] = lx(src[s], so[s] + K); }
                 upds.push_back(u);
             }
             for (int K = 0; K < NT; ++K) {
                 BcrUpd u{}; u.dst = (uint32_t)(geom.oBR + ((size_t)j * NT + K) * 256); u.mode = 0; u.nc = ns;
-                for (int s = 0; s < ns; ++s) { u.a[s] = wx(src[s], 2 * NT); u.b[s] = wx(src[s], so[s] + K); u.rd[s] = rdo(src[s]); }
+                for (int s = 0; s < ns; ++s) { u.a[s] = wx(src[s], 2 * NT); u.b[s] = lx(src[s], so[s] + K); }
                 upds.push_back(u);
             }
         }
         for (size_t e = lv.elim_off; e < elims.size(); ++e) {
             const BcrElim& el = elims[e];
-            if (el.r >= 0) for (int P = 0; P < NT; ++P) for (int Q = 0; Q < NT; ++Q) {     // the new coupling (rows: block r, columns: block l)
+            if (el.l >= 0 && el.r >= 0) for (int P = 0; P < NT; ++P) for (int Q = 0; Q < NT; ++Q) {     // the new coupling (rows: block r, columns: block l)
                 BcrUpd u{}; u.dst = (uint32_t)(geom.oA + ((size_t)el.r * NT * NT + P * NT + Q) * 256); u.mode = 1; u.nc = 1;
-                u.a[0] = wx(el.i, NT + P); u.b[0] = wx(el.i, Q); u.rd[0] = rdo(el.i); upds.push_back(u);
+                u.a[0] = wx(el.i, NT + P); u.b[0] = lx(el.i, Q); upds.push_back(u);
             }
-            if (nbd > 0) { BcrUpd u{}; u.dst = (uint32_t)(geom.ocp + (size_t)(1 + el.i) * 256); u.mode = 2; u.nc = 1; u.a[0] = u.b[0] = wx(el.i, 2 * NT); u.rd[0] = rdo(el.i); upds.push_back(u); }
+            if (nbd > 0) corner_job(el.i);
         }
         lv.nelim = (int)(elims.size() - lv.elim_off); lv.nupd = (int)(upds.size() - lv.upd_off);
         levels.push_back(lv);
-        std::vector<int> next; for (size_t idx = 0; idx < active.size(); idx += 2) next.push_back(active[idx]);
+        std::vector<int> next; for (size_t idx = 1 - first; idx < m; idx += 2) next.push_back(active[idx]);
         active.swap(next);
     }
     {   // the root block
         BcrLevel lv; lv.elim_off = elims.size(); lv.upd_off = upds.size();
         elims.push_back(BcrElim{active[0], -1, -1, 0});
-        if (nbd > 0) { BcrUpd u{}; u.dst = (uint32_t)(geom.ocp + (size_t)(1 + active[0]) * 256); u.mode = 2; u.nc = 1; u.a[0] = u.b[0] = wx(active[0], 2 * NT); u.rd[0] = rdo(active[0]); upds.push_back(u); }
+        if (nbd > 0) corner_job(active[0]);
         lv.nelim = 1; lv.nupd = (int)(upds.size() - lv.upd_off);
         levels.push_back(lv);
     }
@@ -487,19 +514,29 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     return NLLS_OK;
 }
 
+template <int NT>
+static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status) {
+    BcrPanelArgs pa{S.geom, S.d_elim.p + lv.elim_off, status};
+    hipLaunchKernelGGL(bcr_panel_kernel, dim3((unsigned)(2 * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
+    if (lv.nupd > 0) hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd);
+}
+template <int NT>
+static void bcr_launch_back(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, double* xr, int root, int* status) {
+    BcrBackArgs ba{S.geom, S.d_elim.p + lv.elim_off, xr, root, status};
+    hipLaunchKernelGGL((bcr_backward_kernel<NT>), dim3((unsigned)lv.nelim), dim3(64 * NT), S.back_lds, st, ba);
+}
+
 int BcrSolver::enqueue(hipStream_t st, const double* Sb, double* xr, int* status) const {
     const int ND = NT * (NT + 1) / 2, per = ND + NT * NT + NT;
     hipLaunchKernelGGL(bcr_convert_kernel, dim3((unsigned)(N * per + 1)), dim3(256), 0, st, geom, Sb);
-    for (const BcrLevel& lv : levels) {
-        BcrPanelArgs pa{geom, d_elim.p + lv.elim_off, status};
-        hipLaunchKernelGGL(bcr_panel_kernel, dim3((unsigned)(2 * lv.nelim)), dim3(BCR_T), panel_lds, st, pa);
-        if (lv.nupd > 0) hipLaunchKernelGGL(bcr_update_kernel, dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, geom.ws, d_upd.p + lv.upd_off, lv.nupd, NT);
-    }
-    for (size_t li = levels.size(); li-- > 0;) {
-        const BcrLevel& lv = levels[li];
-        BcrBackArgs ba{geom, d_elim.p + lv.elim_off, xr, li + 1 == levels.size() ? 1 : 0, status};
-        hipLaunchKernelGGL(bcr_backward_kernel, dim3((unsigned)lv.nelim), dim3(256), back_lds, st, ba);
-    }
+#define BCR_NT_SWITCH(CALL) switch (NT) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; default: CALL(5); break; }
+#define BCR_FWD(n) bcr_launch_level<n>(*this, st, lv, status)
+    for (const BcrLevel& lv : levels) BCR_NT_SWITCH(BCR_FWD)
+#define BCR_BWD(n) bcr_launch_back<n>(*this, st, levels[li], xr, li + 1 == levels.size() ? 1 : 0, status)
+    for (size_t li = levels.size(); li-- > 0;) BCR_NT_SWITCH(BCR_BWD)
+#undef BCR_FWD
+#undef BCR_BWD
+#undef BCR_NT_SWITCH
     return hipGetLastError() == hipSuccess ? NLLS_OK : NLLS_ERR_HIP;
 }
 

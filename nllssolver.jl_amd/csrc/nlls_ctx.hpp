@@ -11,31 +11,10 @@
 
 #include "../../include/nlls_amd.h"
 #include "nlls_kinds.hpp"
+#include "nlls_devbuf.hpp"
+#include "nlls_bcr.hpp"
 
 namespace nlls {
-
-// ---- device memory ---------------------------------------------------------------------------
-template <class T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
-    ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-    hipError_t alloc(size_t count) {
-        release(); n = count;
-        if (count == 0) { return hipSuccess; }
-        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
-    }
-    hipError_t upload(const std::vector<T>& h) {
-        hipError_t e = alloc(h.size()); if (e != hipSuccess || h.empty()) return e;
-        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
-    }
-};
 
 // ---- accumulate work lists ----------------------------------------------------------------------
 // One tile = the share of one workgroup: a run of block rows whose A.data / b segments are staged
@@ -191,6 +170,7 @@ struct nlls_ctx {
     int solve_mode = 0, band_CH = 0, band_H = 0, band_SEG = 0, band_NSEG = 0;
     bool band_blocked = true;                // blocked (MFMA) band factorisation when the bandwidth allows
     bool band_twisted = true;               // factor the band from both ends at once (two workgroups) when the layout allows
+    nlls::BcrSolver bcr;                    // block cyclic reduction of the bordered band (nlls_bcr.hip): the default band solver when it supports the shape
     nlls::DevBuf<nlls::SchurCopy> d_copy;    // reduced-reduced blocks
     int64_t ncopy = 0;
     nlls::DevBuf<nlls::SchurCopy> d_blk;     // every stored block with full-system dof offsets (quadratic forms)

@@ -1710,6 +1710,8 @@ int enqueue_solve_finish(nlls_ctx* c) {
     const bool band = c->solve_mode == SOLVE_BAND;
     if (c->solve_mode == SOLVE_SMALL) {
         hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s_ptr(), n, npad, c->d_status.p);
+    } else if (band && c->bcr.ready) {
+        if (c->bcr.enqueue(c->stream, c->S.p, c->s_ptr(), c->d_status.p) != NLLS_OK) return herr(c, hipGetLastError(), "block cyclic reduction launch");
     } else if (band) {
         BandArgs a{}; a.Sb = c->S.p; a.Lb = c->Lwork.p; a.xr = c->s_ptr(); a.n_band = L.n_band; a.bw = L.bw; a.nbd = L.nbd; a.H = L.H; a.CH = c->band_CH; a.status = c->d_status.p;
         a.PFC = (L.bw + 1 + a.CH - 1) / a.CH + 1; a.RC = (a.PFC + 1) * a.CH; a.NSC = (L.bw + 1 + c->band_SEG - 1) / c->band_SEG;

@@ -380,7 +380,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     // (a re-upload -- or the retry without Schur elimination after an unsupported shape -- must not see the previous
     // attempt's supernode lists: the solve dispatches on these counters)
     c->n_fast_groups = 0; c->n_slow_groups = 0; c->n_fast_members = 0; c->n_fast_narrow = 0; c->n_fast_n60 = 0; c->fast_dv = 0;
-    c->tE_valid = false; c->S_zeroed = false; c->step_cached = false;
+    c->tE_valid = false; c->S_zeroed = false; c->step_cached = false; c->bcr.release();
     // (the solve also dispatches on the SIZE of these lists: an upload without elimination must not inherit them)
     c->d_elim_ptr.release(); c->d_elim_nbr.release(); c->d_elim_diag.release(); c->d_elim_boff.release(); c->d_elim_dim.release(); c->d_elim_group.release();
     c->d_fast_groups.release(); c->d_slow_groups.release(); c->d_slow_blocks.release(); c->d_fast_members.release(); c->Cinv.release(); c->tE.release();
@@ -559,6 +559,11 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         const size_t nbw = ((size_t)bw + 15) / 16, tsz = (((size_t)c->n_band + 15) / 16) * ((nbw + 1) * 256 + (size_t)(c->nbd + 1) * 16) + 256 + 2 * (size_t)(c->nbd + 1) * (c->nbd + 1) + 2 * (256 * nbw * nbw + 16 * nbw)
                                                     + (16 * nbw) * (16 * nbw + 1) + 8 + (nbw + 1) * ((nbw + 1) * 256 + 16) + 256;   // separator: band system + its factor tiles
         if (hipSuccess != c->S.alloc(sz + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(std::max(sz, tsz)) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "band system alloc");
+        // block cyclic reduction (nlls_bcr.hip) is the band solver whenever it supports the shape; the chain kernels stay as fallbacks
+        if (!(flags & NLLS_FLAG_NO_BCR) && BcrSolver::supports(c->n_band, (int)bw, c->nbd)) {
+            std::string e; const int rc = c->bcr.build(c->n_band, (int)bw, c->nbd, c->band_H, &e);
+            if (rc != NLLS_OK) return fail(c, rc, e.c_str());
+        }
     } else {
         const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
         c->s_elems = (size_t)std::max<int64_t>(npad * npad, 1);

@@ -156,7 +156,9 @@ def test_ba_band_solver():           # narrow-band reduced system -> persistent-
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(120, 4000, 0.06, seed=8), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)
     assert info.solve_mode == 2 and info.nreduced_dof == 720 and 0 < info.bandwidth < 128
-    info = check_problem(p, flags=_capi.FLAG_NO_TWIST, expect_schur=1)     # one-sided factorisation (the default meets in the middle)
+    info = check_problem(p, flags=_capi.FLAG_NO_BCR, expect_schur=1)       # round-1 chain kernels: twisted (two workgroups meet in the middle)
+    assert info.solve_mode == 2
+    info = check_problem(p, flags=_capi.FLAG_NO_BCR | _capi.FLAG_NO_TWIST, expect_schur=1)     # ... and one-sided
     assert info.solve_mode == 2
     info = check_problem(p, flags=_capi.FLAG_NO_BAND, expect_schur=1)      # same system through the dense MFMA path
     assert info.solve_mode == 1
@@ -182,13 +184,14 @@ def test_ba_wide_points_fast_elimination():   # points seen by 11-12 cameras: mo
     (300, 6000, 0.012, 15),    # ~4 cameras per point, long band
 ])
 def test_band_solver_shapes(ncam, npts, prop, seed):
-    """The blocked band path over bandwidths, lengths and remainders (twisted and one-sided); x against the oracle."""
+    """The band solvers over bandwidths, lengths and remainders (block cyclic reduction, twisted and one-sided chain); x against the oracle."""
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed, robust=N.HuberKernel(0.01),
                                                                  outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)
     assert info.nreduced_dof == 6 * ncam
     if info.solve_mode == 2:
-        check_problem(p, flags=_capi.FLAG_NO_TWIST, expect_schur=1)
+        check_problem(p, flags=_capi.FLAG_NO_BCR, expect_schur=1)
+        check_problem(p, flags=_capi.FLAG_NO_BCR | _capi.FLAG_NO_TWIST, expect_schur=1)
 
 
 @pytest.mark.parametrize("seed", list(range(100, 140)))
@@ -207,7 +210,7 @@ def test_randomized_ba_against_oracle(seed):
     if rng.random() < 0.5:                                              # fix a few cameras and points (varflags path)
         unfixed = np.ones(p.nvariables, bool)
         unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 20), replace=False)] = False
-    flags = [0, 0, _capi.FLAG_FORCE_ATOMIC, _capi.FLAG_NO_BAND, _capi.FLAG_NO_TWIST, _capi.FLAG_FORCE_SPARSE][int(rng.integers(0, 6))]
+    flags = [0, _capi.FLAG_NO_BCR, _capi.FLAG_FORCE_ATOMIC, _capi.FLAG_NO_BAND, _capi.FLAG_NO_BCR | _capi.FLAG_NO_TWIST, _capi.FLAG_FORCE_SPARSE][int(rng.integers(0, 6))]
     check_problem(p, unfixed=unfixed, flags=flags, lam_scale=[1e-6, 1e-4, 1e-1, 1e-2][kind])
 
 
@@ -246,8 +249,8 @@ def test_randomized_so3_against_oracle(seed):
 
 @pytest.mark.parametrize("seed", list(range(600, 616)))
 def test_randomized_band_shapes(seed):
-    """Long camera chains with 3-11 cameras per point: the blocked band solver over seeded random lengths, bandwidths
-    (NBW 1..5), separator widths and remainders, twisted and one-sided, against the oracle's sparse LDL'."""
+    """Long camera chains with 3-11 cameras per point: the band solvers over seeded random lengths, bandwidths (1..5 tiles),
+    block counts and remainders -- block cyclic reduction (default), twisted and one-sided chain -- against the oracle's sparse LDL'."""
     rng = np.random.default_rng(seed)
     ncam = int(rng.integers(50, 420)); cpp = float(rng.uniform(3.0, 11.0)); npts = int(rng.integers(10 * ncam, 30 * ncam))
     kw = dict(robust=N.HuberKernel(0.01), outlier_frac=0.05, outlier_sigma=0.05) if rng.random() < 0.5 else {}
@@ -255,7 +258,31 @@ def test_randomized_band_shapes(seed):
     info = check_problem(p, expect_sparse=1, expect_schur=1)
     assert info.nreduced_dof == 6 * ncam
     if info.solve_mode == 2 and rng.random() < 0.5:
-        check_problem(p, flags=_capi.FLAG_NO_TWIST, expect_schur=1)
+        check_problem(p, flags=[_capi.FLAG_NO_BCR, _capi.FLAG_NO_BCR | _capi.FLAG_NO_TWIST][int(rng.integers(0, 2))], expect_schur=1)
+
+
+@pytest.mark.parametrize("ncam,npts,cpp,adaptive,seed", [
+    (48, 1200, 10.5, False, 901),    # 288 dof, 80-column blocks: four blocks (fewer cameras would all be ordered as border)
+    (54, 1500, 10.5, False, 903),    # five blocks: both ends go at once
+    (130, 3000, 10.5, False, 904),   # ten blocks, last one partly padding
+    (333, 7000, 10.5, False, 905),   # 25 blocks
+    (64, 1200, 2.6, False, 906),     # one tile per block (bandwidth < 16): 24 blocks
+    (96, 2000, 5.2, False, 907),     # two tiles per block
+    (150, 3000, 7.9, False, 908),    # three..four tiles per block
+    (60, 1500, 10.5, True, 909),     # SO(3) cameras + kernel variable: border rows ride through every level
+    (200, 5000, 8.0, True, 910),
+])
+def test_block_cyclic_reduction_shapes(ncam, npts, cpp, adaptive, seed):
+    """The block cyclic reduction over block counts (even, odd, partly padded last block), tiles per block and border rows;
+    x against the oracle's sparse LDL'."""
+    if adaptive:
+        p = synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(ncam, npts, cpp / ncam, seed=seed, adaptive=True), 1e-3, 1e-3)
+        info = check_problem(p, expect_sparse=1, lam_scale=1e-4)
+        assert info.nborder_dof > 0
+    else:
+        p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, cpp / ncam, seed=seed), 1e-3, 1e-3)
+        info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.solve_mode == 2
 
 
 @pytest.mark.parametrize("seed", list(range(700, 706)))
