@@ -38,6 +38,9 @@ constexpr int BCR_MAXNT = 5;
 BCR_DEV double bcr_readlane(double x, int k) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
 }
+// workgroup barrier that waits for this wave's LDS traffic only: the exports (global stores nothing in the kernel reads back) stay in
+// flight across it -- __syncthreads() would wait for every one of them to reach memory
+BCR_DEV void bcr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 BCR_DEV int bcr_dtile(int I, int K) { return I * (I + 1) / 2 + K; }      // lower tiles of a block, I >= K
 
 // ---------------------------------------------------------------------------------------------------
@@ -88,14 +91,16 @@ __global__ __launch_bounds__(256) void bcr_convert_kernel(BcrGeom g, const doubl
 // (A[i][kk] = w_i) and, scaled by -1/d, the B operand: one MFMA is the whole rank-1 update.  A second accumulator starts
 // as the identity and ends as inv(L).  Out: Wd (row-major, LDS) = the factored tile (L Delta below, Delta on the
 // diagonal), Lid = inv(L)' ([k][j] = inv(L)[j][k]), dd[0..15] = Delta, dd[16..31] = 1 / Delta.
-BCR_DEV void bcr_factor(const double* T0, const bdouble4_t* Ain, double* Wd, double* Lid, double* dd, int* status, int pivbase, bool report) {
+BCR_DEV void bcr_factor(const double* T0, bool from_regs, const bdouble4_t Ain, double* Wd, double* Lid, double* dd, int* status, int pivbase, bool report) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     bdouble4_t A, Bt;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { A[r] = Ain ? (*Ain)[r] : T0[(lk + 4 * r) * BP + li]; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
-    int badk = 16;
+    for (int r = 0; r < 4; ++r) { const double t = T0[(lk + 4 * r) * BP + li]; A[r] = from_regs ? Ain[r] : t; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
+    // The pivot loop is a chain of dependent vector instructions around the two MFMAs: nothing else is in it.  Delta is
+    // read off the diagonal of the finished tile (entry (k, k) is final once pivot k - 1 has been applied), 1 / Delta is
+    // formed again by sixteen lanes at once (same instructions, same bits), zero / NaN pivots are looked for there too.
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < 15; ++k) {
         const int q = k & 3, r = k >> 2;
         const double w = A[r], bt = Bt[r];
         const double dk = bcr_readlane(w, 16 * q + k);
@@ -104,16 +109,21 @@ BCR_DEV void bcr_factor(const double* T0, const bdouble4_t* Ain, double* Wd, dou
         const double am = (rowq && li > k) ? w : 0.0;
         const double bm = rowq ? bt : 0.0;
         rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
-        if (!(fabs(dk) > 0.0)) badk = badk < k ? badk : k;
-        dd[k] = dk; dd[16 + k] = rdk;
-        if (k < 15) {
-            A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
-            Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);
+        A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
+        Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);
+    }
+    {
+        double dsel = A[0];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) dsel = (li >> 2) == r ? A[r] : dsel;
+        if ((li & 3) == lk) {
+            double rd = __builtin_amdgcn_rcp(dsel); rd = fma(fma(-dsel, rd, 1.0), rd, rd); rd = fma(fma(-dsel, rd, 1.0), rd, rd);
+            dd[li] = dsel; dd[16 + li] = rd;
+            if (report && !(fabs(dsel) > 0.0)) atomicCAS(status, 0, 1 + pivbase + li);
         }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Wd[(lk + 4 * r) * BP + li] = A[r]; Lid[li * BP + (lk + 4 * r)] = Bt[r]; }
-    if (report && badk < 16 && lane == 0) atomicCAS(status, 0, 1 + pivbase + badk);
 }
 // W = T inv(L)'   (one wavefront, one tile)
 BCR_DEV void bcr_panel_tile(const double* T, const double* Lid, double* Wt) {
@@ -157,140 +167,190 @@ BCR_DEV void bcr_panel_update_diag(const double* T, const double* Lid, const dou
 #pragma unroll
     for (int r = 0; r < 4; ++r) diag_out[r] = c[r] + c2[r];
 }
-// up to MAXU tile-updates  C -= W_I (W_K / Delta)'  by one wavefront: all operand loads, then the MFMAs, then the stores
+// MAXU tile-updates  C -= W_I (W_K / Delta)'  by one wavefront: all operand loads, then the MFMAs, then the stores.  Tiles
+// are given as offsets into the workgroup's LDS (no pointer arrays: they would live in scratch memory); a job that does
+// not exist works on a spare tile -- no branches, no predicated stores.
 template <int MAXU>
-BCR_DEV void bcr_update_batch(int n, double* (&C)[MAXU], const double* (&Wi)[MAXU], const double* (&Wk)[MAXU], const double* rd) {
+BCR_DEV void bcr_update_batch(double* S, const int (&C)[MAXU], const int (&Wi)[MAXU], const int (&Wk)[MAXU], int rdoff) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int lo = li * BP + lk, co = lk * BP + li;
     double rdk[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) rdk[kk] = rd[4 * kk + lk];
+    for (int kk = 0; kk < 4; ++kk) rdk[kk] = S[rdoff + 4 * kk + lk];
     bdouble4_t acc[MAXU], acc2[MAXU]; double wv[MAXU][4], lv[MAXU][4];
 #pragma unroll
-    for (int q = 0; q < MAXU; ++q) if (q < n) {
+    for (int q = 0; q < MAXU; ++q) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { wv[q][kk] = -Wi[q][lo + 4 * kk]; lv[q][kk] = Wk[q][lo + 4 * kk] * rdk[kk]; }
+        for (int kk = 0; kk < 4; ++kk) { wv[q][kk] = -S[Wi[q] + lo + 4 * kk]; lv[q][kk] = S[Wk[q] + lo + 4 * kk] * rdk[kk]; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[q][r] = C[q][co + 4 * r * BP];
+        for (int r = 0; r < 4; ++r) acc[q][r] = S[C[q] + co + 4 * r * BP];
         acc2[q] = bdouble4_t{0, 0, 0, 0};
     }
 #pragma unroll
-    for (int q = 0; q < MAXU; ++q) if (q < n) {
+    for (int q = 0; q < MAXU; ++q) {
         acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][0], lv[q][0], acc[q], 0, 0, 0);
         acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][1], lv[q][1], acc2[q], 0, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < MAXU; ++q) if (q < n) {
+    for (int q = 0; q < MAXU; ++q) {
         acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][2], lv[q][2], acc[q], 0, 0, 0);
         acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q][3], lv[q][3], acc2[q], 0, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < MAXU; ++q) if (q < n) {
+    for (int q = 0; q < MAXU; ++q) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) C[q][co + 4 * r * BP] = acc[q][r] + acc2[q][r];
+        for (int r = 0; r < 4; ++r) S[C[q] + co + 4 * r * BP] = acc[q][r] + acc2[q][r];
     }
 }
-// export of one panel tile:  M = (W / Delta) inv(L_JJ)  row-major to dstM (backward pass);  W and L = W / Delta in the MFMA
-// operand order (lane, kk) -> [li][4 kk + lk] to dstW / dstL (update kernel), when wanted
-BCR_DEV void bcr_export_tile(const double* Wt, const double* rd, const double* Lid, double* __restrict__ dstM, double* __restrict__ dstW, double* __restrict__ dstL) {
+// export of one panel tile in the MFMA operand order (lane, kk) -> [li][4 kk + lk]:  L = W / Delta to dstL (update kernel's B
+// operand), W itself to dstW (its A operand) when wanted.  Plain copies: no product on the way out -- the pre-multiplied
+// tiles M = L inv(L_JJ) the backward pass wants are formed by spare wavefronts of the update kernel.
+BCR_DEV void bcr_export_tile(const double* Wt, const double* rd, double* __restrict__ dstW, double* __restrict__ dstL) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    double wv[4], av[4], bv[4];
+    double wv[4], lv[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { wv[m] = Wt[li * BP + 4 * m + lk]; av[m] = wv[m] * rd[4 * m + lk]; bv[m] = Lid[li * BP + 4 * m + lk]; }
-    bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dstM[(lk + 4 * r) * 16 + li] = acc[r] + acc2[r];
-    if (dstW) {
-        *reinterpret_cast<bdouble4_t*>(dstW + 4 * lane) = bdouble4_t{wv[0], wv[1], wv[2], wv[3]};
-        *reinterpret_cast<bdouble4_t*>(dstL + 4 * lane) = bdouble4_t{av[0], av[1], av[2], av[3]};
-    }
+    for (int m = 0; m < 4; ++m) { wv[m] = Wt[li * BP + 4 * m + lk]; lv[m] = wv[m] * rd[4 * m + lk]; }
+    *reinterpret_cast<bdouble4_t*>(dstL + 4 * lane) = bdouble4_t{lv[0], lv[1], lv[2], lv[3]};
+    if (dstW) *reinterpret_cast<bdouble4_t*>(dstW + 4 * lane) = bdouble4_t{wv[0], wv[1], wv[2], wv[3]};
+}
+// inv(L_JJ)' of a factored diagonal tile in the same operand order (the update kernel forms M = L inv(L_JJ) with it)
+BCR_DEV void bcr_export_linv(const double* Lid, double* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    *reinterpret_cast<bdouble4_t*>(dst + 4 * lane) = bdouble4_t{Lid[li * BP + lk], Lid[li * BP + 4 + lk], Lid[li * BP + 8 + lk], Lid[li * BP + 12 + lk]};
 }
 
 struct BcrPanelArgs { BcrGeom g; const BcrElim* jobs; int* status; };
+constexpr int BCR_CH = 3;                                     // X rows (16-row tiles) per workgroup
+__host__ __device__ constexpr int bcr_nchunks(int NT) { return (2 * NT + 1 + BCR_CH - 1) / BCR_CH; }
 
-// Two workgroups per eliminated block: part 0 carries the X rows of the left neighbour (A_il'), part 1 those of the right
-// neighbour (A_ri) and the border / rhs rows; both factor D_i (identical arithmetic, identical bits).
+// The X rows of an eliminated block -- NT tile rows of the left neighbour (A_il'), NT of the right one (A_ri), one of border /
+// rhs rows -- are dealt over bcr_nchunks(NT) workgroups, three tile rows each; every one of them factors D_i (identical
+// arithmetic, identical bits).  The tile-updates run on the matrix pipes of the three SIMDs wave 0 does not sit on: they, not
+// wave 0's pivot chain, would set the pace of a block step with more X rows per workgroup.  The workgroup that holds the border
+// row also exports the D part of the factor and reports bad pivots.
 __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BcrGeom& g = a.g;
-    const BcrElim job = a.jobs[blockIdx.x >> 1]; const int part = blockIdx.x & 1;
-    if (part == 0 && job.l < 0) return;
-    const int NT = g.NT, ND = NT * (NT + 1) / 2, RXT = 2 * NT + 1, PR = 2 * NT + 1;
-    const int RXr = part == 0 ? NT : (job.r >= 0 ? NT : 0), RX = part == 0 ? NT : RXr + 1;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int NT = g.NT, NCH = bcr_nchunks(NT), ND = NT * (NT + 1) / 2, RXT = 2 * NT + 1, PR = NT + BCR_CH;
+    const BcrElim job = a.jobs[blockIdx.x / NCH]; const int ch = blockIdx.x % NCH;
+    // this workgroup's X rows: global row index Rg (0..NT-1: left neighbour, NT..2NT-1: right neighbour, 2NT: border / rhs)
+    static_assert(BCR_CH == 3, "the row list below is written out for three rows");
+    int rw0 = 0, rw1 = 0, rw2 = 0, RX = 0;            // (scalars, not an array: a dynamically indexed array would live in scratch memory)
+#pragma unroll
+    for (int s2 = 0; s2 < BCR_CH; ++s2) { const int Rg = BCR_CH * ch + s2;
+        if (Rg <= 2 * NT && (Rg < NT ? job.l >= 0 : (Rg < 2 * NT ? job.r >= 0 : true))) { if (RX == 0) rw0 = Rg; else if (RX == 1) rw1 = Rg; else rw2 = Rg; ++RX; } }
+    if (RX == 0) return;
+    auto rowRg = [&](int R) { return R == 0 ? rw0 : (R == 1 ? rw1 : rw2); };
+    const bool lead = rowRg(RX - 1) == 2 * NT;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (readfirstlane: the compiler must know the wave index is uniform, or every job decode below becomes per-lane code under exec masks)
+    const int hw = wave < 4 ? wave - 1 : wave - 2;    // helper index of waves 1, 2, 3, 5, 6, 7 (wave 4 shares wave 0's SIMD -- its matrix pipe
+                                                      // and its vector issue: it stays out of the way while wave 0 works)
+    const bool helper = wave != 0 && wave != 4;
+#ifdef BCR_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(); int stn = 0;
+#define BCR_STAMP() do { if (blockIdx.x == gridDim.x - 1 && lane == 0 && wave <= 1 && stn < 20) a.status[16 + 20 * wave + stn++] = (int)(__builtin_amdgcn_s_memtime() - st0); } while (0)
+#else
+#define BCR_STAMP() do {} while (0)
+#endif
     double* Dt = sm;                                  // [ND] lower tiles of D_i
     double* Xt = Dt + ND * BTS;                       // [RX][NT]
-    double* Wp = Xt + (NT + 1) * NT * BTS;            // [2][PR][16][BP]: panel W of block column J, by parity; rows 0..NT-1 the D part, NT.. the X rows
+    double* Wp = Xt + BCR_CH * NT * BTS;              // [2][PR][16][BP]: panel W of block column J, by parity; rows 0..NT-1 the D part, NT.. the X rows
     double* dvec = Wp + 2 * PR * 16 * BP;             // [2][32]
     double* Li = dvec + 64;                           // [2][16][BP]
-    // ---- landing
-    {
-        const double* Dg = g.ws + g.oD + (size_t)job.i * ND * 256;
-        for (int w = tid; w < ND * 256; w += BCR_T) Dt[(w >> 8) * BTS + ((w >> 4) & 15) * BP + (w & 15)] = Dg[w];
-        if (part == 0) {
-            const double* Ag = g.ws + g.oA + (size_t)job.i * NT * NT * 256;          // rows: block i, columns: block l -- transposed in
-            for (int w = tid; w < NT * NT * 256; w += BCR_T) {
-                const int tx = w >> 8, R = tx / NT, K = tx - R * NT, bb = (w >> 4) & 15, aa = w & 15;
-                Xt[(R * NT + K) * BTS + aa * BP + bb] = Ag[(size_t)(K * NT + R) * 256 + bb * 16 + aa];
-            }
-        } else {
-            if (RXr) {
-                const double* Ag = g.ws + g.oA + (size_t)job.r * NT * NT * 256;      // rows: block r, columns: block i
-                for (int w = tid; w < NT * NT * 256; w += BCR_T) Xt[(w >> 8) * BTS + ((w >> 4) & 15) * BP + (w & 15)] = Ag[w];
-            }
-            const double* Bg = g.ws + g.oBR + (size_t)job.i * NT * 256;
-            for (int w = tid; w < NT * 256; w += BCR_T) Xt[(RXr * NT + (w >> 8)) * BTS + ((w >> 4) & 15) * BP + (w & 15)] = Bg[w];
+    const int oDt = 0, oXt = ND * BTS, oWp = oXt + BCR_CH * NT * BTS, odv = oWp + 2 * PR * 16 * BP, oSpare = odv + 64 + 2 * 16 * BP;   // the same as offsets; a spare tile last
+    // ---- landing.  First (every thread): D_i and block column 0 of the X rows -- all that the first factorisation and the first
+    // panel need.  The other X columns are requested by the six helper waves into registers now and put into LDS behind wave 0's
+    // first factorisation.  Word (hi, lo) of a tile: the left neighbour's rows come in transposed.
+    const double* Agl = g.ws + g.oA + (size_t)job.i * NT * NT * 256;                        // rows: block i, columns: block l
+    const double* Agr = g.ws + g.oA + (size_t)(job.r >= 0 ? job.r : 0) * NT * NT * 256;   // rows: block r, columns: block i
+    const double* Bg = g.ws + g.oBR + (size_t)job.i * NT * 256;
+    auto xsrc = [&](int Rg, int K, int hi, int lo) -> const double* {
+        if (Rg < NT) return Agl + (size_t)(K * NT + Rg) * 256 + hi * 16 + lo;               // X(R,K)[lo][hi] = A_il(K,R)[hi][lo]
+        if (Rg < 2 * NT) return Agr + (size_t)((Rg - NT) * NT + K) * 256 + hi * 16 + lo;
+        return Bg + (size_t)K * 256 + hi * 16 + lo;
+    };
+    auto xdst = [&](int R, int Rg, int K, int hi, int lo) -> double* { return Xt + (R * NT + K) * BTS + (Rg < NT ? lo * BP + hi : hi * BP + lo); };
+    constexpr int LANDQ = (BCR_CH * (BCR_MAXNT - 1) * 256 + 6 * 64 - 1) / (6 * 64);      // words per helper thread of the deferred part
+    double lv[LANDQ];
+    const int nB = RX * (NT - 1) * 256;
+    if (helper) {
+#pragma unroll
+        for (int q = 0; q < LANDQ; ++q) {
+            const int w = (64 * hw + lane) + q * 384; lv[q] = 0.0;
+            if (w < nB) { const int idx = w >> 8, R = idx / (NT - 1), K = 1 + idx - R * (NT - 1); lv[q] = *xsrc(rowRg(R), K, (w >> 4) & 15, w & 15); }
         }
     }
+    {   // (all loads first, then the LDS stores: one memory round trip, not one per word)
+        constexpr int DQ = (BCR_MAXNT * (BCR_MAXNT + 1) / 2 * 256 + BCR_T - 1) / BCR_T, XQ = (BCR_CH * 256 + BCR_T - 1) / BCR_T;
+        const double* Dg = g.ws + g.oD + (size_t)job.i * ND * 256;
+        double dv[DQ], xv[XQ];
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; dv[q] = w < ND * 256 ? Dg[w] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) { const int w = tid + q * BCR_T; xv[q] = w < RX * 256 ? *xsrc(rowRg(w >> 8), 0, (w >> 4) & 15, w & 15) : 0.0; }
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; if (w < ND * 256) Dt[(w >> 8) * BTS + ((w >> 4) & 15) * BP + (w & 15)] = dv[q]; }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) { const int w = tid + q * BCR_T; if (w < RX * 256) *xdst(w >> 8, rowRg(w >> 8), 0, (w >> 4) & 15, w & 15) = xv[q]; }
+    }
     __syncthreads();
-    double* const Mdg = g.ws + g.oMd + (size_t)job.i * (NT * (NT - 1) / 2) * 256;
-    double* const Mxg = g.ws + g.oMx + (size_t)job.i * RXT * NT * 256;
+    BCR_STAMP();
+    auto land_rest = [&]() {
+#pragma unroll
+        for (int q = 0; q < LANDQ; ++q) {
+            const int w = (64 * hw + lane) + q * 384;
+            if (w < nB) { const int idx = w >> 8, R = idx / (NT - 1), K = 1 + idx - R * (NT - 1); *xdst(R, rowRg(R), K, (w >> 4) & 15, w & 15) = lv[q]; }
+        }
+    };
+    double* const Mdg = g.ws + g.oLd + (size_t)job.i * (NT * (NT - 1) / 2) * 256;   // L tiles below the diagonal
+    double* const Lig = g.ws + g.oLi + (size_t)job.i * NT * 256;                     // inv(L_JJ)' per tile column
     double* const Wxg = g.ws + g.oWx + (size_t)job.i * RXT * NT * 256;
     double* const Lxg = g.ws + g.oLx + (size_t)job.i * RXT * NT * 256;
     // tile-updates of block column Jp (panel Jp complete) other than the next diagonal tile, dealt over nh waves
-    auto updates = [&](int Jp, int hw, int nh) {
-        const double* Wprev = Wp + (Jp & 1) * PR * 16 * BP; const double* rd = dvec + (Jp & 1) * 32 + 16;
+    auto updates = [&](int Jp, int w0, int nh) {
+        const int oWprev = oWp + (Jp & 1) * PR * 16 * BP, ord = odv + (Jp & 1) * 32 + 16;
         const int m = NT - 1 - Jp; if (m <= 0) return;
         const int nDj = m * (m + 1) / 2 - 1, ntot = nDj + RX * m;
-        for (int u0 = hw; u0 < ntot; u0 += 3 * nh) {
-            double* C[3]; const double* Wi[3]; const double* Wk[3]; int n = 0;
+        for (int u0 = w0; u0 < ntot; u0 += 3 * nh) {
+            int C[3], Wi[3], Wk[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const int u = u0 + q * nh; C[q] = nullptr; Wi[q] = nullptr; Wk[q] = nullptr;
+                const int u = u0 + q * nh; C[q] = oSpare; Wi[q] = oWprev; Wk[q] = oWprev;
                 if (u >= ntot) continue;
-                n = q + 1;
                 if (u < nDj) { int up = u + 1, K = Jp + 1, cnt = m; while (up >= cnt) { up -= cnt; --cnt; ++K; }
-                    const int I = K + up; C[q] = Dt + bcr_dtile(I, K) * BTS; Wi[q] = Wprev + I * 16 * BP; Wk[q] = Wprev + K * 16 * BP; }
-                else { const int v = u - nDj, R = v / m, K = Jp + 1 + (v - R * m);
-                    C[q] = Xt + (R * NT + K) * BTS; Wi[q] = Wprev + (NT + R) * 16 * BP; Wk[q] = Wprev + K * 16 * BP; }
+                    const int I = K + up; C[q] = oDt + bcr_dtile(I, K) * BTS; Wi[q] = oWprev + I * 16 * BP; Wk[q] = oWprev + K * 16 * BP; }
+                else { int v = u - nDj, R = 0; while (v >= m) { v -= m; ++R; } const int K = Jp + 1 + v;
+                    C[q] = oXt + (R * NT + K) * BTS; Wi[q] = oWprev + (NT + R) * 16 * BP; Wk[q] = oWprev + K * 16 * BP; }
             }
-            bcr_update_batch<3>(n, C, Wi, Wk, rd);
+            bcr_update_batch<3>(sm, C, Wi, Wk, ord);
         }
     };
-    auto exports = [&](int Jp, int hw, int nh) {
+    auto exports = [&](int Jp, int w0, int nh) {
         const double* Wprev = Wp + (Jp & 1) * PR * 16 * BP; const double* rd = dvec + (Jp & 1) * 32 + 16; const double* Lid = Li + (Jp & 1) * 16 * BP;
-        const int nDe = part == 1 ? NT - 1 - Jp : 0, ne = nDe + RX;
-        for (int e = hw; e < ne; e += nh) {
-            if (e < nDe) { const int I = Jp + 1 + e; bcr_export_tile(Wprev + I * 16 * BP, rd, Lid, Mdg + (size_t)(I * (I - 1) / 2 + Jp) * 256, nullptr, nullptr); }
-            else { const int R = e - nDe, Rg = part == 0 ? R : (R < RXr ? NT + R : 2 * NT);
-                bcr_export_tile(Wprev + (NT + R) * 16 * BP, rd, Lid, Mxg + (size_t)(Rg * NT + Jp) * 256, Wxg + (size_t)(Rg * NT + Jp) * 256, Lxg + (size_t)(Rg * NT + Jp) * 256); }
+        const int nDe = lead ? NT - Jp : 0, ne = nDe + RX;                   // (lead: inv(L_JJ)' and the NT-1-Jp tiles below the diagonal)
+        for (int e = w0; e < ne; e += nh) {
+            if (e == 0 && lead) bcr_export_linv(Lid, Lig + (size_t)Jp * 256);
+            else if (e < nDe) { const int I = Jp + e; bcr_export_tile(Wprev + I * 16 * BP, rd, nullptr, Mdg + (size_t)(I * (I - 1) / 2 + Jp) * 256); }
+            else { const int R = e - nDe, Rg = rowRg(R);
+                bcr_export_tile(Wprev + (NT + R) * 16 * BP, rd, Wxg + (size_t)(Rg * NT + Jp) * 256, Lxg + (size_t)(Rg * NT + Jp) * 256); }
         }
     };
     bdouble4_t diag = {0, 0, 0, 0};
     for (int J = 0; J < NT; ++J) {
         double* Wb = Wp + (J & 1) * PR * 16 * BP; double* Lid = Li + (J & 1) * 16 * BP; double* db = dvec + (J & 1) * 32;
-        if (wave == 0) bcr_factor(Dt + bcr_dtile(J, J) * BTS, J > 0 ? &diag : nullptr, Wb + J * 16 * BP, Lid, db, a.status, 16 * NT * job.i + 16 * J, part == 1);
-        else if (J > 0) { updates(J - 1, wave - 1, 7); exports(J - 1, wave - 1, 7); }
-        __syncthreads();                                  // diagonal tile factored; block column J final
+        if (wave == 0) bcr_factor(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, 16 * NT * job.i + 16 * J, lead);
+        else if (helper) { if (J > 0) { BCR_STAMP(); updates(J - 1, hw, 6); BCR_STAMP(); exports(J - 1, hw, 6); } else land_rest(); }
+        BCR_STAMP();
+#ifdef BCR_STAMPS
+        if (blockIdx.x == gridDim.x - 1 && lane == 0 && J < 2) a.status[56 + 8 * J + wave] = (int)(__builtin_amdgcn_s_memtime() - st0);
+#endif
+        bcr_lds_barrier();                                // diagonal tile factored; block column J final
+        BCR_STAMP();
         if (J + 1 < NT) {
             if (wave == 0) bcr_panel_update_diag(Dt + bcr_dtile(J + 1, J) * BTS, Lid, db + 16, Wb + (J + 1) * 16 * BP, Dt + bcr_dtile(J + 1, J + 1) * BTS, diag);
-            else {
+            else if (helper) {
                 const int nD = NT - J - 2;
-                for (int p = wave - 1; p < nD + RX; p += 7) {
+                for (int p = hw; p < nD + RX; p += 6) {
                     if (p < nD) bcr_panel_tile(Dt + bcr_dtile(J + 2 + p, J) * BTS, Lid, Wb + (J + 2 + p) * 16 * BP);
                     else bcr_panel_tile(Xt + ((p - nD) * NT + J) * BTS, Lid, Wb + (NT + p - nD) * 16 * BP);
                 }
@@ -298,9 +358,11 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
         } else {
             for (int p = wave; p < RX; p += 8) bcr_panel_tile(Xt + (p * NT + J) * BTS, Lid, Wb + (NT + p) * 16 * BP);
         }
-        __syncthreads();                                  // panel J in LDS
+        BCR_STAMP();
+        bcr_lds_barrier();                                // panel J in LDS
     }
     exports(NT - 1, wave, 8);
+    BCR_STAMP();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -309,9 +371,21 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
 // ---------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs) {
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6); if (j >= njobs) return;
+    const int j = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); if (j >= njobs) return;
     const BcrUpd u = jobs[j];
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    if (u.mode == 3) {                                        // one tile of the factor pre-multiplied for the backward pass:  M = L inv(L_JJ), row-major
+        const bdouble4_t av = *reinterpret_cast<const bdouble4_t*>(ws + u.a[0] + 4 * lane), bv = *reinterpret_cast<const bdouble4_t*>(ws + u.b[0] + 4 * lane);
+        bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+        double* dst = ws + u.dst + lk * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[64 * r] = acc[r] + acc2[r];
+        return;
+    }
     // every operand load of the job is issued before the first MFMA (one memory round trip per job); a job with one
     // contribution reads the same tiles twice and counts the second pass with weight 0
     bdouble4_t av[2][NT], bv[2][NT];
@@ -358,7 +432,7 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
     const BcrElim job = a.jobs[blockIdx.x];
     constexpr int RXT = 2 * NT + 1, NO = NT * (NT - 1) / 2, b = 16 * NT, NTH = 64 * NT;
     const int nbd = g.nbd, nbr = nbd + 1;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, gq = lane >> 4;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, gq = lane >> 4;
     double* xs = sm;                               // [RXT][16]
     double* red = xs + RXT * 16;                   // [NT][4][16]
     double* tt = red + NT * 64;                    // [NT][16]
@@ -374,9 +448,14 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) mx[R][q] = Mxg[(size_t)R * NT * 256 + (gq + 4 * q) * 16];
     }
-    {
+    {   // the block's own triangle: global -> registers -> LDS, every load in flight at once
+        constexpr int MQ = (NO * 256 + NTH - 1) / NTH;
         const double* Mdg = g.ws + g.oMd + (size_t)job.i * NO * 256;
-        for (int w = tid; w < NO * 256; w += NTH) Mdl[w] = Mdg[w];
+        double mdv[MQ > 0 ? MQ : 1];
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) { const int w = tid + q * NTH; mdv[q] = w < NO * 256 ? Mdg[w] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) { const int w = tid + q * NTH; if (w < NO * 256) Mdl[w] = mdv[q]; }
     }
     if (a.root) {
         if (nbd > 0) {
@@ -454,6 +533,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     geom = BcrGeom{};
     geom.oD = take((size_t)N * ND * 256); geom.oA = take((size_t)N * NT * NT * 256); geom.oBR = take((size_t)N * NT * 256);
     geom.oWx = take((size_t)N * RXT * NT * 256); geom.oLx = take((size_t)N * RXT * NT * 256); geom.oMx = take((size_t)N * RXT * NT * 256);
+    geom.oLd = take((size_t)N * std::max(NO, 1) * 256); geom.oLi = take((size_t)N * NT * 256);
     geom.oMd = take((size_t)N * std::max(NO, 1) * 256); geom.ocp = take((size_t)(N + 1) * 256); geom.oxb = take(32);
     if (off >= ((size_t)1 << 32)) { if (err) *err = "block cyclic reduction workspace exceeds 32-bit tile offsets"; return NLLS_ERR_UNSUPPORTED; }
     geom.NT = NT; geom.N = N; geom.nbd = nbd; geom.n_band = n_band; geom.bw = bw; geom.H = H;
@@ -461,6 +541,13 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     std::vector<int> active(N); for (int k = 0; k < N; ++k) active[k] = k;
     auto wx = [&](int src, int P) { return (uint32_t)(geom.oWx + ((size_t)src * RXT + P) * NT * 256); };
     auto lx = [&](int src, int P) { return (uint32_t)(geom.oLx + ((size_t)src * RXT + P) * NT * 256); };
+    // the factor of an eliminated block, pre-multiplied for the backward pass (one wavefront per tile)
+    auto premul_jobs = [&](const BcrElim& el) {
+        auto one = [&](size_t dst, size_t a, int J) { BcrUpd u{}; u.dst = (uint32_t)dst; u.mode = 3; u.nc = 1; u.a[0] = (uint32_t)a; u.b[0] = (uint32_t)(geom.oLi + ((size_t)el.i * NT + J) * 256); upds.push_back(u); };
+        for (int Rg = 0; Rg < RXT; ++Rg) { if (Rg < NT ? el.l < 0 : (Rg < 2 * NT && el.r < 0)) continue;
+            for (int J = 0; J < NT; ++J) one(geom.oMx + (((size_t)el.i * RXT + Rg) * NT + J) * 256, geom.oLx + (((size_t)el.i * RXT + Rg) * NT + J) * 256, J); }
+        for (int I = 1; I < NT; ++I) for (int J = 0; J < I; ++J) one(geom.oMd + ((size_t)el.i * NO + I * (I - 1) / 2 + J) * 256, geom.oLd + ((size_t)el.i * NO + I * (I - 1) / 2 + J) * 256, J);
+    };
     auto corner_job = [&](int i) { BcrUpd u{}; u.dst = (uint32_t)(geom.ocp + (size_t)(1 + i) * 256); u.mode = 2; u.nc = 1; u.a[0] = wx(i, 2 * NT); u.b[0] = lx(i, 2 * NT); upds.push_back(u); };
     while (active.size() > 1) {
         // the larger independent set of the chain goes: positions 0, 2, 4, ... of an odd-length chain (m -> (m - 1) / 2), else 1, 3, ...
@@ -491,6 +578,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
                 u.a[0] = wx(el.i, NT + P); u.b[0] = lx(el.i, Q); upds.push_back(u);
             }
             if (nbd > 0) corner_job(el.i);
+            premul_jobs(el);
         }
         lv.nelim = (int)(elims.size() - lv.elim_off); lv.nupd = (int)(upds.size() - lv.upd_off);
         levels.push_back(lv);
@@ -501,13 +589,14 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
         BcrLevel lv; lv.elim_off = elims.size(); lv.upd_off = upds.size();
         elims.push_back(BcrElim{active[0], -1, -1, 0});
         if (nbd > 0) corner_job(active[0]);
+        premul_jobs(elims.back());
         lv.nelim = 1; lv.nupd = (int)(upds.size() - lv.upd_off);
         levels.push_back(lv);
     }
     if (hipSuccess != ws.alloc(off) || hipSuccess != d_elim.upload(elims) || hipSuccess != d_upd.upload(upds)) { if (err) *err = "block cyclic reduction workspace alloc"; return NLLS_ERR_HIP; }
     if (hipSuccess != hipMemset(ws.p, 0, off * sizeof(double))) { if (err) *err = "workspace memset"; return NLLS_ERR_HIP; }
     geom.ws = ws.p;
-    panel_lds = sizeof(double) * ((size_t)(ND + (NT + 1) * NT) * BTS + 2 * (size_t)RXT * 16 * BP + 64 + 2 * 16 * BP);
+    panel_lds = sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS);
     back_lds = sizeof(double) * ((size_t)RXT * 16 + NT * 64 + 2 * NT * 16 + (size_t)NO * 256 + 256 + 16);
     launches = 1; for (auto& lv : levels) launches += 2 + (lv.nupd > 0);
     ready = true;
@@ -517,7 +606,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
 template <int NT>
 static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status) {
     BcrPanelArgs pa{S.geom, S.d_elim.p + lv.elim_off, status};
-    hipLaunchKernelGGL(bcr_panel_kernel, dim3((unsigned)(2 * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
+    hipLaunchKernelGGL(bcr_panel_kernel, dim3((unsigned)(bcr_nchunks(NT) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     if (lv.nupd > 0) hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd);
 }
 template <int NT>

@@ -14,12 +14,12 @@ namespace nlls {
 
 struct BcrElim { int32_t i, l, r, pad; };          // block i is eliminated between its active neighbours l and r (-1: none)
 // one 16x16 output tile of a level's Schur update:  dst (-)= sum_c  Wx[a_c] Lx[b_c]'   (offsets in doubles into the workspace)
-struct BcrUpd { uint32_t dst, mode, nc, pad; uint32_t a[2], b[2]; };   // mode 0: dst -= sum, 1: dst = -sum, 2: dst = sum
+struct BcrUpd { uint32_t dst, mode, nc, pad; uint32_t a[2], b[2]; };   // mode 0: dst -= sum, 1: dst = -sum, 2: dst = sum, 3: dst = one tile product L inv(L_JJ)
 struct BcrLevel { int nelim = 0, nupd = 0; size_t elim_off = 0, upd_off = 0; };
 
 // workspace geometry handed to the kernels
 struct BcrGeom {
-    double* ws; size_t oD, oA, oBR, oWx, oLx, oMx, oMd, ocp, oxb;
+    double* ws; size_t oD, oA, oBR, oWx, oLx, oMx, oMd, oLd, oLi, ocp, oxb;
     int NT, N, nbd, n_band, bw, H;
 };
 

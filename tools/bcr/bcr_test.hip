@@ -58,14 +58,18 @@ static int run_case(int n, int bw, int nbd, int reps, unsigned seed) {
     BcrSolver S; std::string err;
     if (S.build(n, bw, nbd, H, &err) != 0) { printf("build failed: %s\n", err.c_str()); return 1; }
     double *dS, *dx; int* dst;
-    hipMalloc(&dS, Sb.size() * 8); hipMalloc(&dx, (n + nbd + 16) * 8); hipMalloc(&dst, 64);
-    hipMemcpy(dS, Sb.data(), Sb.size() * 8, hipMemcpyHostToDevice); hipMemset(dst, 0, 64); hipMemset(dx, 0, (n + nbd + 16) * 8);
+    hipMalloc(&dS, Sb.size() * 8); hipMalloc(&dx, (n + nbd + 16) * 8); hipMalloc(&dst, 512);
+    hipMemcpy(dS, Sb.data(), Sb.size() * 8, hipMemcpyHostToDevice); hipMemset(dst, 0, 512); hipMemset(dx, 0, (n + nbd + 16) * 8);
     hipStream_t st; hipStreamCreate(&st);
     S.enqueue(st, dS, dx, dst);
     hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(e)); return 1; }
-    std::vector<double> xg(n + nbd); int status[4];
-    hipMemcpy(xg.data(), dx, (n + nbd) * 8, hipMemcpyDeviceToHost); hipMemcpy(status, dst, 16, hipMemcpyDeviceToHost);
+    std::vector<double> xg(n + nbd); int status[80];
+    hipMemcpy(xg.data(), dx, (n + nbd) * 8, hipMemcpyDeviceToHost); hipMemcpy(status, dst, 320, hipMemcpyDeviceToHost);
+#ifdef BCR_STAMPS
+    for (int w = 0; w < 2; ++w) { printf("   stamps wave %d:", w); for (int i = 0; i < 20; ++i) printf(" %d", status[16 + 20 * w + i]); printf("\n"); }
+    printf("   arrivals at barrier B, J=0:"); for (int i = 0; i < 8; ++i) printf(" %d", status[56 + i]); printf("   J=1:"); for (int i = 0; i < 8; ++i) printf(" %d", status[64 + i]); printf("\n");
+#endif
     double num = 0, den = 0; int worst = -1;
     for (int i = 0; i < n + nbd; ++i) { const double d = std::fabs(xg[i] - xc[i]); if (d > num || d != d) { num = d; worst = i; } den = std::max(den, std::fabs(xc[i])); }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

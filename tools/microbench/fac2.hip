@@ -81,6 +81,84 @@ __global__ void k(const double* tile_in, double* Wout, double* Liout, double* do
             }
             dk = dn; rdk = rdn;
         }
+    } else if (VARIANT == 5) {          // baseline + zero/NaN pivot tracking (what the kernel runs)
+        int badk = 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int q = k & 3, r = k >> 2;
+            const double w = A[r], bt = Bt[r];
+            const double dk = readlane_d(w, 16 * q + k);
+            double rdk = __builtin_amdgcn_rcp(dk);
+            const bool rowq = lk == q;
+            const double am = (rowq && li > k) ? w : 0.0;
+            const double bm = rowq ? bt : 0.0;
+            rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
+            if (!(fabs(dk) > 0.0)) badk = badk < k ? badk : k;
+            db[k] = dk; db[16 + k] = rdk;
+            if (k < 15) {
+                A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
+                Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);
+            }
+        }
+        if (badk < 16 && lane == 0) cyc[1] = badk;
+    } else if (VARIANT == 6) {          // compact code: four pivots unrolled, registers rotated after each group
+#pragma unroll 1
+        for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * g4 + q;
+                const double w = A[0], bt = Bt[0];
+                const double dk = readlane_d(w, 16 * q + k);
+                double rdk = __builtin_amdgcn_rcp(dk);
+                const bool rowq = lk == q;
+                const double am = (rowq && li > k) ? w : 0.0;
+                const double bm = rowq ? bt : 0.0;
+                rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
+                db[k] = dk; db[16 + k] = rdk;
+                A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
+                Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);
+            }
+            A = double4_t{A[1], A[2], A[3], A[0]}; Bt = double4_t{Bt[1], Bt[2], Bt[3], Bt[0]};
+        }
+    } else if (VARIANT == 8 || VARIANT == 9) {          // no per-pivot LDS writes: Delta is the diagonal of the finished tile, 1/Delta recomputed by 16 lanes at the end
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int q = k & 3, r = k >> 2;
+            const double w = A[r], bt = Bt[r];
+            const double dk = readlane_d(w, 16 * q + k);
+            double rdk = __builtin_amdgcn_rcp(dk);
+            const bool rowq = lk == q;
+            const double am = (rowq && li > k) ? w : 0.0;
+            const double bm = rowq ? bt : 0.0;
+            rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
+            if (k < 15) {
+                A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
+                if (VARIANT == 8) Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);
+            }
+        }
+        {
+            double dsel = A[0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) dsel = (li >> 2) == r ? A[r] : dsel;
+            if ((li & 3) == lk) { db[li] = dsel; db[16 + li] = rcp_nr(dsel); }
+        }
+    } else if (VARIANT == 7) {          // one Newton step
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int q = k & 3, r = k >> 2;
+            const double w = A[r], bt = Bt[r];
+            const double dk = readlane_d(w, 16 * q + k);
+            double rdk = __builtin_amdgcn_rcp(dk);
+            const bool rowq = lk == q;
+            const double am = (rowq && li > k) ? w : 0.0;
+            const double bm = rowq ? bt : 0.0;
+            rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
+            db[k] = dk; db[16 + k] = rdk;
+            if (k < 15) {
+                A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
+                Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);
+            }
+        }
     } else if (VARIANT == 1) {          // A only (no inverse)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -106,6 +184,10 @@ __global__ void k(const double* tile_in, double* Wout, double* Liout, double* do
     if (lane < 32) dout[lane] = db[lane];
 }
 
+__global__ void rcpk(double* o) {
+    const int i = threadIdx.x; const double x = 1.0 + i * (1.0 / 1024) + 1e-7 * i;
+    double r = __builtin_amdgcn_rcp(x); o[i] = r; r = fma(fma(-x, r, 1.0), r, r); o[1024 + i] = r; r = fma(fma(-x, r, 1.0), r, r); o[2048 + i] = r;
+}
 static double h[256], dref[16], Lref[16][16], Linv[16][16];
 static void reference() {
     double A[16][16]; for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) A[i][j] = h[i * 16 + j];
@@ -135,5 +217,18 @@ int main() {
     run<2>("2 Bt deferred behind the next readlane", tin, W, Li, d, cyc, true);
     run<3>("3 pivot look-ahead, A only", tin, W, Li, d, cyc, false);
     run<4>("4 pivot look-ahead, A + Bt", tin, W, Li, d, cyc, true);
+    run<5>("5 baseline + zero-pivot tracking", tin, W, Li, d, cyc, true);
+    run<6>("6 compact (4 unrolled, rotating registers)", tin, W, Li, d, cyc, true);
+    run<7>("7 one Newton step", tin, W, Li, d, cyc, true);
+    run<8>("8 no LDS writes in the pivot loop (A + Bt)", tin, W, Li, d, cyc, true);
+    run<9>("9 no LDS writes in the pivot loop (A only)", tin, W, Li, d, cyc, false);
+    {   // accuracy of v_rcp_f64 alone and with one / two Newton steps
+        double* o; hipMalloc(&o, 3 * 1024 * 8);
+        hipLaunchKernelGGL(rcpk, dim3(1), dim3(1024), 0, 0, o);
+        static double ho[3 * 1024]; hipMemcpy(ho, o, sizeof(ho), hipMemcpyDeviceToHost);
+        double e0 = 0, e1 = 0, e2 = 0;
+        for (int i = 0; i < 1024; ++i) { const double x = 1.0 + i * (1.0 / 1024) + 1e-7 * i, ex = 1.0 / x; e0 = fmax(e0, fabs(ho[i] - ex) / ex); e1 = fmax(e1, fabs(ho[1024 + i] - ex) / ex); e2 = fmax(e2, fabs(ho[2048 + i] - ex) / ex); }
+        printf("v_rcp_f64 max rel err: raw %.2e, one Newton step %.2e, two %.2e\n", e0, e1, e2);
+    }
     return 0;
 }
