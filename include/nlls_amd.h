@@ -114,6 +114,7 @@ typedef struct nlls_info {
 #define NLLS_FLAG_FORCE_SPARSE   0x4  /* makesymmvls(...; formarginalization) style: BSM regardless   */
 #define NLLS_FLAG_NO_BAND        0x8  /* never use the bordered-band solver (dense MFMA path instead)  */
 #define NLLS_FLAG_NO_TWIST       0x10 /* band solver: factor from the top only (one workgroup), testing */
+#define NLLS_FLAG_DETERMINISTIC  0x40 /* reduced system assembled without atomics (slab per supernode + ordered gather): x is bit-reproducible   */
 #define NLLS_FLAG_NO_BCR         0x20 /* band solver: the round-1 chain kernels (twisted blocked LDL') instead of block cyclic reduction */
 
 /* variable-set ids for the on-device copies of problem.variables / varnext / varbest

@@ -219,7 +219,12 @@ BCR_DEV void bcr_export_linv(const double* Lid, double* __restrict__ dst) {
     *reinterpret_cast<bdouble4_t*>(dst + 4 * lane) = bdouble4_t{Lid[li * BP + lk], Lid[li * BP + 4 + lk], Lid[li * BP + 8 + lk], Lid[li * BP + 12 + lk]};
 }
 
-struct BcrPanelArgs { BcrGeom g; const BcrElim* jobs; int* status; };
+struct BcrPanelArgs { BcrGeom g; BcrChain ch; int* status; };
+// job e of a level, from the level's chain (no descriptor load in front of everything else)
+BCR_DEV BcrElim bcr_job(const BcrChain& c, int e) {
+    const int idx = c.first + 2 * e, i = c.o + idx * c.s;
+    return BcrElim{i, idx >= 1 ? i - c.s : -1, idx + 1 < c.m ? i + c.s : -1, 0};
+}
 constexpr int BCR_CH = 3;                                     // X rows (16-row tiles) per workgroup
 __host__ __device__ constexpr int bcr_nchunks(int NT) { return (2 * NT + 1 + BCR_CH - 1) / BCR_CH; }
 
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BcrGeom& g = a.g;
     const int NT = g.NT, NCH = bcr_nchunks(NT), ND = NT * (NT + 1) / 2, RXT = 2 * NT + 1, PR = NT + BCR_CH;
-    const BcrElim job = a.jobs[blockIdx.x / NCH]; const int ch = blockIdx.x % NCH;
+    const BcrElim job = bcr_job(a.ch, blockIdx.x / NCH); const int ch = blockIdx.x % NCH;
     // this workgroup's X rows: global row index Rg (0..NT-1: left neighbour, NT..2NT-1: right neighbour, 2NT: border / rhs)
     static_assert(BCR_CH == 3, "the row list below is written out for three rows");
     int rw0 = 0, rw1 = 0, rw2 = 0, RX = 0;            // (scalars, not an array: a dynamically indexed array would live in scratch memory)
@@ -422,14 +427,14 @@ __global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws
 // ---------------------------------------------------------------------------------------------------
 // backward pass of one level: one workgroup per block eliminated at that level
 // ---------------------------------------------------------------------------------------------------
-struct BcrBackArgs { BcrGeom g; const BcrElim* jobs; double* xr; int root; int* status; };
+struct BcrBackArgs { BcrGeom g; BcrChain ch; double* xr; int root; int* status; };
 // NT wavefronts: wave J owns the 16 unknowns of tile column J.  Every load of the factor is issued before anything is
 // waited for (one memory round trip per level); the unknowns of the neighbours (and of the border) go through LDS.
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BcrGeom& g = a.g;
-    const BcrElim job = a.jobs[blockIdx.x];
+    const BcrElim job = bcr_job(a.ch, blockIdx.x);
     constexpr int RXT = 2 * NT + 1, NO = NT * (NT - 1) / 2, b = 16 * NT, NTH = 64 * NT;
     const int nbd = g.nbd, nbr = nbd + 1;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, gq = lane >> 4;
@@ -553,6 +558,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
         // the larger independent set of the chain goes: positions 0, 2, 4, ... of an odd-length chain (m -> (m - 1) / 2), else 1, 3, ...
         const size_t m = active.size(), first = (m & 1) ? 0 : 1;
         BcrLevel lv; lv.elim_off = elims.size(); lv.upd_off = upds.size();
+        lv.o = active[0]; lv.s = m > 1 ? active[1] - active[0] : 1; lv.m = (int)m; lv.first = (int)first;
         for (size_t idx = first; idx < m; idx += 2)
             elims.push_back(BcrElim{active[idx], idx >= 1 ? active[idx - 1] : -1, idx + 1 < m ? active[idx + 1] : -1, 0});
         for (size_t idx = 1 - first; idx < m; idx += 2) {        // the survivors: both chain neighbours (where they exist) are eliminated now
@@ -587,6 +593,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     }
     {   // the root block
         BcrLevel lv; lv.elim_off = elims.size(); lv.upd_off = upds.size();
+        lv.o = active[0]; lv.s = 1; lv.m = 1; lv.first = 0;
         elims.push_back(BcrElim{active[0], -1, -1, 0});
         if (nbd > 0) corner_job(active[0]);
         premul_jobs(elims.back());
@@ -605,19 +612,19 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
 
 template <int NT>
 static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status) {
-    BcrPanelArgs pa{S.geom, S.d_elim.p + lv.elim_off, status};
+    BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status};
     hipLaunchKernelGGL(bcr_panel_kernel, dim3((unsigned)(bcr_nchunks(NT) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     if (lv.nupd > 0) hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd);
 }
 template <int NT>
 static void bcr_launch_back(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, double* xr, int root, int* status) {
-    BcrBackArgs ba{S.geom, S.d_elim.p + lv.elim_off, xr, root, status};
+    BcrBackArgs ba{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, xr, root, status};
     hipLaunchKernelGGL((bcr_backward_kernel<NT>), dim3((unsigned)lv.nelim), dim3(64 * NT), S.back_lds, st, ba);
 }
 
 int BcrSolver::enqueue(hipStream_t st, const double* Sb, double* xr, int* status) const {
     const int ND = NT * (NT + 1) / 2, per = ND + NT * NT + NT;
-    hipLaunchKernelGGL(bcr_convert_kernel, dim3((unsigned)(N * per + 1)), dim3(256), 0, st, geom, Sb);
+    if (Sb) hipLaunchKernelGGL(bcr_convert_kernel, dim3((unsigned)(N * per + 1)), dim3(256), 0, st, geom, Sb);   // (else: the tiles have been assembled in place, schur_gather_kernel)
 #define BCR_NT_SWITCH(CALL) switch (NT) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; default: CALL(5); break; }
 #define BCR_FWD(n) bcr_launch_level<n>(*this, st, lv, status)
     for (const BcrLevel& lv : levels) BCR_NT_SWITCH(BCR_FWD)

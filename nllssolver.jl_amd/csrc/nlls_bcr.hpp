@@ -15,7 +15,9 @@ namespace nlls {
 struct BcrElim { int32_t i, l, r, pad; };          // block i is eliminated between its active neighbours l and r (-1: none)
 // one 16x16 output tile of a level's Schur update:  dst (-)= sum_c  Wx[a_c] Lx[b_c]'   (offsets in doubles into the workspace)
 struct BcrUpd { uint32_t dst, mode, nc, pad; uint32_t a[2], b[2]; };   // mode 0: dst -= sum, 1: dst = -sum, 2: dst = sum, 3: dst = one tile product L inv(L_JJ)
-struct BcrLevel { int nelim = 0, nupd = 0; size_t elim_off = 0, upd_off = 0; };
+// a level's active chain is the arithmetic progression o, o + s, .., o + (m - 1) s; positions first, first + 2, .. of it are eliminated
+struct BcrLevel { int nelim = 0, nupd = 0; size_t elim_off = 0, upd_off = 0; int o = 0, s = 1, m = 0, first = 0; };
+struct BcrChain { int o, s, m, first; };
 
 // workspace geometry handed to the kernels
 struct BcrGeom {

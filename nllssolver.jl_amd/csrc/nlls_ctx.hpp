@@ -88,6 +88,23 @@ constexpr int SOLVE_SMALL = 0, SOLVE_DENSE = 1, SOLVE_BAND = 2;
 struct SchurCopy {           // a reduced-reduced block copied from A.data into S
     int64_t off; uint32_t r, c; uint16_t rows, cols;
 };
+// Deterministic assembly of the reduced system (no atomics): every supernode leaves its share of S -- one contiguous column-major
+// block per pair of its neighbour blocks, then its share of the rhs -- in a slab of its own; one wavefront per block pair of S then
+// sums the shares in a fixed order and writes the block cyclic reduction's tiles directly (schur_gather_kernel).
+struct GatherJob {
+    int64_t copy_off;        // A.data offset of the reduced-reduced block under this pair (-1: none)
+    uint32_t r0, c0;         // reduced dof of the block's first row / column (r0 >= c0); rhs jobs: r0 only
+    uint16_t rows, cols;
+    uint16_t kind;           // 0: block pair, 1: rhs segment of a reduced block, 2: identity on the padding behind the band
+    uint16_t copy_trans;     // the stored block is the transpose (the border reordering flipped it)
+    uint32_t cbeg, cend;     // contributions
+    uint32_t boff;           // rhs jobs: offset in b
+    uint32_t pad_;
+};
+// one share of a block pair: ld > 0 -- a block in a supernode's slab at offset off, leading dimension ld;
+// ld == 0 -- a member of a small supernode, formed on the fly: E_A' (C_v + lambda I)^-1 E_B with E_A at A.data + off, E_B at A.data + aux
+// (rhs segments: b_v at b + aux), the inverse at Cinv + cinv
+struct GatherCon { uint32_t off, ld, aux, cinv; };
 
 }  // namespace nlls
 
@@ -170,6 +187,8 @@ struct nlls_ctx {
     int solve_mode = 0, band_CH = 0, band_H = 0, band_SEG = 0, band_NSEG = 0;
     bool band_blocked = true;                // blocked (MFMA) band factorisation when the bandwidth allows
     bool band_twisted = true;               // factor the band from both ends at once (two workgroups) when the layout allows
+    bool elim_slab = false;                 // slab + gather assembly straight into the block cyclic reduction's tiles (single rank, fast-path supernodes only)
+    nlls::DevBuf<double> slab; nlls::DevBuf<uint32_t> d_slab_off, d_slab_groups; int64_t n_slab60 = 0, n_slabnar = 0, n_slabwide = 0; nlls::DevBuf<nlls::GatherJob> d_gjobs; nlls::DevBuf<nlls::GatherCon> d_gcons; int64_t n_gjobs = 0;
     nlls::BcrSolver bcr;                    // block cyclic reduction of the bordered band (nlls_bcr.hip): the default band solver when it supports the shape
     nlls::DevBuf<nlls::SchurCopy> d_copy;    // reduced-reduced blocks
     int64_t ncopy = 0;

@@ -11,6 +11,7 @@
 // is assembled densely and factored by a blocked right-looking LDL' whose trailing update runs on
 // the fp64 matrix cores (v_mfma_f64_16x16x4_f64); the eliminated blocks are recovered by
 // back-substitution.  Parity contract: x solves (H + lambda*I) x = -b, unique for SPD systems.
+#include <cstdlib>
 #include <utility>
 
 #include "nlls_internal.hpp"
@@ -486,6 +487,320 @@ __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const d
     for (int q = wv; q < nd; q += NT / 64)
         for (int p = q + ln; p < nd; p += 64) atomicAdd(L.at(rc[p], rc[q]), -img[colstart(q) + p]);
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
+}
+
+template <int DV, int NC, int TW>
+__global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_slab_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                               const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
+                                                               const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                               const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
+                                                               const double* __restrict__ Cinv, double* __restrict__ slab, const uint32_t* __restrict__ slab_off) {
+    __shared__ __attribute__((aligned(16))) double Es[2][DV][ELIM_NDP], Ys[2][DV][ELIM_NDP];
+    __shared__ uint32_t rc[ELIM_NDP];
+    const int tid = threadIdx.x; constexpr int NT = 64 * (1 + TW);
+    const uint32_t g = glist[blockIdx.x];
+    const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
+    // structure of the run (identical for all members): reduced column of every E column
+    const int64_t p0 = eptr[v0]; const int nnb = (int)(eptr[v0 + 1] - p0);
+    int nd = 0;
+    __shared__ uint8_t cblk[ELIM_NDP], coff[ELIM_NDP]; __shared__ uint16_t bdim[16], poff[16 * 17 / 2 + 1];
+    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = tid; c2 < nb.dim; c2 += NT) { cblk[nd + c2] = (uint8_t)p; coff[nd + c2] = (uint8_t)c2; } if (tid == 0) bdim[p] = nb.dim; nd += nb.dim; }
+    if (tid == 0) { int acc0 = 0; for (int A2 = 0; A2 < nnb; ++A2) { const int dA = enbr[p0 + A2].dim; for (int B2 = 0; B2 <= A2; ++B2) { poff[A2 * (A2 + 1) / 2 + B2] = (uint16_t)acc0; acc0 += dA * enbr[p0 + B2].dim; } } poff[nnb * (nnb + 1) / 2] = (uint16_t)acc0; }
+    for (int i = tid; i < 2 * DV * ELIM_NDP; i += NT) { (&Es[0][0][0])[i] = 0.0; (&Ys[0][0][0])[i] = 0.0; }
+    __syncthreads();
+    // this thread's tile: t < ntile -> (tp, tq), tq <= tp, pairs (4 tp + i, 4 tq + j).  (The rhs column E' y_b is summed by the
+    // solver wave, which has every column of E in registers: the tile waves then carry no half-empty tiles.)
+    const int T = (nd + 3) >> 2, ntile = T * (T + 1) / 2;
+    // (tiles live on waves 1-3: wave 0 is the solver and runs one member ahead of them)
+    const int tt = tid - 64;
+    int tp = 0, tq = 0; const bool has_tile = tt >= 0 && tt < ntile;
+    if (has_tile) { tp = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5); while (tp * (tp + 1) / 2 > tt) --tp; while ((tp + 1) * (tp + 2) / 2 <= tt) ++tp; tq = tt - tp * (tp + 1) / 2; }
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    // (the members of a supernode are consecutive block rows: constant stride in A.data and in b, nlls_structure.cpp)
+    const int64_t dg0 = ediag[v0], dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = eboff[v0];
+    auto member_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // LDS only: loads stay in flight
+    constexpr int NDMAX = NC == 1 ? 63 : ELIM_NDP - 5;
+    __shared__ double img[NDMAX * (NDMAX + 1) / 2 + 16 * NDMAX + NDMAX];   // one column-major block per pair of neighbour blocks (diagonal pairs: lower triangle filled), then the rhs
+    double* const rhs_out = img + poff[nnb * (nnb + 1) / 2];
+    if (tid < 64) {
+        // ---- solver wave.  Software pipeline: registers hold the column and the inverse diagonal block (schur_cinv_kernel)
+        // of the next ELIM_PF members (HBM latency is a multiple of a member's processing time).  What keeps the pipeline
+        // alive in the compiled code: (a) every load is unconditional -- lanes beyond the last column and steps beyond the
+        // last member re-load a valid address -- so that a load writes the register it is consumed from and its wait sits at
+        // the use, one round later (a conditional load becomes a copy plus vmcnt(0) at the end of the round); (b) the
+        // inverse, although the same for every lane, does NOT come through scalar loads: they share lgkmcnt with the LDS
+        // traffic and return out of order, so the LDS wait of every member would also wait for the scalar load issued a
+        // moment ago for the member four ahead (`vz` hides the uniformity from the compiler).
+        uint32_t vz = 0; asm volatile("" : "+v"(vz));
+        double en[ELIM_PF][NC][DV], cn[ELIM_PF][DV * DV];
+        double racc[NC];                                          // entry tid (+ 64) of the rhs column E' y_b
+#pragma unroll
+        for (int k = 0; k < NC; ++k) racc[k] = 0.0;
+        const int kb = nd >> 6, lb = nd & 63;                     // where the rhs column sits: lane lb, slot kb
+        auto issue = [&](uint32_t v, int slot) {
+            const uint32_t m = (v < v1 ? v : v1 - 1) - v0;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int col = tid + 64 * k < nd ? tid + 64 * k : nd;
+                const double* src = col < nd ? A + (dg0 + (int64_t)m * dstride - (int64_t)DV * nd + (int64_t)DV * col) : b + (eb0 + m * DV);
+#pragma unroll
+                for (int a2 = 0; a2 < DV; ++a2) en[slot][k][a2] = src[a2];
+            }
+#pragma unroll
+            for (int j = 0; j < DV; ++j)
+#pragma unroll
+                for (int i = j; i < DV; ++i) cn[slot][i + DV * j] = Cinv[(int64_t)(v0 + m) * (DV * DV) + i + DV * j + vz];   // symmetric: lower triangle
+        };
+#pragma unroll
+        for (int u = 0; u < ELIM_PF; ++u) issue(v0 + u, u);
+        int buf = 0;
+#pragma unroll 1
+        for (uint32_t vb = v0; vb < v1; vb += ELIM_PF) {
+#pragma unroll
+            for (int u = 0; u < ELIM_PF; ++u) {
+                const uint32_t v = vb + u;
+                if (v >= v1) break;
+                double e[NC][DV], C[DV * DV];
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                    for (int a2 = 0; a2 < DV; ++a2) e[k][a2] = en[u][k][a2];
+#pragma unroll
+                for (int j = 0; j < DV; ++j)
+#pragma unroll
+                    for (int i = j; i < DV; ++i) C[i + DV * j] = cn[u][i + DV * j];
+                issue(v + ELIM_PF, u);
+                double y[NC][DV];                              // y = (C_v + lambda I)^-1 e
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+#pragma unroll
+                    for (int i = 0; i < DV; ++i) { double t = 0;
+#pragma unroll
+                        for (int j = 0; j < DV; ++j) t = fma(i >= j ? C[i + DV * j] : C[j + DV * i], e[k][j], t);
+                        y[k][i] = t; }
+                    if (tid + 64 * k <= nd) {
+#pragma unroll
+                        for (int a2 = 0; a2 < DV; ++a2) { Es[buf][a2][tid + 64 * k] = e[k][a2]; Ys[buf][a2][tid + 64 * k] = y[k][a2]; }
+                    }
+                }
+#pragma unroll
+                for (int a2 = 0; a2 < DV; ++a2) {              // the rhs column: y_b broadcast from its lane
+                    const double ysel = (NC == 2 && kb == 1) ? +y[NC - 1][a2] : +y[0][a2];
+                    const double yb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ysel), lb), __builtin_amdgcn_readlane(__double2loint(ysel), lb));
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) racc[k] = fma(e[k][a2], yb, racc[k]);
+                }
+                member_barrier();                              // member v published; the other buffer is free for v + 1
+                buf ^= 1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) if (tid + 64 * k < nd) rhs_out[tid + 64 * k] = racc[k];
+    } else {
+        // ---- tile waves: one barrier per member, then this thread's 4x4 tile of the rank-DV update
+        int buf = 0;
+#pragma unroll 1
+        for (uint32_t v = v0; v < v1; ++v) {
+            member_barrier();
+            if (has_tile) {
+                double ep[DV][4], yq[DV][4];
+#pragma unroll
+                for (int a2 = 0; a2 < DV; ++a2) {
+                    const double4_t ev = *reinterpret_cast<const double4_t*>(&Es[buf][a2][4 * tp]);
+                    ep[a2][0] = ev[0]; ep[a2][1] = ev[1]; ep[a2][2] = ev[2]; ep[a2][3] = ev[3];
+                    const double4_t yv = *reinterpret_cast<const double4_t*>(&Ys[buf][a2][4 * tq]); yq[a2][0] = yv[0]; yq[a2][1] = yv[1]; yq[a2][2] = yv[2]; yq[a2][3] = yv[3];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        double t = acc[i][j];
+#pragma unroll
+                        for (int a2 = 0; a2 < DV; ++a2) t = fma(ep[a2][i], yq[a2][j], t);
+                        acc[i][j] = t;
+                    }
+            }
+            buf ^= 1;
+        }
+    }
+    // Flush: the register tiles go into the block image in LDS, the image leaves for the supernode's own slab with plain
+    // coalesced stores -- no atomics; schur_gather_kernel sums the shares of all supernodes in a fixed order.
+    if (has_tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = 4 * tp + i; if (p >= nd) continue;
+            const int A2 = cblk[p], oa = coff[p], dA = bdim[A2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int q = 4 * tq + j; if (q <= p) { const int B2 = cblk[q]; img[poff[A2 * (A2 + 1) / 2 + B2] + oa + dA * coff[q]] = acc[i][j]; } }
+        }
+    }
+    __syncthreads();
+    double* const out = slab + slab_off[blockIdx.x];
+    const int total = poff[nnb * (nnb + 1) / 2] + nd;
+    for (int t = tid; t < total; t += NT) out[t] = img[t];
+}
+
+// Elimination without a barrier per member: FOUR INDEPENDENT wavefronts per supernode, each taking every fourth member and
+// owning a full set of 4x4 register tiles of the supernode's share of S.  A wave loads its members' columns of [E | b] itself
+// (a few members ahead, one column per lane -- every byte of the point rows is requested once, by one wave, and with four
+// waves per supernode enough bytes are in flight to cover the HBM latency), multiplies by (C_v + lambda I)^-1, stages e_c, y_c
+// in its own LDS buffer (LDS operations of one wave execute in order: no barrier between its stores and its loads) and applies
+// the rank-DV update to its tiles.  The four partial shares are summed through the block image in LDS in wave order
+// (deterministic) and leave for the supernode's slab with plain coalesced stores: one column-major block per pair of neighbour
+// blocks, then the rhs.
+constexpr int ELIM_NW = 2;
+template <int DV, int NC, int TPL>
+__global__ __launch_bounds__(64 * ELIM_NW) void schur_elim_wave_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                              const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
+                                                              const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
+                                                              const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
+                                                              const double* __restrict__ Cinv, double* __restrict__ slab, const uint32_t* __restrict__ slab_off) {
+    constexpr int NT2 = 64 * ELIM_NW;
+    __shared__ __attribute__((aligned(16))) double Es[ELIM_NW][DV][ELIM_NDP], Ys[ELIM_NW][DV][ELIM_NDP];      // [wave]: private staging
+    __shared__ uint8_t cblk[ELIM_NDP], coff[ELIM_NDP]; __shared__ uint16_t bdim[16], poff[16 * 17 / 2 + 1];
+    constexpr int NDMAX = NC == 1 ? 63 : ELIM_NDP - 5;
+    __shared__ double img[NDMAX * (NDMAX + 1) / 2 + 16 * NDMAX + NDMAX];
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const uint32_t g = glist[blockIdx.x];
+    const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
+    const int64_t p0 = eptr[v0]; const int nnb = (int)(eptr[v0 + 1] - p0);
+    int nd = 0;
+    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = tid; c2 < nb.dim; c2 += NT2) { cblk[nd + c2] = (uint8_t)p; coff[nd + c2] = (uint8_t)c2; } if (tid == 0) bdim[p] = nb.dim; nd += nb.dim; }
+    if (tid == 0) { int acc0 = 0; for (int A2 = 0; A2 < nnb; ++A2) { const int dA = enbr[p0 + A2].dim; for (int B2 = 0; B2 <= A2; ++B2) { poff[A2 * (A2 + 1) / 2 + B2] = (uint16_t)acc0; acc0 += dA * enbr[p0 + B2].dim; } } poff[nnb * (nnb + 1) / 2] = (uint16_t)acc0; }
+    for (int i = tid; i < ELIM_NW * DV * ELIM_NDP; i += NT2) { (&Es[0][0][0])[i] = 0.0; (&Ys[0][0][0])[i] = 0.0; }
+    __syncthreads();
+    // this lane's tiles: t = lane + 64 k < ntile -> (tp, tq), tq <= tp, pairs (4 tp + i, 4 tq + j).  Consecutive lanes hold
+    // consecutive tiles of a tile row, i.e. consecutive 32-byte groups of Y: a 16-byte LDS read per lane then touches every bank
+    // twice (lanes l and l + 8 of a 16-lane group are 256 bytes apart) -- unless the lanes with an odd (tq / 8) read the two
+    // halves of their group in the opposite order.  Their accumulator columns are then permuted (j ^ 2), which only the flush sees.
+    const int T = (nd + 3) >> 2, ntile = T * (T + 1) / 2;
+    int tp[TPL], tq[TPL], sw[TPL]; bool has[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+        const int tt = lane + 64 * k; has[k] = tt < ntile; tp[k] = 0; tq[k] = 0; sw[k] = 0;
+        if (has[k]) { int a2 = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5); while (a2 * (a2 + 1) / 2 > tt) --a2; while ((a2 + 1) * (a2 + 2) / 2 <= tt) ++a2; tp[k] = a2; tq[k] = tt - a2 * (a2 + 1) / 2; sw[k] = (tq[k] >> 3) & 1; }
+    }
+    double acc[TPL][4][4];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][i][j] = 0.0;
+    const int64_t dg0 = ediag[v0], dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = eboff[v0];
+    uint32_t vz = 0; asm volatile("" : "+v"(vz));                // (keeps the inverse's loads vector loads: see the kernel above)
+    double en[ELIM_PF][NC][DV], cn[ELIM_PF][DV * DV];
+    double racc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) racc[k] = 0.0;
+    const int kb = nd >> 6, lb = nd & 63;                         // where the rhs column sits: lane lb, slot kb
+    const uint32_t nmem = v1 - v0;
+    // member index m of this wave's step s2: wv + 4 s2 (clamped: steps behind the last member re-load a valid row)
+    auto issue = [&](uint32_t s2, int slot) {
+        uint32_t m = wv + ELIM_NW * s2; m = m < nmem ? m : nmem - 1;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int col = lane + 64 * k < nd ? lane + 64 * k : nd;
+            const double* src = col < nd ? A + (dg0 + (int64_t)m * dstride - (int64_t)DV * nd + (int64_t)DV * col) : b + (eb0 + m * DV);
+#pragma unroll
+            for (int a2 = 0; a2 < DV; ++a2) en[slot][k][a2] = src[a2];
+        }
+#pragma unroll
+        for (int j = 0; j < DV; ++j)
+#pragma unroll
+            for (int i = j; i < DV; ++i) cn[slot][i + DV * j] = Cinv[(int64_t)(v0 + m) * (DV * DV) + i + DV * j + vz];
+    };
+#pragma unroll
+    for (int u = 0; u < ELIM_PF; ++u) issue(u, u);
+    double (*const myE)[ELIM_NDP] = Es[wv]; double (*const myY)[ELIM_NDP] = Ys[wv];
+    const uint32_t nstep = nmem > (uint32_t)wv ? (nmem - wv + ELIM_NW - 1) / ELIM_NW : 0;
+#pragma unroll 1
+    for (uint32_t sb = 0; sb < nstep; sb += ELIM_PF) {
+#pragma unroll
+        for (int u = 0; u < ELIM_PF; ++u) {
+            const uint32_t s2 = sb + u;
+            if (s2 >= nstep) break;
+            double e[NC][DV], C[DV * DV];
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+#pragma unroll
+                for (int a2 = 0; a2 < DV; ++a2) e[k][a2] = en[u][k][a2];
+#pragma unroll
+            for (int j = 0; j < DV; ++j)
+#pragma unroll
+                for (int i = j; i < DV; ++i) C[i + DV * j] = cn[u][i + DV * j];
+            issue(s2 + ELIM_PF, u);
+            double y[NC][DV];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+#pragma unroll
+                for (int i = 0; i < DV; ++i) { double t = 0;
+#pragma unroll
+                    for (int j = 0; j < DV; ++j) t = fma(i >= j ? C[i + DV * j] : C[j + DV * i], e[k][j], t);
+                    y[k][i] = t; }
+                if (lane + 64 * k <= nd) {
+#pragma unroll
+                    for (int a2 = 0; a2 < DV; ++a2) { myE[a2][lane + 64 * k] = e[k][a2]; myY[a2][lane + 64 * k] = y[k][a2]; }
+                }
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < DV; ++a2) {                  // the rhs column: y_b broadcast from its lane
+                const double ysel = (NC == 2 && kb == 1) ? +y[NC - 1][a2] : +y[0][a2];
+                const double yb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ysel), lb), __builtin_amdgcn_readlane(__double2loint(ysel), lb));
+#pragma unroll
+                for (int k = 0; k < NC; ++k) racc[k] = fma(e[k][a2], yb, racc[k]);
+            }
+            asm volatile("" ::: "memory");                          // the loads below stay behind the stores above (same wave, in-order LDS)
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) {
+                double ep[DV][4], yq[DV][4];
+#pragma unroll
+                for (int a2 = 0; a2 < DV; ++a2) {
+                    const double4_t ev = *reinterpret_cast<const double4_t*>(&myE[a2][4 * tp[k]]);
+                    ep[a2][0] = ev[0]; ep[a2][1] = ev[1]; ep[a2][2] = ev[2]; ep[a2][3] = ev[3];
+                    typedef double double2_t __attribute__((ext_vector_type(2)));
+                    const double2_t y0 = *reinterpret_cast<const double2_t*>(&myY[a2][4 * tq[k] + 2 * sw[k]]), y1 = *reinterpret_cast<const double2_t*>(&myY[a2][4 * tq[k] + 2 - 2 * sw[k]]);
+                    yq[a2][0] = y0[0]; yq[a2][1] = y0[1]; yq[a2][2] = y1[0]; yq[a2][3] = y1[1];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        double t = acc[k][i][j];
+#pragma unroll
+                        for (int a2 = 0; a2 < DV; ++a2) t = fma(ep[a2][i], yq[a2][j], t);
+                        acc[k][i][j] = t;
+                    }
+            }
+            asm volatile("" ::: "memory");                          // ... and the next member's stores behind these loads
+        }
+    }
+    // the four partial shares meet in the block image, in wave order
+    const int roff = poff[nnb * (nnb + 1) / 2];
+    for (int w = 0; w < ELIM_NW; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) if (has[k]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int p = 4 * tp[k] + i; if (p >= nd) continue;
+                    const int A2 = cblk[p], oa = coff[p], dA = bdim[A2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int q = 4 * tq[k] + (j ^ (2 * sw[k])); if (q <= p) { const int B2 = cblk[q]; double* d = &img[poff[A2 * (A2 + 1) / 2 + B2] + oa + dA * coff[q]]; *d = w == 0 ? acc[k][i][j] : *d + acc[k][i][j]; } }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) if (lane + 64 * k < nd) { double* d = &img[roff + lane + 64 * k]; *d = w == 0 ? racc[k] : *d + racc[k]; }
+        }
+        __syncthreads();
+    }
+    double* const out = slab + slab_off[blockIdx.x];
+    const int total = roff + nd;
+    for (int t = tid; t < total; t += NT2) out[t] = img[t];
 }
 
 // x_v = C_v^-1 (b_v - E_v x_R), stored negated (negate!, src/iterators.jl:3)
@@ -1583,6 +1898,70 @@ __global__ __launch_bounds__(256) void quadform_finish_kernel(const double* __re
 }
 
 // ---------------------------------------------------------------------------------------------------
+// assembly of the reduced system from the supernodes' slabs, straight into the block cyclic reduction's tiles:
+// one wavefront per block pair of S (per rhs segment), shares summed in the order the structure lists them.
+// The tiles have been zero-filled by the previous solve's back-substitution launch (or the allocation).
+// ---------------------------------------------------------------------------------------------------
+struct GatherArgs { const GatherJob* jobs; const GatherCon* cons; int64_t njobs; const double* slab; const double* A; const double* b; const double* Cinv; int dv; double lambda; BcrGeom g; int* status; };
+__device__ __forceinline__ void gather_store(const BcrGeom& g, int r, int c, double v) {      // S(r, c), r >= c
+    const int NT = g.NT, bsz = 16 * NT;
+    if (r >= g.n_band) {
+        const int br = r - g.n_band;
+        if (c >= g.n_band) { const int bc = c - g.n_band; g.ws[g.ocp + br * 16 + bc] = v; g.ws[g.ocp + bc * 16 + br] = v; }
+        else { const int k = c / bsz, K = (c - k * bsz) >> 4; g.ws[g.oBR + ((size_t)k * NT + K) * 256 + br * 16 + (c & 15)] = v; }
+        return;
+    }
+    const int kr = r / bsz, kc = c / bsz, I = (r - kr * bsz) >> 4, K = (c - kc * bsz) >> 4;
+    if (kr == kc) {
+        double* t = g.ws + g.oD + ((size_t)kr * (NT * (NT + 1) / 2) + I * (I + 1) / 2 + K) * 256;
+        t[(r & 15) * 16 + (c & 15)] = v; if (I == K) t[(c & 15) * 16 + (r & 15)] = v;
+    } else g.ws[g.oA + ((size_t)kr * NT * NT + I * NT + K) * 256 + (r & 15) * 16 + (c & 15)] = v;     // kr == kc + 1: the block size covers the bandwidth
+}
+__global__ __launch_bounds__(256) void schur_gather_kernel(GatherArgs a) {
+    const int64_t j = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); if (j >= a.njobs) return;
+    const GatherJob J = a.jobs[j]; const int lane = threadIdx.x & 63;
+    const BcrGeom& g = a.g;
+    if (J.kind == 2) {                                         // identity on the padding behind the band (the last block's unused columns)
+        for (int r = g.n_band + lane; r < g.N * 16 * g.NT; r += 64) { const int bsz = 16 * g.NT, k = r / bsz, I = (r - k * bsz) >> 4;
+            g.ws[g.oD + ((size_t)k * (g.NT * (g.NT + 1) / 2) + I * (I + 1) / 2 + I) * 256 + (r & 15) * 17] = 1.0; }
+        return;
+    }
+    const int rows = J.rows, ne = rows * J.cols;
+    for (int e = lane; e < ne; e += 64) {
+        const int b2 = e / rows, a2 = e - b2 * rows;
+        const bool diag = J.kind == 0 && J.r0 == J.c0;
+        if (diag && a2 < b2) continue;                        // diagonal block: the lower triangle (mirrored by the store)
+        double v = 0.0;
+        if (J.kind == 0) { if (J.copy_off >= 0) v = J.copy_trans ? a.A[J.copy_off + b2 + (int)J.cols * a2] : a.A[J.copy_off + a2 + rows * b2]; if (diag && a2 == b2) v += a.lambda; }
+        else v = a.b[J.boff + a2];
+        // shares, four at a time: the descriptors (uniform loads) and then the four values are in flight together
+        for (uint32_t c0 = J.cbeg; c0 < J.cend; c0 += 4) {
+            GatherCon k[4]; double t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = a.cons[c0 + u < J.cend ? c0 + u : J.cend - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k[u].ld) t[u] = a.slab[k[u].off + a2 + k[u].ld * b2];
+                else {                                          // a member of a small supernode: e_a' (C_v + lambda I)^-1 e_b on the fly
+                    const int dv = a.dv; const double* ea = a.A + k[u].off + (size_t)dv * a2; const double* eb = J.kind == 0 ? a.A + k[u].aux + (size_t)dv * b2 : a.b + k[u].aux;
+                    const double* ci = a.Cinv + k[u].cinv; double s2 = 0.0;
+                    for (int m = 0; m < dv; ++m) { double r2 = 0.0; for (int n2 = 0; n2 < dv; ++n2) r2 = fma(ci[m + dv * n2], eb[n2], r2); s2 = fma(ea[m], r2, s2); }
+                    t[u] = s2;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (c0 + u < J.cend) v -= t[u];
+        }
+        if (J.kind == 0) gather_store(g, (int)J.r0 + a2, (int)J.c0 + b2, v);
+        else {                                                 // the rhs row: row nbd of the border / rhs tiles
+            const int r = (int)J.r0 + a2, NT = g.NT, bsz = 16 * NT;
+            if (r >= g.n_band) g.ws[g.ocp + g.nbd * 16 + (r - g.n_band)] = v;
+            else { const int k = r / bsz, K = (r - k * bsz) >> 4; g.ws[g.oBR + ((size_t)k * NT + K) * 256 + g.nbd * 16 + (r & 15)] = v; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 static int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(what) + ": " + hipGetErrorString(e); return NLLS_ERR_HIP; }
@@ -1662,6 +2041,27 @@ int enqueue_solve_local(nlls_ctx* c) {
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
     const SLayout L = make_layout(c); const int npad = L.npad;
     const bool band = c->solve_mode == SOLVE_BAND; const bool lead = c->nranks == 1 || c->rank == 0;
+    if (c->elim_slab) {
+        // slab + gather assembly (deterministic): (C_v + lambda I)^-1, the supernodes' shares into their slabs, one gather into the tiles
+        const int64_t nel = (int64_t)c->d_elim_diag.n;
+        const int64_t n60 = c->n_slab60, nnar = c->n_slabnar, nwid = c->n_slabwide;    // (small supernodes are not here: the gather forms their shares itself)
+#define LAUNCH_SLAB(DV) do { \
+            hipLaunchKernelGGL((schur_cinv_kernel<DV>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, c->stream, c->A.p, c->d_elim_diag.p, c->d_elim_dim.p, nel, c->lambda, c->Cinv.p, c->d_status.p); \
+            if (n60 > 0) hipLaunchKernelGGL((schur_elim_wave_kernel<DV, 1, 2>), dim3((unsigned)n60), dim3(64 * ELIM_NW), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_slab_groups.p, c->Cinv.p, c->slab.p, c->d_slab_off.p); \
+            if (nnar > 0) hipLaunchKernelGGL((schur_elim_wave_kernel<DV, 1, 3>), dim3((unsigned)nnar), dim3(64 * ELIM_NW), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_slab_groups.p + n60, c->Cinv.p, c->slab.p, c->d_slab_off.p + n60); \
+            if (nwid > 0) hipLaunchKernelGGL((schur_elim_wave_kernel<DV, 2, 3>), dim3((unsigned)nwid), dim3(64 * ELIM_NW), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_slab_groups.p + n60 + nnar, c->Cinv.p, c->slab.p, c->d_slab_off.p + n60 + nnar); } while (0)
+        // (the status reset rides in the gather launch; schur_cinv_kernel may flag a bad pivot before it: reset first)
+        HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 4, c->stream));
+        if (c->fast_dv == 3) LAUNCH_SLAB(3); else if (c->fast_dv == 2) LAUNCH_SLAB(2); else LAUNCH_SLAB(1);
+#undef LAUNCH_SLAB
+        GatherArgs ga{c->d_gjobs.p, c->d_gcons.p, c->n_gjobs, c->slab.p, c->A.p, c->b.p, c->Cinv.p, c->fast_dv, c->lambda, c->bcr.geom, c->d_status.p};
+        hipLaunchKernelGGL(schur_gather_kernel, dim3((unsigned)((c->n_gjobs + 3) / 4)), dim3(256), 0, c->stream, ga);
+        HIPCHK(hipGetLastError());
+        return NLLS_OK;
+    }
     const bool one_prepare = lead && c->info.is_sparse && c->ncopy > 0;      // status reset, s and the reduced-reduced blocks in one launch
     if (!one_prepare) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 4, c->stream));
     if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
@@ -1711,7 +2111,7 @@ int enqueue_solve_finish(nlls_ctx* c) {
     if (c->solve_mode == SOLVE_SMALL) {
         hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s_ptr(), n, npad, c->d_status.p);
     } else if (band && c->bcr.ready) {
-        if (c->bcr.enqueue(c->stream, c->S.p, c->s_ptr(), c->d_status.p) != NLLS_OK) return herr(c, hipGetLastError(), "block cyclic reduction launch");
+        if (c->bcr.enqueue(c->stream, c->elim_slab ? (const double*)nullptr : c->S.p, c->s_ptr(), c->d_status.p) != NLLS_OK) return herr(c, hipGetLastError(), "block cyclic reduction launch");
     } else if (band) {
         BandArgs a{}; a.Sb = c->S.p; a.Lb = c->Lwork.p; a.xr = c->s_ptr(); a.n_band = L.n_band; a.bw = L.bw; a.nbd = L.nbd; a.H = L.H; a.CH = c->band_CH; a.status = c->d_status.p;
         a.PFC = (L.bw + 1 + a.CH - 1) / a.CH + 1; a.RC = (a.PFC + 1) * a.CH; a.NSC = (L.bw + 1 + c->band_SEG - 1) / c->band_SEG;
@@ -1809,8 +2209,11 @@ int enqueue_solve_finish(nlls_ctx* c) {
         // (single rank, one_prepare path: s is rewritten in full by schur_prepare_kernel, so only S itself has to be zero)
         const bool zero_S = c->nranks == 1 && c->solve_mode == SOLVE_BAND && c->info.is_sparse && c->ncopy > 0;
         const unsigned nextra = zero_S ? 160 : 32;
+        // what the spare workgroups zero-fill for the next solve: the band storage of S, or (slab + gather assembly) the tiles the gather writes into
+        double* zptr = c->S.p; int64_t zcount = zero_S ? (int64_t)c->s_elems : (int64_t)0;
+        if (c->elim_slab) { const BcrGeom& g = c->bcr.geom; zptr = g.ws + g.oD; zcount = (int64_t)(g.oBR + (size_t)g.N * g.NT * 256 - g.oD); }
 #define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + nextra), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p, \
-                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red, c->S.p, zero_S ? (int64_t)c->s_elems : (int64_t)0)
+                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red, zptr, zcount)
         if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; c->S_zeroed = zero_S; }
 #undef LAUNCH_BSF
     }

@@ -7,6 +7,7 @@
 // block row, LDS-image tiles, and the Schur elimination lists.
 #include <algorithm>
 #include <numeric>
+#include <map>
 #include <unordered_map>
 
 #include "nlls_ctx.hpp"
@@ -381,6 +382,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     // attempt's supernode lists: the solve dispatches on these counters)
     c->n_fast_groups = 0; c->n_slow_groups = 0; c->n_fast_members = 0; c->n_fast_narrow = 0; c->n_fast_n60 = 0; c->fast_dv = 0;
     c->tE_valid = false; c->S_zeroed = false; c->step_cached = false; c->bcr.release();
+    c->elim_slab = false; c->slab.release(); c->d_slab_off.release(); c->d_slab_groups.release(); c->d_gjobs.release(); c->d_gcons.release(); c->n_gjobs = 0;
     // (the solve also dispatches on the SIZE of these lists: an upload without elimination must not inherit them)
     c->d_elim_ptr.release(); c->d_elim_nbr.release(); c->d_elim_diag.release(); c->d_elim_boff.release(); c->d_elim_dim.release(); c->d_elim_group.release();
     c->d_fast_groups.release(); c->d_slow_groups.release(); c->d_slow_blocks.release(); c->d_fast_members.release(); c->Cinv.release(); c->tE.release();
@@ -425,6 +427,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     }
     std::vector<int64_t> eptr; std::vector<SchurNbr> enbr; std::vector<int64_t> ediag; std::vector<uint32_t> eboff; std::vector<uint16_t> edim; std::vector<uint32_t> egroup;
     std::vector<int64_t> erow;                 // block row of each (local) eliminated member
+    std::vector<uint32_t> fastg_all;           // fast supernodes in launch order (copy kept for the gather index)
     std::vector<uint8_t> row_fast(nb, 0);      // block rows whose members take the fast elimination path
     eptr.push_back(0);
     if (c->nelim) {
@@ -480,6 +483,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         c->n_fast_narrow = (int64_t)fastg.size(); c->fast_maxk_narrow = fast_maxk;
         fastg.insert(fastg.end(), fastw.begin(), fastw.end());
         c->n_fast_groups = (int64_t)fastg.size(); c->n_slow_groups = (int64_t)slowg.size(); c->fast_dv = fast_dv; c->fast_maxk = fast_maxk;
+        fastg_all = fastg;
         std::vector<uint32_t> slowb; for (uint32_t gi : slowg) for (uint32_t v = egroup[gi]; v < egroup[gi + 1]; ++v) slowb.push_back(v);
         std::vector<uint32_t> fastb; for (uint32_t gi : fastg) for (uint32_t v = egroup[gi]; v < egroup[gi + 1]; ++v) { fastb.push_back(v); row_fast[erow[v]] = 1; }
         c->n_fast_members = (int64_t)fastb.size();
@@ -563,6 +567,71 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         if (!(flags & NLLS_FLAG_NO_BCR) && BcrSolver::supports(c->n_band, (int)bw, c->nbd)) {
             std::string e; const int rc = c->bcr.build(c->n_band, (int)bw, c->nbd, c->band_H, &e);
             if (rc != NLLS_OK) return fail(c, rc, e.c_str());
+        }
+        // ---- slab + gather assembly (NLLS_FLAG_DETERMINISTIC: no atomics, x is bit-reproducible; 15 % slower than the atomic flush at
+        //      config 4): single rank, every eliminated block on the fast path
+        if (c->bcr.ready && c->nranks == 1 && (flags & NLLS_FLAG_DETERMINISTIC) && c->n_fast_groups > 0 && c->n_slow_groups == 0 && I0.is_sparse) {
+            struct Key { uint32_t r, c; bool operator<(const Key& o) const { return r != o.r ? r < o.r : c < o.c; } };
+            std::map<Key, std::vector<GatherCon>> pairs; std::map<uint32_t, std::vector<GatherCon>> rhs;
+            std::vector<uint32_t> slab_off, slab_groups; uint64_t off = 0; bool ok = (uint64_t)I0.nnz_data < ((uint64_t)1 << 32) && (uint64_t)I0.ndof < ((uint64_t)1 << 32);
+            int64_t cls_count[3] = {0, 0, 0};
+            constexpr uint32_t SMALL_SUPERNODE = 0;      // members: up to here a supernode's share is formed inside the gather, member by member (measured: only pays for supernodes that are rare; the 1-2 member supernodes of config 4 are not -- 0 = off)
+            const int dv = c->fast_dv;
+            for (size_t pos = 0; ok && pos < fastg_all.size(); ++pos) {
+                const uint32_t gi = fastg_all[pos];
+                const uint32_t v0 = egroup[gi], v1 = egroup[gi + 1];
+                std::vector<SchurNbr> nl(enbr.begin() + eptr[v0], enbr.begin() + eptr[v0 + 1]);
+                if (nl.size() > 16) { ok = false; break; }
+                if (v1 - v0 <= SMALL_SUPERNODE) {
+                    for (uint32_t v = v0; v < v1; ++v) {
+                        const SchurNbr* nv = enbr.data() + eptr[v];
+                        for (size_t a = 0; a < nl.size(); ++a) {
+                            for (size_t b2 = 0; b2 <= a; ++b2) pairs[Key{nl[a].rcol, nl[b2].rcol}].push_back(GatherCon{(uint32_t)nv[a].off, 0, (uint32_t)nv[b2].off, (uint32_t)((uint64_t)v * dv * dv)});
+                            rhs[nl[a].rcol].push_back(GatherCon{(uint32_t)nv[a].off, 0, eboff[v], (uint32_t)((uint64_t)v * dv * dv)});
+                        }
+                    }
+                    continue;
+                }
+                const int cls = (int64_t)pos < c->n_fast_n60 ? 0 : ((int64_t)pos < c->n_fast_narrow ? 1 : 2);
+                cls_count[cls]++; slab_groups.push_back(gi);
+                slab_off.push_back((uint32_t)off);
+                uint64_t po = off;
+                for (size_t a = 0; a < nl.size(); ++a)
+                    for (size_t b2 = 0; b2 <= a; ++b2) { pairs[Key{nl[a].rcol, nl[b2].rcol}].push_back(GatherCon{(uint32_t)po, (uint32_t)nl[a].dim, 0, 0}); po += (uint64_t)nl[a].dim * nl[b2].dim; }
+                uint64_t ro = po;
+                for (size_t a = 0; a < nl.size(); ++a) { rhs[nl[a].rcol].push_back(GatherCon{(uint32_t)ro, 1, 0, 0}); ro += nl[a].dim; }
+                off = (ro + 3) & ~(uint64_t)3;
+                if (off >= ((uint64_t)1 << 32)) { ok = false; break; }
+            }
+            c->n_slab60 = cls_count[0]; c->n_slabnar = cls_count[1]; c->n_slabwide = cls_count[2];
+            if (ok) {
+                std::vector<GatherJob> jobs; std::vector<GatherCon> cons;
+                std::map<Key, const SchurCopy*> base;
+                for (const SchurCopy& cp : copies) { if (cp.r >= cp.c) base[Key{cp.r, cp.c}] = &cp; else base[Key{cp.c, cp.r}] = &cp; }
+                std::vector<int32_t> dim_of(c->nred + 1, 0);      // size of the reduced block that starts at a reduced dof
+                std::vector<uint32_t> boff_of(c->nred + 1, 0);
+                for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) { dim_of[red_of[k]] = c->blocksizes[k]; boff_of[red_of[k]] = (uint32_t)c->boffsets[k]; }
+                // every block pair that holds a share or a stored block
+                std::map<Key, int> all; for (auto& kv : pairs) all[kv.first] = 1; for (auto& kv : base) all[kv.first] = 1;
+                for (auto& kv : all) {
+                    GatherJob j{}; j.copy_off = -1; j.r0 = kv.first.r; j.c0 = kv.first.c; j.rows = (uint16_t)dim_of[j.r0]; j.cols = (uint16_t)dim_of[j.c0]; j.kind = 0;
+                    auto bi = base.find(kv.first);
+                    if (bi != base.end()) { j.copy_off = bi->second->off; j.copy_trans = bi->second->r < bi->second->c ? 1 : 0; }
+                    j.cbeg = (uint32_t)cons.size();
+                    auto pi = pairs.find(kv.first); if (pi != pairs.end()) cons.insert(cons.end(), pi->second.begin(), pi->second.end());
+                    j.cend = (uint32_t)cons.size();
+                    jobs.push_back(j);
+                }
+                for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) {
+                    GatherJob j{}; j.copy_off = -1; j.r0 = (uint32_t)red_of[k]; j.rows = (uint16_t)c->blocksizes[k]; j.cols = 1; j.kind = 1; j.boff = (uint32_t)c->boffsets[k];
+                    j.cbeg = (uint32_t)cons.size(); auto ri = rhs.find(j.r0); if (ri != rhs.end()) cons.insert(cons.end(), ri->second.begin(), ri->second.end()); j.cend = (uint32_t)cons.size();
+                    jobs.push_back(j);
+                }
+                { GatherJob j{}; j.copy_off = -1; j.kind = 2; jobs.push_back(j); }
+                if (hipSuccess != c->slab.alloc((size_t)std::max<uint64_t>(off, 4)) || hipSuccess != c->d_slab_off.upload(slab_off) || hipSuccess != c->d_slab_groups.upload(slab_groups) || hipSuccess != c->d_gjobs.upload(jobs) ||
+                    hipSuccess != c->d_gcons.upload(cons)) return fail(c, NLLS_ERR_HIP, "gather index upload");
+                c->n_gjobs = (int64_t)jobs.size(); c->elim_slab = true;
+            }
         }
     } else {
         const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row

@@ -211,6 +211,7 @@ def test_randomized_ba_against_oracle(seed):
         unfixed = np.ones(p.nvariables, bool)
         unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 20), replace=False)] = False
     flags = [0, _capi.FLAG_NO_BCR, _capi.FLAG_FORCE_ATOMIC, _capi.FLAG_NO_BAND, _capi.FLAG_NO_BCR | _capi.FLAG_NO_TWIST, _capi.FLAG_FORCE_SPARSE][int(rng.integers(0, 6))]
+    if seed % 3 == 0: flags |= _capi.FLAG_DETERMINISTIC
     check_problem(p, unfixed=unfixed, flags=flags, lam_scale=[1e-6, 1e-4, 1e-1, 1e-2][kind])
 
 
@@ -283,6 +284,22 @@ def test_block_cyclic_reduction_shapes(ncam, npts, cpp, adaptive, seed):
         p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, cpp / ncam, seed=seed), 1e-3, 1e-3)
         info = check_problem(p, expect_sparse=1, expect_schur=1)
     assert info.solve_mode == 2
+
+
+@pytest.mark.parametrize("ncam,npts,cpp,seed", [(130, 3000, 10.5, 951), (96, 2000, 5.2, 952), (300, 9000, 10.5, 953)])
+def test_deterministic_flag_is_bit_reproducible(ncam, npts, cpp, seed):
+    """NLLS_FLAG_DETERMINISTIC: the reduced system is assembled from per-supernode slabs by an ordered gather (no atomics) and
+    solved by block cyclic reduction (no atomics either): x against the oracle, and bit-identical from one solve to the next."""
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, cpp / ncam, seed=seed, robust=N.HuberKernel(0.01), outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    info = check_problem(p, flags=_capi.FLAG_DETERMINISTIC, expect_sparse=1, expect_schur=1)
+    assert info.solve_mode == 2
+    ctx = _capi.Context(); bi = np.arange(1, p.nvariables + 1, dtype=np.uint64)
+    ctx.upload(p.var_kind, p.var_dim, bi, p.groups(), _capi.FLAG_DETERMINISTIC)
+    ctx.set_variables(p.variables); ctx.sweep_gradhess(); ctx.damp(1e-4 * ctx.max_abs_diag())
+    x0 = ctx.solve(want_x=True).copy()
+    for _ in range(5):
+        assert np.array_equal(ctx.solve(want_x=True), x0)
+    ctx.close()
 
 
 @pytest.mark.parametrize("seed", list(range(700, 706)))

@@ -28,10 +28,11 @@ int main() {
     double* out; long long* cyc; hipMalloc(&out, 1024 * 8); hipMalloc(&cyc, 128);
     long long h[16];
     auto run = [&](auto kern, int nacc, int mask, const char* what) {
-        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(1), dim3(512), 0, 0, out, cyc, 1.0, mask);
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(1), dim3(1024), 0, 0, out, cyc, 1.0, mask);
         hipMemcpy(h, cyc, 128, hipMemcpyDeviceToHost);
         int w0 = 0; while (!((mask >> w0) & 1)) ++w0;
-        printf("%-50s %7.1f cycles per MFMA (wave %d)\n", what, (double)h[w0] / (16.0 * 8 * nacc), w0);
+        long long mx = 0; int nw = 0; for (int w = 0; w < 16; ++w) if ((mask >> w) & 1) { mx = h[w] > mx ? h[w] : mx; ++nw; }
+        printf("%-50s %7.1f cycles per MFMA (wave %d), slowest wave %7.1f, %d waves -> %.1f MFMA-cycles per CU-cycle\n", what, (double)h[w0] / (16.0 * 8 * nacc), w0, (double)mx / (16.0 * 8 * nacc), nw, nw * 64.0 / ((double)mx / (16.0 * 8 * nacc)));
     };
     run(k<1>, 1, 1, "1 accumulator (dependent), 1 wave");
     run(k<2>, 2, 1, "2 accumulators, 1 wave");
@@ -41,5 +42,9 @@ int main() {
     run(k<4>, 4, 0x03, "4 accumulators, waves 0 and 1 (different SIMDs?)");
     run(k<4>, 4, 0xff, "4 accumulators, all 8 waves");
     run(k<1>, 1, 0x11, "1 accumulator, waves 0 and 4");
+    run(k<4>, 4, 0x111, "4 accumulators, waves 0, 4, 8");
+    run(k<4>, 4, 0x1111, "4 accumulators, waves 0, 4, 8, 12");
+    run(k<4>, 4, 0xffff, "4 accumulators, all 16 waves");
+    run(k<1>, 1, 0xffff, "1 accumulator, all 16 waves");
     return 0;
 }
