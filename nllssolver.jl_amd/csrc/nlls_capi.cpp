@@ -9,7 +9,9 @@ namespace {
 int fail(nlls_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
 int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(what) + ": " + hipGetErrorString(e); return NLLS_ERR_HIP; }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return herr(ctx, e_, #expr); } while (0)
-#define NEED_READY() do { if (!ctx) return NLLS_ERR_INVALID_ARG; if (!ctx->ready) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_upload_structure has not succeeded"); } while (0)
+// (every entry point launches on ctx->stream: make the context's device current first -- two contexts on different devices in one
+// process, or a caller that changed the current device, must not end up on a foreign stream)
+#define NEED_READY() do { if (!ctx) return NLLS_ERR_INVALID_ARG; if (!ctx->ready) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_upload_structure has not succeeded"); (void)hipSetDevice(ctx->device); } while (0)
 #define NEED_GRAD() do { NEED_READY(); if (!ctx->have_grad) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_sweep_gradhess has not been run"); } while (0)
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != NLLS_OK) return rc_; } while (0)
 
@@ -92,10 +94,16 @@ int nlls_upload_structure(nlls_ctx* ctx, int64_t nvar, const int32_t* var_kind, 
                           int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
     if (!ctx || nvar < 0 || ngroups < 0 || (nvar && (!var_kind || !var_dim || !blockindices)) || (ngroups && !groups)) return NLLS_ERR_INVALID_ARG;
     try {
+        (void)hipSetDevice(ctx->device);
+        ctx->err_sub = NLLS_SUB_NONE;
         int rc = build_structure(ctx, nvar, var_kind, var_dim, blockindices, ngroups, groups, flags);
         // an eliminated block with more neighbours than the Schur kernels stage in LDS: solve the full system instead of failing
-        if (rc == NLLS_ERR_UNSUPPORTED && !(flags & NLLS_FLAG_NO_SCHUR) && ctx->err.find("NLLS_FLAG_NO_SCHUR") != std::string::npos)
+        // (decided on the sub-code the structure builder left, not on the error text; the retry declines by itself -- dense size
+        // guard in build_schur -- when the full system is too large to factor densely)
+        if (rc == NLLS_ERR_UNSUPPORTED && !(flags & NLLS_FLAG_NO_SCHUR) && ctx->err_sub == NLLS_SUB_SCHUR_SHAPE) {
+            ctx->err_sub = NLLS_SUB_NONE;
             rc = build_structure(ctx, nvar, var_kind, var_dim, blockindices, ngroups, groups, flags | NLLS_FLAG_NO_SCHUR);
+        }
         return rc;
     }
     catch (const std::exception& e) { return fail(ctx, NLLS_ERR_HIP, std::string("host exception: ") + e.what()); }

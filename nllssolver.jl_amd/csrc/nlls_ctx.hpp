@@ -85,6 +85,7 @@ struct SchurNbr {            // one off-diagonal block touching an eliminated bl
     uint16_t trans;          // 0: stored as (elim x nbr) [dv x du]; 1: stored as (nbr x elim) [du x dv]
 };
 constexpr int SOLVE_SMALL = 0, SOLVE_DENSE = 1, SOLVE_BAND = 2;
+constexpr int NLLS_SUB_NONE = 0, NLLS_SUB_SCHUR_SHAPE = 1;     // SCHUR_SHAPE: the Schur kernels cannot stage this structure -- the full system may still be solvable
 struct SchurCopy {           // a reduced-reduced block copied from A.data into S
     int64_t off; uint32_t r, c; uint16_t rows, cols;
 };
@@ -115,6 +116,7 @@ struct nlls_ctx {
     hipStream_t stream2 = nullptr;           // side stream: heavy-row tiles run beside the light-row tiles
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
+    int err_sub = 0;                         // why the last nlls_upload_structure declined (NLLS_SUB_*): control flow never reads the error text
     int rank = 0, nranks = 1;
 
     // ---- structure ------------------------------------------------------------------------------

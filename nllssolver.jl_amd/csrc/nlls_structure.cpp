@@ -494,10 +494,10 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         const size_t nd = c->max_nbr_dof, dv = c->max_elim_dim;
         size_t base = sizeof(double) * (dv * dv + dv * nd + dv * (nd + 1)) + 16 * nd + 12 * nd + 16;
         size_t accb = sizeof(double) * (nd * (nd + 1) / 2 + nd);
-        if (base > 60 * 1024) return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated block with too many neighbours for the LDS-staged Schur kernel (retry with NLLS_FLAG_NO_SCHUR)");
+        if (base > 60 * 1024) { c->err_sub = NLLS_SUB_SCHUR_SHAPE; return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated block with too many neighbours for the LDS-staged Schur kernel (retry with NLLS_FLAG_NO_SCHUR)"); }
         c->elim_use_acc = (base + accb <= 64 * 1024);
         c->elim_lds = base + (c->elim_use_acc ? accb : 0);
-        if (!c->elim_use_acc && c->n_slow_groups > 0) return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated blocks with too many neighbour dof for the LDS accumulators (retry with NLLS_FLAG_NO_SCHUR)");
+        if (!c->elim_use_acc && c->n_slow_groups > 0) { c->err_sub = NLLS_SUB_SCHUR_SHAPE; return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated blocks with too many neighbour dof for the LDS accumulators (retry with NLLS_FLAG_NO_SCHUR)"); }
         if (hipSuccess != c->d_elim_ptr.upload(eptr) || hipSuccess != c->d_elim_nbr.upload(enbr) || hipSuccess != c->d_elim_diag.upload(ediag) ||
             hipSuccess != c->d_elim_boff.upload(eboff) || hipSuccess != c->d_elim_dim.upload(edim) || hipSuccess != c->d_elim_group.upload(egroup)) return fail(c, NLLS_ERR_HIP, "schur upload");
     }
@@ -635,6 +635,8 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         }
     } else {
         const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
+        // a dense reduced system is npad^2 doubles: decline what cannot reasonably be factored densely (the shim then keeps the CPU system)
+        if (npad > 46000) return fail(c, NLLS_ERR_UNSUPPORTED, "reduced system too large for the dense solver (" + std::to_string(n) + " dof, not banded)");
         c->s_elems = (size_t)std::max<int64_t>(npad * npad, 1);
         if (hipSuccess != c->S.alloc(c->s_elems + (size_t)npad + 64) ||
             hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 64 + npad, 1)) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");

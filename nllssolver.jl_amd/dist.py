@@ -36,11 +36,13 @@ class ShardedLS(MultiVariateLSgpu):
         self._pre_upload = (rank, world)
         super().__init__(problem, unfixed, flags, device)
         self._tstream = None
+        self.device = int(device)
+        assert not (world > 1 and dist is None), "ShardedLS with world > 1 needs an initialised torch.distributed"
         if self.sharded and not host_staged:
             # RCCL mode: the library works on a torch stream, and the collectives are issued under that stream -- kernels and
             # all-reduces are then ordered by the stream itself and no device-wide synchronisation is needed between them
             import torch
-            self._tstream = torch.cuda.Stream()
+            self._tstream = torch.cuda.Stream(device=self.device)
             self.ctx.set_stream(self._tstream.cuda_stream)
         sh = self.ctx.shard_info()
         self.local_nobs, self.local_nnz_data, self.local_ndof_written = sh["local_ncost"], sh["local_nnz_data"], sh["local_ndof"]
@@ -60,12 +62,12 @@ class ShardedLS(MultiVariateLSgpu):
             return
         if self.host_staged:       # gloo on host copies: lets two ranks share one GPU in tests
             torch.cuda.synchronize()                   # the local phase was only enqueued (on the library's own stream)
-            t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+            t = torch.as_tensor(_DevArray(ptr, n), device=f"cuda:{self.device}")
             h = t.cpu(); self.dist.all_reduce(h); t.copy_(h)
             torch.cuda.synchronize()
         else:
             with torch.cuda.stream(self._tstream):
-                self.dist.all_reduce(torch.as_tensor(_DevArray(ptr, n), device="cuda"))
+                self.dist.all_reduce(torch.as_tensor(_DevArray(ptr, n), device=f"cuda:{self.device}"))
 
     def _allreduce_scalars(self, values, op="sum"):
         import torch
@@ -74,7 +76,7 @@ class ShardedLS(MultiVariateLSgpu):
             t = torch.tensor(list(values), dtype=torch.float64); self.dist.all_reduce(t, op=op)
         else:
             with torch.cuda.stream(self._tstream):
-                t = torch.tensor(list(values), dtype=torch.float64).cuda(non_blocking=True); self.dist.all_reduce(t, op=op); t = t.cpu()
+                t = torch.tensor(list(values), dtype=torch.float64).cuda(self.device, non_blocking=True); self.dist.all_reduce(t, op=op); t = t.cpu()
         return [float(v) for v in t]
 
     def costgradhess(self, want_cost=True):
@@ -155,7 +157,7 @@ class ShardedLS(MultiVariateLSgpu):
             self.dist.all_reduce(t)
             return t.numpy()
         with torch.cuda.stream(self._tstream):
-            t = t.cuda(); self.dist.all_reduce(t); t = t.cpu()
+            t = t.cuda(self.device); self.dist.all_reduce(t); t = t.cpu()
         return t.numpy()
 
 

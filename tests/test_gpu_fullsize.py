@@ -53,3 +53,31 @@ def test_config5_full_size_so3_adaptive_against_oracle():
     p = synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(500, 50000, 0.02, seed=1, adaptive=True), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
     assert info.nreduced_dof == 6 * 500 + 3 and info.nborder_dof == 3
+
+
+def test_config5_full_size_lm_iterations_against_oracle():
+    """BASELINE config 5 at full size through ten Levenberg-Marquardt iterations on the device and in the oracle (same start,
+    same options): best cost rtol 1e-8.  (The oracle needs about a second per iteration at this size.)"""
+    from tests.helpers import oracle_problem
+    mk = lambda: synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(500, 50000, 0.02, seed=1, adaptive=True), 1e-3, 1e-3)
+    p = mk(); op = oracle_problem(mk())
+    # (the costs of this problem are negative log-likelihoods: 'dcost < bestcost * reldcost', src/optimize.jl:152, needs reldcost > 0 to stay off)
+    ores = op.optimize(maxiters=10, reldcost=1e300, absdcost=-1e300, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
+    res = N.optimize(p, N.NLLSOptions(maxiters=10, reldcost=1e300, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6))
+    assert res.niterations == ores.niterations == 10
+    assert res.bestcost < res.startcost - 1e3
+    assert np.isclose(res.bestcost, ores.bestcost, rtol=1e-8), (res.bestcost, ores.bestcost)
+
+
+@pytest.mark.parametrize("ncam,npts,prop", [(12, 300, 0.5), (120, 6000, 0.08)])
+def test_so3_noise_free_optimum(ncam, npts, prop):
+    """The SO(3) / pinhole kinds on a noise-free problem (analogue of test/optimizeba.jl:62-75): from a perturbed start both the
+    device and the oracle drive the cost below 1e-15 per residual block, and cost(problem) == result.bestcost bit for bit."""
+    from tests.helpers import oracle_problem
+    mk = lambda: synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(ncam, npts, prop, seed=7, adaptive=False, noise=0.0, outlier_frac=0.0), 1e-3, 1e-3)
+    p = mk(); op = oracle_problem(mk())
+    ores = op.optimize(maxiters=40)
+    res = N.optimize(p, N.NLLSOptions(maxiters=40))
+    assert ores.bestcost < 1e-15 * p.ncosts(), ores.bestcost
+    assert res.bestcost < 1e-15 * p.ncosts(), res.bestcost
+    assert N.cost(p) == res.bestcost

@@ -275,3 +275,57 @@ def test_adaptive_contaminated_gaussian():
     assert np.allclose(contaminated_gaussian_params(v[:3]), [1.0, 10.0, 0.8], rtol=0.1)   # :44
     assert np.isclose(v[3], -1.0, rtol=0.1) and np.isclose(v[4], 1.0, rtol=0.1)           # :45-46
     assert res.bestcost <= res.startcost
+
+
+# ---------------------------------------------------------------- new kinds (no reference counterpart): finite differences
+def _fd_block(op, problem, gi, ci, h=1e-6):
+    """Central differences of one cost block through the TRUE retraction (oracle_var_update: R exp([d]x) for the SO(3) pose,
+    src/autodiff.jl:57-61 semantics: derivative of the residual / cost with respect to the tangent step at 0)."""
+    g = list(problem.costs.values())[gi]
+    vi, _ = g.arrays()
+    kind, dim, off = problem.var_kind, problem.var_dim, problem.var_offsets
+    base = problem.variables.copy()
+    nres = K.res_nres(g.res_kind)
+    cols_r, cols_c = [], []
+    for v in vi[ci] - 1:
+        ns, nd = K.var_storage(kind[v], dim[v]), K.var_dof(kind[v], dim[v])
+        for k in range(nd):
+            vals = []
+            for sgn in (+1.0, -1.0):
+                step = np.zeros(nd); step[k] = sgn * h
+                out = np.zeros(ns)
+                L.oracle_var_update(int(kind[v]), int(dim[v]), P(np.ascontiguousarray(base[off[v]:off[v] + ns])), P(step), P(out))
+                x = base.copy(); x[off[v]:off[v] + ns] = out
+                op.set_variables(x)
+                r, _ = op.block_resjac(gi, ci, nres)
+                c, _, _ = op.block_costgradhess(gi, ci)
+                vals.append((r, c))
+            cols_r.append((vals[0][0] - vals[1][0]) / (2 * h)); cols_c.append((vals[0][1] - vals[1][1]) / (2 * h))
+    op.set_variables(base)
+    return np.stack(cols_r, axis=1), np.array(cols_c)
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_so3_kinds_against_finite_differences(adaptive):
+    """NLLS_VAR_POSE_SO3 / NLLS_RES_BA_SO3(_ADAPTIVE): the oracle's Jacobian (duals seeded through R (I + [d]x)) against central
+    differences through the true retraction R exp([d]x), rtol 1e-6; and the block gradient -- kernel-variable border included
+    (src/residual.jl:79-88) -- against differences of the block cost."""
+    robust = None if adaptive else N.HuberKernel(0.05)
+    p = synthetic.create_so3_ba_problem(6, 40, 0.6, seed=5, adaptive=adaptive, robust=robust, noise=5e-3, outlier_frac=0.2)
+    p = synthetic.perturb_ba_problem(p, 1e-2, 1e-2)
+    op = oracle_problem(p)
+    g = list(p.costs.values())[0]
+    nres = K.res_nres(g.res_kind)
+    rng = np.random.default_rng(3)
+    for ci in rng.choice(len(g), size=12, replace=False):
+        r, J = op.block_resjac(0, int(ci), nres)
+        c, grad, H = op.block_costgradhess(0, int(ci))
+        Jfd, gfd = _fd_block(op, p, 0, int(ci))
+        if adaptive:        # the residual does not depend on the kernel variable: its Jacobian covers the camera and the point
+            assert J.shape[1] == 9 and np.allclose(Jfd[:, :3], 0.0, atol=1e-9)
+            Jfd = Jfd[:, 3:]
+        assert np.allclose(J, Jfd, rtol=1e-6, atol=1e-7), (ci, np.abs(J - Jfd).max())
+        if adaptive:        # the reference returns 0.5 c as the block's cost but d c / d kernel (not halved) as the kernel part of its
+            gfd[:3] *= 2.0  # gradient (src/residual.jl:65,87,105-110): the oracle restates exactly that
+        assert np.allclose(grad, gfd, rtol=1e-5, atol=1e-8 * max(1.0, abs(c))), (ci, np.abs(grad - gfd).max())
+        assert np.allclose(H, H.T, rtol=1e-12, atol=1e-14)
