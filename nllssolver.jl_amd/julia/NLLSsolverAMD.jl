@@ -1,10 +1,12 @@
 # NLLSsolverAMD.jl -- the reference-side binding of libnlls_amd.so (include/nlls_amd.h).
 #
-# NOT TESTED IN THIS REPOSITORY: no Julia toolchain exists in the build image (SURVEY.md F6).  It is the
-# `ccall` shim a maintainer of NLLSsolver.jl would add; the Python mirror in nllssolver.jl_amd/ exercises the
-# same C entry points in the test-suite.  Nothing in the reference tree is modified: the shim only adds a new
-# linear-system type and method overloads of the generic functions the iterators already call
-# (src/iterators.jl:139-172, src/optimize.jl:109-180).
+# NOT EXECUTED IN THIS REPOSITORY: no Julia toolchain exists in the build image (SURVEY.md F6).  It is the
+# `ccall` shim a maintainer of NLLSsolver.jl would add.  What it assumes about the library is pinned without Julia:
+# tests/abi/abi_replay.c (plain C, built and run by tests/test_abi_replay.py) static_asserts the two struct layouts
+# mirrored below (CostGroup, NllsInfo), resolves every symbol named in a ccall here, and replays on the GPU the exact
+# call sequence and argument types of the device-resident Levenberg-Marquardt loop at the bottom of this file.
+# Nothing in the reference tree is modified: the shim adds a linear-system type and method overloads of the generic
+# functions the optimizer already calls (src/iterators.jl:139-172, src/optimize.jl:109-180,207-214).
 module NLLSsolverAMD
 
 import NLLSsolver
@@ -25,6 +27,12 @@ struct CostGroup              # nlls_cost_group
     ncost::Int64
     varind::Ptr{Int64}
     data::Ptr{Float64}
+end
+
+struct NllsInfo               # nlls_info (112 bytes: offsets pinned by tests/abi/abi_replay.c)
+    is_sparse::Int32; has_schur::Int32
+    nvar::Int64; nblocks::Int64; ndof::Int64; nnz_data::Int64; nblocks_stored::Int64; ncost::Int64; var_storage::Int64
+    nschur_blocks::Int64; nreduced_dof::Int64; owner_path::Int64; solve_mode::Int64; bandwidth::Int64; nborder_dof::Int64
 end
 
 check(ctx, rc) = rc == 0 ? nothing : error("nlls_amd error $rc: " * unsafe_string(ccall((:nlls_last_error, lib), Cstring, (Ptr{Cvoid},), ctx)))
@@ -63,6 +71,7 @@ mutable struct MultiVariateLSgpu
     b::Vector{Float64}
     kinds::Vector{Tuple{Int32, Int32}}
     packed::Vector{Float64}
+    resident::Bool              # the device's NLLS_VARS_CURRENT holds problem.variables (the device-resident LM loop keeps it so)
 end
 
 "makesymmvls replacement (src/linearsystem.jl:91-124); returns `nothing` to decline (caller keeps the CPU system)."
@@ -90,10 +99,10 @@ function makesymmvls_gpu(problem::NLLSProblem, unfixed, nblocks)
         (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{UInt64}, Int32, Ptr{CostGroup}, Int32),
         ctx, length(kinds), vk, vd, blockindices, length(groups), groups, 0)
     if rc != 0; ccall((:nlls_ctx_destroy, lib), Cint, (Ptr{Cvoid},), ctx); return nothing; end   # NLLS_ERR_UNSUPPORTED: decline
-    info = zeros(Int64, 16); ccall((:nlls_get_info, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), ctx, info)
-    ndof = Int(info[4])          # nlls_info: 2 x int32, then nvar, nblocks, ndof, ...
+    info = Ref{NllsInfo}(); check(ctx, ccall((:nlls_get_info, lib), Cint, (Ptr{Cvoid}, Ptr{NllsInfo}), ctx, info))
+    ndof = Int(info[].ndof)
     boff = zeros(Int64, nb); ccall((:nlls_get_bsm_index, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), ctx, C_NULL, C_NULL, C_NULL, boff)
-    ls = MultiVariateLSgpu(ctx, blockindices, UInt.(boff), ndof, zeros(ndof), zeros(ndof), kinds, Float64[])
+    ls = MultiVariateLSgpu(ctx, blockindices, UInt.(boff), ndof, zeros(ndof), zeros(ndof), kinds, Float64[], false)
     finalizer(l -> ccall((:nlls_ctx_destroy, lib), Cint, (Ptr{Cvoid},), l.ctx), ls)
     return ls
 end
@@ -106,13 +115,17 @@ end
 # ---- generic functions the iterators call (SURVEY.md 8b) ------------------------------------------------
 NLLSsolver.zero!(::MultiVariateLSgpu) = nothing                                # fused into the sweep
 function NLLSsolver.costgradhess!(ls::MultiVariateLSgpu, vars::Vector, costs)   # src/optimize.jl:118,167-170
-    setvariables!(ls, vars, 0); c = Ref(0.0)
+    ls.resident || setvariables!(ls, vars, 0); c = Ref(0.0)
     check(ls.ctx, ccall((:nlls_sweep_gradhess, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, c)); return c[]
 end
-function gpucost(ls::MultiVariateLSgpu, vars::Vector)                           # src/cost.jl:10-13
+function gpucost(ls::MultiVariateLSgpu, vars::Vector)                           # src/cost.jl:10-13, for host-side iterators (dogleg, ...)
     setvariables!(ls, vars, 1); c = Ref(0.0)
     check(ls.ctx, ccall((:nlls_sweep_cost, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ls.ctx, 1, c)); return c[]
 end
+# The reference's iterators call cost(problem.varnext, problem.costs) (src/iterators.jl:24,100,157,191,203), which does not
+# see the linear system.  Host-side iterators reach the device sweep through this wrapper of the cost container:
+struct GpuCosts{C}; costs::C; ls::MultiVariateLSgpu; end
+NLLSsolver.cost(vars::Vector, c::GpuCosts) = gpucost(c.ls, vars)
 struct GpuHessian; ls::MultiVariateLSgpu; end                                  # what gethessgrad hands to the iterator
 function NLLSsolver.gethessgrad(ls::MultiVariateLSgpu)                          # src/linearsystem.jl:190
     check(ls.ctx, ccall((:nlls_get_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, ls.b)); return GpuHessian(ls), ls.b
@@ -132,5 +145,110 @@ end
 # update!(to, from, linsystem) keeps the reference's host implementation (src/linearsystem.jl:206-213): it only
 # needs blockindices / boffsets / x, which this type carries, so arbitrary user `update` methods keep working.
 NLLSsolver.getoffsets(block, ls::MultiVariateLSgpu) = @inbounds(ls.blockindices[NLLSsolver.varindices(block)])
+
+# ---- Levenberg-Marquardt with the variables resident on the device ------------------------------------------------
+# optimizeinternal! (src/optimize.jl:109-180) and iterate!(::LevMarData) (src/iterators.jl:139-172) for the GPU linear system,
+# statement for statement, with
+#   update!(varnext, variables, linsystem) + cost(varnext, costs)  ->  ONE nlls_lm_trial (damp, solve, retract, cost sweep)
+#   updatefromnext! / updatefrombest! / updatetobest!              ->  nlls_swap_variables / nlls_copy_variables (pointer swaps)
+#   zero! + costgradhess!                                          ->  nlls_sweep_gradhess(ctx, NULL): enqueue only
+# No variable crosses PCIe inside the loop; problem.variables is fetched once at the end (and before a user callback).
+# tests/abi/abi_replay.c replays exactly this sequence, with these argument types, against the library on the GPU.
+const VARS_CURRENT, VARS_NEXT, VARS_BEST = Int32(0), Int32(1), Int32(2)
+
+function fetchvariables!(problem::NLLSProblem, ls::MultiVariateLSgpu, which::Int32 = VARS_CURRENT)
+    resize!(ls.packed, sum(k -> ccall((:nlls_var_storage, lib), Cint, (Int32, Int32), k[1], k[2]), ls.kinds))
+    check(ls.ctx, ccall((:nlls_get_variables, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ls.ctx, which, ls.packed))
+    o = 0
+    for (i, v) in enumerate(problem.variables)                   # unpack!: the inverse of pack! for the registered kinds
+        problem.variables[i], o = unpack(v, ls.packed, o)
+    end
+end
+unpack(::Number, p, o) = (p[o+1], o + 1)
+unpack(::EuclideanVector{N, T}, p, o) where {N, T} = (EuclideanVector{N, T}(ntuple(k -> p[o+k], N)), o + N)
+unpack(::ZeroToInfScalar{T}, p, o) where T = (ZeroToInfScalar{T}(p[o+1]), o + 1)
+unpack(::ZeroToOneScalar{T}, p, o) where T = (ZeroToOneScalar{T}(p[o+1]), o + 1)
+unpack(::ContaminatedGaussian{T}, p, o) where T = (ContaminatedGaussian(ZeroToInfScalar{T}(p[o+1]), ZeroToInfScalar{T}(p[o+2]), ZeroToOneScalar{T}(p[o+3])), o + 3)
+
+function lm_trial!(ls::MultiVariateLSgpu, dlambda::Float64)      # src/iterators.jl:149-157 in one call, one synchronisation
+    c = Ref(0.0)
+    check(ls.ctx, ccall((:nlls_lm_trial, lib), Cint, (Ptr{Cvoid}, Float64, Int32, Int32, Ptr{Float64}), ls.ctx, dlambda, VARS_NEXT, VARS_CURRENT, c))
+    return c[]
+end
+function stepmaxabs(ls::MultiVariateLSgpu)                       # maximum(abs, linsystem.x), src/optimize.jl:149
+    m = Ref(0.0); check(ls.ctx, ccall((:nlls_step_maxabs, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, m)); return m[]
+end
+
+function NLLSsolver.iterate!(levmardata::NLLSsolver.LevMarData, data::NLLSInternal{MultiVariateLSgpu}, problem::NLLSProblem, options::NLLSOptions)::Float64
+    ls = data.linsystem
+    @assert levmardata.lambda >= 0.
+    if levmardata.lambda == 0
+        levmardata.lambda = NLLSsolver.initlambda(GpuHessian(ls))
+    end
+    lastlambda = 0.; mu = 2.
+    while true
+        data.timesolver += NLLSsolver.@elapsed_ns cost_ = lm_trial!(ls, levmardata.lambda - lastlambda)
+        lastlambda = levmardata.lambda
+        data.linearsolvers += 1; data.costcomputations += 1
+        if !(cost_ > data.bestcost) || stepmaxabs(ls) < options.dstep
+            NLLSsolver.uniformscaling!(GpuHessian(ls), -lastlambda)
+            q = Ref(0.0); g = Ref(0.0)
+            check(ls.ctx, ccall((:nlls_quadform, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ls.ctx, q, g))
+            stepquality = (cost_ - data.bestcost) / (0.5 * q[] + g[])
+            levmardata.lambda *= stepquality < 0.983 ? 1 - (2 * stepquality - 1) ^ 3 : 0.1
+            return cost_
+        end
+        levmardata.lambda *= mu; mu *= 2.
+    end
+end
+
+swapvars!(ls, a, b) = check(ls.ctx, ccall((:nlls_swap_variables, lib), Cint, (Ptr{Cvoid}, Int32, Int32), ls.ctx, a, b))
+copyvars!(ls, dst, src) = check(ls.ctx, ccall((:nlls_copy_variables, lib), Cint, (Ptr{Cvoid}, Int32, Int32), ls.ctx, dst, src))
+NLLSsolver.updatefromnext!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = swapvars!(data.linsystem, VARS_CURRENT, VARS_NEXT)   # src/optimize.jl:207-209
+NLLSsolver.updatefrombest!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = swapvars!(data.linsystem, VARS_CURRENT, VARS_BEST)   # src/optimize.jl:211-213
+NLLSsolver.updatetobest!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = copyvars!(data.linsystem, VARS_BEST, VARS_CURRENT)     # src/optimize.jl:138-142 (deepcopy)
+
+function NLLSsolver.optimizeinternal!(problem::NLLSProblem, options::NLLSOptions, data::NLLSInternal{MultiVariateLSgpu}, iteratedata::NLLSsolver.LevMarData, callback)
+    ls = data.linsystem
+    data.startcost = NLLSsolver.preoptimization(iteratedata, problem, options, data)::Float64
+    fails = 0; data.iternum = 0
+    stoptime = data.starttime + options.maxtime
+    data.timeinit += Base.time_ns() - data.starttime
+    setvariables!(ls, problem.variables, VARS_CURRENT); copyvars!(ls, VARS_NEXT, VARS_CURRENT); ls.resident = true
+    data.timegradient += NLLSsolver.@elapsed_ns cost = NLLSsolver.costgradhess!(ls, problem.variables, problem.costs)
+    data.gradientcomputations += 1
+    data.bestcost = cost; data.startcost = max(cost, data.startcost)
+    while true
+        data.iternum += 1
+        cost = NLLSsolver.iterate!(iteratedata, data, problem, options)::Float64
+        if callback !== NLLSsolver.nullcallback                      # a user callback reads problem.varnext / linsystem.x on the host
+            fetchvariables!(problem, ls, VARS_NEXT); check(ls.ctx, ccall((:nlls_get_step, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, ls.x))
+        end
+        cost, terminate = callback(cost, problem, data, iteratedata)::Tuple{Float64, Int}
+        dcost = data.bestcost - cost
+        if dcost >= 0
+            data.bestcost = cost; fails = 0
+        else
+            dcost = cost; fails += 1
+            fails == 1 && NLLSsolver.updatetobest!(problem, data)
+        end
+        NLLSsolver.updatefromnext!(problem, data)
+        maxstep = stepmaxabs(ls)
+        converged = 0
+        converged |= isinf(cost) << 0; converged |= isnan(cost) << 1
+        converged |= (dcost < data.bestcost * options.reldcost) << 2; converged |= (dcost < options.absdcost) << 3
+        converged |= isinf(maxstep) << 4; converged |= isnan(maxstep) << 5; converged |= (maxstep < options.dstep) << 6
+        converged |= (fails > options.maxfails) << 7; converged |= (data.iternum >= options.maxiters) << 8
+        converged |= (Base.time_ns() > stoptime) << 9; converged |= terminate << 16
+        data.converged = converged
+        converged != 0 && break
+        data.timegradient += NLLSsolver.@elapsed_ns check(ls.ctx, ccall((:nlls_sweep_gradhess, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, C_NULL))
+        data.gradientcomputations += 1
+    end
+    !(data.bestcost >= cost) && NLLSsolver.updatefrombest!(problem, data)
+    fetchvariables!(problem, ls, VARS_CURRENT); ls.resident = false
+    data.timetotal += Base.time_ns() - data.starttime
+    return data
+end
 
 end # module

@@ -1,0 +1,137 @@
+/* abi_replay.c -- pins, from OUTSIDE Python, what the Julia shim (nllssolver.jl_amd/julia/NLLSsolverAMD.jl) assumes about
+ * libnlls_amd.so: the struct layouts it mirrors by hand and the exact ccall sequence / argument types of its device-resident
+ * Levenberg-Marquardt loop (optimizeinternal! for NLLSInternal{MultiVariateLSgpu}, mirroring src/optimize.jl:109-180 and
+ * src/iterators.jl:139-172).  Plain C (the header must stay C-clean); the library is dlopen()ed like `ccall((:sym, lib), ...)` does.
+ *
+ *   abi_replay --layout  <libnlls_amd.so>    struct layouts + every symbol the shim calls resolves     (no GPU needed)
+ *   abi_replay --replay  <libnlls_amd.so>    the whole sequence on a small noise-free bundle adjustment (needs the GPU)
+ */
+#include <dlfcn.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/nlls_amd.h"
+
+/* ---- layouts the shim writes down by hand (struct CostGroup, struct NllsInfo in NLLSsolverAMD.jl) ---- */
+_Static_assert(sizeof(nlls_cost_group) == 64, "CostGroup: 2 x Int32, NTuple{4,Float64}, Int64, 2 pointers");
+_Static_assert(offsetof(nlls_cost_group, res_kind) == 0 && offsetof(nlls_cost_group, robust_kind) == 4, "CostGroup header");
+_Static_assert(offsetof(nlls_cost_group, robust_params) == 8 && offsetof(nlls_cost_group, ncost) == 40, "CostGroup params / ncost");
+_Static_assert(offsetof(nlls_cost_group, varind) == 48 && offsetof(nlls_cost_group, data) == 56, "CostGroup pointers");
+_Static_assert(sizeof(nlls_info) == 112, "NllsInfo: 2 x Int32 + 13 x Int64");
+_Static_assert(offsetof(nlls_info, is_sparse) == 0 && offsetof(nlls_info, has_schur) == 4 && offsetof(nlls_info, nvar) == 8, "NllsInfo head");
+_Static_assert(offsetof(nlls_info, nblocks) == 16 && offsetof(nlls_info, ndof) == 24 && offsetof(nlls_info, nnz_data) == 32, "NllsInfo ndof");
+_Static_assert(offsetof(nlls_info, var_storage) == 56 && offsetof(nlls_info, nreduced_dof) == 72 && offsetof(nlls_info, solve_mode) == 88, "NllsInfo tail");
+_Static_assert(offsetof(nlls_info, nborder_dof) == 104, "NllsInfo last field");
+
+/* ---- the entry points the shim ccalls, with the argument types it passes ---- */
+typedef int (*fn_ctx_create)(const int32_t*, int32_t, nlls_ctx**);
+typedef int (*fn_ctx_destroy)(nlls_ctx*);
+typedef const char* (*fn_last_error)(const nlls_ctx*);
+typedef int (*fn_upload)(nlls_ctx*, int64_t, const int32_t*, const int32_t*, const uint64_t*, int32_t, const nlls_cost_group*, int32_t);
+typedef int (*fn_get_info)(const nlls_ctx*, nlls_info*);
+typedef int (*fn_bsm_index)(const nlls_ctx*, int64_t*, int64_t*, int64_t*, int64_t*);
+typedef int (*fn_setget_vars)(nlls_ctx*, int32_t, double*);
+typedef int (*fn_swapcopy)(nlls_ctx*, int32_t, int32_t);
+typedef int (*fn_sweep_gradhess)(nlls_ctx*, double*);
+typedef int (*fn_sweep_cost)(nlls_ctx*, int32_t, double*);
+typedef int (*fn_out1)(nlls_ctx*, double*);
+typedef int (*fn_damp)(nlls_ctx*, double);
+typedef int (*fn_quadform)(nlls_ctx*, double*, double*);
+typedef int (*fn_lm_trial)(nlls_ctx*, double, int32_t, int32_t, double*);
+typedef int (*fn_retract)(nlls_ctx*, int32_t, int32_t);
+
+static const char* SYMS[] = {"nlls_ctx_create", "nlls_ctx_destroy", "nlls_last_error", "nlls_upload_structure", "nlls_get_info", "nlls_get_bsm_index",
+    "nlls_set_variables", "nlls_get_variables", "nlls_swap_variables", "nlls_copy_variables", "nlls_sweep_gradhess", "nlls_sweep_cost", "nlls_get_grad",
+    "nlls_max_abs_diag", "nlls_damp", "nlls_solve", "nlls_set_step", "nlls_get_step", "nlls_quadform", "nlls_step_maxabs", "nlls_retract", "nlls_lm_trial", "nlls_var_storage"};
+
+static void* need(void* lib, const char* name) { void* p = dlsym(lib, name); if (!p) { fprintf(stderr, "missing symbol %s\n", name); exit(2); } return p; }
+static uint64_t lcg_state = 88172645463325252ull;
+static double urand(void) { lcg_state ^= lcg_state << 13; lcg_state ^= lcg_state >> 7; lcg_state ^= lcg_state << 17; return (double)(lcg_state >> 11) / 9007199254740992.0; }
+static double nrand(void) { double u = urand() + 1e-300, v = urand(); return sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v); }
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s --layout|--replay <libnlls_amd.so>\n", argv[0]); return 2; }
+    void* lib = dlopen(argv[2], RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+    for (size_t i = 0; i < sizeof(SYMS) / sizeof(SYMS[0]); ++i) need(lib, SYMS[i]);
+    printf("layout ok: sizeof(nlls_cost_group)=%zu sizeof(nlls_info)=%zu offsetof(ndof)=%zu; %zu symbols resolved\n",
+           sizeof(nlls_cost_group), sizeof(nlls_info), offsetof(nlls_info, ndof), sizeof(SYMS) / sizeof(SYMS[0]));
+    if (strcmp(argv[1], "--replay") != 0) return 0;
+
+    fn_ctx_create ctx_create = (fn_ctx_create)need(lib, "nlls_ctx_create"); fn_ctx_destroy ctx_destroy = (fn_ctx_destroy)need(lib, "nlls_ctx_destroy");
+    fn_last_error last_error = (fn_last_error)need(lib, "nlls_last_error"); fn_upload upload = (fn_upload)need(lib, "nlls_upload_structure");
+    fn_get_info get_info = (fn_get_info)need(lib, "nlls_get_info"); fn_bsm_index bsm_index = (fn_bsm_index)need(lib, "nlls_get_bsm_index");
+    fn_setget_vars set_vars = (fn_setget_vars)need(lib, "nlls_set_variables"), get_vars = (fn_setget_vars)need(lib, "nlls_get_variables");
+    fn_swapcopy swap_vars = (fn_swapcopy)need(lib, "nlls_swap_variables"), copy_vars = (fn_swapcopy)need(lib, "nlls_copy_variables");
+    fn_sweep_gradhess sweep_gradhess = (fn_sweep_gradhess)need(lib, "nlls_sweep_gradhess"); fn_sweep_cost sweep_cost = (fn_sweep_cost)need(lib, "nlls_sweep_cost");
+    fn_out1 max_abs_diag = (fn_out1)need(lib, "nlls_max_abs_diag"), step_maxabs = (fn_out1)need(lib, "nlls_step_maxabs");
+    fn_damp damp = (fn_damp)need(lib, "nlls_damp"); fn_quadform quadform = (fn_quadform)need(lib, "nlls_quadform"); fn_lm_trial lm_trial = (fn_lm_trial)need(lib, "nlls_lm_trial");
+
+    /* ---- a noise-free bundle adjustment in the shape of test/optimizeba.jl:6-47: every camera sees every point ---- */
+    enum { NCAM = 6, NPT = 40, NVAR = NCAM + NPT, NOBS = NCAM * NPT };
+    static double truth[NCAM * 6 + NPT * 3], start[NCAM * 6 + NPT * 3], meas[NOBS * 2]; static int64_t varind[NOBS * 2];
+    for (int c = 0; c < NCAM; ++c) for (int k = 0; k < 6; ++k) truth[6 * c + k] = nrand() + ((k == 0 || k == 4) ? 1.0 : 0.0);
+    for (int p = 0; p < NPT; ++p) { double* X = truth + 6 * NCAM + 3 * p; X[0] = urand() - 0.5; X[1] = urand() - 0.5; X[2] = urand() + 10.0; }
+    for (int c = 0, o = 0; c < NCAM; ++c) for (int p = 0; p < NPT; ++p, ++o) {          /* camera-major, 1-based indices as stored */
+        const double* P = truth + 6 * c; const double* X = truth + 6 * NCAM + 3 * p;
+        varind[2 * o] = c + 1; varind[2 * o + 1] = NCAM + p + 1;
+        meas[2 * o] = P[0] * X[0] + P[1] * X[1] + P[2] * X[2]; meas[2 * o + 1] = P[3] * X[0] + P[4] * X[1] + P[5] * X[2];
+    }
+    for (int i = 0; i < NCAM * 6 + NPT * 3; ++i) start[i] = truth[i] + 1e-3 * nrand();
+    int32_t vk[NVAR], vd[NVAR]; uint64_t blockindices[NVAR];
+    for (int i = 0; i < NVAR; ++i) { vk[i] = NLLS_VAR_EUCLIDEAN; vd[i] = i < NCAM ? 6 : 3; blockindices[i] = (uint64_t)(i + 1); }
+    nlls_cost_group grp; memset(&grp, 0, sizeof grp);
+    grp.res_kind = NLLS_RES_BA_AFFINE; grp.robust_kind = NLLS_ROBUST_NONE; grp.ncost = NOBS; grp.varind = varind; grp.data = meas;
+
+#define CK(call) do { int rc_ = (call); if (rc_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, ctx ? last_error(ctx) : ""); return 1; } } while (0)
+    nlls_ctx* ctx = NULL;
+    CK(ctx_create(NULL, 0, &ctx));                                                   /* makesymmvls_gpu */
+    CK(upload(ctx, NVAR, vk, vd, blockindices, 1, &grp, 0));
+    nlls_info info; CK(get_info(ctx, &info));
+    int64_t boff[NVAR]; CK(bsm_index(ctx, NULL, NULL, NULL, boff));
+    if (info.ndof != NCAM * 6 + NPT * 3 || info.var_storage != info.ndof || info.ncost != NOBS || boff[0] != 1 || boff[NCAM] != 6 * NCAM + 1) { fprintf(stderr, "nlls_info / boffsets do not read as the shim expects\n"); return 1; }
+    /* ---- optimizeinternal!: src/optimize.jl:109-180 with the variables resident on the device ---- */
+    double cost = 0, bestcost, startcost;
+    CK(set_vars(ctx, NLLS_VARS_CURRENT, start)); CK(copy_vars(ctx, NLLS_VARS_NEXT, NLLS_VARS_CURRENT));
+    CK(sweep_gradhess(ctx, &cost)); bestcost = startcost = cost;
+    double lambda = 0, lastcost = cost; int fails = 0, iter = 0, converged = 0, trials = 0;
+    while (!converged) {
+        ++iter;
+        /* iterate!(::LevMarData, ...): src/iterators.jl:139-172, one nlls_lm_trial per damped solve */
+        if (lambda == 0) { double m; CK(max_abs_diag(ctx, &m)); lambda = 1e-6 * m; }
+        double lastlambda = 0, mu = 2, c_ = 0, maxstep = 0;
+        for (;;) {
+            CK(lm_trial(ctx, lambda - lastlambda, NLLS_VARS_NEXT, NLLS_VARS_CURRENT, &c_)); lastlambda = lambda; ++trials;
+            CK(step_maxabs(ctx, &maxstep));
+            if (!(c_ > bestcost) || maxstep < 1e-15) {
+                CK(damp(ctx, -lastlambda));
+                double xHx, gx; CK(quadform(ctx, &xHx, &gx));
+                const double q = (c_ - bestcost) / (0.5 * xHx + gx);
+                lambda *= q < 0.983 ? 1 - (2 * q - 1) * (2 * q - 1) * (2 * q - 1) : 0.1;
+                break;
+            }
+            lambda *= mu; mu *= 2;
+        }
+        double dcost = bestcost - c_; lastcost = c_;
+        if (dcost >= 0) { bestcost = c_; fails = 0; }
+        else { dcost = c_; if (++fails == 1) CK(copy_vars(ctx, NLLS_VARS_BEST, NLLS_VARS_CURRENT)); }      /* updatetobest! */
+        CK(swap_vars(ctx, NLLS_VARS_CURRENT, NLLS_VARS_NEXT));                                             /* updatefromnext! */
+        converged |= (isinf(c_) != 0) << 0; converged |= (isnan(c_) != 0) << 1;
+        converged |= (dcost < bestcost * 1e-15) << 2; converged |= (dcost < 1e-15) << 3; converged |= (maxstep < 1e-15) << 6;
+        converged |= (fails > 5) << 7; converged |= (iter >= 100) << 8;
+        if (converged) break;
+        CK(sweep_gradhess(ctx, NULL));                                               /* zero! + costgradhess!: enqueue only */
+    }
+    if (!(bestcost >= lastcost)) CK(swap_vars(ctx, NLLS_VARS_CURRENT, NLLS_VARS_BEST));                       /* updatefrombest!, src/optimize.jl:171-174 */
+    static double final[NCAM * 6 + NPT * 3];
+    CK(get_vars(ctx, NLLS_VARS_CURRENT, final));
+    double check = 0; CK(sweep_cost(ctx, NLLS_VARS_CURRENT, &check));
+    printf("replay: start %.6e -> best %.6e in %d iterations (%d LM trials), termination flags %d, cost(variables) %.6e\n", startcost, bestcost, iter, trials, converged, check);
+    CK(ctx_destroy(ctx));
+    if (!(bestcost < 1e-15 * NOBS) || !(check < 1e-15 * NOBS)) { fprintf(stderr, "did not reach the zero-residual optimum (test/optimizeba.jl:62-75)\n"); return 1; }
+    return 0;
+}
