@@ -25,12 +25,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix = fp64 vector peak: one v_mfma_f64_16x16x4_f64 (2048 flop) per 64 cycles per SIMD
+                               # (tools/microbench/mfma_rate.hip), 1024 SIMDs, 2.4 GHz
+
+
+def sweep_code_hash():
+    """Hash of the sources the accumulate kernel is built from: profiles/pmc_traffic.json carries the hash of the build whose
+    counters it holds, and a stale file is refused (roofline.traffic = null) instead of being quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("nlls_sweep.hip", "nlls_kinds.hpp", "nlls_structure.cpp"):
+        h.update(open(os.path.join(ROOT, "nllssolver.jl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 CONFIGS = {
     # name: (ncameras, npoints, propvisible)            BASELINE.json configs[2], configs[3]
     "ba_100x10k": (100, 10_000, 0.1),
     "ba_1kx100k": (1000, 100_000, 0.01),
     "ba_10kx1M": (10_000, 1_000_000, 0.001),            # 10x config 4 (not in BASELINE.json): 10M residual blocks, A.data 1.5 GB
+    "curvefit_10k": None,                               # BASELINE.json configs[1]: 10k scalar residuals over 4 scalar variables (dense path)
+    "ba_so3_500x50k": (500, 50_000, 0.02),              # BASELINE.json configs[4]: SO(3) cameras + adaptive kernel variable
 }
 
 
@@ -45,6 +59,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ba_1kx100k", choices=sorted(CONFIGS))
+    ap.add_argument("--solver", default="default", choices=["default", "dense", "chain", "deterministic"],
+                    help="reduced-system solver: block cyclic reduction of the band (default), the dense MFMA LDL' (NLLS_FLAG_NO_BAND), "
+                         "the round-1 twisted chain kernels (NLLS_FLAG_NO_BCR), or the atomics-free assembly (NLLS_FLAG_DETERMINISTIC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
@@ -79,14 +96,26 @@ def main():
     from nllssolver_jl_amd._capi import VARS_CURRENT, VARS_NEXT
     from nllssolver_jl_amd.dist import ShardedLS
 
-    ncam, npts, prop = CONFIGS[args.workload]
-    problem = synthetic.create_ba_problem(ncam, npts, prop, seed=1, robust=N.HuberKernel(0.01),
-                                          outlier_frac=0.05, outlier_sigma=0.05)
-    problem = synthetic.perturb_ba_problem(problem, 1e-3, 1e-3)
+    from nllssolver_jl_amd import _capi
+    if args.workload == "curvefit_10k":
+        ncam, npts = 0, 0
+        problem, _ = synthetic.create_curvefit_problem(10_000, seed=1)
+        workload_desc = {"residuals": "a exp(b t) + c t + d - y, 10k scalar residuals over four scalar variables (BlockDenseMatrix path)"}
+    elif args.workload == "ba_so3_500x50k":
+        ncam, npts, prop = CONFIGS[args.workload]
+        problem = synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(ncam, npts, prop, seed=1, adaptive=True), 1e-3, 1e-3)
+        workload_desc = {"robust": "ContaminatedGaussian adaptive kernel (variable #1)", "outliers": "10% of measurements + N(0,0.1^2), seed 1", "cameras": "SO(3) poses, pinhole"}
+    else:
+        ncam, npts, prop = CONFIGS[args.workload]
+        problem = synthetic.create_ba_problem(ncam, npts, prop, seed=1, robust=N.HuberKernel(0.01),
+                                              outlier_frac=0.05, outlier_sigma=0.05)
+        problem = synthetic.perturb_ba_problem(problem, 1e-3, 1e-3)
+        workload_desc = {"robust": "Huber(0.01)", "outliers": "5% of measurements + N(0,0.05^2), seed 1"}
     nobs = problem.ncosts()
     start_vars = problem.variables.copy()
+    flags = {"default": 0, "dense": _capi.FLAG_NO_BAND, "chain": _capi.FLAG_NO_BCR, "deterministic": _capi.FLAG_DETERMINISTIC}[args.solver]
 
-    ls = ShardedLS(problem, np.ones(problem.nvariables, bool), device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged, force_collectives=force_dist)
+    ls = ShardedLS(problem, np.ones(problem.nvariables, bool), flags=flags, device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged, force_collectives=force_dist)
     info = ls.info
     # never terminate early inside the timed region: exactly K outer iterations
     options = N.NLLSOptions(maxiters=10 ** 9, reldcost=-np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
@@ -108,6 +137,7 @@ def main():
     for _ in range(args.warmup):
         loop.iteration()
     loop = fresh_loop()                     # same start point for the timed region
+    ls.ctx.profile_sweep(True)              # event pairs around the accumulate launches of the timed loop itself (in-situ figure)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -118,6 +148,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_staged else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
     data = loop.data
     final_cost, start_cost = data.bestcost, data.startcost
+    insitu = ls.ctx.profile_sweep(False, read=True)       # (avg, min, max ms, samples) of the accumulate launches inside the timed loop
 
     # ---- roofline of the accumulate sweep (dominant HBM-bound kernels), timed with HIP events on the library's stream
     reps = 20
@@ -125,22 +156,61 @@ def main():
     sweep_cost_ms = ls.ctx.time_sweep_gradhess(reps)          # ... plus the reduction of the cost partials
     cost_ms = ls.ctx.time_sweep_cost(reps)
     ls.ctx.damp(1e-3 * ls.ctx.max_abs_diag())
-    solve_ms = ls.ctx.time_solve(3)
+    solve_ms = ls.ctx.time_solve(5)
+    reduced_ms = ls.ctx.time_reduced_solve(5) if world == 1 else 0.0
     solve_stats = ls.ctx.solve_stats()
     alg_bytes = algorithmic_bytes_per_sweep(ls.local_nobs, info.var_storage, ls.local_nnz_data, ls.local_ndof_written)
+    if world == 1:      # per cost group: measurement + variable indices of every block (any residual kind)
+        from nllssolver_jl_amd import kinds as K
+        alg_bytes = sum(len(g) * 8 * (K.res_ndata(g.res_kind) + K.res_ndeps(g.res_kind)) for g in problem.costs.values()) \
+            + 8 * info.var_storage + 8 * (ls.local_nnz_data + ls.local_ndof_written)
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # filled from a separate rocprofv3 --pmc pass
     if os.path.exists(tpath) and world == 1:     # the counters were collected on the unsharded sweep
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_sweep")
+            rec = json.load(open(tpath)).get(args.workload, {})
+            if rec.get("sweep_code_hash") == sweep_code_hash():
+                traffic = rec.get("hbm_bytes_per_sweep")
+            elif rec:
+                traffic_note = "profiles/pmc_traffic.json was collected on a different build of the sweep sources: refused (re-run tools/measure_round.sh)"
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "gh_fused_kernel<BA_AFFINE, point rows (light tiles), camera rows (heavy tiles)>: the accumulate launch of one gradient sweep",
-                "algorithmic_bytes_per_launch": int(alg_bytes), "ms_per_launch": round(sweep_ms, 4), "ms_with_cost_reduction": round(sweep_cost_ms, 4),
+    # the figure quoted as `frac` is the IN-SITU one when the loop recorded enough launches: the average over the accumulate launches of
+    # the timed LM loop itself (what rocprofv3 sees), not the back-to-back best case
+    insitu_ms = insitu[0] if insitu and insitu[3] >= 3 else None
+    quoted_ms = insitu_ms if insitu_ms else sweep_ms
+    achieved_q = alg_bytes / (quoted_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved_q, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved_q / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "the accumulate launch(es) of one gradient sweep (BA: gh_fused_kernel, point rows as light tiles + camera rows as heavy tiles)",
+                "algorithmic_bytes_per_launch": int(alg_bytes), "ms_per_launch": round(quoted_ms, 4),
+                "timing": "in situ: execution span of the launch (first workgroup start .. last workgroup end, stamped by the kernel on the 100 MHz constant clock) averaged over the launches of the timed LM loop itself -- what a kernel trace reports" if insitu_ms else "back to back (nlls_time_sweep_accumulate)",
+                "in_situ": None if not insitu_ms else {"avg_ms": round(insitu[0], 4), "min_ms": round(insitu[1], 4), "max_ms": round(insitu[2], 4), "launches": int(insitu[3])},
+                "back_to_back": {"ms_per_launch": round(sweep_ms, 4), "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4)},
+                "ms_with_cost_reduction": round(sweep_cost_ms, 4),
                 "cost_sweep_ms": round(cost_ms, 4), "solve_ms": round(solve_ms, 4), "solve_stats": solve_stats}
+    if traffic_note:
+        roofline["traffic_note"] = traffic_note
+    # ---- roofline of the reduced solve (north_star: MFMA utilisation on the reduced solve against chip peak)
+    roofline_solve = None
+    if world == 1 and info.nreduced_dof > 0 and reduced_ms > 0:
+        n, bw, mode = int(info.nreduced_dof), int(info.bandwidth), int(info.solve_mode)
+        useful = float(n) * bw * bw if mode == 2 else float(n) ** 3 / 3.0
+        issued = 2048.0 * solve_stats.get("bcr_mfma_issued", 0) if mode == 2 and solve_stats.get("bcr_mfma_issued", 0) else None
+        roofline_solve = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
+                          "kernel": {2: "block cyclic reduction of the bordered band (bcr_panel / bcr_update / bcr_backward kernels)" if solve_stats.get("bcr_levels") else "twisted blocked band LDL' (chain kernels)",
+                                     1: "dense blocked LDL' (MFMA trailing update)", 0: "one-wave dense solve"}[mode],
+                          "reduced_dof": n, "bandwidth": bw, "us": round(1e3 * reduced_ms, 1),
+                          "useful_flops": useful, "useful_flops_formula": "n * bw^2" if mode == 2 else "n^3 / 3",
+                          "issued_mfma_flops": issued,
+                          "achieved": round((issued if issued else useful) / (reduced_ms * 1e-3) / 1e12, 4),
+                          "useful_achieved": round(useful / (reduced_ms * 1e-3) / 1e12, 4),
+                          "frac": round((issued if issued else useful) / (reduced_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5),
+                          "useful_frac": round(useful / (reduced_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5),
+                          "levels": solve_stats.get("bcr_levels"), "launches": solve_stats.get("bcr_launches"),
+                          "note": "a banded LDL' is a chain of dependent pivots: latency-, not MFMA-bound -- the fraction says how far, not how well tuned"
+                                  if mode == 2 else None}
 
     # ---- CPU baseline: the oracle's own optimize! loop on a bounded sample of the same workload (rank 0, N = 1)
     cpu = None
@@ -160,12 +230,11 @@ def main():
     if rank == 0:
         out = {
             "metric": "LM iterations/s on synthetic BA (1k cams x 100k pts x ~1M obs)" if args.workload == "ba_1kx100k"
-                      else f"LM iterations/s on synthetic BA ({args.workload})",
+                      else f"LM iterations/s on {args.workload}",
             "value": round(args.steps / elapsed, 3), "unit": "LM iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "ncameras": ncam, "npoints": npts, "nobs": nobs, "robust": "Huber(0.01)",
-                       "outliers": "5% of measurements + N(0,0.05^2), seed 1", "ndof": int(info.ndof),
+            "config": {"workload": args.workload, "ncameras": ncam, "npoints": npts, "nobs": nobs, **workload_desc, "solver": args.solver, "ndof": int(info.ndof),
                        "reduced_dof": int(info.nreduced_dof), "sharding": ("none" if not force_dist else "none (one rank through the sharded route: NLLS_BENCH_FORCE_DIST)") if world == 1 else f"by point over {world} ranks"},
             "residual_blocks_per_s": round(nobs * args.steps / elapsed, 1),
             "sweep_residual_blocks_per_s": round(ls.local_nobs * world / (sweep_ms * 1e-3), 1),
@@ -175,7 +244,7 @@ def main():
                    # optimiser's noise floor (from about the 12th iteration of this problem) that happens often, so the rate
                    # of LM trials (damped solve + retraction + cost sweep) is the figure that does not depend on --steps
                    "lm_trials_per_s": round(data.linearsolvers / elapsed, 1)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_solve": roofline_solve, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     ls.close()

@@ -190,7 +190,9 @@ int  nlls_damp(nlls_ctx* ctx, double delta);
  * Solves (H + lambda I) y = b and stores x = -y on the device; x_out (length ndof) may be NULL. */
 int  nlls_solve(nlls_ctx* ctx, double* x_out);
 /* diagnostics of the last solve: [0] factorisation status (0 ok), [1] band factor shader cycles,
- * [2] band backward-pass cycles, [3] solve mode, [4] number of elimination supernodes, [5] bandwidth */
+ * [2] band backward-pass cycles, [3] solve mode, [4] number of elimination supernodes, [5] bandwidth,
+ * [6] v_mfma_f64_16x16x4_f64 instructions one reduced solve issues (block cyclic reduction; 2048 flop each), [7] its launches,
+ * [8] its levels, [9] banded dof of the reduced system */
 int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
 int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
 int  nlls_get_step(nlls_ctx* ctx, double* x_out);
@@ -258,6 +260,10 @@ int  nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg);
 int  nlls_time_sweep_accumulate(nlls_ctx* ctx, int32_t reps, float* ms_avg);   /* the accumulate launches alone (what nlls_sweep_gradhess(ctx, NULL) enqueues) */
 int  nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg);
 int  nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);
+/* in-situ timing of the accumulate launches: on != 0 starts recording an event pair around every nlls_sweep_gradhess's accumulate
+ * launch(es) inside the caller's own loop (last 64 kept); a call with any output pointer set synchronises and reports them. */
+int  nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples);
+int  nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);  /* factorisation + backward pass of the (already assembled) reduced system alone */
 
 #ifdef __cplusplus
 }

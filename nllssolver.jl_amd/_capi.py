@@ -23,7 +23,7 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep""".split()
 
 
 class NllsError(RuntimeError):
@@ -95,7 +95,8 @@ def lib():
         L.nlls_get_step_shard.argtypes = [vp, vp, vp, vp, vp]
         L.nlls_get_shard_info.argtypes = [vp, vp, i32]
         L.nlls_time_sweep_gradhess.argtypes = [vp, i32, vp]; L.nlls_time_sweep_cost.argtypes = [vp, i32, vp]; L.nlls_time_sweep_accumulate.argtypes = [vp, i32, vp]
-        L.nlls_time_solve.argtypes = [vp, i32, vp]
+        L.nlls_time_solve.argtypes = [vp, i32, vp]; L.nlls_time_reduced_solve.argtypes = [vp, i32, vp]
+        L.nlls_profile_sweep.argtypes = [vp, i32, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -236,9 +237,10 @@ class Context:
         return iters
 
     def solve_stats(self):
-        out = np.zeros(6, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 6))
+        out = np.zeros(10, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 10))
         return dict(status=int(out[0]), band_factor_cycles=int(out[1]), band_backward_cycles=int(out[2]), solve_mode=int(out[3]),
-                    elim_supernodes=int(out[4]), bandwidth=int(out[5]))
+                    elim_supernodes=int(out[4]), bandwidth=int(out[5]), bcr_mfma_issued=int(out[6]), bcr_launches=int(out[7]), bcr_levels=int(out[8]),
+                    band_dof=int(out[9]))
 
     def set_step(self, x):
         x = np.ascontiguousarray(x, np.float64); assert x.size == self.info.ndof
@@ -302,6 +304,17 @@ class Context:
 
     def time_sweep_cost(self, reps=10):
         ms = C.c_float(); self._chk(self.L.nlls_time_sweep_cost(self.h, reps, C.byref(ms))); return ms.value
+
+    def profile_sweep(self, on=True, read=False):
+        """In-situ timing of the accumulate launches (event pairs inside the caller's loop): read=True -> (avg, min, max ms, samples)."""
+        if not read:
+            self._chk(self.L.nlls_profile_sweep(self.h, 1 if on else 0, None, None, None, None)); return None
+        a, mn, mx, n = C.c_float(), C.c_float(), C.c_float(), C.c_int64()
+        self._chk(self.L.nlls_profile_sweep(self.h, 1 if on else 0, C.byref(a), C.byref(mn), C.byref(mx), C.byref(n)))
+        return a.value, mn.value, mx.value, n.value
+
+    def time_reduced_solve(self, reps=3):
+        ms = C.c_float(); self._chk(self.L.nlls_time_reduced_solve(self.h, reps, C.byref(ms))); return ms.value
 
     def time_solve(self, reps=3):
         ms = C.c_float(); self._chk(self.L.nlls_time_solve(self.h, reps, C.byref(ms))); return ms.value

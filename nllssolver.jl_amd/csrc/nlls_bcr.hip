@@ -606,6 +606,25 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     panel_lds = sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS);
     back_lds = sizeof(double) * ((size_t)RXT * 16 + NT * 64 + 2 * NT * 16 + (size_t)NO * 256 + 256 + 16);
     launches = 1; for (auto& lv : levels) launches += 2 + (lv.nupd > 0);
+    {   // matrix-core instructions per solve (2048 flop each): panel kernel per workgroup + update kernel per job
+        mfma_issued = 0;
+        for (size_t e = 0; e < elims.size(); ++e) {
+            const BcrElim& el = elims[e];
+            for (int ch = 0; ch < bcr_nchunks(NT); ++ch) {
+                int RX = 0; for (int s2 = 0; s2 < BCR_CH; ++s2) { const int Rg = BCR_CH * ch + s2; if (Rg <= 2 * NT && (Rg < NT ? el.l >= 0 : (Rg < 2 * NT ? el.r >= 0 : true))) ++RX; }
+                if (!RX) continue;
+                int64_t m = 0;
+                for (int J = 0; J < NT; ++J) {
+                    m += 30;                                                   // diagonal tile: 15 pivots x (tile + inverse)
+                    if (J + 1 < NT) m += 8;                                    // W_1' and the next diagonal tile's update
+                    m += 4 * ((J + 1 < NT ? NT - J - 2 : 0) + RX);             // panel tiles
+                    const int mm = NT - 1 - J; if (mm > 0) m += 4 * (mm * (mm + 1) / 2 - 1 + RX * mm);   // tile-updates
+                }
+                mfma_issued += m;
+            }
+        }
+        for (const BcrUpd& u : upds) mfma_issued += u.mode == 3 ? 4 : 4 * (int64_t)NT * u.nc;
+    }
     ready = true;
     return NLLS_OK;
 }

@@ -33,6 +33,7 @@ struct BcrSolver {
     BcrGeom geom{};
     size_t panel_lds = 0, back_lds = 0;
     int launches = 0;
+    int64_t mfma_issued = 0;                      // v_mfma_f64_16x16x4_f64 instructions one solve issues (all workgroups, redundant factorisations included)
 
     static bool supports(int64_t n_band, int bw, int nbd);
     int build(int64_t n_band, int bw, int nbd, int H, std::string* err);

@@ -53,6 +53,7 @@ int nlls_ctx_destroy(nlls_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     hipStream_t s = ctx->own_stream ? ctx->stream : nullptr;
@@ -285,8 +286,9 @@ int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
     int32_t status[16] = {0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    const int64_t vals[6] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw};
-    for (int i = 0; i < n && i < 6; ++i) out[i] = vals[i];
+    const int64_t vals[10] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
+                              ctx->bcr.ready ? ctx->bcr.mfma_issued : 0, ctx->bcr.ready ? ctx->bcr.launches : 0, ctx->bcr.ready ? (int64_t)ctx->bcr.levels.size() : 0, ctx->n_band};
+    for (int i = 0; i < n && i < 10; ++i) out[i] = vals[i];
     return NLLS_OK;
 }
 int nlls_set_step(nlls_ctx* ctx, const double* x) {
@@ -415,6 +417,49 @@ int nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
 }
 int nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
     NEED_GRAD(); return time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_solve(c); });
+}
+int nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples) {
+    if (!ctx) return NLLS_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ms_avg || ms_min || ms_max || nsamples) {            // read what has been recorded so far (synchronises the stream)
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const int64_t cap = (int64_t)ctx->prof_ev.size() / 2, n = std::min(ctx->prof_count, cap);
+        double sum = 0; float mn = 1e30f, mx = 0.f;
+        for (int64_t i = 0; i < n; ++i) { float ms = 0.f; if (hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) != hipSuccess) continue; sum += ms; mn = std::min(mn, ms); mx = std::max(mx, ms); }
+        // where the fused accumulate kernel stamped itself (first workgroup start .. last workgroup end), that span is the figure:
+        // it is what a kernel trace reports for the launch; the event pairs also hold the dispatch latency in front of it
+        const int64_t nk = std::min<int64_t>(ctx->prof_kcount, PROF_SLOTS);
+        if (nk > 0 && ctx->prof_clk.p) {
+            std::vector<unsigned long long> h(2 * (size_t)PROF_MAXWG);
+            sum = 0; mn = 1e30f; mx = 0.f; int64_t ok = 0;
+            int khz = 100000; (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device); if (khz <= 0) khz = 100000;
+            const double ms_per_tick = 1.0 / (double)khz;
+            for (int64_t i = 0; i < nk; ++i) {
+                const unsigned nwg = ctx->prof_nwg[i]; if (!nwg) continue;
+                HIPCHK(hipMemcpy(h.data(), ctx->prof_clk.p + (size_t)i * 2 * PROF_MAXWG, sizeof(unsigned long long) * 2 * (size_t)nwg, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, t1 = 0; for (unsigned w = 0; w < nwg; ++w) { t0 = std::min(t0, h[w]); t1 = std::max(t1, h[nwg + w]); }
+                if (t1 <= t0) continue;
+                const float ms = (float)((double)(t1 - t0) * ms_per_tick); sum += ms; mn = std::min(mn, ms); mx = std::max(mx, ms); ++ok;
+            }
+            if (ms_avg) *ms_avg = ok ? (float)(sum / ok) : 0.f; if (ms_min) *ms_min = ok ? mn : 0.f; if (ms_max) *ms_max = mx; if (nsamples) *nsamples = ok;
+        } else {
+            if (ms_avg) *ms_avg = n ? (float)(sum / n) : 0.f; if (ms_min) *ms_min = n ? mn : 0.f; if (ms_max) *ms_max = mx; if (nsamples) *nsamples = n;
+        }
+    }
+    if (on && !ctx->prof_clk.p) { if (ctx->prof_clk.alloc((size_t)PROF_SLOTS * 2 * PROF_MAXWG) != hipSuccess) return NLLS_ERR_HIP; }
+    if (on) ctx->prof_kcount = 0;
+    if (on && ctx->prof_ev.empty()) { ctx->prof_ev.resize(128); for (auto& e : ctx->prof_ev) if (hipEventCreate(&e) != hipSuccess) return NLLS_ERR_HIP; }
+    ctx->prof_sweep = on != 0; if (on) ctx->prof_count = 0;
+    return NLLS_OK;
+}
+int nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+    NEED_GRAD();
+    if (ctx->nred == 0 || ctx->elim_slab) { if (ms_avg) *ms_avg = 0.f; return NLLS_OK; }   // (slab + gather assembly: the tiles are consumed in place)
+    // assemble [S | s] once, then time the factorisation + backward pass of the reduced system alone (it reads S, never writes it)
+    TRY(enqueue_solve_local(ctx));
+    const int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_reduced_solve(c); });
+    ctx->S_zeroed = false; ctx->solved = false;
+    return rc;
 }
 
 }  // extern "C"

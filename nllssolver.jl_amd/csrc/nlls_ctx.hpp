@@ -85,6 +85,7 @@ struct SchurNbr {            // one off-diagonal block touching an eliminated bl
     uint16_t trans;          // 0: stored as (elim x nbr) [dv x du]; 1: stored as (nbr x elim) [du x dv]
 };
 constexpr int SOLVE_SMALL = 0, SOLVE_DENSE = 1, SOLVE_BAND = 2;
+constexpr unsigned PROF_SLOTS = 16, PROF_MAXWG = 16384;
 constexpr int NLLS_SUB_NONE = 0, NLLS_SUB_SCHUR_SHAPE = 1;     // SCHUR_SHAPE: the Schur kernels cannot stage this structure -- the full system may still be solvable
 struct SchurCopy {           // a reduced-reduced block copied from A.data into S
     int64_t off; uint32_t r, c; uint16_t rows, cols;
@@ -115,6 +116,9 @@ struct nlls_ctx {
     bool own_stream = false;
     hipStream_t stream2 = nullptr;           // side stream: heavy-row tiles run beside the light-row tiles
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // in-situ profile of the accumulate launches (nlls_profile_sweep): event pairs recorded around them inside the caller's own loop
+    bool prof_sweep = false; std::vector<hipEvent_t> prof_ev; int64_t prof_count = 0;
+    nlls::DevBuf<unsigned long long> prof_clk; int64_t prof_kcount = 0; unsigned prof_nwg[16] = {0};   // [PROF_SLOTS][2][PROF_MAXWG] start / end stamp of every workgroup (100 MHz constant clock) of the fused accumulate launch
     std::string err;
     int err_sub = 0;                         // why the last nlls_upload_structure declined (NLLS_SUB_*): control flow never reads the error text
     int rank = 0, nranks = 1;

@@ -2103,8 +2103,8 @@ int enqueue_solve_local(nlls_ctx* c) {
     return NLLS_OK;
 }
 
-// finish: factor the (summed) reduced system, solve it, back-substitute this rank's eliminated blocks
-int enqueue_solve_finish(nlls_ctx* c) {
+// the reduced system itself: factorisation + both substitutions; its solution lands in s (c->s_ptr())
+int enqueue_reduced_solve(nlls_ctx* c) {
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
     const SLayout L = make_layout(c); const int npad = L.npad, nblk = npad / NB;
     const bool band = c->solve_mode == SOLVE_BAND;
@@ -2194,6 +2194,14 @@ int enqueue_solve_finish(nlls_ctx* c) {
             hipLaunchKernelGGL(bwd_diag_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, npad, kb, n, acc, c->s_ptr());
         }
     }
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+// finish: factor the (summed) reduced system, solve it, back-substitute this rank's eliminated blocks
+int enqueue_solve_finish(nlls_ctx* c) {
+    const int n = (int)c->nred; if (n == 0) return NLLS_OK;
+    { const int rc = enqueue_reduced_solve(c); if (rc != NLLS_OK) return rc; }
     // x = -solution (folded into the fast back-substitution launch when there is one)
     const int write_red = (c->nranks == 1 || c->rank == 0) ? 1 : 0;
     if (c->n_fast_groups == 0) hipLaunchKernelGGL(scatter_reduced_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->s_ptr(), c->d_red_boff.p, n, c->x.p, write_red);

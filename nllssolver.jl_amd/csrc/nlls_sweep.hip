@@ -438,12 +438,16 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // bound with almost no HBM traffic, the light ones are bound by the A.data stream -- side by side they overlap instead
 // of running back to back.
 template <int KIND, int LSLOT, int HSLOT>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void gh_fused_kernel(GhArgs gl, GhArgs gh, uint32_t heavy_img, uint32_t nhw) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void gh_fused_kernel(GhArgs gl, GhArgs gh, uint32_t heavy_img, uint32_t nhw, unsigned long long* prof) {
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    // in-situ profile (nlls_profile_sweep; prof == nullptr otherwise): first workgroup start / last workgroup end on the 100 MHz
+    // constant clock -- the launch's execution span as a kernel trace reports it, taken inside the caller's own loop
+    if (prof && threadIdx.x == 0) prof[blockIdx.x] = (unsigned long long)wall_clock64();     // (one slot per workgroup: no contention)
     // the heavy workgroups come first: their lifetime is the longest.  (Spreading them through the grid, or alternating
     // them with light ones at the front, measured slower: 114 and 57 us against 49.)
     if (blockIdx.x < nhw) gh_heavy_body<KIND, HSLOT, 2>(gh, blockIdx.x, heavy_img, dyn_lds);
     else gh_light_body<KIND, LSLOT>(gl, blockIdx.x - nhw, dyn_lds);
+    if (prof && threadIdx.x == 0) prof[gridDim.x + blockIdx.x] = (unsigned long long)wall_clock64();
 }
 
 // ================================================================================================
@@ -773,8 +777,13 @@ static bool launch_gh_fused(nlls_ctx* c, const Group& G, const double* vars, int
         if (lds > ((size_t)EL.light_lds + 2) * sizeof(double) + 4096) return false;    // the heavy role must not cost the light one occupancy
         const unsigned nhw = (unsigned)((EH.nheavy + HROWS - 1) / HROWS);
         const GhArgs gl = gh_args<KIND>(c, G, EL, vars, false, c->partials.p + pbase), gh = gh_args<KIND>(c, G, EH, vars, true, c->partials.p + pbase + EL.nlight);
-        if (ls == 0) hipLaunchKernelGGL((gh_fused_kernel<KIND, 0, 1>), dim3(nhw + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw);
-        else         hipLaunchKernelGGL((gh_fused_kernel<KIND, 1, 0>), dim3(nhw + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw);
+        unsigned long long* prof = nullptr;
+        if (c->prof_sweep && c->prof_clk.p) {                   // (profiling only: two 8-byte fills in front of the launch)
+            const unsigned nwg = nhw + (unsigned)EL.nlight;
+            if (nwg <= PROF_MAXWG) { const size_t slot = (size_t)(c->prof_kcount % PROF_SLOTS); prof = c->prof_clk.p + slot * 2 * PROF_MAXWG; c->prof_nwg[slot] = nwg; ++c->prof_kcount; }
+        }
+        if (ls == 0) hipLaunchKernelGGL((gh_fused_kernel<KIND, 0, 1>), dim3(nhw + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw, prof);
+        else         hipLaunchKernelGGL((gh_fused_kernel<KIND, 1, 0>), dim3(nhw + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw, prof);
         pbase += EL.nlight + EH.nheavy;
         return true;
     }
@@ -820,6 +829,9 @@ int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost) {
     } else if (c->nzero > 0) {
         hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)c->nzero), dim3(64), 0, c->stream, c->A.p, c->d_zero_off.p, c->d_zero_len.p, c->b.p, c->d_zero_b_off.p, c->d_zero_b_len.p);
     }
+    const bool prof = c->prof_sweep && !c->prof_ev.empty();
+    const size_t pslot = prof ? (size_t)(c->prof_count % (int64_t)(c->prof_ev.size() / 2)) : 0;
+    if (prof) (void)hipEventRecord(c->prof_ev[2 * pslot], c->stream);
     for (const Group& G : c->groups) {
         switch (G.res_kind) {
 #define X(K) case K: launch_gh<K>(c, G, vars, pbase); break;
@@ -827,6 +839,7 @@ int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost) {
 #undef X
         }
     }
+    if (prof) { (void)hipEventRecord(c->prof_ev[2 * pslot + 1], c->stream); ++c->prof_count; }
     if (!c->info.is_sparse && c->info.ndof > 0) {
         const int64_t n2 = c->info.ndof * c->info.ndof;
         hipLaunchKernelGGL(symmetrize_dense_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->A.p, (int)c->info.ndof);
