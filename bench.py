@@ -118,7 +118,8 @@ def main():
     ls = ShardedLS(problem, np.ones(problem.nvariables, bool), flags=flags, device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged, force_collectives=force_dist)
     info = ls.info
     # never terminate early inside the timed region: exactly K outer iterations
-    options = N.NLLSOptions(maxiters=10 ** 9, reldcost=-np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
+    # (the adaptive-kernel costs are negative log-likelihoods: 'dcost < bestcost * reldcost', src/optimize.jl:152, then needs reldcost = +inf to stay off)
+    options = N.NLLSOptions(maxiters=10 ** 9, reldcost=np.inf if args.workload == "ba_so3_500x50k" else -np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
 
     def fresh_loop():
         ls.ctx.set_variables(start_vars, VARS_CURRENT)

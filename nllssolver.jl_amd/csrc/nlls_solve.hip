@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
             int q = t - p * (p + 1) / 2;
             for (; t < npairs; t += 64) {
                 double a2 = 0; for (int a = 0; a < dv; ++a) a2 += E[a + dv * p] * Y[a + dv * q];
-                if (use_acc) acc[t] += a2; else atomicAdd(L.at(rc[p], rc[q]), -a2);
+                if (use_acc) acc[t] += a2; else atomicAdd(L.at(rc[p] > rc[q] ? rc[p] : rc[q], rc[p] > rc[q] ? rc[q] : rc[p]), -a2);
                 q += 64; while (q > p) { q -= p + 1; ++p; }
             }
         }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
         while (p * (p + 1) / 2 > t) --p;
         while ((p + 1) * (p + 2) / 2 <= t) ++p;
         int q = t - p * (p + 1) / 2;
-        for (; t < npairs; t += 64) { atomicAdd(L.at(rc[p], rc[q]), -acc[t]); q += 64; while (q > p) { q -= p + 1; ++p; } }
+        for (; t < npairs; t += 64) { atomicAdd(L.at(rc[p] > rc[q] ? rc[p] : rc[q], rc[p] > rc[q] ? rc[q] : rc[p]), -acc[t]); q += 64; while (q > p) { q -= p + 1; ++p; } }
         for (int p2 = lane; p2 < nd; p2 += 64) atomicAdd(L.rhs(s, rc[p2]), -acc[npairs + p2]);
     }
 }
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const d
     __syncthreads();
     const int wv = tid >> 6, ln = tid & 63;
     for (int q = wv; q < nd; q += NT / 64)
-        for (int p = q + ln; p < nd; p += 64) atomicAdd(L.at(rc[p], rc[q]), -img[colstart(q) + p]);
+        for (int p = q + ln; p < nd; p += 64) atomicAdd(L.at(rc[p] > rc[q] ? rc[p] : rc[q], rc[p] > rc[q] ? rc[q] : rc[p]), -img[colstart(q) + p]);
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 

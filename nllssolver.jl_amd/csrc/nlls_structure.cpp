@@ -438,7 +438,12 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 nl.push_back(SchurNbr{c->it_nzval[q], (uint32_t)red_of[u], (uint16_t)c->blocksizes[u], 0}); }
             for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) { int64_t w = trow[q]; if (w == v) continue;
                 nl.push_back(SchurNbr{c->it_nzval[tq[q]], (uint32_t)red_of[w], (uint16_t)c->blocksizes[w], 1}); }
-            std::sort(nl.begin(), nl.end(), [](const SchurNbr& a, const SchurNbr& b) { return a.rcol < b.rcol; });
+            // column order of [E_v]: the order the blocks lie in memory when the whole row is stored with the member (the fast kernels
+            // step through it with a constant stride; a border block -- ordered LAST in the reduced system -- may come FIRST here, so
+            // nothing downstream may assume ascending reduced columns: every S(i, j) is addressed as (max, min)); else by reduced column
+            { bool anytrans = false; for (auto& n : nl) anytrans |= n.trans != 0;
+              if (!anytrans) std::sort(nl.begin(), nl.end(), [](const SchurNbr& a, const SchurNbr& b) { return a.off < b.off; });
+              else std::sort(nl.begin(), nl.end(), [](const SchurNbr& a, const SchurNbr& b) { return a.rcol < b.rcol; }); }
             int nd = 0; int64_t lo = -1, hi = -1;
             for (auto& n : nl) { nd += n.dim; if ((int64_t)n.rcol < c->n_band) { if (lo < 0) lo = n.rcol; hi = n.rcol + n.dim - 1; } }
             if (lo >= 0) bw = std::max(bw, hi - lo);
@@ -582,6 +587,8 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 const uint32_t v0 = egroup[gi], v1 = egroup[gi + 1];
                 std::vector<SchurNbr> nl(enbr.begin() + eptr[v0], enbr.begin() + eptr[v0 + 1]);
                 if (nl.size() > 16) { ok = false; break; }
+                for (size_t a = 1; a < nl.size(); ++a) if (nl[a].rcol < nl[a - 1].rcol) ok = false;      // (the gather addresses blocks as (row >= column) in list order)
+                if (!ok) break;
                 if (v1 - v0 <= SMALL_SUPERNODE) {
                     for (uint32_t v = v0; v < v1; ++v) {
                         const SchurNbr* nv = enbr.data() + eptr[v];
