@@ -67,7 +67,11 @@ typedef struct nlls_ctx nlls_ctx;
                                        vars (POSE_SO3, EUCL3); data = meas[2]                                  */
 #define NLLS_RES_BA_SO3_ADAPTIVE  8 /* NEW: as 7 with the robust kernel as variable #1 (src/residual.jl:46-47);
                                        vars (CONT_GAUSS, POSE_SO3, EUCL3); data = meas[2]                      */
-#define NLLS_RES_KIND_COUNT       9
+#define NLLS_RES_LINEAR3          9 /* LinearResidualStatic: X*w - y; vars (EUCL3); data = (y[3], X[9] column-major)   test/nonsquaredcost.jl:4-14 */
+#define NLLS_COST_LINEAR3        10 /* NON-SQUARED AbstractCost (src/autodiff.jl:144-159): computecost = y'w, vars (EUCL3); data = y[3].  The block adds
+                                       its value (not half a squared norm) to the cost, its gradient and Hessian -- by second-order duals through update() --
+                                       to the linear system; robust_kind is ignored.                              test/nonsquaredcost.jl:28-37 */
+#define NLLS_RES_KIND_COUNT      11
 
 /* ---- robust kernels: src/robust.jl:7-77 ------------------------------------------------------ */
 #define NLLS_ROBUST_NONE           0 /* NoRobust                                               */

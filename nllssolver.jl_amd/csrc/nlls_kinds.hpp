@@ -117,6 +117,48 @@ NLLS_DEV Dual2 d2log(const Dual2& a) { double i = 1.0 / a.v; return d2chain(a, l
 NLLS_DEV Dual2 d2recip(const Dual2& a) { double i = 1.0 / a.v; return d2chain(a, i, -i * i, 2.0 * i * i * i); }
 
 // ------------------------------------------------------------------------------------------------
+// second-order duals over N variables: non-squared AbstractCost blocks, computehessian  src/autodiff.jl:123-128,144-159
+// ------------------------------------------------------------------------------------------------
+template <int N> struct Dual2N { double v, g[N], h[N][N]; };
+template <int N> NLLS_DEV Dual2N<N> d2nconst(double v) { Dual2N<N> r; r.v = v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r.g[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) r.h[i][j] = 0.0; } return r; }
+template <int N> NLLS_DEV Dual2N<N> operator+(const Dual2N<N>& a, const Dual2N<N>& b) { Dual2N<N> r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r.g[i] = a.g[i] + b.g[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) r.h[i][j] = a.h[i][j] + b.h[i][j]; } return r; }
+template <int N> NLLS_DEV Dual2N<N> operator-(const Dual2N<N>& a, const Dual2N<N>& b) { Dual2N<N> r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r.g[i] = a.g[i] - b.g[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) r.h[i][j] = a.h[i][j] - b.h[i][j]; } return r; }
+template <int N> NLLS_DEV Dual2N<N> operator*(const Dual2N<N>& a, const Dual2N<N>& b) { Dual2N<N> r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r.g[i] = a.g[i] * b.v + a.v * b.g[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) r.h[i][j] = a.h[i][j] * b.v + a.g[i] * b.g[j] + a.g[j] * b.g[i] + a.v * b.h[i][j]; } return r; }
+template <int N> NLLS_DEV Dual2N<N> operator*(const Dual2N<N>& a, double s) { Dual2N<N> r; r.v = a.v * s;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r.g[i] = a.g[i] * s;
+#pragma unroll
+        for (int j = 0; j < N; ++j) r.h[i][j] = a.h[i][j] * s; } return r; }
+template <int N> NLLS_DEV Dual2N<N> operator*(double s, const Dual2N<N>& a) { return a * s; }
+template <int N> NLLS_DEV Dual2N<N> operator-(const Dual2N<N>& a, double c) { Dual2N<N> r = a; r.v = a.v - c; return r; }
+template <int N> NLLS_DEV Dual2N<N> operator+(const Dual2N<N>& a, double c) { Dual2N<N> r = a; r.v = a.v + c; return r; }
+template <int N> struct Lift<Dual2N<N>> {     // (seeding through a LINEAR retraction only: cost kinds take Euclidean variables)
+    static NLLS_DEV Dual2N<N> c(double v) { return d2nconst<N>(v); }
+    static NLLS_DEV Dual2N<N> seed(double v, int k) { Dual2N<N> r = d2nconst<N>(v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) if (i == k) r.g[i] = 1.0; return r; }
+    static NLLS_DEV Dual2N<N> seedw(double v, int k, double w) { Dual2N<N> r = d2nconst<N>(v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) if (i == k) r.g[i] = w; return r; }
+};
+
+// ------------------------------------------------------------------------------------------------
 // variable kinds
 // ------------------------------------------------------------------------------------------------
 NLLS_HD constexpr int var_storage(int kind, int dim) {
@@ -275,6 +317,27 @@ template <> struct Res<NLLS_RES_BA_SO3_ADAPTIVE> {   // new kind
     template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) { pinhole(data, sv[0], sv[1], r); }
 };
 
+template <> struct Res<NLLS_RES_LINEAR3> {   // test/nonsquaredcost.jl:4-14: X w - y, data = (y[3], X[9] column-major)
+    static constexpr int NDEPS = 1, M = 3, NDATA = 12, ADAPT = 0;
+    static constexpr int SK[4] = {NLLS_VAR_EUCLIDEAN, 0, 0, 0};
+    static constexpr int SD[4] = {3, 0, 0, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) {
+        const T* w = sv[0];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r[i] = w[0] * data[3 + i] + w[1] * data[6 + i] + w[2] * data[9 + i] - data[i];
+    }
+};
+template <> struct Res<NLLS_COST_LINEAR3> {   // test/nonsquaredcost.jl:28-37: a NON-SQUARED cost, computecost = y'w (r[0] carries the cost's value)
+    static constexpr int NDEPS = 1, M = 1, NDATA = 3, ADAPT = 0;
+    static constexpr int SK[4] = {NLLS_VAR_EUCLIDEAN, 0, 0, 0};
+    static constexpr int SD[4] = {3, 0, 0, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) {
+        const T* w = sv[0]; r[0] = w[0] * data[0] + w[1] * data[1] + w[2] * data[2];
+    }
+};
+// kinds whose block is an AbstractCost (value / gradient / Hessian of computecost itself, src/autodiff.jl:144-159), not half a squared residual norm
+template <int KIND> constexpr bool is_cost_kind = (KIND == NLLS_COST_LINEAR3);
+
 // compile-time helpers over a residual kind
 template <int KIND> struct ResInfo {
     using R = Res<KIND>;
@@ -352,6 +415,7 @@ NLLS_DEV double block_cost(const double* __restrict__ vars, const uint32_t* voff
         (var_load<R::SK[S + R::ADAPT], R::SD[S + R::ADAPT], double>(vars + voff[S + R::ADAPT], -1, sv[S]), ...);
     }(std::make_integer_sequence<int, I::NS>{});
     double r[R::M]; R::template eval<double>(data, sv, r);
+    if constexpr (is_cost_kind<KIND>) return r[0];              // computecost: the value itself (src/cost.jl, AbstractCost)
     double s = 0;
 #pragma unroll
     for (int m = 0; m < R::M; ++m) s += r[m] * r[m];
@@ -372,6 +436,7 @@ struct BlockGH {
     double dc, d2c;         // rho', rho'' (residual.jl:78 or :82-84)
     double dck[3];          // d rho / d kernel   (adaptive, kernel optimised)
     double d2ck[3][4];      // d2 rho / d kernel d(kernel, cost)
+    double hc[is_cost_kind<KIND> ? NP : 1][is_cost_kind<KIND> ? NP : 1];   // AbstractCost kinds: the Hessian of the cost (g carries its gradient)
 
     // raw storage of the block's variables (one row per getvars() slot, kernel included), so that callers can issue
     // the gathers of several blocks before evaluating any of them
@@ -415,6 +480,20 @@ struct BlockGH {
         double st[R::NDEPS][MAXST]; load(vars, voff, st); compute_st(st, data, rk, kernel_free);
     }
     NLLS_DEV void compute_st(const double (*st)[MAXST], const double* data, const RobustSpec& rk, bool kernel_free) {
+        if constexpr (is_cost_kind<KIND>) {                     // computecostgradhess, src/autodiff.jl:144-159: second-order duals through update()
+            using T2 = Dual2N<NP>;
+            T2 sv2[I::NS > 0 ? I::NS : 1][MAXST];
+            [&]<int... S>(std::integer_sequence<int, S...>) {
+                (var_load<R::SK[S], R::SD[S], T2>(st[S], I::joff(S), sv2[S]), ...);
+            }(std::make_integer_sequence<int, I::NS>{});
+            T2 c2[1]; R::template eval<T2>(data, sv2, c2);
+            cost = c2[0].v; dc = 1.0; d2c = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) { g[i] = c2[0].g[i];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) hc[i][j] = c2[0].h[i][j]; }
+            return;
+        }
         using T = Dual<NP>;
         T sv[I::NS > 0 ? I::NS : 1][MAXST];
         [&]<int... S>(std::integer_sequence<int, S...>) {
@@ -444,7 +523,9 @@ struct BlockGH {
         cost = 0.5 * rho;
     }
     // local H / g entries over the non-kernel dof (residual.jl:91-101)
-    NLLS_DEV double H(int i, int j) const { double s = 0;
+    NLLS_DEV double H(int i, int j) const {
+        if constexpr (is_cost_kind<KIND>) return hc[i][j];
+        double s = 0;
 #pragma unroll
         for (int m = 0; m < M; ++m) s += J[m][i] * J[m][j];
         return s * dc + (2 * d2c) * g[i] * g[j]; }

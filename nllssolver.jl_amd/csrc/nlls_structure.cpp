@@ -17,7 +17,7 @@ namespace nlls {
 
 bool res_desc(int kind, ResDesc& d) {
     switch (kind) {
-#define X(K) case K: d.ndeps = Res<K>::NDEPS; d.nres = Res<K>::M; d.ndata = Res<K>::NDATA; d.adaptive = Res<K>::ADAPT; \
+#define X(K) case K: d.ndeps = Res<K>::NDEPS; d.nres = is_cost_kind<K> ? 0 : Res<K>::M; d.ndata = Res<K>::NDATA; d.adaptive = Res<K>::ADAPT; \
         for (int i = 0; i < 4; ++i) { d.sk[i] = Res<K>::SK[i]; d.sd[i] = Res<K>::SD[i]; } return true;
         NLLS_FOR_EACH_RES(X)
 #undef X

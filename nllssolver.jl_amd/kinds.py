@@ -20,6 +20,8 @@ RES_CURVE_EXP4 = 5        # BASELINE.json config 2
 RES_ADAPTIVE_MEAN = 6     # test/adaptivecost.jl:3-13
 RES_BA_SO3 = 7            # new
 RES_BA_SO3_ADAPTIVE = 8   # new
+RES_LINEAR3 = 9           # test/nonsquaredcost.jl:4-14: X w - y
+COST_LINEAR3 = 10         # test/nonsquaredcost.jl:28-37: non-squared AbstractCost y'w (value, gradient, Hessian by second-order duals)
 
 # robust kernels: src/robust.jl:7-77
 ROBUST_NONE = 0
@@ -38,6 +40,8 @@ RES_TABLE = {
     RES_ADAPTIVE_MEAN: (2, 1, 1, True, ((VAR_CONTAMINATED_GAUSSIAN, 3), (VAR_EUCLIDEAN, 1))),
     RES_BA_SO3: (2, 2, 2, False, ((VAR_POSE_SO3, 6), (VAR_EUCLIDEAN, 3))),
     RES_BA_SO3_ADAPTIVE: (3, 2, 2, True, ((VAR_CONTAMINATED_GAUSSIAN, 3), (VAR_POSE_SO3, 6), (VAR_EUCLIDEAN, 3))),
+    RES_LINEAR3: (1, 3, 12, False, ((VAR_EUCLIDEAN, 3),)),
+    COST_LINEAR3: (1, 0, 3, False, ((VAR_EUCLIDEAN, 3),)),
 }
 
 

@@ -36,7 +36,10 @@ static const res_desc RES[NLLS_RES_KIND_COUNT] = {
     /* ADAPTIVE_MEAN   */ {2, 1, 1, 1, {NLLS_VAR_CONTAMINATED_GAUSSIAN, NLLS_VAR_EUCLIDEAN}, {3, 1}},
     /* BA_SO3          */ {2, 2, 2, 0, {NLLS_VAR_POSE_SO3, NLLS_VAR_EUCLIDEAN}, {6, 3}},
     /* BA_SO3_ADAPTIVE */ {3, 2, 2, 1, {NLLS_VAR_CONTAMINATED_GAUSSIAN, NLLS_VAR_POSE_SO3, NLLS_VAR_EUCLIDEAN}, {3, 6, 3}},
+    /* LINEAR3         */ {1, 3, 12, 0, {NLLS_VAR_EUCLIDEAN}, {3}},
+    /* COST_LINEAR3    */ {1, 0, 3, 0, {NLLS_VAR_EUCLIDEAN}, {3}},   /* nres = 0: an AbstractCost, not a residual */
 };
+#define IS_COST_KIND(k) ((k) == NLLS_COST_LINEAR3)
 
 static int var_storage(int kind, int dim) {
     switch (kind) {
@@ -165,7 +168,23 @@ static void res_eval(int kind, const double* data, jet* const* sv, jet* r, int n
             Y[i] = jet_add(jet_add(jet_add(jet_mul(P[i], X[0], n), jet_mul(P[i + 3], X[1], n), n), jet_mul(P[i + 6], X[2], n), n), P[9 + i], n);
         r[0] = jet_addc(jet_div(Y[0], Y[2], n), -data[0], n);
         r[1] = jet_addc(jet_div(Y[1], Y[2], n), -data[1], n); break; }
+    case NLLS_RES_LINEAR3: { /* test/nonsquaredcost.jl:13: X * w - y, data = (y[3], X[9] column-major) */
+        const jet* w = sv[0];
+        for (int i = 0; i < 3; ++i)
+            r[i] = jet_addc(jet_add(jet_add(jet_scale(w[0], data[3 + i], n), jet_scale(w[1], data[6 + i], n), n), jet_scale(w[2], data[9 + i], n), n), -data[i], n);
+        break; }
     }
+}
+/* computecost() of the AbstractCost kinds with second-order jets (computehessian, src/autodiff.jl:123-128,144-159); the
+ * variables are Euclidean (linear retraction), seeded as jet2 variable `start + i` */
+static jet2 cost_eval2(int kind, const double* data, const double* const* st, const int* start) {
+    switch (kind) {
+    case NLLS_COST_LINEAR3: { /* test/nonsquaredcost.jl:36: y' * w */
+        jet2 c = j2_const(0.0);
+        for (int i = 0; i < 3; ++i) { jet2 w = start[0] >= 0 ? j2_seed(st[0][i], start[0] + i) : j2_const(st[0][i]); c = j2_add(c, j2_scale(w, data[i])); }
+        return c; }
+    }
+    return j2_const(0.0);
 }
 
 /* ============================================================================================ */
@@ -595,7 +614,13 @@ static void block_residual(const oracle_problem* p, const double* vars, const og
 }
 /* computerescost  src/residual.jl:49-55 */
 static double block_cost(const oracle_problem* p, const double* vars, const ogroup* g, int64_t ci) {
-    const res_desc* d = &RES[g->res_kind]; double r[4]; block_residual(p, vars, g, ci, r);
+    const res_desc* d = &RES[g->res_kind];
+    if (IS_COST_KIND(g->res_kind)) { /* computecost: the value itself (src/cost.jl:10-13 over an AbstractCost) */
+        const double* st[4]; int start[4];
+        for (int s = 0; s < d->ndeps; ++s) { st[s] = vars + p->voff[g->varind[ci * d->ndeps + s] - 1]; start[s] = -1; }
+        return cost_eval2(g->res_kind, g->data + ci * d->ndata, st, start).v;
+    }
+    double r[4]; block_residual(p, vars, g, ci, r);
     double s = 0; for (int m = 0; m < d->nres; ++m) s += r[m] * r[m];
     if (d->adaptive) { int64_t kv = g->varind[ci * d->ndeps] - 1; cgauss k = cg_make(vars + p->voff[kv]); return 0.5 * cg_robustify(&k, s); }
     return 0.5 * fixed_robustify(g->robust_kind, g->rp, s);
@@ -617,6 +642,14 @@ static int block_resjac(const oracle_problem* p, const double* vars, const ogrou
 static int block_costgradhess(const oracle_problem* p, const double* vars, const ogroup* g, int64_t ci, const int* slotfree,
                               double* cost, double* gv, double* H) {
     const res_desc* d = &RES[g->res_kind]; int M = d->nres;
+    if (IS_COST_KIND(g->res_kind)) { /* computecostgradhess  src/autodiff.jl:144-159: value, gradient, Hessian of the cost through update() */
+        const double* st[4]; int start[4], n = 0;
+        for (int s = 0; s < d->ndeps; ++s) { int64_t vi = g->varind[ci * d->ndeps + s] - 1; st[s] = vars + p->voff[vi];
+            if (slotfree[s]) { start[s] = n; n += var_dof(p->kind[vi], p->dim[vi]); } else start[s] = -1; }
+        jet2 c = cost_eval2(g->res_kind, g->data + ci * d->ndata, st, start);
+        *cost = c.v; for (int i = 0; i < n; ++i) { gv[i] = c.g[i]; for (int j = 0; j < n; ++j) H[i + n * j] = c.h[i][j]; }
+        return n;
+    }
     int kernel_opt = d->adaptive && slotfree[0];
     int anyres = 0; for (int s = d->adaptive; s < d->ndeps; ++s) anyres |= slotfree[s];
     const double* kst = 0; if (d->adaptive) { int64_t kv = g->varind[ci * d->ndeps] - 1; kst = vars + p->voff[kv]; }

@@ -241,3 +241,34 @@ def test_randomized_optimizesingles_matches_oracle(seed):
     N.optimizesingles(p, N.NLLSOptions(), indices=pts)
     assert N.cost(p) <= c0
     assert np.max(np.abs(p.variables - expect)) < 1e-7
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_nonsquared_cost_closed_form_on_device(seed):
+    """test/nonsquaredcost.jl:48-68 on the device: LinearResidualStatic + the non-squared LinearCostStatic (value, gradient and
+    Hessian of computecost by second-order duals, src/autodiff.jl:144-159), Newton and Levenberg-Marquardt against the closed
+    form (X'X) \\ ((X' - I) y) and against the oracle's sweep."""
+    from nllssolver_jl_amd import kinds as K, _capi
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((3, 3)); y = rng.standard_normal(3)
+    solution = np.linalg.solve(X.T @ X, (X.T - np.eye(3)) @ y)
+
+    def mk():
+        p = N.NLLSProblem(); p.addvariable(np.zeros(3))
+        p.addcosts(K.RES_LINEAR3, np.array([[1]]), np.concatenate([y, X.ravel(order="F")])[None, :])
+        p.addcosts(K.COST_LINEAR3, np.array([[1]]), y[None, :])
+        return p
+    p = mk(); p.variables[:] = [0.3, -0.2, 0.7]
+    op = oracle_problem(p); ols = op.linear_system(np.array([1], np.uint64))
+    ctx = _capi.Context(); ctx.upload(p.var_kind, p.var_dim, np.array([1], np.uint64), p.groups(), 0); ctx.set_variables(p.variables)
+    assert np.isclose(ctx.sweep_gradhess(), ols.costgradhess(), rtol=1e-13)
+    assert np.allclose(ctx.get_grad(), ols.b, rtol=1e-13)
+    M = ols.data.reshape(3, 3).T; M = np.tril(M) + np.tril(M, -1).T             # the device mirrors the lower triangle (gethessian)
+    assert np.allclose(ctx.get_bsm_data(), M.T.ravel(), rtol=1e-13)
+    assert np.isclose(ctx.sweep_cost(_capi.VARS_CURRENT), op.cost(), rtol=1e-13)
+    ctx.close()
+    for it in (N.newton, N.levenbergmarquardt):
+        q = mk()
+        N.optimize(q, N.NLLSOptions(iterator=it))
+        tol = 1e-9 if it == N.newton else 1e-6               # (Levenberg-Marquardt stops on the default reldcost, as in the reference)
+        assert np.allclose(q.variables, solution, rtol=tol, atol=1e-10), (it, q.variables, solution)

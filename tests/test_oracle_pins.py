@@ -329,3 +329,30 @@ def test_so3_kinds_against_finite_differences(adaptive):
             gfd[:3] *= 2.0  # gradient (src/residual.jl:65,87,105-110): the oracle restates exactly that
         assert np.allclose(grad, gfd, rtol=1e-5, atol=1e-8 * max(1.0, abs(c))), (ci, np.abs(grad - gfd).max())
         assert np.allclose(H, H.T, rtol=1e-12, atol=1e-14)
+
+
+# ---------------------------------------------------------------- test/nonsquaredcost.jl
+def _nonsquared_problem(seed):
+    """test/nonsquaredcost.jl:48-58 (static halves): a 3-dof variable under LinearResidualStatic(y, X) and the NON-SQUARED
+    LinearCostStatic(y); known answer (X'X) \\ ((X' - I) y)."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((3, 3)); y = rng.standard_normal(3)
+    p = N.NLLSProblem()
+    p.addvariable(np.zeros(3))
+    p.addcosts(K.RES_LINEAR3, np.array([[1]]), np.concatenate([y, X.ravel(order="F")])[None, :])
+    p.addcosts(K.COST_LINEAR3, np.array([[1]]), y[None, :])
+    return p, np.linalg.solve(X.T @ X, (X.T - np.eye(3)) @ y), X, y
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_nonsquared_cost_closed_form(seed):
+    p, solution, X, y = _nonsquared_problem(seed)
+    op = oracle_problem(p)
+    # the cost block's value / gradient / Hessian (second-order jets through update()): y'w, y, 0
+    w = np.array([0.3, -0.2, 0.7]); op.set_variables(w)
+    c, g, H = op.block_costgradhess(1, 0)
+    assert np.isclose(c, y @ w) and np.allclose(g, y) and np.allclose(H, 0.0)
+    assert np.isclose(op.cost(), 0.5 * np.sum((X @ w - y) ** 2) + y @ w, rtol=1e-14)
+    op.set_variables(np.zeros(3))
+    r = op.optimize(iterator=0)                             # NLLSOptions(iterator = newton), test/nonsquaredcost.jl:62
+    assert np.allclose(op.get_variables(), solution, rtol=1e-9, atol=1e-12), (op.get_variables(), solution)
