@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void bcr_convert_kernel(BcrGeom g, const doubl
         if (row < g.n_band) { const int e = row - col; if (e <= g.bw) v = Sb[(size_t)col * g.H + e]; }
         else v = (row == col) ? 1.0 : 0.0;
         dst = g.ws + g.oD + ((size_t)k * ND + t) * 256;
+        if (I == K && a == bc) g.ws[g.odg + (size_t)b * k + 16 * I + a] = fabs(v);      // the original diagonal (pivot floor of singular systems)
     } else if (t < ND + NT * NT) {
         const int tt = t - ND, P = tt / NT, Q = tt % NT;
         if (k > 0) { const int row = b * k + 16 * P + a, col = b * (k - 1) + 16 * Q + bc, e = row - col; if (row < g.n_band && e <= g.bw) v = Sb[(size_t)col * g.H + e]; }
@@ -91,8 +92,11 @@ __global__ __launch_bounds__(256) void bcr_convert_kernel(BcrGeom g, const doubl
 // (A[i][kk] = w_i) and, scaled by -1/d, the B operand: one MFMA is the whole rank-1 update.  A second accumulator starts
 // as the identity and ends as inv(L).  Out: Wd (row-major, LDS) = the factored tile (L Delta below, Delta on the
 // diagonal), Lid = inv(L)' ([k][j] = inv(L)[j][k]), dd[0..15] = Delta, dd[16..31] = 1 / Delta.
-BCR_DEV void bcr_factor(const double* T0, bool from_regs, const bdouble4_t Ain, double* Wd, double* Lid, double* dd, int* status, int pivbase, bool report) {
+template <bool FLOOR>
+BCR_DEV void bcr_factor(const double* T0, bool from_regs, const bdouble4_t Ain, double* Wd, double* Lid, double* dd, int* status, int pivbase, bool report, const double* diag0, double relfloor) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    // FLOOR: the floor of pivot li is a fraction of the ORIGINAL diagonal entry of that unknown (loaded once, broadcast per pivot)
+    double fl = 0.0; if constexpr (FLOOR) fl = diag0[pivbase + li] * relfloor;
     bdouble4_t A, Bt;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const double t = T0[(lk + 4 * r) * BP + li]; A[r] = from_regs ? Ain[r] : t; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
@@ -103,7 +107,8 @@ BCR_DEV void bcr_factor(const double* T0, bool from_regs, const bdouble4_t Ain, 
     for (int k = 0; k < 15; ++k) {
         const int q = k & 3, r = k >> 2;
         const double w = A[r], bt = Bt[r];
-        const double dk = bcr_readlane(w, 16 * q + k);
+        double dk = bcr_readlane(w, 16 * q + k);
+        if constexpr (FLOOR) { if (!(fabs(dk) > bcr_readlane(fl, k))) dk = 1e300; }      // a vanished pivot: as if infinite (its unknown comes out 0)
         double rdk = __builtin_amdgcn_rcp(dk);
         const bool rowq = lk == q;
         const double am = (rowq && li > k) ? w : 0.0;
@@ -116,6 +121,7 @@ BCR_DEV void bcr_factor(const double* T0, bool from_regs, const bdouble4_t Ain, 
         double dsel = A[0];
 #pragma unroll
         for (int r = 1; r < 4; ++r) dsel = (li >> 2) == r ? A[r] : dsel;
+        if constexpr (FLOOR) { if (!(fabs(dsel) > fl)) dsel = 1e300; }
         if ((li & 3) == lk) {
             double rd = __builtin_amdgcn_rcp(dsel); rd = fma(fma(-dsel, rd, 1.0), rd, rd); rd = fma(fma(-dsel, rd, 1.0), rd, rd);
             dd[li] = dsel; dd[16 + li] = rd;
@@ -219,7 +225,7 @@ BCR_DEV void bcr_export_linv(const double* Lid, double* __restrict__ dst) {
     *reinterpret_cast<bdouble4_t*>(dst + 4 * lane) = bdouble4_t{Lid[li * BP + lk], Lid[li * BP + 4 + lk], Lid[li * BP + 8 + lk], Lid[li * BP + 12 + lk]};
 }
 
-struct BcrPanelArgs { BcrGeom g; BcrChain ch; int* status; };
+struct BcrPanelArgs { BcrGeom g; BcrChain ch; int* status; double relfloor; };
 // job e of a level, from the level's chain (no descriptor load in front of everything else)
 BCR_DEV BcrElim bcr_job(const BcrChain& c, int e) {
     const int idx = c.first + 2 * e, i = c.o + idx * c.s;
@@ -233,6 +239,7 @@ __host__ __device__ constexpr int bcr_nchunks(int NT) { return (2 * NT + 1 + BCR
 // arithmetic, identical bits).  The tile-updates run on the matrix pipes of the three SIMDs wave 0 does not sit on: they, not
 // wave 0's pivot chain, would set the pace of a block step with more X rows per workgroup.  The workgroup that holds the border
 // row also exports the D part of the factor and reports bad pivots.
+template <bool FLOOR>
 __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BcrGeom& g = a.g;
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     bdouble4_t diag = {0, 0, 0, 0};
     for (int J = 0; J < NT; ++J) {
         double* Wb = Wp + (J & 1) * PR * 16 * BP; double* Lid = Li + (J & 1) * 16 * BP; double* db = dvec + (J & 1) * 32;
-        if (wave == 0) bcr_factor(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, 16 * NT * job.i + 16 * J, lead);
+        if (wave == 0) bcr_factor<FLOOR>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, 16 * NT * job.i + 16 * J, lead, g.ws + g.odg, a.relfloor);
         else if (helper) { if (J > 0) { BCR_STAMP(); updates(J - 1, hw, 6); BCR_STAMP(); exports(J - 1, hw, 6); } else land_rest(); }
         BCR_STAMP();
 #ifdef BCR_STAMPS
@@ -539,7 +546,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     geom.oD = take((size_t)N * ND * 256); geom.oA = take((size_t)N * NT * NT * 256); geom.oBR = take((size_t)N * NT * 256);
     geom.oWx = take((size_t)N * RXT * NT * 256); geom.oLx = take((size_t)N * RXT * NT * 256); geom.oMx = take((size_t)N * RXT * NT * 256);
     geom.oLd = take((size_t)N * std::max(NO, 1) * 256); geom.oLi = take((size_t)N * NT * 256);
-    geom.oMd = take((size_t)N * std::max(NO, 1) * 256); geom.ocp = take((size_t)(N + 1) * 256); geom.oxb = take(32);
+    geom.oMd = take((size_t)N * std::max(NO, 1) * 256); geom.ocp = take((size_t)(N + 1) * 256); geom.oxb = take(32); geom.odg = take((size_t)N * 16 * NT);
     if (off >= ((size_t)1 << 32)) { if (err) *err = "block cyclic reduction workspace exceeds 32-bit tile offsets"; return NLLS_ERR_UNSUPPORTED; }
     geom.NT = NT; geom.N = N; geom.nbd = nbd; geom.n_band = n_band; geom.bw = bw; geom.H = H;
     std::vector<BcrElim> elims; std::vector<BcrUpd> upds;
@@ -630,9 +637,10 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
 }
 
 template <int NT>
-static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status) {
-    BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status};
-    hipLaunchKernelGGL(bcr_panel_kernel, dim3((unsigned)(bcr_nchunks(NT) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
+static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status, double relfloor) {
+    BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status, relfloor};
+    if (relfloor > 0.0) hipLaunchKernelGGL(bcr_panel_kernel<true>, dim3((unsigned)(bcr_nchunks(NT) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
+    else hipLaunchKernelGGL(bcr_panel_kernel<false>, dim3((unsigned)(bcr_nchunks(NT) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     if (lv.nupd > 0) hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd);
 }
 template <int NT>
@@ -641,11 +649,11 @@ static void bcr_launch_back(const BcrSolver& S, hipStream_t st, const BcrLevel& 
     hipLaunchKernelGGL((bcr_backward_kernel<NT>), dim3((unsigned)lv.nelim), dim3(64 * NT), S.back_lds, st, ba);
 }
 
-int BcrSolver::enqueue(hipStream_t st, const double* Sb, double* xr, int* status) const {
+int BcrSolver::enqueue(hipStream_t st, const double* Sb, double* xr, int* status, double pivot_floor) const {
     const int ND = NT * (NT + 1) / 2, per = ND + NT * NT + NT;
     if (Sb) hipLaunchKernelGGL(bcr_convert_kernel, dim3((unsigned)(N * per + 1)), dim3(256), 0, st, geom, Sb);   // (else: the tiles have been assembled in place, schur_gather_kernel)
 #define BCR_NT_SWITCH(CALL) switch (NT) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; default: CALL(5); break; }
-#define BCR_FWD(n) bcr_launch_level<n>(*this, st, lv, status)
+#define BCR_FWD(n) bcr_launch_level<n>(*this, st, lv, status, pivot_floor)
     for (const BcrLevel& lv : levels) BCR_NT_SWITCH(BCR_FWD)
 #define BCR_BWD(n) bcr_launch_back<n>(*this, st, levels[li], xr, li + 1 == levels.size() ? 1 : 0, status)
     for (size_t li = levels.size(); li-- > 0;) BCR_NT_SWITCH(BCR_BWD)

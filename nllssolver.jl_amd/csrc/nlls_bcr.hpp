@@ -21,7 +21,7 @@ struct BcrChain { int o, s, m, first; };
 
 // workspace geometry handed to the kernels
 struct BcrGeom {
-    double* ws; size_t oD, oA, oBR, oWx, oLx, oMx, oMd, oLd, oLi, ocp, oxb;
+    double* ws; size_t oD, oA, oBR, oWx, oLx, oMx, oMd, oLd, oLi, ocp, oxb, odg;
     int NT, N, nbd, n_band, bw, H;
 };
 
@@ -38,7 +38,9 @@ struct BcrSolver {
     static bool supports(int64_t n_band, int bw, int nbd);
     int build(int64_t n_band, int bw, int nbd, int H, std::string* err);
     // Sb: band storage [S | corner] as assembled by the Schur elimination (SLayout, mode SOLVE_BAND); xr: n_band + nbd unknowns out
-    int enqueue(hipStream_t st, const double* Sb, double* xr, int* status) const;
+    // pivot_floor > 0 (undamped Newton / dogleg steps on a gauge-free problem: S is singular): a pivot that has lost more than that
+    // fraction of its original diagonal entry is treated as infinite -- its unknown comes out 0 instead of (rounding) / (rounding)
+    int enqueue(hipStream_t st, const double* Sb, double* xr, int* status, double pivot_floor = 0.0) const;
     void release() { ws.release(); d_elim.release(); d_upd.release(); levels.clear(); ready = false; }
 };
 

@@ -10,6 +10,7 @@ from nllssolver_jl_amd import kinds as K
 from nllssolver_jl_amd import synthetic
 from nllssolver_jl_amd.variables import contaminated_gaussian, contaminated_gaussian_params
 from tests.helpers import oracle_problem
+from tests.test_gpu_parity import rel
 
 pytestmark = pytest.mark.gpu
 
@@ -272,3 +273,50 @@ def test_nonsquared_cost_closed_form_on_device(seed):
         N.optimize(q, N.NLLSOptions(iterator=it))
         tol = 1e-9 if it == N.newton else 1e-6               # (Levenberg-Marquardt stops on the default reldcost, as in the reference)
         assert np.allclose(q.variables, solution, rtol=tol, atol=1e-10), (it, q.variables, solution)
+
+
+def test_reordercostsforschur_is_the_device_ordering():
+    """reordercostsforschur! (src/problem.jl:177-199) as pack-time ordering: a camera-major bundle adjustment re-ordered point-major
+    on the host gives the same linear system (A.data, b to summation order), the same step and the same optimum on the device,
+    and the host's run lengths are the device's elimination structure: run k holds the cost blocks of eliminated block k, as
+    many as that point's block row has off-diagonal blocks in the BlockSparseMatrix."""
+    from nllssolver_jl_amd import kinds as K, _capi
+    mk = lambda: synthetic.perturb_ba_problem(synthetic.create_ba_problem(60, 1500, 0.12, seed=21, robust=N.HuberKernel(0.02), outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    p0, p1 = mk(), mk()
+    schurvars = (p1.var_kind == K.VAR_EUCLIDEAN) & (p1.var_dim == 3)
+    (runs,) = p1.reordercostsforschur(schurvars).values()
+    vi, _ = next(iter(p1.costs.values())).arrays()
+    assert np.all(np.diff(vi[:, 1]) >= 0) and not np.all(np.diff(next(iter(p0.costs.values())).arrays()[0][:, 1]) >= 0)
+    bi = np.arange(1, p0.nvariables + 1, dtype=np.uint64)
+    out = []
+    for p in (p0, p1):
+        ctx = _capi.Context(); info = ctx.upload(p.var_kind, p.var_dim, bi, p.groups(), 0); ctx.set_variables(p.variables)
+        c = ctx.sweep_gradhess(); ctx.damp(1e-4 * ctx.max_abs_diag())
+        out.append((c, ctx.get_bsm_data(), ctx.get_grad(), ctx.solve(want_x=True), ctx.bsm_index(), info)); ctx.close()
+    (c0, A0, b0, x0, idx0, info0), (c1, A1, b1, x1, idx1, info1) = out
+    assert np.isclose(c0, c1, rtol=1e-12) and rel(A0, A1) < 1e-11 and rel(b0, b1) < 1e-11 and rel(x0, x1) < 1e-7
+    assert all(np.array_equal(a, b) for a, b in zip(idx0, idx1))                     # the structure does not depend on the cost order
+    # run lengths <-> block rows of the eliminated (point) blocks: nblocks in row minus the diagonal
+    colptr = idx1[0]; ncam = int((~schurvars).sum())
+    row_blocks = np.diff(colptr)[ncam:] - 1
+    assert runs[0] == 1 and np.array_equal(np.diff(runs[1:]), row_blocks) and info1.nschur_blocks == row_blocks.size
+    r0, r1 = N.optimize(p0), N.optimize(p1)
+    assert np.isclose(r0.bestcost, r1.bestcost, rtol=1e-9)
+
+
+@pytest.mark.parametrize("ncam,npts,prop,seed", [(60, 1500, 0.12, 41), (130, 3000, 0.08, 42)])
+def test_dogleg_and_newton_on_gauge_free_sparse_ba(ncam, npts, prop, seed):
+    """Dogleg and Newton (src/iterators.jl:10-26,47-115) on a sparse noise-free bundle adjustment.  The affine camera has a 9-dof gauge
+    freedom: the undamped system is singular, and an exact factorisation returns (rounding) / (rounding) along the null space --
+    whatever its pivot order makes of it.  The device's reduced solve drops pivots that have lost eleven orders of magnitude against
+    their original diagonal entry (their unknowns come out 0: the small Gauss-Newton step), so that both iterators converge to the
+    zero-residual optimum the reference's criterion asks for (test/optimizeba.jl:62-75) -- and to the same cost as the oracle."""
+    mk = lambda: synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed), 1e-3, 1e-3)
+    for it, name in ((N.dogleg, "dogleg"), (N.newton, "newton")):
+        p = mk(); op = oracle_problem(mk())
+        res = N.optimize(p, N.NLLSOptions(iterator=it, maxiters=60))
+        ores = op.optimize(iterator=int(it), maxiters=60)
+        assert res.bestcost < 1e-15 * p.ncosts(), (name, res.bestcost, res.niterations)
+        assert N.cost(p) == res.bestcost
+        assert ores.bestcost < 1e-12 * p.ncosts() or res.bestcost <= ores.bestcost, (name, ores.bestcost)   # (the oracle's own null-space components may slow it down)
+        assert res.niterations <= 30, (name, res.niterations)
