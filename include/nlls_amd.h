@@ -243,10 +243,15 @@ int  nlls_sweep_cost_finish(nlls_ctx* ctx, double* cost_out);
 int  nlls_solve_local(nlls_ctx* ctx);
 int  nlls_solve_finish(nlls_ctx* ctx, double* x_out);
 /* after the stage-2 reduction (x complete): update!(to, from, x), cost(to), fast_bAb(H, x), dot(g, x), max|x|, |x|^2 of one
- * Levenberg-Marquardt trial (src/iterators.jl:155-163) with one synchronisation.  out[5] = [cost, x'Hx, g'x, max|x|, |x|^2];
- * the first three are this rank's partial sums. */
+ * Levenberg-Marquardt trial (src/iterators.jl:155-163) with one synchronisation.  out[6] = [cost, x'Hx, g'x, max|x|, |x|^2, status]:
+ * with nranks > 1 all of them are this rank's share (sum the first three and the fifth, take the maximum of the fourth and of the
+ * factorisation status, and fail on EVERY rank when that is not 0); with one rank out[5] is not written and a bad pivot is an error. */
 int  nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out);   /* also reports a failed factorisation of the solve before it */
 /* nlls_solve_finish without the synchronisation: for the step of an LM trial, whose status nlls_trial_local reports */
+int  nlls_solve_finish_replicated(nlls_ctx* ctx);   /* ... and with the reduced part of the step on EVERY rank: no stage-2 reduction; each rank
+                                                      retracts the reduced variables and its own eliminated ones (nlls_trial_local) */
+/* this rank's share of a variable set (its own eliminated blocks' variables; rank 0: also all others), zeros elsewhere: sum over ranks */
+int  nlls_get_variables_owned(nlls_ctx* ctx, int32_t which, double* packed);
 int  nlls_solve_finish_async(nlls_ctx* ctx);
 int  nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count);
 int  nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count,

@@ -23,7 +23,7 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_solve_finish_replicated nlls_get_variables_owned""".split()
 
 
 class NllsError(RuntimeError):
@@ -97,6 +97,7 @@ def lib():
         L.nlls_time_sweep_gradhess.argtypes = [vp, i32, vp]; L.nlls_time_sweep_cost.argtypes = [vp, i32, vp]; L.nlls_time_sweep_accumulate.argtypes = [vp, i32, vp]
         L.nlls_time_solve.argtypes = [vp, i32, vp]; L.nlls_time_reduced_solve.argtypes = [vp, i32, vp]
         L.nlls_profile_sweep.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.nlls_solve_finish_replicated.argtypes = [vp]; L.nlls_get_variables_owned.argtypes = [vp, i32, vp]
         _lib = L
     return _lib
 
@@ -278,7 +279,13 @@ class Context:
         self._chk(self.L.nlls_solve_finish_async(self.h))
 
     def trial_local(self, to=VARS_NEXT, frm=VARS_CURRENT):
-        out = np.zeros(5); self._chk(self.L.nlls_trial_local(self.h, to, frm, _p(out))); return out
+        out = np.zeros(6); self._chk(self.L.nlls_trial_local(self.h, to, frm, _p(out))); return out
+
+    def solve_finish_replicated(self):
+        self._chk(self.L.nlls_solve_finish_replicated(self.h))
+
+    def get_variables_owned(self, which=VARS_CURRENT):
+        out = np.zeros(self.info.var_storage); self._chk(self.L.nlls_get_variables_owned(self.h, which, _p(out))); return out
 
     def sweep_gradhess_finish(self, want_cost=True):
         if not want_cost:

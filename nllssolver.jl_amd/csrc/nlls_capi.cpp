@@ -242,7 +242,33 @@ int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
     HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));   // [10]: the factorisation status
     HIPCHK(hipStreamSynchronize(ctx->stream));
     out[0] = ctx->h_scalars[0]; out[1] = ctx->h_scalars[8]; out[2] = ctx->h_scalars[5]; out[3] = ctx->h_scalars[1]; out[4] = ctx->h_scalars[2];
+    if (ctx->nranks > 1) {
+        // sharded: max|x| and |x|^2 over THIS rank's share of the step (its own eliminated blocks; rank 0 also the reduced part), and the
+        // factorisation status as a sixth value instead of an error -- a rank-local zero pivot must not leave this rank out of the
+        // collective its peers are about to enter: the caller reduces all six and raises on every rank
+        out[4] = ctx->h_scalars[9]; out[5] = ctx->h_scalars[10];
+        return NLLS_OK;
+    }
     if ((int32_t)ctx->h_scalars[10] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a zero pivot (code " + std::to_string((int32_t)ctx->h_scalars[10]) + ")");
+    return NLLS_OK;
+}
+// nlls_solve_finish_async for a sharded LM trial: the reduced part of the step stays on every rank (no stage-2 reduction afterwards)
+int nlls_solve_finish_replicated(nlls_ctx* ctx) {
+    NEED_GRAD(); ctx->replicate_xr = true; const int rc = enqueue_solve_finish(ctx); ctx->replicate_xr = false;
+    if (rc != NLLS_OK) return rc;
+    ctx->solved = true; ctx->step_cached = false; return NLLS_OK;
+}
+// this rank's share of a variable set: its own eliminated blocks' variables, on rank 0 also everything else; zeros elsewhere --
+// the sum over ranks is the complete set (what a sharded optimisation hands back at the end)
+int nlls_get_variables_owned(nlls_ctx* ctx, int32_t which, double* packed) {
+    TRY(nlls_get_variables(ctx, which, packed));
+    if (ctx->nranks == 1) return NLLS_OK;
+    for (int64_t i = 0; i < ctx->info.nvar; ++i) {
+        const uint64_t bi = ctx->blockindices[i];
+        int owner = 0;
+        if (bi > 0 && ctx->is_elim.size() >= bi && ctx->is_elim[bi - 1] && !ctx->owner_of_block.empty()) owner = ctx->owner_of_block[bi - 1];
+        if (owner != ctx->rank) for (uint32_t q = ctx->var_off[i]; q < ctx->var_off[i + 1]; ++q) packed[q] = 0.0;
+    }
     return NLLS_OK;
 }
 // optimizesingles!(problem, options, indices)  src/optimize.jl:60-76,183-205

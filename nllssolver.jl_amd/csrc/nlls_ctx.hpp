@@ -156,6 +156,7 @@ struct nlls_ctx {
     bool have_grad = false;
 
     // ---- sharding ------------------------------------------------------------------------------------
+    bool replicate_xr = false;               // the step's reduced part is written on every rank (sharded LM trial without the stage-2 reduction)
     bool elim_selected = false;
     std::vector<int32_t> owner_of_block;
     int64_t local_ncost = 0, local_nnz_data = 0, local_ndof = 0;

@@ -1826,7 +1826,7 @@ __global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) {
     for (int64_t i = (int64_t)b2 * 256 + threadIdx.x; i < a.ndof; i += (int64_t)a.np2 * 256) {
         const double x = a.x[i], w = a.dofmask ? a.dofmask[i] : 1.0;
         if (x != x) nan = 1.0;
-        m = fmax(m, fabs(x)); ss += x * x; vv += w * x * x; bv += w * a.b[i] * x;
+        m = fmax(m, w * fabs(x)); ss += x * x; vv += w * x * x; bv += w * a.b[i] * x;     // (w: this rank's share under sharding, 1 otherwise)
     }
     ss = wsum(ss); vv = wsum(vv); bv = wsum(bv);
 #pragma unroll
@@ -2206,7 +2206,9 @@ int enqueue_solve_finish(nlls_ctx* c) {
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
     { const int rc = enqueue_reduced_solve(c); if (rc != NLLS_OK) return rc; }
     // x = -solution (folded into the fast back-substitution launch when there is one)
-    const int write_red = (c->nranks == 1 || c->rank == 0) ? 1 : 0;
+    // (replicate_xr: a sharded LM trial keeps the reduced part of the step on every rank -- each retracts the cameras and its own
+    //  points itself, no all-reduce of x)
+    const int write_red = (c->nranks == 1 || c->rank == 0 || c->replicate_xr) ? 1 : 0;
     if (c->n_fast_groups == 0) hipLaunchKernelGGL(scatter_reduced_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->s_ptr(), c->d_red_boff.p, n, c->x.p, write_red);
     const int64_t nel_local = (int64_t)(c->d_elim_diag.n);
     if (nel_local > 0) {

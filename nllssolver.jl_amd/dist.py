@@ -4,10 +4,13 @@ Residual blocks are partitioned BY ELIMINATED VARIABLE (bundle adjustment: by po
 contiguous range of points and every cost block that touches them, so the point block-rows of A.data
 (99.8 % of its bytes) are written by exactly one rank and never communicated.  What is summed over ranks
 (torch.distributed: RCCL over xGMI on the GPU box, gloo in the CPU tests):
-  stage 0  after the gradient sweep : [cost | reduced-block rows of A.data | reduced part of b]   (~0.3 MB)
-  stage 1  after local elimination  : [S (dense, lower) | s]  -- the real collective of this path
-  stage 2  after back-substitution  : x  (each rank contributes its own points)                    (~2.4 MB)
-plus one scalar per cost sweep; dogleg / gradient descent also sum the gradient b once per iteration (~2.4 MB).
+  stage 0  after the gradient sweep : [cost | reduced-block rows of A.data | reduced part of b]   (~0.3 MB, once per iteration)
+  stage 1  after local elimination  : [S | s] in band layout -- the real collective of this path   (3.4 MB at config 4, once per LM trial)
+A Levenberg-Marquardt trial needs nothing else but ONE gather of six scalars per rank (cost, x'Hx, g'x, max|x|, |x|^2 and the
+factorisation status -- every rank raises on the reduced status, so a rank-local bad pivot cannot leave the ranks in different
+collectives): the reduced system is factorised on every rank, so every rank holds the reduced part of the step, retracts the
+reduced variables and its own eliminated ones itself and sweeps its own cost blocks -- the step x is never summed (stage 2, 2.4 MB,
+is only taken by plain solve() calls: Newton, dogleg).  Dogleg / gradient descent also sum the gradient b once per iteration.
 """
 import numpy as np
 
@@ -94,13 +97,50 @@ class ShardedLS(MultiVariateLSgpu):
     def lm_trial(self, dlambda):
         if not self.sharded:
             return super().lm_trial(dlambda)
-        # sharded: damp, solve (two buffer reductions), then retraction + cost sweep + step statistics in one call and ONE
-        # three-scalar reduction; what the iterator asks next (quadform, step_maxabs) is answered from here
-        self.uniformscaling(dlambda); self.solve(_in_trial=True)
+        # sharded: damp, local elimination, ONE buffer reduction ([S | s]), replicated reduced solve + own back-substitution, then
+        # retraction + cost sweep + step statistics in one call and ONE gather of six scalars per rank; what the iterator asks next
+        # (quadform, step_maxabs) is answered from here.  No reduction of x: every rank holds the reduced part of the step.
+        self.uniformscaling(dlambda)
+        self._x = None; self._trial = None
+        self.ctx.solve_local()
+        self._allreduce_buffer(1)
+        self.ctx.solve_finish_replicated()                 # enqueue only: the status comes home with the trial's scalars
         out = self.ctx.trial_local(_capi.VARS_NEXT, _capi.VARS_CURRENT)
-        c, a, g = self._allreduce_scalars(out[:3])
-        self._trial = ((a, g), float(out[3]), float(np.sqrt(out[4])))
-        return c
+        allv = self._allgather_scalars(out)                # [world][6]
+        status = int(allv[:, 5].max())
+        if status != 0:                                    # raised on EVERY rank, from the reduced value
+            raise _capi.NllsError(_capi.ERR_NOT_SPD, f"factorisation met a zero pivot on some rank (code {status})")
+        c, a, g = allv[:, 0].sum(), allv[:, 1].sum(), allv[:, 2].sum()
+        self._trial = ((float(a), float(g)), float(allv[:, 3].max()), float(np.sqrt(allv[:, 4].sum())))
+        return float(c)
+
+    def _allgather_scalars(self, values):
+        import torch
+        v = torch.tensor(np.asarray(values, dtype=np.float64))
+        if self.host_staged:
+            outl = [torch.zeros_like(v) for _ in range(self.world)]
+            if self.world > 1: self.dist.all_gather(outl, v)
+            else: outl = [v]
+            return torch.stack(outl).numpy()
+        with torch.cuda.stream(self._tstream):
+            vd = v.cuda(self.device, non_blocking=True)
+            outd = torch.empty((self.world, v.numel()), dtype=torch.float64, device=f"cuda:{self.device}")
+            self.dist.all_gather_into_tensor(outd, vd)
+            return outd.cpu().numpy()
+
+    def variables(self, which=_capi.VARS_CURRENT):
+        """The complete variable set: every rank contributes the variables it has kept up to date (its own eliminated blocks'; rank 0
+        also the reduced ones), one sum over ranks."""
+        if not self.sharded or self.world == 1:
+            return super().variables(which)
+        import torch
+        t = torch.from_numpy(self.ctx.get_variables_owned(which))
+        if self.host_staged:
+            self.dist.all_reduce(t)
+            return t.numpy()
+        with torch.cuda.stream(self._tstream):
+            t = t.cuda(self.device); self.dist.all_reduce(t); t = t.cpu()
+        return t.numpy()
 
     def solve(self, _in_trial=False):
         if not self.sharded:
@@ -108,11 +148,18 @@ class ShardedLS(MultiVariateLSgpu):
         self._x = None; self._trial = None
         self.ctx.solve_local()
         self._allreduce_buffer(1)
-        if _in_trial and not self.host_staged:
-            self.ctx.solve_finish_async()              # no synchronisation: nlls_trial_local reports the factorisation status
-        else:
+        # the factorisation status is made collective before anyone raises: a zero pivot in a rank's own eliminated blocks is seen
+        # by that rank only, and it must still take part in the stage-2 reduction its peers enter
+        err = None
+        try:
             self.ctx.solve_finish()
+        except _capi.NllsError as e:
+            if e.code != _capi.ERR_NOT_SPD:
+                raise
+            err = e
         self._allreduce_buffer(2)
+        if self._allreduce_scalars([1.0 if err else 0.0], "max")[0] != 0:
+            raise err if err else _capi.NllsError(_capi.ERR_NOT_SPD, "factorisation met a zero pivot on another rank")
 
     def initlambda(self):
         m = self.ctx.max_abs_diag()

@@ -29,6 +29,8 @@ def main():
     from nllssolver_jl_amd.linearsystem import MultiVariateLSgpu
 
     seed = int(sys.argv[5]) if len(sys.argv) > 5 else 21
+    if seed < 0:
+        return singular_point_block(rank, world, dist, staged)
     rng = np.random.default_rng(seed)
     ncr = int(rng.integers(12, 90))             # (sharding partitions by eliminated block: stay within what the Schur kernels take)
     shape = (40, 2000, 0.15) if seed == 21 else (ncr, int(rng.integers(300, 4000)), float(rng.uniform(4.0, 10.0)) / ncr)
@@ -80,6 +82,39 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: sharded == unsharded (cost {cs:.6e}, owned {info['local_ncost']} of {p.ncosts()} cost blocks)")
+
+
+def singular_point_block(rank, world, dist, staged):
+    """A zero pivot that only ONE rank sees (an eliminated block whose diagonal block is exactly zero): every rank must raise
+    ERR_NOT_SPD -- from the reduced status -- instead of one rank leaving the collectives its peers are in (a hang)."""
+    import nllssolver_jl_amd as N
+    from nllssolver_jl_amd import synthetic, _capi
+    from nllssolver_jl_amd.dist import ShardedLS
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(30, 1200, 0.2, seed=5), 1e-3, 1e-3)
+    # the LAST point is seen by the first camera only, and that camera's pose is all zeros: the point's Jacobian -- and so its
+    # diagonal block C_v -- is exactly zero.  The last point belongs to the last rank.
+    g = next(iter(p.costs.values())); vi, da = g.arrays()
+    last = p.nvariables
+    keep = vi[:, 1] != last
+    vi2 = np.concatenate([vi[keep], [[1, last]]]); da2 = np.concatenate([da[keep], [[0.0, 0.0]]])
+    g.set_arrays(vi2, da2)
+    p.variables[:6] = 0.0
+    sh = ShardedLS(p, np.ones(p.nvariables, bool), rank=rank, world=world, dist=dist, host_staged=staged, force_collectives=True)
+    sh.costgradhess()
+    raised = 0
+    try:
+        sh.solve()                                  # undamped: the zero block meets the factorisation as it is
+    except _capi.NllsError as e:
+        assert e.code == _capi.ERR_NOT_SPD; raised += 1
+    try:
+        sh.lm_trial(0.0)
+    except _capi.NllsError as e:
+        assert e.code == _capi.ERR_NOT_SPD; raised += 1
+    assert raised == 2, raised                      # on EVERY rank, although only one rank owns the singular block
+    c = sh.lm_trial(1e-3 * sh.initlambda() * 1e6)   # and the ranks are still in step: a damped trial goes through
+    assert np.isfinite(c)
+    sh.close(); dist.barrier(); dist.destroy_process_group()
+    print(f"rank {rank}: singular block raised on every rank")
 
 
 if __name__ == "__main__":

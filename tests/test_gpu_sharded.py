@@ -11,9 +11,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world,backend,seed", [(2, "gloo", 21), (3, "gloo", 21), (1, "nccl", 21), (2, "gloo", 401), (3, "gloo", 402), (2, "gloo", 403)])
+@pytest.mark.parametrize("world,backend,seed", [(2, "gloo", 21), (3, "gloo", 21), (1, "nccl", 21), (2, "gloo", 401), (3, "gloo", 402), (2, "gloo", 403),
+                                                (2, "gloo", -1), (3, "gloo", -1)])
 def test_sharded_matches_unsharded(world, backend, seed):
-    """(1, "nccl"): the local / reduce / finish route over RCCL with device buffers, one rank -- the plumbing bench.py --gpus N uses."""
+    """(1, "nccl"): the local / reduce / finish route over RCCL with device buffers, one rank -- the plumbing bench.py --gpus N uses.
+    seed -1: a zero pivot only one rank sees must be raised on every rank (no rank left behind in a collective)."""
     port = str(29500 + world + seed % 50)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port, backend, str(seed)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -30,4 +32,4 @@ def test_sharded_matches_unsharded(world, backend, seed):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
-        assert "sharded == unsharded" in out
+        assert ("sharded == unsharded" if seed >= 0 else "singular block raised on every rank") in out
