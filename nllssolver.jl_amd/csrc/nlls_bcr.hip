@@ -378,6 +378,145 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same panel machinery for the DENSE reduced system (S column-major, ld = npad, lower triangle; nlls_solve.hip): block
+// column k of 64 columns = four tile columns.  Workgroup ch takes the tile rows 4 (k + 1) + 3 ch .. + 2 below the diagonal
+// block as its X rows; every workgroup factors the 64 x 64 diagonal block itself (identical bits).  Out: L in place of the
+// panel (unit lower, Delta on the diagonal of the diagonal block), W = L Delta of the rows below into the panel workspace
+// (what the MFMA trailing update multiplies with), inv(L_JJ)' of the four diagonal tiles for the backward pass.
+// Replaces one ldlt_diag_kernel (64 dependent pivots with two barriers each: 73 us) + trsm_panel_kernel (one thread per row,
+// uncoalesced: 55 us) launch pair of round 1.
+// ---------------------------------------------------------------------------------------------------
+struct DensePanelArgs { double* S; double* W; double* LiD; int npad, k, T; int* status; };
+__global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int NT = 4, ND = NT * (NT + 1) / 2, PR = NT + BCR_CH;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int hw = wave < 4 ? wave - 1 : wave - 2; const bool helper = wave != 0 && wave != 4;
+    const int ch = blockIdx.x, npad = a.npad, c0 = 64 * a.k;                  // first column of the panel
+    const int R0 = NT * (a.k + 1) + BCR_CH * ch;                                // first X tile row of this workgroup
+    const int RX = R0 >= a.T ? 0 : (a.T - R0 < BCR_CH ? a.T - R0 : BCR_CH);
+    const bool lead = ch == 0;
+    if (RX == 0 && !lead) return;
+    double* Dt = sm; double* Xt = Dt + ND * BTS; double* Wp = Xt + BCR_CH * NT * BTS; double* dvec = Wp + 2 * PR * 16 * BP; double* Li = dvec + 64;
+    const int oDt = 0, oXt = ND * BTS, oWp = oXt + BCR_CH * NT * BTS, odv = oWp + 2 * PR * 16 * BP, oSpare = odv + 64 + 2 * 16 * BP;
+    // ---- landing: element (row a2, column b2) of a tile; consecutive threads walk a column of S (consecutive addresses)
+    {
+        constexpr int DQ = (ND * 256 + BCR_T - 1) / BCR_T, XQ = (BCR_CH * NT * 256 + BCR_T - 1) / BCR_T;
+        double dv[DQ], xv[XQ];
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; dv[q] = 0.0;
+            if (w < ND * 256) { const int t = w >> 8, b2 = (w >> 4) & 15, a2 = w & 15; int I = 0; while ((I + 1) * (I + 2) / 2 <= t) ++I; const int K = t - I * (I + 1) / 2;
+                int row = 16 * I + a2, col = 16 * K + b2; if (row < col) { const int tmp = row; row = col; col = tmp; }
+                dv[q] = a.S[(size_t)(c0 + row) + (size_t)npad * (c0 + col)]; } }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) { const int w = tid + q * BCR_T; xv[q] = 0.0;
+            if (w < RX * NT * 256) { const int t = w >> 8, b2 = (w >> 4) & 15, a2 = w & 15, R = t / NT, K = t - R * NT;
+                xv[q] = a.S[(size_t)(16 * (R0 + R) + a2) + (size_t)npad * (c0 + 16 * K + b2)]; } }
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; if (w < ND * 256) Dt[(w >> 8) * BTS + (w & 15) * BP + ((w >> 4) & 15)] = dv[q]; }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) { const int w = tid + q * BCR_T; if (w < RX * NT * 256) Xt[(w >> 8) * BTS + (w & 15) * BP + ((w >> 4) & 15)] = xv[q]; }
+    }
+    __syncthreads();
+    auto updates = [&](int Jp, int w0, int nh) {
+        const int oWprev = oWp + (Jp & 1) * PR * 16 * BP, ord = odv + (Jp & 1) * 32 + 16;
+        const int m = NT - 1 - Jp; if (m <= 0) return;
+        const int nDj = m * (m + 1) / 2 - 1, ntot = nDj + RX * m;
+        for (int u0 = w0; u0 < ntot; u0 += 3 * nh) {
+            int C[3], Wi[3], Wk[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int u = u0 + q * nh; C[q] = oSpare; Wi[q] = oWprev; Wk[q] = oWprev;
+                if (u >= ntot) continue;
+                if (u < nDj) { int up = u + 1, K = Jp + 1, cnt = m; while (up >= cnt) { up -= cnt; --cnt; ++K; }
+                    const int I = K + up; C[q] = oDt + bcr_dtile(I, K) * BTS; Wi[q] = oWprev + I * 16 * BP; Wk[q] = oWprev + K * 16 * BP; }
+                else { int v = u - nDj, R = 0; while (v >= m) { v -= m; ++R; } const int K = Jp + 1 + v;
+                    C[q] = oXt + (R * NT + K) * BTS; Wi[q] = oWprev + (NT + R) * 16 * BP; Wk[q] = oWprev + K * 16 * BP; }
+            }
+            bcr_update_batch<3>(sm, C, Wi, Wk, ord);
+        }
+    };
+    // panel tile (row-major W in LDS) of block column Jp -> S (L = W / Delta, column-major) and, for X rows, W -> the panel workspace
+    auto store_tile = [&](const double* Wt, const double* rd, int grow, int gcol, bool want_w) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int e = lane + 64 * r, a2 = e & 15, b2 = e >> 4; const double w = Wt[a2 * BP + b2];
+            a.S[(size_t)(grow + a2) + (size_t)npad * (gcol + b2)] = w * rd[b2];
+            if (want_w) a.W[(size_t)(grow + a2) + (size_t)npad * (gcol - c0 + b2)] = w; }
+    };
+    auto exports = [&](int Jp, int w0, int nh) {
+        const double* Wprev = Wp + (Jp & 1) * PR * 16 * BP; const double* rd = dvec + (Jp & 1) * 32 + 16; const double* dd = dvec + (Jp & 1) * 32; const double* Lid = Li + (Jp & 1) * 16 * BP;
+        const int nDe = lead ? NT - Jp + 1 : 0, ne = nDe + RX;      // lead: inv(L_JJ)', the diagonal tile itself, the NT-1-Jp tiles below it
+        for (int e = w0; e < ne; e += nh) {
+            if (lead && e == 0) { double* dst = a.LiD + ((size_t)a.k * NT + Jp) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int q = lane + 64 * r; dst[q] = Lid[(q >> 4) * BP + (q & 15)]; } }
+            else if (lead && e == 1) {                               // the diagonal tile: unit lower L below the diagonal, Delta on it
+                const double* Wt = Wprev + Jp * 16 * BP;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int q = lane + 64 * r, a2 = q & 15, b2 = q >> 4;
+                    if (a2 >= b2) a.S[(size_t)(c0 + 16 * Jp + a2) + (size_t)npad * (c0 + 16 * Jp + b2)] = a2 == b2 ? dd[b2] : Wt[a2 * BP + b2] * rd[b2]; } }
+            else if (e < nDe) { const int I = Jp + e - 1; store_tile(Wprev + I * 16 * BP, rd, c0 + 16 * I, c0 + 16 * Jp, false); }
+            else { const int R = e - nDe; store_tile(Wprev + (NT + R) * 16 * BP, rd, 16 * (R0 + R), c0 + 16 * Jp, true); }
+        }
+    };
+    bdouble4_t diag = {0, 0, 0, 0};
+    for (int J = 0; J < NT; ++J) {
+        double* Wb = Wp + (J & 1) * PR * 16 * BP; double* Lid = Li + (J & 1) * 16 * BP; double* db = dvec + (J & 1) * 32;
+        if (wave == 0) bcr_factor<false>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, c0 + 16 * J, lead, nullptr, 0.0);
+        else if (helper && J > 0) { updates(J - 1, hw, 6); exports(J - 1, hw, 6); }
+        bcr_lds_barrier();
+        if (J + 1 < NT) {
+            if (wave == 0) bcr_panel_update_diag(Dt + bcr_dtile(J + 1, J) * BTS, Lid, db + 16, Wb + (J + 1) * 16 * BP, Dt + bcr_dtile(J + 1, J + 1) * BTS, diag);
+            else if (helper) {
+                const int nD = NT - J - 2;
+                for (int p = hw; p < nD + RX; p += 6) {
+                    if (p < nD) bcr_panel_tile(Dt + bcr_dtile(J + 2 + p, J) * BTS, Lid, Wb + (J + 2 + p) * 16 * BP);
+                    else bcr_panel_tile(Xt + ((p - nD) * NT + J) * BTS, Lid, Wb + (NT + p - nD) * 16 * BP);
+                }
+            }
+        } else {
+            for (int p = wave; p < RX; p += 8) bcr_panel_tile(Xt + (p * NT + J) * BTS, Lid, Wb + (NT + p) * 16 * BP);
+        }
+        bcr_lds_barrier();
+    }
+    exports(NT - 1, wave, 8);
+}
+size_t dense_panel_lds() { constexpr int NT = 4, ND = NT * (NT + 1) / 2; return sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS); }
+void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status) {
+    const int T = npad / 16, below = T - 4 * (k + 1), nch = below > 0 ? (below + BCR_CH - 1) / BCR_CH : 1;
+    DensePanelArgs a{S, W, LiD, npad, k, T, status};
+    hipLaunchKernelGGL(dense_panel_kernel, dim3((unsigned)nch), dim3(BCR_T), dense_panel_lds(), st, a);
+}
+// x_k = L_kk^-T (y_k - acc_k) for the 64 unknowns of block column kb, from the four inverted diagonal tiles and the L tiles below
+// them (one wavefront; replaces a 64-step lane-serial substitution)
+__global__ __launch_bounds__(64) void dense_bwd_diag_kernel(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x) {
+    __shared__ double r[64], xs[64], uu[16];
+    const int lane = threadIdx.x, c = lane & 15, gq = lane >> 4, c0 = 64 * kb;
+    { const int g = c0 + lane; r[lane] = (g < n) ? S[(size_t)n + (size_t)npad * g] - acc[g] : 0.0; xs[lane] = 0.0; }     // y: row n of the factor
+    __syncthreads();
+    for (int J = 3; J >= 0; --J) {
+        double s = 0.0;
+        for (int K = J + 1; K < 4; ++K) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int a2 = gq + 4 * q; s = fma(S[(size_t)(c0 + 16 * K + a2) + (size_t)npad * (c0 + 16 * J + c)], xs[16 * K + a2], s); }
+        }
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        if (gq == 0) uu[c] = r[16 * J + c] - s;
+        __syncthreads();
+        const double* Lk = LiD + ((size_t)kb * 4 + J) * 256 + c * 16;
+        double xv = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv = fma(Lk[gq + 4 * q], uu[gq + 4 * q], xv);
+        xv += __shfl_xor(xv, 16, 64); xv += __shfl_xor(xv, 32, 64);
+        if (gq == 0) { const int g = c0 + 16 * J + c; const double v = g < n ? xv : 0.0; xs[16 * J + c] = v; if (g < n) x[g] = v; }
+        __syncthreads();
+    }
+}
+void launch_dense_bwd_diag(hipStream_t st, const double* S, const double* LiD, int npad, int kb, int n, const double* acc, double* x) {
+    hipLaunchKernelGGL(dense_bwd_diag_kernel, dim3(1), dim3(64), 0, st, S, LiD, npad, kb, n, acc, x);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Schur update of a level: one wavefront per output tile, operands straight from the exported panels (L2 / MALL):
 //   dst (-)= sum_c  sum_J  Wx[a_c][J] Lx[b_c][J]'          (Lx = Wx / Delta)
 // ---------------------------------------------------------------------------------------------------

@@ -44,4 +44,8 @@ struct BcrSolver {
     void release() { ws.release(); d_elim.release(); d_upd.release(); levels.clear(); ready = false; }
 };
 
+// dense reduced system (nlls_solve.hip): panel factorisation of block column k (64 columns) and the backward pass's diagonal block
+void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status);
+void launch_dense_bwd_diag(hipStream_t st, const double* S, const double* LiD, int npad, int kb, int n, const double* acc, double* x);
+
 }  // namespace nlls

@@ -982,22 +982,28 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ S
         for (int a = 0; a < 2; ++a) av[a] = Pi[r0 + 16 * a + li + LDT * (kk + lk)];
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Pj[c0 + 16 * b2 + li + LDT * (kk + lk)];
+        // the product is formed TRANSPOSED (operands swapped): the accumulator then has the ROW of C on the lane index, and a store
+        // instruction covers 16 consecutive rows of one column of the column-major S (128 contiguous bytes) instead of 16 columns
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b2], acc[a][b2], 0, 0, 0);
+            for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
     }
-    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4*reg
+    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4*reg -- of the TRANSPOSED tile: C row = lane & 15
     double* Cg = S + (size_t)ib * NB + (size_t)npad * jb * NB;
+    double cold[2][2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + 16 * a + lk + 4 * r, col = c0 + 16 * b2 + li;
-                Cg[(size_t)row + (size_t)npad * col] -= acc[a][b2][r];
-            }
+            for (int r = 0; r < 4; ++r) cold[a][b2][r] = Cg[(size_t)(r0 + 16 * a + li) + (size_t)npad * (c0 + 16 * b2 + lk + 4 * r)];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cg[(size_t)(r0 + 16 * a + li) + (size_t)npad * (c0 + 16 * b2 + lk + 4 * r)] = cold[a][b2][r] - acc[a][b2][r];
 }
 // backward substitution L' x = z (unit diagonal), block by block from the bottom.  z = D^-1 L^-1 s is row n of the factor.
 // step 1 (one workgroup per 64-column block kb, many row blocks): partial[kb][j] = sum_{i > kb block} L[i][kb*64+j] * x[i]
@@ -2179,13 +2185,13 @@ int enqueue_reduced_solve(nlls_ctx* c) {
         else LAUNCH_BAND(16, 4);
 #undef LAUNCH_BAND
     } else {
+        // blocked right-looking LDL', 64 columns at a time: the panel (diagonal block on the matrix cores with look-ahead, the rows below
+        // it as tile products: dense_panel_kernel, nlls_bcr.hip) and the MFMA trailing update
+        double* LiD = c->Lwork.p + (size_t)npad * NB + npad;         // inv(L_JJ)' of every diagonal tile (backward pass)
         for (int k = 0; k < nblk; ++k) {
-            hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(256), 0, c->stream, c->S.p, npad, k, c->d_status.p);
+            launch_dense_panel(c->stream, c->S.p, c->Lwork.p, LiD, npad, k, c->d_status.p);
             const int T = nblk - k - 1;
-            if (T > 0) {
-                hipLaunchKernelGGL(trsm_panel_kernel, dim3(T), dim3(64), 0, c->stream, c->S.p, c->Lwork.p, npad, k);
-                hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, c->Lwork.p, npad, k, nblk);
-            }
+            if (T > 0) hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, c->Lwork.p, npad, k, nblk);
         }
         // backward substitution into acc / s (x)
         double* acc = c->Lwork.p + (size_t)npad * NB;
@@ -2194,7 +2200,7 @@ int enqueue_reduced_solve(nlls_ctx* c) {
         for (int kb = nb_real - 1; kb >= 0; --kb) {
             const int below = nb_real - 1 - kb;
             if (below > 0) hipLaunchKernelGGL(bwd_gemv_kernel, dim3(below), dim3(256), 0, c->stream, c->S.p, npad, kb, n, c->s_ptr(), acc);
-            hipLaunchKernelGGL(bwd_diag_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, npad, kb, n, acc, c->s_ptr());
+            launch_dense_bwd_diag(c->stream, c->S.p, LiD, npad, kb, n, acc, c->s_ptr());
         }
     }
     HIPCHK(hipGetLastError());
