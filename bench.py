@@ -34,7 +34,7 @@ def sweep_code_hash():
     counters it holds, and a stale file is refused (roofline.traffic = null) instead of being quoted."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("nlls_sweep.hip", "nlls_kinds.hpp", "nlls_structure.cpp"):
+    for f in ("nlls_sweep.hip", "nlls_wave.hpp", "nlls_kinds.hpp", "nlls_structure.cpp"):
         h.update(open(os.path.join(ROOT, "nllssolver.jl_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -121,7 +121,7 @@ def main():
     # (the adaptive-kernel costs are negative log-likelihoods: 'dcost < bestcost * reldcost', src/optimize.jl:152, then needs reldcost = +inf to stay off)
     options = N.NLLSOptions(maxiters=10 ** 9, reldcost=np.inf if args.workload == "ba_so3_500x50k" else -np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
 
-    def fresh_loop():
+    def fresh_loop(ls, problem, start_vars):
         ls.ctx.set_variables(start_vars, VARS_CURRENT)
         ls.ctx.copy_variables(VARS_NEXT, VARS_CURRENT)
         data = Opt.NLLSInternal(ls, time.perf_counter_ns())
@@ -134,19 +134,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    loop = fresh_loop()
-    for _ in range(args.warmup):
-        loop.iteration()
-    loop = fresh_loop()                     # same start point for the timed region
-    ls.ctx.profile_sweep(True)              # event pairs around the accumulate launches of the timed loop itself (in-situ figure)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loop.iteration()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_staged else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    def timed_loop(ls, problem, start_vars, profile=False):
+        """W untimed + exactly K timed outer iterations from the same start point; barrier + device synchronisation on both sides,
+        MAX over ranks"""
+        loop = fresh_loop(ls, problem, start_vars)
+        for _ in range(args.warmup):
+            loop.iteration()
+        loop = fresh_loop(ls, problem, start_vars)
+        if profile:
+            ls.ctx.profile_sweep(True)      # stamps around the accumulate launches of the timed loop itself (in-situ figure)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop.iteration()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_staged else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        return loop, elapsed
+
+    loop, elapsed = timed_loop(ls, problem, start_vars, profile=True)
     data = loop.data
     final_cost, start_cost = data.bestcost, data.startcost
     insitu = ls.ctx.profile_sweep(False, read=True)       # (avg, min, max ms, samples) of the accumulate launches inside the timed loop
@@ -213,6 +220,21 @@ def main():
                           "note": "a banded LDL' is a chain of dependent pivots: latency-, not MFMA-bound -- the fraction says how far, not how well tuned"
                                   if mode == 2 else None}
 
+    # ---- weak-scaling leg (N > 1 only): N x 100k points against the SAME cameras, sharded by point -- per-rank sweeps, elimination and
+    # back-substitution stay those of the one-GPU problem, the replicated reduced system keeps its size; what grows is the data volume
+    weak = None
+    if world > 1 and args.workload == "ba_1kx100k":
+        wproblem = synthetic.create_ba_problem(ncam, world * npts, prop, seed=1, robust=N.HuberKernel(0.01), outlier_frac=0.05, outlier_sigma=0.05)
+        wproblem = synthetic.perturb_ba_problem(wproblem, 1e-3, 1e-3)
+        wls = ShardedLS(wproblem, np.ones(wproblem.nvariables, bool), flags=flags, device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged)
+        wloop, welapsed = timed_loop(wls, wproblem, wproblem.variables.copy())
+        weak = {"scaling": "weak", "workload": f"{ncam} cameras x {world * npts} points ({wproblem.ncosts()} residual blocks; {npts} points per rank)",
+                "value": round(args.steps / welapsed, 3), "unit": "LM iters/s", "ms_per_step": round(1e3 * welapsed / args.steps, 4),
+                "residual_blocks_per_s": round(wproblem.ncosts() * args.steps / welapsed, 1),
+                "lm_trials_per_s": round(wloop.data.linearsolvers / welapsed, 1), "local_residual_blocks": int(wls.local_nobs),
+                "start_cost": wloop.data.startcost, "final_cost": wloop.data.bestcost}
+        wls.close()
+
     # ---- CPU baseline: the oracle's own optimize! loop on a bounded sample of the same workload (rank 0, N = 1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -247,6 +269,8 @@ def main():
                    "lm_trials_per_s": round(data.linearsolvers / elapsed, 1)},
             "roofline": roofline, "roofline_solve": roofline_solve, "cpu_baseline": cpu,
         }
+        if weak:
+            out["weak_scaling"] = weak
         print(json.dumps(out))
     ls.close()
     if dist is not None:

@@ -1,0 +1,318 @@
+// nlls_cost.hip -- cost sweep, retraction, step statistics and optimizesingles! (gfx950).
+//
+//   cost(vars, costs)                     src/cost.jl:10-13 -> src/residual.jl:49-55
+//   update!(to, from, linsystem)          src/linearsystem.jl:206-213
+//   optimizesingles!                      src/optimize.jl:60-76,183-205
+//
+// Built WITHOUT the -fno-honor-nans / -fno-signed-zeros flags of nlls_sweep.hip: the NaN / Inf behaviour of these kernels is part of
+// the reference's semantics (a NaN cost is accepted by '!(cost > bestcost)', the termination flags report non-finite costs and steps).
+#include <cstring>
+#include <utility>
+
+#include "nlls_wave.hpp"
+
+namespace nlls {
+
+// ================================================================================================
+// cost sweep   src/cost.jl:10-13 -> src/residual.jl:49-55
+// ================================================================================================
+template <int KIND>
+__global__ __launch_bounds__(TPB) void cost_kernel(const double* __restrict__ vars, const double* __restrict__ data,
+                                                   const uint32_t* __restrict__ voff, const uint32_t* __restrict__ index,
+                                                   int64_t n, RobustSpec rk, double* __restrict__ partials) {
+    using R = Res<KIND>;
+    __shared__ double red[TPB / 64];
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const int64_t k = index ? index[i] : i;
+        double d[R::NDATA]; uint32_t vo[R::NDEPS];
+#pragma unroll
+        for (int q = 0; q < R::NDATA; ++q) d[q] = data[k * R::NDATA + q];
+#pragma unroll
+        for (int q = 0; q < R::NDEPS; ++q) vo[q] = voff[k * R::NDEPS + q];
+        acc += block_cost<KIND>(vars, vo, d, rk);
+    }
+    double t = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// final deterministic reduction of the per-workgroup partials
+__global__ __launch_bounds__(TPB) void reduce_partials_kernel(const double* __restrict__ partials, int64_t n, double* __restrict__ out) {
+    __shared__ double red[TPB / 64];
+    double acc = 0;
+    for (int64_t i = threadIdx.x; i < n; i += TPB) acc += partials[i];
+    double t = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+// ================================================================================================
+// vector helpers
+// ================================================================================================
+// update!(to, from, linsystem)   src/linearsystem.jl:206-213
+__global__ void retract_kernel(const int32_t* __restrict__ kind, const int32_t* __restrict__ dim, const uint32_t* __restrict__ voff,
+                               const uint32_t* __restrict__ vboff, int64_t nvar, const double* __restrict__ from,
+                               const double* __restrict__ x, double* __restrict__ to) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nvar) retract_one(kind, dim, voff, vboff, i, from, x, to);
+}
+// maximum(abs, x) and x'x   (src/optimize.jl:149, src/iterators.jl:160; NaN propagates like Julia's maximum).
+// Two stages: per-workgroup partials (max, nan flag, sum of squares), then one small finishing workgroup.
+constexpr int RED_BLOCKS = 256;
+__global__ __launch_bounds__(TPB) void step_stats_partial_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ part) {
+    __shared__ double red[TPB / 64];
+    double m = 0, s = 0; bool nan = false;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) { double v = x[i]; nan |= is_nan_bits(v); m = fmax(m, fabs(v)); s += v * v; }
+    double mm = block_max(m, red);
+    double ss = block_sum(s, red);
+    double nn = block_max(nan ? 1.0 : 0.0, red);
+    if (threadIdx.x == 0) { part[3 * blockIdx.x] = mm; part[3 * blockIdx.x + 1] = nn; part[3 * blockIdx.x + 2] = ss; }
+}
+__global__ __launch_bounds__(TPB) void step_stats_finish_kernel(const double* __restrict__ part, int nb, double* __restrict__ out) {
+    __shared__ double red[TPB / 64];
+    double m = 0, s = 0, nn = 0;
+    for (int i = threadIdx.x; i < nb; i += TPB) { m = fmax(m, part[3 * i]); nn = fmax(nn, part[3 * i + 1]); s += part[3 * i + 2]; }
+    double mm = block_max(m, red); double ss = block_sum(s, red); double n2 = block_max(nn, red);
+    if (threadIdx.x == 0) { out[1] = n2 > 0 ? __longlong_as_double(0x7ff8000000000000LL) : mm; out[2] = ss; }
+}
+// initlambda's max |H_ii|   src/iterators.jl:131-137
+__global__ __launch_bounds__(TPB) void max_abs_diag_partial_kernel(const double* __restrict__ A, const int64_t* __restrict__ diag_off,
+                                                                   const int32_t* __restrict__ bs, const uint8_t* __restrict__ rowmask, int64_t nb, int64_t ld_dense, double* __restrict__ part) {
+    __shared__ double red[TPB / 64];
+    double m = 0; bool nan = false;
+    for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < nb; k += (int64_t)gridDim.x * TPB) {
+        const int n = bs[k]; const int64_t o = diag_off[k]; const int64_t ld = ld_dense ? ld_dense : n;
+        if (o < 0 || (rowmask && !rowmask[k])) continue;
+        for (int i = 0; i < n; ++i) { const double a = A[o + i + ld * i]; nan |= is_nan_bits(a); m = fmax(m, fabs(a)); }
+    }
+    double mm = block_max(m, red);
+    double nn = block_max(nan ? 1.0 : 0.0, red);             // Julia's max propagates NaN (src/iterators.jl:131-137): so does this
+    if (threadIdx.x == 0) part[blockIdx.x] = nn > 0 ? __longlong_as_double(0x7ff8000000000000LL) : mm;
+}
+__global__ __launch_bounds__(TPB) void max_finish_kernel(const double* __restrict__ part, int nb, double* __restrict__ out, int slot) {
+    __shared__ double red[TPB / 64];
+    double m = 0;
+    bool nan = false;
+    for (int i = threadIdx.x; i < nb; i += TPB) { nan |= is_nan_bits(part[i]); m = fmax(m, part[i]); }
+    double mm = block_max(m, red);
+    double nn = block_max(nan ? 1.0 : 0.0, red);
+    if (threadIdx.x == 0) out[slot] = nn > 0 ? __longlong_as_double(0x7ff8000000000000LL) : mm;
+}
+
+// ================================================================================================
+// optimizesingles!(problem, options, indices)   src/optimize.jl:60-76,183-205
+// Every listed variable is optimised on its own -- all other variables fixed -- against the cost blocks that depend on
+// it: the whole outer loop (src/optimize.jl:109-180) with the Levenberg-Marquardt iterator (src/iterators.jl:139-172) and
+// the univariate linear system (src/linearsystem.jl:12-32,126-130) runs in ONE thread per variable; the subproblems are
+// independent (no cost block may hold two of the listed variables), so one launch optimises them all.
+// ================================================================================================
+struct SinglesGroup { int kind; const double* data; const uint32_t* voff; RobustSpec rk; };
+struct SinglesOpt { int maxiters, maxfails; double reldcost, absdcost, dstep; };
+constexpr int SGL_MAXD = 6;                                   // dof of a variable optimised this way (registry maximum)
+
+// one cost block of the subproblem: the variable's storage comes from `vloc`, everything else from `vars`
+template <int KIND>
+NLLS_DEV void singles_block(const SinglesGroup& G, uint32_t k, int slot, const double* __restrict__ vars, const double* vloc,
+                            bool want_gh, double& cost, double* g, double* H) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    double d[R::NDATA]; uint32_t vo[R::NDEPS];
+#pragma unroll
+    for (int q = 0; q < R::NDATA; ++q) d[q] = G.data[(size_t)k * R::NDATA + q];
+#pragma unroll
+    for (int q = 0; q < R::NDEPS; ++q) vo[q] = G.voff[(size_t)k * R::NDEPS + q];
+    double st[R::NDEPS][MAXST];
+    BlockGH<KIND>::load(vars, vo, st);
+    static_for<R::NDEPS>([&](auto Sc) {
+        constexpr int S = decltype(Sc)::value;
+        if (S == slot) {
+#pragma unroll
+            for (int q = 0; q < I::sto(S); ++q) st[S][q] = vloc[q];
+        }
+    });
+    BlockGH<KIND> B; B.compute_st(st, d, G.rk, false);        // an adaptive kernel variable stays fixed (it is not the one being optimised)
+    cost += B.cost;
+    if (!want_gh) return;
+    static_for<R::NDEPS>([&](auto Sc) {
+        constexpr int S = decltype(Sc)::value;
+        if (S == slot) {
+            constexpr int DS = I::dof(S);
+#pragma unroll
+            for (int j = 0; j < DS; ++j) {
+                g[j] += g_elem<KIND, S>(B, j);
+#pragma unroll
+                for (int i = 0; i < DS; ++i) H[i + SGL_MAXD * j] += h_elem<KIND, S, S>(B, i, j);
+            }
+        }
+    });
+}
+
+__global__ __launch_bounds__(64) void singles_lm_kernel(const SinglesGroup* __restrict__ groups, const int64_t* __restrict__ selvar, int64_t nsel,
+                                                        const int64_t* __restrict__ cptr, const int32_t* __restrict__ cgroup, const uint32_t* __restrict__ cidx,
+                                                        const int32_t* __restrict__ cslot, const int32_t* __restrict__ vkind, const int32_t* __restrict__ vdim,
+                                                        const uint32_t* __restrict__ voffs, SinglesOpt opt, double* __restrict__ vars, int64_t* __restrict__ iters_out) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= nsel) return;
+    const int64_t v = selvar[t];
+    const int kind = vkind[v], dim = vdim[v], nd = var_dof(kind, dim), ns = var_storage(kind, dim);
+    const uint32_t off = voffs[v];
+    double vcur[MAXST], vnext[MAXST], vbest[MAXST];
+    for (int q = 0; q < ns; ++q) { vcur[q] = vars[off + q]; vbest[q] = vcur[q]; }
+    double g[SGL_MAXD], H[SGL_MAXD * SGL_MAXD];
+    auto evaluate = [&](const double* vloc, bool want_gh) {
+        double cost = 0;
+        if (want_gh) { for (int i = 0; i < SGL_MAXD; ++i) g[i] = 0; for (int i = 0; i < SGL_MAXD * SGL_MAXD; ++i) H[i] = 0; }
+        for (int64_t e = cptr[t]; e < cptr[t + 1]; ++e) {
+            const SinglesGroup G = groups[cgroup[e]];
+            switch (G.kind) {
+#define X(K) case K: singles_block<K>(G, cidx[e], cslot[e], vars, vloc, want_gh, cost, g, H); break;
+                NLLS_FOR_EACH_RES(X)
+#undef X
+            }
+        }
+        return cost;
+    };
+    double bestcost = evaluate(vcur, true), cost = bestcost;   // src/optimize.jl:118
+    double lambda = 0.0;                                       // reset!(iteratedata): every subproblem starts undamped
+    int fails = 0, iter = 0;
+    while (true) {
+        ++iter;
+        // ---- iterate!(LevMarData)   src/iterators.jl:139-172
+        if (lambda == 0.0) { double m = 0; for (int i = 0; i < nd; ++i) m = fmax(m, fabs(H[i + SGL_MAXD * i])); lambda = m * 1e-6; }
+        double mu = 2.0, x[SGL_MAXD], maxstep = 0;
+        while (true) {
+            // (H + lambda I) x = -g by LDL' (the damped univariate system; src/linearsolver.jl:20-32)
+            double Ld[SGL_MAXD * SGL_MAXD], y[SGL_MAXD];
+            for (int j = 0; j < nd; ++j) for (int i = j; i < nd; ++i) Ld[i + SGL_MAXD * j] = H[i + SGL_MAXD * j] + (i == j ? lambda : 0.0);
+            for (int j = 0; j < nd; ++j) {
+                double dj = Ld[j + SGL_MAXD * j];
+                for (int k = 0; k < j; ++k) dj -= Ld[j + SGL_MAXD * k] * Ld[j + SGL_MAXD * k] * Ld[k + SGL_MAXD * k];
+                Ld[j + SGL_MAXD * j] = dj;
+                for (int i = j + 1; i < nd; ++i) { double s2 = Ld[i + SGL_MAXD * j];
+                    for (int k = 0; k < j; ++k) s2 -= Ld[i + SGL_MAXD * k] * Ld[j + SGL_MAXD * k] * Ld[k + SGL_MAXD * k];
+                    Ld[i + SGL_MAXD * j] = s2 / dj; }
+            }
+            for (int i = 0; i < nd; ++i) { double s2 = g[i]; for (int k = 0; k < i; ++k) s2 -= Ld[i + SGL_MAXD * k] * y[k]; y[i] = s2; }
+            for (int i = 0; i < nd; ++i) y[i] /= Ld[i + SGL_MAXD * i];
+            for (int i = nd - 1; i >= 0; --i) { double s2 = y[i]; for (int k = i + 1; k < nd; ++k) s2 -= Ld[k + SGL_MAXD * i] * y[k]; y[i] = s2; }
+            maxstep = 0;
+            for (int i = 0; i < nd; ++i) { x[i] = -y[i]; maxstep = is_nan_bits(x[i]) ? x[i] : fmax(maxstep, fabs(x[i])); }
+            var_update_real(kind, dim, vcur, x, vnext);                        // :155
+            const double cost_ = evaluate(vnext, false);                       // :157
+            if (!(cost_ > bestcost) || maxstep < opt.dstep) {                  // :160
+                double xHx = 0, gx = 0;                                        // fast_bAb(H, x), dot(g, x) on the undamped H  :162-163
+                for (int j = 0; j < nd; ++j) { gx += g[j] * x[j]; for (int i = 0; i < nd; ++i) xHx += x[i] * H[i + SGL_MAXD * j] * x[j]; }
+                const double q = (cost_ - bestcost) / (0.5 * xHx + gx);
+                lambda *= q < 0.983 ? 1.0 - (2.0 * q - 1.0) * (2.0 * q - 1.0) * (2.0 * q - 1.0) : 0.1;   // :164
+                cost = cost_;
+                break;
+            }
+            lambda *= mu; mu *= 2.0;                                           // :169-170
+            if (!(lambda < 1e300)) { cost = cost_; break; }                    // (a block that never improves: leave instead of spinning)
+        }
+        // ---- src/optimize.jl:128-160
+        double dcost = bestcost - cost;
+        if (dcost >= 0) { bestcost = cost; fails = 0; }
+        else { dcost = cost; ++fails; if (fails == 1) for (int q = 0; q < ns; ++q) vbest[q] = vcur[q]; }
+        for (int q = 0; q < ns; ++q) vcur[q] = vnext[q];                       // updatefromnext!
+        int conv = 0;
+        conv |= (fabs(cost) == INFINITY) << 0; conv |= (int)is_nan_bits(cost) << 1;
+        conv |= (dcost < bestcost * opt.reldcost) << 2; conv |= (dcost < opt.absdcost) << 3;
+        conv |= (fabs(maxstep) == INFINITY) << 4; conv |= (int)is_nan_bits(maxstep) << 5;
+        conv |= (maxstep < opt.dstep) << 6; conv |= (fails > opt.maxfails) << 7; conv |= (iter >= opt.maxiters) << 8;
+        if (conv) break;
+        evaluate(vcur, true);                                                  // :167-170
+    }
+    if (!(bestcost >= cost)) for (int q = 0; q < ns; ++q) vcur[q] = vbest[q];  // updatefrombest!  :173-176
+    for (int q = 0; q < ns; ++q) vars[off + q] = vcur[q];
+    iters_out[t] = iter;
+}
+
+// ================================================================================================
+// host-side enqueue
+// ================================================================================================
+static int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(what) + ": " + hipGetErrorString(e); return NLLS_ERR_HIP; }
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return herr(c, e_, #expr); } while (0)
+
+template <int KIND>
+static int launch_cost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if (G.ncost > 0) {
+        int grid = (int)std::min<int64_t>((G.ncost + TPB - 1) / TPB, 2048);
+        hipLaunchKernelGGL(cost_kernel<KIND>, dim3(grid), dim3(TPB), 0, c->stream, vars, G.data.p, G.voff.p, (const uint32_t*)nullptr, G.ncost, G.rk, c->partials.p + pbase);
+        pbase += grid;
+    }
+    return NLLS_OK;
+}
+template <int KIND>
+static int launch_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if (G.nfixedcost > 0) {
+        int grid = (int)std::min<int64_t>((G.nfixedcost + TPB - 1) / TPB, 2048);
+        hipLaunchKernelGGL(cost_kernel<KIND>, dim3(grid), dim3(TPB), 0, c->stream, vars, G.data.p, G.voff.p, G.fixedcost.p, G.nfixedcost, G.rk, c->partials.p + pbase);
+        pbase += grid;
+    }
+    return NLLS_OK;
+}
+// cost blocks whose variables are all fixed: cost only (called from the gradient sweep as well)
+int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    switch (G.res_kind) {
+#define X(K) case K: return launch_fixedcost<K>(c, G, vars, pbase);
+        NLLS_FOR_EACH_RES(X)
+#undef X
+    }
+    return NLLS_OK;
+}
+int enqueue_reduce_partials(nlls_ctx* c, int64_t n) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, n, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+int enqueue_sweep_cost(nlls_ctx* c, int which) {
+    const double* vars = vars_ptr(c, which); int64_t pbase = 0;
+    for (const Group& G : c->groups) {
+        switch (G.res_kind) {
+#define X(K) case K: launch_cost<K>(c, G, vars, pbase); break;
+            NLLS_FOR_EACH_RES(X)
+#undef X
+        }
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, pbase, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+int enqueue_retract(nlls_ctx* c, int to, int from) {
+    const int64_t nvar = c->info.nvar; if (nvar == 0) return NLLS_OK;
+    hipLaunchKernelGGL(retract_kernel, dim3((unsigned)((nvar + 255) / 256)), dim3(256), 0, c->stream, c->d_var_kind.p, c->d_var_dim.p, c->d_var_off.p,
+                       c->d_var_boff.p, nvar, vars_ptr(c, from), c->x.p, vars_ptr(c, to));
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+int enqueue_step_stats(nlls_ctx* c) {
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + TPB - 1) / TPB, RED_BLOCKS));
+    hipLaunchKernelGGL(step_stats_partial_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->x.p, c->info.ndof, c->partials.p);
+    hipLaunchKernelGGL(step_stats_finish_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, nb, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+int enqueue_max_abs_diag(nlls_ctx* c) {
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.nblocks + TPB - 1) / TPB, RED_BLOCKS));
+    hipLaunchKernelGGL(max_abs_diag_partial_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->A.p, c->d_diag_off.p, c->d_blocksizes.p,
+                       c->nranks > 1 ? c->d_row_mask.p : (const uint8_t*)nullptr, c->info.nblocks, c->info.is_sparse ? (int64_t)0 : c->info.ndof, c->partials.p);
+    hipLaunchKernelGGL(max_finish_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, nb, c->scalars.p, 3);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+// optimizesingles!: the launch.  The caller has validated the lists (nlls_optimize_singles).
+int enqueue_optimize_singles(nlls_ctx* c, int64_t nsel, const int64_t* d_selvar, const int64_t* d_cptr, const int32_t* d_cgroup, const uint32_t* d_cidx,
+                             const int32_t* d_cslot, const void* d_groups, int maxiters, int maxfails, double reldcost, double absdcost, double dstep, int64_t* d_iters) {
+    if (nsel <= 0) return NLLS_OK;
+    SinglesOpt o{maxiters, maxfails, reldcost, absdcost, dstep};
+    hipLaunchKernelGGL(singles_lm_kernel, dim3((unsigned)((nsel + 63) / 64)), dim3(64), 0, c->stream, (const SinglesGroup*)d_groups, d_selvar, nsel, d_cptr, d_cgroup, d_cidx, d_cslot,
+                       c->d_var_kind.p, c->d_var_dim.p, c->d_var_off.p, o, vars_ptr(c, NLLS_VARS_CURRENT), d_iters);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+size_t singles_group_size() { return sizeof(SinglesGroup); }
+void singles_group_fill(void* dst, const Group& G) { SinglesGroup g{G.res_kind, G.data.p, G.voff.p, G.rk}; memcpy(dst, &g, sizeof(g)); }
+
+}  // namespace nlls

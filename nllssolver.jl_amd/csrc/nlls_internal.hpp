@@ -19,6 +19,9 @@ int build_schur(nlls_ctx* c, int32_t flags);
 
 // sweeps (nlls_sweep.hip): enqueue on c->stream; cost lands in c->scalars[0]
 int enqueue_sweep_cost(nlls_ctx* c, int which);
+// (nlls_cost.hip) cost-only blocks and the final reduction of the cost partials, shared with the gradient sweep
+int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);
+int enqueue_reduce_partials(nlls_ctx* c, int64_t n);
 int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost = true);
 // vector helpers (nlls_sweep.hip)
 int enqueue_retract(nlls_ctx* c, int to, int from);

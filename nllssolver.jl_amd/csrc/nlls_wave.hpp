@@ -1,0 +1,87 @@
+// nlls_wave.hpp -- wavefront / workgroup reductions and block-element accessors shared by the sweep and cost translation units.
+#pragma once
+#include "nlls_internal.hpp"
+
+namespace nlls {
+
+constexpr int TPB = 256;
+
+template <int N, class F>
+NLLS_DEV void static_for(F&& f) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
+// this file is compiled with -fno-honor-nans (see the Makefile): NaN tests must look at the bits
+// the bits of v behind an empty asm: without it the compiler recognises the integer tests below as floating-point comparisons and, in a
+// file built with -fno-honor-nans, emits the ORDERED ones (seen: "(bits & ~sign) != 0" became v_cmp_lg_f64, false for NaN)
+NLLS_DEV long long opaque_bits(double v) { long long b = __double_as_longlong(v); asm volatile("" : "+v"(b)); return b; }
+NLLS_DEV bool is_nan_bits(double v) { return (opaque_bits(v) & 0x7fffffffffffffffLL) > 0x7ff0000000000000LL; }
+// v != 0.0 by the bits (true for NaN)
+NLLS_DEV bool nonzero_bits(double v) { return (opaque_bits(v) & 0x7fffffffffffffffLL) != 0; }
+NLLS_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// wavefront sum on the VALU (DPP row shifts + row broadcasts, gfx9): the total lands in lane 63.  18 VALU
+// instructions per value; the ds_bpermute form (__shfl_down) costs an LDS round trip per step.
+template <int CTRL, int ROWMASK>
+NLLS_DEV double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, true);
+    const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);
+    return v + __hiloint2double(shi, slo);
+}
+NLLS_DEV double wave_sum_dpp63(double v) {
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds its row's sum
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's sum
+    return v;
+}
+NLLS_DEV double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+// deterministic workgroup sum (fixed tree); result valid in thread 0
+NLLS_DEV double block_sum(double v, double* red /* >= TPB/64 doubles of LDS */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+NLLS_DEV double block_max(double v, double* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, red[i]);
+    return t;
+}
+
+// element (i of slot SA, j of slot SB) of the block's local Hessian / gradient (residual.jl:91-107)
+template <int KIND, int SA, int SB>
+NLLS_DEV double h_elem(const BlockGH<KIND>& B, int i, int j) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    constexpr bool KA = R::ADAPT && SA == 0, KB = R::ADAPT && SB == 0;
+    if constexpr (KA && KB) return B.Hkk(i, j);
+    else if constexpr (KA) return B.Hkv(i, I::joff(SB) + j);
+    else if constexpr (KB) return B.Hkv(j, I::joff(SA) + i);
+    else return B.H(I::joff(SA) + i, I::joff(SB) + j);
+}
+template <int KIND, int SA>
+NLLS_DEV double g_elem(const BlockGH<KIND>& B, int i) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    if constexpr (R::ADAPT && SA == 0) return B.Gk(i); else return B.G(I::joff(SA) + i);
+}
+
+}  // namespace nlls

@@ -56,26 +56,50 @@ def iterate_levmar(lmd, data, problem, options):    # src/iterators.jl:139-172
     lastlambda = 0.0
     mu = 2.0
     while True:
+        # A trial whose damped factorisation meets an exactly ZERO pivot (a singular direction at a tiny lambda): the reference's
+        # LDLFactorizations would throw here; this path counts it as a rejected trial -- more damping, solve again -- and records it in
+        # data.singulartrials (NLLSResult.singulartrials), in both branches.  No cost was computed for such a trial.
+        singular = None
         if hasattr(ls, "lm_trial"):                   # :149-157 in one library call (same kernels, one synchronisation)
             try:
                 cost_ = _timed(data, "timesolver", lambda: ls.lm_trial(lmd.lambda_ - lastlambda))
+                data.costcomputations += 1
             except NllsError as e:
-                # A zero / NaN pivot of the damped system (an exactly singular direction at a tiny lambda): the reference's
-                # LDLFactorizations would throw here; the device path treats it as a rejected trial -- more damping, again.
-                if e.code != ERR_NOT_SPD or not math.isfinite(lmd.lambda_ * mu):
+                if e.code != ERR_NOT_SPD:
                     raise
-                cost_ = math.inf
+                singular = e
             lastlambda = lmd.lambda_
             data.linearsolvers += 1
-            data.costcomputations += 1
         else:
             ls.uniformscaling(lmd.lambda_ - lastlambda)  # :149
             lastlambda = lmd.lambda_
-            _timed(data, "timesolver", ls.solve)         # :152
+            try:
+                _timed(data, "timesolver", ls.solve)     # :152
+            except NllsError as e:
+                if e.code != ERR_NOT_SPD:
+                    raise
+                singular = e
             data.linearsolvers += 1
-            ls.update(VARS_NEXT, VARS_CURRENT)           # :155
-            cost_ = _timed(data, "timecost", lambda: ls.cost(VARS_NEXT))   # :157
+            if not singular:
+                ls.update(VARS_NEXT, VARS_CURRENT)       # :155
+                cost_ = _timed(data, "timecost", lambda: ls.cost(VARS_NEXT))   # :157
+                data.costcomputations += 1
+        if singular and (not math.isfinite(lmd.lambda_) or not np.all(np.isfinite(ls.b))):
+            # ... unless the linear system ITSELF holds NaN / Inf (a non-finite residual): no damping cures that.  The reference's factorisation
+            # does not throw on it -- its step and the trial cost come out NaN, '!(cost_ > bestcost)' accepts them and the outer loop reports
+            # "cost is NaN" + "NaN in the step" (src/optimize.jl:147-152).  Same here: a NaN step, retracted, its cost swept.
+            ls.x = np.full(len(ls.b), np.nan)
+            ls.update(VARS_NEXT, VARS_CURRENT)
+            cost_ = _timed(data, "timecost", lambda: ls.cost(VARS_NEXT))
             data.costcomputations += 1
+            singular = None
+        if singular:
+            if not math.isfinite(lmd.lambda_ * mu):      # nothing left to damp with
+                raise singular
+            data.singulartrials += 1
+            lmd.lambda_ *= mu
+            mu *= 2.0
+            continue
         if not (cost_ > data.bestcost) or ls.step_maxabs() < options.dstep:   # :160
             ls.uniformscaling(-lastlambda)           # :162
             xHx, gx = ls.quadform()

@@ -38,6 +38,7 @@ class NLLSResult:                                    # src/structs.jl:37-79
         self.timecost, self.timegradient, self.timesolver = d.timecost * 1e-9, d.timegradient * 1e-9, d.timesolver * 1e-9
         self.termination, self.niterations = d.converged, d.iternum
         self.costcomputations, self.gradientcomputations, self.linearsolvers = d.costcomputations, d.gradientcomputations, d.linearsolvers
+        self.singulartrials = d.singulartrials      # LM trials rejected because the damped factorisation met an exactly zero pivot (the reference would throw)
 
     def __str__(self):
         other = self.timetotal - self.timecost - self.timegradient - self.timesolver - self.timeinit
@@ -71,6 +72,7 @@ class NLLSInternal:                                  # src/structs.jl:81-104
         self.starttime = starttime
         self.timetotal = self.timeinit = self.timecost = self.timegradient = self.timesolver = 0
         self.iternum = self.costcomputations = self.gradientcomputations = self.linearsolvers = self.converged = 0
+        self.singulartrials = 0
         self.linsystem = linsystem
 
 

@@ -2,6 +2,7 @@
 Checks the sharded sweep / solve / LM against the unsharded device path on the same problem."""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -34,8 +35,12 @@ def main():
     rng = np.random.default_rng(seed)
     ncr = int(rng.integers(12, 90))             # (sharding partitions by eliminated block: stay within what the Schur kernels take)
     shape = (40, 2000, 0.15) if seed == 21 else (ncr, int(rng.integers(300, 4000)), float(rng.uniform(4.0, 10.0)) / ncr)
-    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(*shape, seed=seed, robust=N.HuberKernel(0.05),
-                                                                 outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    config3 = seed == 3000                       # BASELINE config 3 at full size, checked against the ORACLE (not only the unsharded device)
+    if config3:
+        shape = (100, 10000, 0.1)
+    mkp = lambda: synthetic.perturb_ba_problem(synthetic.create_ba_problem(*shape, seed=1 if config3 else seed, robust=N.HuberKernel(0.01 if config3 else 0.05),
+                                                                           outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    p = mkp()
     unfixed = np.ones(p.nvariables, bool)
     ref = MultiVariateLSgpu(p, unfixed)                       # unsharded reference on the same device
     sh = mk()
@@ -57,6 +62,18 @@ def main():
     assert np.allclose(q_ref, q_sh, rtol=1e-9), (q_ref, q_sh)
     assert np.isclose(ref.step_maxabs(), sh.step_maxabs(), rtol=1e-9)
 
+    if config3:
+        # the same sweep, damped solve and four LM iterations in the CPU oracle (every rank checks its own view of the result)
+        from tests.helpers import oracle_problem, blockindices
+        op = oracle_problem(mkp()); ols = op.linear_system(blockindices(p))
+        c_or = ols.costgradhess()
+        assert np.isclose(c_or, c_sh, rtol=1e-11), (c_or, c_sh)
+        b_or = ols.b.copy()
+        assert np.isclose(ols.max_abs_diag() * 1e-6, lam, rtol=1e-12)
+        ols.solve(lam); x_or = ols.x
+        assert np.max(np.abs(x_or - x_sh)) < 1e-7 * np.max(np.abs(x_or)), np.max(np.abs(x_or - x_sh))
+        assert np.max(np.abs(b_or - sh.b)) < 1e-10 * np.max(np.abs(b_or))
+
     # the full gradient is assembled from the ranks' own rows (dogleg / gradient descent need it on every rank)
     b_ref, b_sh = ref.b, sh.b
     assert np.max(np.abs(b_ref - b_sh)) < 1e-10 * np.max(np.abs(b_ref)), np.max(np.abs(b_ref - b_sh))
@@ -65,15 +82,19 @@ def main():
     # a few full iterations through the host loop on both: Levenberg-Marquardt, then dogleg
     def run(ls, iters=4, itdata=It.LevMarData, itfn=It.iterate_levmar):
         opts = N.NLLSOptions(maxiters=iters)
-        data = Opt.NLLSInternal(ls, 0)
+        data = Opt.NLLSInternal(ls, time.perf_counter_ns())
         loop = Opt.OuterLoop(p, opts, data, itdata(), itfn, N.nullcallback)
         loop.start()
         while loop.iteration() == 0:
             pass
+        assert data.iternum > 1, data.iternum                  # (a loop that stops after one iteration compares nothing)
         return data.bestcost, ls.variables(_capi.VARS_CURRENT)
     ref2 = MultiVariateLSgpu(p, unfixed); sh2 = mk()
     cr, vr = run(ref2); cs, vs = run(sh2)
     assert np.isclose(cr, cs, rtol=1e-9), (cr, cs)
+    if config3:
+        ores = oracle_problem(mkp()).optimize(maxiters=4)
+        assert np.isclose(ores.bestcost, cs, rtol=1e-8), (ores.bestcost, cs)
     ref3 = MultiVariateLSgpu(p, unfixed); sh3 = mk()
     cd_r, _ = run(ref3, 4, It.DoglegData, It.iterate_dogleg); cd_s, _ = run(sh3, 4, It.DoglegData, It.iterate_dogleg)
     assert cd_r < 0.9 * c_ref and np.isclose(cd_r, cd_s, rtol=1e-8), (c_ref, cd_r, cd_s)

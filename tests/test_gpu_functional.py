@@ -320,3 +320,28 @@ def test_dogleg_and_newton_on_gauge_free_sparse_ba(ncam, npts, prop, seed):
         assert N.cost(p) == res.bestcost
         assert ores.bestcost < 1e-12 * p.ncosts() or res.bestcost <= ores.bestcost, (name, ores.bestcost)   # (the oracle's own null-space components may slow it down)
         assert res.niterations <= 30, (name, res.niterations)
+
+
+@pytest.mark.parametrize("shape", ["curvefit", "ba_sparse", "ba_sparse_huber", "ba_band"])
+def test_nan_residual_terminates_like_reference(shape):
+    """A NaN measurement: the reference's loop accepts the NaN cost ('!(cost_ > bestcost)', src/iterators.jl:160), leaves after ONE
+    iteration and reports 'cost is NaN' + 'NaN in the step' (bits 1 and 5, src/optimize.jl:147-152) -- no exception, no retry loop.
+    The device must do the same through the dense, the Schur + dense and the Schur + band (block cyclic reduction) solves; the
+    oracle's own loop gives the expected flags.  (The cost sweep, the step statistics and the retraction are built without the
+    accumulate kernels' no-NaN compiler flags for exactly this.)"""
+    from tests.helpers import oracle_problem
+    def mk():
+        if shape == "curvefit":
+            p, _ = synthetic.create_curvefit_problem(200, seed=3); row, col = 5, 1
+        elif shape == "ba_band":
+            p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(60, 3000, 0.1, seed=1, robust=N.HuberKernel(0.01)), 1e-3, 1e-3); row, col = 1234, 1
+        else:
+            p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 50, 0.3, seed=1, robust=N.HuberKernel(0.01) if shape.endswith("huber") else None), 1e-3, 1e-3); row, col = 7, 0
+        g = next(iter(p.costs.values())); vi, da = g.arrays(); da = da.copy(); da[row, col] = np.nan; g.set_arrays(vi, da)
+        return p
+    ores = oracle_problem(mk()).optimize(maxiters=10)
+    res = N.optimize(mk(), N.NLLSOptions(maxiters=10))
+    assert ores.niterations == 1 and ores.termination == (1 << 1) | (1 << 5)
+    assert res.niterations == 1, res.niterations
+    assert res.termination == ores.termination, bin(res.termination)
+    assert res.singulartrials == 0

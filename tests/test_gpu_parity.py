@@ -119,6 +119,23 @@ def test_ba_huber():                 # BASELINE config 4 robustifier
     check_problem(synthetic.perturb_ba_problem(p3, 1e-3, 1e-3), lam_scale=1e-1)
 
 
+@pytest.mark.parametrize("ncam,npts", [(3, 5), (8, 20), (12, 10)])
+def test_indefinite_dense_system(ncam, npts):
+    """test/linearsolve.jl:29-44 on the device: a symmetric system that is NOT positive definite must still be solved exactly (the
+    reference falls from cholesky to qr, src/linearsolver.jl:20-26).  Such systems reach the dense path for real: the second-order
+    term of a redescending kernel (GemanMcclure, src/robust.jl) makes H indefinite far from the optimum.  33 dof: the one-wave
+    Cholesky -> pivoted LU; 108 / 102 dof: the blocked LDL' (no pivot sign required).  (A NON-symmetric system, test/linearsolve.jl:18-27,
+    cannot cross this boundary: the sweeps only ever write the lower triangle of H -- the oracle pins that case on the CPU.)"""
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, 1.0, seed=2, robust=N.GemanMcclureKernel(0.01),
+                                                                 outlier_frac=0.3, outlier_sigma=0.2), 1e-2, 1e-2)
+    op = oracle_problem(p); ols = op.linear_system(blockindices(p)); ols.costgradhess()
+    n = ols.info.ndof; M = ols.data.reshape(n, n).T; H = np.tril(M) + np.tril(M, -1).T
+    ev = np.linalg.eigvalsh(H)
+    assert ev[0] < -1e-3 * ev[-1] and ev[-1] > 0                       # genuinely indefinite
+    info = check_problem(p, expect_sparse=0)
+    assert info.ndof == 6 * ncam + 3 * npts
+
+
 def test_rosenbrock_and_curvefit():  # dense 2-dof and 4-dof systems (BASELINE configs 1-2)
     p = N.NLLSProblem(); p.addvariable(-0.5); p.addvariable(2.5)
     p.addcosts(K.RES_ROSENBROCK_A, [[1]], [[1.0]], N.Scaled(N.Huber2oKernel(1.6), 1.0))

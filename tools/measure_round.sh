@@ -1,15 +1,15 @@
 #!/bin/bash
 # usage (on the GPU box, through gpurun): tools/measure_round.sh <tag>
-# bench line with the CPU baseline (the driver's configuration: --steps 20 --warmup 5), rocprofv3 kernel stats of the same command, the two PMC
-# passes over the sweep (-> profiles/pmc_traffic.json with the hash of the sweep sources), and the bench lines of the other BASELINE configurations
+# the two PMC passes over the sweep first (-> profiles/pmc_traffic.json with the hash of the sweep sources, so that the bench line carries `traffic`),
+# then the bench line with the CPU baseline (the driver's configuration: --steps 20 --warmup 5), rocprofv3 kernel stats of the same command, and the bench lines of the other BASELINE configurations
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
-python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_prof.json 2> gpurun_out/${tag}_stats.err || exit 2
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- python tools/sweep_only.py --reps 3 > /dev/null 2> gpurun_out/${tag}_fetch.err || exit 3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- python tools/sweep_only.py --reps 3 > /dev/null 2> gpurun_out/${tag}_write.err || exit 4
 python tools/pmc_traffic.py ${tag} > gpurun_out/${tag}_traffic.json || exit 5
 cp profiles/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.json
+python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
 for w in ba_100x10k curvefit_10k ba_so3_500x50k ba_10kx1M; do python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_$w.json 2> gpurun_out/${tag}_bench_$w.err || exit 6; done
 python bench.py --solver dense --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_dense.json 2> gpurun_out/${tag}_bench_dense.err || exit 7
 echo done
