@@ -67,6 +67,9 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries exactly ONE line, the JSON result: whatever libraries print there meanwhile (RCCL writes its version banner to stdout
+    # at the first collective) is sent to stderr, and stdout is restored for the result
+    sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
@@ -271,7 +274,9 @@ def main():
         }
         if weak:
             out["weak_scaling"] = weak
-        print(json.dumps(out))
+        sys.stdout.flush(); os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     ls.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -245,7 +245,9 @@ int  nlls_solve_finish(nlls_ctx* ctx, double* x_out);
 /* after the stage-2 reduction (x complete): update!(to, from, x), cost(to), fast_bAb(H, x), dot(g, x), max|x|, |x|^2 of one
  * Levenberg-Marquardt trial (src/iterators.jl:155-163) with one synchronisation.  out[6] = [cost, x'Hx, g'x, max|x|, |x|^2, status]:
  * with nranks > 1 all of them are this rank's share (sum the first three and the fifth, take the maximum of the fourth and of the
- * factorisation status, and fail on EVERY rank when that is not 0); with one rank out[5] is not written and a bad pivot is an error. */
+ * factorisation status, and fail on EVERY rank when that is not 0); with one rank out[5] is not written and a bad pivot is an error.
+ * out = NULL: enqueue only, no synchronisation -- the scalars stay on the device as reduce buffer 3 (eleven doubles: [0] cost, [8] x'Hx,
+ * [5] g'x, [1] max|x|, [9] |x|^2 of this rank's share, [10] status), to be all-GATHERED on the device: a sharded trial then synchronises once. */
 int  nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out);   /* also reports a failed factorisation of the solve before it */
 /* nlls_solve_finish without the synchronisation: for the step of an LM trial, whose status nlls_trial_local reports */
 int  nlls_solve_finish_replicated(nlls_ctx* ctx);   /* ... and with the reduced part of the step on EVERY rank: no stage-2 reduction; each rank

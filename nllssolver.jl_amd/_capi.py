@@ -281,6 +281,10 @@ class Context:
     def trial_local(self, to=VARS_NEXT, frm=VARS_CURRENT):
         out = np.zeros(6); self._chk(self.L.nlls_trial_local(self.h, to, frm, _p(out))); return out
 
+    def trial_local_enqueue(self, to=VARS_NEXT, frm=VARS_CURRENT):
+        """no synchronisation: the scalars stay on the device (reduce_buffer(3))"""
+        self._chk(self.L.nlls_trial_local(self.h, to, frm, None))
+
     def solve_finish_replicated(self):
         self._chk(self.L.nlls_solve_finish_replicated(self.h))
 

@@ -236,9 +236,10 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
 // maximum(abs, x), |x|^2 -- in one enqueue and one synchronisation.  out = [cost, x'Hx, g'x, max|x|, |x|^2]; under
 // nlls_set_shard the first three are this rank's PARTIAL sums (the caller adds them over ranks), the last two are global.
 int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
-    NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from || !out) return NLLS_ERR_INVALID_ARG;
+    NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
     TRY(enqueue_post_solve(ctx, to, from));        // step statistics, quadratic form and the retraction in one launch
     TRY(enqueue_sweep_cost(ctx, to));
+    if (!out) return NLLS_OK;                      // enqueue only: the eleven scalars stay on the device (reduce buffer 3) for a device-side gather
     HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));   // [10]: the factorisation status
     HIPCHK(hipStreamSynchronize(ctx->stream));
     out[0] = ctx->h_scalars[0]; out[1] = ctx->h_scalars[8]; out[2] = ctx->h_scalars[5]; out[3] = ctx->h_scalars[1]; out[4] = ctx->h_scalars[2];
@@ -391,6 +392,9 @@ int nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t
     if (stage == 0) { *dev_ptr = ctx->redbuf.p; *count = ctx->redbuf_len; return NLLS_OK; }                                   // after sweep_gradhess_local
     if (stage == 1) { *dev_ptr = ctx->S.p; *count = (int64_t)ctx->s_elems + ctx->nred; return NLLS_OK; }                      // after solve_local: [S | s]
     if (stage == 2) { *dev_ptr = ctx->x.p; *count = ctx->info.ndof; return NLLS_OK; }                                         // after solve_finish: x
+    // after nlls_trial_local(out = NULL): the trial's scalars, to be GATHERED (not summed) -- [0] cost, [8] x'Hx, [5] g'x (partial sums),
+    // [1] max|x|, [9] |x|^2 over this rank's share of the step, [10] factorisation status
+    if (stage == 3) { *dev_ptr = ctx->scalars.p; *count = 11; return NLLS_OK; }
     return fail(ctx, NLLS_ERR_INVALID_ARG, "unknown reduce stage");
 }
 int nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count, int64_t* own_offset, int64_t* own_count) {

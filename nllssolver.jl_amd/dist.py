@@ -6,7 +6,7 @@ contiguous range of points and every cost block that touches them, so the point 
 (torch.distributed: RCCL over xGMI on the GPU box, gloo in the CPU tests):
   stage 0  after the gradient sweep : [cost | reduced-block rows of A.data | reduced part of b]   (~0.3 MB, once per iteration)
   stage 1  after local elimination  : [S | s] in band layout -- the real collective of this path   (3.4 MB at config 4, once per LM trial)
-A Levenberg-Marquardt trial needs nothing else but ONE gather of six scalars per rank (cost, x'Hx, g'x, max|x|, |x|^2 and the
+A Levenberg-Marquardt trial needs nothing else but ONE gather of the trial's scalars per rank, on the device (cost, x'Hx, g'x, max|x|, |x|^2 and the
 factorisation status -- every rank raises on the reduced status, so a rank-local bad pivot cannot leave the ranks in different
 collectives): the reduced system is factorised on every rank, so every rank holds the reduced part of the step, retracts the
 reduced variables and its own eliminated ones itself and sweeps its own cost blocks -- the step x is never summed (stage 2, 2.4 MB,
@@ -36,6 +36,7 @@ class ShardedLS(MultiVariateLSgpu):
         # force_collectives: take the local / reduce / finish route even with one rank (rehearses the RCCL plumbing on one GPU)
         self.sharded = world > 1 or (force_collectives and dist is not None)
         self._trial = None                         # ((x'Hx, g'x), max|x|, |x|) of the last lm_trial, until the step changes
+        self._views, self._gathered = {}, None
         self._pre_upload = (rank, world)
         super().__init__(problem, unfixed, flags, device)
         self._tstream = None
@@ -58,6 +59,15 @@ class ShardedLS(MultiVariateLSgpu):
         return ctx
 
     # ---- collectives ------------------------------------------------------------------------------
+    def _buffer_tensor(self, stage):
+        """torch view of one of the library's reduce buffers (device memory; wrapped once per buffer)"""
+        import torch
+        ptr, n = self.ctx.reduce_buffer(stage)
+        key = (stage, ptr, n)
+        if key not in self._views:
+            self._views[key] = torch.as_tensor(_DevArray(ptr, n), device=f"cuda:{self.device}") if n > 0 else None
+        return self._views[key]
+
     def _allreduce_buffer(self, stage):
         import torch
         ptr, n = self.ctx.reduce_buffer(stage)
@@ -70,7 +80,7 @@ class ShardedLS(MultiVariateLSgpu):
             torch.cuda.synchronize()
         else:
             with torch.cuda.stream(self._tstream):
-                self.dist.all_reduce(torch.as_tensor(_DevArray(ptr, n), device=f"cuda:{self.device}"))
+                self.dist.all_reduce(self._buffer_tensor(stage))
 
     def _allreduce_scalars(self, values, op="sum"):
         import torch
@@ -105,8 +115,20 @@ class ShardedLS(MultiVariateLSgpu):
         self.ctx.solve_local()
         self._allreduce_buffer(1)
         self.ctx.solve_finish_replicated()                 # enqueue only: the status comes home with the trial's scalars
-        out = self.ctx.trial_local(_capi.VARS_NEXT, _capi.VARS_CURRENT)
-        allv = self._allgather_scalars(out)                # [world][6]
+        if self.host_staged:
+            out = self.ctx.trial_local(_capi.VARS_NEXT, _capi.VARS_CURRENT)
+            allv = self._allgather_scalars(out)            # [world][6]
+        else:
+            # RCCL: the trial is only enqueued, its scalars are gathered on the device -- ONE synchronisation per trial (the copy home)
+            import torch
+            self.ctx.trial_local_enqueue(_capi.VARS_NEXT, _capi.VARS_CURRENT)
+            src = self._buffer_tensor(3)
+            with torch.cuda.stream(self._tstream):
+                if self._gathered is None:
+                    self._gathered = torch.empty((self.world, src.numel()), dtype=torch.float64, device=f"cuda:{self.device}")
+                self.dist.all_gather_into_tensor(self._gathered, src)
+                raw = self._gathered.cpu().numpy()
+            allv = raw[:, [0, 8, 5, 1, 9 if self.world > 1 else 2, 10]]     # cost, x'Hx, g'x, max|x|, |x|^2 (own share), status
         status = int(allv[:, 5].max())
         if status != 0:                                    # raised on EVERY rank, from the reduced value
             raise _capi.NllsError(_capi.ERR_NOT_SPD, f"factorisation met a zero pivot on some rank (code {status})")
