@@ -212,11 +212,14 @@ int  nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from);
  * Every listed variable (1-based) is optimised on its own, all others fixed, against the cost blocks that depend on it:
  * variable i owns the entries cptr[i] .. cptr[i+1]-1 (cptr[0] = 0) of (cgroup = index of the nlls_cost_group at upload,
  * cindex = 0-based position of the block inside that group, cslot = which of the block's variables it is).  No block may
- * contain two listed variables (the subproblems are solved side by side, one thread each).  Levenberg-Marquardt with the
- * outer loop and termination rules of src/optimize.jl:109-180; operates on NLLS_VARS_CURRENT in place;
- * iters_out (nsel, may be NULL) receives the iterations each variable took.  Variables of at most 6 dof. */
+ * contain two variables of ONE call (they are solved side by side, one thread each): listed variables that share a block are
+ * relaxed one after the other by the reference (src/optimize.jl:183-205) -- the caller splits them into calls of independent
+ * sets, in the reference's order (the Python host and the shim do).  iterator: 0 Newton, 1 Levenberg-Marquardt, 2 dogleg,
+ * 3 gradient descent (src/iterators.jl), each reset per variable, with the outer loop and termination rules of
+ * src/optimize.jl:109-180; operates on NLLS_VARS_CURRENT in place; iters_out (nsel, may be NULL) receives the iterations each
+ * variable took.  Variables of at most 6 dof. */
 int  nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices, const int64_t* cptr, const int32_t* cgroup, const int64_t* cindex,
-                           const int32_t* cslot, int32_t maxiters, int32_t maxfails, double reldcost, double absdcost, double dstep, int64_t* iters_out);
+                           const int32_t* cslot, int32_t iterator, int32_t maxiters, int32_t maxfails, double reldcost, double absdcost, double dstep, int64_t* iters_out);
 /* One Levenberg-Marquardt trial (src/iterators.jl:149-157) in one call and one synchronisation:
  * nlls_damp(dlambda); nlls_solve; nlls_retract(to, from); nlls_sweep_cost(to) -> *cost_out.  Same kernels in the same
  * order; the step statistics and the quadratic form of the step are answered from the host afterwards.  Single GPU only. */

@@ -87,7 +87,7 @@ def lib():
         L.nlls_step_maxabs.argtypes = [vp, vp]; L.nlls_step_norm.argtypes = [vp, vp]
         L.nlls_quadform.argtypes = [vp, vp, vp]
         L.nlls_retract.argtypes = [vp, i32, i32]; L.nlls_lm_trial.argtypes = [vp, C.c_double, i32, i32, vp]
-        L.nlls_optimize_singles.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, i32, i32, C.c_double, C.c_double, C.c_double, vp]
+        L.nlls_optimize_singles.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, i32, i32, i32, C.c_double, C.c_double, C.c_double, vp]
         L.nlls_sweep_gradhess_local.argtypes = [vp]; L.nlls_sweep_gradhess_finish.argtypes = [vp, vp]
         L.nlls_sweep_cost_local.argtypes = [vp, i32]; L.nlls_sweep_cost_finish.argtypes = [vp, vp]
         L.nlls_solve_local.argtypes = [vp]; L.nlls_solve_finish.argtypes = [vp, vp]
@@ -227,13 +227,13 @@ class Context:
         self._chk(self.L.nlls_lm_trial(self.h, float(dlambda), to, frm, C.byref(out)))
         return out.value
 
-    def optimize_singles(self, varindices, cptr, cgroup, cindex, cslot, maxiters=100, maxfails=3, reldcost=1e-15, absdcost=1e-15, dstep=1e-15):
+    def optimize_singles(self, varindices, cptr, cgroup, cindex, cslot, maxiters=100, maxfails=3, reldcost=1e-15, absdcost=1e-15, dstep=1e-15, iterator=1):
         """nlls_optimize_singles; returns the iterations each listed variable took."""
         vi = np.ascontiguousarray(varindices, np.int64); cp = np.ascontiguousarray(cptr, np.int64)
         cg = np.ascontiguousarray(cgroup, np.int32); ci = np.ascontiguousarray(cindex, np.int64); cs = np.ascontiguousarray(cslot, np.int32)
         assert cp.size == vi.size + 1 and cg.size == ci.size == cs.size == (int(cp[-1]) if cp.size else 0)
         iters = np.zeros(vi.size, np.int64)
-        self._chk(self.L.nlls_optimize_singles(self.h, vi.size, _p(vi), _p(cp), _p(cg), _p(ci), _p(cs), int(maxiters), int(maxfails),
+        self._chk(self.L.nlls_optimize_singles(self.h, vi.size, _p(vi), _p(cp), _p(cg), _p(ci), _p(cs), int(iterator), int(maxiters), int(maxfails),
                                                 float(reldcost), float(absdcost), float(dstep), _p(iters)))
         return iters
 

@@ -274,8 +274,9 @@ int nlls_get_variables_owned(nlls_ctx* ctx, int32_t which, double* packed) {
 }
 // optimizesingles!(problem, options, indices)  src/optimize.jl:60-76,183-205
 int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices, const int64_t* cptr, const int32_t* cgroup, const int64_t* cindex,
-                          const int32_t* cslot, int32_t maxiters, int32_t maxfails, double reldcost, double absdcost, double dstep, int64_t* iters_out) {
+                          const int32_t* cslot, int32_t iterator, int32_t maxiters, int32_t maxfails, double reldcost, double absdcost, double dstep, int64_t* iters_out) {
     NEED_READY();
+    if (iterator < 0 || iterator > 3) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: iterator must be 0 (Newton), 1 (Levenberg-Marquardt), 2 (dogleg) or 3 (gradient descent)");
     if (nsel < 0 || (nsel > 0 && (!varindices || !cptr))) return NLLS_ERR_INVALID_ARG;
     if (ctx->nranks != 1) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles runs unsharded");
     if (nsel == 0) return NLLS_OK;
@@ -303,7 +304,7 @@ int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices
     HIPCHK(d_groups.upload(gbuf)); HIPCHK(d_iters.alloc((size_t)nsel));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_grad = false; ctx->solved = false; ctx->step_cached = false; ctx->tE_valid = false;   // the variables change under the linear system
-    TRY(enqueue_optimize_singles(ctx, nsel, d_sel.p, d_cptr.p, d_cgroup.p, d_cidx.p, d_cslot.p, d_groups.p, maxiters, maxfails, reldcost, absdcost, dstep, d_iters.p));
+    TRY(enqueue_optimize_singles(ctx, nsel, d_sel.p, d_cptr.p, d_cgroup.p, d_cidx.p, d_cslot.p, d_groups.p, iterator, maxiters, maxfails, reldcost, absdcost, dstep, d_iters.p));
     if (iters_out) HIPCHK(hipMemcpyAsync(iters_out, d_iters.p, sizeof(int64_t) * nsel, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;

@@ -102,11 +102,12 @@ __global__ __launch_bounds__(TPB) void max_finish_kernel(const double* __restric
 // optimizesingles!(problem, options, indices)   src/optimize.jl:60-76,183-205
 // Every listed variable is optimised on its own -- all other variables fixed -- against the cost blocks that depend on
 // it: the whole outer loop (src/optimize.jl:109-180) with the Levenberg-Marquardt iterator (src/iterators.jl:139-172) and
-// the univariate linear system (src/linearsystem.jl:12-32,126-130) runs in ONE thread per variable; the subproblems are
-// independent (no cost block may hold two of the listed variables), so one launch optimises them all.
+// the univariate linear system (src/linearsystem.jl:12-32,126-130) runs in ONE thread per variable -- or with the Newton, dogleg or
+// gradient-descent iterator (src/iterators.jl:15-27,47-115,187-208); the subproblems of one launch are independent (no cost block
+// holds two of them: listed variables that share a block are relaxed one after the other, in launches of independent sets).
 // ================================================================================================
 struct SinglesGroup { int kind; const double* data; const uint32_t* voff; RobustSpec rk; };
-struct SinglesOpt { int maxiters, maxfails; double reldcost, absdcost, dstep; };
+struct SinglesOpt { int maxiters, maxfails; double reldcost, absdcost, dstep; int iterator; };   // iterator: 0 Newton, 1 Levenberg-Marquardt, 2 dogleg, 3 gradient descent
 constexpr int SGL_MAXD = 6;                                   // dof of a variable optimised this way (registry maximum)
 
 // one cost block of the subproblem: the variable's storage comes from `vloc`, everything else from `vars`
@@ -171,43 +172,95 @@ __global__ __launch_bounds__(64) void singles_lm_kernel(const SinglesGroup* __re
         return cost;
     };
     double bestcost = evaluate(vcur, true), cost = bestcost;   // src/optimize.jl:118
-    double lambda = 0.0;                                       // reset!(iteratedata): every subproblem starts undamped
+    double lambda = 0.0, trust = 0.0, stepsize = 1.0;          // reset!(iteratedata): every subproblem starts from the iterator's initial state
     int fails = 0, iter = 0;
+    double x[SGL_MAXD];
+    // (H + lam I) x = -g by LDL' (the univariate system; src/linearsolver.jl:20-32)
+    auto solve = [&](double lam) {
+        double Ld[SGL_MAXD * SGL_MAXD], y[SGL_MAXD];
+        for (int j = 0; j < nd; ++j) for (int i = j; i < nd; ++i) Ld[i + SGL_MAXD * j] = H[i + SGL_MAXD * j] + (i == j ? lam : 0.0);
+        for (int j = 0; j < nd; ++j) {
+            double dj = Ld[j + SGL_MAXD * j];
+            for (int k = 0; k < j; ++k) dj -= Ld[j + SGL_MAXD * k] * Ld[j + SGL_MAXD * k] * Ld[k + SGL_MAXD * k];
+            Ld[j + SGL_MAXD * j] = dj;
+            for (int i = j + 1; i < nd; ++i) { double s2 = Ld[i + SGL_MAXD * j];
+                for (int k = 0; k < j; ++k) s2 -= Ld[i + SGL_MAXD * k] * Ld[j + SGL_MAXD * k] * Ld[k + SGL_MAXD * k];
+                Ld[i + SGL_MAXD * j] = s2 / dj; }
+        }
+        for (int i = 0; i < nd; ++i) { double s2 = g[i]; for (int k = 0; k < i; ++k) s2 -= Ld[i + SGL_MAXD * k] * y[k]; y[i] = s2; }
+        for (int i = 0; i < nd; ++i) y[i] /= Ld[i + SGL_MAXD * i];
+        for (int i = nd - 1; i >= 0; --i) { double s2 = y[i]; for (int k = i + 1; k < nd; ++k) s2 -= Ld[k + SGL_MAXD * i] * y[k]; y[i] = s2; }
+        for (int i = 0; i < nd; ++i) x[i] = -y[i];                             // negate!
+    };
+    auto maxabs_x = [&]() { double m = 0; for (int i = 0; i < nd; ++i) m = is_nan_bits(x[i]) ? x[i] : (is_nan_bits(m) ? m : fmax(m, fabs(x[i]))); return m; };
+    auto trial = [&]() { var_update_real(kind, dim, vcur, x, vnext); return evaluate(vnext, false); };   // update! + cost(varnext)
+    auto quad = [&](const double* u) { double q = 0; for (int j = 0; j < nd; ++j) for (int i = 0; i < nd; ++i) q += u[i] * H[i + SGL_MAXD * j] * u[j]; return q; };   // fast_bAb
     while (true) {
         ++iter;
-        // ---- iterate!(LevMarData)   src/iterators.jl:139-172
-        if (lambda == 0.0) { double m = 0; for (int i = 0; i < nd; ++i) m = fmax(m, fabs(H[i + SGL_MAXD * i])); lambda = m * 1e-6; }
-        double mu = 2.0, x[SGL_MAXD], maxstep = 0;
-        while (true) {
-            // (H + lambda I) x = -g by LDL' (the damped univariate system; src/linearsolver.jl:20-32)
-            double Ld[SGL_MAXD * SGL_MAXD], y[SGL_MAXD];
-            for (int j = 0; j < nd; ++j) for (int i = j; i < nd; ++i) Ld[i + SGL_MAXD * j] = H[i + SGL_MAXD * j] + (i == j ? lambda : 0.0);
-            for (int j = 0; j < nd; ++j) {
-                double dj = Ld[j + SGL_MAXD * j];
-                for (int k = 0; k < j; ++k) dj -= Ld[j + SGL_MAXD * k] * Ld[j + SGL_MAXD * k] * Ld[k + SGL_MAXD * k];
-                Ld[j + SGL_MAXD * j] = dj;
-                for (int i = j + 1; i < nd; ++i) { double s2 = Ld[i + SGL_MAXD * j];
-                    for (int k = 0; k < j; ++k) s2 -= Ld[i + SGL_MAXD * k] * Ld[j + SGL_MAXD * k] * Ld[k + SGL_MAXD * k];
-                    Ld[i + SGL_MAXD * j] = s2 / dj; }
+        double maxstep = 0;
+        if (opt.iterator == 0) {
+            // ---- iterate!(NewtonData)   src/iterators.jl:15-27
+            solve(0.0); cost = trial();
+        } else if (opt.iterator == 1) {
+            // ---- iterate!(LevMarData)   src/iterators.jl:139-172
+            if (lambda == 0.0) { double m = 0; for (int i = 0; i < nd; ++i) m = fmax(m, fabs(H[i + SGL_MAXD * i])); lambda = m * 1e-6; }
+            double mu = 2.0;
+            while (true) {
+                solve(lambda);                                                     // :149-153
+                const double cost_ = trial();                                      // :155-157
+                if (!(cost_ > bestcost) || maxabs_x() < opt.dstep) {               // :160
+                    double gx = 0;                                                 // fast_bAb(H, x), dot(g, x) on the undamped H  :162-163
+                    for (int j = 0; j < nd; ++j) gx += g[j] * x[j];
+                    const double q = (cost_ - bestcost) / (0.5 * quad(x) + gx);
+                    lambda *= q < 0.983 ? 1.0 - (2.0 * q - 1.0) * (2.0 * q - 1.0) * (2.0 * q - 1.0) : 0.1;   // :164
+                    cost = cost_;
+                    break;
+                }
+                lambda *= mu; mu *= 2.0;                                           // :169-170
+                if (!(lambda < 1e300)) { cost = cost_; break; }                    // (a block that never improves: leave instead of spinning)
             }
-            for (int i = 0; i < nd; ++i) { double s2 = g[i]; for (int k = 0; k < i; ++k) s2 -= Ld[i + SGL_MAXD * k] * y[k]; y[i] = s2; }
-            for (int i = 0; i < nd; ++i) y[i] /= Ld[i + SGL_MAXD * i];
-            for (int i = nd - 1; i >= 0; --i) { double s2 = y[i]; for (int k = i + 1; k < nd; ++k) s2 -= Ld[k + SGL_MAXD * i] * y[k]; y[i] = s2; }
-            maxstep = 0;
-            for (int i = 0; i < nd; ++i) { x[i] = -y[i]; maxstep = is_nan_bits(x[i]) ? x[i] : fmax(maxstep, fabs(x[i])); }
-            var_update_real(kind, dim, vcur, x, vnext);                        // :155
-            const double cost_ = evaluate(vnext, false);                       // :157
-            if (!(cost_ > bestcost) || maxstep < opt.dstep) {                  // :160
-                double xHx = 0, gx = 0;                                        // fast_bAb(H, x), dot(g, x) on the undamped H  :162-163
-                for (int j = 0; j < nd; ++j) { gx += g[j] * x[j]; for (int i = 0; i < nd; ++i) xHx += x[i] * H[i + SGL_MAXD * j] * x[j]; }
-                const double q = (cost_ - bestcost) / (0.5 * xHx + gx);
-                lambda *= q < 0.983 ? 1.0 - (2.0 * q - 1.0) * (2.0 * q - 1.0) * (2.0 * q - 1.0) : 0.1;   // :164
-                cost = cost_;
-                break;
+        } else if (opt.iterator == 2) {
+            // ---- iterate!(DoglegData)   src/iterators.jl:47-115
+            double gnorm2 = 0; for (int i = 0; i < nd; ++i) gnorm2 += g[i] * g[i];
+            const double a = gnorm2 / (quad(g) + 2.2250738585072014e-308);         // floatmin
+            double cauchy[SGL_MAXD]; for (int i = 0; i < nd; ++i) cauchy[i] = -a * g[i];
+            const double alpha2 = a * a * gnorm2, alpha = sqrt(alpha2); double beta = 0;
+            if (trust == 0.0) trust = alpha;                                       // first step: the Cauchy point
+            if (alpha < trust) { solve(0.0); double s2 = 0; for (int i = 0; i < nd; ++i) s2 += x[i] * x[i]; beta = sqrt(s2); }
+            double cost_ = bestcost; int spins = 0;
+            while (true) {
+                double linear_approx;
+                if (!(alpha < trust)) { for (int i = 0; i < nd; ++i) x[i] = (trust / alpha) * cauchy[i]; linear_approx = trust * (2 * alpha - trust) / (2 * a); }
+                else if (beta <= trust) linear_approx = cost_;
+                else {
+                    double sq_leg = 0, c = 0;
+                    for (int i = 0; i < nd; ++i) { x[i] -= cauchy[i]; sq_leg += x[i] * x[i]; c += cauchy[i] * x[i]; }
+                    const double trsq = trust * trust - alpha2; double step = sqrt(c * c + sq_leg * trsq);
+                    step = c <= 0 ? (-c + step) / sq_leg : trsq / (c + step);
+                    for (int i = 0; i < nd; ++i) x[i] = x[i] * step + cauchy[i];
+                    linear_approx = 0.5 * (a * (1 - step) * (1 - step) * gnorm2) + step * (2 - step) * cost_;
+                }
+                cost_ = trial();
+                const double mu = (bestcost - cost_) / linear_approx;
+                if (mu > 0.375) { double s2 = 0; for (int i = 0; i < nd; ++i) s2 += x[i] * x[i]; trust = fmax(trust, 3 * sqrt(s2)); }
+                else if (mu < 0.125) trust *= 0.5;
+                if (!(cost_ > bestcost) || maxabs_x() < opt.dstep || ++spins > 2000) break;
             }
-            lambda *= mu; mu *= 2.0;                                           // :169-170
-            if (!(lambda < 1e300)) { cost = cost_; break; }                    // (a block that never improves: leave instead of spinning)
+            cost = cost_;
+        } else {
+            // ---- iterate!(GradientDescentData)   src/iterators.jl:187-208
+            for (int i = 0; i < nd; ++i) x[i] = -g[i] * stepsize;
+            double costc = trial(); int spins = 0;
+            while (costc > bestcost && ++spins <= 2000) {
+                double coststep = 0; for (int i = 0; i < nd; ++i) coststep += x[i] * g[i];
+                const double costdiff = bestcost + coststep - costc;
+                stepsize *= 0.5 * coststep / costdiff;
+                for (int i = 0; i < nd; ++i) x[i] = -g[i] * stepsize;
+                costc = trial();
+            }
+            stepsize *= 2; cost = costc;
         }
+        maxstep = maxabs_x();
         // ---- src/optimize.jl:128-160
         double dcost = bestcost - cost;
         if (dcost >= 0) { bestcost = cost; fails = 0; }
@@ -304,9 +357,9 @@ int enqueue_max_abs_diag(nlls_ctx* c) {
 
 // optimizesingles!: the launch.  The caller has validated the lists (nlls_optimize_singles).
 int enqueue_optimize_singles(nlls_ctx* c, int64_t nsel, const int64_t* d_selvar, const int64_t* d_cptr, const int32_t* d_cgroup, const uint32_t* d_cidx,
-                             const int32_t* d_cslot, const void* d_groups, int maxiters, int maxfails, double reldcost, double absdcost, double dstep, int64_t* d_iters) {
+                             const int32_t* d_cslot, const void* d_groups, int iterator, int maxiters, int maxfails, double reldcost, double absdcost, double dstep, int64_t* d_iters) {
     if (nsel <= 0) return NLLS_OK;
-    SinglesOpt o{maxiters, maxfails, reldcost, absdcost, dstep};
+    SinglesOpt o{maxiters, maxfails, reldcost, absdcost, dstep, iterator};
     hipLaunchKernelGGL(singles_lm_kernel, dim3((unsigned)((nsel + 63) / 64)), dim3(64), 0, c->stream, (const SinglesGroup*)d_groups, d_selvar, nsel, d_cptr, d_cgroup, d_cidx, d_cslot,
                        c->d_var_kind.p, c->d_var_dim.p, c->d_var_off.p, o, vars_ptr(c, NLLS_VARS_CURRENT), d_iters);
     HIPCHK(hipGetLastError());

@@ -198,22 +198,31 @@ def optimize(problem, options=None, unfixed=None, callback=nullcallback, flags=0
 def optimizesingles(problem, options=None, indices=None, kind=None, dim=None, device=0):
     """optimizesingles!(problem, options, indices | type)   src/optimize.jl:60-76,183-205: every listed variable is
     optimised on its own (all others fixed) against the cost blocks that depend on it.  `indices` 1-based, or select by
-    variable kind (and dimension), like the reference's `type` argument.  Levenberg-Marquardt only (the default
-    iterator); one GPU thread per variable.  Returns the iterations each variable took."""
+    variable kind (and dimension), like the reference's `type` argument.  Any of the four iterators; one GPU thread per variable.
+    Listed variables that share a cost block are relaxed one after the other, as the reference does: in launches of independent sets
+    (NLLSProblem.singles_levels).  Returns the iterations each variable took, in the order of `indices`."""
     options = options or NLLSOptions()
-    assert options.iterator == levenbergmarquardt, "optimizesingles on the device implements the Levenberg-Marquardt iterator"
     if indices is None:
         sel = problem.var_kind == kind
         if dim is not None:
             sel &= problem.var_dim == dim
         indices = np.nonzero(sel)[0] + 1
     indices = np.asarray(indices, dtype=np.int64)
-    # "sorted in order of variable size" (src/optimize.jl:67): the order does not matter for independent subproblems
-    cptr, cgroup, cindex, cslot = problem.costlists(indices)
+    # "sorted in order of variable size" (src/optimize.jl:67; sortperm is stable): the processing order
+    from . import kinds as K
+    dof = np.array([K.var_dof(problem.var_kind[i - 1], problem.var_dim[i - 1]) for i in indices], dtype=np.int64) if indices.size else np.zeros(0, np.int64)
+    order = np.argsort(dof, kind="stable")
+    ordered = indices[order]
+    level = problem.singles_levels(ordered)
+    iters = np.zeros(indices.size, np.int64)
     ls = makesymmvls(problem, np.ones(problem.nvariables, bool), 0, device)
     try:
-        iters = ls.ctx.optimize_singles(indices, cptr, cgroup, cindex, cslot, options.maxiters, options.maxfails,
-                                        options.reldcost, options.absdcost, options.dstep)
+        for lv in range(int(level.max()) + 1 if level.size else 0):
+            pick = np.nonzero(level == lv)[0]
+            cptr, cgroup, cindex, cslot = problem.costlists(ordered[pick])
+            it = ls.ctx.optimize_singles(ordered[pick], cptr, cgroup, cindex, cslot, options.maxiters, options.maxfails,
+                                         options.reldcost, options.absdcost, options.dstep, iterator=int(options.iterator))
+            iters[order[pick]] = it
         problem.variables[:] = ls.variables(VARS_CURRENT)
     finally:
         ls.close()

@@ -179,18 +179,18 @@ class NLLSProblem:
         np.cumsum(counts, out=colptr[1:]); colptr[1:] += 1
         return colptr, rowval
 
-    def costlists(self, indices):
+    def costlists(self, indices, check=True):
         """For each variable in `indices` (1-based): the cost blocks that depend on it, as the CSR lists
         (cptr, cgroup, cindex, cslot) that nlls_optimize_singles takes -- sparse(getvarcostmap(problem)') restricted to
-        the listed variables, src/optimize.jl:62.  Raises if a block holds two listed variables (the subproblems would
-        not be independent)."""
+        the listed variables, src/optimize.jl:62.  check: raise if a block holds two listed variables (the subproblems of one
+        nlls_optimize_singles call must be independent; see singles_levels)."""
         indices = np.asarray(indices, dtype=np.int64)
         pos = np.full(self.nvariables + 1, -1, np.int64); pos[indices] = np.arange(indices.size)
         owners, groups, cidx, slots = [], [], [], []
         for gi, g in enumerate(self.costs.values()):
             vi, _ = g.arrays()
             hit = pos[vi]                                       # (n x ndeps): position in `indices` or -1
-            assert np.all((hit >= 0).sum(axis=1) <= 1), "a cost block depends on two of the listed variables"
+            assert not check or np.all((hit >= 0).sum(axis=1) <= 1), "a cost block depends on two of the listed variables"
             k, s = np.nonzero(hit >= 0)
             owners.append(hit[k, s]); groups.append(np.full(k.size, gi, np.int32)); cidx.append(k.astype(np.int64)); slots.append(s.astype(np.int32))
         owners = np.concatenate(owners) if owners else np.zeros(0, np.int64)
@@ -198,6 +198,29 @@ class NLLSProblem:
         cptr = np.zeros(indices.size + 1, np.int64); np.cumsum(np.bincount(owners, minlength=indices.size), out=cptr[1:])
         cat = lambda xs, dt: (np.concatenate(xs)[order] if xs else np.zeros(0, dt))
         return cptr, cat(groups, np.int32), cat(cidx, np.int64), cat(slots, np.int32)
+
+    def singles_levels(self, indices):
+        """optimizesingles! relaxes the listed variables ONE AFTER THE OTHER (src/optimize.jl:183-205), so a variable sees the updated
+        values of every listed variable before it.  Variables that share no cost block commute: the sequential result is reproduced by
+        launches of independent sets -- level(v) = 1 + the highest level among the EARLIER listed variables v shares a block with.
+        Returns the level (0-based) of each entry of `indices` (which must already be in the reference's processing order)."""
+        indices = np.asarray(indices, dtype=np.int64)
+        cptr, cgroup, cindex, _ = self.costlists(indices, check=False)
+        level = np.zeros(indices.size, np.int64)
+        if indices.size == 0:
+            return level
+        # global block number of every (group, index) pair
+        gbase = np.concatenate([[0], np.cumsum([len(g) for g in self.costs.values()])])
+        blk = gbase[cgroup] + cindex
+        if np.unique(blk).size == blk.size:                    # no block holds two listed variables: one level (the common case)
+            return level
+        next_level = np.zeros(int(gbase[-1]), np.int64)        # per block: 1 + level of the last listed variable that touched it
+        for i in range(indices.size):
+            b = blk[cptr[i]:cptr[i + 1]]
+            lv = int(next_level[b].max()) if b.size else 0
+            level[i] = lv
+            next_level[b] = lv + 1
+        return level
 
     def reordercostsforschur(self, schurvars):
         """reordercostsforschur!(problem, schurvars): group each cost type's blocks by the Schur

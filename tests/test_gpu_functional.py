@@ -165,8 +165,10 @@ def _oracle_optimizesingles(problem, indices, **opts):
     """optimizesingles! on the CPU oracle: one sub-problem per variable -- the cost blocks that depend on it, only that
     variable free (src/optimize.jl:183-205) -- through the oracle's own optimize loop."""
     from oracle import oracle as O
-    cptr, cgroup, cindex, cslot = problem.costlists(indices)
-    out = problem.variables.copy()
+    dof = np.array([K.var_dof(problem.var_kind[i - 1], problem.var_dim[i - 1]) for i in indices])
+    indices = np.asarray(indices)[np.argsort(dof, kind="stable")]          # "sorted in order of variable size" (src/optimize.jl:67)
+    cptr, cgroup, cindex, cslot = problem.costlists(indices, check=False)
+    out = problem.variables.copy()                                          # carried forward: a variable sees the listed ones before it
     gl = list(problem.costs.values())
     voff = np.concatenate([[0], np.cumsum([K.var_storage(k, d) for k, d in zip(problem.var_kind, problem.var_dim)])])
     for t, v in enumerate(indices):
@@ -176,7 +178,7 @@ def _oracle_optimizesingles(problem, indices, **opts):
             vi, da = gl[gi].arrays()
             d = dict(gl[gi].as_dict()); d["varind"] = np.ascontiguousarray(vi[sel]); d["data"] = np.ascontiguousarray(da[sel])
             groups.append(d)
-        op = O.OracleProblem(problem.var_kind, problem.var_dim, groups); op.set_variables(problem.variables)
+        op = O.OracleProblem(problem.var_kind, problem.var_dim, groups); op.set_variables(out)
         bi = np.zeros(problem.nvariables, np.uint64); bi[v - 1] = 1
         op.optimize(bi, **opts)
         res = op.get_variables()
@@ -345,3 +347,35 @@ def test_nan_residual_terminates_like_reference(shape):
     assert res.niterations == 1, res.niterations
     assert res.termination == ores.termination, bin(res.termination)
     assert res.singulartrials == 0
+
+
+@pytest.mark.parametrize("iterator", ["newton", "levenbergmarquardt", "dogleg", "gradientdescent"])
+def test_optimizesingles_every_iterator(iterator):
+    """optimizesingles! accepts any iterator (src/optimize.jl:60-76 -> getiterfun): the per-variable loop on the device with Newton,
+    Levenberg-Marquardt, dogleg and gradient descent against the oracle's loop with the same iterator."""
+    itv = getattr(N, iterator)
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 150, 0.4, seed=9, robust=N.HuberKernel(0.02),
+                                                                 outlier_frac=0.05, outlier_sigma=0.05), 3e-3, 0.0)
+    pts = np.nonzero((p.var_kind == K.VAR_EUCLIDEAN) & (p.var_dim == 3))[0] + 1
+    maxit = 40 if iterator == "gradientdescent" else 100
+    c0 = N.cost(p)
+    expect = _oracle_optimizesingles(p, pts, iterator=int(itv), maxiters=maxit)
+    iters = N.optimizesingles(p, N.NLLSOptions(iterator=itv, maxiters=maxit), indices=pts)
+    assert N.cost(p) < c0 and iters.min() >= 1
+    assert np.max(np.abs(p.variables - expect)) < (1e-6 if iterator == "gradientdescent" else 1e-7)
+
+
+def test_optimizesingles_colisted_variables_are_relaxed_in_order():
+    """Cameras AND points listed together: every cost block then holds two listed variables, and the reference relaxes them one after
+    the other in order of variable size (src/optimize.jl:67,183-205) -- all points first, each camera then sees the moved points.
+    The device runs them as launches of independent sets (points, then cameras) and must land where the sequential oracle lands."""
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(6, 80, 0.6, seed=4), 2e-3, 2e-3)
+    allv = np.arange(1, p.nvariables + 1)
+    level = p.singles_levels(allv[np.argsort(np.array([K.var_dof(k, d) for k, d in zip(p.var_kind, p.var_dim)]), kind="stable")])
+    assert level.max() == 1 and (level == 0).sum() == 80 and (level == 1).sum() == 6
+    c0 = N.cost(p)
+    expect = _oracle_optimizesingles(p, allv)
+    iters = N.optimizesingles(p, N.NLLSOptions(), indices=allv)
+    assert iters.shape == (p.nvariables,) and iters.min() >= 1
+    assert N.cost(p) < c0
+    assert np.max(np.abs(p.variables - expect)) < 1e-7
