@@ -78,6 +78,14 @@ struct Group {
 };
 
 // ---- Schur / solve structures ---------------------------------------------------------------------
+// one fast-path supernode, in launch order (position in d_fast_groups): everything a kernel needs to start on it comes with ONE
+// uniform 32-byte load instead of a chain of dependent ones (group list -> group -> neighbour pointer -> neighbour records)
+struct ElimDesc {
+    uint32_t v0, nmem;       // first member (index into the elimination arrays), members
+    uint32_t nd, rc_off;     // columns of [E] (neighbour dof), offset of their reduced columns in d_elim_rc
+    int64_t dg0;             // A.data offset of the first member's diagonal block
+    uint32_t eb0, pad;       // b offset of the first member
+};
 struct SchurNbr {            // one off-diagonal block touching an eliminated block
     int64_t off;             // offset in A.data
     uint32_t rcol;           // dof offset of the neighbour in the reduced system
@@ -157,6 +165,7 @@ struct nlls_ctx {
 
     // ---- sharding ------------------------------------------------------------------------------------
     bool replicate_xr = false;               // the step's reduced part is written on every rank (sharded LM trial without the stage-2 reduction)
+    bool elim_mfma = true;                     // narrow supernodes (nd + 1 <= 64) are eliminated on the matrix cores (NLLS_ELIM_TILED=1: the register-tiled kernel, for A/B runs)
     bool elim_selected = false;
     std::vector<int32_t> owner_of_block;
     int64_t local_ncost = 0, local_nnz_data = 0, local_ndof = 0;
@@ -177,6 +186,7 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_elim_group;     // supernodes: runs of eliminated blocks with identical neighbour sets
     int64_t nelim_groups = 0, n_fast_groups = 0, n_slow_groups = 0;
     nlls::DevBuf<uint32_t> d_fast_groups, d_slow_groups, d_slow_blocks;   // d_slow_blocks: members of the slow supernodes
+    nlls::DevBuf<nlls::ElimDesc> d_elim_desc; nlls::DevBuf<uint32_t> d_elim_rc;   // per fast supernode (launch order): descriptor, reduced column of every E column
     nlls::DevBuf<uint32_t> d_fast_members;   // members of the fast supernodes
     nlls::DevBuf<uint8_t> d_blk_slowmask;    // d_blk entries NOT in rows of fast members (and owned by this rank)
     nlls::DevBuf<nlls::SchurCopy> d_blk_slow; int64_t nblk_slow = 0;   // the same as a compact list

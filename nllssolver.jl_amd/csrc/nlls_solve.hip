@@ -336,19 +336,14 @@ constexpr int ELIM_NDP = 76;                                  // columns of [E |
 // the 4x4 tiles of nd <= 60 (120 tiles on 128 lanes: the bundle-adjustment point seen by ten cameras), three the rest.
 template <int DV, int NC, int TW>
 __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const double* __restrict__ A, const double* __restrict__ b,
-                                                               const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
-                                                               const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
-                                                               const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
+                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
                                                                const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
     __shared__ __attribute__((aligned(16))) double Es[2][DV][ELIM_NDP], Ys[2][DV][ELIM_NDP];
     __shared__ uint32_t rc[ELIM_NDP];
     const int tid = threadIdx.x; constexpr int NT = 64 * (1 + TW);
-    const uint32_t g = glist[blockIdx.x];
-    const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
-    // structure of the run (identical for all members): reduced column of every E column
-    const int64_t p0 = eptr[v0]; const int nnb = (int)(eptr[v0 + 1] - p0);
-    int nd = 0;
-    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = tid; c2 < nb.dim; c2 += NT) rc[nd + c2] = nb.rcol + c2; nd += nb.dim; }
+    const ElimDesc d = desc[blockIdx.x];                       // uniform: one scalar load (the run's structure is identical for all members)
+    const uint32_t v0 = d.v0, v1 = d.v0 + d.nmem; const int nd = (int)d.nd;
+    for (int c2 = tid; c2 < nd; c2 += NT) rc[c2] = rcflat[d.rc_off + c2];
     for (int i = tid; i < 2 * DV * ELIM_NDP; i += NT) { (&Es[0][0][0])[i] = 0.0; (&Ys[0][0][0])[i] = 0.0; }
     __syncthreads();
     // this thread's tile: t < ntile -> (tp, tq), tq <= tp, pairs (4 tp + i, 4 tq + j).  (The rhs column E' y_b is summed by the
@@ -364,7 +359,7 @@ __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const d
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
     // (the members of a supernode are consecutive block rows: constant stride in A.data and in b, nlls_structure.cpp)
-    const int64_t dg0 = ediag[v0], dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = eboff[v0];
+    const int64_t dg0 = d.dg0, dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = d.eb0;
     auto member_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // LDS only: loads stay in flight
     constexpr int NDMAX = NC == 1 ? 63 : ELIM_NDP - 5;
     __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
@@ -486,6 +481,119 @@ __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const d
     const int wv = tid >> 6, ln = tid & 63;
     for (int q = wv; q < nd; q += NT / 64)
         for (int p = q + ln; p < nd; p += 64) atomicAdd(L.at(rc[p] > rc[q] ? rc[p] : rc[q], rc[p] > rc[q] ? rc[q] : rc[p]), -img[colstart(q) + p]);
+    if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
+}
+
+// The same elimination for supernodes with nd + 1 <= 64 columns of [E | b], on the matrix cores and WITHOUT LDS traffic or barriers in
+// the member loop.  S -= E' (C + lambda I)^-1 E is a rank-DV update per member: on v_mfma_f64_16x16x4_f64 the 16x16 tile (R, C) of it is
+// ONE instruction whose A operand is lane (i, k) <- e_{16R+i}[k] and whose B operand is lane (j, k) <- y_{16C+j}[k], y = C^-1 e -- and
+// those are exactly the values a lane can load itself: the DV entries of "its" column of the member's block row are contiguous in A.data.
+// So every wave is independent: it takes every fourth member of the supernode, loads its operands straight from memory into the
+// operand layout (one member ahead), and accumulates the lower tiles in registers; the four waves' tiles meet in the packed LDS image of
+// the old kernel and leave with the same coalesced atomics.  The fp64 matrix rate equals the vector rate on this chip -- what this buys
+// is the operand delivery: the register-tiled kernel above is bound by its LDS reads (2 x DV 32-byte reads per lane and member, bank
+// conflicts included) and by one barrier per member.  The right-hand side rides along as column nd (row nd of the lower triangle).
+constexpr int ELIM_MFMA_NW = 4;                              // waves per supernode, each taking every fourth member (3 and 6 measured slower: 72 and 93 us against 65)
+template <int DV>
+__global__ __launch_bounds__(64 * ELIM_MFMA_NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_mfma_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                              const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
+                                                              const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
+    constexpr int NDMAX = 63, NW = ELIM_MFMA_NW, NTH = 64 * NW;
+    __shared__ uint32_t rc[64];
+    __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
+    double* const irhs = img + NDMAX * (NDMAX + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
+    const ElimDesc d = desc[blockIdx.x];                       // uniform: one scalar load
+    const uint32_t v0 = d.v0, nmem = d.nmem; const int nd = (int)d.nd;
+    if (tid < nd) rc[tid] = rcflat[d.rc_off + tid];               // (nd <= 63 < NTH)
+    for (int i = tid; i < nd * (nd + 1) / 2; i += NTH) img[i] = 0.0;
+    if (tid < NDMAX) irhs[tid] = 0.0;
+    const int T16 = (nd + 1 + 15) >> 4;                       // tile rows of [E | b] in use (<= 4)
+    const int64_t dg0 = d.dg0, dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = d.eb0;
+    // this lane's column in every tile row: < nd a column of E, == nd the right-hand side, beyond: clamped to nd and masked out.
+    // Lane (li, lk) loads ONE double per tile row and member -- e_{16r+li}[lk], the operand value itself -- and one entry of the inverse.
+    constexpr int PF = 2;                                     // members in flight per wave (HBM latency is several members' worth of MFMA time)
+    const bool kslot = lk < DV;                               // the fourth k-slot of the instruction stays zero for DV = 3
+    const int kk = kslot ? lk : 0;
+    const double* ebase[4]; int64_t estride[4]; bool live[4];   // member m's operand value sits at ebase[r] + m * estride[r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = 16 * r + li; live[r] = col <= nd && kslot; const bool isb = col >= nd;
+        ebase[r] = isb ? b + eb0 + kk : A + dg0 + (int64_t)DV * col - (int64_t)DV * nd + kk;
+        estride[r] = isb ? (int64_t)DV : dstride;
+    }
+    double4_t acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // (the member loop is compiled once per number of tile rows: with T16 a run-time value every instruction sat behind its own branch)
+    auto members = [&](auto T16c) {
+        constexpr int TR = decltype(T16c)::value;
+        double en[PF][TR], cn[PF][DV];
+        auto issue = [&](uint32_t m, int slot) {              // unconditional, clamped loads (a predicated load becomes copy + vmcnt(0))
+            const uint32_t mm = m < nmem ? m : nmem - 1;
+#pragma unroll
+            for (int r = 0; r < TR; ++r) en[slot][r] = ebase[r][(int64_t)mm * estride[r]];
+#pragma unroll
+            for (int j = 0; j < DV; ++j) cn[slot][j] = Cinv[(int64_t)(v0 + mm) * (DV * DV) + j + DV * kk];   // row lk of the (symmetric) inverse
+        };
+#pragma unroll
+        for (int u = 0; u < PF; ++u) issue(wave + NW * u, u);
+#pragma unroll 1
+        for (uint32_t mb = wave; mb < nmem; mb += NW * PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const uint32_t m = mb + NW * u;
+                if (m >= nmem) break;
+                double aop[TR], bop[TR], c[DV];
+#pragma unroll
+                for (int r = 0; r < TR; ++r) aop[r] = live[r] ? en[u][r] : 0.0;
+#pragma unroll
+                for (int j = 0; j < DV; ++j) c[j] = kslot ? cn[u][j] : 0.0;
+                issue(m + NW * PF, u);
+                // y_i[k] = sum_j Cinv[k][j] e_i[j]: the three components of column i sit in the lanes (i, 0..2) -- fetched through the LDS
+                // crossbar (ds_bpermute: no LDS memory, no bank conflicts), not recomputed on the matrix cores (four more instructions
+                // per member on the pipe that bounds this loop)
+#pragma unroll
+                for (int r = 0; r < TR; ++r) {
+                    double y = 0.0;
+#pragma unroll
+                    for (int j = 0; j < DV; ++j) {
+                        const int src = 4 * (16 * j + li);
+                        const double ej = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(aop[r])), __builtin_amdgcn_ds_bpermute(src, __double2loint(aop[r])));
+                        y = fma(c[j], ej, y);
+                    }
+                    bop[r] = y;
+                }
+#pragma unroll
+                for (int R = 0; R < TR; ++R)
+#pragma unroll
+                    for (int C = 0; C <= R; ++C) acc[R * (R + 1) / 2 + C] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[R], bop[C], acc[R * (R + 1) / 2 + C], 0, 0, 0);
+            }
+        }
+    };
+    if (T16 == 4) members(std::integral_constant<int, 4>{});
+    else if (T16 == 3) members(std::integral_constant<int, 3>{});
+    else if (T16 == 2) members(std::integral_constant<int, 2>{});
+    else members(std::integral_constant<int, 1>{});
+    __syncthreads();                                           // rc and the zeroed image are in place
+    // the four waves' tiles meet in the packed column-major image of the lower triangle (register v of lane (li, lk) = entry
+    // (row lk + 4 v, column li) of its tile); row nd of the triangle is the right-hand side
+    auto colstart = [nd](int q) { return q * nd - q * (q - 1) / 2 - q; };   // + p addresses (p, q), p >= q
+#pragma unroll
+    for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int C = 0; C <= R; ++C) {
+            if (R >= T16) continue;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int pp = 16 * R + lk + 4 * v, q = 16 * C + li; const double val = acc[R * (R + 1) / 2 + C][v];
+                if (pp < nd && q <= pp) atomicAdd(&img[colstart(q) + pp], val);
+                else if (pp == nd && q < nd) atomicAdd(&irhs[q], val);
+            }
+        }
+    __syncthreads();
+    for (int q = wave; q < nd; q += NW)
+        for (int pp = q + lane; pp < nd; pp += 64) atomicAdd(L.at(rc[pp] > rc[q] ? rc[pp] : rc[q], rc[pp] > rc[q] ? rc[q] : rc[pp]), -img[colstart(q) + pp]);
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 
@@ -2094,12 +2202,14 @@ int enqueue_solve_local(nlls_ctx* c) {
 #define LAUNCH_TILED(DV) do { const int64_t nel = (int64_t)c->d_elim_diag.n; \
             hipLaunchKernelGGL((schur_cinv_kernel<DV>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, c->stream, c->A.p, c->d_elim_diag.p, c->d_elim_dim.p, nel, c->lambda, c->Cinv.p, c->d_status.p); \
             const int64_t n60 = c->n_fast_n60, nnar = c->n_fast_narrow - c->n_fast_n60, nwid = c->n_fast_groups - c->n_fast_narrow;   /* d_fast_groups: nd <= 60, then the other narrow supernodes, then the wide ones */ \
+            if (c->elim_mfma) { if (n60 + nnar > 0) hipLaunchKernelGGL((schur_elim_mfma_kernel<DV>), dim3((unsigned)(n60 + nnar)), dim3(64 * ELIM_MFMA_NW), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr()); } else { \
             if (n60 > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1, 2>), dim3((unsigned)n60), dim3(192), 0, c->stream, c->A.p, c->b.p, \
-                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, L, c->s_ptr()); \
+                c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr()); \
             if (nnar > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1, 3>), dim3((unsigned)nnar), dim3(256), 0, c->stream, c->A.p, c->b.p, \
-                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p + n60, c->Cinv.p, L, c->s_ptr()); \
+                c->d_elim_desc.p + n60, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr()); } \
             if (nwid > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 2, 3>), dim3((unsigned)nwid), dim3(256), 0, c->stream, c->A.p, c->b.p, \
-                c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p + c->n_fast_narrow, c->Cinv.p, L, c->s_ptr()); } while (0)
+                c->d_elim_desc.p + c->n_fast_narrow, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr()); } while (0)
         if (c->n_fast_groups > 0) {
             if (c->fast_dv == 3) LAUNCH_TILED(3); else if (c->fast_dv == 2) LAUNCH_TILED(2); else if (c->fast_dv == 1) LAUNCH_TILED(1);
         }

@@ -385,7 +385,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     c->elim_slab = false; c->slab.release(); c->d_slab_off.release(); c->d_slab_groups.release(); c->d_gjobs.release(); c->d_gcons.release(); c->n_gjobs = 0;
     // (the solve also dispatches on the SIZE of these lists: an upload without elimination must not inherit them)
     c->d_elim_ptr.release(); c->d_elim_nbr.release(); c->d_elim_diag.release(); c->d_elim_boff.release(); c->d_elim_dim.release(); c->d_elim_group.release();
-    c->d_fast_groups.release(); c->d_slow_groups.release(); c->d_slow_blocks.release(); c->d_fast_members.release(); c->Cinv.release(); c->tE.release();
+    c->d_fast_groups.release(); c->d_elim_desc.release(); c->d_elim_rc.release(); c->d_slow_groups.release(); c->d_slow_blocks.release(); c->d_fast_members.release(); c->Cinv.release(); c->tE.release();
     std::vector<int64_t> red_of(nb, -1);     // dof offset in the reduced system
     // transposed block lists: for a block v, the rows w > v that store block (w, v)
     std::vector<int64_t> tptr(nb + 1, 0), trow, tq;
@@ -493,6 +493,13 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         std::vector<uint32_t> fastb; for (uint32_t gi : fastg) for (uint32_t v = egroup[gi]; v < egroup[gi + 1]; ++v) { fastb.push_back(v); row_fast[erow[v]] = 1; }
         c->n_fast_members = (int64_t)fastb.size();
         if (hipSuccess != c->d_fast_members.upload(fastb) || hipSuccess != c->tE.alloc(std::max<size_t>(1, ediag.size() * (size_t)std::max(1, fast_dv)))) return fail(c, NLLS_ERR_HIP, "fast member upload");
+        { std::vector<ElimDesc> desc; std::vector<uint32_t> rcflat;
+          for (uint32_t gi : fastg) { const uint32_t v0 = egroup[gi];
+              ElimDesc d{v0, egroup[gi + 1] - v0, 0, (uint32_t)rcflat.size(), ediag[v0], eboff[v0], 0};
+              for (int64_t p = eptr[v0]; p < eptr[v0 + 1]; ++p) { for (int q = 0; q < enbr[p].dim; ++q) rcflat.push_back(enbr[p].rcol + q); d.nd += enbr[p].dim; }
+              desc.push_back(d); }
+          if (rcflat.empty()) rcflat.push_back(0);
+          if (hipSuccess != c->d_elim_desc.upload(desc) || hipSuccess != c->d_elim_rc.upload(rcflat)) return fail(c, NLLS_ERR_HIP, "supernode descriptor upload"); }
         if (hipSuccess != c->d_fast_groups.upload(fastg) || hipSuccess != c->d_slow_groups.upload(slowg) || hipSuccess != c->d_slow_blocks.upload(slowb) ||
             hipSuccess != c->Cinv.alloc(std::max<size_t>(1, ediag.size() * (size_t)std::max(1, fast_dv * fast_dv)))) return fail(c, NLLS_ERR_HIP, "group list upload");
         // LDS budget of the elimination kernel: C, E, Y, pair accumulators, column map
