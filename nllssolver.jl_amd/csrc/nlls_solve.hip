@@ -240,9 +240,7 @@ NLLS_DEV double row_shr_add(double v) {
 }
 template <int DV>
 __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __restrict__ A, const double* __restrict__ b,
-                                                                const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
-                                                                const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
-                                                                const uint32_t* __restrict__ egroup, const uint32_t* __restrict__ glist,
+                                                                const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
                                                                 const double* __restrict__ Cinv, const double* __restrict__ xr, double* __restrict__ x, double* __restrict__ tE,
                                                                 uint32_t ngroups, const uint32_t* __restrict__ red_boff, int nred, int write_red,
                                                                 double* __restrict__ Szero, int64_t nzero) {
@@ -255,11 +253,9 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
         for (int64_t i = (int64_t)(blockIdx.x - ngroups) * 64 + lane; i < nzero; i += (int64_t)(gridDim.x - ngroups) * 64) Szero[i] = 0.0;
         return;
     }
-    const uint32_t g = glist[blockIdx.x];
-    const uint32_t v0 = egroup[g], v1 = egroup[g + 1];
-    const int64_t p0 = eptr[v0]; const int nnb = (int)(eptr[v0 + 1] - p0);
-    int nd = 0;
-    for (int p = 0; p < nnb; ++p) { const SchurNbr nb = enbr[p0 + p]; for (int c2 = lane; c2 < nb.dim; c2 += 64) rc[nd + c2] = nb.rcol + c2; nd += nb.dim; }
+    const ElimDesc d = desc[blockIdx.x];                       // uniform: one scalar load
+    const uint32_t v0 = d.v0, v1 = d.v0 + d.nmem; const int nd = (int)d.nd;
+    for (int c2 = lane; c2 < nd; c2 += 64) rc[c2] = rcflat[d.rc_off + c2];
     __syncthreads();
     double xw[MAXC];
 #pragma unroll
@@ -269,7 +265,7 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
     // before this one is reduced (two register sets), and the results wait in LDS until the loop is over -- a store
     // between the loads would make every wait a full vmcnt(0) and serialise the steps again.
     __shared__ double xs[128 * DV], ts[128 * DV];
-    const int64_t dg0 = ediag[v0], dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = eboff[v0];
+    const int64_t dg0 = d.dg0, dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = d.eb0;
     struct Step { double a[MAXC][DV], bv[DV], ci[DV * DV]; };
     auto load = [&](uint32_t vb, Step& S) {
         const uint32_t v = vb + gsub; const uint32_t m = v < v1 ? v - v0 : 0u;
@@ -2341,8 +2337,8 @@ int enqueue_solve_finish(nlls_ctx* c) {
         // what the spare workgroups zero-fill for the next solve: the band storage of S, or (slab + gather assembly) the tiles the gather writes into
         double* zptr = c->S.p; int64_t zcount = zero_S ? (int64_t)c->s_elems : (int64_t)0;
         if (c->elim_slab) { const BcrGeom& g = c->bcr.geom; zptr = g.ws + g.oD; zcount = (int64_t)(g.oBR + (size_t)g.N * g.NT * 256 - g.oD); }
-#define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + nextra), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p, \
-                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_fast_groups.p, c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red, zptr, zcount)
+#define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + nextra), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, \
+                c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red, zptr, zcount)
         if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; c->S_zeroed = zero_S; }
 #undef LAUNCH_BSF
     }
