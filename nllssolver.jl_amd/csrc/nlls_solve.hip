@@ -331,13 +331,13 @@ constexpr int ELIM_NDP = 76;                                  // columns of [E |
 // NC: columns of [E | b] per lane of the solver wave (1: nd + 1 <= 64; 2: up to ELIM_NDP - 4).  TW: tile waves -- two hold
 // the 4x4 tiles of nd <= 60 (120 tiles on 128 lanes: the bundle-adjustment point seen by ten cameras), three the rest.
 template <int DV, int NC, int TW>
-__global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const double* __restrict__ A, const double* __restrict__ b,
-                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                               const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
+__device__ __forceinline__ void schur_elim_tiled_body(const double* __restrict__ A, const double* __restrict__ b,
+                                                      const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
+                                                      const double* __restrict__ Cinv, const SLayout& L, double* __restrict__ s, uint32_t bidx) {
     __shared__ __attribute__((aligned(16))) double Es[2][DV][ELIM_NDP], Ys[2][DV][ELIM_NDP];
     __shared__ uint32_t rc[ELIM_NDP];
     const int tid = threadIdx.x; constexpr int NT = 64 * (1 + TW);
-    const ElimDesc d = desc[blockIdx.x];                       // uniform: one scalar load (the run's structure is identical for all members)
+    const ElimDesc d = desc[bidx];                       // uniform: one scalar load (the run's structure is identical for all members)
     const uint32_t v0 = d.v0, v1 = d.v0 + d.nmem; const int nd = (int)d.nd;
     for (int c2 = tid; c2 < nd; c2 += NT) rc[c2] = rcflat[d.rc_off + c2];
     for (int i = tid; i < 2 * DV * ELIM_NDP; i += NT) { (&Es[0][0][0])[i] = 0.0; (&Ys[0][0][0])[i] = 0.0; }
@@ -480,6 +480,13 @@ __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const d
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 
+template <int DV, int NC, int TW>
+__global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
+                                                               const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
+    schur_elim_tiled_body<DV, NC, TW>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
+}
+
 // The same elimination for supernodes with nd + 1 <= 64 columns of [E | b], on the matrix cores and WITHOUT LDS traffic or barriers in
 // the member loop.  S -= E' (C + lambda I)^-1 E is a rank-DV update per member: on v_mfma_f64_16x16x4_f64 the 16x16 tile (R, C) of it is
 // ONE instruction whose A operand is lane (i, k) <- e_{16R+i}[k] and whose B operand is lane (j, k) <- y_{16C+j}[k], y = C^-1 e -- and
@@ -491,15 +498,15 @@ __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const d
 // conflicts included) and by one barrier per member.  The right-hand side rides along as column nd (row nd of the lower triangle).
 constexpr int ELIM_MFMA_NW = 4;                              // waves per supernode, each taking every fourth member (3 and 6 measured slower: 72 and 93 us against 65)
 template <int DV>
-__global__ __launch_bounds__(64 * ELIM_MFMA_NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_mfma_kernel(const double* __restrict__ A, const double* __restrict__ b,
-                                                              const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                              const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
+__device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ A, const double* __restrict__ b,
+                                                     const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
+                                                     const double* __restrict__ Cinv, const SLayout& L, double* __restrict__ s, uint32_t bidx) {
     constexpr int NDMAX = 63, NW = ELIM_MFMA_NW, NTH = 64 * NW;
     __shared__ uint32_t rc[64];
     __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
     double* const irhs = img + NDMAX * (NDMAX + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
-    const ElimDesc d = desc[blockIdx.x];                       // uniform: one scalar load
+    const ElimDesc d = desc[bidx];                       // uniform: one scalar load
     const uint32_t v0 = d.v0, nmem = d.nmem; const int nd = (int)d.nd;
     if (tid < nd) rc[tid] = rcflat[d.rc_off + tid];               // (nd <= 63 < NTH)
     for (int i = tid; i < nd * (nd + 1) / 2; i += NTH) img[i] = 0.0;
@@ -591,6 +598,24 @@ __global__ __launch_bounds__(64 * ELIM_MFMA_NW) __attribute__((amdgpu_waves_per_
     for (int q = wave; q < nd; q += NW)
         for (int pp = q + lane; pp < nd; pp += 64) atomicAdd(L.at(rc[pp] > rc[q] ? rc[pp] : rc[q], rc[pp] > rc[q] ? rc[q] : rc[pp]), -img[colstart(q) + pp]);
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
+}
+
+template <int DV>
+__global__ __launch_bounds__(64 * ELIM_MFMA_NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_mfma_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                              const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
+                                                              const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
+    schur_elim_mfma_body<DV>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
+}
+// Both kinds of fast supernode in ONE launch: the narrow ones (matrix-core body) first, the wide ones (register-tiled body, NC = 2)
+// behind them.  The narrow supernodes need 1.3 rounds of the chip's wave slots; in a launch of their own the second round leaves most
+// CUs idle, and the wide supernodes -- 1-2 members each, all fixed cost -- then wait for it to end.  Here they fill those slots.
+template <int DV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_fused_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                              const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
+                                                              const double* __restrict__ Cinv, SLayout L, double* __restrict__ s, uint32_t nnarrow) {
+    static_assert(ELIM_MFMA_NW == 4, "both bodies run in 256-thread workgroups");
+    if (blockIdx.x < nnarrow) schur_elim_mfma_body<DV>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
+    else schur_elim_tiled_body<DV, 2, 3>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
 }
 
 template <int DV, int NC, int TW>
@@ -2198,6 +2223,8 @@ int enqueue_solve_local(nlls_ctx* c) {
 #define LAUNCH_TILED(DV) do { const int64_t nel = (int64_t)c->d_elim_diag.n; \
             hipLaunchKernelGGL((schur_cinv_kernel<DV>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, c->stream, c->A.p, c->d_elim_diag.p, c->d_elim_dim.p, nel, c->lambda, c->Cinv.p, c->d_status.p); \
             const int64_t n60 = c->n_fast_n60, nnar = c->n_fast_narrow - c->n_fast_n60, nwid = c->n_fast_groups - c->n_fast_narrow;   /* d_fast_groups: nd <= 60, then the other narrow supernodes, then the wide ones */ \
+            if (c->elim_mfma && n60 + nnar > 0 && nwid > 0) { hipLaunchKernelGGL((schur_elim_fused_kernel<DV>), dim3((unsigned)(n60 + nnar + nwid)), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+                c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)(n60 + nnar)); break; } \
             if (c->elim_mfma) { if (n60 + nnar > 0) hipLaunchKernelGGL((schur_elim_mfma_kernel<DV>), dim3((unsigned)(n60 + nnar)), dim3(64 * ELIM_MFMA_NW), 0, c->stream, c->A.p, c->b.p, \
                 c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr()); } else { \
             if (n60 > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1, 2>), dim3((unsigned)n60), dim3(192), 0, c->stream, c->A.p, c->b.p, \
