@@ -221,8 +221,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     ctx->lambda += dlambda;
     ctx->step_cached = false;
     TRY(enqueue_solve(ctx));
-    TRY(enqueue_post_solve(ctx, to, from));        // step statistics, quadratic form and the retraction in one launch
-    TRY(enqueue_sweep_cost(ctx, to));
+    TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form + retraction in one launch, the cost sweep, one finishing launch
     HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));   // scalars and, in [10], the factorisation status
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int32_t status[1] = {(int32_t)ctx->h_scalars[10]};
@@ -238,8 +237,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
 // nlls_set_shard the first three are this rank's PARTIAL sums (the caller adds them over ranks), the last two are global.
 int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
     NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
-    TRY(enqueue_post_solve(ctx, to, from));        // step statistics, quadratic form and the retraction in one launch
-    TRY(enqueue_sweep_cost(ctx, to));
+    TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form + retraction in one launch, the cost sweep, one finishing launch
     if (!out) return NLLS_OK;                      // enqueue only: the eleven scalars stay on the device (reduce buffer 3) for a device-side gather
     HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));   // [10]: the factorisation status
     HIPCHK(hipStreamSynchronize(ctx->stream));

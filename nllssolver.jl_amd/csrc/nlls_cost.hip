@@ -39,10 +39,7 @@ __global__ __launch_bounds__(TPB) void cost_kernel(const double* __restrict__ va
 // final deterministic reduction of the per-workgroup partials
 __global__ __launch_bounds__(TPB) void reduce_partials_kernel(const double* __restrict__ partials, int64_t n, double* __restrict__ out) {
     __shared__ double red[TPB / 64];
-    double acc = 0;
-    for (int64_t i = threadIdx.x; i < n; i += TPB) acc += partials[i];
-    double t = block_sum(acc, red);
-    if (threadIdx.x == 0) out[0] = t;
+    reduce_partials_body(partials, n, out, red);
 }
 
 // ================================================================================================
@@ -318,8 +315,9 @@ int enqueue_reduce_partials(nlls_ctx* c, int64_t n) {
     return NLLS_OK;
 }
 
-int enqueue_sweep_cost(nlls_ctx* c, int which) {
-    const double* vars = vars_ptr(c, which); int64_t pbase = 0;
+// pofs / count: an LM trial leaves the partials un-reduced at partials + pofs (count of them in *count) for enqueue_trial_finish
+int enqueue_sweep_cost(nlls_ctx* c, int which, int64_t pofs, int64_t* count) {
+    const double* vars = vars_ptr(c, which); int64_t pbase = pofs;
     for (const Group& G : c->groups) {
         switch (G.res_kind) {
 #define X(K) case K: launch_cost<K>(c, G, vars, pbase); break;
@@ -327,7 +325,8 @@ int enqueue_sweep_cost(nlls_ctx* c, int which) {
 #undef X
         }
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, pbase, c->scalars.p);
+    if (count) *count = pbase - pofs;
+    else hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p + pofs, pbase - pofs, c->scalars.p);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }

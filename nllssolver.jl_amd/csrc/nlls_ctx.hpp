@@ -80,6 +80,7 @@ struct Group {
 // ---- Schur / solve structures ---------------------------------------------------------------------
 // one fast-path supernode, in launch order (position in d_fast_groups): everything a kernel needs to start on it comes with ONE
 // uniform 32-byte load instead of a chain of dependent ones (group list -> group -> neighbour pointer -> neighbour records)
+constexpr int64_t TRIAL_COST_POFS = 4096;   // offset of the cost partials of an LM trial in nlls_ctx::partials (the post-solve partials end at 2304)
 struct ElimDesc {
     uint32_t v0, nmem;       // first member (index into the elimination arrays), members
     uint32_t nd, rc_off;     // columns of [E] (neighbour dof), offset of their reduced columns in d_elim_rc
@@ -165,6 +166,7 @@ struct nlls_ctx {
 
     // ---- sharding ------------------------------------------------------------------------------------
     bool replicate_xr = false;               // the step's reduced part is written on every rank (sharded LM trial without the stage-2 reduction)
+    int ps_np = 0, ps_np2 = 0;                 // partial counts of the last enqueue_post_solve (for the trial's finishing launch)
     bool elim_mfma = true;                     // narrow supernodes (nd + 1 <= 64) are eliminated on the matrix cores (NLLS_ELIM_TILED=1: the register-tiled kernel, for A/B runs)
     bool elim_selected = false;
     std::vector<int32_t> owner_of_block;

@@ -18,7 +18,7 @@ int select_elimination(nlls_ctx* c, int32_t flags);
 int build_schur(nlls_ctx* c, int32_t flags);
 
 // sweeps (nlls_sweep.hip): enqueue on c->stream; cost lands in c->scalars[0]
-int enqueue_sweep_cost(nlls_ctx* c, int which);
+int enqueue_sweep_cost(nlls_ctx* c, int which, int64_t pofs = 0, int64_t* count = nullptr);
 // (nlls_cost.hip) cost-only blocks and the final reduction of the cost partials, shared with the gradient sweep
 int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);
 int enqueue_reduce_partials(nlls_ctx* c, int64_t n);
@@ -33,7 +33,8 @@ int enqueue_optimize_singles(nlls_ctx* c, int64_t nsel, const int64_t* d_selvar,
 size_t singles_group_size();
 void singles_group_fill(void* dst, const Group& G);
 int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot /* scalars[out], scalars[out+1] = v'Hv, b'v */);
-int enqueue_post_solve(nlls_ctx* c, int retract_to = -1, int retract_from = -1);   // enqueue_step_stats + enqueue_quadform(x, 4) for the step of the last solve, fewer launches; optionally the retraction rides along
+int enqueue_post_solve(nlls_ctx* c, int retract_to = -1, int retract_from = -1, bool finish = true);
+int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from);   // post-solve statistics + retraction, cost sweep, and ONE finishing launch for both reductions   // enqueue_step_stats + enqueue_quadform(x, 4) for the step of the last solve, fewer launches; optionally the retraction rides along
 
 #if defined(__HIPCC__)
 // to[var i] = update(from[var i], x[its block])   (src/linearsystem.jl:206-213); fixed variables are copied

@@ -14,7 +14,7 @@
 #include <cstdlib>
 #include <utility>
 
-#include "nlls_internal.hpp"
+#include "nlls_wave.hpp"
 
 namespace nlls {
 
@@ -1976,9 +1976,8 @@ __global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) {
 }
 // out[1] = max|x| (NaN if any entry is), out[2] = x'x, out[4] = x'(H + lambda I)x, out[5] = g'x, out[8] = x'Hx, out[9] = (masked) x'x,
 // out[10] = factorisation status
-__global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
-                                                                double lambda, double* __restrict__ out, const int* __restrict__ status) {
-    __shared__ double red[6][4];
+NLLS_DEV void post_solve_finish_body(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
+                                     double lambda, double* __restrict__ out, const int* __restrict__ status, double (*red)[4]) {
     double a = 0, m = 0, nan = 0, ss = 0, vv = 0, bv = 0;
     for (int i = threadIdx.x; i < np; i += 256) a += partials[i];
     for (int i = threadIdx.x; i < np2; i += 256) { m = fmax(m, part2[5 * i]); nan = fmax(nan, part2[5 * i + 1]); ss += part2[5 * i + 2]; vv += part2[5 * i + 3]; bv += part2[5 * i + 4]; }
@@ -1995,6 +1994,19 @@ __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __
         out[4] = a + lambda * vv; out[5] = bv; out[8] = a; out[9] = vv;
         out[10] = (double)status[0];                             // the factorisation status rides home with the scalars (one copy)
     }
+}
+__global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
+                                                                double lambda, double* __restrict__ out, const int* __restrict__ status) {
+    __shared__ double red[6][4];
+    post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red);
+}
+// the two one-workgroup reductions that end an LM trial in ONE launch: workgroup 0 sums the cost partials (the same order as
+// reduce_partials_kernel: the totals are bit-identical), workgroup 1 finishes the step statistics
+__global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restrict__ cpart, int64_t ncp, const double* __restrict__ partials, int np,
+                                                           const double* __restrict__ part2, int np2, double lambda, double* __restrict__ out, const int* __restrict__ status) {
+    __shared__ double red[6][4];
+    if (blockIdx.x == 0) reduce_partials_body(cpart, ncp, out, &red[0][0]);
+    else post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red);
 }
 __global__ __launch_bounds__(256) void quadform_dense_kernel(const double* __restrict__ A, int n, const double* __restrict__ v, double* __restrict__ partials) {
     __shared__ double red[4];
@@ -2133,7 +2145,7 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
 __global__ void status_to_scalar_kernel(const int* __restrict__ status, double* __restrict__ out) { *out = (double)status[0]; }
 // step statistics + quadratic form of the step of the last solve (what nlls_solve / nlls_lm_trial / nlls_trial_local
 // precompute): one launch + one finishing workgroup on sparse systems, the separate kernels otherwise
-int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from) {
+int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from, bool finish) {
     if (!c->info.is_sparse) {
         if (retract_to >= 0) { int rc0 = enqueue_retract(c, retract_to, retract_from); if (rc0 != NLLS_OK) return rc0; }
         int rc = enqueue_step_stats(c); if (rc != NLLS_OK) return rc;
@@ -2159,7 +2171,19 @@ int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from) {
     if (c->fast_dv == 3) hipLaunchKernelGGL((post_solve_kernel<3>), grid, dim3(256), 0, c->stream, a);
     else if (c->fast_dv == 2) hipLaunchKernelGGL((post_solve_kernel<2>), grid, dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((post_solve_kernel<1>), grid, dim3(256), 0, c->stream, a);
-    hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p, c->d_status.p);
+    c->ps_np = a.np + a.np3; c->ps_np2 = a.np2;
+    if (finish) hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p, c->d_status.p);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+// what follows the solve in an LM trial (src/iterators.jl:155-163)
+int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
+    if (!c->info.is_sparse) { int rc = enqueue_post_solve(c, to, from); if (rc != NLLS_OK) return rc; return enqueue_sweep_cost(c, to); }
+    int rc = enqueue_post_solve(c, to, from, false); if (rc != NLLS_OK) return rc;
+    int64_t ncp = 0;
+    rc = enqueue_sweep_cost(c, to, TRIAL_COST_POFS, &ncp); if (rc != NLLS_OK) return rc;
+    hipLaunchKernelGGL(trial_finish_kernel, dim3(2), dim3(256), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->partials.p, c->ps_np, c->partials.p + 1024, c->ps_np2,
+                       c->lambda, c->scalars.p, c->d_status.p);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }

@@ -329,7 +329,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     HIPCHK(c->d_zero_off.upload(zero_off)); HIPCHK(c->d_zero_len.upload(zero_len)); HIPCHK(c->d_zero_b_off.upload(zero_b_off)); HIPCHK(c->d_zero_b_len.upload(zero_b_len));
     for (int g = 0; g < ngroups; ++g) npartials += (c->groups[g].ncost + 255) / 256 + 1;
     c->npartials = std::max<int64_t>(npartials + 16, 4096);
-    HIPCHK(c->partials.alloc(c->npartials));
+    // (an LM trial keeps the cost partials behind the post-solve partials, at TRIAL_COST_POFS: both are reduced by ONE finishing launch)
+    HIPCHK(c->partials.alloc(TRIAL_COST_POFS + c->npartials));
     I.owner_path = all_owner ? 1 : 0;
 
     { int64_t lw = 0, ld = 0;

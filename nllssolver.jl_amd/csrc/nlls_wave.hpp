@@ -84,4 +84,11 @@ NLLS_DEV double g_elem(const BlockGH<KIND>& B, int i) {
     if constexpr (R::ADAPT && SA == 0) return B.Gk(i); else return B.G(I::joff(SA) + i);
 }
 
+// final deterministic reduction of per-workgroup partials by ONE workgroup of TPB threads (the order every cost total is summed in)
+NLLS_DEV void reduce_partials_body(const double* __restrict__ partials, int64_t n, double* __restrict__ out, double* red) {
+    double acc = 0;
+    for (int64_t i = threadIdx.x; i < n; i += TPB) acc += partials[i];
+    double t = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = t;
+}
 }  // namespace nlls
