@@ -222,7 +222,8 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     ctx->step_cached = false;
     TRY(enqueue_solve(ctx));
     TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form + retraction in one launch, the cost sweep, one finishing launch
-    HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));   // scalars and, in [10], the factorisation status
+    // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
+    if (!ctx->info.is_sparse || !ctx->h_scalars_dev) HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int32_t status[1] = {(int32_t)ctx->h_scalars[10]};
     ctx->solved = true;
