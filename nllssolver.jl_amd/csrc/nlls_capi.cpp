@@ -1,5 +1,7 @@
 // nlls_capi.cpp -- the extern "C" boundary declared in include/nlls_amd.h.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 
 #include "nlls_internal.hpp"
 
@@ -223,8 +225,21 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     TRY(enqueue_solve(ctx));
     TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form + retraction in one launch, the cost sweep, one finishing launch
     // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
-    if (!ctx->info.is_sparse || !ctx->h_scalars_dev) HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!ctx->info.is_sparse || !ctx->h_scalars_dev) {
+        HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else {
+        // spin on the sequence numbers the finishing launch publishes (a few milliseconds at most: then fall back to the synchronisation,
+        // after which the values are there in any case)
+        volatile double* hs = ctx->h_scalars; const double seq = (double)ctx->trial_seq;
+        const auto t0 = std::chrono::steady_clock::now(); bool seen = false;
+        for (uint64_t spin = 0;; ++spin) {
+            if (hs[32] == seq && hs[33] == seq) { seen = true; break; }
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     const int32_t status[1] = {(int32_t)ctx->h_scalars[10]};
     ctx->solved = true;
     ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9];

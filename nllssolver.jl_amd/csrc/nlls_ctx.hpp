@@ -160,6 +160,7 @@ struct nlls_ctx {
     int num_cus = 256;
     nlls::DevBuf<double> scalars;            // small device scratch for scalar results
     double* h_scalars = nullptr;             // pinned host mirror
+    int64_t trial_seq = 0;                   // sequence number the trial's finishing launch publishes in h_scalars[32], [33]
     double* h_scalars_dev = nullptr;         // ... as the device sees it (the trial's finishing launch writes the scalars there itself)
     int64_t npartials = 0;
     double lambda = 0.0;                     // accumulated uniformscaling! (src/iterators.jl:149,162)

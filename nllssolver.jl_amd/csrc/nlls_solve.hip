@@ -2004,15 +2004,18 @@ __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __
 // reduce_partials_kernel: the totals are bit-identical), workgroup 1 finishes the step statistics
 __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restrict__ cpart, int64_t ncp, const double* __restrict__ partials, int np,
                                                            const double* __restrict__ part2, int np2, double lambda, double* __restrict__ out, const int* __restrict__ status,
-                                                           double* __restrict__ host_out) {
+                                                           double* __restrict__ host_out, double seq) {
     __shared__ double red[6][4];
     if (blockIdx.x == 0) reduce_partials_body(cpart, ncp, out, &red[0][0]);
     else post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red);
-    // the scalars also go straight to the pinned host mirror (device-visible host memory): no copy command behind this launch, the host
-    // reads them after the stream synchronisation
+    // the scalars also go straight to the pinned host mirror (device-visible, coherent host memory): no copy command behind this launch.
+    // Each workgroup then publishes the trial's sequence number: the host spins on the two numbers instead of sleeping in a stream
+    // synchronisation (its wake-up costs more than the kernels of this size it waits for).
     if (host_out && threadIdx.x == 0) {
         if (blockIdx.x == 0) host_out[0] = out[0];
         else { host_out[1] = out[1]; host_out[2] = out[2]; host_out[4] = out[4]; host_out[5] = out[5]; host_out[8] = out[8]; host_out[9] = out[9]; host_out[10] = out[10]; }
+        __threadfence_system();
+        reinterpret_cast<volatile double*>(host_out)[32 + blockIdx.x] = seq;
     }
 }
 __global__ __launch_bounds__(256) void quadform_dense_kernel(const double* __restrict__ A, int n, const double* __restrict__ v, double* __restrict__ partials) {
@@ -2190,7 +2193,7 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
     int64_t ncp = 0;
     rc = enqueue_sweep_cost(c, to, TRIAL_COST_POFS, &ncp); if (rc != NLLS_OK) return rc;
     hipLaunchKernelGGL(trial_finish_kernel, dim3(2), dim3(256), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->partials.p, c->ps_np, c->partials.p + 1024, c->ps_np2,
-                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev);
+                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq));
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }

@@ -133,7 +133,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     HIPCHK(c->d_var_kind.upload(c->var_kind)); HIPCHK(c->d_var_dim.upload(c->var_dim)); HIPCHK(c->d_var_off.upload(c->var_off));
     { std::vector<uint32_t> vb(nvar); for (int64_t i = 0; i < nvar; ++i) vb[i] = bi[i] ? (uint32_t)c->boffsets[bi[i] - 1] : DEST_NONE; HIPCHK(c->d_var_boff.upload(vb)); }
     HIPCHK(c->d_diag_off.upload(c->diag_off)); HIPCHK(c->d_blocksizes.upload(c->blocksizes));
-    if (!c->h_scalars) { HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), 64 * sizeof(double), hipHostMallocMapped));
+    if (!c->h_scalars) { HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)); memset(c->h_scalars, 0, 64 * sizeof(double));
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_scalars_dev), c->h_scalars, 0) != hipSuccess) c->h_scalars_dev = nullptr; }
     c->S_zeroed = false;
     HIPCHK(c->scalars.alloc(64));
