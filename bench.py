@@ -141,15 +141,16 @@ def main():
         """W untimed + exactly K timed outer iterations from the same start point; barrier + device synchronisation on both sides,
         MAX over ranks"""
         loop = fresh_loop(ls, problem, start_vars)
-        for _ in range(args.warmup):
-            loop.iteration()
+        loop.iterations(args.warmup)
         loop = fresh_loop(ls, problem, start_vars)
         if profile:
             ls.ctx.profile_sweep(True)      # stamps around the accumulate launches of the timed loop itself (in-situ figure)
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loop.iteration()
+        # (one GPU: the K iterations run in the library's own host loop, nlls_lm_iterations -- the statements of OuterLoop.iteration +
+        # iterate_levmar in C++, no interpreter between two trials; sharded: the Python loop over the same entry points)
+        loop.iterations(args.steps)
+        assert loop.data.iternum == args.steps, (loop.data.iternum, args.steps)      # exactly K outer iterations
         sync()
         elapsed = time.perf_counter() - t0
         if dist is not None:

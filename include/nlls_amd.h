@@ -220,6 +220,26 @@ int  nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from);
  * variable took.  Variables of at most 6 dof. */
 int  nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices, const int64_t* cptr, const int32_t* cgroup, const int64_t* cindex,
                            const int32_t* cslot, int32_t iterator, int32_t maxiters, int32_t maxfails, double reldcost, double absdcost, double dstep, int64_t* iters_out);
+/* The Levenberg-Marquardt outer loop itself, on the host side of this ABI (csrc/nlls_lm.cpp): up to `niter` passes of the while-loop body
+ * of optimizeinternal! (src/optimize.jl:124-171) with iterate!(::LevMarData) (src/iterators.jl:139-172) inside -- written only in terms of
+ * the entry points of this header, i.e. the loop a binding would write, without an interpreter between two trials (the GPU waits for the
+ * host there).  Before the first call: variables in NLLS_VARS_CURRENT and NLLS_VARS_NEXT, nlls_sweep_gradhess done, state zeroed except
+ * bestcost = that sweep's cost.  Stops early when the termination flags (src/optimize.jl:147-158, bits 0-9) of an iteration are not 0:
+ * they are left in state->converged.  The caller finishes like src/optimize.jl:173-176 (best variables back if !(bestcost >= cost)).
+ * A host that has a per-iteration callback calls it with niter = 1.  Single GPU (it drives nlls_lm_trial). */
+typedef struct nlls_lm_options {
+    double  reldcost, absdcost, dstep;
+    int64_t maxfails, maxiters;
+    int64_t stoptime_ns;            /* CLOCK_MONOTONIC deadline in ns (starttime + maxtime); <= 0: none */
+} nlls_lm_options;
+typedef struct nlls_lm_state {
+    double  lambda;                 /* LevMarData.lambda; 0: initialised from max|H_ii| * 1e-6 (src/iterators.jl:131-144) */
+    double  bestcost, cost;         /* data.bestcost; cost returned by the last iteration */
+    int64_t iternum, fails, have_best, converged;
+    int64_t linearsolvers, costcomputations, gradientcomputations, singulartrials;
+    int64_t timesolver_ns, timegradient_ns;
+} nlls_lm_state;
+int  nlls_lm_iterations(nlls_ctx* ctx, const nlls_lm_options* options, nlls_lm_state* state, int64_t niter);
 /* One Levenberg-Marquardt trial (src/iterators.jl:149-157) in one call and one synchronisation:
  * nlls_damp(dlambda); nlls_solve; nlls_retract(to, from); nlls_sweep_cost(to) -> *cost_out.  Same kernels in the same
  * order; the step statistics and the quadratic form of the step are answered from the host afterwards.  Single GPU only. */

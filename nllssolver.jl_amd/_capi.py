@@ -23,7 +23,18 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_solve_finish_replicated nlls_get_variables_owned""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_solve_finish_replicated nlls_get_variables_owned nlls_lm_iterations""".split()
+
+
+class LmOptions(C.Structure):          # nlls_lm_options
+    _fields_ = [("reldcost", C.c_double), ("absdcost", C.c_double), ("dstep", C.c_double), ("maxfails", C.c_int64), ("maxiters", C.c_int64),
+                ("stoptime_ns", C.c_int64)]
+
+
+class LmState(C.Structure):            # nlls_lm_state
+    _fields_ = [("lambda_", C.c_double), ("bestcost", C.c_double), ("cost", C.c_double), ("iternum", C.c_int64), ("fails", C.c_int64),
+                ("have_best", C.c_int64), ("converged", C.c_int64), ("linearsolvers", C.c_int64), ("costcomputations", C.c_int64),
+                ("gradientcomputations", C.c_int64), ("singulartrials", C.c_int64), ("timesolver_ns", C.c_int64), ("timegradient_ns", C.c_int64)]
 
 
 class NllsError(RuntimeError):
@@ -75,6 +86,7 @@ def lib():
         L.nlls_res_slot_kind.argtypes = [i32, i32, vp, vp]
         L.nlls_upload_structure.argtypes = [vp, i64, vp, vp, vp, i32, vp, i32]
         L.nlls_get_info.argtypes = [vp, vp]
+        L.nlls_lm_iterations.argtypes = [vp, vp, vp, i64]
         L.nlls_get_bsm_index.argtypes = [vp, vp, vp, vp, vp]
         L.nlls_set_variables.argtypes = [vp, i32, vp]; L.nlls_get_variables.argtypes = [vp, i32, vp]
         L.nlls_swap_variables.argtypes = [vp, i32, i32]; L.nlls_copy_variables.argtypes = [vp, i32, i32]
@@ -280,6 +292,10 @@ class Context:
 
     def trial_local(self, to=VARS_NEXT, frm=VARS_CURRENT):
         out = np.zeros(6); self._chk(self.L.nlls_trial_local(self.h, to, frm, _p(out))); return out
+
+    def lm_iterations(self, options, state, niter):
+        """nlls_lm_iterations: up to niter outer Levenberg-Marquardt iterations in the library's own host loop (state updated in place)"""
+        self._chk(self.L.nlls_lm_iterations(self.h, C.byref(options), C.byref(state), int(niter)))
 
     def trial_local_enqueue(self, to=VARS_NEXT, frm=VARS_CURRENT):
         """no synchronisation: the scalars stay on the device (reduce_buffer(3))"""

@@ -208,8 +208,41 @@ NLLSsolver.updatefromnext!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu})
 NLLSsolver.updatefrombest!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = swapvars!(data.linsystem, VARS_CURRENT, VARS_BEST)   # src/optimize.jl:211-213
 NLLSsolver.updatetobest!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = copyvars!(data.linsystem, VARS_BEST, VARS_CURRENT)     # src/optimize.jl:138-142 (deepcopy)
 
+# nlls_lm_options / nlls_lm_state (include/nlls_amd.h; sizes and offsets pinned by tests/abi/abi_replay.c): the library's own outer loop
+struct LmOptions; reldcost::Float64; absdcost::Float64; dstep::Float64; maxfails::Int64; maxiters::Int64; stoptime_ns::Int64; end
+mutable struct LmState
+    lambda::Float64; bestcost::Float64; cost::Float64
+    iternum::Int64; fails::Int64; have_best::Int64; converged::Int64
+    linearsolvers::Int64; costcomputations::Int64; gradientcomputations::Int64; singulartrials::Int64
+    timesolver_ns::Int64; timegradient_ns::Int64
+end
+
 function NLLSsolver.optimizeinternal!(problem::NLLSProblem, options::NLLSOptions, data::NLLSInternal{MultiVariateLSgpu}, iteratedata::NLLSsolver.LevMarData, callback)
     ls = data.linsystem
+    if callback === NLLSsolver.nullcallback
+        # no user code between two iterations: the whole while-loop below runs inside the library (nlls_lm_iterations, csrc/nlls_lm.cpp --
+        # the same statements, in terms of the same entry points), so that the GPU does not wait for this process between two trials
+        data.startcost = NLLSsolver.preoptimization(iteratedata, problem, options, data)::Float64
+        data.iternum = 0
+        data.timeinit += Base.time_ns() - data.starttime
+        setvariables!(ls, problem.variables, VARS_CURRENT); copyvars!(ls, VARS_NEXT, VARS_CURRENT); ls.resident = true
+        data.timegradient += NLLSsolver.@elapsed_ns cost = NLLSsolver.costgradhess!(ls, problem.variables, problem.costs)
+        data.gradientcomputations += 1
+        data.bestcost = cost; data.startcost = max(cost, data.startcost)
+        big = typemax(Int64) >> 1
+        opts = Ref(LmOptions(options.reldcost, options.absdcost, options.dstep, min(Int64(options.maxfails), big), min(Int64(options.maxiters), big),
+                             min(Int64(data.starttime + options.maxtime), big)))           # Base.time_ns() is CLOCK_MONOTONIC, as the library's clock
+        st = LmState(iteratedata.lambda, cost, cost, 0, 0, 0, 0, data.linearsolvers, data.costcomputations, data.gradientcomputations, 0, 0, 0)
+        GC.@preserve st check(ls.ctx, ccall((:nlls_lm_iterations, lib), Cint, (Ptr{Cvoid}, Ptr{LmOptions}, Ptr{LmState}, Int64), ls.ctx, opts,
+                                            Ptr{LmState}(pointer_from_objref(st)), big))
+        iteratedata.lambda = st.lambda; data.bestcost = st.bestcost; data.iternum = st.iternum; data.converged = st.converged
+        data.linearsolvers = st.linearsolvers; data.costcomputations = st.costcomputations; data.gradientcomputations = st.gradientcomputations
+        data.timesolver += st.timesolver_ns; data.timegradient += st.timegradient_ns
+        !(st.bestcost >= st.cost) && NLLSsolver.updatefrombest!(problem, data)
+        fetchvariables!(problem, ls, VARS_CURRENT); ls.resident = false
+        data.timetotal += Base.time_ns() - data.starttime
+        return data
+    end
     data.startcost = NLLSsolver.preoptimization(iteratedata, problem, options, data)::Float64
     fails = 0; data.iternum = 0
     stoptime = data.starttime + options.maxtime

@@ -101,12 +101,20 @@ class OuterLoop:
     """State of optimizeinternal! (src/optimize.jl:109-180), split so that bench.py can time exactly K outer
     iterations: start() = :111-121, iteration() = one pass of the while-loop body :124-171."""
 
-    def __init__(self, problem, options, data, iteratedata, iterate, callback):
+    def __init__(self, problem, options, data, iteratedata, iterate, callback, native=None):
         self.problem, self.options, self.data = problem, options, data
         self.iteratedata, self.iterate, self.callback = iteratedata, iterate, callback
         self.fails = 0
         self.have_best = False
         self.cost = math.nan
+        # native: Levenberg-Marquardt without a per-iteration callback on one GPU runs in the library's own host loop
+        # (nlls_lm_iterations, csrc/nlls_lm.cpp: the same statements as iteration() + iterate_levmar below, without the interpreter
+        # between two trials).  native=False keeps the Python loop (the tests hold the two against each other).
+        ls = data.linsystem
+        can = (iterate is It.iterate_levmar and callback is nullcallback and hasattr(ls, "ctx") and not getattr(ls, "sharded", False)
+               and hasattr(ls.ctx, "lm_iterations"))
+        self.native = can if native is None else (bool(native) and can)
+        self._state = None
 
     def start(self):
         data, ls = self.data, self.data.linsystem
@@ -121,9 +129,43 @@ class OuterLoop:
         data.startcost = max(cost, data.startcost)
         self.cost = cost
 
+    def iterations(self, n):
+        """n outer iterations (or fewer, if one of them terminates); returns the termination flags of the last one."""
+        if not self.native:
+            conv = 0
+            for _ in range(n):
+                conv = self.iteration()
+                if conv:
+                    break
+            return conv
+        from . import _capi
+        data, ls, o = self.data, self.data.linsystem, self.options
+        big = 2 ** 62
+        clamp = lambda v: int(max(-big, min(big, v)))
+        opt = _capi.LmOptions(float(o.reldcost), float(o.absdcost), float(o.dstep), clamp(o.maxfails), clamp(o.maxiters), clamp(self.stoptime))
+        if self._state is None:
+            self._state = _capi.LmState()
+        st = self._state
+        st.lambda_, st.bestcost, st.cost = float(self.iteratedata.lambda_), float(data.bestcost), float(self.cost)
+        st.iternum, st.fails, st.have_best = int(data.iternum), int(self.fails), int(self.have_best)
+        st.linearsolvers, st.costcomputations, st.gradientcomputations, st.singulartrials = data.linearsolvers, data.costcomputations, data.gradientcomputations, data.singulartrials
+        st.timesolver_ns = st.timegradient_ns = 0
+        ls._x = None
+        try:
+            ls.ctx.lm_iterations(opt, st, n)
+        finally:
+            self.iteratedata.lambda_ = st.lambda_
+            data.bestcost, self.cost, data.iternum, self.fails, self.have_best = st.bestcost, st.cost, st.iternum, st.fails, bool(st.have_best)
+            data.linearsolvers, data.costcomputations, data.gradientcomputations, data.singulartrials = st.linearsolvers, st.costcomputations, st.gradientcomputations, st.singulartrials
+            data.timesolver += st.timesolver_ns; data.timegradient += st.timegradient_ns
+            data.converged = st.converged
+        return int(st.converged)
+
     def iteration(self, regrad=True):
         """One outer iteration; returns the termination flags (0 = keep going).  With regrad the linear
         problem for the next iteration is built unless terminating (:167-170)."""
+        if self.native and regrad:
+            return self.iterations(1)
         data, ls, options = self.data, self.data.linsystem, self.options
         data.iternum += 1
         cost = float(self.iterate(self.iteratedata, data, self.problem, options))   # :126
@@ -169,15 +211,15 @@ class OuterLoop:
         return data
 
 
-def optimizeinternal(problem, options, data, iteratedata, iterate, callback):   # src/optimize.jl:109-180
-    loop = OuterLoop(problem, options, data, iteratedata, iterate, callback)
+def optimizeinternal(problem, options, data, iteratedata, iterate, callback, native=None):   # src/optimize.jl:109-180
+    loop = OuterLoop(problem, options, data, iteratedata, iterate, callback, native)
     loop.start()
-    while loop.iteration() == 0:
+    while loop.iterations(1 << 30 if loop.native else 1) == 0:
         pass
     return loop.finish()
 
 
-def optimize(problem, options=None, unfixed=None, callback=nullcallback, flags=0, device=0, stream=None):
+def optimize(problem, options=None, unfixed=None, callback=nullcallback, flags=0, device=0, stream=None, native=None):
     """optimize!(problem, options, unfixed, callback) -> NLLSResult   src/optimize.jl:5-17,57.
     Variables are optimised in place: problem.variables holds the best values on return."""
     options = options or NLLSOptions()
@@ -188,7 +230,7 @@ def optimize(problem, options=None, unfixed=None, callback=nullcallback, flags=0
     data = NLLSInternal(ls, starttime)
     mk, iterate = _ITER[options.iterator]
     try:
-        optimizeinternal(problem, options, data, mk(), iterate, callback or nullcallback)
+        optimizeinternal(problem, options, data, mk(), iterate, callback or nullcallback, native)
         problem.variables[:] = ls.variables(VARS_CURRENT)
     finally:
         ls.close()

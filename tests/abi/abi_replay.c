@@ -26,6 +26,10 @@ _Static_assert(offsetof(nlls_info, is_sparse) == 0 && offsetof(nlls_info, has_sc
 _Static_assert(offsetof(nlls_info, nblocks) == 16 && offsetof(nlls_info, ndof) == 24 && offsetof(nlls_info, nnz_data) == 32, "NllsInfo ndof");
 _Static_assert(offsetof(nlls_info, var_storage) == 56 && offsetof(nlls_info, nreduced_dof) == 72 && offsetof(nlls_info, solve_mode) == 88, "NllsInfo tail");
 _Static_assert(offsetof(nlls_info, nborder_dof) == 104, "NllsInfo last field");
+/* struct LmOptions / mutable struct LmState of the shim (the library's own LM loop, nlls_lm_iterations) */
+_Static_assert(sizeof(nlls_lm_options) == 48 && offsetof(nlls_lm_options, maxfails) == 24 && offsetof(nlls_lm_options, stoptime_ns) == 40, "LmOptions: 3 x Float64 + 3 x Int64");
+_Static_assert(sizeof(nlls_lm_state) == 104 && offsetof(nlls_lm_state, iternum) == 24 && offsetof(nlls_lm_state, converged) == 48, "LmState head");
+_Static_assert(offsetof(nlls_lm_state, linearsolvers) == 56 && offsetof(nlls_lm_state, singulartrials) == 80 && offsetof(nlls_lm_state, timegradient_ns) == 96, "LmState tail");
 
 /* ---- the entry points the shim ccalls, with the argument types it passes ---- */
 typedef int (*fn_ctx_create)(const int32_t*, int32_t, nlls_ctx**);
@@ -43,10 +47,11 @@ typedef int (*fn_damp)(nlls_ctx*, double);
 typedef int (*fn_quadform)(nlls_ctx*, double*, double*);
 typedef int (*fn_lm_trial)(nlls_ctx*, double, int32_t, int32_t, double*);
 typedef int (*fn_retract)(nlls_ctx*, int32_t, int32_t);
+typedef int (*fn_lm_iterations)(nlls_ctx*, const nlls_lm_options*, nlls_lm_state*, int64_t);
 
 static const char* SYMS[] = {"nlls_ctx_create", "nlls_ctx_destroy", "nlls_last_error", "nlls_upload_structure", "nlls_get_info", "nlls_get_bsm_index",
     "nlls_set_variables", "nlls_get_variables", "nlls_swap_variables", "nlls_copy_variables", "nlls_sweep_gradhess", "nlls_sweep_cost", "nlls_get_grad",
-    "nlls_max_abs_diag", "nlls_damp", "nlls_solve", "nlls_set_step", "nlls_get_step", "nlls_quadform", "nlls_step_maxabs", "nlls_retract", "nlls_lm_trial", "nlls_var_storage"};
+    "nlls_max_abs_diag", "nlls_damp", "nlls_solve", "nlls_set_step", "nlls_get_step", "nlls_quadform", "nlls_step_maxabs", "nlls_retract", "nlls_lm_trial", "nlls_var_storage", "nlls_lm_iterations"};
 
 static void* need(void* lib, const char* name) { void* p = dlsym(lib, name); if (!p) { fprintf(stderr, "missing symbol %s\n", name); exit(2); } return p; }
 static uint64_t lcg_state = 88172645463325252ull;
@@ -131,7 +136,19 @@ int main(int argc, char** argv) {
     CK(get_vars(ctx, NLLS_VARS_CURRENT, final));
     double check = 0; CK(sweep_cost(ctx, NLLS_VARS_CURRENT, &check));
     printf("replay: start %.6e -> best %.6e in %d iterations (%d LM trials), termination flags %d, cost(variables) %.6e\n", startcost, bestcost, iter, trials, converged, check);
-    CK(ctx_destroy(ctx));
     if (!(bestcost < 1e-15 * NOBS) || !(check < 1e-15 * NOBS)) { fprintf(stderr, "did not reach the zero-residual optimum (test/optimizeba.jl:62-75)\n"); return 1; }
+    /* ---- the same optimisation through the library's own loop (the shim's path when there is no user callback): one ccall ---- */
+    fn_lm_iterations lm_iterations = (fn_lm_iterations)need(lib, "nlls_lm_iterations");
+    CK(set_vars(ctx, NLLS_VARS_CURRENT, start)); CK(copy_vars(ctx, NLLS_VARS_NEXT, NLLS_VARS_CURRENT));
+    CK(sweep_gradhess(ctx, &cost));
+    nlls_lm_options lo; memset(&lo, 0, sizeof lo); lo.reldcost = 1e-15; lo.absdcost = 1e-15; lo.dstep = 1e-15; lo.maxfails = 5; lo.maxiters = 100; lo.stoptime_ns = 0;
+    nlls_lm_state ls; memset(&ls, 0, sizeof ls); ls.bestcost = cost; ls.cost = cost;
+    CK(lm_iterations(ctx, &lo, &ls, (int64_t)1 << 40));
+    if (!(ls.bestcost >= ls.cost)) CK(swap_vars(ctx, NLLS_VARS_CURRENT, NLLS_VARS_BEST));
+    double check2 = 0; CK(sweep_cost(ctx, NLLS_VARS_CURRENT, &check2));
+    printf("replay (nlls_lm_iterations): best %.6e in %lld iterations (%lld LM trials), termination flags %lld, cost(variables) %.6e\n", ls.bestcost, (long long)ls.iternum,
+           (long long)ls.linearsolvers, (long long)ls.converged, check2);
+    CK(ctx_destroy(ctx));
+    if (!(ls.bestcost < 1e-15 * NOBS) || !(check2 < 1e-15 * NOBS) || ls.converged == 0 || ls.iternum > 100) { fprintf(stderr, "nlls_lm_iterations did not reach the zero-residual optimum\n"); return 1; }
     return 0;
 }

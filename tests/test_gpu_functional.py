@@ -379,3 +379,49 @@ def test_optimizesingles_colisted_variables_are_relaxed_in_order():
     assert iters.shape == (p.nvariables,) and iters.min() >= 1
     assert N.cost(p) < c0
     assert np.max(np.abs(p.variables - expect)) < 1e-7
+
+
+@pytest.mark.parametrize("shape", ["band", "dense_reduced", "curvefit"])
+def test_native_lm_loop_is_the_python_loop(shape):
+    """nlls_lm_iterations (csrc/nlls_lm.cpp: the outer loop + iterate!(LevMarData) in the library, src/optimize.jl:124-171 and
+    src/iterators.jl:139-172) against the Python statements of the same loop (optimizer.OuterLoop.iteration + iterators.iterate_levmar),
+    stepped one outer iteration at a time: the same costs, damping and trial counts iteration by iteration (to the 1e-9 the
+    accumulate sweep's LDS atomics leave between two runs), the same best cost and variables at the end."""
+    import time
+    from nllssolver_jl_amd import iterators as It, optimizer as Opt
+    from nllssolver_jl_amd.linearsystem import makesymmvls
+    def mk():
+        if shape == "curvefit":
+            return synthetic.create_curvefit_problem(2000, seed=4)[0]
+        ncam, npts, prop = (60, 3000, 0.1) if shape == "band" else (14, 300, 0.5)
+        return synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=6, robust=N.HuberKernel(0.02), outlier_frac=0.05, outlier_sigma=0.1), 1e-3, 1e-3)
+    hist = {}
+    for native in (True, False):
+        p = mk()
+        ls = makesymmvls(p, np.ones(p.nvariables, bool), 0, 0)
+        data = Opt.NLLSInternal(ls, time.perf_counter_ns())
+        loop = Opt.OuterLoop(p, N.NLLSOptions(maxiters=12), data, It.LevMarData(), It.iterate_levmar, N.nullcallback, native)
+        assert loop.native == native
+        loop.start()
+        rows = []
+        while True:
+            c = loop.iterations(1)
+            rows.append((loop.cost, data.bestcost, loop.iteratedata.lambda_, data.linearsolvers, data.costcomputations, data.gradientcomputations, c))
+            if c:
+                break
+        loop.finish()
+        hist[native] = (rows, ls.variables().copy(), data.iternum)
+        ls.close()
+    (ra, va, na), (rb, vb, nb) = hist[True], hist[False]
+    assert na == nb == len(ra) == len(rb), (na, nb)
+    prev = None
+    for k, (x, y) in enumerate(zip(ra, rb)):
+        # while an iteration still lowers the cost by more than the run-to-run noise, the two runs take identical decisions
+        early = k < 8 and (prev is None or (prev - x[1]) > 1e-6 * abs(prev))
+        prev = x[1]
+        assert np.isclose(x[0], y[0], rtol=1e-8) and np.isclose(x[1], y[1], rtol=1e-8), (k, x, y)
+        if early:
+            assert np.isclose(x[2], y[2], rtol=1e-5) and x[3:6] == y[3:6], (k, x, y)
+    assert ra[-1][6] != 0 and rb[-1][6] != 0                            # both terminated (the same iteration count, asserted above)
+    if shape == "curvefit":                                            # (the affine bundle adjustments have a gauge freedom: same cost, different variables)
+        assert np.max(np.abs(va - vb)) < 1e-6
