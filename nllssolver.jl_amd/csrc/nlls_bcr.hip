@@ -489,8 +489,8 @@ void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int n
 }
 // x_k = L_kk^-T (y_k - acc_k) for the 64 unknowns of block column kb, from the four inverted diagonal tiles and the L tiles below
 // them (one wavefront; replaces a 64-step lane-serial substitution)
-__global__ __launch_bounds__(64) void dense_bwd_diag_kernel(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x) {
-    __shared__ double r[64], xs[64], uu[16];
+BCR_DEV void dense_bwd_diag_body(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x,
+                                 double* r, double* xs, double* uu) {
     const int lane = threadIdx.x, c = lane & 15, gq = lane >> 4, c0 = 64 * kb;
     { const int g = c0 + lane; r[lane] = (g < n) ? S[(size_t)n + (size_t)npad * g] - acc[g] : 0.0; xs[lane] = 0.0; }     // y: row n of the factor
     __syncthreads();
@@ -512,8 +512,34 @@ __global__ __launch_bounds__(64) void dense_bwd_diag_kernel(const double* __rest
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(64) void dense_bwd_diag_kernel(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x) {
+    __shared__ double r[64], xs[64], uu[16];
+    dense_bwd_diag_body(S, LiD, npad, kb, n, acc, x, r, xs, uu);
+}
+// One launch per step of the backward substitution L' x = z: block s has just been solved (x_s final).  Workgroup j < s pushes its
+// contribution into the 64 entries of block j -- acc_j += L(block s, block j)' x_s: every block column is owned by one workgroup per
+// launch, so no atomics -- and the workgroup of block s - 1, whose acc is complete with that, goes straight on to solve it (its
+// other three wavefronts retire first: the diagonal-block solve is one wavefront's work).
+__global__ __launch_bounds__(256) void dense_bwd_step_kernel(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int s, int n, double* __restrict__ acc, double* __restrict__ x) {
+    __shared__ double red[4][64]; __shared__ double r[64], xs[64], uu[16];
+    const int j = blockIdx.x, t = threadIdx.x, c = t & 63, q = t >> 6;
+    const double* P = S + (size_t)s * 64 + (size_t)npad * ((size_t)j * 64 + c);       // column j*64 + c, rows of block s: contiguous
+    double v = 0.0;
+#pragma unroll 4
+    for (int i = 16 * q; i < 16 * q + 16; ++i) { const int gi = s * 64 + i; if (gi < n) v = fma(P[i], x[gi], v); }
+    red[q][c] = v;
+    __syncthreads();
+    if (q != 0) return;
+    acc[j * 64 + c] += red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (j != s - 1) return;
+    __threadfence_block();
+    dense_bwd_diag_body(S, LiD, npad, s - 1, n, acc, x, r, xs, uu);                   // (one wavefront left in this workgroup: its barriers are its own)
+}
 void launch_dense_bwd_diag(hipStream_t st, const double* S, const double* LiD, int npad, int kb, int n, const double* acc, double* x) {
     hipLaunchKernelGGL(dense_bwd_diag_kernel, dim3(1), dim3(64), 0, st, S, LiD, npad, kb, n, acc, x);
+}
+void launch_dense_bwd_step(hipStream_t st, const double* S, const double* LiD, int npad, int s, int n, double* acc, double* x) {
+    hipLaunchKernelGGL(dense_bwd_step_kernel, dim3((unsigned)s), dim3(256), 0, st, S, LiD, npad, s, n, acc, x);
 }
 
 // ---------------------------------------------------------------------------------------------------

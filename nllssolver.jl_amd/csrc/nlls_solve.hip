@@ -1134,6 +1134,61 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ S
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cg[(size_t)(r0 + 16 * a + li) + (size_t)npad * (c0 + 16 * b2 + lk + 4 * r)] = cold[a][b2][r] - acc[a][b2][r];
 }
+// The trailing update for ONE or TWO panels at a time (NK = 1, 2): C_ij -= sum_q W_{k0+q},i * L_{k0+q},j'.  With two panels per pass every tile of
+// the trailing matrix is read and written half as often -- that read-modify-write of S is what bounds the update (its operands, 3 MB per
+// panel, stay in L2).  narrow != 0: only the block column jb0 (the next panel: all that its factorisation waits for), one workgroup per
+// row block; else the triangle of blocks >= jb0.
+template <int NK>
+__global__ __launch_bounds__(256) void syrk_update2_kernel(double* __restrict__ S, const double* __restrict__ W0, const double* __restrict__ W1, int npad, int k0, int jb0, int narrow) {
+    __shared__ double Pi[NB * LDT];   // Pi[r + LDT*kk]
+    __shared__ double Pj[NB * LDT];
+    int ti, tj;
+    if (narrow) { ti = blockIdx.x; tj = 0; }
+    else { const int tix = blockIdx.x; ti = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > tix) --ti; while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti; tj = tix - ti * (ti + 1) / 2; }
+    const int ib = jb0 + ti, jb = jb0 + tj;
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63, li = lane & 15, lk = lane >> 4;
+    const int r0 = (w & 1) * 32, c0 = (w >> 1) * 32;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = double4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+        const double* Gi = (q == 0 ? W0 : W1) + (size_t)ib * NB;                         // W = L*D rows of block i, panel k0 + q
+        const double* Gj = S + (size_t)jb * NB + (size_t)npad * (k0 + q) * NB;           // L rows of block j, panel k0 + q
+        if (q > 0) __syncthreads();
+        for (int e = t; e < NB * NB; e += 256) { const int r = e % NB, c2 = e / NB; Pi[r + LDT * c2] = Gi[(size_t)r + (size_t)npad * c2]; Pj[r + LDT * c2] = Gj[(size_t)r + (size_t)npad * c2]; }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < NB; kk += 4) {
+            double av[2], bv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = Pi[r0 + 16 * a + li + LDT * (kk + lk)];
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Pj[c0 + 16 * b2 + li + LDT * (kk + lk)];
+            // (formed TRANSPOSED, operands swapped: the accumulator then has the ROW of C on the lane index -- see syrk_update_kernel)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
+        }
+    }
+    double* Cg = S + (size_t)ib * NB + (size_t)npad * jb * NB;
+    double cold[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cold[a][b2][r] = Cg[(size_t)(r0 + 16 * a + li) + (size_t)npad * (c0 + 16 * b2 + lk + 4 * r)];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cg[(size_t)(r0 + 16 * a + li) + (size_t)npad * (c0 + 16 * b2 + lk + 4 * r)] = cold[a][b2][r] - acc[a][b2][r];
+}
 // backward substitution L' x = z (unit diagonal), block by block from the bottom.  z = D^-1 L^-1 s is row n of the factor.
 // step 1 (one workgroup per 64-column block kb, many row blocks): partial[kb][j] = sum_{i > kb block} L[i][kb*64+j] * x[i]
 __global__ __launch_bounds__(256) void bwd_gemv_kernel(const double* __restrict__ S, int npad, int kb, int n, const double* __restrict__ x, double* __restrict__ acc) {
@@ -2355,20 +2410,24 @@ int enqueue_reduced_solve(nlls_ctx* c) {
         // blocked right-looking LDL', 64 columns at a time: the panel (diagonal block on the matrix cores with look-ahead, the rows below
         // it as tile products: dense_panel_kernel, nlls_bcr.hip) and the MFMA trailing update
         double* LiD = c->Lwork.p + (size_t)npad * NB + npad;         // inv(L_JJ)' of every diagonal tile (backward pass)
-        for (int k = 0; k < nblk; ++k) {
-            launch_dense_panel(c->stream, c->S.p, c->Lwork.p, LiD, npad, k, c->d_status.p);
-            const int T = nblk - k - 1;
-            if (T > 0) hipLaunchKernelGGL(syrk_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, c->Lwork.p, npad, k, nblk);
+        // two panels per pass over the trailing matrix: panel k, a NARROW update of block column k + 1 only, panel k + 1, then one update of
+        // everything behind with both panels (K = 128)
+        double* W0 = c->Lwork.p; double* W1 = LiD + (size_t)(npad / 16) * 256 + 256;
+        for (int k = 0; k < nblk; k += 2) {
+            launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p);
+            if (k + 1 >= nblk) break;
+            hipLaunchKernelGGL(syrk_update2_kernel<1>, dim3(nblk - k - 1), dim3(256), 0, c->stream, c->S.p, W0, W0, npad, k, k + 1, 1);
+            launch_dense_panel(c->stream, c->S.p, W1, LiD, npad, k + 1, c->d_status.p);
+            const int T = nblk - k - 2;
+            if (T > 0) hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
         }
         // backward substitution into acc / s (x)
         double* acc = c->Lwork.p + (size_t)npad * NB;
         HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * npad, c->stream));
         const int nb_real = (n + NB - 1) / NB;
-        for (int kb = nb_real - 1; kb >= 0; --kb) {
-            const int below = nb_real - 1 - kb;
-            if (below > 0) hipLaunchKernelGGL(bwd_gemv_kernel, dim3(below), dim3(256), 0, c->stream, c->S.p, npad, kb, n, c->s_ptr(), acc);
-            launch_dense_bwd_diag(c->stream, c->S.p, LiD, npad, kb, n, acc, c->s_ptr());
-        }
+        // one launch per block: the last block alone, then "push block s into the blocks above it and solve block s - 1"
+        launch_dense_bwd_diag(c->stream, c->S.p, LiD, npad, nb_real - 1, n, acc, c->s_ptr());
+        for (int sblk = nb_real - 1; sblk >= 1; --sblk) launch_dense_bwd_step(c->stream, c->S.p, LiD, npad, sblk, n, acc, c->s_ptr());
     }
     HIPCHK(hipGetLastError());
     return NLLS_OK;
