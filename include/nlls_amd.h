@@ -53,6 +53,9 @@ typedef struct nlls_ctx nlls_ctx;
 #define NLLS_VAR_CONTAMINATED_GAUSSIAN  4 /* ContaminatedGaussian: dof 3, storage 3 = (1/s1, 1/s2, w)       */
 #define NLLS_VAR_POSE_SO3               5 /* NEW: R (3x3 col-major) + t, dof 6, storage 12,
                                              R <- R*expm([d(1:3)]x), t <- t + d(4:6)                      */
+#define NLLS_VAR_DYNAMIC                6 /* DynamicVector{Float64}: a Euclidean vector of RUN-TIME length `dim` (1 .. NLLS_MAX_DYN_DIM):
+                                             storage = dof = dim, update = v + delta (src/variable.jl); only under the DYN residual kinds */
+#define NLLS_MAX_DYN_DIM             4096
 
 /* ---- residual kinds: computeresidual() bodies ----------------------------------------------- */
 #define NLLS_RES_BA_AFFINE        1 /* SimpleError2{2}: (pose[1:3].X, pose[4:6].X) - meas; vars (EUCL6, EUCL3);
@@ -71,7 +74,13 @@ typedef struct nlls_ctx nlls_ctx;
 #define NLLS_COST_LINEAR3        10 /* NON-SQUARED AbstractCost (src/autodiff.jl:144-159): computecost = y'w, vars (EUCL3); data = y[3].  The block adds
                                        its value (not half a squared norm) to the cost, its gradient and Hessian -- by second-order duals through update() --
                                        to the linear system; robust_kind is ignored.                              test/nonsquaredcost.jl:28-37 */
-#define NLLS_RES_KIND_COUNT      11
+#define NLLS_RES_DYN_LINEAR      11 /* DYNAMIC-size (src/autodiff.jl:96-121): LinearResidual X'w - y over one NLLS_VAR_DYNAMIC variable of run-time
+                                       length n; data = (y, X[n]) -- n + 1 doubles per block; nres 1            test/dynamicvars.jl:3-11 */
+#define NLLS_RES_DYN_NORM        12 /* DYNAMIC-size: NormResidual w over one NLLS_VAR_DYNAMIC variable: nres = n, no data    test/dynamicvars.jl:13-21.
+                                       Dynamic kinds: every block of a group has the same n; no robust kernel; the system must come out
+                                       dense (src/linearsystem.jl:105-123 decides; one variable always does); nlls_res_ndata / nlls_res_nres
+                                       return -1 where the count is n-dependent */
+#define NLLS_RES_KIND_COUNT      13
 
 /* ---- robust kernels: src/robust.jl:7-77 ------------------------------------------------------ */
 #define NLLS_ROBUST_NONE           0 /* NoRobust                                               */

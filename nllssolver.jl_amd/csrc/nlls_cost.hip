@@ -43,6 +43,41 @@ __global__ __launch_bounds__(TPB) void reduce_partials_kernel(const double* __re
 }
 
 // ================================================================================================
+// dynamic-size residual blocks   computeresjacdynamic, src/autodiff.jl:96-121 (heap-allocated, run-time sizes in the reference)
+// The registered residuals have closed-form Jacobians: LinearResidual X'w - y (test/dynamicvars.jl:3-11), J = X'; NormResidual w
+// (test/dynamicvars.jl:13-21), J = I.  One workgroup per block; n = the variable's run-time length.  With A != nullptr the block's
+// J'J and J'r go into the dense linear system (src/residual.jl:72-74, src/linearsystem.jl:132-175), else only the cost.
+// ================================================================================================
+__global__ __launch_bounds__(TPB) void dyn_block_kernel(int kind, int n, int ndata, const double* __restrict__ vars, const double* __restrict__ data,
+                                                        const uint32_t* __restrict__ voff, const uint32_t* __restrict__ index, const uint32_t* __restrict__ brow,
+                                                        int ndof, double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+    __shared__ double red[TPB / 64]; __shared__ double total;
+    const int64_t k = index ? index[blockIdx.x] : blockIdx.x;
+    const double* w = vars + voff[k];
+    const uint32_t bo = (A && brow) ? brow[blockIdx.x] : DEST_NONE;            // (brow is in launch order: one entry per launched block)
+    double cost;
+    if (kind == NLLS_RES_DYN_LINEAR) {
+        const double* dd = data + k * (int64_t)ndata; const double* X = dd + 1;
+        double acc = 0;
+        for (int i = threadIdx.x; i < n; i += TPB) acc += X[i] * w[i];
+        { const double t = block_sum(acc, red); if (threadIdx.x == 0) total = t; }   // (block_sum leaves the total in thread 0)
+        __syncthreads();
+        const double r = total - dd[0];
+        cost = 0.5 * r * r;
+        if (bo != DEST_NONE) {
+            for (int i = threadIdx.x; i < n; i += TPB) atomicAdd(&b[bo + i], X[i] * r);
+            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int i = (int)(e % n), j = (int)(e / n); if (i >= j) atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + j)], X[i] * X[j]); }
+        }
+    } else {
+        double acc = 0;
+        for (int i = threadIdx.x; i < n; i += TPB) acc += w[i] * w[i];
+        cost = 0.5 * block_sum(acc, red);
+        if (bo != DEST_NONE) for (int i = threadIdx.x; i < n; i += TPB) { atomicAdd(&b[bo + i], w[i]); atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + i)], 1.0); }
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = cost;
+}
+
+// ================================================================================================
 // vector helpers
 // ================================================================================================
 // update!(to, from, linsystem)   src/linearsystem.jl:206-213
@@ -300,8 +335,28 @@ static int launch_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int
     }
     return NLLS_OK;
 }
+static int dyn_n_of(const Group& G) { return G.res_kind == NLLS_RES_DYN_LINEAR ? G.ndata - 1 : G.nres; }
+static int launch_dyn_cost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase, bool fixed_only) {
+    const int64_t nb = fixed_only ? G.nfixedcost : G.ncost;
+    if (nb > 0) {
+        hipLaunchKernelGGL(dyn_block_kernel, dim3((unsigned)nb), dim3(TPB), 0, c->stream, G.res_kind, dyn_n_of(G), G.ndata, vars, G.data.p, G.voff.p,
+                           fixed_only ? G.fixedcost.p : (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, (double*)nullptr, (double*)nullptr, c->partials.p + pbase);
+        pbase += nb;
+    }
+    return NLLS_OK;
+}
+int enqueue_dyn_gradhess(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if (G.dense.n > 0) {
+        hipLaunchKernelGGL(dyn_block_kernel, dim3((unsigned)G.dense.n), dim3(TPB), 0, c->stream, G.res_kind, dyn_n_of(G), G.ndata, vars, G.dense.data.p, G.dense.voff.p,
+                           (const uint32_t*)nullptr, G.dense.brow.p, (int)c->info.ndof, c->A.p, c->b.p, c->partials.p + pbase);
+        pbase += G.dense.n;
+    }
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
 // cost blocks whose variables are all fixed: cost only (called from the gradient sweep as well)
 int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if (is_dyn_kind(G.res_kind)) return launch_dyn_cost(c, G, vars, pbase, true);
     switch (G.res_kind) {
 #define X(K) case K: return launch_fixedcost<K>(c, G, vars, pbase);
         NLLS_FOR_EACH_RES(X)
@@ -319,6 +374,7 @@ int enqueue_reduce_partials(nlls_ctx* c, int64_t n) {
 int enqueue_sweep_cost(nlls_ctx* c, int which, int64_t pofs, int64_t* count) {
     const double* vars = vars_ptr(c, which); int64_t pbase = pofs;
     for (const Group& G : c->groups) {
+        if (is_dyn_kind(G.res_kind)) { launch_dyn_cost(c, G, vars, pbase, false); continue; }
         switch (G.res_kind) {
 #define X(K) case K: launch_cost<K>(c, G, vars, pbase); break;
             NLLS_FOR_EACH_RES(X)

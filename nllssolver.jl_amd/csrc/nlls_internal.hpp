@@ -11,6 +11,7 @@ namespace nlls {
 
 struct ResDesc { int ndeps, nres, ndata, adaptive; int sk[4], sd[4]; };
 bool res_desc(int kind, ResDesc& d);
+inline bool is_dyn_kind(int kind) { return kind == NLLS_RES_DYN_LINEAR || kind == NLLS_RES_DYN_NORM; }
 
 int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags);
@@ -21,6 +22,7 @@ int build_schur(nlls_ctx* c, int32_t flags);
 int enqueue_sweep_cost(nlls_ctx* c, int which, int64_t pofs = 0, int64_t* count = nullptr);
 // (nlls_cost.hip) cost-only blocks and the final reduction of the cost partials, shared with the gradient sweep
 int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);
+int enqueue_dyn_gradhess(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);   // dynamic-size residual blocks (dense system): accumulate
 int enqueue_reduce_partials(nlls_ctx* c, int64_t n);
 int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost = true);
 // vector helpers (nlls_sweep.hip)
@@ -43,7 +45,7 @@ __device__ __forceinline__ void retract_one(const int32_t* __restrict__ kind, co
                                             const double* __restrict__ x, double* __restrict__ to) {
     const int k = kind[i], d = dim[i]; const uint32_t o = voff[i], bo = vboff[i];
     if (bo == DEST_NONE) { const int st = var_storage(k, d); for (int q = 0; q < st; ++q) to[o + q] = from[o + q]; return; }
-    if (k == NLLS_VAR_EUCLIDEAN) { for (int q = 0; q < d; ++q) to[o + q] = from[o + q] + x[bo + q]; return; }   // v + delta (src/variable.jl:5): no staging arrays
+    if (k == NLLS_VAR_EUCLIDEAN || k == NLLS_VAR_DYNAMIC) { for (int q = 0; q < d; ++q) to[o + q] = from[o + q] + x[bo + q]; return; }   // v + delta (src/variable.jl:5): no staging arrays (any length)
     double in[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], out[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], st[NLLS_MAX_BLOCK_SZ];
     const int ns = var_storage(k, d), nd = var_dof(k, d);
     for (int q = 0; q < ns; ++q) in[q] = from[o + q];

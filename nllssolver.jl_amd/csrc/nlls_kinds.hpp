@@ -162,13 +162,13 @@ template <int N> struct Lift<Dual2N<N>> {     // (seeding through a LINEAR retra
 // variable kinds
 // ------------------------------------------------------------------------------------------------
 NLLS_HD constexpr int var_storage(int kind, int dim) {
-    return kind == NLLS_VAR_EUCLIDEAN ? dim
+    return (kind == NLLS_VAR_EUCLIDEAN || kind == NLLS_VAR_DYNAMIC) ? dim
          : (kind == NLLS_VAR_ZERO_TO_INF || kind == NLLS_VAR_ZERO_TO_ONE) ? 1
          : kind == NLLS_VAR_CONTAMINATED_GAUSSIAN ? 3
          : kind == NLLS_VAR_POSE_SO3 ? 12 : -1;
 }
 NLLS_HD constexpr int var_dof(int kind, int dim) {   // nvars(): src/variable.jl:4,9,21,28; robustadaptive.jl:21
-    return kind == NLLS_VAR_EUCLIDEAN ? dim
+    return (kind == NLLS_VAR_EUCLIDEAN || kind == NLLS_VAR_DYNAMIC) ? dim
          : (kind == NLLS_VAR_ZERO_TO_INF || kind == NLLS_VAR_ZERO_TO_ONE) ? 1
          : kind == NLLS_VAR_CONTAMINATED_GAUSSIAN ? 3
          : kind == NLLS_VAR_POSE_SO3 ? 6 : -1;

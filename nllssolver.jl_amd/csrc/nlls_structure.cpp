@@ -21,6 +21,10 @@ bool res_desc(int kind, ResDesc& d) {
         for (int i = 0; i < 4; ++i) { d.sk[i] = Res<K>::SK[i]; d.sd[i] = Res<K>::SD[i]; } return true;
         NLLS_FOR_EACH_RES(X)
 #undef X
+    // dynamic-size kinds (src/autodiff.jl:96-121): counts that depend on the variable's run-time length n are -1 here and fixed per group
+    // at upload (build_structure)
+    case NLLS_RES_DYN_LINEAR: d = ResDesc{1, 1, -1, 0, {NLLS_VAR_DYNAMIC, 0, 0, 0}, {0, 0, 0, 0}}; return true;
+    case NLLS_RES_DYN_NORM:   d = ResDesc{1, -1, 0, 0, {NLLS_VAR_DYNAMIC, 0, 0, 0}, {0, 0, 0, 0}}; return true;
     }
     return false;
 }
@@ -45,7 +49,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     uint64_t off = 0;
     for (int64_t i = 0; i < nvar; ++i) {
         int st = var_storage(var_kind[i], var_dim[i]);
-        if (st <= 0 || var_dof(var_kind[i], var_dim[i]) > NLLS_MAX_BLOCK_SZ) return fail(c, NLLS_ERR_UNSUPPORTED, "unregistered variable kind / block larger than MAX_BLOCK_SZ");
+        if (st <= 0 || var_dof(var_kind[i], var_dim[i]) > (var_kind[i] == NLLS_VAR_DYNAMIC ? NLLS_MAX_DYN_DIM : NLLS_MAX_BLOCK_SZ)) return fail(c, NLLS_ERR_UNSUPPORTED, "unregistered variable kind / block larger than MAX_BLOCK_SZ");
         c->var_off[i] = (uint32_t)off; off += st;
         if (off > 0xFFFFFFF0ull) return fail(c, NLLS_ERR_UNSUPPORTED, "variable storage exceeds 32-bit offsets");
     }
@@ -59,11 +63,22 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     const int64_t ndof = c->boffsets[nb];
     // ---- groups: validate ------------------------------------------------------------------------
     std::vector<ResDesc> desc(ngroups);
-    int64_t ncost_total = 0;
+    int64_t ncost_total = 0; bool any_dyn = false;
     for (int g = 0; g < ngroups; ++g) {
         if (!res_desc(groups[g].res_kind, desc[g])) return fail(c, NLLS_ERR_UNSUPPORTED, "unregistered residual kind");
         int base = groups[g].robust_kind & 0xF;
         if (base > NLLS_ROBUST_GEMAN_MCCLURE || (groups[g].robust_kind & ~0x1F)) return fail(c, NLLS_ERR_UNSUPPORTED, "unregistered robust kernel");
+        if (is_dyn_kind(groups[g].res_kind)) {       // n = the run-time length of the block's variable: the same for every block of the group
+            any_dyn = true;
+            if (base != NLLS_ROBUST_NONE) return fail(c, NLLS_ERR_UNSUPPORTED, "dynamic-size residual kinds take no robust kernel");
+            int n = -1;
+            for (int64_t k = 0; k < groups[g].ncost; ++k) { const int64_t v = groups[g].varind[k];
+                if (v < 1 || v > nvar) return fail(c, NLLS_ERR_INVALID_ARG, "varind out of range");
+                if (n < 0) n = var_dim[v - 1]; else if (var_dim[v - 1] != n) return fail(c, NLLS_ERR_UNSUPPORTED, "dynamic-size blocks of one group must share the variable length"); }
+            if (n < 0) n = 0;
+            if (desc[g].ndata < 0) desc[g].ndata = 1 + n;
+            if (desc[g].nres < 0) desc[g].nres = n;
+        }
         const ResDesc& d = desc[g];
         for (int64_t k = 0; k < groups[g].ncost; ++k) for (int s = 0; s < d.ndeps; ++s) {
             int64_t v = groups[g].varind[k * d.ndeps + s];
@@ -89,6 +104,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
         int64_t bnnz = 0; for (uint64_t k : keys) bnnz += (int64_t)c->blocksizes[k / nb] * c->blocksizes[k % nb];   // utils.jl:110-120
         sparse = (flags & NLLS_FLAG_FORCE_SPARSE) || (bnnz * 64) < (25 * ndof * (ndof - 40));                        // utils.jl:108
     }
+    if (any_dyn && sparse) return fail(c, NLLS_ERR_UNSUPPORTED, "dynamic-size residual blocks are accumulated into the dense linear system only");
+    if (any_dyn && c->nranks > 1) return fail(c, NLLS_ERR_UNSUPPORTED, "dynamic-size residual blocks run unsharded");
     c->it_colptr.clear(); c->it_rowval.clear(); c->it_nzval.clear(); c->diag_off.assign(nb, -1);
     int64_t nnz_data = 0;
     if (sparse) {   // BlockSparseMatrix constructor, BlockSparseMatrix.jl:30-47 (0-based here)
@@ -329,6 +346,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     c->nzero = (int64_t)zero_off.size();
     HIPCHK(c->d_zero_off.upload(zero_off)); HIPCHK(c->d_zero_len.upload(zero_len)); HIPCHK(c->d_zero_b_off.upload(zero_b_off)); HIPCHK(c->d_zero_b_len.upload(zero_b_len));
     for (int g = 0; g < ngroups; ++g) npartials += (c->groups[g].ncost + 255) / 256 + 1;
+    for (int g = 0; g < ngroups; ++g) if (is_dyn_kind(c->groups[g].res_kind)) npartials += 3 * c->groups[g].ncost + 3;   // dynamic-size blocks: one partial per block
     c->npartials = std::max<int64_t>(npartials + 16, 4096);
     // (an LM trial keeps the cost partials behind the post-solve partials, at TRIAL_COST_POFS: both are reduced by ONE finishing launch)
     HIPCHK(c->partials.alloc(TRIAL_COST_POFS + c->npartials));

@@ -18,6 +18,7 @@ const lib = get(ENV, "NLLS_AMD_LIB", "libnlls_amd.so")
 
 # ---- kinds (include/nlls_amd.h) ------------------------------------------------------------------------
 const VAR_EUCLIDEAN, VAR_ZERO_TO_INF, VAR_ZERO_TO_ONE, VAR_CONTAMINATED_GAUSSIAN = Int32(1), Int32(2), Int32(3), Int32(4)
+const VAR_DYNAMIC = Int32(6)                                       # DynamicVector{Float64}: run-time length (dynamic-size residual kinds 11, 12)
 const ROBUST_NONE, ROBUST_HUBER, ROBUST_HUBER2O, ROBUST_GEMAN_MCCLURE, ROBUST_SCALED = Int32(0), Int32(1), Int32(2), Int32(3), Int32(0x10)
 
 struct CostGroup              # nlls_cost_group
@@ -44,6 +45,7 @@ varkind(::ZeroToInfScalar) = (VAR_ZERO_TO_INF, Int32(1));         pack!(out, v::
 varkind(::ZeroToOneScalar) = (VAR_ZERO_TO_ONE, Int32(1));         pack!(out, v::ZeroToOneScalar) = push!(out, v.val)
 varkind(::ContaminatedGaussian) = (VAR_CONTAMINATED_GAUSSIAN, Int32(3))
 pack!(out, v::ContaminatedGaussian) = append!(out, (v.invsigma1.val, v.invsigma2.val, v.w.val))
+varkind(v::NLLSsolver.DynamicVector{Float64}) = (VAR_DYNAMIC, Int32(length(v))); pack!(out, v::NLLSsolver.DynamicVector{Float64}) = append!(out, v)
 varkind(::Any) = nothing                                          # unregistered: decline
 
 robustspec(::NoRobust) = (ROBUST_NONE, (0.0, 0.0, 0.0, 0.0))
@@ -166,6 +168,7 @@ function fetchvariables!(problem::NLLSProblem, ls::MultiVariateLSgpu, which::Int
 end
 unpack(::Number, p, o) = (p[o+1], o + 1)
 unpack(::EuclideanVector{N, T}, p, o) where {N, T} = (EuclideanVector{N, T}(ntuple(k -> p[o+k], N)), o + N)
+unpack(v::NLLSsolver.DynamicVector{Float64}, p, o) = (p[o+1:o+length(v)], o + length(v))
 unpack(::ZeroToInfScalar{T}, p, o) where T = (ZeroToInfScalar{T}(p[o+1]), o + 1)
 unpack(::ZeroToOneScalar{T}, p, o) where T = (ZeroToOneScalar{T}(p[o+1]), o + 1)
 unpack(::ContaminatedGaussian{T}, p, o) where T = (ContaminatedGaussian(ZeroToInfScalar{T}(p[o+1]), ZeroToInfScalar{T}(p[o+2]), ZeroToOneScalar{T}(p[o+3])), o + 3)

@@ -10,6 +10,7 @@ VAR_ZERO_TO_INF = 2
 VAR_ZERO_TO_ONE = 3
 VAR_CONTAMINATED_GAUSSIAN = 4
 VAR_POSE_SO3 = 5
+VAR_DYNAMIC = 6             # DynamicVector{Float64}: run-time length (src/variable.jl), only under the RES_DYN_* kinds
 
 # residual kinds
 RES_BA_AFFINE = 1         # test/optimizeba.jl:4
@@ -22,6 +23,9 @@ RES_BA_SO3 = 7            # new
 RES_BA_SO3_ADAPTIVE = 8   # new
 RES_LINEAR3 = 9           # test/nonsquaredcost.jl:4-14: X w - y
 COST_LINEAR3 = 10         # test/nonsquaredcost.jl:28-37: non-squared AbstractCost y'w (value, gradient, Hessian by second-order duals)
+RES_DYN_LINEAR = 11       # test/dynamicvars.jl:3-11: X'w - y over one dynamic-size variable; data = (y, X[n])
+RES_DYN_NORM = 12         # test/dynamicvars.jl:13-21: w (nres = n); no data
+DYN_KINDS = (RES_DYN_LINEAR, RES_DYN_NORM)
 
 # robust kernels: src/robust.jl:7-77
 ROBUST_NONE = 0
@@ -42,6 +46,8 @@ RES_TABLE = {
     RES_BA_SO3_ADAPTIVE: (3, 2, 2, True, ((VAR_CONTAMINATED_GAUSSIAN, 3), (VAR_POSE_SO3, 6), (VAR_EUCLIDEAN, 3))),
     RES_LINEAR3: (1, 3, 12, False, ((VAR_EUCLIDEAN, 3),)),
     COST_LINEAR3: (1, 0, 3, False, ((VAR_EUCLIDEAN, 3),)),
+    RES_DYN_LINEAR: (1, 1, -1, False, ((VAR_DYNAMIC, 0),)),    # ndata = 1 + n (the variable's run-time length)
+    RES_DYN_NORM: (1, -1, 0, False, ((VAR_DYNAMIC, 0),)),      # nres = n
 }
 
 
@@ -59,13 +65,13 @@ def res_ndata(kind):
 
 def var_storage(kind, dim):
     """Storage length of a variable (may exceed its dof, src/docstrings.jl:11-14)."""
-    return {VAR_EUCLIDEAN: dim, VAR_ZERO_TO_INF: 1, VAR_ZERO_TO_ONE: 1,
+    return {VAR_EUCLIDEAN: dim, VAR_DYNAMIC: dim, VAR_ZERO_TO_INF: 1, VAR_ZERO_TO_ONE: 1,
             VAR_CONTAMINATED_GAUSSIAN: 3, VAR_POSE_SO3: 12}[kind]
 
 
 def var_dof(kind, dim):
     """nvars(): src/variable.jl:4,9,21,28; src/robustadaptive.jl:21."""
-    return {VAR_EUCLIDEAN: dim, VAR_ZERO_TO_INF: 1, VAR_ZERO_TO_ONE: 1,
+    return {VAR_EUCLIDEAN: dim, VAR_DYNAMIC: dim, VAR_ZERO_TO_INF: 1, VAR_ZERO_TO_ONE: 1,
             VAR_CONTAMINATED_GAUSSIAN: 3, VAR_POSE_SO3: 6}[kind]
 
 

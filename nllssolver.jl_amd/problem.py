@@ -31,6 +31,8 @@ class CostGroup:
     def arrays(self):
         if self._cache is None:
             nd, ndata = K.res_ndeps(self.res_kind), K.res_ndata(self.res_kind)
+            if ndata < 0:                      # dynamic-size kind: the width is whatever the blocks came with (1 + n)
+                ndata = self._da[0].shape[1] if self._da else 0
             vi = np.concatenate(self._vi, axis=0) if self._vi else np.zeros((0, nd), np.int64)
             da = np.concatenate(self._da, axis=0) if self._da else np.zeros((0, ndata), np.float64)
             self._vi, self._da = [vi], [da]
@@ -64,7 +66,7 @@ class NLLSProblem:
     def addvariable(self, value, kind=K.VAR_EUCLIDEAN):
         """addvariable!(problem, variable) -> 1-based index   src/problem.jl:114-122"""
         v = np.atleast_1d(np.asarray(value, dtype=np.float64)).ravel()
-        dim = v.size if kind == K.VAR_EUCLIDEAN else K.var_dof(kind, 0)
+        dim = v.size if kind in (K.VAR_EUCLIDEAN, K.VAR_DYNAMIC) else K.var_dof(kind, 0)
         assert v.size == K.var_storage(kind, dim), "storage size does not match the variable kind"
         assert K.var_dof(kind, dim) > 0, "Problem with nvars()"
         self._kind.append(kind); self._dim.append(dim); self._chunks.append(v.copy())
@@ -75,7 +77,7 @@ class NLLSProblem:
         """Bulk addvariable!: values is (n x storage); returns the 1-based index of the first."""
         values = np.ascontiguousarray(values, dtype=np.float64)
         n, st = values.shape
-        dim = st if kind == K.VAR_EUCLIDEAN else K.var_dof(kind, 0)
+        dim = st if kind in (K.VAR_EUCLIDEAN, K.VAR_DYNAMIC) else K.var_dof(kind, 0)
         assert st == K.var_storage(kind, dim)
         first = len(self._kind) + 1
         self._kind += [kind] * n; self._dim += [dim] * n; self._chunks.append(values.ravel().copy())
@@ -130,7 +132,9 @@ class NLLSProblem:
         robust = robust or K.NoRobust()
         nd, ndata = K.res_ndeps(res_kind), K.res_ndata(res_kind)
         varind = np.ascontiguousarray(np.asarray(varind, dtype=np.int64).reshape(-1, nd))
-        data = np.ascontiguousarray(np.asarray(data, dtype=np.float64).reshape(-1, ndata))
+        if ndata < 0:                          # dynamic-size kind (src/autodiff.jl:96-121): 1 + n doubles per block, n = the variable's length
+            ndata = 1 + int(self.var_dim[varind[0, 0] - 1])
+        data = np.ascontiguousarray(np.asarray(data, dtype=np.float64).reshape(varind.shape[0], ndata))
         assert varind.shape[0] == data.shape[0]
         assert 0 < nd <= 10, "Problem with ndeps()"            # MAX_ARGS, src/NLLSsolver.jl:28
         if varind.size:
@@ -141,7 +145,7 @@ class NLLSProblem:
                 assert np.all(vk == sk), f"slot {s + 1}: variable kind does not match the residual"
                 if sk == K.VAR_EUCLIDEAN:
                     assert np.all(dd[varind[:, s] - 1] == sd), f"slot {s + 1}: variable dimension mismatch"
-        key = (int(res_kind), robust.key())
+        key = (int(res_kind), robust.key()) if res_kind not in K.DYN_KINDS else (int(res_kind), robust.key(), int(self.var_dim[varind[0, 0] - 1]))   # dynamic: one group per variable length
         if key not in self.costs:
             self.costs[key] = CostGroup(res_kind, robust)
         self.costs[key].append(varind, data)

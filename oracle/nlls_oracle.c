@@ -38,12 +38,15 @@ static const res_desc RES[NLLS_RES_KIND_COUNT] = {
     /* BA_SO3_ADAPTIVE */ {3, 2, 2, 1, {NLLS_VAR_CONTAMINATED_GAUSSIAN, NLLS_VAR_POSE_SO3, NLLS_VAR_EUCLIDEAN}, {3, 6, 3}},
     /* LINEAR3         */ {1, 3, 12, 0, {NLLS_VAR_EUCLIDEAN}, {3}},
     /* COST_LINEAR3    */ {1, 0, 3, 0, {NLLS_VAR_EUCLIDEAN}, {3}},   /* nres = 0: an AbstractCost, not a residual */
+    /* DYN_LINEAR      */ {1, 1, -1, 0, {NLLS_VAR_DYNAMIC}, {0}},    /* ndata = 1 + n: see ogroup.ndata */
+    /* DYN_NORM        */ {1, -1, 0, 0, {NLLS_VAR_DYNAMIC}, {0}},    /* nres = n */
 };
+#define IS_DYN_KIND(k) ((k) == NLLS_RES_DYN_LINEAR || (k) == NLLS_RES_DYN_NORM)
 #define IS_COST_KIND(k) ((k) == NLLS_COST_LINEAR3)
 
 static int var_storage(int kind, int dim) {
     switch (kind) {
-    case NLLS_VAR_EUCLIDEAN: return dim;
+    case NLLS_VAR_EUCLIDEAN: case NLLS_VAR_DYNAMIC: return dim;
     case NLLS_VAR_ZERO_TO_INF: case NLLS_VAR_ZERO_TO_ONE: return 1;
     case NLLS_VAR_CONTAMINATED_GAUSSIAN: return 3;
     case NLLS_VAR_POSE_SO3: return 12;
@@ -52,7 +55,7 @@ static int var_storage(int kind, int dim) {
 }
 static int var_dof(int kind, int dim) { /* nvars(): src/variable.jl:4,9,14,21,28; robustadaptive.jl:21 */
     switch (kind) {
-    case NLLS_VAR_EUCLIDEAN: return dim;
+    case NLLS_VAR_EUCLIDEAN: case NLLS_VAR_DYNAMIC: return dim;
     case NLLS_VAR_ZERO_TO_INF: case NLLS_VAR_ZERO_TO_ONE: return 1;
     case NLLS_VAR_CONTAMINATED_GAUSSIAN: return 3;
     case NLLS_VAR_POSE_SO3: return 6;
@@ -87,7 +90,7 @@ void oracle_contaminated_gaussian(double s1, double s2, double w, double st[3]) 
 }
 void oracle_var_update(int32_t kind, int32_t dim, const double* in, const double* d, double* out) {
     switch (kind) {
-    case NLLS_VAR_EUCLIDEAN: for (int i = 0; i < dim; ++i) out[i] = in[i] + d[i]; break;
+    case NLLS_VAR_EUCLIDEAN: case NLLS_VAR_DYNAMIC: for (int i = 0; i < dim; ++i) out[i] = in[i] + d[i]; break;
     case NLLS_VAR_ZERO_TO_INF: out[0] = zti_update(in[0], d[0]); break;
     case NLLS_VAR_ZERO_TO_ONE: out[0] = zto_update(in[0], d[0]); break;
     case NLLS_VAR_CONTAMINATED_GAUSSIAN: { /* robustadaptive.jl:22 then the ordering of :13-15 */
@@ -570,7 +573,7 @@ int64_t oracle_bsm_sparse_indices(int64_t nrb, int64_t ncb, const int64_t* cp, c
 /* ============================================================================================ */
 /* problem                                                                                      */
 /* ============================================================================================ */
-typedef struct { int32_t res_kind, robust_kind; double rp[4]; int64_t ncost; int64_t* varind; double* data; } ogroup;
+typedef struct { int32_t res_kind, robust_kind; double rp[4]; int64_t ncost; int64_t* varind; double* data; int64_t ndata; int32_t dyn_n; } ogroup;   /* ndata: doubles per block (dynamic kinds: 1 + n or 0) */
 struct oracle_problem {
     int64_t nvar, nstorage; int32_t *kind, *dim; int64_t* voff; double* vars[3];
     int32_t ngroups; ogroup* g; int64_t ncost_total;
@@ -587,7 +590,10 @@ oracle_problem* oracle_problem_create(int64_t nvar, const int32_t* vk, const int
         g->res_kind = groups[gi].res_kind; g->robust_kind = groups[gi].robust_kind; memcpy(g->rp, groups[gi].robust_params, sizeof g->rp);
         g->ncost = groups[gi].ncost; p->ncost_total += g->ncost;
         g->varind = (int64_t*)malloc(sizeof(int64_t) * (g->ncost * d->ndeps + 1)); memcpy(g->varind, groups[gi].varind, sizeof(int64_t) * g->ncost * d->ndeps);
-        g->data = (double*)malloc(sizeof(double) * (g->ncost * d->ndata + 1)); memcpy(g->data, groups[gi].data, sizeof(double) * g->ncost * d->ndata);
+        g->ndata = d->ndata; g->dyn_n = 0;
+        if (IS_DYN_KIND(g->res_kind)) { /* dynamic-size blocks (src/autodiff.jl:96-121): n = the length of the block's variable, the same for the whole group */
+            g->dyn_n = g->ncost > 0 ? vd[g->varind[0] - 1] : 0; g->ndata = g->res_kind == NLLS_RES_DYN_LINEAR ? 1 + g->dyn_n : 0; }
+        g->data = (double*)malloc(sizeof(double) * (g->ncost * g->ndata + 1)); if (g->ndata > 0) memcpy(g->data, groups[gi].data, sizeof(double) * g->ncost * g->ndata);
     }
     return p;
 }
@@ -613,8 +619,24 @@ static void block_residual(const oracle_problem* p, const double* vars, const og
     for (int m = 0; m < d->nres; ++m) r[m] = rj[m].v;
 }
 /* computerescost  src/residual.jl:49-55 */
+/* dynamic-size residual blocks: computeresjacdynamic (src/autodiff.jl:96-121) of the two registered residuals is known in closed form --
+ * LinearResidual X'w - y (test/dynamicvars.jl:3-11): J = X';  NormResidual w (test/dynamicvars.jl:13-21): J = I -- no robust kernel.
+ * cost = 0.5 r'r; with H / gv (n x n col-major, n) also J'J and J'r (src/residual.jl:72-74). */
+static double dyn_block(const oracle_problem* p, const double* vars, const ogroup* g, int64_t ci, double* gv, double* H) {
+    const int n = g->dyn_n; const double* w = vars + p->voff[g->varind[ci] - 1];
+    if (g->res_kind == NLLS_RES_DYN_LINEAR) {
+        const double* dd = g->data + ci * g->ndata; const double* X = dd + 1; double r = -dd[0];
+        for (int i = 0; i < n; ++i) r += X[i] * w[i];
+        if (gv) for (int i = 0; i < n; ++i) { gv[i] = X[i] * r; for (int j = 0; j < n; ++j) H[i + (size_t)n * j] = X[i] * X[j]; }
+        return 0.5 * r * r;
+    }
+    double c = 0; for (int i = 0; i < n; ++i) c += w[i] * w[i];
+    if (gv) for (int i = 0; i < n; ++i) { gv[i] = w[i]; for (int j = 0; j < n; ++j) H[i + (size_t)n * j] = i == j ? 1.0 : 0.0; }
+    return 0.5 * c;
+}
 static double block_cost(const oracle_problem* p, const double* vars, const ogroup* g, int64_t ci) {
     const res_desc* d = &RES[g->res_kind];
+    if (IS_DYN_KIND(g->res_kind)) return dyn_block(p, vars, g, ci, 0, 0);
     if (IS_COST_KIND(g->res_kind)) { /* computecost: the value itself (src/cost.jl:10-13 over an AbstractCost) */
         const double* st[4]; int start[4];
         for (int s = 0; s < d->ndeps; ++s) { st[s] = vars + p->voff[g->varind[ci * d->ndeps + s] - 1]; start[s] = -1; }
@@ -797,6 +819,13 @@ static double grad_fn(void* cv, int64_t ci) {
     uint64_t bidx[4]; int sf[4], any = 0, dofs[4];
     for (int k = 0; k < d->ndeps; ++k) { int64_t vi = g->varind[ci * d->ndeps + k] - 1; bidx[k] = ls->blockindices[vi]; sf[k] = bidx[k] != 0; any |= sf[k]; dofs[k] = var_dof(p->kind[vi], p->dim[vi]); }
     if (!any) return block_cost(p, s->vars, g, ci); /* cost.jl:51 */
+    if (IS_DYN_KIND(g->res_kind)) { /* one variable of run-time size: heap storage like the reference's dynamic path */
+        const int n = g->dyn_n; double* gd = (double*)malloc(sizeof(double) * (size_t)n * (n + 1)); double* Hd = gd + n;
+        const double cd = dyn_block(p, s->vars, g, ci, gd, Hd);
+        for (int r = 0; r < n; ++r) ls->b[ls->boffsets[bidx[0] - 1] - 1 + r] += gd[r];
+        add_block(ls, bidx[0], bidx[0], Hd, n, 0, n, 0, n);
+        free(gd); return cd;
+    }
     double c, gv[MAXP], H[MAXP * MAXP]; int P = block_costgradhess(p, s->vars, g, ci, sf, &c, gv, H);
     int loff[4], o = 0; for (int k = 0; k < d->ndeps; ++k) { loff[k] = o; if (sf[k]) o += dofs[k]; }
     for (int i = 0; i < d->ndeps; ++i) if (sf[i]) {

@@ -425,3 +425,28 @@ def test_native_lm_loop_is_the_python_loop(shape):
     assert ra[-1][6] != 0 and rb[-1][6] != 0                            # both terminated (the same iteration count, asserted above)
     if shape == "curvefit":                                            # (the affine bundle adjustments have a gauge freedom: same cost, different variables)
         assert np.max(np.abs(va - vb)) < 1e-6
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_dynamic_size_variables_on_device(seed):
+    """test/dynamicvars.jl:24-41 on the device: a DynamicVector variable of run-time length n (51..100: below and above the 64-dof
+    limit of the one-wave dense solve), LinearResidual + NormResidual (dynamic-size blocks, src/autodiff.jl:96-121), Newton as in the
+    reference's test and Levenberg-Marquardt: `X' * Y ~ norm(Y)`, the closed form X / (1 + X'X), and the oracle's sweep."""
+    from nllssolver_jl_amd import _capi
+    from tests.test_gpu_parity import check_problem
+    rng = np.random.default_rng(seed)
+    n = int(np.ceil((1.0 + rng.random()) * 50)) if seed != 4 else 57; X = rng.standard_normal(n); X /= np.linalg.norm(X)
+    def mk(start=None):
+        p = N.NLLSProblem(); p.addvariable(np.zeros(n) if start is None else start, K.VAR_DYNAMIC)
+        p.addcosts(K.RES_DYN_LINEAR, [[1]], np.concatenate([[1.0], X])[None, :])
+        p.addcosts(K.RES_DYN_NORM, [[1]], np.zeros((1, 0)))
+        return p
+    info = check_problem(mk(rng.standard_normal(n)), expect_sparse=0)          # cost, A.data, b, step, retraction against the oracle
+    assert info.ndof == n
+    for it in (N.newton, N.levenbergmarquardt):
+        p = mk()
+        res = N.optimize(p, N.NLLSOptions(iterator=it))
+        Y = p.variables
+        assert np.isclose(X @ Y, np.linalg.norm(Y), rtol=1e-7), (X @ Y, np.linalg.norm(Y))      # test/dynamicvars.jl:40
+        assert np.allclose(Y, X / (1.0 + X @ X), atol=1e-7)
+        assert res.bestcost < res.startcost

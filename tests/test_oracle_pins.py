@@ -356,3 +356,24 @@ def test_nonsquared_cost_closed_form(seed):
     op.set_variables(np.zeros(3))
     r = op.optimize(iterator=0)                             # NLLSOptions(iterator = newton), test/nonsquaredcost.jl:62
     assert np.allclose(op.get_variables(), solution, rtol=1e-9, atol=1e-12), (op.get_variables(), solution)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_dynamic_size_variables_known_answer(seed):
+    """test/dynamicvars.jl:24-41: one DynamicVector variable of run-time length n in (50, 100], a LinearResidual X'w - 1 (scalar) and a
+    NormResidual w (length n), Newton iterator: the optimum is collinear to X, `X' * Y ~ norm(Y)` (:40).  Dynamic-size blocks
+    (src/autodiff.jl:96-121) through the oracle; closed form of the optimum: Y = X / (1 + X'X)."""
+    from nllssolver_jl_amd import kinds as K
+    rng = np.random.default_rng(seed)
+    n = int(np.ceil((1.0 + rng.random()) * 50)); X = rng.standard_normal(n); X /= np.linalg.norm(X)
+    p = N.NLLSProblem(); p.addvariable(np.zeros(n), K.VAR_DYNAMIC)
+    p.addcosts(K.RES_DYN_LINEAR, [[1]], np.concatenate([[1.0], X])[None, :])
+    p.addcosts(K.RES_DYN_NORM, [[1]], np.zeros((1, 0)))
+    for iterator in (0, 1):                                    # newton (as in the reference's test), Levenberg-Marquardt
+        op = oracle_problem(p)
+        res = op.optimize(iterator=iterator)
+        Y = op.get_variables()
+        assert np.isclose(X @ Y, np.linalg.norm(Y), rtol=1e-7), (iterator, X @ Y, np.linalg.norm(Y))
+        assert np.allclose(Y, X / (1.0 + X @ X), atol=1e-7)
+    ols = oracle_problem(p).linear_system(blockindices(p))
+    assert not ols.info.is_sparse and ols.info.ndof == n       # one variable: UniVariateLS / dense
