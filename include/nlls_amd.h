@@ -80,7 +80,11 @@ typedef struct nlls_ctx nlls_ctx;
                                        Dynamic kinds: every block of a group has the same n; no robust kernel; the system must come out
                                        dense (src/linearsystem.jl:105-123 decides; one variable always does); nlls_res_ndata / nlls_res_nres
                                        return -1 where the count is n-dependent */
-#define NLLS_RES_KIND_COUNT      13
+#define NLLS_RES_DYN_LINEARSQ    13 /* DYNAMIC-size: LinearResidualDynamic X*w - y with a square X (n x n, column-major) over one NLLS_VAR_DYNAMIC
+                                       variable of length n; data = (y[n], X[n*n]); nres = n; n <= 512              test/nonsquaredcost.jl:16-26 */
+#define NLLS_COST_DYN_LINEAR     14 /* DYNAMIC-size NON-SQUARED AbstractCost: LinearCostDynamic, computecost = y'w; data = y[n]: value y'w, gradient y,
+                                       Hessian 0 (src/autodiff.jl:144-159)                                          test/nonsquaredcost.jl:39-46 */
+#define NLLS_RES_KIND_COUNT      15
 
 /* ---- robust kernels: src/robust.jl:7-77 ------------------------------------------------------ */
 #define NLLS_ROBUST_NONE           0 /* NoRobust                                               */

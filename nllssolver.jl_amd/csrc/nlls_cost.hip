@@ -68,6 +68,25 @@ __global__ __launch_bounds__(TPB) void dyn_block_kernel(int kind, int n, int nda
             for (int i = threadIdx.x; i < n; i += TPB) atomicAdd(&b[bo + i], X[i] * r);
             for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int i = (int)(e % n), j = (int)(e / n); if (i >= j) atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + j)], X[i] * X[j]); }
         }
+    } else if (kind == NLLS_RES_DYN_LINEARSQ) {                                   // X*w - y, X square (n <= 512): J = X
+        __shared__ double rs[512];
+        const double* dd = data + k * (int64_t)ndata; const double* X = dd + n;
+        for (int i = threadIdx.x; i < n; i += TPB) { double t = -dd[i]; for (int j = 0; j < n; ++j) t = fma(X[i + (size_t)n * j], w[j], t); rs[i] = t; }
+        __syncthreads();
+        double acc = 0;
+        for (int i = threadIdx.x; i < n; i += TPB) acc += rs[i] * rs[i];
+        cost = 0.5 * block_sum(acc, red);
+        if (bo != DEST_NONE) {
+            for (int j = threadIdx.x; j < n; j += TPB) { double t = 0; for (int i = 0; i < n; ++i) t = fma(X[i + (size_t)n * j], rs[i], t); atomicAdd(&b[bo + j], t); }
+            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int j = (int)(e % n), q = (int)(e / n); if (j < q) continue;
+                double h = 0; for (int i = 0; i < n; ++i) h = fma(X[i + (size_t)n * j], X[i + (size_t)n * q], h); atomicAdd(&A[(bo + j) + (size_t)ndof * (bo + q)], h); }
+        }
+    } else if (kind == NLLS_COST_DYN_LINEAR) {                                   // non-squared cost y'w: value, gradient y, Hessian 0
+        const double* y = data + k * (int64_t)ndata;
+        double acc = 0;
+        for (int i = threadIdx.x; i < n; i += TPB) acc += y[i] * w[i];
+        cost = block_sum(acc, red);
+        if (bo != DEST_NONE) for (int i = threadIdx.x; i < n; i += TPB) atomicAdd(&b[bo + i], y[i]);
     } else {
         double acc = 0;
         for (int i = threadIdx.x; i < n; i += TPB) acc += w[i] * w[i];
@@ -335,7 +354,7 @@ static int launch_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int
     }
     return NLLS_OK;
 }
-static int dyn_n_of(const Group& G) { return G.res_kind == NLLS_RES_DYN_LINEAR ? G.ndata - 1 : G.nres; }
+static int dyn_n_of(const Group& G) { return G.res_kind == NLLS_RES_DYN_LINEAR ? G.ndata - 1 : G.res_kind == NLLS_COST_DYN_LINEAR ? G.ndata : G.nres; }
 static int launch_dyn_cost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase, bool fixed_only) {
     const int64_t nb = fixed_only ? G.nfixedcost : G.ncost;
     if (nb > 0) {

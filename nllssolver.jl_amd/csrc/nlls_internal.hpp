@@ -11,7 +11,7 @@ namespace nlls {
 
 struct ResDesc { int ndeps, nres, ndata, adaptive; int sk[4], sd[4]; };
 bool res_desc(int kind, ResDesc& d);
-inline bool is_dyn_kind(int kind) { return kind == NLLS_RES_DYN_LINEAR || kind == NLLS_RES_DYN_NORM; }
+inline bool is_dyn_kind(int kind) { return kind >= NLLS_RES_DYN_LINEAR && kind <= NLLS_COST_DYN_LINEAR; }
 
 int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags);

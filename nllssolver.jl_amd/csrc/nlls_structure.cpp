@@ -25,6 +25,8 @@ bool res_desc(int kind, ResDesc& d) {
     // at upload (build_structure)
     case NLLS_RES_DYN_LINEAR: d = ResDesc{1, 1, -1, 0, {NLLS_VAR_DYNAMIC, 0, 0, 0}, {0, 0, 0, 0}}; return true;
     case NLLS_RES_DYN_NORM:   d = ResDesc{1, -1, 0, 0, {NLLS_VAR_DYNAMIC, 0, 0, 0}, {0, 0, 0, 0}}; return true;
+    case NLLS_RES_DYN_LINEARSQ: d = ResDesc{1, -1, -2, 0, {NLLS_VAR_DYNAMIC, 0, 0, 0}, {0, 0, 0, 0}}; return true;   // ndata = n + n*n
+    case NLLS_COST_DYN_LINEAR:  d = ResDesc{1, 0, -3, 0, {NLLS_VAR_DYNAMIC, 0, 0, 0}, {0, 0, 0, 0}}; return true;   // an AbstractCost (nres 0); ndata = n
     }
     return false;
 }
@@ -76,7 +78,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
                 if (v < 1 || v > nvar) return fail(c, NLLS_ERR_INVALID_ARG, "varind out of range");
                 if (n < 0) n = var_dim[v - 1]; else if (var_dim[v - 1] != n) return fail(c, NLLS_ERR_UNSUPPORTED, "dynamic-size blocks of one group must share the variable length"); }
             if (n < 0) n = 0;
-            if (desc[g].ndata < 0) desc[g].ndata = 1 + n;
+            if (groups[g].res_kind == NLLS_RES_DYN_LINEARSQ && n > 512) return fail(c, NLLS_ERR_UNSUPPORTED, "NLLS_RES_DYN_LINEARSQ: variable longer than 512");
+            if (desc[g].ndata == -1) desc[g].ndata = 1 + n; else if (desc[g].ndata == -2) desc[g].ndata = n + n * n; else if (desc[g].ndata == -3) desc[g].ndata = n;
             if (desc[g].nres < 0) desc[g].nres = n;
         }
         const ResDesc& d = desc[g];

@@ -25,7 +25,9 @@ RES_LINEAR3 = 9           # test/nonsquaredcost.jl:4-14: X w - y
 COST_LINEAR3 = 10         # test/nonsquaredcost.jl:28-37: non-squared AbstractCost y'w (value, gradient, Hessian by second-order duals)
 RES_DYN_LINEAR = 11       # test/dynamicvars.jl:3-11: X'w - y over one dynamic-size variable; data = (y, X[n])
 RES_DYN_NORM = 12         # test/dynamicvars.jl:13-21: w (nres = n); no data
-DYN_KINDS = (RES_DYN_LINEAR, RES_DYN_NORM)
+RES_DYN_LINEARSQ = 13     # test/nonsquaredcost.jl:16-26: X*w - y with a square X over a dynamic-size variable; data = (y[n], X[n*n] column-major)
+COST_DYN_LINEAR = 14      # test/nonsquaredcost.jl:39-46: non-squared cost y'w over a dynamic-size variable; data = y[n]
+DYN_KINDS = (RES_DYN_LINEAR, RES_DYN_NORM, RES_DYN_LINEARSQ, COST_DYN_LINEAR)
 
 # robust kernels: src/robust.jl:7-77
 ROBUST_NONE = 0
@@ -48,6 +50,8 @@ RES_TABLE = {
     COST_LINEAR3: (1, 0, 3, False, ((VAR_EUCLIDEAN, 3),)),
     RES_DYN_LINEAR: (1, 1, -1, False, ((VAR_DYNAMIC, 0),)),    # ndata = 1 + n (the variable's run-time length)
     RES_DYN_NORM: (1, -1, 0, False, ((VAR_DYNAMIC, 0),)),      # nres = n
+    RES_DYN_LINEARSQ: (1, -1, -2, False, ((VAR_DYNAMIC, 0),)),  # nres = n, ndata = n + n*n
+    COST_DYN_LINEAR: (1, 0, -3, False, ((VAR_DYNAMIC, 0),)),   # ndata = n
 }
 
 

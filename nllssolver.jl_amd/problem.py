@@ -133,7 +133,7 @@ class NLLSProblem:
         nd, ndata = K.res_ndeps(res_kind), K.res_ndata(res_kind)
         varind = np.ascontiguousarray(np.asarray(varind, dtype=np.int64).reshape(-1, nd))
         if ndata < 0:                          # dynamic-size kind (src/autodiff.jl:96-121): 1 + n doubles per block, n = the variable's length
-            ndata = 1 + int(self.var_dim[varind[0, 0] - 1])
+            n_ = int(self.var_dim[varind[0, 0] - 1]); ndata = {-1: 1 + n_, -2: n_ + n_ * n_, -3: n_}[ndata]
         data = np.ascontiguousarray(np.asarray(data, dtype=np.float64).reshape(varind.shape[0], ndata))
         assert varind.shape[0] == data.shape[0]
         assert 0 < nd <= 10, "Problem with ndeps()"            # MAX_ARGS, src/NLLSsolver.jl:28

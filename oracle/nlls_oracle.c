@@ -40,8 +40,10 @@ static const res_desc RES[NLLS_RES_KIND_COUNT] = {
     /* COST_LINEAR3    */ {1, 0, 3, 0, {NLLS_VAR_EUCLIDEAN}, {3}},   /* nres = 0: an AbstractCost, not a residual */
     /* DYN_LINEAR      */ {1, 1, -1, 0, {NLLS_VAR_DYNAMIC}, {0}},    /* ndata = 1 + n: see ogroup.ndata */
     /* DYN_NORM        */ {1, -1, 0, 0, {NLLS_VAR_DYNAMIC}, {0}},    /* nres = n */
+    /* DYN_LINEARSQ    */ {1, -1, -1, 0, {NLLS_VAR_DYNAMIC}, {0}},   /* nres = n, ndata = n + n*n */
+    /* COST_DYN_LINEAR */ {1, 0, -1, 0, {NLLS_VAR_DYNAMIC}, {0}},    /* an AbstractCost; ndata = n */
 };
-#define IS_DYN_KIND(k) ((k) == NLLS_RES_DYN_LINEAR || (k) == NLLS_RES_DYN_NORM)
+#define IS_DYN_KIND(k) ((k) >= NLLS_RES_DYN_LINEAR && (k) <= NLLS_COST_DYN_LINEAR)
 #define IS_COST_KIND(k) ((k) == NLLS_COST_LINEAR3)
 
 static int var_storage(int kind, int dim) {
@@ -592,7 +594,7 @@ oracle_problem* oracle_problem_create(int64_t nvar, const int32_t* vk, const int
         g->varind = (int64_t*)malloc(sizeof(int64_t) * (g->ncost * d->ndeps + 1)); memcpy(g->varind, groups[gi].varind, sizeof(int64_t) * g->ncost * d->ndeps);
         g->ndata = d->ndata; g->dyn_n = 0;
         if (IS_DYN_KIND(g->res_kind)) { /* dynamic-size blocks (src/autodiff.jl:96-121): n = the length of the block's variable, the same for the whole group */
-            g->dyn_n = g->ncost > 0 ? vd[g->varind[0] - 1] : 0; g->ndata = g->res_kind == NLLS_RES_DYN_LINEAR ? 1 + g->dyn_n : 0; }
+            g->dyn_n = g->ncost > 0 ? vd[g->varind[0] - 1] : 0; g->ndata = g->res_kind == NLLS_RES_DYN_LINEAR ? 1 + g->dyn_n : g->res_kind == NLLS_RES_DYN_LINEARSQ ? g->dyn_n * (1 + (int64_t)g->dyn_n) : g->res_kind == NLLS_COST_DYN_LINEAR ? g->dyn_n : 0; }
         g->data = (double*)malloc(sizeof(double) * (g->ncost * g->ndata + 1)); if (g->ndata > 0) memcpy(g->data, groups[gi].data, sizeof(double) * g->ncost * g->ndata);
     }
     return p;
@@ -629,6 +631,18 @@ static double dyn_block(const oracle_problem* p, const double* vars, const ogrou
         for (int i = 0; i < n; ++i) r += X[i] * w[i];
         if (gv) for (int i = 0; i < n; ++i) { gv[i] = X[i] * r; for (int j = 0; j < n; ++j) H[i + (size_t)n * j] = X[i] * X[j]; }
         return 0.5 * r * r;
+    }
+    if (g->res_kind == NLLS_RES_DYN_LINEARSQ) { /* LinearResidualDynamic X*w - y, X square col-major (test/nonsquaredcost.jl:16-26): J = X */
+        const double* dd = g->data + ci * g->ndata; const double* X = dd + n; double* r = (double*)malloc(sizeof(double) * n); double c2 = 0;
+        for (int i = 0; i < n; ++i) { double t = -dd[i]; for (int j = 0; j < n; ++j) t += X[i + (size_t)n * j] * w[j]; r[i] = t; c2 += t * t; }
+        if (gv) for (int j = 0; j < n; ++j) { double t = 0; for (int i = 0; i < n; ++i) t += X[i + (size_t)n * j] * r[i]; gv[j] = t;
+            for (int k = 0; k < n; ++k) { double h = 0; for (int i = 0; i < n; ++i) h += X[i + (size_t)n * j] * X[i + (size_t)n * k]; H[j + (size_t)n * k] = h; } }
+        free(r); return 0.5 * c2;
+    }
+    if (g->res_kind == NLLS_COST_DYN_LINEAR) { /* LinearCostDynamic y'w (test/nonsquaredcost.jl:39-46): computecostgradhess src/autodiff.jl:144-159 -> y'w, y, 0 */
+        const double* y = g->data + ci * g->ndata; double c2 = 0; for (int i = 0; i < n; ++i) c2 += y[i] * w[i];
+        if (gv) for (int i = 0; i < n; ++i) { gv[i] = y[i]; for (int j = 0; j < n; ++j) H[i + (size_t)n * j] = 0.0; }
+        return c2;
     }
     double c = 0; for (int i = 0; i < n; ++i) c += w[i] * w[i];
     if (gv) for (int i = 0; i < n; ++i) { gv[i] = w[i]; for (int j = 0; j < n; ++j) H[i + (size_t)n * j] = i == j ? 1.0 : 0.0; }

@@ -450,3 +450,23 @@ def test_dynamic_size_variables_on_device(seed):
         assert np.isclose(X @ Y, np.linalg.norm(Y), rtol=1e-7), (X @ Y, np.linalg.norm(Y))      # test/dynamicvars.jl:40
         assert np.allclose(Y, X / (1.0 + X @ X), atol=1e-7)
         assert res.bestcost < res.startcost
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_nonsquared_cost_static_and_dynamic_on_device(seed):
+    """test/nonsquaredcost.jl:48-69 as written, on the device: a static and a dynamic-size variable in one problem, each under a linear
+    residual and a non-squared linear cost; Newton (as in the reference) and Levenberg-Marquardt reach (X'X) \\ ((X' - I) y) on both."""
+    from tests.test_gpu_parity import check_problem
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((3, 3)); y = rng.standard_normal(3)
+    solution = np.linalg.solve(X.T @ X, (X.T - np.eye(3)) @ y)
+    def mk(start=None):
+        p = N.NLLSProblem(); p.addvariable(np.zeros(3) if start is None else start[:3]); p.addvariable(np.zeros(3) if start is None else start[3:], K.VAR_DYNAMIC)
+        p.addcosts(K.RES_LINEAR3, [[1]], np.concatenate([y, X.ravel(order="F")])[None, :]); p.addcosts(K.COST_LINEAR3, [[1]], y[None, :])
+        p.addcosts(K.RES_DYN_LINEARSQ, [[2]], np.concatenate([y, X.ravel(order="F")])[None, :]); p.addcosts(K.COST_DYN_LINEAR, [[2]], y[None, :])
+        return p
+    check_problem(mk(rng.standard_normal(6)), expect_sparse=0, lam_scale=1e-3)
+    for it, tol in ((N.newton, 1e-9), (N.levenbergmarquardt, 1e-6)):
+        p = mk()
+        N.optimize(p, N.NLLSOptions(iterator=it))
+        assert np.allclose(p.variables[:3], solution, rtol=tol, atol=tol) and np.allclose(p.variables[3:], solution, rtol=tol, atol=tol)

@@ -377,3 +377,20 @@ def test_dynamic_size_variables_known_answer(seed):
         assert np.allclose(Y, X / (1.0 + X @ X), atol=1e-7)
     ols = oracle_problem(p).linear_system(blockindices(p))
     assert not ols.info.is_sparse and ols.info.ndof == n       # one variable: UniVariateLS / dense
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_nonsquared_cost_static_and_dynamic(seed):
+    """test/nonsquaredcost.jl:48-69 as written: ONE problem with a static EuclideanVector{3} (LinearResidualStatic + LinearCostStatic) and a
+    DynamicVector of length 3 (LinearResidualDynamic + LinearCostDynamic), Newton: both variables end at (X'X) \\ ((X' - I) y)."""
+    from nllssolver_jl_amd import kinds as K
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((3, 3)); y = rng.standard_normal(3)
+    solution = np.linalg.solve(X.T @ X, (X.T - np.eye(3)) @ y)
+    p = N.NLLSProblem(); p.addvariable(np.zeros(3)); p.addvariable(np.zeros(3), K.VAR_DYNAMIC)
+    p.addcosts(K.RES_LINEAR3, [[1]], np.concatenate([y, X.ravel(order="F")])[None, :]); p.addcosts(K.COST_LINEAR3, [[1]], y[None, :])
+    p.addcosts(K.RES_DYN_LINEARSQ, [[2]], np.concatenate([y, X.ravel(order="F")])[None, :]); p.addcosts(K.COST_DYN_LINEAR, [[2]], y[None, :])
+    op = oracle_problem(p)
+    op.optimize(iterator=0)
+    v = op.get_variables()
+    assert np.allclose(v[:3], solution, rtol=1e-9, atol=1e-12) and np.allclose(v[3:], solution, rtol=1e-9, atol=1e-12)
