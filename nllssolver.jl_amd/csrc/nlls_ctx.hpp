@@ -55,6 +55,10 @@ struct EntryList {          // all (cost, slot) incidences of one cost group and
     int64_t nlight = 0, nheavy = 0;
     bool unique_dest = false;
     uint32_t light_lds = 0, heavy_lds = 0;   // max image doubles over the tiles
+    // heavy-only lists whose entries write nothing but their own row (no off-diagonal block of theirs is stored in it) and share their flag word:
+    // the heavy pass then streams 4 bytes per other slot instead of the 8 + 8 of voff / dest (BA camera rows: 20 instead of 32 bytes per entry)
+    bool compact = false; uint32_t own_flags = 0;
+    DevBuf<uint32_t> hvoff;  // [n][ndeps - 1]: storage offsets of the OTHER slots' variables, slot order
 };
 
 struct DenseList {          // dense linear system: one entry per cost

@@ -313,7 +313,16 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
               for (int64_t e = 0; e < E.n; ++e) { int64_t k = L.cost[e];
                   for (int q = 0; q < d.ndata; ++q) hd[(size_t)e * d.ndata + q] = in.data[k * d.ndata + q];
                   for (int q = 0; q < d.ndeps; ++q) hv[(size_t)e * d.ndeps + q] = c->var_off[in.varind[k * d.ndeps + q] - 1]; }
-              HIPCHK(E.data.upload(hd)); HIPCHK(E.voff.upload(hv)); HIPCHK(E.dest.upload(dest)); HIPCHK(E.rows.upload(rinfo)); }
+              HIPCHK(E.data.upload(hd)); HIPCHK(E.voff.upload(hv)); HIPCHK(E.dest.upload(dest)); HIPCHK(E.rows.upload(rinfo));
+              // compact form for the heavy pass (see EntryList::compact)
+              E.compact = false; E.own_flags = 0;
+              if (light.empty() && !heavy.empty() && d.ndeps >= 2 && E.n > 0) {
+                  bool ok = true; const uint32_t fl = dest[(size_t)0 * d.ndeps + s] & (OWN_COST_OWNER | OWN_KERNEL_FREE);
+                  for (int64_t e = 0; e < E.n && ok; ++e) { if ((dest[(size_t)e * d.ndeps + s] & (OWN_COST_OWNER | OWN_KERNEL_FREE)) != fl) ok = false;
+                      for (int t = 0; t < d.ndeps; ++t) if (t != s && dest[(size_t)e * d.ndeps + t] != DEST_NONE) ok = false; }
+                  if (ok) { std::vector<uint32_t> ho((size_t)E.n * (d.ndeps - 1));
+                      for (int64_t e = 0; e < E.n; ++e) { int q2 = 0; for (int t = 0; t < d.ndeps; ++t) if (t != s) ho[(size_t)e * (d.ndeps - 1) + q2++] = hv[(size_t)e * d.ndeps + t]; }
+                      HIPCHK(E.hvoff.upload(ho)); E.compact = true; E.own_flags = fl; } } }
             E.nlight = (int64_t)light.size(); E.nheavy = (int64_t)heavy.size();
             HIPCHK(E.light.upload(light)); HIPCHK(E.heavy.upload(heavy));
             npartials += E.nlight + E.nheavy;

@@ -34,6 +34,7 @@ NLLS_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :
 // arguments of one entry list's accumulate pass (light or heavy tiles of it)
 struct GhArgs {
     const double* vars; const double* edata; const uint32_t* evoff; const uint32_t* edest; const RowInfo* rows; const Tile* tiles;
+    const uint32_t* hvoff; uint32_t own_flags; int compact;      // compact heavy list (EntryList::compact)
     RobustSpec rk; int unique_dest; uint32_t ntiles; double* A; double* b; double* partials;
 };
 template <int KIND, int SLOT>
@@ -179,12 +180,20 @@ __device__ __forceinline__ void gh_heavy_body(const GhArgs& g, uint32_t wg, uint
     // is evaluated, the variable gathers of entry i+1 and the entry record of i+2 are in flight.  All workgroups of the
     // launch are resident at once, so this pipeline -- not occupancy -- is what hides the HBM and L2 latency.
     struct Rec { double d[R::NDATA]; uint32_t vo[R::NDEPS], ds[R::NDEPS]; bool ok; };
+    const uint32_t* __restrict__ hvoff = g.hvoff; const bool compact = g.compact != 0; const uint32_t own_flags = g.own_flags;
+    const uint32_t own_vo = evoff[(size_t)t.e0 * R::NDEPS + SLOT];     // the row's own variable (the same in every entry of the tile)
     auto load_rec = [&](uint32_t e, Rec& r) {
         r.ok = e < t.e1; const uint32_t ee = r.ok ? e : t.e0;
 #pragma unroll
         for (int q = 0; q < R::NDATA; ++q) r.d[q] = edata[(size_t)ee * R::NDATA + q];
+        if (compact) {                                                   // 4 bytes per other slot; nothing else varies from entry to entry
+            int q2 = 0;
 #pragma unroll
-        for (int q = 0; q < R::NDEPS; ++q) { r.vo[q] = evoff[(size_t)ee * R::NDEPS + q]; r.ds[q] = edest[(size_t)ee * R::NDEPS + q]; }
+            for (int q = 0; q < R::NDEPS; ++q) { if (q == SLOT) { r.vo[q] = own_vo; r.ds[q] = own_flags; } else { r.vo[q] = hvoff[(size_t)ee * (R::NDEPS - 1) + q2++]; r.ds[q] = DEST_NONE; } }
+        } else {
+#pragma unroll
+            for (int q = 0; q < R::NDEPS; ++q) { r.vo[q] = evoff[(size_t)ee * R::NDEPS + q]; r.ds[q] = edest[(size_t)ee * R::NDEPS + q]; }
+        }
     };
     using St = double[R::NDEPS][MAXST];
     auto stage = [&](uint32_t e2, const Rec& cur, const St& cst, const Rec& nxt, St& nst, Rec& nn) {
@@ -331,15 +340,20 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // bound with almost no HBM traffic, the light ones are bound by the A.data stream -- side by side they overlap instead
 // of running back to back.
 template <int KIND, int LSLOT, int HSLOT>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void gh_fused_kernel(GhArgs gl, GhArgs gh, uint32_t heavy_img, uint32_t nhw, unsigned long long* prof) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void gh_fused_kernel(GhArgs gl, GhArgs gh, uint32_t heavy_img, uint32_t nhw, uint32_t nhw_pad, unsigned long long* prof) {
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
     // in-situ profile (nlls_profile_sweep; prof == nullptr otherwise): first workgroup start / last workgroup end on the 100 MHz
     // constant clock -- the launch's execution span as a kernel trace reports it, taken inside the caller's own loop
     if (prof && threadIdx.x == 0) prof[blockIdx.x] = (unsigned long long)wall_clock64();     // (one slot per workgroup: no contention)
     // the heavy workgroups come first: their lifetime is the longest.  (Spreading them through the grid, or alternating
     // them with light ones at the front, measured slower: 114 and 57 us against 49.)
-    if (blockIdx.x < nhw) gh_heavy_body<KIND, HSLOT, 2>(gh, blockIdx.x, heavy_img, dyn_lds);
-    else gh_light_body<KIND, LSLOT>(gl, blockIdx.x - nhw, dyn_lds);
+    // Heavy workgroup w runs on XCD w % 8 (workgroups are dealt round-robin to the eight XCDs, each with its own L2): give every XCD a
+    // CONTIGUOUS range of heavy rows -- neighbouring camera rows gather the same points, so the point coordinates then cross from HBM
+    // into about one L2 instead of into all eight (2.4 MB x 8 at config 4)
+    // (nhw_pad = 8 * ceil(nhw / 8) workgroups stand for the nhw heavy ones: the few beyond the last row have nothing to do)
+    if (blockIdx.x < nhw_pad) { const uint32_t hw = (blockIdx.x & 7) * (nhw_pad >> 3) + (blockIdx.x >> 3);
+        if (hw < nhw) gh_heavy_body<KIND, HSLOT, 2>(gh, hw, heavy_img, dyn_lds); }
+    else gh_light_body<KIND, LSLOT>(gl, blockIdx.x - nhw_pad, dyn_lds);
     if (prof && threadIdx.x == 0) prof[gridDim.x + blockIdx.x] = (unsigned long long)wall_clock64();
 }
 
@@ -441,6 +455,7 @@ static int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::str
 template <int KIND>
 static GhArgs gh_args(nlls_ctx* c, const Group& G, const EntryList& E, const double* vars, bool heavy, double* partials) {
     GhArgs g{}; g.vars = vars; g.edata = E.data.p; g.evoff = E.voff.p; g.edest = E.dest.p; g.rows = E.rows.p; g.tiles = heavy ? E.heavy.p : E.light.p;
+    g.hvoff = E.hvoff.p; g.own_flags = E.own_flags; g.compact = (heavy && E.compact) ? 1 : 0;
     g.rk = G.rk; g.unique_dest = E.unique_dest ? 1 : 0; g.ntiles = (uint32_t)(heavy ? E.nheavy : E.nlight); g.A = c->A.p; g.b = c->b.p; g.partials = partials;
     return g;
 }
@@ -472,15 +487,15 @@ static bool launch_gh_fused(nlls_ctx* c, const Group& G, const double* vars, int
         const EntryList& EL = ls == 0 ? E0 : E1; const EntryList& EH = ls == 0 ? E1 : E0;
         const size_t lds = std::max<size_t>(EL.light_lds + 2, gh_heavy_lds(EH.heavy_lds)) * sizeof(double);
         if (lds > ((size_t)EL.light_lds + 2) * sizeof(double) + 4096) return false;    // the heavy role must not cost the light one occupancy
-        const unsigned nhw = (unsigned)((EH.nheavy + HROWS - 1) / HROWS);
+        const unsigned nhw = (unsigned)((EH.nheavy + HROWS - 1) / HROWS), nhw_pad = 8 * ((nhw + 7) / 8);
         const GhArgs gl = gh_args<KIND>(c, G, EL, vars, false, c->partials.p + pbase), gh = gh_args<KIND>(c, G, EH, vars, true, c->partials.p + pbase + EL.nlight);
         unsigned long long* prof = nullptr;
         if (c->prof_sweep && c->prof_clk.p) {                   // (profiling only: two 8-byte fills in front of the launch)
-            const unsigned nwg = nhw + (unsigned)EL.nlight;
+            const unsigned nwg = nhw_pad + (unsigned)EL.nlight;
             if (nwg <= PROF_MAXWG) { const size_t slot = (size_t)(c->prof_kcount % PROF_SLOTS); prof = c->prof_clk.p + slot * 2 * PROF_MAXWG; c->prof_nwg[slot] = nwg; ++c->prof_kcount; }
         }
-        if (ls == 0) hipLaunchKernelGGL((gh_fused_kernel<KIND, 0, 1>), dim3(nhw + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw, prof);
-        else         hipLaunchKernelGGL((gh_fused_kernel<KIND, 1, 0>), dim3(nhw + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw, prof);
+        if (ls == 0) hipLaunchKernelGGL((gh_fused_kernel<KIND, 0, 1>), dim3(nhw_pad + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw, nhw_pad, prof);
+        else         hipLaunchKernelGGL((gh_fused_kernel<KIND, 1, 0>), dim3(nhw_pad + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, gh, EH.heavy_lds, nhw, nhw_pad, prof);
         pbase += EL.nlight + EH.nheavy;
         return true;
     }
