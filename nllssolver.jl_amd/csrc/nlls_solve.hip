@@ -1189,6 +1189,85 @@ __global__ __launch_bounds__(256) void syrk_update2_kernel(double* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cg[(size_t)(r0 + 16 * a + li) + (size_t)npad * (c0 + 16 * b2 + lk + 4 * r)] = cold[a][b2][r] - acc[a][b2][r];
 }
+// The two-panel trailing update with 128 x 128 output tiles: C -= W_k0 L_k0' + W_{k0+1} L_{k0+1}' (K = 128).  Four wavefronts, each a 64 x 64
+// quarter = 4 x 4 accumulator tiles of v_mfma_f64_16x16x4_f64 (128 accumulator registers): 8 LDS operand reads per 16 MFMAs where the
+// 64 x 64 kernel above needs 4 per 4, and a quarter of its operand traffic per flop.  The operands go through LDS in chunks of 16 columns,
+// double buffered: the global loads of chunk c + 1 are in flight while chunk c is multiplied.  Products are formed transposed (operands
+// swapped) so that the read-modify-write of S is coalesced.  Tiles start at 64-block jb0; when the number of 64-blocks behind it is odd the
+// last tile row / column is half empty: those wavefronts idle.  The quarter above the diagonal of a diagonal tile is not needed either.
+constexpr int S128_KC = 16, S128_LD = 144;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void syrk_update128_kernel(double* __restrict__ S, const double* __restrict__ W0, const double* __restrict__ W1, int npad, int k0, int jb0, int firstcol) {
+    __shared__ double As[2][S128_KC * S128_LD], Bs[2][S128_KC * S128_LD];
+    int ti, tj;                                                // firstcol: only the first tile column (what the next two panels wait for)
+    if (firstcol) { ti = blockIdx.x; tj = 0; }
+    else { const int tix = blockIdx.x; ti = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > tix) --ti; while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti; tj = tix - ti * (ti + 1) / 2; }
+    const int I0 = jb0 * NB + 128 * ti, J0 = jb0 * NB + 128 * tj;
+    const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
+    const int r0w = (w & 1) * 64, c0w = (w >> 1) * 64;
+    const bool active = I0 + r0w < npad && J0 + c0w < npad && !(ti == tj && c0w > r0w);
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = double4_t{0, 0, 0, 0};
+    // copy roles: thread t moves row (t & 127) of both operands, every other column of a chunk (kq, kq + 2, ..)
+    const int cr = t & 127, kq = t >> 7;
+    const int arow = I0 + cr < npad ? I0 + cr : npad - 1, brow = J0 + cr < npad ? J0 + cr : npad - 1;
+    constexpr int NCP = S128_KC / 2, CPP = NB / S128_KC;       // columns per thread and chunk; chunks per panel
+    double ra[NCP], rb[NCP];
+    auto gload = [&](int chunk) {                              // chunk: panel (chunk / CPP), columns S128_KC * (chunk % CPP) ..
+        const int q = chunk / CPP, col0 = (chunk % CPP) * S128_KC;
+        const double* Wq = q == 0 ? W0 : W1;
+        const double* Ga = Wq + (size_t)arow + (size_t)npad * col0;
+        const double* Gb = S + (size_t)brow + (size_t)npad * ((size_t)(k0 + q) * NB + col0);
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) { ra[i] = Ga[(size_t)npad * (kq + 2 * i)]; rb[i] = Gb[(size_t)npad * (kq + 2 * i)]; }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) { As[buf][(kq + 2 * i) * S128_LD + cr] = ra[i]; Bs[buf][(kq + 2 * i) * S128_LD + cr] = rb[i]; }
+    };
+    constexpr int NCH = 2 * NB / S128_KC;
+    gload(0); lstore(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < NCH) gload(ch + 1);
+        if (active) {
+#pragma unroll
+            for (int kk = 0; kk < S128_KC; kk += 4) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) av[a] = As[buf][(kk + lk) * S128_LD + r0w + 16 * a + li];
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2) bv[b2] = Bs[buf][(kk + lk) * S128_LD + c0w + 16 * b2 + li];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < NCH) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+    // C/D layout of the f64 MFMA of the TRANSPOSED tile: C row = lane & 15 (+ 16 a), column = (lane >> 4) + 4 r (+ 16 b).
+    // (A no-return atomic add per entry -- every entry has one writer per pass -- measured slower than this read-modify-write.)
+    double* Cg = S + (size_t)(I0 + r0w) + (size_t)npad * (J0 + c0w);
+#pragma unroll
+    for (int b2 = 0; b2 < 4; ++b2) {
+        double cold[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cold[a][r] = Cg[(size_t)(16 * a + li) + (size_t)npad * (16 * b2 + lk + 4 * r)];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cg[(size_t)(16 * a + li) + (size_t)npad * (16 * b2 + lk + 4 * r)] = cold[a][r] - acc[a][b2][r];
+    }
+}
 // backward substitution L' x = z (unit diagonal), block by block from the bottom.  z = D^-1 L^-1 s is row n of the factor.
 // step 1 (one workgroup per 64-column block kb, many row blocks): partial[kb][j] = sum_{i > kb block} L[i][kb*64+j] * x[i]
 __global__ __launch_bounds__(256) void bwd_gemv_kernel(const double* __restrict__ S, int npad, int kb, int n, const double* __restrict__ x, double* __restrict__ acc) {
@@ -2411,7 +2490,8 @@ int enqueue_reduced_solve(nlls_ctx* c) {
         // it as tile products: dense_panel_kernel, nlls_bcr.hip) and the MFMA trailing update
         double* LiD = c->Lwork.p + (size_t)npad * NB + npad;         // inv(L_JJ)' of every diagonal tile (backward pass)
         // two panels per pass over the trailing matrix: panel k, a NARROW update of block column k + 1 only, panel k + 1, then one update of
-        // everything behind with both panels (K = 128)
+        // everything behind with both panels (K = 128, 128 x 128 tiles).  (Measured and dropped: the first tile column on this stream and the
+        // rest on a side stream beside the next two panels -- the two event hand-overs per pair cost more than the overlap gained.)
         double* W0 = c->Lwork.p; double* W1 = LiD + (size_t)(npad / 16) * 256 + 256;
         for (int k = 0; k < nblk; k += 2) {
             launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p);
@@ -2419,7 +2499,10 @@ int enqueue_reduced_solve(nlls_ctx* c) {
             hipLaunchKernelGGL(syrk_update2_kernel<1>, dim3(nblk - k - 1), dim3(256), 0, c->stream, c->S.p, W0, W0, npad, k, k + 1, 1);
             launch_dense_panel(c->stream, c->S.p, W1, LiD, npad, k + 1, c->d_status.p);
             const int T = nblk - k - 2;
-            if (T > 0) hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
+            if (T <= 0) break;
+            const int T128 = (T + 1) / 2;
+            if (c->dense_t128) hipLaunchKernelGGL(syrk_update128_kernel, dim3(T128 * (T128 + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
+            else hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
         }
         // backward substitution into acc / s (x)
         double* acc = c->Lwork.p + (size_t)npad * NB;
