@@ -489,24 +489,42 @@ void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int n
 }
 // x_k = L_kk^-T (y_k - acc_k) for the 64 unknowns of block column kb, from the four inverted diagonal tiles and the L tiles below
 // them (one wavefront; replaces a 64-step lane-serial substitution)
-BCR_DEV void dense_bwd_diag_body(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x,
-                                 double* r, double* xs, double* uu) {
-    const int lane = threadIdx.x, c = lane & 15, gq = lane >> 4, c0 = 64 * kb;
+// the tiles of a diagonal block the backward solve needs -- the L tiles below the diagonal tiles (K > J) and the four inverted diagonal
+// tiles -- loaded up front: none of them depends on x, so their latency is taken once (beside the push of dense_bwd_step_kernel) instead of
+// once per step of the chain
+struct DenseBwdTiles { double l[6][4], li[4][4]; };
+BCR_DEV void dense_bwd_diag_load(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int kb, DenseBwdTiles& T) {
+    const int lane = threadIdx.x & 63, c = lane & 15, gq = lane >> 4, c0 = 64 * kb;
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+#pragma unroll
+        for (int K = J + 1; K < 4; ++K)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T.l[J * 3 - J * (J - 1) / 2 + (K - J - 1)][q] = S[(size_t)(c0 + 16 * K + gq + 4 * q) + (size_t)npad * (c0 + 16 * J + c)];
+        const double* Lk = LiD + ((size_t)kb * 4 + J) * 256 + c * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T.li[J][q] = Lk[gq + 4 * q];
+    }
+}
+BCR_DEV void dense_bwd_diag_chain(const double* __restrict__ S, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x, const DenseBwdTiles& T,
+                                  double* r, double* xs, double* uu) {
+    const int lane = threadIdx.x & 63, c = lane & 15, gq = lane >> 4, c0 = 64 * kb;
     { const int g = c0 + lane; r[lane] = (g < n) ? S[(size_t)n + (size_t)npad * g] - acc[g] : 0.0; xs[lane] = 0.0; }     // y: row n of the factor
     __syncthreads();
+#pragma unroll
     for (int J = 3; J >= 0; --J) {
         double s = 0.0;
+#pragma unroll
         for (int K = J + 1; K < 4; ++K) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int a2 = gq + 4 * q; s = fma(S[(size_t)(c0 + 16 * K + a2) + (size_t)npad * (c0 + 16 * J + c)], xs[16 * K + a2], s); }
+            for (int q = 0; q < 4; ++q) s = fma(T.l[J * 3 - J * (J - 1) / 2 + (K - J - 1)][q], xs[16 * K + gq + 4 * q], s);
         }
         s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
         if (gq == 0) uu[c] = r[16 * J + c] - s;
         __syncthreads();
-        const double* Lk = LiD + ((size_t)kb * 4 + J) * 256 + c * 16;
         double xv = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xv = fma(Lk[gq + 4 * q], uu[gq + 4 * q], xv);
+        for (int q = 0; q < 4; ++q) xv = fma(T.li[J][q], uu[gq + 4 * q], xv);
         xv += __shfl_xor(xv, 16, 64); xv += __shfl_xor(xv, 32, 64);
         if (gq == 0) { const int g = c0 + 16 * J + c; const double v = g < n ? xv : 0.0; xs[16 * J + c] = v; if (g < n) x[g] = v; }
         __syncthreads();
@@ -514,15 +532,19 @@ BCR_DEV void dense_bwd_diag_body(const double* __restrict__ S, const double* __r
 }
 __global__ __launch_bounds__(64) void dense_bwd_diag_kernel(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x) {
     __shared__ double r[64], xs[64], uu[16];
-    dense_bwd_diag_body(S, LiD, npad, kb, n, acc, x, r, xs, uu);
+    DenseBwdTiles T; dense_bwd_diag_load(S, LiD, npad, kb, T);
+    dense_bwd_diag_chain(S, npad, kb, n, acc, x, T, r, xs, uu);
 }
 // One launch per step of the backward substitution L' x = z: block s has just been solved (x_s final).  Workgroup j < s pushes its
 // contribution into the 64 entries of block j -- acc_j += L(block s, block j)' x_s: every block column is owned by one workgroup per
 // launch, so no atomics -- and the workgroup of block s - 1, whose acc is complete with that, goes straight on to solve it (its
-// other three wavefronts retire first: the diagonal-block solve is one wavefront's work).
+// other three wavefronts retire first: the diagonal-block solve is one wavefront's work, and its tiles were requested at the start).
 __global__ __launch_bounds__(256) void dense_bwd_step_kernel(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int s, int n, double* __restrict__ acc, double* __restrict__ x) {
     __shared__ double red[4][64]; __shared__ double r[64], xs[64], uu[16];
     const int j = blockIdx.x, t = threadIdx.x, c = t & 63, q = t >> 6;
+    DenseBwdTiles T;
+    const bool solver = j == s - 1 && q == 0;
+    if (solver) dense_bwd_diag_load(S, LiD, npad, s - 1, T);
     const double* P = S + (size_t)s * 64 + (size_t)npad * ((size_t)j * 64 + c);       // column j*64 + c, rows of block s: contiguous
     double v = 0.0;
 #pragma unroll 4
@@ -533,7 +555,7 @@ __global__ __launch_bounds__(256) void dense_bwd_step_kernel(const double* __res
     acc[j * 64 + c] += red[0][c] + red[1][c] + red[2][c] + red[3][c];
     if (j != s - 1) return;
     __threadfence_block();
-    dense_bwd_diag_body(S, LiD, npad, s - 1, n, acc, x, r, xs, uu);                   // (one wavefront left in this workgroup: its barriers are its own)
+    dense_bwd_diag_chain(S, npad, s - 1, n, acc, x, T, r, xs, uu);                   // (one wavefront left in this workgroup: its barriers are its own)
 }
 void launch_dense_bwd_diag(hipStream_t st, const double* S, const double* LiD, int npad, int kb, int n, const double* acc, double* x) {
     hipLaunchKernelGGL(dense_bwd_diag_kernel, dim3(1), dim3(64), 0, st, S, LiD, npad, kb, n, acc, x);

@@ -2501,7 +2501,7 @@ int enqueue_reduced_solve(nlls_ctx* c) {
             const int T = nblk - k - 2;
             if (T <= 0) break;
             const int T128 = (T + 1) / 2;
-            if (c->dense_t128) hipLaunchKernelGGL(syrk_update128_kernel, dim3(T128 * (T128 + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
+            if (c->dense_t128 && T128 >= c->dense_t128_min) hipLaunchKernelGGL(syrk_update128_kernel, dim3(T128 * (T128 + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
             else hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
         }
         // backward substitution into acc / s (x)
