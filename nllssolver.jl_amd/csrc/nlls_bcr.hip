@@ -387,21 +387,24 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
 // uncoalesced: 55 us) launch pair of round 1.
 // ---------------------------------------------------------------------------------------------------
 struct DensePanelArgs { double* S; double* W; double* LiD; int npad, k, T; int* status; };
+// NT tiles = 16 NT columns per panel (4: 64 columns; 8: 128 columns, the width of one pass of the trailing update -- then no narrow update and
+// no second panel launch stand between two passes); DCH X tile rows per workgroup (LDS: 8 tiles of width need 2 rows to stay within 160 KB)
+template <int NT, int DCH>
 __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    constexpr int NT = 4, ND = NT * (NT + 1) / 2, PR = NT + BCR_CH;
+    constexpr int ND = NT * (NT + 1) / 2, PR = NT + DCH;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int hw = wave < 4 ? wave - 1 : wave - 2; const bool helper = wave != 0 && wave != 4;
-    const int ch = blockIdx.x, npad = a.npad, c0 = 64 * a.k;                  // first column of the panel
-    const int R0 = NT * (a.k + 1) + BCR_CH * ch;                                // first X tile row of this workgroup
-    const int RX = R0 >= a.T ? 0 : (a.T - R0 < BCR_CH ? a.T - R0 : BCR_CH);
+    const int ch = blockIdx.x, npad = a.npad, c0 = 16 * NT * a.k;             // first column of the panel (a.k counts panels of this width)
+    const int R0 = NT * (a.k + 1) + DCH * ch;                                   // first X tile row of this workgroup
+    const int RX = R0 >= a.T ? 0 : (a.T - R0 < DCH ? a.T - R0 : DCH);
     const bool lead = ch == 0;
     if (RX == 0 && !lead) return;
-    double* Dt = sm; double* Xt = Dt + ND * BTS; double* Wp = Xt + BCR_CH * NT * BTS; double* dvec = Wp + 2 * PR * 16 * BP; double* Li = dvec + 64;
-    const int oDt = 0, oXt = ND * BTS, oWp = oXt + BCR_CH * NT * BTS, odv = oWp + 2 * PR * 16 * BP, oSpare = odv + 64 + 2 * 16 * BP;
+    double* Dt = sm; double* Xt = Dt + ND * BTS; double* Wp = Xt + DCH * NT * BTS; double* dvec = Wp + 2 * PR * 16 * BP; double* Li = dvec + 64;
+    const int oDt = 0, oXt = ND * BTS, oWp = oXt + DCH * NT * BTS, odv = oWp + 2 * PR * 16 * BP, oSpare = odv + 64 + 2 * 16 * BP;
     // ---- landing: element (row a2, column b2) of a tile; consecutive threads walk a column of S (consecutive addresses)
     {
-        constexpr int DQ = (ND * 256 + BCR_T - 1) / BCR_T, XQ = (BCR_CH * NT * 256 + BCR_T - 1) / BCR_T;
+        constexpr int DQ = (ND * 256 + BCR_T - 1) / BCR_T, XQ = (DCH * NT * 256 + BCR_T - 1) / BCR_T;
         double dv[DQ], xv[XQ];
 #pragma unroll
         for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; dv[q] = 0.0;
@@ -481,11 +484,23 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
     }
     exports(NT - 1, wave, 8);
 }
-size_t dense_panel_lds() { constexpr int NT = 4, ND = NT * (NT + 1) / 2; return sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS); }
-void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status) {
-    const int T = npad / 16, below = T - 4 * (k + 1), nch = below > 0 ? (below + BCR_CH - 1) / BCR_CH : 1;
+template <int NT, int DCH> constexpr size_t dense_panel_lds() { return sizeof(double) * ((size_t)(NT * (NT + 1) / 2 + DCH * NT) * BTS + 2 * (size_t)(NT + DCH) * 16 * BP + 64 + 2 * 16 * BP + BTS); }
+static_assert(dense_panel_lds<8, 2>() <= 160 * 1024, "the 128-column panel must fit the LDS of a CU");
+// k: index of the panel in units of ITS width (64 or 128 columns)
+void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide) {
+    const int T = npad / 16;
     DensePanelArgs a{S, W, LiD, npad, k, T, status};
-    hipLaunchKernelGGL(dense_panel_kernel, dim3((unsigned)nch), dim3(BCR_T), dense_panel_lds(), st, a);
+    if (wide) {
+        const int below = T - 8 * (k + 1), nch = below > 0 ? (below + 1) / 2 : 1;
+        static bool attr = false;
+        if (!attr) { constexpr int ldsw = (int)dense_panel_lds<8, 2>(); (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw); attr = true; }
+        constexpr size_t lds = dense_panel_lds<8, 2>();
+        hipLaunchKernelGGL((dense_panel_kernel<8, 2>), dim3((unsigned)nch), dim3(BCR_T), lds, st, a);
+    } else {
+        const int below = T - 4 * (k + 1), nch = below > 0 ? (below + BCR_CH - 1) / BCR_CH : 1;
+        constexpr size_t lds = dense_panel_lds<4, BCR_CH>();
+        hipLaunchKernelGGL((dense_panel_kernel<4, BCR_CH>), dim3((unsigned)nch), dim3(BCR_T), lds, st, a);
+    }
 }
 // x_k = L_kk^-T (y_k - acc_k) for the 64 unknowns of block column kb, from the four inverted diagonal tiles and the L tiles below
 // them (one wavefront; replaces a 64-step lane-serial substitution)

@@ -2488,24 +2488,35 @@ int enqueue_reduced_solve(nlls_ctx* c) {
     } else {
         // blocked right-looking LDL', 64 columns at a time: the panel (diagonal block on the matrix cores with look-ahead, the rows below
         // it as tile products: dense_panel_kernel, nlls_bcr.hip) and the MFMA trailing update
-        double* LiD = c->Lwork.p + (size_t)npad * NB + npad;         // inv(L_JJ)' of every diagonal tile (backward pass)
-        // two panels per pass over the trailing matrix: panel k, a NARROW update of block column k + 1 only, panel k + 1, then one update of
-        // everything behind with both panels (K = 128, 128 x 128 tiles).  (Measured and dropped: the first tile column on this stream and the
-        // rest on a side stream beside the next two panels -- the two event hand-overs per pair cost more than the overlap gained.)
-        double* W0 = c->Lwork.p; double* W1 = LiD + (size_t)(npad / 16) * 256 + 256;
-        for (int k = 0; k < nblk; k += 2) {
-            launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p);
-            if (k + 1 >= nblk) break;
-            hipLaunchKernelGGL(syrk_update2_kernel<1>, dim3(nblk - k - 1), dim3(256), 0, c->stream, c->S.p, W0, W0, npad, k, k + 1, 1);
-            launch_dense_panel(c->stream, c->S.p, W1, LiD, npad, k + 1, c->d_status.p);
-            const int T = nblk - k - 2;
-            if (T <= 0) break;
-            const int T128 = (T + 1) / 2;
-            if (c->dense_t128 && T128 >= c->dense_t128_min) hipLaunchKernelGGL(syrk_update128_kernel, dim3(T128 * (T128 + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
-            else hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
+        // workspace: W = L Delta of the current panel(s) (npad x 128) | acc (npad) | inv(L_JJ)' of every diagonal tile (backward pass)
+        double* const Wbuf = c->Lwork.p; double* const accb = Wbuf + (size_t)npad * 2 * NB; double* LiD = accb + npad;
+        double* W0 = Wbuf; double* W1 = Wbuf + (size_t)npad * NB;
+        int k = 0;
+        if (c->dense_t128) {
+            // 128-column panels (dense_panel_kernel<8, 2>: one launch factors what used to be panel k, a narrow update of block column k + 1 and
+            // panel k + 1), each followed by ONE update of everything behind it with K = 128 (128 x 128 tiles; 64 x 64 for the small tail)
+            for (; k + 1 < nblk; k += 2) {
+                launch_dense_panel(c->stream, c->S.p, Wbuf, LiD, npad, k / 2, c->d_status.p, 1);
+                const int T = nblk - k - 2;
+                if (T <= 0) continue;
+                const int T128 = (T + 1) / 2;
+                if (T128 >= c->dense_t128_min) hipLaunchKernelGGL(syrk_update128_kernel, dim3(T128 * (T128 + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
+                else hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
+            }
+            if (k < nblk) { launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p, 0); ++k; }     // an odd last 64-column panel: nothing behind it
+        } else {
+            // two 64-column panels per pass: panel k, a NARROW update of block column k + 1 only, panel k + 1, then one update with both (K = 128)
+            for (; k < nblk; k += 2) {
+                launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p, 0);
+                if (k + 1 >= nblk) break;
+                hipLaunchKernelGGL(syrk_update2_kernel<1>, dim3(nblk - k - 1), dim3(256), 0, c->stream, c->S.p, W0, W0, npad, k, k + 1, 1);
+                launch_dense_panel(c->stream, c->S.p, W1, LiD, npad, k + 1, c->d_status.p, 0);
+                const int T = nblk - k - 2;
+                if (T > 0) hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
+            }
         }
         // backward substitution into acc / s (x)
-        double* acc = c->Lwork.p + (size_t)npad * NB;
+        double* acc = accb;
         HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * npad, c->stream));
         const int nb_real = (n + NB - 1) / NB;
         // one launch per block: the last block alone, then "push block s into the blocks above it and solve block s - 1"
