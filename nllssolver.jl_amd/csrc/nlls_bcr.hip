@@ -386,7 +386,7 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
 // Replaces one ldlt_diag_kernel (64 dependent pivots with two barriers each: 73 us) + trsm_panel_kernel (one thread per row,
 // uncoalesced: 55 us) launch pair of round 1.
 // ---------------------------------------------------------------------------------------------------
-struct DensePanelArgs { double* S; double* W; double* LiD; int npad, k, T; int* status; };
+struct DensePanelArgs { double* S; double* W; double* LiD; int npad, k, T; int* status; double* Dfac; };   // Dfac: scratch for the factored diagonal block (16 NT square, column-major)
 // NT tiles = 16 NT columns per panel (4: 64 columns; 8: 128 columns, the width of one pass of the trailing update -- then no narrow update and
 // no second panel launch stand between two passes); DCH X tile rows per workgroup (LDS: 8 tiles of width need 2 rows to stay within 160 KB)
 template <int NT, int DCH>
@@ -453,12 +453,18 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
             if (lead && e == 0) { double* dst = a.LiD + ((size_t)a.k * NT + Jp) * 256;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int q = lane + 64 * r; dst[q] = Lid[(q >> 4) * BP + (q & 15)]; } }
+            // The factored DIAGONAL BLOCK does not go into S here: every workgroup of the launch lands the original block from S, and with more
+            // workgroups than the chip holds at once the late ones would land what the lead has already overwritten.  It goes to the scratch
+            // block Dfac; dense_dcopy_kernel moves it into S behind this launch.
             else if (lead && e == 1) {                               // the diagonal tile: unit lower L below the diagonal, Delta on it
                 const double* Wt = Wprev + Jp * 16 * BP;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int q = lane + 64 * r, a2 = q & 15, b2 = q >> 4;
-                    if (a2 >= b2) a.S[(size_t)(c0 + 16 * Jp + a2) + (size_t)npad * (c0 + 16 * Jp + b2)] = a2 == b2 ? dd[b2] : Wt[a2 * BP + b2] * rd[b2]; } }
-            else if (e < nDe) { const int I = Jp + e - 1; store_tile(Wprev + I * 16 * BP, rd, c0 + 16 * I, c0 + 16 * Jp, false); }
+                    if (a2 >= b2) a.Dfac[(size_t)(16 * Jp + a2) + (size_t)(16 * NT) * (16 * Jp + b2)] = a2 == b2 ? dd[b2] : Wt[a2 * BP + b2] * rd[b2]; } }
+            else if (e < nDe) { const int I = Jp + e - 1; const double* Wt = Wprev + I * 16 * BP;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int e2 = lane + 64 * r, a2 = e2 & 15, b2 = e2 >> 4;
+                    a.Dfac[(size_t)(16 * I + a2) + (size_t)(16 * NT) * (16 * Jp + b2)] = Wt[a2 * BP + b2] * rd[b2]; } }
             else { const int R = e - nDe; store_tile(Wprev + (NT + R) * 16 * BP, rd, 16 * (R0 + R), c0 + 16 * Jp, true); }
         }
     };
@@ -484,22 +490,28 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
     }
     exports(NT - 1, wave, 8);
 }
+// the lower triangle of the factored diagonal block: scratch -> S (behind the panel launch)
+__global__ __launch_bounds__(256) void dense_dcopy_kernel(double* __restrict__ S, const double* __restrict__ Dfac, int npad, int c0, int nb) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nb * nb; e += gridDim.x * 256) { const int i = e % nb, j = e / nb; if (i >= j) S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)] = Dfac[(size_t)i + (size_t)nb * j]; }
+}
 template <int NT, int DCH> constexpr size_t dense_panel_lds() { return sizeof(double) * ((size_t)(NT * (NT + 1) / 2 + DCH * NT) * BTS + 2 * (size_t)(NT + DCH) * 16 * BP + 64 + 2 * 16 * BP + BTS); }
 static_assert(dense_panel_lds<8, 2>() <= 160 * 1024, "the 128-column panel must fit the LDS of a CU");
 // k: index of the panel in units of ITS width (64 or 128 columns)
-void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide) {
+void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac) {
     const int T = npad / 16;
-    DensePanelArgs a{S, W, LiD, npad, k, T, status};
+    DensePanelArgs a{S, W, LiD, npad, k, T, status, Dfac};
     if (wide) {
         const int below = T - 8 * (k + 1), nch = below > 0 ? (below + 1) / 2 : 1;
         static bool attr = false;
         if (!attr) { constexpr int ldsw = (int)dense_panel_lds<8, 2>(); (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw); attr = true; }
         constexpr size_t lds = dense_panel_lds<8, 2>();
         hipLaunchKernelGGL((dense_panel_kernel<8, 2>), dim3((unsigned)nch), dim3(BCR_T), lds, st, a);
+        hipLaunchKernelGGL(dense_dcopy_kernel, dim3(16), dim3(256), 0, st, S, Dfac, npad, 128 * k, 128);
     } else {
         const int below = T - 4 * (k + 1), nch = below > 0 ? (below + BCR_CH - 1) / BCR_CH : 1;
         constexpr size_t lds = dense_panel_lds<4, BCR_CH>();
         hipLaunchKernelGGL((dense_panel_kernel<4, BCR_CH>), dim3((unsigned)nch), dim3(BCR_T), lds, st, a);
+        hipLaunchKernelGGL(dense_dcopy_kernel, dim3(4), dim3(256), 0, st, S, Dfac, npad, 64 * k, 64);
     }
 }
 // x_k = L_kk^-T (y_k - acc_k) for the 64 unknowns of block column kb, from the four inverted diagonal tiles and the L tiles below

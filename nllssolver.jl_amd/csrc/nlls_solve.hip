@@ -2490,27 +2490,28 @@ int enqueue_reduced_solve(nlls_ctx* c) {
         // it as tile products: dense_panel_kernel, nlls_bcr.hip) and the MFMA trailing update
         // workspace: W = L Delta of the current panel(s) (npad x 128) | acc (npad) | inv(L_JJ)' of every diagonal tile (backward pass)
         double* const Wbuf = c->Lwork.p; double* const accb = Wbuf + (size_t)npad * 2 * NB; double* LiD = accb + npad;
+        double* const Dfac = LiD + (size_t)(npad / 16) * 256 + 256;    // the factored diagonal block of a panel, until dense_dcopy_kernel moves it into S
         double* W0 = Wbuf; double* W1 = Wbuf + (size_t)npad * NB;
         int k = 0;
         if (c->dense_t128) {
             // 128-column panels (dense_panel_kernel<8, 2>: one launch factors what used to be panel k, a narrow update of block column k + 1 and
             // panel k + 1), each followed by ONE update of everything behind it with K = 128 (128 x 128 tiles; 64 x 64 for the small tail)
             for (; k + 1 < nblk; k += 2) {
-                launch_dense_panel(c->stream, c->S.p, Wbuf, LiD, npad, k / 2, c->d_status.p, 1);
+                launch_dense_panel(c->stream, c->S.p, Wbuf, LiD, npad, k / 2, c->d_status.p, 1, Dfac);
                 const int T = nblk - k - 2;
                 if (T <= 0) continue;
                 const int T128 = (T + 1) / 2;
                 if (T128 >= c->dense_t128_min) hipLaunchKernelGGL(syrk_update128_kernel, dim3(T128 * (T128 + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
                 else hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
             }
-            if (k < nblk) { launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p, 0); ++k; }     // an odd last 64-column panel: nothing behind it
+            if (k < nblk) { launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p, 0, Dfac); ++k; }     // an odd last 64-column panel: nothing behind it
         } else {
             // two 64-column panels per pass: panel k, a NARROW update of block column k + 1 only, panel k + 1, then one update with both (K = 128)
             for (; k < nblk; k += 2) {
-                launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p, 0);
+                launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p, 0, Dfac);
                 if (k + 1 >= nblk) break;
                 hipLaunchKernelGGL(syrk_update2_kernel<1>, dim3(nblk - k - 1), dim3(256), 0, c->stream, c->S.p, W0, W0, npad, k, k + 1, 1);
-                launch_dense_panel(c->stream, c->S.p, W1, LiD, npad, k + 1, c->d_status.p, 0);
+                launch_dense_panel(c->stream, c->S.p, W1, LiD, npad, k + 1, c->d_status.p, 0, Dfac);
                 const int T = nblk - k - 2;
                 if (T > 0) hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
             }

@@ -81,3 +81,12 @@ def test_so3_noise_free_optimum(ncam, npts, prop):
     assert ores.bestcost < 1e-15 * p.ncosts(), ores.bestcost
     assert res.bestcost < 1e-15 * p.ncosts(), res.bestcost
     assert N.cost(p) == res.bestcost
+
+
+def test_large_dense_solve_more_workgroups_than_the_chip_holds():
+    """A 9198-dof system with no Schur structure the fast kernels take (every point is seen by ~29 cameras: 174 neighbour dof) falls back to
+    the dense blocked LDL' of the FULL system: 72 panels of 128 columns, the first with 284 workgroups -- more than are resident at once.
+    (The stress run tools/stress_parity.py found it: late workgroups landed a diagonal block the lead had already overwritten in place.)"""
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(83, 2900, 0.35, seed=5063, robust=N.HuberKernel(0.05), outlier_frac=0.1, outlier_sigma=0.1), 1e-3, 1e-3)
+    info = check_problem(p, lam_scale=1e-4)
+    assert info.solve_mode == 1 and info.nreduced_dof == info.ndof == 6 * 83 + 3 * 2900

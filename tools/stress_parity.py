@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Stress run (not part of the test suite): the randomized parity checks of tests/test_gpu_parity.py over many more seeds, including larger
+band shapes (more cameras, narrow visibility: the block-cyclic-reduction and matrix-core elimination paths).  Prints failures, exits 1 if any."""
+import os, sys, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import nllssolver_jl_amd as N
+from nllssolver_jl_amd import synthetic, _capi
+from tests.test_gpu_parity import check_problem
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+fails = 0
+for seed in range(lo, hi):
+    rng = np.random.default_rng(seed)
+    try:
+        mode = seed % 3
+        if mode == 0:            # generic small shapes, all flags
+            ncam = int(rng.integers(4, 60)); npts = int(rng.integers(20, 1500)); prop = max(float(rng.uniform(0.05, 0.6)), 3.5 / ncam)
+        elif mode == 1:          # camera chains: band mode with several BCR levels
+            ncam = int(rng.integers(48, 400)); per = int(rng.integers(3, 12)); npts = int(rng.integers(10, 40)) * ncam; prop = per / ncam
+        else:                    # dense reduced systems of a few hundred dof
+            ncam = int(rng.integers(12, 90)); npts = int(rng.integers(200, 3000)); prop = float(rng.uniform(0.3, 0.9))
+        kind = int(rng.integers(0, 4))
+        robust = [None, N.HuberKernel(float(rng.uniform(0.005, 0.1))), N.GemanMcclureKernel(float(rng.uniform(0.02, 0.2))),
+                  N.Scaled(N.Huber2oKernel(float(rng.uniform(0.005, 0.1))), float(rng.uniform(0.5, 3.0)))][kind]
+        kw = dict(robust=robust, outlier_frac=float(rng.uniform(0.0, 0.3)), outlier_sigma=0.1) if robust is not None else {}
+        p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed, **kw), 1e-3, 1e-3)
+        unfixed = None
+        if rng.random() < 0.4:
+            unfixed = np.ones(p.nvariables, bool); unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 20), replace=False)] = False
+        flags = [0, 0, _capi.FLAG_NO_BCR, _capi.FLAG_FORCE_ATOMIC, _capi.FLAG_NO_BAND, _capi.FLAG_DETERMINISTIC][int(rng.integers(0, 6))]
+        check_problem(p, unfixed=unfixed, flags=flags, lam_scale=[1e-6, 1e-4, 1e-1, 1e-2][kind])
+    except Exception as e:
+        fails += 1
+        print(f"seed {seed} FAILED: {type(e).__name__}: {str(e)[:200]}", flush=True)
+    if (seed - lo) % 20 == 19:
+        print(f"... {seed - lo + 1} cases, {fails} failures", flush=True)
+print(f"{hi - lo} cases, {fails} failures")
+sys.exit(1 if fails else 0)
