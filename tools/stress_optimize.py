@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Stress run (not part of the test suite): tests/test_gpu_functional.py::test_randomized_optimize_matches_oracle over many more seeds --
+the whole optimize! loop (Levenberg-Marquardt in the library's own loop, nlls_lm_iterations) on the device against the oracle."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import nllssolver_jl_amd as N
+from nllssolver_jl_amd import synthetic
+from tests.helpers import oracle_problem
+lo, hi = int(sys.argv[1]), int(sys.argv[2]); fails = 0
+for seed in range(lo, hi):
+    rng = np.random.default_rng(seed)
+    ncam = int(rng.integers(5, 120)); npts = int(rng.integers(50, 3000)); prop = max(float(rng.uniform(0.04, 0.5)), 4.0 / ncam)
+    robust = bool(rng.integers(0, 2))
+    kw = dict(robust=N.HuberKernel(float(rng.uniform(0.01, 0.05))), outlier_frac=0.1, outlier_sigma=0.2) if robust else {}
+    mk = lambda: synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed, **kw), 1e-3, 1e-3)
+    try:
+        p = mk(); op = oracle_problem(mk())
+        res = N.optimize(p, N.NLLSOptions(maxiters=60)); ores = op.optimize(maxiters=60)
+        if not robust: assert res.bestcost < 1e-15 * p.ncosts() and ores.bestcost < 1e-15 * p.ncosts(), (res.bestcost, ores.bestcost)
+        else: assert np.isclose(res.bestcost, ores.bestcost, rtol=1e-6), (res.bestcost, ores.bestcost)
+    except Exception as e:
+        fails += 1; print(f"seed {seed} ncam {ncam} npts {npts} prop {prop:.3f} robust {robust} FAILED: {type(e).__name__}: {str(e)[:200]}", flush=True)
+print(f"{hi - lo} cases, {fails} failures"); sys.exit(1 if fails else 0)

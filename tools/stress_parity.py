@@ -13,7 +13,17 @@ fails = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
     try:
-        mode = seed % 3
+        mode = seed % 4
+        if mode == 3:            # SO(3) cameras, pinhole, optionally the adaptive kernel as a border variable (BASELINE config 5 kinds)
+            ncam = int(rng.integers(6, 300)); npts = int(rng.integers(60, 6000)); prop = max(float(rng.uniform(0.02, 0.5)), 4.0 / ncam)
+            adaptive = bool(rng.integers(0, 2))
+            robust = None if adaptive else [None, N.HuberKernel(0.05), N.GemanMcclureKernel(0.1)][int(rng.integers(0, 3))]
+            p = synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(ncam, npts, prop, seed=seed, adaptive=adaptive, robust=robust), 1e-3, 1e-3)
+            unfixed = None
+            if rng.random() < 0.3:
+                unfixed = np.ones(p.nvariables, bool); unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 25), replace=False)] = False
+            check_problem(p, unfixed=unfixed, lam_scale=1e-4 if robust is None or adaptive else 1e-1)
+            continue
         if mode == 0:            # generic small shapes, all flags
             ncam = int(rng.integers(4, 60)); npts = int(rng.integers(20, 1500)); prop = max(float(rng.uniform(0.05, 0.6)), 3.5 / ncam)
         elif mode == 1:          # camera chains: band mode with several BCR levels
@@ -33,6 +43,8 @@ for seed in range(lo, hi):
     except Exception as e:
         fails += 1
         print(f"seed {seed} FAILED: {type(e).__name__}: {str(e)[:200]}", flush=True)
+    finally:
+        pass
     if (seed - lo) % 20 == 19:
         print(f"... {seed - lo + 1} cases, {fails} failures", flush=True)
 print(f"{hi - lo} cases, {fails} failures")
