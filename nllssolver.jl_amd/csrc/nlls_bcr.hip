@@ -454,8 +454,8 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int q = lane + 64 * r; dst[q] = Lid[(q >> 4) * BP + (q & 15)]; } }
             // The factored DIAGONAL BLOCK does not go into S here: every workgroup of the launch lands the original block from S, and with more
-            // workgroups than the chip holds at once the late ones would land what the lead has already overwritten.  It goes to the scratch
-            // block Dfac; dense_dcopy_kernel moves it into S behind this launch.
+            // workgroups than the chip holds at once the late ones would land what the lead has already overwritten.  It goes to the panel's
+            // slot of Dfac; dense_dcopy_all_kernel moves all of them into S behind the last panel.
             else if (lead && e == 1) {                               // the diagonal tile: unit lower L below the diagonal, Delta on it
                 const double* Wt = Wprev + Jp * 16 * BP;
 #pragma unroll
@@ -490,28 +490,33 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
     }
     exports(NT - 1, wave, 8);
 }
-// the lower triangle of the factored diagonal block: scratch -> S (behind the panel launch)
-__global__ __launch_bounds__(256) void dense_dcopy_kernel(double* __restrict__ S, const double* __restrict__ Dfac, int npad, int c0, int nb) {
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < nb * nb; e += gridDim.x * 256) { const int i = e % nb, j = e / nb; if (i >= j) S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)] = Dfac[(size_t)i + (size_t)nb * j]; }
+// the lower triangles of the factored diagonal blocks: their slots -> S, ONE launch behind the last panel (nothing reads them before the
+// backward pass).  Slot of a panel = the 64-block index of its first column, 128 x 128 doubles each; block b < nwide: the 128-column panel b,
+// the others: 64-column panels from 64-block first64 on.
+__global__ __launch_bounds__(256) void dense_dcopy_all_kernel(double* __restrict__ S, const double* __restrict__ Dfac, int npad, int nwide, int first64) {
+    const int b = blockIdx.x, nb = b < nwide ? 128 : 64, k64 = b < nwide ? 2 * b : first64 + (b - nwide), c0 = 64 * k64;
+    const double* D = Dfac + (size_t)k64 * 128 * 128;
+    for (int e = threadIdx.x; e < nb * nb; e += 256) { const int i = e % nb, j = e / nb; if (i >= j) S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)] = D[(size_t)i + (size_t)nb * j]; }
+}
+void launch_dense_dcopy_all(hipStream_t st, double* S, const double* Dfac, int npad, int nwide, int first64, int n64) {
+    if (nwide + n64 > 0) hipLaunchKernelGGL(dense_dcopy_all_kernel, dim3((unsigned)(nwide + n64)), dim3(256), 0, st, S, Dfac, npad, nwide, first64);
 }
 template <int NT, int DCH> constexpr size_t dense_panel_lds() { return sizeof(double) * ((size_t)(NT * (NT + 1) / 2 + DCH * NT) * BTS + 2 * (size_t)(NT + DCH) * 16 * BP + 64 + 2 * 16 * BP + BTS); }
 static_assert(dense_panel_lds<8, 2>() <= 160 * 1024, "the 128-column panel must fit the LDS of a CU");
 // k: index of the panel in units of ITS width (64 or 128 columns)
 void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac) {
     const int T = npad / 16;
-    DensePanelArgs a{S, W, LiD, npad, k, T, status, Dfac};
+    DensePanelArgs a{S, W, LiD, npad, k, T, status, Dfac + (size_t)(wide ? 2 * k : k) * 128 * 128};   // the panel's slot
     if (wide) {
         const int below = T - 8 * (k + 1), nch = below > 0 ? (below + 1) / 2 : 1;
         static bool attr = false;
         if (!attr) { constexpr int ldsw = (int)dense_panel_lds<8, 2>(); (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw); attr = true; }
         constexpr size_t lds = dense_panel_lds<8, 2>();
         hipLaunchKernelGGL((dense_panel_kernel<8, 2>), dim3((unsigned)nch), dim3(BCR_T), lds, st, a);
-        hipLaunchKernelGGL(dense_dcopy_kernel, dim3(16), dim3(256), 0, st, S, Dfac, npad, 128 * k, 128);
     } else {
         const int below = T - 4 * (k + 1), nch = below > 0 ? (below + BCR_CH - 1) / BCR_CH : 1;
         constexpr size_t lds = dense_panel_lds<4, BCR_CH>();
         hipLaunchKernelGGL((dense_panel_kernel<4, BCR_CH>), dim3((unsigned)nch), dim3(BCR_T), lds, st, a);
-        hipLaunchKernelGGL(dense_dcopy_kernel, dim3(4), dim3(256), 0, st, S, Dfac, npad, 64 * k, 64);
     }
 }
 // x_k = L_kk^-T (y_k - acc_k) for the 64 unknowns of block column kb, from the four inverted diagonal tiles and the L tiles below
@@ -533,10 +538,11 @@ BCR_DEV void dense_bwd_diag_load(const double* __restrict__ S, const double* __r
         for (int q = 0; q < 4; ++q) T.li[J][q] = Lk[gq + 4 * q];
     }
 }
-BCR_DEV void dense_bwd_diag_chain(const double* __restrict__ S, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x, const DenseBwdTiles& T,
+// (accb: the 64 entries of acc that belong to block kb -- in global memory or in LDS)
+BCR_DEV void dense_bwd_diag_chain(const double* __restrict__ S, int npad, int kb, int n, const double* accb, double* __restrict__ x, const DenseBwdTiles& T,
                                   double* r, double* xs, double* uu) {
     const int lane = threadIdx.x & 63, c = lane & 15, gq = lane >> 4, c0 = 64 * kb;
-    { const int g = c0 + lane; r[lane] = (g < n) ? S[(size_t)n + (size_t)npad * g] - acc[g] : 0.0; xs[lane] = 0.0; }     // y: row n of the factor
+    { const int g = c0 + lane; r[lane] = (g < n) ? S[(size_t)n + (size_t)npad * g] - accb[lane] : 0.0; xs[lane] = 0.0; }     // y: row n of the factor
     __syncthreads();
 #pragma unroll
     for (int J = 3; J >= 0; --J) {
@@ -560,7 +566,7 @@ BCR_DEV void dense_bwd_diag_chain(const double* __restrict__ S, int npad, int kb
 __global__ __launch_bounds__(64) void dense_bwd_diag_kernel(const double* __restrict__ S, const double* __restrict__ LiD, int npad, int kb, int n, const double* __restrict__ acc, double* __restrict__ x) {
     __shared__ double r[64], xs[64], uu[16];
     DenseBwdTiles T; dense_bwd_diag_load(S, LiD, npad, kb, T);
-    dense_bwd_diag_chain(S, npad, kb, n, acc, x, T, r, xs, uu);
+    dense_bwd_diag_chain(S, npad, kb, n, acc + 64 * kb, x, T, r, xs, uu);
 }
 // One launch per step of the backward substitution L' x = z: block s has just been solved (x_s final).  Workgroup j < s pushes its
 // contribution into the 64 entries of block j -- acc_j += L(block s, block j)' x_s: every block column is owned by one workgroup per
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(256) void dense_bwd_step_kernel(const double* __res
     acc[j * 64 + c] += red[0][c] + red[1][c] + red[2][c] + red[3][c];
     if (j != s - 1) return;
     __threadfence_block();
-    dense_bwd_diag_chain(S, npad, s - 1, n, acc, x, T, r, xs, uu);                   // (one wavefront left in this workgroup: its barriers are its own)
+    dense_bwd_diag_chain(S, npad, s - 1, n, acc + 64 * (s - 1), x, T, r, xs, uu);    // (one wavefront left in this workgroup: its barriers are its own)
 }
 void launch_dense_bwd_diag(hipStream_t st, const double* S, const double* LiD, int npad, int kb, int n, const double* acc, double* x) {
     hipLaunchKernelGGL(dense_bwd_diag_kernel, dim3(1), dim3(64), 0, st, S, LiD, npad, kb, n, acc, x);

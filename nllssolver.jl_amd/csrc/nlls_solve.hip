@@ -1189,31 +1189,39 @@ __global__ __launch_bounds__(256) void syrk_update2_kernel(double* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cg[(size_t)(r0 + 16 * a + li) + (size_t)npad * (c0 + 16 * b2 + lk + 4 * r)] = cold[a][b2][r] - acc[a][b2][r];
 }
-// The two-panel trailing update with 128 x 128 output tiles: C -= W_k0 L_k0' + W_{k0+1} L_{k0+1}' (K = 128).  Four wavefronts, each a 64 x 64
-// quarter = 4 x 4 accumulator tiles of v_mfma_f64_16x16x4_f64 (128 accumulator registers): 8 LDS operand reads per 16 MFMAs where the
-// 64 x 64 kernel above needs 4 per 4, and a quarter of its operand traffic per flop.  The operands go through LDS in chunks of 16 columns,
-// double buffered: the global loads of chunk c + 1 are in flight while chunk c is multiplied.  Products are formed transposed (operands
-// swapped) so that the read-modify-write of S is coalesced.  Tiles start at 64-block jb0; when the number of 64-blocks behind it is odd the
-// last tile row / column is half empty: those wavefronts idle.  The quarter above the diagonal of a diagonal tile is not needed either.
+// The two-panel trailing update with 128 x 128 output tiles: C -= W_k0 L_k0' + W_{k0+1} L_{k0+1}' (K = 128).  EIGHT wavefronts, each a 64 x 32
+// block = 4 x 2 accumulator tiles of v_mfma_f64_16x16x4_f64 (6 LDS operand reads per 8 MFMAs; the 64 x 64 kernel above needs 4 per 4 and four
+// times the operand traffic per flop).  114 registers: two workgroups per CU are four waves per SIMD -- with four waves per tile (64 x 64 each,
+// 213 registers, two waves per SIMD) the same tile took 8 % longer: every workgroup alternates between its MFMA loop and phases in which it
+// only waits (first operands, the read-modify-write of C at the end), and two waves per SIMD leave the matrix pipe idle whenever both wait.
+// The operands go through LDS in chunks of 16 columns, double buffered: the global loads of chunk c + 1 are in flight while chunk c is
+// multiplied.  Products are formed transposed (operands swapped) so that the read-modify-write of S is coalesced.  Tiles start at 64-block
+// jb0; when the number of 64-blocks behind it is odd the last tile row / column is half empty: those wavefronts idle.  The blocks above the
+// diagonal of a diagonal tile are not needed either.
+// What bounds a pass (tools/dense/syrk_test.hip, 1081 tiles = the first pass of a 6000-dof system, 130 us): two workgroups share a CU at 70 k
+// cycles per tile each (the MFMAs of a tile are 32.8 k cycles per SIMD: the steady state is matrix-bound), so a CU works through its 4.2 tiles
+// in three rounds; the read-modify-write of C adds 19 us, the operand loads 18 us (each alone; lone workgroup: loop 34.5 k cycles without,
+// 46.4 k with the operand loads).  Persistent workgroups with dynamic tile fetch and a half-tile stagger between the two workgroups of a CU
+// were measured there too: no gain (129 us).
 constexpr int S128_KC = 16, S128_LD = 144;
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void syrk_update128_kernel(double* __restrict__ S, const double* __restrict__ W0, const double* __restrict__ W1, int npad, int k0, int jb0, int firstcol) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void syrk_update128_kernel(double* __restrict__ S, const double* __restrict__ W0, const double* __restrict__ W1, int npad, int k0, int jb0, int firstcol) {
     __shared__ double As[2][S128_KC * S128_LD], Bs[2][S128_KC * S128_LD];
     int ti, tj;                                                // firstcol: only the first tile column (what the next two panels wait for)
     if (firstcol) { ti = blockIdx.x; tj = 0; }
     else { const int tix = blockIdx.x; ti = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > tix) --ti; while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti; tj = tix - ti * (ti + 1) / 2; }
     const int I0 = jb0 * NB + 128 * ti, J0 = jb0 * NB + 128 * tj;
     const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
-    const int r0w = (w & 1) * 64, c0w = (w >> 1) * 64;
-    const bool active = I0 + r0w < npad && J0 + c0w < npad && !(ti == tj && c0w > r0w);
-    double4_t acc[4][4];
+    const int r0w = (w & 1) * 64, c0w = (w >> 1) * 32;
+    const bool active = I0 + r0w < npad && J0 + c0w < npad && !(ti == tj && c0w >= r0w + 64);
+    double4_t acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = double4_t{0, 0, 0, 0};
-    // copy roles: thread t moves row (t & 127) of both operands, every other column of a chunk (kq, kq + 2, ..)
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = double4_t{0, 0, 0, 0};
+    // copy roles: thread t moves row (t & 127) of both operands, every fourth column of a chunk (kq, kq + 4, ..)
     const int cr = t & 127, kq = t >> 7;
     const int arow = I0 + cr < npad ? I0 + cr : npad - 1, brow = J0 + cr < npad ? J0 + cr : npad - 1;
-    constexpr int NCP = S128_KC / 2, CPP = NB / S128_KC;       // columns per thread and chunk; chunks per panel
+    constexpr int NCP = S128_KC / 4, CPP = NB / S128_KC;       // columns per thread and chunk; chunks per panel
     double ra[NCP], rb[NCP];
     auto gload = [&](int chunk) {                              // chunk: panel (chunk / CPP), columns S128_KC * (chunk % CPP) ..
         const int q = chunk / CPP, col0 = (chunk % CPP) * S128_KC;
@@ -1221,11 +1229,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const double* Ga = Wq + (size_t)arow + (size_t)npad * col0;
         const double* Gb = S + (size_t)brow + (size_t)npad * ((size_t)(k0 + q) * NB + col0);
 #pragma unroll
-        for (int i = 0; i < NCP; ++i) { ra[i] = Ga[(size_t)npad * (kq + 2 * i)]; rb[i] = Gb[(size_t)npad * (kq + 2 * i)]; }
+        for (int i = 0; i < NCP; ++i) { ra[i] = Ga[(size_t)npad * (kq + 4 * i)]; rb[i] = Gb[(size_t)npad * (kq + 4 * i)]; }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NCP; ++i) { As[buf][(kq + 2 * i) * S128_LD + cr] = ra[i]; Bs[buf][(kq + 2 * i) * S128_LD + cr] = rb[i]; }
+        for (int i = 0; i < NCP; ++i) { As[buf][(kq + 4 * i) * S128_LD + cr] = ra[i]; Bs[buf][(kq + 4 * i) * S128_LD + cr] = rb[i]; }
     };
     constexpr int NCH = 2 * NB / S128_KC;
     gload(0); lstore(0);
@@ -1237,15 +1245,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (active) {
 #pragma unroll
             for (int kk = 0; kk < S128_KC; kk += 4) {
-                double av[4], bv[4];
+                double av[4], bv[2];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) av[a] = As[buf][(kk + lk) * S128_LD + r0w + 16 * a + li];
 #pragma unroll
-                for (int b2 = 0; b2 < 4; ++b2) bv[b2] = Bs[buf][(kk + lk) * S128_LD + c0w + 16 * b2 + li];
+                for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Bs[buf][(kk + lk) * S128_LD + c0w + 16 * b2 + li];
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
+                    for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
             }
         }
         if (ch + 1 < NCH) lstore(buf ^ 1);
@@ -1256,7 +1264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // (A no-return atomic add per entry -- every entry has one writer per pass -- measured slower than this read-modify-write.)
     double* Cg = S + (size_t)(I0 + r0w) + (size_t)npad * (J0 + c0w);
 #pragma unroll
-    for (int b2 = 0; b2 < 4; ++b2) {
+    for (int b2 = 0; b2 < 2; ++b2) {
         double cold[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -2490,7 +2498,7 @@ int enqueue_reduced_solve(nlls_ctx* c) {
         // it as tile products: dense_panel_kernel, nlls_bcr.hip) and the MFMA trailing update
         // workspace: W = L Delta of the current panel(s) (npad x 128) | acc (npad) | inv(L_JJ)' of every diagonal tile (backward pass)
         double* const Wbuf = c->Lwork.p; double* const accb = Wbuf + (size_t)npad * 2 * NB; double* LiD = accb + npad;
-        double* const Dfac = LiD + (size_t)(npad / 16) * 256 + 256;    // the factored diagonal block of a panel, until dense_dcopy_kernel moves it into S
+        double* const Dfac = LiD + (size_t)(npad / 16) * 256 + 256;    // the factored diagonal blocks, one slot of 128 x 128 per 64-block, until dense_dcopy_all_kernel moves them into S
         double* W0 = Wbuf; double* W1 = Wbuf + (size_t)npad * NB;
         int k = 0;
         if (c->dense_t128) {
@@ -2501,10 +2509,12 @@ int enqueue_reduced_solve(nlls_ctx* c) {
                 const int T = nblk - k - 2;
                 if (T <= 0) continue;
                 const int T128 = (T + 1) / 2;
-                if (T128 >= c->dense_t128_min) hipLaunchKernelGGL(syrk_update128_kernel, dim3(T128 * (T128 + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
+                if (T128 >= c->dense_t128_min) hipLaunchKernelGGL(syrk_update128_kernel, dim3(T128 * (T128 + 1) / 2), dim3(512), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
                 else hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
             }
+            const int nwide = k / 2;
             if (k < nblk) { launch_dense_panel(c->stream, c->S.p, W0, LiD, npad, k, c->d_status.p, 0, Dfac); ++k; }     // an odd last 64-column panel: nothing behind it
+            launch_dense_dcopy_all(c->stream, c->S.p, Dfac, npad, nwide, 2 * nwide, nblk - 2 * nwide);
         } else {
             // two 64-column panels per pass: panel k, a NARROW update of block column k + 1 only, panel k + 1, then one update with both (K = 128)
             for (; k < nblk; k += 2) {
@@ -2515,12 +2525,14 @@ int enqueue_reduced_solve(nlls_ctx* c) {
                 const int T = nblk - k - 2;
                 if (T > 0) hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, k, k + 2, 0);
             }
+            launch_dense_dcopy_all(c->stream, c->S.p, Dfac, npad, 0, 0, nblk);
         }
         // backward substitution into acc / s (x)
         double* acc = accb;
         HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * npad, c->stream));
         const int nb_real = (n + NB - 1) / NB;
         // one launch per block: the last block alone, then "push block s into the blocks above it and solve block s - 1"
+        // (two blocks per launch -- every workgroup solving block s - 1 redundantly -- was measured: 15.9 us per launch against 2 x 6.7)
         launch_dense_bwd_diag(c->stream, c->S.p, LiD, npad, nb_real - 1, n, acc, c->s_ptr());
         for (int sblk = nb_real - 1; sblk >= 1; --sblk) launch_dense_bwd_step(c->stream, c->S.p, LiD, npad, sblk, n, acc, c->s_ptr());
     }

@@ -685,7 +685,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         if (npad > 46000) return fail(c, NLLS_ERR_UNSUPPORTED, "reduced system too large for the dense solver (" + std::to_string(n) + " dof, not banded)");
         c->s_elems = (size_t)std::max<int64_t>(npad * npad, 1);
         if (hipSuccess != c->S.alloc(c->s_elems + (size_t)npad + 64) ||
-            hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 128 + npad + (npad / 16) * 256 + 256 + 128 * 128, 1))   /* W of a 128-column panel (or of two 64-column ones) | acc | inverted diagonal tiles | factored diagonal block */ || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
+            hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 128 + npad + (npad / 16) * 256 + 256 + (npad / 64 + 1) * 128 * 128, 1))   /* W of a 128-column panel (or of two 64-column ones) | acc | inverted diagonal tiles | factored diagonal blocks (a slot per 64-block) */ || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
     }
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
     c->info.solve_mode = c->solve_mode; c->info.bandwidth = c->bw; c->info.nborder_dof = c->nbd;
