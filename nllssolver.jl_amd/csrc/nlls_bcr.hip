@@ -23,6 +23,7 @@
 //   (bcr_backward_kernel, levels in reverse) is matrix-vector products only:
 //            x_i,J = zh_J - sum_X M_X,J' x_X - sum_{K>J} M_KJ' x_i,K .
 #include <algorithm>
+#include <cstdlib>
 
 #include "nlls_bcr.hpp"
 
@@ -225,14 +226,14 @@ BCR_DEV void bcr_export_linv(const double* Lid, double* __restrict__ dst) {
     *reinterpret_cast<bdouble4_t*>(dst + 4 * lane) = bdouble4_t{Lid[li * BP + lk], Lid[li * BP + 4 + lk], Lid[li * BP + 8 + lk], Lid[li * BP + 12 + lk]};
 }
 
-struct BcrPanelArgs { BcrGeom g; BcrChain ch; int* status; double relfloor; };
+struct BcrPanelArgs { BcrGeom g; BcrChain ch; int* status; double relfloor; int chrows; };   // chrows: X rows per workgroup of this launch (1 .. BCR_CH)
 // job e of a level, from the level's chain (no descriptor load in front of everything else)
 BCR_DEV BcrElim bcr_job(const BcrChain& c, int e) {
     const int idx = c.first + 2 * e, i = c.o + idx * c.s;
     return BcrElim{i, idx >= 1 ? i - c.s : -1, idx + 1 < c.m ? i + c.s : -1, 0};
 }
 constexpr int BCR_CH = 3;                                     // X rows (16-row tiles) per workgroup
-__host__ __device__ constexpr int bcr_nchunks(int NT) { return (2 * NT + 1 + BCR_CH - 1) / BCR_CH; }
+__host__ __device__ constexpr int bcr_nchunks(int NT, int chrows = BCR_CH) { return (2 * NT + 1 + chrows - 1) / chrows; }
 
 // The X rows of an eliminated block -- NT tile rows of the left neighbour (A_il'), NT of the right one (A_ri), one of border /
 // rhs rows -- are dealt over bcr_nchunks(NT) workgroups, three tile rows each; every one of them factors D_i (identical
@@ -243,14 +244,14 @@ template <bool FLOOR>
 __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BcrGeom& g = a.g;
-    const int NT = g.NT, NCH = bcr_nchunks(NT), ND = NT * (NT + 1) / 2, RXT = 2 * NT + 1, PR = NT + BCR_CH;
+    const int NT = g.NT, CHR = a.chrows, NCH = bcr_nchunks(NT, CHR), ND = NT * (NT + 1) / 2, RXT = 2 * NT + 1, PR = NT + BCR_CH;
     const BcrElim job = bcr_job(a.ch, blockIdx.x / NCH); const int ch = blockIdx.x % NCH;
     // this workgroup's X rows: global row index Rg (0..NT-1: left neighbour, NT..2NT-1: right neighbour, 2NT: border / rhs)
     static_assert(BCR_CH == 3, "the row list below is written out for three rows");
     int rw0 = 0, rw1 = 0, rw2 = 0, RX = 0;            // (scalars, not an array: a dynamically indexed array would live in scratch memory)
 #pragma unroll
-    for (int s2 = 0; s2 < BCR_CH; ++s2) { const int Rg = BCR_CH * ch + s2;
-        if (Rg <= 2 * NT && (Rg < NT ? job.l >= 0 : (Rg < 2 * NT ? job.r >= 0 : true))) { if (RX == 0) rw0 = Rg; else if (RX == 1) rw1 = Rg; else rw2 = Rg; ++RX; } }
+    for (int s2 = 0; s2 < BCR_CH; ++s2) { const int Rg = CHR * ch + s2;
+        if (s2 < CHR && Rg <= 2 * NT && (Rg < NT ? job.l >= 0 : (Rg < 2 * NT ? job.r >= 0 : true))) { if (RX == 0) rw0 = Rg; else if (RX == 1) rw1 = Rg; else rw2 = Rg; ++RX; } }
     if (RX == 0) return;
     auto rowRg = [&](int R) { return R == 0 ? rw0 : (R == 1 ? rw1 : rw2); };
     const bool lead = rowRg(RX - 1) == 2 * NT;
@@ -507,7 +508,15 @@ static_assert(dense_panel_lds<8, 2>() <= 160 * 1024, "the 128-column panel must 
 void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac) {
     const int T = npad / 16;
     DensePanelArgs a{S, W, LiD, npad, k, T, status, Dfac + (size_t)(wide ? 2 * k : k) * 128 * 128};   // the panel's slot
-    if (wide) {
+    static const int one_row_max = [] { const char* e = getenv("NLLS_DENSE_DCH1"); return e ? atoi(e) : 256; }();   // (one round of a 256-CU chip; NLLS_DENSE_DCH1=0: two rows per workgroup everywhere, for A/B runs: 4.28 instead of 4.19 ms at 6000 dof)
+    if (wide && T - 8 * (k + 1) <= one_row_max && T - 8 * (k + 1) > 0) {
+        // one X tile row per workgroup while that still fits one round of the chip: less helper work beside the pivot chain
+        const int below = T - 8 * (k + 1);
+        static bool attr1 = false;
+        if (!attr1) { constexpr int ldsw = (int)dense_panel_lds<8, 1>(); (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw); attr1 = true; }
+        constexpr size_t lds = dense_panel_lds<8, 1>();
+        hipLaunchKernelGGL((dense_panel_kernel<8, 1>), dim3((unsigned)below), dim3(BCR_T), lds, st, a);
+    } else if (wide) {
         const int below = T - 8 * (k + 1), nch = below > 0 ? (below + 1) / 2 : 1;
         static bool attr = false;
         if (!attr) { constexpr int ldsw = (int)dense_panel_lds<8, 2>(); (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw); attr = true; }
@@ -832,6 +841,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     geom.ws = ws.p;
     panel_lds = sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS);
     back_lds = sizeof(double) * ((size_t)RXT * 16 + NT * 64 + 2 * NT * 16 + (size_t)NO * 256 + 256 + 16);
+    { const char* e = getenv("NLLS_BCR_CHROWS_SLOTS"); chrows_slots = e ? atoi(e) : 256; }
     launches = 1; for (auto& lv : levels) launches += 2 + (lv.nupd > 0);
     {   // matrix-core instructions per solve (2048 flop each): panel kernel per workgroup + update kernel per job
         mfma_issued = 0;
@@ -858,9 +868,13 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
 
 template <int NT>
 static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status, double relfloor) {
-    BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status, relfloor};
-    if (relfloor > 0.0) hipLaunchKernelGGL(bcr_panel_kernel<true>, dim3((unsigned)(bcr_nchunks(NT) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
-    else hipLaunchKernelGGL(bcr_panel_kernel<false>, dim3((unsigned)(bcr_nchunks(NT) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
+    // X rows per workgroup: as few as still fit ONE round of the chip (every workgroup factors D_i beside its rows; the fewer rows, the less
+    // helper work stands beside the pivot chain that sets the pace): 3 when the level is wide, 1 at the narrow levels near the root
+    int chrows = BCR_CH;
+    for (int c2 = 1; c2 < BCR_CH; ++c2) if (bcr_nchunks(NT, c2) * lv.nelim <= S.chrows_slots) { chrows = c2; break; }
+    BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status, relfloor, chrows};
+    if (relfloor > 0.0) hipLaunchKernelGGL(bcr_panel_kernel<true>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
+    else hipLaunchKernelGGL(bcr_panel_kernel<false>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     if (lv.nupd > 0) hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd);
 }
 template <int NT>

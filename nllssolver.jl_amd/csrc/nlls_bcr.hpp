@@ -32,6 +32,7 @@ struct BcrSolver {
     DevBuf<double> ws; DevBuf<BcrElim> d_elim; DevBuf<BcrUpd> d_upd;
     BcrGeom geom{};
     size_t panel_lds = 0, back_lds = 0;
+    int chrows_slots = 256;                       // a level's panel launch uses fewer X rows per workgroup while its workgroups still fit this many CUs (NLLS_BCR_CHROWS_SLOTS=0: always three)
     int launches = 0;
     int64_t mfma_issued = 0;                      // v_mfma_f64_16x16x4_f64 instructions one solve issues (all workgroups, redundant factorisations included)
 
