@@ -234,6 +234,8 @@ BCR_DEV BcrElim bcr_job(const BcrChain& c, int e) {
 }
 constexpr int BCR_CH = 3;                                     // X rows (16-row tiles) per workgroup
 __host__ __device__ constexpr int bcr_nchunks(int NT, int chrows = BCR_CH) { return (2 * NT + 1 + chrows - 1) / chrows; }
+// X rows per workgroup of a level's panel launch: as few as still fit `slots` workgroups (one round of the chip), else BCR_CH
+constexpr int bcr_level_chrows(int NT, int nelim, int slots) { for (int c2 = 1; c2 < BCR_CH; ++c2) if (bcr_nchunks(NT, c2) * nelim <= slots) return c2; return BCR_CH; }
 
 // The X rows of an eliminated block -- NT tile rows of the left neighbour (A_il'), NT of the right one (A_ri), one of border /
 // rhs rows -- are dealt over bcr_nchunks(NT) workgroups, three tile rows each; every one of them factors D_i (identical
@@ -845,10 +847,11 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     launches = 1; for (auto& lv : levels) launches += 2 + (lv.nupd > 0);
     {   // matrix-core instructions per solve (2048 flop each): panel kernel per workgroup + update kernel per job
         mfma_issued = 0;
-        for (size_t e = 0; e < elims.size(); ++e) {
+        for (const BcrLevel& lv : levels) for (size_t e = lv.elim_off; e < lv.elim_off + (size_t)lv.nelim; ++e) {
             const BcrElim& el = elims[e];
-            for (int ch = 0; ch < bcr_nchunks(NT); ++ch) {
-                int RX = 0; for (int s2 = 0; s2 < BCR_CH; ++s2) { const int Rg = BCR_CH * ch + s2; if (Rg <= 2 * NT && (Rg < NT ? el.l >= 0 : (Rg < 2 * NT ? el.r >= 0 : true))) ++RX; }
+            const int chr = bcr_level_chrows(NT, lv.nelim, chrows_slots);      // (the X rows per workgroup of this level's launch: fewer rows, more redundant factorisations)
+            for (int ch = 0; ch < bcr_nchunks(NT, chr); ++ch) {
+                int RX = 0; for (int s2 = 0; s2 < chr; ++s2) { const int Rg = chr * ch + s2; if (Rg <= 2 * NT && (Rg < NT ? el.l >= 0 : (Rg < 2 * NT ? el.r >= 0 : true))) ++RX; }
                 if (!RX) continue;
                 int64_t m = 0;
                 for (int J = 0; J < NT; ++J) {
@@ -870,8 +873,7 @@ template <int NT>
 static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status, double relfloor) {
     // X rows per workgroup: as few as still fit ONE round of the chip (every workgroup factors D_i beside its rows; the fewer rows, the less
     // helper work stands beside the pivot chain that sets the pace): 3 when the level is wide, 1 at the narrow levels near the root
-    int chrows = BCR_CH;
-    for (int c2 = 1; c2 < BCR_CH; ++c2) if (bcr_nchunks(NT, c2) * lv.nelim <= S.chrows_slots) { chrows = c2; break; }
+    const int chrows = bcr_level_chrows(NT, lv.nelim, S.chrows_slots);
     BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status, relfloor, chrows};
     if (relfloor > 0.0) hipLaunchKernelGGL(bcr_panel_kernel<true>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     else hipLaunchKernelGGL(bcr_panel_kernel<false>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
