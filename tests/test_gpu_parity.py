@@ -341,10 +341,11 @@ def test_randomized_tiny_dense_ba(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"NLLS_DENSE_T64": "1"}, {"NLLS_DENSE_T128_MIN": "1"}, {"NLLS_ELIM_TILED": "1"}])
+@pytest.mark.parametrize("env", [{"NLLS_DENSE_T64": "1"}, {"NLLS_DENSE_T128_MIN": "1"}, {"NLLS_ELIM_TILED": "1"}, {"NLLS_BCR_CHROWS_SLOTS": "0"}])
 def test_ab_switches_select_paths_that_still_match_the_oracle(env, monkeypatch):
     """The environment switches read by nlls_create (the register-tiled elimination instead of the matrix-core one, the
-    64 x 64-tile dense update instead of the 128 x 128 one, the 128 x 128 one from the first pass on) select kernels no default run reaches:
+    64 x 64-tile dense update instead of the 128 x 128 one, the 128 x 128 one from the first pass on, three X rows per panel workgroup at every
+    level of the block cyclic reduction) select kernels or launch shapes no default run of this size reaches:
     the same parity as every other path -- band mode and the dense reduced solve (NLLS_FLAG_NO_BAND) of a camera chain, 2100 reduced dof."""
     for k, v in env.items(): monkeypatch.setenv(k, v)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(350, 7000, 10.0 / 350, seed=77, robust=N.HuberKernel(0.02)), 1e-3, 1e-3)
