@@ -691,6 +691,15 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) mx[R][q] = Mxg[(size_t)R * NT * 256 + (gq + 4 * q) * 16];
     }
+    // the unknowns of the neighbours and of the border that this block's rows multiply: requested NOW, beside the factor's tiles (one memory
+    // round trip per level instead of two; the root forms the border unknowns itself first and takes the loop below)
+    double xpre = 0.0;
+    if (!a.root && tid < RXT * 16) {
+        const int R = tid >> 4, q = tid & 15;
+        if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) xpre = a.xr[row]; } }
+        else if (R < 2 * NT) { if (job.r >= 0) { const int row = b * job.r + 16 * (R - NT) + q; if (row < g.n_band) xpre = a.xr[row]; } }
+        else xpre = q < nbd ? g.ws[g.oxb + q] : (q == nbd ? -1.0 : 0.0);
+    }
     {   // the block's own triangle: global -> registers -> LDS, every load in flight at once
         constexpr int MQ = (NO * 256 + NTH - 1) / NTH;
         const double* Mdg = g.ws + g.oMd + (size_t)job.i * NO * 256;
@@ -720,7 +729,8 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
         }
     } else if (tid < nbd) xb[tid] = g.ws[g.oxb + tid];
     __syncthreads();
-    for (int t = tid; t < RXT * 16; t += NTH) {
+    if (!a.root) { if (tid < RXT * 16) xs[tid] = xpre; }
+    else for (int t = tid; t < RXT * 16; t += NTH) {
         const int R = t >> 4, q = t & 15; double v = 0.0;
         if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) v = a.xr[row]; } }
         else if (R < 2 * NT) { if (job.r >= 0) { const int row = b * job.r + 16 * (R - NT) + q; if (row < g.n_band) v = a.xr[row]; } }
@@ -740,9 +750,11 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
     __syncthreads();
     if (tid < NT * 16) { const int J = tid >> 4, cc = tid & 15; tt[tid] = -((red[(J * 4 + 0) * 16 + cc] + red[(J * 4 + 1) * 16 + cc]) + (red[(J * 4 + 2) * 16 + cc] + red[(J * 4 + 3) * 16 + cc])); }
     __syncthreads();
-    // the block's own triangle: x_J = t_J - sum_{K > J} M_KJ' x_K, J = NT-1 .. 0 (wave 0; one barrier per step)
+    // the block's own triangle: x_J = t_J - sum_{K > J} M_KJ' x_K, J = NT-1 .. 0: wave 0 alone (the others retire: the barrier of each step
+    // then only orders this wave's own LDS traffic)
+    if (wave != 0) return;
     for (int J = NT - 1; J >= 0; --J) {
-        if (wave == 0) {
+        {
             double s = 0.0;
             for (int K = J + 1; K < NT; ++K) {
                 const double* M = Mdl + (K * (K - 1) / 2 + J) * 256 + c;
