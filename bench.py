@@ -53,6 +53,29 @@ def algorithmic_bytes_per_sweep(nobs, var_storage, nnz_data, ndof, M=2, ndeps=2)
     return nobs * (8 * M + 8 * ndeps) + 8 * var_storage + 8 * (nnz_data + ndof)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes of this file, one rank each (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, exactly what torch.distributed.run would set), started BEFORE this process has touched the GPU or
+    imported torch -- a process that has initialised the GPU must never exec or be replaced.  Rank 0's JSON line is relayed; any child
+    that fails makes this process fail."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode()); sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +89,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     # stdout carries exactly ONE line, the JSON result: whatever libraries print there meanwhile (RCCL writes its version banner to stdout
     # at the first collective) is sent to stderr, and stdout is restored for the result
@@ -215,11 +240,13 @@ def main():
                                      1: "dense blocked LDL' (MFMA trailing update)", 0: "one-wave dense solve"}[mode],
                           "reduced_dof": n, "bandwidth": bw, "us": round(1e3 * reduced_ms, 1),
                           "useful_flops": useful, "useful_flops_formula": "n * bw^2" if mode == 2 else "n^3 / 3",
+                          # `achieved` / `frac` count USEFUL flops only; what the matrix cores are actually issued (tile padding, the diagonal
+                          # block factored redundantly by every workgroup of a panel launch, inv(L)) is kept beside them as issued_*
+                          "achieved": round(useful / (reduced_ms * 1e-3) / 1e12, 4),
+                          "frac": round(useful / (reduced_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5),
                           "issued_mfma_flops": issued,
-                          "achieved": round((issued if issued else useful) / (reduced_ms * 1e-3) / 1e12, 4),
-                          "useful_achieved": round(useful / (reduced_ms * 1e-3) / 1e12, 4),
-                          "frac": round((issued if issued else useful) / (reduced_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5),
-                          "useful_frac": round(useful / (reduced_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5),
+                          "issued_achieved": round(issued / (reduced_ms * 1e-3) / 1e12, 4) if issued else None,
+                          "issued_frac": round(issued / (reduced_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5) if issued else None,
                           "levels": solve_stats.get("bcr_levels"), "launches": solve_stats.get("bcr_launches"),
                           "note": "a banded LDL' is a chain of dependent pivots: latency-, not MFMA-bound -- the fraction says how far, not how well tuned"
                                   if mode == 2 else None}

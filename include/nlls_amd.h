@@ -209,7 +209,11 @@ int  nlls_solve(nlls_ctx* ctx, double* x_out);
 /* diagnostics of the last solve: [0] factorisation status (0 ok), [1] band factor shader cycles,
  * [2] band backward-pass cycles, [3] solve mode, [4] number of elimination supernodes, [5] bandwidth,
  * [6] v_mfma_f64_16x16x4_f64 instructions one reduced solve issues (block cyclic reduction; 2048 flop each), [7] its launches,
- * [8] its levels, [9] banded dof of the reduced system */
+ * [8] its levels, [9] banded dof of the reduced system, [10] pivots the last UNDAMPED band solve dropped: with lambda == 0 (Newton,
+ * dogleg's Gauss-Newton step) on a gauge-free problem the reduced system is singular, and the block-cyclic-reduction solver treats a
+ * pivot that has lost eleven orders of magnitude against its original diagonal entry as infinite (that unknown gets no step) instead
+ * of dividing rounding by rounding; NaN pivots are never dropped (they raise NLLS_ERR_NOT_SPD).  The chain and dense solvers
+ * (NLLS_FLAG_NO_BCR, NLLS_FLAG_NO_BAND) have no such floor. */
 int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
 int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
 int  nlls_get_step(nlls_ctx* ctx, double* x_out);

@@ -109,7 +109,7 @@ BCR_DEV void bcr_factor(const double* T0, bool from_regs, const bdouble4_t Ain, 
         const int q = k & 3, r = k >> 2;
         const double w = A[r], bt = Bt[r];
         double dk = bcr_readlane(w, 16 * q + k);
-        if constexpr (FLOOR) { if (!(fabs(dk) > bcr_readlane(fl, k))) dk = 1e300; }      // a vanished pivot: as if infinite (its unknown comes out 0)
+        if constexpr (FLOOR) { if (fabs(dk) <= bcr_readlane(fl, k)) dk = 1e300; }      // a vanished pivot: as if infinite (its unknown comes out 0); a NaN pivot is left alone and reported
         double rdk = __builtin_amdgcn_rcp(dk);
         const bool rowq = lk == q;
         const double am = (rowq && li > k) ? w : 0.0;
@@ -122,7 +122,9 @@ BCR_DEV void bcr_factor(const double* T0, bool from_regs, const bdouble4_t Ain, 
         double dsel = A[0];
 #pragma unroll
         for (int r = 1; r < 4; ++r) dsel = (li >> 2) == r ? A[r] : dsel;
-        if constexpr (FLOOR) { if (!(fabs(dsel) > fl)) dsel = 1e300; }
+        bool dropped = false;
+        if constexpr (FLOOR) { if (fabs(dsel) <= fl) { dsel = 1e300; dropped = true; } }
+        if constexpr (FLOOR) { if (report) { const unsigned long long m = __ballot(dropped && (li & 3) == lk); if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(status + 4, __popcll(m)); } }   // status[4]: pivots dropped by the floor (nlls_get_solve_stats)
         if ((li & 3) == lk) {
             double rd = __builtin_amdgcn_rcp(dsel); rd = fma(fma(-dsel, rd, 1.0), rd, rd); rd = fma(fma(-dsel, rd, 1.0), rd, rd);
             dd[li] = dsel; dd[16 + li] = rd;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     const bool helper = wave != 0 && wave != 4;
 #ifdef BCR_STAMPS
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(); int stn = 0;
-#define BCR_STAMP() do { if (blockIdx.x == gridDim.x - 1 && lane == 0 && wave <= 1 && stn < 20) a.status[16 + 20 * wave + stn++] = (int)(__builtin_amdgcn_s_memtime() - st0); } while (0)
+#define BCR_STAMP() do { if (blockIdx.x == gridDim.x - 1 && lane == 0 && wave <= 1 && stn < 20) a.status[16 + 20 * wave + stn++] = (int)(__builtin_amdgcn_s_memtime() - st0); } while (0)   // (status holds 96 ints: slots 16..55 and 56..71 are the instrumented build's)
 #else
 #define BCR_STAMP() do {} while (0)
 #endif

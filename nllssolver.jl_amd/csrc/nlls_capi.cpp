@@ -237,7 +237,9 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         const auto t0 = std::chrono::steady_clock::now(); bool seen = false;
         for (uint64_t spin = 0;; ++spin) {
             if (hs[32] == seq && hs[33] == seq) { seen = true; break; }
-            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            // (a trial of the problems this path is built for ends within a millisecond; a long one sleeps in the synchronisation instead of
+            //  burning a core)
+            if ((spin & 255) == 255) { if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1500)) break; __builtin_ia32_pause(); }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -311,6 +313,7 @@ int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices
         const Group& G = ctx->groups[cgroup[e]];
         if (cindex[e] < 0 || cindex[e] >= G.ncost || cslot[e] < 0 || cslot[e] >= G.ndeps) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: bad cost index or slot");
         if (G.adaptive && cslot[e] == 0) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles: the adaptive kernel variable cannot be optimised on its own");
+        if (is_dyn_kind(G.res_kind)) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles: dynamic-size cost blocks are not handled by the per-variable kernel");
         cidx[e] = (uint32_t)cindex[e];
     }
     std::vector<unsigned char> gbuf(singles_group_size() * ctx->groups.size());
@@ -331,9 +334,10 @@ int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
     int32_t status[16] = {0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    const int64_t vals[10] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
-                              ctx->bcr.ready ? ctx->bcr.mfma_issued : 0, ctx->bcr.ready ? ctx->bcr.launches : 0, ctx->bcr.ready ? (int64_t)ctx->bcr.levels.size() : 0, ctx->n_band};
-    for (int i = 0; i < n && i < 10; ++i) out[i] = vals[i];
+    const int64_t vals[11] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
+                              ctx->bcr.ready ? ctx->bcr.mfma_issued : 0, ctx->bcr.ready ? ctx->bcr.launches : 0, ctx->bcr.ready ? (int64_t)ctx->bcr.levels.size() : 0, ctx->n_band,
+                              status[4] /* pivots the floor of the last undamped band solve dropped */};
+    for (int i = 0; i < n && i < 11; ++i) out[i] = vals[i];
     return NLLS_OK;
 }
 int nlls_set_step(nlls_ctx* ctx, const double* x) {
@@ -503,10 +507,19 @@ int nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, 
 int nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
     NEED_GRAD();
     if (ctx->nred == 0 || ctx->elim_slab) { if (ms_avg) *ms_avg = 0.f; return NLLS_OK; }   // (slab + gather assembly: the tiles are consumed in place)
-    // assemble [S | s] once, then time the factorisation + backward pass of the reduced system alone (it reads S, never writes it)
-    TRY(enqueue_solve_local(ctx));
-    const int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_reduced_solve(c); });
+    if (ctx->solve_mode == SOLVE_BAND && ctx->bcr.ready) {
+        // block cyclic reduction copies [S | s] into its own tiles: assemble once, then time the factorisation + backward pass alone
+        TRY(enqueue_solve_local(ctx));
+        const int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_reduced_solve(c); });
+        ctx->S_zeroed = false; ctx->solved = false;
+        return rc;
+    }
+    // the dense, one-wave and chain solvers factor S IN PLACE: every repetition assembles it again, and the assembly alone is timed and subtracted
+    float ms_both = 0.f, ms_asm = 0.f;
+    int rc = time_loop(ctx, reps, &ms_both, [](nlls_ctx* c) { c->S_zeroed = false; int r = enqueue_solve_local(c); return r != NLLS_OK ? r : enqueue_reduced_solve(c); });
+    if (rc == NLLS_OK) rc = time_loop(ctx, reps, &ms_asm, [](nlls_ctx* c) { c->S_zeroed = false; return enqueue_solve_local(c); });
     ctx->S_zeroed = false; ctx->solved = false;
+    if (ms_avg) *ms_avg = ms_both > ms_asm ? ms_both - ms_asm : 0.f;
     return rc;
 }
 

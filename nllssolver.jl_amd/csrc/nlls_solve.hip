@@ -60,7 +60,7 @@ __global__ void schur_init_kernel(SLayout L, double* __restrict__ s, const doubl
 // the padding of the dense layout), the rest copy one reduced-reduced block each
 __global__ __launch_bounds__(256) void schur_prepare_kernel(SLayout L, double* __restrict__ s, const double* __restrict__ b, const uint32_t* __restrict__ red_boff,
                                                             const double* __restrict__ A, const SchurCopy* __restrict__ copies, double lambda, int ninit, int* __restrict__ status) {
-    if (blockIdx.x == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 5) status[threadIdx.x] = 0;
     if ((int)blockIdx.x < ninit) {
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < L.n) { *L.rhs(s, i) = b[red_boff[i]]; return; }
@@ -2214,6 +2214,7 @@ __device__ __forceinline__ void gather_store(const BcrGeom& g, int r, int c, dou
     if (kr == kc) {
         double* t = g.ws + g.oD + ((size_t)kr * (NT * (NT + 1) / 2) + I * (I + 1) / 2 + K) * 256;
         t[(r & 15) * 16 + (c & 15)] = v; if (I == K) t[(c & 15) * 16 + (r & 15)] = v;
+        if (r == c) g.ws[g.odg + r] = fabs(v);                // the original diagonal (pivot floor of undamped solves), as bcr_convert_kernel records it
     } else g.ws[g.oA + ((size_t)kr * NT * NT + I * NT + K) * 256 + (r & 15) * 16 + (c & 15)] = v;     // kr == kc + 1: the block size covers the bandwidth
 }
 __global__ __launch_bounds__(256) void schur_gather_kernel(GatherArgs a) {
@@ -2365,7 +2366,7 @@ int enqueue_solve_local(nlls_ctx* c) {
             if (nwid > 0) hipLaunchKernelGGL((schur_elim_wave_kernel<DV, 2, 3>), dim3((unsigned)nwid), dim3(64 * ELIM_NW), 0, c->stream, c->A.p, c->b.p, \
                 c->d_elim_ptr.p, c->d_elim_nbr.p, c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_group.p, c->d_slab_groups.p + n60 + nnar, c->Cinv.p, c->slab.p, c->d_slab_off.p + n60 + nnar); } while (0)
         // (the status reset rides in the gather launch; schur_cinv_kernel may flag a bad pivot before it: reset first)
-        HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 4, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));
         if (c->fast_dv == 3) LAUNCH_SLAB(3); else if (c->fast_dv == 2) LAUNCH_SLAB(2); else LAUNCH_SLAB(1);
 #undef LAUNCH_SLAB
         GatherArgs ga{c->d_gjobs.p, c->d_gcons.p, c->n_gjobs, c->slab.p, c->A.p, c->b.p, c->Cinv.p, c->fast_dv, c->lambda, c->bcr.geom, c->d_status.p};
@@ -2374,7 +2375,7 @@ int enqueue_solve_local(nlls_ctx* c) {
         return NLLS_OK;
     }
     const bool one_prepare = lead && c->info.is_sparse && c->ncopy > 0;      // status reset, s and the reduced-reduced blocks in one launch
-    if (!one_prepare) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 4, c->stream));
+    if (!one_prepare) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));
     if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
     c->S_zeroed = false;
     if (c->nranks > 1) HIPCHK(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->info.ndof, c->stream));
@@ -2428,7 +2429,10 @@ int enqueue_reduced_solve(nlls_ctx* c) {
     } else if (band && c->bcr.ready) {
         // an UNDAMPED step (Newton, dogleg's Gauss-Newton step) of a gauge-free problem: S is singular -- vanished pivots are dropped
         // (src/iterators.jl:47-115 asks for the Gauss-Newton step; any exact factorisation of a singular system returns rounding / rounding)
-        const double pivot_floor = (c->lambda == 0.0 && !c->elim_slab) ? 1e-11 : 0.0;
+        // Rule: a pivot that has lost eleven orders of magnitude against its original diagonal entry is dropped (its unknown gets no step) and
+        // COUNTED (status[4] -> nlls_get_solve_stats()[10]); a NaN pivot is not touched and is reported like any bad pivot.  Both assemblies
+        // of the tiles (atomics, and the deterministic slab + gather) take it; the chain and dense solvers have no floor.
+        const double pivot_floor = c->lambda == 0.0 ? 1e-11 : 0.0;
         if (c->bcr.enqueue(c->stream, c->elim_slab ? (const double*)nullptr : c->S.p, c->s_ptr(), c->d_status.p, pivot_floor) != NLLS_OK) return herr(c, hipGetLastError(), "block cyclic reduction launch");
     } else if (band) {
         BandArgs a{}; a.Sb = c->S.p; a.Lb = c->Lwork.p; a.xr = c->s_ptr(); a.n_band = L.n_band; a.bw = L.bw; a.nbd = L.nbd; a.H = L.H; a.CH = c->band_CH; a.status = c->d_status.p;

@@ -606,7 +606,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         // the blocked factor kernel exports tiles: (NBW + 1) 16x16 tiles + the border/rhs rows per 16-column block
         const size_t nbw = ((size_t)bw + 15) / 16, tsz = (((size_t)c->n_band + 15) / 16) * ((nbw + 1) * 256 + (size_t)(c->nbd + 1) * 16) + 256 + 2 * (size_t)(c->nbd + 1) * (c->nbd + 1) + 2 * (256 * nbw * nbw + 16 * nbw)
                                                     + (16 * nbw) * (16 * nbw + 1) + 8 + (nbw + 1) * ((nbw + 1) * 256 + 16) + 256;   // separator: band system + its factor tiles
-        if (hipSuccess != c->S.alloc(sz + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(std::max(sz, tsz)) || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "band system alloc");
+        if (hipSuccess != c->S.alloc(sz + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(std::max(sz, tsz)) || hipSuccess != c->d_status.alloc(96)) return fail(c, NLLS_ERR_HIP, "band system alloc");
         // block cyclic reduction (nlls_bcr.hip) is the band solver whenever it supports the shape; the chain kernels stay as fallbacks
         if (!(flags & NLLS_FLAG_NO_BCR) && BcrSolver::supports(c->n_band, (int)bw, c->nbd)) {
             std::string e; const int rc = c->bcr.build(c->n_band, (int)bw, c->nbd, c->band_H, &e);
@@ -685,7 +685,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         if (npad > 46000) return fail(c, NLLS_ERR_UNSUPPORTED, "reduced system too large for the dense solver (" + std::to_string(n) + " dof, not banded)");
         c->s_elems = (size_t)std::max<int64_t>(npad * npad, 1);
         if (hipSuccess != c->S.alloc(c->s_elems + (size_t)npad + 64) ||
-            hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 128 + npad + (npad / 16) * 256 + 256 + (npad / 64 + 1) * 128 * 128, 1))   /* W of a 128-column panel (or of two 64-column ones) | acc | inverted diagonal tiles | factored diagonal blocks (a slot per 64-block) */ || hipSuccess != c->d_status.alloc(64)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
+            hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 128 + npad + (npad / 16) * 256 + 256 + (npad / 64 + 1) * 128 * 128, 1))   /* W of a 128-column panel (or of two 64-column ones) | acc | inverted diagonal tiles | factored diagonal blocks (a slot per 64-block) */ || hipSuccess != c->d_status.alloc(96)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
     }
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
     c->info.solve_mode = c->solve_mode; c->info.bandwidth = c->bw; c->info.nborder_dof = c->nbd;

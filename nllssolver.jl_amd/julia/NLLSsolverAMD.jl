@@ -74,6 +74,7 @@ mutable struct MultiVariateLSgpu
     kinds::Vector{Tuple{Int32, Int32}}
     packed::Vector{Float64}
     resident::Bool              # the device's NLLS_VARS_CURRENT holds problem.variables (the device-resident LM loop keeps it so)
+    havebest::Bool              # NLLS_VARS_BEST has been written once (the reference's `length(problem.variables) == length(problem.varbest)`)
 end
 
 "makesymmvls replacement (src/linearsystem.jl:91-124); returns `nothing` to decline (caller keeps the CPU system)."
@@ -104,7 +105,7 @@ function makesymmvls_gpu(problem::NLLSProblem, unfixed, nblocks)
     info = Ref{NllsInfo}(); check(ctx, ccall((:nlls_get_info, lib), Cint, (Ptr{Cvoid}, Ptr{NllsInfo}), ctx, info))
     ndof = Int(info[].ndof)
     boff = zeros(Int64, nb); ccall((:nlls_get_bsm_index, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), ctx, C_NULL, C_NULL, C_NULL, boff)
-    ls = MultiVariateLSgpu(ctx, blockindices, UInt.(boff), ndof, zeros(ndof), zeros(ndof), kinds, Float64[], false)
+    ls = MultiVariateLSgpu(ctx, blockindices, UInt.(boff), ndof, zeros(ndof), zeros(ndof), kinds, Float64[], false, false)
     finalizer(l -> ccall((:nlls_ctx_destroy, lib), Cint, (Ptr{Cvoid},), l.ctx), ls)
     return ls
 end
@@ -124,10 +125,11 @@ function gpucost(ls::MultiVariateLSgpu, vars::Vector)                           
     setvariables!(ls, vars, 1); c = Ref(0.0)
     check(ls.ctx, ccall((:nlls_sweep_cost, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ls.ctx, 1, c)); return c[]
 end
-# The reference's iterators call cost(problem.varnext, problem.costs) (src/iterators.jl:24,100,157,191,203), which does not
-# see the linear system.  Host-side iterators reach the device sweep through this wrapper of the cost container:
-struct GpuCosts{C}; costs::C; ls::MultiVariateLSgpu; end
-NLLSsolver.cost(vars::Vector, c::GpuCosts) = gpucost(c.ls, vars)
+# The reference's OTHER iterators (Newton, dogleg, gradient descent: src/iterators.jl:15-115,175-200) call
+# cost(problem.varnext, problem.costs) (src/iterators.jl:24,100,191,203), which does not see the linear system and cannot be redirected
+# without touching NLLSProblem (its `costs` field is concretely typed).  With this linear-system type they therefore run their gradient /
+# Hessian sweep and their solve on the device and keep the reference's own CPU cost() for the trial points -- correct, and not
+# accelerated.  `gpucost` above is the device cost sweep a maintainer would call from an iterate! method written like the LM one below.
 struct GpuHessian; ls::MultiVariateLSgpu; end                                  # what gethessgrad hands to the iterator
 function NLLSsolver.gethessgrad(ls::MultiVariateLSgpu)                          # src/linearsystem.jl:190
     check(ls.ctx, ccall((:nlls_get_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, ls.b)); return GpuHessian(ls), ls.b
@@ -209,7 +211,12 @@ swapvars!(ls, a, b) = check(ls.ctx, ccall((:nlls_swap_variables, lib), Cint, (Pt
 copyvars!(ls, dst, src) = check(ls.ctx, ccall((:nlls_copy_variables, lib), Cint, (Ptr{Cvoid}, Int32, Int32), ls.ctx, dst, src))
 NLLSsolver.updatefromnext!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = swapvars!(data.linsystem, VARS_CURRENT, VARS_NEXT)   # src/optimize.jl:207-209
 NLLSsolver.updatefrombest!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = swapvars!(data.linsystem, VARS_CURRENT, VARS_BEST)   # src/optimize.jl:211-213
-NLLSsolver.updatetobest!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = copyvars!(data.linsystem, VARS_BEST, VARS_CURRENT)     # src/optimize.jl:138-142 (deepcopy)
+# src/optimize.jl:138-142,214: a swap once varbest exists (what CURRENT then holds is stale, and updatefromnext! replaces it at once), a copy the
+# first time (the reference's deepcopy) -- nlls_lm.cpp does the same
+function NLLSsolver.updatetobest!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu})
+    ls = data.linsystem
+    if ls.havebest; swapvars!(ls, VARS_CURRENT, VARS_BEST); else; copyvars!(ls, VARS_BEST, VARS_CURRENT); ls.havebest = true; end
+end
 
 # nlls_lm_options / nlls_lm_state (include/nlls_amd.h; sizes and offsets pinned by tests/abi/abi_replay.c): the library's own outer loop
 struct LmOptions; reldcost::Float64; absdcost::Float64; dstep::Float64; maxfails::Int64; maxiters::Int64; stoptime_ns::Int64; end
