@@ -84,7 +84,10 @@ typedef struct nlls_ctx nlls_ctx;
                                        variable of length n; data = (y[n], X[n*n]); nres = n; n <= 512              test/nonsquaredcost.jl:16-26 */
 #define NLLS_COST_DYN_LINEAR     14 /* DYNAMIC-size NON-SQUARED AbstractCost: LinearCostDynamic, computecost = y'w; data = y[n]: value y'w, gradient y,
                                        Hessian 0 (src/autodiff.jl:144-159)                                          test/nonsquaredcost.jl:39-46 */
-#define NLLS_RES_KIND_COUNT      15
+#define NLLS_RES_SCALE_MIX       15 /* s * (w a + (1 - w) b) - y over a STANDALONE ZeroToInfScalar s and a standalone ZeroToOneScalar w
+                                     (src/variable.jl:18-32): vars (ZERO_TO_INF, ZERO_TO_ONE); data = (a, b, y).  No counterpart in the
+                                     reference's tests; it makes the two bounded scalar kinds reachable outside ContaminatedGaussian */
+#define NLLS_RES_KIND_COUNT      16
 
 /* ---- robust kernels: src/robust.jl:7-77 ------------------------------------------------------ */
 #define NLLS_ROBUST_NONE           0 /* NoRobust                                               */

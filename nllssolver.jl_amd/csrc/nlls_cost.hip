@@ -340,7 +340,9 @@ template <int KIND>
 static int launch_cost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
     if (G.ncost > 0) {
         int grid = (int)std::min<int64_t>((G.ncost + TPB - 1) / TPB, 2048);
-        hipLaunchKernelGGL(cost_kernel<KIND>, dim3(grid), dim3(TPB), 0, c->stream, vars, G.data.p, G.voff.p, (const uint32_t*)nullptr, G.ncost, G.rk, c->partials.p + pbase);
+        const bool shared = G.cost_list >= 0 && c->info.is_sparse;
+        const double* data = shared ? G.lists[G.cost_list].data.p : G.data.p; const uint32_t* voff = shared ? G.lists[G.cost_list].voff.p : G.voff.p;
+        hipLaunchKernelGGL(cost_kernel<KIND>, dim3(grid), dim3(TPB), 0, c->stream, vars, data, voff, (const uint32_t*)nullptr, G.ncost, G.rk, c->partials.p + pbase);
         pbase += grid;
     }
     return NLLS_OK;

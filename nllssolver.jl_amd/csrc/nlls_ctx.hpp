@@ -79,6 +79,11 @@ struct Group {
     int64_t nfixedcost = 0;
     EntryList lists[4];
     DenseList dense;
+    // the cost sweep's view of the blocks: a light entry list that holds EVERY cost of the group exactly once (all its slot's variables are
+    // free) serves it instead of the cost-order arrays -- the same 24 bytes per block the next gradient sweep streams, so that inside the LM
+    // loop (cost sweep of the accepted trial, then the gradient sweep) they are read from the memory-side cache, and the cost-order arrays
+    // (another 24 bytes per block) stay out of the loop's working set.  -1: none (cost order).  The sum is taken in list order: a fixed order.
+    int cost_list = -1;
 };
 
 // ---- Schur / solve structures ---------------------------------------------------------------------

@@ -335,6 +335,14 @@ template <> struct Res<NLLS_COST_LINEAR3> {   // test/nonsquaredcost.jl:28-37: a
         const T* w = sv[0]; r[0] = w[0] * data[0] + w[1] * data[1] + w[2] * data[2];
     }
 };
+template <> struct Res<NLLS_RES_SCALE_MIX> {   // standalone bounded scalars (src/variable.jl:18-32): s * (w a + (1 - w) b) - y
+    static constexpr int NDEPS = 2, M = 1, NDATA = 3, ADAPT = 0;
+    static constexpr int SK[4] = {NLLS_VAR_ZERO_TO_INF, NLLS_VAR_ZERO_TO_ONE, 0, 0};
+    static constexpr int SD[4] = {1, 1, 0, 0};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) {
+        const T s = sv[0][0], w = sv[1][0]; r[0] = s * (w * data[0] + (1.0 - w) * data[1]) - data[2];
+    }
+};
 // kinds whose block is an AbstractCost (value / gradient / Hessian of computecost itself, src/autodiff.jl:144-159), not half a squared residual norm
 template <int KIND> constexpr bool is_cost_kind = (KIND == NLLS_COST_LINEAR3);
 

@@ -328,6 +328,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
             npartials += E.nlight + E.nheavy;
             std::vector<int64_t>().swap(L.cost);
         }
+        G.cost_list = -1;       // (see Group::cost_list)
+        for (int s2 = 0; s2 < d.ndeps; ++s2) { const EntryList& E = G.lists[s2]; if (E.n == G.ncost && G.ncost > 0 && E.nlight > 0 && E.nheavy == 0) { G.cost_list = s2; break; } }
     }
     std::vector<int64_t> red_off; std::vector<uint32_t> red_len, red_dst, red_which;   // stage-0 reduce ranges
     if (sparse && nranks > 1) {

@@ -27,6 +27,7 @@ RES_DYN_LINEAR = 11       # test/dynamicvars.jl:3-11: X'w - y over one dynamic-s
 RES_DYN_NORM = 12         # test/dynamicvars.jl:13-21: w (nres = n); no data
 RES_DYN_LINEARSQ = 13     # test/nonsquaredcost.jl:16-26: X*w - y with a square X over a dynamic-size variable; data = (y[n], X[n*n] column-major)
 COST_DYN_LINEAR = 14      # test/nonsquaredcost.jl:39-46: non-squared cost y'w over a dynamic-size variable; data = y[n]
+RES_SCALE_MIX = 15        # s (w a + (1 - w) b) - y over a standalone ZeroToInfScalar and a standalone ZeroToOneScalar (src/variable.jl:18-32)
 DYN_KINDS = (RES_DYN_LINEAR, RES_DYN_NORM, RES_DYN_LINEARSQ, COST_DYN_LINEAR)
 
 # robust kernels: src/robust.jl:7-77
@@ -52,6 +53,7 @@ RES_TABLE = {
     RES_DYN_NORM: (1, -1, 0, False, ((VAR_DYNAMIC, 0),)),      # nres = n
     RES_DYN_LINEARSQ: (1, -1, -2, False, ((VAR_DYNAMIC, 0),)),  # nres = n, ndata = n + n*n
     COST_DYN_LINEAR: (1, 0, -3, False, ((VAR_DYNAMIC, 0),)),   # ndata = n
+    RES_SCALE_MIX: (2, 1, 3, False, ((VAR_ZERO_TO_INF, 1), (VAR_ZERO_TO_ONE, 1))),
 }
 
 

@@ -42,6 +42,7 @@ static const res_desc RES[NLLS_RES_KIND_COUNT] = {
     /* DYN_NORM        */ {1, -1, 0, 0, {NLLS_VAR_DYNAMIC}, {0}},    /* nres = n */
     /* DYN_LINEARSQ    */ {1, -1, -1, 0, {NLLS_VAR_DYNAMIC}, {0}},   /* nres = n, ndata = n + n*n */
     /* COST_DYN_LINEAR */ {1, 0, -1, 0, {NLLS_VAR_DYNAMIC}, {0}},    /* an AbstractCost; ndata = n */
+    /* SCALE_MIX       */ {2, 1, 3, 0, {NLLS_VAR_ZERO_TO_INF, NLLS_VAR_ZERO_TO_ONE}, {1, 1}},
 };
 #define IS_DYN_KIND(k) ((k) >= NLLS_RES_DYN_LINEAR && (k) <= NLLS_COST_DYN_LINEAR)
 #define IS_COST_KIND(k) ((k) == NLLS_COST_LINEAR3)
@@ -173,6 +174,10 @@ static void res_eval(int kind, const double* data, jet* const* sv, jet* r, int n
             Y[i] = jet_add(jet_add(jet_add(jet_mul(P[i], X[0], n), jet_mul(P[i + 3], X[1], n), n), jet_mul(P[i + 6], X[2], n), n), P[9 + i], n);
         r[0] = jet_addc(jet_div(Y[0], Y[2], n), -data[0], n);
         r[1] = jet_addc(jet_div(Y[1], Y[2], n), -data[1], n); break; }
+    case NLLS_RES_SCALE_MIX: { /* s * (w a + (1 - w) b) - y over a ZeroToInfScalar and a ZeroToOneScalar (src/variable.jl:18-32) */
+        jet s = sv[0][0], w = sv[1][0];
+        jet mix = jet_add(jet_scale(w, data[0], n), jet_scale(jet_addc(jet_neg(w, n), 1.0, n), data[1], n), n);
+        r[0] = jet_addc(jet_mul(s, mix, n), -data[2], n); break; }
     case NLLS_RES_LINEAR3: { /* test/nonsquaredcost.jl:13: X * w - y, data = (y[3], X[9] column-major) */
         const jet* w = sv[0];
         for (int i = 0; i < 3; ++i)

@@ -72,6 +72,20 @@ def check_problem(problem, unfixed=None, flags=0, lam_scale=1e-6, expect_sparse=
     return info
 
 
+@pytest.mark.parametrize("shared,robust", [(1, None), (3, None), (40, N.HuberKernel(0.05))])
+def test_standalone_bounded_scalar_variables(shared, robust):
+    """NLLS_RES_SCALE_MIX: ZeroToInfScalar and ZeroToOneScalar as variables of their own (src/variable.jl:18-32) -- dual seeding through
+    update(), retraction, sweep, solve against the oracle; then the whole LM loop against the oracle's."""
+    from tests.test_oracle_pins import scale_mix_problem
+    p = scale_mix_problem(5 + shared, n=64, noise=1e-3, shared=shared, robust=robust)
+    check_problem(p, lam_scale=1e-4)
+    q = scale_mix_problem(5 + shared, n=64, noise=1e-3, shared=shared, robust=robust)
+    op = oracle_problem(q); ro = op.optimize(iterator=1)
+    rg = N.optimize(q)
+    assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-9) and np.allclose(q.variables, op.get_variables(), rtol=1e-6)
+    assert np.all(q.variables[0::2] > 0) and np.all((q.variables[1::2] > 0) & (q.variables[1::2] < 1))
+
+
 def test_ba_sparse_small():          # test/optimizeba.jl:71 shape (10 x 50 @ 0.3 -> sparse path)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 50, 0.3, seed=1), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)

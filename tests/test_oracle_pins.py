@@ -331,6 +331,41 @@ def test_so3_kinds_against_finite_differences(adaptive):
         assert np.allclose(H, H.T, rtol=1e-12, atol=1e-14)
 
 
+def scale_mix_problem(seed, n=200, s_true=2.5, w_true=0.3, start=(1.0, 0.5), noise=0.0, shared=1, robust=None):
+    """`shared` pairs of standalone bounded scalars (a ZeroToInfScalar s, a ZeroToOneScalar w: src/variable.jl:18-32) under
+    NLLS_RES_SCALE_MIX blocks  s (w a + (1 - w) b) - y  whose measurements come from (s_true, w_true)."""
+    rng = np.random.default_rng(seed)
+    p = N.NLLSProblem()
+    vi = np.zeros((n * shared, 2), np.int64); da = np.zeros((n * shared, 3))
+    for q in range(shared):
+        si = p.addvariable([start[0] * (1.0 + 0.1 * q)], K.VAR_ZERO_TO_INF); wi = p.addvariable([start[1]], K.VAR_ZERO_TO_ONE)
+        a, b = rng.uniform(0.5, 2.0, n), rng.uniform(-1.0, 1.0, n)
+        vi[q * n:(q + 1) * n] = (si, wi)
+        da[q * n:(q + 1) * n] = np.stack([a, b, (s_true + 0.2 * q) * (w_true * a + (1 - w_true) * b) + noise * rng.standard_normal(n)], axis=1)
+    p.addcosts(K.RES_SCALE_MIX, vi, da, robust)
+    return p
+
+
+def test_standalone_bounded_scalars_finite_differences_and_recovery():
+    """NLLS_VAR_ZERO_TO_INF / NLLS_VAR_ZERO_TO_ONE as variables of their own (not inside ContaminatedGaussian): the oracle's Jacobian with
+    respect to the tangent of update() (src/variable.jl:22,29-32; duals seeded as src/autodiff.jl:57-61 does) against central differences
+    through the true retraction, and LM recovers the generating scale and weight of a noise-free problem."""
+    p = scale_mix_problem(11, n=40)
+    op = oracle_problem(p)
+    for ci in (0, 7, 39):
+        r, J = op.block_resjac(0, ci, 1)
+        Jfd, _ = _fd_block(op, p, 0, ci)
+        assert J.shape == (1, 2) and np.allclose(J, Jfd, rtol=1e-7, atol=1e-9), (J, Jfd)
+    res = op.optimize(iterator=1)
+    v = op.get_variables()
+    assert res.bestcost < 1e-20 and np.allclose(v, [2.5, 0.3], rtol=1e-8), (res.bestcost, v)
+    # the bounds hold along the way by construction of the retractions: a huge step keeps s > 0 and w inside (0, 1)
+    out = np.zeros(1)
+    L.oracle_var_update(K.VAR_ZERO_TO_INF, 1, P(np.array([2.0])), P(np.array([-50.0])), P(out)); assert 0.0 < out[0] < 1e-20
+    L.oracle_var_update(K.VAR_ZERO_TO_ONE, 1, P(np.array([0.5])), P(np.array([40.0])), P(out)); assert 0.5 < out[0] <= 1.0
+    L.oracle_var_update(K.VAR_ZERO_TO_ONE, 1, P(np.array([0.5])), P(np.array([-40.0])), P(out)); assert 0.0 < out[0] < 0.5
+
+
 # ---------------------------------------------------------------- test/nonsquaredcost.jl
 def _nonsquared_problem(seed):
     """test/nonsquaredcost.jl:48-58 (static halves): a 3-dof variable under LinearResidualStatic(y, X) and the NON-SQUARED
