@@ -321,8 +321,11 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     };
     double* const Mdg = g.ws + g.oLd + (size_t)job.i * (NT * (NT - 1) / 2) * 256;   // L tiles below the diagonal
     double* const Lig = g.ws + g.oLi + (size_t)job.i * NT * 256;                     // inv(L_JJ)' per tile column
-    double* const Wxg = g.ws + g.oWx + (size_t)job.i * RXT * NT * 256;
-    double* const Lxg = g.ws + g.oLx + (size_t)job.i * RXT * NT * 256;
+    // (W and L of the X rows live for one level only -- panel -> update: their slot is the block's position in the level's launch, so
+    //  that every level rewrites the same 8 MB instead of each block keeping 220 KB of its own: the solve's footprint in the memory-side
+    //  cache is what the next accumulate launch pays for)
+    double* const Wxg = g.ws + g.oWx + (size_t)(blockIdx.x / NCH) * RXT * NT * 256;
+    double* const Lxg = g.ws + g.oLx + (size_t)(blockIdx.x / NCH) * RXT * NT * 256;
     // tile-updates of block column Jp (panel Jp complete) other than the next diagonal tile, dealt over nh waves
     auto updates = [&](int Jp, int w0, int nh) {
         const int oWprev = oWp + (Jp & 1) * PR * 16 * BP, ord = odv + (Jp & 1) * 32 + 16;
@@ -789,20 +792,22 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     auto take = [&](size_t doubles) { const size_t o = off; off += (doubles + 31) & ~(size_t)31; return o; };
     geom = BcrGeom{};
     geom.oD = take((size_t)N * ND * 256); geom.oA = take((size_t)N * NT * NT * 256); geom.oBR = take((size_t)N * NT * 256);
-    geom.oWx = take((size_t)N * RXT * NT * 256); geom.oLx = take((size_t)N * RXT * NT * 256); geom.oMx = take((size_t)N * RXT * NT * 256);
+    const size_t nslot = (size_t)(N + 1) / 2;                  // blocks a level eliminates at most
+    geom.oWx = take(nslot * RXT * NT * 256); geom.oLx = take(nslot * RXT * NT * 256); geom.oMx = take((size_t)N * RXT * NT * 256);
     geom.oLd = take((size_t)N * std::max(NO, 1) * 256); geom.oLi = take((size_t)N * NT * 256);
     geom.oMd = take((size_t)N * std::max(NO, 1) * 256); geom.ocp = take((size_t)(N + 1) * 256); geom.oxb = take(32); geom.odg = take((size_t)N * 16 * NT);
     if (off >= ((size_t)1 << 32)) { if (err) *err = "block cyclic reduction workspace exceeds 32-bit tile offsets"; return NLLS_ERR_UNSUPPORTED; }
     geom.NT = NT; geom.N = N; geom.nbd = nbd; geom.n_band = n_band; geom.bw = bw; geom.H = H;
     std::vector<BcrElim> elims; std::vector<BcrUpd> upds;
     std::vector<int> active(N); for (int k = 0; k < N; ++k) active[k] = k;
-    auto wx = [&](int src, int P) { return (uint32_t)(geom.oWx + ((size_t)src * RXT + P) * NT * 256); };
-    auto lx = [&](int src, int P) { return (uint32_t)(geom.oLx + ((size_t)src * RXT + P) * NT * 256); };
+    std::vector<int> slot_of(N, 0);                            // position of a block in the launch of the level that eliminates it
+    auto wx = [&](int src, int P) { return (uint32_t)(geom.oWx + ((size_t)slot_of[src] * RXT + P) * NT * 256); };
+    auto lx = [&](int src, int P) { return (uint32_t)(geom.oLx + ((size_t)slot_of[src] * RXT + P) * NT * 256); };
     // the factor of an eliminated block, pre-multiplied for the backward pass (one wavefront per tile)
     auto premul_jobs = [&](const BcrElim& el) {
         auto one = [&](size_t dst, size_t a, int J) { BcrUpd u{}; u.dst = (uint32_t)dst; u.mode = 3; u.nc = 1; u.a[0] = (uint32_t)a; u.b[0] = (uint32_t)(geom.oLi + ((size_t)el.i * NT + J) * 256); upds.push_back(u); };
         for (int Rg = 0; Rg < RXT; ++Rg) { if (Rg < NT ? el.l < 0 : (Rg < 2 * NT && el.r < 0)) continue;
-            for (int J = 0; J < NT; ++J) one(geom.oMx + (((size_t)el.i * RXT + Rg) * NT + J) * 256, geom.oLx + (((size_t)el.i * RXT + Rg) * NT + J) * 256, J); }
+            for (int J = 0; J < NT; ++J) one(geom.oMx + (((size_t)el.i * RXT + Rg) * NT + J) * 256, (size_t)lx(el.i, Rg) + (size_t)J * 256, J); }
         for (int I = 1; I < NT; ++I) for (int J = 0; J < I; ++J) one(geom.oMd + ((size_t)el.i * NO + I * (I - 1) / 2 + J) * 256, geom.oLd + ((size_t)el.i * NO + I * (I - 1) / 2 + J) * 256, J);
     };
     auto corner_job = [&](int i) { BcrUpd u{}; u.dst = (uint32_t)(geom.ocp + (size_t)(1 + i) * 256); u.mode = 2; u.nc = 1; u.a[0] = wx(i, 2 * NT); u.b[0] = lx(i, 2 * NT); upds.push_back(u); };
@@ -811,8 +816,10 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
         const size_t m = active.size(), first = (m & 1) ? 0 : 1;
         BcrLevel lv; lv.elim_off = elims.size(); lv.upd_off = upds.size();
         lv.o = active[0]; lv.s = m > 1 ? active[1] - active[0] : 1; lv.m = (int)m; lv.first = (int)first;
-        for (size_t idx = first; idx < m; idx += 2)
+        for (size_t idx = first; idx < m; idx += 2) {
+            slot_of[active[idx]] = (int)(elims.size() - lv.elim_off);
             elims.push_back(BcrElim{active[idx], idx >= 1 ? active[idx - 1] : -1, idx + 1 < m ? active[idx + 1] : -1, 0});
+        }
         for (size_t idx = 1 - first; idx < m; idx += 2) {        // the survivors: both chain neighbours (where they exist) are eliminated now
             const int j = active[idx];
             int src[2], so[2], ns = 0;
@@ -846,6 +853,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     {   // the root block
         BcrLevel lv; lv.elim_off = elims.size(); lv.upd_off = upds.size();
         lv.o = active[0]; lv.s = 1; lv.m = 1; lv.first = 0;
+        slot_of[active[0]] = 0;
         elims.push_back(BcrElim{active[0], -1, -1, 0});
         if (nbd > 0) corner_job(active[0]);
         premul_jobs(elims.back());

@@ -36,7 +36,7 @@ static int fail(nlls_ctx* c, int code, const std::string& msg) { c->err = msg; r
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(c, NLLS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
 // tiling parameters (see DESIGN.md "accumulate kernel")
-constexpr uint32_t LIGHT_MAX_ENTRIES = 256;    // one entry per lane of a 256-thread workgroup
+constexpr uint32_t LIGHT_MAX_ENTRIES = 256;    // one entry per lane of a 256-thread workgroup (192: 47.1 instead of 43.5 us in situ, 128: 60 -- tools/sweep_ab.py)
 constexpr uint32_t LIGHT_IMG_MAX     = 6144;   // doubles of LDS image (48 KiB) -> 3 workgroups per CU
 constexpr uint32_t HEAVY_ROW_ENTRIES = 128;    // rows with more entries get a workgroup of their own
 constexpr uint32_t HEAVY_MAX_ENTRIES = 1024;   // entries per heavy tile (two wavefronts x 8 pipeline stages); longer rows are split (PARTIAL)
@@ -313,7 +313,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
               for (int64_t e = 0; e < E.n; ++e) { int64_t k = L.cost[e];
                   for (int q = 0; q < d.ndata; ++q) hd[(size_t)e * d.ndata + q] = in.data[k * d.ndata + q];
                   for (int q = 0; q < d.ndeps; ++q) hv[(size_t)e * d.ndeps + q] = c->var_off[in.varind[k * d.ndeps + q] - 1]; }
-              HIPCHK(E.data.upload(hd)); HIPCHK(E.voff.upload(hv)); HIPCHK(E.dest.upload(dest)); HIPCHK(E.rows.upload(rinfo));
+              HIPCHK(E.data.upload(hd)); HIPCHK(E.voff.upload(hv)); HIPCHK(E.rows.upload(rinfo));
+              HIPCHK(E.dest.upload(dest));
               // compact form for the heavy pass (see EntryList::compact)
               E.compact = false; E.own_flags = 0;
               if (light.empty() && !heavy.empty() && d.ndeps >= 2 && E.n > 0) {
@@ -326,10 +327,10 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
             E.nlight = (int64_t)light.size(); E.nheavy = (int64_t)heavy.size();
             HIPCHK(E.light.upload(light)); HIPCHK(E.heavy.upload(heavy));
             npartials += E.nlight + E.nheavy;
-            std::vector<int64_t>().swap(L.cost);
         }
         G.cost_list = -1;       // (see Group::cost_list)
         for (int s2 = 0; s2 < d.ndeps; ++s2) { const EntryList& E = G.lists[s2]; if (E.n == G.ncost && G.ncost > 0 && E.nlight > 0 && E.nheavy == 0) { G.cost_list = s2; break; } }
+        for (int s2 = 0; s2 < d.ndeps; ++s2) std::vector<int64_t>().swap(hl[g][s2].cost);
     }
     std::vector<int64_t> red_off; std::vector<uint32_t> red_len, red_dst, red_which;   // stage-0 reduce ranges
     if (sparse && nranks > 1) {
