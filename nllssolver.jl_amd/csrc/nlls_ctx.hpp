@@ -231,5 +231,10 @@ struct nlls_ctx {
     double* s_ptr() const { return S.p + s_elems; }
     nlls::DevBuf<double> Yelim;              // C^-1 * [E | b] per eliminated block (reused by back-substitution)
     nlls::DevBuf<int32_t> d_status;          // factorisation status
+    // The buffers an LM iteration touches, moved into ONE contiguous allocation at the end of an upload (compact_hot_set, nlls_structure.cpp):
+    // 250 MB at BASELINE config 4 against a 256 MB memory-side cache.  Scattered over separate allocations they alias in that cache by
+    // the luck of their physical placement -- the accumulate launch inside the LM loop took 41 .. 49 us from process to process; side by
+    // side in one window (and the arrays the loop never reads kept out of it) it takes 41 in every process.
+    nlls::DevBuf<char> arena, arena_pre;
     bool solved = false;
 };

@@ -9,17 +9,19 @@
 namespace nlls {
 
 // ---- device memory ---------------------------------------------------------------------------
+// `owned == false`: the memory belongs to the context's hot arena (compact_hot_set, nlls_structure.cpp) -- release() then only forgets it.
 template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool owned = true;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; o.owned = true; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; o.owned = true; } return *this; }
     ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
     hipError_t alloc(size_t count) {
         release(); n = count;
         if (count == 0) { return hipSuccess; }

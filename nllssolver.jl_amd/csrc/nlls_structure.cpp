@@ -41,9 +41,58 @@ constexpr uint32_t LIGHT_IMG_MAX     = 6144;   // doubles of LDS image (48 KiB) 
 constexpr uint32_t HEAVY_ROW_ENTRIES = 128;    // rows with more entries get a workgroup of their own
 constexpr uint32_t HEAVY_MAX_ENTRIES = 1024;   // entries per heavy tile (two wavefronts x 8 pipeline stages); longer rows are split (PARTIAL)
 
+// ---- the hot set ------------------------------------------------------------------------------------------------------------
+// every device buffer the LM loop reads or writes, in the order they are laid out in the arena.  NOT in it: the cost-order arrays of a
+// group whose cost sweep reads a light entry list instead (Group::cost_list), voff / dest of compact heavy lists (one word per tile is
+// read), the per-block neighbour records of the generic elimination, the all-blocks list of the quadratic form (the loop uses the short
+// one), the chain / dense solvers' workspace when block cyclic reduction solves the band.
+namespace {
+struct HotItem { void** pp; size_t bytes; bool* owned; };
+template <class T> void hot(std::vector<HotItem>& v, DevBuf<T>& b) { if (b.p && b.n) v.push_back(HotItem{reinterpret_cast<void**>(&b.p), b.n * sizeof(T), &b.owned}); }
+void hot_set(nlls_ctx* c, std::vector<HotItem>& v) {
+    hot(v, c->A); hot(v, c->b); hot(v, c->x); for (auto& q : c->vars) hot(v, q);
+    for (Group& G : c->groups) {
+        for (EntryList& E : G.lists) { if (E.n == 0) continue;
+            hot(v, E.data); hot(v, E.rows); hot(v, E.light); hot(v, E.heavy); hot(v, E.hvoff);
+            if (!E.compact) { hot(v, E.voff); hot(v, E.dest); } }
+        if (G.cost_list < 0 || !c->info.is_sparse) { hot(v, G.data); hot(v, G.voff); }
+        hot(v, G.fixedcost); hot(v, G.dense.data); hot(v, G.dense.voff); hot(v, G.dense.brow);
+    }
+    hot(v, c->d_var_kind); hot(v, c->d_var_dim); hot(v, c->d_var_off); hot(v, c->d_var_boff); hot(v, c->d_diag_off); hot(v, c->d_blocksizes);
+    hot(v, c->d_zero_off); hot(v, c->d_zero_len); hot(v, c->d_zero_b_off); hot(v, c->d_zero_b_len); hot(v, c->partials); hot(v, c->scalars);
+    hot(v, c->S); hot(v, c->Cinv); hot(v, c->tE); hot(v, c->d_status); hot(v, c->d_copy); hot(v, c->d_red_boff); hot(v, c->d_blk_slow);
+    hot(v, c->d_elim_desc); hot(v, c->d_elim_rc); hot(v, c->d_elim_diag); hot(v, c->d_elim_boff); hot(v, c->d_elim_dim); hot(v, c->d_fast_members); hot(v, c->d_fast_groups);
+    if (c->bcr.ready) { hot(v, c->bcr.ws); hot(v, c->bcr.d_upd); hot(v, c->bcr.d_elim); } else hot(v, c->Lwork);
+}
+}  // namespace
+// move the hot set into one allocation (called at the end of a successful upload; NLLS_NO_ARENA=1: leave every buffer where hipMalloc put it)
+static int compact_hot_set(nlls_ctx* c) {
+    if (getenv("NLLS_NO_ARENA")) return NLLS_OK;
+    std::vector<HotItem> v; hot_set(c, v);
+    size_t total = 0; for (const HotItem& it : v) if (*it.owned) total += (it.bytes + 255) & ~(size_t)255;
+    if (total == 0) return NLLS_OK;
+    // the arena was reserved BEFORE the first buffer of this upload (build_structure): physical placement is best while the device memory
+    // is untouched -- allocated here, behind hundreds of megabytes of allocations, the same window came out at 40 .. 46 us from process
+    // to process, reserved first at 40 .. 41.7 (tools/sweep_ab.py).  An estimate that fell short falls back to allocating now.
+    DevBuf<char> fresh;
+    if (c->arena_pre.p && c->arena_pre.n >= total) fresh = std::move(c->arena_pre);
+    else { c->arena_pre.release(); HIPCHK(fresh.alloc(total)); }
+    size_t off = 0;
+    for (HotItem& it : v) { if (!*it.owned) continue;
+        HIPCHK(hipMemcpyAsync(fresh.p + off, *it.pp, it.bytes, hipMemcpyDeviceToDevice, c->stream));
+        it.bytes = (it.bytes + 255) & ~(size_t)255; off += it.bytes; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    off = 0;
+    for (HotItem& it : v) { if (!*it.owned) continue; (void)hipFree(*it.pp); *it.pp = fresh.p + off; *it.owned = false; off += it.bytes; }
+    c->arena = std::move(fresh);                             // (the previous upload's arena, if any, is freed here: nothing points into it any more)
+    if (c->bcr.ready) c->bcr.geom.ws = c->bcr.ws.p;          // the one cached device pointer
+    return NLLS_OK;
+}
+
 int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
     c->ready = false; c->solved = false; c->have_grad = false; c->lambda = 0;
+    { std::vector<HotItem> v; hot_set(c, v); for (HotItem& it : v) if (!*it.owned) { *it.pp = nullptr; *it.owned = true; } }   // what lived in the previous upload's arena is gone with it
     c->groups.clear();
     // ---- variables ------------------------------------------------------------------------------
     c->var_kind.assign(var_kind, var_kind + nvar); c->var_dim.assign(var_dim, var_dim + nvar);
@@ -146,6 +195,17 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
 
     // ---- device buffers ----------------------------------------------------------------------------------
     HIPCHK(hipSetDevice(c->device));
+    if (!getenv("NLLS_NO_ARENA")) {
+        // reserve the hot arena first (compact_hot_set fills it at the end of the upload).  Estimate: A, b, x, three variable sets, per (cost, slot)
+        // incidence its list record, the cost-order arrays, per block the elimination's inverse + descriptors, and for the reduced system the
+        // band / tile workspaces -- generous (the slack is never touched), and harmless when short
+        size_t est = 8 * ((size_t)nnz_data + 2 * (size_t)ndof + 3 * (size_t)I.var_storage + 64);
+        for (int g = 0; g < ngroups; ++g) { const ResDesc& d = desc[g]; const size_t nc = (size_t)groups[g].ncost, nd = (size_t)std::max(d.ndeps, 1), nda = (size_t)std::max(d.ndata, 1);
+            est += nc * nd * (8 * nda + 8 * nd + 8) + nc * (8 * nda + 4 * nd); }
+        est += (size_t)nb * 256 + (size_t)ndof * 64;
+        est += est / 4 + ((size_t)64 << 20);
+        (void)c->arena_pre.alloc(est);
+    }
     for (int k = 0; k < 3; ++k) { HIPCHK(c->vars[k].alloc(std::max<size_t>(I.var_storage, 1))); HIPCHK(hipMemset(c->vars[k].p, 0, sizeof(double) * std::max<size_t>(I.var_storage, 1))); c->vars_slot[k] = k; }
     HIPCHK(c->A.alloc(std::max<int64_t>(nnz_data, 1))); HIPCHK(hipMemset(c->A.p, 0, sizeof(double) * std::max<int64_t>(nnz_data, 1)));
     HIPCHK(c->b.alloc(std::max<int64_t>(ndof, 1))); HIPCHK(hipMemset(c->b.p, 0, sizeof(double) * std::max<int64_t>(ndof, 1)));
@@ -371,6 +431,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
       for (int64_t r = 0; r < nb; ++r) if (nranks == 1 || !c->is_elim[r] || owner_of_block[r] == rank) { lw += sparse ? segs[r + 1] - segs[r] : 0; ld += c->blocksizes[r]; }
       c->local_nnz_data = sparse ? lw : nnz_data; c->local_ndof = ld; }
     int rc = build_schur(c, flags);
+    if (rc != NLLS_OK) return rc;
+    rc = compact_hot_set(c);
     if (rc != NLLS_OK) return rc;
     c->ready = true;
     return NLLS_OK;
