@@ -319,6 +319,25 @@ int  nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);
 int  nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples);
 int  nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);  /* factorisation + backward pass of the (already assembled) reduced system alone */
 
+/* ---- collectives behind the ABI ("RCCL all-reduce over xGMI on the assembled normal equations") ----------------------
+ * Under nlls_set_shard(rank, nranks) the entry points of the Levenberg-Marquardt loop -- nlls_sweep_gradhess, nlls_max_abs_diag,
+ * nlls_lm_trial, nlls_sweep_cost, nlls_quadform, nlls_grad_sqnorm, and therefore nlls_lm_iterations -- become COLLECTIVE once an
+ * all-reduce is installed: every rank calls them in the same order, the library reduces [cost | camera rows | camera part of b] after a
+ * gradient sweep, [S | s] after the local elimination and the trial's scalars (gathered, with the factorisation status: a rank-local bad
+ * pivot fails the call on EVERY rank) on its own stream, and returns the reduced values.  No host language stands between two trials.
+ * Replaces nothing in the reference (single process); the loop driven is src/optimize.jl:124-171.
+ *   nlls_comm_unique_id / nlls_comm_init_rccl : RCCL inside the library (librccl.so.1 is loaded on first use; one communicator per
+ *                         context, collectives on the context's stream).  id: 128 bytes from rank 0, handed to every rank by the caller.
+ *   nlls_set_allreduce  : any other transport -- fn reduces `count` doubles at dev_ptr (device memory) in place over all ranks, ordered
+ *                         behind the work already enqueued on hip_stream and before work enqueued on it afterwards (a host-staged
+ *                         implementation synchronises the stream itself); returns 0 on success.  fn == NULL removes it. */
+#define NLLS_REDUCE_SUM 0
+#define NLLS_REDUCE_MAX 1
+typedef int (*nlls_allreduce_fn)(void* user, void* dev_ptr, int64_t count, int32_t op, void* hip_stream);
+int  nlls_set_allreduce(nlls_ctx* ctx, nlls_allreduce_fn fn, void* user);
+int  nlls_comm_unique_id(void* id128);
+int  nlls_comm_init_rccl(nlls_ctx* ctx, const void* id128);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,8 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_solve_finish_replicated nlls_get_variables_owned nlls_lm_iterations""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_solve_finish_replicated nlls_get_variables_owned nlls_lm_iterations
+nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl""".split()
 
 
 class LmOptions(C.Structure):          # nlls_lm_options
@@ -110,6 +111,7 @@ def lib():
         L.nlls_time_solve.argtypes = [vp, i32, vp]; L.nlls_time_reduced_solve.argtypes = [vp, i32, vp]
         L.nlls_profile_sweep.argtypes = [vp, i32, vp, vp, vp, vp]
         L.nlls_solve_finish_replicated.argtypes = [vp]; L.nlls_get_variables_owned.argtypes = [vp, i32, vp]
+        L.nlls_set_allreduce.argtypes = [vp, vp, vp]; L.nlls_comm_unique_id.argtypes = [vp]; L.nlls_comm_init_rccl.argtypes = [vp, vp]
         _lib = L
     return _lib
 
@@ -248,6 +250,36 @@ class Context:
         self._chk(self.L.nlls_optimize_singles(self.h, vi.size, _p(vi), _p(cp), _p(cg), _p(ci), _p(cs), int(iterator), int(maxiters), int(maxfails),
                                                 float(reldcost), float(absdcost), float(dstep), _p(iters)))
         return iters
+
+    # ---- collectives behind the ABI (include/nlls_amd.h) ------------------------------------------------------
+    ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+
+    def set_allreduce(self, fn):
+        """fn(dev_ptr, count, op, hip_stream) -> 0: in-place all-reduce of `count` doubles in device memory (op 0 sum, 1 max).  The LM
+        loop's entry points then run collectively inside the library (nlls_lm_iterations included).  fn = None removes it."""
+        if fn is None:
+            self._reduce_cb = None
+            self._chk(self.L.nlls_set_allreduce(self.h, None, None)); return
+        def tramp(user, ptr, count, op, stream):
+            try:
+                return int(fn(ptr, count, op, stream) or 0)
+            except Exception as e:          # (an exception must not unwind through the C frames)
+                self._reduce_exc = e; return 1
+        self._reduce_cb = self.ALLREDUCE_FN(tramp)       # kept alive with the context
+        self._chk(self.L.nlls_set_allreduce(self.h, self._reduce_cb, None))
+
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_ubyte * 128)()
+        rc = lib().nlls_comm_unique_id(buf)
+        if rc != OK:
+            raise NllsError(rc, "nlls_comm_unique_id: librccl could not be loaded")
+        return bytes(buf)
+
+    def comm_init_rccl(self, id128):
+        """RCCL inside the library: one communicator for this context (after set_shard), collectives on the context's stream."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(id128)
+        self._chk(self.L.nlls_comm_init_rccl(self.h, buf))
 
     def solve_stats(self):
         out = np.zeros(11, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 11))

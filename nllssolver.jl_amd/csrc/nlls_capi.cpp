@@ -56,6 +56,7 @@ int nlls_ctx_destroy(nlls_ctx* ctx) {
     if (!ctx) return NLLS_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -157,6 +158,16 @@ int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
     NEED_READY();
     // cost_out == NULL: the caller does not want the cost (the outer loop between iterations, src/optimize.jl:167-170
     // discards it) -- the sweep is then only enqueued: no partial-sum kernel, no synchronisation
+    if (ctx->reduce_fn) {
+        // collective (include/nlls_amd.h): this rank's blocks, then ONE sum over ranks of [cost | reduced rows of A.data | reduced part of b]
+        TRY(enqueue_sweep_gradhess(ctx, true));
+        ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
+        if (ctx->nranks > 1) { TRY(enqueue_pack_reduce0(ctx)); TRY(comm_reduce(ctx, ctx->redbuf.p, ctx->redbuf_len, NLLS_REDUCE_SUM)); TRY(enqueue_unpack_reduce0(ctx)); }
+        else TRY(comm_reduce(ctx, ctx->scalars.p, 1, NLLS_REDUCE_SUM));      // (one rank through the route: the same number of collectives)
+        if (!cost_out) return NLLS_OK;
+        TRY(fetch_scalars(ctx, 0, 1)); *cost_out = ctx->h_scalars[0];
+        return NLLS_OK;
+    }
     TRY(enqueue_sweep_gradhess(ctx, cost_out != nullptr));
     ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
     if (!cost_out) return NLLS_OK;
@@ -167,6 +178,7 @@ int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
 int nlls_sweep_cost(nlls_ctx* ctx, int32_t which, double* cost_out) {
     NEED_READY(); if (!valid_set(which)) return NLLS_ERR_INVALID_ARG;
     TRY(enqueue_sweep_cost(ctx, which));
+    TRY(comm_reduce(ctx, ctx->scalars.p, 1, NLLS_REDUCE_SUM));       // (collective mode: the ranks' partial costs)
     TRY(fetch_scalars(ctx, 0, 1));
     if (cost_out) *cost_out = ctx->h_scalars[0];
     return NLLS_OK;
@@ -185,15 +197,15 @@ int nlls_get_bsm_data(nlls_ctx* ctx, double* data_out) {
     return NLLS_OK;
 }
 int nlls_max_abs_diag(nlls_ctx* ctx, double* out) {
-    NEED_GRAD(); TRY(enqueue_max_abs_diag(ctx)); TRY(fetch_scalars(ctx, 3, 1));
+    NEED_GRAD(); TRY(enqueue_max_abs_diag(ctx)); TRY(comm_reduce(ctx, ctx->scalars.p + 3, 1, NLLS_REDUCE_MAX)); TRY(fetch_scalars(ctx, 3, 1));
     if (out) *out = ctx->h_scalars[3]; return NLLS_OK;
 }
 int nlls_grad_sqnorm(nlls_ctx* ctx, double* out) {
-    NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->b.p, 6)); TRY(fetch_scalars(ctx, 6, 2));
+    NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->b.p, 6)); TRY(comm_reduce(ctx, ctx->scalars.p + 6, 2, NLLS_REDUCE_SUM)); TRY(fetch_scalars(ctx, 6, 2));
     if (out) *out = ctx->h_scalars[7]; return NLLS_OK;
 }
 int nlls_grad_quadform(nlls_ctx* ctx, double* out) {
-    NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->b.p, 6)); TRY(fetch_scalars(ctx, 6, 2));
+    NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->b.p, 6)); TRY(comm_reduce(ctx, ctx->scalars.p + 6, 2, NLLS_REDUCE_SUM)); TRY(fetch_scalars(ctx, 6, 2));
     if (out) *out = ctx->h_scalars[6]; return NLLS_OK;
 }
 
@@ -221,11 +233,24 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
 // solve!, negate!, update!(to, from, x), cost(to).  Same kernels, same order as the separate entry points.
 int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, double* cost_out) {
     NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
-    if (ctx->nranks != 1) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_lm_trial is the single-GPU fast path; sharded runs use the *_local / *_finish pairs");
+    const bool collective = ctx->reduce_fn != nullptr && ctx->info.is_sparse;
+    if (ctx->nranks != 1 && !collective) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_lm_trial under nlls_set_shard needs an all-reduce (nlls_comm_init_rccl / nlls_set_allreduce), or the *_local / *_finish pairs");
     ctx->lambda += dlambda;
     ctx->step_cached = false;
+    if (collective) {
+        // the sharded trial, end to end on this rank's stream: local elimination, ONE sum of [S | s] over ranks, the reduced system solved on
+        // every rank (each then holds the reduced part of the step: x is never summed), own back-substitution, retraction, own cost blocks,
+        // and one gather of the ranks' scalars -- combined on the device and published to the host mirror as the single-GPU trial does
+        TRY(enqueue_solve_local(ctx));
+        TRY(comm_reduce(ctx, ctx->S.p, (int64_t)ctx->s_elems + ctx->nred, NLLS_REDUCE_SUM));
+        ctx->replicate_xr = true; int rc = enqueue_solve_finish(ctx); ctx->replicate_xr = false; TRY(rc);
+        double* const mirror = ctx->h_scalars_dev; ctx->h_scalars_dev = nullptr;           // (the rank's own scalars are not what the host waits for)
+        rc = enqueue_lm_trial_tail(ctx, to, from); ctx->h_scalars_dev = mirror; TRY(rc);
+        TRY(comm_gather_trial_scalars(ctx, (double)ctx->trial_seq));
+    } else {
     TRY(enqueue_solve(ctx));
     TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form + retraction in one launch, the cost sweep, one finishing launch
+    }
     // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
     if (!ctx->info.is_sparse || !ctx->h_scalars_dev) {
         HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));
@@ -366,7 +391,7 @@ int nlls_step_norm(nlls_ctx* ctx, double* out) {
 int nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out) {
     NEED_GRAD();
     if (ctx->step_cached) { if (xHx_out) *xHx_out = ctx->c_xAx + ctx->lambda * ctx->c_xx; if (gx_out) *gx_out = ctx->c_gx; return NLLS_OK; }   // damping may have changed since
-    TRY(enqueue_quadform(ctx, ctx->x.p, 4)); TRY(fetch_scalars(ctx, 4, 2));
+    TRY(enqueue_quadform(ctx, ctx->x.p, 4)); TRY(comm_reduce(ctx, ctx->scalars.p + 4, 2, NLLS_REDUCE_SUM)); TRY(fetch_scalars(ctx, 4, 2));
     if (xHx_out) *xHx_out = ctx->h_scalars[4]; if (gx_out) *gx_out = ctx->h_scalars[5];
     return NLLS_OK;
 }

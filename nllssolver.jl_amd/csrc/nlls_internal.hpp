@@ -63,6 +63,11 @@ int enqueue_pack_reduce0(nlls_ctx* c);      // [cost | reduced rows | reduced b]
 int enqueue_unpack_reduce0(nlls_ctx* c);
 
 
+// collectives (nlls_comm.cpp)
+int comm_reduce(nlls_ctx* c, double* dev_ptr, int64_t count, int op);                 // no-op without an installed all-reduce
+int comm_gather_trial_scalars(nlls_ctx* c, double seq);                               // gather + combine the trial's scalars on the device, publish them (and seq) to the host mirror
+void comm_release(nlls_ctx* c);
+
 inline double* vars_ptr(nlls_ctx* c, int which) { return c->vars[c->vars_slot[which]].p; }
 
 }  // namespace nlls

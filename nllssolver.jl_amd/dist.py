@@ -48,6 +48,21 @@ class ShardedLS(MultiVariateLSgpu):
             import torch
             self._tstream = torch.cuda.Stream(device=self.device)
             self.ctx.set_stream(self._tstream.cuda_stream)
+        # The collectives of the LM loop live BEHIND the C ABI (include/nlls_amd.h): RCCL inside the library on the GPU box, or -- host_staged -- a
+        # callback that sums host copies with gloo so that several ranks can share one GPU in the tests.  costgradhess / initlambda /
+        # lm_trial / cost below are then plain calls of the same entry points as on one GPU, and the library's own outer loop
+        # (nlls_lm_iterations) drives the sharded trials: no Python between two trials.  The Python route further down (solve_local /
+        # all-reduce / solve_finish) remains for plain solve() calls (Newton, dogleg: they want x on every rank).
+        self.native_collectives = False
+        if self.sharded:
+            if host_staged:
+                self.ctx.set_allreduce(self._staged_allreduce)
+            else:
+                ids = [_capi.Context.comm_unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(ids, src=0)
+                self.ctx.comm_init_rccl(ids[0])
+            self.native_collectives = True
         sh = self.ctx.shard_info()
         self.local_nobs, self.local_nnz_data, self.local_ndof_written = sh["local_ncost"], sh["local_nnz_data"], sh["local_ndof"]
 
@@ -57,6 +72,18 @@ class ShardedLS(MultiVariateLSgpu):
         if world > 1:
             ctx.set_shard(rank, world)
         return ctx
+
+    def _staged_allreduce(self, ptr, count, op, stream):
+        """nlls_allreduce_fn for the tests: gloo on host copies (synchronises the stream on both sides)"""
+        import torch
+        torch.cuda.synchronize()
+        t = torch.as_tensor(_DevArray(ptr, count), device=f"cuda:{self.device}")
+        h = t.cpu()
+        if self.world > 1:
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM)
+        t.copy_(h)
+        torch.cuda.synchronize()
+        return 0
 
     # ---- collectives ------------------------------------------------------------------------------
     def _buffer_tensor(self, stage):
@@ -95,18 +122,24 @@ class ShardedLS(MultiVariateLSgpu):
     def costgradhess(self, want_cost=True):
         if not self.sharded:
             return super().costgradhess(want_cost)
+        if self.native_collectives:
+            self._x = None; self._trial = None
+            return MultiVariateLSgpu.costgradhess(self, want_cost)          # collective inside the library
         self._x = None; self._trial = None
         self.ctx.sweep_gradhess_local()
         self._allreduce_buffer(0)
         return self.ctx.sweep_gradhess_finish(want_cost)
 
     def cost(self, which=_capi.VARS_NEXT):
-        c = super().cost(which)                    # this rank's cost blocks only
-        return c if not self.sharded else self._allreduce_scalars([c])[0]
+        c = super().cost(which)                    # this rank's cost blocks only -- summed inside the library under native collectives
+        return c if (not self.sharded or self.native_collectives) else self._allreduce_scalars([c])[0]
 
     def lm_trial(self, dlambda):
         if not self.sharded:
             return super().lm_trial(dlambda)
+        if self.native_collectives:
+            self._x = None; self._trial = None
+            return MultiVariateLSgpu.lm_trial(self, dlambda)                # nlls_lm_trial: the whole sharded trial in one call (csrc/nlls_capi.cpp)
         # sharded: damp, local elimination, ONE buffer reduction ([S | s]), replicated reduced solve + own back-substitution, then
         # retraction + cost sweep + step statistics in one call and ONE gather of six scalars per rank; what the iterator asks next
         # (quadform, step_maxabs) is answered from here.  No reduction of x: every rank holds the reduced part of the step.
@@ -185,7 +218,7 @@ class ShardedLS(MultiVariateLSgpu):
 
     def initlambda(self):
         m = self.ctx.max_abs_diag()
-        if self.sharded:
+        if self.sharded and not self.native_collectives:
             m = self._allreduce_scalars([m], "max")[0]
         return m * 1e-6
 
@@ -208,11 +241,11 @@ class ShardedLS(MultiVariateLSgpu):
         if self._trial:
             return self._trial[0]
         a, g = self.ctx.quadform()
-        return (a, g) if not self.sharded else tuple(self._allreduce_scalars([a, g]))
+        return (a, g) if (not self.sharded or self.native_collectives) else tuple(self._allreduce_scalars([a, g]))
 
     def grad_quadform(self):
         g = self.ctx.grad_quadform()               # this rank's rows of H against the (complete) gradient
-        return g if not self.sharded else self._allreduce_scalars([g])[0]
+        return g if (not self.sharded or self.native_collectives) else self._allreduce_scalars([g])[0]
 
     @property
     def b(self):

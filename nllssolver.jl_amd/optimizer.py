@@ -111,7 +111,8 @@ class OuterLoop:
         # (nlls_lm_iterations, csrc/nlls_lm.cpp: the same statements as iteration() + iterate_levmar below, without the interpreter
         # between two trials).  native=False keeps the Python loop (the tests hold the two against each other).
         ls = data.linsystem
-        can = (iterate is It.iterate_levmar and callback is nullcallback and hasattr(ls, "ctx") and not getattr(ls, "sharded", False)
+        can = (iterate is It.iterate_levmar and callback is nullcallback and hasattr(ls, "ctx")
+               and (not getattr(ls, "sharded", False) or getattr(ls, "native_collectives", False))     # (sharded: the collectives are inside the library)
                and hasattr(ls.ctx, "lm_iterations"))
         self.native = can if native is None else (bool(native) and can)
         self._state = None

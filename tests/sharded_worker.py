@@ -80,18 +80,26 @@ def main():
     assert np.isclose(ref.grad_quadform(), sh.grad_quadform(), rtol=1e-9)
 
     # a few full iterations through the host loop on both: Levenberg-Marquardt, then dogleg
-    def run(ls, iters=4, itdata=It.LevMarData, itfn=It.iterate_levmar):
+    def run(ls, iters=4, itdata=It.LevMarData, itfn=It.iterate_levmar, native=False):
         opts = N.NLLSOptions(maxiters=iters)
         data = Opt.NLLSInternal(ls, time.perf_counter_ns())
-        loop = Opt.OuterLoop(p, opts, data, itdata(), itfn, N.nullcallback)
+        loop = Opt.OuterLoop(p, opts, data, itdata(), itfn, N.nullcallback, native=native)
         loop.start()
-        while loop.iteration() == 0:
-            pass
+        if native:          # nlls_lm_iterations: the library's own outer loop drives the SHARDED trials (collectives behind the C ABI)
+            assert loop.native, "the sharded linear system must qualify for the library's outer loop"
+            while loop.iterations(1 << 30) == 0:
+                pass
+        else:
+            while loop.iteration() == 0:
+                pass
         assert data.iternum > 1, data.iternum                  # (a loop that stops after one iteration compares nothing)
         return data.bestcost, ls.variables(_capi.VARS_CURRENT)
     ref2 = MultiVariateLSgpu(p, unfixed); sh2 = mk()
     cr, vr = run(ref2); cs, vs = run(sh2)
     assert np.isclose(cr, cs, rtol=1e-9), (cr, cs)
+    sh4 = mk(); cs4, vs4 = run(sh4, native=True); sh4.close()
+    assert np.isclose(cs4, cs, rtol=1e-9), (cs4, cs)           # ... and the same loop inside the library, every rank in it
+    assert np.allclose(vs4, vs, rtol=1e-6, atol=1e-9)
     if config3:
         ores = oracle_problem(mkp()).optimize(maxiters=4)
         assert np.isclose(ores.bestcost, cs, rtol=1e-8), (ores.bestcost, cs)
@@ -100,7 +108,10 @@ def main():
     # (dogleg takes UNDAMPED Newton steps: on the gauge-free affine camera H is singular and the step along the gauge directions is decided by
     # rounding -- the summation order of the elimination's atomics -- so two runs of the SAME unsharded loop differ at the 1e-3 level after a
     # few iterations.  What is comparable: both reduce the cost, to the same level.  Exact agreement of single steps is asserted above.)
-    assert cd_r < 0.9 * c_ref and cd_s < 0.9 * c_ref and np.isclose(cd_r, cd_s, rtol=3e-2), (c_ref, cd_r, cd_s)
+    # The tolerance is what two UNSHARDED runs show on this very problem (their spread, measured here), not a constant.
+    ref5 = MultiVariateLSgpu(p, unfixed); cd_r2, _ = run(ref5, 4, It.DoglegData, It.iterate_dogleg); ref5.close()
+    spread = abs(cd_r - cd_r2) / abs(cd_r)
+    assert cd_r < 0.9 * c_ref and cd_s < 0.9 * c_ref and abs(cd_r - cd_s) <= max(8.0 * spread, 1e-6) * abs(cd_r), (c_ref, cd_r, cd_r2, cd_s, spread)
     for o in (ref, sh, ref2, sh2, ref3, sh3):
         o.close()
     dist.barrier()

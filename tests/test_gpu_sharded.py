@@ -36,3 +36,21 @@ def test_sharded_matches_unsharded(world, backend, seed):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
         assert ("sharded == unsharded" if seed >= 0 else "singular block raised on every rank") in out
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the way the driver starts N = 1): bench.py starts one child process per rank before it
+    touches the GPU, relays rank 0's JSON line and fails if a rank fails.  Rehearsed on the one GPU with gloo + host-staged reductions
+    (RCCL refuses two ranks on one device); the sharded trials run in the library's own loop (collectives behind the C ABI)."""
+    import json
+    env = dict(os.environ, NLLS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--workload", "ba_100x10k", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # stdout carries exactly one line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["config"]["sharding"] == "by point over 2 ranks"
+    assert out["lm"]["final_cost"] < out["lm"]["start_cost"] and out["value"] > 0
