@@ -135,6 +135,10 @@ typedef struct nlls_info {
 #define NLLS_FLAG_NO_BAND        0x8  /* never use the bordered-band solver (dense MFMA path instead)  */
 #define NLLS_FLAG_NO_TWIST       0x10 /* band solver: factor from the top only (one workgroup), testing */
 #define NLLS_FLAG_DETERMINISTIC  0x40 /* reduced system assembled without atomics (slab per supernode + ordered gather): x is bit-reproducible   */
+#define NLLS_FLAG_PRESHARDED     0x80 /* under nlls_set_shard(rank, nranks > 1): the caller uploads ONLY this rank's share -- every uploaded cost block is this rank's,
+                                         the eliminated variables present are its own, the other (reduced) variables are the same, in the same order, on every
+                                         rank (bundle adjustment: all cameras + this rank's points).  Nothing is partitioned by the library; variable indices are
+                                         the rank's own.  Lets each process of a large job generate and upload 1/N of the problem                       */
 #define NLLS_FLAG_NO_BCR         0x20 /* band solver: the round-1 chain kernels (twisted blocked LDL') instead of block cyclic reduction */
 
 /* variable-set ids for the on-device copies of problem.variables / varnext / varbest

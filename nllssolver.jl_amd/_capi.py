@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libnlls_amd.so")
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOT_READY, ERR_NOT_SPD, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
 FLAG_FORCE_ATOMIC, FLAG_NO_SCHUR, FLAG_FORCE_SPARSE, FLAG_NO_BAND, FLAG_NO_TWIST, FLAG_NO_BCR, FLAG_DETERMINISTIC = 1, 2, 4, 8, 16, 32, 64
+FLAG_PRESHARDED = 128
 VARS_CURRENT, VARS_NEXT, VARS_BEST = 0, 1, 2
 
 # every symbol include/nlls_amd.h declares (checked by tests/test_capi_symbols.py)

@@ -152,6 +152,9 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
                 uint64_t a = bi[groups[g].varind[k * nd + s] - 1]; if (!a) continue;
                 for (int t = 0; t <= s; ++t) { uint64_t b = bi[groups[g].varind[k * nd + t] - 1]; if (!b) continue;
                     uint64_t hi = std::max(a, b), lo = std::min(a, b); keys.push_back((hi - 1) * (uint64_t)nb + (lo - 1)); } } }
+        // (a rank's share of a pre-sharded problem: a reduced variable none of ITS cost blocks touches still owns its diagonal block -- the sum over
+        //  ranks fills it, and the reduced system must have the same blocks on every rank)
+        if ((flags & NLLS_FLAG_PRESHARDED) && c->nranks > 1) for (int64_t k = 0; k < nb; ++k) keys.push_back((uint64_t)k * (uint64_t)nb + (uint64_t)k);
         std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
         int64_t bnnz = 0; for (uint64_t k : keys) bnnz += (int64_t)c->blocksizes[k / nb] * c->blocksizes[k % nb];   // utils.jl:110-120
         sparse = (flags & NLLS_FLAG_FORCE_SPARSE) || (bnnz * 64) < (25 * ndof * (ndof - 40));                        // utils.jl:108
@@ -230,6 +233,9 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
         c->info = I;
         int rc0 = select_elimination(c, flags); if (rc0 != NLLS_OK) return rc0;
         if (!c->nelim) return fail(c, NLLS_ERR_UNSUPPORTED, "sharding needs an eliminated (Schur) variable set to partition by");
+        if (flags & NLLS_FLAG_PRESHARDED) {                   // the caller has partitioned: everything uploaded here is this rank's
+            for (int64_t k = 0; k < nb; ++k) if (c->is_elim[k]) owner_of_block[k] = rank;
+        } else {
         // weight of an eliminated block = number of cost blocks touching it; contiguous ranges of equal weight
         std::vector<int64_t> w(nb, 0);
         for (int g = 0; g < ngroups; ++g) { const int nd = desc[g].ndeps;
@@ -241,6 +247,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
             for (int64_t k = 0; k < groups[g].ncost; ++k) { int own = (int)(k % nranks);
                 for (int s = 0; s < nd; ++s) { uint64_t r = bi[groups[g].varind[k * nd + s] - 1]; if (r && c->is_elim[r - 1]) { own = owner_of_block[r - 1]; break; } }
                 mine[g][k] = own == rank; c->local_ncost += mine[g][k]; } }
+        }
     }
     c->owner_of_block = owner_of_block;
     // ---- per-group lists ---------------------------------------------------------------------------------
@@ -504,9 +511,25 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         std::vector<int64_t> rcnt(nb, 0);
         if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) { if (c->is_elim[row]) continue;
             for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q]; if (col != row && !c->is_elim[col]) { rcnt[row]++; rcnt[col]++; } } }
+        int64_t nelim_all = c->nelim;
+        if ((flags & NLLS_FLAG_PRESHARDED) && c->nranks > 1) {
+            // a rank's share alone would put different blocks into the border on different ranks: the rule is applied to the counts of the WHOLE
+            // problem -- couplings to eliminated blocks summed over ranks (every rank eliminates its own), couplings among the reduced blocks as the
+            // maximum (every rank sees a subset of the same blocks)
+            if (!c->reduce_fn) return fail(c, NLLS_ERR_INVALID_ARG, "NLLS_FLAG_PRESHARDED: install the all-reduce (nlls_comm_init_rccl / nlls_set_allreduce) before nlls_upload_structure -- the reduced system's layout is agreed on collectively");
+            std::vector<double> hs(1 + (size_t)nR), hm((size_t)nR);
+            { size_t r = 0; hs[0] = (double)c->nelim; for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) { hs[1 + r] = (double)cnt[k]; hm[r] = (double)rcnt[k]; ++r; } }
+            DevBuf<double> ds, dm;
+            HIPCHK(ds.upload(hs)); HIPCHK(dm.upload(hm));
+            { int rc = comm_reduce(c, ds.p, (int64_t)hs.size(), NLLS_REDUCE_SUM); if (rc == NLLS_OK && nR > 0) rc = comm_reduce(c, dm.p, (int64_t)hm.size(), NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(hs.data(), ds.p, sizeof(double) * hs.size(), hipMemcpyDeviceToHost)); if (nR > 0) HIPCHK(hipMemcpy(hm.data(), dm.p, sizeof(double) * hm.size(), hipMemcpyDeviceToHost));
+            nelim_all = (int64_t)hs[0];
+            { size_t r = 0; for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) { cnt[k] = (int64_t)hs[1 + r]; rcnt[k] = (int64_t)hm[r]; ++r; } }
+        }
         int64_t bd = 0;
         for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) {
-            bool big = (c->nelim >= 64 && cnt[k] * 4 > c->nelim) || (nR >= 64 && rcnt[k] * 4 > nR);
+            bool big = (nelim_all >= 64 && cnt[k] * 4 > nelim_all) || (nR >= 64 && rcnt[k] * 4 > nR);
             if (big && bd + c->blocksizes[k] <= 15) { is_border[k] = 1; bd += c->blocksizes[k]; } }
         int64_t ro = 0;
         for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && !is_border[k]) { red_of[k] = ro; ro += c->blocksizes[k]; }
@@ -622,6 +645,17 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             if (row == col) bw = std::max<int64_t>(bw, c->blocksizes[row] - 1);
         } }
     c->ncopy = (int64_t)copies.size();
+    if ((flags & NLLS_FLAG_PRESHARDED) && c->nranks > 1) {
+        // every rank has built the reduced system from ITS cost blocks only: the layout of [S | s] -- summed element by element over ranks --
+        // must be one layout.  The bandwidth is the maximum over ranks; the reduced order itself (banded part, border, size) has to agree.
+        if (!c->reduce_fn) return fail(c, NLLS_ERR_INVALID_ARG, "NLLS_FLAG_PRESHARDED: install the all-reduce (nlls_comm_init_rccl / nlls_set_allreduce) before nlls_upload_structure -- the reduced system's layout is agreed on collectively");
+        double h[8] = {(double)bw, (double)c->nbd, (double)c->n_band, (double)c->nred, -(double)c->nbd, -(double)c->n_band, -(double)c->nred, 0.0};
+        HIPCHK(hipMemcpyAsync(c->scalars.p + 16, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+        { const int rc = comm_reduce(c, c->scalars.p + 16, 8, NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
+        HIPCHK(hipMemcpyAsync(h, c->scalars.p + 16, sizeof h, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+        if (h[1] != -h[4] || h[2] != -h[5] || h[3] != -h[6]) return fail(c, NLLS_ERR_INVALID_ARG, "NLLS_FLAG_PRESHARDED: the ranks' reduced systems differ in size or border (the reduced variables must be the same on every rank)");
+        bw = (int64_t)h[0];
+    }
     { std::vector<SchurCopy> blks;
       if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q];
           blks.push_back(SchurCopy{c->it_nzval[q], (uint32_t)c->boffsets[row], (uint32_t)c->boffsets[col], (uint16_t)c->blocksizes[row], (uint16_t)c->blocksizes[col]}); }

@@ -31,8 +31,13 @@ class ShardedLS(MultiVariateLSgpu):
     dist: torch.distributed (initialised by the caller: "nccl" = RCCL on the GPU box).  host_staged=True routes the
     buffer reductions through host copies (gloo), which lets several ranks share ONE GPU in tests."""
 
-    def __init__(self, problem, unfixed, flags=0, device=0, rank=0, world=1, dist=None, host_staged=False, force_collectives=False):
+    def __init__(self, problem, unfixed, flags=0, device=0, rank=0, world=1, dist=None, host_staged=False, force_collectives=False, presharded=False):
+        """presharded: `problem` is already THIS rank's share (all reduced variables + its own eliminated ones, its own cost blocks:
+        synthetic.create_ba_problem_shard) -- NLLS_FLAG_PRESHARDED; nothing is partitioned by the library."""
         self.rank, self.world, self.dist, self.host_staged = rank, world, dist, host_staged
+        self.device = int(device)
+        if presharded and world > 1:
+            flags |= _capi.FLAG_PRESHARDED
         # force_collectives: take the local / reduce / finish route even with one rank (rehearses the RCCL plumbing on one GPU)
         self.sharded = world > 1 or (force_collectives and dist is not None)
         self._trial = None                         # ((x'Hx, g'x), max|x|, |x|) of the last lm_trial, until the step changes
@@ -53,16 +58,7 @@ class ShardedLS(MultiVariateLSgpu):
         # lm_trial / cost below are then plain calls of the same entry points as on one GPU, and the library's own outer loop
         # (nlls_lm_iterations) drives the sharded trials: no Python between two trials.  The Python route further down (solve_local /
         # all-reduce / solve_finish) remains for plain solve() calls (Newton, dogleg: they want x on every rank).
-        self.native_collectives = False
-        if self.sharded:
-            if host_staged:
-                self.ctx.set_allreduce(self._staged_allreduce)
-            else:
-                ids = [_capi.Context.comm_unique_id() if rank == 0 else None]
-                if world > 1:
-                    dist.broadcast_object_list(ids, src=0)
-                self.ctx.comm_init_rccl(ids[0])
-            self.native_collectives = True
+        self.native_collectives = self.sharded                 # (installed in _make_context: a pre-sharded upload is itself collective)
         sh = self.ctx.shard_info()
         self.local_nobs, self.local_nnz_data, self.local_ndof_written = sh["local_ncost"], sh["local_nnz_data"], sh["local_ndof"]
 
@@ -71,6 +67,14 @@ class ShardedLS(MultiVariateLSgpu):
         rank, world = self._pre_upload
         if world > 1:
             ctx.set_shard(rank, world)
+        if self.sharded:
+            if self.host_staged:
+                ctx.set_allreduce(self._staged_allreduce)
+            else:
+                ids = [_capi.Context.comm_unique_id() if rank == 0 else None]
+                if world > 1:
+                    self.dist.broadcast_object_list(ids, src=0)
+                ctx.comm_init_rccl(ids[0])
         return ctx
 
     def _staged_allreduce(self, ptr, count, op, stream):

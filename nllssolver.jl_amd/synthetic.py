@@ -64,6 +64,66 @@ def create_ba_problem(ncameras, nlandmarks, propvisible, seed=1, robust=None, ou
     return problem
 
 
+def create_ba_problem_shard(ncameras, nlandmarks, propvisible, rank, world, seed=1, robust=None, outlier_frac=0.0, outlier_sigma=0.0, pointnoise=0.0, posenoise=0.0):
+    """Rank `rank`'s share of create_ba_problem(ncameras, nlandmarks, ...) WITHOUT building the whole: all cameras (the same values on every rank) and
+    the contiguous range of landmarks [l0, l1) this rank owns, with exactly the cost blocks of the whole problem that touch them (same visibility
+    threshold, camera-major order).  For NLLS_FLAG_PRESHARDED (ShardedLS(..., presharded=True)): each of N processes generates and uploads 1/N
+    of an N-times larger job.  Landmark coordinates and outliers come from per-rank random streams (a workload, not a parity target; the
+    structure is the reference generator's, test/optimizeba.jl:6-35)."""
+    rng = np.random.default_rng(seed)
+    cams = rng.standard_normal((ncameras, 6)) + np.array([1.0, 0, 0, 0, 1.0, 0])
+    l0, l1 = (nlandmarks * rank) // world, (nlandmarks * (rank + 1)) // world
+    t = np.linspace(2.0, ncameras - 1.0, nlandmarks) if nlandmarks > 1 else np.array([2.0])
+    kth = int(np.ceil(ncameras * nlandmarks * propvisible))
+    def count(tau):
+        lo = np.maximum(np.ceil(t - tau), 1); hi = np.minimum(np.floor(t + tau), ncameras)
+        return int(np.maximum(hi - lo + 1, 0).sum())
+    a, b = 0.0, float(ncameras)
+    for _ in range(200):
+        m = 0.5 * (a + b)
+        if count(m) >= kth:
+            b = m
+        else:
+            a = m
+        if b - a <= np.spacing(b):
+            break
+    thr = b
+    tl = t[l0:l1]
+    lo = np.maximum(np.ceil(tl - thr), 1).astype(np.int64); hi = np.minimum(np.floor(tl + thr), ncameras).astype(np.int64)
+    cnt = np.maximum(hi - lo + 1, 0)
+    lm = np.repeat(np.arange(1, l1 - l0 + 1), cnt)                 # local landmark numbers, 1-based
+    start = np.repeat(lo, cnt); pos = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    cam = start + pos
+    order = np.lexsort((lm, cam)); cam, lm = cam[order], lm[order]
+    rng_l = np.random.default_rng([seed, 7919, rank])
+    pts = rng_l.random((l1 - l0, 3)) + np.array([-0.5, -0.5, 10.0])
+    problem = NLLSProblem()
+    # starting point (perturb_ba_problem's role): the cameras' noise from the SHARED stream (every rank must start from the same cameras)
+    problem.addvariables(cams + rng.standard_normal(cams.shape) * posenoise); problem.addvariables(pts + rng_l.standard_normal(pts.shape) * pointnoise)
+    c, X = cams[cam - 1], pts[lm - 1]
+    meas = np.stack([(c[:, 0:3] * X).sum(1), (c[:, 3:6] * X).sum(1)], axis=1)
+    if outlier_frac > 0:
+        bad = rng_l.random(meas.shape[0]) < outlier_frac
+        meas[bad] += rng_l.standard_normal((int(bad.sum()), 2)) * outlier_sigma
+    problem.addcosts(K.RES_BA_AFFINE, np.stack([cam, lm + ncameras], axis=1), meas, robust)
+    return problem
+
+
+def shard_of_problem(problem, ncameras, rank, world):
+    """The share of an EXISTING two-slot (camera, landmark) problem that create_ba_problem_shard would hand to `rank`: all cameras, a contiguous
+    range of landmarks, the cost blocks that touch them (order kept).  Lets a test hold a pre-sharded run against the unsharded one."""
+    g = next(iter(problem.costs.values())); vi, da = g.arrays()
+    npts = problem.nvariables - ncameras
+    l0, l1 = (npts * rank) // world, (npts * (rank + 1)) // world
+    keep = (vi[:, 1] > ncameras + l0) & (vi[:, 1] <= ncameras + l1)
+    off = problem.var_offsets
+    q = NLLSProblem()
+    q.addvariables(problem.variables[: 6 * ncameras].reshape(ncameras, 6)); q.addvariables(problem.variables[off[ncameras + l0]: off[ncameras + l0] + 3 * (l1 - l0)].reshape(l1 - l0, 3))
+    vi2 = vi[keep].copy(); vi2[:, 1] -= l0
+    q.addcosts(g.res_kind, vi2, da[keep], g.robust)
+    return q
+
+
 def perturb_ba_problem(problem, pointnoise, posenoise, seed=2):
     """test/optimizeba.jl:38-47."""
     rng = np.random.default_rng(seed)

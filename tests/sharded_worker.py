@@ -32,6 +32,8 @@ def main():
     seed = int(sys.argv[5]) if len(sys.argv) > 5 else 21
     if seed < 0:
         return singular_point_block(rank, world, dist, staged)
+    if seed >= 5000:
+        return presharded(rank, world, dist, staged, seed)
     rng = np.random.default_rng(seed)
     ncr = int(rng.integers(12, 90))             # (sharding partitions by eliminated block: stay within what the Schur kernels take)
     shape = (40, 2000, 0.15) if seed == 21 else (ncr, int(rng.integers(300, 4000)), float(rng.uniform(4.0, 10.0)) / ncr)
@@ -117,6 +119,43 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: sharded == unsharded (cost {cs:.6e}, owned {info['local_ncost']} of {p.ncosts()} cost blocks)")
+
+
+def presharded(rank, world, dist, staged, seed):
+    """NLLS_FLAG_PRESHARDED: every rank uploads ONLY its share (all cameras + its own points and their cost blocks, its own variable numbering);
+    the library's outer loop over the collective entry points must reach what the unsharded device reaches on the whole problem."""
+    import nllssolver_jl_amd as N
+    from nllssolver_jl_amd import synthetic, _capi, iterators as It, optimizer as Opt
+    from nllssolver_jl_amd.dist import ShardedLS
+    from nllssolver_jl_amd.linearsystem import MultiVariateLSgpu
+    ncam, npts = 60, 3000
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, 0.12, seed=seed, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    mine = synthetic.shard_of_problem(p, ncam, rank, world)
+    counts = [None] * world
+    dist.all_gather_object(counts, mine.ncosts()); assert sum(counts) == p.ncosts(), (counts, p.ncosts())
+    def run(ls, prob, native):
+        data = Opt.NLLSInternal(ls, time.perf_counter_ns())
+        loop = Opt.OuterLoop(prob, N.NLLSOptions(maxiters=5), data, It.LevMarData(), It.iterate_levmar, N.nullcallback, native=native)
+        loop.start()
+        while (loop.iterations(1 << 30) if native else loop.iteration()) == 0:
+            pass
+        return data
+    ref = MultiVariateLSgpu(p, np.ones(p.nvariables, bool)); dr = run(ref, p, True)
+    sh = ShardedLS(mine, np.ones(mine.nvariables, bool), rank=rank, world=world, dist=dist, host_staged=staged, presharded=True)
+    assert sh.info.nreduced_dof == ref.info.nreduced_dof and sh.info.bandwidth == ref.info.bandwidth, (sh.info.bandwidth, ref.info.bandwidth)   # the agreed layout
+    ds = run(sh, mine, True)
+    assert np.isclose(ds.startcost, dr.startcost, rtol=1e-12) and np.isclose(ds.bestcost, dr.bestcost, rtol=1e-9), (ds.bestcost, dr.bestcost)
+    assert ds.iternum == dr.iternum and ds.linearsolvers == dr.linearsolvers
+    vr, vs = ref.variables(_capi.VARS_CURRENT), sh.ctx.get_variables(_capi.VARS_CURRENT)
+    assert np.allclose(vs[: 6 * ncam], vr[: 6 * ncam], rtol=1e-7, atol=1e-10)                       # every rank holds the cameras
+    l0, l1 = (npts * rank) // world, (npts * (rank + 1)) // world
+    assert np.allclose(vs[6 * ncam:], vr[6 * ncam + 3 * l0: 6 * ncam + 3 * l1], rtol=1e-7, atol=1e-10)   # ... and its own points
+    # the generator of a rank's share alone: the same structure as the slice of the whole (counts per rank), nothing else built
+    g = synthetic.create_ba_problem_shard(ncam, npts, 0.12, rank, world, seed=seed)
+    assert g.ncosts() == mine.ncosts() and g.nvariables == mine.nvariables
+    assert np.array_equal(next(iter(g.costs.values())).arrays()[0], next(iter(mine.costs.values())).arrays()[0])
+    ref.close(); sh.close(); dist.barrier(); dist.destroy_process_group()
+    print(f"rank {rank}: sharded == unsharded (presharded: {mine.ncosts()} of {p.ncosts()} cost blocks uploaded, best cost {ds.bestcost:.6e})")
 
 
 def singular_point_block(rank, world, dist, staged):
