@@ -670,14 +670,23 @@ __global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws
 // ---------------------------------------------------------------------------------------------------
 // backward pass of one level: one workgroup per block eliminated at that level
 // ---------------------------------------------------------------------------------------------------
-struct BcrBackArgs { BcrGeom g; BcrChain ch; double* xr; int root; int* status; };
+struct BcrBackArgs { BcrGeom g; BcrChain ch; double* xr; int root; int* status; const BcrElim* elims; int* done; int seq; };
+// unknowns that cross workgroups INSIDE one launch (FUSED): relaxed agent-scope accesses -- they go past the (per-XCD, mutually incoherent) L2s
+// to the memory side, so that no cache has to be written back or invalidated; the order "unknowns, then flag" is this wave's s_waitcnt
+BCR_DEV void bcr_xstore(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+BCR_DEV double bcr_xload(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // NT wavefronts: wave J owns the 16 unknowns of tile column J.  Every load of the factor is issued before anything is
 // waited for (one memory round trip per level); the unknowns of the neighbours (and of the border) go through LDS.
-template <int NT>
+// FUSED: ONE launch for the whole backward pass.  Workgroup w takes the block eliminated (N - 1 - w)-th: the root first, then level by level
+// down to the first one -- whatever a workgroup waits for belongs to a workgroup with a smaller index, which was dispatched before it, so the
+// wait ends whether or not all of them fit the chip at once.  A block publishes its unknowns and then a flag (= the solve's sequence number:
+// nothing to reset between solves); its dependants have requested their own factor tiles long before and spin on two flags.
+template <int NT, bool FUSED>
 __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BcrGeom& g = a.g;
-    const BcrElim job = bcr_job(a.ch, blockIdx.x);
+    const BcrElim job = FUSED ? a.elims[g.N - 1 - (int)blockIdx.x] : bcr_job(a.ch, blockIdx.x);
+    const bool root = FUSED ? blockIdx.x == 0 : a.root != 0;
     constexpr int RXT = 2 * NT + 1, NO = NT * (NT - 1) / 2, b = 16 * NT, NTH = 64 * NT;
     const int nbd = g.nbd, nbr = nbd + 1;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, gq = lane >> 4;
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
     // the unknowns of the neighbours and of the border that this block's rows multiply: requested NOW, beside the factor's tiles (one memory
     // round trip per level instead of two; the root forms the border unknowns itself first and takes the loop below)
     double xpre = 0.0;
-    if (!a.root && tid < RXT * 16) {
+    if (!FUSED && !root && tid < RXT * 16) {
         const int R = tid >> 4, q = tid & 15;
         if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) xpre = a.xr[row]; } }
         else if (R < 2 * NT) { if (job.r >= 0) { const int row = b * job.r + 16 * (R - NT) + q; if (row < g.n_band) xpre = a.xr[row]; } }
@@ -714,7 +723,19 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
 #pragma unroll
         for (int q = 0; q < MQ; ++q) { const int w = tid + q * NTH; if (w < NO * 256) Mdl[w] = mdv[q]; }
     }
-    if (a.root) {
+    if (FUSED && !root) {
+        // wait for the neighbours (and, through them, the root's border unknowns): one lane polls, the factor's loads above are in flight meanwhile
+        if (tid == 0) { for (int q = 0; q < 2; ++q) { const int nb = q ? job.r : job.l; if (nb < 0) continue;
+                while (__hip_atomic_load(a.done + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) __builtin_amdgcn_s_sleep(2); } }
+        __syncthreads();
+        if (tid < RXT * 16) {
+            const int R = tid >> 4, q = tid & 15;
+            if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) xpre = bcr_xload(a.xr + row); } }
+            else if (R < 2 * NT) { if (job.r >= 0) { const int row = b * job.r + 16 * (R - NT) + q; if (row < g.n_band) xpre = bcr_xload(a.xr + row); } }
+            else xpre = q < nbd ? bcr_xload(g.ws + g.oxb + q) : (q == nbd ? -1.0 : 0.0);
+        }
+    }
+    if (root) {
         if (nbd > 0) {
             // corner = cp[0] - sum_i cp[1 + i], blocks in index order (fixed order: reproducible)
             for (int e = tid; e < 256; e += NTH) { double v = g.ws[g.ocp + e]; for (int i = 0; i < g.N; ++i) v -= g.ws[g.ocp + (size_t)(1 + i) * 256 + e]; Cl[e] = v; }
@@ -730,11 +751,11 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
                 for (int r = nbd - 1; r >= 0; --r) { double v2 = Cl[nbd * 16 + r]; for (int r2 = r + 1; r2 < nbd; ++r2) v2 -= Cl[r2 * 16 + r] * xb[r2]; xb[r] = v2; }
             }
             __syncthreads();
-            if (tid < nbd) { g.ws[g.oxb + tid] = xb[tid]; a.xr[g.n_band + tid] = xb[tid]; }
+            if (tid < nbd) { if (FUSED) bcr_xstore(g.ws + g.oxb + tid, xb[tid]); else g.ws[g.oxb + tid] = xb[tid]; a.xr[g.n_band + tid] = xb[tid]; }
         }
-    } else if (tid < nbd) xb[tid] = g.ws[g.oxb + tid];
+    } else if (tid < nbd) xb[tid] = FUSED ? bcr_xload(g.ws + g.oxb + tid) : g.ws[g.oxb + tid];
     __syncthreads();
-    if (!a.root) { if (tid < RXT * 16) xs[tid] = xpre; }
+    if (!root) { if (tid < RXT * 16) xs[tid] = xpre; }
     else for (int t = tid; t < RXT * 16; t += NTH) {
         const int R = t >> 4, q = t & 15; double v = 0.0;
         if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) v = a.xr[row]; } }
@@ -769,10 +790,14 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
             s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
             if (gq == 0) {
                 const double x = tt[16 * J + c] - s; xi[16 * J + c] = x;
-                const int row = b * job.i + 16 * J + c; if (row < g.n_band) a.xr[row] = x;
+                const int row = b * job.i + 16 * J + c; if (row < g.n_band) { if (FUSED) bcr_xstore(a.xr + row, x); else a.xr[row] = x; }
             }
         }
         __syncthreads();
+    }
+    if (FUSED) {      // every unknown of this block has left this wave (vmcnt) before the flag does
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) __hip_atomic_store(a.done + job.i, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -862,11 +887,14 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     }
     if (hipSuccess != ws.alloc(off) || hipSuccess != d_elim.upload(elims) || hipSuccess != d_upd.upload(upds)) { if (err) *err = "block cyclic reduction workspace alloc"; return NLLS_ERR_HIP; }
     if (hipSuccess != hipMemset(ws.p, 0, off * sizeof(double))) { if (err) *err = "workspace memset"; return NLLS_ERR_HIP; }
+    { std::vector<int32_t> z((size_t)N, 0); if (hipSuccess != d_done.upload(z)) { if (err) *err = "flag alloc"; return NLLS_ERR_HIP; } seq = 0; }
+    { const char* e = getenv("NLLS_BCR_LEVEL_BACKWARD"); fused_backward = !(e && e[0] == '1'); }      // A/B switch: one backward launch per level, as in round 2
     geom.ws = ws.p;
     panel_lds = sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS);
     back_lds = sizeof(double) * ((size_t)RXT * 16 + NT * 64 + 2 * NT * 16 + (size_t)NO * 256 + 256 + 16);
     { const char* e = getenv("NLLS_BCR_CHROWS_SLOTS"); chrows_slots = e ? atoi(e) : 256; }
-    launches = 1; for (auto& lv : levels) launches += 2 + (lv.nupd > 0);
+    launches = 1; for (auto& lv : levels) launches += 1 + (lv.nupd > 0) + (fused_backward ? 0 : 1);
+    launches += fused_backward ? 1 : 0;
     {   // matrix-core instructions per solve (2048 flop each): panel kernel per workgroup + update kernel per job
         mfma_issued = 0;
         for (const BcrLevel& lv : levels) for (size_t e = lv.elim_off; e < lv.elim_off + (size_t)lv.nelim; ++e) {
@@ -903,8 +931,13 @@ static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel&
 }
 template <int NT>
 static void bcr_launch_back(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, double* xr, int root, int* status) {
-    BcrBackArgs ba{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, xr, root, status};
-    hipLaunchKernelGGL((bcr_backward_kernel<NT>), dim3((unsigned)lv.nelim), dim3(64 * NT), S.back_lds, st, ba);
+    BcrBackArgs ba{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, xr, root, status, nullptr, nullptr, 0};
+    hipLaunchKernelGGL((bcr_backward_kernel<NT, false>), dim3((unsigned)lv.nelim), dim3(64 * NT), S.back_lds, st, ba);
+}
+template <int NT>
+static void bcr_launch_back_all(const BcrSolver& S, hipStream_t st, double* xr, int* status) {
+    BcrBackArgs ba{S.geom, BcrChain{0, 1, 0, 0}, xr, 0, status, S.d_elim.p, S.d_done.p, ++S.seq};
+    hipLaunchKernelGGL((bcr_backward_kernel<NT, true>), dim3((unsigned)S.N), dim3(64 * NT), S.back_lds, st, ba);
 }
 
 int BcrSolver::enqueue(hipStream_t st, const double* Sb, double* xr, int* status, double pivot_floor) const {
@@ -914,7 +947,10 @@ int BcrSolver::enqueue(hipStream_t st, const double* Sb, double* xr, int* status
 #define BCR_FWD(n) bcr_launch_level<n>(*this, st, lv, status, pivot_floor)
     for (const BcrLevel& lv : levels) BCR_NT_SWITCH(BCR_FWD)
 #define BCR_BWD(n) bcr_launch_back<n>(*this, st, levels[li], xr, li + 1 == levels.size() ? 1 : 0, status)
-    for (size_t li = levels.size(); li-- > 0;) BCR_NT_SWITCH(BCR_BWD)
+#define BCR_BWD_ALL(n) bcr_launch_back_all<n>(*this, st, xr, status)
+    if (fused_backward) { BCR_NT_SWITCH(BCR_BWD_ALL) }
+    else for (size_t li = levels.size(); li-- > 0;) BCR_NT_SWITCH(BCR_BWD)
+#undef BCR_BWD_ALL
 #undef BCR_FWD
 #undef BCR_BWD
 #undef BCR_NT_SWITCH

@@ -30,6 +30,8 @@ struct BcrSolver {
     bool ready = false;
     std::vector<BcrLevel> levels;                 // elimination levels, the root block last
     DevBuf<double> ws; DevBuf<BcrElim> d_elim; DevBuf<BcrUpd> d_upd;
+    DevBuf<int32_t> d_done; mutable int seq = 0;   // fused backward pass: per block, the sequence number of the solve whose unknowns it has published
+    bool fused_backward = true;
     BcrGeom geom{};
     size_t panel_lds = 0, back_lds = 0;
     int chrows_slots = 256;                       // a level's panel launch uses fewer X rows per workgroup while its workgroups still fit this many CUs (NLLS_BCR_CHROWS_SLOTS=0: always three)
@@ -42,7 +44,7 @@ struct BcrSolver {
     // pivot_floor > 0 (undamped Newton / dogleg steps on a gauge-free problem: S is singular): a pivot that has lost more than that
     // fraction of its original diagonal entry is treated as infinite -- its unknown comes out 0 instead of (rounding) / (rounding)
     int enqueue(hipStream_t st, const double* Sb, double* xr, int* status, double pivot_floor = 0.0) const;
-    void release() { ws.release(); d_elim.release(); d_upd.release(); levels.clear(); ready = false; }
+    void release() { ws.release(); d_elim.release(); d_upd.release(); d_done.release(); levels.clear(); ready = false; }
 };
 
 // dense reduced system (nlls_solve.hip): panel factorisation of block column k (64 columns) and the backward pass's diagonal block

@@ -217,7 +217,9 @@ struct nlls_ctx {
     int64_t n_fast_narrow = 0;               // fast supernodes with nd + 1 <= 64 come first in d_fast_groups
     int64_t n_fast_n60 = 0;                  // ... and among them those with nd <= 60 (two tile waves suffice) first of all
     int max_elim_dim = 0, max_nbr_dof = 0;
-    bool elim_use_acc = false; size_t elim_lds = 0;
+    // generic (LDS-staged) elimination, per supernode class: d_slow_groups = [supernodes whose pair accumulators fit in LDS | those that add
+    // every member's products straight into S]; each class is one launch with the LDS its own widest supernode needs (up to gfx950's 160 KB)
+    int64_t n_slow_acc = 0; int slow_nd_acc = 0, slow_nd_noacc = 0; size_t elim_lds_acc = 0, elim_lds_noacc = 0;
     int64_t n_band = 0; int nbd = 0, bw = 0;   // reduced ordering: [banded part | border dof | rhs]
     int solve_mode = 0, band_CH = 0, band_H = 0, band_SEG = 0, band_NSEG = 0;
     bool band_blocked = true;                // blocked (MFMA) band factorisation when the bandwidth allows

@@ -2393,10 +2393,16 @@ int enqueue_solve_local(nlls_ctx* c) {
         }
     }
     if (c->nelim_groups > 0) {
-        if (c->n_slow_groups > 0)
-            hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)c->n_slow_groups), dim3(64), c->elim_lds, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
-                               c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->d_slow_groups.p, c->lambda, c->max_elim_dim, c->max_nbr_dof,
-                               c->elim_use_acc ? 1 : 0, L, c->s_ptr(), c->d_status.p);
+        if (c->n_slow_groups > 0) {
+            // (more than 64 KB of dynamic LDS has to be asked for once per process)
+            static size_t lds_granted = 0; const size_t want = std::max(c->elim_lds_acc, c->elim_lds_noacc);
+            if (want > lds_granted) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_elim_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want)); lds_granted = want; }
+            const int64_t nacc = c->n_slow_acc, nno = c->n_slow_groups - nacc;
+            if (nacc > 0) hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)nacc), dim3(64), c->elim_lds_acc, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
+                               c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->d_slow_groups.p, c->lambda, c->max_elim_dim, c->slow_nd_acc, 1, L, c->s_ptr(), c->d_status.p);
+            if (nno > 0) hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)nno), dim3(64), c->elim_lds_noacc, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
+                               c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->d_slow_groups.p + nacc, c->lambda, c->max_elim_dim, c->slow_nd_noacc, 0, L, c->s_ptr(), c->d_status.p);
+        }
 #define LAUNCH_TILED(DV) do { const int64_t nel = (int64_t)c->d_elim_diag.n; \
             hipLaunchKernelGGL((schur_cinv_kernel<DV>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, c->stream, c->A.p, c->d_elim_diag.p, c->d_elim_dim.p, nel, c->lambda, c->Cinv.p, c->d_status.p); \
             const int64_t n60 = c->n_fast_n60, nnar = c->n_fast_narrow - c->n_fast_n60, nwid = c->n_fast_groups - c->n_fast_narrow;   /* d_fast_groups: nd <= 60, then the other narrow supernodes, then the wide ones */ \

@@ -607,6 +607,21 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         fastg.insert(fastg.begin(), fastg60.begin(), fastg60.end());
         c->n_fast_narrow = (int64_t)fastg.size(); c->fast_maxk_narrow = fast_maxk;
         fastg.insert(fastg.end(), fastw.begin(), fastw.end());
+        // the generic kernel stages [C | E | Y] of a member (and, where they fit, the supernode's pair accumulators) in LDS: a supernode is limited
+        // by ITS OWN width -- a point seen by 40 cameras costs its own workgroup more LDS and more atomics, not the whole problem its Schur
+        // path -- and by the 160 KB of a gfx950 CU (150 KB budget: 328 six-dof neighbours of a three-dof block)
+        constexpr size_t ELIM_LDS_BUDGET = 150 * 1024;
+        auto lds_base = [](size_t nd, size_t dv) { return sizeof(double) * (dv * dv + dv * nd + dv * (nd + 1)) + 16 * nd + 12 * nd + 16; };
+        auto lds_acc = [](size_t nd) { return sizeof(double) * (nd * (nd + 1) / 2 + nd); };
+        { std::vector<uint32_t> sacc, snoacc; c->slow_nd_acc = c->slow_nd_noacc = 0;
+          const size_t dvm = (size_t)c->max_elim_dim;
+          for (uint32_t gi : slowg) { int nd = 0; for (int64_t p = eptr[egroup[gi]]; p < eptr[egroup[gi] + 1]; ++p) nd += enbr[p].dim;
+              if (lds_base((size_t)nd, dvm) > ELIM_LDS_BUDGET) { c->err_sub = NLLS_SUB_SCHUR_SHAPE; return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated block with too many neighbours for the LDS-staged Schur kernel (retry with NLLS_FLAG_NO_SCHUR)"); }
+              if (lds_base((size_t)nd, dvm) + lds_acc((size_t)nd) <= ELIM_LDS_BUDGET) { sacc.push_back(gi); c->slow_nd_acc = std::max(c->slow_nd_acc, nd); }
+              else { snoacc.push_back(gi); c->slow_nd_noacc = std::max(c->slow_nd_noacc, nd); } }
+          c->n_slow_acc = (int64_t)sacc.size();
+          slowg = sacc; slowg.insert(slowg.end(), snoacc.begin(), snoacc.end());
+          c->elim_lds_acc = lds_base((size_t)c->slow_nd_acc, dvm) + lds_acc((size_t)c->slow_nd_acc); c->elim_lds_noacc = lds_base((size_t)c->slow_nd_noacc, dvm); }
         c->n_fast_groups = (int64_t)fastg.size(); c->n_slow_groups = (int64_t)slowg.size(); c->fast_dv = fast_dv; c->fast_maxk = fast_maxk;
         fastg_all = fastg;
         std::vector<uint32_t> slowb; for (uint32_t gi : slowg) for (uint32_t v = egroup[gi]; v < egroup[gi + 1]; ++v) slowb.push_back(v);
@@ -622,14 +637,6 @@ int build_schur(nlls_ctx* c, int32_t flags) {
           if (hipSuccess != c->d_elim_desc.upload(desc) || hipSuccess != c->d_elim_rc.upload(rcflat)) return fail(c, NLLS_ERR_HIP, "supernode descriptor upload"); }
         if (hipSuccess != c->d_fast_groups.upload(fastg) || hipSuccess != c->d_slow_groups.upload(slowg) || hipSuccess != c->d_slow_blocks.upload(slowb) ||
             hipSuccess != c->Cinv.alloc(std::max<size_t>(1, ediag.size() * (size_t)std::max(1, fast_dv * fast_dv)))) return fail(c, NLLS_ERR_HIP, "group list upload");
-        // LDS budget of the elimination kernel: C, E, Y, pair accumulators, column map
-        const size_t nd = c->max_nbr_dof, dv = c->max_elim_dim;
-        size_t base = sizeof(double) * (dv * dv + dv * nd + dv * (nd + 1)) + 16 * nd + 12 * nd + 16;
-        size_t accb = sizeof(double) * (nd * (nd + 1) / 2 + nd);
-        if (base > 60 * 1024) { c->err_sub = NLLS_SUB_SCHUR_SHAPE; return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated block with too many neighbours for the LDS-staged Schur kernel (retry with NLLS_FLAG_NO_SCHUR)"); }
-        c->elim_use_acc = (base + accb <= 64 * 1024);
-        c->elim_lds = base + (c->elim_use_acc ? accb : 0);
-        if (!c->elim_use_acc && c->n_slow_groups > 0) { c->err_sub = NLLS_SUB_SCHUR_SHAPE; return fail(c, NLLS_ERR_UNSUPPORTED, "eliminated blocks with too many neighbour dof for the LDS accumulators (retry with NLLS_FLAG_NO_SCHUR)"); }
         if (hipSuccess != c->d_elim_ptr.upload(eptr) || hipSuccess != c->d_elim_nbr.upload(enbr) || hipSuccess != c->d_elim_diag.upload(ediag) ||
             hipSuccess != c->d_elim_boff.upload(eboff) || hipSuccess != c->d_elim_dim.upload(edim) || hipSuccess != c->d_elim_group.upload(egroup)) return fail(c, NLLS_ERR_HIP, "schur upload");
     }

@@ -124,6 +124,32 @@ def shard_of_problem(problem, ncameras, rank, world):
     return q
 
 
+def widen_visibility(problem, ncameras, wide):
+    """Real bundle-adjustment graphs have a tail of landmarks seen by many cameras (test/optimizeba.jl:22-23 leaves visibility a free parameter).
+    `wide` = {landmark (1-based among the landmarks): number of cameras}: each listed landmark gets noiseless measurements from a window of that
+    many consecutive cameras around the ones that already see it (all cameras when the number reaches ncameras).  Call BEFORE perturbing: the
+    variables are then still the ground truth the measurements are generated from."""
+    g = next(iter(problem.costs.values())); vi, da = g.arrays()
+    off = problem.var_offsets; v = problem.variables
+    have = {}
+    for c, l in vi:
+        have.setdefault(int(l) - ncameras, set()).add(int(c))
+    add_vi, add_da = [], []
+    for lm, k in wide.items():
+        seen = have.get(lm, set()); k = min(int(k), ncameras)
+        mid = int(round(np.mean(sorted(seen)))) if seen else ncameras // 2
+        lo = max(1, min(mid - k // 2, ncameras - k + 1))
+        X = v[off[ncameras + lm - 1]: off[ncameras + lm - 1] + 3]
+        for c in range(lo, lo + k):
+            if c in seen:
+                continue
+            cam = v[off[c - 1]: off[c - 1] + 6]
+            add_vi.append((c, ncameras + lm)); add_da.append((cam[0:3] @ X, cam[3:6] @ X))
+    if add_vi:
+        g.set_arrays(np.concatenate([vi, np.array(add_vi, dtype=vi.dtype)]), np.concatenate([da, np.array(add_da)]))
+    return problem
+
+
 def perturb_ba_problem(problem, pointnoise, posenoise, seed=2):
     """test/optimizeba.jl:38-47."""
     rng = np.random.default_rng(seed)

@@ -86,6 +86,26 @@ def test_standalone_bounded_scalar_variables(shared, robust):
     assert np.all(q.variables[0::2] > 0) and np.all((q.variables[1::2] > 0) & (q.variables[1::2] < 1))
 
 
+def test_wide_visibility_keeps_the_schur_path():
+    """Real BA visibility at BASELINE config 3's size (100 cameras x 10k points): 1 % of the points are seen by 40 cameras and one by all 100.
+    The reference's solve takes any sparsity (src/linearsolver.jl:28-32, src/linearsystem.jl:91-124); here a wide point must cost ITS OWN
+    supernode more (LDS-staged generic kernel, up to the 160 KB of a CU; no pair accumulators beyond 29 cameras) and nobody else anything:
+    the problem stays on the Schur path (no NLLS_SUB_SCHUR_SHAPE retry to the full dense system), the reduced camera system -- no longer a
+    narrow band -- is solved by the dense MFMA LDL', x matches the oracle and LM converges to the oracle's cost."""
+    ncam, npts = 100, 10_000
+    p = synthetic.create_ba_problem(ncam, npts, 0.1, seed=11, robust=N.HuberKernel(0.05), outlier_frac=0.02, outlier_sigma=0.05)
+    rng = np.random.default_rng(4)
+    wide = {int(l): 40 for l in rng.choice(np.arange(1, npts + 1), size=npts // 100, replace=False)}
+    wide[int(rng.integers(1, npts + 1))] = ncam
+    p = synthetic.perturb_ba_problem(synthetic.widen_visibility(p, ncam, wide), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
+    assert info.nreduced_dof == 6 * ncam and info.solve_mode == 1                 # the camera system, dense
+    q = synthetic.perturb_ba_problem(synthetic.widen_visibility(synthetic.create_ba_problem(ncam, npts, 0.1, seed=11, robust=N.HuberKernel(0.05), outlier_frac=0.02, outlier_sigma=0.05), ncam, wide), 1e-3, 1e-3)
+    op = oracle_problem(q); ro = op.optimize(iterator=1, maxiters=8)
+    rg = N.optimize(q, N.NLLSOptions(maxiters=8))
+    assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
+
+
 def test_ba_sparse_small():          # test/optimizeba.jl:71 shape (10 x 50 @ 0.3 -> sparse path)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 50, 0.3, seed=1), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)

@@ -22,6 +22,9 @@ for seed in range(lo, hi):
             # a run that stops at maxiters (termination bit 256) has not converged: its cost still moves in the 6th digit from one iteration to
             # the next, and device and oracle need not have taken the same number of rejected trials on the way
             unconverged = bool((res.termination | ores.termination) & 256)
+            if os.environ.get("STRESS_DETAIL"):      # both runs' iteration / trial counts beside the costs (why two runs that stop at maxiters differ in the 6th digit)
+                print(f"  seed {seed}: device cost {res.bestcost:.12e} in {res.niterations} iterations / {res.linearsolvers} trials (termination {res.termination}); "
+                      f"oracle {ores.bestcost:.12e} in {ores.niterations} / {ores.linearsolvers} ({ores.termination}); rel diff {abs(res.bestcost - ores.bestcost) / abs(ores.bestcost):.2e}", flush=True)
             assert np.isclose(res.bestcost, ores.bestcost, rtol=1e-4 if unconverged else 1e-6), (res.bestcost, ores.bestcost, res.termination, ores.termination)
     except Exception as e:
         fails += 1; print(f"seed {seed} ncam {ncam} npts {npts} prop {prop:.3f} robust {robust} FAILED: {type(e).__name__}: {str(e)[:200]}", flush=True)
