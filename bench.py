@@ -235,6 +235,23 @@ def main():
         n, bw, mode = int(info.nreduced_dof), int(info.bandwidth), int(info.solve_mode)
         useful = float(n) * bw * bw if mode == 2 else float(n) ** 3 / 3.0
         issued = 2048.0 * solve_stats.get("bcr_mfma_issued", 0) if mode == 2 and solve_stats.get("bcr_mfma_issued", 0) else None
+        # the launcher's count of issued MFMAs against the hardware counter (profiles/pmc_mfma.json, tools/pmc_mfma.sh): quoted only when the
+        # counters were collected on THIS build of the solver and agree with it
+        issued_check = None
+        if issued:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools")); import pmc_mfma
+                rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma.json")))
+                if rec.get("solver_code_hash") != pmc_mfma.solver_code_hash():
+                    issued_check = "unchecked: profiles/pmc_mfma.json was collected on a different build of the solver sources (re-run tools/pmc_mfma.sh)"
+                else:
+                    hw = 2048.0 * rec["bcr_mfma_f64_instructions_per_solve"]
+                    if abs(hw - issued) <= 0.02 * issued:
+                        issued_check = f"confirmed by SQ_INSTS_VALU_MFMA_F64: {rec['bcr_mfma_f64_instructions_per_solve']:.0f} instructions per solve counted by the hardware"
+                    else:
+                        issued_check = f"REFUSED: the launcher counts {issued / 2048:.0f} MFMAs per solve, SQ_INSTS_VALU_MFMA_F64 {rec['bcr_mfma_f64_instructions_per_solve']:.0f}"; issued = None
+            except Exception as e:
+                issued_check = f"unchecked: {type(e).__name__}"
         roofline_solve = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
                           "kernel": {2: "block cyclic reduction of the bordered band (bcr_panel / bcr_update / bcr_backward kernels)" if solve_stats.get("bcr_levels") else "twisted blocked band LDL' (chain kernels)",
                                      1: "dense blocked LDL' (MFMA trailing update)", 0: "one-wave dense solve"}[mode],
@@ -244,7 +261,7 @@ def main():
                           # block factored redundantly by every workgroup of a panel launch, inv(L)) is kept beside them as issued_*
                           "achieved": round(useful / (reduced_ms * 1e-3) / 1e12, 4),
                           "frac": round(useful / (reduced_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5),
-                          "issued_mfma_flops": issued,
+                          "issued_mfma_flops": issued, "issued_mfma_check": issued_check,
                           "issued_achieved": round(issued / (reduced_ms * 1e-3) / 1e12, 4) if issued else None,
                           "issued_frac": round(issued / (reduced_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5) if issued else None,
                           "levels": solve_stats.get("bcr_levels"), "launches": solve_stats.get("bcr_launches"),

@@ -726,7 +726,11 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
     if (FUSED && !root) {
         // wait for the neighbours (and, through them, the root's border unknowns): one lane polls, the factor's loads above are in flight meanwhile
         if (tid == 0) { for (int q = 0; q < 2; ++q) { const int nb = q ? job.r : job.l; if (nb < 0) continue;
-                while (__hip_atomic_load(a.done + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) __builtin_amdgcn_s_sleep(2); } }
+                // (bounded: half a second on the 100 MHz constant clock, then the solve is flagged instead of hanging the queue)
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                while (__hip_atomic_load(a.done + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_readcyclecounter() - t0 > 1200000000ull) { atomicCAS(a.status, 0, 1 + g.n_band + 64); break; } } } }
         __syncthreads();
         if (tid < RXT * 16) {
             const int R = tid >> 4, q = tid & 15;
@@ -889,6 +893,9 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     if (hipSuccess != hipMemset(ws.p, 0, off * sizeof(double))) { if (err) *err = "workspace memset"; return NLLS_ERR_HIP; }
     { std::vector<int32_t> z((size_t)N, 0); if (hipSuccess != d_done.upload(z)) { if (err) *err = "flag alloc"; return NLLS_ERR_HIP; } seq = 0; }
     { const char* e = getenv("NLLS_BCR_LEVEL_BACKWARD"); fused_backward = !(e && e[0] == '1'); }      // A/B switch: one backward launch per level, as in round 2
+    // (the dispatch order of workgroups is not a contract: the fused pass is taken only while ALL its workgroups are resident at once -- 23 KB of LDS
+    //  and 5 wavefronts each, six per CU -- so that nothing waits on a workgroup that has not started)
+    if (N > 4 * 256) fused_backward = false;
     geom.ws = ws.p;
     panel_lds = sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS);
     back_lds = sizeof(double) * ((size_t)RXT * 16 + NT * 64 + 2 * NT * 16 + (size_t)NO * 256 + 256 + 16);
@@ -908,7 +915,10 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
                     m += 30;                                                   // diagonal tile: 15 pivots x (tile + inverse)
                     if (J + 1 < NT) m += 8;                                    // W_1' and the next diagonal tile's update
                     m += 4 * ((J + 1 < NT ? NT - J - 2 : 0) + RX);             // panel tiles
-                    const int mm = NT - 1 - J; if (mm > 0) m += 4 * (mm * (mm + 1) / 2 - 1 + RX * mm);   // tile-updates
+                    // tile-updates: six helper waves, batches of three jobs -- a batch issues its twelve MFMAs whether or not all three jobs exist
+                    // (the absent ones work on a spare tile: no branches), so the count is per BATCH (checked against SQ_INSTS_VALU_MFMA_F64: tools/pmc_mfma.sh)
+                    const int mm = NT - 1 - J;
+                    if (mm > 0) { const int ntot = mm * (mm + 1) / 2 - 1 + RX * mm; for (int w0 = 0; w0 < 6 && w0 < ntot; ++w0) m += 12 * ((ntot - w0 + 17) / 18); }
                 }
                 mfma_issued += m;
             }

@@ -8,6 +8,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- python tools/sweep_only.py --reps 3 > /dev/null 2> gpurun_out/${tag}_fetch.err || exit 3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- python tools/sweep_only.py --reps 3 > /dev/null 2> gpurun_out/${tag}_write.err || exit 4
 python tools/pmc_traffic.py ${tag} > gpurun_out/${tag}_traffic.json || exit 5
+# hardware counters under the matrix-core figures (f64 MFMA instructions, matrix-pipe busy cycles): profiles/pmc_mfma.json, checked by bench.py against the launcher's count
+bash tools/pmc_mfma.sh ${tag} > gpurun_out/${tag}_pmc_mfma.txt 2>&1 || exit 10
+cp profiles/pmc_mfma.json gpurun_out/${tag}_pmc_mfma.json
 cp profiles/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.json
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
 for w in ba_100x10k curvefit_10k ba_so3_500x50k ba_10kx1M; do python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_$w.json 2> gpurun_out/${tag}_bench_$w.err || exit 6; done
