@@ -270,6 +270,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     const int32_t status[1] = {(int32_t)ctx->h_scalars[10]};
+    ctx->status_known_zero = status[0] == 0;       // (nothing has touched the device's status word since: the next solve need not reset it)
     ctx->solved = true;
     ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9];
     if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");

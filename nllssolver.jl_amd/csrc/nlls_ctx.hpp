@@ -210,6 +210,7 @@ struct nlls_ctx {
     nlls::DevBuf<nlls::SchurCopy> d_blk_slow; int64_t nblk_slow = 0;   // the same as a compact list
     nlls::DevBuf<double> tE;                 // E_v s of the last solve per fast member (s = reduced solution): reused by the quadratic form
     bool tE_valid = false; int64_t n_fast_members = 0;
+    bool status_known_zero = false;          // the host has read the last solve's status and it was 0: the next solve need not reset it on the device
     bool S_zeroed = false;                   // the last solve's back-substitution left S zero-filled for the next one (saves the memset launches)
     bool step_cached = false; double c_maxabs = 0, c_sumsq = 0, c_gx = 0, c_xAx = 0, c_xx = 0;   // host copies of the last solve's step statistics
     nlls::DevBuf<double> Cinv;               // (C_v + lambda I)^-1 of the fast-path members, fast_dv^2 doubles per eliminated block

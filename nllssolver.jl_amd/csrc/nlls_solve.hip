@@ -617,6 +617,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (blockIdx.x < nnarrow) schur_elim_mfma_body<DV>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
     else schur_elim_tiled_body<DV, 2, 3>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
 }
+// ... and with the two small launches that used to stand in front of it folded in (4 + 8 us of launch latency per solve):
+//  * every supernode's workgroup inverts the diagonal blocks of ITS members first ((C_v + lambda I)^-1: one lane per member, what schur_cinv_kernel
+//    does), stores them for the back-substitution and reads them back itself behind a workgroup barrier;
+//  * the workgroups behind the supernodes ADD the reduced-reduced blocks (+ lambda on their diagonals) and the reduced right-hand side into
+//    [S | s] -- the storage is zero when the launch starts (the previous solve's back-substitution leaves it so), and sums commute with the
+//    supernodes' atomic adds, so the order inside the launch does not matter.
+struct PrepArgs { const uint32_t* red_boff; const SchurCopy* copies; double lambda; int ninit; uint32_t nfast; int* status; };
+template <int DV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_all_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                              const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
+                                                              double* __restrict__ Cinv, SLayout L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa) {
+    if (blockIdx.x >= pa.nfast) {
+        const int w = (int)(blockIdx.x - pa.nfast);
+        if (w == 0 && threadIdx.x == 0) pa.status[4] = 0;                       // (pivots dropped by the floor: only the panels of this solve add to it)
+        if (w < pa.ninit) {
+            const int i = w * 256 + threadIdx.x;
+            if (i < L.n) { atomicAdd(L.rhs(s, i), b[pa.red_boff[i]]); return; }
+            if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+            return;
+        }
+        const SchurCopy cp = pa.copies[w - pa.ninit];
+        for (int e = threadIdx.x; e < cp.rows * cp.cols; e += 256) {
+            const int i = e % cp.rows, j = e / cp.rows;
+            double v = A[cp.off + e];
+            if (cp.r == cp.c) { if (i < j) continue; if (i == j) v += pa.lambda; atomicAdd(L.at(cp.r + i, cp.c + j), v); }
+            else if (cp.r > cp.c) atomicAdd(L.at(cp.r + i, cp.c + j), v);
+            else atomicAdd(L.at(cp.c + j, cp.r + i), v);
+        }
+        return;
+    }
+    {   // the members' inverse diagonal blocks (schur_cinv_kernel's arithmetic, same bits)
+        const ElimDesc d = desc[blockIdx.x];
+        const int64_t dstride = (int64_t)DV * d.nd + DV * DV;
+        for (uint32_t m = threadIdx.x; m < d.nmem; m += 256) {
+            const double* Cg = A + d.dg0 + (int64_t)m * dstride; double C[DV * DV];
+#pragma unroll
+            for (int j = 0; j < DV; ++j)
+#pragma unroll
+                for (int i = j; i < DV; ++i) C[i + DV * j] = Cg[i + DV * j];
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                double dd = C[j + DV * j] + pa.lambda;
+#pragma unroll
+                for (int k = 0; k < j; ++k) dd -= C[j + DV * k] * C[j + DV * k] * C[k + DV * k];
+                if (dd == 0.0 || dd != dd) { atomicCAS(pa.status, 0, 1); dd = 1.0; }
+                C[j + DV * j] = dd;
+#pragma unroll
+                for (int i = j + 1; i < DV; ++i) { double t = C[i + DV * j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) t -= C[i + DV * k] * C[j + DV * k] * C[k + DV * k];
+                    C[i + DV * j] = t / dd; }
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < DV; ++c2) {
+                double y[DV];
+#pragma unroll
+                for (int i = 0; i < DV; ++i) { double t = (i == c2) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) t -= C[i + DV * k] * y[k]; y[i] = t; }
+#pragma unroll
+                for (int i = 0; i < DV; ++i) y[i] /= C[i + DV * i];
+#pragma unroll
+                for (int i = DV - 1; i >= 0; --i) { double t = y[i];
+#pragma unroll
+                    for (int k = i + 1; k < DV; ++k) t -= C[k + DV * i] * y[k]; y[i] = t; }
+#pragma unroll
+                for (int i = 0; i < DV; ++i) Cinv[(int64_t)(d.v0 + m) * (DV * DV) + i + DV * c2] = y[i];
+            }
+        }
+        __threadfence_block();          // the workgroup's own stores, then its own loads of them (workgroup scope)
+        __syncthreads();
+    }
+    if (blockIdx.x < nnarrow) schur_elim_mfma_body<DV>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
+    else schur_elim_tiled_body<DV, 2, 3>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
+}
 
 template <int DV, int NC, int TW>
 __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_slab_kernel(const double* __restrict__ A, const double* __restrict__ b,
@@ -2375,6 +2450,27 @@ int enqueue_solve_local(nlls_ctx* c) {
         return NLLS_OK;
     }
     const bool one_prepare = lead && c->info.is_sparse && c->ncopy > 0;      // status reset, s and the reduced-reduced blocks in one launch
+    // ONE launch for the whole assembly (schur_elim_all_kernel): every eliminated block on the fast path with both kinds of supernode present, one rank,
+    // [S | s] carrying the right-hand side as a row (band / dense layouts).  NLLS_ELIM_SPLIT=1 keeps the three launches (A/B).
+    static const bool split_env = [] { const char* e = getenv("NLLS_ELIM_SPLIT"); return e && e[0] == '1'; }();
+    const int64_t nfast_narrow = c->n_fast_narrow, nfast_wide = c->n_fast_groups - c->n_fast_narrow;
+    const bool all_in_one = one_prepare && !split_env && c->nranks == 1 && c->elim_mfma && c->n_slow_groups == 0 && nfast_narrow > 0 && nfast_wide > 0 &&
+                            c->solve_mode != SOLVE_SMALL && c->fast_dv >= 1 && c->fast_dv <= 3 && (int64_t)c->d_elim_diag.n == c->n_fast_members;
+    if (all_in_one) {
+        if (!c->status_known_zero) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));
+        c->status_known_zero = false;
+        if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
+        c->S_zeroed = false;
+        const int ninit = (std::max(npad, n) + 255) / 256;
+        PrepArgs pa{c->d_red_boff.p, c->d_copy.p, c->lambda, ninit, (uint32_t)c->n_fast_groups, c->d_status.p};
+        const dim3 grid((unsigned)(c->n_fast_groups + ninit + c->ncopy));
+#define LAUNCH_ALL(DV) hipLaunchKernelGGL((schur_elim_all_kernel<DV>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nfast_narrow, pa)
+        if (c->fast_dv == 3) LAUNCH_ALL(3); else if (c->fast_dv == 2) LAUNCH_ALL(2); else LAUNCH_ALL(1);
+#undef LAUNCH_ALL
+        HIPCHK(hipGetLastError());
+        return NLLS_OK;
+    }
+    c->status_known_zero = false;
     if (!one_prepare) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));
     if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
     c->S_zeroed = false;

@@ -485,7 +485,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     // (a re-upload -- or the retry without Schur elimination after an unsupported shape -- must not see the previous
     // attempt's supernode lists: the solve dispatches on these counters)
     c->n_fast_groups = 0; c->n_slow_groups = 0; c->n_fast_members = 0; c->n_fast_narrow = 0; c->n_fast_n60 = 0; c->fast_dv = 0;
-    c->tE_valid = false; c->S_zeroed = false; c->step_cached = false; c->bcr.release();
+    c->tE_valid = false; c->S_zeroed = false; c->status_known_zero = false; c->step_cached = false; c->bcr.release();
     c->elim_slab = false; c->slab.release(); c->d_slab_off.release(); c->d_slab_groups.release(); c->d_gjobs.release(); c->d_gcons.release(); c->n_gjobs = 0;
     // (the solve also dispatches on the SIZE of these lists: an upload without elimination must not inherit them)
     c->d_elim_ptr.release(); c->d_elim_nbr.release(); c->d_elim_diag.release(); c->d_elim_boff.release(); c->d_elim_dim.release(); c->d_elim_group.release();
