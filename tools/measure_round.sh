@@ -8,6 +8,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- python tools/sweep_only.py --reps 3 > /dev/null 2> gpurun_out/${tag}_fetch.err || exit 3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- python tools/sweep_only.py --reps 3 > /dev/null 2> gpurun_out/${tag}_write.err || exit 4
 python tools/pmc_traffic.py ${tag} > gpurun_out/${tag}_traffic.json || exit 5
+# ... the same two passes for BASELINE configs 3 and 5, and one pass of issue counters (vector / matrix instructions, busy cycles) over their sweeps: "compute-bound" with a counter
+for w in ba_100x10k ba_so3_500x50k; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch_$w -- python tools/sweep_only.py --workload $w --reps 3 > /dev/null 2> gpurun_out/${tag}_fetch_$w.err || exit 11
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write_$w -- python tools/sweep_only.py --workload $w --reps 3 > /dev/null 2> gpurun_out/${tag}_write_$w.err || exit 12
+  python tools/pmc_traffic.py ${tag} $w > gpurun_out/${tag}_traffic_$w.json || exit 13
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_valu_$w -- python tools/sweep_only.py --workload $w --reps 3 > /dev/null 2> gpurun_out/${tag}_valu_$w.err || exit 14
+done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_valu_ba_1kx100k -- python tools/sweep_only.py --reps 3 > /dev/null 2> gpurun_out/${tag}_valu_ba_1kx100k.err || exit 14
+cp profiles/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.json
 # hardware counters under the matrix-core figures (f64 MFMA instructions, matrix-pipe busy cycles): profiles/pmc_mfma.json, checked by bench.py against the launcher's count
 bash tools/pmc_mfma.sh ${tag} > gpurun_out/${tag}_pmc_mfma.txt 2>&1 || exit 10
 cp profiles/pmc_mfma.json gpurun_out/${tag}_pmc_mfma.json

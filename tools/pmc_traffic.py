@@ -15,14 +15,15 @@ def per_launch(pattern, counter, kernel_substr):
     return sum(vals) / len(vals) * 1024.0, len(vals), f
 
 tag, workload = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "ba_1kx100k")
-kern = "gh_fused_kernel"
-fetch, nf, ff = per_launch(f"gpurun_out/{tag}_fetch/*/*counter_collection.csv", "FETCH_SIZE", kern)
-write, nw, fw = per_launch(f"gpurun_out/{tag}_write/*/*counter_collection.csv", "WRITE_SIZE", kern)
+kern = "gh_fused"            # gh_fused_kernel (two-slot kinds) / gh_fused3_kernel (three-slot kinds: config 5)
+sfx = "" if workload == "ba_1kx100k" else "_" + workload
+fetch, nf, ff = per_launch(f"gpurun_out/{tag}_fetch{sfx}/*/*counter_collection.csv", "FETCH_SIZE", kern)
+write, nw, fw = per_launch(f"gpurun_out/{tag}_write{sfx}/*/*counter_collection.csv", "WRITE_SIZE", kern)
 path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 rec = json.load(open(path)) if os.path.exists(path) else {}
 rec[workload] = {"hbm_bytes_per_sweep": int(2 * fetch + write), "fetch_bytes_corrected": int(2 * fetch), "write_bytes": int(write), "launches_averaged": [nf, nw],
                  "sweep_code_hash": sweep_code_hash(),
                  "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/sweep_only.py (tools/measure_round.sh); KiB units; FETCH_SIZE doubled "
-                         "(gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); gh_fused_kernel (light + heavy tiles in one launch), average per launch"}
+                         "(gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); the fused accumulate launch (light + heavy tiles in one launch), average per launch"}
 json.dump(rec, open(path, "w"), indent=1)
 print(json.dumps(rec[workload]))
