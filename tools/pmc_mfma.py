@@ -22,7 +22,7 @@ def collect(pattern, solve_marker):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("nlls::", "")
         per[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k].add(r["Dispatch_Id"])
-    nsolve = max(1, len(calls.get(solve_marker, ())))
+    nsolve = max([len(calls.get(m, ())) for m in solve_marker] + [1])       # a kernel launched exactly once per solve
     out = {}
     for k, c in per.items():
         if c.get("SQ_INSTS_VALU_MFMA_F64", 0) <= 0:
@@ -35,8 +35,9 @@ def collect(pattern, solve_marker):
 
 if __name__ == "__main__":
     tag = sys.argv[1]
-    band, nb, fb = collect(f"gpurun_out/{tag}_mfma_band/*/*counter_collection.csv", "schur_cinv_kernel<3>")
-    dense, nd_, fd = collect(f"gpurun_out/{tag}_mfma_dense/*/*counter_collection.csv", "schur_cinv_kernel<3>")
+    once = ("schur_elim_all_kernel<3>", "schur_backsub_fast_kernel<3>")
+    band, nb, fb = collect(f"gpurun_out/{tag}_mfma_band/*/*counter_collection.csv", once)
+    dense, nd_, fd = collect(f"gpurun_out/{tag}_mfma_dense/*/*counter_collection.csv", once)
     bcr = sum(v["mfma_f64_instructions_per_solve"] for k, v in band.items() if k.startswith("bcr_"))
     rec = {"solver_code_hash": solver_code_hash(), "workload": "ba_1kx100k (tools/solve_only.py)", "solves_counted": {"band": nb, "dense": nd_},
            "band": band, "dense": dense, "bcr_mfma_f64_instructions_per_solve": bcr,
