@@ -106,6 +106,28 @@ def test_wide_visibility_keeps_the_schur_path():
     assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
 
 
+@pytest.mark.parametrize("ncam,npts,prop,seed", [(40, 1500, 0.12, 31), (150, 6000, 0.04, 32)])
+def test_unbanded_visibility(ncam, npts, prop, seed):
+    """The generator of test/optimizeba.jl gives every point a window of NEIGHBOURING cameras (a banded reduced system); real image collections do
+    not number their cameras that way.  The same problems with the cameras' labels shuffled: no band, few supernodes of more than one member (consecutive
+    points no longer share their camera set in memory order) -- Schur elimination with the dense reduced camera system, against the oracle."""
+    p = synthetic.create_ba_problem(ncam, npts, prop, seed=seed, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05)
+    perm = np.random.default_rng(seed).permutation(ncam)
+    g = next(iter(p.costs.values())); vi, da = g.arrays()
+    inv = np.empty(ncam, np.int64); inv[perm] = np.arange(ncam)
+    vi2 = vi.copy(); vi2[:, 0] = inv[vi[:, 0] - 1] + 1                                  # camera c is now called inv[c]
+    cams = p.variables[: 6 * ncam].reshape(ncam, 6).copy(); p.variables[: 6 * ncam] = cams[perm].ravel()   # ... and its pose moves with the label
+    g.set_arrays(vi2, da)
+    p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
+    assert info.solve_mode in (0, 1) or info.bandwidth > 6 * 10                          # not the narrow band of the unshuffled problem
+    q_vars = p.variables.copy()
+    op = oracle_problem(p); ro = op.optimize(iterator=1, maxiters=6)
+    p.variables[:] = q_vars
+    rg = N.optimize(p, N.NLLSOptions(maxiters=6))
+    assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
+
+
 def test_ba_sparse_small():          # test/optimizeba.jl:71 shape (10 x 50 @ 0.3 -> sparse path)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 50, 0.3, seed=1), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)
