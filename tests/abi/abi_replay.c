@@ -150,5 +150,25 @@ int main(int argc, char** argv) {
            (long long)ls.linearsolvers, (long long)ls.converged, check2);
     CK(ctx_destroy(ctx));
     if (!(ls.bestcost < 1e-15 * NOBS) || !(check2 < 1e-15 * NOBS) || ls.converged == 0 || ls.iternum > 100) { fprintf(stderr, "nlls_lm_iterations did not reach the zero-residual optimum\n"); return 1; }
+    /* ---- the collectives behind the ABI, from plain C (no Python, no PyTorch in this process: the library dlopens librccl.so.1 itself): one rank of one --
+     *      nlls_comm_unique_id, nlls_comm_init_rccl, then the SAME single ccall; every entry point of the loop goes through its collective route ---- */
+    if (argc > 3 && strcmp(argv[3], "--rccl") == 0) {
+        typedef int (*fn_uid)(void*); typedef int (*fn_cinit)(nlls_ctx*, const void*); typedef int (*fn_shard)(nlls_ctx*, int32_t, int32_t);
+        fn_uid comm_unique_id = (fn_uid)need(lib, "nlls_comm_unique_id"); fn_cinit comm_init_rccl = (fn_cinit)need(lib, "nlls_comm_init_rccl"); fn_shard set_shard = (fn_shard)need(lib, "nlls_set_shard");
+        unsigned char id[128];
+        ctx = NULL; CK(ctx_create(NULL, 0, &ctx));
+        CK(set_shard(ctx, 0, 1)); CK(comm_unique_id(id)); CK(comm_init_rccl(ctx, id));
+        CK(upload(ctx, NVAR, vk, vd, blockindices, 1, &grp, 0));
+        CK(set_vars(ctx, NLLS_VARS_CURRENT, start)); CK(copy_vars(ctx, NLLS_VARS_NEXT, NLLS_VARS_CURRENT));
+        CK(sweep_gradhess(ctx, &cost));
+        nlls_lm_state l3; memset(&l3, 0, sizeof l3); l3.bestcost = cost; l3.cost = cost;
+        CK(lm_iterations(ctx, &lo, &l3, (int64_t)1 << 40));
+        if (!(l3.bestcost >= l3.cost)) CK(swap_vars(ctx, NLLS_VARS_CURRENT, NLLS_VARS_BEST));
+        double check3 = 0; CK(sweep_cost(ctx, NLLS_VARS_CURRENT, &check3));
+        printf("replay (collective route over the library's own RCCL communicator, one rank): best %.6e in %lld iterations (%lld LM trials), cost(variables) %.6e\n", l3.bestcost, (long long)l3.iternum,
+               (long long)l3.linearsolvers, check3);
+        CK(ctx_destroy(ctx));
+        if (!(l3.bestcost < 1e-15 * NOBS) || !(check3 < 1e-15 * NOBS) || l3.iternum != ls.iternum) { fprintf(stderr, "the collective route did not reproduce the single-GPU loop\n"); return 1; }
+    }
     return 0;
 }

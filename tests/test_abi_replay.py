@@ -29,3 +29,12 @@ def test_shim_call_sequence_replay():
     out = subprocess.run([_build(), "--replay", LIB], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "replay: start" in out.stdout
+
+
+@pytest.mark.gpu
+def test_collectives_from_plain_c():
+    """nlls_comm_unique_id / nlls_comm_init_rccl / nlls_lm_iterations from a C program: no Python, no PyTorch in the process -- the library loads
+    librccl.so.1 itself, and one rank through the collective route takes the same iterations as the single-GPU loop."""
+    out = subprocess.run([_build(), "--replay", LIB, "--rccl"], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "collective route over the library's own RCCL communicator" in out.stdout
