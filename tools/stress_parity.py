@@ -13,7 +13,7 @@ fails = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
     try:
-        mode = seed % 4
+        mode = seed % 5
         if mode == 3:            # SO(3) cameras, pinhole, optionally the adaptive kernel as a border variable (BASELINE config 5 kinds)
             ncam = int(rng.integers(6, 300)); npts = int(rng.integers(60, 6000)); prop = max(float(rng.uniform(0.02, 0.5)), 4.0 / ncam)
             adaptive = bool(rng.integers(0, 2))
@@ -28,13 +28,20 @@ for seed in range(lo, hi):
             ncam = int(rng.integers(4, 60)); npts = int(rng.integers(20, 1500)); prop = max(float(rng.uniform(0.05, 0.6)), 3.5 / ncam)
         elif mode == 1:          # camera chains: band mode with several BCR levels
             ncam = int(rng.integers(48, 400)); per = int(rng.integers(3, 12)); npts = int(rng.integers(10, 40)) * ncam; prop = per / ncam
+        elif mode == 4:          # camera chains with a tail of widely seen landmarks: wide supernodes (generic LDS-budgeted elimination, both classes)
+            ncam = int(rng.integers(48, 300)); per = int(rng.integers(3, 10)); npts = int(rng.integers(10, 30)) * ncam; prop = per / ncam
         else:                    # dense reduced systems of a few hundred dof
             ncam = int(rng.integers(12, 90)); npts = int(rng.integers(200, 3000)); prop = float(rng.uniform(0.3, 0.9))
         kind = int(rng.integers(0, 4))
         robust = [None, N.HuberKernel(float(rng.uniform(0.005, 0.1))), N.GemanMcclureKernel(float(rng.uniform(0.02, 0.2))),
                   N.Scaled(N.Huber2oKernel(float(rng.uniform(0.005, 0.1))), float(rng.uniform(0.5, 3.0)))][kind]
         kw = dict(robust=robust, outlier_frac=float(rng.uniform(0.0, 0.3)), outlier_sigma=0.1) if robust is not None else {}
-        p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed, **kw), 1e-3, 1e-3)
+        p = synthetic.create_ba_problem(ncam, npts, prop, seed=seed, **kw)
+        if mode == 4:
+            nw = int(rng.integers(1, 12))
+            wide = {int(l): int(rng.integers(per + 2, ncam + 1)) if rng.random() < 0.8 else ncam for l in rng.choice(npts, size=nw, replace=False) + 1}
+            p = synthetic.widen_visibility(p, ncam, wide)
+        p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
         unfixed = None
         if rng.random() < 0.4:
             unfixed = np.ones(p.nvariables, bool); unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 20), replace=False)] = False
