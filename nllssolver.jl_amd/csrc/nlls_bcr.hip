@@ -30,6 +30,7 @@
 namespace nlls {
 
 typedef double bdouble4_t __attribute__((ext_vector_type(4)));
+typedef double bdouble2_t __attribute__((ext_vector_type(2)));
 constexpr int BP = 17, BTS = 16 * BP;             // LDS tile: 16 rows padded to 17 doubles
 constexpr int BCR_T = 512;                        // threads of the panel kernel: wave 0 factors, seven waves help
 constexpr int BCR_MAXNT = 5;
@@ -803,6 +804,127 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) __hip_atomic_store(a.done + job.i, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DENSE reduced system: the backward substitution L' x = z in ONE launch (was one launch per 64-column block: 93 dependent launches of 6.7 us at
+// 6000 dof).  128-column blocks; workgroup w owns block j = NBB - 1 - w: it accumulates  acc_j = sum_{s > j} L(s, j)' x_s  in registers, hop by hop
+// as the blocks below it publish their unknowns, the tile of the NEXT hop requested before this one's unknowns are waited for; then
+// x_j = inv(L_jj)' (z_j - acc_j)  with the EXPLICIT inverse of the unit-lower diagonal block (dense_dinv_kernel: once per solve, all blocks at once)
+// -- one matrix-vector product instead of eight dependent tile steps.  The hand-off carries no flag: x is pre-set to a sentinel (a NaN with a
+// payload no arithmetic produces) by the launch in front, a block's unknowns are single 8-byte relaxed agent-scope stores past the (per-XCD,
+// mutually incoherent) L2s, and a dependant polls the very words it needs -- one memory round trip per hop instead of three (unknowns out, flag
+// out, flag seen, unknowns in).  Whatever a workgroup waits for belongs to a workgroup with a smaller index.
+// ---------------------------------------------------------------------------------------------------
+constexpr int DBB = 128;
+constexpr unsigned long long DENSE_X_SENTINEL = 0x7ff8dead5eed1234ull;
+// inverse of every 128 x 128 unit-lower diagonal block of the factor (column-major, ld = npad) by 16 x 16 tiles on the matrix cores:
+//   X_JJ = inv(L_JJ) (exported by the panels: LiD),   X_IJ = -X_II sum_{K = J}^{I-1} L_IK X_KJ,   tile row by tile row, in place in LDS
+// (row I of L is read for the last time when row I of X is formed).  The sum leaves the matrix cores in the accumulator layout, which IS the B
+// operand layout of the product with X_II: no LDS round trip between the two.  Tiles beyond npad: identity.  Out: Dinv[b] column-major 128 x 128,
+// ones on the diagonal, zeros above it.  Also: the sentinel into x[0, n).
+__global__ __launch_bounds__(512) void dense_dinv_kernel(const double* __restrict__ S, const double* __restrict__ LiD, double* __restrict__ Dinv, double* __restrict__ x, int npad, int n) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];          // the 36 lower tiles of the block, [16][BP] each
+    const int b = blockIdx.x, t = threadIdx.x, c0 = DBB * b;
+    if (t < DBB && c0 + t < n) x[c0 + t] = __longlong_as_double((long long)DENSE_X_SENTINEL);
+    for (int e = t; e < DBB * DBB; e += 512) { const int i = e & 127, j = e >> 7, I = i >> 4, J = j >> 4;      // consecutive threads walk a column of S
+        if (I < J) continue;
+        double v;
+        if (I == J) { const int gt = 8 * b + I; v = gt < npad / 16 ? LiD[(size_t)gt * 256 + (i & 15) + 16 * (j & 15)] : ((i & 15) == (j & 15) ? 1.0 : 0.0); }
+        else v = c0 + i < npad ? S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)] : 0.0;
+        sm[bcr_dtile(I, J) * BTS + (i & 15) * BP + (j & 15)] = v; }
+    __syncthreads();
+    const int J = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
+    for (int I = 1; I < 8; ++I) {
+        bdouble4_t res = {0, 0, 0, 0}, res2 = {0, 0, 0, 0};
+        if (J < I) {
+            bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+            for (int K = J; K < I; ++K) {
+                const double* A = sm + bcr_dtile(I, K) * BTS; const double* B = sm + bcr_dtile(K, J) * BTS;
+                double av[4], bv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { av[kk] = A[li * BP + 4 * kk + lk]; bv[kk] = B[(4 * kk + lk) * BP + li]; }
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+            }
+            const double* D = sm + bcr_dtile(I, I) * BTS;
+            double dv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dv[kk] = D[li * BP + 4 * kk + lk];
+            res = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[0], acc[0] + acc2[0], res, 0, 0, 0);        // (register kk of the sum = rows 4 kk + lk: the B operand of k-slice kk)
+            res2 = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[1], acc[1] + acc2[1], res2, 0, 0, 0);
+            res = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[2], acc[2] + acc2[2], res, 0, 0, 0);
+            res2 = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[3], acc[3] + acc2[3], res2, 0, 0, 0);
+        }
+        __syncthreads();               // row I of L has been read for the last time
+        if (J < I) { double* X = sm + bcr_dtile(I, J) * BTS;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[(lk + 4 * r) * BP + li] = -(res[r] + res2[r]); }
+        __syncthreads();
+    }
+    double* out = Dinv + (size_t)b * DBB * DBB;
+    for (int e = t; e < DBB * DBB; e += 512) { const int r = e & 127, c = e >> 7; out[e] = (r >> 4) >= (c >> 4) ? sm[bcr_dtile(r >> 4, c >> 4) * BTS + (r & 15) * BP + (c & 15)] : 0.0; }
+}
+struct DenseBwdArgs { const double* S; const double* Dinv; double* x; int* status; int npad, n, NBB; };
+// Thread t: rows 32 (t & 3) .. of column t >> 2 of a tile (contiguous in memory).  The tile of the next hop is requested right BEHIND this hop's
+// products: a wave's loads return in order, and a poll issued behind a tile request waits for all of it -- placed here the request is long served
+// when the workgroup whose turn is next looks for its unknowns (it has been waiting a whole hop), and only workgroups with slack poll behind it.
+// The block's inverse stays in registers from the start.
+__global__ __launch_bounds__(512) void dense_bwd_fused_kernel(DenseBwdArgs a) {
+    __shared__ double xs[2][DBB], us[DBB];
+    const int t = threadIdx.x, c = t >> 2, q = t & 3, npad = a.npad, n = a.n;
+    const int j = a.NBB - 1 - (int)blockIdx.x, gc = DBB * j + c;
+    const bool colok = gc < npad;
+    // (rows / columns beyond npad -- the half-empty last block of an odd number of 64-blocks -- are not multiplied at all: tile_ok)
+    auto tile_ok = [&](int s) { return colok && DBB * s + 32 * q < npad; };
+    // (macros, not lambdas over the arrays: an array whose address is taken lives in scratch memory)
+#define DBW_LOAD(T, P) do { _Pragma("unroll") for (int i = 0; i < 32; i += 2) { const bdouble2_t w = *reinterpret_cast<const bdouble2_t*>((P) + i); T[i] = w[0]; T[i + 1] = w[1]; } } while (0)
+#define DBW_TILE(T, s) do { const double* P_ = tile_ok(s) ? a.S + (size_t)(DBB * (s) + 32 * q) + (size_t)npad * gc : a.S; DBW_LOAD(T, P_); } while (0)
+    // sum_i T[i] v[i], v in LDS: the 32 words first (eight 32-byte reads in flight), then four independent chains
+#define DBW_DOT(OUT, T, V) do { double v_[32]; _Pragma("unroll") for (int i = 0; i < 32; i += 4) { const bdouble4_t w = *reinterpret_cast<const bdouble4_t*>((V) + i); v_[i] = w[0]; v_[i + 1] = w[1]; v_[i + 2] = w[2]; v_[i + 3] = w[3]; } \
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0; _Pragma("unroll") for (int i = 0; i < 32; i += 4) { s0 = fma(T[i], v_[i], s0); s1 = fma(T[i + 1], v_[i + 1], s1); s2 = fma(T[i + 2], v_[i + 2], s2); s3 = fma(T[i + 3], v_[i + 3], s3); } \
+        OUT = (s0 + s1) + (s2 + s3); } while (0)
+    double T[32], INV[32];
+    if (j + 1 < a.NBB) DBW_TILE(T, a.NBB - 1);
+    { const double* Pi = a.Dinv + (size_t)j * DBB * DBB + (size_t)DBB * c + 32 * q; DBW_LOAD(INV, Pi); }     // rows 32 q .. of column c of inv(L_jj)
+    const double z = (q == 0 && gc < n) ? a.S[(size_t)n + (size_t)npad * gc] : 0.0;       // z = D^-1 L^-1 s: row n of the factor
+    double acc = 0.0;
+#pragma unroll 1
+    for (int s = a.NBB - 1; s > j; --s) {
+        if (t < DBB) {
+            const int g = DBB * s + t; double v = 0.0;
+            if (g < n) {   // (bounded: half a second on the 100 MHz constant clock, then the solve is flagged instead of hanging the queue)
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                for (;;) { v = bcr_xload(a.x + g); if ((unsigned long long)__double_as_longlong(v) != DENSE_X_SENTINEL) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_readcyclecounter() - t0 > 1200000000ull) { atomicCAS(a.status, 0, 1 + n + 64); break; } }
+            }
+            xs[s & 1][t] = v;
+        }
+        bcr_lds_barrier();             // (xs is double buffered: one barrier per hop)
+        if (tile_ok(s)) { double d; DBW_DOT(d, T, xs[s & 1] + 32 * q); acc += d; }
+        if (s - 1 > j) DBW_TILE(T, s - 1);
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+    if (q == 0) us[c] = gc < n ? z - acc : 0.0;
+    bcr_lds_barrier();
+    double xv; DBW_DOT(xv, INV, us + 32 * q);
+    xv += __shfl_xor(xv, 1, 64); xv += __shfl_xor(xv, 2, 64);
+    if (q == 0 && gc < n) bcr_xstore(a.x + gc, xv);
+#undef DBW_DOT
+#undef DBW_TILE
+#undef DBW_LOAD
+}
+// Dinv: ceil(n / 128) slots of 128 x 128 doubles
+void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, double* Dinv, int npad, int n, double* x, int* status) {
+    const int NBB = (n + DBB - 1) / DBB; if (NBB <= 0) return;
+    static bool attr = false; constexpr int lds = (int)(sizeof(double) * 36 * BTS);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(dense_dinv_kernel, dim3((unsigned)NBB), dim3(512), lds, st, S, LiD, Dinv, x, npad, n);
+    DenseBwdArgs a{S, Dinv, x, status, npad, n, NBB};
+    hipLaunchKernelGGL(dense_bwd_fused_kernel, dim3((unsigned)NBB), dim3(512), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -51,6 +51,7 @@ struct BcrSolver {
 void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac);
 void launch_dense_dcopy_all(hipStream_t st, double* S, const double* Dfac, int npad, int nwide, int first64, int n64);   // the factored diagonal blocks: slots of Dfac -> S   // wide: a 128-column panel (k counts panels of the width used)
 void launch_dense_bwd_diag(hipStream_t st, const double* S, const double* LiD, int npad, int kb, int n, const double* acc, double* x);
+void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, double* Dinv, int npad, int n, double* x, int* status);   // the whole backward substitution in one launch (+ the diagonal blocks' inverses)
 void launch_dense_bwd_step(hipStream_t st, const double* S, const double* LiD, int npad, int s, int n, double* acc, double* x);   // push block s's x into the blocks above, solve block s - 1
 
 }  // namespace nlls

@@ -2634,6 +2634,13 @@ int enqueue_reduced_solve(nlls_ctx* c) {
             launch_dense_dcopy_all(c->stream, c->S.p, Dfac, npad, 0, 0, nblk);
         }
         // backward substitution into acc / s (x)
+        if (c->dense_fused_bwd) {
+            // ONE launch for the whole substitution (+ one for the explicit inverses of the 128 x 128 diagonal blocks, into the slots the factored
+            // diagonal blocks have just left, and the sentinel in x)
+            launch_dense_bwd_fused(c->stream, c->S.p, LiD, Dfac, npad, n, c->s_ptr(), c->d_status.p);
+            HIPCHK(hipGetLastError());
+            return NLLS_OK;
+        }
         double* acc = accb;
         HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * npad, c->stream));
         const int nb_real = (n + NB - 1) / NB;
