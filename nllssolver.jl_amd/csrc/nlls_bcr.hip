@@ -34,6 +34,7 @@ typedef double bdouble2_t __attribute__((ext_vector_type(2)));
 constexpr int BP = 17, BTS = 16 * BP;             // LDS tile: 16 rows padded to 17 doubles
 constexpr int BCR_T = 512;                        // threads of the panel kernel: wave 0 factors, seven waves help
 constexpr int BCR_MAXNT = 5;
+constexpr unsigned long long BCR_X_SENTINEL = 0x7ff8dead5eed1234ull;   // a NaN with a payload no arithmetic produces: "not published yet"
 
 #define BCR_DEV __device__ __forceinline__
 
@@ -229,7 +230,7 @@ BCR_DEV void bcr_export_linv(const double* Lid, double* __restrict__ dst) {
     *reinterpret_cast<bdouble4_t*>(dst + 4 * lane) = bdouble4_t{Lid[li * BP + lk], Lid[li * BP + 4 + lk], Lid[li * BP + 8 + lk], Lid[li * BP + 12 + lk]};
 }
 
-struct BcrPanelArgs { BcrGeom g; BcrChain ch; int* status; double relfloor; int chrows; };   // chrows: X rows per workgroup of this launch (1 .. BCR_CH)
+struct BcrPanelArgs { BcrGeom g; BcrChain ch; int* status; double relfloor; int chrows; double* xr; };   // xr != nullptr: the fused backward pass follows -- the block's unknowns get the sentinel here   // chrows: X rows per workgroup of this launch (1 .. BCR_CH)
 // job e of a level, from the level's chain (no descriptor load in front of everything else)
 BCR_DEV BcrElim bcr_job(const BcrChain& c, int e) {
     const int idx = c.first + 2 * e, i = c.o + idx * c.s;
@@ -264,6 +265,10 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     const int hw = wave < 4 ? wave - 1 : wave - 2;    // helper index of waves 1, 2, 3, 5, 6, 7 (wave 4 shares wave 0's SIMD -- its matrix pipe
                                                       // and its vector issue: it stays out of the way while wave 0 works)
     const bool helper = wave != 0 && wave != 4;
+    if (a.xr && lead) {      // the hand-off of the fused backward pass carries no flag: a dependant polls the unknowns themselves until the sentinel is gone
+        if (tid < 16 * NT) { const int row = 16 * NT * job.i + tid; if (row < g.n_band) a.xr[row] = __longlong_as_double((long long)BCR_X_SENTINEL); }
+        if (job.l < 0 && job.r < 0 && tid < g.nbd) g.ws[g.oxb + tid] = __longlong_as_double((long long)BCR_X_SENTINEL);      // (the root: the border's unknowns)
+    }
 #ifdef BCR_STAMPS
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(); int stn = 0;
 #define BCR_STAMP() do { if (blockIdx.x == gridDim.x - 1 && lane == 0 && wave <= 1 && stn < 20) a.status[16 + 20 * wave + stn++] = (int)(__builtin_amdgcn_s_memtime() - st0); } while (0)   // (status holds 96 ints: slots 16..55 and 56..71 are the instrumented build's)
@@ -671,17 +676,18 @@ __global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws
 // ---------------------------------------------------------------------------------------------------
 // backward pass of one level: one workgroup per block eliminated at that level
 // ---------------------------------------------------------------------------------------------------
-struct BcrBackArgs { BcrGeom g; BcrChain ch; double* xr; int root; int* status; const BcrElim* elims; int* done; int seq; };
+struct BcrBackArgs { BcrGeom g; BcrChain ch; double* xr; int root; int* status; const BcrElim* elims; };
 // unknowns that cross workgroups INSIDE one launch (FUSED): relaxed agent-scope accesses -- they go past the (per-XCD, mutually incoherent) L2s
-// to the memory side, so that no cache has to be written back or invalidated; the order "unknowns, then flag" is this wave's s_waitcnt
+// to the memory side, so that no cache has to be written back or invalidated; every word is its own message (8-byte stores are single-copy atomic)
 BCR_DEV void bcr_xstore(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 BCR_DEV double bcr_xload(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // NT wavefronts: wave J owns the 16 unknowns of tile column J.  Every load of the factor is issued before anything is
 // waited for (one memory round trip per level); the unknowns of the neighbours (and of the border) go through LDS.
 // FUSED: ONE launch for the whole backward pass.  Workgroup w takes the block eliminated (N - 1 - w)-th: the root first, then level by level
 // down to the first one -- whatever a workgroup waits for belongs to a workgroup with a smaller index, which was dispatched before it, so the
-// wait ends whether or not all of them fit the chip at once.  A block publishes its unknowns and then a flag (= the solve's sequence number:
-// nothing to reset between solves); its dependants have requested their own factor tiles long before and spin on two flags.
+// wait ends whether or not all of them fit the chip at once.  No flags: the unknowns were pre-set to a sentinel by the panel launches (a NaN with a
+// payload no arithmetic produces), a block publishes them with single 8-byte stores, and its dependants -- their own factor tiles requested long
+// before -- poll the very words they need.
 template <int NT, bool FUSED>
 __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -725,19 +731,19 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
         for (int q = 0; q < MQ; ++q) { const int w = tid + q * NTH; if (w < NO * 256) Mdl[w] = mdv[q]; }
     }
     if (FUSED && !root) {
-        // wait for the neighbours (and, through them, the root's border unknowns): one lane polls, the factor's loads above are in flight meanwhile
-        if (tid == 0) { for (int q = 0; q < 2; ++q) { const int nb = q ? job.r : job.l; if (nb < 0) continue;
-                // (bounded: half a second on the 100 MHz constant clock, then the solve is flagged instead of hanging the queue)
-                const unsigned long long t0 = __builtin_readcyclecounter();
-                while (__hip_atomic_load(a.done + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (__builtin_readcyclecounter() - t0 > 1200000000ull) { atomicCAS(a.status, 0, 1 + g.n_band + 64); break; } } } }
-        __syncthreads();
+        // wait for the neighbours' and the border's unknowns: every lane polls the very word it needs until the sentinel is gone (the factor's loads above are
+        // in flight meanwhile) -- one memory round trip per hop, where "unknowns, then a flag" needed three
         if (tid < RXT * 16) {
-            const int R = tid >> 4, q = tid & 15;
-            if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) xpre = bcr_xload(a.xr + row); } }
-            else if (R < 2 * NT) { if (job.r >= 0) { const int row = b * job.r + 16 * (R - NT) + q; if (row < g.n_band) xpre = bcr_xload(a.xr + row); } }
-            else xpre = q < nbd ? bcr_xload(g.ws + g.oxb + q) : (q == nbd ? -1.0 : 0.0);
+            const int R = tid >> 4, q = tid & 15; const double* src = nullptr;
+            if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) src = a.xr + row; } }
+            else if (R < 2 * NT) { if (job.r >= 0) { const int row = b * job.r + 16 * (R - NT) + q; if (row < g.n_band) src = a.xr + row; } }
+            else if (q < nbd) src = g.ws + g.oxb + q; else xpre = q == nbd ? -1.0 : 0.0;
+            if (src) {   // (bounded: half a second on the 100 MHz constant clock, then the solve is flagged instead of hanging the queue)
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                for (;;) { xpre = bcr_xload(src); if ((unsigned long long)__double_as_longlong(xpre) != BCR_X_SENTINEL) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_readcyclecounter() - t0 > 1200000000ull) { atomicCAS(a.status, 0, 1 + g.n_band + 64); break; } }
+            }
         }
     }
     if (root) {
@@ -758,7 +764,7 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
             __syncthreads();
             if (tid < nbd) { if (FUSED) bcr_xstore(g.ws + g.oxb + tid, xb[tid]); else g.ws[g.oxb + tid] = xb[tid]; a.xr[g.n_band + tid] = xb[tid]; }
         }
-    } else if (tid < nbd) xb[tid] = FUSED ? bcr_xload(g.ws + g.oxb + tid) : g.ws[g.oxb + tid];
+    } else if (!FUSED && tid < nbd) xb[tid] = g.ws[g.oxb + tid];
     __syncthreads();
     if (!root) { if (tid < RXT * 16) xs[tid] = xpre; }
     else for (int t = tid; t < RXT * 16; t += NTH) {
@@ -800,10 +806,6 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
         }
         __syncthreads();
     }
-    if (FUSED) {      // every unknown of this block has left this wave (vmcnt) before the flag does
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) __hip_atomic_store(a.done + job.i, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -817,7 +819,6 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
 // out, flag seen, unknowns in).  Whatever a workgroup waits for belongs to a workgroup with a smaller index.
 // ---------------------------------------------------------------------------------------------------
 constexpr int DBB = 128;
-constexpr unsigned long long DENSE_X_SENTINEL = 0x7ff8dead5eed1234ull;
 // inverse of every 128 x 128 unit-lower diagonal block of the factor (column-major, ld = npad) by 16 x 16 tiles on the matrix cores:
 //   X_JJ = inv(L_JJ) (exported by the panels: LiD),   X_IJ = -X_II sum_{K = J}^{I-1} L_IK X_KJ,   tile row by tile row, in place in LDS
 // (row I of L is read for the last time when row I of X is formed).  The sum leaves the matrix cores in the accumulator layout, which IS the B
@@ -826,7 +827,7 @@ constexpr unsigned long long DENSE_X_SENTINEL = 0x7ff8dead5eed1234ull;
 __global__ __launch_bounds__(512) void dense_dinv_kernel(const double* __restrict__ S, const double* __restrict__ LiD, double* __restrict__ Dinv, double* __restrict__ x, int npad, int n) {
     extern __shared__ __attribute__((aligned(16))) double sm[];          // the 36 lower tiles of the block, [16][BP] each
     const int b = blockIdx.x, t = threadIdx.x, c0 = DBB * b;
-    if (t < DBB && c0 + t < n) x[c0 + t] = __longlong_as_double((long long)DENSE_X_SENTINEL);
+    if (t < DBB && c0 + t < n) x[c0 + t] = __longlong_as_double((long long)BCR_X_SENTINEL);
     for (int e = t; e < DBB * DBB; e += 512) { const int i = e & 127, j = e >> 7, I = i >> 4, J = j >> 4;      // consecutive threads walk a column of S
         if (I < J) continue;
         double v;
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(512) void dense_bwd_fused_kernel(DenseBwdArgs a) {
             const int g = DBB * s + t; double v = 0.0;
             if (g < n) {   // (bounded: half a second on the 100 MHz constant clock, then the solve is flagged instead of hanging the queue)
                 const unsigned long long t0 = __builtin_readcyclecounter();
-                for (;;) { v = bcr_xload(a.x + g); if ((unsigned long long)__double_as_longlong(v) != DENSE_X_SENTINEL) break;
+                for (;;) { v = bcr_xload(a.x + g); if ((unsigned long long)__double_as_longlong(v) != BCR_X_SENTINEL) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (__builtin_readcyclecounter() - t0 > 1200000000ull) { atomicCAS(a.status, 0, 1 + n + 64); break; } }
             }
@@ -1013,7 +1014,6 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     }
     if (hipSuccess != ws.alloc(off) || hipSuccess != d_elim.upload(elims) || hipSuccess != d_upd.upload(upds)) { if (err) *err = "block cyclic reduction workspace alloc"; return NLLS_ERR_HIP; }
     if (hipSuccess != hipMemset(ws.p, 0, off * sizeof(double))) { if (err) *err = "workspace memset"; return NLLS_ERR_HIP; }
-    { std::vector<int32_t> z((size_t)N, 0); if (hipSuccess != d_done.upload(z)) { if (err) *err = "flag alloc"; return NLLS_ERR_HIP; } seq = 0; }
     { const char* e = getenv("NLLS_BCR_LEVEL_BACKWARD"); fused_backward = !(e && e[0] == '1'); }      // A/B switch: one backward launch per level, as in round 2
     // (the dispatch order of workgroups is not a contract: the fused pass is taken only while ALL its workgroups are resident at once -- 23 KB of LDS
     //  and 5 wavefronts each, six per CU -- so that nothing waits on a workgroup that has not started)
@@ -1052,23 +1052,23 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
 }
 
 template <int NT>
-static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status, double relfloor) {
+static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status, double relfloor, double* xr) {
     // X rows per workgroup: as few as still fit ONE round of the chip (every workgroup factors D_i beside its rows; the fewer rows, the less
     // helper work stands beside the pivot chain that sets the pace): 3 when the level is wide, 1 at the narrow levels near the root
     const int chrows = bcr_level_chrows(NT, lv.nelim, S.chrows_slots);
-    BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status, relfloor, chrows};
+    BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status, relfloor, chrows, S.fused_backward ? xr : nullptr};
     if (relfloor > 0.0) hipLaunchKernelGGL(bcr_panel_kernel<true>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     else hipLaunchKernelGGL(bcr_panel_kernel<false>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     if (lv.nupd > 0) hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd);
 }
 template <int NT>
 static void bcr_launch_back(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, double* xr, int root, int* status) {
-    BcrBackArgs ba{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, xr, root, status, nullptr, nullptr, 0};
+    BcrBackArgs ba{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, xr, root, status, nullptr};
     hipLaunchKernelGGL((bcr_backward_kernel<NT, false>), dim3((unsigned)lv.nelim), dim3(64 * NT), S.back_lds, st, ba);
 }
 template <int NT>
 static void bcr_launch_back_all(const BcrSolver& S, hipStream_t st, double* xr, int* status) {
-    BcrBackArgs ba{S.geom, BcrChain{0, 1, 0, 0}, xr, 0, status, S.d_elim.p, S.d_done.p, ++S.seq};
+    BcrBackArgs ba{S.geom, BcrChain{0, 1, 0, 0}, xr, 0, status, S.d_elim.p};
     hipLaunchKernelGGL((bcr_backward_kernel<NT, true>), dim3((unsigned)S.N), dim3(64 * NT), S.back_lds, st, ba);
 }
 
@@ -1076,7 +1076,7 @@ int BcrSolver::enqueue(hipStream_t st, const double* Sb, double* xr, int* status
     const int ND = NT * (NT + 1) / 2, per = ND + NT * NT + NT;
     if (Sb) hipLaunchKernelGGL(bcr_convert_kernel, dim3((unsigned)(N * per + 1)), dim3(256), 0, st, geom, Sb);   // (else: the tiles have been assembled in place, schur_gather_kernel)
 #define BCR_NT_SWITCH(CALL) switch (NT) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; default: CALL(5); break; }
-#define BCR_FWD(n) bcr_launch_level<n>(*this, st, lv, status, pivot_floor)
+#define BCR_FWD(n) bcr_launch_level<n>(*this, st, lv, status, pivot_floor, xr)
     for (const BcrLevel& lv : levels) BCR_NT_SWITCH(BCR_FWD)
 #define BCR_BWD(n) bcr_launch_back<n>(*this, st, levels[li], xr, li + 1 == levels.size() ? 1 : 0, status)
 #define BCR_BWD_ALL(n) bcr_launch_back_all<n>(*this, st, xr, status)

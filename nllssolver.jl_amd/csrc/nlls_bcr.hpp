@@ -30,7 +30,6 @@ struct BcrSolver {
     bool ready = false;
     std::vector<BcrLevel> levels;                 // elimination levels, the root block last
     DevBuf<double> ws; DevBuf<BcrElim> d_elim; DevBuf<BcrUpd> d_upd;
-    DevBuf<int32_t> d_done; mutable int seq = 0;   // fused backward pass: per block, the sequence number of the solve whose unknowns it has published
     bool fused_backward = true;
     BcrGeom geom{};
     size_t panel_lds = 0, back_lds = 0;
@@ -44,7 +43,7 @@ struct BcrSolver {
     // pivot_floor > 0 (undamped Newton / dogleg steps on a gauge-free problem: S is singular): a pivot that has lost more than that
     // fraction of its original diagonal entry is treated as infinite -- its unknown comes out 0 instead of (rounding) / (rounding)
     int enqueue(hipStream_t st, const double* Sb, double* xr, int* status, double pivot_floor = 0.0) const;
-    void release() { ws.release(); d_elim.release(); d_upd.release(); d_done.release(); levels.clear(); ready = false; }
+    void release() { ws.release(); d_elim.release(); d_upd.release(); levels.clear(); ready = false; }
 };
 
 // dense reduced system (nlls_solve.hip): panel factorisation of block column k (64 columns) and the backward pass's diagonal block
