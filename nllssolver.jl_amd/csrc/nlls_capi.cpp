@@ -43,6 +43,8 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     c->device = dev; c->num_cus = prop.multiProcessorCount;
     { const char* e = getenv("NLLS_ELIM_TILED"); if (e && e[0] == '1') c->elim_mfma = false; }
     { const char* e = getenv("NLLS_DENSE_T64"); if (e && e[0] == '1') c->dense_t128 = false; }
+    { const char* e = getenv("NLLS_ELIM_SPLIT"); if (e && e[0] == '1') c->elim_split = true; }
+    { const char* e = getenv("NLLS_SWEEP_SPLIT3"); if (e && e[0] == '1') c->sweep_split3 = true; }
     { const char* e = getenv("NLLS_DENSE_STEP_BACKWARD"); if (e && e[0] == '1') c->dense_fused_bwd = false; }
     { const char* e = getenv("NLLS_DENSE_T128_MIN"); if (e) c->dense_t128_min = atoi(e); }
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return NLLS_ERR_HIP; }

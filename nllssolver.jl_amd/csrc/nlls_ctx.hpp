@@ -184,6 +184,8 @@ struct nlls_ctx {
     int dense_t128_min = 16;                   // ... only while the trailing matrix has at least this many 128-blocks per side (fewer: the 64 x 64 kernel fills the chip better)
     bool dense_t128 = true;                    // dense LDL': 128 x 128 tiles in the two-panel trailing update (NLLS_DENSE_T64=1: the 64 x 64 kernel, for A/B runs)
     bool dense_fused_bwd = true;               // dense LDL': the backward substitution in one launch (NLLS_DENSE_STEP_BACKWARD=1: one launch per 64-column block, for A/B runs)
+    bool elim_split = false;                   // NLLS_ELIM_SPLIT=1: the assembly of the reduced system in three launches (A/B)
+    bool sweep_split3 = false;                 // NLLS_SWEEP_SPLIT3=1: the three-slot accumulate sweep in one launch per role (A/B)
     bool elim_mfma = true;                     // narrow supernodes (nd + 1 <= 64) are eliminated on the matrix cores (NLLS_ELIM_TILED=1: the register-tiled kernel, for A/B runs)
     bool elim_selected = false;
     std::vector<int32_t> owner_of_block;

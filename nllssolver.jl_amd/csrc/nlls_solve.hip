@@ -2452,9 +2452,8 @@ int enqueue_solve_local(nlls_ctx* c) {
     const bool one_prepare = lead && c->info.is_sparse && c->ncopy > 0;      // status reset, s and the reduced-reduced blocks in one launch
     // ONE launch for the whole assembly (schur_elim_all_kernel): every eliminated block on the fast path with both kinds of supernode present, one rank,
     // [S | s] carrying the right-hand side as a row (band / dense layouts).  NLLS_ELIM_SPLIT=1 keeps the three launches (A/B).
-    static const bool split_env = [] { const char* e = getenv("NLLS_ELIM_SPLIT"); return e && e[0] == '1'; }();
     const int64_t nfast_narrow = c->n_fast_narrow, nfast_wide = c->n_fast_groups - c->n_fast_narrow;
-    const bool all_in_one = one_prepare && !split_env && c->nranks == 1 && c->elim_mfma && c->n_slow_groups == 0 && nfast_narrow > 0 && nfast_wide > 0 &&
+    const bool all_in_one = one_prepare && !c->elim_split && c->nranks == 1 && c->elim_mfma && c->n_slow_groups == 0 && nfast_narrow > 0 && nfast_wide > 0 &&
                             c->solve_mode != SOLVE_SMALL && c->fast_dv >= 1 && c->fast_dv <= 3 && (int64_t)c->d_elim_diag.n == c->n_fast_members;
     if (all_in_one) {
         if (!c->status_known_zero) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));

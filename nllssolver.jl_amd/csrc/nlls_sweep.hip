@@ -529,8 +529,7 @@ static void launch_gh_fused3_as(nlls_ctx* c, const Group& G, const double* vars,
 template <int KIND>
 static bool launch_gh_fused3(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
     if constexpr (Res<KIND>::NDEPS == 3) {
-        static const bool split = [] { const char* e = getenv("NLLS_SWEEP_SPLIT3"); return e && e[0] == '1'; }();
-        if (split) return false;
+        if (c->sweep_split3) return false;                   // (NLLS_SWEEP_SPLIT3=1: one launch per role, for A/B runs)
         int nl = 0, nh = 0, ls = -1;
         for (int q = 0; q < 3; ++q) { const EntryList& E = G.lists[q];
             if (E.nlight > 0 && E.nheavy == 0) { ++nl; ls = q; } else if (E.nheavy > 0 && E.nlight == 0) ++nh; }

@@ -267,6 +267,17 @@ def test_band_solver_shapes(ncam, npts, prop, seed):
         check_problem(p, flags=_capi.FLAG_NO_BCR | _capi.FLAG_NO_TWIST, expect_schur=1)
 
 
+@pytest.mark.parametrize("ncam", [11, 21, 22, 31, 32, 33, 43, 53, 64, 75])
+def test_dense_backward_block_edges(ncam):
+    """The dense reduced solve's one-launch backward substitution works in 128-column blocks over a system padded to a multiple of 64 (+ the
+    right-hand side's row): reduced sizes just below / at / above a block edge (6 ncam = 66 .. 450: 126 | 132, 186 | 192 | 198, 258, 318, 384, 450),
+    with an even and an odd number of 64-blocks; x against the oracle's sparse LDL', and against the one-launch-per-block substitution it replaced."""
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, 40 * ncam, min(1.0, 8.0 / ncam), seed=900 + ncam, robust=N.HuberKernel(0.02),
+                                                                 outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    info = check_problem(p, flags=_capi.FLAG_NO_BAND, expect_schur=1)
+    assert info.nreduced_dof == 6 * ncam and info.solve_mode == 1
+
+
 @pytest.mark.parametrize("seed", list(range(100, 140)))
 def test_randomized_ba_against_oracle(seed):
     """Seeded random shapes: cameras, points, visibility, robustifier, outliers and fixed variables drawn per case --
@@ -397,11 +408,21 @@ def test_randomized_tiny_dense_ba(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"NLLS_DENSE_T64": "1"}, {"NLLS_DENSE_T128_MIN": "1"}, {"NLLS_ELIM_TILED": "1"}, {"NLLS_BCR_CHROWS_SLOTS": "0"}])
+def test_three_slot_sweep_in_one_launch_per_role(monkeypatch):
+    """NLLS_SWEEP_SPLIT3=1: the adaptive-kernel bundle adjustment's accumulate sweep as round 2 launched it (one launch per role) -- the same sums."""
+    monkeypatch.setenv("NLLS_SWEEP_SPLIT3", "1")
+    q = synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(60, 1500, 0.15, seed=41, adaptive=True), 1e-3, 1e-3)
+    check_problem(q, lam_scale=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"NLLS_DENSE_T64": "1"}, {"NLLS_DENSE_T128_MIN": "1"}, {"NLLS_ELIM_TILED": "1"}, {"NLLS_BCR_CHROWS_SLOTS": "0"},
+                                 {"NLLS_DENSE_STEP_BACKWARD": "1"}, {"NLLS_BCR_LEVEL_BACKWARD": "1"}, {"NLLS_ELIM_SPLIT": "1"}])
 def test_ab_switches_select_paths_that_still_match_the_oracle(env, monkeypatch):
     """The environment switches read by nlls_create (the register-tiled elimination instead of the matrix-core one, the
     64 x 64-tile dense update instead of the 128 x 128 one, the 128 x 128 one from the first pass on, three X rows per panel workgroup at every
-    level of the block cyclic reduction) select kernels or launch shapes no default run of this size reaches:
+    level of the block cyclic reduction, one backward launch per block / per level instead of the one-launch substitutions, the assembly in three
+    launches) select kernels or launch shapes no default run of this size reaches:
     the same parity as every other path -- band mode and the dense reduced solve (NLLS_FLAG_NO_BAND) of a camera chain, 2100 reduced dof."""
     for k, v in env.items(): monkeypatch.setenv(k, v)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(350, 7000, 10.0 / 350, seed=77, robust=N.HuberKernel(0.02)), 1e-3, 1e-3)
