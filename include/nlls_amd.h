@@ -220,7 +220,9 @@ int  nlls_solve(nlls_ctx* ctx, double* x_out);
  * dogleg's Gauss-Newton step) on a gauge-free problem the reduced system is singular, and the block-cyclic-reduction solver treats a
  * pivot that has lost eleven orders of magnitude against its original diagonal entry as infinite (that unknown gets no step) instead
  * of dividing rounding by rounding; NaN pivots are never dropped (they raise NLLS_ERR_NOT_SPD).  The chain and dense solvers
- * (NLLS_FLAG_NO_BCR, NLLS_FLAG_NO_BAND) have no such floor. */
+ * (NLLS_FLAG_NO_BCR, NLLS_FLAG_NO_BAND) have no such floor.  Collective route (see "collectives"): [11] sums over ranks of the reduced rows
+ * of A.data / b since the upload, [12] LM trials since the upload that ran on rows NOT summed (nlls_sweep_gradhess(ctx, NULL) leaves them as the
+ * rank's share: everything a trial takes from them is linear in them). */
 int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
 int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
 int  nlls_get_step(nlls_ctx* ctx, double* x_out);

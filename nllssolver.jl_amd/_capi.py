@@ -283,10 +283,10 @@ class Context:
         self._chk(self.L.nlls_comm_init_rccl(self.h, buf))
 
     def solve_stats(self):
-        out = np.zeros(11, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 11))
+        out = np.zeros(13, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 13))
         return dict(status=int(out[0]), band_factor_cycles=int(out[1]), band_backward_cycles=int(out[2]), solve_mode=int(out[3]),
                     elim_supernodes=int(out[4]), bandwidth=int(out[5]), bcr_mfma_issued=int(out[6]), bcr_launches=int(out[7]), bcr_levels=int(out[8]),
-                    band_dof=int(out[9]), dropped_pivots=int(out[10]))
+                    band_dof=int(out[9]), dropped_pivots=int(out[10]), reduced_row_sums=int(out[11]), lazy_trials=int(out[12]))
 
     def set_step(self, x):
         x = np.ascontiguousarray(x, np.float64); assert x.size == self.info.ndof

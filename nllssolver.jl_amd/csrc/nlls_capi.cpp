@@ -14,7 +14,9 @@ int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(wha
 // (every entry point launches on ctx->stream: make the context's device current first -- two contexts on different devices in one
 // process, or a caller that changed the current device, must not end up on a foreign stream)
 #define NEED_READY() do { if (!ctx) return NLLS_ERR_INVALID_ARG; if (!ctx->ready) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_upload_structure has not succeeded"); (void)hipSetDevice(ctx->device); } while (0)
-#define NEED_GRAD() do { NEED_READY(); if (!ctx->have_grad) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_sweep_gradhess has not been run"); } while (0)
+#define NEED_GRAD_LAZY() do { NEED_READY(); if (!ctx->have_grad) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_sweep_gradhess has not been run"); } while (0)
+// (... and with the reduced rows summed over ranks: every entry point but the LM trial itself reads them as if one GPU had swept all cost blocks)
+#define NEED_GRAD() do { NEED_GRAD_LAZY(); TRY(ensure_reduced_summed(ctx)); } while (0)
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != NLLS_OK) return rc_; } while (0)
 
 // copy `count` scalars starting at `slot` to the pinned mirror and wait
@@ -43,6 +45,7 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     c->device = dev; c->num_cus = prop.multiProcessorCount;
     { const char* e = getenv("NLLS_ELIM_TILED"); if (e && e[0] == '1') c->elim_mfma = false; }
     { const char* e = getenv("NLLS_DENSE_T64"); if (e && e[0] == '1') c->dense_t128 = false; }
+    { const char* e = getenv("NLLS_EAGER_STAGE0"); if (e && e[0] == '1') c->lazy_stage0 = false; }
     { const char* e = getenv("NLLS_ELIM_SPLIT"); if (e && e[0] == '1') c->elim_split = true; }
     { const char* e = getenv("NLLS_SWEEP_SPLIT3"); if (e && e[0] == '1') c->sweep_split3 = true; }
     { const char* e = getenv("NLLS_DENSE_STEP_BACKWARD"); if (e && e[0] == '1') c->dense_fused_bwd = false; }
@@ -157,22 +160,37 @@ int nlls_copy_variables(nlls_ctx* ctx, int32_t dst, int32_t src) {
     return NLLS_OK;
 }
 
+// Lazy stage 0 (collective route): nlls_sweep_gradhess(ctx, NULL) leaves the reduced rows of A.data and b as this rank's share -- all an LM trial
+// takes from them is linear in them (the reduced-reduced blocks and b_R enter [S | s], which is summed over ranks anyway; x'Hx and g'x are sums of
+// the ranks' scalars), so the per-iteration all-reduce of [cost | reduced rows | reduced b] and its pack / unpack launches are skipped.  Whatever else
+// reads them (the initial damping's max |diag|, nlls_get_grad, nlls_solve, ...) sums them first, here: a collective -- every rank makes the same calls.
+static int ensure_reduced_summed(nlls_ctx* ctx) {
+    if (ctx->reduced_summed) return NLLS_OK;
+    ctx->reduced_summed = true;
+    if (!ctx->reduce_fn || ctx->nranks <= 1) return NLLS_OK;
+    ctx->n_stage0++;
+    TRY(enqueue_pack_reduce0(ctx)); TRY(comm_reduce(ctx, ctx->redbuf.p, ctx->redbuf_len, NLLS_REDUCE_SUM)); TRY(enqueue_unpack_reduce0(ctx, false));
+    return NLLS_OK;
+}
 int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
     NEED_READY();
     // cost_out == NULL: the caller does not want the cost (the outer loop between iterations, src/optimize.jl:167-170
     // discards it) -- the sweep is then only enqueued: no partial-sum kernel, no synchronisation
     if (ctx->reduce_fn) {
         // collective (include/nlls_amd.h): this rank's blocks, then ONE sum over ranks of [cost | reduced rows of A.data | reduced part of b]
-        TRY(enqueue_sweep_gradhess(ctx, true));
+        const bool lazy = !cost_out && ctx->lazy_stage0 && ctx->info.is_sparse && !ctx->elim_slab;
+        TRY(enqueue_sweep_gradhess(ctx, !lazy));
         ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
-        if (ctx->nranks > 1) { TRY(enqueue_pack_reduce0(ctx)); TRY(comm_reduce(ctx, ctx->redbuf.p, ctx->redbuf_len, NLLS_REDUCE_SUM)); TRY(enqueue_unpack_reduce0(ctx)); }
+        ctx->reduced_summed = !lazy;
+        if (lazy) return NLLS_OK;                                            // nothing is summed now: ensure_reduced_summed, or never
+        if (ctx->nranks > 1) { ctx->n_stage0++; TRY(enqueue_pack_reduce0(ctx)); TRY(comm_reduce(ctx, ctx->redbuf.p, ctx->redbuf_len, NLLS_REDUCE_SUM)); TRY(enqueue_unpack_reduce0(ctx, true)); }
         else TRY(comm_reduce(ctx, ctx->scalars.p, 1, NLLS_REDUCE_SUM));      // (one rank through the route: the same number of collectives)
         if (!cost_out) return NLLS_OK;
         TRY(fetch_scalars(ctx, 0, 1)); *cost_out = ctx->h_scalars[0];
         return NLLS_OK;
     }
     TRY(enqueue_sweep_gradhess(ctx, cost_out != nullptr));
-    ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
+    ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; ctx->reduced_summed = true;
     if (!cost_out) return NLLS_OK;
     TRY(fetch_scalars(ctx, 0, 1));
     *cost_out = ctx->h_scalars[0];
@@ -212,7 +230,7 @@ int nlls_grad_quadform(nlls_ctx* ctx, double* out) {
     if (out) *out = ctx->h_scalars[6]; return NLLS_OK;
 }
 
-int nlls_damp(nlls_ctx* ctx, double delta) { NEED_GRAD(); ctx->lambda += delta; return NLLS_OK; }
+int nlls_damp(nlls_ctx* ctx, double delta) { NEED_GRAD_LAZY(); ctx->lambda += delta; return NLLS_OK; }
 
 int nlls_solve(nlls_ctx* ctx, double* x_out) {
     NEED_GRAD();
@@ -235,8 +253,9 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
 // One Levenberg-Marquardt trial in one call and one synchronisation (src/iterators.jl:149-157): uniformscaling!(H, dlambda),
 // solve!, negate!, update!(to, from, x), cost(to).  Same kernels, same order as the separate entry points.
 int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, double* cost_out) {
-    NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
+    NEED_GRAD_LAZY(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
     const bool collective = ctx->reduce_fn != nullptr && ctx->info.is_sparse;
+    if (!collective) TRY(ensure_reduced_summed(ctx));
     if (ctx->nranks != 1 && !collective) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_lm_trial under nlls_set_shard needs an all-reduce (nlls_comm_init_rccl / nlls_set_allreduce), or the *_local / *_finish pairs");
     ctx->lambda += dlambda;
     ctx->step_cached = false;
@@ -244,6 +263,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         // the sharded trial, end to end on this rank's stream: local elimination, ONE sum of [S | s] over ranks, the reduced system solved on
         // every rank (each then holds the reduced part of the step: x is never summed), own back-substitution, retraction, own cost blocks,
         // and one gather of the ranks' scalars -- combined on the device and published to the host mirror as the single-GPU trial does
+        if (ctx->nranks > 1 && !ctx->reduced_summed) ctx->n_lazy_trials++;
         TRY(enqueue_solve_local(ctx));
         TRY(comm_reduce(ctx, ctx->S.p, (int64_t)ctx->s_elems + ctx->nred, NLLS_REDUCE_SUM));
         ctx->replicate_xr = true; int rc = enqueue_solve_finish(ctx); ctx->replicate_xr = false; TRY(rc);
@@ -363,10 +383,10 @@ int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
     int32_t status[16] = {0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    const int64_t vals[11] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
+    const int64_t vals[13] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
                               ctx->bcr.ready ? ctx->bcr.mfma_issued : 0, ctx->bcr.ready ? ctx->bcr.launches : 0, ctx->bcr.ready ? (int64_t)ctx->bcr.levels.size() : 0, ctx->n_band,
-                              status[4] /* pivots the floor of the last undamped band solve dropped */};
-    for (int i = 0; i < n && i < 11; ++i) out[i] = vals[i];
+                              status[4] /* pivots the floor of the last undamped band solve dropped */, ctx->n_stage0, ctx->n_lazy_trials};
+    for (int i = 0; i < n && i < 13; ++i) out[i] = vals[i];
     return NLLS_OK;
 }
 int nlls_set_step(nlls_ctx* ctx, const double* x) {
@@ -393,8 +413,9 @@ int nlls_step_norm(nlls_ctx* ctx, double* out) {
     if (out) *out = std::sqrt(ctx->h_scalars[2]); return NLLS_OK;
 }
 int nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out) {
-    NEED_GRAD();
+    NEED_GRAD_LAZY();
     if (ctx->step_cached) { if (xHx_out) *xHx_out = ctx->c_xAx + ctx->lambda * ctx->c_xx; if (gx_out) *gx_out = ctx->c_gx; return NLLS_OK; }   // damping may have changed since
+    TRY(ensure_reduced_summed(ctx));
     TRY(enqueue_quadform(ctx, ctx->x.p, 4)); TRY(comm_reduce(ctx, ctx->scalars.p + 4, 2, NLLS_REDUCE_SUM)); TRY(fetch_scalars(ctx, 4, 2));
     if (xHx_out) *xHx_out = ctx->h_scalars[4]; if (gx_out) *gx_out = ctx->h_scalars[5];
     return NLLS_OK;
@@ -409,7 +430,7 @@ int nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from) {
 //   sums, or takes the max of, them over ranks); the *_local / *_finish pairs bracket the buffer reductions.
 int nlls_sweep_gradhess_local(nlls_ctx* ctx) {
     NEED_READY(); TRY(enqueue_sweep_gradhess(ctx));
-    ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
+    ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; ctx->reduced_summed = true;     // (the caller sums the reduce buffer)
     if (ctx->nranks > 1) TRY(enqueue_pack_reduce0(ctx));
     return NLLS_OK;                                  // enqueue only: the reduce buffer is complete in stream order
 }
@@ -487,11 +508,11 @@ static int time_loop(nlls_ctx* ctx, int reps, float* ms_avg, int (*fn)(nlls_ctx*
 
 int nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
     NEED_READY(); int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c); });
-    ctx->have_grad = true; return rc;
+    ctx->have_grad = true; ctx->reduced_summed = true; return rc;
 }
 int nlls_time_sweep_accumulate(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
     NEED_READY(); int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c, false); });
-    ctx->have_grad = true; return rc;
+    ctx->have_grad = true; ctx->reduced_summed = true; return rc;
 }
 int nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
     NEED_READY(); return time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_cost(c, NLLS_VARS_CURRENT); });

@@ -211,6 +211,13 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_fast_members;   // members of the fast supernodes
     nlls::DevBuf<uint8_t> d_blk_slowmask;    // d_blk entries NOT in rows of fast members (and owned by this rank)
     nlls::DevBuf<nlls::SchurCopy> d_blk_slow; int64_t nblk_slow = 0;   // the same as a compact list
+    // collective route with the reduced rows NOT yet summed over ranks (lazy stage 0, nlls_sweep_gradhess(ctx, NULL)): every rank accounts for ITS share
+    // of the reduced rows -- the compact list with the reduced-reduced blocks on every rank, the all-blocks mask, and the dof mask of g'x
+    nlls::DevBuf<nlls::SchurCopy> d_blk_slow_lazy; int64_t nblk_slow_lazy = 0;
+    nlls::DevBuf<uint8_t> d_blk_mask_lazy; nlls::DevBuf<double> d_dof_mask_lazy;
+    bool reduced_summed = true;              // false between a lazy sweep and the first entry point that needs the summed rows (ensure_reduced_summed)
+    int64_t n_stage0 = 0, n_lazy_trials = 0; // (diagnostics: nlls_get_solve_stats [11], [12])
+    bool lazy_stage0 = true;                 // NLLS_EAGER_STAGE0=1: sum the reduced rows behind every sweep, as round 2 did (A/B)
     nlls::DevBuf<double> tE;                 // E_v s of the last solve per fast member (s = reduced solution): reused by the quadratic form
     bool tE_valid = false; int64_t n_fast_members = 0;
     bool status_known_zero = false;          // the host has read the last solve's status and it was 0: the next solve need not reset it on the device

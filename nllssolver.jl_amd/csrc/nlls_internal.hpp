@@ -60,7 +60,7 @@ int enqueue_solve_local(nlls_ctx* c);
 int enqueue_solve_finish(nlls_ctx* c);
 int enqueue_reduced_solve(nlls_ctx* c);   // the factorisation + backward pass of the assembled reduced system alone (timing)
 int enqueue_pack_reduce0(nlls_ctx* c);      // [cost | reduced rows | reduced b] -> redbuf
-int enqueue_unpack_reduce0(nlls_ctx* c);
+int enqueue_unpack_reduce0(nlls_ctx* c, bool with_cost = true);
 
 
 // collectives (nlls_comm.cpp)

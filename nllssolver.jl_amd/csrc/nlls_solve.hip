@@ -2159,7 +2159,7 @@ __global__ __launch_bounds__(256) void quadform_points_kernel(const double* __re
 // (six launches before; a launch boundary costs ~5 us here).  Workgroups [0, np): blocks of H outside the fast-path rows;
 // [np, np + np3): the fast-path rows from E_v s; [np + np3, np + np3 + np2): one pass over x and b.
 struct PostSolveArgs { const double* A; const SchurCopy* blk; int64_t nblk; const uint8_t* blkmask; const int64_t* ediag; const uint32_t* eboff;
-                       const uint32_t* members; int64_t nm; const double* tE; const double* x; const double* b; const double* dofmask; int64_t ndof;
+                       const uint32_t* members; int64_t nm; const double* tE; const double* x; const double* b; const double* dofmask; const double* dofmask_b; int64_t ndof;
                        double* partials; double* part2; int np, np3, np2;
                        int nretract; const int32_t* vkind; const int32_t* vdim; const uint32_t* voff; const uint32_t* vboff; int64_t nvar; const double* vfrom; double* vto; };
 template <int DV>
@@ -2176,9 +2176,9 @@ __global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) {
     const int b2 = bid - a.np - a.np3;
     double m = 0, ss = 0, vv = 0, bv = 0, nan = 0;
     for (int64_t i = (int64_t)b2 * 256 + threadIdx.x; i < a.ndof; i += (int64_t)a.np2 * 256) {
-        const double x = a.x[i], w = a.dofmask ? a.dofmask[i] : 1.0;
+        const double x = a.x[i], w = a.dofmask ? a.dofmask[i] : 1.0, wb = a.dofmask_b ? a.dofmask_b[i] : w;
         if (x != x) nan = 1.0;
-        m = fmax(m, w * fabs(x)); ss += x * x; vv += w * x * x; bv += w * a.b[i] * x;     // (w: this rank's share under sharding, 1 otherwise)
+        m = fmax(m, w * fabs(x)); ss += x * x; vv += w * x * x; bv += wb * a.b[i] * x;    // (w: this rank's share under sharding, 1 otherwise; wb: its share of g -- the reduced part too while the reduced rows are not summed over ranks)
     }
     ss = wsum(ss); vv = wsum(vv); bv = wsum(bv);
 #pragma unroll
@@ -2383,9 +2383,11 @@ int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from, bool finis
     }
     const bool reuse = c->tE_valid && c->n_fast_members > 0;
     PostSolveArgs a{};
-    a.A = c->A.p; a.blk = reuse ? c->d_blk_slow.p : c->d_blk.p; a.nblk = reuse ? c->nblk_slow : c->nblk; a.blkmask = reuse ? (const uint8_t*)nullptr : (c->nranks > 1 ? c->d_blk_mask.p : (const uint8_t*)nullptr);
+    const bool lazy = c->nranks > 1 && !c->reduced_summed;      // the reduced rows of A.data and b hold this rank's share only: they count on every rank
+    a.A = c->A.p; a.blk = reuse ? (lazy ? c->d_blk_slow_lazy.p : c->d_blk_slow.p) : c->d_blk.p; a.nblk = reuse ? (lazy ? c->nblk_slow_lazy : c->nblk_slow) : c->nblk;
+    a.blkmask = reuse ? (const uint8_t*)nullptr : (c->nranks > 1 ? (lazy ? c->d_blk_mask_lazy.p : c->d_blk_mask.p) : (const uint8_t*)nullptr);
     a.ediag = c->d_elim_diag.p; a.eboff = c->d_elim_boff.p; a.members = c->d_fast_members.p; a.nm = c->n_fast_members; a.tE = c->tE.p;
-    a.x = c->x.p; a.b = c->b.p; a.dofmask = c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr; a.ndof = c->info.ndof;
+    a.x = c->x.p; a.b = c->b.p; a.dofmask = c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr; a.dofmask_b = lazy ? c->d_dof_mask_lazy.p : (const double*)nullptr; a.ndof = c->info.ndof;
     a.np = (int)std::max<int64_t>(1, std::min<int64_t>((a.nblk + 255) / 256, 768));
     a.np3 = reuse ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
     a.np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 256));
@@ -2427,7 +2429,11 @@ static SLayout make_layout(nlls_ctx* c) {
 int enqueue_solve_local(nlls_ctx* c) {
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
     const SLayout L = make_layout(c); const int npad = L.npad;
-    const bool band = c->solve_mode == SOLVE_BAND; const bool lead = c->nranks == 1 || c->rank == 0;
+    // lazy stage 0 (collective route, reduced rows not summed over ranks): EVERY rank adds its share of the reduced-reduced blocks and of b_R to its
+    // share of [S | s] -- the one sum over ranks that follows completes both; the damping is rank 0's
+    const bool lazy = c->nranks > 1 && !c->reduced_summed;
+    const bool band = c->solve_mode == SOLVE_BAND; const bool lead = c->nranks == 1 || c->rank == 0 || lazy;
+    const double lambda_rr = (c->nranks == 1 || c->rank == 0) ? c->lambda : 0.0;
     if (c->elim_slab) {
         // slab + gather assembly (deterministic): (C_v + lambda I)^-1, the supernodes' shares into their slabs, one gather into the tiles
         const int64_t nel = (int64_t)c->d_elim_diag.n;
@@ -2477,11 +2483,11 @@ int enqueue_solve_local(nlls_ctx* c) {
     if (one_prepare) {
         const int ninit = (std::max(npad, n) + 255) / 256;
         hipLaunchKernelGGL(schur_prepare_kernel, dim3((unsigned)(ninit + c->ncopy)), dim3(256), 0, c->stream, L, c->s_ptr(), c->b.p, c->d_red_boff.p,
-                           c->A.p, c->d_copy.p, c->lambda, ninit, c->d_status.p);
+                           c->A.p, c->d_copy.p, lambda_rr, ninit, c->d_status.p);
     } else if (lead) {
         hipLaunchKernelGGL(schur_init_kernel, dim3((std::max(npad, n) + 255) / 256), dim3(256), 0, c->stream, L, c->s_ptr(), c->b.p, c->d_red_boff.p);
         if (c->info.is_sparse) {
-            if (c->ncopy > 0) hipLaunchKernelGGL(schur_copy_kernel, dim3((unsigned)c->ncopy), dim3(64), 0, c->stream, L, c->A.p, c->d_copy.p, c->lambda);
+            if (c->ncopy > 0) hipLaunchKernelGGL(schur_copy_kernel, dim3((unsigned)c->ncopy), dim3(64), 0, c->stream, L, c->A.p, c->d_copy.p, lambda_rr);
         } else {
             const int64_t n2 = (int64_t)n * n;
             hipLaunchKernelGGL(dense_to_S_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->S.p, c->A.p, c->lambda, n, npad);

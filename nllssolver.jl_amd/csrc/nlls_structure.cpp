@@ -91,7 +91,7 @@ static int compact_hot_set(nlls_ctx* c) {
 
 int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
-    c->ready = false; c->solved = false; c->have_grad = false; c->lambda = 0;
+    c->ready = false; c->solved = false; c->have_grad = false; c->lambda = 0; c->reduced_summed = true; c->n_stage0 = 0; c->n_lazy_trials = 0;
     { std::vector<HotItem> v; hot_set(c, v); for (HotItem& it : v) if (!*it.owned) { *it.pp = nullptr; *it.owned = true; } }   // what lived in the previous upload's arena is gone with it
     c->groups.clear();
     // ---- variables ------------------------------------------------------------------------------
@@ -681,6 +681,15 @@ int build_schur(nlls_ctx* c, int32_t flags) {
       std::vector<SchurCopy> slowblks;
       for (size_t q = 0; q < slowmask.size(); ++q) if (slowmask[q]) slowblks.push_back(blks[q]);
       c->nblk_slow = (int64_t)slowblks.size();
+      if (c->nranks > 1) {      // lazy stage 0: the reduced rows hold this rank's share only -- they count on EVERY rank
+          std::vector<uint8_t> blkmask2; std::vector<double> dofmask2(dofmask); std::vector<SchurCopy> slow2; size_t q = 0;
+          for (int64_t row = 0; row < nb; ++row) { const bool own2 = c->is_elim[row] ? rowmask[row] != 0 : true;
+              if (!c->is_elim[row]) for (int i = 0; i < c->blocksizes[row]; ++i) dofmask2[c->boffsets[row] + i] = 1.0;
+              for (int64_t qq = c->it_colptr[row]; qq < c->it_colptr[row + 1]; ++qq, ++q) { blkmask2.push_back(own2);
+                  if (!slowmask.empty() && own2 && !row_fast[row]) slow2.push_back(blks[q]); } }
+          c->nblk_slow_lazy = (int64_t)slow2.size();
+          if (hipSuccess != c->d_blk_mask_lazy.upload(blkmask2) || hipSuccess != c->d_dof_mask_lazy.upload(dofmask2) || hipSuccess != c->d_blk_slow_lazy.upload(slow2)) return fail(c, NLLS_ERR_HIP, "mask upload");
+      }
       if (hipSuccess != c->d_row_mask.upload(rowmask) || hipSuccess != c->d_blk_mask.upload(blkmask) || hipSuccess != c->d_dof_mask.upload(dofmask) ||
           hipSuccess != c->d_blk_slowmask.upload(slowmask) || hipSuccess != c->d_blk_slow.upload(slowblks)) return fail(c, NLLS_ERR_HIP, "mask upload"); }
     if (hipSuccess != c->d_copy.upload(copies) || hipSuccess != c->d_red_boff.upload(red_boff)) return fail(c, NLLS_ERR_HIP, "schur upload");

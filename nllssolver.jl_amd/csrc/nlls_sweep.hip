@@ -456,7 +456,7 @@ __global__ void unpack_reduce0_kernel(double* __restrict__ A, double* __restrict
                                       const uint32_t* __restrict__ dst, const uint32_t* __restrict__ which, double* __restrict__ scalars, const double* __restrict__ buf) {
     double* d = (which[blockIdx.x] ? b : A) + off[blockIdx.x]; const double* src = buf + dst[blockIdx.x];
     for (uint32_t i = threadIdx.x; i < len[blockIdx.x]; i += blockDim.x) d[i] = src[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) scalars[0] = buf[0];
+    if (scalars && blockIdx.x == 0 && threadIdx.x == 0) scalars[0] = buf[0];
 }
 
 // ================================================================================================
@@ -597,10 +597,10 @@ int enqueue_pack_reduce0(nlls_ctx* c) {
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
-int enqueue_unpack_reduce0(nlls_ctx* c) {
+int enqueue_unpack_reduce0(nlls_ctx* c, bool with_cost) {
     if (c->nred_ranges > 0)
         hipLaunchKernelGGL(unpack_reduce0_kernel, dim3((unsigned)c->nred_ranges), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_red_off.p, c->d_red_len.p,
-                           c->d_red_dst.p, c->d_red_which.p, c->scalars.p, c->redbuf.p);
+                           c->d_red_dst.p, c->d_red_which.p, with_cost ? c->scalars.p : (double*)nullptr, c->redbuf.p);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
