@@ -116,7 +116,10 @@ def main():
     # few iterations.  What is comparable: both reduce the cost, to the same level.  Exact agreement of single steps is asserted above.)
     # The tolerance is what two UNSHARDED runs show on this very problem (their spread, measured here), not a constant.
     ref5 = MultiVariateLSgpu(p, unfixed); cd_r2, _ = run(ref5, 4, It.DoglegData, It.iterate_dogleg); ref5.close()
-    spread = abs(cd_r - cd_r2) / abs(cd_r)
+    # (every rank has run the unsharded loop twice in its own process: the spread over ALL of these runs -- two runs of one process agree more closely
+    #  than runs of different processes do)
+    runs = [None] * world; dist.all_gather_object(runs, (cd_r, cd_r2)); runs = [v for pair in runs for v in pair]
+    spread = (max(runs) - min(runs)) / abs(cd_r)
     assert cd_r < 0.9 * c_ref and cd_s < 0.9 * c_ref and abs(cd_r - cd_s) <= max(8.0 * spread, 1e-6) * abs(cd_r), (c_ref, cd_r, cd_r2, cd_s, spread)
     for o in (ref, sh, ref2, sh2, ref3, sh3):
         o.close()
