@@ -46,6 +46,7 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     { const char* e = getenv("NLLS_ELIM_TILED"); if (e && e[0] == '1') c->elim_mfma = false; }
     { const char* e = getenv("NLLS_DENSE_T64"); if (e && e[0] == '1') c->dense_t128 = false; }
     { const char* e = getenv("NLLS_EAGER_STAGE0"); if (e && e[0] == '1') c->lazy_stage0 = false; }
+    { const char* e = getenv("NLLS_POST_SPLIT"); if (e && e[0] == '1') c->post_fuse = false; }
     { const char* e = getenv("NLLS_ELIM_SPLIT"); if (e && e[0] == '1') c->elim_split = true; }
     { const char* e = getenv("NLLS_SWEEP_SPLIT3"); if (e && e[0] == '1') c->sweep_split3 = true; }
     { const char* e = getenv("NLLS_DENSE_STEP_BACKWARD"); if (e && e[0] == '1') c->dense_fused_bwd = false; }
@@ -266,13 +267,15 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         if (ctx->nranks > 1 && !ctx->reduced_summed) ctx->n_lazy_trials++;
         TRY(enqueue_solve_local(ctx));
         TRY(comm_reduce(ctx, ctx->S.p, (int64_t)ctx->s_elems + ctx->nred, NLLS_REDUCE_SUM));
-        ctx->replicate_xr = true; int rc = enqueue_solve_finish(ctx); ctx->replicate_xr = false; TRY(rc);
+        if (ctx->nranks == 1) { ctx->trial_to = to; ctx->trial_from = from; }      // (one rank through the route: the same launches as the unsharded trial)
+        ctx->replicate_xr = true; int rc = enqueue_solve_finish(ctx); ctx->replicate_xr = false; ctx->trial_to = ctx->trial_from = -1; TRY(rc);
         double* const mirror = ctx->h_scalars_dev; ctx->h_scalars_dev = nullptr;           // (the rank's own scalars are not what the host waits for)
         rc = enqueue_lm_trial_tail(ctx, to, from); ctx->h_scalars_dev = mirror; TRY(rc);
         TRY(comm_gather_trial_scalars(ctx, (double)ctx->trial_seq));
     } else {
-    TRY(enqueue_solve(ctx));
-    TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form + retraction in one launch, the cost sweep, one finishing launch
+    ctx->trial_to = to; ctx->trial_from = from;    // (the back-substitution launch may take the retraction with it: enqueue_solve_finish)
+    { const int rc = enqueue_solve(ctx); ctx->trial_to = ctx->trial_from = -1; TRY(rc); }
+    TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form (+ retraction) and the cost sweep, one finishing launch
     }
     // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
     if (!ctx->info.is_sparse || !ctx->h_scalars_dev) {

@@ -10,20 +10,27 @@
 #include <utility>
 
 #include "nlls_wave.hpp"
+#include "nlls_post.hpp"
 
 namespace nlls {
 
 // ================================================================================================
 // cost sweep   src/cost.jl:10-13 -> src/residual.jl:49-55
 // ================================================================================================
-template <int KIND>
+// POST: the workgroups in front of the last `cgrid` carry the step-statistics roles of an LM trial (nlls_post.hpp: quadratic form, g'x, max |x| of the step the
+// back-substitution in front of this launch has just formed -- independent of the cost blocks, and a launch of their own would cost more than they do)
+template <int KIND, bool POST>
 __global__ __launch_bounds__(TPB) void cost_kernel(const double* __restrict__ vars, const double* __restrict__ data,
                                                    const uint32_t* __restrict__ voff, const uint32_t* __restrict__ index,
-                                                   int64_t n, RobustSpec rk, double* __restrict__ partials) {
+                                                   int64_t n, RobustSpec rk, double* __restrict__ partials, int cgrid, PostSolveArgs post) {
     using R = Res<KIND>;
+    // (the roles come FIRST in the grid: their chains of dependent loads are the longer ones, and the cost blocks alone fill every wave slot of the chip --
+    //  behind them the roles would only start when the sweep is over)
+    int bid = (int)blockIdx.x;
+    if constexpr (POST) { const int npost = (int)gridDim.x - cgrid; if (bid < npost) { post_roles_any(post, bid); return; } bid -= npost; }
     __shared__ double red[TPB / 64];
     double acc = 0;
-    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    for (int64_t i = (int64_t)bid * TPB + threadIdx.x; i < n; i += (int64_t)cgrid * TPB) {
         const int64_t k = index ? index[i] : i;
         double d[R::NDATA]; uint32_t vo[R::NDEPS];
 #pragma unroll
@@ -33,7 +40,7 @@ __global__ __launch_bounds__(TPB) void cost_kernel(const double* __restrict__ va
         acc += block_cost<KIND>(vars, vo, d, rk);
     }
     double t = block_sum(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    if (threadIdx.x == 0) partials[bid] = t;
 }
 
 // final deterministic reduction of the per-workgroup partials
@@ -337,12 +344,15 @@ static int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::str
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return herr(c, e_, #expr); } while (0)
 
 template <int KIND>
-static int launch_cost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+static int launch_cost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase, const PostSolveArgs* post, bool* taken) {
     if (G.ncost > 0) {
         int grid = (int)std::min<int64_t>((G.ncost + TPB - 1) / TPB, 2048);
         const bool shared = G.cost_list >= 0 && c->info.is_sparse;
         const double* data = shared ? G.lists[G.cost_list].data.p : G.data.p; const uint32_t* voff = shared ? G.lists[G.cost_list].voff.p : G.voff.p;
-        hipLaunchKernelGGL(cost_kernel<KIND>, dim3(grid), dim3(TPB), 0, c->stream, vars, data, voff, (const uint32_t*)nullptr, G.ncost, G.rk, c->partials.p + pbase);
+        if (post && taken && !*taken) {      // the first launch of the sweep takes the statistics roles along
+            hipLaunchKernelGGL((cost_kernel<KIND, true>), dim3(grid + post->np + post->np3 + post->np2), dim3(TPB), 0, c->stream, vars, data, voff, (const uint32_t*)nullptr, G.ncost, G.rk, c->partials.p + pbase, grid, *post);
+            *taken = true;
+        } else hipLaunchKernelGGL((cost_kernel<KIND, false>), dim3(grid), dim3(TPB), 0, c->stream, vars, data, voff, (const uint32_t*)nullptr, G.ncost, G.rk, c->partials.p + pbase, grid, PostSolveArgs{});
         pbase += grid;
     }
     return NLLS_OK;
@@ -351,7 +361,7 @@ template <int KIND>
 static int launch_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
     if (G.nfixedcost > 0) {
         int grid = (int)std::min<int64_t>((G.nfixedcost + TPB - 1) / TPB, 2048);
-        hipLaunchKernelGGL(cost_kernel<KIND>, dim3(grid), dim3(TPB), 0, c->stream, vars, G.data.p, G.voff.p, G.fixedcost.p, G.nfixedcost, G.rk, c->partials.p + pbase);
+        hipLaunchKernelGGL((cost_kernel<KIND, false>), dim3(grid), dim3(TPB), 0, c->stream, vars, G.data.p, G.voff.p, G.fixedcost.p, G.nfixedcost, G.rk, c->partials.p + pbase, grid, PostSolveArgs{});
         pbase += grid;
     }
     return NLLS_OK;
@@ -392,12 +402,12 @@ int enqueue_reduce_partials(nlls_ctx* c, int64_t n) {
 }
 
 // pofs / count: an LM trial leaves the partials un-reduced at partials + pofs (count of them in *count) for enqueue_trial_finish
-int enqueue_sweep_cost(nlls_ctx* c, int which, int64_t pofs, int64_t* count) {
+int enqueue_sweep_cost(nlls_ctx* c, int which, int64_t pofs, int64_t* count, const PostSolveArgs* post, bool* post_taken) {
     const double* vars = vars_ptr(c, which); int64_t pbase = pofs;
     for (const Group& G : c->groups) {
         if (is_dyn_kind(G.res_kind)) { launch_dyn_cost(c, G, vars, pbase, false); continue; }
         switch (G.res_kind) {
-#define X(K) case K: launch_cost<K>(c, G, vars, pbase); break;
+#define X(K) case K: launch_cost<K>(c, G, vars, pbase, post, post_taken); break;
             NLLS_FOR_EACH_RES(X)
 #undef X
         }

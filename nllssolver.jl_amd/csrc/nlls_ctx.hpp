@@ -89,7 +89,7 @@ struct Group {
 // ---- Schur / solve structures ---------------------------------------------------------------------
 // one fast-path supernode, in launch order (position in d_fast_groups): everything a kernel needs to start on it comes with ONE
 // uniform 32-byte load instead of a chain of dependent ones (group list -> group -> neighbour pointer -> neighbour records)
-constexpr int64_t TRIAL_COST_POFS = 4096;   // offset of the cost partials of an LM trial in nlls_ctx::partials (the post-solve partials end at 2304)
+constexpr int64_t TRIAL_COST_POFS = 4096;   // offset of the cost partials of an LM trial in nlls_ctx::partials (the post-solve partials end at 3584)
 struct ElimDesc {
     uint32_t v0, nmem;       // first member (index into the elimination arrays), members
     uint32_t nd, rc_off;     // columns of [E] (neighbour dof), offset of their reduced columns in d_elim_rc
@@ -184,6 +184,11 @@ struct nlls_ctx {
     int dense_t128_min = 16;                   // ... only while the trailing matrix has at least this many 128-blocks per side (fewer: the 64 x 64 kernel fills the chip better)
     bool dense_t128 = true;                    // dense LDL': 128 x 128 tiles in the two-panel trailing update (NLLS_DENSE_T64=1: the 64 x 64 kernel, for A/B runs)
     bool dense_fused_bwd = true;               // dense LDL': the backward substitution in one launch (NLLS_DENSE_STEP_BACKWARD=1: one launch per 64-column block, for A/B runs)
+    // LM trial with the retraction inside the back-substitution launch and the step statistics / quadratic form inside the cost sweep's launch
+    // (one rank, every eliminated block on the fast path, Euclidean eliminated variables): no launch of its own for them.  NLLS_POST_SPLIT=1: off (A/B)
+    nlls::DevBuf<uint32_t> d_fast_voff;      // where the variable of each eliminated member is stored (elimination order)
+    nlls::DevBuf<uint32_t> d_rest_var; nlls::DevBuf<int32_t> d_rest_red;   // the other variables, and where their step starts in the reduced solution (-1: fixed)
+    bool fast_all_euclid = false, post_fuse = true, retract_done = false; int trial_to = -1, trial_from = -1;
     bool elim_split = false;                   // NLLS_ELIM_SPLIT=1: the assembly of the reduced system in three launches (A/B)
     bool sweep_split3 = false;                 // NLLS_SWEEP_SPLIT3=1: the three-slot accumulate sweep in one launch per role (A/B)
     bool elim_mfma = true;                     // narrow supernodes (nd + 1 <= 64) are eliminated on the matrix cores (NLLS_ELIM_TILED=1: the register-tiled kernel, for A/B runs)

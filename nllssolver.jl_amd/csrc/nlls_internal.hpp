@@ -19,7 +19,8 @@ int select_elimination(nlls_ctx* c, int32_t flags);
 int build_schur(nlls_ctx* c, int32_t flags);
 
 // sweeps (nlls_sweep.hip): enqueue on c->stream; cost lands in c->scalars[0]
-int enqueue_sweep_cost(nlls_ctx* c, int which, int64_t pofs = 0, int64_t* count = nullptr);
+struct PostSolveArgs;
+int enqueue_sweep_cost(nlls_ctx* c, int which, int64_t pofs = 0, int64_t* count = nullptr, const PostSolveArgs* post = nullptr, bool* post_taken = nullptr);   // post: the step-statistics roles of an LM trial ride in the first launch (nlls_post.hpp)
 // (nlls_cost.hip) cost-only blocks and the final reduction of the cost partials, shared with the gradient sweep
 int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);
 int enqueue_dyn_gradhess(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);   // dynamic-size residual blocks (dense system): accumulate
@@ -40,18 +41,22 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from);   // post-solve statis
 
 #if defined(__HIPCC__)
 // to[var i] = update(from[var i], x[its block])   (src/linearsystem.jl:206-213); fixed variables are copied
+// dx: the variable's own step (its block of x)
+__device__ __forceinline__ void retract_var(int k, int d, uint32_t o, const double* __restrict__ from, const double* __restrict__ dx, double* __restrict__ to) {
+    if (k == NLLS_VAR_EUCLIDEAN || k == NLLS_VAR_DYNAMIC) { for (int q = 0; q < d; ++q) to[o + q] = from[o + q] + dx[q]; return; }   // v + delta (src/variable.jl:5): no staging arrays (any length)
+    double in[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], out[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], st[NLLS_MAX_BLOCK_SZ];
+    const int ns = var_storage(k, d), nd = var_dof(k, d);
+    for (int q = 0; q < ns; ++q) in[q] = from[o + q];
+    for (int q = 0; q < nd; ++q) st[q] = dx[q];
+    var_update_real(k, d, in, st, out);
+    for (int q = 0; q < ns; ++q) to[o + q] = out[q];
+}
 __device__ __forceinline__ void retract_one(const int32_t* __restrict__ kind, const int32_t* __restrict__ dim, const uint32_t* __restrict__ voff,
                                             const uint32_t* __restrict__ vboff, int64_t i, const double* __restrict__ from,
                                             const double* __restrict__ x, double* __restrict__ to) {
     const int k = kind[i], d = dim[i]; const uint32_t o = voff[i], bo = vboff[i];
     if (bo == DEST_NONE) { const int st = var_storage(k, d); for (int q = 0; q < st; ++q) to[o + q] = from[o + q]; return; }
-    if (k == NLLS_VAR_EUCLIDEAN || k == NLLS_VAR_DYNAMIC) { for (int q = 0; q < d; ++q) to[o + q] = from[o + q] + x[bo + q]; return; }   // v + delta (src/variable.jl:5): no staging arrays (any length)
-    double in[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], out[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], st[NLLS_MAX_BLOCK_SZ];
-    const int ns = var_storage(k, d), nd = var_dof(k, d);
-    for (int q = 0; q < ns; ++q) in[q] = from[o + q];
-    for (int q = 0; q < nd; ++q) st[q] = x[bo + q];
-    var_update_real(k, d, in, st, out);
-    for (int q = 0; q < ns; ++q) to[o + q] = out[q];
+    retract_var(k, d, o, from, x + bo, to);
 }
 #endif
 // solve (nlls_solve.hip)

@@ -15,6 +15,7 @@
 #include <utility>
 
 #include "nlls_wave.hpp"
+#include "nlls_post.hpp"
 
 namespace nlls {
 
@@ -238,19 +239,34 @@ NLLS_DEV double row_shr_add(double v) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
     return v + __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true));
 }
+// The retraction of an LM trial (update!(to, from, x), src/iterators.jl:155) rides in this launch (on != 0): the supernode's wavefront retracts its own
+// members from the step it has just formed (Euclidean variables of DV entries: checked at upload), workgroups behind the others retract every
+// other variable from the reduced solution itself (x_R = -xr: the scatter of this very launch is not visible to them) -- the cost sweep is then the
+// next launch, and the step statistics ride in ITS launch (nlls_post.hpp): no launch of their own for either.
+struct BsfRetract { int on, nrest; const uint32_t* fast_voff; const uint32_t* rest_var; const int32_t* rest_red;
+                    const int32_t* vkind; const int32_t* vdim; const uint32_t* voff; const double* vfrom; double* vto; };
 template <int DV>
 __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                                 const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
                                                                 const double* __restrict__ Cinv, const double* __restrict__ xr, double* __restrict__ x, double* __restrict__ tE,
                                                                 uint32_t ngroups, const uint32_t* __restrict__ red_boff, int nred, int write_red,
-                                                                double* __restrict__ Szero, int64_t nzero) {
+                                                                double* __restrict__ Szero, int64_t nzero, uint32_t nextra, BsfRetract rt) {
     constexpr int MAXC = (72 + 15) / 16;                      // columns per lane (nd <= 72)
     __shared__ uint32_t rc[80];
     const int lane = threadIdx.x, l = lane & 15, gsub = lane >> 4;
+    if (blockIdx.x >= ngroups + nextra) {                     // (only with rt.on) one thread per variable that is no member of a fast supernode
+        const int j = (int)(blockIdx.x - ngroups - nextra) * 64 + lane; if (j >= rt.nrest) return;
+        const uint32_t i = rt.rest_var[j]; const int r0 = rt.rest_red[j]; const int k = rt.vkind[i], d = rt.vdim[i]; const uint32_t o = rt.voff[i];
+        if (r0 < 0) { const int st = var_storage(k, d); for (int q = 0; q < st; ++q) rt.vto[o + q] = rt.vfrom[o + q]; return; }      // fixed: copied
+        double dx[NLLS_MAX_BLOCK_SZ]; const int nd2 = var_dof(k, d);
+        for (int q = 0; q < NLLS_MAX_BLOCK_SZ; ++q) dx[q] = (q < nd2 && write_red) ? -xr[r0 + q] : 0.0;
+        retract_var(k, d, o, rt.vfrom, dx, rt.vto);
+        return;
+    }
     if (blockIdx.x >= ngroups) {                              // the workgroups behind the supernodes scatter the reduced part: x_R = -s
-        for (int i = (blockIdx.x - ngroups) * 64 + lane; i < nred; i += (gridDim.x - ngroups) * 64) x[red_boff[i]] = write_red ? -xr[i] : 0.0;
+        for (int i = (blockIdx.x - ngroups) * 64 + lane; i < nred; i += nextra * 64) x[red_boff[i]] = write_red ? -xr[i] : 0.0;
         // ... and leave the reduced system's storage zero-filled for the next solve (nothing reads S any more)
-        for (int64_t i = (int64_t)(blockIdx.x - ngroups) * 64 + lane; i < nzero; i += (int64_t)(gridDim.x - ngroups) * 64) Szero[i] = 0.0;
+        for (int64_t i = (int64_t)(blockIdx.x - ngroups) * 64 + lane; i < nzero; i += (int64_t)nextra * 64) Szero[i] = 0.0;
         return;
     }
     const ElimDesc d = desc[blockIdx.x];                       // uniform: one scalar load
@@ -260,6 +276,14 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
     double xw[MAXC];
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) { const int col = l + 16 * k; xw[k] = col < nd ? xr[rc[col]] : 0.0; }
+    // (rt.on) the members' variables, two per lane, requested NOW: at the end of the loop only an add and a store are left
+    uint32_t ro[2] = {0, 0}; double rv[2][DV];
+    if (rt.on) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const uint32_t m = lane + 64 * h; ro[h] = rt.fast_voff[v0 + (m < v1 - v0 ? m : 0)];
+#pragma unroll
+            for (int a2 = 0; a2 < DV; ++a2) rv[h][a2] = rt.vfrom[ro[h] + a2]; }
+    }
     // The members of a supernode are consecutive block rows (constant stride in A.data, b and x: nlls_structure.cpp), so
     // nothing is looked up per member.  Four members per step, one per 16 lanes; the loads of the next step are issued
     // before this one is reduced (two register sets), and the results wait in LDS until the loop is over -- a store
@@ -314,6 +338,12 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
     __syncthreads();
     const uint32_t nout = (v1 - v0) * DV;                     // x and tE of the supernode's members are contiguous
     for (uint32_t i = lane; i < nout; i += 64) { x[eb0 + i] = xs[i]; tE[(int64_t)v0 * DV + i] = ts[i]; }
+    if (rt.on) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const uint32_t m = lane + 64 * h; if (m >= v1 - v0) continue;
+#pragma unroll
+            for (int a2 = 0; a2 < DV; ++a2) rt.vto[ro[h] + a2] = rv[h][a2] + xs[m * DV + a2]; }
+    }
 }
 
 // Fast path of the elimination for supernodes whose members (a) have the compile-time block size DV and (b) store
@@ -2103,50 +2133,9 @@ __global__ __launch_bounds__(256) void band_backward_tiles_kernel(BwdArgs2 args)
 // ---------------------------------------------------------------------------------------------------
 // fast_bAb(H + lambda I, v) and dot(b, v)   src/utils.jl:71-106, src/iterators.jl:52,163
 // ---------------------------------------------------------------------------------------------------
-// (bodies take a virtual workgroup index / count, so that post_solve_kernel can run several of them in one launch)
-__device__ __forceinline__ void quadform_blocks_body(const double* __restrict__ A, const SchurCopy* __restrict__ blk, int64_t nblk,
-                                                     const double* __restrict__ v, const uint8_t* __restrict__ mask, double* __restrict__ partials, int bid, int nb) {
-    __shared__ double red[4];
-    double acc = 0;
-    for (int64_t q = (int64_t)bid * 256 + threadIdx.x; q < nblk; q += (int64_t)nb * 256) {
-        if (mask && !mask[q]) continue;
-        const SchurCopy bk = blk[q]; double t = 0;
-        for (int j = 0; j < bk.cols; ++j) { double c2 = 0; for (int i = 0; i < bk.rows; ++i) c2 += A[bk.off + i + bk.rows * j] * v[bk.r + i]; t += c2 * v[bk.c + j]; }
-        acc += (bk.r == bk.c) ? t : 2.0 * t;
-    }
-    acc = wsum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[bid] = red[0] + red[1] + red[2] + red[3];
-}
 __global__ __launch_bounds__(256) void quadform_blocks_kernel(const double* __restrict__ A, const SchurCopy* __restrict__ blk, int64_t nblk,
                                                               const double* __restrict__ v, const uint8_t* __restrict__ mask, double* __restrict__ partials) {
     quadform_blocks_body(A, blk, nblk, v, mask, partials, (int)blockIdx.x, (int)gridDim.x);
-}
-// rows of fast-path members, for the step x of the last solve: x' A x restricted to row v is
-//   2 x_v' (E_v x_R) + x_v' C_v x_v,   E_v x_R = -E_v s  -- and E_v s is what schur_backsub_fast_kernel left in tE
-template <int DV>
-__device__ __forceinline__ void quadform_points_body(const double* __restrict__ A, const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
-                                                     const uint32_t* __restrict__ members, int64_t nm, const double* __restrict__ tE,
-                                                     const double* __restrict__ x, double* __restrict__ partials, int bid, int nb) {
-    __shared__ double red[4];
-    double acc = 0;
-    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < nm; i += (int64_t)nb * 256) {
-        const uint32_t v = members[i];
-        double xv[DV], t = 0;
-#pragma unroll
-        for (int a2 = 0; a2 < DV; ++a2) { xv[a2] = x[eboff[v] + a2]; t -= 2.0 * xv[a2] * tE[(int64_t)v * DV + a2]; }
-#pragma unroll
-        for (int j = 0; j < DV; ++j) { double c2 = 0;
-#pragma unroll
-            for (int i2 = 0; i2 < DV; ++i2) c2 += A[ediag[v] + i2 + DV * j] * xv[i2];
-            t += c2 * xv[j]; }
-        acc += t;
-    }
-    acc = wsum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[bid] = red[0] + red[1] + red[2] + red[3];
 }
 template <int DV>
 __global__ __launch_bounds__(256) void quadform_points_kernel(const double* __restrict__ A, const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
@@ -2154,43 +2143,8 @@ __global__ __launch_bounds__(256) void quadform_points_kernel(const double* __re
                                                               const double* __restrict__ x, double* __restrict__ partials) {
     quadform_points_body<DV>(A, ediag, eboff, members, nm, tE, x, partials, (int)blockIdx.x, (int)gridDim.x);
 }
-// Everything the iterators ask about the step x of the last solve -- maximum(abs, x), |x|^2 (src/optimize.jl:149,
-// src/callbacks.jl:47), fast_bAb(H, x) and dot(g, x) (src/iterators.jl:163) -- in ONE launch plus one finishing workgroup
-// (six launches before; a launch boundary costs ~5 us here).  Workgroups [0, np): blocks of H outside the fast-path rows;
-// [np, np + np3): the fast-path rows from E_v s; [np + np3, np + np3 + np2): one pass over x and b.
-struct PostSolveArgs { const double* A; const SchurCopy* blk; int64_t nblk; const uint8_t* blkmask; const int64_t* ediag; const uint32_t* eboff;
-                       const uint32_t* members; int64_t nm; const double* tE; const double* x; const double* b; const double* dofmask; const double* dofmask_b; int64_t ndof;
-                       double* partials; double* part2; int np, np3, np2;
-                       int nretract; const int32_t* vkind; const int32_t* vdim; const uint32_t* voff; const uint32_t* vboff; int64_t nvar; const double* vfrom; double* vto; };
 template <int DV>
-__global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) {
-    const int bid = (int)blockIdx.x;
-    if (bid < a.np) { quadform_blocks_body(a.A, a.blk, a.nblk, a.x, a.blkmask, a.partials, bid, a.np); return; }
-    if (bid < a.np + a.np3) { quadform_points_body<DV>(a.A, a.ediag, a.eboff, a.members, a.nm, a.tE, a.x, a.partials + a.np, bid - a.np, a.np3); return; }
-    if (bid >= a.np + a.np3 + a.np2) {                          // the retraction of the LM trial (update!, src/iterators.jl:155): one thread per variable
-        const int64_t i = (int64_t)(bid - a.np - a.np3 - a.np2) * 256 + threadIdx.x;
-        if (i < a.nvar) retract_one(a.vkind, a.vdim, a.voff, a.vboff, i, a.vfrom, a.x, a.vto);
-        return;
-    }
-    __shared__ double red[5][4];
-    const int b2 = bid - a.np - a.np3;
-    double m = 0, ss = 0, vv = 0, bv = 0, nan = 0;
-    for (int64_t i = (int64_t)b2 * 256 + threadIdx.x; i < a.ndof; i += (int64_t)a.np2 * 256) {
-        const double x = a.x[i], w = a.dofmask ? a.dofmask[i] : 1.0, wb = a.dofmask_b ? a.dofmask_b[i] : w;
-        if (x != x) nan = 1.0;
-        m = fmax(m, w * fabs(x)); ss += x * x; vv += w * x * x; bv += wb * a.b[i] * x;    // (w: this rank's share under sharding, 1 otherwise; wb: its share of g -- the reduced part too while the reduced rows are not summed over ranks)
-    }
-    ss = wsum(ss); vv = wsum(vv); bv = wsum(bv);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o)); nan = fmax(nan, __shfl_xor(nan, o)); }
-    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red[0][w] = m; red[1][w] = nan; red[2][w] = ss; red[3][w] = vv; red[4][w] = bv; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double* o = a.part2 + 5 * b2;
-        o[0] = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3])); o[1] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
-        o[2] = red[2][0] + red[2][1] + red[2][2] + red[2][3]; o[3] = red[3][0] + red[3][1] + red[3][2] + red[3][3]; o[4] = red[4][0] + red[4][1] + red[4][2] + red[4][3];
-    }
-}
+__global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) { post_roles_body<DV>(a, (int)blockIdx.x); }
 // out[1] = max|x| (NaN if any entry is), out[2] = x'x, out[4] = x'(H + lambda I)x, out[5] = g'x, out[8] = x'Hx, out[9] = (masked) x'x,
 // out[10] = factorisation status
 NLLS_DEV void post_solve_finish_body(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
@@ -2347,7 +2301,7 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
     if (c->info.is_sparse) {
         // the step of the last solve: the rows of fast-path members come from E_v s, which the back-substitution kept
         const bool reuse = d_vec == c->x.p && c->tE_valid && c->n_fast_members > 0;
-        np = (int)std::min<int64_t>((c->nblk + 255) / 256, 768); if (np < 1) np = 1;
+        np = (int)std::min<int64_t>((c->nblk * QF_COLS + 255) / 256, 768); if (np < 1) np = 1;
         hipLaunchKernelGGL(quadform_blocks_kernel, dim3(np), dim3(256), 0, c->stream, c->A.p, c->d_blk.p, c->nblk, d_vec,
                            reuse ? c->d_blk_slowmask.p : (c->nranks > 1 ? c->d_blk_mask.p : (const uint8_t*)nullptr), c->partials.p);
         if (reuse) {
@@ -2370,6 +2324,27 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
     return NLLS_OK;
 }
 
+// the arguments of the step-statistics roles (nlls_post.hpp) for the step of the last solve; retract_to >= 0: with the retraction role
+PostSolveArgs post_solve_args(nlls_ctx* c, int retract_to, int retract_from) {
+    const bool reuse = c->tE_valid && c->n_fast_members > 0;
+    PostSolveArgs a{};
+    const bool lazy = c->nranks > 1 && !c->reduced_summed;      // the reduced rows of A.data and b hold this rank's share only: they count on every rank
+    a.A = c->A.p; a.blk = reuse ? (lazy ? c->d_blk_slow_lazy.p : c->d_blk_slow.p) : c->d_blk.p; a.nblk = reuse ? (lazy ? c->nblk_slow_lazy : c->nblk_slow) : c->nblk;
+    a.blkmask = reuse ? (const uint8_t*)nullptr : (c->nranks > 1 ? (lazy ? c->d_blk_mask_lazy.p : c->d_blk_mask.p) : (const uint8_t*)nullptr);
+    a.ediag = c->d_elim_diag.p; a.eboff = c->d_elim_boff.p; a.members = c->n_fast_members == (int64_t)c->d_elim_diag.n ? (const uint32_t*)nullptr : c->d_fast_members.p; a.nm = c->n_fast_members; a.tE = c->tE.p;
+    a.x = c->x.p; a.b = c->b.p; a.dofmask = c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr; a.dofmask_b = lazy ? c->d_dof_mask_lazy.p : (const double*)nullptr; a.ndof = c->info.ndof;
+    a.np = (int)std::max<int64_t>(1, std::min<int64_t>((a.nblk * QF_COLS + 255) / 256, 768));
+    a.np3 = reuse ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
+    a.np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 512));      // (5 partials each, behind the quadratic form's at 1024: ends at 3584 < TRIAL_COST_POFS)
+    a.partials = c->partials.p; a.part2 = c->partials.p + 1024;
+    a.nretract = 0;
+    if (retract_to >= 0 && c->info.nvar > 0) {
+        a.nretract = (int)((c->info.nvar + 255) / 256); a.vkind = c->d_var_kind.p; a.vdim = c->d_var_dim.p; a.voff = c->d_var_off.p; a.vboff = c->d_var_boff.p;
+        a.nvar = c->info.nvar; a.vfrom = vars_ptr(c, retract_from); a.vto = vars_ptr(c, retract_to);
+    }
+    c->ps_np = a.np + a.np3; c->ps_np2 = a.np2;
+    return a;
+}
 __global__ void status_to_scalar_kernel(const int* __restrict__ status, double* __restrict__ out) { *out = (double)status[0]; }
 // step statistics + quadratic form of the step of the last solve (what nlls_solve / nlls_lm_trial / nlls_trial_local
 // precompute): one launch + one finishing workgroup on sparse systems, the separate kernels otherwise
@@ -2381,27 +2356,11 @@ int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from, bool finis
         hipLaunchKernelGGL(status_to_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_status.p, c->scalars.p + 10);
         return NLLS_OK;
     }
-    const bool reuse = c->tE_valid && c->n_fast_members > 0;
-    PostSolveArgs a{};
-    const bool lazy = c->nranks > 1 && !c->reduced_summed;      // the reduced rows of A.data and b hold this rank's share only: they count on every rank
-    a.A = c->A.p; a.blk = reuse ? (lazy ? c->d_blk_slow_lazy.p : c->d_blk_slow.p) : c->d_blk.p; a.nblk = reuse ? (lazy ? c->nblk_slow_lazy : c->nblk_slow) : c->nblk;
-    a.blkmask = reuse ? (const uint8_t*)nullptr : (c->nranks > 1 ? (lazy ? c->d_blk_mask_lazy.p : c->d_blk_mask.p) : (const uint8_t*)nullptr);
-    a.ediag = c->d_elim_diag.p; a.eboff = c->d_elim_boff.p; a.members = c->d_fast_members.p; a.nm = c->n_fast_members; a.tE = c->tE.p;
-    a.x = c->x.p; a.b = c->b.p; a.dofmask = c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr; a.dofmask_b = lazy ? c->d_dof_mask_lazy.p : (const double*)nullptr; a.ndof = c->info.ndof;
-    a.np = (int)std::max<int64_t>(1, std::min<int64_t>((a.nblk + 255) / 256, 768));
-    a.np3 = reuse ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
-    a.np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 256));
-    a.partials = c->partials.p; a.part2 = c->partials.p + 1024;
-    a.nretract = 0;
-    if (retract_to >= 0 && c->info.nvar > 0) {
-        a.nretract = (int)((c->info.nvar + 255) / 256); a.vkind = c->d_var_kind.p; a.vdim = c->d_var_dim.p; a.voff = c->d_var_off.p; a.vboff = c->d_var_boff.p;
-        a.nvar = c->info.nvar; a.vfrom = vars_ptr(c, retract_from); a.vto = vars_ptr(c, retract_to);
-    }
+    PostSolveArgs a = post_solve_args(c, retract_to, retract_from);
     const dim3 grid((unsigned)(a.np + a.np3 + a.np2 + a.nretract));
     if (c->fast_dv == 3) hipLaunchKernelGGL((post_solve_kernel<3>), grid, dim3(256), 0, c->stream, a);
     else if (c->fast_dv == 2) hipLaunchKernelGGL((post_solve_kernel<2>), grid, dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((post_solve_kernel<1>), grid, dim3(256), 0, c->stream, a);
-    c->ps_np = a.np + a.np3; c->ps_np2 = a.np2;
     if (finish) hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p, c->d_status.p);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
@@ -2409,9 +2368,17 @@ int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from, bool finis
 // what follows the solve in an LM trial (src/iterators.jl:155-163)
 int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
     if (!c->info.is_sparse) { int rc = enqueue_post_solve(c, to, from); if (rc != NLLS_OK) return rc; return enqueue_sweep_cost(c, to); }
-    int rc = enqueue_post_solve(c, to, from, false); if (rc != NLLS_OK) return rc;
-    int64_t ncp = 0;
+    int rc; int64_t ncp = 0;
+    if (c->retract_done) {
+        // the retraction went with the back-substitution launch: the statistics roles ride in the cost sweep's (first) launch -- no launch of their own
+        c->retract_done = false;
+        PostSolveArgs a = post_solve_args(c, -1, -1); a.dv = c->fast_dv; bool taken = false;
+        rc = enqueue_sweep_cost(c, to, TRIAL_COST_POFS, &ncp, &a, &taken); if (rc != NLLS_OK) return rc;
+        if (!taken) { rc = enqueue_post_solve(c, -1, -1, false); if (rc != NLLS_OK) return rc; }      // (no launch of the cost sweep could carry them)
+    } else {
+    rc = enqueue_post_solve(c, to, from, false); if (rc != NLLS_OK) return rc;
     rc = enqueue_sweep_cost(c, to, TRIAL_COST_POFS, &ncp); if (rc != NLLS_OK) return rc;
+    }
     hipLaunchKernelGGL(trial_finish_kernel, dim3(2), dim3(256), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->partials.p, c->ps_np, c->partials.p + 1024, c->ps_np2,
                        c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq));
     HIPCHK(hipGetLastError());
@@ -2660,6 +2627,7 @@ int enqueue_reduced_solve(nlls_ctx* c) {
 
 // finish: factor the (summed) reduced system, solve it, back-substitute this rank's eliminated blocks
 int enqueue_solve_finish(nlls_ctx* c) {
+    c->retract_done = false;
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
     { const int rc = enqueue_reduced_solve(c); if (rc != NLLS_OK) return rc; }
     // x = -solution (folded into the fast back-substitution launch when there is one)
@@ -2682,9 +2650,18 @@ int enqueue_solve_finish(nlls_ctx* c) {
         // what the spare workgroups zero-fill for the next solve: the band storage of S, or (slab + gather assembly) the tiles the gather writes into
         double* zptr = c->S.p; int64_t zcount = zero_S ? (int64_t)c->s_elems : (int64_t)0;
         if (c->elim_slab) { const BcrGeom& g = c->bcr.geom; zptr = g.ws + g.oD; zcount = (int64_t)(g.oBR + (size_t)g.N * g.NT * 256 - g.oD); }
-#define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + nextra), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, \
-                c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red, zptr, zcount)
+        // an LM trial (nlls_lm_trial sets trial_to / trial_from): the retraction in this launch
+        BsfRetract rt{}; unsigned nrestwg = 0;
+        c->retract_done = false;
+        if (c->trial_to >= 0 && c->post_fuse && c->fast_all_euclid && c->nranks == 1 && nslow == 0 && c->info.is_sparse && c->n_fast_groups > 0 && c->info.nvar > 0) {
+            rt.on = 1; rt.nrest = (int)c->d_rest_var.n; rt.fast_voff = c->d_fast_voff.p; rt.rest_var = c->d_rest_var.p; rt.rest_red = c->d_rest_red.p;
+            rt.vkind = c->d_var_kind.p; rt.vdim = c->d_var_dim.p; rt.voff = c->d_var_off.p; rt.vfrom = vars_ptr(c, c->trial_from); rt.vto = vars_ptr(c, c->trial_to);
+            nrestwg = (unsigned)((rt.nrest + 63) / 64); c->retract_done = true;
+        }
+#define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + nextra + nrestwg), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, \
+                c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red, zptr, zcount, nextra, rt)
         if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; c->S_zeroed = zero_S; }
+        else c->retract_done = false;
 #undef LAUNCH_BSF
     }
     HIPCHK(hipGetLastError());

@@ -693,6 +693,21 @@ int build_schur(nlls_ctx* c, int32_t flags) {
       if (hipSuccess != c->d_row_mask.upload(rowmask) || hipSuccess != c->d_blk_mask.upload(blkmask) || hipSuccess != c->d_dof_mask.upload(dofmask) ||
           hipSuccess != c->d_blk_slowmask.upload(slowmask) || hipSuccess != c->d_blk_slow.upload(slowblks)) return fail(c, NLLS_ERR_HIP, "mask upload"); }
     if (hipSuccess != c->d_copy.upload(copies) || hipSuccess != c->d_red_boff.upload(red_boff)) return fail(c, NLLS_ERR_HIP, "schur upload");
+    {   // the retraction of an LM trial inside the back-substitution launch: eliminated member -> where its variable is stored; every other variable -> where its step
+        // starts in the reduced solution (fixed variables: -1, they are copied)
+        const int64_t nvar = (int64_t)c->var_kind.size();
+        std::vector<int64_t> var_of_block(nb, -1); for (int64_t i = 0; i < nvar; ++i) if (c->blockindices[i]) var_of_block[c->blockindices[i] - 1] = i;
+        std::vector<uint32_t> fast_var(erow.size(), 0), rest_var; std::vector<int32_t> rest_red; std::vector<uint8_t> is_member(nvar, 0);
+        bool euclid = c->n_fast_members > 0 && c->n_fast_members == (int64_t)erow.size();
+        for (size_t v = 0; v < erow.size(); ++v) { const int64_t i = var_of_block[erow[v]]; if (i < 0) { euclid = false; continue; }
+            fast_var[v] = c->var_off[i]; is_member[i] = 1;
+            if (c->var_kind[i] != NLLS_VAR_EUCLIDEAN || c->var_dim[i] != c->fast_dv || c->blocksizes[erow[v]] != c->fast_dv) euclid = false; }
+        for (int64_t i = 0; i < nvar; ++i) { if (is_member[i]) continue;
+            const int64_t k = (int64_t)c->blockindices[i] - 1; rest_var.push_back((uint32_t)i);
+            rest_red.push_back(k < 0 ? -1 : (c->is_elim[k] ? -2 : (int32_t)red_of[k])); if (k >= 0 && c->is_elim[k]) euclid = false; }
+        c->fast_all_euclid = euclid && c->nranks == 1;
+        if (hipSuccess != c->d_fast_voff.upload(fast_var) || hipSuccess != c->d_rest_var.upload(rest_var) || hipSuccess != c->d_rest_red.upload(rest_red)) return fail(c, NLLS_ERR_HIP, "schur upload");
+    }
     // ---- choose the reduced-system solver ----------------------------------------------------------------------
     const int64_t n = c->nred;
     c->bw = (int)bw; c->solve_mode = SOLVE_DENSE; c->band_twisted = !(flags & NLLS_FLAG_NO_TWIST);
