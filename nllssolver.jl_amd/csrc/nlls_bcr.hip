@@ -507,13 +507,18 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
 // the lower triangles of the factored diagonal blocks: their slots -> S, ONE launch behind the last panel (nothing reads them before the
 // backward pass).  Slot of a panel = the 64-block index of its first column, 128 x 128 doubles each; block b < nwide: the 128-column panel b,
 // the others: 64-column panels from 64-block first64 on.
+// (sixteen workgroups per block, four elements per thread requested at once: one workgroup walking a block in a loop took 26 us -- 64 dependent round trips)
 __global__ __launch_bounds__(256) void dense_dcopy_all_kernel(double* __restrict__ S, const double* __restrict__ Dfac, int npad, int nwide, int first64) {
-    const int b = blockIdx.x, nb = b < nwide ? 128 : 64, k64 = b < nwide ? 2 * b : first64 + (b - nwide), c0 = 64 * k64;
+    const int b = blockIdx.x >> 4, sl = blockIdx.x & 15, nb = b < nwide ? 128 : 64, k64 = b < nwide ? 2 * b : first64 + (b - nwide), c0 = 64 * k64;
     const double* D = Dfac + (size_t)k64 * 128 * 128;
-    for (int e = threadIdx.x; e < nb * nb; e += 256) { const int i = e % nb, j = e / nb; if (i >= j) S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)] = D[(size_t)i + (size_t)nb * j]; }
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = sl * 1024 + u * 256 + (int)threadIdx.x; v[u] = e < nb * nb ? D[e] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = sl * 1024 + u * 256 + (int)threadIdx.x; if (e < nb * nb) { const int i = e % nb, j = e / nb; if (i >= j) S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)] = v[u]; } }
 }
 void launch_dense_dcopy_all(hipStream_t st, double* S, const double* Dfac, int npad, int nwide, int first64, int n64) {
-    if (nwide + n64 > 0) hipLaunchKernelGGL(dense_dcopy_all_kernel, dim3((unsigned)(nwide + n64)), dim3(256), 0, st, S, Dfac, npad, nwide, first64);
+    if (nwide + n64 > 0) hipLaunchKernelGGL(dense_dcopy_all_kernel, dim3((unsigned)(nwide + n64) * 16), dim3(256), 0, st, S, Dfac, npad, nwide, first64);
 }
 template <int NT, int DCH> constexpr size_t dense_panel_lds() { return sizeof(double) * ((size_t)(NT * (NT + 1) / 2 + DCH * NT) * BTS + 2 * (size_t)(NT + DCH) * 16 * BP + 64 + 2 * 16 * BP + BTS); }
 static_assert(dense_panel_lds<8, 2>() <= 160 * 1024, "the 128-column panel must fit the LDS of a CU");
@@ -828,12 +833,16 @@ __global__ __launch_bounds__(512) void dense_dinv_kernel(const double* __restric
     extern __shared__ __attribute__((aligned(16))) double sm[];          // the 36 lower tiles of the block, [16][BP] each
     const int b = blockIdx.x, t = threadIdx.x, c0 = DBB * b;
     if (t < DBB && c0 + t < n) x[c0 + t] = __longlong_as_double((long long)BCR_X_SENTINEL);
-    for (int e = t; e < DBB * DBB; e += 512) { const int i = e & 127, j = e >> 7, I = i >> 4, J = j >> 4;      // consecutive threads walk a column of S
-        if (I < J) continue;
-        double v;
-        if (I == J) { const int gt = 8 * b + I; v = gt < npad / 16 ? LiD[(size_t)gt * 256 + (i & 15) + 16 * (j & 15)] : ((i & 15) == (j & 15) ? 1.0 : 0.0); }
-        else v = c0 + i < npad ? S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)] : 0.0;
-        sm[bcr_dtile(I, J) * BTS + (i & 15) * BP + (j & 15)] = v; }
+    for (int e0 = t; e0 < DBB * DBB; e0 += 8 * 512) {      // consecutive threads walk a column of S; eight loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 512 * u, i = e & 127, j = e >> 7, I = i >> 4, J = j >> 4; v[u] = 0.0;
+            if (I == J) { const int gt = 8 * b + I; v[u] = gt < npad / 16 ? LiD[(size_t)gt * 256 + (i & 15) + 16 * (j & 15)] : ((i & 15) == (j & 15) ? 1.0 : 0.0); }
+            else if (I > J && c0 + i < npad) v[u] = S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 512 * u, i = e & 127, j = e >> 7, I = i >> 4, J = j >> 4;
+            if (I >= J) sm[bcr_dtile(I, J) * BTS + (i & 15) * BP + (j & 15)] = v[u]; }
+    }
     __syncthreads();
     const int J = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
     for (int I = 1; I < 8; ++I) {

@@ -136,7 +136,13 @@ __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict
             ndv += du;
         }
         __syncthreads();
-        for (int e = lane; e < dv * ndv; e += 64) { const int a2 = e % dv, c2 = e / dv; E[e] = A[csrc[c2] + (int64_t)a2 * cstr[c2]]; }
+        for (int e0 = lane; e0 < dv * ndv; e0 += 4 * 64) {      // (four loads in flight per lane: a copy loop waits for each load before the next)
+            double g4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = e0 + 64 * u; g4[u] = 0.0; if (e < dv * ndv) { const int a2 = e % dv, c2 = e / dv; g4[u] = A[csrc[c2] + (int64_t)a2 * cstr[c2]]; } }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = e0 + 64 * u; if (e < dv * ndv) E[e] = g4[u]; }
+        }
         for (int a = lane; a < dv; a += 64) Y[a + dv * ndv] = b[eboff[v] + a];
         if (v == v0) { nd = ndv; npairs = nd * (nd + 1) / 2; if (use_acc) for (int t = lane; t < npairs + nd; t += 64) acc[t] = 0.0; }
         __syncthreads();
@@ -1263,7 +1269,14 @@ __global__ __launch_bounds__(256) void syrk_update2_kernel(double* __restrict__ 
         const double* Gi = (q == 0 ? W0 : W1) + (size_t)ib * NB;                         // W = L*D rows of block i, panel k0 + q
         const double* Gj = S + (size_t)jb * NB + (size_t)npad * (k0 + q) * NB;           // L rows of block j, panel k0 + q
         if (q > 0) __syncthreads();
-        for (int e = t; e < NB * NB; e += 256) { const int r = e % NB, c2 = e / NB; Pi[r + LDT * c2] = Gi[(size_t)r + (size_t)npad * c2]; Pj[r + LDT * c2] = Gj[(size_t)r + (size_t)npad * c2]; }
+        {   // every load first, then the LDS stores: a copy loop global -> LDS waits for each load before it issues the next (16 dependent round trips
+            // per operand were most of this kernel's 18.7 us)
+            constexpr int NQ = NB * NB / 256; double vi[NQ], vj[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) { const int e = t + 256 * u, r = e % NB, c2 = e / NB; vi[u] = Gi[(size_t)r + (size_t)npad * c2]; vj[u] = Gj[(size_t)r + (size_t)npad * c2]; }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) { const int e = t + 256 * u, r = e % NB, c2 = e / NB; Pi[r + LDT * c2] = vi[u]; Pj[r + LDT * c2] = vj[u]; }
+        }
         __syncthreads();
 #pragma unroll 4
         for (int kk = 0; kk < NB; kk += 4) {
