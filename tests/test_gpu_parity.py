@@ -68,6 +68,16 @@ def check_problem(problem, unfixed=None, flags=0, lam_scale=1e-6, expect_sparse=
     op.update(ols, O.VARS_NEXT, O.VARS_CURRENT, step=x_gpu)
     v_gpu, v_ora = ctx.get_variables(_capi.VARS_NEXT), op.get_variables(O.VARS_NEXT)
     assert rel(v_gpu, v_ora) < 1e-13
+    # ---- the same trial in ONE call (nlls_lm_trial: damp, solve, retract, cost, step statistics -- where the structure allows it without a launch of
+    # their own for the retraction and the statistics): against the separate entry points above.  (Atomics: the step agrees to rounding, not bits.)
+    c_next = ctx.sweep_cost(_capi.VARS_NEXT)
+    ctx.set_variables(np.zeros_like(v_gpu), _capi.VARS_NEXT)                     # (whatever the trial leaves there must be its own work)
+    c_trial = ctx.lm_trial(0.0)
+    assert np.isclose(c_trial, c_next, rtol=1e-9, atol=1e-300), (c_trial, c_next)
+    assert rel(ctx.get_variables(_capi.VARS_NEXT), v_gpu) < 1e-9
+    xHx2, gx2 = ctx.quadform()
+    assert np.isclose(xHx2, xHx, rtol=1e-8) and np.isclose(gx2, gx, rtol=1e-8), (xHx2, xHx, gx2, gx)
+    assert np.isclose(ctx.step_maxabs(), np.max(np.abs(x_gpu)), rtol=1e-8)
     ctx.close()
     return info
 
@@ -417,12 +427,12 @@ def test_three_slot_sweep_in_one_launch_per_role(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"NLLS_DENSE_T64": "1"}, {"NLLS_DENSE_T128_MIN": "1"}, {"NLLS_ELIM_TILED": "1"}, {"NLLS_BCR_CHROWS_SLOTS": "0"},
-                                 {"NLLS_DENSE_STEP_BACKWARD": "1"}, {"NLLS_BCR_LEVEL_BACKWARD": "1"}, {"NLLS_ELIM_SPLIT": "1"}])
+                                 {"NLLS_DENSE_STEP_BACKWARD": "1"}, {"NLLS_BCR_LEVEL_BACKWARD": "1"}, {"NLLS_ELIM_SPLIT": "1"}, {"NLLS_POST_SPLIT": "1"}])
 def test_ab_switches_select_paths_that_still_match_the_oracle(env, monkeypatch):
     """The environment switches read by nlls_create (the register-tiled elimination instead of the matrix-core one, the
     64 x 64-tile dense update instead of the 128 x 128 one, the 128 x 128 one from the first pass on, three X rows per panel workgroup at every
     level of the block cyclic reduction, one backward launch per block / per level instead of the one-launch substitutions, the assembly in three
-    launches) select kernels or launch shapes no default run of this size reaches:
+    launches, the trial's retraction and step statistics in a launch of their own) select kernels or launch shapes no default run of this size reaches:
     the same parity as every other path -- band mode and the dense reduced solve (NLLS_FLAG_NO_BAND) of a camera chain, 2100 reduced dof."""
     for k, v in env.items(): monkeypatch.setenv(k, v)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(350, 7000, 10.0 / 350, seed=77, robust=N.HuberKernel(0.02)), 1e-3, 1e-3)
