@@ -77,7 +77,8 @@ typedef struct nlls_ctx nlls_ctx;
 #define NLLS_RES_DYN_LINEAR      11 /* DYNAMIC-size (src/autodiff.jl:96-121): LinearResidual X'w - y over one NLLS_VAR_DYNAMIC variable of run-time
                                        length n; data = (y, X[n]) -- n + 1 doubles per block; nres 1            test/dynamicvars.jl:3-11 */
 #define NLLS_RES_DYN_NORM        12 /* DYNAMIC-size: NormResidual w over one NLLS_VAR_DYNAMIC variable: nres = n, no data    test/dynamicvars.jl:13-21.
-                                       Dynamic kinds: every block of a group has the same n; no robust kernel; the system must come out
+                                       Dynamic kinds: every block of a group has the same n; the residual kinds take the robust kernels like any other residual
+                                       (src/residual.jl:76-101), the non-squared cost kind none; the system must come out
                                        dense (src/linearsystem.jl:105-123 decides; one variable always does); nlls_res_ndata / nlls_res_nres
                                        return -1 where the count is n-dependent */
 #define NLLS_RES_DYN_LINEARSQ    13 /* DYNAMIC-size: LinearResidualDynamic X*w - y with a square X (n x n, column-major) over one NLLS_VAR_DYNAMIC

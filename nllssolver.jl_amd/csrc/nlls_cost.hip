@@ -55,14 +55,19 @@ __global__ __launch_bounds__(TPB) void reduce_partials_kernel(const double* __re
 // (test/dynamicvars.jl:13-21), J = I.  One workgroup per block; n = the variable's run-time length.  With A != nullptr the block's
 // J'J and J'r go into the dense linear system (src/residual.jl:72-74, src/linearsystem.jl:132-175), else only the cost.
 // ================================================================================================
+// Under a robust kernel rho (round 3): cost = rho(r'r) / 2, g = rho' J'r, H = rho' J'J + 2 rho'' (J'r)(J'r)'   (src/residual.jl:76-101 applies to any
+// residual, the dynamic ones included); the non-squared cost kind takes none.
 __global__ __launch_bounds__(TPB) void dyn_block_kernel(int kind, int n, int ndata, const double* __restrict__ vars, const double* __restrict__ data,
                                                         const uint32_t* __restrict__ voff, const uint32_t* __restrict__ index, const uint32_t* __restrict__ brow,
-                                                        int ndof, double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+                                                        int ndof, double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials, RobustSpec rk) {
     __shared__ double red[TPB / 64]; __shared__ double total;
     const int64_t k = index ? index[blockIdx.x] : blockIdx.x;
     const double* w = vars + voff[k];
     const uint32_t bo = (A && brow) ? brow[blockIdx.x] : DEST_NONE;            // (brow is in launch order: one entry per launched block)
+    const bool robust = (rk.kind & 0xF) != NLLS_ROBUST_NONE || (rk.kind & NLLS_ROBUST_SCALED);
     double cost;
+    // rho, rho', rho'' at c = r'r (every thread: c is the workgroup's total)
+    auto kernel_at = [&](double c, double& rho, double& d1, double& d2) { if (robust) robustifydcost_fixed(rk, c, rho, d1, d2); else { rho = c; d1 = 1.0; d2 = 0.0; } };
     if (kind == NLLS_RES_DYN_LINEAR) {
         const double* dd = data + k * (int64_t)ndata; const double* X = dd + 1;
         double acc = 0;
@@ -70,23 +75,30 @@ __global__ __launch_bounds__(TPB) void dyn_block_kernel(int kind, int n, int nda
         { const double t = block_sum(acc, red); if (threadIdx.x == 0) total = t; }   // (block_sum leaves the total in thread 0)
         __syncthreads();
         const double r = total - dd[0];
-        cost = 0.5 * r * r;
+        double rho, d1, d2; kernel_at(r * r, rho, d1, d2);
+        cost = 0.5 * rho;
         if (bo != DEST_NONE) {
-            for (int i = threadIdx.x; i < n; i += TPB) atomicAdd(&b[bo + i], X[i] * r);
-            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int i = (int)(e % n), j = (int)(e / n); if (i >= j) atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + j)], X[i] * X[j]); }
+            const double hs = d1 + 2.0 * d2 * r * r;                             // J'J = X X', J'r = X r: H = (rho' + 2 rho'' r^2) X X'
+            for (int i = threadIdx.x; i < n; i += TPB) atomicAdd(&b[bo + i], d1 * (X[i] * r));
+            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int i = (int)(e % n), j = (int)(e / n); if (i >= j) atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + j)], hs * (X[i] * X[j])); }
         }
     } else if (kind == NLLS_RES_DYN_LINEARSQ) {                                   // X*w - y, X square (n <= 512): J = X
-        __shared__ double rs[512];
+        __shared__ double rs[512], gs[512];
         const double* dd = data + k * (int64_t)ndata; const double* X = dd + n;
         for (int i = threadIdx.x; i < n; i += TPB) { double t = -dd[i]; for (int j = 0; j < n; ++j) t = fma(X[i + (size_t)n * j], w[j], t); rs[i] = t; }
         __syncthreads();
         double acc = 0;
         for (int i = threadIdx.x; i < n; i += TPB) acc += rs[i] * rs[i];
-        cost = 0.5 * block_sum(acc, red);
+        { const double t = block_sum(acc, red); if (threadIdx.x == 0) total = t; }
+        __syncthreads();
+        double rho, d1, d2; kernel_at(total, rho, d1, d2);
+        cost = 0.5 * rho;
         if (bo != DEST_NONE) {
-            for (int j = threadIdx.x; j < n; j += TPB) { double t = 0; for (int i = 0; i < n; ++i) t = fma(X[i + (size_t)n * j], rs[i], t); atomicAdd(&b[bo + j], t); }
+            for (int j = threadIdx.x; j < n; j += TPB) { double t = 0; for (int i = 0; i < n; ++i) t = fma(X[i + (size_t)n * j], rs[i], t); gs[j] = t; atomicAdd(&b[bo + j], d1 * t); }
+            __syncthreads();
             for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int j = (int)(e % n), q = (int)(e / n); if (j < q) continue;
-                double h = 0; for (int i = 0; i < n; ++i) h = fma(X[i + (size_t)n * j], X[i + (size_t)n * q], h); atomicAdd(&A[(bo + j) + (size_t)ndof * (bo + q)], h); }
+                double h = 0; for (int i = 0; i < n; ++i) h = fma(X[i + (size_t)n * j], X[i + (size_t)n * q], h);
+                atomicAdd(&A[(bo + j) + (size_t)ndof * (bo + q)], robust ? d1 * h + (2.0 * d2 * gs[j]) * gs[q] : h); }
         }
     } else if (kind == NLLS_COST_DYN_LINEAR) {                                   // non-squared cost y'w: value, gradient y, Hessian 0
         const double* y = data + k * (int64_t)ndata;
@@ -94,11 +106,18 @@ __global__ __launch_bounds__(TPB) void dyn_block_kernel(int kind, int n, int nda
         for (int i = threadIdx.x; i < n; i += TPB) acc += y[i] * w[i];
         cost = block_sum(acc, red);
         if (bo != DEST_NONE) for (int i = threadIdx.x; i < n; i += TPB) atomicAdd(&b[bo + i], y[i]);
-    } else {
+    } else {                                                                      // NormResidual w: J = I
         double acc = 0;
         for (int i = threadIdx.x; i < n; i += TPB) acc += w[i] * w[i];
-        cost = 0.5 * block_sum(acc, red);
-        if (bo != DEST_NONE) for (int i = threadIdx.x; i < n; i += TPB) { atomicAdd(&b[bo + i], w[i]); atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + i)], 1.0); }
+        { const double t = block_sum(acc, red); if (threadIdx.x == 0) total = t; }
+        __syncthreads();
+        double rho, d1, d2; kernel_at(total, rho, d1, d2);
+        cost = 0.5 * rho;
+        if (bo != DEST_NONE) {
+            for (int i = threadIdx.x; i < n; i += TPB) { atomicAdd(&b[bo + i], d1 * w[i]); if (!robust || d2 == 0.0) atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + i)], d1); }
+            if (robust && d2 != 0.0)                                                // H = rho' I + 2 rho'' w w'
+                for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int i = (int)(e % n), j = (int)(e / n); if (i >= j) atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + j)], (i == j ? d1 : 0.0) + (2.0 * d2 * w[i]) * w[j]); }
+        }
     }
     if (threadIdx.x == 0) partials[blockIdx.x] = cost;
 }
@@ -371,7 +390,7 @@ static int launch_dyn_cost(nlls_ctx* c, const Group& G, const double* vars, int6
     const int64_t nb = fixed_only ? G.nfixedcost : G.ncost;
     if (nb > 0) {
         hipLaunchKernelGGL(dyn_block_kernel, dim3((unsigned)nb), dim3(TPB), 0, c->stream, G.res_kind, dyn_n_of(G), G.ndata, vars, G.data.p, G.voff.p,
-                           fixed_only ? G.fixedcost.p : (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, (double*)nullptr, (double*)nullptr, c->partials.p + pbase);
+                           fixed_only ? G.fixedcost.p : (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, (double*)nullptr, (double*)nullptr, c->partials.p + pbase, G.rk);
         pbase += nb;
     }
     return NLLS_OK;
@@ -379,7 +398,7 @@ static int launch_dyn_cost(nlls_ctx* c, const Group& G, const double* vars, int6
 int enqueue_dyn_gradhess(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
     if (G.dense.n > 0) {
         hipLaunchKernelGGL(dyn_block_kernel, dim3((unsigned)G.dense.n), dim3(TPB), 0, c->stream, G.res_kind, dyn_n_of(G), G.ndata, vars, G.dense.data.p, G.dense.voff.p,
-                           (const uint32_t*)nullptr, G.dense.brow.p, (int)c->info.ndof, c->A.p, c->b.p, c->partials.p + pbase);
+                           (const uint32_t*)nullptr, G.dense.brow.p, (int)c->info.ndof, c->A.p, c->b.p, c->partials.p + pbase, G.rk);
         pbase += G.dense.n;
     }
     HIPCHK(hipGetLastError());

@@ -121,7 +121,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
         if (base > NLLS_ROBUST_GEMAN_MCCLURE || (groups[g].robust_kind & ~0x1F)) return fail(c, NLLS_ERR_UNSUPPORTED, "unregistered robust kernel");
         if (is_dyn_kind(groups[g].res_kind)) {       // n = the run-time length of the block's variable: the same for every block of the group
             any_dyn = true;
-            if (base != NLLS_ROBUST_NONE) return fail(c, NLLS_ERR_UNSUPPORTED, "dynamic-size residual kinds take no robust kernel");
+            if ((base != NLLS_ROBUST_NONE || (groups[g].robust_kind & NLLS_ROBUST_SCALED)) && groups[g].res_kind == NLLS_COST_DYN_LINEAR) return fail(c, NLLS_ERR_UNSUPPORTED, "a non-squared cost takes no robust kernel");
             int n = -1;
             for (int64_t k = 0; k < groups[g].ncost; ++k) { const int64_t v = groups[g].varind[k];
                 if (v < 1 || v > nvar) return fail(c, NLLS_ERR_INVALID_ARG, "varind out of range");

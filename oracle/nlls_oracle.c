@@ -627,9 +627,22 @@ static void block_residual(const oracle_problem* p, const double* vars, const og
 }
 /* computerescost  src/residual.jl:49-55 */
 /* dynamic-size residual blocks: computeresjacdynamic (src/autodiff.jl:96-121) of the two registered residuals is known in closed form --
- * LinearResidual X'w - y (test/dynamicvars.jl:3-11): J = X';  NormResidual w (test/dynamicvars.jl:13-21): J = I -- no robust kernel.
+ * LinearResidual X'w - y (test/dynamicvars.jl:3-11): J = X';  NormResidual w (test/dynamicvars.jl:13-21): J = I.
  * cost = 0.5 r'r; with H / gv (n x n col-major, n) also J'J and J'r (src/residual.jl:72-74). */
+static double dyn_block_plain(const oracle_problem* p, const double* vars, const ogroup* g, int64_t ci, double* gv, double* H);
+/* ... under a robust kernel like any other residual (src/residual.jl:76-101): cost = rho(r'r) / 2, g = rho' J'r, H = rho' J'J + 2 rho'' (J'r)(J'r)' */
 static double dyn_block(const oracle_problem* p, const double* vars, const ogroup* g, int64_t ci, double* gv, double* H) {
+    const double c = 2.0 * dyn_block_plain(p, vars, g, ci, gv, H);              /* r'r (the non-squared cost kind takes no kernel: refused at setup) */
+    if (g->robust_kind == NLLS_ROBUST_NONE || g->res_kind == NLLS_COST_DYN_LINEAR) return 0.5 * c;
+    const int n = g->dyn_n; double o[3]; fixed_robustifydcost(g->robust_kind, g->rp, c, o);
+    if (gv) {
+        if (o[1] != 1) for (size_t i = 0; i < (size_t)n * n; ++i) H[i] *= o[1];                                                    /* :91-93 */
+        if (o[2] != 0) for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) H[i + (size_t)n * j] += ((2 * o[2]) * gv[i]) * gv[j];   /* :95-97 */
+        if (o[1] != 1) for (int i = 0; i < n; ++i) gv[i] *= o[1];                                                                   /* :99-101 */
+    }
+    return 0.5 * o[0];
+}
+static double dyn_block_plain(const oracle_problem* p, const double* vars, const ogroup* g, int64_t ci, double* gv, double* H) {
     const int n = g->dyn_n; const double* w = vars + p->voff[g->varind[ci] - 1];
     if (g->res_kind == NLLS_RES_DYN_LINEAR) {
         const double* dd = g->data + ci * g->ndata; const double* X = dd + 1; double r = -dd[0];

@@ -452,6 +452,32 @@ def test_dynamic_size_variables_on_device(seed):
         assert res.bestcost < res.startcost
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("robust", [N.HuberKernel(0.4), N.GemanMcclureKernel(0.7), N.Scaled(N.Huber2oKernel(0.5), 1.7)])
+def test_dynamic_size_blocks_under_a_robust_kernel_on_device(robust):
+    """Dynamic-size residual blocks (src/autodiff.jl:96-121) under a robust kernel (src/residual.jl:76-101; round 3: declined before): the three
+    dynamic residual kinds in one dense problem over a 70-dof variable, inside and outside the kernels' quadratic regions -- cost, A.data, b,
+    damped step, retraction and the one-call trial against the oracle (whose robustified dynamic blocks tests/test_oracle_pins.py pins by
+    finite differences and by the formula); then Levenberg-Marquardt to the oracle's optimum."""
+    from tests.test_gpu_parity import check_problem
+    rng = np.random.default_rng(11)
+    n = 70
+    def mk(mag):
+        X = rng.standard_normal(n); Xs = rng.standard_normal((n, n)) / np.sqrt(n) + np.eye(n); y = mag * rng.standard_normal(n)
+        p = N.NLLSProblem(); p.addvariable(mag * rng.standard_normal(n), K.VAR_DYNAMIC)
+        p.addcosts(K.RES_DYN_LINEAR, [[1]], np.concatenate([[0.3], X])[None, :], robust=robust)
+        p.addcosts(K.RES_DYN_NORM, [[1]], np.zeros((1, 0)), robust=robust)
+        p.addcosts(K.RES_DYN_LINEARSQ, [[1]], np.concatenate([y, Xs.ravel(order="F")])[None, :], robust=robust)
+        return p
+    for mag in (0.01, 2.0):
+        p = mk(mag)
+        info = check_problem(p, expect_sparse=0, lam_scale=1e-2)
+        assert info.ndof == n
+        ores = oracle_problem(p).optimize(maxiters=30)
+        res = N.optimize(p, N.NLLSOptions(maxiters=30))
+        assert np.isclose(res.bestcost, ores.bestcost, rtol=1e-7, atol=1e-14), (res.bestcost, ores.bestcost)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_nonsquared_cost_static_and_dynamic_on_device(seed):
     """test/nonsquaredcost.jl:48-69 as written, on the device: a static and a dynamic-size variable in one problem, each under a linear

@@ -414,6 +414,45 @@ def test_dynamic_size_variables_known_answer(seed):
     assert not ols.info.is_sparse and ols.info.ndof == n       # one variable: UniVariateLS / dense
 
 
+@pytest.mark.parametrize("robust", [N.HuberKernel(0.4), N.GemanMcclureKernel(0.7), N.Scaled(N.Huber2oKernel(0.5), 1.7)])
+def test_dynamic_size_blocks_under_a_robust_kernel(robust):
+    """src/residual.jl:76-101 applies to any residual, the dynamic-size ones (src/autodiff.jl:96-121) included: cost = rho(r'r) / 2,
+    g = rho' J'r, H = rho' J'J + 2 rho'' (J'r)(J'r)'.  The reference's tests hold no vector for the combination; pinned here by (i) central
+    differences of the oracle's own robustified cost for the gradient, (ii) the formula itself, written in numpy from the kernels'
+    closed forms that test/robust.jl pins (test_robust_kernels_closed_forms), for the Hessian -- on all three dynamic residual kinds, each
+    once inside the kernel's quadratic region and once outside it."""
+    from nllssolver_jl_amd import kinds as K
+    rng = np.random.default_rng(7)
+    n = 5
+    def rho_d(c):                       # (rho, rho', rho'') of the registered kernels: src/robust.jl:11-12,26-31,47-55,71-77
+        base = robust.kind & 0xF; w = robust.params[0]; w2 = w * w; scale = robust.params[1] if robust.kind & K.ROBUST_SCALED else 1.0
+        if base in (K.ROBUST_HUBER, K.ROBUST_HUBER2O):
+            if c < w2: o = (c, 1.0, 0.0)
+            else:
+                sq = np.sqrt(c); o = (2 * w * sq - w2, w / sq, (-0.5 * w / (c * sq)) if base == K.ROBUST_HUBER2O else 0.0)
+        else:
+            t = 1.0 / (c + w2); o = (c * w2 * t, (w2 * t) ** 2, -2 * w2 * w2 * t ** 3)
+        return tuple(scale * v for v in o)
+    for kind in (K.RES_DYN_LINEAR, K.RES_DYN_NORM, K.RES_DYN_LINEARSQ):
+        for mag in (0.05, 3.0):
+            w0 = mag * rng.standard_normal(n); X = rng.standard_normal(n); Xs = rng.standard_normal((n, n)); y = mag * rng.standard_normal(n)
+            data = {K.RES_DYN_LINEAR: np.concatenate([[0.1], X]), K.RES_DYN_NORM: np.zeros(0), K.RES_DYN_LINEARSQ: np.concatenate([y, Xs.ravel(order="F")])}[kind]
+            def mk(w):
+                p = N.NLLSProblem(); p.addvariable(w.copy(), K.VAR_DYNAMIC); p.addcosts(kind, [[1]], data[None, :], robust=robust); return p
+            op = oracle_problem(mk(w0)); ols = op.linear_system(blockindices(mk(w0)))
+            cost = ols.costgradhess(); g = ols.b.copy(); H = ols.data.reshape(n, n).T.copy(); H = np.tril(H) + np.tril(H, -1).T
+            # residual and Jacobian by hand
+            if kind == K.RES_DYN_LINEAR: r = np.array([X @ w0 - 0.1]); J = X[None, :]
+            elif kind == K.RES_DYN_NORM: r = w0.copy(); J = np.eye(n)
+            else: r = Xs @ w0 - y; J = Xs
+            c = float(r @ r); rho, d1, d2 = rho_d(c); Jr = J.T @ r
+            assert np.isclose(cost, 0.5 * rho, rtol=1e-13)
+            assert np.allclose(g, d1 * Jr, rtol=1e-12, atol=1e-15)
+            assert np.allclose(H, d1 * (J.T @ J) + 2 * d2 * np.outer(Jr, Jr), rtol=1e-12, atol=1e-14)
+            h = 1e-6; gfd = np.array([(oracle_problem(mk(w0 + h * e)).cost() - oracle_problem(mk(w0 - h * e)).cost()) / (2 * h) for e in np.eye(n)])
+            assert np.allclose(g, gfd, rtol=2e-6, atol=1e-9), (kind, mag, g, gfd)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_nonsquared_cost_static_and_dynamic(seed):
     """test/nonsquaredcost.jl:48-69 as written: ONE problem with a static EuclideanVector{3} (LinearResidualStatic + LinearCostStatic) and a
