@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--solver", default="default", choices=["default", "dense", "chain", "deterministic"],
                     help="reduced-system solver: block cyclic reduction of the band (default), the dense MFMA LDL' (NLLS_FLAG_NO_BAND), "
                          "the round-1 twisted chain kernels (NLLS_FLAG_NO_BCR), or the atomics-free assembly (NLLS_FLAG_DETERMINISTIC)")
+    ap.add_argument("--shuffle-cameras", type=int, default=None, metavar="SEED",
+                    help="permute the cameras' labels (seeded) before the upload: the reference generator numbers neighbouring cameras consecutively, "
+                         "real image collections do not -- the reduced camera system is then re-ordered at upload (reverse Cuthill-McKee)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
@@ -131,14 +134,21 @@ def main():
         workload_desc = {"residuals": "a exp(b t) + c t + d - y, 10k scalar residuals over four scalar variables (BlockDenseMatrix path)"}
     elif args.workload == "ba_so3_500x50k":
         ncam, npts, prop = CONFIGS[args.workload]
-        problem = synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(ncam, npts, prop, seed=1, adaptive=True), 1e-3, 1e-3)
+        problem = synthetic.create_so3_ba_problem(ncam, npts, prop, seed=1, adaptive=True)
+        if args.shuffle_cameras is not None:
+            problem = synthetic.shuffle_camera_labels(problem, ncam, args.shuffle_cameras, first=2)
+        problem = synthetic.perturb_ba_problem(problem, 1e-3, 1e-3)
         workload_desc = {"robust": "ContaminatedGaussian adaptive kernel (variable #1)", "outliers": "10% of measurements + N(0,0.1^2), seed 1", "cameras": "SO(3) poses, pinhole"}
     else:
         ncam, npts, prop = CONFIGS[args.workload]
         problem = synthetic.create_ba_problem(ncam, npts, prop, seed=1, robust=N.HuberKernel(0.01),
                                               outlier_frac=0.05, outlier_sigma=0.05)
+        if args.shuffle_cameras is not None:
+            problem = synthetic.shuffle_camera_labels(problem, ncam, args.shuffle_cameras)
         problem = synthetic.perturb_ba_problem(problem, 1e-3, 1e-3)
         workload_desc = {"robust": "Huber(0.01)", "outliers": "5% of measurements + N(0,0.05^2), seed 1"}
+    if args.shuffle_cameras is not None and ncam:
+        workload_desc["camera_labels"] = f"permuted (seed {args.shuffle_cameras})"
     nobs = problem.ncosts()
     start_vars = problem.variables.copy()
     flags = {"default": 0, "dense": _capi.FLAG_NO_BAND, "chain": _capi.FLAG_NO_BCR, "deterministic": _capi.FLAG_DETERMINISTIC}[args.solver]

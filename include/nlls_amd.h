@@ -141,6 +141,9 @@ typedef struct nlls_info {
                                          rank (bundle adjustment: all cameras + this rank's points).  Nothing is partitioned by the library; variable indices are
                                          the rank's own.  Lets each process of a large job generate and upload 1/N of the problem                       */
 #define NLLS_FLAG_NO_BCR         0x20 /* band solver: the round-1 chain kernels (twisted blocked LDL') instead of block cyclic reduction */
+#define NLLS_FLAG_NO_REORDER    0x100 /* keep the reduced variables in the caller's block order.  Default: the reduced blocks are put in reverse Cuthill-McKee
+                                         order whenever that narrows the band of the reduced system -- the reference orders its factorisation itself
+                                         (ldl_analyze, src/linearsystem.jl:52,68) and does not care how the caller numbers the variables; neither does x here */
 
 /* variable-set ids for the on-device copies of problem.variables / varnext / varbest
  * (src/problem.jl:9-12) */
@@ -166,6 +169,11 @@ int  nlls_res_ndeps(int32_t res_kind);
 int  nlls_res_nres(int32_t res_kind);
 int  nlls_res_ndata(int32_t res_kind);
 int  nlls_res_slot_kind(int32_t res_kind, int32_t slot, int32_t* var_kind, int32_t* var_dim);
+/* host-only helper (no context, no device): the ordering nlls_upload_structure applies to the banded part of the reduced system -- reverse
+ * Cuthill-McKee (pseudo-peripheral start node, neighbours by ascending degree, components one after the other) of a symmetric graph in CSR form
+ * (adjptr[n+1], adj: 0-based neighbours, no self loops; both directions listed).  perm_out[new position] = node.  Stands where the reference
+ * calls ldl_analyze (src/linearsystem.jl:52,68), which orders the factorisation itself: the solve must not depend on the caller's numbering. */
+int  nlls_rcm_order(int32_t n, const int64_t* adjptr, const int32_t* adj, int32_t* perm_out);
 
 /* ---- factory ----------------------------------------------------------------------------------
  * replaces: makesymmvls(problem, unfixed, nblocks)   src/linearsystem.jl:91-124
@@ -223,7 +231,8 @@ int  nlls_solve(nlls_ctx* ctx, double* x_out);
  * of dividing rounding by rounding; NaN pivots are never dropped (they raise NLLS_ERR_NOT_SPD).  The chain and dense solvers
  * (NLLS_FLAG_NO_BCR, NLLS_FLAG_NO_BAND) have no such floor.  Collective route (see "collectives"): [11] sums over ranks of the reduced rows
  * of A.data / b since the upload, [12] LM trials since the upload that ran on rows NOT summed (nlls_sweep_gradhess(ctx, NULL) leaves them as the
- * rank's share: everything a trial takes from them is linear in them). */
+ * rank's share: everything a trial takes from them is linear in them).  [13] 1: the reduced blocks are in reverse Cuthill-McKee order (0: the caller's),
+ * [14] half bandwidth (dof) the caller's order would have given (-1: not computed). */
 int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
 int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
 int  nlls_get_step(nlls_ctx* ctx, double* x_out);

@@ -103,6 +103,15 @@ int nlls_res_slot_kind(int32_t k, int32_t slot, int32_t* vk, int32_t* vd) {
     if (vk) *vk = d.sk[slot]; if (vd) *vd = d.sd[slot];
     return NLLS_OK;
 }
+int nlls_rcm_order(int32_t n, const int64_t* adjptr, const int32_t* adj, int32_t* perm_out) {
+    if (n < 0 || (n > 0 && (!adjptr || !perm_out))) return NLLS_ERR_INVALID_ARG;
+    std::vector<std::vector<int32_t>> a((size_t)n);
+    for (int32_t i = 0; i < n; ++i) { if (adjptr[i + 1] < adjptr[i]) return NLLS_ERR_INVALID_ARG;
+        for (int64_t q = adjptr[i]; q < adjptr[i + 1]; ++q) { if (adj[q] < 0 || adj[q] >= n || adj[q] == i) return NLLS_ERR_INVALID_ARG; a[i].push_back(adj[q]); } }
+    const std::vector<int32_t> p = nlls::rcm_order(a);
+    for (int32_t i = 0; i < n; ++i) perm_out[i] = p[i];
+    return NLLS_OK;
+}
 
 int nlls_upload_structure(nlls_ctx* ctx, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* blockindices,
                           int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
@@ -386,10 +395,10 @@ int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
     int32_t status[16] = {0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    const int64_t vals[13] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
+    const int64_t vals[15] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
                               ctx->bcr.ready ? ctx->bcr.mfma_issued : 0, ctx->bcr.ready ? ctx->bcr.launches : 0, ctx->bcr.ready ? (int64_t)ctx->bcr.levels.size() : 0, ctx->n_band,
-                              status[4] /* pivots the floor of the last undamped band solve dropped */, ctx->n_stage0, ctx->n_lazy_trials};
-    for (int i = 0; i < n && i < 13; ++i) out[i] = vals[i];
+                              status[4] /* pivots the floor of the last undamped band solve dropped */, ctx->n_stage0, ctx->n_lazy_trials, ctx->red_reordered, ctx->bw_caller};
+    for (int i = 0; i < n && i < 15; ++i) out[i] = vals[i];
     return NLLS_OK;
 }
 int nlls_set_step(nlls_ctx* ctx, const double* x) {

@@ -121,7 +121,7 @@ struct GatherJob {
     uint32_t boff;           // rhs jobs: offset in b
     uint32_t pad_;
 };
-// one share of a block pair: ld > 0 -- a block in a supernode's slab at offset off, leading dimension ld;
+// one share of a block pair: ld > 0 -- a block in a supernode's slab at offset off, leading dimension ld (aux = 1: stored as the transpose of the pair's block in S);
 // ld == 0 -- a member of a small supernode, formed on the fly: E_A' (C_v + lambda I)^-1 E_B with E_A at A.data + off, E_B at A.data + aux
 // (rhs segments: b_v at b + aux), the inverse at Cinv + cinv
 struct GatherCon { uint32_t off, ld, aux, cinv; };
@@ -237,6 +237,7 @@ struct nlls_ctx {
     // every member's products straight into S]; each class is one launch with the LDS its own widest supernode needs (up to gfx950's 160 KB)
     int64_t n_slow_acc = 0; int slow_nd_acc = 0, slow_nd_noacc = 0; size_t elim_lds_acc = 0, elim_lds_noacc = 0;
     int64_t n_band = 0; int nbd = 0, bw = 0;   // reduced ordering: [banded part | border dof | rhs]
+    int red_reordered = 0; int64_t bw_caller = -1;   // the banded part is in reverse Cuthill-McKee order (narrower than the caller's block order, whose half bandwidth was bw_caller)
     int solve_mode = 0, band_CH = 0, band_H = 0, band_SEG = 0, band_NSEG = 0;
     bool band_blocked = true;                // blocked (MFMA) band factorisation when the bandwidth allows
     bool band_twisted = true;               // factor the band from both ends at once (two workgroups) when the layout allows

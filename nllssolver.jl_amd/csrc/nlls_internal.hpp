@@ -17,6 +17,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags);
 int select_elimination(nlls_ctx* c, int32_t flags);
 int build_schur(nlls_ctx* c, int32_t flags);
+std::vector<int32_t> rcm_order(const std::vector<std::vector<int32_t>>& adj);   // reverse Cuthill-McKee: perm[new position] = node (nlls_structure.cpp)
 
 // sweeps (nlls_sweep.hip): enqueue on c->stream; cost lands in c->scalars[0]
 struct PostSolveArgs;

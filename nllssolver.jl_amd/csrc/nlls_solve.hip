@@ -371,11 +371,11 @@ __device__ __forceinline__ void schur_elim_tiled_body(const double* __restrict__
                                                       const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
                                                       const double* __restrict__ Cinv, const SLayout& L, double* __restrict__ s, uint32_t bidx) {
     __shared__ __attribute__((aligned(16))) double Es[2][DV][ELIM_NDP], Ys[2][DV][ELIM_NDP];
-    __shared__ uint32_t rc[ELIM_NDP];
+    __shared__ uint32_t rc[ELIM_NDP], rs[ELIM_NDP];          // rc: reduced column of list column p (MEMORY order); rs: the list columns by ascending reduced column
     const int tid = threadIdx.x; constexpr int NT = 64 * (1 + TW);
     const ElimDesc d = desc[bidx];                       // uniform: one scalar load (the run's structure is identical for all members)
     const uint32_t v0 = d.v0, v1 = d.v0 + d.nmem; const int nd = (int)d.nd;
-    for (int c2 = tid; c2 < nd; c2 += NT) rc[c2] = rcflat[d.rc_off + c2];
+    for (int c2 = tid; c2 < nd; c2 += NT) { rc[c2] = rcflat[d.rc_off + c2]; rs[c2] = rcflat[d.rc_off + nd + c2]; }
     for (int i = tid; i < 2 * DV * ELIM_NDP; i += NT) { (&Es[0][0][0])[i] = 0.0; (&Ys[0][0][0])[i] = 0.0; }
     __syncthreads();
     // this thread's tile: t < ntile -> (tp, tq), tq <= tp, pairs (4 tp + i, 4 tq + j).  (The rhs column E' y_b is summed by the
@@ -511,8 +511,10 @@ __device__ __forceinline__ void schur_elim_tiled_body(const double* __restrict__
     }
     __syncthreads();
     const int wv = tid >> 6, ln = tid & 63;
-    for (int q = wv; q < nd; q += NT / 64)
-        for (int p = q + ln; p < nd; p += 64) atomicAdd(L.at(rc[p] > rc[q] ? rc[p] : rc[q], rc[p] > rc[q] ? rc[q] : rc[p]), -img[colstart(q) + p]);
+    // (in ascending REDUCED order -- a permutation of the memory order when the reduced system was re-ordered at upload -- so that the lanes of one
+    //  instruction still walk down one column of S: addressed pair by pair as (max, min) in memory order, half of them would land in other columns)
+    for (int qs = wv; qs < nd; qs += NT / 64) { const int q = (int)rs[qs];
+        for (int ps = qs + ln; ps < nd; ps += 64) { const int p = (int)rs[ps]; atomicAdd(L.at(rc[p], rc[q]), -img[p > q ? colstart(q) + p : colstart(p) + q]); } }
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 
@@ -538,13 +540,13 @@ __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ 
                                                      const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
                                                      const double* __restrict__ Cinv, const SLayout& L, double* __restrict__ s, uint32_t bidx) {
     constexpr int NDMAX = 63, NW = ELIM_MFMA_NW, NTH = 64 * NW;
-    __shared__ uint32_t rc[64];
+    __shared__ uint32_t rc[64], rs[64];                       // rc: reduced column of list column p (MEMORY order); rs: the list columns by ascending reduced column
     __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
     double* const irhs = img + NDMAX * (NDMAX + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
     const ElimDesc d = desc[bidx];                       // uniform: one scalar load
     const uint32_t v0 = d.v0, nmem = d.nmem; const int nd = (int)d.nd;
-    if (tid < nd) rc[tid] = rcflat[d.rc_off + tid];               // (nd <= 63 < NTH)
+    if (tid < nd) { rc[tid] = rcflat[d.rc_off + tid]; rs[tid] = rcflat[d.rc_off + nd + tid]; }               // (nd <= 63 < NTH)
     for (int i = tid; i < nd * (nd + 1) / 2; i += NTH) img[i] = 0.0;
     if (tid < NDMAX) irhs[tid] = 0.0;
     const int T16 = (nd + 1 + 15) >> 4;                       // tile rows of [E | b] in use (<= 4)
@@ -631,8 +633,9 @@ __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ 
             }
         }
     __syncthreads();
-    for (int q = wave; q < nd; q += NW)
-        for (int pp = q + lane; pp < nd; pp += 64) atomicAdd(L.at(rc[pp] > rc[q] ? rc[pp] : rc[q], rc[pp] > rc[q] ? rc[q] : rc[pp]), -img[colstart(q) + pp]);
+    // (in ascending REDUCED order, see schur_elim_tiled_body: one column of S per instruction whatever the memory order of the columns)
+    for (int qs = wave; qs < nd; qs += NW) { const int q = (int)rs[qs];
+        for (int ps = qs + lane; ps < nd; ps += 64) { const int pp = (int)rs[ps]; atomicAdd(L.at(rc[pp], rc[q]), -img[pp > q ? colstart(q) + pp : colstart(pp) + q]); } }
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 
@@ -2283,7 +2286,7 @@ __global__ __launch_bounds__(256) void schur_gather_kernel(GatherArgs a) {
             for (int u = 0; u < 4; ++u) k[u] = a.cons[c0 + u < J.cend ? c0 + u : J.cend - 1];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (k[u].ld) t[u] = a.slab[k[u].off + a2 + k[u].ld * b2];
+                if (k[u].ld) t[u] = k[u].aux ? a.slab[k[u].off + b2 + k[u].ld * a2] : a.slab[k[u].off + a2 + k[u].ld * b2];   // aux: the share lies above the diagonal of S in reduced order -- its transpose is wanted
                 else {                                          // a member of a small supernode: e_a' (C_v + lambda I)^-1 e_b on the fly
                     const int dv = a.dv; const double* ea = a.A + k[u].off + (size_t)dv * a2; const double* eb = J.kind == 0 ? a.A + k[u].aux + (size_t)dv * b2 : a.b + k[u].aux;
                     const double* ci = a.Cinv + k[u].cinv; double s2 = 0.0;

@@ -474,6 +474,50 @@ int select_elimination(nlls_ctx* c, int32_t flags) {
     return NLLS_OK;
 }
 
+// ---- ordering of the reduced system ---------------------------------------------------------------------------
+// The reference analyses the sparsity of the full system once with a fill-reducing ordering (ldl_analyze, src/linearsystem.jl:52,68) and is
+// therefore insensitive to how the caller numbers the variables.  Here the reduced system is solved as a bordered BAND, so the numbering of
+// the reduced blocks IS the fill: a reverse Cuthill-McKee ordering (George & Liu's pseudo-peripheral start node, neighbours by ascending
+// degree, components one after the other) of the reduced blocks' graph replaces the caller's order whenever it gives the narrower band.
+// adj: symmetric adjacency lists (sorted, no self loops).  Returns perm[new position] = node.
+std::vector<int32_t> rcm_order(const std::vector<std::vector<int32_t>>& adj) {
+    const int32_t n = (int32_t)adj.size();
+    std::vector<int32_t> order; order.reserve(n);
+    std::vector<int32_t> level(n, -1), q; q.reserve(n);
+    std::vector<uint8_t> done(n, 0);
+    auto deg = [&](int32_t v) { return (int32_t)adj[v].size(); };
+    // breadth-first level structure of the component of r among nodes not yet ordered; returns the eccentricity, q = the nodes in visiting order
+    auto bfs = [&](int32_t r) { q.clear(); q.push_back(r); level[r] = 0; int32_t ecc = 0;
+        for (size_t h = 0; h < q.size(); ++h) { const int32_t u = q[h]; ecc = level[u];
+            for (int32_t w : adj[u]) if (!done[w] && level[w] < 0) { level[w] = level[u] + 1; q.push_back(w); } }
+        return ecc; };
+    auto clear_levels = [&]() { for (int32_t u : q) level[u] = -1; };
+    std::vector<int32_t> starts(n); std::iota(starts.begin(), starts.end(), 0);
+    std::stable_sort(starts.begin(), starts.end(), [&](int32_t a, int32_t b) { return deg(a) < deg(b); });
+    std::vector<int32_t> nb_sorted;
+    for (int32_t s0 : starts) { if (done[s0]) continue;
+        // pseudo-peripheral node: restart from a minimum-degree node of the last level while the eccentricity grows
+        int32_t r = s0, ecc = bfs(r);
+        for (int it = 0; it < 32; ++it) {
+            int32_t cand = -1; for (int32_t u : q) if (level[u] == ecc && (cand < 0 || deg(u) < deg(cand))) cand = u;
+            clear_levels();
+            if (cand < 0 || cand == r) { bfs(r); break; }
+            const int32_t e2 = bfs(cand);
+            if (e2 > ecc) { r = cand; ecc = e2; } else { clear_levels(); bfs(r); break; }
+        }
+        clear_levels();
+        // Cuthill-McKee from r
+        const size_t first = order.size();
+        order.push_back(r); done[r] = 1;
+        for (size_t h = first; h < order.size(); ++h) { const int32_t u = order[h];
+            nb_sorted.clear(); for (int32_t w : adj[u]) if (!done[w]) { nb_sorted.push_back(w); done[w] = 1; }
+            std::stable_sort(nb_sorted.begin(), nb_sorted.end(), [&](int32_t a, int32_t b) { return deg(a) < deg(b); });
+            order.insert(order.end(), nb_sorted.begin(), nb_sorted.end()); }
+    }
+    std::reverse(order.begin(), order.end());
+    return order;
+}
+
 // ---- Schur structures --------------------------------------------------------------------------------------
 // The reference factors the FULL sparse system with LDLFactorizations (src/linearsolver.jl:29); there is no
 // Schur complement in it.  Here an independent set of blocks (no two share a stored block) is
@@ -531,8 +575,64 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) {
             bool big = (nelim_all >= 64 && cnt[k] * 4 > nelim_all) || (nR >= 64 && rcnt[k] * 4 > nR);
             if (big && bd + c->blocksizes[k] <= 15) { is_border[k] = 1; bd += c->blocksizes[k]; } }
+        // ---- order of the banded part: the caller's block order, or reverse Cuthill-McKee where that gives the narrower band ----------
+        std::vector<int64_t> band_blocks;                    // reduced, non-border blocks in the order they take in S
+        for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && !is_border[k]) band_blocks.push_back(k);
+        c->red_reordered = 0; c->bw_caller = -1;
+        if (I0.is_sparse && c->nelim > 0 && band_blocks.size() >= 3 && !(flags & NLLS_FLAG_NO_REORDER) && band_blocks.size() < ((size_t)1 << 30)) {
+            const int32_t nRb = (int32_t)band_blocks.size();
+            std::vector<int32_t> rid(nb, -1); for (int32_t i = 0; i < nRb; ++i) rid[band_blocks[i]] = i;
+            std::vector<std::vector<int32_t>> adj(nRb); std::vector<uint32_t> cap(nRb, 64);
+            auto add = [&](int32_t a, int32_t b2) { auto& l = adj[a]; l.push_back(b2);
+                if (l.size() > cap[a]) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); cap[a] = (uint32_t)std::max<size_t>(64, 2 * l.size()); } };
+            std::vector<int32_t> nl, prevnl;
+            for (int64_t v = 0; v < nb; ++v) if (c->is_elim[v]) {        // an eliminated block couples all its reduced neighbours pairwise
+                nl.clear();
+                for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) { const int64_t u = c->it_rowval[q]; if (u != v && rid[u] >= 0) nl.push_back(rid[u]); }
+                for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) { const int64_t w = trow[q]; if (w != v && rid[w] >= 0) nl.push_back(rid[w]); }
+                std::sort(nl.begin(), nl.end());
+                if (nl == prevnl) continue;                                 // (supernodes: the same clique again)
+                for (size_t a = 0; a < nl.size(); ++a) for (size_t b2 = 0; b2 < a; ++b2) { add(nl[a], nl[b2]); add(nl[b2], nl[a]); }
+                prevnl = nl;
+            }
+            for (int64_t row = 0; row < nb; ++row) { if (rid[row] < 0) continue;       // stored reduced-reduced blocks
+                for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { const int64_t col = c->it_rowval[q]; if (col != row && rid[col] >= 0) { add(rid[row], rid[col]); add(rid[col], rid[row]); } } }
+            bool graph_ok = true;
+            if ((flags & NLLS_FLAG_PRESHARDED) && c->nranks > 1) {
+                // every rank sees the couplings of ITS eliminated blocks only: the graph is the union over ranks (one double per pair of the lower
+                // triangle, MAX-reduced -- up to 4096 reduced blocks = 67 MB; beyond that the caller's order stays: every rank decides alike)
+                if (nRb > 4096) graph_ok = false;
+                else {
+                    const size_t npair = (size_t)nRb * (nRb - 1) / 2;
+                    std::vector<double> hp(npair, 0.0);
+                    for (int32_t a = 0; a < nRb; ++a) for (int32_t b2 : adj[a]) if (b2 < a) hp[(size_t)a * (a - 1) / 2 + b2] = 1.0;
+                    DevBuf<double> dp; HIPCHK(dp.upload(hp));
+                    { const int rc = comm_reduce(c, dp.p, (int64_t)npair, NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    HIPCHK(hipMemcpy(hp.data(), dp.p, sizeof(double) * npair, hipMemcpyDeviceToHost));
+                    for (auto& l : adj) l.clear();
+                    for (int32_t a = 1; a < nRb; ++a) for (int32_t b2 = 0; b2 < a; ++b2) if (hp[(size_t)a * (a - 1) / 2 + b2] != 0.0) { adj[a].push_back(b2); adj[b2].push_back(a); }
+                }
+            }
+            if (graph_ok) {
+                for (auto& l : adj) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
+                // half bandwidth (dof) of an order: the farthest coupled pair, first dof of the one to the last dof of the other
+                auto bandwidth_of = [&](const std::vector<int32_t>& perm) { std::vector<int64_t> o(nRb + 1, 0), pos(nRb);
+                    for (int32_t i = 0; i < nRb; ++i) { pos[perm[i]] = i; o[i + 1] = o[i] + c->blocksizes[band_blocks[perm[i]]]; }
+                    int64_t w = 0; for (int32_t a = 0; a < nRb; ++a) { w = std::max<int64_t>(w, c->blocksizes[band_blocks[a]] - 1);
+                        for (int32_t b2 : adj[a]) { const int64_t pa = pos[a], pb = pos[b2]; w = std::max(w, std::max(o[pa + 1], o[pb + 1]) - std::min(o[pa], o[pb]) - 1); } }
+                    return w; };
+                std::vector<int32_t> ident(nRb); std::iota(ident.begin(), ident.end(), 0);
+                const int64_t bw_nat = bandwidth_of(ident);
+                c->bw_caller = bw_nat;
+                const std::vector<int32_t> perm = rcm_order(adj);
+                if ((int32_t)perm.size() == nRb && bandwidth_of(perm) < bw_nat) {
+                    std::vector<int64_t> nbk(nRb); for (int32_t i = 0; i < nRb; ++i) nbk[i] = band_blocks[perm[i]];
+                    band_blocks.swap(nbk); c->red_reordered = 1; }
+            }
+        }
         int64_t ro = 0;
-        for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && !is_border[k]) { red_of[k] = ro; ro += c->blocksizes[k]; }
+        for (int64_t k : band_blocks) { red_of[k] = ro; ro += c->blocksizes[k]; }
         c->n_band = ro;
         for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && is_border[k]) { red_of[k] = ro; ro += c->blocksizes[k]; }
         c->nred = ro; c->nbd = (int)(ro - c->n_band);
@@ -565,7 +665,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
               if (!anytrans) std::sort(nl.begin(), nl.end(), [](const SchurNbr& a, const SchurNbr& b) { return a.off < b.off; });
               else std::sort(nl.begin(), nl.end(), [](const SchurNbr& a, const SchurNbr& b) { return a.rcol < b.rcol; }); }
             int nd = 0; int64_t lo = -1, hi = -1;
-            for (auto& n : nl) { nd += n.dim; if ((int64_t)n.rcol < c->n_band) { if (lo < 0) lo = n.rcol; hi = n.rcol + n.dim - 1; } }
+            for (auto& n : nl) { nd += n.dim; if ((int64_t)n.rcol < c->n_band) { lo = lo < 0 ? (int64_t)n.rcol : std::min<int64_t>(lo, n.rcol); hi = std::max<int64_t>(hi, (int64_t)n.rcol + n.dim - 1); } }   // (any order: the columns are in MEMORY order)
             if (lo >= 0) bw = std::max(bw, hi - lo);
             c->max_nbr_dof = std::max(c->max_nbr_dof, nd); c->max_elim_dim = std::max(c->max_elim_dim, (int)c->blocksizes[v]);
             // supernode: same neighbour columns and own size as the previous eliminated block
@@ -632,6 +732,10 @@ int build_schur(nlls_ctx* c, int32_t flags) {
           for (uint32_t gi : fastg) { const uint32_t v0 = egroup[gi];
               ElimDesc d{v0, egroup[gi + 1] - v0, 0, (uint32_t)rcflat.size(), ediag[v0], eboff[v0], 0};
               for (int64_t p = eptr[v0]; p < eptr[v0 + 1]; ++p) { for (int q = 0; q < enbr[p].dim; ++q) rcflat.push_back(enbr[p].rcol + q); d.nd += enbr[p].dim; }
+              // ... followed by the list columns sorted by reduced column (the flush walks S column by column whatever order the columns have in memory)
+              { std::vector<uint32_t> idx(d.nd); std::iota(idx.begin(), idx.end(), 0u); const uint32_t* r0 = rcflat.data() + d.rc_off;
+                std::sort(idx.begin(), idx.end(), [r0](uint32_t a, uint32_t b2) { return r0[a] < r0[b2]; });
+                rcflat.insert(rcflat.end(), idx.begin(), idx.end()); }
               desc.push_back(d); }
           if (rcflat.empty()) rcflat.push_back(0);
           if (hipSuccess != c->d_elim_desc.upload(desc) || hipSuccess != c->d_elim_rc.upload(rcflat)) return fail(c, NLLS_ERR_HIP, "supernode descriptor upload"); }
@@ -756,13 +860,14 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 const uint32_t v0 = egroup[gi], v1 = egroup[gi + 1];
                 std::vector<SchurNbr> nl(enbr.begin() + eptr[v0], enbr.begin() + eptr[v0 + 1]);
                 if (nl.size() > 16) { ok = false; break; }
-                for (size_t a = 1; a < nl.size(); ++a) if (nl[a].rcol < nl[a - 1].rcol) ok = false;      // (the gather addresses blocks as (row >= column) in list order)
-                if (!ok) break;
+                // (the columns of a supernode are in MEMORY order, the reduced order may be any permutation of it: a share whose list pair (a >= b) lies
+                //  above the diagonal of S is flagged and read transposed by the gather)
                 if (v1 - v0 <= SMALL_SUPERNODE) {
                     for (uint32_t v = v0; v < v1; ++v) {
                         const SchurNbr* nv = enbr.data() + eptr[v];
                         for (size_t a = 0; a < nl.size(); ++a) {
-                            for (size_t b2 = 0; b2 <= a; ++b2) pairs[Key{nl[a].rcol, nl[b2].rcol}].push_back(GatherCon{(uint32_t)nv[a].off, 0, (uint32_t)nv[b2].off, (uint32_t)((uint64_t)v * dv * dv)});
+                            for (size_t b2 = 0; b2 <= a; ++b2) { const bool tr = nl[a].rcol < nl[b2].rcol; const size_t hi2 = tr ? b2 : a, lo2 = tr ? a : b2;
+                                pairs[Key{nl[hi2].rcol, nl[lo2].rcol}].push_back(GatherCon{(uint32_t)nv[hi2].off, 0, (uint32_t)nv[lo2].off, (uint32_t)((uint64_t)v * dv * dv)}); }
                             rhs[nl[a].rcol].push_back(GatherCon{(uint32_t)nv[a].off, 0, eboff[v], (uint32_t)((uint64_t)v * dv * dv)});
                         }
                     }
@@ -773,7 +878,8 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 slab_off.push_back((uint32_t)off);
                 uint64_t po = off;
                 for (size_t a = 0; a < nl.size(); ++a)
-                    for (size_t b2 = 0; b2 <= a; ++b2) { pairs[Key{nl[a].rcol, nl[b2].rcol}].push_back(GatherCon{(uint32_t)po, (uint32_t)nl[a].dim, 0, 0}); po += (uint64_t)nl[a].dim * nl[b2].dim; }
+                    for (size_t b2 = 0; b2 <= a; ++b2) { const bool tr = nl[a].rcol < nl[b2].rcol;
+                        pairs[tr ? Key{nl[b2].rcol, nl[a].rcol} : Key{nl[a].rcol, nl[b2].rcol}].push_back(GatherCon{(uint32_t)po, (uint32_t)nl[a].dim, tr ? 1u : 0u, 0}); po += (uint64_t)nl[a].dim * nl[b2].dim; }
                 uint64_t ro = po;
                 for (size_t a = 0; a < nl.size(); ++a) { rhs[nl[a].rcol].push_back(GatherCon{(uint32_t)ro, 1, 0, 0}); ro += nl[a].dim; }
                 off = (ro + 3) & ~(uint64_t)3;

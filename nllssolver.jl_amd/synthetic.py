@@ -150,6 +150,29 @@ def widen_visibility(problem, ncameras, wide):
     return problem
 
 
+def shuffle_camera_labels(problem, ncameras, seed, first=1):
+    """The same problem with the cameras' LABELS permuted (camera c is afterwards variable perm^-1[c]; its pose moves with the label, cost blocks are
+    re-listed camera-major in the new labels, as test/optimizeba.jl:24-31 adds them).  test/optimizeba.jl:22 numbers neighbouring cameras consecutively --
+    a property of that generator, not of bundle adjustment: the reference's solve does not depend on it (ldl_analyze orders the factorisation itself,
+    src/linearsystem.jl:52,68), and neither may this path.  `first`: 1-based variable index of the first camera (2 behind an adaptive kernel variable).
+    Works for the affine (6 doubles per camera) and the SO(3) (12 doubles) kinds, two- and three-slot residuals."""
+    perm = np.random.default_rng(seed).permutation(ncameras)
+    inv = np.empty(ncameras, np.int64); inv[perm] = np.arange(ncameras)
+    off = problem.var_offsets; v = problem.variables
+    st = int(off[first] - off[first - 1])
+    a0 = int(off[first - 1])
+    cams = v[a0: a0 + st * ncameras].reshape(ncameras, st).copy()
+    v[a0: a0 + st * ncameras] = cams[perm].ravel()                                   # new camera j holds old camera perm[j]
+    for g in problem.costs.values():
+        vi, da = g.arrays()
+        col = next(c for c in range(vi.shape[1]) if vi.shape[0] and first <= vi[0, c] < first + ncameras)
+        vi2 = vi.copy(); vi2[:, col] = inv[vi[:, col] - first] + first
+        order = np.lexsort(tuple(vi2[:, c] for c in range(vi2.shape[1] - 1, -1, -1) if c != col) + (vi2[:, col],))
+        g.set_arrays(np.ascontiguousarray(vi2[order]), np.ascontiguousarray(da[order]))
+    problem._gpu = None
+    return problem
+
+
 def perturb_ba_problem(problem, pointnoise, posenoise, seed=2):
     """test/optimizeba.jl:38-47."""
     rng = np.random.default_rng(seed)

@@ -32,20 +32,25 @@ def main():
     seed = int(sys.argv[5]) if len(sys.argv) > 5 else 21
     if seed < 0:
         return singular_point_block(rank, world, dist, staged)
-    if seed >= 5000:
+    if 5000 <= seed < 6000:
         return presharded(rank, world, dist, staged, seed)
+    shuffled = seed >= 6000                      # the cameras' labels permuted: the reduced system is re-ordered at upload (every rank must arrive at the same order)
     rng = np.random.default_rng(seed)
     ncr = int(rng.integers(12, 90))             # (sharding partitions by eliminated block: stay within what the Schur kernels take)
-    shape = (40, 2000, 0.15) if seed == 21 else (ncr, int(rng.integers(300, 4000)), float(rng.uniform(4.0, 10.0)) / ncr)
+    shape = (40, 2000, 0.15) if seed == 21 else (90, 3000, 0.08) if shuffled else (ncr, int(rng.integers(300, 4000)), float(rng.uniform(4.0, 10.0)) / ncr)
     config3 = seed == 3000                       # BASELINE config 3 at full size, checked against the ORACLE (not only the unsharded device)
     if config3:
         shape = (100, 10000, 0.1)
-    mkp = lambda: synthetic.perturb_ba_problem(synthetic.create_ba_problem(*shape, seed=1 if config3 else seed, robust=N.HuberKernel(0.01 if config3 else 0.05),
-                                                                           outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    shuf = (lambda q: synthetic.shuffle_camera_labels(q, shape[0], seed)) if shuffled else (lambda q: q)
+    mkp = lambda: synthetic.perturb_ba_problem(shuf(synthetic.create_ba_problem(*shape, seed=1 if config3 else seed, robust=N.HuberKernel(0.01 if config3 else 0.05),
+                                                                                outlier_frac=0.05, outlier_sigma=0.05)), 1e-3, 1e-3)
     p = mkp()
     unfixed = np.ones(p.nvariables, bool)
     ref = MultiVariateLSgpu(p, unfixed)                       # unsharded reference on the same device
     sh = mk()
+    if shuffled:
+        st_r, st_s = ref.ctx.solve_stats(), sh.ctx.solve_stats()
+        assert st_r["reordered"] == 1 and st_s["reordered"] == 1 and ref.info.solve_mode == 2 and sh.info.solve_mode == 2 and sh.info.bandwidth == ref.info.bandwidth, (st_r, st_s)
     info = sh.ctx.shard_info()
     counts = [None] * world
     dist.all_gather_object(counts, info["local_ncost"])
@@ -136,7 +141,11 @@ def presharded(rank, world, dist, staged, seed):
     from nllssolver_jl_amd.dist import ShardedLS
     from nllssolver_jl_amd.linearsystem import MultiVariateLSgpu
     ncam, npts = 60, 3000
-    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, 0.12, seed=seed, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    shuffled = seed % 1000 >= 100               # camera labels permuted: the ranks agree on the reverse Cuthill-McKee order of the UNION of their camera graphs
+    p = synthetic.create_ba_problem(ncam, npts, 0.12, seed=seed, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05)
+    if shuffled:
+        p = synthetic.shuffle_camera_labels(p, ncam, seed)
+    p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
     mine = synthetic.shard_of_problem(p, ncam, rank, world)
     counts = [None] * world
     dist.all_gather_object(counts, mine.ncosts()); assert sum(counts) == p.ncosts(), (counts, p.ncosts())
@@ -150,6 +159,8 @@ def presharded(rank, world, dist, staged, seed):
     ref = MultiVariateLSgpu(p, np.ones(p.nvariables, bool)); dr = run(ref, p, True)
     sh = ShardedLS(mine, np.ones(mine.nvariables, bool), rank=rank, world=world, dist=dist, host_staged=staged, presharded=True)
     assert sh.info.nreduced_dof == ref.info.nreduced_dof and sh.info.bandwidth == ref.info.bandwidth, (sh.info.bandwidth, ref.info.bandwidth)   # the agreed layout
+    if shuffled:
+        assert sh.ctx.solve_stats()["reordered"] == 1 and sh.info.solve_mode == 2, (sh.ctx.solve_stats(), sh.info.solve_mode)
     ds = run(sh, mine, True)
     assert np.isclose(ds.startcost, dr.startcost, rtol=1e-12) and np.isclose(ds.bestcost, dr.bestcost, rtol=1e-9), (ds.bestcost, dr.bestcost)
     assert ds.iternum == dr.iternum and ds.linearsolvers == dr.linearsolvers
@@ -158,9 +169,10 @@ def presharded(rank, world, dist, staged, seed):
     l0, l1 = (npts * rank) // world, (npts * (rank + 1)) // world
     assert np.allclose(vs[6 * ncam:], vr[6 * ncam + 3 * l0: 6 * ncam + 3 * l1], rtol=1e-7, atol=1e-10)   # ... and its own points
     # the generator of a rank's share alone: the same structure as the slice of the whole (counts per rank), nothing else built
-    g = synthetic.create_ba_problem_shard(ncam, npts, 0.12, rank, world, seed=seed)
-    assert g.ncosts() == mine.ncosts() and g.nvariables == mine.nvariables
-    assert np.array_equal(next(iter(g.costs.values())).arrays()[0], next(iter(mine.costs.values())).arrays()[0])
+    if not shuffled:
+        g = synthetic.create_ba_problem_shard(ncam, npts, 0.12, rank, world, seed=seed)
+        assert g.ncosts() == mine.ncosts() and g.nvariables == mine.nvariables
+        assert np.array_equal(next(iter(g.costs.values())).arrays()[0], next(iter(mine.costs.values())).arrays()[0])
     ref.close(); sh.close(); dist.barrier(); dist.destroy_process_group()
     print(f"rank {rank}: sharded == unsharded (presharded: {mine.ncosts()} of {p.ncosts()} cost blocks uploaded, best cost {ds.bestcost:.6e})")
 

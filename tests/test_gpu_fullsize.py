@@ -21,6 +21,16 @@ def test_full_size_sweeps_and_solve_against_oracle(ncam, npts, prop):
     assert info.nreduced_dof == 6 * ncam and info.ndof == 6 * ncam + 3 * npts
 
 
+def test_config4_shuffled_camera_labels_against_oracle():
+    """BASELINE config 4 at full size with the cameras' labels permuted (seeded): the reduced camera system is re-ordered at upload (reverse
+    Cuthill-McKee) and stays on the band / block-cyclic-reduction path with the unshuffled problem's bandwidth; structure, sweeps, x (1e-7), x'Hx and the
+    retraction against the oracle, whose sparse LDL' takes any numbering (as the reference's does: src/linearsystem.jl:52,68, src/linearsolver.jl:28-32)."""
+    mk = lambda: synthetic.create_ba_problem(1000, 100000, 0.01, seed=1, robust=N.HuberKernel(0.01), outlier_frac=0.05, outlier_sigma=0.05)
+    p = synthetic.perturb_ba_problem(synthetic.shuffle_camera_labels(mk(), 1000, 2024), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.nreduced_dof == 6000 and info.solve_mode == 2 and info.bandwidth <= 1.25 * 65, info.bandwidth
+
+
 def test_config4_step_identity_and_reproducibility():
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(1000, 100000, 0.01, seed=1, robust=N.HuberKernel(0.01),
                                                                  outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)

@@ -116,26 +116,57 @@ def test_wide_visibility_keeps_the_schur_path():
     assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
 
 
-@pytest.mark.parametrize("ncam,npts,prop,seed", [(40, 1500, 0.12, 31), (150, 6000, 0.04, 32)])
-def test_unbanded_visibility(ncam, npts, prop, seed):
+def _upload_info(p, flags=0):
+    ctx = _capi.Context()
+    info = ctx.upload(p.var_kind, p.var_dim, np.arange(1, p.nvariables + 1, dtype=np.uint64), p.groups(), flags)
+    st = ctx.solve_stats(); ctx.close()
+    return info, st
+
+
+@pytest.mark.parametrize("ncam,npts,prop,seed", [(40, 1500, 0.12, 31), (150, 6000, 0.04, 32), (300, 9000, 0.03, 33)])
+@pytest.mark.parametrize("reorder", [1, 0])
+def test_shuffled_camera_labels(ncam, npts, prop, seed, reorder):
     """The generator of test/optimizeba.jl gives every point a window of NEIGHBOURING cameras (a banded reduced system); real image collections do
-    not number their cameras that way.  The same problems with the cameras' labels shuffled: no band, few supernodes of more than one member (consecutive
-    points no longer share their camera set in memory order) -- Schur elimination with the dense reduced camera system, against the oracle."""
-    p = synthetic.create_ba_problem(ncam, npts, prop, seed=seed, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05)
-    perm = np.random.default_rng(seed).permutation(ncam)
-    g = next(iter(p.costs.values())); vi, da = g.arrays()
-    inv = np.empty(ncam, np.int64); inv[perm] = np.arange(ncam)
-    vi2 = vi.copy(); vi2[:, 0] = inv[vi[:, 0] - 1] + 1                                  # camera c is now called inv[c]
-    cams = p.variables[: 6 * ncam].reshape(ncam, 6).copy(); p.variables[: 6 * ncam] = cams[perm].ravel()   # ... and its pose moves with the label
-    g.set_arrays(vi2, da)
+    not number their cameras that way, and the reference does not care: ldl_analyze orders the factorisation itself (src/linearsystem.jl:52,68).
+    The same problems with the cameras' labels shuffled.  Default: the reduced camera system is put in reverse Cuthill-McKee order at upload and
+    stays on the band path, with a band no wider than 1.25 x the unshuffled problem's.  NLLS_FLAG_NO_REORDER: the caller's order -- no band, the
+    dense reduced system (what round 3 did with every such problem).  Both against the oracle: sweep, solve, retraction, then the LM loop."""
+    mk = lambda: synthetic.create_ba_problem(ncam, npts, prop, seed=seed, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05)
+    info0, st0 = _upload_info(mk())
+    assert info0.solve_mode == 2 and st0["reordered"] == 0                               # the generator's own numbering is already the narrowest
+    p = synthetic.perturb_ba_problem(synthetic.shuffle_camera_labels(mk(), ncam, seed), 1e-3, 1e-3)
+    flags = 0 if reorder else _capi.FLAG_NO_REORDER
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4, flags=flags)
+    _, st = _upload_info(p, flags)
+    if reorder:
+        assert info.solve_mode == 2 and info.bandwidth <= 1.25 * info0.bandwidth, (info.bandwidth, info0.bandwidth)
+        assert st["reordered"] == 1 and st["bandwidth_caller_order"] > 3 * info0.bandwidth
+    else:
+        assert st["reordered"] == 0 and (info.solve_mode in (0, 1) or info.bandwidth > 3 * info0.bandwidth)
+    if reorder:
+        q_vars = p.variables.copy()
+        op = oracle_problem(p); ro = op.optimize(iterator=1, maxiters=6)
+        p.variables[:] = q_vars
+        rg = N.optimize(p, N.NLLSOptions(maxiters=6))
+        assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
+
+
+@pytest.mark.parametrize("ncam,npts,k,seed", [(60, 2000, 4, 41), (200, 5000, 3, 42)])
+def test_random_visibility_has_no_band(ncam, npts, k, seed):
+    """Every point seen by k cameras drawn at random: the reduced camera graph is an expander -- no ordering gives a band.  Reverse Cuthill-McKee
+    is tried and whatever is narrower is kept; the dense MFMA LDL' solves the reduced system; against the oracle."""
+    rng = np.random.default_rng(seed)
+    p = N.NLLSProblem()
+    cams = rng.standard_normal((ncam, 6)) + np.array([1.0, 0, 0, 0, 1.0, 0]); pts = rng.random((npts, 3)) + np.array([-0.5, -0.5, 10.0])
+    p.addvariables(cams); p.addvariables(pts)
+    cam = np.concatenate([rng.choice(ncam, size=k, replace=False) for _ in range(npts)]) + 1; lm = np.repeat(np.arange(1, npts + 1), k)
+    order = np.lexsort((lm, cam)); cam, lm = cam[order], lm[order]
+    c, X = cams[cam - 1], pts[lm - 1]
+    meas = np.stack([(c[:, 0:3] * X).sum(1), (c[:, 3:6] * X).sum(1)], axis=1) + rng.standard_normal((cam.size, 2)) * 1e-3
+    p.addcosts(K.RES_BA_AFFINE, np.stack([cam, lm + ncam], axis=1), meas, N.HuberKernel(0.05))
     p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
-    assert info.solve_mode in (0, 1) or info.bandwidth > 6 * 10                          # not the narrow band of the unshuffled problem
-    q_vars = p.variables.copy()
-    op = oracle_problem(p); ro = op.optimize(iterator=1, maxiters=6)
-    p.variables[:] = q_vars
-    rg = N.optimize(p, N.NLLSOptions(maxiters=6))
-    assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
+    assert info.nreduced_dof == 6 * ncam and info.solve_mode == 1
 
 
 def test_ba_sparse_small():          # test/optimizeba.jl:71 shape (10 x 50 @ 0.3 -> sparse path)
@@ -389,6 +420,24 @@ def test_deterministic_flag_is_bit_reproducible(ncam, npts, cpp, seed):
     assert info.solve_mode == 2
     ctx = _capi.Context(); bi = np.arange(1, p.nvariables + 1, dtype=np.uint64)
     ctx.upload(p.var_kind, p.var_dim, bi, p.groups(), _capi.FLAG_DETERMINISTIC)
+    ctx.set_variables(p.variables); ctx.sweep_gradhess(); ctx.damp(1e-4 * ctx.max_abs_diag())
+    x0 = ctx.solve(want_x=True).copy()
+    for _ in range(5):
+        assert np.array_equal(ctx.solve(want_x=True), x0)
+    ctx.close()
+
+
+def test_deterministic_flag_with_reordered_cameras():
+    """NLLS_FLAG_DETERMINISTIC on a problem whose reduced system is re-ordered at upload: a supernode's columns are in MEMORY order, the reduced
+    order is a permutation of it -- shares above the diagonal of S are gathered transposed.  x against the oracle, bit-identical run to run."""
+    ncam, npts = 120, 4000
+    p = synthetic.create_ba_problem(ncam, npts, 8 / ncam, seed=77, robust=N.HuberKernel(0.01), outlier_frac=0.05, outlier_sigma=0.05)
+    p = synthetic.perturb_ba_problem(synthetic.shuffle_camera_labels(p, ncam, 77), 1e-3, 1e-3)
+    info = check_problem(p, flags=_capi.FLAG_DETERMINISTIC, expect_sparse=1, expect_schur=1)
+    assert info.solve_mode == 2
+    ctx = _capi.Context(); bi = np.arange(1, p.nvariables + 1, dtype=np.uint64)
+    ctx.upload(p.var_kind, p.var_dim, bi, p.groups(), _capi.FLAG_DETERMINISTIC)
+    assert ctx.solve_stats()["reordered"] == 1
     ctx.set_variables(p.variables); ctx.sweep_gradhess(); ctx.damp(1e-4 * ctx.max_abs_diag())
     x0 = ctx.solve(want_x=True).copy()
     for _ in range(5):

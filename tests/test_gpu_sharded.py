@@ -13,13 +13,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("world,backend,seed", [(2, "gloo", 21), (3, "gloo", 21), (1, "nccl", 21), (2, "gloo", 401), (3, "gloo", 402), (2, "gloo", 403),
                                                 (2, "gloo", -1), (3, "gloo", -1),
-                                                (2, "gloo", 3000), (3, "gloo", 3000), (2, "gloo", 5001), (3, "gloo", 5002)])
+                                                (2, "gloo", 3000), (3, "gloo", 3000), (2, "gloo", 5001), (3, "gloo", 5002),
+                                                (2, "gloo", 6001), (3, "gloo", 5102)])
 def test_sharded_matches_unsharded(world, backend, seed):
     """(1, "nccl"): the local / reduce / finish route over RCCL with device buffers, one rank -- the plumbing bench.py --gpus N uses.
     seed 3000: BASELINE config 3 at full size (100 cameras x 10k points, ~100k residual blocks) against the CPU oracle: cost, gradient,
     damped step and four Levenberg-Marquardt iterations.
     seed -1: a zero pivot only one rank sees must be raised on every rank (no rank left behind in a collective).
-    seed >= 5000: NLLS_FLAG_PRESHARDED -- every rank uploads only its own share (all cameras + its points), the reduced system's layout is agreed on
+    seed >= 6000: the cameras' labels permuted -- every rank re-orders the reduced system at upload (reverse Cuthill-McKee) and must arrive at the same order;
+    seed 51xx: the same under NLLS_FLAG_PRESHARDED, where each rank sees only its own part of the camera graph (the union is taken collectively).
+    5000 <= seed < 6000: NLLS_FLAG_PRESHARDED -- every rank uploads only its own share (all cameras + its points), the reduced system's layout is agreed on
     collectively, and the library's outer loop must reach the unsharded result."""
     port = str(29500 + world + seed % 50)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port, backend, str(seed)],

@@ -36,3 +36,72 @@ def test_partition_by_weight_is_contiguous_and_balanced():
     assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b) >= 0)
     parts = [w[b[i]:b[i + 1]].sum() for i in range(4)]
     assert max(parts) - min(parts) <= 2 * w.max()
+
+
+def _camera_graph(ncam, npts, prop, seed):
+    """CSR graph of the reduced camera system of the reference's BA generator (test/optimizeba.jl:22-23) with the cameras' labels permuted:
+    two cameras are coupled when one point sees both."""
+    cam, lm = synthetic.ba_visibility(ncam, npts, prop)
+    perm = np.random.default_rng(seed).permutation(ncam) if seed is not None else np.arange(ncam)
+    inv = np.empty(ncam, np.int64); inv[perm] = np.arange(ncam)
+    c2 = inv[cam - 1]; order = np.lexsort((c2, lm)); c2, l2 = c2[order], lm[order]
+    starts = np.r_[0, np.nonzero(np.diff(l2))[0] + 1, len(l2)]
+    pairs = set()
+    for s in {tuple(c2[starts[i]:starts[i + 1]]) for i in range(len(starts) - 1)}:
+        pairs.update((a, b) for a in s for b in s if a != b)
+    pa = np.array(sorted(pairs), dtype=np.int64)
+    ptr = np.zeros(ncam + 1, np.int64); np.add.at(ptr, pa[:, 0] + 1, 1)
+    return np.cumsum(ptr), pa[:, 1].astype(np.int32).copy(), pa
+
+
+def _rcm(ptr, adj):
+    from nllssolver_jl_amd import _capi
+    n = len(ptr) - 1; out = np.zeros(n, np.int32)
+    assert _capi.lib().nlls_rcm_order(n, _capi._p(ptr), _capi._p(adj), _capi._p(out)) == 0
+    assert sorted(out.tolist()) == list(range(n))                         # a permutation
+    return out
+
+
+def test_rcm_order_recovers_the_band_of_relabelled_cameras():
+    """The reference's factorisation orders itself (ldl_analyze, src/linearsystem.jl:52,68); here the ordering of the reduced camera system is
+    reverse Cuthill-McKee (host side, nlls_rcm_order -- the routine nlls_upload_structure applies).  On the reference generator's visibility
+    (test/optimizeba.jl:22-23) with shuffled camera labels it must give back the band of the unshuffled numbering."""
+    for ncam, npts, prop, seed in [(40, 1500, 0.12, 31), (150, 6000, 0.04, 32), (100, 10000, 0.1, 5), (1000, 100000, 0.01, 7)]:
+        ptr0, adj0, pa0 = _camera_graph(ncam, npts, prop, None)
+        bw0 = int(np.abs(pa0[:, 0] - pa0[:, 1]).max())
+        ptr, adj, pa = _camera_graph(ncam, npts, prop, seed)
+        assert int(np.abs(pa[:, 0] - pa[:, 1]).max()) > 4 * bw0            # the shuffled labels have no band
+        out = _rcm(ptr, adj)
+        pos = np.empty(ncam, np.int64); pos[out] = np.arange(ncam)
+        assert int(np.abs(pos[pa[:, 0]] - pos[pa[:, 1]]).max()) <= int(1.25 * bw0)
+
+
+def test_rcm_order_components_grid_and_bad_input():
+    from nllssolver_jl_amd import _capi
+    # two components (a path of 5 and a triangle) + an isolated node: every node is placed, components stay contiguous
+    edges = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6), (6, 7), (5, 7)]
+    n = 9; nb = [[] for _ in range(n)]
+    for a, b in edges:
+        nb[a].append(b); nb[b].append(a)
+    ptr = np.cumsum([0] + [len(x) for x in nb]).astype(np.int64); adj = np.array([y for x in nb for y in x], np.int32)
+    out = _rcm(ptr, adj); pos = np.empty(n, np.int64); pos[out] = np.arange(n)
+    assert max(abs(pos[a] - pos[b]) for a, b in edges) <= 2
+    for comp in ([0, 1, 2, 3, 4], [5, 6, 7]):
+        p = sorted(pos[comp]); assert p[-1] - p[0] == len(comp) - 1
+    # a 2-D grid (k x k, 4-neighbourhood): the bandwidth of any level-set ordering is about k
+    k = 12; idx = lambda i, j: i * k + j; nb = [[] for _ in range(k * k)]
+    for i in range(k):
+        for j in range(k):
+            for di, dj in ((1, 0), (0, 1)):
+                if i + di < k and j + dj < k:
+                    nb[idx(i, j)].append(idx(i + di, j + dj)); nb[idx(i + di, j + dj)].append(idx(i, j))
+    perm = np.random.default_rng(0).permutation(k * k); inv = np.empty(k * k, np.int64); inv[perm] = np.arange(k * k)
+    nb2 = [[] for _ in range(k * k)]
+    for a in range(k * k):
+        nb2[inv[a]] = sorted(int(inv[b]) for b in nb[a])
+    ptr = np.cumsum([0] + [len(x) for x in nb2]).astype(np.int64); adj = np.array([y for x in nb2 for y in x], np.int32)
+    out = _rcm(ptr, adj); pos = np.empty(k * k, np.int64); pos[out] = np.arange(k * k)
+    assert max(abs(pos[a] - pos[b]) for a in range(k * k) for b in nb2[a]) <= k + 2
+    # a self loop / an index out of range is an argument error, not a crash
+    bad = np.array([0], np.int32); out1 = np.zeros(1, np.int32)
+    assert _capi.lib().nlls_rcm_order(1, _capi._p(np.array([0, 1], np.int64)), _capi._p(bad), _capi._p(out1)) == _capi.ERR_INVALID_ARG
