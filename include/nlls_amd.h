@@ -334,6 +334,12 @@ int  nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);
  * launch(es) inside the caller's own loop (last 64 kept); a call with any output pointer set synchronises and reports them. */
 int  nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples);
 int  nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);  /* factorisation + backward pass of the (already assembled) reduced system alone */
+/* measurement helpers.  nlls_get_memory_info: out[0] = bytes of the LM loop's working set (every device buffer an iteration reads or writes -- the
+ * "hot arena"), out[1] = bytes reserved for it in one allocation (0: NLLS_NO_ARENA), out[2] = bytes of A.data, out[3] = bytes of the reduced system [S | s].
+ * nlls_flush_cache: streams `bytes` of foreign data through the memory side on the context's stream (a device-to-device copy between two scratch
+ * halves): whatever the 256 MiB Infinity Cache held of the working set is gone afterwards -- a launch timed behind it is the COLD figure. */
+int  nlls_get_memory_info(nlls_ctx* ctx, int64_t* out, int32_t n);
+int  nlls_flush_cache(nlls_ctx* ctx, int64_t bytes);
 
 /* ---- collectives behind the ABI ("RCCL all-reduce over xGMI on the assembled normal equations") ----------------------
  * Under nlls_set_shard(rank, nranks) the entry points of the Levenberg-Marquardt loop -- nlls_sweep_gradhess, nlls_max_abs_diag,
@@ -353,6 +359,19 @@ typedef int (*nlls_allreduce_fn)(void* user, void* dev_ptr, int64_t count, int32
 int  nlls_set_allreduce(nlls_ctx* ctx, nlls_allreduce_fn fn, void* user);
 int  nlls_comm_unique_id(void* id128);
 int  nlls_comm_init_rccl(nlls_ctx* ctx, const void* id128);
+/* A termination word the ranks agree on WITHOUT a collective of its own (src/optimize.jl:158 compares the wall clock with starttime + maxtime:
+ * under sharding every rank has its own clock, and a rank that leaves the loop alone leaves its peers inside the next trial's collectives).
+ *   nlls_comm_post_flag(v)            : this rank's value (>= 0) rides in its row of the NEXT nlls_lm_trial's scalar gather;
+ *   nlls_comm_agreed_flag(local, out) : *out = the MAXIMUM over ranks of the values posted before the last nlls_lm_trial -- the same number on
+ *                                       every rank; without an installed all-reduce (one process) *out = local, the caller's own value now.
+ * nlls_lm_iterations posts `now > stoptime` at the top of every outer iteration and stops on the agreed value: all ranks leave in the same
+ * iteration, at most one iteration after the first of them crossed the deadline. */
+int  nlls_comm_post_flag(nlls_ctx* ctx, double value);
+int  nlls_comm_agreed_flag(nlls_ctx* ctx, double local_value, double* out);
+/* what the library's own communicator reports (RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice), not what the launcher's
+ * environment says: out[0] = ranks in the communicator, out[1] = this rank, out[2] = its device, out[3] = 1 RCCL inside the library /
+ * 2 a caller-installed all-reduce / 0 none (then out[0] = 1, out[1] = 0).  n >= 4. */
+int  nlls_comm_info(nlls_ctx* ctx, int64_t* out, int32_t n);
 
 #ifdef __cplusplus
 }

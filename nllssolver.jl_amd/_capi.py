@@ -26,7 +26,7 @@ nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_qua
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
 nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_solve_finish_replicated nlls_get_variables_owned nlls_lm_iterations
-nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl""".split()
+nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl nlls_comm_post_flag nlls_comm_agreed_flag nlls_comm_info nlls_get_memory_info nlls_flush_cache""".split()
 
 
 class LmOptions(C.Structure):          # nlls_lm_options
@@ -115,6 +115,8 @@ def lib():
         L.nlls_profile_sweep.argtypes = [vp, i32, vp, vp, vp, vp]
         L.nlls_solve_finish_replicated.argtypes = [vp]; L.nlls_get_variables_owned.argtypes = [vp, i32, vp]
         L.nlls_set_allreduce.argtypes = [vp, vp, vp]; L.nlls_comm_unique_id.argtypes = [vp]; L.nlls_comm_init_rccl.argtypes = [vp, vp]
+        L.nlls_get_memory_info.argtypes = [vp, vp, i32]; L.nlls_flush_cache.argtypes = [vp, i64]
+        L.nlls_comm_post_flag.argtypes = [vp, dbl]; L.nlls_comm_agreed_flag.argtypes = [vp, dbl, vp]; L.nlls_comm_info.argtypes = [vp, vp, i32]
         _lib = L
     return _lib
 
@@ -151,6 +153,10 @@ class Context:
 
     def _chk(self, rc):
         if rc != OK:
+            exc = getattr(self, "_reduce_exc", None)
+            if exc is not None:             # the installed all-reduce raised inside the library's call: that exception is the cause, not "all-reduce failed"
+                self._reduce_exc = None
+                raise NllsError(rc, self.L.nlls_last_error(self.h).decode() + f" ({type(exc).__name__}: {exc})") from exc
             raise NllsError(rc, self.L.nlls_last_error(self.h).decode())
         return rc
 
@@ -283,6 +289,24 @@ class Context:
         """RCCL inside the library: one communicator for this context (after set_shard), collectives on the context's stream."""
         buf = (C.c_ubyte * 128).from_buffer_copy(id128)
         self._chk(self.L.nlls_comm_init_rccl(self.h, buf))
+
+    def memory_info(self):
+        out = np.zeros(4, np.int64); self._chk(self.L.nlls_get_memory_info(self.h, _p(out), 4))
+        return dict(working_set_bytes=int(out[0]), arena_bytes=int(out[1]), a_data_bytes=int(out[2]), reduced_system_bytes=int(out[3]))
+
+    def flush_cache(self, nbytes):
+        self._chk(self.L.nlls_flush_cache(self.h, int(nbytes)))
+
+    def comm_post_flag(self, value):
+        self._chk(self.L.nlls_comm_post_flag(self.h, float(value)))
+
+    def comm_agreed_flag(self, local_value):
+        out = C.c_double(0.0); self._chk(self.L.nlls_comm_agreed_flag(self.h, float(local_value), C.byref(out))); return float(out.value)
+
+    def comm_info(self):
+        """what the library's own communicator reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), not the launcher's environment"""
+        out = np.zeros(4, np.int64); self._chk(self.L.nlls_comm_info(self.h, _p(out), 4))
+        return dict(nranks=int(out[0]), rank=int(out[1]), device=int(out[2]), transport={0: "none", 1: "rccl", 2: "caller-installed all-reduce"}[int(out[3])])
 
     def solve_stats(self):
         out = np.zeros(15, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 15))

@@ -288,7 +288,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     }
     // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
     if (!ctx->info.is_sparse || !ctx->h_scalars_dev) {
-        HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 12, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     } else {
         // spin on the sequence numbers the finishing launch publishes (a few milliseconds at most: then fall back to the synchronisation,
@@ -305,6 +305,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     const int32_t status[1] = {(int32_t)ctx->h_scalars[10]};
+    if (collective) ctx->comm_agreed = ctx->h_scalars[11];      // the ranks' posted termination flags, combined by maximum in the same gather (nlls_comm_agreed_flag)
     ctx->status_known_zero = status[0] == 0;       // (nothing has touched the device's status word since: the next solve need not reset it)
     ctx->solved = true;
     ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9];
@@ -531,6 +532,19 @@ int nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
 }
 int nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
     NEED_GRAD(); return time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_solve(c); });
+}
+int nlls_get_memory_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
+    NEED_READY(); if (!out || n < 4) return NLLS_ERR_INVALID_ARG;
+    out[0] = ctx->hot_bytes; out[1] = (int64_t)ctx->arena.n; out[2] = (int64_t)sizeof(double) * ctx->info.nnz_data; out[3] = (int64_t)sizeof(double) * ((int64_t)ctx->s_elems + ctx->nred);
+    return NLLS_OK;
+}
+int nlls_flush_cache(nlls_ctx* ctx, int64_t bytes) {
+    if (!ctx || bytes <= 0 || bytes > ((int64_t)8 << 30)) return NLLS_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    const size_t half = ((size_t)bytes / 2 + 255) & ~(size_t)255;
+    if (ctx->flushbuf.n < 2 * half) { HIPCHK(ctx->flushbuf.alloc(2 * half)); HIPCHK(hipMemsetAsync(ctx->flushbuf.p, 1, 2 * half, ctx->stream)); }
+    HIPCHK(hipMemcpyAsync(ctx->flushbuf.p + half, ctx->flushbuf.p, half, hipMemcpyDeviceToDevice, ctx->stream));
+    return NLLS_OK;
 }
 int nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples) {
     if (!ctx) return NLLS_ERR_INVALID_ARG;

@@ -20,6 +20,7 @@ struct Rccl {
     void* lib = nullptr;
     decltype(&ncclGetUniqueId) get_unique_id = nullptr; decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr; decltype(&ncclCommDestroy) comm_destroy = nullptr; decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr; decltype(&ncclCommUserRank) comm_user_rank = nullptr; decltype(&ncclCommCuDevice) comm_cu_device = nullptr;
     std::string err;
     bool load() {
         if (lib) return true;
@@ -30,6 +31,9 @@ struct Rccl {
         all_reduce = reinterpret_cast<decltype(all_reduce)>(dlsym(lib, "ncclAllReduce"));
         comm_destroy = reinterpret_cast<decltype(comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
         error_string = reinterpret_cast<decltype(error_string)>(dlsym(lib, "ncclGetErrorString"));
+        comm_count = reinterpret_cast<decltype(comm_count)>(dlsym(lib, "ncclCommCount"));
+        comm_user_rank = reinterpret_cast<decltype(comm_user_rank)>(dlsym(lib, "ncclCommUserRank"));
+        comm_cu_device = reinterpret_cast<decltype(comm_cu_device)>(dlsym(lib, "ncclCommCuDevice"));
         if (!get_unique_id || !comm_init_rank || !all_reduce || !comm_destroy || !error_string) { err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy"; lib = nullptr; return false; }
         return true;
     }
@@ -47,21 +51,22 @@ int rccl_allreduce(void* user, void* dev_ptr, int64_t count, int32_t op, void* h
 }
 
 // row `rank` of the gather buffer <- this rank's trial scalars, zeros everywhere else
-__global__ void gather_pack_kernel(const double* __restrict__ scalars, double* __restrict__ g, int rank, int nranks) {
-    for (int i = threadIdx.x; i < 16 * nranks; i += blockDim.x) g[i] = (i >> 4) == rank && (i & 15) < 11 ? scalars[i & 15] : 0.0;
+// (slot 11: the rank's posted termination flag, nlls_comm_post_flag -- non-negative, combined by maximum)
+__global__ void gather_pack_kernel(const double* __restrict__ scalars, double* __restrict__ g, int rank, int nranks, double posted) {
+    for (int i = threadIdx.x; i < 16 * nranks; i += blockDim.x) g[i] = (i >> 4) == rank ? ((i & 15) < 11 ? scalars[i & 15] : ((i & 15) == 11 ? posted : 0.0)) : 0.0;
 }
 // rows -> the reduced scalars, in the slots the single-GPU trial fills: [0] cost, [1] max|x|, [2] |x|^2, [5] g'x, [8] x'Ax, [9] x'x, [10] status
 // (sharded ranks report max|x| and |x|^2 over their OWN share of the step in [1] and [9]: nlls_trial_local)
 __global__ void gather_combine_kernel(const double* __restrict__ g, int nranks, double* __restrict__ out, double* __restrict__ host_out, double seq) {
     if (threadIdx.x != 0) return;
-    double cost = 0, mx = 0, gx = 0, xax = 0, xx = 0, st = 0;
-    for (int r = 0; r < nranks; ++r) { const double* q = g + 16 * r;
+    double cost = 0, mx = 0, gx = 0, xax = 0, xx = 0, st = 0, fl = 0;
+    for (int r = 0; r < nranks; ++r) { const double* q = g + 16 * r; fl = q[11] > fl ? q[11] : fl;
         cost += q[0]; gx += q[5]; xax += q[8]; xx += nranks > 1 ? q[9] : q[2];
         mx = (q[1] > mx || q[1] != q[1]) ? q[1] : mx;          // (a NaN step must reach the host: src/optimize.jl:150-151)
         st = q[10] > st ? q[10] : st; }
-    out[0] = cost; out[1] = mx; out[2] = xx; out[5] = gx; out[8] = xax; out[9] = xx; out[10] = st;
+    out[0] = cost; out[1] = mx; out[2] = xx; out[5] = gx; out[8] = xax; out[9] = xx; out[10] = st; out[11] = fl;
     if (host_out) {
-        host_out[0] = cost; host_out[1] = mx; host_out[2] = xx; host_out[5] = gx; host_out[8] = xax; host_out[9] = xx; host_out[10] = st;
+        host_out[11] = fl; host_out[0] = cost; host_out[1] = mx; host_out[2] = xx; host_out[5] = gx; host_out[8] = xax; host_out[9] = xx; host_out[10] = st;
         __threadfence_system();
         reinterpret_cast<volatile double*>(host_out)[32] = seq; reinterpret_cast<volatile double*>(host_out)[33] = seq;
     }
@@ -77,7 +82,7 @@ int comm_reduce(nlls_ctx* c, double* dev_ptr, int64_t count, int op) {
 int comm_gather_trial_scalars(nlls_ctx* c, double seq) {
     const int nr = c->nranks;
     if (c->gatherbuf.n < (size_t)16 * nr && c->gatherbuf.alloc((size_t)16 * nr) != hipSuccess) return fail(c, NLLS_ERR_HIP, "gather buffer alloc");
-    hipLaunchKernelGGL(gather_pack_kernel, dim3(1), dim3(64), 0, c->stream, c->scalars.p, c->gatherbuf.p, c->rank, nr);
+    hipLaunchKernelGGL(gather_pack_kernel, dim3(1), dim3(64), 0, c->stream, c->scalars.p, c->gatherbuf.p, c->rank, nr, c->comm_posted);
     const int rc = comm_reduce(c, c->gatherbuf.p, (int64_t)16 * nr, NLLS_REDUCE_SUM); if (rc != NLLS_OK) return rc;
     hipLaunchKernelGGL(gather_combine_kernel, dim3(1), dim3(64), 0, c->stream, c->gatherbuf.p, nr, c->scalars.p, c->h_scalars_dev, seq);
     return hipGetLastError() == hipSuccess ? NLLS_OK : fail(c, NLLS_ERR_HIP, "gather launch");
@@ -112,6 +117,28 @@ int nlls_comm_init_rccl(nlls_ctx* ctx, const void* id128) {
     const ncclResult_t r = rccl().comm_init_rank(&comm, ctx->nranks, id, ctx->rank);
     if (r != ncclSuccess) return fail(ctx, NLLS_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().error_string(r));
     ctx->rccl_comm = comm; ctx->reduce_fn = rccl_allreduce; ctx->reduce_user = ctx;
+    return NLLS_OK;
+}
+int nlls_comm_post_flag(nlls_ctx* ctx, double value) {
+    if (!ctx || !(value >= 0.0)) return NLLS_ERR_INVALID_ARG;
+    ctx->comm_posted = value;
+    return NLLS_OK;
+}
+int nlls_comm_agreed_flag(nlls_ctx* ctx, double local_value, double* out) {
+    if (!ctx || !out) return NLLS_ERR_INVALID_ARG;
+    *out = ctx->reduce_fn ? ctx->comm_agreed : local_value;
+    return NLLS_OK;
+}
+int nlls_comm_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
+    if (!ctx || !out || n < 4) return NLLS_ERR_INVALID_ARG;
+    out[0] = 1; out[1] = 0; out[2] = ctx->device; out[3] = 0;
+    if (ctx->rccl_comm && rccl().lib && rccl().comm_count && rccl().comm_user_rank) {
+        int cnt = 0, rk = 0, dev = ctx->device; ncclComm_t comm = static_cast<ncclComm_t>(ctx->rccl_comm);
+        ncclResult_t r = rccl().comm_count(comm, &cnt); if (r == ncclSuccess) r = rccl().comm_user_rank(comm, &rk);
+        if (r == ncclSuccess && rccl().comm_cu_device) r = rccl().comm_cu_device(comm, &dev);
+        if (r != ncclSuccess) return fail(ctx, NLLS_ERR_HIP, std::string("ncclCommCount / ncclCommUserRank: ") + rccl().error_string(r));
+        out[0] = cnt; out[1] = rk; out[2] = dev; out[3] = 1;
+    } else if (ctx->reduce_fn) { out[0] = ctx->nranks; out[1] = ctx->rank; out[3] = 2; }
     return NLLS_OK;
 }
 }

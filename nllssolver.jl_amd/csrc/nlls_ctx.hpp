@@ -143,6 +143,7 @@ struct nlls_ctx {
     // collectives behind the ABI (nlls_comm.cpp): the installed all-reduce, and the library's own RCCL communicator when it is that
     nlls_allreduce_fn reduce_fn = nullptr; void* reduce_user = nullptr; void* rccl_comm = nullptr;
     nlls::DevBuf<double> gatherbuf;          // [nranks][16]: the ranks' trial scalars, gathered by a sum over rows that are zero elsewhere
+    double comm_posted = 0.0, comm_agreed = 0.0;   // nlls_comm_post_flag / nlls_comm_agreed_flag: slot 11 of the gather rows, combined by maximum
 
     // ---- structure ------------------------------------------------------------------------------
     bool ready = false;
@@ -258,5 +259,7 @@ struct nlls_ctx {
     // the luck of their physical placement -- the accumulate launch inside the LM loop took 41 .. 49 us from process to process; side by
     // side in one window (and the arrays the loop never reads kept out of it) it takes 41 in every process.
     nlls::DevBuf<char> arena, arena_pre;
+    int64_t hot_bytes = 0;                   // bytes of the hot set (what an LM iteration reads or writes): nlls_get_memory_info
+    nlls::DevBuf<char> flushbuf;             // nlls_flush_cache: foreign traffic for cold-cache timings
     bool solved = false;
 };

@@ -68,7 +68,11 @@ int iterate_levmar(nlls_ctx* ctx, const nlls_lm_options* opt, nlls_lm_state* st,
 
 extern "C" int nlls_lm_iterations(nlls_ctx* ctx, const nlls_lm_options* opt, nlls_lm_state* st, int64_t niter) {
     if (!ctx || !opt || !st) return NLLS_ERR_INVALID_ARG;
+    const bool timed = opt->stoptime_ns > 0;
     for (int64_t it = 0; it < niter; ++it) {
+        // the deadline under sharding: every rank has its own clock -- each posts what ITS clock says now, the flags ride in the scalar gather of this
+        // iteration's trials, and all ranks stop on the agreed maximum (one process: the clock is read after the iteration, as src/optimize.jl:158 does)
+        if (timed) { const int rcp = nlls_comm_post_flag(ctx, monotonic_ns() > opt->stoptime_ns ? 1.0 : 0.0); if (rcp != NLLS_OK) return rcp; }
         st->iternum++;                                                                    // src/optimize.jl:124
         double cost = 0.0;
         int rc = iterate_levmar(ctx, opt, st, &cost);                                     // :126
@@ -95,7 +99,8 @@ extern "C" int nlls_lm_iterations(nlls_ctx* ctx, const nlls_lm_options* opt, nll
         conv |= (int64_t)(maxstep < opt->dstep) << 6;
         conv |= (int64_t)(st->fails > opt->maxfails) << 7;
         conv |= (int64_t)(st->iternum >= opt->maxiters) << 8;
-        conv |= (int64_t)(opt->stoptime_ns > 0 && monotonic_ns() > opt->stoptime_ns) << 9;
+        if (timed) { double late = 0.0; if ((rc = nlls_comm_agreed_flag(ctx, monotonic_ns() > opt->stoptime_ns ? 1.0 : 0.0, &late)) != NLLS_OK) return rc;
+            conv |= (int64_t)(late > 0.0) << 9; }
         st->converged = conv; st->cost = cost;
         if (conv != 0) break;
         { Timer t(st->timegradient_ns);

@@ -67,16 +67,18 @@ void hot_set(nlls_ctx* c, std::vector<HotItem>& v) {
 }  // namespace
 // move the hot set into one allocation (called at the end of a successful upload; NLLS_NO_ARENA=1: leave every buffer where hipMalloc put it)
 static int compact_hot_set(nlls_ctx* c) {
-    if (getenv("NLLS_NO_ARENA")) return NLLS_OK;
+    if (getenv("NLLS_NO_ARENA")) { std::vector<HotItem> v; hot_set(c, v); size_t t = 0; for (const HotItem& it : v) t += it.bytes; c->hot_bytes = (int64_t)t; return NLLS_OK; }
     std::vector<HotItem> v; hot_set(c, v);
     size_t total = 0; for (const HotItem& it : v) if (*it.owned) total += (it.bytes + 255) & ~(size_t)255;
+    c->hot_bytes = (int64_t)total;
     if (total == 0) return NLLS_OK;
     // the arena was reserved BEFORE the first buffer of this upload (build_structure): physical placement is best while the device memory
     // is untouched -- allocated here, behind hundreds of megabytes of allocations, the same window came out at 40 .. 46 us from process
     // to process, reserved first at 40 .. 41.7 (tools/sweep_ab.py).  An estimate that fell short falls back to allocating now.
     DevBuf<char> fresh;
     if (c->arena_pre.p && c->arena_pre.n >= total) fresh = std::move(c->arena_pre);
-    else { c->arena_pre.release(); HIPCHK(fresh.alloc(total)); }
+    else { c->arena_pre.release();
+        if (fresh.alloc(total) != hipSuccess) { (void)hipGetLastError(); return NLLS_OK; } }   // no room for a second copy of the working set: the buffers stay where hipMalloc put them (placement is an optimisation, not a requirement)
     size_t off = 0;
     for (HotItem& it : v) { if (!*it.owned) continue;
         HIPCHK(hipMemcpyAsync(fresh.p + off, *it.pp, it.bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -93,6 +95,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
     c->ready = false; c->solved = false; c->have_grad = false; c->lambda = 0; c->reduced_summed = true; c->n_stage0 = 0; c->n_lazy_trials = 0;
     { std::vector<HotItem> v; hot_set(c, v); for (HotItem& it : v) if (!*it.owned) { *it.pp = nullptr; *it.owned = true; } }   // what lived in the previous upload's arena is gone with it
+    c->arena.release(); c->arena_pre.release();     // ... so release it NOW: a re-upload would otherwise hold two arenas (and every buffer once more) at its peak
     c->groups.clear();
     // ---- variables ------------------------------------------------------------------------------
     c->var_kind.assign(var_kind, var_kind + nvar); c->var_dim.assign(var_dim, var_dim + nvar);
@@ -760,11 +763,24 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         // every rank has built the reduced system from ITS cost blocks only: the layout of [S | s] -- summed element by element over ranks --
         // must be one layout.  The bandwidth is the maximum over ranks; the reduced order itself (banded part, border, size) has to agree.
         if (!c->reduce_fn) return fail(c, NLLS_ERR_INVALID_ARG, "NLLS_FLAG_PRESHARDED: install the all-reduce (nlls_comm_init_rccl / nlls_set_allreduce) before nlls_upload_structure -- the reduced system's layout is agreed on collectively");
-        double h[8] = {(double)bw, (double)c->nbd, (double)c->n_band, (double)c->nred, -(double)c->nbd, -(double)c->n_band, -(double)c->nred, 0.0};
-        HIPCHK(hipMemcpyAsync(c->scalars.p + 16, h, sizeof h, hipMemcpyHostToDevice, c->stream));
-        { const int rc = comm_reduce(c, c->scalars.p + 16, 8, NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
-        HIPCHK(hipMemcpyAsync(h, c->scalars.p + 16, sizeof h, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+        // ... and so must everything that is summed element by element: the stage-0 buffer ([cost | reduced rows of A.data | reduced part of b]: its length
+        // and the lengths of its segments -- they differ when a rank's reduced rows hold E blocks another rank's do not, i.e. when an eliminated block
+        // precedes a reduced one in block order) and the list of reduced-reduced blocks.  +x / -x pairs under MAX: equal on all ranks or refused.
+        double seghash = 0.0;      // order-sensitive checksum of the reduced rows' segment lengths and of the reduced order itself (exact in a double)
+        { uint64_t hsh = 1469598103934665603ull; auto mix = [&](uint64_t v) { hsh ^= v; hsh *= 1099511628211ull; };
+          for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) { mix((uint64_t)red_of[k]); mix((uint64_t)c->blocksizes[k]);
+              int64_t len = 0; if (I0.is_sparse) for (int64_t q = c->it_colptr[k]; q < c->it_colptr[k + 1]; ++q) len += (int64_t)c->blocksizes[k] * c->blocksizes[c->it_rowval[q]];
+              mix((uint64_t)len); }
+          seghash = (double)(hsh >> 12); }
+        double h[16] = {(double)bw, (double)c->nbd, (double)c->n_band, (double)c->nred, -(double)c->nbd, -(double)c->n_band, -(double)c->nred, 0.0,
+                        (double)c->redbuf_len, -(double)c->redbuf_len, (double)c->ncopy, -(double)c->ncopy, seghash, -seghash, 0.0, 0.0};
+        DevBuf<double> dh; HIPCHK(dh.alloc(16));
+        HIPCHK(hipMemcpyAsync(dh.p, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+        { const int rc = comm_reduce(c, dh.p, 16, NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
+        HIPCHK(hipMemcpyAsync(h, dh.p, sizeof h, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
         if (h[1] != -h[4] || h[2] != -h[5] || h[3] != -h[6]) return fail(c, NLLS_ERR_INVALID_ARG, "NLLS_FLAG_PRESHARDED: the ranks' reduced systems differ in size or border (the reduced variables must be the same on every rank)");
+        if (h[8] != -h[9] || h[10] != -h[11] || h[12] != -h[13]) return fail(c, NLLS_ERR_INVALID_ARG, "NLLS_FLAG_PRESHARDED: the ranks' reduced rows differ in layout (stage-0 buffer length, reduced-reduced block list or segment lengths): "
+                                                                                      "every rank must hold the same reduced variables in the same order, each coupled to the same stored blocks -- list the reduced variables before the eliminated ones");
         bw = (int64_t)h[0];
     }
     { std::vector<SchurCopy> blks;

@@ -220,6 +220,10 @@ class ShardedLS(MultiVariateLSgpu):
         if self._allreduce_scalars([1.0 if err else 0.0], "max")[0] != 0:
             raise err if err else _capi.NllsError(_capi.ERR_NOT_SPD, "factorisation met a zero pivot on another rank")
 
+    def agree_max(self, value):
+        """the maximum over ranks of a rank-local scalar (the Python outer loop's deadline flag: src/optimize.jl:158 under sharding)"""
+        return self._allreduce_scalars([float(value)], "max")[0] if self.world > 1 else float(value)
+
     def initlambda(self):
         m = self.ctx.max_abs_diag()
         if self.sharded and not self.native_collectives:

@@ -195,7 +195,10 @@ class OuterLoop:
         converged |= int(maxstep < options.dstep) << 6
         converged |= int(self.fails > options.maxfails) << 7
         converged |= int(data.iternum >= options.maxiters) << 8
-        converged |= int(time.perf_counter_ns() > self.stoptime) << 9
+        late = time.perf_counter_ns() > self.stoptime
+        if getattr(ls, "sharded", False) and hasattr(ls, "agree_max"):
+            late = ls.agree_max(float(late)) > 0          # every rank has its own clock: all leave in the same iteration (one all-reduce of a flag)
+        converged |= int(late) << 9
         converged |= int(terminate) << 16
         data.converged = converged
         self.cost = cost

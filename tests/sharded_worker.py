@@ -34,6 +34,8 @@ def main():
         return singular_point_block(rank, world, dist, staged)
     if 5000 <= seed < 6000:
         return presharded(rank, world, dist, staged, seed)
+    if 7000 <= seed < 8000:
+        return deadline(rank, world, dist, staged)
     shuffled = seed >= 6000                      # the cameras' labels permuted: the reduced system is re-ordered at upload (every rank must arrive at the same order)
     rng = np.random.default_rng(seed)
     ncr = int(rng.integers(12, 90))             # (sharding partitions by eliminated block: stay within what the Schur kernels take)
@@ -147,6 +149,20 @@ def presharded(rank, world, dist, staged, seed):
         p = synthetic.shuffle_camera_labels(p, ncam, seed)
     p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
     mine = synthetic.shard_of_problem(p, ncam, rank, world)
+    if seed % 1000 >= 200:
+        # the share with its POINTS listed before the cameras: the cameras' rows of A.data then hold the E blocks, as many as this rank has observations --
+        # the ranks' stage-0 buffers would differ in length and be summed element by element.  The upload must refuse it, on every rank alike.
+        g = next(iter(mine.costs.values())); vi, da = g.arrays(); nl = mine.nvariables - ncam
+        q = N.NLLSProblem(); q.addvariables(mine.variables[6 * ncam:].reshape(nl, 3)); q.addvariables(mine.variables[: 6 * ncam].reshape(ncam, 6))
+        q.addcosts(g.res_kind, np.stack([vi[:, 0] + nl, vi[:, 1] - ncam], axis=1), da, g.robust)
+        try:
+            ShardedLS(q, np.ones(q.nvariables, bool), rank=rank, world=world, dist=dist, host_staged=staged, presharded=True)
+            raise AssertionError("a pre-sharded upload whose reduced rows differ between ranks was accepted")
+        except _capi.NllsError as e:
+            assert e.code == _capi.ERR_INVALID_ARG and "reduced rows differ" in str(e), str(e)
+        dist.barrier(); dist.destroy_process_group()
+        print(f"rank {rank}: sharded == unsharded (mismatched pre-sharded layout refused on every rank)")
+        return
     counts = [None] * world
     dist.all_gather_object(counts, mine.ncosts()); assert sum(counts) == p.ncosts(), (counts, p.ncosts())
     def run(ls, prob, native):
@@ -175,6 +191,34 @@ def presharded(rank, world, dist, staged, seed):
         assert np.array_equal(next(iter(g.costs.values())).arrays()[0], next(iter(mine.costs.values())).arrays()[0])
     ref.close(); sh.close(); dist.barrier(); dist.destroy_process_group()
     print(f"rank {rank}: sharded == unsharded (presharded: {mine.ncosts()} of {p.ncosts()} cost blocks uploaded, best cost {ds.bestcost:.6e})")
+
+
+def deadline(rank, world, dist, staged):
+    """src/optimize.jl:158 under sharding: `time > starttime + maxtime` is rank-local (every process has its own clock and its own start time).  Rank 0 is
+    given a deadline it crosses after a few iterations, the other ranks one they never reach: all ranks must leave the loop in the SAME iteration with
+    the time-out bit set -- a rank that left alone would leave its peers inside the next trial's collectives (a hang).  Both loops: the library's
+    (nlls_lm_iterations: the flags ride in the trial's scalar gather) and the Python one (one all-reduce of the flag)."""
+    import nllssolver_jl_amd as N
+    from nllssolver_jl_amd import synthetic, _capi, iterators as It, optimizer as Opt
+    from nllssolver_jl_amd.dist import ShardedLS
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(40, 2000, 0.15, seed=21, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    for native in (True, False):
+        sh = ShardedLS(p, np.ones(p.nvariables, bool), rank=rank, world=world, dist=dist, host_staged=staged, force_collectives=True)
+        opts = N.NLLSOptions(maxiters=10 ** 6, reldcost=-np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=0.15 if rank == 0 else 1e6)
+        dist.barrier()
+        data = Opt.NLLSInternal(sh, time.perf_counter_ns())
+        loop = Opt.OuterLoop(p, opts, data, It.LevMarData(), It.iterate_levmar, N.nullcallback, native=native)
+        loop.start()
+        assert loop.native == native
+        conv = 0
+        while conv == 0:
+            conv = loop.iterations(1 << 30) if native else loop.iteration()
+        seen = [None] * world; dist.all_gather_object(seen, (int(data.iternum), int(conv)))
+        assert all(v == seen[0] for v in seen), seen              # the same iteration, the same flags, on every rank
+        assert conv == 1 << 9 and data.iternum >= 2, (conv, data.iternum)
+        sh.close()
+    dist.barrier(); dist.destroy_process_group()
+    print(f"rank {rank}: sharded == unsharded (deadline agreed: all ranks left in iteration {seen[0][0]})")
 
 
 def singular_point_block(rank, world, dist, staged):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.parametrize("world,backend,seed", [(2, "gloo", 21), (3, "gloo", 21), (1, "nccl", 21), (2, "gloo", 401), (3, "gloo", 402), (2, "gloo", 403),
                                                 (2, "gloo", -1), (3, "gloo", -1),
                                                 (2, "gloo", 3000), (3, "gloo", 3000), (2, "gloo", 5001), (3, "gloo", 5002),
-                                                (2, "gloo", 6001), (3, "gloo", 5102)])
+                                                (2, "gloo", 6001), (3, "gloo", 5102), (2, "gloo", 7001), (3, "gloo", 7001), (2, "gloo", 5201)])
 def test_sharded_matches_unsharded(world, backend, seed):
     """(1, "nccl"): the local / reduce / finish route over RCCL with device buffers, one rank -- the plumbing bench.py --gpus N uses.
     seed 3000: BASELINE config 3 at full size (100 cameras x 10k points, ~100k residual blocks) against the CPU oracle: cost, gradient,
@@ -22,6 +22,8 @@ def test_sharded_matches_unsharded(world, backend, seed):
     seed -1: a zero pivot only one rank sees must be raised on every rank (no rank left behind in a collective).
     seed >= 6000: the cameras' labels permuted -- every rank re-orders the reduced system at upload (reverse Cuthill-McKee) and must arrive at the same order;
     seed 51xx: the same under NLLS_FLAG_PRESHARDED, where each rank sees only its own part of the camera graph (the union is taken collectively).
+    seed 52xx: a pre-sharded upload whose reduced rows differ in layout between ranks (points listed before the cameras) is refused on every rank.
+    seed 7001: a deadline (maxtime) only rank 0 crosses -- all ranks leave the loop in the same iteration (no rank left in a collective).
     5000 <= seed < 6000: NLLS_FLAG_PRESHARDED -- every rank uploads only its own share (all cameras + its points), the reduced system's layout is agreed on
     collectively, and the library's outer loop must reach the unsharded result."""
     port = str(29500 + world + seed % 50)
@@ -52,10 +54,26 @@ def test_bench_launches_its_own_ranks():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--workload", "ba_100x10k", "--steps", "4", "--warmup", "1",
-                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+                        "--repeats", "3", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines                      # stdout carries exactly one line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["config"]["sharding"] == "by point over 2 ranks"
     assert out["lm"]["final_cost"] < out["lm"]["start_cost"] and out["value"] > 0
+    assert out["rccl"]["nranks"] == 2 and out["rccl"]["rank"] == 0 and out["spread"]["runs"] >= 3 and len(out["spread"]["trials_per_run"]) == out["spread"]["runs"]
+
+
+def test_bench_fails_fast_when_a_rank_dies():
+    """A rank that dies in the middle of the timed loop leaves its peers inside a collective.  bench.py's own launcher watches ALL its children: it must
+    terminate the survivors and exit non-zero within seconds, not sit until the driver's limit (rank 1 exits with code 17 half way through the runs)."""
+    env = dict(os.environ, NLLS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--workload", "ba_100x10k", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline", "--die-rank", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=200)
+    took = time.monotonic() - t0
+    assert r.returncode != 0 and "ranks failed (rank, exit code): [(1, 17)]" in r.stderr, (r.returncode, r.stderr[-2000:])
+    assert not r.stdout.strip()                        # no result line from a failed run
+    assert took < 90, took                             # (start-up of two torch processes included; the wait for the dead rank's peers is what must be short)
