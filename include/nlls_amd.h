@@ -232,7 +232,8 @@ int  nlls_solve(nlls_ctx* ctx, double* x_out);
  * (NLLS_FLAG_NO_BCR, NLLS_FLAG_NO_BAND) have no such floor.  Collective route (see "collectives"): [11] sums over ranks of the reduced rows
  * of A.data / b since the upload, [12] LM trials since the upload that ran on rows NOT summed (nlls_sweep_gradhess(ctx, NULL) leaves them as the
  * rank's share: everything a trial takes from them is linear in them).  [13] 1: the reduced blocks are in reverse Cuthill-McKee order (0: the caller's),
- * [14] half bandwidth (dof) the caller's order would have given (-1: not computed). */
+ * [14] half bandwidth (dof) the caller's order would have given (-1: not computed), [15] 1: the dense LDL' (solve_mode 1) is restricted to the band of the
+ * re-ordered reduced system and the border strip ("windowed": O(n w^2) work in dense storage, for bands too wide for the band kernels). */
 int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
 int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
 int  nlls_get_step(nlls_ctx* ctx, double* x_out);

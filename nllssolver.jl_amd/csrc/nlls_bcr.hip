@@ -400,7 +400,7 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
 // Replaces one ldlt_diag_kernel (64 dependent pivots with two barriers each: 73 us) + trsm_panel_kernel (one thread per row,
 // uncoalesced: 55 us) launch pair of round 1.
 // ---------------------------------------------------------------------------------------------------
-struct DensePanelArgs { double* S; double* W; double* LiD; int npad, k, T; int* status; double* Dfac; };   // Dfac: scratch for the factored diagonal block (16 NT square, column-major)
+struct DensePanelArgs { double* S; double* W; double* LiD; int npad, k, T; int* status; double* Dfac; int wq, wstrip; };   // wq >= 0: windowed -- logical X tile row q (T of them) is tile row  q < wq ? NT (k + 1) + q : wstrip + (q - wq)   // Dfac: scratch for the factored diagonal block (16 NT square, column-major)
 // NT tiles = 16 NT columns per panel (4: 64 columns; 8: 128 columns, the width of one pass of the trailing update -- then no narrow update and
 // no second panel launch stand between two passes); DCH X tile rows per workgroup (LDS: 8 tiles of width need 2 rows to stay within 160 KB)
 template <int NT, int DCH>
@@ -410,8 +410,12 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int hw = wave < 4 ? wave - 1 : wave - 2; const bool helper = wave != 0 && wave != 4;
     const int ch = blockIdx.x, npad = a.npad, c0 = 16 * NT * a.k;             // first column of the panel (a.k counts panels of this width)
-    const int R0 = NT * (a.k + 1) + DCH * ch;                                   // first X tile row of this workgroup
-    const int RX = R0 >= a.T ? 0 : (a.T - R0 < DCH ? a.T - R0 : DCH);
+    // X tile rows of this workgroup: logical rows Q0 .. Q0 + RX - 1 below the diagonal block; unwindowed they are the tile rows NT (k + 1) + Q0 .. of S
+    // (a.T then counts ALL tile rows of S), windowed the band's rows followed by the bottom strip (a.T counts the step's logical rows)
+    const bool windowed = a.wq >= 0;
+    const int Q0 = DCH * ch, Tq = windowed ? a.T : a.T - NT * (a.k + 1);
+    const int RX = Q0 >= Tq ? 0 : (Tq - Q0 < DCH ? Tq - Q0 : DCH);
+    auto trow = [&](int R) { const int q = Q0 + R; return (!windowed || q < a.wq) ? NT * (a.k + 1) + q : a.wstrip + (q - a.wq); };   // actual tile row of X row R
     const bool lead = ch == 0;
     if (RX == 0 && !lead) return;
     double* Dt = sm; double* Xt = Dt + ND * BTS; double* Wp = Xt + DCH * NT * BTS; double* dvec = Wp + 2 * PR * 16 * BP; double* Li = dvec + 64;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
 #pragma unroll
         for (int q = 0; q < XQ; ++q) { const int w = tid + q * BCR_T; xv[q] = 0.0;
             if (w < RX * NT * 256) { const int t = w >> 8, b2 = (w >> 4) & 15, a2 = w & 15, R = t / NT, K = t - R * NT;
-                xv[q] = a.S[(size_t)(16 * (R0 + R) + a2) + (size_t)npad * (c0 + 16 * K + b2)]; } }
+                xv[q] = a.S[(size_t)(16 * trow(R) + a2) + (size_t)npad * (c0 + 16 * K + b2)]; } }
 #pragma unroll
         for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; if (w < ND * 256) Dt[(w >> 8) * BTS + (w & 15) * BP + ((w >> 4) & 15)] = dv[q]; }
 #pragma unroll
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int e2 = lane + 64 * r, a2 = e2 & 15, b2 = e2 >> 4;
                     a.Dfac[(size_t)(16 * I + a2) + (size_t)(16 * NT) * (16 * Jp + b2)] = Wt[a2 * BP + b2] * rd[b2]; } }
-            else { const int R = e - nDe; store_tile(Wprev + (NT + R) * 16 * BP, rd, 16 * (R0 + R), c0 + 16 * Jp, true); }
+            else { const int R = e - nDe; store_tile(Wprev + (NT + R) * 16 * BP, rd, 16 * trow(R), c0 + 16 * Jp, true); }
         }
     };
     bdouble4_t diag = {0, 0, 0, 0};
@@ -523,9 +527,18 @@ void launch_dense_dcopy_all(hipStream_t st, double* S, const double* Dfac, int n
 template <int NT, int DCH> constexpr size_t dense_panel_lds() { return sizeof(double) * ((size_t)(NT * (NT + 1) / 2 + DCH * NT) * BTS + 2 * (size_t)(NT + DCH) * 16 * BP + 64 + 2 * 16 * BP + BTS); }
 static_assert(dense_panel_lds<8, 2>() <= 160 * 1024, "the 128-column panel must fit the LDS of a CU");
 // k: index of the panel in units of ITS width (64 or 128 columns)
-void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac) {
+void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac, DenseWin win) {
     const int T = npad / 16;
-    DensePanelArgs a{S, W, LiD, npad, k, T, status, Dfac + (size_t)(wide ? 2 * k : k) * 128 * 128};   // the panel's slot
+    DensePanelArgs a{S, W, LiD, npad, k, T, status, Dfac + (size_t)(wide ? 2 * k : k) * 128 * 128, -1, 0};   // the panel's slot
+    if (win.nwin >= 0 && wide) {
+        // windowed: the step's logical tile rows = 8 per 128-row block of the window and of the strip; one X tile row per workgroup (few rows: the pivot chain sets the pace)
+        a.T = 8 * win.ntot; a.wq = 8 * win.nwin; a.wstrip = 8 * win.strip;
+        static bool attrw = false;
+        if (!attrw) { constexpr int ldsw = (int)dense_panel_lds<8, 1>(); (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw); attrw = true; }
+        constexpr size_t ldsq = dense_panel_lds<8, 1>();
+        hipLaunchKernelGGL((dense_panel_kernel<8, 1>), dim3((unsigned)std::max(a.T, 1)), dim3(BCR_T), ldsq, st, a);
+        return;
+    }
     static const int one_row_max = [] { const char* e = getenv("NLLS_DENSE_DCH1"); return e ? atoi(e) : 256; }();   // (one round of a 256-CU chip; NLLS_DENSE_DCH1=0: two rows per workgroup everywhere, for A/B runs: 4.28 instead of 4.19 ms at 6000 dof)
     if (wide && T - 8 * (k + 1) <= one_row_max && T - 8 * (k + 1) > 0) {
         // one X tile row per workgroup while that still fits one round of the chip: less helper work beside the pivot chain

@@ -47,7 +47,11 @@ struct BcrSolver {
 };
 
 // dense reduced system (nlls_solve.hip): panel factorisation of block column k (64 columns) and the backward pass's diagonal block
-void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac);
+// Row window of a step of the WINDOWED dense factorisation (a reduced system that an ordering has turned into a wide band, stored densely): below a
+// 128-column panel p only the 128-row blocks p + 1 .. p + nwin (the band) and strip .. (the border + right-hand side rows at the bottom) hold anything.
+// Logical row block q of the step -> actual 128-row block  q < nwin ? p + 1 + q : strip + (q - nwin);  ntot = blocks of the step.  nwin < 0: no window.
+struct DenseWin { int nwin = -1, strip = 0, ntot = 0; };
+void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac, DenseWin win = DenseWin{});
 void launch_dense_dcopy_all(hipStream_t st, double* S, const double* Dfac, int npad, int nwide, int first64, int n64);   // the factored diagonal blocks: slots of Dfac -> S   // wide: a 128-column panel (k counts panels of the width used)
 void launch_dense_bwd_diag(hipStream_t st, const double* S, const double* LiD, int npad, int kb, int n, const double* acc, double* x);
 void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, double* Dinv, int npad, int n, double* x, int* status);   // the whole backward substitution in one launch (+ the diagonal blocks' inverses)

@@ -43,14 +43,33 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from);   // post-solve statis
 #if defined(__HIPCC__)
 // to[var i] = update(from[var i], x[its block])   (src/linearsystem.jl:206-213); fixed variables are copied
 // dx: the variable's own step (its block of x)
+// DX(q) = component q of the variable's own step.  No staging arrays with run-time indices (they would live in scratch memory -- 1040 bytes per lane
+// of every kernel this is inlined into): Euclidean / dynamic vectors add in place, the other kinds have compile-time sizes.
+template <class DXF>
+__device__ __forceinline__ void retract_var_fn(int k, int d, uint32_t o, const double* __restrict__ from, double* __restrict__ to, DXF DX) {
+    switch (k) {
+    case NLLS_VAR_EUCLIDEAN: case NLLS_VAR_DYNAMIC: for (int q = 0; q < d; ++q) to[o + q] = from[o + q] + DX(q); return;   // v + delta (src/variable.jl:5): any length
+    case NLLS_VAR_ZERO_TO_INF: case NLLS_VAR_ZERO_TO_ONE: { const double in0 = from[o], st0 = DX(0); double out0; var_update_real(k, d, &in0, &st0, &out0); to[o] = out0; return; }
+    case NLLS_VAR_CONTAMINATED_GAUSSIAN: { double in[3], st[3], out[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { in[q] = from[o + q]; st[q] = DX(q); }
+        var_update_real(NLLS_VAR_CONTAMINATED_GAUSSIAN, d, in, st, out);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) to[o + q] = out[q];
+        return; }
+    case NLLS_VAR_POSE_SO3: { double in[12], st[6], out[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) in[q] = from[o + q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) st[q] = DX(q);
+        var_update_real(NLLS_VAR_POSE_SO3, d, in, st, out);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) to[o + q] = out[q];
+        return; }
+    }
+}
 __device__ __forceinline__ void retract_var(int k, int d, uint32_t o, const double* __restrict__ from, const double* __restrict__ dx, double* __restrict__ to) {
-    if (k == NLLS_VAR_EUCLIDEAN || k == NLLS_VAR_DYNAMIC) { for (int q = 0; q < d; ++q) to[o + q] = from[o + q] + dx[q]; return; }   // v + delta (src/variable.jl:5): no staging arrays (any length)
-    double in[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], out[MAXST > NLLS_MAX_BLOCK_SZ ? MAXST : NLLS_MAX_BLOCK_SZ], st[NLLS_MAX_BLOCK_SZ];
-    const int ns = var_storage(k, d), nd = var_dof(k, d);
-    for (int q = 0; q < ns; ++q) in[q] = from[o + q];
-    for (int q = 0; q < nd; ++q) st[q] = dx[q];
-    var_update_real(k, d, in, st, out);
-    for (int q = 0; q < ns; ++q) to[o + q] = out[q];
+    retract_var_fn(k, d, o, from, to, [dx](int q) { return dx[q]; });
 }
 __device__ __forceinline__ void retract_one(const int32_t* __restrict__ kind, const int32_t* __restrict__ dim, const uint32_t* __restrict__ voff,
                                             const uint32_t* __restrict__ vboff, int64_t i, const double* __restrict__ from,

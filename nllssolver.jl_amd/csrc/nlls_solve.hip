@@ -264,9 +264,7 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
         const int j = (int)(blockIdx.x - ngroups - nextra) * 64 + lane; if (j >= rt.nrest) return;
         const uint32_t i = rt.rest_var[j]; const int r0 = rt.rest_red[j]; const int k = rt.vkind[i], d = rt.vdim[i]; const uint32_t o = rt.voff[i];
         if (r0 < 0) { const int st = var_storage(k, d); for (int q = 0; q < st; ++q) rt.vto[o + q] = rt.vfrom[o + q]; return; }      // fixed: copied
-        double dx[NLLS_MAX_BLOCK_SZ]; const int nd2 = var_dof(k, d);
-        for (int q = 0; q < NLLS_MAX_BLOCK_SZ; ++q) dx[q] = (q < nd2 && write_red) ? -xr[r0 + q] : 0.0;
-        retract_var(k, d, o, rt.vfrom, dx, rt.vto);
+        retract_var_fn(k, d, o, rt.vfrom, rt.vto, [&](int q) { return write_red ? -xr[r0 + q] : 0.0; });     // (no staging array: it lived in scratch memory, 1040 bytes per lane of this launch)
         return;
     }
     if (blockIdx.x >= ngroups) {                              // the workgroups behind the supernodes scatter the reduced part: x_R = -s
@@ -1253,13 +1251,14 @@ __global__ __launch_bounds__(256) void syrk_update_kernel(double* __restrict__ S
 // panel, stay in L2).  narrow != 0: only the block column jb0 (the next panel: all that its factorisation waits for), one workgroup per
 // row block; else the triangle of blocks >= jb0.
 template <int NK>
-__global__ __launch_bounds__(256) void syrk_update2_kernel(double* __restrict__ S, const double* __restrict__ W0, const double* __restrict__ W1, int npad, int k0, int jb0, int narrow) {
+__global__ __launch_bounds__(256) void syrk_update2_kernel(double* __restrict__ S, const double* __restrict__ W0, const double* __restrict__ W1, int npad, int k0, int jb0, int narrow, int wq = -1, int wstrip = 0) {
     __shared__ double Pi[NB * LDT];   // Pi[r + LDT*kk]
     __shared__ double Pj[NB * LDT];
     int ti, tj;
     if (narrow) { ti = blockIdx.x; tj = 0; }
     else { const int tix = blockIdx.x; ti = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > tix) --ti; while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti; tj = tix - ti * (ti + 1) / 2; }
-    const int ib = jb0 + ti, jb = jb0 + tj;
+    // (windowed factorisation, wq >= 0: logical 64-row block t of the step is block jb0 + t inside the band window and wstrip + (t - wq) in the bottom strip)
+    const int ib = (wq < 0 || ti < wq) ? jb0 + ti : wstrip + (ti - wq), jb = (wq < 0 || tj < wq) ? jb0 + tj : wstrip + (tj - wq);
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, li = lane & 15, lk = lane >> 4;
     const int r0 = (w & 1) * 32, c0 = (w >> 1) * 32;
     double4_t acc[2][2];
@@ -1325,12 +1324,13 @@ __global__ __launch_bounds__(256) void syrk_update2_kernel(double* __restrict__ 
 // 46.4 k with the operand loads).  Persistent workgroups with dynamic tile fetch and a half-tile stagger between the two workgroups of a CU
 // were measured there too: no gain (129 us).
 constexpr int S128_KC = 16, S128_LD = 144;
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void syrk_update128_kernel(double* __restrict__ S, const double* __restrict__ W0, const double* __restrict__ W1, int npad, int k0, int jb0, int firstcol) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void syrk_update128_kernel(double* __restrict__ S, const double* __restrict__ W0, const double* __restrict__ W1, int npad, int k0, int jb0, int firstcol, int wq = -1, int wstrip = 0) {
     __shared__ double As[2][S128_KC * S128_LD], Bs[2][S128_KC * S128_LD];
     int ti, tj;                                                // firstcol: only the first tile column (what the next two panels wait for)
     if (firstcol) { ti = blockIdx.x; tj = 0; }
     else { const int tix = blockIdx.x; ti = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > tix) --ti; while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti; tj = tix - ti * (ti + 1) / 2; }
-    const int I0 = jb0 * NB + 128 * ti, J0 = jb0 * NB + 128 * tj;
+    // (windowed, wq >= 0: logical 128-row block t is row jb0 NB + 128 t inside the band window, 128 (wstrip + t - wq) in the bottom strip)
+    const int I0 = (wq < 0 || ti < wq) ? jb0 * NB + 128 * ti : 128 * (wstrip + ti - wq), J0 = (wq < 0 || tj < wq) ? jb0 * NB + 128 * tj : 128 * (wstrip + tj - wq);
     const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
     const int r0w = (w & 1) * 64, c0w = (w >> 1) * 32;
     const bool active = I0 + r0w < npad && J0 + c0w < npad && !(ti == tj && c0w >= r0w + 64);
@@ -2402,7 +2402,7 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
 }
 
 static SLayout make_layout(nlls_ctx* c) {
-    SLayout L{}; L.S = c->S.p; L.mode = c->solve_mode; L.n = (int)c->nred; L.npad = (((int)c->nred + 1 + NB - 1) / NB) * NB;
+    SLayout L{}; L.S = c->S.p; L.mode = c->solve_mode; L.n = (int)c->nred; L.npad = c->dense_window ? (((int)c->nred + 1 + 127) / 128) * 128 : (((int)c->nred + 1 + NB - 1) / NB) * NB;
     L.n_band = (int)c->n_band; L.bw = c->bw; L.nbd = c->nbd; L.H = c->band_H;
     return L;
 }
@@ -2595,7 +2595,22 @@ int enqueue_reduced_solve(nlls_ctx* c) {
         double* const Dfac = LiD + (size_t)(npad / 16) * 256 + 256;    // the factored diagonal blocks, one slot of 128 x 128 per 64-block, until dense_dcopy_all_kernel moves them into S
         double* W0 = Wbuf; double* W1 = Wbuf + (size_t)npad * NB;
         int k = 0;
-        if (c->dense_t128) {
+        if (c->dense_window) {
+            // WINDOWED: the reduced system is a wide band (after the reverse Cuthill-McKee ordering of the upload) + border rows, stored densely.  The same
+            // 128-column panels and trailing updates, restricted to what a banded LDL' touches: below panel p the 128-row blocks p + 1 .. whi - 1 (fill stays
+            // inside the band: rows up to 128 p + 127 + bw) and the strip of border / right-hand-side rows at the bottom.  O(n w^2) instead of n^3 / 3.
+            const int NB128 = npad / 128, strip128 = (int)(c->n_band / 128);
+            for (int p = 0; p < NB128; ++p) {
+                const int whi = std::min(NB128, (128 * p + 127 + c->bw) / 128 + 1);            // first 128-row block BEHIND the band of this panel
+                DenseWin w; w.nwin = std::max(0, std::min(whi, NB128) - (p + 1)); w.strip = std::max(strip128, p + 1 + w.nwin); w.ntot = w.nwin + std::max(0, NB128 - w.strip);
+                launch_dense_panel(c->stream, c->S.p, Wbuf, LiD, npad, p, c->d_status.p, 1, Dfac, w);
+                if (w.ntot <= 0) continue;
+                if (w.ntot >= c->dense_t128_min) hipLaunchKernelGGL(syrk_update128_kernel, dim3(w.ntot * (w.ntot + 1) / 2), dim3(512), 0, c->stream, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 0, w.nwin, w.strip);
+                else { const int T = 2 * w.ntot; hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 0, 2 * w.nwin, 2 * w.strip); }
+            }
+            launch_dense_dcopy_all(c->stream, c->S.p, Dfac, npad, NB128, 2 * NB128, 0);
+            k = nblk;
+        } else if (c->dense_t128) {
             // 128-column panels (dense_panel_kernel<8, 2>: one launch factors what used to be panel k, a narrow update of block column k + 1 and
             // panel k + 1), each followed by ONE update of everything behind it with K = 128 (128 x 128 tiles; 64 x 64 for the small tail)
             for (; k + 1 < nblk; k += 2) {

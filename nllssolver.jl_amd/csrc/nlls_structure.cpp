@@ -830,7 +830,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     }
     // ---- choose the reduced-system solver ----------------------------------------------------------------------
     const int64_t n = c->nred;
-    c->bw = (int)bw; c->solve_mode = SOLVE_DENSE; c->band_twisted = !(flags & NLLS_FLAG_NO_TWIST);
+    c->bw = (int)bw; c->solve_mode = SOLVE_DENSE; c->band_twisted = !(flags & NLLS_FLAG_NO_TWIST); c->dense_window = false;
     if (n < 64) c->solve_mode = SOLVE_SMALL;
     else if (!I0.is_sparse) c->solve_mode = SOLVE_DENSE;
     else if (c->n_band >= 128 && !(flags & NLLS_FLAG_NO_BAND)) {
@@ -932,12 +932,20 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             }
         }
     } else {
-        const int64_t npad = ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
-        // a dense reduced system is npad^2 doubles: decline what cannot reasonably be factored densely (the shim then keeps the CPU system)
-        if (npad > 46000) return fail(c, NLLS_ERR_UNSUPPORTED, "reduced system too large for the dense solver (" + std::to_string(n) + " dof, not banded)");
+        // dense storage, column-major, the rhs riding along as row n.  When the (re-ordered) reduced system is a WIDE band -- too wide for the band
+        // kernels, much narrower than the system: a 2-D camera grid, a loop closure -- the blocked LDL' is restricted to the band and the border strip
+        // (enqueue_reduced_solve, `dense_window`): O(n w^2) work instead of n^3 / 3.  The reference's LDL' takes any sparsity (src/linearsolver.jl:28-32).
+        c->dense_window = I0.is_sparse && c->nelim > 0 && c->n_band >= 1024 && !(flags & NLLS_FLAG_NO_BAND) && 2 * (bw + 256) < c->n_band && !getenv("NLLS_NO_DENSE_WINDOW");
+        const int64_t npad = c->dense_window ? ((n + 1 + 127) / 128) * 128 : ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
+        // npad^2 doubles: what the DEVICE holds decides (288 GB on an MI355X: ~150 000 reduced dof), not a constant; the shim keeps the CPU system when it does not fit
+        const size_t lw = (size_t)std::max<int64_t>(npad * 128 + npad + (npad / 16) * 256 + 256 + (npad / 64 + 1) * 128 * 128, 1);
+        { size_t mfree = 0, mtotal = 0; const size_t want = sizeof(double) * ((size_t)npad * npad + (size_t)npad + 64 + lw);
+          if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && want + ((size_t)2 << 30) > mfree)
+              return fail(c, NLLS_ERR_UNSUPPORTED, "reduced system too large for the dense solver on this device (" + std::to_string(n) + " dof need " + std::to_string(want >> 20) + " MiB, " + std::to_string(mfree >> 20) + " MiB free)"); }
+        if (npad >= ((int64_t)1 << 30)) return fail(c, NLLS_ERR_UNSUPPORTED, "reduced system too large for 32-bit row indices");
         c->s_elems = (size_t)std::max<int64_t>(npad * npad, 1);
         if (hipSuccess != c->S.alloc(c->s_elems + (size_t)npad + 64) ||
-            hipSuccess != c->Lwork.alloc((size_t)std::max<int64_t>(npad * 128 + npad + (npad / 16) * 256 + 256 + (npad / 64 + 1) * 128 * 128, 1))   /* W of a 128-column panel (or of two 64-column ones) | acc | inverted diagonal tiles | factored diagonal blocks (a slot per 64-block) */ || hipSuccess != c->d_status.alloc(96)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
+            hipSuccess != c->Lwork.alloc(lw)   /* W of a 128-column panel (or of two 64-column ones) | acc | inverted diagonal tiles | factored diagonal blocks (a slot per 64-block) */ || hipSuccess != c->d_status.alloc(96)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
     }
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
     c->info.solve_mode = c->solve_mode; c->info.bandwidth = c->bw; c->info.nborder_dof = c->nbd;

@@ -125,11 +125,10 @@ function gpucost(ls::MultiVariateLSgpu, vars::Vector)                           
     setvariables!(ls, vars, 1); c = Ref(0.0)
     check(ls.ctx, ccall((:nlls_sweep_cost, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ls.ctx, 1, c)); return c[]
 end
-# The reference's OTHER iterators (Newton, dogleg, gradient descent: src/iterators.jl:15-115,175-200) call
-# cost(problem.varnext, problem.costs) (src/iterators.jl:24,100,191,203), which does not see the linear system and cannot be redirected
-# without touching NLLSProblem (its `costs` field is concretely typed).  With this linear-system type they therefore run their gradient /
-# Hessian sweep and their solve on the device and keep the reference's own CPU cost() for the trial points -- correct, and not
-# accelerated.  `gpucost` above is the device cost sweep a maintainer would call from an iterate! method written like the LM one below.
+# The reference's OTHER iterators (Newton, dogleg, gradient descent: src/iterators.jl:15-27,47-115,187-208) evaluate their trial points with
+# cost(problem.varnext, problem.costs) (src/iterators.jl:24,100,191,203), which does not see the linear system.  NLLSInternal is parametric in the
+# linear-system type (src/structs.jl:81-104), so -- exactly as for Levenberg-Marquardt below -- iterate! methods on NLLSInternal{MultiVariateLSgpu}
+# take their place and call `gpucost` (the device cost sweep, src/cost.jl:10-13) instead: see "the other iterators" further down.
 struct GpuHessian; ls::MultiVariateLSgpu; end                                  # what gethessgrad hands to the iterator
 function NLLSsolver.gethessgrad(ls::MultiVariateLSgpu)                          # src/linearsystem.jl:190
     check(ls.ctx, ccall((:nlls_get_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, ls.b)); return GpuHessian(ls), ls.b
@@ -160,14 +159,16 @@ NLLSsolver.getoffsets(block, ls::MultiVariateLSgpu) = @inbounds(ls.blockindices[
 # tests/abi/abi_replay.c replays exactly this sequence, with these argument types, against the library on the GPU.
 const VARS_CURRENT, VARS_NEXT, VARS_BEST = Int32(0), Int32(1), Int32(2)
 
-function fetchvariables!(problem::NLLSProblem, ls::MultiVariateLSgpu, which::Int32 = VARS_CURRENT)
+"device variable set `which` -> the host vector `dest` (problem.variables, problem.varnext or problem.varbest): the inverse of pack!"
+function fetchvariables!(dest::Vector, ls::MultiVariateLSgpu, which::Int32)
     resize!(ls.packed, sum(k -> ccall((:nlls_var_storage, lib), Cint, (Int32, Int32), k[1], k[2]), ls.kinds))
     check(ls.ctx, ccall((:nlls_get_variables, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ls.ctx, which, ls.packed))
     o = 0
-    for (i, v) in enumerate(problem.variables)                   # unpack!: the inverse of pack! for the registered kinds
-        problem.variables[i], o = unpack(v, ls.packed, o)
+    for (i, v) in enumerate(dest)
+        dest[i], o = unpack(v, ls.packed, o)
     end
 end
+fetchvariables!(problem::NLLSProblem, ls::MultiVariateLSgpu, which::Int32 = VARS_CURRENT) = fetchvariables!(problem.variables, ls, which)
 unpack(::Number, p, o) = (p[o+1], o + 1)
 unpack(::EuclideanVector{N, T}, p, o) where {N, T} = (EuclideanVector{N, T}(ntuple(k -> p[o+k], N)), o + N)
 unpack(v::NLLSsolver.DynamicVector{Float64}, p, o) = (p[o+1:o+length(v)], o + length(v))
@@ -204,6 +205,76 @@ function NLLSsolver.iterate!(levmardata::NLLSsolver.LevMarData, data::NLLSIntern
             return cost_
         end
         levmardata.lambda *= mu; mu *= 2.
+    end
+end
+
+# ---- the other iterators (src/iterators.jl:15-27 Newton, :47-115 dogleg, :187-208 gradient descent) on the GPU linear system ----------------
+# Same quantities, same order of evaluation as the reference; the one substitution is the trial cost: gpucost(ls, problem.varnext) -- an upload of
+# the trial point and the device cost sweep -- where the reference calls cost(problem.varnext, problem.costs).  Gradient, Hessian products and the
+# solve already go through the overloads above (gethessgrad, fast_bAb, solve!); update! stays the reference's (host: arbitrary `update` methods).
+trialcost!(data, problem) = (t0 = Base.time_ns(); c = gpucost(data.linsystem, problem.varnext); data.timecost += Base.time_ns() - t0; data.costcomputations += 1; c)
+
+function NLLSsolver.iterate!(::NLLSsolver.NewtonData, data::NLLSInternal{MultiVariateLSgpu}, problem::NLLSProblem, options::NLLSOptions)::Float64
+    NLLSsolver.gethessian(data.linsystem)
+    data.timesolver += NLLSsolver.@elapsed_ns NLLSsolver.negate!(NLLSsolver.solve!(data.linsystem, options))
+    data.linearsolvers += 1
+    NLLSsolver.update!(problem.varnext, problem.variables, data.linsystem)
+    return trialcost!(data, problem)
+end
+
+function NLLSsolver.iterate!(gd::NLLSsolver.GradientDescentData, data::NLLSInternal{MultiVariateLSgpu}, problem::NLLSProblem, options::NLLSOptions)::Float64
+    ls = data.linsystem; g = NLLSsolver.getgrad(ls)
+    trial(step) = (ls.x .= (-step) .* g; NLLSsolver.update!(problem.varnext, problem.variables, ls); trialcost!(data, problem))
+    c = trial(gd.stepsize)
+    while c > data.bestcost                                          # quadratic fit through the last trial (src/iterators.jl:196-204)
+        slope = ls.x' * g
+        gd.stepsize *= 0.5 * slope / (data.bestcost + slope - c)
+        c = trial(gd.stepsize)
+    end
+    gd.stepsize *= 2
+    return c
+end
+NLLSsolver.getgrad(ls::MultiVariateLSgpu) = (check(ls.ctx, ccall((:nlls_get_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, ls.b)); ls.b)
+
+function NLLSsolver.iterate!(dl::NLLSsolver.DoglegData, data::NLLSInternal{MultiVariateLSgpu}, problem::NLLSProblem, options::NLLSOptions)::Float64
+    ls = data.linsystem
+    H, g = NLLSsolver.gethessgrad(ls)
+    local a, gg, alpha, alpha2, beta
+    data.timesolver += NLLSsolver.@elapsed_ns begin
+        gg = g' * g
+        a = gg / (NLLSsolver.fast_bAb(H, g) + floatmin(Float64))      # Cauchy step length along -g
+        dl.cauchy .= (-a) .* g
+        alpha2 = a * a * gg; alpha = sqrt(alpha2)
+        dl.trustradius == 0 && (dl.trustradius = alpha)               # the first step is the Cauchy point
+        beta = Inf
+        if alpha < dl.trustradius                                     # the Gauss-Newton step is needed
+            NLLSsolver.negate!(NLLSsolver.solve!(ls, options)); beta = sqrt(ls.x' * ls.x); data.linearsolvers += 1
+        end
+    end
+    c = data.bestcost
+    while true
+        if !(alpha < dl.trustradius)                                  # first leg: along the Cauchy direction
+            ls.x .= (dl.trustradius / alpha) .* dl.cauchy
+            predicted = dl.trustradius * (2 * alpha - dl.trustradius) / (2 * a)
+        elseif beta <= dl.trustradius                                 # the whole Gauss-Newton step fits
+            predicted = c
+        else                                                          # second leg: Cauchy -> Newton, cut at the trust-region boundary
+            ls.x .-= dl.cauchy
+            leg2 = ls.x' * ls.x; cl = dl.cauchy' * ls.x; room = dl.trustradius^2 - alpha2
+            t = sqrt(cl * cl + leg2 * room)
+            t = cl <= 0 ? (t - cl) / leg2 : room / (cl + t)
+            ls.x .*= t; ls.x .+= dl.cauchy
+            predicted = 0.5 * (a * (1 - t)^2 * gg) + t * (2 - t) * c
+        end
+        NLLSsolver.update!(problem.varnext, problem.variables, ls)
+        c = trialcost!(data, problem)
+        gain = (data.bestcost - c) / predicted
+        if gain > 0.375
+            dl.trustradius = max(dl.trustradius, 3 * sqrt(ls.x' * ls.x))
+        elseif gain < 0.125
+            dl.trustradius *= 0.5
+        end
+        (!(c > data.bestcost) || maximum(abs, ls.x) < options.dstep) && return c
     end
 end
 
@@ -264,10 +335,13 @@ function NLLSsolver.optimizeinternal!(problem::NLLSProblem, options::NLLSOptions
     while true
         data.iternum += 1
         cost = NLLSsolver.iterate!(iteratedata, data, problem, options)::Float64
-        if callback !== NLLSsolver.nullcallback                      # a user callback reads problem.varnext / linsystem.x on the host
-            fetchvariables!(problem, ls, VARS_NEXT); check(ls.ctx, ccall((:nlls_get_step, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, ls.x))
-        end
+        # a user callback sees the trial point where the reference puts it -- problem.varnext (src/optimize.jl:128; src/callbacks.jl) -- and the step in
+        # linsystem.x; what it WRITES there counts: the reference's own EM pattern edits varnext inside the callback (src/robustadaptive.jl:48-73,
+        # test/adaptivecost.jl:54), and updatefromnext! then makes it the current point.  So: next variables down before, and up again after.
+        length(problem.varnext) == length(problem.variables) || (problem.varnext = deepcopy(problem.variables))
+        fetchvariables!(problem.varnext, ls, VARS_NEXT); check(ls.ctx, ccall((:nlls_get_step, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), ls.ctx, ls.x))
         cost, terminate = callback(cost, problem, data, iteratedata)::Tuple{Float64, Int}
+        setvariables!(ls, problem.varnext, VARS_NEXT)                # nlls_set_variables(ctx, 1, ...): host edits of varnext reach the device
         dcost = data.bestcost - cost
         if dcost >= 0
             data.bestcost = cost; fails = 0

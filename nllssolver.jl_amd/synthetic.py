@@ -150,6 +150,38 @@ def widen_visibility(problem, ncameras, wide):
     return problem
 
 
+def create_grid_ba_problem(gw, gh, pts_per_cell=6, seed=1, robust=None, outlier_frac=0.0, outlier_sigma=0.0, noise=0.0):
+    """A bundle adjustment whose camera graph is a 2-D GRID (an aerial survey: gw x gh cameras in rows, every landmark seen by the 3 x 3 block of cameras
+    around its cell, clipped at the border) -- the reduced camera system is then neither a narrow band nor small: row-major numbering gives a half bandwidth of
+    about (2 gw + 2) cameras, no ordering gives less than about gw.  test/optimizeba.jl:22-23 leaves visibility a free parameter; residual model, variable
+    order (all cameras, then all landmarks) and camera-major cost order are the reference generator's (test/optimizeba.jl:4-35)."""
+    rng = np.random.default_rng(seed)
+    ncam = gw * gh
+    cams = rng.standard_normal((ncam, 6)) + np.array([1.0, 0, 0, 0, 1.0, 0])
+    cx, cy = np.meshgrid(np.arange(gw), np.arange(gh), indexing="xy")
+    cell = np.repeat(np.stack([cx.ravel(), cy.ravel()], axis=1), pts_per_cell, axis=0)            # the cell of every landmark
+    npts = cell.shape[0]
+    pts = rng.random((npts, 3)) + np.array([-0.5, -0.5, 10.0])
+    cam_l, lm_l = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            x, y = cell[:, 0] + dx, cell[:, 1] + dy
+            ok = (x >= 0) & (x < gw) & (y >= 0) & (y < gh)
+            cam_l.append((y[ok] * gw + x[ok]) + 1); lm_l.append(np.nonzero(ok)[0] + 1)
+    cam, lm = np.concatenate(cam_l), np.concatenate(lm_l)
+    order = np.lexsort((lm, cam)); cam, lm = cam[order], lm[order]
+    problem = NLLSProblem(); problem.addvariables(cams); problem.addvariables(pts)
+    c, X = cams[cam - 1], pts[lm - 1]
+    meas = np.stack([(c[:, 0:3] * X).sum(1), (c[:, 3:6] * X).sum(1)], axis=1)
+    if noise > 0:
+        meas += rng.standard_normal(meas.shape) * noise
+    if outlier_frac > 0:
+        bad = rng.random(meas.shape[0]) < outlier_frac
+        meas[bad] += rng.standard_normal((int(bad.sum()), 2)) * outlier_sigma
+    problem.addcosts(K.RES_BA_AFFINE, np.stack([cam, lm + ncam], axis=1), meas, robust)
+    return problem
+
+
 def shuffle_camera_labels(problem, ncameras, seed, first=1):
     """The same problem with the cameras' LABELS permuted (camera c is afterwards variable perm^-1[c]; its pose moves with the label, cost blocks are
     re-listed camera-major in the new labels, as test/optimizeba.jl:24-31 adds them).  test/optimizeba.jl:22 numbers neighbouring cameras consecutively --

@@ -137,6 +137,44 @@ int main(int argc, char** argv) {
     double check = 0; CK(sweep_cost(ctx, NLLS_VARS_CURRENT, &check));
     printf("replay: start %.6e -> best %.6e in %d iterations (%d LM trials), termination flags %d, cost(variables) %.6e\n", startcost, bestcost, iter, trials, converged, check);
     if (!(bestcost < 1e-15 * NOBS) || !(check < 1e-15 * NOBS)) { fprintf(stderr, "did not reach the zero-residual optimum (test/optimizeba.jl:62-75)\n"); return 1; }
+    /* ---- the shim's path WITH a user callback (src/optimize.jl:128): after iterate! the trial point is fetched into problem.varnext (nlls_get_variables(ctx, 1)) and the
+     *      step into linsystem.x (nlls_get_step), the callback runs, and what it left in varnext goes back down (nlls_set_variables(ctx, 1)) before updatefromnext! makes it the
+     *      current point.  The "callback" here rewrites a variable (point 1, rounded to single precision, in the first three iterations) the way the reference's EM callback rewrites
+     *      one (src/robustadaptive.jl:48-73): the edit must be bit for bit what the device holds as the current point after the swap, and the optimisation must go on from it.  ---- */
+    {
+        typedef int (*fn_get_step)(nlls_ctx*, double*); fn_get_step get_step = (fn_get_step)need(lib, "nlls_get_step");
+        static double varnext[NCAM * 6 + NPT * 3], xstep[NCAM * 6 + NPT * 3], cur[NCAM * 6 + NPT * 3];
+        CK(set_vars(ctx, NLLS_VARS_CURRENT, start)); CK(copy_vars(ctx, NLLS_VARS_NEXT, NLLS_VARS_CURRENT));
+        CK(sweep_gradhess(ctx, &cost)); double best2 = cost, lam2 = 0; int it2 = 0, conv2 = 0, edits = 0;
+        while (!conv2) {
+            ++it2;
+            if (lam2 == 0) { double m; CK(max_abs_diag(ctx, &m)); lam2 = 1e-6 * m; }
+            double lastlambda = 0, mu = 2, c_ = 0, maxstep = 0;
+            for (;;) {
+                CK(lm_trial(ctx, lam2 - lastlambda, NLLS_VARS_NEXT, NLLS_VARS_CURRENT, &c_)); lastlambda = lam2;
+                CK(step_maxabs(ctx, &maxstep));
+                if (!(c_ > best2) || maxstep < 1e-15) { CK(damp(ctx, -lastlambda)); double xHx, gx; CK(quadform(ctx, &xHx, &gx));
+                    const double q = (c_ - best2) / (0.5 * xHx + gx); lam2 *= q < 0.983 ? 1 - (2 * q - 1) * (2 * q - 1) * (2 * q - 1) : 0.1; break; }
+                lam2 *= mu; mu *= 2;
+            }
+            CK(get_vars(ctx, NLLS_VARS_NEXT, varnext)); CK(get_step(ctx, xstep));                       /* fetchvariables!(problem.varnext, ...), linsystem.x */
+            double edited[3] = {varnext[6 * NCAM], varnext[6 * NCAM + 1], varnext[6 * NCAM + 2]};
+            if (it2 <= 3) { ++edits; for (int k = 0; k < 3; ++k) edited[k] = (double)(float)edited[k]; }   /* the callback edits problem.varnext: point 1 rounded to single precision */
+            for (int k = 0; k < 3; ++k) varnext[6 * NCAM + k] = edited[k];
+            CK(set_vars(ctx, NLLS_VARS_NEXT, varnext));                                                  /* ... and the edit goes back to the device */
+            CK(sweep_cost(ctx, NLLS_VARS_NEXT, &c_));                                                    /* (the callback returns the cost of what it left there) */
+            double dcost = best2 - c_; if (dcost >= 0) best2 = c_; else dcost = c_;
+            CK(swap_vars(ctx, NLLS_VARS_CURRENT, NLLS_VARS_NEXT));
+            CK(get_vars(ctx, NLLS_VARS_CURRENT, cur));
+            for (int k = 0; k < 3; ++k) if (cur[6 * NCAM + k] != edited[k]) { fprintf(stderr, "callback path: the host's edit of varnext did not reach the device\n"); return 1; }
+            conv2 |= (dcost < 1e-15) << 3; conv2 |= (maxstep < 1e-15) << 6; conv2 |= (it2 >= 60) << 8;
+            if (conv2) break;
+            CK(sweep_gradhess(ctx, NULL));
+        }
+        double check4 = 0; CK(sweep_cost(ctx, NLLS_VARS_CURRENT, &check4));
+        printf("replay (callback path: varnext fetched, edited on the host, set again before updatefromnext!): best %.6e in %d iterations, %d edits, cost(variables) %.6e\n", best2, it2, edits, check4);
+        if (!(check4 < 1e-15 * NOBS)) { fprintf(stderr, "the callback path did not reach the zero-residual optimum\n"); return 1; }
+    }
     /* ---- the same optimisation through the library's own loop (the shim's path when there is no user callback): one ccall ---- */
     fn_lm_iterations lm_iterations = (fn_lm_iterations)need(lib, "nlls_lm_iterations");
     CK(set_vars(ctx, NLLS_VARS_CURRENT, start)); CK(copy_vars(ctx, NLLS_VARS_NEXT, NLLS_VARS_CURRENT));

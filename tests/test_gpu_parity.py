@@ -169,6 +169,33 @@ def test_random_visibility_has_no_band(ncam, npts, k, seed):
     assert info.nreduced_dof == 6 * ncam and info.solve_mode == 1
 
 
+@pytest.mark.parametrize("gw,gh,shuffle", [(16, 12, None), (24, 24, 5)])
+def test_grid_camera_graph_windowed_dense_solve(gw, gh, shuffle):
+    """A 2-D grid of cameras (every landmark seen by a 3 x 3 block): the reduced camera system is a WIDE band -- too wide for the band kernels (> 80 columns),
+    far narrower than the system.  The dense blocked LDL' then works only inside the band of the re-ordered system and the border strip (`dense_window`);
+    with shuffled camera labels the reverse Cuthill-McKee ordering of the upload has to find the band first.  Sweep, solve, retraction and LM against the oracle,
+    whose sparse LDL' takes any structure (as the reference's does: src/linearsolver.jl:28-32)."""
+    mk = lambda: synthetic.create_grid_ba_problem(gw, gh, 4, seed=3, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05, noise=1e-3)
+    p = mk()
+    if shuffle is not None:
+        p = synthetic.shuffle_camera_labels(p, gw * gh, shuffle)
+    p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
+    _, st = _upload_info(p)
+    assert info.solve_mode == 1 and info.nreduced_dof == 6 * gw * gh
+    if 6 * gw * gh >= 1024:
+        assert st["dense_window"] == 1 and 80 < info.bandwidth <= 6 * (2 * min(gw, gh) + 4), (st, info.bandwidth)
+        info2 = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4, flags=_capi.FLAG_NO_BAND)           # the same system by the full dense LDL'
+        assert info2.solve_mode == 1 and _upload_info(p, _capi.FLAG_NO_BAND)[1]["dense_window"] == 0
+    if shuffle is not None:
+        assert st["reordered"] == 1
+    q_vars = p.variables.copy()
+    op = oracle_problem(p); ro = op.optimize(iterator=1, maxiters=5)
+    p.variables[:] = q_vars
+    rg = N.optimize(p, N.NLLSOptions(maxiters=5))
+    assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
+
+
 def test_ba_sparse_small():          # test/optimizeba.jl:71 shape (10 x 50 @ 0.3 -> sparse path)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 50, 0.3, seed=1), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)
