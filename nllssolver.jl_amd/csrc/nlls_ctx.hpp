@@ -191,6 +191,7 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_fast_voff;      // where the variable of each eliminated member is stored (elimination order)
     nlls::DevBuf<uint32_t> d_rest_var; nlls::DevBuf<int32_t> d_rest_red;   // the other variables, and where their step starts in the reduced solution (-1: fixed)
     bool fast_all_euclid = false, post_fuse = true, retract_done = false; int trial_to = -1, trial_from = -1;
+    bool elim_dma = false;                     // NLLS_ELIM_DMA=1: schur_elim_all_dma_kernel (member loop fed by global_load_lds: built, parity-green, 7 us slower at config 4)
     bool elim_split = false;                   // NLLS_ELIM_SPLIT=1: the assembly of the reduced system in three launches (A/B)
     bool sweep_split3 = false;                 // NLLS_SWEEP_SPLIT3=1: the three-slot accumulate sweep in one launch per role (A/B)
     bool elim_mfma = true;                     // narrow supernodes (nd + 1 <= 64) are eliminated on the matrix cores (NLLS_ELIM_TILED=1: the register-tiled kernel, for A/B runs)

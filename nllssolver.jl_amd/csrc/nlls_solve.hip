@@ -364,12 +364,23 @@ constexpr int ELIM_PF = 4;                                    // members in flig
 constexpr int ELIM_NDP = 76;                                  // columns of [E | b] rounded up to a multiple of 4 (nd + 1 <= 72)
 // NC: columns of [E | b] per lane of the solver wave (1: nd + 1 <= 64; 2: up to ELIM_NDP - 4).  TW: tile waves -- two hold
 // the 4x4 tiles of nd <= 60 (120 tiles on 128 lanes: the bundle-adjustment point seen by ten cameras), three the rest.
-template <int DV, int NC, int TW>
+// (EXT: the workgroup's LDS is handed in -- ext, 16-byte aligned, schur_elim_tiled_lds<DV, NC>() doubles -- so that a kernel that runs either this body or
+//  another one in a workgroup pays for the larger of the two, not for their sum)
+template <int DV, int NC> constexpr int schur_elim_tiled_lds() { constexpr int NDM = NC == 1 ? 63 : ELIM_NDP - 5; return 4 * DV * ELIM_NDP + ELIM_NDP + NDM * (NDM + 1) / 2 + NDM + 2; }
+template <int DV, int NC, int TW, bool EXT = false>
 __device__ __forceinline__ void schur_elim_tiled_body(const double* __restrict__ A, const double* __restrict__ b,
                                                       const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                      const double* __restrict__ Cinv, const SLayout& L, double* __restrict__ s, uint32_t bidx) {
-    __shared__ __attribute__((aligned(16))) double Es[2][DV][ELIM_NDP], Ys[2][DV][ELIM_NDP];
-    __shared__ uint32_t rc[ELIM_NDP], rs[ELIM_NDP];          // rc: reduced column of list column p (MEMORY order); rs: the list columns by ascending reduced column
+                                                      const double* __restrict__ Cinv, const SLayout& L, double* __restrict__ s, uint32_t bidx, double* ext = nullptr) {
+    double (*Es)[DV][ELIM_NDP]; double (*Ys)[DV][ELIM_NDP]; uint32_t* rc; uint32_t* rs; double* img;      // rc: reduced column of list column p (MEMORY order); rs: the list columns by ascending reduced column
+    if constexpr (EXT) {
+        Es = reinterpret_cast<double (*)[DV][ELIM_NDP]>(ext); Ys = reinterpret_cast<double (*)[DV][ELIM_NDP]>(ext + 2 * DV * ELIM_NDP);
+        rc = reinterpret_cast<uint32_t*>(ext + 4 * DV * ELIM_NDP); rs = rc + ELIM_NDP; img = ext + 4 * DV * ELIM_NDP + ELIM_NDP;
+    } else {
+        __shared__ __attribute__((aligned(16))) double Es_[2][DV][ELIM_NDP], Ys_[2][DV][ELIM_NDP];
+        __shared__ uint32_t rc_[ELIM_NDP], rs_[ELIM_NDP];
+        __shared__ double img_[(NC == 1 ? 63 : ELIM_NDP - 5) * ((NC == 1 ? 63 : ELIM_NDP - 5) + 1) / 2 + (NC == 1 ? 63 : ELIM_NDP - 5)];
+        Es = Es_; Ys = Ys_; rc = rc_; rs = rs_; img = img_;
+    }
     const int tid = threadIdx.x; constexpr int NT = 64 * (1 + TW);
     const ElimDesc d = desc[bidx];                       // uniform: one scalar load (the run's structure is identical for all members)
     const uint32_t v0 = d.v0, v1 = d.v0 + d.nmem; const int nd = (int)d.nd;
@@ -392,7 +403,6 @@ __device__ __forceinline__ void schur_elim_tiled_body(const double* __restrict__
     const int64_t dg0 = d.dg0, dstride = (int64_t)DV * nd + DV * DV; const uint32_t eb0 = d.eb0;
     auto member_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // LDS only: loads stay in flight
     constexpr int NDMAX = NC == 1 ? 63 : ELIM_NDP - 5;
-    __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
     double* const irhs = img + NDMAX * (NDMAX + 1) / 2; double* const rhs_out = irhs;   // (the flush image: used after the member loop)
     if (tid < 64) {
         // ---- solver wave.  Software pipeline: registers hold the column and the inverse diagonal block (schur_cinv_kernel)
@@ -637,6 +647,111 @@ __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ 
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 
+// ---- the same member loop fed by LDS-DMA (global_load_lds_dwordx4) ------------------------------------------------------------------------
+// The loop above keeps PF = 2 members per wave in flight -- all the registers allow at three waves per SIMD (168 of 170) -- and is bound by the
+// latency of those loads: 24 members (36 KB) in flight per CU.  Here the rows of E go global -> LDS without passing through registers: every wave
+// owns a ring of ELIM_DMA_NS slots, one member's E (DV nd doubles, contiguous in A.data) per slot, filled by one or two 1-KiB DMA instructions (lane l
+// of an instruction moves 16 bytes to slot + 16 l: the destination is lane-linear, the source per lane).  The inverse diagonal blocks and the right-hand
+// sides of the supernode's members are put into LDS by the workgroup's prologue (it has just formed the inverses), so the loop has no register-
+// staged global load at all.  hipcc does not see the DMAs: their completion is waited for by hand (s_waitcnt vmcnt(N), N = the DMA instructions
+// issued behind the member about to be consumed; clamped re-loads of the last member keep N the same to the end).
+constexpr int ELIM_DMA_NS = 4, ELIM_DMA_SLOT = 192;           // members in flight per wave; doubles per ring slot (E <= 3 * 63 = 189 doubles)
+NLLS_DEV void glds16(const void* gsrc, uint32_t lds_dst) {     // M0 (the DMA's LDS base) is compiler-reserved: written and restored inside the statement
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> NLLS_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+struct ElimDmaLds { double* ring; double* cinv; double* bv; double* img; uint32_t* rc; uint32_t* rs; };
+template <int DV>
+__device__ __forceinline__ void schur_elim_mfma_dma_body(const double* __restrict__ A, const ElimDesc& d, const uint32_t* __restrict__ rcflat,
+                                                         const SLayout& L, double* __restrict__ s, const ElimDmaLds& lds) {
+    constexpr int NDMAX = 63, NW = ELIM_MFMA_NW, NTH = 64 * NW, NS = ELIM_DMA_NS;
+    double* const img = lds.img; double* const irhs = img + NDMAX * (NDMAX + 1) / 2; uint32_t* const rc = lds.rc; uint32_t* const rs = lds.rs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
+    const uint32_t nmem = d.nmem; const int nd = (int)d.nd;
+    if (tid < nd) { rc[tid] = rcflat[d.rc_off + tid]; rs[tid] = rcflat[d.rc_off + nd + tid]; }
+    for (int i = tid; i < nd * (nd + 1) / 2; i += NTH) img[i] = 0.0;
+    if (tid < NDMAX) irhs[tid] = 0.0;
+    const int T16 = (nd + 1 + 15) >> 4;
+    const int64_t e0 = d.dg0 - (int64_t)DV * nd, dstride = (int64_t)DV * nd + DV * DV;          // E of member m starts at A[e0 + m dstride]
+    const int n16 = (DV * nd + 1) >> 1;                                                         // 16-byte pieces of one member's E (an odd tail reads one double of C: valid memory)
+    const bool two = n16 > 64;                                                                  // uniform: DMA instructions per member
+    double* const myring = lds.ring + (size_t)wave * NS * ELIM_DMA_SLOT;
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(char*)myring);
+    auto issue = [&](uint32_t m, int slot) {
+        const uint32_t mm = m < nmem ? m : nmem - 1;
+        const double* src = A + e0 + (int64_t)mm * dstride + 2 * lane;
+        const uint32_t dst = ring_lds + (uint32_t)slot * (ELIM_DMA_SLOT * 8);
+        if (lane < (n16 < 64 ? n16 : 64)) glds16(src, dst);
+        if (two) { if (lane < n16 - 64) glds16(src + 128, dst + 1024); }
+    };
+    const bool kslot = lk < DV; const int kk = kslot ? lk : 0;
+    double4_t acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+    auto members = [&](auto T16c, auto TWOc) {
+        constexpr int TR = decltype(T16c)::value; constexpr bool TWO = decltype(TWOc)::value; constexpr int NI = TWO ? 2 : 1;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) issue(wave + NW * u, u);
+        int slot = 0;
+#pragma unroll 1
+        for (uint32_t m = wave; m < nmem; m += NW) {
+            wait_vmcnt<NI * (NS - 1)>();                       // this member's pieces have landed; the NS - 1 members behind it may still be in flight
+            const double* E = myring + (size_t)slot * ELIM_DMA_SLOT;
+            double aop[TR], bop[TR], c[DV];
+#pragma unroll
+            for (int r = 0; r < TR; ++r) { const int col = 16 * r + li;
+                aop[r] = (kslot && col < nd) ? E[DV * col + kk] : ((kslot && col == nd) ? lds.bv[(size_t)m * DV + kk] : 0.0); }
+#pragma unroll
+            for (int j = 0; j < DV; ++j) { const int hi = j > kk ? j : kk, lo = j > kk ? kk : j;       // the inverse is symmetric: its lower triangle, packed by columns
+                c[j] = kslot ? lds.cinv[(size_t)m * (DV * (DV + 1) / 2) + lo * DV - lo * (lo - 1) / 2 + (hi - lo)] : 0.0; }
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                double y = 0.0;
+#pragma unroll
+                for (int j = 0; j < DV; ++j) {
+                    const int src = 4 * (16 * j + li);
+                    const double ej = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(aop[r])), __builtin_amdgcn_ds_bpermute(src, __double2loint(aop[r])));
+                    y = fma(c[j], ej, y);
+                }
+                bop[r] = y;
+            }
+            issue(m + NW * NS, slot);                             // (the slot's words are in registers: the bpermutes above have used them)
+            slot = slot + 1 == NS ? 0 : slot + 1;
+#pragma unroll
+            for (int R = 0; R < TR; ++R)
+#pragma unroll
+                for (int C = 0; C <= R; ++C) acc[R * (R + 1) / 2 + C] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[R], bop[C], acc[R * (R + 1) / 2 + C], 0, 0, 0);
+        }
+        wait_vmcnt<0>();                                           // the clamped re-loads behind the last member: nothing may land in LDS after this point
+    };
+    auto dispatch = [&](auto TWOc) {
+        if (T16 == 4) members(std::integral_constant<int, 4>{}, TWOc);
+        else if (T16 == 3) members(std::integral_constant<int, 3>{}, TWOc);
+        else if (T16 == 2) members(std::integral_constant<int, 2>{}, TWOc);
+        else members(std::integral_constant<int, 1>{}, TWOc);
+    };
+    if (two) dispatch(std::true_type{}); else dispatch(std::false_type{});
+    __syncthreads();
+    auto colstart = [nd](int q) { return q * nd - q * (q - 1) / 2 - q; };
+#pragma unroll
+    for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int C = 0; C <= R; ++C) {
+            if (R >= T16) continue;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int pp = 16 * R + lk + 4 * v, q = 16 * C + li; const double val = acc[R * (R + 1) / 2 + C][v];
+                if (pp < nd && q <= pp) atomicAdd(&img[colstart(q) + pp], val);
+                else if (pp == nd && q < nd) atomicAdd(&irhs[q], val);
+            }
+        }
+    __syncthreads();
+    for (int qs = wave; qs < nd; qs += NW) { const int q = (int)rs[qs];
+        for (int ps = qs + lane; ps < nd; ps += 64) { const int pp = (int)rs[ps]; atomicAdd(L.at(rc[pp], rc[q]), -img[pp > q ? colstart(q) + pp : colstart(pp) + q]); } }
+    if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
+}
+
 template <int DV>
 __global__ __launch_bounds__(64 * ELIM_MFMA_NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_mfma_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
@@ -728,6 +843,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     if (blockIdx.x < nnarrow) schur_elim_mfma_body<DV>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
     else schur_elim_tiled_body<DV, 2, 3>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
+}
+
+// schur_elim_all_kernel with the narrow supernodes' member loop fed by LDS-DMA (schur_elim_mfma_dma_body).  The prologue keeps the inverse diagonal
+// blocks and the right-hand sides of the supernode's members in LDS as well (at most 128 members per supernode: build_schur).
+template <int DV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_all_dma_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                              const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
+                                                              double* __restrict__ Cinv, SLayout L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa) {
+    if (blockIdx.x >= pa.nfast) {
+        const int w = (int)(blockIdx.x - pa.nfast);
+        if (w == 0 && threadIdx.x == 0) pa.status[4] = 0;
+        if (w < pa.ninit) {
+            const int i = w * 256 + threadIdx.x;
+            if (i < L.n) { atomicAdd(L.rhs(s, i), b[pa.red_boff[i]]); return; }
+            if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+            return;
+        }
+        const SchurCopy cp = pa.copies[w - pa.ninit];
+        for (int e = threadIdx.x; e < cp.rows * cp.cols; e += 256) {
+            const int i = e % cp.rows, j = e / cp.rows;
+            double v = A[cp.off + e];
+            if (cp.r == cp.c) { if (i < j) continue; if (i == j) v += pa.lambda; atomicAdd(L.at(cp.r + i, cp.c + j), v); }
+            else if (cp.r > cp.c) atomicAdd(L.at(cp.r + i, cp.c + j), v);
+            else atomicAdd(L.at(cp.c + j, cp.r + i), v);
+        }
+        return;
+    }
+    // ONE LDS buffer for whichever body the workgroup runs (the larger of the two footprints, not their sum: three workgroups per CU)
+    constexpr int MAXM = 128;
+    constexpr int oRing = 0, oCinv = oRing + ELIM_MFMA_NW * ELIM_DMA_NS * ELIM_DMA_SLOT, oBv = oCinv + MAXM * DV * (DV + 1) / 2, oImg = oBv + MAXM * DV, oRc = oImg + 63 * 64 / 2 + 63 + 1,
+                  DMA_LDS = oRc + 64, TILED_LDS = schur_elim_tiled_lds<DV, 2>(), ALL_LDS = DMA_LDS > TILED_LDS ? DMA_LDS : TILED_LDS;
+    __shared__ __attribute__((aligned(16))) double ldsU[ALL_LDS];
+    double* const ringL = ldsU + oRing; double* const cinvL = ldsU + oCinv; double* const bvL = ldsU + oBv; double* const imgL = ldsU + oImg;
+    uint32_t* const rcL = reinterpret_cast<uint32_t*>(ldsU + oRc); uint32_t* const rsL = rcL + 64;
+    const ElimDesc d = desc[blockIdx.x];
+    const bool narrow = blockIdx.x < nnarrow;                  // (at most MAXM = 128 members per supernode: build_schur closes a supernode there)
+    {   // the members' inverse diagonal blocks (schur_cinv_kernel's arithmetic, same bits): to memory for the back-substitution, to LDS for this workgroup's loop
+        const int64_t dstride = (int64_t)DV * d.nd + DV * DV;
+        for (uint32_t m = threadIdx.x; m < d.nmem; m += 256) {
+            const double* Cg = A + d.dg0 + (int64_t)m * dstride; double C[DV * DV];
+#pragma unroll
+            for (int j = 0; j < DV; ++j)
+#pragma unroll
+                for (int i = j; i < DV; ++i) C[i + DV * j] = Cg[i + DV * j];
+            double bm[DV];
+#pragma unroll
+            for (int i = 0; i < DV; ++i) bm[i] = b[d.eb0 + m * DV + i];
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                double dd = C[j + DV * j] + pa.lambda;
+#pragma unroll
+                for (int k = 0; k < j; ++k) dd -= C[j + DV * k] * C[j + DV * k] * C[k + DV * k];
+                if (dd == 0.0 || dd != dd) { atomicCAS(pa.status, 0, 1); dd = 1.0; }
+                C[j + DV * j] = dd;
+#pragma unroll
+                for (int i = j + 1; i < DV; ++i) { double t = C[i + DV * j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) t -= C[i + DV * k] * C[j + DV * k] * C[k + DV * k];
+                    C[i + DV * j] = t / dd; }
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < DV; ++c2) {
+                double y[DV];
+#pragma unroll
+                for (int i = 0; i < DV; ++i) { double t = (i == c2) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) t -= C[i + DV * k] * y[k]; y[i] = t; }
+#pragma unroll
+                for (int i = 0; i < DV; ++i) y[i] /= C[i + DV * i];
+#pragma unroll
+                for (int i = DV - 1; i >= 0; --i) { double t = y[i];
+#pragma unroll
+                    for (int k = i + 1; k < DV; ++k) t -= C[k + DV * i] * y[k]; y[i] = t; }
+#pragma unroll
+                for (int i = 0; i < DV; ++i) { Cinv[(int64_t)(d.v0 + m) * (DV * DV) + i + DV * c2] = y[i]; if (narrow && i >= c2) cinvL[m * (DV * (DV + 1) / 2) + c2 * DV - c2 * (c2 - 1) / 2 + (i - c2)] = y[i]; }
+            }
+            if (narrow) {
+#pragma unroll
+                for (int i = 0; i < DV; ++i) bvL[m * DV + i] = bm[i];
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (narrow) { const ElimDmaLds lds{ringL, cinvL, bvL, imgL, rcL, rsL}; schur_elim_mfma_dma_body<DV>(A, d, rcflat, L, s, lds); }
+    else schur_elim_tiled_body<DV, 2, 3, true>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x, ldsU);
 }
 
 template <int DV, int NC, int TW>
@@ -2452,7 +2653,9 @@ int enqueue_solve_local(nlls_ctx* c) {
         const int ninit = (std::max(npad, n) + 255) / 256;
         PrepArgs pa{c->d_red_boff.p, c->d_copy.p, c->lambda, ninit, (uint32_t)c->n_fast_groups, c->d_status.p};
         const dim3 grid((unsigned)(c->n_fast_groups + ninit + c->ncopy));
-#define LAUNCH_ALL(DV) hipLaunchKernelGGL((schur_elim_all_kernel<DV>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nfast_narrow, pa)
+        const bool elim_dma = c->elim_dma;      // A/B: the narrow supernodes' member loop fed by LDS-DMA
+#define LAUNCH_ALL(DV) do { if (elim_dma) hipLaunchKernelGGL((schur_elim_all_dma_kernel<DV>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nfast_narrow, pa); \
+        else hipLaunchKernelGGL((schur_elim_all_kernel<DV>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nfast_narrow, pa); } while (0)
         if (c->fast_dv == 3) LAUNCH_ALL(3); else if (c->fast_dv == 2) LAUNCH_ALL(2); else LAUNCH_ALL(1);
 #undef LAUNCH_ALL
         HIPCHK(hipGetLastError());

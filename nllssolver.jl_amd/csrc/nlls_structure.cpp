@@ -39,7 +39,7 @@ static int fail(nlls_ctx* c, int code, const std::string& msg) { c->err = msg; r
 constexpr uint32_t LIGHT_MAX_ENTRIES = 256;    // one entry per lane of a 256-thread workgroup (192: 47.1 instead of 43.5 us in situ, 128: 60 -- tools/sweep_ab.py)
 constexpr uint32_t LIGHT_IMG_MAX     = 6144;   // doubles of LDS image (48 KiB) -> 3 workgroups per CU
 constexpr uint32_t HEAVY_ROW_ENTRIES = 128;    // rows with more entries get a workgroup of their own
-constexpr uint32_t HEAVY_MAX_ENTRIES = 1024;   // entries per heavy tile (two wavefronts x 8 pipeline stages); longer rows are split (PARTIAL)
+constexpr uint32_t HEAVY_MAX_ENTRIES_DEFAULT = 1024;   // entries per heavy tile (two wavefronts x 8 pipeline stages); longer rows are split (PARTIAL)
 
 // ---- the hot set ------------------------------------------------------------------------------------------------------------
 // every device buffer the LM loop reads or writes, in the order they are laid out in the arena.  NOT in it: the cost-order arrays of a
@@ -323,6 +323,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
                   E.light_lds = std::max(E.light_lds, t.data_len + t.b_len + t.nrows * per_row); }
                 light.push_back(t); if (partial) all_owner = false;
             };
+            // (NLLS_HEAVY_MAX_ENTRIES: A/B knob -- shorter heavy tiles spread a few long rows over more workgroups, at the price of atomic flushes)
+            const uint32_t HEAVY_MAX_ENTRIES = [] { const char* e = getenv("NLLS_HEAVY_MAX_ENTRIES"); const int v = e ? atoi(e) : 0; return v >= 128 ? (uint32_t)v : HEAVY_MAX_ENTRIES_DEFAULT; }();
             size_t r = 0;
             while (r < nrows) {
                 int64_t br = L.rows[r]; int64_t ne = L.rowptr[r + 1] - L.rowptr[r]; int64_t seglen = segs[br + 1] - segs[br];
