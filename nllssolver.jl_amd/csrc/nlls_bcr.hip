@@ -842,16 +842,19 @@ constexpr int DBB = 128;
 // (row I of L is read for the last time when row I of X is formed).  The sum leaves the matrix cores in the accumulator layout, which IS the B
 // operand layout of the product with X_II: no LDS round trip between the two.  Tiles beyond npad: identity.  Out: Dinv[b] column-major 128 x 128,
 // ones on the diagonal, zeros above it.  Also: the sentinel into x[0, n).
-__global__ __launch_bounds__(512) void dense_dinv_kernel(const double* __restrict__ S, const double* __restrict__ LiD, double* __restrict__ Dinv, double* __restrict__ x, int npad, int n) {
+// ONE: a single block b1 whose factored tiles are still in its panel's scratch slot (Lslot, column-major 128 x 128: the look-ahead factorisation inverts a block
+// the moment it is factored -- the rows below it are then ONE matrix product with the inverse); no sentinel.
+template <bool ONE>
+__global__ __launch_bounds__(512) void dense_dinv_kernel(const double* __restrict__ S, const double* __restrict__ LiD, double* __restrict__ Dinv, double* __restrict__ x, int npad, int n, int b1, const double* __restrict__ Lslot) {
     extern __shared__ __attribute__((aligned(16))) double sm[];          // the 36 lower tiles of the block, [16][BP] each
-    const int b = blockIdx.x, t = threadIdx.x, c0 = DBB * b;
-    if (t < DBB && c0 + t < n) x[c0 + t] = __longlong_as_double((long long)BCR_X_SENTINEL);
+    const int b = ONE ? b1 : (int)blockIdx.x, t = threadIdx.x, c0 = DBB * b;
+    if (!ONE && t < DBB && c0 + t < n) x[c0 + t] = __longlong_as_double((long long)BCR_X_SENTINEL);
     for (int e0 = t; e0 < DBB * DBB; e0 += 8 * 512) {      // consecutive threads walk a column of S; eight loads in flight per thread
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int e = e0 + 512 * u, i = e & 127, j = e >> 7, I = i >> 4, J = j >> 4; v[u] = 0.0;
             if (I == J) { const int gt = 8 * b + I; v[u] = gt < npad / 16 ? LiD[(size_t)gt * 256 + (i & 15) + 16 * (j & 15)] : ((i & 15) == (j & 15) ? 1.0 : 0.0); }
-            else if (I > J && c0 + i < npad) v[u] = S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)]; }
+            else if (I > J && c0 + i < npad) v[u] = ONE ? Lslot[(size_t)i + (size_t)DBB * j] : S[(size_t)(c0 + i) + (size_t)npad * (c0 + j)]; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int e = e0 + 512 * u, i = e & 127, j = e >> 7, I = i >> 4, J = j >> 4;
             if (I >= J) sm[bcr_dtile(I, J) * BTS + (i & 15) * BP + (j & 15)] = v[u]; }
@@ -940,12 +943,18 @@ __global__ __launch_bounds__(512) void dense_bwd_fused_kernel(DenseBwdArgs a) {
 #undef DBW_TILE
 #undef DBW_LOAD
 }
+// inverse of ONE freshly factored diagonal block (its tiles still in the panel's scratch slot) -> Dinv slot b
+void launch_dense_dinv_one(hipStream_t st, const double* LiD, const double* Lslot, double* Dinv_b, int npad, int b) {
+    static bool attr = false; constexpr int lds = (int)(sizeof(double) * 36 * BTS);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(dense_dinv_kernel<true>, dim3(1), dim3(512), lds, st, (const double*)nullptr, LiD, Dinv_b - (size_t)b * DBB * DBB, (double*)nullptr, npad, 0, b, Lslot);
+}
 // Dinv: ceil(n / 128) slots of 128 x 128 doubles
 void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, double* Dinv, int npad, int n, double* x, int* status) {
     const int NBB = (n + DBB - 1) / DBB; if (NBB <= 0) return;
     static bool attr = false; constexpr int lds = (int)(sizeof(double) * 36 * BTS);
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL(dense_dinv_kernel, dim3((unsigned)NBB), dim3(512), lds, st, S, LiD, Dinv, x, npad, n);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(dense_dinv_kernel<false>, dim3((unsigned)NBB), dim3(512), lds, st, S, LiD, Dinv, x, npad, n, 0, (const double*)nullptr);
     DenseBwdArgs a{S, Dinv, x, status, npad, n, NBB};
     hipLaunchKernelGGL(dense_bwd_fused_kernel, dim3((unsigned)NBB), dim3(512), 0, st, a);
 }

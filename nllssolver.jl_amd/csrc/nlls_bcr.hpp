@@ -54,6 +54,7 @@ struct DenseWin { int nwin = -1, strip = 0, ntot = 0; };
 void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac, DenseWin win = DenseWin{});
 void launch_dense_dcopy_all(hipStream_t st, double* S, const double* Dfac, int npad, int nwide, int first64, int n64);   // the factored diagonal blocks: slots of Dfac -> S   // wide: a 128-column panel (k counts panels of the width used)
 void launch_dense_bwd_diag(hipStream_t st, const double* S, const double* LiD, int npad, int kb, int n, const double* acc, double* x);
+void launch_dense_dinv_one(hipStream_t st, const double* LiD, const double* Lslot, double* Dinv_b, int npad, int b);   // look-ahead factorisation: inverse of one freshly factored 128 x 128 diagonal block
 void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, double* Dinv, int npad, int n, double* x, int* status);   // the whole backward substitution in one launch (+ the diagonal blocks' inverses)
 void launch_dense_bwd_step(hipStream_t st, const double* S, const double* LiD, int npad, int s, int n, double* acc, double* x);   // push block s's x into the blocks above, solve block s - 1
 

@@ -183,6 +183,8 @@ struct nlls_ctx {
     bool replicate_xr = false;               // the step's reduced part is written on every rank (sharded LM trial without the stage-2 reduction)
     int ps_np = 0, ps_np2 = 0;                 // partial counts of the last enqueue_post_solve (for the trial's finishing launch)
     int dense_t128_min = 16;                   // ... only while the trailing matrix has at least this many 128-blocks per side (fewer: the 64 x 64 kernel fills the chip better)
+    bool dense_pad128 = false;                 // the dense layout is padded to a multiple of 128 rows (windowed and look-ahead factorisations: 128-column panels only)
+    bool dense_lookahead = false;              // NLLS_DENSE_LOOKAHEAD=1 (A/B; built, parity-green, SLOWER: 6.2 against 3.7 ms at 6000 dof): the diagonal block factored + inverted by one workgroup on a second stream beside the bulk of the previous trailing update, the rows below as one matrix product
     bool dense_window = false;                 // dense LDL' restricted to the band of the (re-ordered) reduced system + the border strip: O(n w^2) instead of n^3 / 3 (build_schur decides)
     bool dense_t128 = true;                    // dense LDL': 128 x 128 tiles in the two-panel trailing update (NLLS_DENSE_T64=1: the 64 x 64 kernel, for A/B runs)
     bool dense_fused_bwd = true;               // dense LDL': the backward substitution in one launch (NLLS_DENSE_STEP_BACKWARD=1: one launch per 64-column block, for A/B runs)

@@ -1528,8 +1528,9 @@ constexpr int S128_KC = 16, S128_LD = 144;
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void syrk_update128_kernel(double* __restrict__ S, const double* __restrict__ W0, const double* __restrict__ W1, int npad, int k0, int jb0, int firstcol, int wq = -1, int wstrip = 0) {
     __shared__ double As[2][S128_KC * S128_LD], Bs[2][S128_KC * S128_LD];
     int ti, tj;                                                // firstcol: only the first tile column (what the next two panels wait for)
-    if (firstcol) { ti = blockIdx.x; tj = 0; }
-    else { const int tix = blockIdx.x; ti = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > tix) --ti; while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti; tj = tix - ti * (ti + 1) / 2; }
+    if (firstcol == 1) { ti = blockIdx.x; tj = 0; }
+    else { const int tix = blockIdx.x; ti = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > tix) --ti; while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti; tj = tix - ti * (ti + 1) / 2;
+           if (firstcol == 2) { ++ti; ++tj; } }                  // firstcol == 2: everything BUT the first tile column (the look-ahead factorisation: that column went ahead)
     // (windowed, wq >= 0: logical 128-row block t is row jb0 NB + 128 t inside the band window, 128 (wstrip + t - wq) in the bottom strip)
     const int I0 = (wq < 0 || ti < wq) ? jb0 * NB + 128 * ti : 128 * (wstrip + ti - wq), J0 = (wq < 0 || tj < wq) ? jb0 * NB + 128 * tj : 128 * (wstrip + tj - wq);
     const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
@@ -1597,6 +1598,80 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cg[(size_t)(16 * a + li) + (size_t)npad * (16 * b2 + lk + 4 * r)] = cold[a][r] - acc[a][b2][r];
     }
+}
+// The rows below a factored 128 x 128 diagonal block in ONE matrix product (look-ahead factorisation): with the explicit inverse X = inv(L_pp) of the
+// unit-lower block (dense_dinv_kernel<true>) the panel rows are  W = S(rows, panel) X'  and  L = W / Delta  -- no chain of tile-column steps, every
+// 128-row block of S independent work for a workgroup (syrk_update128_kernel's tiling: eight wavefronts, 64 x 32 each, operands through LDS in chunks
+// of 16 columns, products formed transposed so that the stores of a wavefront walk down columns).  Out: L in place of the rows in S, W = L Delta to
+// the panel workspace (the A operand of the trailing update).  Dslot: the factored diagonal block (Delta on its diagonal), column-major 128 x 128.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_trsm128_kernel(double* __restrict__ S, double* __restrict__ W, const double* __restrict__ Xinv, const double* __restrict__ Dslot, int npad, int p) {
+    __shared__ double As[2][S128_KC * S128_LD], Bs[2][S128_KC * S128_LD];
+    __shared__ double rd[128];
+    const int c0 = 128 * p, I0 = 128 * (p + 1 + (int)blockIdx.x);
+    const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
+    const int r0w = (w & 1) * 64, c0w = (w >> 1) * 32;
+    const bool active = I0 + r0w < npad;
+    if (t < 128) rd[t] = 1.0 / Dslot[(size_t)t * 129];
+    double4_t acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = double4_t{0, 0, 0, 0};
+    const int cr = t & 127, kq = t >> 7;
+    const int arow = I0 + cr < npad ? I0 + cr : npad - 1;
+    constexpr int NCP = S128_KC / 4, NCH = 128 / S128_KC;
+    double ra[2][NCP], rb[2][NCP];                             // (operand chunks requested two ahead, as in syrk_update128_kernel)
+    auto gload = [&](int chunk, int set) {
+        const int col0 = chunk * S128_KC;
+        const double* Ga = S + (size_t)arow + (size_t)npad * (c0 + col0);        // S(row, panel column k)
+        const double* Gb = Xinv + (size_t)cr + (size_t)128 * col0;               // X(j = cr, k)
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) { ra[set][i] = Ga[(size_t)npad * (kq + 4 * i)]; rb[set][i] = Gb[(size_t)128 * (kq + 4 * i)]; }
+    };
+    auto lstore = [&](int buf, int set) {
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) { As[buf][(kq + 4 * i) * S128_LD + cr] = ra[set][i]; Bs[buf][(kq + 4 * i) * S128_LD + cr] = rb[set][i]; }
+    };
+    auto products = [&](int buf) {
+        if (!active) return;
+#pragma unroll
+        for (int kk = 0; kk < S128_KC; kk += 4) {
+            double av[4], bv[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = As[buf][(kk + lk) * S128_LD + r0w + 16 * a + li];
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Bs[buf][(kk + lk) * S128_LD + c0w + 16 * b2 + li];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
+        }
+    };
+    gload(0, 0); gload(1, 1); lstore(0, 0);
+    __syncthreads();
+    static_assert(NCH % 2 == 0, "unrolled by two");
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ch += 2) {
+        if (ch + 2 < NCH) gload(ch + 2, 0);
+        products(0);
+        lstore(1, 1);
+        __syncthreads();
+        if (ch + 3 < NCH) gload(ch + 3, 1);
+        products(1);
+        if (ch + 2 < NCH) lstore(0, 0);
+        __syncthreads();
+    }
+    if (!active) return;
+    // (transposed tile: row = lane & 15 (+ 16 a), column = (lane >> 4) + 4 r (+ 16 b2), as in syrk_update128_kernel)
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = I0 + r0w + 16 * a + li, j = c0w + 16 * b2 + lk + 4 * r; const double wv = acc[a][b2][r];
+                if (i < npad) { W[(size_t)i + (size_t)npad * j] = wv; S[(size_t)i + (size_t)npad * (c0 + j)] = wv * rd[j]; }
+            }
 }
 // backward substitution L' x = z (unit diagonal), block by block from the bottom.  z = D^-1 L^-1 s is row n of the factor.
 // step 1 (one workgroup per 64-column block kb, many row blocks): partial[kb][j] = sum_{i > kb block} L[i][kb*64+j] * x[i]
@@ -2603,7 +2678,7 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
 }
 
 static SLayout make_layout(nlls_ctx* c) {
-    SLayout L{}; L.S = c->S.p; L.mode = c->solve_mode; L.n = (int)c->nred; L.npad = c->dense_window ? (((int)c->nred + 1 + 127) / 128) * 128 : (((int)c->nred + 1 + NB - 1) / NB) * NB;
+    SLayout L{}; L.S = c->S.p; L.mode = c->solve_mode; L.n = (int)c->nred; L.npad = c->dense_pad128 ? (((int)c->nred + 1 + 127) / 128) * 128 : (((int)c->nred + 1 + NB - 1) / NB) * NB;
     L.n_band = (int)c->n_band; L.bw = c->bw; L.nbd = c->nbd; L.H = c->band_H;
     return L;
 }
@@ -2810,6 +2885,39 @@ int enqueue_reduced_solve(nlls_ctx* c) {
                 if (w.ntot <= 0) continue;
                 if (w.ntot >= c->dense_t128_min) hipLaunchKernelGGL(syrk_update128_kernel, dim3(w.ntot * (w.ntot + 1) / 2), dim3(512), 0, c->stream, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 0, w.nwin, w.strip);
                 else { const int T = 2 * w.ntot; hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 0, 2 * w.nwin, 2 * w.strip); }
+            }
+            launch_dense_dcopy_all(c->stream, c->S.p, Dfac, npad, NB128, 2 * NB128, 0);
+            k = nblk;
+        } else if (c->dense_lookahead && c->dense_t128 && npad % 128 == 0 && npad >= 128 * 8) {
+            // LOOK-AHEAD: the 128-pivot chain of a diagonal block leaves the critical path.  A panel is three small launches -- the diagonal block factored by ONE
+            // workgroup (dense_panel_kernel without rows), its explicit inverse, and the rows below as one matrix product (dense_trsm128_kernel) -- instead of one
+            // launch in which every workgroup repeats the chain; the trailing update goes in two parts: the first tile column (what the next panel needs), then the rest,
+            // and the next diagonal block is factored and inverted on a second stream BESIDE the rest.  (Round 3 overlapped whole panels with whole updates: the
+            // 256-workgroup panel left no room beside it and the two event hand-overs per step cost more than the overlap gained; here the overlapped part is one workgroup.)
+            const int NB128 = npad / 128;
+            double* const Dinv = Dfac + (size_t)(npad / 64 + 1) * 128 * 128;                   // inverses of the diagonal blocks, one slot per 128-block (behind the panels' scratch slots)
+            const DenseWin norows{0, 0, 0};
+            hipStream_t sA = c->stream, sB = c->stream2;
+            auto factor = [&](hipStream_t st, int p) {
+                launch_dense_panel(st, c->S.p, Wbuf, LiD, npad, p, c->d_status.p, 1, Dfac, norows);
+                launch_dense_dinv_one(st, LiD, Dfac + (size_t)(2 * p) * 128 * 128, Dinv + (size_t)p * 128 * 128, npad, p);
+            };
+            factor(sA, 0);
+            for (int p = 0; p < NB128; ++p) {
+                const int T = NB128 - p - 1;                                                    // 128-row blocks behind the panel
+                if (T <= 0) break;
+                hipLaunchKernelGGL(dense_trsm128_kernel, dim3((unsigned)T), dim3(512), 0, sA, c->S.p, Wbuf, (const double*)(Dinv + (size_t)p * 128 * 128), (const double*)(Dfac + (size_t)(2 * p) * 128 * 128), npad, p);
+                if (T >= c->dense_t128_min) {
+                    hipLaunchKernelGGL(syrk_update128_kernel, dim3((unsigned)T), dim3(512), 0, sA, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 1, -1, 0);     // first tile column
+                    HIPCHK(hipEventRecord(c->ev_fork, sA)); HIPCHK(hipStreamWaitEvent(sB, c->ev_fork, 0));
+                    factor(sB, p + 1);                                                          // ... the next diagonal block, beside the rest of the update
+                    HIPCHK(hipEventRecord(c->ev_join, sB));
+                    if (T > 1) hipLaunchKernelGGL(syrk_update128_kernel, dim3((unsigned)((T - 1) * T / 2)), dim3(512), 0, sA, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 2, -1, 0);
+                    HIPCHK(hipStreamWaitEvent(sA, c->ev_join, 0));
+                } else {
+                    const int T64 = 2 * T; hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T64 * (T64 + 1) / 2), dim3(256), 0, sA, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 0, -1, 0);
+                    factor(sA, p + 1);
+                }
             }
             launch_dense_dcopy_all(c->stream, c->S.p, Dfac, npad, NB128, 2 * NB128, 0);
             k = nblk;

@@ -832,7 +832,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     }
     // ---- choose the reduced-system solver ----------------------------------------------------------------------
     const int64_t n = c->nred;
-    c->bw = (int)bw; c->solve_mode = SOLVE_DENSE; c->band_twisted = !(flags & NLLS_FLAG_NO_TWIST); c->dense_window = false;
+    c->bw = (int)bw; c->solve_mode = SOLVE_DENSE; c->band_twisted = !(flags & NLLS_FLAG_NO_TWIST); c->dense_window = false; c->dense_pad128 = false;
     if (n < 64) c->solve_mode = SOLVE_SMALL;
     else if (!I0.is_sparse) c->solve_mode = SOLVE_DENSE;
     else if (c->n_band >= 128 && !(flags & NLLS_FLAG_NO_BAND)) {
@@ -938,9 +938,10 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         // kernels, much narrower than the system: a 2-D camera grid, a loop closure -- the blocked LDL' is restricted to the band and the border strip
         // (enqueue_reduced_solve, `dense_window`): O(n w^2) work instead of n^3 / 3.  The reference's LDL' takes any sparsity (src/linearsolver.jl:28-32).
         c->dense_window = I0.is_sparse && c->nelim > 0 && c->n_band >= 1024 && !(flags & NLLS_FLAG_NO_BAND) && 2 * (bw + 256) < c->n_band && !getenv("NLLS_NO_DENSE_WINDOW");
-        const int64_t npad = c->dense_window ? ((n + 1 + 127) / 128) * 128 : ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
+        c->dense_pad128 = c->dense_window || (c->dense_lookahead && n + 1 >= 1024);
+        const int64_t npad = c->dense_pad128 ? ((n + 1 + 127) / 128) * 128 : ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
         // npad^2 doubles: what the DEVICE holds decides (288 GB on an MI355X: ~150 000 reduced dof), not a constant; the shim keeps the CPU system when it does not fit
-        const size_t lw = (size_t)std::max<int64_t>(npad * 128 + npad + (npad / 16) * 256 + 256 + (npad / 64 + 1) * 128 * 128, 1);
+        const size_t lw = (size_t)std::max<int64_t>(npad * 128 + npad + (npad / 16) * 256 + 256 + (npad / 64 + 1) * 128 * 128 + (npad / 128 + 1) * 128 * 128, 1);   // ... | inverses of the diagonal blocks (look-ahead)
         { size_t mfree = 0, mtotal = 0; const size_t want = sizeof(double) * ((size_t)npad * npad + (size_t)npad + 64 + lw);
           if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && want + ((size_t)2 << 30) > mfree)
               return fail(c, NLLS_ERR_UNSUPPORTED, "reduced system too large for the dense solver on this device (" + std::to_string(n) + " dof need " + std::to_string(want >> 20) + " MiB, " + std::to_string(mfree >> 20) + " MiB free)"); }
