@@ -234,12 +234,19 @@ def main():
               "lm_trials_per_s": [round(l.data.linearsolvers / e, 1) for e, l in runs]}
     trials_rates = sorted(l.data.linearsolvers / e for e, l in runs)
     trials_median = trials_rates[len(trials_rates) // 2]
-    # where the optimiser reaches its noise floor (untimed, one iteration per call): the first iteration whose relative cost decrease is below 1e-12
-    floor_at, trace = None, []
+    # where the optimiser reaches its noise floor (untimed, one iteration per call): the first iteration whose relative cost decrease is below 1e-12, and -- what
+    # actually costs time -- the iterations that needed more than one trial (a rejected step, src/iterators.jl:160-171: near the floor lambda has shrunk to the
+    # rounding level of the gauge-free reduced system and accept / reject is decided by the last bits of the cost; tools/step_residual.py)
+    floor_at, first_reject, n_reject_iters, trials_trace = None, None, 0, []
     if world == 1:
-        fl = fresh_loop(ls, problem, start_vars); prev = fl.data.bestcost
+        fl = fresh_loop(ls, problem, start_vars); prev = fl.data.bestcost; prev_solves = fl.data.linearsolvers
         for it in range(args.steps):
-            fl.iterations(1); cur = fl.data.bestcost; trace.append(cur)
+            fl.iterations(1); cur = fl.data.bestcost
+            k = fl.data.linearsolvers - prev_solves; prev_solves = fl.data.linearsolvers; trials_trace.append(int(k))
+            if k > 1:
+                n_reject_iters += 1
+                if first_reject is None:
+                    first_reject = it + 1
             if floor_at is None and not (prev - cur > 1e-12 * abs(prev)):
                 floor_at = it + 1
             prev = cur
@@ -407,7 +414,8 @@ def main():
                    # optimiser's noise floor (from about the 12th iteration of this problem) that happens often, so the rate
                    # of LM trials (damped solve + retraction + cost sweep) is the figure that does not depend on --steps
                    "lm_trials_per_s": round(data.linearsolvers / elapsed, 1), "lm_trials_per_s_median": round(trials_median, 1),
-                   "noise_floor_iterations": noise_floor_iterations, "noise_floor_from_iteration": floor_at},
+                   "noise_floor_iterations": noise_floor_iterations, "noise_floor_from_iteration": floor_at,
+                   "first_iteration_with_a_rejected_trial": first_reject, "iterations_with_rejected_trials": n_reject_iters, "trials_per_iteration": trials_trace},
             "spread": spread,
             "roofline": roofline, "roofline_solve": roofline_solve, "roofline_solve_dense": roofline_solve_dense, "cpu_baseline": cpu,
         }

@@ -23,6 +23,7 @@ cp profiles/pmc_mfma.json gpurun_out/${tag}_pmc_mfma.json
 cp profiles/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.json
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
 for w in ba_100x10k curvefit_10k ba_so3_500x50k ba_10kx1M; do python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_$w.json 2> gpurun_out/${tag}_bench_$w.err || exit 6; done
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --shuffle-cameras 7 > gpurun_out/${tag}_bench_shuffled.json 2> gpurun_out/${tag}_bench_shuffled.err || exit 15
 python bench.py --solver dense --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_dense.json 2> gpurun_out/${tag}_bench_dense.err || exit 7
 # rocprofv3 kernel stats of the other BASELINE configurations (2, 3, 5) and of the dense solver
 for w in ba_100x10k curvefit_10k ba_so3_500x50k; do rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_$w -- python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> gpurun_out/${tag}_stats_$w.err || exit 8; done
