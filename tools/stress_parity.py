@@ -13,7 +13,7 @@ fails = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
     try:
-        mode = seed % 5
+        mode = seed % 7           # (round 4: 5 = camera chains with SHUFFLED labels -- the reduced system is re-ordered at upload; 6 = 2-D camera grids, some shuffled: windowed dense solve)
         if mode == 3:            # SO(3) cameras, pinhole, optionally the adaptive kernel as a border variable (BASELINE config 5 kinds)
             ncam = int(rng.integers(6, 300)); npts = int(rng.integers(60, 6000)); prop = max(float(rng.uniform(0.02, 0.5)), 4.0 / ncam)
             adaptive = bool(rng.integers(0, 2))
@@ -24,9 +24,18 @@ for seed in range(lo, hi):
                 unfixed = np.ones(p.nvariables, bool); unfixed[rng.choice(p.nvariables, size=max(1, p.nvariables // 25), replace=False)] = False
             check_problem(p, unfixed=unfixed, lam_scale=1e-4 if robust is None or adaptive else 1e-1)
             continue
+        if mode == 6:
+            gw = int(rng.integers(5, 34)); gh = int(rng.integers(5, 34)); ppc = int(rng.integers(2, 6))
+            kind = int(rng.integers(0, 3)); robust = [None, N.HuberKernel(float(rng.uniform(0.01, 0.1))), N.GemanMcclureKernel(float(rng.uniform(0.05, 0.2)))][kind]
+            p = synthetic.create_grid_ba_problem(gw, gh, ppc, seed=seed, robust=robust, outlier_frac=0.05 if robust else 0.0, outlier_sigma=0.05, noise=1e-3)
+            if rng.random() < 0.5: p = synthetic.shuffle_camera_labels(p, gw * gh, seed)
+            p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
+            flags = [0, 0, _capi.FLAG_NO_REORDER, _capi.FLAG_FORCE_ATOMIC][int(rng.integers(0, 4))]
+            check_problem(p, flags=flags, lam_scale=[1e-4, 1e-3, 1e-1][kind])
+            continue
         if mode == 0:            # generic small shapes, all flags
             ncam = int(rng.integers(4, 60)); npts = int(rng.integers(20, 1500)); prop = max(float(rng.uniform(0.05, 0.6)), 3.5 / ncam)
-        elif mode == 1:          # camera chains: band mode with several BCR levels
+        elif mode == 1 or mode == 5:          # camera chains: band mode with several BCR levels (5: labels shuffled below)
             ncam = int(rng.integers(48, 400)); per = int(rng.integers(3, 12)); npts = int(rng.integers(10, 40)) * ncam; prop = per / ncam
         elif mode == 4:          # camera chains with a tail of widely seen landmarks: wide supernodes (generic LDS-budgeted elimination, both classes)
             ncam = int(rng.integers(48, 300)); per = int(rng.integers(3, 10)); npts = int(rng.integers(10, 30)) * ncam; prop = per / ncam
@@ -41,6 +50,7 @@ for seed in range(lo, hi):
             nw = int(rng.integers(1, 12))
             wide = {int(l): int(rng.integers(per + 2, ncam + 1)) if rng.random() < 0.8 else ncam for l in rng.choice(npts, size=nw, replace=False) + 1}
             p = synthetic.widen_visibility(p, ncam, wide)
+        if mode == 5: p = synthetic.shuffle_camera_labels(p, ncam, seed)
         p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
         unfixed = None
         if rng.random() < 0.4:
