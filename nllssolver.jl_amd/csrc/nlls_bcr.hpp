@@ -31,6 +31,7 @@ struct BcrSolver {
     std::vector<BcrLevel> levels;                 // elimination levels, the root block last
     DevBuf<double> ws; DevBuf<BcrElim> d_elim; DevBuf<BcrUpd> d_upd;
     bool fused_backward = true;
+    bool fold_convert = false;                    // NLLS_BCR_FOLD_CONVERT=1 (A/B): damped solves without the conversion launch -- the first level reads the band storage itself (measured: no gain)
     BcrGeom geom{};
     size_t panel_lds = 0, back_lds = 0;
     int chrows_slots = 256;                       // a level's panel launch uses fewer X rows per workgroup while its workgroups still fit this many CUs (NLLS_BCR_CHROWS_SLOTS=0: always three)
