@@ -35,6 +35,11 @@ constexpr int BP = 17, BTS = 16 * BP;             // LDS tile: 16 rows padded to
 constexpr int BCR_T = 512;                        // threads of the panel kernel: wave 0 factors, seven waves help
 constexpr int BCR_MAXNT = 5;
 constexpr unsigned long long BCR_X_SENTINEL = 0x7ff8dead5eed1234ull;   // a NaN with a payload no arithmetic produces: "not published yet"
+// A hand-off that never arrives (a workgroup that was not dispatched: dispatch order is no contract) must not hang the queue: the poll is bounded on the CONSTANT
+// 100 MHz clock (s_memrealtime -- the shader clock of s_memtime / readcyclecounter moves with the power state) at half a second, and says so with a status code of its
+// own (BCR_STATUS_HANDOFF_TIMEOUT: the host reports NLLS_ERR_HIP "hand-off timed out", not a bad pivot)
+constexpr unsigned long long BCR_HANDOFF_TICKS = 50000000ull;          // 0.5 s at 100 MHz
+constexpr int BCR_STATUS_HANDOFF_TIMEOUT = 0x40000000;
 
 #define BCR_DEV __device__ __forceinline__
 
@@ -798,11 +803,11 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
             if (R < NT) { if (job.l >= 0) { const int row = b * job.l + 16 * R + q; if (row < g.n_band) src = a.xr + row; } }
             else if (R < 2 * NT) { if (job.r >= 0) { const int row = b * job.r + 16 * (R - NT) + q; if (row < g.n_band) src = a.xr + row; } }
             else if (q < nbd) src = g.ws + g.oxb + q; else xpre = q == nbd ? -1.0 : 0.0;
-            if (src) {   // (bounded: half a second on the 100 MHz constant clock, then the solve is flagged instead of hanging the queue)
-                const unsigned long long t0 = __builtin_readcyclecounter();
+            if (src) {   // (bounded: half a second on the constant 100 MHz clock, then the solve is flagged with BCR_STATUS_HANDOFF_TIMEOUT instead of hanging the queue)
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) { xpre = bcr_xload(src); if ((unsigned long long)__double_as_longlong(xpre) != BCR_X_SENTINEL) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (__builtin_readcyclecounter() - t0 > 1200000000ull) { atomicCAS(a.status, 0, 1 + g.n_band + 64); break; } }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > BCR_HANDOFF_TICKS) { atomicCAS(a.status, 0, BCR_STATUS_HANDOFF_TIMEOUT); break; } }
             }
         }
     }
@@ -963,11 +968,11 @@ __global__ __launch_bounds__(512) void dense_bwd_fused_kernel(DenseBwdArgs a) {
     for (int s = a.NBB - 1; s > j; --s) {
         if (t < DBB) {
             const int g = DBB * s + t; double v = 0.0;
-            if (g < n) {   // (bounded: half a second on the 100 MHz constant clock, then the solve is flagged instead of hanging the queue)
-                const unsigned long long t0 = __builtin_readcyclecounter();
+            if (g < n) {   // (bounded: half a second on the constant 100 MHz clock, then the solve is flagged with BCR_STATUS_HANDOFF_TIMEOUT instead of hanging the queue)
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) { v = bcr_xload(a.x + g); if ((unsigned long long)__double_as_longlong(v) != BCR_X_SENTINEL) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (__builtin_readcyclecounter() - t0 > 1200000000ull) { atomicCAS(a.status, 0, 1 + n + 64); break; } }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > BCR_HANDOFF_TICKS) { atomicCAS(a.status, 0, BCR_STATUS_HANDOFF_TIMEOUT); break; } }
             }
             xs[s & 1][t] = v;
         }

@@ -49,6 +49,7 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     { const char* e = getenv("NLLS_POST_SPLIT"); if (e && e[0] == '1') c->post_fuse = false; }
     { const char* e = getenv("NLLS_ELIM_SPLIT"); if (e && e[0] == '1') c->elim_split = true; }
     { const char* e = getenv("NLLS_DENSE_LOOKAHEAD"); if (e && e[0] == '1') c->dense_lookahead = true; }
+    { const char* e = getenv("NLLS_ELIM_FOLD"); if (e && e[0] == '1') c->elim_fold = true; }      // A/B: tiny supernodes folded into their large neighbours (measured slower: off)
     { const char* e = getenv("NLLS_ELIM_DMA"); if (e && e[0] == '1') c->elim_dma = true; }      // A/B: the narrow supernodes' member loop fed by LDS-DMA (measured slower: off)
     { const char* e = getenv("NLLS_SWEEP_SPLIT3"); if (e && e[0] == '1') c->sweep_split3 = true; }
     { const char* e = getenv("NLLS_DENSE_STEP_BACKWARD"); if (e && e[0] == '1') c->dense_fused_bwd = false; }
@@ -242,6 +243,12 @@ int nlls_grad_quadform(nlls_ctx* ctx, double* out) {
     if (out) *out = ctx->h_scalars[6]; return NLLS_OK;
 }
 
+// what a non-zero factorisation status means: a bad pivot (NLLS_ERR_NOT_SPD: the iterators damp more and retry) or a hand-off inside a one-launch backward pass that
+// timed out (0x40000000, nlls_bcr.hip: not a property of the system -- NLLS_ERR_HIP; NLLS_BCR_LEVEL_BACKWARD=1 / NLLS_DENSE_STEP_BACKWARD=1 select the per-level launches)
+static int status_error(nlls_ctx* ctx, int32_t st, const char* what) {
+    if (st == 0x40000000) return fail(ctx, NLLS_ERR_HIP, "a hand-off between workgroups of the one-launch backward substitution timed out (0.5 s): not a pivot failure -- NLLS_BCR_LEVEL_BACKWARD=1 / NLLS_DENSE_STEP_BACKWARD=1 select the per-level launches");
+    return fail(ctx, NLLS_ERR_NOT_SPD, std::string(what) + " (code " + std::to_string(st) + ")");
+}
 int nlls_damp(nlls_ctx* ctx, double delta) { NEED_GRAD_LAZY(); ctx->lambda += delta; return NLLS_OK; }
 
 int nlls_solve(nlls_ctx* ctx, double* x_out) {
@@ -259,7 +266,7 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->solved = true;
     if (precompute) { status[0] = (int32_t)ctx->h_scalars[10]; ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9]; }
-    if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");
+    if (status[0] != 0) return status_error(ctx, status[0], "factorisation met a non-positive pivot");
     return NLLS_OK;
 }
 // One Levenberg-Marquardt trial in one call and one synchronisation (src/iterators.jl:149-157): uniformscaling!(H, dlambda),
@@ -311,7 +318,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     ctx->status_known_zero = status[0] == 0;       // (nothing has touched the device's status word since: the next solve need not reset it)
     ctx->solved = true;
     ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9];
-    if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a non-positive pivot (code " + std::to_string(status[0]) + ")");
+    if (status[0] != 0) return status_error(ctx, status[0], "factorisation met a non-positive pivot");
     if (cost_out) *cost_out = ctx->h_scalars[0];
     return NLLS_OK;
 }
@@ -333,7 +340,7 @@ int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
         out[4] = ctx->h_scalars[9]; out[5] = ctx->h_scalars[10];
         return NLLS_OK;
     }
-    if ((int32_t)ctx->h_scalars[10] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a zero pivot (code " + std::to_string((int32_t)ctx->h_scalars[10]) + ")");
+    if ((int32_t)ctx->h_scalars[10] != 0) return status_error(ctx, (int32_t)ctx->h_scalars[10], "factorisation met a zero pivot");
     return NLLS_OK;
 }
 // nlls_solve_finish_async for a sharded LM trial: the reduced part of the step stays on every rank (no stage-2 reduction afterwards)
@@ -468,7 +475,7 @@ int nlls_solve_finish(nlls_ctx* ctx, double* x_out) {
     if (x_out) HIPCHK(hipMemcpyAsync(x_out, ctx->x.p, sizeof(double) * ctx->info.ndof, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->solved = true;
-    if (status[0] != 0) return fail(ctx, NLLS_ERR_NOT_SPD, "factorisation met a zero pivot (code " + std::to_string(status[0]) + ")");
+    if (status[0] != 0) return status_error(ctx, status[0], "factorisation met a zero pivot");
     return NLLS_OK;
 }
 int nlls_solve_finish_async(nlls_ctx* ctx) {          // enqueue only: the status comes home with nlls_trial_local's scalars

@@ -96,6 +96,14 @@ struct ElimDesc {
     int64_t dg0;             // A.data offset of the first member's diagonal block
     uint32_t eb0, pad;       // b offset of the first member
 };
+// A member of a tiny supernode folded into a neighbouring large one (build_schur, "fold"): the large supernode's columns are a prefix or a suffix of its own, so its
+// share of S over those columns rides in the large supernode's accumulators and flush; only the strip of its nx extra columns is added to S on its own.
+struct ElimPre {
+    int64_t e0;              // A.data offset of the member's row [E (DV x ndf) | C]
+    uint32_t eb, v;          // offset of its right-hand side in b; its index among the eliminated members (inverse block, back-substitution)
+    uint32_t ndf, xoff;      // columns of its own E; column of its row where the host supernode's columns start (0: extra columns behind them, nx: in front)
+    uint32_t rc_off, nx;     // its own reduced-column list in d_elim_rc; extra columns
+};
 struct SchurNbr {            // one off-diagonal block touching an eliminated block
     int64_t off;             // offset in A.data
     uint32_t rcol;           // dof offset of the neighbour in the reduced system
@@ -217,6 +225,9 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_elim_group;     // supernodes: runs of eliminated blocks with identical neighbour sets
     int64_t nelim_groups = 0, n_fast_groups = 0, n_slow_groups = 0;
     nlls::DevBuf<uint32_t> d_fast_groups, d_slow_groups, d_slow_blocks;   // d_slow_blocks: members of the slow supernodes
+    // the elimination's own view of the fast supernodes (single rank, one-launch assembly): tiny supernodes whose columns extend a neighbouring large one's by a few are
+    // folded into it as extra members (ElimPre) -- half of the launch's atomics and a quarter of its vector instructions are theirs
+    nlls::DevBuf<nlls::ElimDesc> d_elim_desc_fold; nlls::DevBuf<nlls::ElimPre> d_elim_pre; int64_t n_fold_groups = 0, n_fold_narrow = 0, n_folded = 0; bool elim_fold = false;   // NLLS_ELIM_FOLD=1 (A/B; parity-green, SLOWER: 316 against 294 us per solve at config 4 -- the tiny supernodes were filling idle slots; folded, their strips lengthen the workgroups that set the launch's pace)
     nlls::DevBuf<nlls::ElimDesc> d_elim_desc; nlls::DevBuf<uint32_t> d_elim_rc;   // per fast supernode (launch order): descriptor, reduced column of every E column
     nlls::DevBuf<uint32_t> d_fast_members;   // members of the fast supernodes
     nlls::DevBuf<uint8_t> d_blk_slowmask;    // d_blk entries NOT in rows of fast members (and owned by this rank)

@@ -569,12 +569,14 @@ __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ 
     // with a row start, right-hand-side offset and inverse-block index of their own (uniform values, selected per member); the strip of their extra columns follows
     // behind the flush.
     const uint32_t npre = (pre != nullptr && d.pad != 0) ? d.pad >> 24 : 0u, pre0 = d.pad & 0xFFFFFFu, nall = nmem + npre;
-    const double* ebase[4]; bool live[4], isb[4];               // member m's operand value sits at ebase[r] + (a column of E: offE(m); the right-hand side: offB(m))
+    int64_t pe0_0 = 0, pe0_1 = 0, pe0_2 = 0, pe0_3 = 0; uint32_t peb_0 = 0, peb_1 = 0, peb_2 = 0, peb_3 = 0, pv_0 = 0, pv_1 = 0, pv_2 = 0, pv_3 = 0;
+    if (npre > 0) { const ElimPre q = pre[pre0 + 0]; pe0_0 = q.e0 + (int64_t)DV * q.xoff; peb_0 = q.eb; pv_0 = q.v; }
+    if (npre > 1) { const ElimPre q = pre[pre0 + 1]; pe0_1 = q.e0 + (int64_t)DV * q.xoff; peb_1 = q.eb; pv_1 = q.v; }
+    if (npre > 2) { const ElimPre q = pre[pre0 + 2]; pe0_2 = q.e0 + (int64_t)DV * q.xoff; peb_2 = q.eb; pv_2 = q.v; }
+    if (npre > 3) { const ElimPre q = pre[pre0 + 3]; pe0_3 = q.e0 + (int64_t)DV * q.xoff; peb_3 = q.eb; pv_3 = q.v; }
+    int lofs[4]; bool live[4], isb[4];                          // member m's operand value: A[row(m) + lofs[r]] (a column of E) or b[rhs(m) + kk] (the right-hand side)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int col = 16 * r + li; live[r] = col <= nd && kslot; isb[r] = col >= nd;
-        ebase[r] = isb[r] ? b + eb0 + kk : A + dg0 + (int64_t)DV * col - (int64_t)DV * nd + kk;
-    }
+    for (int r = 0; r < 4; ++r) { const int col = 16 * r + li; live[r] = col <= nd && kslot; isb[r] = col >= nd; lofs[r] = DV * (isb[r] ? 0 : col) + kk; }
     const int64_t e0row = dg0 - (int64_t)DV * nd;
     double4_t acc[10];
 #pragma unroll
@@ -585,12 +587,12 @@ __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ 
         double en[PF][TR], cn[PF][DV];
         auto issue = [&](uint32_t m, int slot) {              // unconditional, clamped loads (a predicated load becomes copy + vmcnt(0))
             const uint32_t mm = m < nall ? m : nall - 1;
-            int64_t offE, offB; uint32_t vi;                   // uniform: the member's row / right-hand side relative to the supernode's first member, its inverse-block index
-            if (mm < nmem) { offE = (int64_t)mm * dstride; offB = (int64_t)mm * DV; vi = v0 + mm; }
-            else { const ElimPre* q = pre + pre0 + (mm - nmem);            // (uniform address: scalar loads; a select chain over four register copies became a table in scratch memory)
-                   offE = q->e0 + (int64_t)DV * q->xoff - e0row; offB = (int64_t)q->eb - (int64_t)eb0; vi = q->v; }
+            int64_t ro; uint32_t bo, vi;                       // uniform: row start in A.data, right-hand side in b, inverse-block index
+            if (mm < nmem) { ro = e0row + (int64_t)mm * dstride; bo = eb0 + mm * DV; vi = v0 + mm; }
+            else { const uint32_t q = mm - nmem; ro = q == 0 ? pe0_0 : (q == 1 ? pe0_1 : (q == 2 ? pe0_2 : pe0_3)); bo = q == 0 ? peb_0 : (q == 1 ? peb_1 : (q == 2 ? peb_2 : peb_3));
+                   vi = q == 0 ? pv_0 : (q == 1 ? pv_1 : (q == 2 ? pv_2 : pv_3)); }
 #pragma unroll
-            for (int r = 0; r < TR; ++r) en[slot][r] = ebase[r][isb[r] ? offB : offE];
+            for (int r = 0; r < TR; ++r) { const double* src = isb[r] ? b + bo + kk : A + ro + lofs[r]; en[slot][r] = *src; }
 #pragma unroll
             for (int j = 0; j < DV; ++j) cn[slot][j] = Cinv[(int64_t)vi * (DV * DV) + j + DV * kk];   // row lk of the (symmetric) inverse
         };
@@ -844,9 +846,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int64_t dstride = (int64_t)DV * d.nd + DV * DV;
         const uint32_t npre = pre != nullptr ? d.pad >> 24 : 0u, pre0 = d.pad & 0xFFFFFFu;          // folded members: their inverse blocks are this workgroup's job too
         for (uint32_t m = threadIdx.x; m < d.nmem + npre; m += 256) {
-            const bool ispre = m >= d.nmem; ElimPre pm{}; if (ispre) pm = pre[pre0 + (m - d.nmem)];
-            const double* Cg = ispre ? A + pm.e0 + (int64_t)DV * pm.ndf : A + d.dg0 + (int64_t)m * dstride; double C[DV * DV];
-            const int64_t vidx = ispre ? (int64_t)pm.v : (int64_t)(d.v0 + m);
+            const bool ispre = m >= d.nmem; int64_t pm_e0 = 0; uint32_t pm_ndf = 0, pm_v = 0; if (ispre) { const ElimPre* q = pre + pre0 + (m - d.nmem); pm_e0 = q->e0; pm_ndf = q->ndf; pm_v = q->v; }
+            const double* Cg = ispre ? A + pm_e0 + (int64_t)DV * pm_ndf : A + d.dg0 + (int64_t)m * dstride; double C[DV * DV];
+            const int64_t vidx = ispre ? (int64_t)pm_v : (int64_t)(d.v0 + m);
 #pragma unroll
             for (int j = 0; j < DV; ++j)
 #pragma unroll

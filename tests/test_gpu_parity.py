@@ -505,7 +505,7 @@ def test_three_slot_sweep_in_one_launch_per_role(monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"NLLS_DENSE_T64": "1"}, {"NLLS_DENSE_T128_MIN": "1"}, {"NLLS_ELIM_TILED": "1"}, {"NLLS_BCR_CHROWS_SLOTS": "0"},
                                  {"NLLS_DENSE_STEP_BACKWARD": "1"}, {"NLLS_BCR_LEVEL_BACKWARD": "1"}, {"NLLS_ELIM_SPLIT": "1"}, {"NLLS_POST_SPLIT": "1"},
-                                 {"NLLS_ELIM_DMA": "1"}, {"NLLS_HEAVY_MAX_ENTRIES": "256"}, {"NLLS_DENSE_LOOKAHEAD": "1"}, {"NLLS_BCR_FOLD_CONVERT": "1"}])
+                                 {"NLLS_ELIM_DMA": "1"}, {"NLLS_HEAVY_MAX_ENTRIES": "256"}, {"NLLS_DENSE_LOOKAHEAD": "1"}, {"NLLS_BCR_FOLD_CONVERT": "1"}, {"NLLS_ELIM_FOLD": "1"}])
 def test_ab_switches_select_paths_that_still_match_the_oracle(env, monkeypatch):
     """The environment switches read by nlls_create (the register-tiled elimination instead of the matrix-core one, the
     64 x 64-tile dense update instead of the 128 x 128 one, the 128 x 128 one from the first pass on, three X rows per panel workgroup at every

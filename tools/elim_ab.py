@@ -16,10 +16,11 @@ ctx.set_variables(p.variables); ctx.sweep_gradhess(); ctx.damp(1e-3 * ctx.max_ab
 x = ctx.solve(want_x=True).copy()
 c = ctx.lm_trial(0.0)
 ms = ctx.time_solve(20)
-tag = os.environ.get("NLLS_ELIM_DMA", "0")
+tag = os.environ.get("NLLS_ELIM_DMA", "0") + os.environ.get("NLLS_ELIM_NO_FOLD", "0")
 np.save(f"/tmp/elim_x_{wl}_{tag}.npy", x)
-other = f"/tmp/elim_x_{wl}_{'0' if tag == '1' else '1'}.npy"
+other = f"/tmp/elim_x_{wl}_{os.environ.get('OTHER', '00')}.npy"
 diff = None
 if os.path.exists(other):
     xo = np.load(other); diff = float(np.max(np.abs(x - xo)) / np.max(np.abs(xo)))
-print(json.dumps({"workload": wl, "elim_dma": tag, "solve_ms": ms, "trial_cost": c, "x_rel_diff_vs_other": diff}))
+st = ctx.solve_stats()
+print(json.dumps({"workload": wl, "tag": tag, "supernodes": st["elim_supernodes"], "solve_ms": ms, "trial_cost": c, "x_rel_diff_vs_other": diff}))
