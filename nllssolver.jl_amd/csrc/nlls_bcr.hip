@@ -679,8 +679,9 @@ void launch_dense_bwd_step(hipStream_t st, const double* S, const double* LiD, i
 // ---------------------------------------------------------------------------------------------------
 // (Sb != nullptr: the level's RMW jobs -- u.pad = 1 + block for a D tile, -(1 + block) for a border / rhs tile, the tile from dst -- take their OLD value from the
 //  band storage instead of the tile: the first level of a solve whose tiles were never converted)
-template <int NT>
-__global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs, BcrGeom g, const double* __restrict__ Sb) {
+struct BcrUpdBand { BcrGeom g; const double* Sb; };
+template <int NT, bool BAND>
+__device__ __forceinline__ void bcr_update_body(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs, const BcrGeom* gp, const double* __restrict__ Sb) {
     const int j = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); if (j >= njobs) return;
     const BcrUpd u = jobs[j];
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
@@ -710,7 +711,8 @@ __global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws
     double old[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) old[r] = u.mode == 0 ? dst[64 * r] : 0.0;
-    if (Sb != nullptr && u.mode == 0 && u.pad != 0) {
+    if constexpr (BAND) { if (u.mode == 0 && u.pad != 0) {
+        const BcrGeom& g = *gp;
         const int sp = (int)u.pad, bsz = 16 * NT;
         if (sp > 0) { const int j = sp - 1, ND = NT * (NT + 1) / 2, t = (int)((u.dst - g.oD) / 256) - j * ND; int I = 0; while ((I + 1) * (I + 2) / 2 <= t) ++I; const int K = t - I * (I + 1) / 2;
 #pragma unroll
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws
         else { const int j = -sp - 1, K = (int)((u.dst - g.oBR) / 256) - j * NT;
 #pragma unroll
             for (int r = 0; r < 4; ++r) old[r] = bcr_band_br(g, Sb, lk + 4 * r, bsz * j + 16 * K + li); }
-    }
+    } }
     bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -737,6 +739,10 @@ __global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws
         dst[64 * r] = u.mode == 2 ? v : old[r] - v;
     }
 }
+template <int NT>
+__global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs) { bcr_update_body<NT, false>(ws, jobs, njobs, nullptr, nullptr); }
+template <int NT>
+__global__ __launch_bounds__(256) void bcr_update_band_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs, BcrUpdBand bb) { bcr_update_body<NT, true>(ws, jobs, njobs, &bb.g, bb.Sb); }
 
 // ---------------------------------------------------------------------------------------------------
 // backward pass of one level: one workgroup per block eliminated at that level
@@ -1140,7 +1146,10 @@ static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel&
     if (relfloor > 0.0) hipLaunchKernelGGL(bcr_panel_kernel<true>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     else if (Sb_first) hipLaunchKernelGGL((bcr_panel_kernel<false, true>), dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     else hipLaunchKernelGGL(bcr_panel_kernel<false>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
-    if (lv.nupd > 0) hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd, S.geom, Sb_first);
+    if (lv.nupd > 0) {
+        if (Sb_first) hipLaunchKernelGGL((bcr_update_band_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd, BcrUpdBand{S.geom, Sb_first});
+        else hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd);
+    }
 }
 template <int NT>
 static void bcr_launch_back(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, double* xr, int root, int* status) {

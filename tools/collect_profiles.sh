@@ -2,7 +2,7 @@
 # usage (in the repository, after `gpurun -- tools/measure_round.sh <tag>` has merged gpurun_out/ back): tools/collect_profiles.sh <tag>
 # copies what is judged from the scratch directory into profiles/ under the names profiles/README.md lists
 t=$1; o=gpurun_out; p=profiles
-last() { ls $1 2>/dev/null | sort | tail -1; }
+last() { ls -t $1 2>/dev/null | head -1; }   # the NEWEST match (a tag measured twice leaves both runs in the scratch directory)
 cp $o/${t}_bench.json $p/${t}_bench.json
 cp $o/${t}_bench_prof.json $p/${t}_bench_under_rocprof.json
 cp "$(last "$o/${t}_stats/*/*kernel_stats.csv")" $p/${t}_kernel_stats.csv
