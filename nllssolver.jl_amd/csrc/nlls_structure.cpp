@@ -604,19 +604,24 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { const int64_t col = c->it_rowval[q]; if (col != row && rid[col] >= 0) { add(rid[row], rid[col]); add(rid[col], rid[row]); } } }
             bool graph_ok = true;
             if ((flags & NLLS_FLAG_PRESHARDED) && c->nranks > 1) {
-                // every rank sees the couplings of ITS eliminated blocks only: the graph is the union over ranks (one double per pair of the lower
-                // triangle, MAX-reduced -- up to 4096 reduced blocks = 67 MB; beyond that the caller's order stays: every rank decides alike)
-                if (nRb > 4096) graph_ok = false;
-                else {
-                    const size_t npair = (size_t)nRb * (nRb - 1) / 2;
-                    std::vector<double> hp(npair, 0.0);
-                    for (int32_t a = 0; a < nRb; ++a) for (int32_t b2 : adj[a]) if (b2 < a) hp[(size_t)a * (a - 1) / 2 + b2] = 1.0;
-                    DevBuf<double> dp; HIPCHK(dp.upload(hp));
-                    { const int rc = comm_reduce(c, dp.p, (int64_t)npair, NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
-                    HIPCHK(hipStreamSynchronize(c->stream));
-                    HIPCHK(hipMemcpy(hp.data(), dp.p, sizeof(double) * npair, hipMemcpyDeviceToHost));
+                // every rank sees the couplings of ITS eliminated blocks only: the graph is the union over ranks.  The edges are GATHERED with the one primitive there is
+                // (an all-reduce): the ranks' edge counts first (a sum over a [nranks] vector, each rank writing its own slot), then every rank writes its edges -- one double
+                // per edge, a * nRb + b: exact up to 2^53 -- into its own segment of a buffer of the total length, zeros elsewhere; the sum is the concatenation.
+                std::vector<double> hc((size_t)c->nranks, 0.0);
+                { size_t ne = 0; for (int32_t a = 0; a < nRb; ++a) for (int32_t b2 : adj[a]) ne += b2 < a; hc[c->rank] = (double)ne; }
+                DevBuf<double> dc; HIPCHK(dc.upload(hc));
+                { const int rc = comm_reduce(c, dc.p, (int64_t)hc.size(), NLLS_REDUCE_SUM); if (rc != NLLS_OK) return rc; }
+                HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMemcpy(hc.data(), dc.p, sizeof(double) * hc.size(), hipMemcpyDeviceToHost));
+                size_t total = 0, my0 = 0; for (int r = 0; r < c->nranks; ++r) { if (r == c->rank) my0 = total; total += (size_t)hc[r]; }
+                if ((double)nRb * (double)nRb >= 9.0e15 || total > ((size_t)1 << 31)) graph_ok = false;       // (every rank decides alike: the counts are the same everywhere)
+                else if (total > 0) {
+                    std::vector<double> he(total, 0.0);
+                    { size_t q = my0; for (int32_t a = 0; a < nRb; ++a) for (int32_t b2 : adj[a]) if (b2 < a) he[q++] = (double)a * (double)nRb + (double)b2; }
+                    DevBuf<double> de; HIPCHK(de.upload(he));
+                    { const int rc = comm_reduce(c, de.p, (int64_t)total, NLLS_REDUCE_SUM); if (rc != NLLS_OK) return rc; }
+                    HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMemcpy(he.data(), de.p, sizeof(double) * total, hipMemcpyDeviceToHost));
                     for (auto& l : adj) l.clear();
-                    for (int32_t a = 1; a < nRb; ++a) for (int32_t b2 = 0; b2 < a; ++b2) if (hp[(size_t)a * (a - 1) / 2 + b2] != 0.0) { adj[a].push_back(b2); adj[b2].push_back(a); }
+                    for (double e : he) { const int64_t k = (int64_t)e; const int32_t a = (int32_t)(k / nRb), b2 = (int32_t)(k % nRb); if (a > b2 && a < nRb) { adj[a].push_back(b2); adj[b2].push_back(a); } }
                 }
             }
             if (graph_ok) {
