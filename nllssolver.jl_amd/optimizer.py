@@ -170,7 +170,15 @@ class OuterLoop:
         data, ls, options = self.data, self.data.linsystem, self.options
         data.iternum += 1
         cost = float(self.iterate(self.iteratedata, data, self.problem, options))   # :126
+        if self.callback is not nullcallback:
+            # a user callback sees the trial point where the reference puts it -- problem.varnext (src/optimize.jl:128) -- and what it writes there counts: the
+            # reference's EM callback rewrites the kernel variable in varnext (test/adaptivecost.jl:15-25, src/robustadaptive.jl:48-73) and updatefromnext! then
+            # makes it the current point.  So: the next variables up before the callback, and down again after it when they changed.
+            self.problem.varnext = ls.variables(VARS_NEXT)
+            before = self.problem.varnext.copy()
         cost, terminate = self.callback(cost, self.problem, data, self.iteratedata)   # :128
+        if self.callback is not nullcallback and not np.array_equal(before, self.problem.varnext, equal_nan=True):
+            ls.ctx.set_variables(np.ascontiguousarray(self.problem.varnext, np.float64), VARS_NEXT)
         dcost = data.bestcost - cost
         if dcost >= 0:
             data.bestcost = cost

@@ -60,6 +60,7 @@ class NLLSProblem:
         self._chunks = []          # storage chunks (1-D f64)
         self._packed = None
         self.costs = {}            # insertion-ordered: key -> CostGroup   (CostStruct = VectorRepo)
+        self.varnext = None        # packed trial point (problem.varnext, src/problem.jl:11): filled before a user callback runs, read back after it
         self._gpu = None           # cached device context (see linearsystem.py)
 
     # ---- variables ---------------------------------------------------------------------------

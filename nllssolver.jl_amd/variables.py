@@ -27,3 +27,26 @@ def contaminated_gaussian(s1, s2, w):
 def contaminated_gaussian_params(storage):
     """params(var)  src/robustadaptive.jl:23"""
     return np.array([1.0 / storage[0], 1.0 / storage[1], storage[2]])
+
+
+def contaminated_gaussian_em(storage, squarederrors, maxiters=10):
+    """optimize(kernel::ContaminatedGaussian, squarederrors, maxiters)  src/robustadaptive.jl:48-73: the kernel's parameters by Expectation-Maximization
+    on the blocks' squared errors (host side in the reference too: it is what the EM callback of test/adaptivecost.jl:15-25 calls between two iterations).
+    storage = (1/sigma1, 1/sigma2, w); returns the new storage."""
+    err = np.asarray(squarederrors, dtype=np.float64)
+    k = np.array(storage, dtype=np.float64)
+    total = float(err.sum())
+    old = contaminated_gaussian_params(k)
+    for _ in range(int(maxiters)):
+        is1, is2, w = k
+        wratio = ((1.0 - w) * is2) / (is1 * w)
+        halfs1sqminuss2sq = -0.5 * (is2 * is2 - is1 * is1)
+        with np.errstate(over="ignore"):                                          # (exp overflows to Inf for far outliers: their weight is then exactly 0, as in the reference)
+            lat = 1.0 / (1.0 + wratio * np.exp(halfs1sqminuss2sq * err))       # expectation: the latent variables as a likelihood ratio
+        sigma1 = float((lat * err).sum()); tw = float(lat.sum())
+        new = np.array([np.sqrt(sigma1 / tw), np.sqrt((total - sigma1) / (err.size - tw)), tw / err.size])   # maximization
+        k = contaminated_gaussian(*new)
+        if np.linalg.norm(old - new) <= 1e-6 * max(np.linalg.norm(old), np.linalg.norm(new)):      # isapprox(oldparams, newparams; rtol=1.e-6)
+            break
+        old = new
+    return k

@@ -7,7 +7,7 @@ import pytest
 
 import nllssolver_jl_amd as N
 from nllssolver_jl_amd import kinds as K
-from nllssolver_jl_amd import synthetic
+from nllssolver_jl_amd import synthetic, _capi
 from nllssolver_jl_amd.variables import contaminated_gaussian, contaminated_gaussian_params
 from tests.helpers import oracle_problem
 from tests.test_gpu_parity import rel
@@ -85,6 +85,23 @@ def test_adaptivecost():
     assert np.allclose(contaminated_gaussian_params(p.variables[:3]), [1.0, 10.0, 0.8], rtol=0.1)   # :44
     assert np.isclose(p.variables[3], -1.0, rtol=0.1) and np.isclose(p.variables[4], 1.0, rtol=0.1)
     assert res.bestcost <= res.startcost
+    # ---- the second half of the reference's test (test/adaptivecost.jl:47-59): the kernel variable FIXED for the optimiser (unfixed = (1, 2, 3) .> 1), Newton on the
+    # two means, and the kernel re-estimated by Expectation-Maximization inside a user callback that EDITS problem.varnext and returns the cost of what it left there
+    from nllssolver_jl_amd.variables import contaminated_gaussian_em
+    p.variables[:3] = contaminated_gaussian(0.5, 5.0, 0.6); p.variables[3] = 0.0; p.variables[4] = 0.0      # :48-50
+    calls = []
+    def emcallback(cost, problem, data, *unused):                               # test/adaptivecost.jl:15-25
+        vn = problem.varnext
+        sq = (vn[1 + vi[:, 1]] - da[:, 0]) ** 2                                 # computeresidual(res, varnext[res.varind]) ^ 2   (variable 2 -> storage 3, variable 3 -> 4)
+        vn[:3] = contaminated_gaussian_em(vn[:3], sq)                           # problem.varnext[1] = optimize(problem.varnext[1], squarederrors)
+        data.linsystem.ctx.set_variables(vn, _capi.VARS_NEXT)
+        newcost = data.linsystem.cost(_capi.VARS_NEXT); data.costcomputations += 1
+        calls.append(newcost)
+        return newcost, 0
+    res2 = N.optimize(p, N.NLLSOptions(iterator=N.newton), np.array([False, True, True]), emcallback)       # :53
+    assert len(calls) >= 2
+    assert np.allclose(contaminated_gaussian_params(p.variables[:3]), [1.0, 10.0, 0.8], rtol=0.1), contaminated_gaussian_params(p.variables[:3])   # :56
+    assert np.isclose(p.variables[3], -1.0, rtol=0.1) and np.isclose(p.variables[4], 1.0, rtol=0.1)          # :57-58
 
 
 # Converged-variable parity with the CPU oracle's optimize!: tolerance 1e-8 absolute on variables of O(1..10).

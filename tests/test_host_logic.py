@@ -105,3 +105,20 @@ def test_rcm_order_components_grid_and_bad_input():
     # a self loop / an index out of range is an argument error, not a crash
     bad = np.array([0], np.int32); out1 = np.zeros(1, np.int32)
     assert _capi.lib().nlls_rcm_order(1, _capi._p(np.array([0, 1], np.int64)), _capi._p(bad), _capi._p(out1)) == _capi.ERR_INVALID_ARG
+
+
+def test_contaminated_gaussian_em_recovers_the_mixture():
+    """optimize(kernel::ContaminatedGaussian, squarederrors) (src/robustadaptive.jl:48-73), the host-side EM step of the reference's EM callback
+    (test/adaptivecost.jl:15-25): on squared errors drawn from 0.8 N(0, 1) + 0.2 N(0, 10^2) it must recover (1, 10, 0.8) to the tolerance the reference's
+    own test uses (rtol 0.1, test/adaptivecost.jl:57), from the reference's starting kernel (0.5, 5, 0.6)."""
+    from nllssolver_jl_amd.variables import contaminated_gaussian, contaminated_gaussian_em, contaminated_gaussian_params
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.standard_normal(8000), rng.standard_normal(2000) * 10.0])
+    k = contaminated_gaussian(0.5, 5.0, 0.6)
+    for _ in range(20):
+        k = contaminated_gaussian_em(k, x * x)
+    assert np.allclose(contaminated_gaussian_params(k), [1.0, 10.0, 0.8], rtol=0.1), contaminated_gaussian_params(k)
+    assert k[0] >= k[1]                                                       # the narrowest Gaussian first (src/robustadaptive.jl:14)
+    # one step from the truth stays at the truth
+    k2 = contaminated_gaussian_em(contaminated_gaussian(1.0, 10.0, 0.8), x * x, maxiters=1)
+    assert np.allclose(contaminated_gaussian_params(k2), [1.0, 10.0, 0.8], rtol=0.1)
