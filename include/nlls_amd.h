@@ -144,6 +144,8 @@ typedef struct nlls_info {
 #define NLLS_FLAG_NO_REORDER    0x100 /* keep the reduced variables in the caller's block order.  Default: the reduced blocks are put in reverse Cuthill-McKee
                                          order whenever that narrows the band of the reduced system -- the reference orders its factorisation itself
                                          (ldl_analyze, src/linearsystem.jl:52,68) and does not care how the caller numbers the variables; neither does x here */
+#define NLLS_FLAG_NO_TILE_SPARSE 0x200 /* reduced solver: never the tile-sparse LDL' (solve_mode 3: nested dissection of the reduced blocks' graph, factored level by
+                                         level of its elimination tree); the reduced system that is neither a narrow band nor small then takes the dense / windowed LDL' */
 
 /* variable-set ids for the on-device copies of problem.variables / varnext / varbest
  * (src/problem.jl:9-12) */
@@ -174,6 +176,16 @@ int  nlls_res_slot_kind(int32_t res_kind, int32_t slot, int32_t* var_kind, int32
  * (adjptr[n+1], adj: 0-based neighbours, no self loops; both directions listed).  perm_out[new position] = node.  Stands where the reference
  * calls ldl_analyze (src/linearsystem.jl:52,68), which orders the factorisation itself: the solve must not depend on the caller's numbering. */
 int  nlls_rcm_order(int32_t n, const int64_t* adjptr, const int32_t* adj, int32_t* perm_out);
+/* host-only helper (no context, no device): the symbolic phase of the tile-sparse reduced solver (solve_mode 3) -- nested dissection of the reduced
+ * blocks' graph by breadth-first level structures, every part and separator packed into tiles of at most 128 unknowns, then the elimination tree and
+ * the fill of the TILE graph.  n nodes with dof[i] unknowns each (CSR adjacency as for nlls_rcm_order) followed by nborder border nodes that couple
+ * to everything (dof has n + nborder entries).  Out: tile_of / row_in_tile [n + nborder] (a node's tile, in elimination order, and its first row in
+ * it); parent / level [max_tiles] (elimination tree over the tiles, -1 = root; tiles of one level are factored in one launch); the lower triangle of
+ * the tile pattern of L as CSR (colptr [max_tiles + 1], rows [max_rows]: tiles i > k of column k, ascending).  Returns the number of tiles, or
+ * NLLS_ERR_INVALID_ARG (malformed graph, a node wider than 128, outputs too small).  The reference's counterpart is ldl_analyze
+ * (src/linearsystem.jl:52,68). */
+int  nlls_nd_tiles(int32_t n, int32_t nborder, const int64_t* adjptr, const int32_t* adj, const int32_t* dof, int32_t* tile_of, int32_t* row_in_tile,
+                   int32_t max_tiles, int32_t* parent, int32_t* level, int64_t* colptr, int64_t max_rows, int32_t* rows);
 
 /* ---- factory ----------------------------------------------------------------------------------
  * replaces: makesymmvls(problem, unfixed, nblocks)   src/linearsystem.jl:91-124

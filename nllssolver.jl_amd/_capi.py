@@ -16,11 +16,12 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOT_READY, ERR_NOT_SPD, ERR_N
 FLAG_FORCE_ATOMIC, FLAG_NO_SCHUR, FLAG_FORCE_SPARSE, FLAG_NO_BAND, FLAG_NO_TWIST, FLAG_NO_BCR, FLAG_DETERMINISTIC = 1, 2, 4, 8, 16, 32, 64
 FLAG_PRESHARDED = 128
 FLAG_NO_REORDER = 256
+FLAG_NO_TILE_SPARSE = 512
 VARS_CURRENT, VARS_NEXT, VARS_BEST = 0, 1, 2
 
 # every symbol include/nlls_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = """nlls_ctx_create nlls_ctx_destroy nlls_last_error nlls_set_stream nlls_set_shard nlls_var_storage nlls_var_dof
-nlls_res_ndeps nlls_res_nres nlls_res_ndata nlls_res_slot_kind nlls_rcm_order nlls_upload_structure nlls_get_info nlls_get_bsm_index
+nlls_res_ndeps nlls_res_nres nlls_res_ndata nlls_res_slot_kind nlls_rcm_order nlls_nd_tiles nlls_upload_structure nlls_get_info nlls_get_bsm_index
 nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nlls_sweep_gradhess nlls_sweep_cost
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
@@ -88,6 +89,7 @@ def lib():
         L.nlls_res_ndeps.argtypes = [i32]; L.nlls_res_nres.argtypes = [i32]; L.nlls_res_ndata.argtypes = [i32]
         L.nlls_res_slot_kind.argtypes = [i32, i32, vp, vp]
         L.nlls_rcm_order.argtypes = [i32, vp, vp, vp]
+        L.nlls_nd_tiles.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]
         L.nlls_upload_structure.argtypes = [vp, i64, vp, vp, vp, i32, vp, i32]
         L.nlls_get_info.argtypes = [vp, vp]
         L.nlls_lm_iterations.argtypes = [vp, vp, vp, i64]

@@ -24,8 +24,10 @@
 //            x_i,J = zh_J - sum_X M_X,J' x_X - sum_{K>J} M_KJ' x_i,K .
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "nlls_bcr.hpp"
+#include "nlls_tsp.hpp"
 
 namespace nlls {
 
@@ -439,20 +441,30 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
 struct DensePanelArgs { double* S; double* W; double* LiD; int npad, k, T; int* status; double* Dfac; int wq, wstrip; };   // wq >= 0: windowed -- logical X tile row q (T of them) is tile row  q < wq ? NT (k + 1) + q : wstrip + (q - wq)   // Dfac: scratch for the factored diagonal block (16 NT square, column-major)
 // NT tiles = 16 NT columns per panel (4: 64 columns; 8: 128 columns, the width of one pass of the trailing update -- then no narrow update and
 // no second panel launch stand between two passes); DCH X tile rows per workgroup (LDS: 8 tiles of width need 2 rows to stay within 160 KB)
-template <int NT, int DCH>
-__global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
+// TSP (tile-sparse reduced system, nlls_tsp.hip): the same panel for a pivot TILE of a level of the elimination tree -- the workgroup's job names the diagonal
+// tile and the 16-row chunk(s) of a tile below it (or of the right-hand-side strip) by their offsets in the tile storage; W goes to the same offsets of a
+// second buffer, the factored diagonal tile and inv(L_JJ)' to the pivot tile's slots.  One launch factors every pivot tile of a level.
+struct TspPanelArgs { double* S; double* W; double* LiD; double* Dfac; const TspPanelJob* jobs; int* status; };
+template <int NT, int DCH, bool TSP = false>
+__global__ __launch_bounds__(BCR_T) void dense_panel_kernel(std::conditional_t<TSP, TspPanelArgs, DensePanelArgs> a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int ND = NT * (NT + 1) / 2, PR = NT + DCH;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int hw = wave < 4 ? wave - 1 : wave - 2; const bool helper = wave != 0 && wave != 4;
-    const int ch = blockIdx.x, npad = a.npad, c0 = 16 * NT * a.k;             // first column of the panel (a.k counts panels of this width)
-    // X tile rows of this workgroup: logical rows Q0 .. Q0 + RX - 1 below the diagonal block; unwindowed they are the tile rows NT (k + 1) + Q0 .. of S
-    // (a.T then counts ALL tile rows of S), windowed the band's rows followed by the bottom strip (a.T counts the step's logical rows)
-    const bool windowed = a.wq >= 0;
-    const int Q0 = DCH * ch, Tq = windowed ? a.T : a.T - NT * (a.k + 1);
-    const int RX = Q0 >= Tq ? 0 : (Tq - Q0 < DCH ? Tq - Q0 : DCH);
-    auto trow = [&](int R) { const int q = Q0 + R; return (!windowed || q < a.wq) ? NT * (a.k + 1) + q : a.wstrip + (q - a.wq); };   // actual tile row of X row R
-    const bool lead = ch == 0;
+    int npad = 0, c0 = 0, RX = 0, kslot = 0, Q0 = 0, xld = 0; bool lead = false, windowed = false; int64_t dbase = 0, xbase = 0;
+    if constexpr (TSP) {
+        const TspPanelJob jb = a.jobs[blockIdx.x];
+        kslot = jb.k; c0 = 16 * NT * jb.k; RX = jb.rx < DCH ? jb.rx : DCH; lead = jb.lead != 0; dbase = jb.doff; xbase = jb.xoff; xld = jb.xld;
+    } else {
+        const int ch = blockIdx.x; npad = a.npad; c0 = 16 * NT * a.k; kslot = a.k;             // first column of the panel (a.k counts panels of this width)
+        // X tile rows of this workgroup: logical rows Q0 .. Q0 + RX - 1 below the diagonal block; unwindowed they are the tile rows NT (k + 1) + Q0 .. of S
+        // (a.T then counts ALL tile rows of S), windowed the band's rows followed by the bottom strip (a.T counts the step's logical rows)
+        windowed = a.wq >= 0;
+        Q0 = DCH * ch; const int Tq = windowed ? a.T : a.T - NT * (a.k + 1);
+        RX = Q0 >= Tq ? 0 : (Tq - Q0 < DCH ? Tq - Q0 : DCH);
+        lead = ch == 0;
+    }
+    auto trow = [&](int R) { if constexpr (TSP) return 0; else { const int q = Q0 + R; return (!windowed || q < a.wq) ? NT * (a.k + 1) + q : a.wstrip + (q - a.wq); } };   // actual tile row of X row R
     if (RX == 0 && !lead) return;
     double* Dt = sm; double* Xt = Dt + ND * BTS; double* Wp = Xt + DCH * NT * BTS; double* dvec = Wp + 2 * PR * 16 * BP; double* Li = dvec + 64;
     const int oDt = 0, oXt = ND * BTS, oWp = oXt + DCH * NT * BTS, odv = oWp + 2 * PR * 16 * BP, oSpare = odv + 64 + 2 * 16 * BP;
@@ -464,11 +476,11 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
         for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; dv[q] = 0.0;
             if (w < ND * 256) { const int t = w >> 8, b2 = (w >> 4) & 15, a2 = w & 15; int I = 0; while ((I + 1) * (I + 2) / 2 <= t) ++I; const int K = t - I * (I + 1) / 2;
                 int row = 16 * I + a2, col = 16 * K + b2; if (row < col) { const int tmp = row; row = col; col = tmp; }
-                dv[q] = a.S[(size_t)(c0 + row) + (size_t)npad * (c0 + col)]; } }
+                if constexpr (TSP) dv[q] = a.S[dbase + row + 16 * NT * col]; else dv[q] = a.S[(size_t)(c0 + row) + (size_t)npad * (c0 + col)]; } }
 #pragma unroll
         for (int q = 0; q < XQ; ++q) { const int w = tid + q * BCR_T; xv[q] = 0.0;
             if (w < RX * NT * 256) { const int t = w >> 8, b2 = (w >> 4) & 15, a2 = w & 15, R = t / NT, K = t - R * NT;
-                xv[q] = a.S[(size_t)(16 * trow(R) + a2) + (size_t)npad * (c0 + 16 * K + b2)]; } }
+                if constexpr (TSP) xv[q] = a.S[xbase + (16 * R + a2) + (int64_t)xld * (16 * K + b2)]; else xv[q] = a.S[(size_t)(16 * trow(R) + a2) + (size_t)npad * (c0 + 16 * K + b2)]; } }
 #pragma unroll
         for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; if (w < ND * 256) Dt[(w >> 8) * BTS + (w & 15) * BP + ((w >> 4) & 15)] = dv[q]; }
 #pragma unroll
@@ -494,17 +506,20 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
         }
     };
     // panel tile (row-major W in LDS) of block column Jp -> S (L = W / Delta, column-major) and, for X rows, W -> the panel workspace
-    auto store_tile = [&](const double* Wt, const double* rd, int grow, int gcol, bool want_w) {
+    auto store_tile = [&](const double* Wt, const double* rd, int R, int Jp) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int e = lane + 64 * r, a2 = e & 15, b2 = e >> 4; const double w = Wt[a2 * BP + b2];
-            a.S[(size_t)(grow + a2) + (size_t)npad * (gcol + b2)] = w * rd[b2];
-            if (want_w) a.W[(size_t)(grow + a2) + (size_t)npad * (gcol - c0 + b2)] = w; }
+            if constexpr (TSP) { const int64_t o = xbase + (16 * R + a2) + (int64_t)xld * (16 * Jp + b2); a.S[o] = w * rd[b2]; a.W[o] = w; }
+            else { const int grow = 16 * trow(R), gcol = c0 + 16 * Jp;
+                a.S[(size_t)(grow + a2) + (size_t)npad * (gcol + b2)] = w * rd[b2];
+                a.W[(size_t)(grow + a2) + (size_t)npad * (gcol - c0 + b2)] = w; } }
     };
+    double* const Dfac = TSP ? a.Dfac + (size_t)kslot * (16 * NT) * (16 * NT) : a.Dfac;
     auto exports = [&](int Jp, int w0, int nh) {
         const double* Wprev = Wp + (Jp & 1) * PR * 16 * BP; const double* rd = dvec + (Jp & 1) * 32 + 16; const double* dd = dvec + (Jp & 1) * 32; const double* Lid = Li + (Jp & 1) * 16 * BP;
         const int nDe = lead ? NT - Jp + 1 : 0, ne = nDe + RX;      // lead: inv(L_JJ)', the diagonal tile itself, the NT-1-Jp tiles below it
         for (int e = w0; e < ne; e += nh) {
-            if (lead && e == 0) { double* dst = a.LiD + ((size_t)a.k * NT + Jp) * 256;
+            if (lead && e == 0) { double* dst = a.LiD + ((size_t)kslot * NT + Jp) * 256;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int q = lane + 64 * r; dst[q] = Lid[(q >> 4) * BP + (q & 15)]; } }
             // The factored DIAGONAL BLOCK does not go into S here: every workgroup of the launch lands the original block from S, and with more
@@ -514,12 +529,12 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(DensePanelArgs a) {
                 const double* Wt = Wprev + Jp * 16 * BP;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int q = lane + 64 * r, a2 = q & 15, b2 = q >> 4;
-                    if (a2 >= b2) a.Dfac[(size_t)(16 * Jp + a2) + (size_t)(16 * NT) * (16 * Jp + b2)] = a2 == b2 ? dd[b2] : Wt[a2 * BP + b2] * rd[b2]; } }
+                    if (a2 >= b2) Dfac[(size_t)(16 * Jp + a2) + (size_t)(16 * NT) * (16 * Jp + b2)] = a2 == b2 ? dd[b2] : Wt[a2 * BP + b2] * rd[b2]; } }
             else if (e < nDe) { const int I = Jp + e - 1; const double* Wt = Wprev + I * 16 * BP;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int e2 = lane + 64 * r, a2 = e2 & 15, b2 = e2 >> 4;
-                    a.Dfac[(size_t)(16 * I + a2) + (size_t)(16 * NT) * (16 * Jp + b2)] = Wt[a2 * BP + b2] * rd[b2]; } }
-            else { const int R = e - nDe; store_tile(Wprev + (NT + R) * 16 * BP, rd, 16 * trow(R), c0 + 16 * Jp, true); }
+                    Dfac[(size_t)(16 * I + a2) + (size_t)(16 * NT) * (16 * Jp + b2)] = Wt[a2 * BP + b2] * rd[b2]; } }
+            else { const int R = e - nDe; store_tile(Wprev + (NT + R) * 16 * BP, rd, R, Jp); }
         }
     };
     bdouble4_t diag = {0, 0, 0, 0};
@@ -897,10 +912,12 @@ constexpr int DBB = 128;
 // ones on the diagonal, zeros above it.  Also: the sentinel into x[0, n).
 // ONE: a single block b1 whose factored tiles are still in its panel's scratch slot (Lslot, column-major 128 x 128: the look-ahead factorisation inverts a block
 // the moment it is factored -- the rows below it are then ONE matrix product with the inverse); no sentinel.
-template <bool ONE>
+// ONE == 2 (tile-sparse reduced system): every pivot tile's factored block in its own slot (Lslot + 128 x 128 per tile), no sentinel.
+template <int ONE>
 __global__ __launch_bounds__(512) void dense_dinv_kernel(const double* __restrict__ S, const double* __restrict__ LiD, double* __restrict__ Dinv, double* __restrict__ x, int npad, int n, int b1, const double* __restrict__ Lslot) {
     extern __shared__ __attribute__((aligned(16))) double sm[];          // the 36 lower tiles of the block, [16][BP] each
-    const int b = ONE ? b1 : (int)blockIdx.x, t = threadIdx.x, c0 = DBB * b;
+    const int b = ONE == 1 ? b1 : (int)blockIdx.x, t = threadIdx.x, c0 = DBB * b;
+    if (ONE == 2) Lslot += (size_t)b * DBB * DBB;
     if (!ONE && t < DBB && c0 + t < n) x[c0 + t] = __longlong_as_double((long long)BCR_X_SENTINEL);
     for (int e0 = t; e0 < DBB * DBB; e0 += 8 * 512) {      // consecutive threads walk a column of S; eight loads in flight per thread
         double v[8];
@@ -999,17 +1016,32 @@ __global__ __launch_bounds__(512) void dense_bwd_fused_kernel(DenseBwdArgs a) {
 // inverse of ONE freshly factored diagonal block (its tiles still in the panel's scratch slot) -> Dinv slot b
 void launch_dense_dinv_one(hipStream_t st, const double* LiD, const double* Lslot, double* Dinv_b, int npad, int b) {
     static bool attr = false; constexpr int lds = (int)(sizeof(double) * 36 * BTS);
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL(dense_dinv_kernel<true>, dim3(1), dim3(512), lds, st, (const double*)nullptr, LiD, Dinv_b - (size_t)b * DBB * DBB, (double*)nullptr, npad, 0, b, Lslot);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(dense_dinv_kernel<1>, dim3(1), dim3(512), lds, st, (const double*)nullptr, LiD, Dinv_b - (size_t)b * DBB * DBB, (double*)nullptr, npad, 0, b, Lslot);
 }
 // Dinv: ceil(n / 128) slots of 128 x 128 doubles
 void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, double* Dinv, int npad, int n, double* x, int* status) {
     const int NBB = (n + DBB - 1) / DBB; if (NBB <= 0) return;
     static bool attr = false; constexpr int lds = (int)(sizeof(double) * 36 * BTS);
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL(dense_dinv_kernel<false>, dim3((unsigned)NBB), dim3(512), lds, st, S, LiD, Dinv, x, npad, n, 0, (const double*)nullptr);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(dense_dinv_kernel<0>, dim3((unsigned)NBB), dim3(512), lds, st, S, LiD, Dinv, x, npad, n, 0, (const double*)nullptr);
     DenseBwdArgs a{S, Dinv, x, status, npad, n, NBB};
     hipLaunchKernelGGL(dense_bwd_fused_kernel, dim3((unsigned)NBB), dim3(512), 0, st, a);
+}
+
+// tile-sparse reduced system (nlls_tsp.hip): the panels of all pivot tiles of a level; the inverses of all factored diagonal tiles
+void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status) {
+    if (njobs <= 0) return;
+    static bool attr = false; constexpr int lds = (int)dense_panel_lds<8, 1>();
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    TspPanelArgs a{S, W, LiD, Dfac, jobs, status};
+    hipLaunchKernelGGL((dense_panel_kernel<8, 1, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds, st, a);
+}
+void launch_tsp_dinv(hipStream_t st, const double* LiD, const double* Dfac, double* Dinv, int nt) {
+    if (nt <= 0) return;
+    static bool attr = false; constexpr int lds = (int)(sizeof(double) * 36 * BTS);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(dense_dinv_kernel<2>, dim3((unsigned)nt), dim3(512), lds, st, (const double*)nullptr, LiD, Dinv, (double*)nullptr, DBB * nt, 0, 0, Dfac);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -116,6 +116,22 @@ int nlls_rcm_order(int32_t n, const int64_t* adjptr, const int32_t* adj, int32_t
     return NLLS_OK;
 }
 
+int nlls_nd_tiles(int32_t n, int32_t nborder, const int64_t* adjptr, const int32_t* adj, const int32_t* dof, int32_t* tile_of, int32_t* row_in_tile,
+                  int32_t max_tiles, int32_t* parent, int32_t* level, int64_t* colptr, int64_t max_rows, int32_t* rows) {
+    if (n < 0 || nborder < 0 || (n > 0 && !adjptr) || (n + nborder > 0 && (!dof || !tile_of || !row_in_tile)) || !parent || !level || !colptr || (max_rows > 0 && !rows)) return NLLS_ERR_INVALID_ARG;
+    std::vector<std::vector<int32_t>> a((size_t)n);
+    for (int32_t i = 0; i < n; ++i) { if (adjptr[i + 1] < adjptr[i]) return NLLS_ERR_INVALID_ARG;
+        for (int64_t q = adjptr[i]; q < adjptr[i + 1]; ++q) { if (adj[q] < 0 || adj[q] >= n || adj[q] == i) return NLLS_ERR_INVALID_ARG; a[i].push_back(adj[q]); }
+        std::sort(a[i].begin(), a[i].end()); a[i].erase(std::unique(a[i].begin(), a[i].end()), a[i].end()); }
+    nlls::TspSym sym;
+    if (!nlls::tsp_symbolic(a, std::vector<int32_t>(dof, dof + n + nborder), nborder, sym)) return NLLS_ERR_INVALID_ARG;
+    if (sym.nt > max_tiles || sym.ntiles_lower - sym.nt > max_rows) return NLLS_ERR_INVALID_ARG;
+    for (int32_t i = 0; i < n + nborder; ++i) { tile_of[i] = sym.tile_of[i]; row_in_tile[i] = sym.row_in_tile[i]; }
+    colptr[0] = 0;
+    for (int k = 0; k < sym.nt; ++k) { parent[k] = sym.parent[k]; level[k] = sym.level[k]; int64_t q = colptr[k]; for (int32_t t : sym.cstruct[k]) rows[q++] = t; colptr[k + 1] = q; }
+    return sym.nt;
+}
+
 int nlls_upload_structure(nlls_ctx* ctx, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* blockindices,
                           int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
     if (!ctx || nvar < 0 || ngroups < 0 || (nvar && (!var_kind || !var_dim || !blockindices)) || (ngroups && !groups)) return NLLS_ERR_INVALID_ARG;

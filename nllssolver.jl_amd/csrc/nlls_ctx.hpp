@@ -13,6 +13,7 @@
 #include "nlls_kinds.hpp"
 #include "nlls_devbuf.hpp"
 #include "nlls_bcr.hpp"
+#include "nlls_tsp.hpp"
 
 namespace nlls {
 
@@ -110,7 +111,7 @@ struct SchurNbr {            // one off-diagonal block touching an eliminated bl
     uint16_t dim;            // neighbour block size
     uint16_t trans;          // 0: stored as (elim x nbr) [dv x du]; 1: stored as (nbr x elim) [du x dv]
 };
-constexpr int SOLVE_SMALL = 0, SOLVE_DENSE = 1, SOLVE_BAND = 2;
+constexpr int SOLVE_SMALL = 0, SOLVE_DENSE = 1, SOLVE_BAND = 2, SOLVE_TSPARSE = 3;   // (3: tile-sparse LDL' in a nested-dissection order, nlls_tsp.hip)
 constexpr unsigned PROF_SLOTS = 16, PROF_MAXWG = 16384;
 constexpr int NLLS_SUB_NONE = 0, NLLS_SUB_SCHUR_SHAPE = 1;     // SCHUR_SHAPE: the Schur kernels cannot stage this structure -- the full system may still be solvable
 struct SchurCopy {           // a reduced-reduced block copied from A.data into S
@@ -259,6 +260,7 @@ struct nlls_ctx {
     bool band_twisted = true;               // factor the band from both ends at once (two workgroups) when the layout allows
     bool elim_slab = false;                 // slab + gather assembly straight into the block cyclic reduction's tiles (single rank, fast-path supernodes only)
     nlls::DevBuf<double> slab; nlls::DevBuf<uint32_t> d_slab_off, d_slab_groups; int64_t n_slab60 = 0, n_slabnar = 0, n_slabwide = 0; nlls::DevBuf<nlls::GatherJob> d_gjobs; nlls::DevBuf<nlls::GatherCon> d_gcons; int64_t n_gjobs = 0;
+    nlls::TspSolver tsp;                    // tile-sparse LDL' of a reduced system that is neither a narrow band nor small (nlls_tsp.hip)
     nlls::BcrSolver bcr;                    // block cyclic reduction of the bordered band (nlls_bcr.hip): the default band solver when it supports the shape
     nlls::DevBuf<nlls::SchurCopy> d_copy;    // reduced-reduced blocks
     int64_t ncopy = 0;

@@ -36,18 +36,23 @@ NLLS_DEV double wsum(double v) {
 //   dense: col-major, ld = npad                         (general systems; MFMA blocked LDL')
 //   band : column j of the banded part holds H = bw+1+nbd+1 entries [S(j..j+bw, j) | S(border, j) | s(j)],
 //          followed by the (nbd+1)^2 border corner        (narrow-band systems; persistent-workgroup LDL')
+//   tile-sparse: the lower tiles of the filled tile pattern, 128 x 128 column-major each, in a nested-dissection order of its own (nlls_tsp.hip):
+//          tsp[0, n) = position of a reduced unknown in that order, tsp[n + I npad + J] = slot of tile (I, J), I >= J  (npad = number of tiles)
 // ---------------------------------------------------------------------------------------------------
 struct SLayout {
-    double* S; int mode; int n, npad, n_band, bw, nbd, H;
+    double* S; int mode; int n, npad, n_band, bw, nbd, H; const int32_t* tsp;
     NLLS_DEV double* at(int i, int j) const {   // i >= j
-        if (mode != SOLVE_BAND) return S + (size_t)i + (size_t)npad * j;
+        if (mode != SOLVE_BAND) {
+            if (mode == SOLVE_TSPARSE) { int pi = tsp[i], pj = tsp[j]; if (pi < pj) { const int t = pi; pi = pj; pj = t; }      // (the tile order is not the reduced order: the entry lives at (max, min) of the POSITIONS)
+                return S + (size_t)tsp[n + (pi >> 7) * npad + (pj >> 7)] * (128 * 128) + (pi & 127) + 128 * (pj & 127); }
+            return S + (size_t)i + (size_t)npad * j; }
         if (i < n_band) return S + (size_t)j * H + (i - j);
         if (j < n_band) return S + (size_t)j * H + bw + 1 + (i - n_band);
         return S + (size_t)n_band * H + (i - n_band) + (size_t)(nbd + 1) * (j - n_band);
     }
     // entry i of the reduced right-hand side while the system is assembled: the factorisations carry it as row n of S
     // (band and dense layouts); only the one-wave solver of tiny systems reads it from the vector s
-    NLLS_DEV double* rhs(double* s, int i) const { return mode == SOLVE_SMALL ? s + i : at(n, i); }
+    NLLS_DEV double* rhs(double* s, int i) const { return (mode == SOLVE_SMALL || mode == SOLVE_TSPARSE) ? s + i : at(n, i); }
 };
 
 // identity on the padding of the dense layout; the rhs as row n: factoring the bordered matrix
@@ -55,7 +60,7 @@ struct SLayout {
 __global__ void schur_init_kernel(SLayout L, double* __restrict__ s, const double* __restrict__ b, const uint32_t* __restrict__ red_boff) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < L.n) { *L.rhs(s, i) = b[red_boff[i]]; return; }
-    if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+    if (L.mode != SOLVE_BAND && L.mode != SOLVE_TSPARSE && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
 }
 // schur_init + schur_copy + the status reset in one launch (sparse systems): the first ninit workgroups initialise s (and
 // the padding of the dense layout), the rest copy one reduced-reduced block each
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(256) void schur_prepare_kernel(SLayout L, double* _
     if ((int)blockIdx.x < ninit) {
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < L.n) { *L.rhs(s, i) = b[red_boff[i]]; return; }
-        if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+        if (L.mode != SOLVE_BAND && L.mode != SOLVE_TSPARSE && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
         return;
     }
     const SchurCopy cp = copies[blockIdx.x - ninit];
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (w < pa.ninit) {
             const int i = w * 256 + threadIdx.x;
             if (i < L.n) { atomicAdd(L.rhs(s, i), b[pa.red_boff[i]]); return; }
-            if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+            if (L.mode != SOLVE_BAND && L.mode != SOLVE_TSPARSE && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
             return;
         }
         const SchurCopy cp = pa.copies[w - pa.ninit];
@@ -900,7 +905,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (w < pa.ninit) {
             const int i = w * 256 + threadIdx.x;
             if (i < L.n) { atomicAdd(L.rhs(s, i), b[pa.red_boff[i]]); return; }
-            if (L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+            if (L.mode != SOLVE_BAND && L.mode != SOLVE_TSPARSE && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
             return;
         }
         const SchurCopy cp = pa.copies[w - pa.ninit];
@@ -2722,7 +2727,8 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
 
 static SLayout make_layout(nlls_ctx* c) {
     SLayout L{}; L.S = c->S.p; L.mode = c->solve_mode; L.n = (int)c->nred; L.npad = c->dense_pad128 ? (((int)c->nred + 1 + 127) / 128) * 128 : (((int)c->nred + 1 + NB - 1) / NB) * NB;
-    L.n_band = (int)c->n_band; L.bw = c->bw; L.nbd = c->nbd; L.H = c->band_H;
+    L.n_band = (int)c->n_band; L.bw = c->bw; L.nbd = c->nbd; L.H = c->band_H; L.tsp = nullptr;
+    if (c->solve_mode == SOLVE_TSPARSE) { L.npad = c->tsp.nt; L.tsp = c->tsp.d_map.p; }
     return L;
 }
 
@@ -2766,7 +2772,7 @@ int enqueue_solve_local(nlls_ctx* c) {
     if (all_in_one) {
         if (!c->status_known_zero) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));
         c->status_known_zero = false;
-        if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
+        if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)((band || c->solve_mode == SOLVE_TSPARSE) ? n : npad)), c->stream));
         c->S_zeroed = false;
         const int ninit = (std::max(npad, n) + 255) / 256;
         // (the elimination's own list when tiny supernodes were folded into their neighbours at upload: fewer workgroups, half the atomics)
@@ -2785,7 +2791,7 @@ int enqueue_solve_local(nlls_ctx* c) {
     }
     c->status_known_zero = false;
     if (!one_prepare) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));
-    if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)(band ? n : npad)), c->stream));
+    if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)((band || c->solve_mode == SOLVE_TSPARSE) ? n : npad)), c->stream));
     c->S_zeroed = false;
     if (c->nranks > 1) HIPCHK(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->info.ndof, c->stream));
     if (one_prepare) {
@@ -2841,6 +2847,8 @@ int enqueue_reduced_solve(nlls_ctx* c) {
     const bool band = c->solve_mode == SOLVE_BAND;
     if (c->solve_mode == SOLVE_SMALL) {
         hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s_ptr(), n, npad, c->d_status.p);
+    } else if (c->solve_mode == SOLVE_TSPARSE) {
+        if (c->tsp.enqueue(c->stream, c->S.p, c->s_ptr(), c->d_status.p) != NLLS_OK) return herr(c, hipGetLastError(), "tile-sparse reduced solve launch");
     } else if (band && c->bcr.ready) {
         // an UNDAMPED step (Newton, dogleg's Gauss-Newton step) of a gauge-free problem: S is singular -- vanished pivots are dropped
         // (src/iterators.jl:47-115 asks for the Gauss-Newton step; any exact factorisation of a singular system returns rounding / rounding)

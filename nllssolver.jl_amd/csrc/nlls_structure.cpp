@@ -540,6 +540,8 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     c->d_elim_ptr.release(); c->d_elim_nbr.release(); c->d_elim_diag.release(); c->d_elim_boff.release(); c->d_elim_dim.release(); c->d_elim_group.release();
     c->d_fast_groups.release(); c->d_elim_desc.release(); c->d_elim_desc_fold.release(); c->d_elim_pre.release(); c->n_fold_groups = 0; c->n_folded = 0; c->d_elim_rc.release(); c->d_slow_groups.release(); c->d_slow_blocks.release(); c->d_fast_members.release(); c->Cinv.release(); c->tE.release();
     std::vector<int64_t> red_of(nb, -1);     // dof offset in the reduced system
+    std::vector<std::vector<int32_t>> red_adj; std::vector<int64_t> red_adj_blocks;     // graph of the reduced non-border blocks (kept for the tile-sparse solver's symbolic phase)
+    c->tsp.release();
     // transposed block lists: for a block v, the rows w > v that store block (w, v)
     std::vector<int64_t> tptr(nb + 1, 0), trow, tq;
     if (I0.is_sparse) {
@@ -636,9 +638,11 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 const int64_t bw_nat = bandwidth_of(ident);
                 c->bw_caller = bw_nat;
                 const std::vector<int32_t> perm = rcm_order(adj);
+                red_adj_blocks = band_blocks;
                 if ((int32_t)perm.size() == nRb && bandwidth_of(perm) < bw_nat) {
                     std::vector<int64_t> nbk(nRb); for (int32_t i = 0; i < nRb; ++i) nbk[i] = band_blocks[perm[i]];
                     band_blocks.swap(nbk); c->red_reordered = 1; }
+                red_adj.swap(adj);
             }
         }
         int64_t ro = 0;
@@ -980,6 +984,33 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         c->dense_window = I0.is_sparse && c->nelim > 0 && c->n_band >= 1024 && !(flags & NLLS_FLAG_NO_BAND) && 2 * (bw + 256) < c->n_band && !getenv("NLLS_NO_DENSE_WINDOW");
         c->dense_pad128 = c->dense_window || (c->dense_lookahead && n + 1 >= 1024);
         const int64_t npad = c->dense_pad128 ? ((n + 1 + 127) / 128) * 128 : ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
+        // TILE-SPARSE: nested dissection of the reduced blocks' graph, the factorisation level by level of its elimination tree (nlls_tsp.hip).  Taken when its
+        // dependent chain (levels of the tree) and its tile products come out clearly below what the dense / windowed factorisation of the same system costs
+        // (rough launch + matrix-core times, in us: a level = panel + update + backward launches; a 128^3 tile product ~0.17 us of the chip).
+        if (I0.is_sparse && c->nelim > 0 && n >= 512 && !red_adj_blocks.empty() && !(flags & (NLLS_FLAG_NO_BAND | NLLS_FLAG_NO_TILE_SPARSE)) && !getenv("NLLS_NO_TSPARSE")) {
+            std::vector<int32_t> ndof, noff;
+            for (int64_t k : red_adj_blocks) { ndof.push_back((int32_t)c->blocksizes[k]); noff.push_back((int32_t)red_of[k]); }
+            int nbdn = 0; for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && red_of[k] >= c->n_band) { ndof.push_back((int32_t)c->blocksizes[k]); noff.push_back((int32_t)red_of[k]); ++nbdn; }
+            TspSym sym;
+            if (tsp_symbolic(red_adj, ndof, nbdn, sym) && sym.nt > 0 && sym.nt <= 4096) {
+                const double NB128 = (double)(npad / 128 + (npad % 128 ? 1 : 0));
+                const double t_tsp = 48.0 * sym.nlevels + 0.17 * (double)sym.nupd_products + 30.0 * (8.0 * (double)(sym.ntiles_lower - sym.nt) + sym.nt) / 256.0;
+                double t_dense = 32.0 * NB128 + 0.17 * NB128 * NB128 * NB128 / 6.0;
+                if (c->dense_window) { const double wt = (double)((bw + 127) / 128 + 1 + (c->nbd + 1 + 127) / 128); t_dense = std::min(t_dense, NB128 * (40.0 + 0.17 * wt * (wt + 1) / 2.0)); }
+                const bool force = getenv("NLLS_FORCE_TSPARSE") != nullptr;
+                if (t_tsp < 0.8 * t_dense || force) {
+                    std::string e; const int rc = c->tsp.build(sym, noff, ndof, (int)n, &e);
+                    size_t mfree = 0, mtotal = 0;
+                    if (rc == NLLS_OK && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && sizeof(double) * (c->tsp.s_elems() + (size_t)n + 64) + ((size_t)2 << 30) > mfree) c->tsp.release();
+                    if (rc != NLLS_OK && rc != NLLS_ERR_UNSUPPORTED) return fail(c, rc, e.c_str());
+                }
+            }
+        }
+        if (c->tsp.ready) {
+            c->solve_mode = SOLVE_TSPARSE; c->dense_window = false; c->dense_pad128 = false;
+            c->s_elems = c->tsp.s_elems();
+            if (hipSuccess != c->S.alloc(c->s_elems + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(64) || hipSuccess != c->d_status.alloc(96)) return fail(c, NLLS_ERR_HIP, "tile-sparse reduced system alloc");
+        } else {
         // npad^2 doubles: what the DEVICE holds decides (288 GB on an MI355X: ~150 000 reduced dof), not a constant; the shim keeps the CPU system when it does not fit
         const size_t lw = (size_t)std::max<int64_t>(npad * 128 + npad + (npad / 16) * 256 + 256 + (npad / 64 + 1) * 128 * 128 + (npad / 128 + 1) * 128 * 128, 1);   // ... | inverses of the diagonal blocks (look-ahead)
         { size_t mfree = 0, mtotal = 0; const size_t want = sizeof(double) * ((size_t)npad * npad + (size_t)npad + 64 + lw);
@@ -989,6 +1020,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         c->s_elems = (size_t)std::max<int64_t>(npad * npad, 1);
         if (hipSuccess != c->S.alloc(c->s_elems + (size_t)npad + 64) ||
             hipSuccess != c->Lwork.alloc(lw)   /* W of a 128-column panel (or of two 64-column ones) | acc | inverted diagonal tiles | factored diagonal blocks (a slot per 64-block) */ || hipSuccess != c->d_status.alloc(96)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
+        }
     }
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
     c->info.solve_mode = c->solve_mode; c->info.bandwidth = c->bw; c->info.nborder_dof = c->nbd;

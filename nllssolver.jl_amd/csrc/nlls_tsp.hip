@@ -1,0 +1,241 @@
+// nlls_tsp.hip -- the reduced system as a TILE-SPARSE symmetric matrix, factored level by level of a nested-dissection elimination tree (gfx950).
+//
+// Same contract as every other reduced solver (src/linearsolver.jl:28-32, src/iterators.jl:149-153): x solves S x = s.  The reference's sparse LDL'
+// analyses the pattern once with a fill-reducing ordering (src/linearsystem.jl:52,68) and takes any sparsity; of the device solvers, block cyclic
+// reduction (nlls_bcr.hip) needs a narrow band and the dense LDL' (nlls_solve.hip) costs n^3 / 3 -- or, restricted to a wide band, still one dependent
+// panel step per 128 columns.  A camera graph that is a 2-D grid, a loop, a tree of sub-maps is neither narrow nor dense.
+//
+// Here the reduced blocks are ordered by nested dissection (nlls_nd.cpp) and packed into TILES of 128 unknowns; S is stored as the lower tiles of the
+// filled tile pattern (128 x 128 column-major each) + one right-hand-side strip per tile column.  The elimination tree over the tiles is cut into LEVELS
+// (tiles of one level do not touch each other), and each level is three launches over ALL its tiles:
+//   panel    (dense_panel_kernel<8, 1, TSP>, nlls_bcr.hip)  every pivot tile of the level: LDL' of the diagonal tile on the matrix cores, the tiles
+//            below it (and the right-hand-side strip) as 16-row chunks, one workgroup each: L in place, W = L Delta beside it;
+//   update   (tsp_update_kernel)  every tile (i, j) that receives a Schur complement from the level:  C_ij -= sum_k W_ik L_jk'  -- one workgroup per
+//            TARGET tile walks all its contributions, so no two workgroups write the same tile and the result is bit-reproducible given S;
+//            the strips take  z_j -= sum_k L_jk w_k  in the same launch (the forward substitution rides along, as in the dense solver);
+//   backward (tsp_backward_kernel, levels in reverse)  x_k = inv(L_kk)' (z_k - sum_i L_ik' x_i)  with the explicit inverses of the unit-lower
+//            diagonal tiles (dense_dinv_kernel<2>: one launch for all tiles).
+// The depth of the tree, not the number of tile columns, is the length of the dependent chain.
+#include <algorithm>
+#include <map>
+
+#include "nlls_tsp.hpp"
+
+namespace nlls {
+
+typedef double tdouble4_t __attribute__((ext_vector_type(4)));
+typedef double tdouble2_t __attribute__((ext_vector_type(2)));
+
+// padding -> identity, reduced right-hand side -> row 0 of the strips (tile order)
+__global__ __launch_bounds__(256) void tsp_begin_kernel(double* __restrict__ S, const double* __restrict__ s, const int32_t* __restrict__ ipos, const int64_t* __restrict__ padpos,
+                                                        int64_t npadpos, int64_t npos, int64_t strip0) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < npos) { const int32_t src = ipos[i]; S[strip0 + (i >> 7) * TSP_STRIP + 16 * (i & 127)] = src >= 0 ? s[src] : 0.0; }
+    else if (i - npos < npadpos) S[padpos[i - npos]] = 1.0;
+}
+__global__ __launch_bounds__(256) void tsp_scatter_kernel(double* __restrict__ s, const double* __restrict__ xt, const int32_t* __restrict__ tpos, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) s[i] = xt[tpos[i]];
+}
+
+// One TARGET per workgroup.  kind 0: a 128 x 128 tile, syrk_update128_kernel's tiling (nlls_solve.hip): eight wavefronts, 64 x 32 each = 4 x 2 accumulator
+// tiles of v_mfma_f64_16x16x4_f64, operands through LDS in chunks of 16 columns, double buffered, products formed transposed so that the read-modify-write
+// of C walks down columns; the K loop runs over all contributions (128 columns each).  kind 1: a right-hand-side strip, matrix-vector products.
+constexpr int TU_KC = 16, TU_LD = 144;
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void tsp_update_kernel(double* __restrict__ S, const double* __restrict__ W, const TspUpdJob* __restrict__ jobs,
+                                                                                                    const TspCon* __restrict__ cons) {
+    __shared__ double As[2][TU_KC * TU_LD], Bs[2][TU_KC * TU_LD];
+    const TspUpdJob jb = jobs[blockIdx.x];
+    const int t = threadIdx.x;
+    if (jb.kind == 1) {
+        // z_j[c] -= sum over contributions, m:  L_jk[c][m] w_k[m]      (w_k: row 0 of the W strip of pivot k)
+        const int c = t & 127, mq = t >> 7; double acc = 0.0;
+        for (int q = 0; q < jb.ncon; ++q) { const TspCon cn = cons[jb.con0 + q];
+            const double* __restrict__ L = S + cn.loff + c; const double* __restrict__ w = W + cn.woff;
+#pragma unroll 8
+            for (int m = mq; m < TSP_TR; m += 4) acc = fma(L[(size_t)TSP_TR * m], w[16 * m], acc); }
+        As[0][t] = acc;
+        __syncthreads();
+        if (t < 128) S[jb.coff + 16 * t] -= (As[0][t] + As[0][t + 128]) + (As[0][t + 256] + As[0][t + 384]);
+        return;
+    }
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
+    const int r0w = (w & 1) * 64, c0w = (w >> 1) * 32;
+    const bool active = !(jb.diag && c0w >= r0w + 64);
+    tdouble4_t acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = tdouble4_t{0, 0, 0, 0};
+    const int cr = t & 127, kq = t >> 7;                        // copy roles: row cr of both operands, every fourth column of a chunk
+    constexpr int NCP = TU_KC / 4, CPT = TSP_TR / TU_KC;        // columns per thread and chunk; chunks per contribution
+    double ra[NCP], rb[NCP];
+    auto gload = [&](int chunk) {
+        const TspCon cn = cons[jb.con0 + chunk / CPT]; const int col0 = (chunk % CPT) * TU_KC;
+        const double* Ga = W + cn.woff + cr + (size_t)TSP_TR * col0; const double* Gb = S + cn.loff + cr + (size_t)TSP_TR * col0;
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) { ra[i] = Ga[(size_t)TSP_TR * (kq + 4 * i)]; rb[i] = Gb[(size_t)TSP_TR * (kq + 4 * i)]; }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) { As[buf][(kq + 4 * i) * TU_LD + cr] = ra[i]; Bs[buf][(kq + 4 * i) * TU_LD + cr] = rb[i]; }
+    };
+    const int NCH = jb.ncon * CPT;
+    gload(0); lstore(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < NCH) gload(ch + 1);
+        if (active) {
+#pragma unroll
+            for (int kk = 0; kk < TU_KC; kk += 4) {
+                double av[4], bv[2];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) av[a] = As[buf][(kk + lk) * TU_LD + r0w + 16 * a + li];
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Bs[buf][(kk + lk) * TU_LD + c0w + 16 * b2 + li];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < NCH) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+    // C/D layout of the TRANSPOSED product: row = lane & 15 (+ 16 a), column = (lane >> 4) + 4 r (+ 16 b)
+    double* Cg = S + jb.coff + r0w + (size_t)TSP_TR * c0w;
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+        double cold[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cold[a][r] = Cg[(size_t)(16 * a + li) + (size_t)TSP_TR * (16 * b2 + lk + 4 * r)];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cg[(size_t)(16 * a + li) + (size_t)TSP_TR * (16 * b2 + lk + 4 * r)] = cold[a][r] - acc[a][b2][r];
+    }
+}
+
+// One pivot tile per workgroup: thread t = rows 32 (t & 3) .. of column t >> 2 of a tile (contiguous in memory).
+__global__ __launch_bounds__(512) void tsp_backward_kernel(const double* __restrict__ S, const double* __restrict__ Dinv, double* __restrict__ xt, const TspBwdJob* __restrict__ jobs,
+                                                           const TspBwdCon* __restrict__ cons, int64_t strip0) {
+    __shared__ __attribute__((aligned(32))) double xs[2][TSP_TR], us[TSP_TR];
+    const TspBwdJob jb = jobs[blockIdx.x];
+    const int t = threadIdx.x, c = t >> 2, q = t & 3;
+    double INV[32], T[32];
+    { const double* P = Dinv + (size_t)jb.k * TSP_TE + (size_t)TSP_TR * c + 32 * q;
+#pragma unroll
+      for (int i = 0; i < 32; i += 2) { const tdouble2_t v = *reinterpret_cast<const tdouble2_t*>(P + i); INV[i] = v[0]; INV[i + 1] = v[1]; } }
+    const double z = q == 0 ? S[strip0 + (int64_t)jb.k * TSP_STRIP + 16 * c] : 0.0;
+    double acc = 0.0;
+#pragma unroll 1
+    for (int m = 0; m < jb.ncon; ++m) {
+        const TspBwdCon cn = cons[jb.con0 + m];
+        { const double* P = S + cn.loff + (size_t)TSP_TR * c + 32 * q;
+#pragma unroll
+          for (int i = 0; i < 32; i += 2) { const tdouble2_t v = *reinterpret_cast<const tdouble2_t*>(P + i); T[i] = v[0]; T[i + 1] = v[1]; } }
+        if (t < TSP_TR) xs[m & 1][t] = xt[(size_t)TSP_TR * cn.i + t];
+        __syncthreads();                        // (xs is double buffered: one barrier per contribution)
+        const double* xv = xs[m & 1] + 32 * q;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) { s0 = fma(T[i], xv[i], s0); s1 = fma(T[i + 1], xv[i + 1], s1); s2 = fma(T[i + 2], xv[i + 2], s2); s3 = fma(T[i + 3], xv[i + 3], s3); }
+        acc += (s0 + s1) + (s2 + s3);
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+    if (q == 0) us[c] = z - acc;
+    __syncthreads();
+    const double* uv = us + 32 * q;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) { s0 = fma(INV[i], uv[i], s0); s1 = fma(INV[i + 1], uv[i + 1], s1); s2 = fma(INV[i + 2], uv[i + 2], s2); s3 = fma(INV[i + 3], uv[i + 3], s3); }
+    double xv = (s0 + s1) + (s2 + s3);
+    xv += __shfl_xor(xv, 1, 64); xv += __shfl_xor(xv, 2, 64);
+    if (q == 0) xt[(size_t)TSP_TR * jb.k + c] = xv;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------
+int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off, const std::vector<int32_t>& dof, int n_red, std::string* err) {
+    release();
+    n = n_red; nt = sym.nt;
+    if (nt <= 0 || nt > 4096) { if (err) *err = "tile-sparse solver: tile count out of range"; return NLLS_ERR_UNSUPPORTED; }
+    const size_t nnode = sym.tile_of.size();
+    std::vector<int32_t> map((size_t)n + (size_t)nt * nt, -1), ipos((size_t)nt * TSP_TR, -1);
+    for (size_t v = 0; v < nnode; ++v) for (int d = 0; d < dof[v]; ++d) {
+        const int32_t p = sym.tile_of[v] * TSP_TR + sym.row_in_tile[v] + d, r = node_red_off[v] + d;
+        if (r < 0 || r >= n || p < 0 || p >= nt * TSP_TR || map[r] >= 0 || ipos[p] >= 0) { if (err) *err = "tile-sparse solver: inconsistent tiling"; return NLLS_ERR_INVALID_ARG; }
+        map[r] = p; ipos[p] = r; }
+    for (int r = 0; r < n; ++r) if (map[r] < 0) { if (err) *err = "tile-sparse solver: a reduced unknown without a tile"; return NLLS_ERR_INVALID_ARG; }
+    int32_t* tmap = map.data() + n;
+    nslots = 0;
+    for (int k = 0; k < nt; ++k) { tmap[(size_t)k * nt + k] = (int32_t)nslots++; for (int32_t i : sym.cstruct[k]) tmap[(size_t)i * nt + k] = (int32_t)nslots++; }
+    if (nslots >= ((int64_t)1 << 31) / 4) { if (err) *err = "tile-sparse solver: too many tiles"; return NLLS_ERR_UNSUPPORTED; }
+    auto slot = [&](int i, int k) { return (int64_t)tmap[(size_t)i * nt + k] * TSP_TE; };
+    const int64_t strip0 = nslots * TSP_TE;
+    std::vector<int64_t> padpos;
+    for (int k = 0; k < nt; ++k) for (int r = sym.fill[k]; r < TSP_TR; ++r) padpos.push_back(slot(k, k) + r + (int64_t)TSP_TR * r);
+    npad_entries = (int64_t)padpos.size();
+    std::vector<TspPanelJob> pj; std::vector<TspUpdJob> uj; std::vector<TspCon> uc; std::vector<TspBwdJob> bj; std::vector<TspBwdCon> bc;
+    levels.assign(sym.nlevels, TspLevel{});
+    std::vector<std::vector<int32_t>> by_level(sym.nlevels);
+    for (int k = 0; k < nt; ++k) by_level[sym.level[k]].push_back(k);
+    products = 0;
+    for (int lv = 0; lv < sym.nlevels; ++lv) {
+        TspLevel& L = levels[lv]; L.panel0 = pj.size(); L.upd0 = uj.size(); L.bwd0 = bj.size();
+        std::map<std::pair<int32_t, int32_t>, std::vector<TspCon>> tgt; std::map<int32_t, std::vector<TspCon>> rhs;
+        for (int32_t k : by_level[lv]) {
+            const auto& cs = sym.cstruct[k];
+            pj.push_back(TspPanelJob{slot(k, k), strip0 + (int64_t)k * TSP_STRIP, k, 16, 1, 1});        // the strip's chunk: the lead (exports the factored diagonal tile)
+            for (int32_t i : cs) for (int q = 0; q < TSP_TR / 16; ++q) pj.push_back(TspPanelJob{slot(k, k), slot(i, k) + 16 * q, k, TSP_TR, 1, 0});
+            for (size_t a = 0; a < cs.size(); ++a) { for (size_t b = 0; b <= a; ++b) tgt[{cs[a], cs[b]}].push_back(TspCon{slot(cs[a], k), slot(cs[b], k)});
+                rhs[cs[a]].push_back(TspCon{strip0 + (int64_t)k * TSP_STRIP, slot(cs[a], k)}); }
+            TspBwdJob b{k, (int32_t)bc.size(), (int32_t)cs.size(), 0};
+            for (int32_t i : cs) bc.push_back(TspBwdCon{slot(i, k), i, 0});
+            bj.push_back(b);
+        }
+        // heaviest targets first (a launch ends with its longest workgroup)
+        std::vector<std::pair<int64_t, std::pair<int32_t, int32_t>>> order;
+        for (auto& kv : tgt) order.push_back({-(int64_t)kv.second.size(), kv.first});
+        std::sort(order.begin(), order.end());
+        for (auto& o : order) { auto& cl = tgt[o.second];
+            if (tmap[(size_t)o.second.first * nt + o.second.second] < 0) { if (err) *err = "tile-sparse solver: fill outside the symbolic pattern"; return NLLS_ERR_INVALID_ARG; }
+            uj.push_back(TspUpdJob{slot(o.second.first, o.second.second), (int32_t)uc.size(), (int32_t)cl.size(), o.second.first == o.second.second ? 1 : 0, 0});
+            uc.insert(uc.end(), cl.begin(), cl.end()); products += (int64_t)cl.size(); }
+        for (auto& kv : rhs) { uj.push_back(TspUpdJob{strip0 + (int64_t)kv.first * TSP_STRIP, (int32_t)uc.size(), (int32_t)kv.second.size(), 0, 1}); uc.insert(uc.end(), kv.second.begin(), kv.second.end()); }
+        L.npanel = (int)(pj.size() - L.panel0); L.nupd = (int)(uj.size() - L.upd0); L.nbwd = (int)(bj.size() - L.bwd0);
+    }
+    if (uc.empty()) uc.push_back(TspCon{0, 0}); if (uj.empty()) uj.push_back(TspUpdJob{}); if (bc.empty()) bc.push_back(TspBwdCon{}); if (padpos.empty()) padpos.push_back(0);
+    oW = 0; oLiD = s_elems(); oDfac = oLiD + (size_t)nt * 8 * 256; oDinv = oDfac + (size_t)nt * TSP_TE; oxt = oDinv + (size_t)nt * TSP_TE;
+    if (hipSuccess != d_map.upload(map) || hipSuccess != d_ipos.upload(ipos) || hipSuccess != d_panel.upload(pj) || hipSuccess != d_upd.upload(uj) || hipSuccess != d_con.upload(uc) ||
+        hipSuccess != d_bwd.upload(bj) || hipSuccess != d_bcon.upload(bc) || hipSuccess != d_padpos.upload(padpos) || hipSuccess != ws.alloc(oxt + (size_t)nt * TSP_TR + 64)) {
+        release(); if (err) *err = "tile-sparse solver: device allocation"; return NLLS_ERR_HIP; }
+    launches = 0; for (auto& L : levels) launches += 1 + (L.nupd > 0 ? 1 : 0) + 1;
+    launches += 3;
+    ready = true;
+    return NLLS_OK;
+}
+
+int TspSolver::enqueue(hipStream_t st, double* S, double* s, int* status) const {
+    if (!ready) return NLLS_ERR_NOT_READY;
+    const int64_t strip0 = nslots * TSP_TE, npos = (int64_t)nt * TSP_TR;
+    double* W = ws.p + oW; double* LiD = ws.p + oLiD; double* Dfac = ws.p + oDfac; double* Dinv = ws.p + oDinv; double* xt = ws.p + oxt;
+    hipLaunchKernelGGL(tsp_begin_kernel, dim3((unsigned)((npos + npad_entries + 255) / 256)), dim3(256), 0, st, S, (const double*)s, (const int32_t*)d_ipos.p, (const int64_t*)d_padpos.p, npad_entries, npos, strip0);
+    for (const TspLevel& L : levels) {
+        launch_tsp_panel(st, S, W, LiD, Dfac, d_panel.p + L.panel0, L.npanel, status);
+        if (L.nupd > 0) hipLaunchKernelGGL(tsp_update_kernel, dim3((unsigned)L.nupd), dim3(512), 0, st, S, (const double*)W, (const TspUpdJob*)(d_upd.p + L.upd0), (const TspCon*)d_con.p);
+    }
+    launch_tsp_dinv(st, LiD, Dfac, Dinv, nt);
+    for (int lv = (int)levels.size() - 1; lv >= 0; --lv) { const TspLevel& L = levels[lv];
+        hipLaunchKernelGGL(tsp_backward_kernel, dim3((unsigned)L.nbwd), dim3(512), 0, st, (const double*)S, (const double*)Dinv, xt, (const TspBwdJob*)(d_bwd.p + L.bwd0), (const TspBwdCon*)d_bcon.p, strip0); }
+    hipLaunchKernelGGL(tsp_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, (const double*)xt, (const int32_t*)d_map.p, n);
+    return hipGetLastError() == hipSuccess ? NLLS_OK : NLLS_ERR_HIP;
+}
+
+}  // namespace nlls

@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: the ordering / independent-set rule of optimizesingles!, the sharding partition rule."""
 import numpy as np
+import pytest
 
 import nllssolver_jl_amd as N
 from nllssolver_jl_amd import kinds as K
@@ -122,3 +123,76 @@ def test_contaminated_gaussian_em_recovers_the_mixture():
     # one step from the truth stays at the truth
     k2 = contaminated_gaussian_em(contaminated_gaussian(1.0, 10.0, 0.8), x * x, maxiters=1)
     assert np.allclose(contaminated_gaussian_params(k2), [1.0, 10.0, 0.8], rtol=0.1)
+
+
+def _grid_graph(gw, gh, reach=2):
+    """cameras on a gw x gh grid, coupled when they lie within `reach` of each other in both directions (what a point seen by a 3 x 3 neighbourhood leaves)"""
+    idx = lambda x, y: y * gw + x
+    nbrs = [[] for _ in range(gw * gh)]
+    for y in range(gh):
+        for x in range(gw):
+            for dy in range(-reach, reach + 1):
+                for dx in range(-reach, reach + 1):
+                    xx, yy = x + dx, y + dy
+                    if (dx or dy) and 0 <= xx < gw and 0 <= yy < gh:
+                        nbrs[idx(x, y)].append(idx(xx, yy))
+    ptr = np.zeros(gw * gh + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in nbrs])
+    return ptr, np.array([w for l in nbrs for w in l], np.int32)
+
+
+def _nd_tiles(ptr, adj, dof, nborder=0):
+    from nllssolver_jl_amd import _capi
+    n = len(ptr) - 1; nall = n + nborder
+    tile_of = np.zeros(nall, np.int32); row = np.zeros(nall, np.int32); mt = nall + 1
+    parent = np.zeros(mt, np.int32); level = np.zeros(mt, np.int32); colptr = np.zeros(mt + 1, np.int64); rows = np.zeros(mt * mt // 2 + 1, np.int32)
+    nt = _capi.lib().nlls_nd_tiles(n, nborder, _capi._p(ptr), _capi._p(adj), _capi._p(dof), _capi._p(tile_of), _capi._p(row), mt, _capi._p(parent), _capi._p(level),
+                                   _capi._p(colptr), len(rows), _capi._p(rows))
+    assert nt > 0, nt
+    return nt, tile_of, row, parent[:nt], level[:nt], colptr[:nt + 1], rows
+
+
+@pytest.mark.parametrize("gw,gh,nborder,seed", [(12, 12, 0, 0), (17, 9, 0, 1), (14, 14, 2, 2)])
+def test_nd_tiles_symbolic_phase(gw, gh, nborder, seed):
+    """The symbolic phase of the tile-sparse reduced solver (nlls_nd_tiles -- what nlls_upload_structure runs; the reference's counterpart is ldl_analyze,
+    src/linearsystem.jl:52,68): every node in exactly one tile of at most 128 rows; the NUMERIC Cholesky factor of a random matrix with the graph's pattern,
+    permuted into the tile order, has no entry outside the predicted tile pattern; tiles of one level do not touch; the tree is much shallower than the
+    number of tile columns (the dependent chain of the factorisation)."""
+    rng = np.random.default_rng(seed)
+    ptr, adj = _grid_graph(gw, gh)
+    if seed == 1:                                              # relabelled cameras: the result must not depend on the numbering
+        n = gw * gh; p = rng.permutation(n); inv = np.argsort(p)
+        lists = [sorted(int(inv[w]) for w in adj[ptr[p[i]]:ptr[p[i] + 1]]) for i in range(n)]
+        ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists]); adj = np.array([w for l in lists for w in l], np.int32)
+    n = len(ptr) - 1; nall = n + nborder
+    dof = np.full(nall, 6, np.int32); dof[n:] = 3
+    nt, tile_of, row, parent, level, colptr, rows = _nd_tiles(ptr, adj, dof, nborder)
+    pos = tile_of.astype(np.int64) * 128 + row
+    used = np.zeros(nt * 128, bool)
+    for v in range(nall):
+        assert row[v] + dof[v] <= 128 and not used[pos[v]:pos[v] + dof[v]].any(); used[pos[v]:pos[v] + dof[v]] = True
+    # a random symmetric positive definite matrix with the graph's block pattern (+ border rows coupled to everything), in tile order, identity on the padding
+    N = nt * 128; M = np.zeros((N, N))
+    for v in range(n):
+        for w in adj[ptr[v]:ptr[v + 1]]:
+            if w < v:
+                B = rng.normal(size=(dof[v], dof[w])); M[pos[v]:pos[v] + dof[v], pos[w]:pos[w] + dof[w]] = B; M[pos[w]:pos[w] + dof[w], pos[v]:pos[v] + dof[v]] = B.T
+    for b in range(n, nall):
+        B = rng.normal(size=(dof[b], N)) * used; M[pos[b]:pos[b] + dof[b], :] = B; M[:, pos[b]:pos[b] + dof[b]] = B.T
+    M[np.arange(N), np.arange(N)] = np.where(used, 2.0 * np.abs(M).sum(axis=1).max() + 1.0, 1.0)
+    Lf = np.linalg.cholesky(M)
+    struct = [set(rows[colptr[k]:colptr[k + 1]].tolist()) for k in range(nt)]
+    for k in range(nt):
+        for i in range(k + 1, nt):
+            if np.abs(Lf[128 * i:128 * i + 128, 128 * k:128 * k + 128]).max() > 1e-13:
+                assert i in struct[k], (i, k)
+        assert all(level[i] > level[k] for i in struct[k])              # what a tile updates is factored in a later launch
+        assert parent[k] == (min(struct[k]) if struct[k] else -1)
+    assert level.max() + 1 <= 0.7 * nt, (level.max() + 1, nt)
+
+
+def test_nd_tiles_rejects_bad_input():
+    from nllssolver_jl_amd import _capi
+    z = np.zeros(8, np.int32); z64 = np.zeros(8, np.int64)
+    bad = np.array([5], np.int32)
+    assert _capi.lib().nlls_nd_tiles(1, 0, _capi._p(np.array([0, 1], np.int64)), _capi._p(bad), _capi._p(np.array([6], np.int32)), _capi._p(z), _capi._p(z), 4, _capi._p(z), _capi._p(z), _capi._p(z64), 4, _capi._p(z)) == _capi.ERR_INVALID_ARG
+    assert _capi.lib().nlls_nd_tiles(1, 0, _capi._p(np.array([0, 0], np.int64)), _capi._p(bad), _capi._p(np.array([129], np.int32)), _capi._p(z), _capi._p(z), 4, _capi._p(z), _capi._p(z), _capi._p(z64), 4, _capi._p(z)) == _capi.ERR_INVALID_ARG
