@@ -912,11 +912,12 @@ constexpr int DBB = 128;
 // ones on the diagonal, zeros above it.  Also: the sentinel into x[0, n).
 // ONE: a single block b1 whose factored tiles are still in its panel's scratch slot (Lslot, column-major 128 x 128: the look-ahead factorisation inverts a block
 // the moment it is factored -- the rows below it are then ONE matrix product with the inverse); no sentinel.
-// ONE == 2 (tile-sparse reduced system): every pivot tile's factored block in its own slot (Lslot + 128 x 128 per tile), no sentinel.
+// ONE == 2 (tile-sparse reduced system): the pivot tiles list[blockIdx.x], each one's factored block in its own slot (Lslot + 128 x 128 per tile), no sentinel.
 template <int ONE>
-__global__ __launch_bounds__(512) void dense_dinv_kernel(const double* __restrict__ S, const double* __restrict__ LiD, double* __restrict__ Dinv, double* __restrict__ x, int npad, int n, int b1, const double* __restrict__ Lslot) {
+__global__ __launch_bounds__(512) void dense_dinv_kernel(const double* __restrict__ S, const double* __restrict__ LiD, double* __restrict__ Dinv, double* __restrict__ x, int npad, int n, int b1, const double* __restrict__ Lslot,
+                                                         const int32_t* __restrict__ list = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];          // the 36 lower tiles of the block, [16][BP] each
-    const int b = ONE == 1 ? b1 : (int)blockIdx.x, t = threadIdx.x, c0 = DBB * b;
+    const int b = ONE == 1 ? b1 : (ONE == 2 ? list[blockIdx.x] : (int)blockIdx.x), t = threadIdx.x, c0 = DBB * b;
     if (ONE == 2) Lslot += (size_t)b * DBB * DBB;
     if (!ONE && t < DBB && c0 + t < n) x[c0 + t] = __longlong_as_double((long long)BCR_X_SENTINEL);
     for (int e0 = t; e0 < DBB * DBB; e0 += 8 * 512) {      // consecutive threads walk a column of S; eight loads in flight per thread
@@ -1030,18 +1031,20 @@ void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, 
 }
 
 // tile-sparse reduced system (nlls_tsp.hip): the panels of all pivot tiles of a level; the inverses of all factored diagonal tiles
-void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status) {
+void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch) {
     if (njobs <= 0) return;
-    static bool attr = false; constexpr int lds = (int)dense_panel_lds<8, 1>();
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    static bool attr = false; constexpr int lds1 = (int)dense_panel_lds<8, 1>(), lds2 = (int)dense_panel_lds<8, 2>();
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2); attr = true; }
     TspPanelArgs a{S, W, LiD, Dfac, jobs, status};
-    hipLaunchKernelGGL((dense_panel_kernel<8, 1, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds, st, a);
+    if (dch == 2) hipLaunchKernelGGL((dense_panel_kernel<8, 2, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds2, st, a);
+    else hipLaunchKernelGGL((dense_panel_kernel<8, 1, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds1, st, a);
 }
-void launch_tsp_dinv(hipStream_t st, const double* LiD, const double* Dfac, double* Dinv, int nt) {
-    if (nt <= 0) return;
+void launch_tsp_dinv(hipStream_t st, const double* LiD, const double* Dfac, double* Dinv, const int32_t* list, int nlist, int nt) {
+    if (nlist <= 0) return;
     static bool attr = false; constexpr int lds = (int)(sizeof(double) * 36 * BTS);
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL(dense_dinv_kernel<2>, dim3((unsigned)nt), dim3(512), lds, st, (const double*)nullptr, LiD, Dinv, (double*)nullptr, DBB * nt, 0, 0, Dfac);
+    hipLaunchKernelGGL(dense_dinv_kernel<2>, dim3((unsigned)nlist), dim3(512), lds, st, (const double*)nullptr, LiD, Dinv, (double*)nullptr, DBB * nt, 0, 0, Dfac, list);
 }
 
 // ---------------------------------------------------------------------------------------------------

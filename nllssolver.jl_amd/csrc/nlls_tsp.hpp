@@ -36,10 +36,12 @@ bool tsp_symbolic(const std::vector<std::vector<int32_t>>& adj, const std::vecto
 // ---- device side (nlls_tsp.hip) ----------------------------------------------------------------------------------------------------------
 struct TspPanelJob { int64_t doff, xoff; int32_t k, xld, rx, lead; };      // one workgroup of a level's panel launch: pivot tile k (diagonal tile at doff), 16 rx rows of X at xoff (leading dimension xld)
 struct TspCon { int64_t woff, loff; };                                      // one 128^3 product of an update job: C -= W(woff) L(loff)'
-struct TspUpdJob { int64_t coff; int32_t con0, ncon, diag, kind; };        // kind 0: 128 x 128 target tile (diag: on the diagonal, the strictly upper 64 x 64 blocks are skipped); kind 1: right-hand-side strip
-struct TspBwdJob { int32_t k, con0, ncon, pad; };                           // x_k = inv(L_kk)' (z_k - sum_c L(c.loff)' x_{c.i})
-struct TspBwdCon { int64_t loff; int32_t i, pad; };
-struct TspLevel { int npanel = 0, nupd = 0, nbwd = 0; size_t panel0 = 0, upd0 = 0, bwd0 = 0; };
+struct TspUpdJob { int64_t coff; int32_t con0, ncon, diag, kind; };        // kind 0: 128 x 128 target tile (diag: on the diagonal, the strictly upper 64 x 64 blocks are skipped); kind 1: right-hand-side strip; kind 2: a target tile whose contributions are split over several workgroups (atomic adds)
+struct TspTrsmJob { int64_t xoff; int32_t k, pad; };                        // a tile below the pivot tile k as ONE matrix product with inv(L_kk) (levels with many tiles)
+struct TspBwdJob { int32_t i, k; int64_t loff; };                           // backward pass: form x_i; k >= 0: push L_ik' x_i (tile at loff) to acc_k; k < 0: store x_i
+// scheme of a level's panel: 1 / 2 = one launch, every workgroup factors the pivot tile itself and takes 1 / 2 sixteen-row chunks of a tile below it (few tiles:
+// the pivot chain sets the pace); 3 = the pivot tiles alone (+ their strips), their explicit inverses, then every tile below as one matrix product (many tiles)
+struct TspLevel { int npanel = 0, nupd = 0, nupd_tile = 0, nbwd = 0, ntrsm = 0, npiv = 0, scheme = 1; size_t panel0 = 0, upd0 = 0, bwd0 = 0, trsm0 = 0; };
 
 struct TspSolver {
     bool ready = false;
@@ -48,21 +50,23 @@ struct TspSolver {
     std::vector<TspLevel> levels;
     DevBuf<int32_t> d_map;                         // [tpos (n) | tmap (nt * nt)]: position of a reduced unknown in tile order; slot of tile (i, j), i >= j (-1: structurally zero)
     DevBuf<int32_t> d_ipos;                        // reduced unknown at a tile-order position (-1: padding)
-    DevBuf<TspPanelJob> d_panel; DevBuf<TspUpdJob> d_upd; DevBuf<TspCon> d_con; DevBuf<TspBwdJob> d_bwd; DevBuf<TspBwdCon> d_bcon;
+    DevBuf<TspPanelJob> d_panel; DevBuf<TspUpdJob> d_upd; DevBuf<TspCon> d_con; DevBuf<TspBwdJob> d_bwd; DevBuf<TspTrsmJob> d_trsm;
+    DevBuf<int32_t> d_plist;                       // pivot tiles level by level (the inverses of a scheme-3 level), then the tiles of the other levels (inverted behind the last level)
+    int nrest = 0; size_t rest0 = 0;
     DevBuf<int64_t> d_padpos;                      // offsets (in S) of the padding's diagonal entries
-    DevBuf<double> ws;                             // W tiles + strips (as S) | LiD | Dfac | Dinv | xt
-    size_t oW = 0, oLiD = 0, oDfac = 0, oDinv = 0, oxt = 0;
+    DevBuf<double> ws;                             // W tiles + strips (as S) | LiD | Dfac | Dinv | xt | acc
+    size_t oW = 0, oLiD = 0, oDfac = 0, oDinv = 0, oxt = 0, oacc = 0;
     int64_t npad_entries = 0;
     int launches = 0; int64_t products = 0;
     size_t s_elems() const { return (size_t)nslots * TSP_TE + (size_t)nt * TSP_STRIP; }     // tiles, then one right-hand-side strip per tile column
     int build(const TspSym& sym, const std::vector<int32_t>& node_red_off, const std::vector<int32_t>& dof, int n_red, std::string* err);
     // S: [tiles | strips] assembled by the elimination through SLayout::at (mode SOLVE_TSPARSE), s: the reduced right-hand side in, the solution out
     int enqueue(hipStream_t st, double* S, double* s, int* status) const;
-    void release() { d_map.release(); d_ipos.release(); d_panel.release(); d_upd.release(); d_con.release(); d_bwd.release(); d_bcon.release(); d_padpos.release(); ws.release(); levels.clear(); ready = false; }
+    void release() { d_map.release(); d_ipos.release(); d_panel.release(); d_upd.release(); d_con.release(); d_bwd.release(); d_trsm.release(); d_plist.release(); d_padpos.release(); ws.release(); levels.clear(); ready = false; }
 };
 
 // (kernels shared with the dense LDL', nlls_bcr.hip)
-void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status);
-void launch_tsp_dinv(hipStream_t st, const double* LiD, const double* Dfac, double* Dinv, int nt);
+void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch);
+void launch_tsp_dinv(hipStream_t st, const double* LiD, const double* Dfac, double* Dinv, const int32_t* list, int nlist, int nt);
 
 }  // namespace nlls
