@@ -45,6 +45,10 @@ CONFIGS = {
     "ba_10kx1M": (10_000, 1_000_000, 0.001),            # 10x config 4 (not in BASELINE.json): 10M residual blocks, A.data 1.5 GB
     "curvefit_10k": None,                               # BASELINE.json configs[1]: 10k scalar residuals over 4 scalar variables (dense path)
     "ba_so3_500x50k": (500, 50_000, 0.02),              # BASELINE.json configs[4]: SO(3) cameras + adaptive kernel variable
+    # camera GRIDS (not in BASELINE.json; test/optimizeba.jl:22-23 leaves visibility a free parameter): (grid width, grid height, landmarks per cell), every landmark
+    # seen by the 3 x 3 block of cameras around its cell -- a reduced camera system that is neither a narrow band nor small: the tile-sparse solver's workload
+    "ba_grid_40x40": (40, 40, 6),
+    "ba_grid_100x100": (100, 100, 3),
 }
 
 
@@ -104,7 +108,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ba_1kx100k", choices=sorted(CONFIGS))
-    ap.add_argument("--solver", default="default", choices=["default", "dense", "chain", "deterministic"],
+    ap.add_argument("--solver", default="default", choices=["default", "dense", "chain", "deterministic", "windowed"],
                     help="reduced-system solver: block cyclic reduction of the band (default), the dense MFMA LDL' (NLLS_FLAG_NO_BAND), "
                          "the round-1 twisted chain kernels (NLLS_FLAG_NO_BCR), or the atomics-free assembly (NLLS_FLAG_DETERMINISTIC)")
     ap.add_argument("--shuffle-cameras", type=int, default=None, metavar="SEED",
@@ -163,6 +167,14 @@ def main():
             problem = synthetic.shuffle_camera_labels(problem, ncam, args.shuffle_cameras, first=2)
         problem = synthetic.perturb_ba_problem(problem, 1e-3, 1e-3)
         workload_desc = {"robust": "ContaminatedGaussian adaptive kernel (variable #1)", "outliers": "10% of measurements + N(0,0.1^2), seed 1", "cameras": "SO(3) poses, pinhole"}
+    elif args.workload.startswith("ba_grid_"):
+        gw, gh, ppc = CONFIGS[args.workload]
+        ncam, npts = gw * gh, gw * gh * ppc
+        problem = synthetic.create_grid_ba_problem(gw, gh, ppc, seed=1, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05, noise=1e-3)
+        if args.shuffle_cameras is not None:
+            problem = synthetic.shuffle_camera_labels(problem, ncam, args.shuffle_cameras)
+        problem = synthetic.perturb_ba_problem(problem, 1e-3, 1e-3)
+        workload_desc = {"robust": "Huber(0.05)", "outliers": "5% of measurements + N(0,0.05^2), seed 1", "visibility": f"{gw} x {gh} camera grid, {ppc} landmarks per cell, each seen by a 3 x 3 block of cameras"}
     else:
         ncam, npts, prop = CONFIGS[args.workload]
         problem = synthetic.create_ba_problem(ncam, npts, prop, seed=1, robust=N.HuberKernel(0.01),
@@ -175,7 +187,7 @@ def main():
         workload_desc["camera_labels"] = f"permuted (seed {args.shuffle_cameras})"
     nobs = problem.ncosts()
     start_vars = problem.variables.copy()
-    flags = {"default": 0, "dense": _capi.FLAG_NO_BAND, "chain": _capi.FLAG_NO_BCR, "deterministic": _capi.FLAG_DETERMINISTIC}[args.solver]
+    flags = {"default": 0, "dense": _capi.FLAG_NO_BAND, "chain": _capi.FLAG_NO_BCR, "deterministic": _capi.FLAG_DETERMINISTIC, "windowed": _capi.FLAG_NO_TILE_SPARSE}[args.solver]
 
     ls = ShardedLS(problem, np.ones(problem.nvariables, bool), flags=flags, device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged, force_collectives=force_dist)
     info = ls.info
@@ -314,7 +326,7 @@ def main():
     roofline_solve = None
     if world == 1 and info.nreduced_dof > 0 and reduced_ms > 0:
         n, bw, mode = int(info.nreduced_dof), int(info.bandwidth), int(info.solve_mode)
-        useful = float(n) * bw * bw if mode == 2 else float(n) ** 3 / 3.0
+        useful = float(n) * bw * bw if mode == 2 else (2.0 * 128 ** 3 * solve_stats.get("tsp_products", 0) if mode == 3 else float(n) ** 3 / 3.0)
         issued = 2048.0 * solve_stats.get("bcr_mfma_issued", 0) if mode == 2 and solve_stats.get("bcr_mfma_issued", 0) else None
         # the launcher's count of issued MFMAs against the hardware counter (profiles/pmc_mfma.json, tools/pmc_mfma.sh): quoted only when the
         # counters were collected on THIS build of the solver and agree with it
@@ -337,9 +349,10 @@ def main():
                 issued_check = f"unchecked: {type(e).__name__}"
         roofline_solve = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
                           "kernel": {2: "block cyclic reduction of the bordered band (bcr_panel / bcr_update / bcr_backward kernels)" if solve_stats.get("bcr_levels") else "twisted blocked band LDL' (chain kernels)",
-                                     1: "dense blocked LDL' (MFMA trailing update)", 0: "one-wave dense solve"}[mode],
+                                     1: "dense blocked LDL' (MFMA trailing update)", 0: "one-wave dense solve",
+                                     3: "tile-sparse LDL' in a nested-dissection order, level by level of the tile elimination tree (dense_panel<TSP> / tsp_trsm / tsp_update / tsp_backward kernels)"}[mode],
                           "reduced_dof": n, "bandwidth": bw, "us": round(1e3 * reduced_ms, 1),
-                          "useful_flops": useful, "useful_flops_formula": "n * bw^2" if mode == 2 else "n^3 / 3",
+                          "useful_flops": useful, "useful_flops_formula": "n * bw^2" if mode == 2 else ("2 * 128^3 * (tile products of the updates + panel products)" if mode == 3 else "n^3 / 3"),
                           # `achieved` / `frac` count USEFUL flops only; what the matrix cores are actually issued (tile padding, the diagonal
                           # block factored redundantly by every workgroup of a panel launch, inv(L)) is kept beside them as issued_*
                           "achieved": round(useful / (reduced_ms * 1e-3) / 1e12, 4),
@@ -347,14 +360,15 @@ def main():
                           "issued_mfma_flops": issued, "issued_mfma_check": issued_check,
                           "issued_achieved": round(issued / (reduced_ms * 1e-3) / 1e12, 4) if issued else None,
                           "issued_frac": round(issued / (reduced_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5) if issued else None,
-                          "levels": solve_stats.get("bcr_levels"), "launches": solve_stats.get("bcr_launches"),
+                          "levels": solve_stats.get("tsp_levels") if mode == 3 else solve_stats.get("bcr_levels"), "launches": solve_stats.get("tsp_launches") if mode == 3 else solve_stats.get("bcr_launches"),
+                          "tiles": solve_stats.get("tsp_tiles") if mode == 3 else None, "lower_tiles_stored": solve_stats.get("tsp_lower_tiles") if mode == 3 else None,
                           "note": "a banded LDL' is a chain of dependent pivots: latency-, not MFMA-bound -- the fraction says how far, not how well tuned"
-                                  if mode == 2 else None}
+                                  if mode == 2 else ("the depth of the tile elimination tree (levels), not the flops, is the dependent chain: one 128-pivot panel per level" if mode == 3 else None)}
 
     # ---- the DENSE reduced solve (NLLS_FLAG_NO_BAND) of the same reduced system: the only MFMA-bound kernel of the path, and the solver of every reduced
     # system that no ordering turns into a band.  One upload of its own, outside the timed region.
     roofline_solve_dense = None
-    if world == 1 and info.is_sparse and info.has_schur and info.nreduced_dof >= 512 and args.solver == "default" and not os.environ.get("NLLS_BENCH_NO_DENSE"):
+    if world == 1 and info.is_sparse and info.has_schur and 512 <= info.nreduced_dof <= 20000 and args.solver == "default" and not os.environ.get("NLLS_BENCH_NO_DENSE"):
         dls = ShardedLS(problem, np.ones(problem.nvariables, bool), flags=_capi.FLAG_NO_BAND, device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged)
         if dls.info.solve_mode == 1:
             dls.ctx.set_variables(start_vars, VARS_CURRENT); dls.ctx.sweep_gradhess(); dls.ctx.damp(1e-3 * dls.ctx.max_abs_diag())

@@ -123,7 +123,7 @@ typedef struct nlls_info {
     int64_t nschur_blocks;   /* number of eliminated (Schur) variable blocks                         */
     int64_t nreduced_dof;    /* order of the dense reduced system                                    */
     int64_t owner_path;      /* 1: deterministic owner-gather accumulate, 0: atomic scatter          */
-    int64_t solve_mode;      /* 0 small (one wave), 1 dense blocked LDL' (MFMA), 2 bordered band      */
+    int64_t solve_mode;      /* 0 small (one wave), 1 dense blocked LDL' (MFMA), 2 bordered band, 3 tile-sparse LDL' (nested dissection) */
     int64_t bandwidth;       /* half bandwidth (dof) of the banded part of the reduced system         */
     int64_t nborder_dof;     /* dof ordered last in the reduced system (dense border)                 */
 } nlls_info;
@@ -245,7 +245,9 @@ int  nlls_solve(nlls_ctx* ctx, double* x_out);
  * of A.data / b since the upload, [12] LM trials since the upload that ran on rows NOT summed (nlls_sweep_gradhess(ctx, NULL) leaves them as the
  * rank's share: everything a trial takes from them is linear in them).  [13] 1: the reduced blocks are in reverse Cuthill-McKee order (0: the caller's),
  * [14] half bandwidth (dof) the caller's order would have given (-1: not computed), [15] 1: the dense LDL' (solve_mode 1) is restricted to the band of the
- * re-ordered reduced system and the border strip ("windowed": O(n w^2) work in dense storage, for bands too wide for the band kernels). */
+ * re-ordered reduced system and the border strip ("windowed": O(n w^2) work in dense storage, for bands too wide for the band kernels).
+ * Tile-sparse solver (solve_mode 3): [16] tiles of 128 unknowns, [17] levels of the tile elimination tree (the dependent chain of the factorisation),
+ * [18] lower tiles stored (fill included), [19] kernel launches per reduced solve, [20] 128^3 tile products per factorisation (updates + panels). */
 int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
 int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
 int  nlls_get_step(nlls_ctx* ctx, double* x_out);

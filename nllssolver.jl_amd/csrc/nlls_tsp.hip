@@ -376,6 +376,7 @@ int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off
             for (int64_t pc = 0; pc < pieces; ++pc) { const int64_t c0 = pc * nc / pieces, c1 = (pc + 1) * nc / pieces;
                 uj.push_back(TspUpdJob{slot(o.second.first, o.second.second), (int32_t)(uc.size() + c0), (int32_t)(c1 - c0), o.second.first == o.second.second ? 1 : 0, pieces > 1 ? 2 : 0}); }
             uc.insert(uc.end(), cl.begin(), cl.end()); products += nc; }
+        products += below;                                     // (the tiles below the pivot tiles: one product each with inv(L_kk)')
         L.nupd_tile = (int)(uj.size() - L.upd0);
         for (auto& kv : rhs) { uj.push_back(TspUpdJob{strip0 + (int64_t)kv.first * TSP_STRIP, (int32_t)uc.size(), (int32_t)kv.second.size(), 0, 1}); uc.insert(uc.end(), kv.second.begin(), kv.second.end()); }
         L.npanel = (int)(pj.size() - L.panel0); L.nupd = (int)(uj.size() - L.upd0); L.nbwd = (int)(bj.size() - L.bwd0); L.ntrsm = (int)(tj.size() - L.trsm0); L.npiv = (int)np;

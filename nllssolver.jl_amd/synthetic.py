@@ -150,6 +150,22 @@ def widen_visibility(problem, ncameras, wide):
     return problem
 
 
+def grid_visibility(gw, gh, pts_per_cell):
+    """(camera, landmark) pairs, 1-based and camera-major, of gw x gh cameras on a grid with pts_per_cell landmarks per cell, each seen by the 3 x 3 block of
+    cameras around its cell (clipped at the border); the number of landmarks."""
+    cx, cy = np.meshgrid(np.arange(gw), np.arange(gh), indexing="xy")
+    cell = np.repeat(np.stack([cx.ravel(), cy.ravel()], axis=1), pts_per_cell, axis=0)            # the cell of every landmark
+    cam_l, lm_l = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            x, y = cell[:, 0] + dx, cell[:, 1] + dy
+            ok = (x >= 0) & (x < gw) & (y >= 0) & (y < gh)
+            cam_l.append((y[ok] * gw + x[ok]) + 1); lm_l.append(np.nonzero(ok)[0] + 1)
+    cam, lm = np.concatenate(cam_l), np.concatenate(lm_l)
+    order = np.lexsort((lm, cam))
+    return cam[order], lm[order], cell.shape[0]
+
+
 def create_grid_ba_problem(gw, gh, pts_per_cell=6, seed=1, robust=None, outlier_frac=0.0, outlier_sigma=0.0, noise=0.0):
     """A bundle adjustment whose camera graph is a 2-D GRID (an aerial survey: gw x gh cameras in rows, every landmark seen by the 3 x 3 block of cameras
     around its cell, clipped at the border) -- the reduced camera system is then neither a narrow band nor small: row-major numbering gives a half bandwidth of
@@ -158,18 +174,8 @@ def create_grid_ba_problem(gw, gh, pts_per_cell=6, seed=1, robust=None, outlier_
     rng = np.random.default_rng(seed)
     ncam = gw * gh
     cams = rng.standard_normal((ncam, 6)) + np.array([1.0, 0, 0, 0, 1.0, 0])
-    cx, cy = np.meshgrid(np.arange(gw), np.arange(gh), indexing="xy")
-    cell = np.repeat(np.stack([cx.ravel(), cy.ravel()], axis=1), pts_per_cell, axis=0)            # the cell of every landmark
-    npts = cell.shape[0]
+    cam, lm, npts = grid_visibility(gw, gh, pts_per_cell)
     pts = rng.random((npts, 3)) + np.array([-0.5, -0.5, 10.0])
-    cam_l, lm_l = [], []
-    for dx in (-1, 0, 1):
-        for dy in (-1, 0, 1):
-            x, y = cell[:, 0] + dx, cell[:, 1] + dy
-            ok = (x >= 0) & (x < gw) & (y >= 0) & (y < gh)
-            cam_l.append((y[ok] * gw + x[ok]) + 1); lm_l.append(np.nonzero(ok)[0] + 1)
-    cam, lm = np.concatenate(cam_l), np.concatenate(lm_l)
-    order = np.lexsort((lm, cam)); cam, lm = cam[order], lm[order]
     problem = NLLSProblem(); problem.addvariables(cams); problem.addvariables(pts)
     c, X = cams[cam - 1], pts[lm - 1]
     meas = np.stack([(c[:, 0:3] * X).sum(1), (c[:, 3:6] * X).sum(1)], axis=1)
@@ -245,9 +251,10 @@ def create_curvefit_problem(n=10_000, seed=1, noise=0.01):
 
 
 def create_so3_ba_problem(ncameras, nlandmarks, propvisible, seed=1, adaptive=True, outlier_frac=0.1,
-                          noise=1e-3, outlier_sigma=0.1, robust=None):
+                          noise=1e-3, outlier_sigma=0.1, robust=None, visibility=None):
     """BASELINE config 5: pinhole cameras with SO(3) rotations (new kind), optionally with
-    a ContaminatedGaussian adaptive kernel as variable #1 (src/residual.jl:46-47)."""
+    a ContaminatedGaussian adaptive kernel as variable #1 (src/residual.jl:46-47).  visibility: (camera, landmark) pairs
+    to use instead of the reference generator's windows (e.g. grid_visibility)."""
     from .variables import so3_exp
     rng = np.random.default_rng(seed)
     problem = NLLSProblem()
@@ -265,7 +272,7 @@ def create_so3_ba_problem(ncameras, nlandmarks, propvisible, seed=1, adaptive=Tr
     pts = rng.random((nlandmarks, 3)) + np.array([-0.5, -0.5, 5.0])
     problem.addvariables(poses, K.VAR_POSE_SO3)
     problem.addvariables(pts)
-    cam, lm = ba_visibility(ncameras, nlandmarks, propvisible)
+    cam, lm = ba_visibility(ncameras, nlandmarks, propvisible) if visibility is None else visibility
     R = poses[cam - 1, :9].reshape(-1, 3, 3).transpose(0, 2, 1)      # col-major storage -> R[n, r, c]
     Y = np.einsum("nrc,nc->nr", R, pts[lm - 1]) + poses[cam - 1, 9:]
     meas = Y[:, :2] / Y[:, 2:3] + rng.standard_normal((cam.size, 2)) * noise

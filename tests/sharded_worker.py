@@ -36,7 +36,8 @@ def main():
         return presharded(rank, world, dist, staged, seed)
     if 7000 <= seed < 8000:
         return deadline(rank, world, dist, staged)
-    shuffled = seed >= 6000                      # the cameras' labels permuted: the reduced system is re-ordered at upload (every rank must arrive at the same order)
+    grid = 8000 <= seed < 9000                   # a 24 x 24 camera grid with permuted labels: the reduced system goes to the tile-sparse solver (nested dissection at upload: every rank must arrive at the same tiles)
+    shuffled = 6000 <= seed < 8000               # the cameras' labels permuted: the reduced system is re-ordered at upload (every rank must arrive at the same order)
     rng = np.random.default_rng(seed)
     ncr = int(rng.integers(12, 90))             # (sharding partitions by eliminated block: stay within what the Schur kernels take)
     shape = (40, 2000, 0.15) if seed == 21 else (90, 3000, 0.08) if shuffled else (ncr, int(rng.integers(300, 4000)), float(rng.uniform(4.0, 10.0)) / ncr)
@@ -46,10 +47,16 @@ def main():
     shuf = (lambda q: synthetic.shuffle_camera_labels(q, shape[0], seed)) if shuffled else (lambda q: q)
     mkp = lambda: synthetic.perturb_ba_problem(shuf(synthetic.create_ba_problem(*shape, seed=1 if config3 else seed, robust=N.HuberKernel(0.01 if config3 else 0.05),
                                                                                 outlier_frac=0.05, outlier_sigma=0.05)), 1e-3, 1e-3)
+    if grid:
+        mkp = lambda: synthetic.perturb_ba_problem(synthetic.shuffle_camera_labels(synthetic.create_grid_ba_problem(24, 24, 4, seed=3, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05,
+                                                                                                                    noise=1e-3), 576, seed), 1e-3, 1e-3)
     p = mkp()
     unfixed = np.ones(p.nvariables, bool)
     ref = MultiVariateLSgpu(p, unfixed)                       # unsharded reference on the same device
     sh = mk()
+    if grid:
+        st_r, st_s = ref.ctx.solve_stats(), sh.ctx.solve_stats()
+        assert ref.info.solve_mode == 3 and sh.info.solve_mode == 3 and all(st_r[k] == st_s[k] for k in ("tsp_tiles", "tsp_levels", "tsp_lower_tiles")), (st_r, st_s)
     if shuffled:
         st_r, st_s = ref.ctx.solve_stats(), sh.ctx.solve_stats()
         assert st_r["reordered"] == 1 and st_s["reordered"] == 1 and ref.info.solve_mode == 2 and sh.info.solve_mode == 2 and sh.info.bandwidth == ref.info.bandwidth, (st_r, st_s)
@@ -116,6 +123,12 @@ def main():
     if config3:
         ores = oracle_problem(mkp()).optimize(maxiters=4)
         assert np.isclose(ores.bestcost, cs, rtol=1e-8), (ores.bestcost, cs)
+    if grid:        # (no dogleg leg: its undamped steps on this gauge-free problem need the pivot floor only the band solver has)
+        for o in (ref, sh, ref2, sh2):
+            o.close()
+        dist.barrier(); dist.destroy_process_group()
+        print(f"rank {rank}: sharded == unsharded (tile-sparse reduced solver, cost {cs:.6e}, owned {info['local_ncost']} of {p.ncosts()} cost blocks)")
+        return
     ref3 = MultiVariateLSgpu(p, unfixed); sh3 = mk()
     cd_r, _ = run(ref3, 4, It.DoglegData, It.iterate_dogleg); cd_s, _ = run(sh3, 4, It.DoglegData, It.iterate_dogleg)
     # (dogleg takes UNDAMPED Newton steps: on the gauge-free affine camera H is singular and the step along the gauge directions is decided by
@@ -144,12 +157,17 @@ def presharded(rank, world, dist, staged, seed):
     from nllssolver_jl_amd.linearsystem import MultiVariateLSgpu
     ncam, npts = 60, 3000
     shuffled = seed % 1000 >= 100               # camera labels permuted: the ranks agree on the reverse Cuthill-McKee order of the UNION of their camera graphs
-    p = synthetic.create_ba_problem(ncam, npts, 0.12, seed=seed, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05)
+    grid = seed % 1000 >= 300                   # a 24 x 24 camera grid (labels permuted): the tile-sparse solver's nested dissection runs on the UNION of the ranks' camera graphs
+    if grid:
+        ncam, npts = 576, 576 * 4
+        p = synthetic.create_grid_ba_problem(24, 24, 4, seed=3, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05, noise=1e-3)
+    else:
+        p = synthetic.create_ba_problem(ncam, npts, 0.12, seed=seed, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05)
     if shuffled:
         p = synthetic.shuffle_camera_labels(p, ncam, seed)
     p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
     mine = synthetic.shard_of_problem(p, ncam, rank, world)
-    if seed % 1000 >= 200:
+    if 200 <= seed % 1000 < 300:
         # the share with its POINTS listed before the cameras: the cameras' rows of A.data then hold the E blocks, as many as this rank has observations --
         # the ranks' stage-0 buffers would differ in length and be summed element by element.  The upload must refuse it, on every rank alike.
         g = next(iter(mine.costs.values())); vi, da = g.arrays(); nl = mine.nvariables - ncam
@@ -175,7 +193,10 @@ def presharded(rank, world, dist, staged, seed):
     ref = MultiVariateLSgpu(p, np.ones(p.nvariables, bool)); dr = run(ref, p, True)
     sh = ShardedLS(mine, np.ones(mine.nvariables, bool), rank=rank, world=world, dist=dist, host_staged=staged, presharded=True)
     assert sh.info.nreduced_dof == ref.info.nreduced_dof and sh.info.bandwidth == ref.info.bandwidth, (sh.info.bandwidth, ref.info.bandwidth)   # the agreed layout
-    if shuffled:
+    if grid:
+        st_r, st_s = ref.ctx.solve_stats(), sh.ctx.solve_stats()
+        assert ref.info.solve_mode == 3 and sh.info.solve_mode == 3 and all(st_r[k] == st_s[k] for k in ("tsp_tiles", "tsp_levels", "tsp_lower_tiles")), (st_r, st_s)
+    elif shuffled:
         assert sh.ctx.solve_stats()["reordered"] == 1 and sh.info.solve_mode == 2, (sh.ctx.solve_stats(), sh.info.solve_mode)
     ds = run(sh, mine, True)
     assert np.isclose(ds.startcost, dr.startcost, rtol=1e-12) and np.isclose(ds.bestcost, dr.bestcost, rtol=1e-9), (ds.bestcost, dr.bestcost)

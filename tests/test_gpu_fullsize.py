@@ -106,27 +106,33 @@ def test_large_dense_solve_more_workgroups_than_the_chip_holds():
     assert info.solve_mode == 1 and info.nreduced_dof == info.ndof == 6 * 83 + 3 * 2900
 
 
-def test_grid_40x40_windowed_solve_is_faster_than_dense():
-    """40 x 40 cameras on a grid, every landmark seen by a 3 x 3 block: 9600 reduced dof, half bandwidth ~ 500.  The windowed dense LDL' (band of the
-    re-ordered system + border strip) against the oracle, and at least 2.5 x faster than the full dense factorisation of the same reduced system (NLLS_FLAG_NO_BAND;
-    measured: 3.45 against 10.5 ms -- 75 dependent 128-column steps of ~45 us each are what is left: the pivot chain of a step, not its flops)."""
+def test_grid_40x40_tile_sparse_and_windowed_solves_against_dense():
+    """40 x 40 cameras on a grid, every landmark seen by a 3 x 3 block: 9600 reduced dof, half bandwidth ~ 500 -- neither a narrow band nor small.  Default: the
+    TILE-SPARSE solver (nested dissection into 107 tiles, 16 levels of the elimination tree instead of 75 dependent 128-column steps) against the oracle, and at
+    least 5 x faster than the full dense factorisation of the same reduced system (NLLS_FLAG_NO_BAND; measured: 1.2 against 10.5 ms).  NLLS_FLAG_NO_TILE_SPARSE:
+    the windowed dense LDL' (band of the re-ordered system + border strip), at least 2.5 x faster than dense (measured 3.45 ms: 75 steps of ~45 us)."""
     p = synthetic.perturb_ba_problem(synthetic.create_grid_ba_problem(40, 40, 6, seed=2, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05, noise=1e-3), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
-    assert info.nreduced_dof == 9600 and info.solve_mode == 1
+    assert info.nreduced_dof == 9600 and info.solve_mode == 3
+    info_w = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4, flags=_capi.FLAG_NO_TILE_SPARSE)
+    assert info_w.solve_mode == 1
     bi = np.arange(1, p.nvariables + 1, dtype=np.uint64)
     times = {}
-    for name, flags in (("windowed", 0), ("dense", _capi.FLAG_NO_BAND)):
+    for name, flags in (("tile_sparse", 0), ("windowed", _capi.FLAG_NO_TILE_SPARSE), ("dense", _capi.FLAG_NO_BAND)):
         ctx = _capi.Context(); ctx.upload(p.var_kind, p.var_dim, bi, p.groups(), flags)
         assert ctx.solve_stats()["dense_window"] == (1 if name == "windowed" else 0)
         ctx.set_variables(p.variables); ctx.sweep_gradhess(); ctx.damp(1e-4 * ctx.max_abs_diag()); ctx.solve()
         times[name] = ctx.time_reduced_solve(3); ctx.close()
-    print(f"reduced solve of 9600 dof: windowed {times['windowed']:.3f} ms, dense {times['dense']:.3f} ms")
+    print(f"reduced solve of 9600 dof: tile-sparse {times['tile_sparse']:.3f} ms, windowed {times['windowed']:.3f} ms, dense {times['dense']:.3f} ms")
     assert times["dense"] >= 2.5 * times["windowed"], times
+    assert times["dense"] >= 5.0 * times["tile_sparse"], times
 
 
-def test_grid_10k_cameras_is_not_declined():
-    """100 x 100 cameras (60 000 reduced dof, no narrow band): round 3 declined everything above 46 000 reduced dof.  The limit is now what the device holds
-    (the windowed dense solver in npad^2 doubles: 29 GB of the 288 GB); one sweep + damped solve against the oracle."""
+@pytest.mark.parametrize("flags,mode", [(0, 3), (_capi.FLAG_NO_TILE_SPARSE, 1)])
+def test_grid_10k_cameras_is_not_declined(flags, mode):
+    """100 x 100 cameras (60 000 reduced dof, no narrow band): round 3 declined everything above 46 000 reduced dof.  Default: the tile-sparse solver (699 tiles,
+    43 levels; measured 6.5 ms per reduced solve); NLLS_FLAG_NO_TILE_SPARSE: the windowed dense solver in npad^2 doubles (29 GB of the 288 GB; 24 ms) -- the
+    limit is what the device holds.  One sweep + damped solve against the oracle."""
     p = synthetic.perturb_ba_problem(synthetic.create_grid_ba_problem(100, 100, 3, seed=4, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05, noise=1e-3), 1e-3, 1e-3)
-    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
-    assert info.nreduced_dof == 60000 and info.solve_mode == 1 and info.bandwidth < 6 * 230
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4, flags=flags)
+    assert info.nreduced_dof == 60000 and info.solve_mode == mode and info.bandwidth < 6 * 230

@@ -2,6 +2,8 @@
 same seeded inputs.  Tolerances (fp64): the GPU sums in a different order than the sequential reference
 (SURVEY.md "fp64 reduction order"), so values agree to ~1e-12 relative, not bit for bit; index arrays
 (the BlockSparseMatrix layout) must agree exactly."""
+import os
+
 import numpy as np
 import pytest
 
@@ -172,16 +174,17 @@ def test_random_visibility_has_no_band(ncam, npts, k, seed):
 @pytest.mark.parametrize("gw,gh,shuffle", [(16, 12, None), (24, 24, 5)])
 def test_grid_camera_graph_windowed_dense_solve(gw, gh, shuffle):
     """A 2-D grid of cameras (every landmark seen by a 3 x 3 block): the reduced camera system is a WIDE band -- too wide for the band kernels (> 80 columns),
-    far narrower than the system.  The dense blocked LDL' then works only inside the band of the re-ordered system and the border strip (`dense_window`);
-    with shuffled camera labels the reverse Cuthill-McKee ordering of the upload has to find the band first.  Sweep, solve, retraction and LM against the oracle,
-    whose sparse LDL' takes any structure (as the reference's does: src/linearsolver.jl:28-32)."""
+    far narrower than the system.  With the tile-sparse solver switched off (NLLS_FLAG_NO_TILE_SPARSE) the dense blocked LDL' works only inside the band of the
+    re-ordered system and the border strip (`dense_window`); with shuffled camera labels the reverse Cuthill-McKee ordering of the upload has to find the band
+    first.  Sweep, solve, retraction and LM against the oracle, whose sparse LDL' takes any structure (as the reference's does: src/linearsolver.jl:28-32)."""
     mk = lambda: synthetic.create_grid_ba_problem(gw, gh, 4, seed=3, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05, noise=1e-3)
     p = mk()
     if shuffle is not None:
         p = synthetic.shuffle_camera_labels(p, gw * gh, shuffle)
     p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
-    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
-    _, st = _upload_info(p)
+    NTS = _capi.FLAG_NO_TILE_SPARSE
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4, flags=NTS)
+    _, st = _upload_info(p, NTS)
     assert info.solve_mode == 1 and info.nreduced_dof == 6 * gw * gh
     if 6 * gw * gh >= 1024:
         # (row-major numbering: 2 rows + 2 cameras; reverse Cuthill-McKee from a corner of a shuffled grid walks L-shaped shells: up to twice that)
@@ -190,6 +193,44 @@ def test_grid_camera_graph_windowed_dense_solve(gw, gh, shuffle):
         assert info2.solve_mode == 1 and _upload_info(p, _capi.FLAG_NO_BAND)[1]["dense_window"] == 0
     if shuffle is not None:
         assert st["reordered"] == 1
+    q_vars = p.variables.copy()
+    op = oracle_problem(p); ro = op.optimize(iterator=1, maxiters=5)
+    p.variables[:] = q_vars
+    os.environ["NLLS_NO_TSPARSE"] = "1"
+    try:
+        rg = N.optimize(p, N.NLLSOptions(maxiters=5))
+    finally:
+        del os.environ["NLLS_NO_TSPARSE"]
+    assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
+
+
+@pytest.mark.parametrize("gw,gh,shuffle,kind", [(24, 24, None, "affine"), (24, 24, 5, "affine"), (31, 17, 9, "affine"), (20, 20, 3, "so3_adaptive"), (13, 40, None, "affine")])
+def test_grid_camera_graph_tile_sparse_solve(gw, gh, shuffle, kind):
+    """The same camera grids through the TILE-SPARSE reduced solver (solve_mode 3, nlls_tsp.hip): the reduced blocks ordered by nested dissection and packed into
+    128-row tiles, the LDL' factored level by level of the tile elimination tree -- the counterpart of the reference's ldl_analyze + ldl_factorize
+    (src/linearsystem.jl:52,68, src/linearsolver.jl:28-32), which take any sparsity and any numbering.  Labels shuffled or not, affine cameras or SO(3) poses
+    under an adaptive kernel whose variable couples to every block (a BORDER of the reduced system: its tile is a neighbour of every tile): sweep, damped solve
+    (x at rtol 1e-7), retraction and five LM iterations against the oracle; x also against the dense LDL' of the same system."""
+    if kind == "affine":
+        p = synthetic.create_grid_ba_problem(gw, gh, 4, seed=3, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05, noise=1e-3)
+        first, cdof = 1, 6
+    else:
+        cam, lm, npts = synthetic.grid_visibility(gw, gh, 4)
+        p = synthetic.create_so3_ba_problem(gw * gh, npts, 0.0, seed=3, adaptive=True, visibility=(cam, lm))
+        first, cdof = 2, 6
+    if shuffle is not None:
+        p = synthetic.shuffle_camera_labels(p, gw * gh, shuffle, first=first)
+    p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3) if kind == "affine" else p
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
+    assert info.solve_mode == 3 and info.nreduced_dof == cdof * gw * gh + (3 if kind != "affine" else 0), (info.solve_mode, info.nreduced_dof)
+    if kind != "affine":
+        assert info.nborder_dof == 3
+    # the same damped system by the dense LDL'
+    bi = np.arange(1, p.nvariables + 1, dtype=np.uint64); xs = []
+    for flags in (0, _capi.FLAG_NO_BAND):
+        ctx = _capi.Context(); ctx.upload(p.var_kind, p.var_dim, bi, p.groups(), flags)
+        ctx.set_variables(p.variables); ctx.sweep_gradhess(); ctx.damp(1e-4 * ctx.max_abs_diag()); ctx.solve(); xs.append(ctx.get_step().copy()); ctx.close()
+    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-10 * np.linalg.norm(xs[1])
     q_vars = p.variables.copy()
     op = oracle_problem(p); ro = op.optimize(iterator=1, maxiters=5)
     p.variables[:] = q_vars
