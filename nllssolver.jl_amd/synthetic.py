@@ -166,6 +166,42 @@ def grid_visibility(gw, gh, pts_per_cell):
     return cam[order], lm[order], cell.shape[0]
 
 
+def scattered_visibility(ncameras, nlandmarks, nviews, seed, loop=False):
+    """(camera, landmark) pairs, 1-based and camera-major, of cameras SCATTERED over the unit square (loop=True: along a closed ring -- a loop closure), every
+    landmark at a random place seen by the `nviews` cameras nearest to it: an unstructured camera graph (no grid, no numbering to exploit)."""
+    rng = np.random.default_rng(seed)
+    if loop:
+        t = np.sort(rng.random(ncameras)) * 2 * np.pi
+        cpos = np.stack([np.cos(t), np.sin(t)], axis=1) * (1.0 + 0.02 * rng.standard_normal((ncameras, 1)))
+        tl = rng.random(nlandmarks) * 2 * np.pi
+        lpos = np.stack([np.cos(tl), np.sin(tl)], axis=1) * (1.0 + 0.05 * rng.standard_normal((nlandmarks, 1)))
+    else:
+        cpos = rng.random((ncameras, 2)); lpos = rng.random((nlandmarks, 2))
+    from scipy.spatial import cKDTree
+    _, nn = cKDTree(cpos).query(lpos, k=nviews)
+    cam = nn.ravel() + 1; lm = np.repeat(np.arange(nlandmarks), nviews) + 1
+    order = np.lexsort((lm, cam))
+    return cam[order], lm[order]
+
+
+def create_scattered_ba_problem(ncameras, nlandmarks, nviews=6, seed=1, robust=None, outlier_frac=0.0, outlier_sigma=0.0, noise=0.0, loop=False):
+    """The affine-camera bundle adjustment of test/optimizeba.jl:4-35 over scattered_visibility (visibility is that generator's free parameter, :22-23)."""
+    rng = np.random.default_rng(seed + 1000)
+    cams = rng.standard_normal((ncameras, 6)) + np.array([1.0, 0, 0, 0, 1.0, 0])
+    pts = rng.random((nlandmarks, 3)) + np.array([-0.5, -0.5, 10.0])
+    cam, lm = scattered_visibility(ncameras, nlandmarks, nviews, seed, loop)
+    problem = NLLSProblem(); problem.addvariables(cams); problem.addvariables(pts)
+    c, X = cams[cam - 1], pts[lm - 1]
+    meas = np.stack([(c[:, 0:3] * X).sum(1), (c[:, 3:6] * X).sum(1)], axis=1)
+    if noise > 0:
+        meas += rng.standard_normal(meas.shape) * noise
+    if outlier_frac > 0:
+        bad = rng.random(meas.shape[0]) < outlier_frac
+        meas[bad] += rng.standard_normal((int(bad.sum()), 2)) * outlier_sigma
+    problem.addcosts(K.RES_BA_AFFINE, np.stack([cam, lm + ncameras], axis=1), meas, robust)
+    return problem
+
+
 def create_grid_ba_problem(gw, gh, pts_per_cell=6, seed=1, robust=None, outlier_frac=0.0, outlier_sigma=0.0, noise=0.0):
     """A bundle adjustment whose camera graph is a 2-D GRID (an aerial survey: gw x gh cameras in rows, every landmark seen by the 3 x 3 block of cameras
     around its cell, clipped at the border) -- the reduced camera system is then neither a narrow band nor small: row-major numbering gives a half bandwidth of

@@ -238,6 +238,24 @@ def test_grid_camera_graph_tile_sparse_solve(gw, gh, shuffle, kind):
     assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
 
 
+@pytest.mark.parametrize("ncam,npts,nviews,loop", [(700, 5000, 6, False), (900, 5000, 5, True)])
+def test_scattered_camera_graph_tile_sparse_solve(ncam, npts, nviews, loop):
+    """Cameras scattered over a square -- or along a closed ring: a loop closure, whose reduced system no ordering turns into a narrow band -- every landmark seen by
+    the cameras nearest to it: a camera graph with no grid and no numbering to exploit.  The upload's nested dissection (breadth-first level structures from
+    pseudo-peripheral nodes) must still find a shallow elimination tree; sweep, damped solve, retraction and five LM iterations against the oracle, whose LDL' orders
+    itself (as the reference's: src/linearsystem.jl:52,68)."""
+    mk = lambda: synthetic.perturb_ba_problem(synthetic.create_scattered_ba_problem(ncam, npts, nviews, seed=5, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05,
+                                                                                     noise=1e-3, loop=loop), 1e-3, 1e-3)
+    p = mk()
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
+    _, st = _upload_info(p)
+    assert info.solve_mode == 3 and info.nreduced_dof == 6 * ncam, (info.solve_mode, info.bandwidth)
+    assert st["tsp_levels"] <= 0.5 * ((6 * ncam + 127) // 128), st                     # the dependent chain: levels of the tree, not tile columns
+    op = oracle_problem(mk()); ro = op.optimize(iterator=1, maxiters=5)
+    rg = N.optimize(p, N.NLLSOptions(maxiters=5))
+    assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
+
+
 def test_ba_sparse_small():          # test/optimizeba.jl:71 shape (10 x 50 @ 0.3 -> sparse path)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 50, 0.3, seed=1), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)
