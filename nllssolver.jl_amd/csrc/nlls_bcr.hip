@@ -444,8 +444,8 @@ struct DensePanelArgs { double* S; double* W; double* LiD; int npad, k, T; int* 
 // TSP (tile-sparse reduced system, nlls_tsp.hip): the same panel for a pivot TILE of a level of the elimination tree -- the workgroup's job names the diagonal
 // tile and the 16-row chunk(s) of a tile below it (or of the right-hand-side strip) by their offsets in the tile storage; W goes to the same offsets of a
 // second buffer, the factored diagonal tile and inv(L_JJ)' to the pivot tile's slots.  One launch factors every pivot tile of a level.
-struct TspPanelArgs { double* S; double* W; double* LiD; double* Dfac; const TspPanelJob* jobs; int* status; };
-template <int NT, int DCH, bool TSP = false>
+struct TspPanelArgs { double* S; double* W; double* LiD; double* Dfac; const TspPanelJob* jobs; int* status; const double* diag0; double relfloor; };   // diag0 / relfloor (FLOOR instantiations: undamped solves of a singular system): |original diagonal| in tile order, the fraction of it below which a pivot is dropped
+template <int NT, int DCH, bool TSP = false, bool FLOOR = false>
 __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(std::conditional_t<TSP, TspPanelArgs, DensePanelArgs> a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int ND = NT * (NT + 1) / 2, PR = NT + DCH;
@@ -540,7 +540,8 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(std::conditional_t<T
     bdouble4_t diag = {0, 0, 0, 0};
     for (int J = 0; J < NT; ++J) {
         double* Wb = Wp + (J & 1) * PR * 16 * BP; double* Lid = Li + (J & 1) * 16 * BP; double* db = dvec + (J & 1) * 32;
-        if (wave == 0) bcr_factor<false>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, c0 + 16 * J, lead, nullptr, 0.0);
+        if (wave == 0) { if constexpr (TSP && FLOOR) bcr_factor<true>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, c0 + 16 * J, lead, a.diag0, a.relfloor);
+                         else bcr_factor<false>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, c0 + 16 * J, lead, nullptr, 0.0); }
         else if (helper && J > 0) { updates(J - 1, hw, 6); exports(J - 1, hw, 6); }
         bcr_lds_barrier();
         if (J + 1 < NT) {
@@ -1031,13 +1032,18 @@ void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, 
 }
 
 // tile-sparse reduced system (nlls_tsp.hip): the panels of all pivot tiles of a level; the inverses of all factored diagonal tiles
-void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch) {
+void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch, const double* diag0, double relfloor) {
     if (njobs <= 0) return;
     static bool attr = false; constexpr int lds1 = (int)dense_panel_lds<8, 1>(), lds2 = (int)dense_panel_lds<8, 2>();
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2); attr = true; }
-    TspPanelArgs a{S, W, LiD, Dfac, jobs, status};
-    if (dch == 2) hipLaunchKernelGGL((dense_panel_kernel<8, 2, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds2, st, a);
+                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2); attr = true; }
+    TspPanelArgs a{S, W, LiD, Dfac, jobs, status, diag0, relfloor};
+    if (relfloor > 0.0) {
+        if (dch == 2) hipLaunchKernelGGL((dense_panel_kernel<8, 2, true, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds2, st, a);
+        else hipLaunchKernelGGL((dense_panel_kernel<8, 1, true, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds1, st, a);
+    } else if (dch == 2) hipLaunchKernelGGL((dense_panel_kernel<8, 2, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds2, st, a);
     else hipLaunchKernelGGL((dense_panel_kernel<8, 1, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds1, st, a);
 }
 void launch_tsp_dinv(hipStream_t st, const double* LiD, const double* Dfac, double* Dinv, const int32_t* list, int nlist, int nt) {

@@ -2848,7 +2848,8 @@ int enqueue_reduced_solve(nlls_ctx* c) {
     if (c->solve_mode == SOLVE_SMALL) {
         hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s_ptr(), n, npad, c->d_status.p);
     } else if (c->solve_mode == SOLVE_TSPARSE) {
-        if (c->tsp.enqueue(c->stream, c->S.p, c->s_ptr(), c->d_status.p) != NLLS_OK) return herr(c, hipGetLastError(), "tile-sparse reduced solve launch");
+        // (an undamped step of a gauge-free problem: vanished pivots are dropped and counted, the band solver's rule -- see below)
+        if (c->tsp.enqueue(c->stream, c->S.p, c->s_ptr(), c->d_status.p, c->lambda == 0.0 ? 1e-11 : 0.0) != NLLS_OK) return herr(c, hipGetLastError(), "tile-sparse reduced solve launch");
     } else if (band && c->bcr.ready) {
         // an UNDAMPED step (Newton, dogleg's Gauss-Newton step) of a gauge-free problem: S is singular -- vanished pivots are dropped
         // (src/iterators.jl:47-115 asks for the Gauss-Newton step; any exact factorisation of a singular system returns rounding / rounding)

@@ -29,9 +29,11 @@ typedef double tdouble2_t __attribute__((ext_vector_type(2)));
 
 // padding -> identity, reduced right-hand side -> row 0 of the strips (tile order)
 __global__ __launch_bounds__(256) void tsp_begin_kernel(double* __restrict__ S, const double* __restrict__ s, const int32_t* __restrict__ ipos, const int64_t* __restrict__ padpos,
-                                                        int64_t npadpos, int64_t npos, int64_t strip0, double* __restrict__ acc) {
+                                                        int64_t npadpos, int64_t npos, int64_t strip0, double* __restrict__ acc, double* __restrict__ diag0, const int32_t* __restrict__ tmap, int nt) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < npos) { const int32_t src = ipos[i]; S[strip0 + (i >> 7) * TSP_STRIP + 16 * (i & 127)] = src >= 0 ? s[src] : 0.0; acc[i] = 0.0; }
+    if (i < npos) { const int32_t src = ipos[i]; S[strip0 + (i >> 7) * TSP_STRIP + 16 * (i & 127)] = src >= 0 ? s[src] : 0.0; acc[i] = 0.0;
+        // the original diagonal, in tile order (pivot floor of undamped solves; the padding's 1.0 is written by another thread of this launch: say so here)
+        const int k = (int)(i >> 7), r = (int)(i & 127); diag0[i] = src >= 0 ? fabs(S[(size_t)tmap[(size_t)k * nt + k] * TSP_TE + r + (size_t)TSP_TR * r]) : 1.0; }
     else if (i - npos < npadpos) S[padpos[i - npos]] = 1.0;
 }
 __global__ __launch_bounds__(256) void tsp_scatter_kernel(double* __restrict__ s, const double* __restrict__ xt, const int32_t* __restrict__ tpos, int n) {
@@ -383,25 +385,25 @@ int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off
     }
     rest0 = plist.size(); nrest = (int)rest.size(); plist.insert(plist.end(), rest.begin(), rest.end());
     if (uc.empty()) uc.push_back(TspCon{0, 0}); if (uj.empty()) uj.push_back(TspUpdJob{}); if (padpos.empty()) padpos.push_back(0); if (tj.empty()) tj.push_back(TspTrsmJob{});
-    oW = 0; oLiD = s_elems(); oDfac = oLiD + (size_t)nt * 8 * 256; oDinv = oDfac + (size_t)nt * TSP_TE; oxt = oDinv + (size_t)nt * TSP_TE; oacc = oxt + (size_t)nt * TSP_TR;
+    oW = 0; oLiD = s_elems(); oDfac = oLiD + (size_t)nt * 8 * 256; oDinv = oDfac + (size_t)nt * TSP_TE; oxt = oDinv + (size_t)nt * TSP_TE; oacc = oxt + (size_t)nt * TSP_TR; odg = oacc + (size_t)nt * TSP_TR;
     if (hipSuccess != d_map.upload(map) || hipSuccess != d_ipos.upload(ipos) || hipSuccess != d_panel.upload(pj) || hipSuccess != d_upd.upload(uj) || hipSuccess != d_con.upload(uc) ||
         hipSuccess != d_bwd.upload(bj) || hipSuccess != d_trsm.upload(tj) || hipSuccess != d_plist.upload(plist) || hipSuccess != d_padpos.upload(padpos) ||
-        hipSuccess != ws.alloc(oacc + (size_t)nt * TSP_TR + 64)) {
+        hipSuccess != ws.alloc(odg + (size_t)nt * TSP_TR + 64)) {
         release(); if (err) *err = "tile-sparse solver: device allocation"; return NLLS_ERR_HIP; }
     launches = 3 + (nrest > 0 ? 1 : 0); for (auto& L : levels) launches += (L.scheme == 3 ? 3 : 1) + (L.nupd > 0 ? 1 : 0) + 1;
     ready = true;
     return NLLS_OK;
 }
 
-int TspSolver::enqueue(hipStream_t st, double* S, double* s, int* status) const {
+int TspSolver::enqueue(hipStream_t st, double* S, double* s, int* status, double pivot_floor) const {
     if (!ready) return NLLS_ERR_NOT_READY;
     const int64_t strip0 = nslots * TSP_TE, npos = (int64_t)nt * TSP_TR;
-    double* W = ws.p + oW; double* LiD = ws.p + oLiD; double* Dfac = ws.p + oDfac; double* Dinv = ws.p + oDinv; double* xt = ws.p + oxt; double* acc = ws.p + oacc;
-    hipLaunchKernelGGL(tsp_begin_kernel, dim3((unsigned)((npos + npad_entries + 255) / 256)), dim3(256), 0, st, S, (const double*)s, (const int32_t*)d_ipos.p, (const int64_t*)d_padpos.p, npad_entries, npos, strip0, acc);
+    double* W = ws.p + oW; double* LiD = ws.p + oLiD; double* Dfac = ws.p + oDfac; double* Dinv = ws.p + oDinv; double* xt = ws.p + oxt; double* acc = ws.p + oacc; double* diag0 = ws.p + odg;
+    hipLaunchKernelGGL(tsp_begin_kernel, dim3((unsigned)((npos + npad_entries + 255) / 256)), dim3(256), 0, st, S, (const double*)s, (const int32_t*)d_ipos.p, (const int64_t*)d_padpos.p, npad_entries, npos, strip0, acc, diag0, (const int32_t*)(d_map.p + n), nt);
     size_t pl = 0;
     static const int quad_max = [] { const char* e = getenv("NLLS_TSP_QUAD_MAX"); return e ? atoi(e) : 160; }();      // target tiles of a level up to which a workgroup takes a quarter tile
     for (const TspLevel& L : levels) {
-        launch_tsp_panel(st, S, W, LiD, Dfac, d_panel.p + L.panel0, L.npanel, status, L.scheme == 2 ? 2 : 1);
+        launch_tsp_panel(st, S, W, LiD, Dfac, d_panel.p + L.panel0, L.npanel, status, L.scheme == 2 ? 2 : 1, diag0, pivot_floor);
         if (L.scheme == 3) {
             launch_tsp_dinv(st, LiD, Dfac, Dinv, d_plist.p + pl, L.npiv, nt); pl += (size_t)L.npiv;
             if (L.ntrsm > 0) hipLaunchKernelGGL(tsp_trsm_kernel, dim3((unsigned)L.ntrsm), dim3(512), 0, st, S, W, (const double*)Dinv, (const double*)Dfac, (const TspTrsmJob*)(d_trsm.p + L.trsm0));

@@ -55,18 +55,20 @@ struct TspSolver {
     int nrest = 0; size_t rest0 = 0;
     DevBuf<int64_t> d_padpos;                      // offsets (in S) of the padding's diagonal entries
     DevBuf<double> ws;                             // W tiles + strips (as S) | LiD | Dfac | Dinv | xt | acc
-    size_t oW = 0, oLiD = 0, oDfac = 0, oDinv = 0, oxt = 0, oacc = 0;
+    size_t oW = 0, oLiD = 0, oDfac = 0, oDinv = 0, oxt = 0, oacc = 0, odg = 0;
     int64_t npad_entries = 0;
     int launches = 0; int64_t products = 0;
     size_t s_elems() const { return (size_t)nslots * TSP_TE + (size_t)nt * TSP_STRIP; }     // tiles, then one right-hand-side strip per tile column
     int build(const TspSym& sym, const std::vector<int32_t>& node_red_off, const std::vector<int32_t>& dof, int n_red, std::string* err);
     // S: [tiles | strips] assembled by the elimination through SLayout::at (mode SOLVE_TSPARSE), s: the reduced right-hand side in, the solution out
-    int enqueue(hipStream_t st, double* S, double* s, int* status) const;
+    // pivot_floor > 0 (undamped Newton / dogleg steps on a gauge-free problem: S is singular): a pivot that has lost more than that fraction of its original
+    // diagonal entry is treated as infinite -- its unknown gets no step -- and counted in status[4] (the rule of the band solver, nlls_bcr.hpp)
+    int enqueue(hipStream_t st, double* S, double* s, int* status, double pivot_floor = 0.0) const;
     void release() { d_map.release(); d_ipos.release(); d_panel.release(); d_upd.release(); d_con.release(); d_bwd.release(); d_trsm.release(); d_plist.release(); d_padpos.release(); ws.release(); levels.clear(); ready = false; }
 };
 
 // (kernels shared with the dense LDL', nlls_bcr.hip)
-void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch);
+void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch, const double* diag0, double relfloor);
 void launch_tsp_dinv(hipStream_t st, const double* LiD, const double* Dfac, double* Dinv, const int32_t* list, int nlist, int nt);
 
 }  // namespace nlls

@@ -341,7 +341,25 @@ def test_dogleg_and_newton_on_gauge_free_sparse_ba(ncam, npts, prop, seed):
         assert res.niterations <= 30, (name, res.niterations)
 
 
-@pytest.mark.parametrize("shape", ["curvefit", "ba_sparse", "ba_sparse_huber", "ba_band"])
+def test_dogleg_and_newton_on_gauge_free_camera_grid():
+    """The same through the TILE-SPARSE reduced solver (a 24 x 24 camera grid, noise-free): its panels take the band solver's rule for undamped steps -- a pivot
+    that has lost eleven orders of magnitude against its original diagonal entry is dropped and counted (nlls_get_solve_stats [10]) -- so dogleg and Newton
+    (src/iterators.jl:10-26,47-115) reach the zero-residual optimum on a camera graph that is not a band either."""
+    from nllssolver_jl_amd import _capi
+    mk = lambda: synthetic.perturb_ba_problem(synthetic.create_grid_ba_problem(24, 24, 4, seed=6), 1e-3, 1e-3)
+    p = mk(); ctx = _capi.Context(); info = ctx.upload(p.var_kind, p.var_dim, np.arange(1, p.nvariables + 1, dtype=np.uint64), p.groups(), 0)
+    assert info.solve_mode == 3
+    ctx.set_variables(p.variables); ctx.sweep_gradhess(); ctx.damp(0.0); ctx.solve()
+    st = ctx.solve_stats(); ctx.close()
+    assert 1 <= st["dropped_pivots"] <= 40, st                     # the gauge directions (9 for the affine camera; rounding decides the exact count)
+    for it, name in ((N.dogleg, "dogleg"), (N.newton, "newton")):
+        p = mk()
+        res = N.optimize(p, N.NLLSOptions(iterator=it, maxiters=60))
+        assert res.bestcost < 1e-15 * p.ncosts(), (name, res.bestcost, res.niterations)
+        assert res.niterations <= 30, (name, res.niterations)
+
+
+@pytest.mark.parametrize("shape", ["curvefit", "ba_sparse", "ba_sparse_huber", "ba_band", "ba_grid"])
 def test_nan_residual_terminates_like_reference(shape):
     """A NaN measurement: the reference's loop accepts the NaN cost ('!(cost_ > bestcost)', src/iterators.jl:160), leaves after ONE
     iteration and reports 'cost is NaN' + 'NaN in the step' (bits 1 and 5, src/optimize.jl:147-152) -- no exception, no retry loop.
@@ -354,6 +372,8 @@ def test_nan_residual_terminates_like_reference(shape):
             p, _ = synthetic.create_curvefit_problem(200, seed=3); row, col = 5, 1
         elif shape == "ba_band":
             p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(60, 3000, 0.1, seed=1, robust=N.HuberKernel(0.01)), 1e-3, 1e-3); row, col = 1234, 1
+        elif shape == "ba_grid":                                           # (the tile-sparse reduced solver)
+            p = synthetic.perturb_ba_problem(synthetic.create_grid_ba_problem(24, 24, 4, seed=1, robust=N.HuberKernel(0.01)), 1e-3, 1e-3); row, col = 1234, 1
         else:
             p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(10, 50, 0.3, seed=1, robust=N.HuberKernel(0.01) if shape.endswith("huber") else None), 1e-3, 1e-3); row, col = 7, 0
         g = next(iter(p.costs.values())); vi, da = g.arrays(); da = da.copy(); da[row, col] = np.nan; g.set_arrays(vi, da)
