@@ -444,7 +444,7 @@ struct DensePanelArgs { double* S; double* W; double* LiD; int npad, k, T; int* 
 // TSP (tile-sparse reduced system, nlls_tsp.hip): the same panel for a pivot TILE of a level of the elimination tree -- the workgroup's job names the diagonal
 // tile and the 16-row chunk(s) of a tile below it (or of the right-hand-side strip) by their offsets in the tile storage; W goes to the same offsets of a
 // second buffer, the factored diagonal tile and inv(L_JJ)' to the pivot tile's slots.  One launch factors every pivot tile of a level.
-struct TspPanelArgs { double* S; double* W; double* LiD; double* Dfac; const TspPanelJob* jobs; int* status; const double* diag0; double relfloor; };   // diag0 / relfloor (FLOOR instantiations: undamped solves of a singular system): |original diagonal| in tile order, the fraction of it below which a pivot is dropped
+struct TspPanelArgs { double* S; double* W; double* LiD; double* Dfac; const TspPanelJob* jobs; int* status; const double* diag0; double relfloor; unsigned* mask; };   // mask[tile slot]: bit c set = the 16-row chunk c of the tile holds a non-zero (the update skips products with chunks that hold none)   // diag0 / relfloor (FLOOR instantiations: undamped solves of a singular system): |original diagonal| in tile order, the fraction of it below which a pivot is dropped
 template <int NT, int DCH, bool TSP = false, bool FLOOR = false>
 __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(std::conditional_t<TSP, TspPanelArgs, DensePanelArgs> a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -481,6 +481,17 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(std::conditional_t<T
         for (int q = 0; q < XQ; ++q) { const int w = tid + q * BCR_T; xv[q] = 0.0;
             if (w < RX * NT * 256) { const int t = w >> 8, b2 = (w >> 4) & 15, a2 = w & 15, R = t / NT, K = t - R * NT;
                 if constexpr (TSP) xv[q] = a.S[xbase + (16 * R + a2) + (int64_t)xld * (16 * K + b2)]; else xv[q] = a.S[(size_t)(16 * trow(R) + a2) + (size_t)npad * (c0 + 16 * K + b2)]; } }
+        if constexpr (TSP) {
+            // which of this workgroup's 16-row chunks hold anything at all (structural zeros stay exact zeros through the factorisation: a zero row of S_ik gets
+            // nothing from any update): the update kernels skip the tile products of chunks that hold nothing -- half of all products on a camera grid
+            if (xld != 16 && a.mask) {
+#pragma unroll
+                for (int R = 0; R < DCH; ++R) { bool nz = false;
+#pragma unroll
+                    for (int q = 0; q < XQ; ++q) { const int w = tid + q * BCR_T; if (w < RX * NT * 256 && (w >> 8) / NT == R && xv[q] != 0.0) nz = true; }
+                    if (__any(nz) && lane == 0) atomicOr(&a.mask[xbase >> 14], 1u << (int)(((xbase & 16383) >> 4) + R)); }      // (one atomic per wavefront that saw something: no barrier, no LDS)
+            }
+        }
 #pragma unroll
         for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; if (w < ND * 256) Dt[(w >> 8) * BTS + (w & 15) * BP + ((w >> 4) & 15)] = dv[q]; }
 #pragma unroll
@@ -1032,14 +1043,14 @@ void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, 
 }
 
 // tile-sparse reduced system (nlls_tsp.hip): the panels of all pivot tiles of a level; the inverses of all factored diagonal tiles
-void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch, const double* diag0, double relfloor) {
+void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch, const double* diag0, double relfloor, unsigned* mask) {
     if (njobs <= 0) return;
     static bool attr = false; constexpr int lds1 = (int)dense_panel_lds<8, 1>(), lds2 = (int)dense_panel_lds<8, 2>();
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
                  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
                  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
                  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_panel_kernel<8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2); attr = true; }
-    TspPanelArgs a{S, W, LiD, Dfac, jobs, status, diag0, relfloor};
+    TspPanelArgs a{S, W, LiD, Dfac, jobs, status, diag0, relfloor, mask};
     if (relfloor > 0.0) {
         if (dch == 2) hipLaunchKernelGGL((dense_panel_kernel<8, 2, true, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds2, st, a);
         else hipLaunchKernelGGL((dense_panel_kernel<8, 1, true, true>), dim3((unsigned)njobs), dim3(BCR_T), (size_t)lds1, st, a);

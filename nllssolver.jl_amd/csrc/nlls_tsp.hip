@@ -29,8 +29,10 @@ typedef double tdouble2_t __attribute__((ext_vector_type(2)));
 
 // padding -> identity, reduced right-hand side -> row 0 of the strips (tile order)
 __global__ __launch_bounds__(256) void tsp_begin_kernel(double* __restrict__ S, const double* __restrict__ s, const int32_t* __restrict__ ipos, const int64_t* __restrict__ padpos,
-                                                        int64_t npadpos, int64_t npos, int64_t strip0, double* __restrict__ acc, double* __restrict__ diag0, const int32_t* __restrict__ tmap, int nt) {
+                                                        int64_t npadpos, int64_t npos, int64_t strip0, double* __restrict__ acc, double* __restrict__ diag0, const int32_t* __restrict__ tmap, int nt,
+                                                        unsigned* __restrict__ mask, int64_t nslots) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nslots) mask[i] = 0u;
     if (i < npos) { const int32_t src = ipos[i]; S[strip0 + (i >> 7) * TSP_STRIP + 16 * (i & 127)] = src >= 0 ? s[src] : 0.0; acc[i] = 0.0;
         // the original diagonal, in tile order (pivot floor of undamped solves; the padding's 1.0 is written by another thread of this launch: say so here)
         const int k = (int)(i >> 7), r = (int)(i & 127); diag0[i] = src >= 0 ? fabs(S[(size_t)tmap[(size_t)k * nt + k] * TSP_TE + r + (size_t)TSP_TR * r]) : 1.0; }
@@ -57,14 +59,15 @@ __device__ __forceinline__ void tsp_rhs_job(double* __restrict__ S, const double
     if (t < 128) S[jb.coff + 16 * t] -= (red[t] + red[t + 128]) + (red[t + 256] + red[t + 384]);
 }
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void tsp_update_kernel(double* __restrict__ S, const double* __restrict__ W, const TspUpdJob* __restrict__ jobs,
-                                                                                                    const TspCon* __restrict__ cons) {
+                                                                                                    const TspCon* __restrict__ cons, const unsigned* __restrict__ mask) {
     __shared__ double As[2][TU_KC * TU_LD], Bs[2][TU_KC * TU_LD];
     const TspUpdJob jb = jobs[blockIdx.x];
     const int t = threadIdx.x;
     if (jb.kind == 1) { tsp_rhs_job(S, W, jb, cons, As[0]); return; }
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
-    const int r0w = (w & 1) * 64, c0w = (w >> 1) * 32;
-    const bool active = !(jb.diag && c0w >= r0w + 64);
+    // Wavefront w owns the 16 x 16 blocks (row chunk 2 a + (w & 1), column chunk (w >> 1) + 4 b), a < 4, b < 2 -- INTERLEAVED over the tile, not one 64 x 32
+    // corner: the chunks of a tile that hold anything are a contiguous range more often than not, and the skipped products should thin every wavefront alike.
+    const int rw = w & 1, cw = w >> 1;
     tdouble4_t acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -83,65 +86,81 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int i = 0; i < NCP; ++i) { As[buf][(kq + 4 * i) * TU_LD + cr] = ra[set][i]; Bs[buf][(kq + 4 * i) * TU_LD + cr] = rb[set][i]; }
     };
-    auto products = [&](int buf) {
-        if (!active) return;
+    // the 16 x 16 products of this wavefront that a contribution needs: bit 2 a + b set = row chunk of W_ik AND column chunk of L_jk hold something, and (a tile
+    // on the diagonal) the block is not above it  (wave-uniform: scalar loads of the two tiles' chunk masks)
+    unsigned shape = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) if (!jb.diag || 2 * a + rw >= cw + 4 * b2) shape |= 1u << (2 * a + b2);
+    auto need_of = [&](int chunk) -> unsigned {
+        if (!mask) return shape;
+        const TspCon cn = cons[jb.con0 + chunk / CPT];
+        const unsigned mw = __builtin_amdgcn_readfirstlane(mask[cn.woff >> 14]), ml = __builtin_amdgcn_readfirstlane(mask[cn.loff >> 14]);
+        unsigned nd = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) if (((mw >> (2 * a + rw)) & 1u) && ((ml >> (cw + 4 * b2)) & 1u)) nd |= 1u << (2 * a + b2);
+        return nd & shape;
+    };
+    auto products = [&](int buf, unsigned need) {
+        if (need == 0) return;
 #pragma unroll
         for (int kk = 0; kk < TU_KC; kk += 4) {
             double av[4], bv[2];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = As[buf][(kk + lk) * TU_LD + r0w + 16 * a + li];
+            for (int a = 0; a < 4; ++a) av[a] = As[buf][(kk + lk) * TU_LD + 16 * (2 * a + rw) + li];
 #pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Bs[buf][(kk + lk) * TU_LD + c0w + 16 * b2 + li];
+            for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Bs[buf][(kk + lk) * TU_LD + 16 * (cw + 4 * b2) + li];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
+                for (int b2 = 0; b2 < 2; ++b2) if (need & (1u << (2 * a + b2))) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
         }
     };
     const int NCH = jb.ncon * CPT;                              // (even: CPT is)
+    unsigned touched = 0;
     gload(0, 0); gload(1, 1); lstore(0, 0);
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ch += 2) {
+        const unsigned need = need_of(ch);                     // (chunks ch and ch + 1 belong to the same contribution)
+        touched |= need;
         if (ch + 2 < NCH) gload(ch + 2, 0);
-        products(0);
+        products(0, need);
         lstore(1, 1);
         __syncthreads();
         if (ch + 3 < NCH) gload(ch + 3, 1);
-        products(1);
+        products(1, need);
         if (ch + 2 < NCH) lstore(0, 0);
         __syncthreads();
     }
-    if (!active) return;
-    // C/D layout of the TRANSPOSED product: row = lane & 15 (+ 16 a), column = (lane >> 4) + 4 r (+ 16 b)
-    double* Cg = S + jb.coff + r0w + (size_t)TSP_TR * c0w;
-    if (jb.kind == 2) {                                         // the target's contributions are split over several workgroups
+    // C/D layout of the TRANSPOSED product: row = lane & 15, column = (lane >> 4) + 4 r of the 16 x 16 block; blocks nothing was added to are left alone
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2)
+    for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
+            if (!(touched & (1u << (2 * a + b2)))) continue;
+            double* Cg = S + jb.coff + 16 * (2 * a + rw) + li + (size_t)TSP_TR * (16 * (cw + 4 * b2) + lk);
+            if (jb.kind == 2) {                                 // the target's contributions are split over several workgroups
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&Cg[(size_t)(16 * a + li) + (size_t)TSP_TR * (16 * b2 + lk + 4 * r)], -acc[a][b2][r]);
-        return;
-    }
+                for (int r = 0; r < 4; ++r) atomicAdd(&Cg[(size_t)TSP_TR * 4 * r], -acc[a][b2][r]);
+            } else {
+                double cold[4];
 #pragma unroll
-    for (int b2 = 0; b2 < 2; ++b2) {
-        double cold[4][4];
+                for (int r = 0; r < 4; ++r) cold[r] = Cg[(size_t)TSP_TR * 4 * r];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cold[a][r] = Cg[(size_t)(16 * a + li) + (size_t)TSP_TR * (16 * b2 + lk + 4 * r)];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cg[(size_t)(16 * a + li) + (size_t)TSP_TR * (16 * b2 + lk + 4 * r)] = cold[a][r] - acc[a][b2][r];
-    }
+                for (int r = 0; r < 4; ++r) Cg[(size_t)TSP_TR * 4 * r] = cold[r] - acc[a][b2][r];
+            }
+        }
 }
 
 // The same update with a QUARTER of a target tile per workgroup (64 x 64; wavefront w: the 16 x 32 block at rows 16 (w & 3), columns 32 (w >> 2)): for the levels
 // near the root, whose few target tiles would leave most of the chip idle behind 14 us products.  Workgroup b: quarter b & 3 of tile job b >> 2 (the upper right
 // quarter of a diagonal tile is not needed); the strip jobs follow the 4 ntile quarters.
-__global__ __launch_bounds__(512) void tsp_update_quad_kernel(double* __restrict__ S, const double* __restrict__ W, const TspUpdJob* __restrict__ jobs, const TspCon* __restrict__ cons, int ntile) {
+__global__ __launch_bounds__(512) void tsp_update_quad_kernel(double* __restrict__ S, const double* __restrict__ W, const TspUpdJob* __restrict__ jobs, const TspCon* __restrict__ cons, int ntile,
+                                                              const unsigned* __restrict__ mask) {
     __shared__ double As[2][TU_KC * TU_LD], Bs[2][TU_KC * TU_LD];
     const int t = threadIdx.x;
     if ((int)blockIdx.x >= 4 * ntile) { tsp_rhs_job(S, W, jobs[ntile + ((int)blockIdx.x - 4 * ntile)], cons, As[0]); return; }
@@ -165,13 +184,20 @@ __global__ __launch_bounds__(512) void tsp_update_quad_kernel(double* __restrict
 #pragma unroll
         for (int i = 0; i < NCP; ++i) D[(kq + 4 * i) * TU_LD + cr] = rr[set][i];
     };
-    auto products = [&](int buf) {
+    auto need_of = [&](int chunk) -> unsigned {
+        if (!mask) return 3u;
+        const TspCon cn = cons[jb.con0 + chunk / CPT];
+        const unsigned mw = __builtin_amdgcn_readfirstlane(mask[cn.woff >> 14]) >> (4 * qi + (r0w >> 4)), ml = __builtin_amdgcn_readfirstlane(mask[cn.loff >> 14]) >> (4 * qj + (c0w >> 4));
+        return (mw & 1u) ? (ml & 3u) : 0u;
+    };
+    auto products = [&](int buf, unsigned need) {
+        if (need == 0) return;
 #pragma unroll
         for (int kk = 0; kk < TU_KC; kk += 4) {
             const double av = As[buf][(kk + lk) * TU_LD + r0w + li];
             const double b0 = Bs[buf][(kk + lk) * TU_LD + c0w + li], b1 = Bs[buf][(kk + lk) * TU_LD + c0w + 16 + li];
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, av, acc[1], 0, 0, 0);
+            if (need & 1u) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av, acc[0], 0, 0, 0);
+            if (need & 2u) acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, av, acc[1], 0, 0, 0);
         }
     };
     const int NCH = jb.ncon * CPT;
@@ -179,12 +205,13 @@ __global__ __launch_bounds__(512) void tsp_update_quad_kernel(double* __restrict
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ch += 2) {
+        const unsigned need = need_of(ch);
         if (ch + 2 < NCH) gload(ch + 2, 0);
-        products(0);
+        products(0, need);
         lstore(1, 1);
         __syncthreads();
         if (ch + 3 < NCH) gload(ch + 3, 1);
-        products(1);
+        products(1, need);
         if (ch + 2 < NCH) lstore(0, 0);
         __syncthreads();
     }
@@ -207,7 +234,7 @@ __global__ __launch_bounds__(512) void tsp_update_quad_kernel(double* __restrict
 // A tile below a factored pivot tile in ONE matrix product (levels with many tiles: dense_trsm128_kernel's scheme, nlls_solve.hip): with X = inv(L_kk) of the
 // unit-lower pivot tile,  W = S_ik X'  and  L = W / Delta;  L in place, W beside it.  Dfac: the factored pivot tiles (Delta on the diagonal).
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void tsp_trsm_kernel(double* __restrict__ S, double* __restrict__ W, const double* __restrict__ Dinv, const double* __restrict__ Dfac,
-                                                                                                  const TspTrsmJob* __restrict__ jobs) {
+                                                                                                  const TspTrsmJob* __restrict__ jobs, unsigned* __restrict__ mask) {
     __shared__ double As[2][TU_KC * TU_LD], Bs[2][TU_KC * TU_LD];
     __shared__ double rd[TSP_TR];
     const TspTrsmJob jb = jobs[blockIdx.x];
@@ -261,6 +288,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         products(1);
         if (ch + 2 < NCH) lstore(0, 0);
         __syncthreads();
+    }
+    if (mask) {          // the 16-row chunks of the tile that hold anything (see dense_panel_kernel<TSP>)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { bool nz = false;
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nz |= acc[a][b2][r] != 0.0;
+            if (__any(nz) && lane == 0) atomicOr(&mask[jb.xoff >> 14], 1u << ((r0w >> 4) + a)); }
     }
 #pragma unroll
     for (int b2 = 0; b2 < 2; ++b2)
@@ -385,10 +421,11 @@ int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off
     }
     rest0 = plist.size(); nrest = (int)rest.size(); plist.insert(plist.end(), rest.begin(), rest.end());
     if (uc.empty()) uc.push_back(TspCon{0, 0}); if (uj.empty()) uj.push_back(TspUpdJob{}); if (padpos.empty()) padpos.push_back(0); if (tj.empty()) tj.push_back(TspTrsmJob{});
-    oW = 0; oLiD = s_elems(); oDfac = oLiD + (size_t)nt * 8 * 256; oDinv = oDfac + (size_t)nt * TSP_TE; oxt = oDinv + (size_t)nt * TSP_TE; oacc = oxt + (size_t)nt * TSP_TR; odg = oacc + (size_t)nt * TSP_TR;
+    oW = 0; oLiD = s_elems(); oDfac = oLiD + (size_t)nt * 8 * 256; oDinv = oDfac + (size_t)nt * TSP_TE; oxt = oDinv + (size_t)nt * TSP_TE; oacc = oxt + (size_t)nt * TSP_TR; odg = oacc + (size_t)nt * TSP_TR; omask = odg + (size_t)nt * TSP_TR;
+    chunk_masks = getenv("NLLS_TSP_NO_MASKS") == nullptr;
     if (hipSuccess != d_map.upload(map) || hipSuccess != d_ipos.upload(ipos) || hipSuccess != d_panel.upload(pj) || hipSuccess != d_upd.upload(uj) || hipSuccess != d_con.upload(uc) ||
         hipSuccess != d_bwd.upload(bj) || hipSuccess != d_trsm.upload(tj) || hipSuccess != d_plist.upload(plist) || hipSuccess != d_padpos.upload(padpos) ||
-        hipSuccess != ws.alloc(odg + (size_t)nt * TSP_TR + 64)) {
+        hipSuccess != ws.alloc(omask + (size_t)(nslots + 1) / 2 + 64)) {
         release(); if (err) *err = "tile-sparse solver: device allocation"; return NLLS_ERR_HIP; }
     launches = 3 + (nrest > 0 ? 1 : 0); for (auto& L : levels) launches += (L.scheme == 3 ? 3 : 1) + (L.nupd > 0 ? 1 : 0) + 1;
     ready = true;
@@ -398,24 +435,24 @@ int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off
 int TspSolver::enqueue(hipStream_t st, double* S, double* s, int* status, double pivot_floor) const {
     if (!ready) return NLLS_ERR_NOT_READY;
     const int64_t strip0 = nslots * TSP_TE, npos = (int64_t)nt * TSP_TR;
-    double* W = ws.p + oW; double* LiD = ws.p + oLiD; double* Dfac = ws.p + oDfac; double* Dinv = ws.p + oDinv; double* xt = ws.p + oxt; double* acc = ws.p + oacc; double* diag0 = ws.p + odg;
-    hipLaunchKernelGGL(tsp_begin_kernel, dim3((unsigned)((npos + npad_entries + 255) / 256)), dim3(256), 0, st, S, (const double*)s, (const int32_t*)d_ipos.p, (const int64_t*)d_padpos.p, npad_entries, npos, strip0, acc, diag0, (const int32_t*)(d_map.p + n), nt);
+    double* W = ws.p + oW; double* LiD = ws.p + oLiD; double* Dfac = ws.p + oDfac; double* Dinv = ws.p + oDinv; double* xt = ws.p + oxt; double* acc = ws.p + oacc; double* diag0 = ws.p + odg; unsigned* mask = reinterpret_cast<unsigned*>(ws.p + omask); unsigned* umask = chunk_masks ? mask : nullptr;
+    hipLaunchKernelGGL(tsp_begin_kernel, dim3((unsigned)((std::max<int64_t>(npos + npad_entries, nslots) + 255) / 256)), dim3(256), 0, st, S, (const double*)s, (const int32_t*)d_ipos.p, (const int64_t*)d_padpos.p, npad_entries, npos, strip0, acc, diag0, (const int32_t*)(d_map.p + n), nt, mask, nslots);
     size_t pl = 0;
     static const int quad_max = [] { const char* e = getenv("NLLS_TSP_QUAD_MAX"); return e ? atoi(e) : 160; }();      // target tiles of a level up to which a workgroup takes a quarter tile
     for (const TspLevel& L : levels) {
-        launch_tsp_panel(st, S, W, LiD, Dfac, d_panel.p + L.panel0, L.npanel, status, L.scheme == 2 ? 2 : 1, diag0, pivot_floor);
+        launch_tsp_panel(st, S, W, LiD, Dfac, d_panel.p + L.panel0, L.npanel, status, L.scheme == 2 ? 2 : 1, diag0, pivot_floor, umask);
         if (L.scheme == 3) {
             launch_tsp_dinv(st, LiD, Dfac, Dinv, d_plist.p + pl, L.npiv, nt); pl += (size_t)L.npiv;
-            if (L.ntrsm > 0) hipLaunchKernelGGL(tsp_trsm_kernel, dim3((unsigned)L.ntrsm), dim3(512), 0, st, S, W, (const double*)Dinv, (const double*)Dfac, (const TspTrsmJob*)(d_trsm.p + L.trsm0));
+            if (L.ntrsm > 0) hipLaunchKernelGGL(tsp_trsm_kernel, dim3((unsigned)L.ntrsm), dim3(512), 0, st, S, W, (const double*)Dinv, (const double*)Dfac, (const TspTrsmJob*)(d_trsm.p + L.trsm0), umask);
         }
-        if (L.nupd > 0 && L.nupd_tile <= quad_max) hipLaunchKernelGGL(tsp_update_quad_kernel, dim3((unsigned)(4 * L.nupd_tile + (L.nupd - L.nupd_tile))), dim3(512), 0, st, S, (const double*)W, (const TspUpdJob*)(d_upd.p + L.upd0), (const TspCon*)d_con.p, L.nupd_tile);
-        else if (L.nupd > 0) hipLaunchKernelGGL(tsp_update_kernel, dim3((unsigned)L.nupd), dim3(512), 0, st, S, (const double*)W, (const TspUpdJob*)(d_upd.p + L.upd0), (const TspCon*)d_con.p);
+        if (L.nupd > 0 && L.nupd_tile <= quad_max) hipLaunchKernelGGL(tsp_update_quad_kernel, dim3((unsigned)(4 * L.nupd_tile + (L.nupd - L.nupd_tile))), dim3(512), 0, st, S, (const double*)W, (const TspUpdJob*)(d_upd.p + L.upd0), (const TspCon*)d_con.p, L.nupd_tile, (const unsigned*)umask);
+        else if (L.nupd > 0) hipLaunchKernelGGL(tsp_update_kernel, dim3((unsigned)L.nupd), dim3(512), 0, st, S, (const double*)W, (const TspUpdJob*)(d_upd.p + L.upd0), (const TspCon*)d_con.p, (const unsigned*)umask);
     }
     launch_tsp_dinv(st, LiD, Dfac, Dinv, d_plist.p + rest0, nrest, nt);
     for (int lv = (int)levels.size() - 1; lv >= 0; --lv) { const TspLevel& L = levels[lv];
         hipLaunchKernelGGL(tsp_backward_kernel, dim3((unsigned)L.nbwd), dim3(512), 0, st, (const double*)S, (const double*)Dinv, xt, acc, (const TspBwdJob*)(d_bwd.p + L.bwd0), strip0); }
     hipLaunchKernelGGL(tsp_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, (const double*)xt, (const int32_t*)d_map.p, n);
-    return hipGetLastError() == hipSuccess ? NLLS_OK : NLLS_ERR_HIP;
+    return hipPeekAtLastError() == hipSuccess ? NLLS_OK : NLLS_ERR_HIP;       // (peek: the caller reports the error text)
 }
 
 }  // namespace nlls

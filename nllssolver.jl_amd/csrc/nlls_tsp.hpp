@@ -55,7 +55,8 @@ struct TspSolver {
     int nrest = 0; size_t rest0 = 0;
     DevBuf<int64_t> d_padpos;                      // offsets (in S) of the padding's diagonal entries
     DevBuf<double> ws;                             // W tiles + strips (as S) | LiD | Dfac | Dinv | xt | acc
-    size_t oW = 0, oLiD = 0, oDfac = 0, oDinv = 0, oxt = 0, oacc = 0, odg = 0;
+    size_t oW = 0, oLiD = 0, oDfac = 0, oDinv = 0, oxt = 0, oacc = 0, odg = 0, omask = 0;
+    bool chunk_masks = true;                       // NLLS_TSP_NO_MASKS=1 (A/B): every tile product in full
     int64_t npad_entries = 0;
     int launches = 0; int64_t products = 0;
     size_t s_elems() const { return (size_t)nslots * TSP_TE + (size_t)nt * TSP_STRIP; }     // tiles, then one right-hand-side strip per tile column
@@ -68,7 +69,7 @@ struct TspSolver {
 };
 
 // (kernels shared with the dense LDL', nlls_bcr.hip)
-void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch, const double* diag0, double relfloor);
+void launch_tsp_panel(hipStream_t st, double* S, double* W, double* LiD, double* Dfac, const TspPanelJob* jobs, int njobs, int* status, int dch, const double* diag0, double relfloor, unsigned* mask);
 void launch_tsp_dinv(hipStream_t st, const double* LiD, const double* Dfac, double* Dinv, const int32_t* list, int nlist, int nt);
 
 }  // namespace nlls
