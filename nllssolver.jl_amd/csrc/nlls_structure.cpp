@@ -999,10 +999,13 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 if (c->dense_window) { const double wt = (double)((bw + 127) / 128 + 1 + (c->nbd + 1 + 127) / 128); t_dense = std::min(t_dense, NB128 * (40.0 + 0.17 * wt * (wt + 1) / 2.0)); }
                 const bool force = getenv("NLLS_FORCE_TSPARSE") != nullptr;
                 if (t_tsp < 0.8 * t_dense || force) {
-                    std::string e; const int rc = c->tsp.build(sym, noff, ndof, (int)n, &e);
-                    size_t mfree = 0, mtotal = 0;
-                    if (rc == NLLS_OK && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && sizeof(double) * (c->tsp.s_elems() + (size_t)n + 64) + ((size_t)2 << 30) > mfree) c->tsp.release();
-                    if (rc != NLLS_OK && rc != NLLS_ERR_UNSUPPORTED) return fail(c, rc, e.c_str());
+                    // (what the device holds decides: the tiles twice -- S and W -- + slots per tile; a system whose tiles do not fit falls back to the dense / windowed solver,
+                    //  which then declines by its own size check)
+                    size_t mfree = 0, mtotal = 0; const size_t want = sizeof(double) * (2 * ((size_t)sym.ntiles_lower * TSP_TE + (size_t)sym.nt * TSP_STRIP) + 3 * (size_t)sym.nt * TSP_TE + (size_t)n + 4096);
+                    const bool fits = hipMemGetInfo(&mfree, &mtotal) != hipSuccess || want + ((size_t)2 << 30) <= mfree;
+                    std::string e; const int rc = fits ? c->tsp.build(sym, noff, ndof, (int)n, &e) : NLLS_ERR_UNSUPPORTED;
+                    if (rc == NLLS_ERR_HIP) { (void)hipGetLastError(); c->tsp.release(); }        // an allocation that failed after all: the other solvers
+                    else if (rc != NLLS_OK && rc != NLLS_ERR_UNSUPPORTED) return fail(c, rc, e.c_str());
                 }
             }
         }

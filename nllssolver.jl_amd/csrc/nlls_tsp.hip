@@ -239,7 +239,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ double rd[TSP_TR];
     const TspTrsmJob jb = jobs[blockIdx.x];
     const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
-    const int r0w = (w & 1) * 64, c0w = (w >> 1) * 32;
+    // wavefront w: the 64 rows r0w .. and the column chunks cw and 7 - cw (16 columns each): X = inv(L_kk) is LOWER triangular, so the columns of output chunk c
+    // take K only up to 16 (c + 1) -- chunk c costs c + 1 K-steps, and the pair (cw, 7 - cw) costs nine for every wavefront (sixteen without the skip)
+    const int r0w = (w & 1) * 64, cw = w >> 1, cc0 = cw, cc1 = 7 - cw;
     const double* __restrict__ Xinv = Dinv + (size_t)jb.k * TSP_TE;
     if (t < TSP_TR) rd[t] = 1.0 / Dfac[(size_t)jb.k * TSP_TE + (size_t)t * (TSP_TR + 1)];
     tdouble4_t acc[4][2];
@@ -261,18 +263,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int i = 0; i < NCP; ++i) { As[buf][(kq + 4 * i) * TU_LD + cr] = ra[set][i]; Bs[buf][(kq + 4 * i) * TU_LD + cr] = rb[set][i]; }
     };
-    auto products = [&](int buf) {
+    auto products = [&](int buf, int ch) {                     // K chunk ch (16 columns of X): X(j, k) = 0 for k > j
+        const bool n0 = cc0 >= ch, n1 = cc1 >= ch;
+        if (!n0 && !n1) return;
 #pragma unroll
         for (int kk = 0; kk < TU_KC; kk += 4) {
             double av[4], bv[2];
 #pragma unroll
             for (int a = 0; a < 4; ++a) av[a] = As[buf][(kk + lk) * TU_LD + r0w + 16 * a + li];
+            bv[0] = Bs[buf][(kk + lk) * TU_LD + 16 * cc0 + li]; bv[1] = Bs[buf][(kk + lk) * TU_LD + 16 * cc1 + li];
 #pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Bs[buf][(kk + lk) * TU_LD + c0w + 16 * b2 + li];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
+            for (int a = 0; a < 4; ++a) {
+                if (n0) acc[a][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[0], av[a], acc[a][0], 0, 0, 0);
+                if (n1) acc[a][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[1], av[a], acc[a][1], 0, 0, 0);
+            }
         }
     };
     gload(0, 0); gload(1, 1); lstore(0, 0);
@@ -281,11 +285,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ch += 2) {
         if (ch + 2 < NCH) gload(ch + 2, 0);
-        products(0);
+        products(0, ch);
         lstore(1, 1);
         __syncthreads();
         if (ch + 3 < NCH) gload(ch + 3, 1);
-        products(1);
+        products(1, ch + 1);
         if (ch + 2 < NCH) lstore(0, 0);
         __syncthreads();
     }
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = r0w + 16 * a + li, j = c0w + 16 * b2 + lk + 4 * r; const double wv = acc[a][b2][r];
+                const int i = r0w + 16 * a + li, j = 16 * (b2 ? cc1 : cc0) + lk + 4 * r; const double wv = acc[a][b2][r];
                 W[jb.xoff + i + (size_t)TSP_TR * j] = wv; S[jb.xoff + i + (size_t)TSP_TR * j] = wv * rd[j];
             }
 }
