@@ -95,8 +95,17 @@ bool tsp_symbolic(const std::vector<std::vector<int32_t>>& adj, const std::vecto
     for (int32_t d : dof) if (d < 1 || d > TSP_TR) return false;
     out = TspSym{};
     out.tile_of.assign(nall, -1); out.row_in_tile.assign(nall, 0);
-    Dissector D(adj, dof);
-    { std::vector<int32_t> all(n); std::iota(all.begin(), all.end(), 0); D.run(std::move(all), 0); }
+    // HUBS -- nodes coupled to an eighth of all nodes or more (an overview image that sees half the scene): no level structure has an interior level while they are
+    // in the graph (everything is within two steps of everything).  They are taken out before the dissection and ordered behind it, next to the border nodes:
+    // their tiles count as neighbours of every tile (the root front of the factorisation).
+    std::vector<uint8_t> hub(n, 0); std::vector<int32_t> hubs; int64_t hubdof = 0;
+    { const size_t thr = std::max<size_t>(48, (size_t)n / 8);
+      for (int32_t v = 0; v < n; ++v) if (adj[v].size() >= thr && hubdof + dof[v] <= 16 * TSP_TR) { hub[v] = 1; hubs.push_back(v); hubdof += dof[v]; } }
+    std::vector<std::vector<int32_t>> adj_nohub;
+    if (!hubs.empty()) { adj_nohub.resize(n); for (int32_t v = 0; v < n; ++v) if (!hub[v]) for (int32_t w : adj[v]) if (!hub[w]) adj_nohub[v].push_back(w); }
+    const std::vector<std::vector<int32_t>>& G = hubs.empty() ? adj : adj_nohub;
+    Dissector D(G, dof);
+    { std::vector<int32_t> all; all.reserve(n); for (int32_t v = 0; v < n; ++v) if (!hub[v]) all.push_back(v); D.run(std::move(all), 0); }
     // supernodes -> tiles.  A supernode starts a tile of its own (a tile that mixed two sibling parts would chain their subtrees) -- but the nodes of its LAST,
     // poorly filled tile move up into the first tile of the separator it hangs under (they are eliminated with that front instead: any order is a valid
     // one, and a tile shared by a separator and the tails of its own parts chains nothing that was not chained already).  Without this 30 % of all tile rows
@@ -114,18 +123,20 @@ bool tsp_symbolic(const std::vector<std::vector<int32_t>>& adj, const std::vecto
         for (int32_t v : sn) { if (out.fill.back() + dof[v] > TSP_TR) out.fill.push_back(0);
             out.tile_of[v] = (int32_t)out.fill.size() - 1; out.row_in_tile[v] = out.fill.back(); out.fill.back() += dof[v]; }
     }
-    bool dense_last = false;
-    if (nborder > 0) {            // border nodes couple to everything: behind all the others, their tile a neighbour of every tile
-        for (int32_t v = n; v < nall; ++v) { if (out.fill.empty() || out.fill.back() + dof[v] > TSP_TR) out.fill.push_back(0);
+    bool dense_last = false; int32_t first_border_tile = -1;
+    if (nborder > 0 || !hubs.empty()) {            // hubs and border nodes couple to everything: behind all the others, every tile from the first of theirs on a neighbour of every tile
+        std::vector<int32_t> last = hubs; for (int32_t v = n; v < nall; ++v) last.push_back(v);
+        // (they start in the last tile there is -- the tail of the last root front, which becomes a neighbour of everything with them: it was the last step anyway)
+        for (int32_t v : last) { if (out.fill.empty() || out.fill.back() + dof[v] > TSP_TR) out.fill.push_back(0);
+            if (first_border_tile < 0) first_border_tile = (int32_t)out.fill.size() - 1;
             out.tile_of[v] = (int32_t)out.fill.size() - 1; out.row_in_tile[v] = out.fill.back(); out.fill.back() += dof[v]; }
         dense_last = true;
-        // (border nodes that opened a second tile: every tile from the first border node's on is such a neighbour)
     }
     const int nt = out.nt = (int)out.fill.size();
     if (nt == 0) return true;
-    const int32_t first_border_tile = nborder > 0 ? out.tile_of[n] : nt;
+    if (first_border_tile < 0) first_border_tile = nt;
     std::vector<std::vector<int32_t>> tadj(nt);
-    for (int32_t v = 0; v < n; ++v) { const int32_t tv = out.tile_of[v]; for (int32_t w : adj[v]) { const int32_t tw = out.tile_of[w]; if (tw != tv) tadj[tv].push_back(tw); } }
+    for (int32_t v = 0; v < n; ++v) { const int32_t tv = out.tile_of[v]; for (int32_t w : G[v]) { const int32_t tw = out.tile_of[w]; if (tw != tv) tadj[tv].push_back(tw); } }      // (hubs: covered by dense_last)
     for (auto& l : tadj) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
     out.cstruct.assign(nt, {}); out.parent.assign(nt, -1); out.level.assign(nt, 0);
     std::vector<std::vector<int32_t>> children(nt);

@@ -39,38 +39,46 @@ NLLS_DEV double wsum(double v) {
 //   tile-sparse: the lower tiles of the filled tile pattern, 128 x 128 column-major each, in a nested-dissection order of its own (nlls_tsp.hip):
 //          tsp[0, n) = position of a reduced unknown in that order, tsp[n + I npad + J] = slot of tile (I, J), I >= J  (npad = number of tiles)
 // ---------------------------------------------------------------------------------------------------
-struct SLayout {
-    double* S; int mode; int n, npad, n_band, bw, nbd, H; const int32_t* tsp;
+// The tile-sparse addressing is a TYPE of its own (SLayoutT<true>: one more pointer, two dependent loads per entry): every kernel that assembles [S | s] is
+// instantiated for both, and the band / dense instantiations are byte for byte what they were without it (with the branch inside one struct the elimination
+// launch of BASELINE config 4 was measured 4 us slower -- registers, not the branch).
+struct SLayoutNoMap {}; struct SLayoutMap { const int32_t* tsp; };
+template <bool TSP>
+struct SLayoutT : std::conditional_t<TSP, SLayoutMap, SLayoutNoMap> {
+    double* S; int mode; int n, npad, n_band, bw, nbd, H;
     NLLS_DEV double* at(int i, int j) const {   // i >= j
-        if (mode != SOLVE_BAND) {
-            if (mode == SOLVE_TSPARSE) { int pi = tsp[i], pj = tsp[j]; if (pi < pj) { const int t = pi; pi = pj; pj = t; }      // (the tile order is not the reduced order: the entry lives at (max, min) of the POSITIONS)
-                return S + (size_t)tsp[n + (pi >> 7) * npad + (pj >> 7)] * (128 * 128) + (pi & 127) + 128 * (pj & 127); }
-            return S + (size_t)i + (size_t)npad * j; }
+        if constexpr (TSP) { int pi = this->tsp[i], pj = this->tsp[j]; if (pi < pj) { const int t = pi; pi = pj; pj = t; }      // (the tile order is not the reduced order: the entry lives at (max, min) of the POSITIONS)
+            return S + (size_t)this->tsp[n + (pi >> 7) * npad + (pj >> 7)] * (128 * 128) + (pi & 127) + 128 * (pj & 127); }
+        if (mode != SOLVE_BAND) return S + (size_t)i + (size_t)npad * j;
         if (i < n_band) return S + (size_t)j * H + (i - j);
         if (j < n_band) return S + (size_t)j * H + bw + 1 + (i - n_band);
         return S + (size_t)n_band * H + (i - n_band) + (size_t)(nbd + 1) * (j - n_band);
     }
     // entry i of the reduced right-hand side while the system is assembled: the factorisations carry it as row n of S
     // (band and dense layouts); only the one-wave solver of tiny systems reads it from the vector s
-    NLLS_DEV double* rhs(double* s, int i) const { return (mode == SOLVE_SMALL || mode == SOLVE_TSPARSE) ? s + i : at(n, i); }
+    NLLS_DEV double* rhs(double* s, int i) const { if constexpr (TSP) return s + i; else return mode == SOLVE_SMALL ? s + i : at(n, i); }
 };
+using SLayout = SLayoutT<false>;
+template <bool T> NLLS_HD constexpr bool LAY_IS_TSP(const SLayoutT<T>&) { return T; }
 
 // identity on the padding of the dense layout; the rhs as row n: factoring the bordered matrix
 // [[S, s], [s', c]] leaves z = D^-1 L^-1 s in row n of the factor, so no separate forward substitution is needed.
-__global__ void schur_init_kernel(SLayout L, double* __restrict__ s, const double* __restrict__ b, const uint32_t* __restrict__ red_boff) {
+template <class LAY = SLayout>
+__global__ void schur_init_kernel(LAY L, double* __restrict__ s, const double* __restrict__ b, const uint32_t* __restrict__ red_boff) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < L.n) { *L.rhs(s, i) = b[red_boff[i]]; return; }
-    if (L.mode != SOLVE_BAND && L.mode != SOLVE_TSPARSE && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+    if (!LAY_IS_TSP(L) && L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
 }
 // schur_init + schur_copy + the status reset in one launch (sparse systems): the first ninit workgroups initialise s (and
 // the padding of the dense layout), the rest copy one reduced-reduced block each
-__global__ __launch_bounds__(256) void schur_prepare_kernel(SLayout L, double* __restrict__ s, const double* __restrict__ b, const uint32_t* __restrict__ red_boff,
+template <class LAY = SLayout>
+__global__ __launch_bounds__(256) void schur_prepare_kernel(LAY L, double* __restrict__ s, const double* __restrict__ b, const uint32_t* __restrict__ red_boff,
                                                             const double* __restrict__ A, const SchurCopy* __restrict__ copies, double lambda, int ninit, int* __restrict__ status) {
     if (blockIdx.x == 0 && threadIdx.x < 5) status[threadIdx.x] = 0;
     if ((int)blockIdx.x < ninit) {
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < L.n) { *L.rhs(s, i) = b[red_boff[i]]; return; }
-        if (L.mode != SOLVE_BAND && L.mode != SOLVE_TSPARSE && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+        if (!LAY_IS_TSP(L) && L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
         return;
     }
     const SchurCopy cp = copies[blockIdx.x - ninit];
@@ -82,7 +90,8 @@ __global__ __launch_bounds__(256) void schur_prepare_kernel(SLayout L, double* _
         else *L.at(cp.c + j, cp.r + i) = v;          // the border reordering flipped this block: store its transpose
     }
 }
-__global__ void schur_copy_kernel(SLayout L, const double* __restrict__ A, const SchurCopy* __restrict__ copies, double lambda) {
+template <class LAY = SLayout>
+__global__ void schur_copy_kernel(LAY L, const double* __restrict__ A, const SchurCopy* __restrict__ copies, double lambda) {
     const SchurCopy cp = copies[blockIdx.x];
     for (int e = threadIdx.x; e < cp.rows * cp.cols; e += blockDim.x) {
         const int i = e % cp.rows, j = e / cp.rows;
@@ -104,12 +113,13 @@ __global__ void dense_to_S_kernel(double* __restrict__ S, const double* __restri
 // the products E_v' Y_E (lower triangle) and E_v' y_b are summed over the run in LDS accumulators owned
 // lane-wise, then flushed once with HBM atomics -- 50-100x fewer atomics than one flush per block.
 // LDS: C (dv x dv), E (dv x nd), Y (dv x (nd+1)), acc (nd(nd+1)/2 + nd), column map.
+template <class LAY = SLayout>
 __global__ __launch_bounds__(64) void schur_elim_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                         const int64_t* __restrict__ eptr, const SchurNbr* __restrict__ enbr,
                                                         const int64_t* __restrict__ ediag, const uint32_t* __restrict__ eboff,
                                                         const uint16_t* __restrict__ edim, const uint32_t* __restrict__ egroup,
                                                         const uint32_t* __restrict__ glist, double lambda, int maxdv, int maxnd, int use_acc,
-                                                        SLayout L, double* __restrict__ s, int* __restrict__ status) {
+                                                        LAY L, double* __restrict__ s, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x;
     double* C = sm;                                   // dv*dv
@@ -372,10 +382,10 @@ constexpr int ELIM_NDP = 76;                                  // columns of [E |
 // (EXT: the workgroup's LDS is handed in -- ext, 16-byte aligned, schur_elim_tiled_lds<DV, NC>() doubles -- so that a kernel that runs either this body or
 //  another one in a workgroup pays for the larger of the two, not for their sum)
 template <int DV, int NC> constexpr int schur_elim_tiled_lds() { constexpr int NDM = NC == 1 ? 63 : ELIM_NDP - 5; return 4 * DV * ELIM_NDP + ELIM_NDP + NDM * (NDM + 1) / 2 + NDM + 2; }
-template <int DV, int NC, int TW, bool EXT = false>
+template <int DV, int NC, int TW, bool EXT = false, class LAY = SLayout>
 __device__ __forceinline__ void schur_elim_tiled_body(const double* __restrict__ A, const double* __restrict__ b,
                                                       const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                      const double* __restrict__ Cinv, const SLayout& L, double* __restrict__ s, uint32_t bidx, double* ext = nullptr) {
+                                                      const double* __restrict__ Cinv, const LAY& L, double* __restrict__ s, uint32_t bidx, double* ext = nullptr) {
     double (*Es)[DV][ELIM_NDP]; double (*Ys)[DV][ELIM_NDP]; uint32_t* rc; uint32_t* rs; double* img;      // rc: reduced column of list column p (MEMORY order); rs: the list columns by ascending reduced column
     if constexpr (EXT) {
         Es = reinterpret_cast<double (*)[DV][ELIM_NDP]>(ext); Ys = reinterpret_cast<double (*)[DV][ELIM_NDP]>(ext + 2 * DV * ELIM_NDP);
@@ -531,10 +541,10 @@ __device__ __forceinline__ void schur_elim_tiled_body(const double* __restrict__
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 
-template <int DV, int NC, int TW>
+template <int DV, int NC, int TW, class LAY = SLayout>
 __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                                const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                               const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
+                                                               const double* __restrict__ Cinv, LAY L, double* __restrict__ s) {
     schur_elim_tiled_body<DV, NC, TW>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
 }
 
@@ -548,10 +558,10 @@ __global__ __launch_bounds__(64 * (1 + TW)) void schur_elim_tiled_kernel(const d
 // is the operand delivery: the register-tiled kernel above is bound by its LDS reads (2 x DV 32-byte reads per lane and member, bank
 // conflicts included) and by one barrier per member.  The right-hand side rides along as column nd (row nd of the lower triangle).
 constexpr int ELIM_MFMA_NW = 4;                              // waves per supernode, each taking every fourth member (3 and 6 measured slower: 72 and 93 us against 65)
-template <int DV>
+template <int DV, class LAY = SLayout>
 __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ A, const double* __restrict__ b,
                                                      const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                     const double* __restrict__ Cinv, const SLayout& L, double* __restrict__ s, uint32_t bidx, const ElimPre* __restrict__ pre = nullptr) {
+                                                     const double* __restrict__ Cinv, const LAY& L, double* __restrict__ s, uint32_t bidx, const ElimPre* __restrict__ pre = nullptr) {
     constexpr int NDMAX = 63, NW = ELIM_MFMA_NW, NTH = 64 * NW;
     __shared__ uint32_t rc[64], rs[64];                       // rc: reduced column of list column p (MEMORY order); rs: the list columns by ascending reduced column
     __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
@@ -707,9 +717,9 @@ NLLS_DEV void glds16(const void* gsrc, uint32_t lds_dst) {     // M0 (the DMA's 
 }
 template <int N> NLLS_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 struct ElimDmaLds { double* ring; double* cinv; double* bv; double* img; uint32_t* rc; uint32_t* rs; };
-template <int DV>
+template <int DV, class LAY = SLayout>
 __device__ __forceinline__ void schur_elim_mfma_dma_body(const double* __restrict__ A, const ElimDesc& d, const uint32_t* __restrict__ rcflat,
-                                                         const SLayout& L, double* __restrict__ s, const ElimDmaLds& lds) {
+                                                         const LAY& L, double* __restrict__ s, const ElimDmaLds& lds) {
     constexpr int NDMAX = 63, NW = ELIM_MFMA_NW, NTH = 64 * NW, NS = ELIM_DMA_NS;
     double* const img = lds.img; double* const irhs = img + NDMAX * (NDMAX + 1) / 2; uint32_t* const rc = lds.rc; uint32_t* const rs = lds.rs;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
@@ -797,19 +807,19 @@ __device__ __forceinline__ void schur_elim_mfma_dma_body(const double* __restric
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 
-template <int DV>
+template <int DV, class LAY = SLayout>
 __global__ __launch_bounds__(64 * ELIM_MFMA_NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_mfma_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                              const double* __restrict__ Cinv, SLayout L, double* __restrict__ s) {
+                                                              const double* __restrict__ Cinv, LAY L, double* __restrict__ s) {
     schur_elim_mfma_body<DV>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
 }
 // Both kinds of fast supernode in ONE launch: the narrow ones (matrix-core body) first, the wide ones (register-tiled body, NC = 2)
 // behind them.  The narrow supernodes need 1.3 rounds of the chip's wave slots; in a launch of their own the second round leaves most
 // CUs idle, and the wide supernodes -- 1-2 members each, all fixed cost -- then wait for it to end.  Here they fill those slots.
-template <int DV>
+template <int DV, class LAY = SLayout>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_fused_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                              const double* __restrict__ Cinv, SLayout L, double* __restrict__ s, uint32_t nnarrow) {
+                                                              const double* __restrict__ Cinv, LAY L, double* __restrict__ s, uint32_t nnarrow) {
     static_assert(ELIM_MFMA_NW == 4, "both bodies run in 256-thread workgroups");
     if (blockIdx.x < nnarrow) schur_elim_mfma_body<DV>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
     else schur_elim_tiled_body<DV, 2, 3>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
@@ -821,17 +831,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 //    [S | s] -- the storage is zero when the launch starts (the previous solve's back-substitution leaves it so), and sums commute with the
 //    supernodes' atomic adds, so the order inside the launch does not matter.
 struct PrepArgs { const uint32_t* red_boff; const SchurCopy* copies; double lambda; int ninit; uint32_t nfast; int* status; };
-template <int DV>
+template <int DV, class LAY = SLayout>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_all_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                              double* __restrict__ Cinv, SLayout L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa, const ElimPre* __restrict__ pre) {
+                                                              double* __restrict__ Cinv, LAY L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa, const ElimPre* __restrict__ pre) {
     if (blockIdx.x >= pa.nfast) {
         const int w = (int)(blockIdx.x - pa.nfast);
         if (w == 0 && threadIdx.x == 0) pa.status[4] = 0;                       // (pivots dropped by the floor: only the panels of this solve add to it)
         if (w < pa.ninit) {
             const int i = w * 256 + threadIdx.x;
             if (i < L.n) { atomicAdd(L.rhs(s, i), b[pa.red_boff[i]]); return; }
-            if (L.mode != SOLVE_BAND && L.mode != SOLVE_TSPARSE && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+            if (!LAY_IS_TSP(L) && L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
             return;
         }
         const SchurCopy cp = pa.copies[w - pa.ninit];
@@ -895,17 +905,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 // schur_elim_all_kernel with the narrow supernodes' member loop fed by LDS-DMA (schur_elim_mfma_dma_body).  The prologue keeps the inverse diagonal
 // blocks and the right-hand sides of the supernode's members in LDS as well (at most 128 members per supernode: build_schur).
-template <int DV>
+template <int DV, class LAY = SLayout>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_all_dma_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                              double* __restrict__ Cinv, SLayout L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa) {
+                                                              double* __restrict__ Cinv, LAY L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa) {
     if (blockIdx.x >= pa.nfast) {
         const int w = (int)(blockIdx.x - pa.nfast);
         if (w == 0 && threadIdx.x == 0) pa.status[4] = 0;
         if (w < pa.ninit) {
             const int i = w * 256 + threadIdx.x;
             if (i < L.n) { atomicAdd(L.rhs(s, i), b[pa.red_boff[i]]); return; }
-            if (L.mode != SOLVE_BAND && L.mode != SOLVE_TSPARSE && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
+            if (!LAY_IS_TSP(L) && L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
             return;
         }
         const SchurCopy cp = pa.copies[w - pa.ninit];
@@ -2725,18 +2735,21 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
     return NLLS_OK;
 }
 
-static SLayout make_layout(nlls_ctx* c) {
-    SLayout L{}; L.S = c->S.p; L.mode = c->solve_mode; L.n = (int)c->nred; L.npad = c->dense_pad128 ? (((int)c->nred + 1 + 127) / 128) * 128 : (((int)c->nred + 1 + NB - 1) / NB) * NB;
-    L.n_band = (int)c->n_band; L.bw = c->bw; L.nbd = c->nbd; L.H = c->band_H; L.tsp = nullptr;
-    if (c->solve_mode == SOLVE_TSPARSE) { L.npad = c->tsp.nt; L.tsp = c->tsp.d_map.p; }
+template <bool TSP = false>
+static SLayoutT<TSP> make_layout(nlls_ctx* c) {
+    SLayoutT<TSP> L{}; L.S = c->S.p; L.mode = c->solve_mode; L.n = (int)c->nred; L.npad = c->dense_pad128 ? (((int)c->nred + 1 + 127) / 128) * 128 : (((int)c->nred + 1 + NB - 1) / NB) * NB;
+    L.n_band = (int)c->n_band; L.bw = c->bw; L.nbd = c->nbd; L.H = c->band_H;
+    if constexpr (TSP) { L.npad = c->tsp.nt; L.tsp = c->tsp.d_map.p; }
     return L;
 }
 
 // local phase: assemble this rank's share of [S | s] (rank 0 also contributes the reduced-reduced blocks,
 // lambda*I and b_R); under sharding the buffer is then summed over ranks
-int enqueue_solve_local(nlls_ctx* c) {
+template <bool TSP>
+static int enqueue_solve_local_t(nlls_ctx* c) {
+    using LAY = SLayoutT<TSP>;
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
-    const SLayout L = make_layout(c); const int npad = L.npad;
+    const LAY L = make_layout<TSP>(c); const int npad = TSP ? 0 : L.npad;
     // lazy stage 0 (collective route, reduced rows not summed over ranks): EVERY rank adds its share of the reduced-reduced blocks and of b_R to its
     // share of [S | s] -- the one sum over ranks that follows completes both; the damping is rank 0's
     const bool lazy = c->nranks > 1 && !c->reduced_summed;
@@ -2772,7 +2785,7 @@ int enqueue_solve_local(nlls_ctx* c) {
     if (all_in_one) {
         if (!c->status_known_zero) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));
         c->status_known_zero = false;
-        if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)((band || c->solve_mode == SOLVE_TSPARSE) ? n : npad)), c->stream));
+        if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)((band || TSP) ? n : npad)), c->stream));
         c->S_zeroed = false;
         const int ninit = (std::max(npad, n) + 255) / 256;
         // (the elimination's own list when tiny supernodes were folded into their neighbours at upload: fewer workgroups, half the atomics)
@@ -2782,8 +2795,8 @@ int enqueue_solve_local(nlls_ctx* c) {
         PrepArgs pa{c->d_red_boff.p, c->d_copy.p, c->lambda, ninit, (uint32_t)ngroups_l, c->d_status.p};
         const dim3 grid((unsigned)(ngroups_l + ninit + c->ncopy));
         const bool elim_dma = c->elim_dma;      // A/B: the narrow supernodes' member loop fed by LDS-DMA
-#define LAUNCH_ALL(DV) do { if (elim_dma) hipLaunchKernelGGL((schur_elim_all_dma_kernel<DV>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nfast_narrow, pa); \
-        else hipLaunchKernelGGL((schur_elim_all_kernel<DV>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, desc_l, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nnarrow_l, pa, pre_l); } while (0)
+#define LAUNCH_ALL(DV) do { if (elim_dma) hipLaunchKernelGGL((schur_elim_all_dma_kernel<DV, LAY>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nfast_narrow, pa); \
+        else hipLaunchKernelGGL((schur_elim_all_kernel<DV, LAY>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, desc_l, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nnarrow_l, pa, pre_l); } while (0)
         if (c->fast_dv == 3) LAUNCH_ALL(3); else if (c->fast_dv == 2) LAUNCH_ALL(2); else LAUNCH_ALL(1);
 #undef LAUNCH_ALL
         HIPCHK(hipGetLastError());
@@ -2791,17 +2804,17 @@ int enqueue_solve_local(nlls_ctx* c) {
     }
     c->status_known_zero = false;
     if (!one_prepare) HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));
-    if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)((band || c->solve_mode == SOLVE_TSPARSE) ? n : npad)), c->stream));
+    if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)((band || TSP) ? n : npad)), c->stream));
     c->S_zeroed = false;
     if (c->nranks > 1) HIPCHK(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->info.ndof, c->stream));
     if (one_prepare) {
         const int ninit = (std::max(npad, n) + 255) / 256;
-        hipLaunchKernelGGL(schur_prepare_kernel, dim3((unsigned)(ninit + c->ncopy)), dim3(256), 0, c->stream, L, c->s_ptr(), c->b.p, c->d_red_boff.p,
+        hipLaunchKernelGGL(schur_prepare_kernel<LAY>, dim3((unsigned)(ninit + c->ncopy)), dim3(256), 0, c->stream, L, c->s_ptr(), c->b.p, c->d_red_boff.p,
                            c->A.p, c->d_copy.p, lambda_rr, ninit, c->d_status.p);
     } else if (lead) {
-        hipLaunchKernelGGL(schur_init_kernel, dim3((std::max(npad, n) + 255) / 256), dim3(256), 0, c->stream, L, c->s_ptr(), c->b.p, c->d_red_boff.p);
+        hipLaunchKernelGGL(schur_init_kernel<LAY>, dim3((std::max(npad, n) + 255) / 256), dim3(256), 0, c->stream, L, c->s_ptr(), c->b.p, c->d_red_boff.p);
         if (c->info.is_sparse) {
-            if (c->ncopy > 0) hipLaunchKernelGGL(schur_copy_kernel, dim3((unsigned)c->ncopy), dim3(64), 0, c->stream, L, c->A.p, c->d_copy.p, lambda_rr);
+            if (c->ncopy > 0) hipLaunchKernelGGL(schur_copy_kernel<LAY>, dim3((unsigned)c->ncopy), dim3(64), 0, c->stream, L, c->A.p, c->d_copy.p, lambda_rr);
         } else {
             const int64_t n2 = (int64_t)n * n;
             hipLaunchKernelGGL(dense_to_S_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->S.p, c->A.p, c->lambda, n, npad);
@@ -2811,25 +2824,25 @@ int enqueue_solve_local(nlls_ctx* c) {
         if (c->n_slow_groups > 0) {
             // (more than 64 KB of dynamic LDS has to be asked for once per process)
             static size_t lds_granted = 0; const size_t want = std::max(c->elim_lds_acc, c->elim_lds_noacc);
-            if (want > lds_granted) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_elim_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want)); lds_granted = want; }
+            if (want > lds_granted) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_elim_kernel<LAY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want)); lds_granted = want; }
             const int64_t nacc = c->n_slow_acc, nno = c->n_slow_groups - nacc;
-            if (nacc > 0) hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)nacc), dim3(64), c->elim_lds_acc, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
+            if (nacc > 0) hipLaunchKernelGGL(schur_elim_kernel<LAY>, dim3((unsigned)nacc), dim3(64), c->elim_lds_acc, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
                                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->d_slow_groups.p, c->lambda, c->max_elim_dim, c->slow_nd_acc, 1, L, c->s_ptr(), c->d_status.p);
-            if (nno > 0) hipLaunchKernelGGL(schur_elim_kernel, dim3((unsigned)nno), dim3(64), c->elim_lds_noacc, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
+            if (nno > 0) hipLaunchKernelGGL(schur_elim_kernel<LAY>, dim3((unsigned)nno), dim3(64), c->elim_lds_noacc, c->stream, c->A.p, c->b.p, c->d_elim_ptr.p, c->d_elim_nbr.p,
                                c->d_elim_diag.p, c->d_elim_boff.p, c->d_elim_dim.p, c->d_elim_group.p, c->d_slow_groups.p + nacc, c->lambda, c->max_elim_dim, c->slow_nd_noacc, 0, L, c->s_ptr(), c->d_status.p);
         }
 #define LAUNCH_TILED(DV) do { const int64_t nel = (int64_t)c->d_elim_diag.n; \
             hipLaunchKernelGGL((schur_cinv_kernel<DV>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, c->stream, c->A.p, c->d_elim_diag.p, c->d_elim_dim.p, nel, c->lambda, c->Cinv.p, c->d_status.p); \
             const int64_t n60 = c->n_fast_n60, nnar = c->n_fast_narrow - c->n_fast_n60, nwid = c->n_fast_groups - c->n_fast_narrow;   /* d_fast_groups: nd <= 60, then the other narrow supernodes, then the wide ones */ \
-            if (c->elim_mfma && n60 + nnar > 0 && nwid > 0) { hipLaunchKernelGGL((schur_elim_fused_kernel<DV>), dim3((unsigned)(n60 + nnar + nwid)), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+            if (c->elim_mfma && n60 + nnar > 0 && nwid > 0) { hipLaunchKernelGGL((schur_elim_fused_kernel<DV, LAY>), dim3((unsigned)(n60 + nnar + nwid)), dim3(256), 0, c->stream, c->A.p, c->b.p, \
                 c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)(n60 + nnar)); break; } \
-            if (c->elim_mfma) { if (n60 + nnar > 0) hipLaunchKernelGGL((schur_elim_mfma_kernel<DV>), dim3((unsigned)(n60 + nnar)), dim3(64 * ELIM_MFMA_NW), 0, c->stream, c->A.p, c->b.p, \
+            if (c->elim_mfma) { if (n60 + nnar > 0) hipLaunchKernelGGL((schur_elim_mfma_kernel<DV, LAY>), dim3((unsigned)(n60 + nnar)), dim3(64 * ELIM_MFMA_NW), 0, c->stream, c->A.p, c->b.p, \
                 c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr()); } else { \
-            if (n60 > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1, 2>), dim3((unsigned)n60), dim3(192), 0, c->stream, c->A.p, c->b.p, \
+            if (n60 > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1, 2, LAY>), dim3((unsigned)n60), dim3(192), 0, c->stream, c->A.p, c->b.p, \
                 c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr()); \
-            if (nnar > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1, 3>), dim3((unsigned)nnar), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+            if (nnar > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 1, 3, LAY>), dim3((unsigned)nnar), dim3(256), 0, c->stream, c->A.p, c->b.p, \
                 c->d_elim_desc.p + n60, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr()); } \
-            if (nwid > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 2, 3>), dim3((unsigned)nwid), dim3(256), 0, c->stream, c->A.p, c->b.p, \
+            if (nwid > 0) hipLaunchKernelGGL((schur_elim_tiled_kernel<DV, 2, 3, LAY>), dim3((unsigned)nwid), dim3(256), 0, c->stream, c->A.p, c->b.p, \
                 c->d_elim_desc.p + c->n_fast_narrow, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr()); } while (0)
         if (c->n_fast_groups > 0) {
             if (c->fast_dv == 3) LAUNCH_TILED(3); else if (c->fast_dv == 2) LAUNCH_TILED(2); else if (c->fast_dv == 1) LAUNCH_TILED(1);
@@ -2839,6 +2852,8 @@ int enqueue_solve_local(nlls_ctx* c) {
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
+
+int enqueue_solve_local(nlls_ctx* c) { return c->solve_mode == SOLVE_TSPARSE ? enqueue_solve_local_t<true>(c) : enqueue_solve_local_t<false>(c); }
 
 // the reduced system itself: factorisation + both substitutions; its solution lands in s (c->s_ptr())
 int enqueue_reduced_solve(nlls_ctx* c) {

@@ -986,7 +986,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         const int64_t npad = c->dense_pad128 ? ((n + 1 + 127) / 128) * 128 : ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
         // TILE-SPARSE: nested dissection of the reduced blocks' graph, the factorisation level by level of its elimination tree (nlls_tsp.hip).  Taken when its
         // dependent chain (levels of the tree) and its tile products come out clearly below what the dense / windowed factorisation of the same system costs
-        // (rough launch + matrix-core times, in us: a level = panel + update + backward launches; a 128^3 tile product ~0.17 us of the chip).
+        // (rough launch + matrix-core times, in us).
         if (I0.is_sparse && c->nelim > 0 && n >= 512 && !red_adj_blocks.empty() && !(flags & (NLLS_FLAG_NO_BAND | NLLS_FLAG_NO_TILE_SPARSE)) && !getenv("NLLS_NO_TSPARSE")) {
             std::vector<int32_t> ndof, noff;
             for (int64_t k : red_adj_blocks) { ndof.push_back((int32_t)c->blocksizes[k]); noff.push_back((int32_t)red_of[k]); }
@@ -994,8 +994,10 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             TspSym sym;
             if (tsp_symbolic(red_adj, ndof, nbdn, sym) && sym.nt > 0 && sym.nt <= 4096) {
                 const double NB128 = (double)(npad / 128 + (npad % 128 ? 1 : 0));
-                const double t_tsp = 48.0 * sym.nlevels + 0.17 * (double)sym.nupd_products + 30.0 * (8.0 * (double)(sym.ntiles_lower - sym.nt) + sym.nt) / 256.0;
-                double t_dense = 32.0 * NB128 + 0.17 * NB128 * NB128 * NB128 / 6.0;
+                // (calibrated on camera grids of 24 x 24 ... 100 x 100: a level = panel 30 + update 12 + backward 10 us; a 128^3 product of an update 0.09 us of the chip
+                //  with the empty chunks skipped, of a panel 0.07; the dense trailing update 0.12 us per tile product)
+                const double t_tsp = 52.0 * sym.nlevels + 0.09 * (double)sym.nupd_products + 0.07 * (double)(sym.ntiles_lower - sym.nt);
+                double t_dense = 32.0 * NB128 + 0.12 * NB128 * NB128 * NB128 / 6.0;
                 if (c->dense_window) { const double wt = (double)((bw + 127) / 128 + 1 + (c->nbd + 1 + 127) / 128); t_dense = std::min(t_dense, NB128 * (40.0 + 0.17 * wt * (wt + 1) / 2.0)); }
                 const bool force = getenv("NLLS_FORCE_TSPARSE") != nullptr;
                 if (t_tsp < 0.8 * t_dense || force) {

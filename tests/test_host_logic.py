@@ -196,3 +196,36 @@ def test_nd_tiles_rejects_bad_input():
     bad = np.array([5], np.int32)
     assert _capi.lib().nlls_nd_tiles(1, 0, _capi._p(np.array([0, 1], np.int64)), _capi._p(bad), _capi._p(np.array([6], np.int32)), _capi._p(z), _capi._p(z), 4, _capi._p(z), _capi._p(z), _capi._p(z64), 4, _capi._p(z)) == _capi.ERR_INVALID_ARG
     assert _capi.lib().nlls_nd_tiles(1, 0, _capi._p(np.array([0, 0], np.int64)), _capi._p(bad), _capi._p(np.array([129], np.int32)), _capi._p(z), _capi._p(z), 4, _capi._p(z), _capi._p(z), _capi._p(z64), 4, _capi._p(z)) == _capi.ERR_INVALID_ARG
+
+
+def test_nd_tiles_takes_hub_cameras_out_of_the_dissection():
+    """Three overview cameras coupled to 40 % of a 20 x 20 camera grid: with them in the graph everything is within two steps of everything and no breadth-first
+    level structure has an interior level to cut at (one dense front: as many levels as tiles).  The symbolic phase orders such hubs last -- the root front, a
+    neighbour of every tile -- and dissects the rest: the tree stays shallow, and the numeric factor of a random matrix with the pattern stays inside the
+    predicted tile pattern."""
+    rng = np.random.default_rng(4)
+    gw = gh = 20; ptr, adj = _grid_graph(gw, gh); n0 = gw * gh; nh = 3
+    lists = [adj[ptr[i]:ptr[i + 1]].tolist() for i in range(n0)] + [[] for _ in range(nh)]
+    for h in range(nh):
+        for v in rng.choice(n0, size=int(0.4 * n0), replace=False):
+            lists[n0 + h].append(int(v)); lists[int(v)].append(n0 + h)
+    n = n0 + nh
+    ptr2 = np.zeros(n + 1, np.int64); ptr2[1:] = np.cumsum([len(l) for l in lists]); adj2 = np.array([w for l in lists for w in l], np.int32)
+    dof = np.full(n, 6, np.int32)
+    nt, tile_of, row, parent, level, colptr, rows = _nd_tiles(ptr2, adj2, dof)
+    assert level.max() + 1 <= 0.6 * nt, (level.max() + 1, nt)
+    assert all(tile_of[n0 + h] >= nt - 2 for h in range(nh))                      # the hubs: at the very end (they start in the last front's tail tile)
+    pos = tile_of.astype(np.int64) * 128 + row
+    N = nt * 128; M = np.zeros((N, N)); used = np.zeros(N, bool)
+    for v in range(n):
+        used[pos[v]:pos[v] + 6] = True
+        for w in lists[v]:
+            if w < v:
+                B = rng.normal(size=(6, 6)); M[pos[v]:pos[v] + 6, pos[w]:pos[w] + 6] = B; M[pos[w]:pos[w] + 6, pos[v]:pos[v] + 6] = B.T
+    M[np.arange(N), np.arange(N)] = np.where(used, 2.0 * np.abs(M).sum(axis=1).max() + 1.0, 1.0)
+    Lf = np.linalg.cholesky(M)
+    struct = [set(rows[colptr[k]:colptr[k + 1]].tolist()) for k in range(nt)]
+    for k in range(nt):
+        for i in range(k + 1, nt):
+            if np.abs(Lf[128 * i:128 * i + 128, 128 * k:128 * k + 128]).max() > 1e-13:
+                assert i in struct[k], (i, k)

@@ -28,4 +28,10 @@ python bench.py --solver dense --steps 5 --warmup 1 --no-cpu-baseline > gpurun_o
 # rocprofv3 kernel stats of the other BASELINE configurations (2, 3, 5) and of the dense solver
 for w in ba_100x10k curvefit_10k ba_so3_500x50k; do rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_$w -- python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> gpurun_out/${tag}_stats_$w.err || exit 8; done
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_dense -- python bench.py --solver dense --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/${tag}_stats_dense.err || exit 9
+# the tile-sparse reduced solver (solve_mode 3): camera grids -- LM lines, kernel stats of the 40 x 40 grid, the reduced solve against the windowed and the dense LDL'
+for w in ba_grid_40x40 ba_grid_100x100; do python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_$w.json 2> gpurun_out/${tag}_bench_$w.err || exit 16; done
+python bench.py --workload ba_grid_40x40 --solver windowed --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_ba_grid_40x40_windowed.json 2> gpurun_out/${tag}_bench_ba_grid_40x40_windowed.err || exit 17
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_ba_grid_40x40 -- python bench.py --workload ba_grid_40x40 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> gpurun_out/${tag}_stats_ba_grid_40x40.err || exit 18
+python tools/tsp_try.py --grids 24x24,40x40 > gpurun_out/${tag}_tsp_try.json 2> gpurun_out/${tag}_tsp_try.err || exit 19
+python tools/tsp_try.py --grids 100x100 --no-dense >> gpurun_out/${tag}_tsp_try.json 2>> gpurun_out/${tag}_tsp_try.err || exit 20
 echo done
