@@ -166,7 +166,7 @@ def grid_visibility(gw, gh, pts_per_cell):
     return cam[order], lm[order], cell.shape[0]
 
 
-def scattered_visibility(ncameras, nlandmarks, nviews, seed, loop=False):
+def scattered_visibility(ncameras, nlandmarks, nviews, seed, loop=False, overview=0, overview_frac=0.3):
     """(camera, landmark) pairs, 1-based and camera-major, of cameras SCATTERED over the unit square (loop=True: along a closed ring -- a loop closure), every
     landmark at a random place seen by the `nviews` cameras nearest to it: an unstructured camera graph (no grid, no numbering to exploit)."""
     rng = np.random.default_rng(seed)
@@ -180,16 +180,21 @@ def scattered_visibility(ncameras, nlandmarks, nviews, seed, loop=False):
     from scipy.spatial import cKDTree
     _, nn = cKDTree(cpos).query(lpos, k=nviews)
     cam = nn.ravel() + 1; lm = np.repeat(np.arange(nlandmarks), nviews) + 1
+    for h in range(overview):                      # OVERVIEW cameras (the last `overview` ones): each also sees a random `overview_frac` of all landmarks
+        seen = np.flatnonzero(rng.random(nlandmarks) < overview_frac) + 1
+        c = ncameras - overview + h + 1
+        seen = seen[~np.isin(seen, lm[cam == c])]
+        cam = np.concatenate([cam, np.full(seen.size, c)]); lm = np.concatenate([lm, seen])
     order = np.lexsort((lm, cam))
     return cam[order], lm[order]
 
 
-def create_scattered_ba_problem(ncameras, nlandmarks, nviews=6, seed=1, robust=None, outlier_frac=0.0, outlier_sigma=0.0, noise=0.0, loop=False):
+def create_scattered_ba_problem(ncameras, nlandmarks, nviews=6, seed=1, robust=None, outlier_frac=0.0, outlier_sigma=0.0, noise=0.0, loop=False, overview=0):
     """The affine-camera bundle adjustment of test/optimizeba.jl:4-35 over scattered_visibility (visibility is that generator's free parameter, :22-23)."""
     rng = np.random.default_rng(seed + 1000)
     cams = rng.standard_normal((ncameras, 6)) + np.array([1.0, 0, 0, 0, 1.0, 0])
     pts = rng.random((nlandmarks, 3)) + np.array([-0.5, -0.5, 10.0])
-    cam, lm = scattered_visibility(ncameras, nlandmarks, nviews, seed, loop)
+    cam, lm = scattered_visibility(ncameras, nlandmarks, nviews, seed, loop, overview)
     problem = NLLSProblem(); problem.addvariables(cams); problem.addvariables(pts)
     c, X = cams[cam - 1], pts[lm - 1]
     meas = np.stack([(c[:, 0:3] * X).sum(1), (c[:, 3:6] * X).sum(1)], axis=1)

@@ -238,14 +238,15 @@ def test_grid_camera_graph_tile_sparse_solve(gw, gh, shuffle, kind):
     assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
 
 
-@pytest.mark.parametrize("ncam,npts,nviews,loop", [(700, 5000, 6, False), (900, 5000, 5, True)])
-def test_scattered_camera_graph_tile_sparse_solve(ncam, npts, nviews, loop):
+@pytest.mark.parametrize("ncam,npts,nviews,loop,overview", [(700, 5000, 6, False, 0), (900, 5000, 5, True, 0), (800, 5000, 6, False, 5)])
+def test_scattered_camera_graph_tile_sparse_solve(ncam, npts, nviews, loop, overview):
     """Cameras scattered over a square -- or along a closed ring: a loop closure, whose reduced system no ordering turns into a narrow band -- every landmark seen by
     the cameras nearest to it: a camera graph with no grid and no numbering to exploit.  The upload's nested dissection (breadth-first level structures from
     pseudo-peripheral nodes) must still find a shallow elimination tree; sweep, damped solve, retraction and five LM iterations against the oracle, whose LDL' orders
-    itself (as the reference's: src/linearsystem.jl:52,68)."""
+    itself (as the reference's: src/linearsystem.jl:52,68).  overview: that many cameras also see 30 % of ALL landmarks each -- hubs coupled to most other cameras, within
+    two steps of which everything lies: two of them fit the border of the reduced system (15 dof), the others are ordered last by the symbolic phase (the root front)."""
     mk = lambda: synthetic.perturb_ba_problem(synthetic.create_scattered_ba_problem(ncam, npts, nviews, seed=5, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05,
-                                                                                     noise=1e-3, loop=loop), 1e-3, 1e-3)
+                                                                                     noise=1e-3, loop=loop, overview=overview), 1e-3, 1e-3)
     p = mk()
     info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
     _, st = _upload_info(p)
