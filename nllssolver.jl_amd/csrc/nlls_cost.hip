@@ -59,11 +59,16 @@ __global__ __launch_bounds__(TPB) void reduce_partials_kernel(const double* __re
 // residual, the dynamic ones included); the non-squared cost kind takes none.
 __global__ __launch_bounds__(TPB) void dyn_block_kernel(int kind, int n, int ndata, const double* __restrict__ vars, const double* __restrict__ data,
                                                         const uint32_t* __restrict__ voff, const uint32_t* __restrict__ index, const uint32_t* __restrict__ brow,
-                                                        int ndof, double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials, RobustSpec rk) {
+                                                        int ndof, double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials, RobustSpec rk,
+                                                        const uint32_t* __restrict__ aoff = nullptr) {
     __shared__ double red[TPB / 64]; __shared__ double total;
     const int64_t k = index ? index[blockIdx.x] : blockIdx.x;
     const double* w = vars + voff[k];
     const uint32_t bo = (A && brow) ? brow[blockIdx.x] : DEST_NONE;            // (brow is in launch order: one entry per launched block)
+    // where H(i, j) of the block goes: the dense system (lower triangle: mirrored behind the sweep), or -- aoff -- the variable's n x n diagonal block of a
+    // block-sparse system, which is stored in full (src/linearsystem.jl:140)
+    const bool blk = aoff != nullptr; const size_t abase = blk ? (size_t)aoff[blockIdx.x] : 0;
+    auto Hat = [&](int i, int j) -> double* { return blk ? A + abase + i + (size_t)n * j : A + (bo + i) + (size_t)ndof * (bo + j); };
     const bool robust = (rk.kind & 0xF) != NLLS_ROBUST_NONE || (rk.kind & NLLS_ROBUST_SCALED);
     double cost;
     // rho, rho', rho'' at c = r'r (every thread: c is the workgroup's total)
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(TPB) void dyn_block_kernel(int kind, int n, int nda
         if (bo != DEST_NONE) {
             const double hs = d1 + 2.0 * d2 * r * r;                             // J'J = X X', J'r = X r: H = (rho' + 2 rho'' r^2) X X'
             for (int i = threadIdx.x; i < n; i += TPB) atomicAdd(&b[bo + i], d1 * (X[i] * r));
-            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int i = (int)(e % n), j = (int)(e / n); if (i >= j) atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + j)], hs * (X[i] * X[j])); }
+            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int i = (int)(e % n), j = (int)(e / n); if (i >= j || blk) atomicAdd(Hat(i, j), hs * (X[i] * X[j])); }
         }
     } else if (kind == NLLS_RES_DYN_LINEARSQ) {                                   // X*w - y, X square (n <= 512): J = X
         __shared__ double rs[512], gs[512];
@@ -96,9 +101,9 @@ __global__ __launch_bounds__(TPB) void dyn_block_kernel(int kind, int n, int nda
         if (bo != DEST_NONE) {
             for (int j = threadIdx.x; j < n; j += TPB) { double t = 0; for (int i = 0; i < n; ++i) t = fma(X[i + (size_t)n * j], rs[i], t); gs[j] = t; atomicAdd(&b[bo + j], d1 * t); }
             __syncthreads();
-            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int j = (int)(e % n), q = (int)(e / n); if (j < q) continue;
+            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int j = (int)(e % n), q = (int)(e / n); if (j < q && !blk) continue;
                 double h = 0; for (int i = 0; i < n; ++i) h = fma(X[i + (size_t)n * j], X[i + (size_t)n * q], h);
-                atomicAdd(&A[(bo + j) + (size_t)ndof * (bo + q)], robust ? d1 * h + (2.0 * d2 * gs[j]) * gs[q] : h); }
+                atomicAdd(Hat(j, q), robust ? d1 * h + (2.0 * d2 * gs[j]) * gs[q] : h); }
         }
     } else if (kind == NLLS_COST_DYN_LINEAR) {                                   // non-squared cost y'w: value, gradient y, Hessian 0
         const double* y = data + k * (int64_t)ndata;
@@ -114,9 +119,9 @@ __global__ __launch_bounds__(TPB) void dyn_block_kernel(int kind, int n, int nda
         double rho, d1, d2; kernel_at(total, rho, d1, d2);
         cost = 0.5 * rho;
         if (bo != DEST_NONE) {
-            for (int i = threadIdx.x; i < n; i += TPB) { atomicAdd(&b[bo + i], d1 * w[i]); if (!robust || d2 == 0.0) atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + i)], d1); }
+            for (int i = threadIdx.x; i < n; i += TPB) { atomicAdd(&b[bo + i], d1 * w[i]); if (!robust || d2 == 0.0) atomicAdd(Hat(i, i), d1); }
             if (robust && d2 != 0.0)                                                // H = rho' I + 2 rho'' w w'
-                for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int i = (int)(e % n), j = (int)(e / n); if (i >= j) atomicAdd(&A[(bo + i) + (size_t)ndof * (bo + j)], (i == j ? d1 : 0.0) + (2.0 * d2 * w[i]) * w[j]); }
+                for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += TPB) { const int i = (int)(e % n), j = (int)(e / n); if (i >= j || blk) atomicAdd(Hat(i, j), (i == j ? d1 : 0.0) + (2.0 * d2 * w[i]) * w[j]); }
         }
     }
     if (threadIdx.x == 0) partials[blockIdx.x] = cost;
@@ -398,7 +403,7 @@ static int launch_dyn_cost(nlls_ctx* c, const Group& G, const double* vars, int6
 int enqueue_dyn_gradhess(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
     if (G.dense.n > 0) {
         hipLaunchKernelGGL(dyn_block_kernel, dim3((unsigned)G.dense.n), dim3(TPB), 0, c->stream, G.res_kind, dyn_n_of(G), G.ndata, vars, G.dense.data.p, G.dense.voff.p,
-                           (const uint32_t*)nullptr, G.dense.brow.p, (int)c->info.ndof, c->A.p, c->b.p, c->partials.p + pbase, G.rk);
+                           (const uint32_t*)nullptr, G.dense.brow.p, (int)c->info.ndof, c->A.p, c->b.p, c->partials.p + pbase, G.rk, (const uint32_t*)(c->info.is_sparse ? G.dense.aoff.p : nullptr));
         pbase += G.dense.n;
     }
     HIPCHK(hipGetLastError());

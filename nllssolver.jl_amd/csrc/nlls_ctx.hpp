@@ -67,6 +67,7 @@ struct DenseList {          // dense linear system: one entry per cost
     DevBuf<double>   data;  // [n][ndata]
     DevBuf<uint32_t> voff;  // [n][ndeps]
     DevBuf<uint32_t> brow;  // [n][ndeps] dof offset of the slot's block in b, DEST_NONE if fixed
+    DevBuf<uint32_t> aoff;  // dynamic-size groups of a BLOCK-SPARSE system: [n] offset of the variable's diagonal block in A.data (empty: dense system)
 };
 
 struct Group {

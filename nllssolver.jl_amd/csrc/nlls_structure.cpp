@@ -162,7 +162,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
         int64_t bnnz = 0; for (uint64_t k : keys) bnnz += (int64_t)c->blocksizes[k / nb] * c->blocksizes[k % nb];   // utils.jl:110-120
         sparse = (flags & NLLS_FLAG_FORCE_SPARSE) || (bnnz * 64) < (25 * ndof * (ndof - 40));                        // utils.jl:108
     }
-    if (any_dyn && sparse) return fail(c, NLLS_ERR_UNSUPPORTED, "dynamic-size residual blocks are accumulated into the dense linear system only");
+    // (dynamic-size blocks in a BLOCK-SPARSE system -- src/autodiff.jl:96-121 with src/linearsystem.jl:105-121: their variable appears in no other kind of block,
+    //  so its block row holds its diagonal block only; the blocks accumulate into it directly, below)
     if (any_dyn && c->nranks > 1) return fail(c, NLLS_ERR_UNSUPPORTED, "dynamic-size residual blocks run unsharded");
     c->it_colptr.clear(); c->it_rowval.clear(); c->it_nzval.clear(); c->diag_off.assign(nb, -1);
     int64_t nnz_data = 0;
@@ -278,7 +279,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
         G.nfixedcost = (int64_t)fixedcost.size(); HIPCHK(G.fixedcost.upload(fixedcost));
         npartials += (G.nfixedcost + 255) / 256;
         hl[g].resize(d.ndeps);
-        if (!sparse) continue;
+        if (!sparse || is_dyn_kind(in.res_kind)) continue;      // (dynamic-size groups take no entry lists: see the DenseList built for them below)
         for (int s = 0; s < d.ndeps; ++s) {
             HostList& L = hl[g][s];
             // counting sort of the incidences (cost, s) by block row
@@ -414,6 +415,21 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
         HIPCHK(c->d_red_off.upload(red_off)); HIPCHK(c->d_red_len.upload(red_len)); HIPCHK(c->d_red_dst.upload(red_dst)); HIPCHK(c->d_red_which.upload(red_which));
         HIPCHK(c->redbuf.alloc(dst));
     } else { c->nred_ranges = 0; c->redbuf_len = 0; }
+    if (sparse) for (int g = 0; g < ngroups; ++g) {
+        // dynamic-size groups of a block-sparse system: one entry per cost block with a free variable, accumulated with atomics straight into the variable's
+        // (full) diagonal block -- the row is zeroed in front of every sweep
+        Group& G = c->groups[g]; const ResDesc& d = desc[g]; const nlls_cost_group& in = groups[g];
+        if (!is_dyn_kind(in.res_kind)) continue;
+        std::vector<double> hd; std::vector<uint32_t> hv, hb, ha;
+        for (int64_t k = 0; k < in.ncost; ++k) { const int64_t v = in.varind[k] - 1; if (!bi[v]) continue;
+            const int64_t blk = (int64_t)bi[v] - 1;
+            for (int q = 0; q < d.ndata; ++q) hd.push_back(in.data[k * d.ndata + q]);
+            hv.push_back(c->var_off[v]); hb.push_back((uint32_t)c->boffsets[blk]); ha.push_back((uint32_t)c->diag_off[blk]); row_zero[blk] = 1; }
+        G.dense.n = (int64_t)hv.size();
+        HIPCHK(G.dense.data.upload(hd)); HIPCHK(G.dense.voff.upload(hv)); HIPCHK(G.dense.brow.upload(hb)); HIPCHK(G.dense.aoff.upload(ha));
+        npartials += (G.dense.n + 255) / 256 + 1;
+        all_owner = false;
+    }
     if (sparse) {
         for (int64_t r = 0; r < nb; ++r) if (row_zero[r]) { zero_off.push_back(segs[r]); zero_len.push_back((uint32_t)(segs[r + 1] - segs[r])); zero_b_off.push_back((uint32_t)c->boffsets[r]); zero_b_len.push_back((uint32_t)c->blocksizes[r]); }
     } else {
@@ -469,7 +485,7 @@ int select_elimination(nlls_ctx* c, int32_t flags) {
         std::unordered_map<int, int64_t> classcount; for (int64_t k = 0; k < nb; ++k) classcount[c->blocksizes[k]]++;
         int best = -1; int64_t bestn = 0; for (auto& kv : classcount) if (kv.second > bestn || (kv.second == bestn && kv.first < best)) { best = kv.first; bestn = kv.second; }
         std::vector<uint8_t> blocked(nb, 0);
-        std::vector<int64_t> order; for (int64_t k = 0; k < nb; ++k) if (c->blocksizes[k] == best) order.push_back(k);
+        std::vector<int64_t> order; for (int64_t k = 0; k < nb; ++k) if (c->blocksizes[k] == best && best <= NLLS_MAX_BLOCK_SZ) order.push_back(k);    // (a dynamic-size variable's block -- up to 4096 unknowns -- is never eliminated: the Schur kernels stage a block in LDS)
         std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return deg[a] < deg[b]; });
         for (int64_t v : order) { if (blocked[v]) continue; c->is_elim[v] = 1; c->nelim++;
             for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) blocked[c->it_rowval[q]] = 1;

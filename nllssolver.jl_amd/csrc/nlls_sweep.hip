@@ -573,7 +573,7 @@ int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost) {
     const size_t pslot = prof ? (size_t)(c->prof_count % (int64_t)(c->prof_ev.size() / 2)) : 0;
     if (prof) (void)hipEventRecord(c->prof_ev[2 * pslot], c->stream);
     for (const Group& G : c->groups) {
-        if (is_dyn_kind(G.res_kind)) { enqueue_dyn_gradhess(c, G, vars, pbase); enqueue_fixedcost(c, G, vars, pbase); continue; }   // (dense systems only: build_structure)
+        if (is_dyn_kind(G.res_kind)) { enqueue_dyn_gradhess(c, G, vars, pbase); enqueue_fixedcost(c, G, vars, pbase); continue; }   // (into the dense system, or the variable's diagonal block of a block-sparse one)
         switch (G.res_kind) {
 #define X(K) case K: launch_gh<K>(c, G, vars, pbase); break;
             NLLS_FOR_EACH_RES(X)
