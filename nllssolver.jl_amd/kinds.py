@@ -29,6 +29,7 @@ RES_DYN_LINEARSQ = 13     # test/nonsquaredcost.jl:16-26: X*w - y with a square 
 COST_DYN_LINEAR = 14      # test/nonsquaredcost.jl:39-46: non-squared cost y'w over a dynamic-size variable; data = y[n]
 RES_SCALE_MIX = 15        # s (w a + (1 - w) b) - y over a standalone ZeroToInfScalar and a standalone ZeroToOneScalar (src/variable.jl:18-32)
 DYN_KINDS = (RES_DYN_LINEAR, RES_DYN_NORM, RES_DYN_LINEARSQ, COST_DYN_LINEAR)
+ADAPTIVE_KINDS = (RES_ADAPTIVE_MEAN, RES_BA_SO3_ADAPTIVE)      # residual kinds whose slot 0 is the adaptive kernel's variable (src/residual.jl:46-47)
 
 # robust kernels: src/robust.jl:7-77
 ROBUST_NONE = 0

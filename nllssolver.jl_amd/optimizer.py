@@ -267,16 +267,48 @@ def optimizesingles(problem, options=None, indices=None, kind=None, dim=None, de
     dof = np.array([K.var_dof(problem.var_kind[i - 1], problem.var_dim[i - 1]) for i in indices], dtype=np.int64) if indices.size else np.zeros(0, np.int64)
     order = np.argsort(dof, kind="stable")
     ordered = indices[order]
-    level = problem.singles_levels(ordered)
     iters = np.zeros(indices.size, np.int64)
+    # What the one-thread-per-variable kernel takes: at most 6 degrees of freedom, fixed-size blocks, not the adaptive kernel's variable.  Anything else -- a
+    # DynamicVector of run-time length, the kernel variable -- is relaxed the way the reference relaxes EVERY listed variable (src/optimize.jl:183-205): the
+    # sub-problem of the cost blocks that depend on it, only that variable free, through the ordinary device path (a univariate dense system).  The listed
+    # order is kept: runs of kernel-sized variables go in launches of independent sets, a wide variable in between is a sub-problem of its own.
+    gl = list(problem.costs.values())
+    adaptive_first = {gi for gi, g in enumerate(gl) if g.res_kind in K.ADAPTIVE_KINDS}
+    def wide(pos):
+        v = ordered[pos]
+        if dof[order[pos]] > 6 or problem.var_kind[v - 1] == K.VAR_DYNAMIC:
+            return True
+        return any(np.any(gl[gi].arrays()[0][:, 0] == v) for gi in adaptive_first)
+    is_wide = np.array([wide(q) for q in range(ordered.size)], bool) if ordered.size else np.zeros(0, bool)
     ls = makesymmvls(problem, np.ones(problem.nvariables, bool), 0, device)
     try:
-        for lv in range(int(level.max()) + 1 if level.size else 0):
-            pick = np.nonzero(level == lv)[0]
-            cptr, cgroup, cindex, cslot = problem.costlists(ordered[pick])
-            it = ls.ctx.optimize_singles(ordered[pick], cptr, cgroup, cindex, cslot, options.maxiters, options.maxfails,
-                                         options.reldcost, options.absdcost, options.dstep, iterator=int(options.iterator))
-            iters[order[pick]] = it
+        q = 0
+        while q < ordered.size:
+            if is_wide[q]:
+                v = int(ordered[q])
+                cptr, cgroup, cindex, _ = problem.costlists(np.array([v]), check=False)
+                from .problem import NLLSProblem
+                sub = NLLSProblem(); sub.copy_variables_from(problem, ls.variables(VARS_CURRENT))
+                for gi in sorted(set(cgroup.tolist())):
+                    vi, da = gl[gi].arrays(); sel = cindex[cgroup == gi]
+                    sub.addcosts(gl[gi].res_kind, vi[sel], da[sel], gl[gi].robust)
+                unfixed = np.zeros(problem.nvariables, bool); unfixed[v - 1] = True
+                res = optimize(sub, options, unfixed, device=device)
+                ls.ctx.set_variables(sub.variables, VARS_CURRENT)
+                iters[order[q]] = res.niterations
+                q += 1
+                continue
+            r = q
+            while r < ordered.size and not is_wide[r]:
+                r += 1
+            run = ordered[q:r]; level = problem.singles_levels(run)
+            for lv in range(int(level.max()) + 1 if level.size else 0):
+                pick = np.nonzero(level == lv)[0]
+                cptr, cgroup, cindex, cslot = problem.costlists(run[pick])
+                it = ls.ctx.optimize_singles(run[pick], cptr, cgroup, cindex, cslot, options.maxiters, options.maxfails,
+                                             options.reldcost, options.absdcost, options.dstep, iterator=int(options.iterator))
+                iters[order[q + pick]] = it
+            q = r
         problem.variables[:] = ls.variables(VARS_CURRENT)
     finally:
         ls.close()

@@ -85,6 +85,13 @@ class NLLSProblem:
         self._invalidate()
         return first
 
+    def copy_variables_from(self, other, values=None):
+        """The variables of `other` (kinds, sizes, and their values -- or the packed `values`): the start of a sub-problem over the same variables
+        (subproblem(problem, ...), src/problem.jl:73-109, keeps the variable vector and selects costs)."""
+        self._kind = list(other._kind); self._dim = list(other._dim)
+        self._chunks = [np.array(other.variables if values is None else values, dtype=np.float64)]
+        self._invalidate()
+
     def _invalidate(self):
         self._packed = None
         self._gpu = None

@@ -402,6 +402,40 @@ def test_optimizesingles_every_iterator(iterator):
     assert np.max(np.abs(p.variables - expect)) < (1e-6 if iterator == "gradientdescent" else 1e-7)
 
 
+def test_optimizesingles_of_wide_variables():
+    """optimizesingles! takes ANY variable (src/optimize.jl:60-76: the sub-problem of the blocks that depend on it, src/optimize.jl:183-205).  The one-thread-per-
+    variable kernel takes up to 6 degrees of freedom and fixed-size blocks; a DynamicVector of run-time length and the adaptive kernel's own variable go through
+    the ordinary device path on their sub-problem instead (round 3 declined them) -- in the listed order, between the launches of the kernel-sized ones.  Against
+    the oracle's per-variable loop."""
+    rng = np.random.default_rng(3)
+    def mk():
+        r = np.random.default_rng(5)
+        p = N.NLLSProblem()
+        a = p.addvariable(r.standard_normal(3)); X3 = r.standard_normal((3, 3)); y3 = r.standard_normal(3)
+        p.addcosts(K.RES_LINEAR3, [[a]], np.concatenate([y3, X3.ravel(order="F")])[None, :])
+        for n in (40, 75):
+            v = p.addvariable(0.2 * r.standard_normal(n), K.VAR_DYNAMIC); X = r.standard_normal(n); X /= np.linalg.norm(X)
+            p.addcosts(K.RES_DYN_LINEAR, [[v]], np.concatenate([[1.0], X])[None, :]); p.addcosts(K.RES_DYN_NORM, [[v]], np.zeros((1, 0)))
+        return p
+    p = mk(); allv = np.arange(1, p.nvariables + 1)
+    expect = _oracle_optimizesingles(mk(), allv)
+    iters = N.optimizesingles(p, N.NLLSOptions(), indices=allv)
+    assert np.all(iters >= 1) and np.allclose(p.variables, expect, rtol=1e-7, atol=1e-9), np.max(np.abs(p.variables - expect))
+    # the adaptive kernel's variable on its own (test/adaptivecost.jl's problem shape: one kernel variable, scalar means)
+    def mk2():
+        r = np.random.default_rng(9)
+        q = N.NLLSProblem(); q.addvariable(contaminated_gaussian(1.0, 5.0, 0.7), K.VAR_CONTAMINATED_GAUSSIAN)
+        means = [q.addvariable(np.array([0.1 * r.standard_normal()])) for _ in range(4)]
+        for m in means:
+            y = np.where(r.random(60) < 0.8, r.standard_normal(60), 6.0 * r.standard_normal(60))
+            q.addcosts(K.RES_ADAPTIVE_MEAN, np.stack([np.ones(60, np.int64), np.full(60, m)], axis=1), y[:, None])
+        return q
+    q = mk2()
+    expect2 = _oracle_optimizesingles(mk2(), np.array([1]), maxiters=15)
+    N.optimizesingles(q, N.NLLSOptions(maxiters=15), indices=np.array([1]))
+    assert np.allclose(q.variables, expect2, rtol=1e-6, atol=1e-9), (q.variables[:3], expect2[:3])
+
+
 def test_optimizesingles_colisted_variables_are_relaxed_in_order():
     """Cameras AND points listed together: every cost block then holds two listed variables, and the reference relaxes them one after
     the other in order of variable size (src/optimize.jl:67,183-205) -- all points first, each camera then sees the moved points.
