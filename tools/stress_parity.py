@@ -13,7 +13,24 @@ fails = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
     try:
-        mode = seed % 7           # (round 4: 5 = camera chains with SHUFFLED labels -- the reduced system is re-ordered at upload; 6 = 2-D camera grids, some shuffled: windowed dense solve)
+        mode = seed % 8           # (round 4: 5 = camera chains with SHUFFLED labels -- the reduced system is re-ordered at upload; 6 = 2-D camera grids, some shuffled: windowed dense /
+                                  #  tile-sparse solve; 7 = scattered cameras, loop closures, overview cameras, larger grids: the tile-sparse solver (nested dissection at upload))
+        if mode == 7:
+            kind = int(rng.integers(0, 3)); robust = [None, N.HuberKernel(float(rng.uniform(0.01, 0.1))), N.GemanMcclureKernel(float(rng.uniform(0.05, 0.2)))][kind]
+            shape = int(rng.integers(0, 4))
+            if shape == 3:
+                gw = int(rng.integers(20, 46)); gh = int(rng.integers(20, 46))
+                p = synthetic.create_grid_ba_problem(gw, gh, int(rng.integers(2, 5)), seed=seed, robust=robust, outlier_frac=0.05 if robust else 0.0, outlier_sigma=0.05, noise=1e-3); ncam = gw * gh
+            else:
+                ncam = int(rng.integers(300, 1500)); npts = int(rng.integers(5, 9)) * ncam
+                p = synthetic.create_scattered_ba_problem(ncam, npts, int(rng.integers(4, 8)), seed=seed, robust=robust, outlier_frac=0.05 if robust else 0.0, outlier_sigma=0.05, noise=1e-3,
+                                                          loop=shape == 1, overview=int(rng.integers(1, 7)) if shape == 2 else 0)
+            if rng.random() < 0.5: p = synthetic.shuffle_camera_labels(p, ncam, seed)
+            p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
+            flags = [0, 0, 0, _capi.FLAG_NO_TILE_SPARSE, _capi.FLAG_FORCE_ATOMIC][int(rng.integers(0, 5))]
+            info = check_problem(p, flags=flags, lam_scale=[1e-4, 1e-3, 1e-1][kind])
+            modes_seen = globals().setdefault("modes_seen", {}); modes_seen[int(info.solve_mode)] = modes_seen.get(int(info.solve_mode), 0) + 1
+            continue
         if mode == 3:            # SO(3) cameras, pinhole, optionally the adaptive kernel as a border variable (BASELINE config 5 kinds)
             ncam = int(rng.integers(6, 300)); npts = int(rng.integers(60, 6000)); prop = max(float(rng.uniform(0.02, 0.5)), 4.0 / ncam)
             adaptive = bool(rng.integers(0, 2))
@@ -30,7 +47,7 @@ for seed in range(lo, hi):
             p = synthetic.create_grid_ba_problem(gw, gh, ppc, seed=seed, robust=robust, outlier_frac=0.05 if robust else 0.0, outlier_sigma=0.05, noise=1e-3)
             if rng.random() < 0.5: p = synthetic.shuffle_camera_labels(p, gw * gh, seed)
             p = synthetic.perturb_ba_problem(p, 1e-3, 1e-3)
-            flags = [0, 0, _capi.FLAG_NO_REORDER, _capi.FLAG_FORCE_ATOMIC][int(rng.integers(0, 4))]
+            flags = [0, 0, _capi.FLAG_NO_REORDER, _capi.FLAG_FORCE_ATOMIC, _capi.FLAG_NO_TILE_SPARSE][int(rng.integers(0, 5))]
             check_problem(p, flags=flags, lam_scale=[1e-4, 1e-3, 1e-1][kind])
             continue
         if mode == 0:            # generic small shapes, all flags
@@ -64,5 +81,5 @@ for seed in range(lo, hi):
         pass
     if (seed - lo) % 20 == 19:
         print(f"... {seed - lo + 1} cases, {fails} failures", flush=True)
-print(f"{hi - lo} cases, {fails} failures")
+print(f"{hi - lo} cases, {fails} failures" + (f"; solve modes of the mode-7 cases: {dict(sorted(globals().get('modes_seen', {}).items()))}" if globals().get("modes_seen") else ""))
 sys.exit(1 if fails else 0)
