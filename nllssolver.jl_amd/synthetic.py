@@ -180,6 +180,14 @@ def scattered_visibility(ncameras, nlandmarks, nviews, seed, loop=False, overvie
     from scipy.spatial import cKDTree
     _, nn = cKDTree(cpos).query(lpos, k=nviews)
     cam = nn.ravel() + 1; lm = np.repeat(np.arange(nlandmarks), nviews) + 1
+    # (a camera that is among the nearest of NO landmark would be a variable without a cost block -- a zero diagonal block: it sees its own three nearest landmarks)
+    lonely = np.flatnonzero(np.bincount(cam - 1, minlength=ncameras) < 3)
+    if lonely.size:
+        _, nl = cKDTree(lpos).query(cpos[lonely], k=3)
+        have = set(zip(cam.tolist(), lm.tolist()))
+        extra = [(int(c) + 1, int(l) + 1) for c, row in zip(lonely, np.atleast_2d(nl)) for l in row if (int(c) + 1, int(l) + 1) not in have]
+        if extra:
+            cam = np.concatenate([cam, [e[0] for e in extra]]); lm = np.concatenate([lm, [e[1] for e in extra]])
     for h in range(overview):                      # OVERVIEW cameras (the last `overview` ones): each also sees a random `overview_frac` of all landmarks
         seen = np.flatnonzero(rng.random(nlandmarks) < overview_frac) + 1
         c = ncameras - overview + h + 1
