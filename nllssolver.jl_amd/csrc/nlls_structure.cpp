@@ -485,7 +485,14 @@ int select_elimination(nlls_ctx* c, int32_t flags) {
         std::unordered_map<int, int64_t> classcount; for (int64_t k = 0; k < nb; ++k) classcount[c->blocksizes[k]]++;
         int best = -1; int64_t bestn = 0; for (auto& kv : classcount) if (kv.second > bestn || (kv.second == bestn && kv.first < best)) { best = kv.first; bestn = kv.second; }
         std::vector<uint8_t> blocked(nb, 0);
-        std::vector<int64_t> order; for (int64_t k = 0; k < nb; ++k) if (c->blocksizes[k] == best && best <= NLLS_MAX_BLOCK_SZ) order.push_back(k);    // (a dynamic-size variable's block -- up to 4096 unknowns -- is never eliminated: the Schur kernels stage a block in LDS)
+        // A block whose neighbours do not fit the LDS-staged elimination (a landmark seen by more than ~330 six-dof cameras: 150 KB of a CU's 160) is NOT a
+        // candidate: it stays in the reduced system -- as a border block when it couples to a quarter of it (build_schur), a hub of the tile-sparse solver, or a
+        // plain block of the dense one -- instead of taking the whole problem off the Schur path (rounds 1-3: NLLS_SUB_SCHUR_SHAPE, retry without elimination).
+        auto fits_lds = [&](int64_t v) { size_t nd = 0;
+            for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) if (c->it_rowval[q] != v) nd += (size_t)c->blocksizes[c->it_rowval[q]];
+            for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) if (trow[q] != v) nd += (size_t)c->blocksizes[trow[q]];
+            const size_t dv = (size_t)best; return sizeof(double) * (dv * dv + dv * nd + dv * (nd + 1)) + 28 * nd + 16 <= (size_t)150 * 1024; };
+        std::vector<int64_t> order; for (int64_t k = 0; k < nb; ++k) if (c->blocksizes[k] == best && best <= NLLS_MAX_BLOCK_SZ && fits_lds(k)) order.push_back(k);    // (a dynamic-size variable's block -- up to 4096 unknowns -- is never eliminated: the Schur kernels stage a block in LDS)
         std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return deg[a] < deg[b]; });
         for (int64_t v : order) { if (blocked[v]) continue; c->is_elim[v] = 1; c->nelim++;
             for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) blocked[c->it_rowval[q]] = 1;

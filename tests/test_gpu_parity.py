@@ -118,6 +118,26 @@ def test_wide_visibility_keeps_the_schur_path():
     assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
 
 
+@pytest.mark.parametrize("nwide,kwide", [(2, 420), (1, 600)])
+def test_landmarks_seen_by_hundreds_of_cameras_stay_out_of_the_eliminated_set(nwide, kwide):
+    """A landmark seen by more cameras than the LDS-staged elimination can stage (~330 six-dof neighbours: 150 KB of a CU's LDS) used to take the WHOLE problem off
+    the Schur path (NLLS_SUB_SCHUR_SHAPE: retry without elimination, i.e. the full system densely -- a decline at any real size).  Now such a block is simply not
+    eliminated: it stays in the reduced system (a border block when it couples to a quarter of the cameras, else a hub of the tile-sparse solver / a block of the
+    dense one), every other landmark is eliminated as before.  600 cameras, 4000 landmarks, one or two of them seen by 420 / by all cameras: structure, sweep,
+    damped solve, retraction and five LM iterations against the oracle (whose LDL' takes any sparsity: src/linearsolver.jl:28-32)."""
+    ncam, npts = 600, 4000
+    def mk():
+        p = synthetic.create_ba_problem(ncam, npts, 8.0 / ncam, seed=17, robust=N.HuberKernel(0.05), outlier_frac=0.02, outlier_sigma=0.05)
+        wide = {int(l): kwide for l in np.random.default_rng(3).choice(np.arange(1, npts + 1), size=nwide, replace=False)}
+        return synthetic.perturb_ba_problem(synthetic.widen_visibility(p, ncam, wide), 1e-3, 1e-3)
+    p = mk()
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
+    assert info.nschur_blocks == npts - nwide and info.nreduced_dof == 6 * ncam + 3 * nwide, (info.nschur_blocks, info.nreduced_dof)
+    op = oracle_problem(mk()); ro = op.optimize(iterator=1, maxiters=5)
+    rg = N.optimize(p, N.NLLSOptions(maxiters=5))
+    assert np.isclose(rg.bestcost, ro.bestcost, rtol=1e-7), (rg.bestcost, ro.bestcost)
+
+
 def _upload_info(p, flags=0):
     ctx = _capi.Context()
     info = ctx.upload(p.var_kind, p.var_dim, np.arange(1, p.nvariables + 1, dtype=np.uint64), p.groups(), flags)
