@@ -14,9 +14,16 @@ for seed in range(lo, hi):
     robust = bool(rng.integers(0, 2))
     kw = dict(robust=N.HuberKernel(float(rng.uniform(0.01, 0.05))), outlier_frac=0.1, outlier_sigma=0.2) if robust else {}
     mk = lambda: synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed, **kw), 1e-3, 1e-3)
+    if seed >= 10000:        # (round 4) camera graphs that are no band -- grids, scattered cameras, loops, overview cameras: the tile-sparse reduced solver inside the whole loop
+        shape = int(rng.integers(0, 4)); gw = int(rng.integers(22, 40)); gh = int(rng.integers(22, 40)); nc = int(rng.integers(500, 1400)); nv = int(rng.integers(5, 8)); ov = int(rng.integers(1, 5))
+        ncam, npts, prop = (gw * gh, gw * gh * 3, 0.0) if shape == 3 else (nc, 6 * nc, 0.0)
+        kw2 = dict(kw); kw2.setdefault("noise", 0.0)
+        if shape == 3: mk = lambda: synthetic.perturb_ba_problem(synthetic.create_grid_ba_problem(gw, gh, 3, seed=seed, **kw2), 1e-3, 1e-3)
+        else: mk = lambda: synthetic.perturb_ba_problem(synthetic.create_scattered_ba_problem(nc, 6 * nc, nv, seed=seed, loop=shape == 1, overview=ov if shape == 2 else 0, **kw2), 1e-3, 1e-3)
     try:
         p = mk(); op = oracle_problem(mk())
-        res = N.optimize(p, N.NLLSOptions(maxiters=60)); ores = op.optimize(maxiters=60)
+        mi = 60 if seed < 10000 else 40
+        res = N.optimize(p, N.NLLSOptions(maxiters=mi)); ores = op.optimize(maxiters=mi)
         if not robust: assert res.bestcost < 1e-15 * p.ncosts() and ores.bestcost < 1e-15 * p.ncosts(), (res.bestcost, ores.bestcost)
         else:
             # a run that stops at maxiters (termination bit 256) has not converged: its cost still moves in the 6th digit from one iteration to
