@@ -136,7 +136,9 @@ typedef struct nlls_info {
 #define NLLS_FLAG_FORCE_SPARSE   0x4  /* makesymmvls(...; formarginalization) style: BSM regardless   */
 #define NLLS_FLAG_NO_BAND        0x8  /* never use the bordered-band solver (dense MFMA path instead)  */
 #define NLLS_FLAG_NO_TWIST       0x10 /* band solver: factor from the top only (one workgroup), testing */
-#define NLLS_FLAG_DETERMINISTIC  0x40 /* reduced system assembled without atomics (slab per supernode + ordered gather): x is bit-reproducible   */
+#define NLLS_FLAG_DETERMINISTIC  0x40 /* reduced system assembled without atomics (slab per supernode + ordered gather): x is bit-reproducible.  Takes effect where the
+                                         reduced system is a band solved by block cyclic reduction (solve_mode 2, one rank, every eliminated block on the fast path);
+                                         the dense and tile-sparse solvers assemble with atomic adds -- x reproducible to rounding -- and ignore it            */
 #define NLLS_FLAG_PRESHARDED     0x80 /* under nlls_set_shard(rank, nranks > 1): the caller uploads ONLY this rank's share -- every uploaded cost block is this rank's,
                                          the eliminated variables present are its own, the other (reduced) variables are the same, in the same order, on every
                                          rank (bundle adjustment: all cameras + this rank's points).  Nothing is partitioned by the library; variable indices are

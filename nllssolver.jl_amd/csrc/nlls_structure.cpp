@@ -1027,9 +1027,11 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                     // (what the device holds decides: the tiles twice -- S and W -- + slots per tile; a system whose tiles do not fit falls back to the dense / windowed solver,
                     //  which then declines by its own size check)
                     size_t mfree = 0, mtotal = 0; const size_t want = sizeof(double) * (2 * ((size_t)sym.ntiles_lower * TSP_TE + (size_t)sym.nt * TSP_STRIP) + 3 * (size_t)sym.nt * TSP_TE + (size_t)n + 4096);
-                    const bool fits = hipMemGetInfo(&mfree, &mtotal) != hipSuccess || want + ((size_t)2 << 30) <= mfree;
+                    // (under sharding every rank must arrive at the SAME solver -- the layout of the summed [S | s] depends on it --, so nothing rank-local may decide:
+                    //  no look at this device's free memory, and an allocation that fails is an error of the upload, not a quiet change of solver)
+                    const bool fits = c->nranks > 1 || hipMemGetInfo(&mfree, &mtotal) != hipSuccess || want + ((size_t)2 << 30) <= mfree;
                     std::string e; const int rc = fits ? c->tsp.build(sym, noff, ndof, (int)n, &e) : NLLS_ERR_UNSUPPORTED;
-                    if (rc == NLLS_ERR_HIP) { (void)hipGetLastError(); c->tsp.release(); }        // an allocation that failed after all: the other solvers
+                    if (rc == NLLS_ERR_HIP && c->nranks == 1) { (void)hipGetLastError(); c->tsp.release(); }        // an allocation that failed after all: the other solvers
                     else if (rc != NLLS_OK && rc != NLLS_ERR_UNSUPPORTED) return fail(c, rc, e.c_str());
                 }
             }
