@@ -110,7 +110,7 @@ bool tsp_symbolic(const std::vector<std::vector<int32_t>>& adj, const std::vecto
     // poorly filled tile move up into the first tile of the separator it hangs under (they are eliminated with that front instead: any order is a valid
     // one, and a tile shared by a separator and the tails of its own parts chains nothing that was not chained already).  Without this 30 % of all tile rows
     // are padding -- 2.9 x the tile products of full tiles.
-    static const int carry_max = [] { const char* e = getenv("NLLS_TSP_CARRY"); return e ? atoi(e) : 80; }();      // rows of a last tile up to which it is carried up (0: never)
+    const int carry_max = [] { const char* e = getenv("NLLS_TSP_CARRY"); return e ? atoi(e) : 80; }();      // rows of a last tile up to which it is carried up (0: never)
     std::vector<std::vector<int32_t>> carried(D.supernodes.size());
     for (size_t si = 0; si < D.supernodes.size(); ++si) {
         std::vector<int32_t> sn = std::move(carried[si]); sn.insert(sn.end(), D.supernodes[si].begin(), D.supernodes[si].end());

@@ -382,8 +382,10 @@ int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off
     std::vector<std::vector<int32_t>> by_level(sym.nlevels), rowlist(nt);
     for (int k = 0; k < nt; ++k) { by_level[sym.level[k]].push_back(k); for (int32_t i : sym.cstruct[k]) rowlist[i].push_back(k); }
     products = 0;
-    static const int force_scheme = [] { const char* e = getenv("NLLS_TSP_SCHEME"); return e ? atoi(e) : 0; }();      // A/B: 1 / 2 / 3 for every level
-    static const int slots = [] { const char* e = getenv("NLLS_TSP_SLOTS"); return e ? atoi(e) : 256; }();             // workgroups of one round of the chip (a panel workgroup fills a CU's LDS)
+    // (A/B switches, read at every build: a context's upload decides, not the process)
+    const int force_scheme = [] { const char* e = getenv("NLLS_TSP_SCHEME"); return e ? atoi(e) : 0; }();      // 1 / 2 / 3 for every level
+    const int slots = [] { const char* e = getenv("NLLS_TSP_SLOTS"); return e ? atoi(e) : 256; }();             // workgroups of one round of the chip (a panel workgroup fills a CU's LDS)
+    quad_max = [] { const char* e = getenv("NLLS_TSP_QUAD_MAX"); return e ? atoi(e) : 160; }();                 // target tiles of a level up to which a workgroup takes a quarter tile
     for (int lv = 0; lv < sym.nlevels; ++lv) {
         TspLevel& L = levels[lv]; L.panel0 = pj.size(); L.upd0 = uj.size(); L.bwd0 = bj.size(); L.trsm0 = tj.size();
         std::map<std::pair<int32_t, int32_t>, std::vector<TspCon>> tgt; std::map<int32_t, std::vector<TspCon>> rhs;
@@ -407,7 +409,7 @@ int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off
         // keeps a CU busy ~14 us, so with P products in the level a workgroup should not hold more than ~P / 256 of them; longer lists are cut and their pieces add
         // atomically (the elimination's flush into S is atomic as well: x is reproducible to rounding, not to the bit)
         int64_t P = 0; for (auto& kv : tgt) P += (int64_t)kv.second.size();
-        static const int cap_env = [] { const char* e = getenv("NLLS_TSP_CAP"); return e ? atoi(e) : 0; }();
+        const int cap_env = [] { const char* e = getenv("NLLS_TSP_CAP"); return e ? atoi(e) : 0; }();
         const int64_t cap = cap_env > 0 ? cap_env : std::max<int64_t>(2, (P + 255) / 256);
         std::vector<std::pair<int64_t, std::pair<int32_t, int32_t>>> order;
         for (auto& kv : tgt) order.push_back({-(int64_t)kv.second.size(), kv.first});
@@ -442,7 +444,6 @@ int TspSolver::enqueue(hipStream_t st, double* S, double* s, int* status, double
     double* W = ws.p + oW; double* LiD = ws.p + oLiD; double* Dfac = ws.p + oDfac; double* Dinv = ws.p + oDinv; double* xt = ws.p + oxt; double* acc = ws.p + oacc; double* diag0 = ws.p + odg; unsigned* mask = reinterpret_cast<unsigned*>(ws.p + omask); unsigned* umask = chunk_masks ? mask : nullptr;
     hipLaunchKernelGGL(tsp_begin_kernel, dim3((unsigned)((std::max<int64_t>(npos + npad_entries, nslots) + 255) / 256)), dim3(256), 0, st, S, (const double*)s, (const int32_t*)d_ipos.p, (const int64_t*)d_padpos.p, npad_entries, npos, strip0, acc, diag0, (const int32_t*)(d_map.p + n), nt, mask, nslots);
     size_t pl = 0;
-    static const int quad_max = [] { const char* e = getenv("NLLS_TSP_QUAD_MAX"); return e ? atoi(e) : 160; }();      // target tiles of a level up to which a workgroup takes a quarter tile
     for (const TspLevel& L : levels) {
         launch_tsp_panel(st, S, W, LiD, Dfac, d_panel.p + L.panel0, L.npanel, status, L.scheme == 2 ? 2 : 1, diag0, pivot_floor, umask);
         if (L.scheme == 3) {

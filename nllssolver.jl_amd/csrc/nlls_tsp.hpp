@@ -56,6 +56,7 @@ struct TspSolver {
     DevBuf<int64_t> d_padpos;                      // offsets (in S) of the padding's diagonal entries
     DevBuf<double> ws;                             // W tiles + strips (as S) | LiD | Dfac | Dinv | xt | acc
     size_t oW = 0, oLiD = 0, oDfac = 0, oDinv = 0, oxt = 0, oacc = 0, odg = 0, omask = 0;
+    int quad_max = 160;                            // NLLS_TSP_QUAD_MAX (A/B): target tiles of a level up to which an update workgroup takes a quarter tile
     bool chunk_masks = true;                       // NLLS_TSP_NO_MASKS=1 (A/B): every tile product in full
     int64_t npad_entries = 0;
     int launches = 0; int64_t products = 0;

@@ -575,6 +575,26 @@ def test_randomized_tiny_dense_ba(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"NLLS_TSP_NO_MASKS": "1"}, {"NLLS_TSP_CARRY": "0"}, {"NLLS_TSP_SCHEME": "1"}, {"NLLS_TSP_SCHEME": "2"}, {"NLLS_TSP_SCHEME": "3"}, {"NLLS_TSP_CAP": "1"},
+                                 {"NLLS_TSP_CAP": "64"}, {"NLLS_TSP_QUAD_MAX": "0"}, {"NLLS_TSP_QUAD_MAX": "100000"}, {"NLLS_TSP_SLOTS": "64"}])
+def test_tile_sparse_ab_switches_still_match_the_oracle(env, monkeypatch):
+    """The tile-sparse solver's A/B switches (every tile product in full, no tails carried up, each of the three panel schemes at every level,
+    update jobs never / always cut into atomic pieces, whole-tile / quarter-tile update jobs everywhere, a smaller chip) select launch shapes the default run of
+    one problem does not reach: the same parity -- a shuffled 26 x 26 camera grid, sweep, damped solve, retraction against the oracle."""
+    for k, v in env.items(): monkeypatch.setenv(k, v)
+    p = synthetic.perturb_ba_problem(synthetic.shuffle_camera_labels(synthetic.create_grid_ba_problem(26, 26, 4, seed=8, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05,
+                                                                                                       noise=1e-3), 676, 4), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4)
+    assert info.solve_mode == 3
+    _, st = _upload_info(p)                                   # (the switches are read at every upload: what is visible from outside must have moved)
+    for k in env: monkeypatch.delenv(k)
+    _, st0 = _upload_info(p)
+    if "NLLS_TSP_CARRY" in env: assert st["tsp_tiles"] > st0["tsp_tiles"], (st, st0)
+    if env.get("NLLS_TSP_SCHEME") == "3": assert st["tsp_launches"] > st0["tsp_launches"], (st, st0)
+    if env.get("NLLS_TSP_SCHEME") == "1": assert st["tsp_launches"] < st0["tsp_launches"], (st, st0)
+
+
+@pytest.mark.gpu
 def test_three_slot_sweep_in_one_launch_per_role(monkeypatch):
     """NLLS_SWEEP_SPLIT3=1: the adaptive-kernel bundle adjustment's accumulate sweep as round 2 launched it (one launch per role) -- the same sums."""
     monkeypatch.setenv("NLLS_SWEEP_SPLIT3", "1")
