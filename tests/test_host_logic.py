@@ -229,3 +229,45 @@ def test_nd_tiles_takes_hub_cameras_out_of_the_dissection():
         for i in range(k + 1, nt):
             if np.abs(Lf[128 * i:128 * i + 128, 128 * k:128 * k + 128]).max() > 1e-13:
                 assert i in struct[k], (i, k)
+
+
+def test_nd_tiles_on_degenerate_graphs():
+    """The symbolic phase on graphs a dissection has nothing to cut in, or too much: no edges at all, a path, a star, one clique, several components of very
+    different sizes, two nodes, nodes of 128 unknowns each, a random sparse graph with isolated nodes -- every node placed exactly once, the tree a tree, the
+    pattern closed under elimination (struct[k] without its first entry lies inside struct of that entry: the defining property of a symbolic factorisation)."""
+    rng = np.random.default_rng(0)
+    def csr(n, edges):
+        lists = [set() for _ in range(n)]
+        for a, b in edges:
+            if a != b: lists[a].add(b); lists[b].add(a)
+        ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists])
+        return ptr, np.array([w for l in lists for w in sorted(l)], np.int32)
+    cases = []
+    cases.append((300, [], 6))                                                        # no edges
+    cases.append((500, [(i, i + 1) for i in range(499)], 6))                          # a path
+    cases.append((400, [(0, i) for i in range(1, 400)], 6))                           # a star (its centre is a hub)
+    cases.append((90, [(i, j) for i in range(90) for j in range(i)], 6))              # one clique: a dense front
+    comp = [(i, i + 1) for i in range(0, 700)] + [(800 + i, 800 + j) for i in range(40) for j in range(i)] + [(900, 901)]
+    cases.append((1000, comp, 6))                                                     # components: a long path, a clique, a pair, isolated nodes
+    cases.append((2, [(0, 1)], 6))
+    cases.append((40, [(i, (i + 1) % 40) for i in range(40)], 128))                   # a ring of nodes that fill a tile each
+    e = rng.integers(0, 2000, size=(5000, 2)); cases.append((2000, [tuple(x) for x in e.tolist()], 3))
+    for n, edges, d in cases:
+        ptr, adj = csr(n, edges); dof = np.full(n, d, np.int32)
+        nt, tile_of, row, parent, level, colptr, rows = _nd_tiles(ptr, adj, dof)
+        pos = tile_of.astype(np.int64) * 128 + row
+        used = np.zeros(nt * 128, bool)
+        for v in range(n):
+            assert 0 <= tile_of[v] < nt and row[v] + d <= 128 and not used[pos[v]:pos[v] + d].any(); used[pos[v]:pos[v] + d] = True
+        struct = [rows[colptr[k]:colptr[k + 1]].tolist() for k in range(nt)]
+        for k in range(nt):
+            assert struct[k] == sorted(set(struct[k])) and all(i > k for i in struct[k])
+            assert parent[k] == (struct[k][0] if struct[k] else -1)
+            if struct[k]:
+                assert set(struct[k][1:]) <= set(struct[struct[k][0]]), (n, k)          # closed under elimination
+                assert level[struct[k][0]] > level[k]
+        # every edge of the graph lies inside the pattern
+        for v in range(n):
+            for w in adj[ptr[v]:ptr[v + 1]]:
+                a, b = sorted((int(tile_of[v]), int(tile_of[w])))
+                assert a == b or b in struct[a], (n, v, w)
