@@ -182,7 +182,8 @@ int  nlls_rcm_order(int32_t n, const int64_t* adjptr, const int32_t* adj, int32_
 /* host-only helper (no context, no device): the symbolic phase of the tile-sparse reduced solver (solve_mode 3) -- nested dissection of the reduced
  * blocks' graph by breadth-first level structures, every part and separator packed into tiles of at most 128 unknowns, then the elimination tree and
  * the fill of the TILE graph.  n nodes with dof[i] unknowns each (CSR adjacency as for nlls_rcm_order) followed by nborder border nodes that couple
- * to everything (dof has n + nborder entries).  Out: tile_of / row_in_tile [n + nborder] (a node's tile, in elimination order, and its first row in
+ * to everything (dof has n + nborder entries; nodes coupled to an eighth of all nodes or more are treated the same way: ordered last, their tiles neighbours of
+ * every tile).  Out: tile_of / row_in_tile [n + nborder] (a node's tile, in elimination order, and its first row in
  * it); parent / level [max_tiles] (elimination tree over the tiles, -1 = root; tiles of one level are factored in one launch); the lower triangle of
  * the tile pattern of L as CSR (colptr [max_tiles + 1], rows [max_rows]: tiles i > k of column k, ascending).  Returns the number of tiles, or
  * NLLS_ERR_INVALID_ARG (malformed graph, a node wider than 128, outputs too small).  The reference's counterpart is ldl_analyze
