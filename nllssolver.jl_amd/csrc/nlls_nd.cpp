@@ -19,6 +19,7 @@ struct Dissector {
     const std::vector<std::vector<int32_t>>& adj; const std::vector<int32_t>& dof;
     std::vector<int32_t> stamp, lev, q;
     int32_t cur = 0;
+    int64_t leaf_dof = [] { const char* e = getenv("NLLS_TSP_LEAF"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 2 * TSP_TR); }();   // parts up to here are not cut further (A/B: NLLS_TSP_LEAF=<unknowns>)
     std::vector<std::vector<int32_t>> supernodes;      // in elimination order: parts before their separator
     std::vector<int32_t> parent;                       // the separator a part hangs under (-1: none)
     int32_t emit(std::vector<int32_t>&& nodes) { supernodes.push_back(std::move(nodes)); parent.push_back(-1); return (int32_t)supernodes.size() - 1; }
@@ -36,7 +37,7 @@ struct Dissector {
     std::vector<int32_t> run(std::vector<int32_t> nodes, int depth) {
         if (nodes.empty()) return {};
         const int64_t total = dofsum(nodes);
-        if (total <= 2 * TSP_TR || depth >= 64) return {emit(std::move(nodes))};     // one or two tiles: a chain of at most two steps either way
+        if (total <= leaf_dof || depth >= 64) return {emit(std::move(nodes))};     // one or two tiles: a chain of at most two steps either way
         const int32_t id = ++cur; for (int32_t v : nodes) stamp[v] = id;
         // connected components: independent subtrees, no separator between them
         {
