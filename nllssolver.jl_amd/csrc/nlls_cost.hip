@@ -370,7 +370,8 @@ static int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::str
 template <int KIND>
 static int launch_cost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase, const PostSolveArgs* post, bool* taken) {
     if (G.ncost > 0) {
-        int grid = (int)std::min<int64_t>((G.ncost + TPB - 1) / TPB, 2048);
+        static const int cost_grid_max = [] { const char* e = getenv("NLLS_COST_GRID_MAX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();   // (A/B: workgroups of the cost sweep)
+        int grid = (int)std::min<int64_t>((G.ncost + TPB - 1) / TPB, cost_grid_max);
         const bool shared = G.cost_list >= 0 && c->info.is_sparse;
         const double* data = shared ? G.lists[G.cost_list].data.p : G.data.p; const uint32_t* voff = shared ? G.lists[G.cost_list].voff.p : G.voff.p;
         if (post && taken && !*taken) {      // the first launch of the sweep takes the statistics roles along
