@@ -80,7 +80,7 @@ typedef struct nlls_ctx nlls_ctx;
                                        Dynamic kinds: every block of a group has the same n; the residual kinds take the robust kernels like any other residual
                                        (src/residual.jl:76-101), the non-squared cost kind none; the system may come out dense or block-sparse
                                        (src/linearsystem.jl:105-123 decides; round 4: block-sparse systems are taken too -- a dynamic variable's block
-                                       row holds its diagonal block only, it is never eliminated); unsharded only; nlls_res_ndata / nlls_res_nres
+                                       row holds its diagonal block only, it is never eliminated; under nlls_set_shard its blocks are owned round robin); nlls_res_ndata / nlls_res_nres
                                        return -1 where the count is n-dependent */
 #define NLLS_RES_DYN_LINEARSQ    13 /* DYNAMIC-size: LinearResidualDynamic X*w - y with a square X (n x n, column-major) over one NLLS_VAR_DYNAMIC
                                        variable of length n; data = (y[n], X[n*n]); nres = n; n <= 512              test/nonsquaredcost.jl:16-26 */

@@ -164,7 +164,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     }
     // (dynamic-size blocks in a BLOCK-SPARSE system -- src/autodiff.jl:96-121 with src/linearsystem.jl:105-121: their variable appears in no other kind of block,
     //  so its block row holds its diagonal block only; the blocks accumulate into it directly, below)
-    if (any_dyn && c->nranks > 1) return fail(c, NLLS_ERR_UNSUPPORTED, "dynamic-size residual blocks run unsharded");
+    // (under sharding a dynamic-size block -- no eliminated variable in it -- is owned like any other such cost block: round robin; its variable's row is a reduced
+    //  row, summed over ranks with the others)
     c->it_colptr.clear(); c->it_rowval.clear(); c->it_nzval.clear(); c->diag_off.assign(nb, -1);
     int64_t nnz_data = 0;
     if (sparse) {   // BlockSparseMatrix constructor, BlockSparseMatrix.jl:30-47 (0-based here)
@@ -423,6 +424,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
         std::vector<double> hd; std::vector<uint32_t> hv, hb, ha;
         for (int64_t k = 0; k < in.ncost; ++k) { const int64_t v = in.varind[k] - 1; if (!bi[v]) continue;
             const int64_t blk = (int64_t)bi[v] - 1;
+            row_zero[blk] = 1;                                   // (every rank zeroes the row: it is summed over ranks)
+            if (!mine[g][k]) continue;
             for (int q = 0; q < d.ndata; ++q) hd.push_back(in.data[k * d.ndata + q]);
             hv.push_back(c->var_off[v]); hb.push_back((uint32_t)c->boffsets[blk]); ha.push_back((uint32_t)c->diag_off[blk]); row_zero[blk] = 1; }
         G.dense.n = (int64_t)hv.size();

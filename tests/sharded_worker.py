@@ -47,6 +47,17 @@ def main():
     shuf = (lambda q: synthetic.shuffle_camera_labels(q, shape[0], seed)) if shuffled else (lambda q: q)
     mkp = lambda: synthetic.perturb_ba_problem(shuf(synthetic.create_ba_problem(*shape, seed=1 if config3 else seed, robust=N.HuberKernel(0.01 if config3 else 0.05),
                                                                                 outlier_frac=0.05, outlier_sigma=0.05)), 1e-3, 1e-3)
+    if 9000 <= seed < 10000:
+        # a bundle adjustment with three dynamic-size variables beside it (src/autodiff.jl:96-121): their cost blocks hold no eliminated variable -- owned round robin --
+        # and their diagonal blocks are reduced rows, summed over ranks like the cameras'
+        from nllssolver_jl_amd import kinds as K
+        def mkp():
+            q = synthetic.perturb_ba_problem(synthetic.create_ba_problem(40, 2000, 0.15, seed=seed, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+            r = np.random.default_rng(seed)
+            for n in (20, 70, 33):
+                v = q.addvariable(0.3 * r.standard_normal(n), K.VAR_DYNAMIC); X = r.standard_normal(n); X /= np.linalg.norm(X)
+                q.addcosts(K.RES_DYN_LINEAR, [[v]], np.concatenate([[1.0], X])[None, :]); q.addcosts(K.RES_DYN_NORM, [[v]], np.zeros((1, 0)))
+            return q
     if grid:
         mkp = lambda: synthetic.perturb_ba_problem(synthetic.shuffle_camera_labels(synthetic.create_grid_ba_problem(24, 24, 4, seed=3, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05,
                                                                                                                     noise=1e-3), 576, seed), 1e-3, 1e-3)

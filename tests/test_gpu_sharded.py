@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
                                                 (2, "gloo", -1), (3, "gloo", -1),
                                                 (2, "gloo", 3000), (3, "gloo", 3000), (2, "gloo", 5001), (3, "gloo", 5002),
                                                 (2, "gloo", 6001), (3, "gloo", 5102), (2, "gloo", 7001), (3, "gloo", 7001), (2, "gloo", 5201),
-                                                (2, "gloo", 8001), (3, "gloo", 5301)])
+                                                (2, "gloo", 8001), (3, "gloo", 5301), (2, "gloo", 9001), (3, "gloo", 9001)])
 def test_sharded_matches_unsharded(world, backend, seed):
     """(1, "nccl"): the local / reduce / finish route over RCCL with device buffers, one rank -- the plumbing bench.py --gpus N uses.
     seed 3000: BASELINE config 3 at full size (100 cameras x 10k points, ~100k residual blocks) against the CPU oracle: cost, gradient,
@@ -25,6 +25,7 @@ def test_sharded_matches_unsharded(world, backend, seed):
     seed 51xx: the same under NLLS_FLAG_PRESHARDED, where each rank sees only its own part of the camera graph (the union is taken collectively).
     seed 52xx: a pre-sharded upload whose reduced rows differ in layout between ranks (points listed before the cameras) is refused on every rank.
     seed 7001: a deadline (maxtime) only rank 0 crosses -- all ranks leave the loop in the same iteration (no rank left in a collective).
+    seed 9001: a bundle adjustment with three dynamic-size variables beside it (round 4: dynamic-size blocks in a block-sparse system, also under sharding).
     seed 8001 / 5301: a 24 x 24 camera grid with permuted labels -- the reduced system goes to the tile-sparse solver (solve_mode 3); the nested dissection at upload
     must give every rank the same tiles (5301: pre-sharded, from the union of the ranks' camera graphs).
     5000 <= seed < 6000: NLLS_FLAG_PRESHARDED -- every rank uploads only its own share (all cameras + its points), the reduced system's layout is agreed on
