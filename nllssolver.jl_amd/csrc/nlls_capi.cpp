@@ -330,6 +330,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     const int32_t status[1] = {(int32_t)ctx->h_scalars[10]};
+    ctx->comm_gathered = collective;
     if (collective) ctx->comm_agreed = ctx->h_scalars[11];      // the ranks' posted termination flags, combined by maximum in the same gather (nlls_comm_agreed_flag)
     ctx->status_known_zero = status[0] == 0;       // (nothing has touched the device's status word since: the next solve need not reset it)
     ctx->solved = true;

@@ -121,12 +121,14 @@ int nlls_comm_init_rccl(nlls_ctx* ctx, const void* id128) {
 }
 int nlls_comm_post_flag(nlls_ctx* ctx, double value) {
     if (!ctx || !(value >= 0.0)) return NLLS_ERR_INVALID_ARG;
-    ctx->comm_posted = value;
+    ctx->comm_posted = value; ctx->comm_gathered = false;      // (a new iteration: the answer must come from a trial that follows this post)
     return NLLS_OK;
 }
 int nlls_comm_agreed_flag(nlls_ctx* ctx, double local_value, double* out) {
     if (!ctx || !out) return NLLS_ERR_INVALID_ARG;
-    *out = ctx->reduce_fn ? ctx->comm_agreed : local_value;
+    // the agreed value only when the last trial really gathered it: with an all-reduce installed on a DENSE system (or before the first trial) nothing
+    // writes comm_agreed, and answering 0 would silently disable the caller's deadline (advisor, round 4)
+    *out = (ctx->reduce_fn && ctx->comm_gathered) ? ctx->comm_agreed : local_value;
     return NLLS_OK;
 }
 int nlls_comm_info(nlls_ctx* ctx, int64_t* out, int32_t n) {

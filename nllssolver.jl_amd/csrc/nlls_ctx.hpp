@@ -45,6 +45,38 @@ constexpr uint32_t OWN_KERNEL_FREE = 1u << 17;   // adaptive residual whose kern
 constexpr uint32_t OWN_COPY_SHIFT  = 18;         // which of the ACC_COPIES diagonal accumulators of its row the entry adds to
 constexpr uint32_t ACC_COPIES      = 4;          // (spreads the LDS atomics of a row's entries over distinct addresses)
 
+// ---- the folded accumulate sweep (round 5): every block evaluated ONCE -------------------------------------------
+// A group whose entry lists split into {one light-only list that holds every cost block, heavy-only lists} (bundle adjustment: point rows
+// light, camera rows heavy, the adaptive kernel's one long row heavy) used to evaluate each block once per ROLE -- three times at BASELINE
+// config 5.  Folded, the light pass alone evaluates the block and also forms the block's contributions to its heavy rows (diagonal block, b,
+// and the row's off-diagonal blocks that all its entries share); a tile sums them per heavy row it touches in LDS (a "slot" = one heavy
+// row inside one tile) and leaves one record per slot in a slab; `gh_fold_gather_kernel` then sums every heavy row's records IN A FIXED
+// ORDER and writes the row -- no atomics in HBM, A.data bit-reproducible as before, each byte of it still written exactly once.
+constexpr int FOLD_MAX_HEAVY = 3;          // heavy slots of one group
+constexpr uint32_t FOLD_SLOT_NONE = 0x3F;  // (6 bits of slot + 4 bits of accumulator copy per heavy slot in EntryList::fslot)
+constexpr int FOLD_MAX_CW = 128;           // doubles of one record
+struct FoldTile {            // per light tile
+    uint32_t slab_off;       // first double of the tile's records in Group::fslab
+    uint8_t  ns[FOLD_MAX_HEAVY];   // slots per heavy slot h (records of h start behind those of h - 1)
+    uint8_t  pad;
+};
+struct FoldHeavy {           // per heavy slot h of a folded group (kernel argument)
+    int32_t slot;            // the residual's slot T
+    int32_t ds, nsym, cw;    // dof of T, lower triangle of its diagonal block, doubles per record: [nsym | ds | shared off-diagonal blocks (T, t) in slot order]
+    int32_t xmask;           // bit t: block (T, t) is stored in T's row and shared by all entries of the row -> part of the record
+    int32_t copies;          // LDS accumulator copies per slot (power of two)
+    int32_t maxns;           // most slots of h in any tile
+    int32_t xdof[4];         // dof of the residual's slot t (size of block (T, t): ds x xdof[t], column-major)
+};
+struct FoldRow {             // one heavy row: where its record components go, and which records are its own
+    int64_t  data_off;       // A.data offset of the row's segment
+    uint32_t diag_off;       // ... of its diagonal block inside the segment
+    uint32_t b_off;          // offset in b
+    uint32_t xoff[4];        // segment-relative offset of block (T, t), DEST_NONE if not stored
+    uint32_t cbeg, cend;     // its records: Group::fcons[cbeg .. cend) = offsets into the slab, in tile order
+    uint32_t h, pad;
+};
+
 struct EntryList {          // all (cost, slot) incidences of one cost group and one slot, sorted by block row
     int slot = 0;
     int64_t n = 0;
@@ -60,6 +92,8 @@ struct EntryList {          // all (cost, slot) incidences of one cost group and
     // the heavy pass then streams 4 bytes per other slot instead of the 8 + 8 of voff / dest (BA camera rows: 20 instead of 32 bytes per entry)
     bool compact = false; uint32_t own_flags = 0;
     DevBuf<uint32_t> hvoff;  // [n][ndeps - 1]: storage offsets of the OTHER slots' variables, slot order
+    DevBuf<uint32_t> fslot;  // folded sweep, light list only: per entry, 10 bits per heavy slot h -- slot of the entry's heavy row inside its tile (FOLD_SLOT_NONE: that variable is fixed) | accumulator copy << 6
+    DevBuf<FoldTile> ftiles; // ... per light tile
 };
 
 struct DenseList {          // dense linear system: one entry per cost
@@ -80,6 +114,9 @@ struct Group {
     DevBuf<uint32_t> fixedcost; // costs without any free variable (only their cost counts in the sweep)
     int64_t nfixedcost = 0;
     EntryList lists[4];
+    // folded sweep (see FoldTile): the light list `fold_ls` carries every block; lists[fold_ls].fslot / .ftiles hold its per-entry / per-tile words
+    bool fold = false; int fold_ls = -1, fold_nh = 0; FoldHeavy fh[FOLD_MAX_HEAVY] = {}; uint32_t fold_lds = 0, fold_unique = 0;   // fold_lds: doubles of LDS per workgroup; fold_unique: bit t -- the light rows' blocks (ls, t) have one writer each
+    DevBuf<FoldRow> frows; DevBuf<uint32_t> fcons; DevBuf<double> fslab; int64_t nfrows = 0;
     DenseList dense;
     // the cost sweep's view of the blocks: a light entry list that holds EVERY cost of the group exactly once (all its slot's variables are
     // free) serves it instead of the cost-order arrays -- the same 24 bytes per block the next gradient sweep streams, so that inside the LM
@@ -154,6 +191,7 @@ struct nlls_ctx {
     nlls_allreduce_fn reduce_fn = nullptr; void* reduce_user = nullptr; void* rccl_comm = nullptr;
     nlls::DevBuf<double> gatherbuf;          // [nranks][16]: the ranks' trial scalars, gathered by a sum over rows that are zero elsewhere
     double comm_posted = 0.0, comm_agreed = 0.0;   // nlls_comm_post_flag / nlls_comm_agreed_flag: slot 11 of the gather rows, combined by maximum
+    bool comm_gathered = false;                    // the last LM trial went through the collective route and gathered the flags: comm_agreed is this iteration's (a dense system, or no trial yet: the local value decides)
 
     // ---- structure ------------------------------------------------------------------------------
     bool ready = false;
@@ -219,6 +257,7 @@ struct nlls_ctx {
     // ---- solve ---------------------------------------------------------------------------------------
     std::vector<uint8_t> is_elim;            // per block
     int64_t nelim = 0, nred = 0;             // blocks eliminated / dof of the reduced system
+    int64_t nelim_all = 0;                   // ... eliminated over ALL ranks of a pre-sharded upload (= nelim otherwise): nothing rank-local may gate a collective or the solver choice
     nlls::DevBuf<int64_t> d_elim_ptr;        // CSR over eliminated blocks -> SchurNbr
     nlls::DevBuf<nlls::SchurNbr> d_elim_nbr;
     nlls::DevBuf<int64_t> d_elim_diag;       // A.data offset of C_v

@@ -53,8 +53,11 @@ void hot_set(nlls_ctx* c, std::vector<HotItem>& v) {
     hot(v, c->A); hot(v, c->b); hot(v, c->x); for (auto& q : c->vars) hot(v, q);
     for (Group& G : c->groups) {
         for (EntryList& E : G.lists) { if (E.n == 0) continue;
+            if (G.fold && E.slot != G.fold_ls) continue;          // folded sweep: the heavy lists are never read
             hot(v, E.data); hot(v, E.rows); hot(v, E.light); hot(v, E.heavy); hot(v, E.hvoff);
-            if (!E.compact) { hot(v, E.voff); hot(v, E.dest); } }
+            if (!E.compact) { hot(v, E.voff); hot(v, E.dest); }
+            hot(v, E.fslot); hot(v, E.ftiles); }
+        if (G.fold) { hot(v, G.frows); hot(v, G.fcons); hot(v, G.fslab); }
         if (G.cost_list < 0 || !c->info.is_sparse) { hot(v, G.data); hot(v, G.voff); }
         hot(v, G.fixedcost); hot(v, G.dense.data); hot(v, G.dense.voff); hot(v, G.dense.brow);
     }
@@ -88,6 +91,104 @@ static int compact_hot_set(nlls_ctx* c) {
     for (HotItem& it : v) { if (!*it.owned) continue; (void)hipFree(*it.pp); *it.pp = fresh.p + off; *it.owned = false; off += it.bytes; }
     c->arena = std::move(fresh);                             // (the previous upload's arena, if any, is freed here: nothing points into it any more)
     if (c->bcr.ready) c->bcr.geom.ws = c->bcr.ws.p;          // the one cached device pointer
+    return NLLS_OK;
+}
+
+struct HostList { std::vector<int64_t> cost; std::vector<int64_t> rowptr; std::vector<int64_t> rows; };   // the incidences (cost, slot) of one group and slot, sorted by block row
+struct SlotHost { std::vector<uint32_t> dest; std::vector<Tile> light, heavy; };                          // what build_structure uploaded for that list, kept for build_fold
+
+// The folded accumulate sweep of one group (nlls_ctx.hpp, FoldTile): decides whether the group qualifies and builds the per-entry slot words, the per-tile
+// record layout and every heavy row's list of records.  Leaves G.fold false (and everything else untouched) when it does not qualify.
+//   NLLS_SWEEP_FOLD=0: never; =1: every group that qualifies; default: groups of three or more slots (BASELINE config 5: three evaluations per block become one;
+//   for two-slot bundle adjustment the heavy rows already hide behind the light tiles of the fused launch -- A/B in DESIGN.md 4.1)
+static int build_fold(nlls_ctx* c, Group& G, const ResDesc& d, const nlls_cost_group& in, const uint64_t* bi, std::vector<HostList>& hls, std::vector<SlotHost>& sh,
+                      const std::vector<int64_t>& segs, const std::vector<int32_t>& row_nlists, std::vector<uint8_t>& row_zero, int32_t flags) {
+    G.fold = false; G.fold_ls = -1; G.fold_nh = 0; G.nfrows = 0;
+    const char* env = getenv("NLLS_SWEEP_FOLD"); const int mode = env ? atoi(env) : -1;
+    if (mode == 0 || (mode < 0 && d.ndeps < 3) || d.ndeps < 2 || d.ndeps > FOLD_MAX_HEAVY + 1 || (flags & NLLS_FLAG_FORCE_ATOMIC)) return NLLS_OK;
+    const int nd = d.ndeps; const int64_t nb = (int64_t)c->blocksizes.size();
+    int ls = -1; for (int s = 0; s < nd; ++s) { const EntryList& E = G.lists[s]; if (E.n == 0) continue;
+        if (E.nlight > 0 && E.nheavy == 0) { if (ls >= 0) return NLLS_OK; ls = s; } else if (!(E.nheavy > 0 && E.nlight == 0)) return NLLS_OK; }
+    if (ls < 0 || G.lists[ls].n != G.ncost) return NLLS_OK;            // the light list must hold EVERY cost block of the group
+    int nheavy = 0; for (int s = 0; s < nd; ++s) if (s != ls && G.lists[s].n > 0) ++nheavy;
+    if (!nheavy) return NLLS_OK;
+    auto dof = [&](int s) { return var_dof(d.sk[s], d.sd[s]); };
+    FoldHeavy fh[FOLD_MAX_HEAVY] = {};
+    std::vector<std::vector<int32_t>> rowidx(nd - 1);                 // block row -> index of the heavy row in its list
+    std::vector<FoldRow> frows; std::vector<uint32_t> row_base(nd - 1, 0);
+    for (int T = 0; T < nd; ++T) { if (T == ls) continue; const int h = T - (T > ls); FoldHeavy& F = fh[h];
+        F.slot = T; F.ds = dof(T); F.nsym = F.ds * (F.ds + 1) / 2; F.cw = 0; F.xmask = 0; F.copies = 1; F.maxns = 0;
+        for (int t = 0; t < 4; ++t) F.xdof[t] = t < nd ? dof(t) : 0;
+        const EntryList& E = G.lists[T]; if (E.n == 0) continue;
+        const HostList& L = hls[T]; const SlotHost& H = sh[T];
+        for (const Tile& t : H.heavy) if (t.flags & TILE_DIRECT) return NLLS_OK;      // a row too long for an LDS image: its blocks have one writer each, nothing to fold
+        rowidx[h].assign(nb, -1); row_base[h] = (uint32_t)frows.size();
+        for (size_t r = 0; r < L.rows.size(); ++r) { const int64_t br = L.rows[r];
+            if (row_nlists[br] != 1) return NLLS_OK;                                    // a row other lists add to as well
+            FoldRow fr{}; fr.data_off = segs[br]; fr.diag_off = (uint32_t)(c->diag_off[br] - segs[br]); fr.b_off = (uint32_t)c->boffsets[br]; fr.h = (uint32_t)h;
+            int xm = 0;
+            for (int t = 0; t < 4; ++t) fr.xoff[t] = DEST_NONE;
+            for (int t = 0; t < nd; ++t) { if (t == T) continue;
+                const uint32_t first = H.dest[(size_t)L.rowptr[r] * nd + t];
+                for (int64_t e = L.rowptr[r]; e < L.rowptr[r + 1]; ++e) if (H.dest[(size_t)e * nd + t] != first) return NLLS_OK;   // blocks with one writer each in a heavy row (points listed before cameras): not folded
+                fr.xoff[t] = first; if (first != DEST_NONE) xm |= 1 << t; }
+            if (r == 0) F.xmask = xm; else if (F.xmask != xm) return NLLS_OK;
+            rowidx[h][br] = (int32_t)r; frows.push_back(fr); }
+        F.cw = F.nsym + F.ds; for (int t = 0; t < nd; ++t) if (F.xmask >> t & 1) F.cw += F.ds * dof(t);
+        if (F.cw > FOLD_MAX_CW) return NLLS_OK;
+    }
+    // slots: the distinct heavy rows every light tile touches, per heavy slot; an entry's rank among its tile's entries of the same heavy row picks its accumulator copy
+    const HostList& LL = hls[ls]; const SlotHost& HL = sh[ls]; const int64_t n = G.lists[ls].n;
+    std::vector<uint8_t> eslot((size_t)n * (nd - 1), (uint8_t)FOLD_SLOT_NONE), erank((size_t)n * (nd - 1), 0);
+    std::vector<FoldTile> ftiles(HL.light.size());
+    std::vector<std::vector<uint32_t>> cons(frows.size());
+    uint64_t slab = 0; uint32_t max_img = 0;
+    for (size_t ti = 0; ti < HL.light.size(); ++ti) { const Tile& t = HL.light[ti]; FoldTile& ft = ftiles[ti]; ft = FoldTile{};
+        if (slab > 0xFFFF0000ull) return NLLS_OK;
+        ft.slab_off = (uint32_t)slab; uint32_t tile_acc = 0;
+        for (int h = 0; h < nd - 1; ++h) { const FoldHeavy& F = fh[h]; if (G.lists[F.slot].n == 0) continue;
+            std::vector<int32_t> rows_here; std::vector<uint32_t> count;
+            for (uint32_t e = t.e0; e < t.e1; ++e) { const int64_t k = LL.cost[e]; const uint64_t bv = bi[in.varind[k * nd + F.slot] - 1]; if (!bv) continue;
+                const int32_t r = rowidx[h][bv - 1]; if (r < 0) return NLLS_OK;
+                size_t j = 0; while (j < rows_here.size() && rows_here[j] != r) ++j;
+                if (j == rows_here.size()) { if (rows_here.size() >= FOLD_SLOT_NONE - 1) return NLLS_OK; rows_here.push_back(r); count.push_back(0); }
+                eslot[(size_t)e * (nd - 1) + h] = (uint8_t)j; erank[(size_t)e * (nd - 1) + h] = (uint8_t)(count[j]++ & 0xFF); }
+            ft.ns[h] = (uint8_t)rows_here.size(); fh[h].maxns = std::max<int32_t>(fh[h].maxns, (int32_t)rows_here.size());
+            for (size_t j = 0; j < rows_here.size(); ++j) cons[row_base[h] + rows_here[j]].push_back((uint32_t)(slab + (uint64_t)j * F.cw));
+            slab += (uint64_t)rows_here.size() * F.cw; }
+        (void)tile_acc; }
+    // accumulator copies: about a thousand doubles of LDS per heavy slot (conflicts of a wavefront's lanes on one address serialise: a slot every lane adds to gets 16)
+    for (int h = 0; h < nd - 1; ++h) { FoldHeavy& F = fh[h]; if (!F.cw || !F.maxns) { F.copies = 1; continue; }
+        int cp = 1; while (cp < 16 && (int64_t)2 * cp * F.maxns * F.cw <= 1024) cp *= 2; F.copies = cp; }
+    for (size_t ti = 0; ti < HL.light.size(); ++ti) { const Tile& t = HL.light[ti]; const uint32_t dsz = (uint32_t)c->blocksizes[LL.rows[t.row0]];
+        uint32_t need = t.data_len + t.b_len + t.nrows * ACC_COPIES * (dsz * (dsz + 1) / 2 + dsz);
+        for (int h = 0; h < nd - 1; ++h) need += (uint32_t)ftiles[ti].ns[h] * (uint32_t)fh[h].copies * (uint32_t)fh[h].cw;
+        max_img = std::max(max_img, need); }
+    if ((size_t)(max_img + 2) * sizeof(double) > 64 * 1024) return NLLS_OK;
+    std::vector<uint32_t> fslot((size_t)n, 0);
+    for (int64_t e = 0; e < n; ++e) { uint32_t w = 0;
+        for (int h = 0; h < FOLD_MAX_HEAVY; ++h) { uint32_t sl = FOLD_SLOT_NONE, cp = 0;
+            if (h < nd - 1) { sl = eslot[(size_t)e * (nd - 1) + h]; cp = erank[(size_t)e * (nd - 1) + h] & (uint32_t)(fh[h].copies - 1); }
+            w |= (sl | cp << 6) << (10 * h); }
+        fslot[(size_t)e] = w; }
+    // which blocks (ls, t) of the light rows have exactly one writer (plain LDS stores instead of LDS atomics)
+    uint32_t uniq = 0;
+    for (int t = 0; t < nd; ++t) { if (t == ls) continue; bool u = true; std::vector<uint32_t> tmp;
+        for (size_t rr = 0; rr < LL.rows.size() && u; ++rr) { tmp.clear();
+            for (int64_t e = LL.rowptr[rr]; e < LL.rowptr[rr + 1]; ++e) if (HL.dest[(size_t)e * nd + t] != DEST_NONE) tmp.push_back(HL.dest[(size_t)e * nd + t]);
+            std::sort(tmp.begin(), tmp.end()); for (size_t i = 1; i < tmp.size(); ++i) if (tmp[i] == tmp[i - 1]) { u = false; break; } }
+        if (u) uniq |= 1u << t; }
+    std::vector<uint32_t> fcons; fcons.reserve((size_t)(slab / 8 + 16));
+    for (size_t r = 0; r < frows.size(); ++r) { frows[r].cbeg = (uint32_t)fcons.size(); fcons.insert(fcons.end(), cons[r].begin(), cons[r].end()); frows[r].cend = (uint32_t)fcons.size(); }
+    EntryList& EL = G.lists[ls];
+    HIPCHK(EL.fslot.upload(fslot)); HIPCHK(EL.ftiles.upload(ftiles));
+    HIPCHK(G.frows.upload(frows)); HIPCHK(G.fcons.upload(fcons)); HIPCHK(G.fslab.alloc(std::max<uint64_t>(slab, 1)));
+    G.nfrows = (int64_t)frows.size(); G.fold_lds = max_img; G.fold_unique = uniq; G.fold_ls = ls; G.fold_nh = nd - 1;
+    for (int h = 0; h < FOLD_MAX_HEAVY; ++h) G.fh[h] = fh[h];
+    // the heavy rows are written whole by the gather launch: no zero fill in front of the sweep on their account (a sharded upload zeroes every reduced row anyway: build_structure)
+    for (const FoldRow& fr : frows) { (void)fr; }
+    for (int T = 0; T < nd; ++T) if (T != ls && G.lists[T].n > 0) for (int64_t br : hls[T].rows) row_zero[br] = 0;
+    G.fold = true;
     return NLLS_OK;
 }
 
@@ -258,7 +359,6 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     // ---- per-group lists ---------------------------------------------------------------------------------
     c->groups.resize(ngroups);
     std::vector<int32_t> row_nlists(nb, 0);         // how many entry lists touch a row
-    struct HostList { std::vector<int64_t> cost; std::vector<int64_t> rowptr; std::vector<int64_t> rows; };   // entries sorted by row
     std::vector<std::vector<HostList>> hl(ngroups);
     int64_t npartials = 0;
     for (int g = 0; g < ngroups; ++g) {
@@ -301,6 +401,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     bool all_owner = true;
     if (sparse) for (int g = 0; g < ngroups; ++g) {
         Group& G = c->groups[g]; const ResDesc& d = desc[g]; const nlls_cost_group& in = groups[g];
+        std::vector<SlotHost> sh(d.ndeps);
         for (int s = 0; s < d.ndeps; ++s) {
             HostList& L = hl[g][s]; EntryList& E = G.lists[s]; E.slot = s; E.n = (int64_t)L.cost.size();
             if (E.n == 0) continue;
@@ -401,7 +502,9 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
             E.nlight = (int64_t)light.size(); E.nheavy = (int64_t)heavy.size();
             HIPCHK(E.light.upload(light)); HIPCHK(E.heavy.upload(heavy));
             npartials += E.nlight + E.nheavy;
+            sh[s].dest = std::move(dest); sh[s].light = std::move(light); sh[s].heavy = std::move(heavy);
         }
+        { const int rcf = build_fold(c, G, d, in, bi, hl[g], sh, segs, row_nlists, row_zero, flags); if (rcf != NLLS_OK) return rcf; }
         G.cost_list = -1;       // (see Group::cost_list)
         for (int s2 = 0; s2 < d.ndeps; ++s2) { const EntryList& E = G.lists[s2]; if (E.n == G.ncost && G.ncost > 0 && E.nlight > 0 && E.nheavy == 0) { G.cost_list = s2; break; } }
         for (int s2 = 0; s2 < d.ndeps; ++s2) std::vector<int64_t>().swap(hl[g][s2].cost);
@@ -589,6 +692,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) { if (c->is_elim[row]) continue;
             for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q]; if (col != row && !c->is_elim[col]) { rcnt[row]++; rcnt[col]++; } } }
         int64_t nelim_all = c->nelim;
+        c->nelim_all = c->nelim;
         if ((flags & NLLS_FLAG_PRESHARDED) && c->nranks > 1) {
             // a rank's share alone would put different blocks into the border on different ranks: the rule is applied to the counts of the WHOLE
             // problem -- couplings to eliminated blocks summed over ranks (every rank eliminates its own), couplings among the reduced blocks as the
@@ -601,7 +705,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             { int rc = comm_reduce(c, ds.p, (int64_t)hs.size(), NLLS_REDUCE_SUM); if (rc == NLLS_OK && nR > 0) rc = comm_reduce(c, dm.p, (int64_t)hm.size(), NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipMemcpy(hs.data(), ds.p, sizeof(double) * hs.size(), hipMemcpyDeviceToHost)); if (nR > 0) HIPCHK(hipMemcpy(hm.data(), dm.p, sizeof(double) * hm.size(), hipMemcpyDeviceToHost));
-            nelim_all = (int64_t)hs[0];
+            nelim_all = (int64_t)hs[0]; c->nelim_all = nelim_all;   // (what decides anything collective below: a rank whose share holds no eliminated block must still enter its peers' collectives)
             { size_t r = 0; for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k]) { cnt[k] = (int64_t)hs[1 + r]; rcnt[k] = (int64_t)hm[r]; ++r; } }
         }
         int64_t bd = 0;
@@ -612,7 +716,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         std::vector<int64_t> band_blocks;                    // reduced, non-border blocks in the order they take in S
         for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && !is_border[k]) band_blocks.push_back(k);
         c->red_reordered = 0; c->bw_caller = -1;
-        if (I0.is_sparse && c->nelim > 0 && band_blocks.size() >= 3 && !(flags & NLLS_FLAG_NO_REORDER) && band_blocks.size() < ((size_t)1 << 30)) {
+        if (I0.is_sparse && c->nelim_all > 0 && band_blocks.size() >= 3 && !(flags & NLLS_FLAG_NO_REORDER) && band_blocks.size() < ((size_t)1 << 30)) {
             const int32_t nRb = (int32_t)band_blocks.size();
             std::vector<int32_t> rid(nb, -1); for (int32_t i = 0; i < nRb; ++i) rid[band_blocks[i]] = i;
             std::vector<std::vector<int32_t>> adj(nRb); std::vector<uint32_t> cap(nRb, 64);
@@ -1007,13 +1111,13 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         // dense storage, column-major, the rhs riding along as row n.  When the (re-ordered) reduced system is a WIDE band -- too wide for the band
         // kernels, much narrower than the system: a 2-D camera grid, a loop closure -- the blocked LDL' is restricted to the band and the border strip
         // (enqueue_reduced_solve, `dense_window`): O(n w^2) work instead of n^3 / 3.  The reference's LDL' takes any sparsity (src/linearsolver.jl:28-32).
-        c->dense_window = I0.is_sparse && c->nelim > 0 && c->n_band >= 1024 && !(flags & NLLS_FLAG_NO_BAND) && 2 * (bw + 256) < c->n_band && !getenv("NLLS_NO_DENSE_WINDOW");
+        c->dense_window = I0.is_sparse && c->nelim_all > 0 && c->n_band >= 1024 && !(flags & NLLS_FLAG_NO_BAND) && 2 * (bw + 256) < c->n_band && !getenv("NLLS_NO_DENSE_WINDOW");
         c->dense_pad128 = c->dense_window || (c->dense_lookahead && n + 1 >= 1024);
         const int64_t npad = c->dense_pad128 ? ((n + 1 + 127) / 128) * 128 : ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
         // TILE-SPARSE: nested dissection of the reduced blocks' graph, the factorisation level by level of its elimination tree (nlls_tsp.hip).  Taken when its
         // dependent chain (levels of the tree) and its tile products come out clearly below what the dense / windowed factorisation of the same system costs
         // (rough launch + matrix-core times, in us).
-        if (I0.is_sparse && c->nelim > 0 && n >= 512 && !red_adj_blocks.empty() && !(flags & (NLLS_FLAG_NO_BAND | NLLS_FLAG_NO_TILE_SPARSE)) && !getenv("NLLS_NO_TSPARSE")) {
+        if (I0.is_sparse && c->nelim_all > 0 && n >= 512 && !red_adj_blocks.empty() && !(flags & (NLLS_FLAG_NO_BAND | NLLS_FLAG_NO_TILE_SPARSE)) && !getenv("NLLS_NO_TSPARSE")) {
             std::vector<int32_t> ndof, noff;
             for (int64_t k : red_adj_blocks) { ndof.push_back((int32_t)c->blocksizes[k]); noff.push_back((int32_t)red_of[k]); }
             int nbdn = 0; for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && red_of[k] >= c->n_band) { ndof.push_back((int32_t)c->blocksizes[k]); noff.push_back((int32_t)red_of[k]); ++nbdn; }
@@ -1054,6 +1158,15 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         if (hipSuccess != c->S.alloc(c->s_elems + (size_t)npad + 64) ||
             hipSuccess != c->Lwork.alloc(lw)   /* W of a 128-column panel (or of two 64-column ones) | acc | inverted diagonal tiles | factored diagonal blocks (a slot per 64-block) */ || hipSuccess != c->d_status.alloc(96)) return fail(c, NLLS_ERR_HIP, "reduced system alloc");
         }
+    }
+    if ((flags & NLLS_FLAG_PRESHARDED) && c->nranks > 1 && c->reduce_fn) {
+        // the solver of the reduced system and the size of [S | s] are part of the layout that is summed element by element: +x / -x pairs under MAX, equal on every rank or refused
+        double h[4] = {(double)c->solve_mode, -(double)c->solve_mode, (double)c->s_elems, -(double)c->s_elems};
+        DevBuf<double> dh; HIPCHK(dh.alloc(4));
+        HIPCHK(hipMemcpyAsync(dh.p, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+        { const int rc = comm_reduce(c, dh.p, 4, NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
+        HIPCHK(hipMemcpyAsync(h, dh.p, sizeof h, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+        if (h[0] != -h[1] || h[2] != -h[3]) return fail(c, NLLS_ERR_INVALID_ARG, "NLLS_FLAG_PRESHARDED: the ranks chose different solvers or sizes for the reduced system");
     }
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
     c->info.solve_mode = c->solve_mode; c->info.bandwidth = c->bw; c->info.nborder_dof = c->nbd;

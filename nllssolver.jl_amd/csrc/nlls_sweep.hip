@@ -371,6 +371,198 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ================================================================================================
+// accumulate, folded (round 5): every block is evaluated ONCE, by the light tile of its light row
+// ================================================================================================
+// The light tile of gh_light_body, plus: what the block adds to its HEAVY rows (costgradhess! of the same block, src/residual.jl:91-107: diagonal
+// block, gradient, and the off-diagonal blocks every entry of such a row shares -- BASELINE config 5: camera rows with their (camera, kernel) block, the
+// kernel variable's own row) is summed per heavy row and tile in LDS accumulators ("slots", FoldTile) and leaves the tile as one record per slot in the
+// slab; gh_fold_gather_kernel sums every heavy row's records in a fixed order.  Replaces the heavy passes (gh_heavy_body: one more evaluation of the
+// block per role, 244 registers for the second-order duals) -- same A.data, same b, no HBM atomics, bit-reproducible.
+struct GhFoldArgs { GhArgs g; const uint32_t* fslot; const FoldTile* ftiles; double* slab; FoldHeavy fh[FOLD_MAX_HEAVY]; uint32_t unique_mask; };
+template <int KIND, int SLOT>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(3, 4))) void gh_fold_kernel(GhFoldArgs a) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    constexpr int DS = I::dof(SLOT);
+    constexpr int NSYM = DS * (DS + 1) / 2, NACC = NSYM + DS;
+    constexpr int NH = R::NDEPS - 1;
+    __shared__ double red[TPB / 64];
+    const GhArgs& g = a.g;
+    const double* __restrict__ vars = g.vars; const double* __restrict__ edata = g.edata; const uint32_t* __restrict__ evoff = g.evoff;
+    const uint32_t* __restrict__ edest = g.edest; const RowInfo* __restrict__ rows = g.rows; const RobustSpec rk = g.rk;
+    double* __restrict__ A = g.A; double* __restrict__ b = g.b; double* __restrict__ partials = g.partials;
+    const uint32_t tile = blockIdx.x;
+    const Tile t = g.tiles[tile]; const FoldTile ft = a.ftiles[tile];
+    const uint32_t odd = (uint32_t)(t.data_off & 1);
+    double* img = dyn_lds + odd;
+    const uint32_t imglen = t.data_len + t.b_len;
+    double* acc = img + imglen;                                 // [nrows][ACC_COPIES][NACC]
+    const uint32_t acclen = t.nrows * ACC_COPIES * NACC;
+    double* facc = acc + acclen;                                // per heavy slot h: [slot][copy][cw]
+    uint32_t hoff[NH + 1], roff[NH + 1];                        // first accumulator / first record double of heavy slot h
+    hoff[0] = 0; roff[0] = 0;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { hoff[h + 1] = hoff[h] + (uint32_t)ft.ns[h] * (uint32_t)a.fh[h].copies * (uint32_t)a.fh[h].cw; roff[h + 1] = roff[h] + (uint32_t)ft.ns[h] * (uint32_t)a.fh[h].cw; }
+    const uint32_t e = t.e0 + threadIdx.x; const bool ok = e < t.e1; const uint32_t ee = ok ? e : t.e0;
+    double d[R::NDATA]; uint32_t vo[R::NDEPS], ds[R::NDEPS];
+#pragma unroll
+    for (int q = 0; q < R::NDATA; ++q) d[q] = edata[(size_t)ee * R::NDATA + q];
+#pragma unroll
+    for (int q = 0; q < R::NDEPS; ++q) { vo[q] = evoff[(size_t)ee * R::NDEPS + q]; ds[q] = edest[(size_t)ee * R::NDEPS + q]; }
+    const uint32_t fs = a.fslot[ee];
+    const uint32_t nfold = t.nrows * NACC;
+    const RowInfo ri0 = rows[t.row0 + (threadIdx.x < nfold ? threadIdx.x / NACC : 0)];
+    if (!(t.flags & TILE_NOZERO)) for (uint32_t i = threadIdx.x; i < imglen; i += TPB) img[i] = 0.0;
+    for (uint32_t i = threadIdx.x; i < acclen + hoff[NH]; i += TPB) acc[i] = 0.0;
+    lds_barrier();
+    double mycost = 0;
+    if (ok) {
+        const uint32_t own = ds[SLOT];
+        BlockGH<KIND> B; B.compute(vars, vo, d, rk, (own & OWN_KERNEL_FREE) != 0);
+        mycost = B.cost;                                        // the light list holds every block of the group exactly once
+        double* ar = acc + ((size_t)(own & OWN_ROW_MASK) * ACC_COPIES + ((own >> OWN_COPY_SHIFT) & (ACC_COPIES - 1))) * NACC;
+        {
+            int q = 0;
+#pragma unroll
+            for (int j = 0; j < DS; ++j)
+#pragma unroll
+                for (int i = j; i < DS; ++i) atomicAdd(&ar[q++], h_elem<KIND, SLOT, SLOT>(B, i, j));
+#pragma unroll
+            for (int i = 0; i < DS; ++i) atomicAdd(&ar[NSYM + i], g_elem<KIND, SLOT>(B, i));
+        }
+        static_for<R::NDEPS>([&](auto Tc) {
+            constexpr int T = decltype(Tc)::value;
+            if constexpr (T != SLOT) {
+                constexpr int DT = I::dof(T);
+                // the light row's own off-diagonal block (SLOT, T): one writer (plain store) or shared by the row's entries (BASELINE config 5: (point, kernel))
+                if (ds[T] != DEST_NONE) {
+                    if (a.unique_mask >> T & 1) {
+#pragma unroll
+                        for (int j = 0; j < DT; ++j)
+#pragma unroll
+                            for (int i = 0; i < DS; ++i) img[ds[T] + i + DS * j] = h_elem<KIND, SLOT, T>(B, i, j);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < DT; ++j)
+#pragma unroll
+                            for (int i = 0; i < DS; ++i) atomicAdd(&img[ds[T] + i + DS * j], h_elem<KIND, SLOT, T>(B, i, j));
+                    }
+                }
+                // ... and the block's share of T's heavy row: [lower triangle of (T, T) | gradient | blocks (T, U) the row's entries share]
+                constexpr int h = T - (T > SLOT ? 1 : 0);
+                const uint32_t w = (fs >> (10 * h)) & 0x3FFu, sl = w & 0x3Fu, cp = w >> 6;
+                if (sl != FOLD_SLOT_NONE) {
+                    double* fa = facc + hoff[h] + (size_t)(sl * (uint32_t)a.fh[h].copies + cp) * (uint32_t)a.fh[h].cw;
+                    int q = 0;
+#pragma unroll
+                    for (int j = 0; j < DT; ++j)
+#pragma unroll
+                        for (int i = j; i < DT; ++i) atomicAdd(&fa[q++], h_elem<KIND, T, T>(B, i, j));
+#pragma unroll
+                    for (int i = 0; i < DT; ++i) atomicAdd(&fa[q++], g_elem<KIND, T>(B, i));
+                    const int xm = a.fh[h].xmask; double* fx = fa + q;
+                    static_for<R::NDEPS>([&](auto Uc) {
+                        constexpr int U = decltype(Uc)::value;
+                        if constexpr (U != T) {
+                            constexpr int DU = I::dof(U);
+                            if (xm >> U & 1) {
+#pragma unroll
+                                for (int j = 0; j < DU; ++j)
+#pragma unroll
+                                    for (int i = 0; i < DT; ++i) atomicAdd(&fx[i + DT * j], h_elem<KIND, T, U>(B, i, j));
+                                fx += DT * DU;
+                            }
+                        }
+                    });
+                }
+            }
+        });
+    }
+    mycost = wave_sum_dpp63(mycost);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = mycost;
+    lds_barrier();
+    if (threadIdx.x == 0) { double tc = 0;
+#pragma unroll
+        for (int k = 0; k < TPB / 64; ++k) tc += red[k];
+        partials[tile] = tc; }
+    // the tile's records: per slot the sum of its accumulator copies, in slab order [h][slot][component]
+    {
+        double* __restrict__ rec = a.slab + ft.slab_off;
+        for (uint32_t w = threadIdx.x; w < roff[NH]; w += TPB) {
+            uint32_t cw = (uint32_t)a.fh[0].cw, cps = (uint32_t)a.fh[0].copies, r0 = 0, h0 = 0;      // (selects, not indexed arrays: those would live in scratch memory)
+#pragma unroll
+            for (int k = 1; k < NH; ++k) if (w >= roff[k]) { cw = (uint32_t)a.fh[k].cw; cps = (uint32_t)a.fh[k].copies; r0 = roff[k]; h0 = hoff[k]; }
+            const uint32_t r = w - r0, sl = r / cw, q = r - sl * cw;
+            const double* fa = facc + h0 + (size_t)sl * cps * cw + q;
+            double v = 0; for (uint32_t k = 0; k < cps; ++k) v += fa[k * cw];
+            rec[w] = v;
+        }
+    }
+    for (uint32_t w = threadIdx.x; w < nfold; w += TPB) {
+        const uint32_t r = w / NACC, q = w - r * NACC;
+        const double* ar = acc + (size_t)r * ACC_COPIES * NACC + q;
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < (int)ACC_COPIES; ++k) v += ar[k * NACC];
+        const RowInfo ri = w < TPB ? ri0 : rows[t.row0 + r];
+        if ((int)q >= NSYM) img[ri.b_off + (q - NSYM)] = v;
+        else { int qq = q, j = 0; while (qq >= DS - j) { qq -= DS - j; ++j; } const int i = j + qq;
+               img[ri.diag_off + i + DS * j] = v; if (i != j) img[ri.diag_off + j + DS * i] = v; }
+    }
+    lds_barrier();
+    if (t.flags & TILE_PARTIAL) {
+        for (uint32_t i = threadIdx.x; i < t.data_len; i += TPB) { double v = img[i]; if (nonzero_bits(v)) atomicAdd(&A[t.data_off + i], v); }
+        for (uint32_t i = threadIdx.x; i < t.b_len; i += TPB) { double v = img[t.data_len + i]; if (nonzero_bits(v)) atomicAdd(&b[t.b_off + i], v); }
+    } else {
+        double* dst = A + t.data_off;
+        const uint32_t npair = (t.data_len - odd) >> 1;
+        const double2* src2 = reinterpret_cast<const double2*>(img + odd);
+        double2* dst2 = reinterpret_cast<double2*>(dst + odd);
+        for (uint32_t k = threadIdx.x; k < npair; k += TPB) dst2[k] = src2[k];
+        if (threadIdx.x == 0 && odd) dst[0] = img[0];
+        if (threadIdx.x == 1 && odd + 2 * npair < t.data_len) dst[t.data_len - 1] = img[t.data_len - 1];
+        for (uint32_t i = threadIdx.x; i < t.b_len; i += TPB) b[t.b_off + i] = img[t.data_len + i];
+    }
+}
+// One workgroup per heavy row: sums the row's records (FoldRow::cbeg .. cend, tile order) component by component -- GTPB / cwp groups of threads walk
+// every (GTPB / cwp)-th record, a fixed tree joins the groups -- and writes the row: the diagonal block mirrored (src/linearsystem.jl:140), its part of b,
+// the shared off-diagonal blocks.  The row's whole segment of A.data is written here, once.
+constexpr int GTPB = 1024, GCONS = 4096;
+__global__ __launch_bounds__(GTPB) void gh_fold_gather_kernel(const FoldRow* __restrict__ frows, const uint32_t* __restrict__ cons, const double* __restrict__ slab,
+                                                              GhFoldArgs a, double* __restrict__ A, double* __restrict__ b) {
+    __shared__ uint32_t scon[GCONS];
+    __shared__ double part[GTPB];
+    const FoldRow fr = frows[blockIdx.x]; const FoldHeavy F = a.fh[fr.h];
+    const uint32_t cw = (uint32_t)F.cw; uint32_t cwp = 1; while (cwp < cw) cwp <<= 1;
+    const uint32_t ng = GTPB / cwp, gi = threadIdx.x / cwp, q = threadIdx.x % cwp;
+    double sum = 0;
+    for (uint32_t c0 = fr.cbeg; c0 < fr.cend; c0 += GCONS) {
+        const uint32_t nc = min((uint32_t)GCONS, fr.cend - c0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nc; i += GTPB) scon[i] = cons[c0 + i];
+        __syncthreads();
+        if (q < cw) {
+            uint32_t k = gi;
+            for (; k + 3 * ng < nc; k += 4 * ng) {                 // four independent loads in flight per thread
+                const double v0 = slab[scon[k] + q], v1 = slab[scon[k + ng] + q], v2 = slab[scon[k + 2 * ng] + q], v3 = slab[scon[k + 3 * ng] + q];
+                sum += v0; sum += v1; sum += v2; sum += v3; }
+            for (; k < nc; k += ng) sum += slab[scon[k] + q];
+        }
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x >= cw) return;
+    double v = 0; for (uint32_t k = 0; k < ng; ++k) v += part[k * cwp + threadIdx.x];
+    const int ds = F.ds, nsym = F.nsym; const int qq = (int)threadIdx.x;
+    double* row = A + fr.data_off;
+    if (qq < nsym) { int r = qq, j = 0; while (r >= ds - j) { r -= ds - j; ++j; } const int i = j + r;
+        row[fr.diag_off + i + ds * j] = v; if (i != j) row[fr.diag_off + j + ds * i] = v; }
+    else if (qq < nsym + ds) b[fr.b_off + (qq - nsym)] = v;
+    else { int r = qq - nsym - ds;
+        for (int t = 0; t < 4; ++t) if (F.xmask >> t & 1) { const int sz = ds * F.xdof[t]; if (r < sz) { row[fr.xoff[t] + r] = v; break; } r -= sz; } }
+}
+
+// ================================================================================================
 // accumulate: dense linear system (MultiVariateLSdense, src/linearsystem.jl:73-87; BlockDenseMatrix.jl)
 // ================================================================================================
 template <int KIND>
@@ -543,10 +735,34 @@ static bool launch_gh_fused3(nlls_ctx* c, const Group& G, const double* vars, in
     }
     return false;
 }
+// the folded sweep of a group (Group::fold, built at upload): the light tiles' launch, then the heavy rows' gather
+template <int KIND, int LS>
+static void launch_gh_fold_as(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if constexpr (LS < Res<KIND>::NDEPS && Res<KIND>::NDEPS >= 2 && Res<KIND>::NDEPS <= FOLD_MAX_HEAVY + 1) {
+        const EntryList& EL = G.lists[LS];
+        GhFoldArgs a{}; a.g = gh_args<KIND>(c, G, EL, vars, false, c->partials.p + pbase); a.fslot = EL.fslot.p; a.ftiles = EL.ftiles.p; a.slab = G.fslab.p; a.unique_mask = G.fold_unique;
+        for (int h = 0; h < FOLD_MAX_HEAVY; ++h) a.fh[h] = G.fh[h];
+        hipLaunchKernelGGL((gh_fold_kernel<KIND, LS>), dim3((unsigned)EL.nlight), dim3(TPB), ((size_t)G.fold_lds + 2) * sizeof(double), c->stream, a);
+        if (G.nfrows > 0) hipLaunchKernelGGL(gh_fold_gather_kernel, dim3((unsigned)G.nfrows), dim3(GTPB), 0, c->stream, G.frows.p, G.fcons.p, G.fslab.p, a, c->A.p, c->b.p);
+        pbase += EL.nlight;
+    }
+}
+template <int KIND>
+static bool launch_gh_fold(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if (!G.fold) return false;
+    switch (G.fold_ls) {
+    case 0: launch_gh_fold_as<KIND, 0>(c, G, vars, pbase); break;
+    case 1: launch_gh_fold_as<KIND, 1>(c, G, vars, pbase); break;
+    case 2: launch_gh_fold_as<KIND, 2>(c, G, vars, pbase); break;
+    case 3: launch_gh_fold_as<KIND, 3>(c, G, vars, pbase); break;
+    default: return false;
+    }
+    return true;
+}
 template <int KIND>
 static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
     if (c->info.is_sparse) {
-        if (!launch_gh_fused<KIND>(c, G, vars, pbase) && !launch_gh_fused3<KIND>(c, G, vars, pbase)) {
+        if (!launch_gh_fold<KIND>(c, G, vars, pbase) && !launch_gh_fused<KIND>(c, G, vars, pbase) && !launch_gh_fused3<KIND>(c, G, vars, pbase)) {
             launch_gh_slot<KIND, 0>(c, G, vars, pbase); launch_gh_slot<KIND, 1>(c, G, vars, pbase);
             launch_gh_slot<KIND, 2>(c, G, vars, pbase); launch_gh_slot<KIND, 3>(c, G, vars, pbase);
         }

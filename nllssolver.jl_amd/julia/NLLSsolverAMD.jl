@@ -280,12 +280,23 @@ end
 
 swapvars!(ls, a, b) = check(ls.ctx, ccall((:nlls_swap_variables, lib), Cint, (Ptr{Cvoid}, Int32, Int32), ls.ctx, a, b))
 copyvars!(ls, dst, src) = check(ls.ctx, ccall((:nlls_copy_variables, lib), Cint, (Ptr{Cvoid}, Int32, Int32), ls.ctx, dst, src))
-NLLSsolver.updatefromnext!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = swapvars!(data.linsystem, VARS_CURRENT, VARS_NEXT)   # src/optimize.jl:207-209
-NLLSsolver.updatefrombest!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu}) = swapvars!(data.linsystem, VARS_CURRENT, VARS_BEST)   # src/optimize.jl:211-213
-# src/optimize.jl:138-142,214: a swap once varbest exists (what CURRENT then holds is stale, and updatefromnext! replaces it at once), a copy the
-# first time (the reference's deepcopy) -- nlls_lm.cpp does the same
-function NLLSsolver.updatetobest!(::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu})
+# Two callers reach these three (src/optimize.jl:207-214).  The Levenberg-Marquardt overload of optimizeinternal! below keeps the variables ON THE DEVICE
+# (ls.resident): the three device sets are swapped, the host vectors are fetched once at the end.  Every other iterator (Newton, dogleg, gradient descent)
+# runs the reference's generic optimizeinternal!, whose costgradhess!(linsystem, problem.variables, costs) uploads the HOST vector every iteration
+# (ls.resident == false): there the host vectors are the authority and must advance exactly as the reference's own methods advance them.
+function NLLSsolver.updatefromnext!(problem::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu})
+    if data.linsystem.resident; swapvars!(data.linsystem, VARS_CURRENT, VARS_NEXT)
+    else; problem.variables, problem.varnext = problem.varnext, problem.variables; end
+end
+function NLLSsolver.updatefrombest!(problem::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu})
+    if data.linsystem.resident; swapvars!(data.linsystem, VARS_CURRENT, VARS_BEST)
+    else; problem.variables, problem.varbest = problem.varbest, problem.variables; end
+end
+# src/optimize.jl:138-142,214.  Device-resident: a swap once varbest exists (what CURRENT then holds is stale, and updatefromnext! replaces it at once), a copy
+# the first time (the reference's deepcopy) -- nlls_lm.cpp does the same.  Host-resident: the reference's swap (its caller has checked the lengths).
+function NLLSsolver.updatetobest!(problem::NLLSProblem, data::NLLSInternal{MultiVariateLSgpu})
     ls = data.linsystem
+    if !ls.resident; problem.variables, problem.varbest = problem.varbest, problem.variables; return; end
     if ls.havebest; swapvars!(ls, VARS_CURRENT, VARS_BEST); else; copyvars!(ls, VARS_BEST, VARS_CURRENT); ls.havebest = true; end
 end
 

@@ -264,7 +264,8 @@ def optimizesingles(problem, options=None, indices=None, kind=None, dim=None, de
     indices = np.asarray(indices, dtype=np.int64)
     # "sorted in order of variable size" (src/optimize.jl:67; sortperm is stable): the processing order
     from . import kinds as K
-    dof = np.array([K.var_dof(problem.var_kind[i - 1], problem.var_dim[i - 1]) for i in indices], dtype=np.int64) if indices.size else np.zeros(0, np.int64)
+    vkind, vdim = problem.var_kind, problem.var_dim            # (properties that build an array per access: taken once)
+    dof = np.array([K.var_dof(vkind[i - 1], vdim[i - 1]) for i in indices], dtype=np.int64) if indices.size else np.zeros(0, np.int64)
     order = np.argsort(dof, kind="stable")
     ordered = indices[order]
     iters = np.zeros(indices.size, np.int64)
@@ -273,13 +274,13 @@ def optimizesingles(problem, options=None, indices=None, kind=None, dim=None, de
     # sub-problem of the cost blocks that depend on it, only that variable free, through the ordinary device path (a univariate dense system).  The listed
     # order is kept: runs of kernel-sized variables go in launches of independent sets, a wide variable in between is a sub-problem of its own.
     gl = list(problem.costs.values())
-    adaptive_first = {gi for gi, g in enumerate(gl) if g.res_kind in K.ADAPTIVE_KINDS}
-    def wide(pos):
-        v = ordered[pos]
-        if dof[order[pos]] > 6 or problem.var_kind[v - 1] == K.VAR_DYNAMIC:
-            return True
-        return any(np.any(gl[gi].arrays()[0][:, 0] == v) for gi in adaptive_first)
-    is_wide = np.array([wide(q) for q in range(ordered.size)], bool) if ordered.size else np.zeros(0, bool)
+    adaptive_first = [gi for gi, g in enumerate(gl) if g.res_kind in K.ADAPTIVE_KINDS]
+    # (the kernel variables of the adaptive groups, gathered ONCE: a scan of every adaptive group per listed variable was O(listed x blocks) -- 37 s of host time on ba_so3_500x50k)
+    kernelvars = np.unique(np.concatenate([gl[gi].arrays()[0][:, 0] for gi in adaptive_first])) if adaptive_first else np.zeros(0, np.int64)
+    if ordered.size:
+        is_wide = (dof[order] > 6) | (vkind[ordered - 1] == K.VAR_DYNAMIC) | np.isin(ordered, kernelvars)
+    else:
+        is_wide = np.zeros(0, bool)
     ls = makesymmvls(problem, np.ones(problem.nvariables, bool), 0, device)
     try:
         q = 0

@@ -175,6 +175,43 @@ int main(int argc, char** argv) {
         printf("replay (callback path: varnext fetched, edited on the host, set again before updatefromnext!): best %.6e in %d iterations, %d edits, cost(variables) %.6e\n", best2, it2, edits, check4);
         if (!(check4 < 1e-15 * NOBS)) { fprintf(stderr, "the callback path did not reach the zero-residual optimum\n"); return 1; }
     }
+    /* ---- the shim's OTHER iterators (Newton here; dogleg and gradient descent share the sequence): they run the reference's generic optimizeinternal! (src/optimize.jl:109-180), so the
+     *      HOST vectors are the authority -- costgradhess!(linsystem, problem.variables, costs) uploads problem.variables every iteration (ls.resident == false), iterate! solves, forms
+     *      problem.varnext = update(problem.variables, x) on the host and takes its cost from the device (gpucost: nlls_set_variables(ctx, 1) + nlls_sweep_cost(ctx, 1)), and
+     *      updatefromnext! SWAPS THE HOST VECTORS (round 5: the shim's overload used to swap device slots only, the host vector never advanced and the loop returned its start point).
+     *      The first two cameras are fixed (blockindices 0): that removes the affine gauge freedom, the undamped Newton system is definite.  Progress over >= 3 iterations is required. ---- */
+    {
+        typedef int (*fn_solve)(nlls_ctx*, double*); fn_solve solve = (fn_solve)need(lib, "nlls_solve");
+        uint64_t bi2[NVAR]; for (int i = 0; i < NVAR; ++i) bi2[i] = i < 2 ? 0 : (uint64_t)(i - 1);
+        nlls_ctx* c2 = NULL;
+        if (ctx_create(NULL, 0, &c2) != 0 || upload(c2, NVAR, vk, vd, bi2, 1, &grp, 0) != 0) { fprintf(stderr, "newton replay: upload failed: %s\n", c2 ? last_error(c2) : ""); return 1; }
+        nlls_info i2; if (get_info(c2, &i2) != 0 || i2.ndof != (NCAM - 2) * 6 + NPT * 3) { fprintf(stderr, "newton replay: unexpected ndof\n"); return 1; }
+        int64_t boff2[NVAR]; if (bsm_index(c2, NULL, NULL, NULL, boff2) != 0) return 1;
+        static double variables[NCAM * 6 + NPT * 3], varnext[NCAM * 6 + NPT * 3], xs[NCAM * 6 + NPT * 3];
+        for (int i = 0; i < NCAM * 6 + NPT * 3; ++i) variables[i] = i < 12 ? truth[i] : truth[i] + 20.0 * (start[i] - truth[i]);   /* the fixed cameras sit at their true values; the others start 2e-2 away */
+        double* pv = variables; double* pn = varnext; double costs[16]; int nit = 0, conv = 0; double best = 0, cN = 0;
+#define CK2(call) do { int rc_ = (call); if (rc_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, last_error(c2)); return 1; } } while (0)
+        CK2(set_vars(c2, NLLS_VARS_CURRENT, pv)); CK2(sweep_gradhess(c2, &cN)); best = cN; costs[0] = cN;
+        while (!conv) {
+            ++nit;
+            CK2(solve(c2, xs));                                             /* solve! hands back -x; the shim flips it and negate!() flips it again: xs IS the step */
+            for (int i = 0, o = 0; i < NVAR; ++i) { const int dof = i < NCAM ? 6 : 3;          /* update!(problem.varnext, problem.variables, linsystem): host, src/linearsystem.jl:206-213 */
+                for (int k = 0; k < dof; ++k) pn[o + k] = pv[o + k] + (bi2[i] ? xs[boff2[bi2[i] - 1] - 1 + k] : 0.0);
+                o += dof; }
+            CK2(set_vars(c2, NLLS_VARS_NEXT, pn)); CK2(sweep_cost(c2, NLLS_VARS_NEXT, &cN));  /* gpucost(ls, problem.varnext) */
+            double dcost = best - cN; if (dcost >= 0) best = cN; else dcost = cN;
+            { double* tmp = pv; pv = pn; pn = tmp; }                        /* updatefromnext!: problem.variables, problem.varnext = problem.varnext, problem.variables */
+            if (nit < 16) costs[nit] = cN;
+            conv |= (dcost < best * 1e-15) << 2; conv |= (dcost < 1e-15) << 3; conv |= (nit >= 12) << 8;
+            if (conv) break;
+            CK2(set_vars(c2, NLLS_VARS_CURRENT, pv)); CK2(sweep_gradhess(c2, &cN));           /* zero! + costgradhess!(linsystem, problem.variables, costs): the HOST vector goes up again */
+        }
+        double checkN = 0; CK2(set_vars(c2, NLLS_VARS_CURRENT, pv)); CK2(sweep_cost(c2, NLLS_VARS_CURRENT, &checkN));
+        printf("replay (Newton through the generic loop, host vectors swapped by updatefromnext!): %.6e -> %.6e -> %.6e -> %.6e ... best %.6e in %d iterations, cost(variables) %.6e\n",
+               costs[0], costs[1], costs[2], costs[3], best, nit, checkN);
+        if (nit < 3 || !(costs[1] < costs[0]) || !(costs[2] < costs[1]) || !(costs[3] < costs[2]) || !(checkN < 1e-15 * NOBS)) { fprintf(stderr, "the Newton replay made no progress: the host vectors do not advance\n"); return 1; }
+        CK2(ctx_destroy(c2));
+    }
     /* ---- the same optimisation through the library's own loop (the shim's path when there is no user callback): one ccall ---- */
     fn_lm_iterations lm_iterations = (fn_lm_iterations)need(lib, "nlls_lm_iterations");
     CK(set_vars(ctx, NLLS_VARS_CURRENT, start)); CK(copy_vars(ctx, NLLS_VARS_NEXT, NLLS_VARS_CURRENT));

@@ -29,6 +29,8 @@ def test_shim_call_sequence_replay():
     out = subprocess.run([_build(), "--replay", LIB], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "replay: start" in out.stdout
+    # the generic loop of the non-LM iterators: host vectors advance through the shim's updatefromnext! (advisor, round 4)
+    assert "replay (Newton through the generic loop" in out.stdout
 
 
 @pytest.mark.gpu
