@@ -352,12 +352,20 @@ int  nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);
 /* in-situ timing of the accumulate launches: on != 0 starts recording an event pair around every nlls_sweep_gradhess's accumulate
  * launch(es) inside the caller's own loop (last 64 kept); a call with any output pointer set synchronises and reports them. */
 int  nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples);
+/* ... the same launches by their DISPATCH timestamps (begin .. end as the command processor records them for the launch: hipExtLaunchKernelGGL's
+ * start / stop events) -- the duration rocprofv3 --kernel-trace reports per dispatch, measured inside the caller's own loop; read-only, synchronises. */
+int  nlls_profile_sweep_dispatch(nlls_ctx* ctx, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples);
 int  nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);  /* factorisation + backward pass of the (already assembled) reduced system alone */
 /* measurement helpers.  nlls_get_memory_info: out[0] = bytes of the LM loop's working set (every device buffer an iteration reads or writes -- the
  * "hot arena"), out[1] = bytes reserved for it in one allocation (0: NLLS_NO_ARENA), out[2] = bytes of A.data, out[3] = bytes of the reduced system [S | s].
  * nlls_flush_cache: streams `bytes` of foreign data through the memory side on the context's stream (a device-to-device copy between two scratch
  * halves): whatever the 256 MiB Infinity Cache held of the working set is gone afterwards -- a launch timed behind it is the COLD figure. */
 int  nlls_get_memory_info(nlls_ctx* ctx, int64_t* out, int32_t n);
+/* test hook (round 5): residual kinds may bring their Jacobian in closed form (the pinhole kinds) and the adaptive kernel's second derivatives are taken in
+ * closed form -- the generic statement through dual numbers (/root/reference/src/autodiff.jl:81-93,164-165) stays in the library as the check.  Evaluates every
+ * block of the uploaded problem at NLLS_VARS_CURRENT both ways; out[0..6] = largest difference of J, J'r, cost, rho', rho'', d rho / d kernel,
+ * d2 rho / d kernel d(kernel, cost), each relative to the largest magnitude of that quantity in its block.  n >= 7. */
+int  nlls_check_analytic(nlls_ctx* ctx, double* out, int32_t n);
 int  nlls_flush_cache(nlls_ctx* ctx, int64_t bytes);
 
 /* ---- collectives behind the ABI ("RCCL all-reduce over xGMI on the assembled normal equations") ----------------------

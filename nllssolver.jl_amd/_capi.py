@@ -26,8 +26,8 @@ nlls_set_variables nlls_get_variables nlls_swap_variables nlls_copy_variables nl
 nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_quadform nlls_damp nlls_solve nlls_get_solve_stats nlls_set_step
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
-nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_solve_finish_replicated nlls_get_variables_owned nlls_lm_iterations
-nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl nlls_comm_post_flag nlls_comm_agreed_flag nlls_comm_info nlls_get_memory_info nlls_flush_cache""".split()
+nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_profile_sweep_dispatch nlls_solve_finish_replicated nlls_get_variables_owned nlls_lm_iterations
+nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl nlls_comm_post_flag nlls_comm_agreed_flag nlls_comm_info nlls_get_memory_info nlls_flush_cache nlls_check_analytic""".split()
 
 
 class LmOptions(C.Structure):          # nlls_lm_options
@@ -114,10 +114,10 @@ def lib():
         L.nlls_get_shard_info.argtypes = [vp, vp, i32]
         L.nlls_time_sweep_gradhess.argtypes = [vp, i32, vp]; L.nlls_time_sweep_cost.argtypes = [vp, i32, vp]; L.nlls_time_sweep_accumulate.argtypes = [vp, i32, vp]
         L.nlls_time_solve.argtypes = [vp, i32, vp]; L.nlls_time_reduced_solve.argtypes = [vp, i32, vp]
-        L.nlls_profile_sweep.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.nlls_profile_sweep.argtypes = [vp, i32, vp, vp, vp, vp]; L.nlls_profile_sweep_dispatch.argtypes = [vp, vp, vp, vp, vp]
         L.nlls_solve_finish_replicated.argtypes = [vp]; L.nlls_get_variables_owned.argtypes = [vp, i32, vp]
         L.nlls_set_allreduce.argtypes = [vp, vp, vp]; L.nlls_comm_unique_id.argtypes = [vp]; L.nlls_comm_init_rccl.argtypes = [vp, vp]
-        L.nlls_get_memory_info.argtypes = [vp, vp, i32]; L.nlls_flush_cache.argtypes = [vp, i64]
+        L.nlls_get_memory_info.argtypes = [vp, vp, i32]; L.nlls_flush_cache.argtypes = [vp, i64]; L.nlls_check_analytic.argtypes = [vp, vp, i32]
         L.nlls_comm_post_flag.argtypes = [vp, dbl]; L.nlls_comm_agreed_flag.argtypes = [vp, dbl, vp]; L.nlls_comm_info.argtypes = [vp, vp, i32]
         _lib = L
     return _lib
@@ -296,6 +296,11 @@ class Context:
         out = np.zeros(4, np.int64); self._chk(self.L.nlls_get_memory_info(self.h, _p(out), 4))
         return dict(working_set_bytes=int(out[0]), arena_bytes=int(out[1]), a_data_bytes=int(out[2]), reduced_system_bytes=int(out[3]))
 
+    def check_analytic(self):
+        """closed-form Jacobians / kernel derivatives against the dual-number statement, per quantity (include/nlls_amd.h)"""
+        out = np.zeros(7); self._chk(self.L.nlls_check_analytic(self.h, _p(out), 7))
+        return dict(zip(("J", "Jtr", "cost", "drho", "d2rho", "dkernel", "d2kernel"), out.tolist()))
+
     def flush_cache(self, nbytes):
         self._chk(self.L.nlls_flush_cache(self.h, int(nbytes)))
 
@@ -401,6 +406,12 @@ class Context:
             self._chk(self.L.nlls_profile_sweep(self.h, 1 if on else 0, None, None, None, None)); return None
         a, mn, mx, n = C.c_float(), C.c_float(), C.c_float(), C.c_int64()
         self._chk(self.L.nlls_profile_sweep(self.h, 1 if on else 0, C.byref(a), C.byref(mn), C.byref(mx), C.byref(n)))
+        return a.value, mn.value, mx.value, n.value
+
+    def profile_sweep_dispatch(self):
+        """(avg, min, max ms, samples) of the recorded accumulate launches by their dispatch timestamps (what a kernel trace reports); read before profile_sweep(False, read=True) resets nothing"""
+        a, mn, mx, n = C.c_float(), C.c_float(), C.c_float(), C.c_int64()
+        self._chk(self.L.nlls_profile_sweep_dispatch(self.h, C.byref(a), C.byref(mn), C.byref(mx), C.byref(n)))
         return a.value, mn.value, mx.value, n.value
 
     def time_reduced_solve(self, reps=3):

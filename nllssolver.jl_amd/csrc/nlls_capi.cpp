@@ -565,6 +565,19 @@ int nlls_get_memory_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
     out[0] = ctx->hot_bytes; out[1] = (int64_t)ctx->arena.n; out[2] = (int64_t)sizeof(double) * ctx->info.nnz_data; out[3] = (int64_t)sizeof(double) * ((int64_t)ctx->s_elems + ctx->nred);
     return NLLS_OK;
 }
+int nlls_check_analytic(nlls_ctx* ctx, double* out, int32_t n) {
+    NEED_READY(); if (!out || n < 7) return NLLS_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    int64_t nb = 0; TRY(enqueue_check_analytic(ctx, nullptr, &nb));
+    for (int q = 0; q < 7; ++q) out[q] = 0.0;
+    if (nb == 0) return NLLS_OK;
+    nlls::DevBuf<double> d; HIPCHK(d.alloc((size_t)nb * 8));
+    TRY(enqueue_check_analytic(ctx, d.p, nullptr));
+    std::vector<double> h((size_t)nb * 8);
+    HIPCHK(hipMemcpyAsync(h.data(), d.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int64_t b = 0; b < nb; ++b) for (int q = 0; q < 7; ++q) { const double v = h[(size_t)b * 8 + q]; if (!(v <= out[q])) out[q] = v; }   // (a NaN difference comes through)
+    return NLLS_OK;
+}
 int nlls_flush_cache(nlls_ctx* ctx, int64_t bytes) {
     if (!ctx || bytes <= 0 || bytes > ((int64_t)8 << 30)) return NLLS_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
@@ -605,6 +618,17 @@ int nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, 
     if (on) ctx->prof_kcount = 0;
     if (on && ctx->prof_ev.empty()) { ctx->prof_ev.resize(128); for (auto& e : ctx->prof_ev) if (hipEventCreate(&e) != hipSuccess) return NLLS_ERR_HIP; }
     ctx->prof_sweep = on != 0; if (on) ctx->prof_count = 0;
+    return NLLS_OK;
+}
+// the event pairs alone: begin .. end of the accumulate dispatch(es) as the command processor stamped them -- what rocprofv3 --kernel-trace reports per dispatch
+int nlls_profile_sweep_dispatch(nlls_ctx* ctx, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples) {
+    if (!ctx) return NLLS_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int64_t cap = (int64_t)ctx->prof_ev.size() / 2, n = std::min(ctx->prof_count, cap);
+    double sum = 0; float mn = 1e30f, mx = 0.f; int64_t ok = 0;
+    for (int64_t i = 0; i < n; ++i) { float ms = 0.f; if (hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) != hipSuccess) { (void)hipGetLastError(); continue; } sum += ms; mn = std::min(mn, ms); mx = std::max(mx, ms); ++ok; }
+    if (ms_avg) *ms_avg = ok ? (float)(sum / ok) : 0.f; if (ms_min) *ms_min = ok ? mn : 0.f; if (ms_max) *ms_max = mx; if (nsamples) *nsamples = ok;
     return NLLS_OK;
 }
 int nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {

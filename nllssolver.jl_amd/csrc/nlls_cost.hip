@@ -420,6 +420,57 @@ int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& 
     }
     return NLLS_OK;
 }
+// ---- closed forms against dual numbers (nlls_check_analytic) --------------------------------------------------------------------------------------
+// Every block of a group evaluated twice -- BlockGH<KIND, true> (a residual kind's own `jac`, the adaptive kernel's closed-form derivatives) and
+// BlockGH<KIND, false> (everything through Dual<N> / Dual2: src/autodiff.jl:81-93,164-165 as written) -- and the largest difference of each quantity,
+// relative to the largest magnitude of that quantity in the block: out[0] J, [1] J'r, [2] cost, [3] rho', [4] rho'', [5] d rho / d kernel, [6] d2 rho / d kernel d(kernel, cost).
+template <int KIND>
+__global__ __launch_bounds__(TPB) void check_analytic_kernel(const double* __restrict__ vars, const double* __restrict__ data, const uint32_t* __restrict__ voff, int64_t n,
+                                                             RobustSpec rk, int kernel_free, double* __restrict__ out) {
+    using R = Res<KIND>; using BA = BlockGH<KIND, true>; using BD = BlockGH<KIND, false>;
+    __shared__ double red[TPB / 64];
+    double m[7] = {0, 0, 0, 0, 0, 0, 0};
+    if constexpr (!is_cost_kind<KIND>) {
+        for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+            double d[R::NDATA]; uint32_t vo[R::NDEPS];
+#pragma unroll
+            for (int q = 0; q < R::NDATA; ++q) d[q] = data[(size_t)e * R::NDATA + q];
+#pragma unroll
+            for (int q = 0; q < R::NDEPS; ++q) vo[q] = voff[(size_t)e * R::NDEPS + q];
+            BA a; a.compute(vars, vo, d, rk, kernel_free != 0);
+            BD b; b.compute(vars, vo, d, rk, kernel_free != 0);
+            auto upd = [](double& mx, double diff, double scale) { const double r = fabs(diff) / fmax(scale, 1e-300); if (!(r <= mx)) mx = r; };
+            double sj = 0, sg = 0;
+            for (int q = 0; q < BA::M; ++q) for (int j = 0; j < BA::NP; ++j) sj = fmax(sj, fabs(b.J[q][j]));
+            for (int j = 0; j < BA::NP; ++j) sg = fmax(sg, fabs(b.g[j]));
+            for (int q = 0; q < BA::M; ++q) for (int j = 0; j < BA::NP; ++j) upd(m[0], a.J[q][j] - b.J[q][j], sj);
+            for (int j = 0; j < BA::NP; ++j) upd(m[1], a.g[j] - b.g[j], sg);
+            upd(m[2], a.cost - b.cost, fabs(b.cost)); upd(m[3], a.dc - b.dc, fabs(b.dc)); upd(m[4], a.d2c - b.d2c, fmax(fabs(b.d2c), fabs(b.dc)));
+            if constexpr (R::ADAPT) if (kernel_free) {
+                double s1 = 0, s2 = 0;
+                for (int i = 0; i < 3; ++i) { s1 = fmax(s1, fabs(b.dck[i])); for (int j = 0; j < 4; ++j) s2 = fmax(s2, fabs(b.d2ck[i][j])); }
+                for (int i = 0; i < 3; ++i) { upd(m[5], a.dck[i] - b.dck[i], s1); for (int j = 0; j < 4; ++j) upd(m[6], a.d2ck[i][j] - b.d2ck[i][j], s2); }
+            }
+        }
+    }
+    for (int q = 0; q < 7; ++q) { const double t = block_max(m[q], red); if (threadIdx.x == 0) out[(size_t)blockIdx.x * 8 + q] = t; __syncthreads(); }
+}
+int enqueue_check_analytic(nlls_ctx* c, double* d_out /* [nblocks_total][8] */, int64_t* nblocks_out) {
+    const double* vars = vars_ptr(c, NLLS_VARS_CURRENT); int64_t base = 0;
+    for (const Group& G : c->groups) {
+        if (is_dyn_kind(G.res_kind) || G.ncost == 0) continue;
+        const int grid = (int)std::min<int64_t>((G.ncost + TPB - 1) / TPB, 256);
+        if (d_out) switch (G.res_kind) {
+#define X(K) case K: hipLaunchKernelGGL(check_analytic_kernel<K>, dim3(grid), dim3(TPB), 0, c->stream, vars, G.data.p, G.voff.p, G.ncost, G.rk, 1, d_out + base * 8); break;
+            NLLS_FOR_EACH_RES(X)
+#undef X
+        }
+        base += grid;
+    }
+    if (nblocks_out) *nblocks_out = base;
+    return hipGetLastError() == hipSuccess ? NLLS_OK : NLLS_ERR_HIP;
+}
+
 int enqueue_reduce_partials(nlls_ctx* c, int64_t n) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p, n, c->scalars.p);
     HIPCHK(hipGetLastError());

@@ -94,6 +94,7 @@ struct EntryList {          // all (cost, slot) incidences of one cost group and
     DevBuf<uint32_t> hvoff;  // [n][ndeps - 1]: storage offsets of the OTHER slots' variables, slot order
     DevBuf<uint32_t> fslot;  // folded sweep, light list only: per entry, 10 bits per heavy slot h -- slot of the entry's heavy row inside its tile (FOLD_SLOT_NONE: that variable is fixed) | accumulator copy << 6
     DevBuf<FoldTile> ftiles; // ... per light tile
+    DevBuf<uint32_t> frowx;  // ... per light row [4]: tile-relative A.data offset of the row's block (slot, t) that all its entries share (DEST_NONE: none)
 };
 
 struct DenseList {          // dense linear system: one entry per cost
@@ -115,7 +116,7 @@ struct Group {
     int64_t nfixedcost = 0;
     EntryList lists[4];
     // folded sweep (see FoldTile): the light list `fold_ls` carries every block; lists[fold_ls].fslot / .ftiles hold its per-entry / per-tile words
-    bool fold = false; int fold_ls = -1, fold_nh = 0; FoldHeavy fh[FOLD_MAX_HEAVY] = {}; uint32_t fold_lds = 0, fold_unique = 0;   // fold_lds: doubles of LDS per workgroup; fold_unique: bit t -- the light rows' blocks (ls, t) have one writer each
+    bool fold = false; int fold_ls = -1, fold_nh = 0; FoldHeavy fh[FOLD_MAX_HEAVY] = {}; uint32_t fold_lds = 0, fold_unique = 0, fold_shared = 0;   // fold_lds: doubles of LDS per workgroup; fold_unique: bit t -- the light rows' blocks (ls, t) have one writer each; fold_shared: bit t -- they are shared by all entries of their row
     DevBuf<FoldRow> frows; DevBuf<uint32_t> fcons; DevBuf<double> fslab; int64_t nfrows = 0;
     DenseList dense;
     // the cost sweep's view of the blocks: a light entry list that holds EVERY cost of the group exactly once (all its slot's variables are
@@ -183,6 +184,7 @@ struct nlls_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // in-situ profile of the accumulate launches (nlls_profile_sweep): event pairs recorded around them inside the caller's own loop
     bool prof_sweep = false; std::vector<hipEvent_t> prof_ev; int64_t prof_count = 0;
+    hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr; bool prof_taken = false;   // the event pair of the sweep being enqueued, handed to its fused / folded launch (hipExtLaunchKernelGGL)
     nlls::DevBuf<unsigned long long> prof_clk; int64_t prof_kcount = 0; unsigned prof_nwg[16] = {0};   // [PROF_SLOTS][2][PROF_MAXWG] start / end stamp of every workgroup (100 MHz constant clock) of the fused accumulate launch
     std::string err;
     int err_sub = 0;                         // why the last nlls_upload_structure declined (NLLS_SUB_*): control flow never reads the error text

@@ -26,6 +26,7 @@ int enqueue_sweep_cost(nlls_ctx* c, int which, int64_t pofs = 0, int64_t* count 
 int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);
 int enqueue_dyn_gradhess(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);   // dynamic-size residual blocks (dense system): accumulate
 int enqueue_reduce_partials(nlls_ctx* c, int64_t n);
+int enqueue_check_analytic(nlls_ctx* c, double* d_out, int64_t* nblocks_out);   // closed-form block maths against the dual-number statement (nlls_check_analytic)
 int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost = true);
 // vector helpers (nlls_sweep.hip)
 int enqueue_retract(nlls_ctx* c, int to, int from);

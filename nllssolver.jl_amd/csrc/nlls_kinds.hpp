@@ -304,17 +304,41 @@ template <class T> NLLS_DEV void pinhole(const double* data, const T* P, const T
     for (int i = 0; i < 3; ++i) Y[i] = P[i] * X[0] + P[i + 3] * X[1] + P[i + 6] * X[2] + P[9 + i];
     r[0] = Y[0] / Y[2] - data[0]; r[1] = Y[1] / Y[2] - data[1];
 }
+// Residual AND Jacobian of the pinhole model in closed form (round 5; the optional `jac` of a residual kind -- BlockGH takes it instead of pushing `eval` through
+// Dual<9>, which stays the generic path and the check: nlls_check_analytic).  Tangent of the pose: R <- R expm([w]x), t <- t + tau (var_load / var_update_real), so
+//   Y = R X + t,   dY/dw = R [e_k x X] = (R2 X1 - R1 X2 | R0 X2 - R2 X0 | R1 X0 - R0 X1)   (Rk = column k of R),   dY/dtau = I,   dY/dX = R,
+//   r = (Y0 / Y2, Y1 / Y2) - data,   dr/dY = [[1, 0, -u], [0, 1, -v]] / Y2   with (u, v) = (Y0, Y1) / Y2:   J = dr/dY [dY/dw | I | R].
+NLLS_DEV void pinhole_jac(const double* data, const double* P, const double* X, double* r, double (*J)[9]) {
+    double Y[3], Mw[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double R0 = P[i], R1 = P[i + 3], R2 = P[i + 6];
+        Y[i] = R0 * X[0] + R1 * X[1] + R2 * X[2] + P[9 + i];
+        Mw[i][0] = R2 * X[1] - R1 * X[2]; Mw[i][1] = R0 * X[2] - R2 * X[0]; Mw[i][2] = R1 * X[0] - R0 * X[1];
+    }
+    const double iz = 1.0 / Y[2], u = Y[0] * iz, v = Y[1] * iz;
+    r[0] = u - data[0]; r[1] = v - data[1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        J[0][k] = iz * (Mw[0][k] - u * Mw[2][k]);         J[1][k] = iz * (Mw[1][k] - v * Mw[2][k]);
+        J[0][6 + k] = iz * (P[3 * k] - u * P[3 * k + 2]); J[1][6 + k] = iz * (P[3 * k + 1] - v * P[3 * k + 2]);
+    }
+    J[0][3] = iz; J[0][4] = 0.0; J[0][5] = -u * iz;
+    J[1][3] = 0.0; J[1][4] = iz; J[1][5] = -v * iz;
+}
 template <> struct Res<NLLS_RES_BA_SO3> {   // new kind
     static constexpr int NDEPS = 2, M = 2, NDATA = 2, ADAPT = 0;
     static constexpr int SK[4] = {NLLS_VAR_POSE_SO3, NLLS_VAR_EUCLIDEAN, 0, 0};
     static constexpr int SD[4] = {6, 3, 0, 0};
     template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) { pinhole(data, sv[0], sv[1], r); }
+    static NLLS_DEV void jac(const double* data, const double (*st)[MAXST], double* r, double (*J)[9]) { pinhole_jac(data, st[0], st[1], r, J); }
 };
 template <> struct Res<NLLS_RES_BA_SO3_ADAPTIVE> {   // new kind
     static constexpr int NDEPS = 3, M = 2, NDATA = 2, ADAPT = 1;
     static constexpr int SK[4] = {NLLS_VAR_CONTAMINATED_GAUSSIAN, NLLS_VAR_POSE_SO3, NLLS_VAR_EUCLIDEAN, 0};
     static constexpr int SD[4] = {3, 6, 3, 0};
     template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) { pinhole(data, sv[0], sv[1], r); }
+    static NLLS_DEV void jac(const double* data, const double (*st)[MAXST], double* r, double (*J)[9]) { pinhole_jac(data, st[1], st[2], r, J); }   // (st[] includes the kernel's slot)
 };
 
 template <> struct Res<NLLS_RES_LINEAR3> {   // test/nonsquaredcost.jl:4-14: X w - y, data = (y[3], X[9] column-major)
@@ -411,6 +435,42 @@ NLLS_DEV Dual2 cg_robustifydkernel(const double* st, double cost) {
     return d2add(d2mul(c, hs2), d2scale(d2log(d2add(a, b)), -1.0));
 }
 
+// The same value / gradient / Hessian in closed form (round 5): the second-order duals above carry 21 doubles through every operation -- twelve d2mul's,
+// most of the registers of the adaptive kinds' accumulate kernels.  With  u = log a,  v = log b  (a = w is1 exp(c hd), b = (1 - w) is2, S = a + b):
+//   rho = c hs2 - log S,   (log S)_i = pa u_i + pb v_i,   (log S)_ij = pa (u_i u_j + u_ij) + pb (v_i v_j + v_ij) - (log S)_i (log S)_j,   pa = a / S, pb = b / S
+// and u, v are sums of terms in ONE variable each (x0, x1, x2 the tangent steps of (1/s1, 1/s2, w) through their retractions at 0, x3 = c), so their
+// derivatives are a handful of scalars.  Kept beside the dual-number version, which is the generic statement of src/autodiff.jl:164-165 and the
+// check: nlls_check_analytic compares the two on the device (tests/test_gpu_parity.py).
+NLLS_DEV Dual2 cg_robustifydkernel_closed(const double* st, double c) {
+    const double b0 = st[0] > 0 ? st[0] : DBL_MIN, b1 = st[1] > 0 ? st[1] : DBL_MIN, b2 = st[2] > 0 ? st[2] : DBL_MIN;
+    const double w = b2 / (b2 + (1.0 - st[2])), omw = 1.0 - w, wo = w * omw;      // ZeroToOne: val / (1 + (val - v)) at step 0; d w / d x2 = w (1 - w)
+    const double s1 = b0 * b0, s2 = b1 * b1, hd = 0.5 * (s2 - s1), hs2 = 0.5 * s2;
+    const double a = w * b0 * exp(c * hd), b = omw * b1, iS = 1.0 / (a + b), pa = a * iS, pb = b * iS;
+    // u = log w + log is1 + c hd;  v = log(1 - w) + log is2
+    const double u0 = 1.0 - c * s1, u1 = c * s2, u2 = omw, u3 = hd;
+    const double u00 = -2.0 * c * s1, u11 = 2.0 * c * s2, u22 = -wo, u03 = -s1, u13 = s2;
+    const double v1 = 1.0, v2 = -w, v22 = -wo;
+    const double L0 = pa * u0, L1 = pa * u1 + pb * v1, L2 = pa * u2 + pb * v2, L3 = pa * u3;
+    Dual2 k;
+    k.v = c * hs2 - log(a + b);
+    k.g[0] = -L0; k.g[1] = c * s2 - L1; k.g[2] = -L2; k.g[3] = hs2 - L3;
+    const double h00 = -(pa * (u0 * u0 + u00) - L0 * L0);
+    const double h01 = -(pa * (u0 * u1) - L0 * L1);
+    const double h02 = -(pa * (u0 * u2) - L0 * L2);
+    const double h03 = -(pa * (u0 * u3 + u03) - L0 * L3);
+    const double h11 = 2.0 * c * s2 - (pa * (u1 * u1 + u11) + pb * (v1 * v1) - L1 * L1);
+    const double h12 = -(pa * (u1 * u2) + pb * (v1 * v2) - L1 * L2);
+    const double h13 = s2 - (pa * (u1 * u3 + u13) - L1 * L3);
+    const double h22 = -(pa * (u2 * u2 + u22) + pb * (v2 * v2 + v22) - L2 * L2);
+    const double h23 = -(pa * (u2 * u3) - L2 * L3);
+    const double h33 = -(pa * (u3 * u3) - L3 * L3);
+    k.h[0][0] = h00; k.h[0][1] = h01; k.h[0][2] = h02; k.h[0][3] = h03;
+    k.h[1][0] = h01; k.h[1][1] = h11; k.h[1][2] = h12; k.h[1][3] = h13;
+    k.h[2][0] = h02; k.h[2][1] = h12; k.h[2][2] = h22; k.h[2][3] = h23;
+    k.h[3][0] = h03; k.h[3][1] = h13; k.h[3][2] = h23; k.h[3][3] = h33;
+    return k;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-block evaluation  (src/residual.jl:44-111, src/autodiff.jl:81-93)
 // ------------------------------------------------------------------------------------------------
@@ -434,11 +494,16 @@ NLLS_DEV double block_cost(const double* __restrict__ vars, const uint32_t* voff
 // Everything the accumulate kernels need from one block, with ALL variables treated as free
 // (the reference's varflags specialisations only drop rows/columns of g and H; the kept entries
 // are identical -- src/residual.jl:57-111).
-template <int KIND>
+template <class R> struct ResJacCols { static constexpr int value = [] { int n = 0; for (int s = R::ADAPT; s < R::NDEPS; ++s) n += var_dof(R::SK[s], R::SD[s]); return n > 0 ? n : 1; }(); };
+// does the residual kind bring its own Jacobian (`jac`: residual and Jacobian w.r.t. the tangent of update() in closed form)?
+template <class R> concept HasJac = requires(const double* d, const double (*st)[MAXST], double* r, double (*J)[ResJacCols<R>::value]) { R::jac(d, st, r, J); };
+// ANALYTIC = false: everything through dual numbers (src/autodiff.jl as written) -- the reference statement the closed forms are checked against (nlls_check_analytic)
+template <int KIND, bool ANALYTIC = true>
 struct BlockGH {
     using R = Res<KIND>; using I = ResInfo<KIND>;
     static constexpr int NP = I::NP, M = R::M;
     double J[M][NP];        // jacobian
+    double Jw[M][NP], gw[NP];   // rho' J and 2 rho'' g: H(i, j) = sum_m Jw[m][i] J[m][j] + gw[i] g[j]  (residual.jl:91-101 with the common factors taken once per block)
     double g[NP];           // UN-weighted J'r (residual.jl:73)
     double cost;            // 0.5 * rho   (residual.jl:110)
     double dc, d2c;         // rho', rho'' (residual.jl:78 or :82-84)
@@ -502,25 +567,32 @@ struct BlockGH {
                 for (int j = 0; j < NP; ++j) hc[i][j] = c2[0].h[i][j]; }
             return;
         }
-        using T = Dual<NP>;
-        T sv[I::NS > 0 ? I::NS : 1][MAXST];
-        [&]<int... S>(std::integer_sequence<int, S...>) {
-            (var_load<R::SK[S + R::ADAPT], R::SD[S + R::ADAPT], T>(st[S + R::ADAPT], I::joff(S + R::ADAPT), sv[S]), ...);
-        }(std::make_integer_sequence<int, I::NS>{});
-        T r[M]; R::template eval<T>(data, sv, r);
+        double rv[M];
+        if constexpr (ANALYTIC && HasJac<R>) {
+            R::jac(data, st, rv, J);
+        } else {
+            using T = Dual<NP>;
+            T sv[I::NS > 0 ? I::NS : 1][MAXST];
+            [&]<int... S>(std::integer_sequence<int, S...>) {
+                (var_load<R::SK[S + R::ADAPT], R::SD[S + R::ADAPT], T>(st[S + R::ADAPT], I::joff(S + R::ADAPT), sv[S]), ...);
+            }(std::make_integer_sequence<int, I::NS>{});
+            T r[M]; R::template eval<T>(data, sv, r);
+#pragma unroll
+            for (int m = 0; m < M; ++m) { rv[m] = r[m].v;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) J[m][j] = r[m].d[j]; }
+        }
         double c = 0;
 #pragma unroll
-        for (int m = 0; m < M; ++m) { c += r[m].v * r[m].v;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) J[m][j] = r[m].d[j]; }
+        for (int m = 0; m < M; ++m) c += rv[m] * rv[m];
 #pragma unroll
         for (int j = 0; j < NP; ++j) { double s = 0;
 #pragma unroll
-            for (int m = 0; m < M; ++m) s += r[m].d[j] * r[m].v; g[j] = s; }
+            for (int m = 0; m < M; ++m) s += J[m][j] * rv[m]; g[j] = s; }
         double rho;
         if constexpr (R::ADAPT) {
             if (kernel_free) {                                  // residual.jl:79-88
-                Dual2 k = cg_robustifydkernel(st[0], c);
+                Dual2 k; if constexpr (ANALYTIC) k = cg_robustifydkernel_closed(st[0], c); else k = cg_robustifydkernel(st[0], c);
                 rho = k.v; dc = k.g[3]; d2c = k.h[3][3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { dck[i] = k.g[i];
@@ -529,14 +601,19 @@ struct BlockGH {
             } else cg_robustifydcost(st[0], c, rho, dc, d2c);   // residual.jl:76-78
         } else robustifydcost_fixed(rk, c, rho, dc, d2c);
         cost = 0.5 * rho;
+        const double d2c2 = 2 * d2c;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { gw[j] = d2c2 * g[j];
+#pragma unroll
+            for (int m = 0; m < M; ++m) Jw[m][j] = dc * J[m][j]; }
     }
     // local H / g entries over the non-kernel dof (residual.jl:91-101)
     NLLS_DEV double H(int i, int j) const {
         if constexpr (is_cost_kind<KIND>) return hc[i][j];
-        double s = 0;
+        double s = gw[i] * g[j];
 #pragma unroll
-        for (int m = 0; m < M; ++m) s += J[m][i] * J[m][j];
-        return s * dc + (2 * d2c) * g[i] * g[j]; }
+        for (int m = 0; m < M; ++m) s += Jw[m][i] * J[m][j];
+        return s; }
     NLLS_DEV double G(int i) const { return g[i] * dc; }
     // kernel border (residual.jl:86-88,103-107): d2/dkernel_k dvar_i, d2/dkernel^2, d/dkernel
     NLLS_DEV double Hkv(int k, int i) const { return g[i] * d2ck[k][3]; }

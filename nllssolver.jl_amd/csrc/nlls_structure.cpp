@@ -56,7 +56,7 @@ void hot_set(nlls_ctx* c, std::vector<HotItem>& v) {
             if (G.fold && E.slot != G.fold_ls) continue;          // folded sweep: the heavy lists are never read
             hot(v, E.data); hot(v, E.rows); hot(v, E.light); hot(v, E.heavy); hot(v, E.hvoff);
             if (!E.compact) { hot(v, E.voff); hot(v, E.dest); }
-            hot(v, E.fslot); hot(v, E.ftiles); }
+            hot(v, E.fslot); hot(v, E.ftiles); hot(v, E.frowx); }
         if (G.fold) { hot(v, G.frows); hot(v, G.fcons); hot(v, G.fslab); }
         if (G.cost_list < 0 || !c->info.is_sparse) { hot(v, G.data); hot(v, G.voff); }
         hot(v, G.fixedcost); hot(v, G.dense.data); hot(v, G.dense.voff); hot(v, G.dense.brow);
@@ -145,7 +145,7 @@ static int build_fold(nlls_ctx* c, Group& G, const ResDesc& d, const nlls_cost_g
     uint64_t slab = 0; uint32_t max_img = 0;
     for (size_t ti = 0; ti < HL.light.size(); ++ti) { const Tile& t = HL.light[ti]; FoldTile& ft = ftiles[ti]; ft = FoldTile{};
         if (slab > 0xFFFF0000ull) return NLLS_OK;
-        ft.slab_off = (uint32_t)slab; uint32_t tile_acc = 0;
+        ft.slab_off = (uint32_t)slab;
         for (int h = 0; h < nd - 1; ++h) { const FoldHeavy& F = fh[h]; if (G.lists[F.slot].n == 0) continue;
             std::vector<int32_t> rows_here; std::vector<uint32_t> count;
             for (uint32_t e = t.e0; e < t.e1; ++e) { const int64_t k = LL.cost[e]; const uint64_t bv = bi[in.varind[k * nd + F.slot] - 1]; if (!bv) continue;
@@ -156,12 +156,27 @@ static int build_fold(nlls_ctx* c, Group& G, const ResDesc& d, const nlls_cost_g
             ft.ns[h] = (uint8_t)rows_here.size(); fh[h].maxns = std::max<int32_t>(fh[h].maxns, (int32_t)rows_here.size());
             for (size_t j = 0; j < rows_here.size(); ++j) cons[row_base[h] + rows_here[j]].push_back((uint32_t)(slab + (uint64_t)j * F.cw));
             slab += (uint64_t)rows_here.size() * F.cw; }
-        (void)tile_acc; }
+        }
     // accumulator copies: about a thousand doubles of LDS per heavy slot (conflicts of a wavefront's lanes on one address serialise: a slot every lane adds to gets 16)
     for (int h = 0; h < nd - 1; ++h) { FoldHeavy& F = fh[h]; if (!F.cw || !F.maxns) { F.copies = 1; continue; }
-        int cp = 1; while (cp < 16 && (int64_t)2 * cp * F.maxns * F.cw <= 1024) cp *= 2; F.copies = cp; }
-    for (size_t ti = 0; ti < HL.light.size(); ++ti) { const Tile& t = HL.light[ti]; const uint32_t dsz = (uint32_t)c->blocksizes[LL.rows[t.row0]];
-        uint32_t need = t.data_len + t.b_len + t.nrows * ACC_COPIES * (dsz * (dsz + 1) / 2 + dsz);
+        int cp = 1; while (cp < 16 && (int64_t)2 * cp * F.maxns * F.cw <= 1024) cp *= 2; F.copies = cp; }   // (measured at config 5: 2048 doubles per heavy slot 73 us against 68 -- the zero fill and the sum of more copies cost more than the conflicts they spare)
+    // the light rows' own off-diagonal blocks (ls, t): ONE writer each (registers -> HBM) or shared by all entries of the row (summed in the row's accumulator); anything in between: not folded
+    uint32_t uniq = 0, shared = 0; std::vector<uint32_t> rowx(LL.rows.size() * 4, DEST_NONE);
+    for (const Tile& t : HL.light) if (t.flags & TILE_PARTIAL) return NLLS_OK;      // rows other lists add to as well
+    for (int t = 0; t < nd; ++t) { if (t == ls) continue; bool any = false, u = true, sh = true; std::vector<uint32_t> tmp;
+        for (size_t rr = 0; rr < LL.rows.size(); ++rr) { tmp.clear();
+            for (int64_t e = LL.rowptr[rr]; e < LL.rowptr[rr + 1]; ++e) if (HL.dest[(size_t)e * nd + t] != DEST_NONE) tmp.push_back(HL.dest[(size_t)e * nd + t]);
+            if (tmp.empty()) continue;
+            any = true;
+            if (tmp.size() != (size_t)(LL.rowptr[rr + 1] - LL.rowptr[rr])) sh = false;
+            for (size_t i = 1; i < tmp.size(); ++i) if (tmp[i] != tmp[0]) sh = false;
+            rowx[rr * 4 + t] = tmp[0];
+            std::sort(tmp.begin(), tmp.end()); for (size_t i = 1; i < tmp.size(); ++i) if (tmp[i] == tmp[i - 1]) { u = false; break; } }
+        if (!any) continue;
+        if (u) uniq |= 1u << t; else if (sh) shared |= 1u << t; else return NLLS_OK; }
+    const uint32_t dsl = (uint32_t)dof(ls); uint32_t nw = dsl * (dsl + 1) / 2 + dsl; for (int t = 0; t < nd; ++t) if (shared >> t & 1) nw += dsl * (uint32_t)dof(t);
+    for (size_t ti = 0; ti < HL.light.size(); ++ti) { const Tile& t = HL.light[ti];
+        uint32_t need = t.nrows * 2u /* FOLD_ROW_COPIES */ * nw;
         for (int h = 0; h < nd - 1; ++h) need += (uint32_t)ftiles[ti].ns[h] * (uint32_t)fh[h].copies * (uint32_t)fh[h].cw;
         max_img = std::max(max_img, need); }
     if ((size_t)(max_img + 2) * sizeof(double) > 64 * 1024) return NLLS_OK;
@@ -171,22 +186,14 @@ static int build_fold(nlls_ctx* c, Group& G, const ResDesc& d, const nlls_cost_g
             if (h < nd - 1) { sl = eslot[(size_t)e * (nd - 1) + h]; cp = erank[(size_t)e * (nd - 1) + h] & (uint32_t)(fh[h].copies - 1); }
             w |= (sl | cp << 6) << (10 * h); }
         fslot[(size_t)e] = w; }
-    // which blocks (ls, t) of the light rows have exactly one writer (plain LDS stores instead of LDS atomics)
-    uint32_t uniq = 0;
-    for (int t = 0; t < nd; ++t) { if (t == ls) continue; bool u = true; std::vector<uint32_t> tmp;
-        for (size_t rr = 0; rr < LL.rows.size() && u; ++rr) { tmp.clear();
-            for (int64_t e = LL.rowptr[rr]; e < LL.rowptr[rr + 1]; ++e) if (HL.dest[(size_t)e * nd + t] != DEST_NONE) tmp.push_back(HL.dest[(size_t)e * nd + t]);
-            std::sort(tmp.begin(), tmp.end()); for (size_t i = 1; i < tmp.size(); ++i) if (tmp[i] == tmp[i - 1]) { u = false; break; } }
-        if (u) uniq |= 1u << t; }
     std::vector<uint32_t> fcons; fcons.reserve((size_t)(slab / 8 + 16));
     for (size_t r = 0; r < frows.size(); ++r) { frows[r].cbeg = (uint32_t)fcons.size(); fcons.insert(fcons.end(), cons[r].begin(), cons[r].end()); frows[r].cend = (uint32_t)fcons.size(); }
     EntryList& EL = G.lists[ls];
-    HIPCHK(EL.fslot.upload(fslot)); HIPCHK(EL.ftiles.upload(ftiles));
+    HIPCHK(EL.fslot.upload(fslot)); HIPCHK(EL.ftiles.upload(ftiles)); HIPCHK(EL.frowx.upload(rowx));
     HIPCHK(G.frows.upload(frows)); HIPCHK(G.fcons.upload(fcons)); HIPCHK(G.fslab.alloc(std::max<uint64_t>(slab, 1)));
-    G.nfrows = (int64_t)frows.size(); G.fold_lds = max_img; G.fold_unique = uniq; G.fold_ls = ls; G.fold_nh = nd - 1;
+    G.nfrows = (int64_t)frows.size(); G.fold_lds = max_img; G.fold_unique = uniq; G.fold_shared = shared; G.fold_ls = ls; G.fold_nh = nd - 1;
     for (int h = 0; h < FOLD_MAX_HEAVY; ++h) G.fh[h] = fh[h];
     // the heavy rows are written whole by the gather launch: no zero fill in front of the sweep on their account (a sharded upload zeroes every reduced row anyway: build_structure)
-    for (const FoldRow& fr : frows) { (void)fr; }
     for (int T = 0; T < nd; ++T) if (T != ls && G.lists[T].n > 0) for (int64_t br : hls[T].rows) row_zero[br] = 0;
     G.fold = true;
     return NLLS_OK;

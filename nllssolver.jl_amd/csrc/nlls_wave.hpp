@@ -68,6 +68,38 @@ NLLS_DEV double block_max(double v, double* red) {
     return t;
 }
 
+// Runs of equal keys over the lanes of a wavefront, cut at the 16-lane rows the DPP shifts work in (entries of an entry list are sorted by block row: the
+// lanes of one row are neighbours).  rank = position of the lane in its (cut) run, tail = last lane of it.  `key` must not be 0.
+struct WaveRuns { int rank; bool tail; int maxstep; };
+NLLS_DEV WaveRuns wave_runs(uint32_t key) {
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true);   // row_shr:1 -- the first lane of a 16-lane row reads 0
+    const unsigned long long m = __ballot(prev != key);                     // run starts
+    const int start = 63 - __clzll((long long)(m & (~0ull >> (63 - lane))));
+    WaveRuns r; r.rank = lane - start; r.tail = lane == 63 || ((m >> (lane + 1)) & 1ull);
+    int mx = 0;                                                              // the longest run of the wavefront decides how many doubling steps a sum takes (uniform)
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) if (__ballot(r.rank >= s)) mx = s;
+    r.maxstep = mx;
+    return r;
+}
+template <int CTRL>
+NLLS_DEV double dpp_get(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true));
+}
+// Sum of v over the lanes of this lane's run, valid in the run's TAIL lane: a segmented inclusive scan in four DPP row shifts on the vector ALU -- where the lanes
+// of a run would otherwise all add to ONE address of an LDS accumulator: same-address LDS atomics serialise at the full latency of a read-modify-write, lane by lane
+// (measured at BASELINE config 5: ten lanes per point row = 17 of a 59 us launch; a crossbar-shuffle version of this sum was SLOWER than the atomics: it queues in the
+// same LDS pipe)
+NLLS_DEV double wave_run_sum(double v, const WaveRuns& r) {
+    if (r.maxstep >= 1) { const double t = dpp_get<0x111>(v); v += r.rank >= 1 ? t : 0.0; }
+    if (r.maxstep >= 2) { const double t = dpp_get<0x112>(v); v += r.rank >= 2 ? t : 0.0; }
+    if (r.maxstep >= 4) { const double t = dpp_get<0x114>(v); v += r.rank >= 4 ? t : 0.0; }
+    if (r.maxstep >= 8) { const double t = dpp_get<0x118>(v); v += r.rank >= 8 ? t : 0.0; }
+    return v;
+}
+
 // element (i of slot SA, j of slot SB) of the block's local Hessian / gradient (residual.jl:91-107)
 template <int KIND, int SA, int SB>
 NLLS_DEV double h_elem(const BlockGH<KIND>& B, int i, int j) {

@@ -374,6 +374,27 @@ def test_so3_ba():                   # BASELINE config 5 shapes (new kinds)
     check_problem(q, unfixed=unfixed, expect_sparse=1, lam_scale=1e-4)
 
 
+def test_closed_forms_against_dual_numbers():
+    """Round 5: the pinhole kinds bring their Jacobian in closed form (Res<KIND>::jac) and the adaptive kernel's second derivatives are closed forms
+    (cg_robustifydkernel_closed); the statement through dual numbers (src/autodiff.jl:81-93,164-165: Dual<N> through update(), Dual2 over (kernel, cost)) stays
+    in the library as the check.  nlls_check_analytic evaluates EVERY block of the problem both ways on the device: J to 1e-14, everything else to 1e-12 of the
+    largest magnitude of the quantity in its block (the tolerance is stated here: fp64, two different orders of the same arithmetic)."""
+    for adaptive, robust in ((True, None), (False, N.HuberKernel(0.05)), (False, N.GemanMcclureKernel(0.1))):
+        p = synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(40, 2000, 0.2, seed=11, adaptive=adaptive, robust=robust), 1e-2, 1e-2)
+        ctx = _capi.Context(0)
+        ctx.upload(p.var_kind, p.var_dim, blockindices(p), p.groups())
+        ctx.set_variables(p.variables)
+        d = ctx.check_analytic(); ctx.close()
+        assert d["J"] < 1e-14 and d["Jtr"] < 1e-13 and d["cost"] < 1e-13 and d["drho"] < 1e-12 and d["d2rho"] < 1e-11, d
+        if adaptive:
+            assert 0 < d["dkernel"] < 1e-11 and 0 < d["d2kernel"] < 1e-10, d      # (0 would mean the two paths are the same code)
+    # kinds without a closed form go through dual numbers on both sides: identical
+    q = synthetic.perturb_ba_problem(synthetic.create_ba_problem(30, 800, 0.2, seed=3, robust=N.HuberKernel(0.01)), 1e-3, 1e-3)
+    ctx = _capi.Context(0); ctx.upload(q.var_kind, q.var_dim, blockindices(q), q.groups()); ctx.set_variables(q.variables)
+    d = ctx.check_analytic(); ctx.close()
+    assert d["J"] == 0 and d["Jtr"] == 0 and d["cost"] == 0, d
+
+
 def test_ba_band_solver():           # narrow-band reduced system -> persistent-workgroup bordered-band LDL'
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(120, 4000, 0.06, seed=8), 1e-3, 1e-3)
     info = check_problem(p, expect_sparse=1, expect_schur=1)
