@@ -102,13 +102,21 @@ def self_launch(n, deadline_s=None):
     return 0
 
 
+def oracle_loop_fixture(workload, steps):
+    try:
+        rec = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_trials.json")))[workload][f"iterations_{steps}"]
+        return {"oracle_trials": rec["trials"], "oracle_final_cost": rec["final_cost"]}
+    except Exception:
+        return {"oracle_trials": None, "oracle_final_cost": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ba_1kx100k", choices=sorted(CONFIGS))
-    ap.add_argument("--solver", default="default", choices=["default", "dense", "chain", "deterministic", "windowed"],
+    ap.add_argument("--solver", default="default", choices=["default", "dense", "chain", "deterministic", "windowed", "nofloor"],
                     help="reduced-system solver: block cyclic reduction of the band (default), the dense MFMA LDL' (NLLS_FLAG_NO_BAND), "
                          "the round-1 twisted chain kernels (NLLS_FLAG_NO_BCR), or the atomics-free assembly (NLLS_FLAG_DETERMINISTIC)")
     ap.add_argument("--shuffle-cameras", type=int, default=None, metavar="SEED",
@@ -187,7 +195,7 @@ def main():
         workload_desc["camera_labels"] = f"permuted (seed {args.shuffle_cameras})"
     nobs = problem.ncosts()
     start_vars = problem.variables.copy()
-    flags = {"default": 0, "dense": _capi.FLAG_NO_BAND, "chain": _capi.FLAG_NO_BCR, "deterministic": _capi.FLAG_DETERMINISTIC, "windowed": _capi.FLAG_NO_TILE_SPARSE}[args.solver]
+    flags = {"default": 0, "dense": _capi.FLAG_NO_BAND, "chain": _capi.FLAG_NO_BCR, "deterministic": _capi.FLAG_DETERMINISTIC, "windowed": _capi.FLAG_NO_TILE_SPARSE, "nofloor": _capi.FLAG_NO_PIVOT_FLOOR}[args.solver]
 
     ls = ShardedLS(problem, np.ones(problem.nvariables, bool), flags=flags, device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged, force_collectives=force_dist)
     info = ls.info
@@ -442,7 +450,10 @@ def main():
                    # of LM trials (damped solve + retraction + cost sweep) is the figure that does not depend on --steps
                    "lm_trials_per_s": round(data.linearsolvers / elapsed, 1), "lm_trials_per_s_median": round(trials_median, 1),
                    "noise_floor_iterations": noise_floor_iterations, "noise_floor_from_iteration": floor_at,
-                   "first_iteration_with_a_rejected_trial": first_reject, "iterations_with_rejected_trials": n_reject_iters, "trials_per_iteration": trials_trace},
+                   "first_iteration_with_a_rejected_trial": first_reject, "iterations_with_rejected_trials": n_reject_iters, "trials_per_iteration": trials_trace,
+                   # the CPU oracle's own loop (the reference's full sparse LDL') over the same K iterations from the same start: a committed fixture
+                   # (tests/golden/oracle_trials.json, tools/oracle_trials.py), not a run on this box
+                   **oracle_loop_fixture(args.workload, args.steps)},
             "spread": spread,
             "roofline": roofline, "roofline_solve": roofline_solve, "roofline_solve_dense": roofline_solve_dense, "cpu_baseline": cpu,
         }

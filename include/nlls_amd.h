@@ -149,6 +149,10 @@ typedef struct nlls_info {
                                          (ldl_analyze, src/linearsystem.jl:52,68) and does not care how the caller numbers the variables; neither does x here */
 #define NLLS_FLAG_NO_TILE_SPARSE 0x200 /* reduced solver: never the tile-sparse LDL' (solve_mode 3: nested dissection of the reduced blocks' graph, factored level by
                                          level of its elimination tree); the reduced system that is neither a narrow band nor small then takes the dense / windowed LDL' */
+#define NLLS_FLAG_NO_PIVOT_FLOOR 0x400 /* damped solves (block cyclic reduction, tile-sparse LDL'): no pivot floor.  Default (round 5): a pivot that has lost eleven orders of
+                                         magnitude against its unknown's original diagonal entry is dropped -- the unknown gets no step -- and counted (nlls_get_solve_stats()[10]),
+                                         the rule undamped solves have had since round 2.  Silent while lambda / |diagonal| > 1e-11; below that it keeps rounding noise in the
+                                         gauge directions of a converged problem from deciding the trial (the reference's LDL' divides by that noise: /root/reference/src/linearsolver.jl:28-32) */
 
 /* variable-set ids for the on-device copies of problem.variables / varnext / varbest
  * (src/problem.jl:9-12) */

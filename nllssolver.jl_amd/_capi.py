@@ -17,6 +17,7 @@ FLAG_FORCE_ATOMIC, FLAG_NO_SCHUR, FLAG_FORCE_SPARSE, FLAG_NO_BAND, FLAG_NO_TWIST
 FLAG_PRESHARDED = 128
 FLAG_NO_REORDER = 256
 FLAG_NO_TILE_SPARSE = 512
+FLAG_NO_PIVOT_FLOOR = 1024
 VARS_CURRENT, VARS_NEXT, VARS_BEST = 0, 1, 2
 
 # every symbol include/nlls_amd.h declares (checked by tests/test_capi_symbols.py)

@@ -117,43 +117,62 @@ __global__ __launch_bounds__(256) void bcr_convert_kernel(BcrGeom g, const doubl
 // (A[i][kk] = w_i) and, scaled by -1/d, the B operand: one MFMA is the whole rank-1 update.  A second accumulator starts
 // as the identity and ends as inv(L).  Out: Wd (row-major, LDS) = the factored tile (L Delta below, Delta on the
 // diagonal), Lid = inv(L)' ([k][j] = inv(L)[j][k]), dd[0..15] = Delta, dd[16..31] = 1 / Delta.
-template <bool FLOOR>
-BCR_DEV void bcr_factor(const double* T0, bool from_regs, const bdouble4_t Ain, double* Wd, double* Lid, double* dd, int* status, int pivbase, bool report, const double* diag0, double relfloor) {
-    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    // FLOOR: the floor of pivot li is a fraction of the ORIGINAL diagonal entry of that unknown (loaded once, broadcast per pivot)
-    double fl = 0.0; if constexpr (FLOOR) fl = diag0[pivbase + li] * relfloor;
-    bdouble4_t A, Bt;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const double t = T0[(lk + 4 * r) * BP + li]; A[r] = from_regs ? Ain[r] : t; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
-    // The pivot loop is a chain of dependent vector instructions around the two MFMAs: nothing else is in it.  Delta is
-    // read off the diagonal of the finished tile (entry (k, k) is final once pivot k - 1 has been applied), 1 / Delta is
-    // formed again by sixteen lanes at once (same instructions, same bits), zero / NaN pivots are looked for there too.
+// the sixteen pivots of a tile: a chain of dependent vector instructions around the two MFMAs, nothing else.  GUARD: a vanished pivot (|d| <= fl, the floor of its
+// unknown) is treated as infinite -- its rank-1 update is multiplied by 0, its unknown comes out 0; a NaN pivot is left alone (it is reported).
+template <bool GUARD>
+BCR_DEV void bcr_pivot_chain(bdouble4_t& A, bdouble4_t& Bt, double fl, int li, int lk) {
 #pragma unroll
     for (int k = 0; k < 15; ++k) {
         const int q = k & 3, r = k >> 2;
         const double w = A[r], bt = Bt[r];
+        bool drop = false; if constexpr (GUARD) drop = (__ballot(fabs(w) <= fl) >> (16 * q + k)) & 1ull;     // (lane 16 q + k holds pivot k and -- li = k -- its floor)
         double dk = bcr_readlane(w, 16 * q + k);
-        if constexpr (FLOOR) { if (fabs(dk) <= bcr_readlane(fl, k)) dk = 1e300; }      // a vanished pivot: as if infinite (its unknown comes out 0); a NaN pivot is left alone and reported
         double rdk = __builtin_amdgcn_rcp(dk);
         const bool rowq = lk == q;
         const double am = (rowq && li > k) ? w : 0.0;
         const double bm = rowq ? bt : 0.0;
         rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk); rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
+        if constexpr (GUARD) rdk = drop ? 0.0 : rdk;
         A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
         Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);
     }
-    {
-        double dsel = A[0];
+}
+template <bool FLOOR>
+BCR_DEV void bcr_factor(const double* T0, bool from_regs, const bdouble4_t Ain, double* Wd, double* Lid, double* dd, int* status, int pivbase, bool report, double fl) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    // FLOOR: fl = the floor of pivot li, a fraction of the ORIGINAL diagonal entry of that unknown (handed in by the caller: see bcr_panel_kernel)
+    if constexpr (!FLOOR) fl = 0.0;
+    bdouble4_t A, Bt;
 #pragma unroll
-        for (int r = 1; r < 4; ++r) dsel = (li >> 2) == r ? A[r] : dsel;
-        bool dropped = false;
-        if constexpr (FLOOR) { if (fabs(dsel) <= fl) { dsel = 1e300; dropped = true; } }
-        if constexpr (FLOOR) { if (report) { const unsigned long long m = __ballot(dropped && (li & 3) == lk); if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(status + 4, __popcll(m)); } }   // status[4]: pivots dropped by the floor (nlls_get_solve_stats)
-        if ((li & 3) == lk) {
-            double rd = __builtin_amdgcn_rcp(dsel); rd = fma(fma(-dsel, rd, 1.0), rd, rd); rd = fma(fma(-dsel, rd, 1.0), rd, rd);
-            dd[li] = dsel; dd[16 + li] = rd;
-            if (report && !(fabs(dsel) > 0.0)) atomicCAS(status, 0, 1 + pivbase + li);
+    for (int r = 0; r < 4; ++r) { const double t = T0[(lk + 4 * r) * BP + li]; A[r] = from_regs ? Ain[r] : t; Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
+    // Delta is read off the diagonal of the finished tile (entry (k, k) is final once pivot k - 1 has been applied), 1 / Delta is
+    // formed again by sixteen lanes at once (same instructions, same bits), zero / NaN pivots are looked for there too.
+    // The floor (round 5: on EVERY solve, damped ones too) stays off the chain: the tile is factored as if no pivot could vanish, the sixteen pivots it used are held
+    // against their floors afterwards -- one vector compare, one ballot -- and only a tile that met a vanished pivot is factored again from the kept copy, guarded
+    // (the guard inside the chain, on every pivot of every tile: bcr_panel_kernel 18.9 against 16.2 us per level, seven levels per solve).
+    const bdouble4_t A0 = A;
+    bcr_pivot_chain<false>(A, Bt, 0.0, li, lk);
+    auto diag_of = [&]() { double d = A[0];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) d = (li >> 2) == r ? A[r] : d;
+        return d; };
+    double dsel = diag_of();
+    bool dropped = false;
+    if constexpr (FLOOR) {
+        if (__ballot((li & 3) == lk && fabs(dsel) <= fl) != 0) {          // (uniform: rare -- lambda far below the rounding level of the diagonal)
+            A = A0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Bt[r] = (lk + 4 * r == li) ? 1.0 : 0.0;
+            bcr_pivot_chain<true>(A, Bt, fl, li, lk);
+            dsel = diag_of();
+            if (fabs(dsel) <= fl) { dsel = 1e300; dropped = true; }
+            if (report) { const unsigned long long m = __ballot(dropped && (li & 3) == lk); if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(status + 4, __popcll(m)); }   // status[4]: pivots dropped by the floor (nlls_get_solve_stats)
         }
+    }
+    if ((li & 3) == lk) {
+        double rd = __builtin_amdgcn_rcp(dsel); rd = fma(fma(-dsel, rd, 1.0), rd, rd); rd = fma(fma(-dsel, rd, 1.0), rd, rd);
+        dd[li] = dsel; dd[16 + li] = rd;
+        if (report && !(fabs(dsel) > 0.0)) atomicCAS(status, 0, 1 + pivbase + li);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Wd[(lk + 4 * r) * BP + li] = A[r]; Lid[li * BP + (lk + 4 * r)] = Bt[r]; }
@@ -287,6 +306,7 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     const int hw = wave < 4 ? wave - 1 : wave - 2;    // helper index of waves 1, 2, 3, 5, 6, 7 (wave 4 shares wave 0's SIMD -- its matrix pipe
                                                       // and its vector issue: it stays out of the way while wave 0 works)
     const bool helper = wave != 0 && wave != 4;
+    double flc = 0.0;                                 // pivot floor of the tile wave 0 factors next (bcr_factor): the block's floors are put into LDS by the landing
     if constexpr (BAND1) {   // the border corner (cp[0]: what the root sums the blocks' shares against), by the lead workgroup of the launch's first job
         if (lead && blockIdx.x / NCH == 0 && tid < 256) { const int ca = tid >> 4, cb = tid & 15, nbr = g.nbd + 1; double v = 0.0;
             if (ca < nbr && cb < nbr) { const int hi = ca > cb ? ca : cb, lo = ca > cb ? cb : ca; v = a.Sb[(size_t)g.n_band * g.H + hi + nbr * lo]; }
@@ -308,6 +328,9 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     double* dvec = Wp + 2 * PR * 16 * BP;             // [2][32]
     double* Li = dvec + 64;                           // [2][16][BP]
     const int oDt = 0, oXt = ND * BTS, oWp = oXt + BCR_CH * NT * BTS, odv = oWp + 2 * PR * 16 * BP, oSpare = odv + 64 + 2 * 16 * BP;   // the same as offsets; a spare tile last
+    double* flds = sm + oSpare + BTS;                 // [16 NT] pivot floors of the block's unknowns (FLOOR).  Through LDS, not a load per tile: wave 0 has export STORES in flight, and a global load
+                                                      // behind them waits for all of them (vmcnt counts in order) -- on the pivot chain that was +2.7 us per level
+    if constexpr (FLOOR) { if (tid < 16 * NT) flds[tid] = g.ws[g.odg + 16 * NT * job.i + tid] * a.relfloor; }
     // ---- landing.  First (every thread): D_i and block column 0 of the X rows -- all that the first factorisation and the first
     // panel need.  The other X columns are requested by the six helper waves into registers now and put into LDS behind wave 0's
     // first factorisation.  Word (hi, lo) of a tile: the left neighbour's rows come in transposed.
@@ -402,7 +425,8 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     bdouble4_t diag = {0, 0, 0, 0};
     for (int J = 0; J < NT; ++J) {
         double* Wb = Wp + (J & 1) * PR * 16 * BP; double* Lid = Li + (J & 1) * 16 * BP; double* db = dvec + (J & 1) * 32;
-        if (wave == 0) bcr_factor<FLOOR>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, 16 * NT * job.i + 16 * J, lead, g.ws + g.odg, a.relfloor);
+        if (wave == 0) { if constexpr (FLOOR) flc = flds[16 * J + (lane & 15)];
+                         bcr_factor<FLOOR>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, 16 * NT * job.i + 16 * J, lead, flc); }
         else if (helper) { if (J > 0) { BCR_STAMP(); updates(J - 1, hw, 6); BCR_STAMP(); exports(J - 1, hw, 6); } else land_rest(); }
         BCR_STAMP();
 #ifdef BCR_STAMPS
@@ -464,10 +488,16 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(std::conditional_t<T
         RX = Q0 >= Tq ? 0 : (Tq - Q0 < DCH ? Tq - Q0 : DCH);
         lead = ch == 0;
     }
+    double flc = 0.0;                                 // pivot floor of the tile wave 0 factors next (bcr_factor)
     auto trow = [&](int R) { if constexpr (TSP) return 0; else { const int q = Q0 + R; return (!windowed || q < a.wq) ? NT * (a.k + 1) + q : a.wstrip + (q - a.wq); } };   // actual tile row of X row R
     if (RX == 0 && !lead) return;
     double* Dt = sm; double* Xt = Dt + ND * BTS; double* Wp = Xt + DCH * NT * BTS; double* dvec = Wp + 2 * PR * 16 * BP; double* Li = dvec + 64;
     const int oDt = 0, oXt = ND * BTS, oWp = oXt + DCH * NT * BTS, odv = oWp + 2 * PR * 16 * BP, oSpare = odv + 64 + 2 * 16 * BP;
+    // pivot floors (TSP && FLOOR) of the tile's 16 NT unknowns: requested HERE, before this wavefront has any store in flight (a load behind its export stores would
+    // wait for all of them: bcr_panel_kernel), kept across wave 0's lanes -- unknown u in lane u % 64 of register u / 64 -- and handed to the lanes of a tile by a
+    // crossbar shuffle (this kernel's LDS is full: 160 KB at NT = 8)
+    double fla = 0.0, flb = 0.0;
+    if constexpr (TSP && FLOOR) if (wave == 0) { fla = a.diag0[c0 + lane] * a.relfloor; if constexpr (NT > 4) flb = a.diag0[c0 + 64 + lane] * a.relfloor; }
     // ---- landing: element (row a2, column b2) of a tile; consecutive threads walk a column of S (consecutive addresses)
     {
         constexpr int DQ = (ND * 256 + BCR_T - 1) / BCR_T, XQ = (DCH * NT * 256 + BCR_T - 1) / BCR_T;
@@ -551,8 +581,8 @@ __global__ __launch_bounds__(BCR_T) void dense_panel_kernel(std::conditional_t<T
     bdouble4_t diag = {0, 0, 0, 0};
     for (int J = 0; J < NT; ++J) {
         double* Wb = Wp + (J & 1) * PR * 16 * BP; double* Lid = Li + (J & 1) * 16 * BP; double* db = dvec + (J & 1) * 32;
-        if (wave == 0) { if constexpr (TSP && FLOOR) bcr_factor<true>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, c0 + 16 * J, lead, a.diag0, a.relfloor);
-                         else bcr_factor<false>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, c0 + 16 * J, lead, nullptr, 0.0); }
+        if (wave == 0) { if constexpr (TSP && FLOOR) { flc = __shfl((J & 4) ? flb : fla, 16 * (J & 3) + (lane & 15), 64); bcr_factor<true>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, c0 + 16 * J, lead, flc); }
+                         else bcr_factor<false>(Dt + bcr_dtile(J, J) * BTS, J > 0, diag, Wb + J * 16 * BP, Lid, db, a.status, c0 + 16 * J, lead, 0.0); }
         else if (helper && J > 0) { updates(J - 1, hw, 6); exports(J - 1, hw, 6); }
         bcr_lds_barrier();
         if (J + 1 < NT) {
@@ -1156,7 +1186,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     //  and 5 wavefronts each, six per CU -- so that nothing waits on a workgroup that has not started)
     if (N > 4 * 256) fused_backward = false;
     geom.ws = ws.p;
-    panel_lds = sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS);
+    panel_lds = sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS + 128);
     back_lds = sizeof(double) * ((size_t)RXT * 16 + NT * 64 + 2 * NT * 16 + (size_t)NO * 256 + 256 + 16);
     { const char* e = getenv("NLLS_BCR_CHROWS_SLOTS"); chrows_slots = e ? atoi(e) : 256; }
     { const char* e = getenv("NLLS_BCR_FOLD_CONVERT"); fold_convert = e && e[0] == '1'; }      // (built, parity-green, no gain: 312.5 against 313.0 us per trial -- the first level's landing from the band costs what the launch saved)

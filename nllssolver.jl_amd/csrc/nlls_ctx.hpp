@@ -297,6 +297,7 @@ struct nlls_ctx {
     int64_t n_slow_acc = 0; int slow_nd_acc = 0, slow_nd_noacc = 0; size_t elim_lds_acc = 0, elim_lds_noacc = 0;
     int64_t n_band = 0; int nbd = 0, bw = 0;   // reduced ordering: [banded part | border dof | rhs]
     int red_reordered = 0; int64_t bw_caller = -1;   // the banded part is in reverse Cuthill-McKee order (narrower than the caller's block order, whose half bandwidth was bw_caller)
+    double damped_floor = 1e-11;             // pivot floor of DAMPED solves (block cyclic reduction and tile-sparse LDL'): relative to the unknown's original diagonal entry; 0 with NLLS_FLAG_NO_PIVOT_FLOOR
     int solve_mode = 0, band_CH = 0, band_H = 0, band_SEG = 0, band_NSEG = 0;
     bool band_blocked = true;                // blocked (MFMA) band factorisation when the bandwidth allows
     bool band_twisted = true;               // factor the band from both ends at once (two workgroups) when the layout allows

@@ -2864,14 +2864,18 @@ int enqueue_reduced_solve(nlls_ctx* c) {
         hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(64), 0, c->stream, c->S.p, c->s_ptr(), n, npad, c->d_status.p);
     } else if (c->solve_mode == SOLVE_TSPARSE) {
         // (an undamped step of a gauge-free problem: vanished pivots are dropped and counted, the band solver's rule -- see below)
-        if (c->tsp.enqueue(c->stream, c->S.p, c->s_ptr(), c->d_status.p, c->lambda == 0.0 ? 1e-11 : 0.0) != NLLS_OK) return herr(c, hipGetLastError(), "tile-sparse reduced solve launch");
+        if (c->tsp.enqueue(c->stream, c->S.p, c->s_ptr(), c->d_status.p, c->lambda == 0.0 ? 1e-11 : c->damped_floor) != NLLS_OK) return herr(c, hipGetLastError(), "tile-sparse reduced solve launch");
     } else if (band && c->bcr.ready) {
         // an UNDAMPED step (Newton, dogleg's Gauss-Newton step) of a gauge-free problem: S is singular -- vanished pivots are dropped
         // (src/iterators.jl:47-115 asks for the Gauss-Newton step; any exact factorisation of a singular system returns rounding / rounding)
         // Rule: a pivot that has lost eleven orders of magnitude against its original diagonal entry is dropped (its unknown gets no step) and
         // COUNTED (status[4] -> nlls_get_solve_stats()[10]); a NaN pivot is not touched and is reported like any bad pivot.  Both assemblies
         // of the tiles (atomics, and the deterministic slab + gather) take it; the chain and dense solvers have no floor.
-        const double pivot_floor = c->lambda == 0.0 ? 1e-11 : 0.0;
+        // Round 5: the SAME rule under damping (c->damped_floor = 1e-11 unless NLLS_FLAG_NO_PIVOT_FLOOR).  A damped pivot is at least lambda, so the rule is silent while
+        // lambda / |original diagonal| > 1e-11; below that -- the late iterations of a converged, gauge-free problem, lambda at 1e-19 of the diagonal -- the pivots of the
+        // gauge directions are rounding noise of either sign, the step along them noise / noise, and whether the trial is accepted a coin toss: at BASELINE config 4
+        // 29-31 damped solves for 20 iterations (the oracle's LDL': 24) against 20 with the rule, ending at the oracle's cost to 12 digits.
+        const double pivot_floor = c->lambda == 0.0 ? 1e-11 : c->damped_floor;
         if (c->bcr.enqueue(c->stream, c->elim_slab ? (const double*)nullptr : c->S.p, c->s_ptr(), c->d_status.p, pivot_floor) != NLLS_OK) return herr(c, hipGetLastError(), "block cyclic reduction launch");
     } else if (band) {
         BandArgs a{}; a.Sb = c->S.p; a.Lb = c->Lwork.p; a.xr = c->s_ptr(); a.n_band = L.n_band; a.bw = L.bw; a.nbd = L.nbd; a.H = L.H; a.CH = c->band_CH; a.status = c->d_status.p;

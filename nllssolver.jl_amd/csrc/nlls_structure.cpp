@@ -667,6 +667,7 @@ std::vector<int32_t> rcm_order(const std::vector<std::vector<int32_t>>& adj) {
 int build_schur(nlls_ctx* c, int32_t flags) {
     const nlls_info& I0 = c->info; const int64_t nb = I0.nblocks;
     c->nelim_groups = 0; c->max_elim_dim = 0; c->max_nbr_dof = 0;
+    c->damped_floor = (flags & NLLS_FLAG_NO_PIVOT_FLOOR) ? 0.0 : 1e-11;
     // (a re-upload -- or the retry without Schur elimination after an unsupported shape -- must not see the previous
     // attempt's supernode lists: the solve dispatches on these counters)
     c->n_fast_groups = 0; c->n_slow_groups = 0; c->n_fast_members = 0; c->n_fast_narrow = 0; c->n_fast_n60 = 0; c->fast_dv = 0;
