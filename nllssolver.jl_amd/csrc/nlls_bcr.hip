@@ -55,19 +55,6 @@ BCR_DEV int bcr_dtile(int I, int K) { return I * (I + 1) / 2 + K; }      // lowe
 // entries of the assembled reduced system read straight from its BAND storage (column j: [S(j .. j + bw, j) | border rows | rhs], SLayout of nlls_solve.hip): what
 // bcr_convert_kernel re-tiles.  The first level of a damped solve reads them here instead (its panels land from the band, its update jobs take their old values
 // from it): no conversion launch stands in front of the levels.
-BCR_DEV double bcr_band_sym(const BcrGeom& g, const double* __restrict__ Sb, int row, int col) {     // S(row, col) of the banded part, either triangle; identity on the padding
-    if (row < col) { const int t = row; row = col; col = t; }
-    if (row >= g.n_band) return row == col ? 1.0 : 0.0;
-    const int e = row - col; return e <= g.bw ? Sb[(size_t)col * g.H + e] : 0.0;
-}
-BCR_DEV double bcr_band_low(const BcrGeom& g, const double* __restrict__ Sb, int row, int col) {     // S(row, col), row > col blocks (no mirroring): zero outside the band / the padding
-    if (row >= g.n_band) return 0.0;
-    const int e = row - col; return (e >= 0 && e <= g.bw) ? Sb[(size_t)col * g.H + e] : 0.0;
-}
-BCR_DEV double bcr_band_br(const BcrGeom& g, const double* __restrict__ Sb, int a, int col) {        // border row a (a == nbd: the right-hand side) at banded column col
-    return (col < g.n_band && a <= g.nbd) ? Sb[(size_t)col * g.H + g.bw + 1 + a] : 0.0;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // band storage -> block tridiagonal tiles.  Tiles are 16x16 row-major ([row][col], 256 doubles):
 //   D[k]  : NT(NT+1)/2 lower tiles of block k (diagonal tiles full and symmetric); columns >= n_band: identity
@@ -271,7 +258,7 @@ BCR_DEV void bcr_export_linv(const double* Lid, double* __restrict__ dst) {
     *reinterpret_cast<bdouble4_t*>(dst + 4 * lane) = bdouble4_t{Lid[li * BP + lk], Lid[li * BP + 4 + lk], Lid[li * BP + 8 + lk], Lid[li * BP + 12 + lk]};
 }
 
-struct BcrPanelArgs { BcrGeom g; BcrChain ch; int* status; double relfloor; int chrows; double* xr; const double* Sb; };   // Sb != nullptr (BAND1 instantiation): the first level lands from the band storage   // xr != nullptr: the fused backward pass follows -- the block's unknowns get the sentinel here   // chrows: X rows per workgroup of this launch (1 .. BCR_CH)
+struct BcrPanelArgs { BcrGeom g; BcrChain ch; int* status; double relfloor; int chrows; double* xr; };   // xr != nullptr: the fused backward pass follows -- the block's unknowns get the sentinel here   // chrows: X rows per workgroup of this launch (1 .. BCR_CH)
 // job e of a level, from the level's chain (no descriptor load in front of everything else)
 BCR_DEV BcrElim bcr_job(const BcrChain& c, int e) {
     const int idx = c.first + 2 * e, i = c.o + idx * c.s;
@@ -287,7 +274,7 @@ constexpr int bcr_level_chrows(int NT, int nelim, int slots) { for (int c2 = 1; 
 // arithmetic, identical bits).  The tile-updates run on the matrix pipes of the three SIMDs wave 0 does not sit on: they, not
 // wave 0's pivot chain, would set the pace of a block step with more X rows per workgroup.  The workgroup that holds the border
 // row also exports the D part of the factor and reports bad pivots.
-template <bool FLOOR, bool BAND1 = false>
+template <bool FLOOR>
 __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BcrGeom& g = a.g;
@@ -307,11 +294,6 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
                                                       // and its vector issue: it stays out of the way while wave 0 works)
     const bool helper = wave != 0 && wave != 4;
     double flc = 0.0;                                 // pivot floor of the tile wave 0 factors next (bcr_factor): the block's floors are put into LDS by the landing
-    if constexpr (BAND1) {   // the border corner (cp[0]: what the root sums the blocks' shares against), by the lead workgroup of the launch's first job
-        if (lead && blockIdx.x / NCH == 0 && tid < 256) { const int ca = tid >> 4, cb = tid & 15, nbr = g.nbd + 1; double v = 0.0;
-            if (ca < nbr && cb < nbr) { const int hi = ca > cb ? ca : cb, lo = ca > cb ? cb : ca; v = a.Sb[(size_t)g.n_band * g.H + hi + nbr * lo]; }
-            g.ws[g.ocp + ca * 16 + cb] = v; }
-    }
     if (a.xr && lead) {      // the hand-off of the fused backward pass carries no flag: a dependant polls the unknowns themselves until the sentinel is gone
         if (tid < 16 * NT) { const int row = 16 * NT * job.i + tid; if (row < g.n_band) a.xr[row] = __longlong_as_double((long long)BCR_X_SENTINEL); }
         if (job.l < 0 && job.r < 0 && tid < g.nbd) g.ws[g.oxb + tid] = __longlong_as_double((long long)BCR_X_SENTINEL);      // (the root: the border's unknowns)
@@ -339,15 +321,9 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
     const double* Bg = g.ws + g.oBR + (size_t)job.i * NT * 256;
     const int bsz = 16 * NT;
     auto xsrc = [&](int Rg, int K, int hi, int lo) -> double {
-        if constexpr (BAND1) {          // (first level: the chain's stride is one -- the neighbours are blocks i - 1 and i + 1)
-            if (Rg < NT) return bcr_band_low(g, a.Sb, bsz * job.i + 16 * K + hi, bsz * job.l + 16 * Rg + lo);          // A_il(K, R)[hi][lo]
-            if (Rg < 2 * NT) return bcr_band_low(g, a.Sb, bsz * job.r + 16 * (Rg - NT) + hi, bsz * job.i + 16 * K + lo);   // A_ri(R, K)[hi][lo]
-            return bcr_band_br(g, a.Sb, hi, bsz * job.i + 16 * K + lo);
-        } else {
-            if (Rg < NT) return Agl[(size_t)(K * NT + Rg) * 256 + hi * 16 + lo];               // X(R,K)[lo][hi] = A_il(K,R)[hi][lo]
-            if (Rg < 2 * NT) return Agr[(size_t)((Rg - NT) * NT + K) * 256 + hi * 16 + lo];
-            return Bg[(size_t)K * 256 + hi * 16 + lo];
-        }
+        if (Rg < NT) return Agl[(size_t)(K * NT + Rg) * 256 + hi * 16 + lo];               // X(R,K)[lo][hi] = A_il(K,R)[hi][lo]
+        if (Rg < 2 * NT) return Agr[(size_t)((Rg - NT) * NT + K) * 256 + hi * 16 + lo];
+        return Bg[(size_t)K * 256 + hi * 16 + lo];
     };
     auto xdst = [&](int R, int Rg, int K, int hi, int lo) -> double* { return Xt + (R * NT + K) * BTS + (Rg < NT ? lo * BP + hi : hi * BP + lo); };
     constexpr int LANDQ = (BCR_CH * (BCR_MAXNT - 1) * 256 + 6 * 64 - 1) / (6 * 64);      // words per helper thread of the deferred part
@@ -367,9 +343,7 @@ __global__ __launch_bounds__(BCR_T) void bcr_panel_kernel(BcrPanelArgs a) {
 #pragma unroll
         for (int q = 0; q < DQ; ++q) { const int w = tid + q * BCR_T; dv[q] = 0.0;
             if (w < ND * 256) {
-                if constexpr (BAND1) { const int t = w >> 8; int I = 0; while ((I + 1) * (I + 2) / 2 <= t) ++I; const int K = t - I * (I + 1) / 2;
-                    dv[q] = bcr_band_sym(g, a.Sb, bsz * job.i + 16 * I + ((w >> 4) & 15), bsz * job.i + 16 * K + (w & 15)); }
-                else dv[q] = Dg[w]; } }
+                dv[q] = Dg[w]; } }
 #pragma unroll
         for (int q = 0; q < XQ; ++q) { const int w = tid + q * BCR_T; xv[q] = w < RX * 256 ? xsrc(rowRg(w >> 8), 0, (w >> 4) & 15, w & 15) : 0.0; }
 #pragma unroll
@@ -734,11 +708,8 @@ void launch_dense_bwd_step(hipStream_t st, const double* S, const double* LiD, i
 // Schur update of a level: one wavefront per output tile, operands straight from the exported panels (L2 / MALL):
 //   dst (-)= sum_c  sum_J  Wx[a_c][J] Lx[b_c][J]'          (Lx = Wx / Delta)
 // ---------------------------------------------------------------------------------------------------
-// (Sb != nullptr: the level's RMW jobs -- u.pad = 1 + block for a D tile, -(1 + block) for a border / rhs tile, the tile from dst -- take their OLD value from the
-//  band storage instead of the tile: the first level of a solve whose tiles were never converted)
-struct BcrUpdBand { BcrGeom g; const double* Sb; };
-template <int NT, bool BAND>
-__device__ __forceinline__ void bcr_update_body(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs, const BcrGeom* gp, const double* __restrict__ Sb) {
+template <int NT>
+__device__ __forceinline__ void bcr_update_body(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs) {
     const int j = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); if (j >= njobs) return;
     const BcrUpd u = jobs[j];
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
@@ -768,16 +739,6 @@ __device__ __forceinline__ void bcr_update_body(double* __restrict__ ws, const B
     double old[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) old[r] = u.mode == 0 ? dst[64 * r] : 0.0;
-    if constexpr (BAND) { if (u.mode == 0 && u.pad != 0) {
-        const BcrGeom& g = *gp;
-        const int sp = (int)u.pad, bsz = 16 * NT;
-        if (sp > 0) { const int j = sp - 1, ND = NT * (NT + 1) / 2, t = (int)((u.dst - g.oD) / 256) - j * ND; int I = 0; while ((I + 1) * (I + 2) / 2 <= t) ++I; const int K = t - I * (I + 1) / 2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) old[r] = bcr_band_sym(g, Sb, bsz * j + 16 * I + lk + 4 * r, bsz * j + 16 * K + li); }
-        else { const int j = -sp - 1, K = (int)((u.dst - g.oBR) / 256) - j * NT;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) old[r] = bcr_band_br(g, Sb, lk + 4 * r, bsz * j + 16 * K + li); }
-    } }
     bdouble4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -797,9 +758,7 @@ __device__ __forceinline__ void bcr_update_body(double* __restrict__ ws, const B
     }
 }
 template <int NT>
-__global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs) { bcr_update_body<NT, false>(ws, jobs, njobs, nullptr, nullptr); }
-template <int NT>
-__global__ __launch_bounds__(256) void bcr_update_band_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs, BcrUpdBand bb) { bcr_update_body<NT, true>(ws, jobs, njobs, &bb.g, bb.Sb); }
+__global__ __launch_bounds__(256) void bcr_update_kernel(double* __restrict__ ws, const BcrUpd* __restrict__ jobs, int njobs) { bcr_update_body<NT>(ws, jobs, njobs); }
 
 // ---------------------------------------------------------------------------------------------------
 // backward pass of one level: one workgroup per block eliminated at that level
@@ -1056,12 +1015,6 @@ __global__ __launch_bounds__(512) void dense_bwd_fused_kernel(DenseBwdArgs a) {
 #undef DBW_TILE
 #undef DBW_LOAD
 }
-// inverse of ONE freshly factored diagonal block (its tiles still in the panel's scratch slot) -> Dinv slot b
-void launch_dense_dinv_one(hipStream_t st, const double* LiD, const double* Lslot, double* Dinv_b, int npad, int b) {
-    static bool attr = false; constexpr int lds = (int)(sizeof(double) * 36 * BTS);
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dinv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL(dense_dinv_kernel<1>, dim3(1), dim3(512), lds, st, (const double*)nullptr, LiD, Dinv_b - (size_t)b * DBB * DBB, (double*)nullptr, npad, 0, b, Lslot);
-}
 // Dinv: ceil(n / 128) slots of 128 x 128 doubles
 void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, double* Dinv, int npad, int n, double* x, int* status) {
     const int NBB = (n + DBB - 1) / DBB; if (NBB <= 0) return;
@@ -1189,8 +1142,7 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
     panel_lds = sizeof(double) * ((size_t)(ND + BCR_CH * NT) * BTS + 2 * (size_t)(NT + BCR_CH) * 16 * BP + 64 + 2 * 16 * BP + BTS + 128);
     back_lds = sizeof(double) * ((size_t)RXT * 16 + NT * 64 + 2 * NT * 16 + (size_t)NO * 256 + 256 + 16);
     { const char* e = getenv("NLLS_BCR_CHROWS_SLOTS"); chrows_slots = e ? atoi(e) : 256; }
-    { const char* e = getenv("NLLS_BCR_FOLD_CONVERT"); fold_convert = e && e[0] == '1'; }      // (built, parity-green, no gain: 312.5 against 313.0 us per trial -- the first level's landing from the band costs what the launch saved)
-    launches = fold_convert ? 0 : 1; for (auto& lv : levels) launches += 1 + (lv.nupd > 0) + (fused_backward ? 0 : 1);
+    launches = 1; for (auto& lv : levels) launches += 1 + (lv.nupd > 0) + (fused_backward ? 0 : 1);
     launches += fused_backward ? 1 : 0;
     {   // matrix-core instructions per solve (2048 flop each): panel kernel per workgroup + update kernel per job
         mfma_issued = 0;
@@ -1220,17 +1172,15 @@ int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* er
 }
 
 template <int NT>
-static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status, double relfloor, double* xr, const double* Sb_first) {
+static void bcr_launch_level(const BcrSolver& S, hipStream_t st, const BcrLevel& lv, int* status, double relfloor, double* xr) {
     // X rows per workgroup: as few as still fit ONE round of the chip (every workgroup factors D_i beside its rows; the fewer rows, the less
     // helper work stands beside the pivot chain that sets the pace): 3 when the level is wide, 1 at the narrow levels near the root
     const int chrows = bcr_level_chrows(NT, lv.nelim, S.chrows_slots);
-    BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status, relfloor, chrows, S.fused_backward ? xr : nullptr, Sb_first};
+    BcrPanelArgs pa{S.geom, BcrChain{lv.o, lv.s, lv.m, lv.first}, status, relfloor, chrows, S.fused_backward ? xr : nullptr};
     if (relfloor > 0.0) hipLaunchKernelGGL(bcr_panel_kernel<true>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
-    else if (Sb_first) hipLaunchKernelGGL((bcr_panel_kernel<false, true>), dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     else hipLaunchKernelGGL(bcr_panel_kernel<false>, dim3((unsigned)(bcr_nchunks(NT, chrows) * lv.nelim)), dim3(BCR_T), S.panel_lds, st, pa);
     if (lv.nupd > 0) {
-        if (Sb_first) hipLaunchKernelGGL((bcr_update_band_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd, BcrUpdBand{S.geom, Sb_first});
-        else hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd);
+        hipLaunchKernelGGL((bcr_update_kernel<NT>), dim3((unsigned)((lv.nupd + 3) / 4)), dim3(256), 0, st, S.geom.ws, S.d_upd.p + lv.upd_off, lv.nupd);
     }
 }
 template <int NT>
@@ -1246,12 +1196,11 @@ static void bcr_launch_back_all(const BcrSolver& S, hipStream_t st, double* xr, 
 
 int BcrSolver::enqueue(hipStream_t st, const double* Sb, double* xr, int* status, double pivot_floor) const {
     const int ND = NT * (NT + 1) / 2, per = ND + NT * NT + NT;
-    // The tiles: assembled in place (Sb == nullptr: schur_gather_kernel), converted from the band storage (undamped solves with the pivot floor: it wants the original
-    // diagonal, which the conversion records), or -- NLLS_BCR_FOLD_CONVERT=1, damped solves -- never formed: the FIRST level reads the band storage itself (A/B: measured equal, off)
-    const bool fold = Sb != nullptr && pivot_floor == 0.0 && fold_convert;
-    if (Sb && !fold) hipLaunchKernelGGL(bcr_convert_kernel, dim3((unsigned)(N * per + 1)), dim3(256), 0, st, geom, Sb);
+    // The tiles: assembled in place (Sb == nullptr: schur_gather_kernel) or converted from the band storage.  (Rounds 3-4 could skip the conversion for damped solves -- the first
+    // level reading the band storage itself, NLLS_BCR_FOLD_CONVERT: measured equal, 312.5 against 313.0 us per trial; out of the library since round 5, last in the tree at 6e015b8.)
+    if (Sb) hipLaunchKernelGGL(bcr_convert_kernel, dim3((unsigned)(N * per + 1)), dim3(256), 0, st, geom, Sb);
 #define BCR_NT_SWITCH(CALL) switch (NT) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; default: CALL(5); break; }
-#define BCR_FWD(n) bcr_launch_level<n>(*this, st, lv, status, pivot_floor, xr, (fold && &lv == &levels.front()) ? Sb : (const double*)nullptr)
+#define BCR_FWD(n) bcr_launch_level<n>(*this, st, lv, status, pivot_floor, xr)
     for (const BcrLevel& lv : levels) BCR_NT_SWITCH(BCR_FWD)
 #define BCR_BWD(n) bcr_launch_back<n>(*this, st, levels[li], xr, li + 1 == levels.size() ? 1 : 0, status)
 #define BCR_BWD_ALL(n) bcr_launch_back_all<n>(*this, st, xr, status)

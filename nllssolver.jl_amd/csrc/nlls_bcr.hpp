@@ -31,7 +31,6 @@ struct BcrSolver {
     std::vector<BcrLevel> levels;                 // elimination levels, the root block last
     DevBuf<double> ws; DevBuf<BcrElim> d_elim; DevBuf<BcrUpd> d_upd;
     bool fused_backward = true;
-    bool fold_convert = false;                    // NLLS_BCR_FOLD_CONVERT=1 (A/B): damped solves without the conversion launch -- the first level reads the band storage itself (measured: no gain)
     BcrGeom geom{};
     size_t panel_lds = 0, back_lds = 0;
     int chrows_slots = 256;                       // a level's panel launch uses fewer X rows per workgroup while its workgroups still fit this many CUs (NLLS_BCR_CHROWS_SLOTS=0: always three)
@@ -55,7 +54,6 @@ struct DenseWin { int nwin = -1, strip = 0, ntot = 0; };
 void launch_dense_panel(hipStream_t st, double* S, double* W, double* LiD, int npad, int k, int* status, int wide, double* Dfac, DenseWin win = DenseWin{});
 void launch_dense_dcopy_all(hipStream_t st, double* S, const double* Dfac, int npad, int nwide, int first64, int n64);   // the factored diagonal blocks: slots of Dfac -> S   // wide: a 128-column panel (k counts panels of the width used)
 void launch_dense_bwd_diag(hipStream_t st, const double* S, const double* LiD, int npad, int kb, int n, const double* acc, double* x);
-void launch_dense_dinv_one(hipStream_t st, const double* LiD, const double* Lslot, double* Dinv_b, int npad, int b);   // look-ahead factorisation: inverse of one freshly factored 128 x 128 diagonal block
 void launch_dense_bwd_fused(hipStream_t st, const double* S, const double* LiD, double* Dinv, int npad, int n, double* x, int* status);   // the whole backward substitution in one launch (+ the diagonal blocks' inverses)
 void launch_dense_bwd_step(hipStream_t st, const double* S, const double* LiD, int npad, int s, int n, double* acc, double* x);   // push block s's x into the blocks above, solve block s - 1
 

@@ -48,10 +48,6 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     { const char* e = getenv("NLLS_EAGER_STAGE0"); if (e && e[0] == '1') c->lazy_stage0 = false; }
     { const char* e = getenv("NLLS_POST_SPLIT"); if (e && e[0] == '1') c->post_fuse = false; }
     { const char* e = getenv("NLLS_ELIM_SPLIT"); if (e && e[0] == '1') c->elim_split = true; }
-    { const char* e = getenv("NLLS_DENSE_LOOKAHEAD"); if (e && e[0] == '1') c->dense_lookahead = true; }
-    { const char* e = getenv("NLLS_ELIM_FOLD"); if (e && e[0] == '1') c->elim_fold = true; }      // A/B: tiny supernodes folded into their large neighbours (measured slower: off)
-    { const char* e = getenv("NLLS_ELIM_DMA"); if (e && e[0] == '1') c->elim_dma = true; }      // A/B: the narrow supernodes' member loop fed by LDS-DMA (measured slower: off)
-    { const char* e = getenv("NLLS_SWEEP_SPLIT3"); if (e && e[0] == '1') c->sweep_split3 = true; }
     { const char* e = getenv("NLLS_DENSE_STEP_BACKWARD"); if (e && e[0] == '1') c->dense_fused_bwd = false; }
     { const char* e = getenv("NLLS_DENSE_T128_MIN"); if (e) c->dense_t128_min = atoi(e); }
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return NLLS_ERR_HIP; }

@@ -136,14 +136,6 @@ struct ElimDesc {
     int64_t dg0;             // A.data offset of the first member's diagonal block
     uint32_t eb0, pad;       // b offset of the first member
 };
-// A member of a tiny supernode folded into a neighbouring large one (build_schur, "fold"): the large supernode's columns are a prefix or a suffix of its own, so its
-// share of S over those columns rides in the large supernode's accumulators and flush; only the strip of its nx extra columns is added to S on its own.
-struct ElimPre {
-    int64_t e0;              // A.data offset of the member's row [E (DV x ndf) | C]
-    uint32_t eb, v;          // offset of its right-hand side in b; its index among the eliminated members (inverse block, back-substitution)
-    uint32_t ndf, xoff;      // columns of its own E; column of its row where the host supernode's columns start (0: extra columns behind them, nx: in front)
-    uint32_t rc_off, nx;     // its own reduced-column list in d_elim_rc; extra columns
-};
 struct SchurNbr {            // one off-diagonal block touching an eliminated block
     int64_t off;             // offset in A.data
     uint32_t rcol;           // dof offset of the neighbour in the reduced system
@@ -234,7 +226,6 @@ struct nlls_ctx {
     int ps_np = 0, ps_np2 = 0;                 // partial counts of the last enqueue_post_solve (for the trial's finishing launch)
     int dense_t128_min = 16;                   // ... only while the trailing matrix has at least this many 128-blocks per side (fewer: the 64 x 64 kernel fills the chip better)
     bool dense_pad128 = false;                 // the dense layout is padded to a multiple of 128 rows (windowed and look-ahead factorisations: 128-column panels only)
-    bool dense_lookahead = false;              // NLLS_DENSE_LOOKAHEAD=1 (A/B; built, parity-green, SLOWER: 6.2 against 3.7 ms at 6000 dof): the diagonal block factored + inverted by one workgroup on a second stream beside the bulk of the previous trailing update, the rows below as one matrix product
     bool dense_window = false;                 // dense LDL' restricted to the band of the (re-ordered) reduced system + the border strip: O(n w^2) instead of n^3 / 3 (build_schur decides)
     bool dense_t128 = true;                    // dense LDL': 128 x 128 tiles in the two-panel trailing update (NLLS_DENSE_T64=1: the 64 x 64 kernel, for A/B runs)
     bool dense_fused_bwd = true;               // dense LDL': the backward substitution in one launch (NLLS_DENSE_STEP_BACKWARD=1: one launch per 64-column block, for A/B runs)
@@ -243,9 +234,7 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_fast_voff;      // where the variable of each eliminated member is stored (elimination order)
     nlls::DevBuf<uint32_t> d_rest_var; nlls::DevBuf<int32_t> d_rest_red;   // the other variables, and where their step starts in the reduced solution (-1: fixed)
     bool fast_all_euclid = false, post_fuse = true, retract_done = false; int trial_to = -1, trial_from = -1;
-    bool elim_dma = false;                     // NLLS_ELIM_DMA=1: schur_elim_all_dma_kernel (member loop fed by global_load_lds: built, parity-green, 7 us slower at config 4)
     bool elim_split = false;                   // NLLS_ELIM_SPLIT=1: the assembly of the reduced system in three launches (A/B)
-    bool sweep_split3 = false;                 // NLLS_SWEEP_SPLIT3=1: the three-slot accumulate sweep in one launch per role (A/B)
     bool elim_mfma = true;                     // narrow supernodes (nd + 1 <= 64) are eliminated on the matrix cores (NLLS_ELIM_TILED=1: the register-tiled kernel, for A/B runs)
     bool elim_selected = false;
     std::vector<int32_t> owner_of_block;
@@ -268,9 +257,6 @@ struct nlls_ctx {
     nlls::DevBuf<uint32_t> d_elim_group;     // supernodes: runs of eliminated blocks with identical neighbour sets
     int64_t nelim_groups = 0, n_fast_groups = 0, n_slow_groups = 0;
     nlls::DevBuf<uint32_t> d_fast_groups, d_slow_groups, d_slow_blocks;   // d_slow_blocks: members of the slow supernodes
-    // the elimination's own view of the fast supernodes (single rank, one-launch assembly): tiny supernodes whose columns extend a neighbouring large one's by a few are
-    // folded into it as extra members (ElimPre) -- half of the launch's atomics and a quarter of its vector instructions are theirs
-    nlls::DevBuf<nlls::ElimDesc> d_elim_desc_fold; nlls::DevBuf<nlls::ElimPre> d_elim_pre; int64_t n_fold_groups = 0, n_fold_narrow = 0, n_folded = 0; bool elim_fold = false;   // NLLS_ELIM_FOLD=1 (A/B; parity-green, SLOWER: 316 against 294 us per solve at config 4 -- the tiny supernodes were filling idle slots; folded, their strips lengthen the workgroups that set the launch's pace)
     nlls::DevBuf<nlls::ElimDesc> d_elim_desc; nlls::DevBuf<uint32_t> d_elim_rc;   // per fast supernode (launch order): descriptor, reduced column of every E column
     nlls::DevBuf<uint32_t> d_fast_members;   // members of the fast supernodes
     nlls::DevBuf<uint8_t> d_blk_slowmask;    // d_blk entries NOT in rows of fast members (and owned by this rank)

@@ -561,7 +561,7 @@ constexpr int ELIM_MFMA_NW = 4;                              // waves per supern
 template <int DV, class LAY = SLayout>
 __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ A, const double* __restrict__ b,
                                                      const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                     const double* __restrict__ Cinv, const LAY& L, double* __restrict__ s, uint32_t bidx, const ElimPre* __restrict__ pre = nullptr) {
+                                                     const double* __restrict__ Cinv, const LAY& L, double* __restrict__ s, uint32_t bidx) {
     constexpr int NDMAX = 63, NW = ELIM_MFMA_NW, NTH = 64 * NW;
     __shared__ uint32_t rc[64], rs[64];                       // rc: reduced column of list column p (MEMORY order); rs: the list columns by ascending reduced column
     __shared__ double img[NDMAX * (NDMAX + 1) / 2 + NDMAX];
@@ -579,18 +579,13 @@ __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ 
     constexpr int PF = 2;                                     // members in flight per wave (HBM latency is several members' worth of MFMA time)
     const bool kslot = lk < DV;                               // the fourth k-slot of the instruction stays zero for DV = 3
     const int kk = kslot ? lk : 0;
-    // FOLDED members (ElimPre; build_schur): up to four members of a tiny neighbouring supernode whose columns are this one's plus a few in front or behind.  Over
-    // the common columns they are ordinary members m = nmem .. nmem + npre - 1 of the loop below -- the same accumulators, the same flush: no atomics of their own --
-    // with a row start, right-hand-side offset and inverse-block index of their own (uniform values, selected per member); the strip of their extra columns follows
-    // behind the flush.
-    const uint32_t npre = (pre != nullptr && d.pad != 0) ? d.pad >> 24 : 0u, pre0 = d.pad & 0xFFFFFFu, nall = nmem + npre;
+    const uint32_t nall = nmem;
     const double* ebase[4]; bool live[4], isb[4];               // member m's operand value sits at ebase[r] + (a column of E: offE(m); the right-hand side: offB(m))
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int col = 16 * r + li; live[r] = col <= nd && kslot; isb[r] = col >= nd;
         ebase[r] = isb[r] ? b + eb0 + kk : A + dg0 + (int64_t)DV * col - (int64_t)DV * nd + kk;
     }
-    const int64_t e0row = dg0 - (int64_t)DV * nd;
     double4_t acc[10];
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -600,10 +595,7 @@ __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ 
         double en[PF][TR], cn[PF][DV];
         auto issue = [&](uint32_t m, int slot) {              // unconditional, clamped loads (a predicated load becomes copy + vmcnt(0))
             const uint32_t mm = m < nall ? m : nall - 1;
-            int64_t offE, offB; uint32_t vi;                   // uniform: the member's row / right-hand side relative to the supernode's first member, its inverse-block index
-            if (mm < nmem) { offE = (int64_t)mm * dstride; offB = (int64_t)mm * DV; vi = v0 + mm; }
-            else { const ElimPre* q = pre + pre0 + (mm - nmem);            // (uniform address: scalar loads; a select chain over four register copies became a table in scratch memory)
-                   offE = q->e0 + (int64_t)DV * q->xoff - e0row; offB = (int64_t)q->eb - (int64_t)eb0; vi = q->v; }
+            const int64_t offE = (int64_t)mm * dstride, offB = (int64_t)mm * DV; const uint32_t vi = v0 + mm;      // (uniform) the member's row / right-hand side relative to the supernode's first member, its inverse block
 #pragma unroll
             for (int r = 0; r < TR; ++r) en[slot][r] = ebase[r][isb[r] ? offB : offE];
 #pragma unroll
@@ -669,142 +661,6 @@ __device__ __forceinline__ void schur_elim_mfma_body(const double* __restrict__ 
     for (int qs = wave; qs < nd; qs += NW) { const int q = (int)rs[qs];
         for (int ps = qs + lane; ps < nd; ps += 64) { const int pp = (int)rs[ps]; atomicAdd(L.at(rc[pp], rc[q]), -img[pp > q ? colstart(q) + pp : colstart(pp) + q]); } }
     if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
-    // ---- the folded members' strips (their extra columns against all their own columns), behind the flush: the accumulators are dead by now
-    if (pre != nullptr && d.pad != 0) {
-        const uint32_t npre = d.pad >> 24, pre0 = d.pad & 0xFFFFFFu;
-        for (uint32_t ip = wave; ip < npre; ip += NW) {
-            const ElimPre pm = pre[pre0 + ip];
-            // the strip: S(x, y) -= e_x' (C + lambda I)^-1 e_y for the nx extra columns x against every column y of the member's own row (and the right-hand side)
-            const uint32_t* rcT = rcflat + pm.rc_off; const int ndf = (int)pm.ndf, nx = (int)pm.nx, xe0 = pm.xoff == 0 ? nd : 0;
-            double ci[DV * DV];
-#pragma unroll
-            for (int q = 0; q < DV * DV; ++q) ci[q] = Cinv[(int64_t)pm.v * (DV * DV) + q];
-            for (int ycol = lane; ycol <= ndf; ycol += 64) {
-                double ey[DV], yv[DV];
-#pragma unroll
-                for (int k = 0; k < DV; ++k) ey[k] = ycol < ndf ? A[pm.e0 + (int64_t)DV * ycol + k] : b[pm.eb + k];
-#pragma unroll
-                for (int k = 0; k < DV; ++k) { double t = 0.0;
-#pragma unroll
-                    for (int j = 0; j < DV; ++j) t = fma(ci[k + DV * j], ey[j], t); yv[k] = t; }
-                const uint32_t ry = ycol < ndf ? rcT[ycol] : 0u;
-                const bool yextra = ycol < ndf && ycol >= xe0 && ycol < xe0 + nx;
-                for (int x = xe0; x < xe0 + nx; ++x) {
-                    double val = 0.0;
-#pragma unroll
-                    for (int k = 0; k < DV; ++k) val = fma(A[pm.e0 + (int64_t)DV * x + k], yv[k], val);
-                    const uint32_t rx = rcT[x];
-                    if (ycol == ndf) atomicAdd(L.rhs(s, rx), -val);
-                    else if (!yextra || ycol == x || ry < rx) atomicAdd(L.at(rx > ry ? rx : ry, rx > ry ? ry : rx), -val);
-                }
-            }
-        }
-    }
-}
-
-// ---- the same member loop fed by LDS-DMA (global_load_lds_dwordx4) ------------------------------------------------------------------------
-// The loop above keeps PF = 2 members per wave in flight -- all the registers allow at three waves per SIMD (168 of 170) -- and is bound by the
-// latency of those loads: 24 members (36 KB) in flight per CU.  Here the rows of E go global -> LDS without passing through registers: every wave
-// owns a ring of ELIM_DMA_NS slots, one member's E (DV nd doubles, contiguous in A.data) per slot, filled by one or two 1-KiB DMA instructions (lane l
-// of an instruction moves 16 bytes to slot + 16 l: the destination is lane-linear, the source per lane).  The inverse diagonal blocks and the right-hand
-// sides of the supernode's members are put into LDS by the workgroup's prologue (it has just formed the inverses), so the loop has no register-
-// staged global load at all.  hipcc does not see the DMAs: their completion is waited for by hand (s_waitcnt vmcnt(N), N = the DMA instructions
-// issued behind the member about to be consumed; clamped re-loads of the last member keep N the same to the end).
-constexpr int ELIM_DMA_NS = 4, ELIM_DMA_SLOT = 192;           // members in flight per wave; doubles per ring slot (E <= 3 * 63 = 189 doubles)
-NLLS_DEV void glds16(const void* gsrc, uint32_t lds_dst) {     // M0 (the DMA's LDS base) is compiler-reserved: written and restored inside the statement
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N> NLLS_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-struct ElimDmaLds { double* ring; double* cinv; double* bv; double* img; uint32_t* rc; uint32_t* rs; };
-template <int DV, class LAY = SLayout>
-__device__ __forceinline__ void schur_elim_mfma_dma_body(const double* __restrict__ A, const ElimDesc& d, const uint32_t* __restrict__ rcflat,
-                                                         const LAY& L, double* __restrict__ s, const ElimDmaLds& lds) {
-    constexpr int NDMAX = 63, NW = ELIM_MFMA_NW, NTH = 64 * NW, NS = ELIM_DMA_NS;
-    double* const img = lds.img; double* const irhs = img + NDMAX * (NDMAX + 1) / 2; uint32_t* const rc = lds.rc; uint32_t* const rs = lds.rs;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
-    const uint32_t nmem = d.nmem; const int nd = (int)d.nd;
-    if (tid < nd) { rc[tid] = rcflat[d.rc_off + tid]; rs[tid] = rcflat[d.rc_off + nd + tid]; }
-    for (int i = tid; i < nd * (nd + 1) / 2; i += NTH) img[i] = 0.0;
-    if (tid < NDMAX) irhs[tid] = 0.0;
-    const int T16 = (nd + 1 + 15) >> 4;
-    const int64_t e0 = d.dg0 - (int64_t)DV * nd, dstride = (int64_t)DV * nd + DV * DV;          // E of member m starts at A[e0 + m dstride]
-    const int n16 = (DV * nd + 1) >> 1;                                                         // 16-byte pieces of one member's E (an odd tail reads one double of C: valid memory)
-    const bool two = n16 > 64;                                                                  // uniform: DMA instructions per member
-    double* const myring = lds.ring + (size_t)wave * NS * ELIM_DMA_SLOT;
-    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(char*)myring);
-    auto issue = [&](uint32_t m, int slot) {
-        const uint32_t mm = m < nmem ? m : nmem - 1;
-        const double* src = A + e0 + (int64_t)mm * dstride + 2 * lane;
-        const uint32_t dst = ring_lds + (uint32_t)slot * (ELIM_DMA_SLOT * 8);
-        if (lane < (n16 < 64 ? n16 : 64)) glds16(src, dst);
-        if (two) { if (lane < n16 - 64) glds16(src + 128, dst + 1024); }
-    };
-    const bool kslot = lk < DV; const int kk = kslot ? lk : 0;
-    double4_t acc[10];
-#pragma unroll
-    for (int t = 0; t < 10; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-    auto members = [&](auto T16c, auto TWOc) {
-        constexpr int TR = decltype(T16c)::value; constexpr bool TWO = decltype(TWOc)::value; constexpr int NI = TWO ? 2 : 1;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) issue(wave + NW * u, u);
-        int slot = 0;
-#pragma unroll 1
-        for (uint32_t m = wave; m < nmem; m += NW) {
-            wait_vmcnt<NI * (NS - 1)>();                       // this member's pieces have landed; the NS - 1 members behind it may still be in flight
-            const double* E = myring + (size_t)slot * ELIM_DMA_SLOT;
-            double aop[TR], bop[TR], c[DV];
-#pragma unroll
-            for (int r = 0; r < TR; ++r) { const int col = 16 * r + li;
-                aop[r] = (kslot && col < nd) ? E[DV * col + kk] : ((kslot && col == nd) ? lds.bv[(size_t)m * DV + kk] : 0.0); }
-#pragma unroll
-            for (int j = 0; j < DV; ++j) { const int hi = j > kk ? j : kk, lo = j > kk ? kk : j;       // the inverse is symmetric: its lower triangle, packed by columns
-                c[j] = kslot ? lds.cinv[(size_t)m * (DV * (DV + 1) / 2) + lo * DV - lo * (lo - 1) / 2 + (hi - lo)] : 0.0; }
-#pragma unroll
-            for (int r = 0; r < TR; ++r) {
-                double y = 0.0;
-#pragma unroll
-                for (int j = 0; j < DV; ++j) {
-                    const int src = 4 * (16 * j + li);
-                    const double ej = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(aop[r])), __builtin_amdgcn_ds_bpermute(src, __double2loint(aop[r])));
-                    y = fma(c[j], ej, y);
-                }
-                bop[r] = y;
-            }
-            issue(m + NW * NS, slot);                             // (the slot's words are in registers: the bpermutes above have used them)
-            slot = slot + 1 == NS ? 0 : slot + 1;
-#pragma unroll
-            for (int R = 0; R < TR; ++R)
-#pragma unroll
-                for (int C = 0; C <= R; ++C) acc[R * (R + 1) / 2 + C] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[R], bop[C], acc[R * (R + 1) / 2 + C], 0, 0, 0);
-        }
-        wait_vmcnt<0>();                                           // the clamped re-loads behind the last member: nothing may land in LDS after this point
-    };
-    auto dispatch = [&](auto TWOc) {
-        if (T16 == 4) members(std::integral_constant<int, 4>{}, TWOc);
-        else if (T16 == 3) members(std::integral_constant<int, 3>{}, TWOc);
-        else if (T16 == 2) members(std::integral_constant<int, 2>{}, TWOc);
-        else members(std::integral_constant<int, 1>{}, TWOc);
-    };
-    if (two) dispatch(std::true_type{}); else dispatch(std::false_type{});
-    __syncthreads();
-    auto colstart = [nd](int q) { return q * nd - q * (q - 1) / 2 - q; };
-#pragma unroll
-    for (int R = 0; R < 4; ++R)
-#pragma unroll
-        for (int C = 0; C <= R; ++C) {
-            if (R >= T16) continue;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int pp = 16 * R + lk + 4 * v, q = 16 * C + li; const double val = acc[R * (R + 1) / 2 + C][v];
-                if (pp < nd && q <= pp) atomicAdd(&img[colstart(q) + pp], val);
-                else if (pp == nd && q < nd) atomicAdd(&irhs[q], val);
-            }
-        }
-    __syncthreads();
-    for (int qs = wave; qs < nd; qs += NW) { const int q = (int)rs[qs];
-        for (int ps = qs + lane; ps < nd; ps += 64) { const int pp = (int)rs[ps]; atomicAdd(L.at(rc[pp], rc[q]), -img[pp > q ? colstart(q) + pp : colstart(pp) + q]); } }
-    if (tid < nd) atomicAdd(L.rhs(s, rc[tid]), -irhs[tid]);
 }
 
 template <int DV, class LAY = SLayout>
@@ -834,7 +690,7 @@ struct PrepArgs { const uint32_t* red_boff; const SchurCopy* copies; double lamb
 template <int DV, class LAY = SLayout>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_all_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                              double* __restrict__ Cinv, LAY L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa, const ElimPre* __restrict__ pre) {
+                                                              double* __restrict__ Cinv, LAY L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa) {
     if (blockIdx.x >= pa.nfast) {
         const int w = (int)(blockIdx.x - pa.nfast);
         if (w == 0 && threadIdx.x == 0) pa.status[4] = 0;                       // (pivots dropped by the floor: only the panels of this solve add to it)
@@ -857,11 +713,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     {   // the members' inverse diagonal blocks (schur_cinv_kernel's arithmetic, same bits)
         const ElimDesc d = desc[blockIdx.x];
         const int64_t dstride = (int64_t)DV * d.nd + DV * DV;
-        const uint32_t npre = pre != nullptr ? d.pad >> 24 : 0u, pre0 = d.pad & 0xFFFFFFu;          // folded members: their inverse blocks are this workgroup's job too
-        for (uint32_t m = threadIdx.x; m < d.nmem + npre; m += 256) {
-            const bool ispre = m >= d.nmem; ElimPre pm{}; if (ispre) pm = pre[pre0 + (m - d.nmem)];
-            const double* Cg = ispre ? A + pm.e0 + (int64_t)DV * pm.ndf : A + d.dg0 + (int64_t)m * dstride; double C[DV * DV];
-            const int64_t vidx = ispre ? (int64_t)pm.v : (int64_t)(d.v0 + m);
+        for (uint32_t m = threadIdx.x; m < d.nmem; m += 256) {
+            const double* Cg = A + d.dg0 + (int64_t)m * dstride; double C[DV * DV];
+            const int64_t vidx = (int64_t)(d.v0 + m);
 #pragma unroll
             for (int j = 0; j < DV; ++j)
 #pragma unroll
@@ -899,94 +753,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __threadfence_block();          // the workgroup's own stores, then its own loads of them (workgroup scope)
         __syncthreads();
     }
-    if (blockIdx.x < nnarrow) schur_elim_mfma_body<DV>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x, pre);
+    if (blockIdx.x < nnarrow) schur_elim_mfma_body<DV>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
     else schur_elim_tiled_body<DV, 2, 3>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x);
-}
-
-// schur_elim_all_kernel with the narrow supernodes' member loop fed by LDS-DMA (schur_elim_mfma_dma_body).  The prologue keeps the inverse diagonal
-// blocks and the right-hand sides of the supernode's members in LDS as well (at most 128 members per supernode: build_schur).
-template <int DV, class LAY = SLayout>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_all_dma_kernel(const double* __restrict__ A, const double* __restrict__ b,
-                                                              const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
-                                                              double* __restrict__ Cinv, LAY L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa) {
-    if (blockIdx.x >= pa.nfast) {
-        const int w = (int)(blockIdx.x - pa.nfast);
-        if (w == 0 && threadIdx.x == 0) pa.status[4] = 0;
-        if (w < pa.ninit) {
-            const int i = w * 256 + threadIdx.x;
-            if (i < L.n) { atomicAdd(L.rhs(s, i), b[pa.red_boff[i]]); return; }
-            if (!LAY_IS_TSP(L) && L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
-            return;
-        }
-        const SchurCopy cp = pa.copies[w - pa.ninit];
-        for (int e = threadIdx.x; e < cp.rows * cp.cols; e += 256) {
-            const int i = e % cp.rows, j = e / cp.rows;
-            double v = A[cp.off + e];
-            if (cp.r == cp.c) { if (i < j) continue; if (i == j) v += pa.lambda; atomicAdd(L.at(cp.r + i, cp.c + j), v); }
-            else if (cp.r > cp.c) atomicAdd(L.at(cp.r + i, cp.c + j), v);
-            else atomicAdd(L.at(cp.c + j, cp.r + i), v);
-        }
-        return;
-    }
-    // ONE LDS buffer for whichever body the workgroup runs (the larger of the two footprints, not their sum: three workgroups per CU)
-    constexpr int MAXM = 128;
-    constexpr int oRing = 0, oCinv = oRing + ELIM_MFMA_NW * ELIM_DMA_NS * ELIM_DMA_SLOT, oBv = oCinv + MAXM * DV * (DV + 1) / 2, oImg = oBv + MAXM * DV, oRc = oImg + 63 * 64 / 2 + 63 + 1,
-                  DMA_LDS = oRc + 64, TILED_LDS = schur_elim_tiled_lds<DV, 2>(), ALL_LDS = DMA_LDS > TILED_LDS ? DMA_LDS : TILED_LDS;
-    __shared__ __attribute__((aligned(16))) double ldsU[ALL_LDS];
-    double* const ringL = ldsU + oRing; double* const cinvL = ldsU + oCinv; double* const bvL = ldsU + oBv; double* const imgL = ldsU + oImg;
-    uint32_t* const rcL = reinterpret_cast<uint32_t*>(ldsU + oRc); uint32_t* const rsL = rcL + 64;
-    const ElimDesc d = desc[blockIdx.x];
-    const bool narrow = blockIdx.x < nnarrow;                  // (at most MAXM = 128 members per supernode: build_schur closes a supernode there)
-    {   // the members' inverse diagonal blocks (schur_cinv_kernel's arithmetic, same bits): to memory for the back-substitution, to LDS for this workgroup's loop
-        const int64_t dstride = (int64_t)DV * d.nd + DV * DV;
-        for (uint32_t m = threadIdx.x; m < d.nmem; m += 256) {
-            const double* Cg = A + d.dg0 + (int64_t)m * dstride; double C[DV * DV];
-#pragma unroll
-            for (int j = 0; j < DV; ++j)
-#pragma unroll
-                for (int i = j; i < DV; ++i) C[i + DV * j] = Cg[i + DV * j];
-            double bm[DV];
-#pragma unroll
-            for (int i = 0; i < DV; ++i) bm[i] = b[d.eb0 + m * DV + i];
-#pragma unroll
-            for (int j = 0; j < DV; ++j) {
-                double dd = C[j + DV * j] + pa.lambda;
-#pragma unroll
-                for (int k = 0; k < j; ++k) dd -= C[j + DV * k] * C[j + DV * k] * C[k + DV * k];
-                if (dd == 0.0 || dd != dd) { atomicCAS(pa.status, 0, 1); dd = 1.0; }
-                C[j + DV * j] = dd;
-#pragma unroll
-                for (int i = j + 1; i < DV; ++i) { double t = C[i + DV * j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) t -= C[i + DV * k] * C[j + DV * k] * C[k + DV * k];
-                    C[i + DV * j] = t / dd; }
-            }
-#pragma unroll
-            for (int c2 = 0; c2 < DV; ++c2) {
-                double y[DV];
-#pragma unroll
-                for (int i = 0; i < DV; ++i) { double t = (i == c2) ? 1.0 : 0.0;
-#pragma unroll
-                    for (int k = 0; k < i; ++k) t -= C[i + DV * k] * y[k]; y[i] = t; }
-#pragma unroll
-                for (int i = 0; i < DV; ++i) y[i] /= C[i + DV * i];
-#pragma unroll
-                for (int i = DV - 1; i >= 0; --i) { double t = y[i];
-#pragma unroll
-                    for (int k = i + 1; k < DV; ++k) t -= C[k + DV * i] * y[k]; y[i] = t; }
-#pragma unroll
-                for (int i = 0; i < DV; ++i) { Cinv[(int64_t)(d.v0 + m) * (DV * DV) + i + DV * c2] = y[i]; if (narrow && i >= c2) cinvL[m * (DV * (DV + 1) / 2) + c2 * DV - c2 * (c2 - 1) / 2 + (i - c2)] = y[i]; }
-            }
-            if (narrow) {
-#pragma unroll
-                for (int i = 0; i < DV; ++i) bvL[m * DV + i] = bm[i];
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    if (narrow) { const ElimDmaLds lds{ringL, cinvL, bvL, imgL, rcL, rsL}; schur_elim_mfma_dma_body<DV>(A, d, rcflat, L, s, lds); }
-    else schur_elim_tiled_body<DV, 2, 3, true>(A, b, desc, rcflat, Cinv, L, s, blockIdx.x, ldsU);
 }
 
 template <int DV, int NC, int TW>
@@ -1656,80 +1424,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cg[(size_t)(16 * a + li) + (size_t)npad * (16 * b2 + lk + 4 * r)] = cold[a][r] - acc[a][b2][r];
     }
-}
-// The rows below a factored 128 x 128 diagonal block in ONE matrix product (look-ahead factorisation): with the explicit inverse X = inv(L_pp) of the
-// unit-lower block (dense_dinv_kernel<true>) the panel rows are  W = S(rows, panel) X'  and  L = W / Delta  -- no chain of tile-column steps, every
-// 128-row block of S independent work for a workgroup (syrk_update128_kernel's tiling: eight wavefronts, 64 x 32 each, operands through LDS in chunks
-// of 16 columns, products formed transposed so that the stores of a wavefront walk down columns).  Out: L in place of the rows in S, W = L Delta to
-// the panel workspace (the A operand of the trailing update).  Dslot: the factored diagonal block (Delta on its diagonal), column-major 128 x 128.
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void dense_trsm128_kernel(double* __restrict__ S, double* __restrict__ W, const double* __restrict__ Xinv, const double* __restrict__ Dslot, int npad, int p) {
-    __shared__ double As[2][S128_KC * S128_LD], Bs[2][S128_KC * S128_LD];
-    __shared__ double rd[128];
-    const int c0 = 128 * p, I0 = 128 * (p + 1 + (int)blockIdx.x);
-    const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, lk = lane >> 4;
-    const int r0w = (w & 1) * 64, c0w = (w >> 1) * 32;
-    const bool active = I0 + r0w < npad;
-    if (t < 128) rd[t] = 1.0 / Dslot[(size_t)t * 129];
-    double4_t acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = double4_t{0, 0, 0, 0};
-    const int cr = t & 127, kq = t >> 7;
-    const int arow = I0 + cr < npad ? I0 + cr : npad - 1;
-    constexpr int NCP = S128_KC / 4, NCH = 128 / S128_KC;
-    double ra[2][NCP], rb[2][NCP];                             // (operand chunks requested two ahead, as in syrk_update128_kernel)
-    auto gload = [&](int chunk, int set) {
-        const int col0 = chunk * S128_KC;
-        const double* Ga = S + (size_t)arow + (size_t)npad * (c0 + col0);        // S(row, panel column k)
-        const double* Gb = Xinv + (size_t)cr + (size_t)128 * col0;               // X(j = cr, k)
-#pragma unroll
-        for (int i = 0; i < NCP; ++i) { ra[set][i] = Ga[(size_t)npad * (kq + 4 * i)]; rb[set][i] = Gb[(size_t)128 * (kq + 4 * i)]; }
-    };
-    auto lstore = [&](int buf, int set) {
-#pragma unroll
-        for (int i = 0; i < NCP; ++i) { As[buf][(kq + 4 * i) * S128_LD + cr] = ra[set][i]; Bs[buf][(kq + 4 * i) * S128_LD + cr] = rb[set][i]; }
-    };
-    auto products = [&](int buf) {
-        if (!active) return;
-#pragma unroll
-        for (int kk = 0; kk < S128_KC; kk += 4) {
-            double av[4], bv[2];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = As[buf][(kk + lk) * S128_LD + r0w + 16 * a + li];
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) bv[b2] = Bs[buf][(kk + lk) * S128_LD + c0w + 16 * b2 + li];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b2], av[a], acc[a][b2], 0, 0, 0);
-        }
-    };
-    gload(0, 0); gload(1, 1); lstore(0, 0);
-    __syncthreads();
-    static_assert(NCH % 2 == 0, "unrolled by two");
-#pragma unroll 1
-    for (int ch = 0; ch < NCH; ch += 2) {
-        if (ch + 2 < NCH) gload(ch + 2, 0);
-        products(0);
-        lstore(1, 1);
-        __syncthreads();
-        if (ch + 3 < NCH) gload(ch + 3, 1);
-        products(1);
-        if (ch + 2 < NCH) lstore(0, 0);
-        __syncthreads();
-    }
-    if (!active) return;
-    // (transposed tile: row = lane & 15 (+ 16 a), column = (lane >> 4) + 4 r (+ 16 b2), as in syrk_update128_kernel)
-#pragma unroll
-    for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = I0 + r0w + 16 * a + li, j = c0w + 16 * b2 + lk + 4 * r; const double wv = acc[a][b2][r];
-                if (i < npad) { W[(size_t)i + (size_t)npad * j] = wv; S[(size_t)i + (size_t)npad * (c0 + j)] = wv * rd[j]; }
-            }
 }
 // backward substitution L' x = z (unit diagonal), block by block from the bottom.  z = D^-1 L^-1 s is row n of the factor.
 // step 1 (one workgroup per 64-column block kb, many row blocks): partial[kb][j] = sum_{i > kb block} L[i][kb*64+j] * x[i]
@@ -2788,15 +2482,9 @@ static int enqueue_solve_local_t(nlls_ctx* c) {
         if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)((band || TSP) ? n : npad)), c->stream));
         c->S_zeroed = false;
         const int ninit = (std::max(npad, n) + 255) / 256;
-        // (the elimination's own list when tiny supernodes were folded into their neighbours at upload: fewer workgroups, half the atomics)
-        const bool fold = c->n_folded > 0 && c->elim_fold && !c->elim_dma && c->d_elim_desc_fold.p != nullptr;
-        const int64_t ngroups_l = fold ? c->n_fold_groups : c->n_fast_groups, nnarrow_l = fold ? c->n_fold_narrow : nfast_narrow;
-        const ElimDesc* desc_l = fold ? c->d_elim_desc_fold.p : c->d_elim_desc.p; const ElimPre* pre_l = fold ? c->d_elim_pre.p : nullptr;
-        PrepArgs pa{c->d_red_boff.p, c->d_copy.p, c->lambda, ninit, (uint32_t)ngroups_l, c->d_status.p};
-        const dim3 grid((unsigned)(ngroups_l + ninit + c->ncopy));
-        const bool elim_dma = c->elim_dma;      // A/B: the narrow supernodes' member loop fed by LDS-DMA
-#define LAUNCH_ALL(DV) do { if (elim_dma) hipLaunchKernelGGL((schur_elim_all_dma_kernel<DV, LAY>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nfast_narrow, pa); \
-        else hipLaunchKernelGGL((schur_elim_all_kernel<DV, LAY>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, desc_l, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nnarrow_l, pa, pre_l); } while (0)
+        PrepArgs pa{c->d_red_boff.p, c->d_copy.p, c->lambda, ninit, (uint32_t)c->n_fast_groups, c->d_status.p};
+        const dim3 grid((unsigned)(c->n_fast_groups + ninit + c->ncopy));
+#define LAUNCH_ALL(DV) hipLaunchKernelGGL((schur_elim_all_kernel<DV, LAY>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nfast_narrow, pa)
         if (c->fast_dv == 3) LAUNCH_ALL(3); else if (c->fast_dv == 2) LAUNCH_ALL(2); else LAUNCH_ALL(1);
 #undef LAUNCH_ALL
         HIPCHK(hipGetLastError());
@@ -2960,39 +2648,6 @@ int enqueue_reduced_solve(nlls_ctx* c) {
                 if (w.ntot <= 0) continue;
                 if (w.ntot >= c->dense_t128_min) hipLaunchKernelGGL(syrk_update128_kernel, dim3(w.ntot * (w.ntot + 1) / 2), dim3(512), 0, c->stream, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 0, w.nwin, w.strip);
                 else { const int T = 2 * w.ntot; hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T * (T + 1) / 2), dim3(256), 0, c->stream, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 0, 2 * w.nwin, 2 * w.strip); }
-            }
-            launch_dense_dcopy_all(c->stream, c->S.p, Dfac, npad, NB128, 2 * NB128, 0);
-            k = nblk;
-        } else if (c->dense_lookahead && c->dense_t128 && npad % 128 == 0 && npad >= 128 * 8) {
-            // LOOK-AHEAD: the 128-pivot chain of a diagonal block leaves the critical path.  A panel is three small launches -- the diagonal block factored by ONE
-            // workgroup (dense_panel_kernel without rows), its explicit inverse, and the rows below as one matrix product (dense_trsm128_kernel) -- instead of one
-            // launch in which every workgroup repeats the chain; the trailing update goes in two parts: the first tile column (what the next panel needs), then the rest,
-            // and the next diagonal block is factored and inverted on a second stream BESIDE the rest.  (Round 3 overlapped whole panels with whole updates: the
-            // 256-workgroup panel left no room beside it and the two event hand-overs per step cost more than the overlap gained; here the overlapped part is one workgroup.)
-            const int NB128 = npad / 128;
-            double* const Dinv = Dfac + (size_t)(npad / 64 + 1) * 128 * 128;                   // inverses of the diagonal blocks, one slot per 128-block (behind the panels' scratch slots)
-            const DenseWin norows{0, 0, 0};
-            hipStream_t sA = c->stream, sB = c->stream2;
-            auto factor = [&](hipStream_t st, int p) {
-                launch_dense_panel(st, c->S.p, Wbuf, LiD, npad, p, c->d_status.p, 1, Dfac, norows);
-                launch_dense_dinv_one(st, LiD, Dfac + (size_t)(2 * p) * 128 * 128, Dinv + (size_t)p * 128 * 128, npad, p);
-            };
-            factor(sA, 0);
-            for (int p = 0; p < NB128; ++p) {
-                const int T = NB128 - p - 1;                                                    // 128-row blocks behind the panel
-                if (T <= 0) break;
-                hipLaunchKernelGGL(dense_trsm128_kernel, dim3((unsigned)T), dim3(512), 0, sA, c->S.p, Wbuf, (const double*)(Dinv + (size_t)p * 128 * 128), (const double*)(Dfac + (size_t)(2 * p) * 128 * 128), npad, p);
-                if (T >= c->dense_t128_min) {
-                    hipLaunchKernelGGL(syrk_update128_kernel, dim3((unsigned)T), dim3(512), 0, sA, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 1, -1, 0);     // first tile column
-                    HIPCHK(hipEventRecord(c->ev_fork, sA)); HIPCHK(hipStreamWaitEvent(sB, c->ev_fork, 0));
-                    factor(sB, p + 1);                                                          // ... the next diagonal block, beside the rest of the update
-                    HIPCHK(hipEventRecord(c->ev_join, sB));
-                    if (T > 1) hipLaunchKernelGGL(syrk_update128_kernel, dim3((unsigned)((T - 1) * T / 2)), dim3(512), 0, sA, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 2, -1, 0);
-                    HIPCHK(hipStreamWaitEvent(sA, c->ev_join, 0));
-                } else {
-                    const int T64 = 2 * T; hipLaunchKernelGGL(syrk_update2_kernel<2>, dim3(T64 * (T64 + 1) / 2), dim3(256), 0, sA, c->S.p, W0, W1, npad, 2 * p, 2 * p + 2, 0, -1, 0);
-                    factor(sA, p + 1);
-                }
             }
             launch_dense_dcopy_all(c->stream, c->S.p, Dfac, npad, NB128, 2 * NB128, 0);
             k = nblk;

@@ -64,7 +64,7 @@ void hot_set(nlls_ctx* c, std::vector<HotItem>& v) {
     hot(v, c->d_var_kind); hot(v, c->d_var_dim); hot(v, c->d_var_off); hot(v, c->d_var_boff); hot(v, c->d_diag_off); hot(v, c->d_blocksizes);
     hot(v, c->d_zero_off); hot(v, c->d_zero_len); hot(v, c->d_zero_b_off); hot(v, c->d_zero_b_len); hot(v, c->partials); hot(v, c->scalars);
     hot(v, c->S); hot(v, c->Cinv); hot(v, c->tE); hot(v, c->d_status); hot(v, c->d_copy); hot(v, c->d_red_boff); hot(v, c->d_blk_slow);
-    hot(v, c->d_elim_desc); hot(v, c->d_elim_desc_fold); hot(v, c->d_elim_pre); hot(v, c->d_elim_rc); hot(v, c->d_elim_diag); hot(v, c->d_elim_boff); hot(v, c->d_elim_dim); hot(v, c->d_fast_members); hot(v, c->d_fast_groups);
+    hot(v, c->d_elim_desc); hot(v, c->d_elim_rc); hot(v, c->d_elim_diag); hot(v, c->d_elim_boff); hot(v, c->d_elim_dim); hot(v, c->d_fast_members); hot(v, c->d_fast_groups);
     if (c->bcr.ready) { hot(v, c->bcr.ws); hot(v, c->bcr.d_upd); hot(v, c->bcr.d_elim); } else hot(v, c->Lwork);
 }
 }  // namespace
@@ -675,7 +675,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     c->elim_slab = false; c->slab.release(); c->d_slab_off.release(); c->d_slab_groups.release(); c->d_gjobs.release(); c->d_gcons.release(); c->n_gjobs = 0;
     // (the solve also dispatches on the SIZE of these lists: an upload without elimination must not inherit them)
     c->d_elim_ptr.release(); c->d_elim_nbr.release(); c->d_elim_diag.release(); c->d_elim_boff.release(); c->d_elim_dim.release(); c->d_elim_group.release();
-    c->d_fast_groups.release(); c->d_elim_desc.release(); c->d_elim_desc_fold.release(); c->d_elim_pre.release(); c->n_fold_groups = 0; c->n_folded = 0; c->d_elim_rc.release(); c->d_slow_groups.release(); c->d_slow_blocks.release(); c->d_fast_members.release(); c->Cinv.release(); c->tE.release();
+    c->d_fast_groups.release(); c->d_elim_desc.release(); c->d_elim_rc.release(); c->d_slow_groups.release(); c->d_slow_blocks.release(); c->d_fast_members.release(); c->Cinv.release(); c->tE.release();
     std::vector<int64_t> red_of(nb, -1);     // dof offset in the reduced system
     std::vector<std::vector<int32_t>> red_adj; std::vector<int64_t> red_adj_blocks;     // graph of the reduced non-border blocks (kept for the tile-sparse solver's symbolic phase)
     c->tsp.release();
@@ -890,41 +890,8 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 rcflat.insert(rcflat.end(), idx.begin(), idx.end()); }
               desc.push_back(d); }
           if (rcflat.empty()) rcflat.push_back(0);
-          // ---- fold: a tiny supernode (<= 4 members) whose column list is a neighbouring narrow supernode's plus a few columns in front or behind becomes extra
-          // members of that neighbour (bundle adjustment: the one or two points at every step of the visibility window, seen by the cameras of BOTH adjoining runs).
-          // Their share of S over the common columns then costs no atomics and no workgroup of its own; only the strip of the extra columns is added separately.
-          c->n_fold_groups = 0; c->n_fold_narrow = 0; c->n_folded = 0; c->d_elim_desc_fold.release(); c->d_elim_pre.release();
-          if (c->elim_fold && c->nranks == 1 && c->n_fast_narrow > 0 && (int64_t)fastg.size() > c->n_fast_narrow) {
-              std::unordered_map<uint32_t, uint32_t> pos_of; for (uint32_t pos = 0; pos < fastg.size(); ++pos) pos_of[fastg[pos]] = pos;
-              std::vector<std::vector<ElimPre>> pre_of(fastg.size()); std::vector<uint8_t> folded(fastg.size(), 0);
-              for (uint32_t pos = (uint32_t)c->n_fast_narrow; pos < fastg.size(); ++pos) {
-                  const uint32_t gi = fastg[pos]; const ElimDesc& T = desc[pos]; if (T.nmem > 4) continue;
-                  const uint32_t* RT = rcflat.data() + T.rc_off;
-                  int best = -1; uint32_t best_xoff = 0;
-                  for (int side = 0; side < 2; ++side) {        // side 0: the supernode in front (extra columns BEHIND its own), 1: the one behind (extra columns in FRONT)
-                      if (side == 0 ? gi == 0 : gi + 2 >= egroup.size()) continue;
-                      auto it = pos_of.find(side == 0 ? gi - 1 : gi + 1); if (it == pos_of.end() || (int64_t)it->second >= c->n_fast_narrow) continue;
-                      const ElimDesc& B = desc[it->second]; if (B.nd >= T.nd || T.nd - B.nd > 12 || pre_of[it->second].size() + T.nmem > 4) continue;
-                      const uint32_t xoff = side == 0 ? 0u : T.nd - B.nd; const uint32_t* RB = rcflat.data() + B.rc_off;
-                      bool same = true; for (uint32_t q = 0; q < B.nd && same; ++q) same = RB[q] == RT[xoff + q];
-                      if (same && (best < 0 || pre_of[it->second].size() < pre_of[best].size())) { best = (int)it->second; best_xoff = xoff; }
-                  }
-                  if (best < 0) continue;
-                  const int64_t dstrideT = (int64_t)fast_dv * T.nd + fast_dv * fast_dv;
-                  for (uint32_t m = 0; m < T.nmem; ++m)
-                      pre_of[best].push_back(ElimPre{T.dg0 - (int64_t)fast_dv * T.nd + (int64_t)m * dstrideT, T.eb0 + m * (uint32_t)fast_dv, T.v0 + m, T.nd, best_xoff, T.rc_off, T.nd - desc[best].nd});
-                  folded[pos] = 1; c->n_folded++;
-              }
-              if (c->n_folded > 0) {
-                  std::vector<ElimDesc> fdesc; std::vector<ElimPre> pres;
-                  for (uint32_t pos = 0; pos < fastg.size(); ++pos) { if (folded[pos]) continue;
-                      ElimDesc d = desc[pos]; d.pad = pre_of[pos].empty() ? 0u : (uint32_t)((pre_of[pos].size() << 24) | pres.size());
-                      pres.insert(pres.end(), pre_of[pos].begin(), pre_of[pos].end()); fdesc.push_back(d);
-                      if ((int64_t)pos < c->n_fast_narrow) c->n_fold_narrow++; }
-                  c->n_fold_groups = (int64_t)fdesc.size();
-                  if (pres.size() >= ((size_t)1 << 24) || hipSuccess != c->d_elim_desc_fold.upload(fdesc) || hipSuccess != c->d_elim_pre.upload(pres)) { c->n_fold_groups = 0; c->n_folded = 0; c->d_elim_desc_fold.release(); c->d_elim_pre.release(); }
-              }
-          }
+          // (rounds 3-4 could fold the tiny supernodes at every step of the visibility window into a large neighbour -- ElimPre, NLLS_ELIM_FOLD: parity-green, 316 against 294 us
+          //  per solve: the tiny workgroups were filling slots the large ones leave idle.  Out of the library since round 5; last in the tree at commit 6e015b8.)
           if (hipSuccess != c->d_elim_desc.upload(desc) || hipSuccess != c->d_elim_rc.upload(rcflat)) return fail(c, NLLS_ERR_HIP, "supernode descriptor upload"); }
         if (hipSuccess != c->d_fast_groups.upload(fastg) || hipSuccess != c->d_slow_groups.upload(slowg) || hipSuccess != c->d_slow_blocks.upload(slowb) ||
             hipSuccess != c->Cinv.alloc(std::max<size_t>(1, ediag.size() * (size_t)std::max(1, fast_dv * fast_dv)))) return fail(c, NLLS_ERR_HIP, "group list upload");
@@ -1120,7 +1087,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         // kernels, much narrower than the system: a 2-D camera grid, a loop closure -- the blocked LDL' is restricted to the band and the border strip
         // (enqueue_reduced_solve, `dense_window`): O(n w^2) work instead of n^3 / 3.  The reference's LDL' takes any sparsity (src/linearsolver.jl:28-32).
         c->dense_window = I0.is_sparse && c->nelim_all > 0 && c->n_band >= 1024 && !(flags & NLLS_FLAG_NO_BAND) && 2 * (bw + 256) < c->n_band && !getenv("NLLS_NO_DENSE_WINDOW");
-        c->dense_pad128 = c->dense_window || (c->dense_lookahead && n + 1 >= 1024);
+        c->dense_pad128 = c->dense_window;
         const int64_t npad = c->dense_pad128 ? ((n + 1 + 127) / 128) * 128 : ((n + 1 + 63) / 64) * 64;   // +1: the rhs rides along as an extra row
         // TILE-SPARSE: nested dissection of the reduced blocks' graph, the factorisation level by level of its elimination tree (nlls_tsp.hip).  Taken when its
         // dependent chain (levels of the tree) and its tile products come out clearly below what the dense / windowed factorisation of the same system costs

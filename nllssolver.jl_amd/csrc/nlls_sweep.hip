@@ -358,19 +358,6 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (prof && threadIdx.x == 0) prof[gridDim.x + blockIdx.x] = (unsigned long long)wall_clock64();
 }
 
-// The same for THREE-slot kinds whose lists split into {heavy only, heavy only, light only} (BASELINE config 5: the adaptive kernel variable's one
-// 500k-entry row, the camera rows, the point rows): the two heavy roles in front -- compute-bound, two wavefronts per row slice -- the light tiles behind
-// them, ONE launch instead of three that each waited for the previous one's last workgroup (55 + 40 + 25 us at config 5).  Two wavefronts per SIMD:
-// the second-order duals of the adaptive kinds need the registers (three would spill).
-template <int KIND, int LSLOT, int H1SLOT, int H2SLOT>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void gh_fused3_kernel(GhArgs gl, GhArgs gh1, GhArgs gh2, uint32_t heavy_img1, uint32_t heavy_img2,
-                                                                                                    uint32_t nhw1, uint32_t nhw2) {
-    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
-    if (blockIdx.x < nhw1) gh_heavy_body<KIND, H1SLOT, 3>(gh1, blockIdx.x, heavy_img1, dyn_lds);
-    else if (blockIdx.x < nhw1 + nhw2) gh_heavy_body<KIND, H2SLOT, 3>(gh2, blockIdx.x - nhw1, heavy_img2, dyn_lds);
-    else gh_light_body<KIND, LSLOT>(gl, blockIdx.x - nhw1 - nhw2, dyn_lds);
-}
-
 // ================================================================================================
 // accumulate, folded (round 5): every block is evaluated ONCE, by the workgroup of its light row -- and nothing is staged
 // ================================================================================================
@@ -718,35 +705,6 @@ static bool launch_gh_fused(nlls_ctx* c, const Group& G, const double* vars, int
     }
     return false;
 }
-// three-slot kinds: {heavy only, heavy only, light only} in one launch (gh_fused3_kernel); NLLS_SWEEP_SPLIT3=1 keeps the three launches (A/B)
-template <int KIND, int L, int H1, int H2>
-static void launch_gh_fused3_as(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
-    const EntryList& EL = G.lists[L]; const EntryList& E1 = G.lists[H1]; const EntryList& E2 = G.lists[H2];
-    const unsigned nhw1 = (unsigned)((E1.nheavy + HROWS - 1) / HROWS), nhw2 = (unsigned)((E2.nheavy + HROWS - 1) / HROWS);
-    const size_t lds = std::max<size_t>(std::max<size_t>(EL.light_lds + 2, gh_heavy_lds(E1.heavy_lds)), gh_heavy_lds(E2.heavy_lds)) * sizeof(double);
-    // partial sums: the light tiles' first, then the heavy rows' (the order launch_gh_slot would have produced is not kept: the total is a fixed-order sum either way)
-    const GhArgs gl = gh_args<KIND>(c, G, EL, vars, false, c->partials.p + pbase);
-    const GhArgs g1 = gh_args<KIND>(c, G, E1, vars, true, c->partials.p + pbase + EL.nlight), g2 = gh_args<KIND>(c, G, E2, vars, true, c->partials.p + pbase + EL.nlight + E1.nheavy);
-    hipLaunchKernelGGL((gh_fused3_kernel<KIND, L, H1, H2>), dim3(nhw1 + nhw2 + (unsigned)EL.nlight), dim3(TPB), lds, c->stream, gl, g1, g2, E1.heavy_lds, E2.heavy_lds, nhw1, nhw2);
-    pbase += EL.nlight + E1.nheavy + E2.nheavy;
-}
-template <int KIND>
-static bool launch_gh_fused3(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
-    if constexpr (Res<KIND>::NDEPS == 3) {
-        if (c->sweep_split3) return false;                   // (NLLS_SWEEP_SPLIT3=1: one launch per role, for A/B runs)
-        int nl = 0, nh = 0, ls = -1;
-        for (int q = 0; q < 3; ++q) { const EntryList& E = G.lists[q];
-            if (E.nlight > 0 && E.nheavy == 0) { ++nl; ls = q; } else if (E.nheavy > 0 && E.nlight == 0) ++nh; }
-        if (nl != 1 || nh != 2) return false;
-        size_t lds = G.lists[ls].light_lds + 2; for (int q = 0; q < 3; ++q) if (q != ls) lds = std::max(lds, gh_heavy_lds(G.lists[q].heavy_lds));
-        if (lds * sizeof(double) > 64 * 1024) return false;
-        if (ls == 2) launch_gh_fused3_as<KIND, 2, 0, 1>(c, G, vars, pbase);
-        else if (ls == 1) launch_gh_fused3_as<KIND, 1, 0, 2>(c, G, vars, pbase);
-        else launch_gh_fused3_as<KIND, 0, 1, 2>(c, G, vars, pbase);
-        return true;
-    }
-    return false;
-}
 // the folded sweep of a group (Group::fold, built at upload): the light tiles' launch, then the heavy rows' gather
 template <int KIND, int LS>
 static void launch_gh_fold_as(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
@@ -776,7 +734,9 @@ static bool launch_gh_fold(nlls_ctx* c, const Group& G, const double* vars, int6
 template <int KIND>
 static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
     if (c->info.is_sparse) {
-        if (!launch_gh_fold<KIND>(c, G, vars, pbase) && !launch_gh_fused<KIND>(c, G, vars, pbase) && !launch_gh_fused3<KIND>(c, G, vars, pbase)) {
+        // (three-slot kinds whose lists do not qualify for the folded sweep take one launch per role: rounds 2-4's one-launch form of that, gh_fused3_kernel -- every block
+        //  evaluated once per ROLE, 244 registers -- went with the fold: 104 against 55 us at BASELINE config 5; last in the tree at commit 6e015b8)
+        if (!launch_gh_fold<KIND>(c, G, vars, pbase) && !launch_gh_fused<KIND>(c, G, vars, pbase)) {
             launch_gh_slot<KIND, 0>(c, G, vars, pbase); launch_gh_slot<KIND, 1>(c, G, vars, pbase);
             launch_gh_slot<KIND, 2>(c, G, vars, pbase); launch_gh_slot<KIND, 3>(c, G, vars, pbase);
         }

@@ -616,17 +616,25 @@ def test_tile_sparse_ab_switches_still_match_the_oracle(env, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_three_slot_sweep_in_one_launch_per_role(monkeypatch):
-    """NLLS_SWEEP_SPLIT3=1: the adaptive-kernel bundle adjustment's accumulate sweep as round 2 launched it (one launch per role) -- the same sums."""
-    monkeypatch.setenv("NLLS_SWEEP_SPLIT3", "1")
+@pytest.mark.parametrize("fold", ["0", "1"])
+def test_folded_sweep_switch(fold, monkeypatch):
+    """NLLS_SWEEP_FOLD (read at upload): 0 -- no group takes the folded accumulate sweep (a three-slot group then takes one launch per role, every block evaluated once per
+    role: rounds 1-4); 1 -- every group that qualifies takes it, two-slot bundle adjustment included (default: three-slot groups only).  The same sums either way."""
+    monkeypatch.setenv("NLLS_SWEEP_FOLD", fold)
     q = synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(60, 1500, 0.15, seed=41, adaptive=True), 1e-3, 1e-3)
     check_problem(q, lam_scale=1e-4)
+    unfixed = np.ones(q.nvariables, bool); unfixed[0] = False        # the adaptive kernel's variable fixed: its heavy slot has no row at all
+    check_problem(q, unfixed=unfixed, lam_scale=1e-4)
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(60, 1500, 0.15, seed=42, robust=N.HuberKernel(0.02)), 1e-3, 1e-3)
+    check_problem(p, lam_scale=1e-4)
+    unfixed = np.ones(p.nvariables, bool); unfixed[3:40:5] = False; unfixed[100:900:7] = False     # fixed cameras and points: entries without a heavy row, rows without entries
+    check_problem(p, unfixed=unfixed, lam_scale=1e-4)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"NLLS_DENSE_T64": "1"}, {"NLLS_DENSE_T128_MIN": "1"}, {"NLLS_ELIM_TILED": "1"}, {"NLLS_BCR_CHROWS_SLOTS": "0"},
                                  {"NLLS_DENSE_STEP_BACKWARD": "1"}, {"NLLS_BCR_LEVEL_BACKWARD": "1"}, {"NLLS_ELIM_SPLIT": "1"}, {"NLLS_POST_SPLIT": "1"},
-                                 {"NLLS_ELIM_DMA": "1"}, {"NLLS_HEAVY_MAX_ENTRIES": "256"}, {"NLLS_DENSE_LOOKAHEAD": "1"}, {"NLLS_BCR_FOLD_CONVERT": "1"}, {"NLLS_ELIM_FOLD": "1"}])
+                                 {"NLLS_HEAVY_MAX_ENTRIES": "256"}])
 def test_ab_switches_select_paths_that_still_match_the_oracle(env, monkeypatch):
     """The environment switches read by nlls_create (the register-tiled elimination instead of the matrix-core one, the
     64 x 64-tile dense update instead of the 128 x 128 one, the 128 x 128 one from the first pass on, three X rows per panel workgroup at every
