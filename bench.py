@@ -102,6 +102,26 @@ def self_launch(n, deadline_s=None):
     return 0
 
 
+def predicted_scaling(world):
+    """The scaling model of DESIGN.md 5 for `bench.py --gpus N` on BASELINE config 4, printed WITH the measured line so that the first multi-GPU run falsifies it on the spot
+    (no multi-GPU node has been available to this build in five rounds: every number here is a prediction from one-GPU measurements, not a measurement)."""
+    # one LM iteration on one MI355X (round 5: one damped solve per iteration), in us -- from profiles/r05_kernel_stats.csv
+    divides = {"accumulate sweep": 46.0, "Schur elimination": 80.0, "back-substitution + retraction": 27.0, "cost sweep + step statistics": 12.0}
+    replicated = {"block cyclic reduction of the reduced system (every rank)": 170.0, "convert + finish launches": 10.0, "host turn-around + launch gaps": 20.0}
+    allreduce = {2: 40.0, 4: 50.0, 8: 60.0}.get(world, 40.0 + 10.0 * max(0, world.bit_length() - 2))      # [S | s], 3.4 MB, ring over point-to-point xGMI links: latency-dominated
+    route = 9.0                                                                                            # pack / combine launches + the trial's 128-byte gather (measured with one rank: DESIGN.md 5)
+    d, r = sum(divides.values()), sum(replicated.values())
+    strong_us = r + d / world + allreduce + route
+    weak_us = r + d + allreduce + route
+    one = 1e6 / (r + d)
+    return {"model": "t(N) = replicated + divides / N + all-reduce(N) + route  [us per LM iteration, one damped solve each]",
+            "inputs_us": {"divides_by_N": divides, "replicated": replicated, "allreduce_S": allreduce, "collective_route": route},
+            "strong": {"lm_iters_per_s": round(1e6 / strong_us, 1), "speedup_over_1_gpu": round((r + d) / strong_us, 3)},
+            "weak": {"lm_iters_per_s": round(1e6 / weak_us, 1), "residual_blocks_per_s": round(world * 1e6 * 1e6 / weak_us, 1), "throughput_over_1_gpu": round(world * (r + d) / weak_us, 3)},
+            "one_gpu_lm_iters_per_s": round(one, 1),
+            "status": "PREDICTION from one-GPU measurements; strong scaling is bounded by the replicated reduced solve (Amdahl: at most %.2fx)" % ((r + d) / r)}
+
+
 def oracle_loop_fixture(workload, steps):
     try:
         rec = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_trials.json")))[workload][f"iterations_{steps}"]
@@ -461,6 +481,8 @@ def main():
             out["rccl"] = ls.ctx.comm_info()        # what the library's communicator reports (ncclCommCount / ncclCommUserRank), not the environment
         if weak:
             out["weak_scaling"] = weak
+        if world > 1 and args.workload == "ba_1kx100k":
+            out["predicted"] = predicted_scaling(world)
         sys.stdout.flush(); os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)

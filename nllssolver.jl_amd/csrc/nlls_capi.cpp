@@ -381,36 +381,73 @@ int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices
     NEED_READY();
     if (iterator < 0 || iterator > 3) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: iterator must be 0 (Newton), 1 (Levenberg-Marquardt), 2 (dogleg) or 3 (gradient descent)");
     if (nsel < 0 || (nsel > 0 && (!varindices || !cptr))) return NLLS_ERR_INVALID_ARG;
-    if (ctx->nranks != 1) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles runs unsharded");
+    // Under nlls_set_shard (round 5; /root/reference/src/optimize.jl:60-76 is embarrassingly parallel per variable): every rank passes the SAME lists -- the caller's
+    // variable and cost-block numbering -- and relaxes the variables whose cost blocks it owns (an eliminated variable's blocks all live on the rank that owns it:
+    // build_structure); the results are gathered with the installed all-reduce, once.  A variable whose blocks are spread over ranks (a camera) is declined on every rank.
+    const bool sharded = ctx->nranks > 1;
+    if (sharded && (!ctx->reduce_fn || ctx->presharded)) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles under nlls_set_shard needs an installed all-reduce and a library-partitioned upload (not NLLS_FLAG_PRESHARDED)");
     if (nsel == 0) return NLLS_OK;
     const int64_t nc = cptr[nsel];
     if (cptr[0] != 0 || nc < 0 || (nc > 0 && (!cgroup || !cindex || !cslot))) return NLLS_ERR_INVALID_ARG;
-    std::vector<int64_t> sel(nsel); std::vector<uint32_t> cidx((size_t)nc);
     for (int64_t i = 0; i < nsel; ++i) {
         const int64_t v = varindices[i] - 1;
         if (v < 0 || v >= ctx->info.nvar || cptr[i + 1] < cptr[i]) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: bad variable index or cost list");
         if (var_dof(ctx->var_kind[v], ctx->var_dim[v]) > 6) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles: variable with more than 6 degrees of freedom");
-        sel[i] = v;
     }
-    for (int64_t e = 0; e < nc; ++e) {
-        if (cgroup[e] < 0 || cgroup[e] >= (int32_t)ctx->groups.size()) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: bad cost group");
-        const Group& G = ctx->groups[cgroup[e]];
-        if (cindex[e] < 0 || cindex[e] >= G.ncost || cslot[e] < 0 || cslot[e] >= G.ndeps) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: bad cost index or slot");
-        if (G.adaptive && cslot[e] == 0) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles: the adaptive kernel variable cannot be optimised on its own");
-        if (is_dyn_kind(G.res_kind)) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles: dynamic-size cost blocks are not handled by the per-variable kernel");
-        cidx[e] = (uint32_t)cindex[e];
+    // this rank's share: the variables all of whose blocks are local, with the blocks' LOCAL indices
+    std::vector<int64_t> sel, cp(1, 0), pos; std::vector<uint32_t> cidx; std::vector<int32_t> cg, cs; double spread = 0.0;
+    sel.reserve((size_t)nsel); cidx.reserve((size_t)nc); cg.reserve((size_t)nc); cs.reserve((size_t)nc);
+    for (int64_t i = 0; i < nsel; ++i) {
+        int64_t mine = 0; const size_t mark = cidx.size();
+        for (int64_t e = cptr[i]; e < cptr[i + 1]; ++e) {
+            if (cgroup[e] < 0 || cgroup[e] >= (int32_t)ctx->groups.size()) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: bad cost group");
+            const Group& G = ctx->groups[cgroup[e]];
+            const int64_t nglob = G.local_of.empty() ? G.ncost : (int64_t)G.local_of.size();
+            if (cindex[e] < 0 || cindex[e] >= nglob || cslot[e] < 0 || cslot[e] >= G.ndeps) return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_optimize_singles: bad cost index or slot");
+            if (G.adaptive && cslot[e] == 0) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles: the adaptive kernel variable cannot be optimised on its own");
+            if (is_dyn_kind(G.res_kind)) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles: dynamic-size cost blocks are not handled by the per-variable kernel");
+            const int64_t loc = G.local_of.empty() ? cindex[e] : (int64_t)G.local_of[(size_t)cindex[e]];
+            if (loc >= 0) { ++mine; cidx.push_back((uint32_t)loc); cg.push_back(cgroup[e]); cs.push_back(cslot[e]); }
+        }
+        const int64_t all = cptr[i + 1] - cptr[i];
+        // a variable without any block is relaxed (trivially) by rank 0
+        if (mine == all && (all > 0 || ctx->rank == 0 || !sharded)) { sel.push_back(varindices[i] - 1); pos.push_back(i); cp.push_back((int64_t)cidx.size()); }
+        else { cidx.resize(mark); cg.resize(mark); cs.resize(mark); if (mine != 0) spread = 1.0; }
     }
+    if (sharded) {          // a variable whose blocks are spread over ranks: declined everywhere (one small collective, so that no rank is left in the gather below)
+        DevBuf<double> df; HIPCHK(df.alloc(1)); HIPCHK(hipMemcpyAsync(df.p, &spread, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TRY(comm_reduce(ctx, df.p, 1, NLLS_REDUCE_MAX));
+        HIPCHK(hipMemcpyAsync(&spread, df.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (spread != 0.0) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_optimize_singles under nlls_set_shard: a listed variable's cost blocks are spread over ranks (only variables whose blocks one rank owns -- the eliminated ones -- are relaxed in parallel)");
+    }
+    const int64_t nloc = (int64_t)sel.size();
     std::vector<unsigned char> gbuf(singles_group_size() * ctx->groups.size());
     for (size_t g = 0; g < ctx->groups.size(); ++g) singles_group_fill(gbuf.data() + g * singles_group_size(), ctx->groups[g]);
-    DevBuf<int64_t> d_sel, d_cptr, d_iters; DevBuf<int32_t> d_cgroup, d_cslot; DevBuf<uint32_t> d_cidx; DevBuf<unsigned char> d_groups;
-    std::vector<int64_t> cp(cptr, cptr + nsel + 1); std::vector<int32_t> cg(cgroup, cgroup + nc), cs(cslot, cslot + nc);
-    HIPCHK(d_sel.upload(sel)); HIPCHK(d_cptr.upload(cp)); HIPCHK(d_cgroup.upload(cg)); HIPCHK(d_cslot.upload(cs)); HIPCHK(d_cidx.upload(cidx));
-    HIPCHK(d_groups.upload(gbuf)); HIPCHK(d_iters.alloc((size_t)nsel));
+    DevBuf<int64_t> d_sel, d_cptr, d_iters, d_pos, d_all; DevBuf<int32_t> d_cgroup, d_cslot; DevBuf<uint32_t> d_cidx; DevBuf<unsigned char> d_groups;
+    if (cidx.empty()) { cidx.push_back(0); cg.push_back(0); cs.push_back(0); }
+    if (nloc > 0) { HIPCHK(d_sel.upload(sel)); HIPCHK(d_cptr.upload(cp)); HIPCHK(d_cgroup.upload(cg)); HIPCHK(d_cslot.upload(cs)); HIPCHK(d_cidx.upload(cidx)); HIPCHK(d_iters.alloc((size_t)nloc)); }
+    HIPCHK(d_groups.upload(gbuf));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_grad = false; ctx->solved = false; ctx->step_cached = false; ctx->tE_valid = false;   // the variables change under the linear system
-    TRY(enqueue_optimize_singles(ctx, nsel, d_sel.p, d_cptr.p, d_cgroup.p, d_cidx.p, d_cslot.p, d_groups.p, iterator, maxiters, maxfails, reldcost, absdcost, dstep, d_iters.p));
-    if (iters_out) HIPCHK(hipMemcpyAsync(iters_out, d_iters.p, sizeof(int64_t) * nsel, hipMemcpyDeviceToHost, ctx->stream));
+    if (nloc > 0) TRY(enqueue_optimize_singles(ctx, nloc, d_sel.p, d_cptr.p, d_cgroup.p, d_cidx.p, d_cslot.p, d_groups.p, iterator, maxiters, maxfails, reldcost, absdcost, dstep, d_iters.p));
+    if (!sharded) {
+        if (iters_out) HIPCHK(hipMemcpyAsync(iters_out, d_iters.p, sizeof(int64_t) * nsel, hipMemcpyDeviceToHost, ctx->stream));      // (unsharded: nloc == nsel, the caller's order)
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return NLLS_OK;
+    }
+    // the gather: [storage of the variables this rank relaxed, zero elsewhere | their iteration counts at the caller's positions] summed over ranks; then every listed
+    // variable's storage is taken from the sum -- exact: each entry has one non-zero contribution
+    const size_t nst = (size_t)ctx->info.var_storage; DevBuf<double> gb; HIPCHK(gb.alloc(nst + (size_t)nsel));
+    HIPCHK(hipMemsetAsync(gb.p, 0, sizeof(double) * (nst + (size_t)nsel), ctx->stream));
+    double* cur = vars_ptr(ctx, NLLS_VARS_CURRENT);
+    if (nloc > 0) { HIPCHK(d_pos.upload(pos)); TRY(enqueue_copy_var_storage(ctx, d_sel.p, nloc, cur, gb.p)); TRY(enqueue_iters_to_double(ctx, d_iters.p, d_pos.p, nloc, gb.p + nst)); }
+    TRY(comm_reduce(ctx, gb.p, (int64_t)(nst + (size_t)nsel), NLLS_REDUCE_SUM));
+    { std::vector<int64_t> all((size_t)nsel); for (int64_t i = 0; i < nsel; ++i) all[(size_t)i] = varindices[i] - 1; HIPCHK(d_all.upload(all)); }
+    TRY(enqueue_copy_var_storage(ctx, d_all.p, nsel, gb.p, cur));
+    std::vector<double> hit((size_t)nsel);
+    HIPCHK(hipMemcpyAsync(hit.data(), gb.p + nst, sizeof(double) * (size_t)nsel, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (iters_out) for (int64_t i = 0; i < nsel; ++i) iters_out[i] = (int64_t)hit[(size_t)i];
     return NLLS_OK;
 }
 int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {

@@ -518,6 +518,24 @@ int enqueue_max_abs_diag(nlls_ctx* c) {
 }
 
 // optimizesingles!: the launch.  The caller has validated the lists (nlls_optimize_singles).
+// optimizesingles! under sharding: the storage of the listed variables, between the variable set and a dense buffer of the same layout (the ranks' results are
+// gathered by a sum over buffers that are zero where another rank did the work)
+__global__ void copy_var_storage_kernel(const int64_t* __restrict__ sel, int64_t nsel, const uint32_t* __restrict__ var_off, const double* __restrict__ src, double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= nsel) return;
+    const int64_t v = sel[i];
+    for (uint32_t q = var_off[v]; q < var_off[v + 1]; ++q) dst[q] = src[q];
+}
+__global__ void iters_to_double_kernel(const int64_t* __restrict__ it, const int64_t* __restrict__ pos, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[pos[i]] = (double)it[i];
+}
+int enqueue_copy_var_storage(nlls_ctx* c, const int64_t* d_sel, int64_t nsel, const double* src, double* dst) {
+    if (nsel > 0) hipLaunchKernelGGL(copy_var_storage_kernel, dim3((unsigned)((nsel + 255) / 256)), dim3(256), 0, c->stream, d_sel, nsel, c->d_var_off.p, src, dst);
+    return hipGetLastError() == hipSuccess ? NLLS_OK : NLLS_ERR_HIP;
+}
+int enqueue_iters_to_double(nlls_ctx* c, const int64_t* d_it, const int64_t* d_pos, int64_t n, double* d_out) {
+    if (n > 0) hipLaunchKernelGGL(iters_to_double_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_it, d_pos, n, d_out);
+    return hipGetLastError() == hipSuccess ? NLLS_OK : NLLS_ERR_HIP;
+}
 int enqueue_optimize_singles(nlls_ctx* c, int64_t nsel, const int64_t* d_selvar, const int64_t* d_cptr, const int32_t* d_cgroup, const uint32_t* d_cidx,
                              const int32_t* d_cslot, const void* d_groups, int iterator, int maxiters, int maxfails, double reldcost, double absdcost, double dstep, int64_t* d_iters) {
     if (nsel <= 0) return NLLS_OK;

@@ -119,6 +119,7 @@ struct Group {
     bool fold = false; int fold_ls = -1, fold_nh = 0; FoldHeavy fh[FOLD_MAX_HEAVY] = {}; uint32_t fold_lds = 0, fold_unique = 0, fold_shared = 0;   // fold_lds: doubles of LDS per workgroup; fold_unique: bit t -- the light rows' blocks (ls, t) have one writer each; fold_shared: bit t -- they are shared by all entries of their row
     DevBuf<FoldRow> frows; DevBuf<uint32_t> fcons; DevBuf<double> fslab; int64_t nfrows = 0;
     DenseList dense;
+    std::vector<int32_t> local_of;   // sharded upload (the library partitions): cost block k of the caller's group -> its index in this rank's arrays, -1: another rank's.  Empty: every block is local
     // the cost sweep's view of the blocks: a light entry list that holds EVERY cost of the group exactly once (all its slot's variables are
     // free) serves it instead of the cost-order arrays -- the same 24 bytes per block the next gradient sweep streams, so that inside the LM
     // loop (cost sweep of the accepted trial, then the gradient sweep) they are read from the memory-side cache, and the cost-order arrays
@@ -180,7 +181,7 @@ struct nlls_ctx {
     nlls::DevBuf<unsigned long long> prof_clk; int64_t prof_kcount = 0; unsigned prof_nwg[16] = {0};   // [PROF_SLOTS][2][PROF_MAXWG] start / end stamp of every workgroup (100 MHz constant clock) of the fused accumulate launch
     std::string err;
     int err_sub = 0;                         // why the last nlls_upload_structure declined (NLLS_SUB_*): control flow never reads the error text
-    int rank = 0, nranks = 1;
+    int rank = 0, nranks = 1; bool presharded = false;
     // collectives behind the ABI (nlls_comm.cpp): the installed all-reduce, and the library's own RCCL communicator when it is that
     nlls_allreduce_fn reduce_fn = nullptr; void* reduce_user = nullptr; void* rccl_comm = nullptr;
     nlls::DevBuf<double> gatherbuf;          // [nranks][16]: the ranks' trial scalars, gathered by a sum over rows that are zero elsewhere

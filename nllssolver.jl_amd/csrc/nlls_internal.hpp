@@ -35,6 +35,8 @@ int enqueue_max_abs_diag(nlls_ctx* c);        // scalars[3]
 // optimizesingles! (nlls_sweep.hip): all arrays on the device; d_groups = singles_group_size() bytes per cost group
 int enqueue_optimize_singles(nlls_ctx* c, int64_t nsel, const int64_t* d_selvar, const int64_t* d_cptr, const int32_t* d_cgroup, const uint32_t* d_cidx,
                              const int32_t* d_cslot, const void* d_groups, int iterator, int maxiters, int maxfails, double reldcost, double absdcost, double dstep, int64_t* d_iters);
+int enqueue_copy_var_storage(nlls_ctx* c, const int64_t* d_sel, int64_t nsel, const double* src, double* dst);      // the listed variables' storage, src -> dst (same layout)
+int enqueue_iters_to_double(nlls_ctx* c, const int64_t* d_it, const int64_t* d_pos, int64_t n, double* d_out);
 size_t singles_group_size();
 void singles_group_fill(void* dst, const Group& G);
 int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot /* scalars[out], scalars[out+1] = v'Hv, b'v */);

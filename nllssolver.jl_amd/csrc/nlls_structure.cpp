@@ -201,6 +201,7 @@ static int build_fold(nlls_ctx* c, Group& G, const ResDesc& d, const nlls_cost_g
 
 int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
+    c->presharded = (flags & NLLS_FLAG_PRESHARDED) != 0 && c->nranks > 1;
     c->ready = false; c->solved = false; c->have_grad = false; c->lambda = 0; c->reduced_summed = true; c->n_stage0 = 0; c->n_lazy_trials = 0;
     { std::vector<HotItem> v; hot_set(c, v); for (HotItem& it : v) if (!*it.owned) { *it.pp = nullptr; *it.owned = true; } }   // what lived in the previous upload's arena is gone with it
     c->arena.release(); c->arena_pre.release();     // ... so release it NOW: a re-upload would otherwise hold two arenas (and every buffer once more) at its peak
@@ -383,6 +384,8 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
               if (!any) fixedcost.push_back((uint32_t)nl);
               ++nl; }
           G.ncost = nl;
+          G.local_of.clear();
+          if (nranks > 1 && !(flags & NLLS_FLAG_PRESHARDED)) { G.local_of.assign((size_t)in.ncost, -1); int32_t q = 0; for (int64_t k = 0; k < in.ncost; ++k) if (mine[g][k]) G.local_of[(size_t)k] = q++; }
           HIPCHK(G.data.upload(hd)); HIPCHK(G.voff.upload(hv)); }
         G.nfixedcost = (int64_t)fixedcost.size(); HIPCHK(G.fixedcost.upload(fixedcost));
         npartials += (G.nfixedcost + 255) / 256;

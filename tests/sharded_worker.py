@@ -101,6 +101,27 @@ def main():
         assert np.max(np.abs(x_or - x_sh)) < 1e-7 * np.max(np.abs(x_or)), np.max(np.abs(x_or - x_sh))
         assert np.max(np.abs(b_or - sh.b)) < 1e-10 * np.max(np.abs(b_or))
 
+    if seed == 21:
+        # optimizesingles! under sharding (round 5; src/optimize.jl:60-76): every rank passes the same lists and relaxes the points it owns -- all their cost blocks are
+        # local --, one gather of the results: bit for bit what the unsharded device does to the same points; cameras (their blocks spread over ranks) are declined everywhere
+        pts = np.nonzero(p.var_dim == 3)[0] + 1
+        cptr, cgroup, cindex, cslot = p.costlists(pts)
+        o = N.NLLSOptions()
+        kw = dict(maxiters=o.maxiters, maxfails=o.maxfails, reldcost=o.reldcost, absdcost=o.absdcost, dstep=o.dstep, iterator=int(o.iterator))
+        for c_ in (ref.ctx, sh.ctx): c_.set_variables(p.variables, _capi.VARS_CURRENT)
+        it_r = ref.ctx.optimize_singles(pts, cptr, cgroup, cindex, cslot, **kw)
+        it_s = sh.ctx.optimize_singles(pts, cptr, cgroup, cindex, cslot, **kw)
+        v_r, v_s = ref.ctx.get_variables(_capi.VARS_CURRENT), sh.ctx.get_variables(_capi.VARS_CURRENT)
+        assert np.array_equal(it_r, it_s) and it_r.min() >= 1, (it_r[:8], it_s[:8])
+        assert np.array_equal(v_r, v_s) and not np.array_equal(v_r, p.variables), np.max(np.abs(v_r - v_s))
+        if world > 1:
+            cams = np.nonzero(p.var_dim == 6)[0] + 1              # (every camera: those at the ranks' boundaries see points of two ranks)
+            try:
+                sh.ctx.optimize_singles(cams, *p.costlists(cams), **kw); raise AssertionError("cameras relaxed under sharding")
+            except _capi.NllsError as e:
+                assert e.code == _capi.ERR_UNSUPPORTED, e
+        for c_ in (ref.ctx, sh.ctx): c_.set_variables(p.variables, _capi.VARS_CURRENT)
+        ref.costgradhess(); sh.costgradhess()
     # the full gradient is assembled from the ranks' own rows (dogleg / gradient descent need it on every rank)
     b_ref, b_sh = ref.b, sh.b
     assert np.max(np.abs(b_ref - b_sh)) < 1e-10 * np.max(np.abs(b_ref)), np.max(np.abs(b_ref - b_sh))
