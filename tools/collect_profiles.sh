@@ -9,6 +9,7 @@ cp "$(last "$o/${t}_stats/*/*kernel_stats.csv")" $p/${t}_kernel_stats.csv
 for w in ba_100x10k curvefit_10k ba_so3_500x50k; do cp $o/${t}_bench_$w.json $p/${t}_bench_$w.json; cp "$(last "$o/${t}_stats_$w/*/*kernel_stats.csv")" $p/${t}_kernel_stats_$w.csv; done
 cp $o/${t}_bench_ba_10kx1M.json $p/${t}_bench_ba_10kx1M.json
 cp $o/${t}_bench_shuffled.json $p/${t}_bench_shuffled.json
+for x in nofloor forcedist; do [ -f $o/${t}_bench_$x.json ] && cp $o/${t}_bench_$x.json $p/${t}_bench_$x.json; done
 cp $o/${t}_bench_dense.json $p/${t}_bench_dense.json; cp "$(last "$o/${t}_stats_dense/*/*kernel_stats.csv")" $p/${t}_kernel_stats_dense.csv
 cp "$(last "$o/${t}_fetch/*/*counter_collection.csv")" $p/${t}_pmc_fetch_sweep.csv; cp "$(last "$o/${t}_write/*/*counter_collection.csv")" $p/${t}_pmc_write_sweep.csv
 for w in ba_100x10k ba_so3_500x50k; do
