@@ -16,7 +16,7 @@ int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(wha
 #define NEED_READY() do { if (!ctx) return NLLS_ERR_INVALID_ARG; if (!ctx->ready) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_upload_structure has not succeeded"); (void)hipSetDevice(ctx->device); } while (0)
 #define NEED_GRAD_LAZY() do { NEED_READY(); if (!ctx->have_grad) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_sweep_gradhess has not been run"); } while (0)
 // (... and with the reduced rows summed over ranks: every entry point but the LM trial itself reads them as if one GPU had swept all cost blocks)
-#define NEED_GRAD() do { NEED_GRAD_LAZY(); TRY(ensure_reduced_summed(ctx)); } while (0)
+#define NEED_GRAD() do { NEED_GRAD_LAZY(); TRY(ensure_grad_current(ctx)); TRY(ensure_reduced_summed(ctx)); } while (0)
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != NLLS_OK) return rc_; } while (0)
 
 // copy `count` scalars starting at `slot` to the pinned mirror and wait
@@ -26,6 +26,20 @@ int fetch_scalars(nlls_ctx* ctx, int slot, int count) {
     return NLLS_OK;
 }
 bool valid_set(int w) { return w >= 0 && w < 3; }
+// Look-ahead sweep (nlls_ctx::spec_pending): A and b may hold the linearisation at the last trial's point instead of the current one.  Whoever needs them for the
+// CURRENT point comes through here: after the swap of an accepted trial they simply ARE the current point's (a hit); otherwise the current point is swept again (a miss:
+// one accumulate launch, the damping kept) and the look-ahead stays off until the next sweep the caller asks for.
+int ensure_grad_current(nlls_ctx* ctx) {
+    if (!ctx->spec_pending) return NLLS_OK;
+    ctx->spec_pending = false;
+    if (!ctx->spec_stale && ctx->grad_phys == ctx->vars_slot[NLLS_VARS_CURRENT]) { ctx->spec_hits++; return NLLS_OK; }
+    ctx->spec_misses++; ctx->spec_armed = false; ctx->spec_stale = false;
+    const double lam = ctx->lambda; const bool solved = ctx->solved;
+    TRY(enqueue_sweep_gradhess(ctx, false));
+    ctx->lambda = lam; ctx->solved = false; (void)solved;
+    return NLLS_OK;
+}
+void spec_note_write(nlls_ctx* ctx, int32_t which) { if (ctx->spec_pending && ctx->vars_slot[which] == ctx->grad_phys) ctx->spec_stale = true; }
 }  // namespace
 
 extern "C" {
@@ -43,6 +57,7 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     nlls_ctx* c = new (std::nothrow) nlls_ctx();
     if (!c) return NLLS_ERR_HIP;
     c->device = dev; c->num_cus = prop.multiProcessorCount;
+    { const char* e = getenv("NLLS_NO_LOOKAHEAD_SWEEP"); if (e && e[0] == '1') c->spec_on = false; }
     { const char* e = getenv("NLLS_ELIM_TILED"); if (e && e[0] == '1') c->elim_mfma = false; }
     { const char* e = getenv("NLLS_DENSE_T64"); if (e && e[0] == '1') c->dense_t128 = false; }
     { const char* e = getenv("NLLS_EAGER_STAGE0"); if (e && e[0] == '1') c->lazy_stage0 = false; }
@@ -165,6 +180,7 @@ int nlls_get_bsm_index(const nlls_ctx* ctx, int64_t* colptr, int64_t* rowval, in
 
 int nlls_set_variables(nlls_ctx* ctx, int32_t which, const double* packed) {
     NEED_READY(); if (!valid_set(which) || !packed) return NLLS_ERR_INVALID_ARG;
+    spec_note_write(ctx, which);
     HIPCHK(hipMemcpyAsync(vars_ptr(ctx, which), packed, sizeof(double) * ctx->info.var_storage, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
@@ -181,6 +197,7 @@ int nlls_swap_variables(nlls_ctx* ctx, int32_t a, int32_t b) {
 }
 int nlls_copy_variables(nlls_ctx* ctx, int32_t dst, int32_t src) {
     NEED_READY(); if (!valid_set(dst) || !valid_set(src)) return NLLS_ERR_INVALID_ARG;
+    if (dst != src) spec_note_write(ctx, dst);
     if (dst != src) HIPCHK(hipMemcpyAsync(vars_ptr(ctx, dst), vars_ptr(ctx, src), sizeof(double) * ctx->info.var_storage, hipMemcpyDeviceToDevice, ctx->stream));
     return NLLS_OK;
 }
@@ -199,6 +216,13 @@ static int ensure_reduced_summed(nlls_ctx* ctx) {
 }
 int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
     NEED_READY();
+    ctx->spec_armed = true;                                                  // (a sweep the caller asks for: the look-ahead may try again behind the next trial)
+    if (ctx->spec_pending) {
+        const bool hit = !cost_out && !ctx->spec_stale && ctx->grad_phys == ctx->vars_slot[NLLS_VARS_CURRENT];
+        ctx->spec_pending = false; ctx->spec_stale = false;
+        if (hit) { ctx->spec_hits++; ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; ctx->reduced_summed = true; return NLLS_OK; }   // already enqueued behind the trial
+        ctx->spec_misses++;
+    }
     // cost_out == NULL: the caller does not want the cost (the outer loop between iterations, src/optimize.jl:167-170
     // discards it) -- the sweep is then only enqueued: no partial-sum kernel, no synchronisation
     if (ctx->reduce_fn) {
@@ -285,6 +309,7 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
 // solve!, negate!, update!(to, from, x), cost(to).  Same kernels, same order as the separate entry points.
 int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, double* cost_out) {
     NEED_GRAD_LAZY(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
+    TRY(ensure_grad_current(ctx));                 // (a trial right behind a REJECTED one: the look-ahead sweep of that trial's point is in A and b)
     const bool collective = ctx->reduce_fn != nullptr && ctx->info.is_sparse;
     if (!collective) TRY(ensure_reduced_summed(ctx));
     if (ctx->nranks != 1 && !collective) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_lm_trial under nlls_set_shard needs an all-reduce (nlls_comm_init_rccl / nlls_set_allreduce), or the *_local / *_finish pairs");
@@ -306,6 +331,9 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     ctx->trial_to = to; ctx->trial_from = from;    // (the back-substitution launch may take the retraction with it: enqueue_solve_finish)
     { const int rc = enqueue_solve(ctx); ctx->trial_to = ctx->trial_from = -1; TRY(rc); }
     TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form (+ retraction) and the cost sweep, one finishing launch
+    // the look-ahead sweep: the gradient sweep of the trial point, enqueued behind the finishing launch (the host reads the trial's scalars while it runs)
+    if (ctx->spec_on && ctx->spec_armed && ctx->nranks == 1 && ctx->info.is_sparse && from == NLLS_VARS_CURRENT) {
+        TRY(enqueue_sweep_gradhess(ctx, false, to)); ctx->spec_pending = true; ctx->spec_stale = false; }
     }
     // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
     if (!ctx->info.is_sparse || !ctx->h_scalars_dev) {
@@ -455,11 +483,12 @@ int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
     int32_t status[16] = {0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    const int64_t vals[21] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
+    const int64_t vals[23] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
                               ctx->bcr.ready ? ctx->bcr.mfma_issued : 0, ctx->bcr.ready ? ctx->bcr.launches : 0, ctx->bcr.ready ? (int64_t)ctx->bcr.levels.size() : 0, ctx->n_band,
                               status[4] /* pivots the floor of the last undamped band solve dropped */, ctx->n_stage0, ctx->n_lazy_trials, ctx->red_reordered, ctx->bw_caller, ctx->dense_window ? 1 : 0,
-                              ctx->tsp.ready ? ctx->tsp.nt : 0, ctx->tsp.ready ? (int64_t)ctx->tsp.levels.size() : 0, ctx->tsp.ready ? ctx->tsp.nslots : 0, ctx->tsp.ready ? ctx->tsp.launches : 0, ctx->tsp.ready ? ctx->tsp.products : 0};
-    for (int i = 0; i < n && i < 21; ++i) out[i] = vals[i];
+                              ctx->tsp.ready ? ctx->tsp.nt : 0, ctx->tsp.ready ? (int64_t)ctx->tsp.levels.size() : 0, ctx->tsp.ready ? ctx->tsp.nslots : 0, ctx->tsp.ready ? ctx->tsp.launches : 0, ctx->tsp.ready ? ctx->tsp.products : 0,
+                              ctx->spec_hits, ctx->spec_misses /* look-ahead sweeps used / thrown away */};
+    for (int i = 0; i < n && i < 23; ++i) out[i] = vals[i];
     return NLLS_OK;
 }
 int nlls_set_step(nlls_ctx* ctx, const double* x) {
@@ -488,13 +517,14 @@ int nlls_step_norm(nlls_ctx* ctx, double* out) {
 int nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out) {
     NEED_GRAD_LAZY();
     if (ctx->step_cached) { if (xHx_out) *xHx_out = ctx->c_xAx + ctx->lambda * ctx->c_xx; if (gx_out) *gx_out = ctx->c_gx; return NLLS_OK; }   // damping may have changed since
-    TRY(ensure_reduced_summed(ctx));
+    TRY(ensure_grad_current(ctx)); TRY(ensure_reduced_summed(ctx));
     TRY(enqueue_quadform(ctx, ctx->x.p, 4)); TRY(comm_reduce(ctx, ctx->scalars.p + 4, 2, NLLS_REDUCE_SUM)); TRY(fetch_scalars(ctx, 4, 2));
     if (xHx_out) *xHx_out = ctx->h_scalars[4]; if (gx_out) *gx_out = ctx->h_scalars[5];
     return NLLS_OK;
 }
 int nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from) {
     NEED_READY(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
+    spec_note_write(ctx, to);
     return enqueue_retract(ctx, to, from);
 }
 

@@ -220,6 +220,12 @@ struct nlls_ctx {
     double* h_scalars_dev = nullptr;         // ... as the device sees it (the trial's finishing launch writes the scalars there itself)
     int64_t npartials = 0;
     double lambda = 0.0;                     // accumulated uniformscaling! (src/iterators.jl:149,162)
+    // Look-ahead sweep (round 5): nlls_lm_trial enqueues the gradient sweep of the TRIAL point behind the trial's own launches, before the host has seen the trial's cost --
+    // the accepted path (swap CURRENT <-> NEXT, nlls_sweep_gradhess(ctx, NULL)) then finds A and b already being computed and the GPU does not idle through the host's
+    // turn-around; a rejected trial (the next nlls_lm_trial without a swap) sweeps the current point again first.  Transparent: same kernels, same data, same results.
+    int grad_phys = -1;                      // physical variable slot A and b are the linearisation of
+    bool spec_on = true, spec_pending = false, spec_stale = false, spec_armed = true;   // spec_on: NLLS_NO_LOOKAHEAD_SWEEP unset; pending: A, b belong to grad_phys, not (yet) to CURRENT; stale: that slot was written since; armed: the last look-ahead was used (a miss disarms until the next real sweep)
+    int64_t spec_hits = 0, spec_misses = 0;  // nlls_get_solve_stats
     bool have_grad = false;
 
     // ---- sharding ------------------------------------------------------------------------------------

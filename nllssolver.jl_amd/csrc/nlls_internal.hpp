@@ -27,7 +27,7 @@ int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& 
 int enqueue_dyn_gradhess(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);   // dynamic-size residual blocks (dense system): accumulate
 int enqueue_reduce_partials(nlls_ctx* c, int64_t n);
 int enqueue_check_analytic(nlls_ctx* c, double* d_out, int64_t* nblocks_out);   // closed-form block maths against the dual-number statement (nlls_check_analytic)
-int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost = true);
+int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost = true, int which = NLLS_VARS_CURRENT);   // which: the variable set to linearise at (the look-ahead sweep of an LM trial: NLLS_VARS_NEXT)
 // vector helpers (nlls_sweep.hip)
 int enqueue_retract(nlls_ctx* c, int to, int from);
 int enqueue_step_stats(nlls_ctx* c);          // scalars[1] = max|x|, scalars[2] = x'x

@@ -750,9 +750,10 @@ static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& p
     return enqueue_fixedcost(c, G, vars, pbase);
 }
 
-int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost) {
+int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost, int which) {
     c->tE_valid = false; c->step_cached = false;  // A and b change: what the last solve kept of them is stale
-    const double* vars = vars_ptr(c, NLLS_VARS_CURRENT); int64_t pbase = 0;
+    c->grad_phys = c->vars_slot[which];           // the variable set (physical slot) A and b are the linearisation of
+    const double* vars = vars_ptr(c, which); int64_t pbase = 0;
     if (!c->info.is_sparse) {
         HIPCHK(hipMemsetAsync(c->A.p, 0, sizeof(double) * std::max<int64_t>(c->info.nnz_data, 1), c->stream));
         HIPCHK(hipMemsetAsync(c->b.p, 0, sizeof(double) * std::max<int64_t>(c->info.ndof, 1), c->stream));

@@ -151,7 +151,7 @@ def test_damped_pivot_floor_ends_the_noise_floor_rejections():
     ores = oracle_problem(mk()).optimize(maxiters=40, reldcost=-1e300, absdcost=-1e300, dstep=-1.0, maxfails=10 ** 9)
     assert r1.niterations == r0.niterations == ores.niterations == 40
     assert r1.linearsolvers <= r0.linearsolvers and r1.linearsolvers <= ores.linearsolvers, (r1.linearsolvers, r0.linearsolvers, ores.linearsolvers)
-    assert r0.linearsolvers > 44, r0.linearsolvers                    # (the rejections are there without the floor: else this test checks nothing)
+    assert r1.linearsolvers == 40 and r0.linearsolvers > 40, (r1.linearsolvers, r0.linearsolvers)   # one solve per iteration with the floor; rejections without it (how many varies from run to run: they are decided by rounding noise)
     assert np.isclose(r1.bestcost, ores.bestcost, rtol=1e-9) and np.isclose(r0.bestcost, ores.bestcost, rtol=1e-9), (r1.bestcost, r0.bestcost, ores.bestcost)
 
 
