@@ -155,6 +155,43 @@ def test_damped_pivot_floor_ends_the_noise_floor_rejections():
     assert np.isclose(r1.bestcost, ores.bestcost, rtol=1e-9) and np.isclose(r0.bestcost, ores.bestcost, rtol=1e-9), (r1.bestcost, r0.bestcost, ores.bestcost)
 
 
+@pytest.mark.parametrize("floor", [True, False])
+def test_lookahead_sweep_is_transparent(floor, monkeypatch):
+    """Round 5: nlls_lm_trial enqueues the gradient sweep of the TRIAL point behind the trial (the host reads the trial's cost while it runs); an accepted trial's
+    nlls_sweep_gradhess(ctx, NULL) finds it done, a rejected one sweeps the current point again.  Nothing a caller can see changes: with the deterministic assembly of the
+    reduced system (NLLS_FLAG_DETERMINISTIC) every iteration's cost, damping and trial count and the final variables are bit for bit those of NLLS_NO_LOOKAHEAD_SWEEP=1 --
+    with the pivot floor (every look-ahead used) and without it (rejected trials: every rejection a thrown-away look-ahead, counted)."""
+    import time
+    from nllssolver_jl_amd import iterators as It, optimizer as Opt
+    from nllssolver_jl_amd.linearsystem import MultiVariateLSgpu
+    mk = lambda: synthetic.perturb_ba_problem(synthetic.create_ba_problem(120, 4000, 0.06, seed=21, robust=N.HuberKernel(0.02), outlier_frac=0.1, outlier_sigma=0.2), 1e-3, 1e-3)
+    flags = _capi.FLAG_DETERMINISTIC | (0 if floor else _capi.FLAG_NO_PIVOT_FLOOR)
+    out = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("NLLS_NO_LOOKAHEAD_SWEEP", off)
+        p = mk(); ls = MultiVariateLSgpu(p, np.ones(p.nvariables, bool), flags=flags)
+        data = Opt.NLLSInternal(ls, time.perf_counter_ns())
+        loop = Opt.OuterLoop(p, N.NLLSOptions(maxiters=30, reldcost=-np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9), data, It.LevMarData(), It.iterate_levmar, N.nullcallback, True)
+        loop.start(); rows = []
+        while True:
+            c = loop.iterations(1); rows.append((loop.cost, data.bestcost, loop.iteratedata.lambda_, data.linearsolvers))
+            if c: break
+        loop.finish()
+        out[off] = (rows, ls.variables().copy(), ls.ctx.solve_stats()); ls.close()
+    (r1, v1, s1), (r0, v0, s0) = out["1"], out["0"]
+    # (two runs of ONE configuration already differ in the last bits -- the back-substitution's and the sweep's LDS sums are not ordered --, so: tolerances, not bits)
+    assert len(r1) == len(r0) == 30 and np.isclose(r1[-1][1], r0[-1][1], rtol=1e-9 if floor else 1e-7), (r1[-1], r0[-1])    # (without the floor which trials get rejected is decided by rounding noise: two runs of one configuration differ as much)
+    if floor:       # one damped solve per iteration either way: the trajectories can be held against each other iteration by iteration
+        assert [x[3] for x in r1] == [x[3] for x in r0] == list(range(1, 31))
+        assert np.allclose([x[0] for x in r1], [x[0] for x in r0], rtol=1e-11) and np.allclose([x[2] for x in r1], [x[2] for x in r0], rtol=1e-6)
+        q = mk(); assert np.max(np.abs(_ba_predictions(q, v1) - _ba_predictions(q, v0))) < 1e-6      # (gauge-invariant: the optimum is a manifold, the variables drift along it)
+    assert s1["lookahead_hits"] == 0 and s1["lookahead_misses"] == 0
+    rejected = r0[-1][3] - len(r0)                                      # damped solves beyond one per iteration
+    # a rejected trial throws its look-ahead away -- at most once per iteration (the look-ahead then stays off until the next sweep the loop asks for)
+    assert s0["lookahead_hits"] >= len(r0) - 1 - s0["lookahead_misses"] and s0["lookahead_misses"] <= rejected and (s0["lookahead_misses"] > 0) == (rejected > 0), (s0, rejected)
+    assert (rejected == 0) == floor, rejected
+
+
 def test_curvefit_dense():                          # BASELINE config 2
     p, truth = synthetic.create_curvefit_problem(10_000, seed=1)
     op = oracle_problem(p)
