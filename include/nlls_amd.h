@@ -90,6 +90,21 @@ typedef struct nlls_ctx nlls_ctx;
                                      (src/variable.jl:18-32): vars (ZERO_TO_INF, ZERO_TO_ONE); data = (a, b, y).  No counterpart in the
                                      reference's tests; it makes the two bounded scalar kinds reachable outside ContaminatedGaussian */
 #define NLLS_RES_KIND_COUNT      16
+/* USER residual kinds (round 5).  The reference takes any Julia function as a residual and differentiates it with ForwardDiff (/root/reference/src/autodiff.jl:81-93,
+ * README.md:36-46); a HIP kernel cannot call those, so the registry above is closed at run time -- but not at BUILD time: ids 100 .. 107 are reserved for kinds a user
+ * header adds.  Such a header (nllssolver.jl_amd/csrc/Makefile: `make user USER_KINDS=/abs/path/kinds.hpp LIB=libmine.so OBJDIR=build_mine`) specialises
+ * nlls::Res<NLLS_RES_USERk> -- NDEPS (<= 4 slots), M, NDATA, the slots' variable kinds SK / dimensions SD, and ONE templated eval<T>(data, variables, r), generic in the
+ * scalar type exactly like the reference's computeresidual -- and lists its kinds in NLLS_USER_RES(X).  Everything else follows from that: the Jacobian w.r.t. the tangent of
+ * update() by dual numbers, the accumulate kernels, the cost sweep, optimizesingles, the Schur path.  tests/user_kinds/radial_ba.hpp is a worked example (an affine camera
+ * with one radial distortion coefficient), built by __graft_entry__.build() and exercised on the GPU by tests/test_gpu_userkind.py. */
+#define NLLS_RES_USER0          100
+#define NLLS_RES_USER1          101
+#define NLLS_RES_USER2          102
+#define NLLS_RES_USER3          103
+#define NLLS_RES_USER4          104
+#define NLLS_RES_USER5          105
+#define NLLS_RES_USER6          106
+#define NLLS_RES_USER7          107
 
 /* ---- robust kernels: src/robust.jl:7-77 ------------------------------------------------------ */
 #define NLLS_ROBUST_NONE           0 /* NoRobust                                               */

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnlls_amd.so")
+# NLLS_AMD_LIB: another build of the library -- one with USER residual kinds (include/nlls_amd.h, NLLS_RES_USER0 .. 7; the Julia shim reads the same variable)
+LIB_PATH = os.environ.get("NLLS_AMD_LIB") or os.path.join(_HERE, "csrc", "libnlls_amd.so")
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOT_READY, ERR_NOT_SPD, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
 FLAG_FORCE_ATOMIC, FLAG_NO_SCHUR, FLAG_FORCE_SPARSE, FLAG_NO_BAND, FLAG_NO_TWIST, FLAG_NO_BCR, FLAG_DETERMINISTIC = 1, 2, 4, 8, 16, 32, 64

@@ -5,7 +5,7 @@
 
 #define NLLS_FOR_EACH_RES(X) \
     X(NLLS_RES_BA_AFFINE) X(NLLS_RES_ROSENBROCK_A) X(NLLS_RES_ROSENBROCK_B) X(NLLS_RES_ROSENBROCK_2D) \
-    X(NLLS_RES_CURVE_EXP4) X(NLLS_RES_ADAPTIVE_MEAN) X(NLLS_RES_BA_SO3) X(NLLS_RES_BA_SO3_ADAPTIVE) X(NLLS_RES_LINEAR3) X(NLLS_COST_LINEAR3) X(NLLS_RES_SCALE_MIX)
+    X(NLLS_RES_CURVE_EXP4) X(NLLS_RES_ADAPTIVE_MEAN) X(NLLS_RES_BA_SO3) X(NLLS_RES_BA_SO3_ADAPTIVE) X(NLLS_RES_LINEAR3) X(NLLS_COST_LINEAR3) X(NLLS_RES_SCALE_MIX) NLLS_USER_RES(X)
 
 namespace nlls {
 

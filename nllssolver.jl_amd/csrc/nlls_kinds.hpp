@@ -367,6 +367,15 @@ template <> struct Res<NLLS_RES_SCALE_MIX> {   // standalone bounded scalars (sr
         const T s = sv[0][0], w = sv[1][0]; r[0] = s * (w * data[0] + (1.0 - w) * data[1]) - data[2];
     }
 };
+}  // namespace nlls
+// user residual kinds, added at BUILD time (include/nlls_amd.h, NLLS_RES_USER0 .. 7): the header specialises nlls::Res<> and defines NLLS_USER_RES(X)
+#ifdef NLLS_USER_KINDS_HEADER
+#include NLLS_USER_KINDS_HEADER
+#endif
+#ifndef NLLS_USER_RES
+#define NLLS_USER_RES(X)
+#endif
+namespace nlls {
 // kinds whose block is an AbstractCost (value / gradient / Hessian of computecost itself, src/autodiff.jl:144-159), not half a squared residual norm
 template <int KIND> constexpr bool is_cost_kind = (KIND == NLLS_COST_LINEAR3);
 
