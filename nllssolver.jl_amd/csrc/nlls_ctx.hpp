@@ -114,7 +114,7 @@ struct Group {
     DevBuf<uint32_t> voff;      // [ncost][ndeps]
     DevBuf<uint32_t> fixedcost; // costs without any free variable (only their cost counts in the sweep)
     int64_t nfixedcost = 0;
-    EntryList lists[4];
+    EntryList lists[MAX_SLOTS];
     // folded sweep (see FoldTile): the light list `fold_ls` carries every block; lists[fold_ls].fslot / .ftiles hold its per-entry / per-tile words
     bool fold = false; int fold_ls = -1, fold_nh = 0; FoldHeavy fh[FOLD_MAX_HEAVY] = {}; uint32_t fold_lds = 0, fold_unique = 0, fold_shared = 0;   // fold_lds: doubles of LDS per workgroup; fold_unique: bit t -- the light rows' blocks (ls, t) have one writer each; fold_shared: bit t -- they are shared by all entries of their row
     DevBuf<FoldRow> frows; DevBuf<uint32_t> fcons; DevBuf<double> fslab; int64_t nfrows = 0;

@@ -9,7 +9,7 @@
 
 namespace nlls {
 
-struct ResDesc { int ndeps, nres, ndata, adaptive; int sk[4], sd[4]; };
+struct ResDesc { int ndeps, nres, ndata, adaptive; int sk[MAX_SLOTS], sd[MAX_SLOTS]; };
 bool res_desc(int kind, ResDesc& d);
 inline bool is_dyn_kind(int kind) { return kind >= NLLS_RES_DYN_LINEAR && kind <= NLLS_COST_DYN_LINEAR; }
 

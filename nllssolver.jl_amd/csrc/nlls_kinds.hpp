@@ -252,6 +252,7 @@ NLLS_DEV void var_load(const double* v, int start, T* out) {
 // residual kinds: computeresidual() bodies, generic in the scalar type
 // ------------------------------------------------------------------------------------------------
 constexpr int MAXST = 12;   // largest variable storage (POSE_SO3)
+constexpr int MAX_SLOTS = 10;   // variables per cost block: MAX_ARGS of the reference (src/NLLSsolver.jl:28).  The built-in kinds declare SK / SD with four entries; a kind with more slots (a user kind) declares as many as it has
 
 template <int KIND> struct Res;
 

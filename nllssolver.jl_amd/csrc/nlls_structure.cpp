@@ -18,7 +18,8 @@ namespace nlls {
 bool res_desc(int kind, ResDesc& d) {
     switch (kind) {
 #define X(K) case K: d.ndeps = Res<K>::NDEPS; d.nres = is_cost_kind<K> ? 0 : Res<K>::M; d.ndata = Res<K>::NDATA; d.adaptive = Res<K>::ADAPT; \
-        for (int i = 0; i < 4; ++i) { d.sk[i] = Res<K>::SK[i]; d.sd[i] = Res<K>::SD[i]; } return true;
+        static_assert(Res<K>::NDEPS <= MAX_SLOTS, "at most MAX_SLOTS variables per cost block"); \
+        for (int i = 0; i < MAX_SLOTS; ++i) { d.sk[i] = i < Res<K>::NDEPS ? Res<K>::SK[i] : 0; d.sd[i] = i < Res<K>::NDEPS ? Res<K>::SD[i] : 0; } return true;
         NLLS_FOR_EACH_RES(X)
 #undef X
     // dynamic-size kinds (src/autodiff.jl:96-121): counts that depend on the variable's run-time length n are -1 here and fixed per group

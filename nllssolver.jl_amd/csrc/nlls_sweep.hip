@@ -737,8 +737,7 @@ static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& p
         // (three-slot kinds whose lists do not qualify for the folded sweep take one launch per role: rounds 2-4's one-launch form of that, gh_fused3_kernel -- every block
         //  evaluated once per ROLE, 244 registers -- went with the fold: 104 against 55 us at BASELINE config 5; last in the tree at commit 6e015b8)
         if (!launch_gh_fold<KIND>(c, G, vars, pbase) && !launch_gh_fused<KIND>(c, G, vars, pbase)) {
-            launch_gh_slot<KIND, 0>(c, G, vars, pbase); launch_gh_slot<KIND, 1>(c, G, vars, pbase);
-            launch_gh_slot<KIND, 2>(c, G, vars, pbase); launch_gh_slot<KIND, 3>(c, G, vars, pbase);
+            [&]<int... S>(std::integer_sequence<int, S...>) { (launch_gh_slot<KIND, S>(c, G, vars, pbase), ...); }(std::make_integer_sequence<int, Res<KIND>::NDEPS>{});   // (one pass per slot: up to MAX_SLOTS)
         }
     } else if (G.dense.n > 0) {
         const int ndof = (int)c->info.ndof; const int use_lds = ndof <= 64;

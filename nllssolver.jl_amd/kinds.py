@@ -64,7 +64,7 @@ RES_USER0 = 100           # .. 107: residual kinds a USER header adds at build t
 def register_user_kind(kind, ndeps, nres, ndata, slots, adaptive=False):
     """Tell the host mirror about a residual kind of a library built with a user header (ids 100 .. 107): what Res<kind> declares there -- NDEPS, M, NDATA and
     the slots' (variable kind, dimension).  The library itself knows the kind from its build; this table only sizes and checks the host-side arrays."""
-    assert 100 <= kind <= 107 and len(slots) == ndeps <= 4
+    assert 100 <= kind <= 107 and len(slots) == ndeps <= 10
     RES_TABLE[kind] = (int(ndeps), int(nres), int(ndata), bool(adaptive), tuple((int(k), int(d)) for k, d in slots))
 
 

@@ -152,7 +152,7 @@ def test_damped_pivot_floor_ends_the_noise_floor_rejections():
     assert r1.niterations == r0.niterations == ores.niterations == 40
     assert r1.linearsolvers <= r0.linearsolvers and r1.linearsolvers <= ores.linearsolvers, (r1.linearsolvers, r0.linearsolvers, ores.linearsolvers)
     assert r1.linearsolvers == 40 and r0.linearsolvers > 40, (r1.linearsolvers, r0.linearsolvers)   # one solve per iteration with the floor; rejections without it (how many varies from run to run: they are decided by rounding noise)
-    assert np.isclose(r1.bestcost, ores.bestcost, rtol=1e-9) and np.isclose(r0.bestcost, ores.bestcost, rtol=1e-9), (r1.bestcost, r0.bestcost, ores.bestcost)
+    assert np.isclose(r1.bestcost, ores.bestcost, rtol=1e-9) and np.isclose(r0.bestcost, ores.bestcost, rtol=1e-7), (r1.bestcost, r0.bestcost, ores.bestcost)   # (without the floor the trajectory is decided by rounding noise: run to run it ends 1e-9 ... 1e-8 apart)
 
 
 @pytest.mark.parametrize("floor", [True, False])

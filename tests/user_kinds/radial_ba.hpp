@@ -29,5 +29,16 @@ template <> struct Res<NLLS_RES_USER1> {
         r[1] = f * (c[3] * X[0] + c[4] * X[1] + c[5] * X[2]) - data[1];
     }
 };
+// USER2: FIVE slots (the built-in kinds have at most four; the reference allows MAX_ARGS = 10 variables per cost, src/NLLSsolver.jl:28): a quartic through five scalar
+// coefficients, each a variable of its own:  r = a + b t + c t^2 + d t^3 + e t^4 - y,  data = (t, y).  Five degrees of freedom in all: the dense linear system.
+template <> struct Res<NLLS_RES_USER2> {
+    static constexpr int NDEPS = 5, M = 1, NDATA = 2, ADAPT = 0;
+    static constexpr int SK[5] = {NLLS_VAR_EUCLIDEAN, NLLS_VAR_EUCLIDEAN, NLLS_VAR_EUCLIDEAN, NLLS_VAR_EUCLIDEAN, NLLS_VAR_EUCLIDEAN};
+    static constexpr int SD[5] = {1, 1, 1, 1, 1};
+    template <class T> static NLLS_DEV void eval(const double* data, const T (*sv)[MAXST], T* r) {
+        const double t = data[0];
+        r[0] = sv[0][0] + sv[1][0] * t + sv[2][0] * (t * t) + sv[3][0] * (t * t * t) + sv[4][0] * (t * t * t * t) - data[1];
+    }
+};
 }  // namespace nlls
-#define NLLS_USER_RES(X) X(NLLS_RES_USER0) X(NLLS_RES_USER1)
+#define NLLS_USER_RES(X) X(NLLS_RES_USER0) X(NLLS_RES_USER1) X(NLLS_RES_USER2)

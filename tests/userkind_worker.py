@@ -91,6 +91,20 @@ def check(kind):
     print(f"user kind {kind}: cost {c_dev:.6e} = numpy, gradient = central differences, optimize -> {res.bestcost:.2e} in {res.niterations} iterations, optimizesingles ok")
 
 
+def check_five_slots():
+    """USER2: five variables per cost block (more than any built-in kind): a quartic fitted through 4000 noisy samples -- the optimum is the linear least-squares solution"""
+    USER2 = 102
+    K.register_user_kind(USER2, 5, 1, 2, ((K.VAR_EUCLIDEAN, 1),) * 5)
+    rng = np.random.default_rng(9); t = rng.uniform(-1, 1, 4000); coef = np.array([0.3, -1.2, 0.7, 2.0, -0.5])
+    y = np.vander(t, 5, increasing=True) @ coef + 0.01 * rng.standard_normal(t.size)
+    p = N.NLLSProblem(); idx = [p.addvariable([0.0]) for _ in range(5)]
+    p.addcosts(USER2, np.tile(np.array(idx, np.int64), (t.size, 1)), np.stack([t, y], 1))
+    res = N.optimize(p, N.NLLSOptions(maxiters=30))
+    ref = np.linalg.lstsq(np.vander(t, 5, increasing=True), y, rcond=None)[0]
+    assert np.allclose(p.variables, ref, rtol=1e-8, atol=1e-10), (p.variables, ref)
+    print(f"user kind {USER2} (five slots): optimum = numpy lstsq, cost {res.bestcost:.6e}")
+
+
 if __name__ == "__main__":
-    check(USER0); check(USER1)
+    check(USER0); check(USER1); check_five_slots()
     print("user kinds ok")
