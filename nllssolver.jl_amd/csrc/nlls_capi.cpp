@@ -58,6 +58,7 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     if (!c) return NLLS_ERR_HIP;
     c->device = dev; c->num_cus = prop.multiProcessorCount;
     { const char* e = getenv("NLLS_NO_LOOKAHEAD_SWEEP"); if (e && e[0] == '1') c->spec_on = false; }
+    { const char* e = getenv("NLLS_TINY_DENSE"); if (e && e[0] == '0') c->tiny_dense_on = false; }
     { const char* e = getenv("NLLS_ELIM_TILED"); if (e && e[0] == '1') c->elim_mfma = false; }
     { const char* e = getenv("NLLS_DENSE_T64"); if (e && e[0] == '1') c->dense_t128 = false; }
     { const char* e = getenv("NLLS_EAGER_STAGE0"); if (e && e[0] == '1') c->lazy_stage0 = false; }
@@ -327,6 +328,9 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         double* const mirror = ctx->h_scalars_dev; ctx->h_scalars_dev = nullptr;           // (the rank's own scalars are not what the host waits for)
         rc = enqueue_lm_trial_tail(ctx, to, from); ctx->h_scalars_dev = mirror; TRY(rc);
         TRY(comm_gather_trial_scalars(ctx, (double)ctx->trial_seq));
+    } else if (ctx->tiny_dense) {
+        TRY(enqueue_tiny_dense_trial(ctx, to, from));
+        if (ctx->spec_on && ctx->spec_armed && from == NLLS_VARS_CURRENT) { TRY(enqueue_sweep_gradhess(ctx, false, to)); ctx->spec_pending = true; ctx->spec_stale = false; }
     } else {
     ctx->trial_to = to; ctx->trial_from = from;    // (the back-substitution launch may take the retraction with it: enqueue_solve_finish)
     { const int rc = enqueue_solve(ctx); ctx->trial_to = ctx->trial_from = -1; TRY(rc); }
@@ -336,7 +340,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         TRY(enqueue_sweep_gradhess(ctx, false, to)); ctx->spec_pending = true; ctx->spec_stale = false; }
     }
     // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
-    if (!ctx->info.is_sparse || !ctx->h_scalars_dev) {
+    if ((!ctx->info.is_sparse && !ctx->tiny_dense) || !ctx->h_scalars_dev) {
         HIPCHK(hipMemcpyAsync(ctx->h_scalars, ctx->scalars.p, sizeof(double) * 12, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     } else {

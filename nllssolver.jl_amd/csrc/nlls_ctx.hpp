@@ -130,6 +130,7 @@ struct Group {
 // ---- Schur / solve structures ---------------------------------------------------------------------
 // one fast-path supernode, in launch order (position in d_fast_groups): everything a kernel needs to start on it comes with ONE
 // uniform 32-byte load instead of a chain of dependent ones (group list -> group -> neighbour pointer -> neighbour records)
+constexpr int TINY_DENSE_MAX_WGS = 256;     // workgroups (= images of [A | b]) per cost group in the small dense system's sweep
 constexpr int64_t TRIAL_COST_POFS = 4096;   // offset of the cost partials of an LM trial in nlls_ctx::partials (the post-solve partials end at 3584)
 struct ElimDesc {
     uint32_t v0, nmem;       // first member (index into the elimination arrays), members
@@ -226,6 +227,10 @@ struct nlls_ctx {
     int grad_phys = -1;                      // physical variable slot A and b are the linearisation of
     bool spec_on = true, spec_pending = false, spec_stale = false, spec_armed = true;   // spec_on: NLLS_NO_LOOKAHEAD_SWEEP unset; pending: A, b belong to grad_phys, not (yet) to CURRENT; stale: that slot was written since; armed: the last look-ahead was used (a miss disarms until the next real sweep)
     int64_t spec_hits = 0, spec_misses = 0;  // nlls_get_solve_stats
+    // the small dense system (fewer than 64 unknowns, nothing eliminated, one rank: curve fits, Rosenbrock): the sweep leaves one image of [A | b] per workgroup in
+    // dense_slab and ONE gathering launch sums them (no zero fill, no atomics on HBM, no mirror launch); an LM trial is one single-workgroup launch for
+    // damping + factorisation + step statistics + retraction, then the cost sweep.  NLLS_TINY_DENSE=0 keeps the general kernels (A/B)
+    bool tiny_dense = false, tiny_dense_on = true; nlls::DevBuf<double> dense_slab; int64_t dense_slab_wgs = 0, dense_slab_used = 0;
     bool have_grad = false;
 
     // ---- sharding ------------------------------------------------------------------------------------

@@ -1114,19 +1114,24 @@ __global__ void scatter_reduced_kernel(const double* __restrict__ xr, const uint
 // small systems (n < 64): Cholesky, else LU with partial pivoting (the reference falls back from
 // cholesky to qr, src/linearsolver.jl:20-26; any exact solver of a nonsingular system is equivalent)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void small_solve_kernel(const double* __restrict__ S, double* __restrict__ s, int n, int npad, int* __restrict__ status) {
-    __shared__ double M[64 * 65]; __shared__ double rhs[64]; __shared__ int piv; __shared__ int ok;
+// One wavefront.  M (64 x 65 doubles of LDS) = the symmetric matrix read from the lower triangle of S (leading dimension ld) + lambda on the diagonal,
+// rhs = bsrc[map ? map[i] : i]; on return (all lanes, behind a barrier) rhs holds the solution.
+NLLS_DEV void small_solve_lds(const double* __restrict__ S, int ld, double lambda, const double* __restrict__ bsrc, const uint32_t* __restrict__ map, int n,
+                              double* M, double* rhs, int* piv, int* ok, int* __restrict__ status) {
     const int t = threadIdx.x;
-    for (int e = t; e < n * n; e += 64) { const int i = e % n, j = e / n; M[i + 65 * j] = (i >= j) ? S[(size_t)i + (size_t)npad * j] : S[(size_t)j + (size_t)npad * i]; }
-    if (t < n) rhs[t] = s[t];
-    if (t == 0) ok = 1;
+    auto load = [&]() {
+        for (int e = t; e < n * n; e += 64) { const int i = e % n, j = e / n; M[i + 65 * j] = ((i >= j) ? S[(size_t)i + (size_t)ld * j] : S[(size_t)j + (size_t)ld * i]) + (i == j ? lambda : 0.0); }
+        if (t < n) rhs[t] = bsrc[map ? map[t] : (uint32_t)t];
+    };
+    load();
+    if (t == 0) *ok = 1;
     __syncthreads();
     // Cholesky (right-looking), thread = row
     for (int j = 0; j < n; ++j) {
         const double d = M[j + 65 * j];
-        if (!(d > 0)) { if (t == 0) ok = 0; }
+        if (!(d > 0)) { if (t == 0) *ok = 0; }
         __syncthreads();
-        if (!ok) break;
+        if (!*ok) break;
         const double sd = sqrt(d);
         double lij = 0;
         if (t > j && t < n) { lij = M[t + 65 * j] / sd; }
@@ -1137,24 +1142,22 @@ __global__ __launch_bounds__(64) void small_solve_kernel(const double* __restric
         if (t > j && t < n) for (int c2 = j + 1; c2 <= t; ++c2) M[t + 65 * c2] -= lij * M[c2 + 65 * j];
         __syncthreads();
     }
-    if (ok) {
+    if (*ok) {
         if (t == 0) {
             for (int i = 0; i < n; ++i) { double v = rhs[i]; for (int k = 0; k < i; ++k) v -= M[i + 65 * k] * rhs[k]; rhs[i] = v / M[i + 65 * i]; }
             for (int i = n - 1; i >= 0; --i) { double v = rhs[i]; for (int k = i + 1; k < n; ++k) v -= M[k + 65 * i] * rhs[k]; rhs[i] = v / M[i + 65 * i]; }
         }
         __syncthreads();
-        if (t < n) s[t] = rhs[t];
         return;
     }
     // LU with partial pivoting on a fresh symmetric copy
     __syncthreads();
-    for (int e = t; e < n * n; e += 64) { const int i = e % n, j = e / n; M[i + 65 * j] = (i >= j) ? S[(size_t)i + (size_t)npad * j] : S[(size_t)j + (size_t)npad * i]; }
-    if (t < n) rhs[t] = s[t];
+    load();
     __syncthreads();
     for (int j = 0; j < n; ++j) {
-        if (t == 0) { int p = j; double best = fabs(M[j + 65 * j]); for (int i = j + 1; i < n; ++i) { double a = fabs(M[i + 65 * j]); if (a > best) { best = a; p = i; } } piv = p; if (best == 0.0) atomicCAS(status, 0, 2); }
+        if (t == 0) { int p = j; double best = fabs(M[j + 65 * j]); for (int i = j + 1; i < n; ++i) { double a = fabs(M[i + 65 * j]); if (a > best) { best = a; p = i; } } *piv = p; if (best == 0.0) atomicCAS(status, 0, 2); }
         __syncthreads();
-        const int p = piv;
+        const int p = *piv;
         if (p != j) { if (t < n) { double a = M[j + 65 * t]; M[j + 65 * t] = M[p + 65 * t]; M[p + 65 * t] = a; } if (t == 0) { double a = rhs[j]; rhs[j] = rhs[p]; rhs[p] = a; } }
         __syncthreads();
         double f = 0;
@@ -1165,7 +1168,39 @@ __global__ __launch_bounds__(64) void small_solve_kernel(const double* __restric
     }
     if (t == 0) for (int i = n - 1; i >= 0; --i) { double v = rhs[i]; for (int k = i + 1; k < n; ++k) v -= M[i + 65 * k] * rhs[k]; rhs[i] = v / M[i + 65 * i]; }
     __syncthreads();
-    if (t < n) s[t] = rhs[t];
+}
+__global__ __launch_bounds__(64) void small_solve_kernel(const double* __restrict__ S, double* __restrict__ s, int n, int npad, int* __restrict__ status) {
+    __shared__ double M[64 * 65]; __shared__ double rhs[64]; __shared__ int piv; __shared__ int ok;
+    small_solve_lds(S, npad, 0.0, s, nullptr, n, M, rhs, &piv, &ok, status);
+    if ((int)threadIdx.x < n) s[threadIdx.x] = rhs[threadIdx.x];
+}
+// The LM trial of the small dense system (nlls_ctx::tiny_dense) up to its cost sweep, in ONE single-wavefront launch: uniformscaling!(H, lambda), solve!, negate!
+// (src/iterators.jl:149-155), the step's statistics (max|x|, x'x, x'Hx, g'x: what nlls_lm_trial caches for nlls_quadform / nlls_step_stats) and, for problems of at
+// most TINY_RETRACT_MAX variables, update!(to, from, x) (src/linearsystem.jl:206-213).  A is the full symmetric undamped matrix (leading dimension n).
+constexpr int TINY_RETRACT_MAX = 4096;
+__global__ __launch_bounds__(64) void tiny_dense_trial_kernel(const double* __restrict__ A, const double* __restrict__ b, const uint32_t* __restrict__ red_boff, double lambda, int n,
+                                                              double* __restrict__ x, double* __restrict__ scalars, int* __restrict__ status,
+                                                              const int32_t* __restrict__ vkind, const int32_t* __restrict__ vdim, const uint32_t* __restrict__ voff, const uint32_t* __restrict__ vboff,
+                                                              int64_t nretract, const double* __restrict__ vfrom, double* __restrict__ vto) {
+    __shared__ double M[64 * 65]; __shared__ double rhs[64]; __shared__ double xs[64]; __shared__ int piv; __shared__ int ok;
+    const int t = threadIdx.x;
+    if (t < 5) status[t] = 0;
+    xs[t] = 0.0;
+    __syncthreads();
+    small_solve_lds(A, n, lambda, b, red_boff, n, M, rhs, &piv, &ok, status);
+    const uint32_t bo = t < n ? red_boff[t] : 0u;
+    const double xv = t < n ? -rhs[t] : 0.0, bt = t < n ? b[bo] : 0.0;
+    if (t < n) { x[bo] = xv; xs[bo] = xv; }
+    __syncthreads();
+    double Ax = 0;                                                   // row bo of A times x (A is symmetric and stored in full)
+    if (t < n) for (int j = 0; j < n; ++j) Ax += A[(size_t)bo + (size_t)n * j] * xs[j];
+    const bool anynan = __any(is_nan_bits(xv));
+    const double mx = wave_max(fabs(xv)), xx = wave_sum(xv * xv), gx = wave_sum(bt * xv), xAx = wave_sum(xv * Ax);
+    if (t == 0) {
+        scalars[1] = anynan ? __longlong_as_double(0x7ff8000000000000LL) : mx; scalars[2] = xx; scalars[4] = xAx + lambda * xx; scalars[5] = gx;
+        scalars[8] = xAx; scalars[9] = xx; scalars[10] = (double)status[0];
+    }
+    for (int64_t i = t; i < nretract; i += 64) retract_one(vkind, vdim, voff, vboff, i, vfrom, xs, vto);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1952,6 +1987,32 @@ int enqueue_solve_finish(nlls_ctx* c) {
         else c->retract_done = false;
 #undef LAUNCH_BSF
     }
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
+// the end of that trial: the cost partials' sum (the order of reduce_partials_kernel), and the scalars published to the pinned host mirror as trial_finish_kernel does
+__global__ __launch_bounds__(TPB) void tiny_trial_finish_kernel(const double* __restrict__ cpart, int64_t ncp, double* __restrict__ out, double* __restrict__ host_out, double seq) {
+    __shared__ double red[TPB / 64];
+    reduce_partials_body(cpart, ncp, out, red);
+    if (host_out && threadIdx.x == 0) {
+        host_out[0] = out[0]; host_out[1] = out[1]; host_out[2] = out[2]; host_out[4] = out[4]; host_out[5] = out[5]; host_out[8] = out[8]; host_out[9] = out[9]; host_out[10] = out[10];
+        __threadfence_system();
+        reinterpret_cast<volatile double*>(host_out)[32] = seq; reinterpret_cast<volatile double*>(host_out)[33] = seq;
+    }
+}
+// the small dense system's LM trial: damped solve + statistics (+ retraction) in one launch, then the cost sweep; scalars[0..10] as enqueue_lm_trial_tail leaves them
+int enqueue_tiny_dense_trial(nlls_ctx* c, int to, int from) {
+    const int n = (int)c->info.ndof; const int64_t nvar = c->info.nvar;
+    const bool fused_retract = nvar <= TINY_RETRACT_MAX;
+    c->status_known_zero = false; c->retract_done = false;
+    hipLaunchKernelGGL(tiny_dense_trial_kernel, dim3(1), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_red_boff.p, c->lambda, n, c->x.p, c->scalars.p, c->d_status.p,
+                       c->d_var_kind.p, c->d_var_dim.p, c->d_var_off.p, c->d_var_boff.p, fused_retract ? nvar : (int64_t)0, vars_ptr(c, from), vars_ptr(c, to));
+    HIPCHK(hipGetLastError());
+    if (!fused_retract) { const int rc = enqueue_retract(c, to, from); if (rc != NLLS_OK) return rc; }
+    int64_t ncp = 0;
+    { const int rc = enqueue_sweep_cost(c, to, TRIAL_COST_POFS, &ncp); if (rc != NLLS_OK) return rc; }
+    hipLaunchKernelGGL(tiny_trial_finish_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->scalars.p, c->h_scalars_dev, (double)(++c->trial_seq));
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }

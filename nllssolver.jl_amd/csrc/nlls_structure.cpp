@@ -1149,6 +1149,16 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     }
     c->info.has_schur = c->nelim > 0; c->info.nschur_blocks = c->nelim; c->info.nreduced_dof = c->nred;
     c->info.solve_mode = c->solve_mode; c->info.bandwidth = c->bw; c->info.nborder_dof = c->nbd;
+    // the small dense system's own route (nlls_ctx::tiny_dense): one image of [A | b] per sweep workgroup, summed by one gathering launch
+    c->tiny_dense = false; c->dense_slab_wgs = 0;
+    if (c->tiny_dense_on && !c->info.is_sparse && c->solve_mode == SOLVE_SMALL && c->nranks == 1 && c->nelim == 0 && c->info.ndof > 0 && c->nred == c->info.ndof) {
+        bool ok = true; int64_t wgs = 0;
+        for (const Group& G : c->groups) { if (is_dyn_kind(G.res_kind)) ok = false; if (G.dense.n > 0) wgs += std::min<int64_t>((G.dense.n + 255) / 256, TINY_DENSE_MAX_WGS); }
+        if (ok && wgs > 0) {
+            if (hipSuccess != c->dense_slab.alloc((size_t)wgs * (size_t)(c->info.ndof * c->info.ndof + c->info.ndof))) return fail(c, NLLS_ERR_HIP, "dense slab alloc");
+            c->tiny_dense = true; c->dense_slab_wgs = wgs;
+        }
+    }
     return NLLS_OK;
 }
 

@@ -559,6 +559,28 @@ __global__ __launch_bounds__(GTPB) void gh_fold_gather_kernel(const FoldRow* __r
         for (int t = 0; t < 4; ++t) if (F.xmask >> t & 1) { const int sz = ds * F.xdof[t]; if (r < sz) { row[fr.xoff[t] + r] = v; break; } r -= sz; } }
 }
 
+// The small dense system (nlls_ctx::tiny_dense): A and b = the sum of the sweep workgroups' images in launch order, the lower triangle mirrored
+// (symmetrifyfull, BlockDenseMatrix.jl:24-34), and the cost partials' sum -- what two zero fills, the atomics' flush, the mirror launch and the reduction did.
+// Element e of [A | b] (e < n^2 + n), summed by one lane.
+NLLS_DEV void dense_tiny_gather_elem(const double* __restrict__ slab, int nimg, int n, double* __restrict__ A, double* __restrict__ b, int e) {
+    const int n2 = n * n, imglen = n2 + n;
+    const int r = e < n2 ? e % n : 0, cc = e < n2 ? e / n : 0;
+    if (e < n2 && r < cc) return;                                 // (the upper triangle is written by its mirror's lane)
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int k = 0;             // (four partial sums, fixed association)
+    for (; k + 4 <= nimg; k += 4) { a0 += slab[(size_t)k * imglen + e]; a1 += slab[(size_t)(k + 1) * imglen + e]; a2 += slab[(size_t)(k + 2) * imglen + e]; a3 += slab[(size_t)(k + 3) * imglen + e]; }
+    for (; k < nimg; ++k) a0 += slab[(size_t)k * imglen + e];
+    const double v = (a0 + a1) + (a2 + a3);
+    if (e >= n2) b[e - n2] = v; else { A[e] = v; if (r > cc) A[cc + (size_t)n * r] = v; }
+}
+// (The gather as the tail of the last accumulate launch -- the workgroup that draws the last ticket sums the images -- was measured and is SLOWER than this launch:
+//  32.5k against 37.7k LM iterations/s at BASELINE config 2; the device-scope fences it needs write the L2 back.  Same for the trial's cost sweep and its reduction.)
+__global__ __launch_bounds__(TPB) void dense_tiny_gather_kernel(const double* __restrict__ slab, int nimg, int n, double* __restrict__ A, double* __restrict__ b,
+                                                                const double* __restrict__ partials, int64_t npart, double* __restrict__ scalars) {
+    __shared__ double red[TPB / 64];
+    const int e = blockIdx.x * TPB + threadIdx.x;
+    if (e < n * n + n) dense_tiny_gather_elem(slab, nimg, n, A, b, e);
+    if (blockIdx.x == 0 && scalars) reduce_partials_body(partials, npart, scalars, red);
+}
 // ================================================================================================
 // accumulate: dense linear system (MultiVariateLSdense, src/linearsystem.jl:73-87; BlockDenseMatrix.jl)
 // ================================================================================================
@@ -566,7 +588,7 @@ template <int KIND>
 __global__ __launch_bounds__(TPB) void gh_dense_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
                                                        const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ ebrow,
                                                        int64_t n, RobustSpec rk, int ndof, int use_lds,
-                                                       double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials) {
+                                                       double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials, double* __restrict__ slab) {
     using R = Res<KIND>; using I = ResInfo<KIND>;
     extern __shared__ __attribute__((aligned(16))) double img[];
     __shared__ double red[TPB / 64];
@@ -576,15 +598,59 @@ __global__ __launch_bounds__(TPB) void gh_dense_kernel(const double* __restrict_
     double* HA = use_lds ? img : A;
     double* Hb = use_lds ? img + ndof * ndof : b;
     double mycost = 0;
-    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+    // (the loop is uniform per wavefront -- lanes past the end carry zeros -- so that the sums below may run across the whole wave)
+    for (int64_t base = (int64_t)blockIdx.x * TPB; base < n; base += (int64_t)gridDim.x * TPB) {
+        const int64_t e = base + threadIdx.x; const bool valid = e < n;
+        const uint64_t vmask = __ballot(valid);
+        if (vmask == 0) continue;
         double d[R::NDATA]; uint32_t vo[R::NDEPS], br[R::NDEPS];
 #pragma unroll
-        for (int q = 0; q < R::NDATA; ++q) d[q] = edata[(size_t)e * R::NDATA + q];
+        for (int q = 0; q < R::NDEPS; ++q) br[q] = DEST_NONE;
+        BlockGH<KIND> B;
+        if (valid) {
 #pragma unroll
-        for (int q = 0; q < R::NDEPS; ++q) { vo[q] = evoff[(size_t)e * R::NDEPS + q]; br[q] = ebrow[(size_t)e * R::NDEPS + q]; }
-        bool kfree = false; if constexpr (R::ADAPT) kfree = br[0] != DEST_NONE;
-        BlockGH<KIND> B; B.compute(vars, vo, d, rk, kfree);
-        mycost += B.cost;
+            for (int q = 0; q < R::NDATA; ++q) d[q] = edata[(size_t)e * R::NDATA + q];
+#pragma unroll
+            for (int q = 0; q < R::NDEPS; ++q) { vo[q] = evoff[(size_t)e * R::NDEPS + q]; br[q] = ebrow[(size_t)e * R::NDEPS + q]; }
+            bool kfree = false; if constexpr (R::ADAPT) kfree = br[0] != DEST_NONE;
+            B.compute(vars, vo, d, rk, kfree);
+            mycost += B.cost;
+        }
+        // Every block of the wavefront on the SAME variables (a curve fit: all of them, always): 64 lanes' atomics on one LDS address serialise at the read-modify-write
+        // latency -- sum across the wave on the VALU instead (DPP, the total in lane 63) and add once.
+        bool uni = use_lds != 0; uint32_t ubr[R::NDEPS];
+        { const int src = __ffsll((unsigned long long)vmask) - 1;
+#pragma unroll
+          for (int q = 0; q < R::NDEPS; ++q) { ubr[q] = (uint32_t)__shfl((int)br[q], src, 64); uni = uni && __all(!valid || br[q] == ubr[q]); } }
+        if (uni) {
+            const bool l63 = (threadIdx.x & 63) == 63;
+            static_for<R::NDEPS>([&](auto Sc) {
+                constexpr int S = decltype(Sc)::value; constexpr int DS = I::dof(S);
+                if (ubr[S] != DEST_NONE) {
+#pragma unroll
+                    for (int i = 0; i < DS; ++i) { const double v = wave_sum_dpp63(valid ? g_elem<KIND, S>(B, i) : 0.0); if (l63) atomicAdd(&Hb[ubr[S] + i], v); }
+#pragma unroll
+                    for (int j = 0; j < DS; ++j)
+#pragma unroll
+                        for (int i = 0; i < DS; ++i) { const double v = wave_sum_dpp63(valid ? h_elem<KIND, S, S>(B, i, j) : 0.0); if (l63) atomicAdd(&HA[(ubr[S] + i) + (size_t)ndof * (ubr[S] + j)], v); }
+                    static_for<S>([&](auto Tc) {
+                        constexpr int T = decltype(Tc)::value; constexpr int DT = I::dof(T);
+                        if (ubr[T] != DEST_NONE) {
+#pragma unroll
+                            for (int j = 0; j < DT; ++j)
+#pragma unroll
+                                for (int i = 0; i < DS; ++i) {
+                                    const double v = wave_sum_dpp63(valid ? h_elem<KIND, S, T>(B, i, j) : 0.0);
+                                    if (l63) { if (ubr[S] >= ubr[T]) atomicAdd(&HA[(ubr[S] + i) + (size_t)ndof * (ubr[T] + j)], v);
+                                               else atomicAdd(&HA[(ubr[T] + j) + (size_t)ndof * (ubr[S] + i)], v); }
+                                }
+                        }
+                    });
+                }
+            });
+            continue;
+        }
+        if (!valid) continue;
         static_for<R::NDEPS>([&](auto Sc) {
             constexpr int S = decltype(Sc)::value; constexpr int DS = I::dof(S);
             if (br[S] != DEST_NONE) {
@@ -613,7 +679,9 @@ __global__ __launch_bounds__(TPB) void gh_dense_kernel(const double* __restrict_
     double tc = block_sum(mycost, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tc;
     __syncthreads();
-    if (use_lds) {
+    if (slab) {   // the small dense system: this workgroup's image as it is; dense_tiny_gather_kernel sums the images in launch order
+        for (int i = threadIdx.x; i < imglen; i += TPB) slab[(size_t)blockIdx.x * imglen + i] = img[i];
+    } else if (use_lds) {
         for (int i = threadIdx.x; i < ndof * ndof; i += TPB) { double v = img[i]; if (nonzero_bits(v)) atomicAdd(&A[i], v); }
         for (int i = threadIdx.x; i < ndof; i += TPB) { double v = img[ndof * ndof + i]; if (nonzero_bits(v)) atomicAdd(&b[i], v); }
     }
@@ -741,9 +809,11 @@ static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& p
         }
     } else if (G.dense.n > 0) {
         const int ndof = (int)c->info.ndof; const int use_lds = ndof <= 64;
-        int grid = (int)std::min<int64_t>((G.dense.n + TPB - 1) / TPB, 1024);
+        int grid = (int)std::min<int64_t>((G.dense.n + TPB - 1) / TPB, c->tiny_dense ? TINY_DENSE_MAX_WGS : 1024);
+        double* slab = nullptr;
+        if (c->tiny_dense) { slab = c->dense_slab.p + (size_t)c->dense_slab_used * (size_t)(ndof * ndof + ndof); c->dense_slab_used += grid; }
         hipLaunchKernelGGL(gh_dense_kernel<KIND>, dim3(grid), dim3(TPB), use_lds ? (size_t)(ndof * ndof + ndof) * sizeof(double) : 0, c->stream,
-                           vars, G.dense.data.p, G.dense.voff.p, G.dense.brow.p, G.dense.n, G.rk, ndof, use_lds, c->A.p, c->b.p, c->partials.p + pbase);
+                           vars, G.dense.data.p, G.dense.voff.p, G.dense.brow.p, G.dense.n, G.rk, ndof, use_lds, c->A.p, c->b.p, c->partials.p + pbase, slab);
         pbase += grid;
     }
     return enqueue_fixedcost(c, G, vars, pbase);
@@ -753,7 +823,10 @@ int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost, int which) {
     c->tE_valid = false; c->step_cached = false;  // A and b change: what the last solve kept of them is stale
     c->grad_phys = c->vars_slot[which];           // the variable set (physical slot) A and b are the linearisation of
     const double* vars = vars_ptr(c, which); int64_t pbase = 0;
-    if (!c->info.is_sparse) {
+    c->dense_slab_used = 0;
+    if (c->tiny_dense) {
+        // (nothing to zero: the gathering launch writes every element of A and b)
+    } else if (!c->info.is_sparse) {
         HIPCHK(hipMemsetAsync(c->A.p, 0, sizeof(double) * std::max<int64_t>(c->info.nnz_data, 1), c->stream));
         HIPCHK(hipMemsetAsync(c->b.p, 0, sizeof(double) * std::max<int64_t>(c->info.ndof, 1), c->stream));
     } else if (c->nzero > 0) {
@@ -778,6 +851,14 @@ int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost, int which) {
         if (c->prof_e0) { (void)hipEventRecord(c->prof_e0, c->stream); c->prof_e0 = nullptr; c->prof_taken = false; c->prof_e1 = nullptr; }   // (no launch took the pair: bracket what ran -- late, but both events exist)
         if (!c->prof_taken) (void)hipEventRecord(c->prof_ev[2 * pslot + 1], c->stream);
         ++c->prof_count; }
+    if (c->tiny_dense) {
+        const int n = (int)c->info.ndof;
+        if (c->dense_slab_used > c->dense_slab_wgs) { c->err = "dense slab overrun"; return NLLS_ERR_HIP; }
+        hipLaunchKernelGGL(dense_tiny_gather_kernel, dim3((unsigned)((n * n + n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->dense_slab.p, (int)c->dense_slab_used, n, c->A.p, c->b.p,
+                           c->partials.p, pbase, want_cost ? c->scalars.p : (double*)nullptr);
+        HIPCHK(hipGetLastError());
+        return NLLS_OK;
+    }
     if (!c->info.is_sparse && c->info.ndof > 0) {
         const int64_t n2 = c->info.ndof * c->info.ndof;
         hipLaunchKernelGGL(symmetrize_dense_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, c->A.p, (int)c->info.ndof);

@@ -616,6 +616,29 @@ def test_tile_sparse_ab_switches_still_match_the_oracle(env, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tiny", ["0", "1"])
+def test_small_dense_system_switch(tiny, monkeypatch):
+    """NLLS_TINY_DENSE (read by nlls_create): 1 (default) -- a dense system of fewer than 64 unknowns takes its own route (one image of [A | b] per sweep workgroup summed by
+    one gathering launch, no atomics on HBM; the LM trial's damping, factorisation, step statistics and retraction in ONE single-wavefront launch); 0 -- the general dense
+    kernels of rounds 1-4.  The same parity either way: a curve fit, a robustified one, and six free cameras over 5000 FIXED points (more variables than the trial launch
+    retracts itself: the retraction in a launch of its own)."""
+    monkeypatch.setenv("NLLS_TINY_DENSE", tiny)
+    c, _ = synthetic.create_curvefit_problem(3000, seed=5)
+    check_problem(c, expect_sparse=0)
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(6, 5000, 0.5, seed=9, robust=N.HuberKernel(0.05)), 1e-3, 1e-3)
+    unfixed = np.zeros(p.nvariables, bool); unfixed[:6] = True
+    info = check_problem(p, unfixed=unfixed, lam_scale=1e-4, expect_sparse=0)
+    assert info.ndof == 36 and p.nvariables > 4096
+    if tiny == "1":      # the cost is a fixed-order sum; a workgroup's image is built with LDS atomics (rounding-level run-to-run differences), its mirror is exact
+        ctx = _capi.Context(); ctx.upload(p.var_kind, p.var_dim, blockindices(p, unfixed), p.groups(), 0); ctx.set_variables(p.variables)
+        c0 = ctx.sweep_gradhess(); A0, b0 = ctx.get_bsm_data().copy(), ctx.get_grad().copy()
+        for _ in range(3):
+            assert ctx.sweep_gradhess() == c0 and rel(ctx.get_bsm_data(), A0) < 1e-14 and rel(ctx.get_grad(), b0) < 1e-13
+        assert np.array_equal(A0.reshape(36, 36), A0.reshape(36, 36).T)
+        ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fold", ["0", "1"])
 def test_folded_sweep_switch(fold, monkeypatch):
     """NLLS_SWEEP_FOLD (read at upload): 0 -- no group takes the folded accumulate sweep (a three-slot group then takes one launch per role, every block evaluated once per
