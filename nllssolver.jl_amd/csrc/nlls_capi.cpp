@@ -59,6 +59,7 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     c->device = dev; c->num_cus = prop.multiProcessorCount;
     { const char* e = getenv("NLLS_NO_LOOKAHEAD_SWEEP"); if (e && e[0] == '1') c->spec_on = false; }
     { const char* e = getenv("NLLS_TINY_DENSE"); if (e && e[0] == '0') c->tiny_dense_on = false; }
+    { const char* e = getenv("NLLS_TINY_FIN_ROLE"); if (e && e[0] == '0') c->tiny_fin_role = false; }             // (A/B: the trial's finishing reduction always in a launch of its own)
     { const char* e = getenv("NLLS_ELIM_TILED"); if (e && e[0] == '1') c->elim_mfma = false; }
     { const char* e = getenv("NLLS_DENSE_T64"); if (e && e[0] == '1') c->dense_t128 = false; }
     { const char* e = getenv("NLLS_EAGER_STAGE0"); if (e && e[0] == '1') c->lazy_stage0 = false; }
@@ -329,8 +330,10 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         rc = enqueue_lm_trial_tail(ctx, to, from); ctx->h_scalars_dev = mirror; TRY(rc);
         TRY(comm_gather_trial_scalars(ctx, (double)ctx->trial_seq));
     } else if (ctx->tiny_dense) {
-        TRY(enqueue_tiny_dense_trial(ctx, to, from));
-        if (ctx->spec_on && ctx->spec_armed && from == NLLS_VARS_CURRENT) { TRY(enqueue_sweep_gradhess(ctx, false, to)); ctx->spec_pending = true; ctx->spec_stale = false; }
+        const bool la = ctx->spec_on && ctx->spec_armed && from == NLLS_VARS_CURRENT;
+        TRY(enqueue_tiny_dense_trial(ctx, to, from, la && ctx->tiny_fin_role));
+        if (la) { TRY(enqueue_sweep_gradhess(ctx, false, to)); ctx->spec_pending = true; ctx->spec_stale = false; }
+        TRY(enqueue_tiny_trial_finish_pending(ctx));      // (no accumulate launch took the finishing reduction along)
     } else {
     ctx->trial_to = to; ctx->trial_from = from;    // (the back-substitution launch may take the retraction with it: enqueue_solve_finish)
     { const int rc = enqueue_solve(ctx); ctx->trial_to = ctx->trial_from = -1; TRY(rc); }

@@ -130,6 +130,8 @@ struct Group {
 // ---- Schur / solve structures ---------------------------------------------------------------------
 // one fast-path supernode, in launch order (position in d_fast_groups): everything a kernel needs to start on it comes with ONE
 // uniform 32-byte load instead of a chain of dependent ones (group list -> group -> neighbour pointer -> neighbour records)
+// the finishing reduction of the small dense system's LM trial (nlls_wave.hpp dense_fin_body): cost partials -> out[0], the trial's scalars -> the pinned host mirror
+struct DenseFin { const double* cpart; int64_t ncp; double* out; double* host_out; double seq; };
 constexpr int TINY_DENSE_MAX_WGS = 256;     // workgroups (= images of [A | b]) per cost group in the small dense system's sweep
 constexpr int64_t TRIAL_COST_POFS = 4096;   // offset of the cost partials of an LM trial in nlls_ctx::partials (the post-solve partials end at 3584)
 struct ElimDesc {
@@ -231,6 +233,10 @@ struct nlls_ctx {
     // dense_slab and ONE gathering launch sums them (no zero fill, no atomics on HBM, no mirror launch); an LM trial is one single-workgroup launch for
     // damping + factorisation + step statistics + retraction, then the cost sweep.  NLLS_TINY_DENSE=0 keeps the general kernels (A/B)
     bool tiny_dense = false, tiny_dense_on = true; nlls::DevBuf<double> dense_slab; int64_t dense_slab_wgs = 0, dense_slab_used = 0;
+    // An LM trial followed by its look-ahead sweep is FOUR launches: [damped solve + statistics + retraction] (one wavefront), the cost sweep, [the finishing reduction as
+    // workgroup 0 + the look-ahead accumulate sweep], the gather.  dense_fin: a finishing reduction waiting for the accumulate launch that carries it (NLLS_TINY_FIN_ROLE=0:
+    // always a launch of its own, A/B)
+    nlls::DenseFin dense_fin{}; bool dense_fin_pending = false, tiny_fin_role = true;
     bool have_grad = false;
 
     // ---- sharding ------------------------------------------------------------------------------------

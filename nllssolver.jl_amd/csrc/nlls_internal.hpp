@@ -86,7 +86,8 @@ __device__ __forceinline__ void retract_one(const int32_t* __restrict__ kind, co
 int enqueue_solve(nlls_ctx* c);
 int enqueue_solve_local(nlls_ctx* c);
 int enqueue_solve_finish(nlls_ctx* c);
-int enqueue_tiny_dense_trial(nlls_ctx* c, int to, int from);   // nlls_ctx::tiny_dense: damped solve + step statistics + retraction in one launch, then the cost sweep
+int enqueue_tiny_dense_trial(nlls_ctx* c, int to, int from, bool lookahead_follows);
+int enqueue_tiny_trial_finish_pending(nlls_ctx* c);   // the finishing reduction no accumulate launch has carried   // nlls_ctx::tiny_dense: damped solve + step statistics + retraction in one launch, then the cost sweep
 int enqueue_chain_solve(nlls_ctx* c, int n_band, int bw, int nbd, int H);   // the banded reduced system by the chain kernels (nlls_chain.hip)
 int enqueue_reduced_solve(nlls_ctx* c);   // the factorisation + backward pass of the assembled reduced system alone (timing)
 int enqueue_pack_reduce0(nlls_ctx* c);      // [cost | reduced rows | reduced b] -> redbuf

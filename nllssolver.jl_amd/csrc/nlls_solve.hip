@@ -1992,17 +1992,19 @@ int enqueue_solve_finish(nlls_ctx* c) {
 }
 
 // the end of that trial: the cost partials' sum (the order of reduce_partials_kernel), and the scalars published to the pinned host mirror as trial_finish_kernel does
-__global__ __launch_bounds__(TPB) void tiny_trial_finish_kernel(const double* __restrict__ cpart, int64_t ncp, double* __restrict__ out, double* __restrict__ host_out, double seq) {
+__global__ __launch_bounds__(TPB) void tiny_trial_finish_kernel(DenseFin fin) {
     __shared__ double red[TPB / 64];
-    reduce_partials_body(cpart, ncp, out, red);
-    if (host_out && threadIdx.x == 0) {
-        host_out[0] = out[0]; host_out[1] = out[1]; host_out[2] = out[2]; host_out[4] = out[4]; host_out[5] = out[5]; host_out[8] = out[8]; host_out[9] = out[9]; host_out[10] = out[10];
-        __threadfence_system();
-        reinterpret_cast<volatile double*>(host_out)[32] = seq; reinterpret_cast<volatile double*>(host_out)[33] = seq;
-    }
+    dense_fin_body(fin, red);
 }
 // the small dense system's LM trial: damped solve + statistics (+ retraction) in one launch, then the cost sweep; scalars[0..10] as enqueue_lm_trial_tail leaves them
-int enqueue_tiny_dense_trial(nlls_ctx* c, int to, int from) {
+int enqueue_tiny_trial_finish_pending(nlls_ctx* c) {
+    if (!c->dense_fin_pending) return NLLS_OK;
+    c->dense_fin_pending = false;
+    hipLaunchKernelGGL(tiny_trial_finish_kernel, dim3(1), dim3(TPB), 0, c->stream, c->dense_fin);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+int enqueue_tiny_dense_trial(nlls_ctx* c, int to, int from, bool lookahead_follows) {
     const int n = (int)c->info.ndof; const int64_t nvar = c->info.nvar;
     const bool fused_retract = nvar <= TINY_RETRACT_MAX;
     c->status_known_zero = false; c->retract_done = false;
@@ -2012,9 +2014,9 @@ int enqueue_tiny_dense_trial(nlls_ctx* c, int to, int from) {
     if (!fused_retract) { const int rc = enqueue_retract(c, to, from); if (rc != NLLS_OK) return rc; }
     int64_t ncp = 0;
     { const int rc = enqueue_sweep_cost(c, to, TRIAL_COST_POFS, &ncp); if (rc != NLLS_OK) return rc; }
-    hipLaunchKernelGGL(tiny_trial_finish_kernel, dim3(1), dim3(TPB), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->scalars.p, c->h_scalars_dev, (double)(++c->trial_seq));
-    HIPCHK(hipGetLastError());
-    return NLLS_OK;
+    c->dense_fin = DenseFin{c->partials.p + TRIAL_COST_POFS, ncp, c->scalars.p, c->h_scalars_dev, (double)(++c->trial_seq)}; c->dense_fin_pending = true;
+    if (lookahead_follows) return NLLS_OK;                        // (the look-ahead sweep's accumulate launch carries the finishing reduction; nlls_lm_trial launches what is left)
+    return enqueue_tiny_trial_finish_pending(c);
 }
 
 int enqueue_solve(nlls_ctx* c) {

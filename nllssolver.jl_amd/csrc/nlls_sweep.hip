@@ -561,17 +561,6 @@ __global__ __launch_bounds__(GTPB) void gh_fold_gather_kernel(const FoldRow* __r
 
 // The small dense system (nlls_ctx::tiny_dense): A and b = the sum of the sweep workgroups' images in launch order, the lower triangle mirrored
 // (symmetrifyfull, BlockDenseMatrix.jl:24-34), and the cost partials' sum -- what two zero fills, the atomics' flush, the mirror launch and the reduction did.
-// Element e of [A | b] (e < n^2 + n), summed by one lane.
-NLLS_DEV void dense_tiny_gather_elem(const double* __restrict__ slab, int nimg, int n, double* __restrict__ A, double* __restrict__ b, int e) {
-    const int n2 = n * n, imglen = n2 + n;
-    const int r = e < n2 ? e % n : 0, cc = e < n2 ? e / n : 0;
-    if (e < n2 && r < cc) return;                                 // (the upper triangle is written by its mirror's lane)
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int k = 0;             // (four partial sums, fixed association)
-    for (; k + 4 <= nimg; k += 4) { a0 += slab[(size_t)k * imglen + e]; a1 += slab[(size_t)(k + 1) * imglen + e]; a2 += slab[(size_t)(k + 2) * imglen + e]; a3 += slab[(size_t)(k + 3) * imglen + e]; }
-    for (; k < nimg; ++k) a0 += slab[(size_t)k * imglen + e];
-    const double v = (a0 + a1) + (a2 + a3);
-    if (e >= n2) b[e - n2] = v; else { A[e] = v; if (r > cc) A[cc + (size_t)n * r] = v; }
-}
 // (The gather as the tail of the last accumulate launch -- the workgroup that draws the last ticket sums the images -- was measured and is SLOWER than this launch:
 //  32.5k against 37.7k LM iterations/s at BASELINE config 2; the device-scope fences it needs write the L2 back.  Same for the trial's cost sweep and its reduction.)
 __global__ __launch_bounds__(TPB) void dense_tiny_gather_kernel(const double* __restrict__ slab, int nimg, int n, double* __restrict__ A, double* __restrict__ b,
@@ -588,10 +577,13 @@ template <int KIND>
 __global__ __launch_bounds__(TPB) void gh_dense_kernel(const double* __restrict__ vars, const double* __restrict__ edata,
                                                        const uint32_t* __restrict__ evoff, const uint32_t* __restrict__ ebrow,
                                                        int64_t n, RobustSpec rk, int ndof, int use_lds,
-                                                       double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials, double* __restrict__ slab) {
+                                                       double* __restrict__ A, double* __restrict__ b, double* __restrict__ partials, double* __restrict__ slab, DenseFin fin) {
     using R = Res<KIND>; using I = ResInfo<KIND>;
     extern __shared__ __attribute__((aligned(16))) double img[];
     __shared__ double red[TPB / 64];
+    // (fin: workgroup 0 ends the LM trial in front of this look-ahead sweep -- first in the grid, the host is waiting for it)
+    int bid = (int)blockIdx.x, nwg = (int)gridDim.x;
+    if (fin.cpart) { if (bid == 0) { dense_fin_body(fin, red); return; } --bid; --nwg; }
     const int imglen = use_lds ? ndof * ndof + ndof : 0;
     for (int i = threadIdx.x; i < imglen; i += TPB) img[i] = 0.0;
     __syncthreads();
@@ -599,7 +591,7 @@ __global__ __launch_bounds__(TPB) void gh_dense_kernel(const double* __restrict_
     double* Hb = use_lds ? img + ndof * ndof : b;
     double mycost = 0;
     // (the loop is uniform per wavefront -- lanes past the end carry zeros -- so that the sums below may run across the whole wave)
-    for (int64_t base = (int64_t)blockIdx.x * TPB; base < n; base += (int64_t)gridDim.x * TPB) {
+    for (int64_t base = (int64_t)bid * TPB; base < n; base += (int64_t)nwg * TPB) {
         const int64_t e = base + threadIdx.x; const bool valid = e < n;
         const uint64_t vmask = __ballot(valid);
         if (vmask == 0) continue;
@@ -677,10 +669,10 @@ __global__ __launch_bounds__(TPB) void gh_dense_kernel(const double* __restrict_
         });
     }
     double tc = block_sum(mycost, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = tc;
+    if (threadIdx.x == 0) partials[bid] = tc;
     __syncthreads();
     if (slab) {   // the small dense system: this workgroup's image as it is; dense_tiny_gather_kernel sums the images in launch order
-        for (int i = threadIdx.x; i < imglen; i += TPB) slab[(size_t)blockIdx.x * imglen + i] = img[i];
+        for (int i = threadIdx.x; i < imglen; i += TPB) slab[(size_t)bid * imglen + i] = img[i];
     } else if (use_lds) {
         for (int i = threadIdx.x; i < ndof * ndof; i += TPB) { double v = img[i]; if (nonzero_bits(v)) atomicAdd(&A[i], v); }
         for (int i = threadIdx.x; i < ndof; i += TPB) { double v = img[ndof * ndof + i]; if (nonzero_bits(v)) atomicAdd(&b[i], v); }
@@ -810,10 +802,11 @@ static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& p
     } else if (G.dense.n > 0) {
         const int ndof = (int)c->info.ndof; const int use_lds = ndof <= 64;
         int grid = (int)std::min<int64_t>((G.dense.n + TPB - 1) / TPB, c->tiny_dense ? TINY_DENSE_MAX_WGS : 1024);
-        double* slab = nullptr;
+        double* slab = nullptr; DenseFin fin{};
         if (c->tiny_dense) { slab = c->dense_slab.p + (size_t)c->dense_slab_used * (size_t)(ndof * ndof + ndof); c->dense_slab_used += grid; }
-        hipLaunchKernelGGL(gh_dense_kernel<KIND>, dim3(grid), dim3(TPB), use_lds ? (size_t)(ndof * ndof + ndof) * sizeof(double) : 0, c->stream,
-                           vars, G.dense.data.p, G.dense.voff.p, G.dense.brow.p, G.dense.n, G.rk, ndof, use_lds, c->A.p, c->b.p, c->partials.p + pbase, slab);
+        if (c->dense_fin_pending) { fin = c->dense_fin; c->dense_fin_pending = false; }
+        hipLaunchKernelGGL(gh_dense_kernel<KIND>, dim3(grid + (fin.cpart ? 1 : 0)), dim3(TPB), use_lds ? (size_t)(ndof * ndof + ndof) * sizeof(double) : 0, c->stream,
+                           vars, G.dense.data.p, G.dense.voff.p, G.dense.brow.p, G.dense.n, G.rk, ndof, use_lds, c->A.p, c->b.p, c->partials.p + pbase, slab, fin);
         pbase += grid;
     }
     return enqueue_fixedcost(c, G, vars, pbase);
@@ -854,6 +847,8 @@ int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost, int which) {
     if (c->tiny_dense) {
         const int n = (int)c->info.ndof;
         if (c->dense_slab_used > c->dense_slab_wgs) { c->err = "dense slab overrun"; return NLLS_ERR_HIP; }
+        // (summing the images in the next trial's own launch instead -- one launch fewer -- was measured: 39.9k against 46.5k LM iterations/s at BASELINE config 2; the host's
+        //  turn-around between two trials hides behind this launch)
         hipLaunchKernelGGL(dense_tiny_gather_kernel, dim3((unsigned)((n * n + n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->dense_slab.p, (int)c->dense_slab_used, n, c->A.p, c->b.p,
                            c->partials.p, pbase, want_cost ? c->scalars.p : (double*)nullptr);
         HIPCHK(hipGetLastError());

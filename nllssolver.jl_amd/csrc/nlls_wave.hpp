@@ -116,11 +116,35 @@ NLLS_DEV double g_elem(const BlockGH<KIND>& B, int i) {
     if constexpr (R::ADAPT && SA == 0) return B.Gk(i); else return B.G(I::joff(SA) + i);
 }
 
+// the small dense system (nlls_ctx::tiny_dense): the sum of the sweep workgroups' images of [A | b] (nlls_sweep.hip), the lower triangle of A mirrored.
+// Element e of [A | b] (e < n^2 + n), summed by one lane.
+NLLS_DEV void dense_tiny_gather_elem(const double* __restrict__ slab, int nimg, int n, double* __restrict__ A, double* __restrict__ b, int e) {
+    const int n2 = n * n, imglen = n2 + n;
+    const int r = e < n2 ? e % n : 0, cc = e < n2 ? e / n : 0;
+    if (e < n2 && r < cc) return;                                 // (the upper triangle is written by its mirror's lane)
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int k = 0;             // (four partial sums, fixed association)
+    for (; k + 4 <= nimg; k += 4) { a0 += slab[(size_t)k * imglen + e]; a1 += slab[(size_t)(k + 1) * imglen + e]; a2 += slab[(size_t)(k + 2) * imglen + e]; a3 += slab[(size_t)(k + 3) * imglen + e]; }
+    for (; k < nimg; ++k) a0 += slab[(size_t)k * imglen + e];
+    const double v = (a0 + a1) + (a2 + a3);
+    if (e >= n2) b[e - n2] = v; else { A[e] = v; if (r > cc) A[cc + (size_t)n * r] = v; }
+}
+// the end of that system's LM trial: the cost partials' sum and the trial's scalars published to the pinned host mirror (what trial_finish_kernel does for sparse systems).
+// Rides as workgroup 0 of the look-ahead sweep's accumulate launch when there is one (nlls_lm_trial), else tiny_trial_finish_kernel.
+// (struct DenseFin: nlls_ctx.hpp)
 // final deterministic reduction of per-workgroup partials by ONE workgroup of TPB threads (the order every cost total is summed in)
 NLLS_DEV void reduce_partials_body(const double* __restrict__ partials, int64_t n, double* __restrict__ out, double* red) {
     double acc = 0;
     for (int64_t i = threadIdx.x; i < n; i += TPB) acc += partials[i];
     double t = block_sum(acc, red);
     if (threadIdx.x == 0) out[0] = t;
+}
+NLLS_DEV void dense_fin_body(const DenseFin& f, double* red) {
+    reduce_partials_body(f.cpart, f.ncp, f.out, red);
+    if (f.host_out && threadIdx.x == 0) {
+        double* h = f.host_out; const double* o = f.out;
+        h[0] = o[0]; h[1] = o[1]; h[2] = o[2]; h[4] = o[4]; h[5] = o[5]; h[8] = o[8]; h[9] = o[9]; h[10] = o[10];
+        __threadfence_system();
+        reinterpret_cast<volatile double*>(h)[32] = f.seq; reinterpret_cast<volatile double*>(h)[33] = f.seq;
+    }
 }
 }  // namespace nlls

@@ -616,13 +616,14 @@ def test_tile_sparse_ab_switches_still_match_the_oracle(env, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tiny", ["0", "1"])
+@pytest.mark.parametrize("tiny", ["0", "1", "nofinrole"])
 def test_small_dense_system_switch(tiny, monkeypatch):
     """NLLS_TINY_DENSE (read by nlls_create): 1 (default) -- a dense system of fewer than 64 unknowns takes its own route (one image of [A | b] per sweep workgroup summed by
     one gathering launch, no atomics on HBM; the LM trial's damping, factorisation, step statistics and retraction in ONE single-wavefront launch); 0 -- the general dense
     kernels of rounds 1-4.  The same parity either way: a curve fit, a robustified one, and six free cameras over 5000 FIXED points (more variables than the trial launch
     retracts itself: the retraction in a launch of its own)."""
-    monkeypatch.setenv("NLLS_TINY_DENSE", tiny)
+    if tiny == "nofinrole": monkeypatch.setenv("NLLS_TINY_FIN_ROLE", "0"); tiny = "1"    # (the trial's finishing reduction in a launch of its own instead of workgroup 0 of the look-ahead sweep)
+    else: monkeypatch.setenv("NLLS_TINY_DENSE", tiny)
     c, _ = synthetic.create_curvefit_problem(3000, seed=5)
     check_problem(c, expect_sparse=0)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(6, 5000, 0.5, seed=9, robust=N.HuberKernel(0.05)), 1e-3, 1e-3)
