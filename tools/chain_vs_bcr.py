@@ -1,5 +1,7 @@
+"""Reduced solve of camera chains from 50 to 1000 cameras (300 .. 6000 reduced dof): block cyclic reduction (default) against the one-workgroup chain kernels
+(NLLS_FLAG_NO_BCR).  Prints, per size: (reduced solve us, whole solve us, solve_mode, bandwidth) for both.  gpurun -- python tools/chain_vs_bcr.py   """
 import sys, os, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import nllssolver_jl_amd as N
 from nllssolver_jl_amd import synthetic, _capi
