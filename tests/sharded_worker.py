@@ -23,13 +23,26 @@ def main():
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__('datetime').timedelta(seconds=90))
     staged = backend != "nccl"
+    # one scenario per seed; a comma-separated list runs them one after the other in ONE process group (the start of a rank -- interpreter, torch, rendezvous -- is most of a
+    # scenario's two seconds): every scenario ends with a barrier and `destroy_process_group`, which is held back until the last one
+    seeds = [int(v) for v in (sys.argv[5] if len(sys.argv) > 5 else "21").split(",")]
+    real_destroy = dist.destroy_process_group
+    if len(seeds) > 1:
+        dist.destroy_process_group = lambda: None
+    for seed in seeds:
+        scenario(rank, world, dist, staged, seed)
+        sys.stdout.flush()
+    if len(seeds) > 1:
+        dist.barrier(); real_destroy()
+
+
+def scenario(rank, world, dist, staged, seed):
     mk = lambda: ShardedLS(p, unfixed, rank=rank, world=world, dist=dist, host_staged=staged, force_collectives=True)
     import nllssolver_jl_amd as N
     from nllssolver_jl_amd import synthetic, _capi, iterators as It, optimizer as Opt
     from nllssolver_jl_amd.dist import ShardedLS
     from nllssolver_jl_amd.linearsystem import MultiVariateLSgpu
 
-    seed = int(sys.argv[5]) if len(sys.argv) > 5 else 21
     if seed < 0:
         return singular_point_block(rank, world, dist, staged)
     if 5000 <= seed < 6000:

@@ -66,15 +66,15 @@ def test_config5_full_size_so3_adaptive_against_oracle():
 
 
 def test_config5_full_size_lm_iterations_against_oracle():
-    """BASELINE config 5 at full size through ten Levenberg-Marquardt iterations on the device and in the oracle (same start,
+    """BASELINE config 5 at full size through six Levenberg-Marquardt iterations on the device and in the oracle (same start,
     same options): best cost rtol 1e-8.  (The oracle needs about a second per iteration at this size.)"""
     from tests.helpers import oracle_problem
     mk = lambda: synthetic.perturb_ba_problem(synthetic.create_so3_ba_problem(500, 50000, 0.02, seed=1, adaptive=True), 1e-3, 1e-3)
     p = mk(); op = oracle_problem(mk())
     # (the costs of this problem are negative log-likelihoods: 'dcost < bestcost * reldcost', src/optimize.jl:152, needs reldcost > 0 to stay off)
-    ores = op.optimize(maxiters=10, reldcost=1e300, absdcost=-1e300, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
-    res = N.optimize(p, N.NLLSOptions(maxiters=10, reldcost=1e300, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6))
-    assert res.niterations == ores.niterations == 10
+    ores = op.optimize(maxiters=6, reldcost=1e300, absdcost=-1e300, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
+    res = N.optimize(p, N.NLLSOptions(maxiters=6, reldcost=1e300, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6))
+    assert res.niterations == ores.niterations == 6
     assert res.bestcost < res.startcost - 1e3
     assert np.isclose(res.bestcost, ores.bestcost, rtol=1e-8), (res.bestcost, ores.bestcost)
 
@@ -128,14 +128,21 @@ def test_grid_40x40_tile_sparse_and_windowed_solves_against_dense():
     assert times["dense"] >= 5.0 * times["tile_sparse"], times
 
 
-@pytest.mark.parametrize("flags,mode", [(0, 3), (_capi.FLAG_NO_TILE_SPARSE, 1)])
-def test_grid_10k_cameras_is_not_declined(flags, mode):
+def test_grid_10k_cameras_is_not_declined():
     """100 x 100 cameras (60 000 reduced dof, no narrow band): round 3 declined everything above 46 000 reduced dof.  Default: the tile-sparse solver (699 tiles,
-    43 levels; measured 6.5 ms per reduced solve); NLLS_FLAG_NO_TILE_SPARSE: the windowed dense solver in npad^2 doubles (29 GB of the 288 GB; 24 ms) -- the
-    limit is what the device holds.  One sweep + damped solve against the oracle."""
+    43 levels; measured 6.5 ms per reduced solve) -- one sweep + damped solve against the oracle.  NLLS_FLAG_NO_TILE_SPARSE: the windowed dense solver in npad^2 doubles
+    (29 GB of the 288 GB; 24 ms) -- the limit is what the device holds; its damped step against the tile-sparse solver's on the same system (the oracle's factorisation
+    of this system is most of this test's time: it is run once)."""
     p = synthetic.perturb_ba_problem(synthetic.create_grid_ba_problem(100, 100, 3, seed=4, robust=N.HuberKernel(0.05), outlier_frac=0.05, outlier_sigma=0.05, noise=1e-3), 1e-3, 1e-3)
-    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4, flags=flags)
-    assert info.nreduced_dof == 60000 and info.solve_mode == mode and info.bandwidth < 6 * 230
+    info = check_problem(p, expect_sparse=1, expect_schur=1, lam_scale=1e-4, flags=0)
+    assert info.nreduced_dof == 60000 and info.solve_mode == 3 and info.bandwidth < 6 * 230
+    xs = {}
+    for flags, mode in ((0, 3), (_capi.FLAG_NO_TILE_SPARSE, 1)):
+        ctx = _capi.Context(); inf = ctx.upload(p.var_kind, p.var_dim, np.arange(1, p.nvariables + 1, dtype=np.uint64), p.groups(), flags)
+        assert inf.nreduced_dof == 60000 and inf.solve_mode == mode
+        ctx.set_variables(p.variables); ctx.sweep_gradhess(); ctx.damp(1e-4 * ctx.max_abs_diag())
+        xs[mode] = ctx.solve(want_x=True).copy(); ctx.close()
+    assert np.max(np.abs(xs[1] - xs[3])) < 2e-7 * np.max(np.abs(xs[3])), np.max(np.abs(xs[1] - xs[3])) / np.max(np.abs(xs[3]))
 
 
 def test_grid_40k_cameras_tile_sparse_solve_residual():
