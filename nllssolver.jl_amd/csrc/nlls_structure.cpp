@@ -808,6 +808,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     eptr.push_back(0);
     if (c->nelim) {
         std::vector<SchurNbr> prev; uint32_t glen = 0;
+        constexpr uint32_t sn_cap = 128;            // members per supernode
         for (int64_t v = 0; v < nb; ++v) if (c->is_elim[v] && (c->nranks == 1 || c->owner_of_block[v] == c->rank)) {
             std::vector<SchurNbr> nl;
             for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) { int64_t u = c->it_rowval[q]; if (u == v) continue;
@@ -825,7 +826,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             if (lo >= 0) bw = std::max(bw, hi - lo);
             c->max_nbr_dof = std::max(c->max_nbr_dof, nd); c->max_elim_dim = std::max(c->max_elim_dim, (int)c->blocksizes[v]);
             // supernode: same neighbour columns and own size as the previous eliminated block
-            bool same = !edim.empty() && glen < 128 && prev.size() == nl.size() && edim.back() == (uint16_t)c->blocksizes[v];
+            bool same = !edim.empty() && glen < sn_cap && prev.size() == nl.size() && edim.back() == (uint16_t)c->blocksizes[v];
             if (same) for (size_t i = 0; i < prev.size(); ++i) if (prev[i].rcol != nl[i].rcol || prev[i].dim != nl[i].dim) { same = false; break; }
             // ... and its block row follows the previous member's directly in A.data and b: the kernels then step through a
             // supernode with a constant stride instead of looking every member's offsets up (a dependent load per member)
@@ -837,6 +838,22 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             erow.push_back(v); eptr.push_back((int64_t)enbr.size()); ediag.push_back(c->diag_off[v]); eboff.push_back((uint32_t)c->boffsets[v]); edim.push_back((uint16_t)c->blocksizes[v]);
         }
         egroup.push_back((uint32_t)ediag.size());
+        // Few eliminated blocks (BASELINE config 3: 10k points in ~100 runs of 99): one workgroup per run would leave most of the chip idle through the assembly and the
+        // back-substitution.  Runs are cut into balanced pieces of about nelim / 384 members, never below 24 (every piece pays its own flush of the packed image: 1830 atomics at
+        // ten cameras) -- measured at config 3: 5903 (99 members per workgroup), 6346 (50), 6478 (25), 6330 (16), 5706 (8) LM iterations/s; configs 4 and 5 (991 / 500 runs)
+        // lose with ANY cut (2848 -> 2667 / 2505 -> 2332 at 64) and are not cut.  NLLS_SUPERNODE_PIECE=n: the piece size by hand (A/B).
+        { static const int piece_env = [] { const char* e = getenv("NLLS_SUPERNODE_PIECE"); return e ? atoi(e) : 0; }();
+          const int64_t total = (int64_t)ediag.size();
+          const int64_t piece = piece_env > 0 ? piece_env : std::min<int64_t>(128, std::max<int64_t>(24, (total + 383) / 384));
+          if (piece < 128 && c->nranks == 1) {
+              std::vector<uint32_t> cut; cut.reserve(egroup.size() * 2);
+              for (size_t gi = 0; gi + 1 < egroup.size(); ++gi) {
+                  const uint32_t a0 = egroup[gi], m = egroup[gi + 1] - a0;
+                  const uint32_t np = (uint32_t)std::max<int64_t>(1, (2 * (int64_t)m + piece) / (2 * piece));        // round(m / piece)
+                  for (uint32_t k = 0; k < np; ++k) cut.push_back(a0 + (uint32_t)(((uint64_t)m * k) / np));
+              }
+              cut.push_back(egroup.back()); egroup.swap(cut);
+          } }
         c->nelim_groups = (int64_t)egroup.size() - 1;
         // fast-path eligibility: small compile-time block size, few neighbour dof, and the member's off-diagonal
         // blocks stored back to back right before its diagonal block, in reduced-column order

@@ -180,7 +180,7 @@ def test_lookahead_sweep_is_transparent(floor, monkeypatch):
         out[off] = (rows, ls.variables().copy(), ls.ctx.solve_stats()); ls.close()
     (r1, v1, s1), (r0, v0, s0) = out["1"], out["0"]
     # (two runs of ONE configuration already differ in the last bits -- the back-substitution's and the sweep's LDS sums are not ordered --, so: tolerances, not bits)
-    assert len(r1) == len(r0) == 30 and np.isclose(r1[-1][1], r0[-1][1], rtol=1e-9 if floor else 1e-7), (r1[-1], r0[-1])    # (without the floor which trials get rejected is decided by rounding noise: two runs of one configuration differ as much)
+    assert len(r1) == len(r0) == 30 and np.isclose(r1[-1][1], r0[-1][1], rtol=1e-9 if floor else 1e-6), (r1[-1], r0[-1])    # (without the floor which trials get rejected is decided by rounding noise: two runs of one configuration differ as much)
     if floor:       # one damped solve per iteration either way: the trajectories can be held against each other iteration by iteration
         assert [x[3] for x in r1] == [x[3] for x in r0] == list(range(1, 31))
         assert np.allclose([x[0] for x in r1], [x[0] for x in r0], rtol=1e-11) and np.allclose([x[2] for x in r1], [x[2] for x in r0], rtol=1e-6)
