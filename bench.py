@@ -329,8 +329,9 @@ def main():
     achieved_q = alg_bytes / (quoted_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved_q, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved_q / HBM_PEAK_GBS, 4), "frac_cold": None, "traffic": traffic,
-                "kernel": "the accumulate launch(es) of one gradient sweep (two-slot bundle adjustment: gh_fused_kernel, point rows as light tiles + camera rows as heavy tiles; "
-                          "three-slot kinds: gh_fold_kernel + gh_fold_gather_kernel, every block evaluated once)",
+                "kernel": ("the accumulate launch(es) of one gradient sweep (two-slot bundle adjustment: gh_fused_kernel, point rows as light tiles + camera rows as heavy tiles; "
+                           "three-slot kinds: gh_fold_kernel + gh_fold_gather_kernel, every block evaluated once)") if info.is_sparse else
+                          "the gradient sweep of a dense system: gh_dense_kernel (one image of [A | b] per workgroup) + dense_tiny_gather_kernel, bracketed by events -- launch-bound, not HBM-bound (DESIGN.md 4.5)",
                 "algorithmic_bytes_per_launch": int(alg_bytes), "ms_per_launch": round(quoted_ms, 4),
                 "timing": ("in situ, dispatch timestamps: begin .. end of the accumulate dispatch(es) as the command processor records them (hipExtLaunchKernelGGL start / stop events), averaged over the launches "
                            "of the timed LM loop itself -- what rocprofv3 --kernel-trace reports per dispatch") if disp_ms else

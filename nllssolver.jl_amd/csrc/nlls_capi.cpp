@@ -337,10 +337,11 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     } else {
     ctx->trial_to = to; ctx->trial_from = from;    // (the back-substitution launch may take the retraction with it: enqueue_solve_finish)
     { const int rc = enqueue_solve(ctx); ctx->trial_to = ctx->trial_from = -1; TRY(rc); }
-    TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form (+ retraction) and the cost sweep, one finishing launch
+    const bool la = ctx->spec_on && ctx->spec_armed && ctx->nranks == 1 && ctx->info.is_sparse && from == NLLS_VARS_CURRENT;
+    ctx->tail_zero_for_lookahead = la; ctx->heavy_rows_zeroed = false;
+    { const int rc = enqueue_lm_trial_tail(ctx, to, from); ctx->tail_zero_for_lookahead = false; TRY(rc); }     // step statistics + quadratic form (+ retraction) and the cost sweep, one finishing launch
     // the look-ahead sweep: the gradient sweep of the trial point, enqueued behind the finishing launch (the host reads the trial's scalars while it runs)
-    if (ctx->spec_on && ctx->spec_armed && ctx->nranks == 1 && ctx->info.is_sparse && from == NLLS_VARS_CURRENT) {
-        TRY(enqueue_sweep_gradhess(ctx, false, to)); ctx->spec_pending = true; ctx->spec_stale = false; }
+    if (la) { const int rc = enqueue_sweep_gradhess(ctx, false, to); ctx->heavy_rows_zeroed = false; TRY(rc); ctx->spec_pending = true; ctx->spec_stale = false; }
     }
     // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
     if ((!ctx->info.is_sparse && !ctx->tiny_dense) || !ctx->h_scalars_dev) {

@@ -1528,10 +1528,21 @@ __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __
 }
 // the two one-workgroup reductions that end an LM trial in ONE launch: workgroup 0 sums the cost partials (the same order as
 // reduce_partials_kernel: the totals are bit-identical), workgroup 1 finishes the step statistics
+// Workgroups 2 .. (zr.n + 1), when the look-ahead sweep follows (nlls_lm_trial): the zero fill of the rows that sweep accumulates into with atomics (zero_ranges_kernel's
+// work -- a launch of its own in front of every other sweep).  Nothing reads A or b between this launch and that sweep.
+struct ZeroRanges { double* A; const int64_t* off; const uint32_t* len; double* b; const uint32_t* boff; const uint32_t* blen; int n; };
 __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restrict__ cpart, int64_t ncp, const double* __restrict__ partials, int np,
                                                            const double* __restrict__ part2, int np2, double lambda, double* __restrict__ out, const int* __restrict__ status,
-                                                           double* __restrict__ host_out, double seq) {
+                                                           double* __restrict__ host_out, double seq, ZeroRanges zr) {
     __shared__ double red[6][4];
+    if (blockIdx.x >= 2) {
+        const int r = (int)blockIdx.x - 2;
+        const int64_t o = zr.off[r]; const uint32_t l = zr.len[r];
+        for (uint32_t i = threadIdx.x; i < l; i += 256) zr.A[o + i] = 0.0;
+        const uint32_t bo = zr.boff[r], bl = zr.blen[r];
+        for (uint32_t i = threadIdx.x; i < bl; i += 256) zr.b[bo + i] = 0.0;
+        return;
+    }
     if (blockIdx.x == 0) reduce_partials_body(cpart, ncp, out, &red[0][0]);
     else post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red);
     // the scalars also go straight to the pinned host mirror (device-visible, coherent host memory): no copy command behind this launch.
@@ -1734,8 +1745,11 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
     rc = enqueue_post_solve(c, to, from, false); if (rc != NLLS_OK) return rc;
     rc = enqueue_sweep_cost(c, to, TRIAL_COST_POFS, &ncp); if (rc != NLLS_OK) return rc;
     }
-    hipLaunchKernelGGL(trial_finish_kernel, dim3(2), dim3(256), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->partials.p, c->ps_np, c->partials.p + 1024, c->ps_np2,
-                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq));
+    // (the look-ahead sweep follows: its zero fill rides here -- enqueue_sweep_gradhess skips the launch once)
+    ZeroRanges zr{};
+    if (c->tail_zero_for_lookahead && c->nzero > 0) { zr = ZeroRanges{c->A.p, c->d_zero_off.p, c->d_zero_len.p, c->b.p, c->d_zero_b_off.p, c->d_zero_b_len.p, (int)c->nzero}; c->heavy_rows_zeroed = true; }
+    hipLaunchKernelGGL(trial_finish_kernel, dim3(2 + (unsigned)zr.n), dim3(256), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->partials.p, c->ps_np, c->partials.p + 1024, c->ps_np2,
+                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq), zr);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }

@@ -822,6 +822,8 @@ int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost, int which) {
     } else if (!c->info.is_sparse) {
         HIPCHK(hipMemsetAsync(c->A.p, 0, sizeof(double) * std::max<int64_t>(c->info.nnz_data, 1), c->stream));
         HIPCHK(hipMemsetAsync(c->b.p, 0, sizeof(double) * std::max<int64_t>(c->info.ndof, 1), c->stream));
+    } else if (c->nzero > 0 && c->heavy_rows_zeroed) {
+        c->heavy_rows_zeroed = false;          // (the finishing launch of the trial in front of this look-ahead sweep has done it)
     } else if (c->nzero > 0) {
         hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)c->nzero), dim3(64), 0, c->stream, c->A.p, c->d_zero_off.p, c->d_zero_len.p, c->b.p, c->d_zero_b_off.p, c->d_zero_b_len.p);
     }
