@@ -376,7 +376,8 @@ int  nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min,
 int  nlls_profile_sweep_dispatch(nlls_ctx* ctx, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples);
 int  nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg);  /* factorisation + backward pass of the (already assembled) reduced system alone */
 /* measurement helpers.  nlls_get_memory_info: out[0] = bytes of the LM loop's working set (every device buffer an iteration reads or writes -- the
- * "hot arena"), out[1] = bytes reserved for it in one allocation (0: NLLS_NO_ARENA), out[2] = bytes of A.data, out[3] = bytes of the reduced system [S | s].
+ * "hot arena"), out[1] = bytes reserved for it in one allocation (0: NLLS_NO_ARENA), out[2] = bytes of A.data, out[3] = bytes of the reduced system [S | s],
+ * out[4] (n >= 5) = bytes of it a sharded trial sums over ranks (tile-sparse solver: the assembled tiles and s -- the fill tiles are zero until the factorisation).
  * nlls_flush_cache: streams `bytes` of foreign data through the memory side on the context's stream (a device-to-device copy between two scratch
  * halves): whatever the 256 MiB Infinity Cache held of the working set is gone afterwards -- a launch timed behind it is the COLD figure. */
 int  nlls_get_memory_info(nlls_ctx* ctx, int64_t* out, int32_t n);

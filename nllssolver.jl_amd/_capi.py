@@ -295,8 +295,8 @@ class Context:
         self._chk(self.L.nlls_comm_init_rccl(self.h, buf))
 
     def memory_info(self):
-        out = np.zeros(4, np.int64); self._chk(self.L.nlls_get_memory_info(self.h, _p(out), 4))
-        return dict(working_set_bytes=int(out[0]), arena_bytes=int(out[1]), a_data_bytes=int(out[2]), reduced_system_bytes=int(out[3]))
+        out = np.zeros(5, np.int64); self._chk(self.L.nlls_get_memory_info(self.h, _p(out), 5))
+        return dict(working_set_bytes=int(out[0]), arena_bytes=int(out[1]), a_data_bytes=int(out[2]), reduced_system_bytes=int(out[3]), sharded_reduce_bytes=int(out[4]))
 
     def check_analytic(self):
         """closed-form Jacobians / kernel derivatives against the dual-number statement, per quantity (include/nlls_amd.h)"""

@@ -323,7 +323,12 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         // and one gather of the ranks' scalars -- combined on the device and published to the host mirror as the single-GPU trial does
         if (ctx->nranks > 1 && !ctx->reduced_summed) ctx->n_lazy_trials++;
         TRY(enqueue_solve_local(ctx));
-        TRY(comm_reduce(ctx, ctx->S.p, (int64_t)ctx->s_elems + ctx->nred, NLLS_REDUCE_SUM));
+        if (ctx->solve_mode == SOLVE_TSPARSE && ctx->tsp.nslots_assembled < ctx->tsp.nslots) {
+            // tile-sparse layout [assembled tiles | fill tiles | strips | s]: the fill tiles and the strips are zero on every rank until the factorisation -- the assembled
+            // prefix and s are what is summed (two collectives: on the 100 x 100 camera grid most of the volume was zeros)
+            TRY(comm_reduce(ctx, ctx->S.p, ctx->tsp.nslots_assembled * (int64_t)TSP_TE, NLLS_REDUCE_SUM));
+            TRY(comm_reduce(ctx, ctx->S.p + ctx->s_elems, ctx->nred, NLLS_REDUCE_SUM));
+        } else TRY(comm_reduce(ctx, ctx->S.p, (int64_t)ctx->s_elems + ctx->nred, NLLS_REDUCE_SUM));
         if (ctx->nranks == 1) { ctx->trial_to = to; ctx->trial_from = from; }      // (one rank through the route: the same launches as the unsharded trial)
         ctx->replicate_xr = true; int rc = enqueue_solve_finish(ctx); ctx->replicate_xr = false; ctx->trial_to = ctx->trial_from = -1; TRY(rc);
         double* const mirror = ctx->h_scalars_dev; ctx->h_scalars_dev = nullptr;           // (the rank's own scalars are not what the host waits for)
@@ -634,6 +639,7 @@ int nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
 int nlls_get_memory_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
     NEED_READY(); if (!out || n < 4) return NLLS_ERR_INVALID_ARG;
     out[0] = ctx->hot_bytes; out[1] = (int64_t)ctx->arena.n; out[2] = (int64_t)sizeof(double) * ctx->info.nnz_data; out[3] = (int64_t)sizeof(double) * ((int64_t)ctx->s_elems + ctx->nred);
+    if (n >= 5) out[4] = (int64_t)sizeof(double) * ((ctx->solve_mode == SOLVE_TSPARSE ? ctx->tsp.nslots_assembled * (int64_t)TSP_TE : (int64_t)ctx->s_elems) + ctx->nred);   // what a sharded trial sums over ranks
     return NLLS_OK;
 }
 int nlls_check_analytic(nlls_ctx* ctx, double* out, int32_t n) {

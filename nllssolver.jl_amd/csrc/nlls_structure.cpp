@@ -1133,7 +1133,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                     // (under sharding every rank must arrive at the SAME solver -- the layout of the summed [S | s] depends on it --, so nothing rank-local may decide:
                     //  no look at this device's free memory, and an allocation that fails is an error of the upload, not a quiet change of solver)
                     const bool fits = c->nranks > 1 || hipMemGetInfo(&mfree, &mtotal) != hipSuccess || want + ((size_t)2 << 30) <= mfree;
-                    std::string e; const int rc = fits ? c->tsp.build(sym, noff, ndof, (int)n, &e) : NLLS_ERR_UNSUPPORTED;
+                    std::string e; const int rc = fits ? c->tsp.build(sym, noff, ndof, (int)n, &e, &red_adj, nbdn) : NLLS_ERR_UNSUPPORTED;
                     if (rc == NLLS_ERR_HIP && c->nranks == 1) { (void)hipGetLastError(); c->tsp.release(); }        // an allocation that failed after all: the other solvers
                     else if (rc != NLLS_OK && rc != NLLS_ERR_UNSUPPORTED) return fail(c, rc, e.c_str());
                 }

@@ -356,7 +356,8 @@ __global__ __launch_bounds__(512) void tsp_backward_kernel(const double* __restr
 // ---------------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------------
-int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off, const std::vector<int32_t>& dof, int n_red, std::string* err) {
+int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off, const std::vector<int32_t>& dof, int n_red, std::string* err,
+                     const std::vector<std::vector<int32_t>>* adj, int nborder) {
     release();
     n = n_red; nt = sym.nt;
     if (nt <= 0 || nt > 4096) { if (err) *err = "tile-sparse solver: tile count out of range"; return NLLS_ERR_UNSUPPORTED; }
@@ -369,7 +370,20 @@ int TspSolver::build(const TspSym& sym, const std::vector<int32_t>& node_red_off
     for (int r = 0; r < n; ++r) if (map[r] < 0) { if (err) *err = "tile-sparse solver: a reduced unknown without a tile"; return NLLS_ERR_INVALID_ARG; }
     int32_t* tmap = map.data() + n;
     nslots = 0;
-    for (int k = 0; k < nt; ++k) { tmap[(size_t)k * nt + k] = (int32_t)nslots++; for (int32_t i : sym.cstruct[k]) tmap[(size_t)i * nt + k] = (int32_t)nslots++; }
+    // tiles (i, k), i > k, that hold a coupling of S as assembled (before fill): first in the slot order
+    std::vector<std::vector<int32_t>> asm_col((size_t)nt);
+    if (adj) {
+        const size_t ninner = adj->size();
+        auto mark = [&](int32_t a, int32_t b) { if (a != b) asm_col[(size_t)std::min(a, b)].push_back(std::max(a, b)); };
+        for (size_t v = 0; v < ninner; ++v) for (int32_t u : (*adj)[v]) if ((size_t)u > v) mark(sym.tile_of[v], sym.tile_of[(size_t)u]);
+        for (size_t bnode = ninner; bnode < ninner + (size_t)nborder && bnode < nnode; ++bnode) for (int t = 0; t < nt; ++t) mark(sym.tile_of[bnode], t);   // (a border node is coupled to everything)
+        for (auto& v : asm_col) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+    }
+    auto is_asm = [&](int32_t i, int k) { return !adj || std::binary_search(asm_col[(size_t)k].begin(), asm_col[(size_t)k].end(), i); };
+    for (int k = 0; k < nt; ++k) { tmap[(size_t)k * nt + k] = (int32_t)nslots++; for (int32_t i : sym.cstruct[k]) if (is_asm(i, k)) tmap[(size_t)i * nt + k] = (int32_t)nslots++; }
+    nslots_assembled = nslots;
+    for (int k = 0; k < nt; ++k) for (int32_t i : sym.cstruct[k]) if (!is_asm(i, k)) tmap[(size_t)i * nt + k] = (int32_t)nslots++;
+    if (adj) for (int k = 0; k < nt; ++k) for (int32_t i : asm_col[(size_t)k]) if (tmap[(size_t)i * nt + k] < 0) { if (err) *err = "tile-sparse solver: an assembled tile outside the symbolic pattern"; return NLLS_ERR_INVALID_ARG; }
     if (nslots >= ((int64_t)1 << 31) / 4) { if (err) *err = "tile-sparse solver: too many tiles"; return NLLS_ERR_UNSUPPORTED; }
     auto slot = [&](int i, int k) { return (int64_t)tmap[(size_t)i * nt + k] * TSP_TE; };
     const int64_t strip0 = nslots * TSP_TE;

@@ -61,7 +61,11 @@ struct TspSolver {
     int64_t npad_entries = 0;
     int launches = 0; int64_t products = 0;
     size_t s_elems() const { return (size_t)nslots * TSP_TE + (size_t)nt * TSP_STRIP; }     // tiles, then one right-hand-side strip per tile column
-    int build(const TspSym& sym, const std::vector<int32_t>& node_red_off, const std::vector<int32_t>& dof, int n_red, std::string* err);
+    // adj / nborder (as given to tsp_symbolic): the tiles the ASSEMBLY writes into (a coupling of S before fill; the border's rows; every diagonal tile) take the first
+    // nslots_assembled slots -- under sharding only that prefix of the tiles is summed over ranks, the fill tiles are zero on every rank until the factorisation
+    int build(const TspSym& sym, const std::vector<int32_t>& node_red_off, const std::vector<int32_t>& dof, int n_red, std::string* err,
+              const std::vector<std::vector<int32_t>>* adj = nullptr, int nborder = 0);
+    int64_t nslots_assembled = 0;
     // S: [tiles | strips] assembled by the elimination through SLayout::at (mode SOLVE_TSPARSE), s: the reduced right-hand side in, the solution out
     // pivot_floor > 0 (undamped Newton / dogleg steps on a gauge-free problem: S is singular): a pivot that has lost more than that fraction of its original
     // diagonal entry is treated as infinite -- its unknown gets no step -- and counted in status[4] (the rule of the band solver, nlls_bcr.hpp)

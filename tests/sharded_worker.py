@@ -81,6 +81,8 @@ def scenario(rank, world, dist, staged, seed):
     if grid:
         st_r, st_s = ref.ctx.solve_stats(), sh.ctx.solve_stats()
         assert ref.info.solve_mode == 3 and sh.info.solve_mode == 3 and all(st_r[k] == st_s[k] for k in ("tsp_tiles", "tsp_levels", "tsp_lower_tiles")), (st_r, st_s)
+        mi = sh.ctx.memory_info()       # only the tiles the assembly writes into (and s) are summed over ranks: the fill tiles are zero on every rank until the factorisation
+        assert 0 < mi["sharded_reduce_bytes"] < mi["reduced_system_bytes"], mi
     if shuffled:
         st_r, st_s = ref.ctx.solve_stats(), sh.ctx.solve_stats()
         assert st_r["reordered"] == 1 and st_s["reordered"] == 1 and ref.info.solve_mode == 2 and sh.info.solve_mode == 2 and sh.info.bandwidth == ref.info.bandwidth, (st_r, st_s)
