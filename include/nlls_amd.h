@@ -355,7 +355,9 @@ int  nlls_solve_finish_async(nlls_ctx* ctx);
 int  nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count);
 int  nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count,
                          int64_t* own_offset, int64_t* own_count);
-/* [0] rank, [1] nranks, [2] cost blocks owned, [3] doubles of A.data this rank writes, [4] dof of b it writes */
+/* [0] rank, [1] nranks, [2] cost blocks owned, [3] doubles of A.data this rank writes, [4] dof of b it writes, [5] (n >= 6) 0, or -- REPLICAS -- the nranks of
+ * nlls_set_shard: the uploaded problem does not shard (a dense system, or no eliminated variable set to partition by); every rank runs the whole problem as rank 0
+ * of 1, no entry point enters a collective, every rank holds the complete result ([0], [1] then read 0, 1) */
 int  nlls_get_shard_info(nlls_ctx* ctx, int64_t* out, int32_t n);
 /* this rank's share of the gradient b (length ndof): the rows of the eliminated blocks it owns, the reduced rows on
  * rank 0, zeros elsewhere -- the sum over ranks is the full gradient that gethessgrad (src/linearsystem.jl:190) hands to

@@ -352,8 +352,8 @@ class Context:
         self._chk(self.L.nlls_set_shard(self.h, rank, nranks))
 
     def shard_info(self):
-        out = np.zeros(5, np.int64); self._chk(self.L.nlls_get_shard_info(self.h, _p(out), 5))
-        return dict(rank=int(out[0]), nranks=int(out[1]), local_ncost=int(out[2]), local_nnz_data=int(out[3]), local_ndof=int(out[4]))
+        out = np.zeros(6, np.int64); self._chk(self.L.nlls_get_shard_info(self.h, _p(out), 6))
+        return dict(rank=int(out[0]), nranks=int(out[1]), local_ncost=int(out[2]), local_nnz_data=int(out[3]), local_ndof=int(out[4]), replicated=int(out[5]))
 
     def sweep_gradhess_local(self):
         self._chk(self.L.nlls_sweep_gradhess_local(self.h))

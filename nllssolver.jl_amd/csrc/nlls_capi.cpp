@@ -104,7 +104,7 @@ int nlls_set_stream(nlls_ctx* ctx, void* hip_stream) {
 
 int nlls_set_shard(nlls_ctx* ctx, int32_t rank, int32_t nranks) {
     if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return NLLS_ERR_INVALID_ARG;
-    ctx->rank = rank; ctx->nranks = nranks; ctx->ready = false;
+    ctx->rank = ctx->shard_rank = rank; ctx->nranks = ctx->shard_nranks = nranks; ctx->replicated = false; ctx->ready = false;
     return NLLS_OK;
 }
 
@@ -312,7 +312,7 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
 int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, double* cost_out) {
     NEED_GRAD_LAZY(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
     TRY(ensure_grad_current(ctx));                 // (a trial right behind a REJECTED one: the look-ahead sweep of that trial's point is in A and b)
-    const bool collective = ctx->reduce_fn != nullptr && ctx->info.is_sparse;
+    const bool collective = ctx->reduce_fn != nullptr && ctx->info.is_sparse && !ctx->replicated;
     if (!collective) TRY(ensure_reduced_summed(ctx));
     if (ctx->nranks != 1 && !collective) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_lm_trial under nlls_set_shard needs an all-reduce (nlls_comm_init_rccl / nlls_set_allreduce), or the *_local / *_finish pairs");
     ctx->lambda += dlambda;
@@ -602,8 +602,8 @@ int nlls_get_grad_owned(nlls_ctx* ctx, double* b_out) {
 }
 int nlls_get_shard_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
     NEED_READY(); if (!out || n < 1) return NLLS_ERR_INVALID_ARG;
-    const int64_t vals[5] = {ctx->rank, ctx->nranks, ctx->local_ncost, ctx->local_nnz_data, ctx->local_ndof};
-    for (int i = 0; i < n && i < 5; ++i) out[i] = vals[i];
+    const int64_t vals[6] = {ctx->rank, ctx->nranks, ctx->local_ncost, ctx->local_nnz_data, ctx->local_ndof, ctx->replicated ? ctx->shard_nranks : 0};
+    for (int i = 0; i < n && i < 6; ++i) out[i] = vals[i];
     return NLLS_OK;
 }
 

@@ -75,7 +75,7 @@ __global__ void gather_combine_kernel(const double* __restrict__ g, int nranks, 
 
 namespace nlls {
 int comm_reduce(nlls_ctx* c, double* dev_ptr, int64_t count, int op) {
-    if (!c->reduce_fn || count <= 0) return NLLS_OK;
+    if (!c->reduce_fn || count <= 0 || c->replicated) return NLLS_OK;      // (replicas: every rank holds the whole problem, nothing to sum)
     if (c->reduce_fn(c->reduce_user, dev_ptr, count, op, c->stream) != 0) { if (c->err.empty()) c->err = "the installed all-reduce failed"; return NLLS_ERR_HIP; }
     return NLLS_OK;
 }
@@ -114,7 +114,7 @@ int nlls_comm_init_rccl(nlls_ctx* ctx, const void* id128) {
     comm_release(ctx);
     ncclUniqueId id; memcpy(&id, id128, 128);
     ncclComm_t comm = nullptr;
-    const ncclResult_t r = rccl().comm_init_rank(&comm, ctx->nranks, id, ctx->rank);
+    const ncclResult_t r = rccl().comm_init_rank(&comm, ctx->shard_nranks, id, ctx->shard_rank);
     if (r != ncclSuccess) return fail(ctx, NLLS_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().error_string(r));
     ctx->rccl_comm = comm; ctx->reduce_fn = rccl_allreduce; ctx->reduce_user = ctx;
     return NLLS_OK;

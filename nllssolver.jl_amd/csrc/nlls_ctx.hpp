@@ -185,6 +185,9 @@ struct nlls_ctx {
     std::string err;
     int err_sub = 0;                         // why the last nlls_upload_structure declined (NLLS_SUB_*): control flow never reads the error text
     int rank = 0, nranks = 1; bool presharded = false;
+    // what nlls_set_shard asked for; rank / nranks above are what the uploaded problem RUNS with: a problem that does not shard (a dense system, no eliminated set to
+    // partition by) runs as replicas -- every rank the whole problem, rank 0 of 1, no collective (replicated)
+    int shard_rank = 0, shard_nranks = 1; bool replicated = false;
     // collectives behind the ABI (nlls_comm.cpp): the installed all-reduce, and the library's own RCCL communicator when it is that
     nlls_allreduce_fn reduce_fn = nullptr; void* reduce_user = nullptr; void* rccl_comm = nullptr;
     nlls::DevBuf<double> gatherbuf;          // [nranks][16]: the ranks' trial scalars, gathered by a sum over rows that are zero elsewhere

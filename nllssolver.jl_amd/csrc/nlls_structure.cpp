@@ -202,6 +202,7 @@ static int build_fold(nlls_ctx* c, Group& G, const ResDesc& d, const nlls_cost_g
 
 int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const int32_t* var_dim, const uint64_t* bi,
                     int32_t ngroups, const nlls_cost_group* groups, int32_t flags) {
+    c->rank = c->shard_rank; c->nranks = c->shard_nranks; c->replicated = false;      // what nlls_set_shard asked for (a problem that does not shard falls back to replicas below)
     c->presharded = (flags & NLLS_FLAG_PRESHARDED) != 0 && c->nranks > 1;
     c->ready = false; c->solved = false; c->have_grad = false; c->lambda = 0; c->reduced_summed = true; c->n_stage0 = 0; c->n_lazy_trials = 0;
     { std::vector<HotItem> v; hot_set(c, v); for (HotItem& it : v) if (!*it.owned) { *it.pp = nullptr; *it.owned = true; } }   // what lived in the previous upload's arena is gone with it
@@ -338,16 +339,25 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
 
     // ---- observation sharding: costs are owned by the rank that owns their eliminated block ----------
     c->elim_selected = false;
-    const int nranks = c->nranks, rank = c->rank;
+    int nranks = c->nranks, rank = c->rank;
+    // A dense system, or a block-sparse one without an eliminated variable set to partition by: REPLICAS -- every rank runs the whole problem as rank 0 of 1 and no
+    // collective is entered (comm_reduce is a no-op, nlls_lm_trial takes the single-GPU route); nlls_get_shard_info()[5] tells the host.  A pre-sharded upload holds
+    // only this rank's share and cannot be replicated: refused as before.
+    auto replicate = [&]() { c->replicated = true; c->rank = rank = 0; c->nranks = nranks = 1; };
     std::vector<int32_t> owner_of_block(nb, 0);           // eliminated blocks: owning rank; reduced blocks: 0
     std::vector<std::vector<uint8_t>> mine(ngroups);
     for (int g = 0; g < ngroups; ++g) mine[g].assign(groups[g].ncost, 1);
     c->local_ncost = ncost_total;
     if (nranks > 1) {
-        if (!sparse) return fail(c, NLLS_ERR_UNSUPPORTED, "sharding needs the block-sparse path");
+        if (!sparse) { if (flags & NLLS_FLAG_PRESHARDED) return fail(c, NLLS_ERR_UNSUPPORTED, "sharding needs the block-sparse path"); replicate(); }
+    }
+    if (nranks > 1) {
         c->info = I;
         int rc0 = select_elimination(c, flags); if (rc0 != NLLS_OK) return rc0;
-        if (!c->nelim) return fail(c, NLLS_ERR_UNSUPPORTED, "sharding needs an eliminated (Schur) variable set to partition by");
+        if (!c->nelim && (flags & NLLS_FLAG_PRESHARDED)) return fail(c, NLLS_ERR_UNSUPPORTED, "sharding needs an eliminated (Schur) variable set to partition by");
+        if (!c->nelim) { replicate(); c->elim_selected = false; }
+    }
+    if (nranks > 1) {
         if (flags & NLLS_FLAG_PRESHARDED) {                   // the caller has partitioned: everything uploaded here is this rank's
             for (int64_t k = 0; k < nb; ++k) if (c->is_elim[k]) owner_of_block[k] = rank;
         } else {

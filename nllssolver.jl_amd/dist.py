@@ -60,6 +60,11 @@ class ShardedLS(MultiVariateLSgpu):
         # all-reduce / solve_finish) remains for plain solve() calls (Newton, dogleg: they want x on every rank).
         self.native_collectives = self.sharded                 # (installed in _make_context: a pre-sharded upload is itself collective)
         sh = self.ctx.shard_info()
+        # REPLICAS (include/nlls_amd.h, nlls_get_shard_info): the problem does not shard -- every rank runs the whole of it and holds the complete result; nothing below may
+        # enter a collective (agree_max still does: every rank calls it)
+        self.replicated = bool(sh.get("replicated", 0))
+        if self.replicated:
+            self.sharded = False; self.native_collectives = False
         self.local_nobs, self.local_nnz_data, self.local_ndof_written = sh["local_ncost"], sh["local_nnz_data"], sh["local_ndof"]
 
     def _make_context(self, device):

@@ -49,6 +49,8 @@ def scenario(rank, world, dist, staged, seed):
         return presharded(rank, world, dist, staged, seed)
     if 7000 <= seed < 8000:
         return deadline(rank, world, dist, staged)
+    if 10000 <= seed < 11000:
+        return replicas(rank, world, dist, staged, seed)
     grid = 8000 <= seed < 9000                   # a 24 x 24 camera grid with permuted labels: the reduced system goes to the tile-sparse solver (nested dissection at upload: every rank must arrive at the same tiles)
     shuffled = 6000 <= seed < 8000               # the cameras' labels permuted: the reduced system is re-ordered at upload (every rank must arrive at the same order)
     rng = np.random.default_rng(seed)
@@ -259,6 +261,42 @@ def presharded(rank, world, dist, staged, seed):
         assert np.array_equal(next(iter(g.costs.values())).arrays()[0], next(iter(mine.costs.values())).arrays()[0])
     ref.close(); sh.close(); dist.barrier(); dist.destroy_process_group()
     print(f"rank {rank}: sharded == unsharded (presharded: {mine.ncosts()} of {p.ncosts()} cost blocks uploaded, best cost {ds.bestcost:.6e})")
+
+
+def replicas(rank, world, dist, staged, seed):
+    """Problems that do not shard (round 5): a DENSE system (a curve fit: 3000 scalar residuals over four scalar variables; a three-camera bundle adjustment whose whole system is
+    dense) under nlls_set_shard(rank, world > 1) used to be refused ("sharding needs the block-sparse path").  Now: replicas -- every rank runs the whole problem as rank 0 of 1,
+    no entry point enters a collective (an installed all-reduce is never called), nlls_get_shard_info()[5] = world; every rank reaches the unsharded result bit for bit
+    in its own sums' order (rtol 1e-12), through the library's outer loop and the Python one, and holds the complete variable set."""
+    import nllssolver_jl_amd as N
+    from nllssolver_jl_amd import synthetic, _capi, iterators as It, optimizer as Opt
+    from nllssolver_jl_amd.dist import ShardedLS
+    from nllssolver_jl_amd.linearsystem import MultiVariateLSgpu
+    for which in ("curvefit", "tiny_ba"):
+        mkp = (lambda: synthetic.create_curvefit_problem(3000, seed=seed)[0]) if which == "curvefit" else \
+              (lambda: synthetic.perturb_ba_problem(synthetic.create_ba_problem(3, 8, 1.0, seed=seed), 1e-3, 1e-3))
+        for native in (True, False):
+            p, q = mkp(), mkp()
+            unfixed = np.ones(p.nvariables, bool)
+            sh = ShardedLS(q, unfixed, rank=rank, world=world, dist=dist, host_staged=staged, force_collectives=True)
+            info = sh.ctx.shard_info()
+            assert sh.replicated == (world > 1) and info["replicated"] == (world if world > 1 else 0) and info["nranks"] == 1 and not sh.info.is_sparse, info
+            ref = MultiVariateLSgpu(p, unfixed)
+            out = []
+            for ls, prob in ((ref, p), (sh, q)):
+                opts = N.NLLSOptions(maxiters=12)
+                data = Opt.NLLSInternal(ls, time.perf_counter_ns())
+                loop = Opt.OuterLoop(prob, opts, data, It.LevMarData(), It.iterate_levmar, N.nullcallback, native=native)
+                loop.start()
+                while (loop.iterations(1 << 30) if loop.native else loop.iteration()) == 0:
+                    pass
+                assert data.iternum > 1
+                out.append((data.bestcost, data.iternum, ls.variables(_capi.VARS_CURRENT).copy()))
+            assert out[0][1] == out[1][1] and np.isclose(out[0][0], out[1][0], rtol=1e-12) and np.allclose(out[0][2], out[1][2], rtol=1e-9, atol=1e-12), (out[0][:2], out[1][:2])
+            assert out[1][0] < 0.5 * N.cost(mkp())
+            ref.close(); sh.close()
+    dist.barrier(); dist.destroy_process_group()
+    print(f"rank {rank}: sharded == unsharded (replicas: dense systems run whole on every one of {world} ranks, no collective)")
 
 
 def deadline(rank, world, dist, staged):

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 # (a string of seeds = several scenarios in ONE process group: most of a scenario's two seconds is the start of its ranks)
-@pytest.mark.parametrize("world,backend,seed", [(1, "nccl", 21), (2, "gloo", "21,401,403,5001,6001,7001,5201,8001,9001"), (3, "gloo", "21,402,5002,5102,7001,5301,9001"),
+@pytest.mark.parametrize("world,backend,seed", [(1, "nccl", 21), (2, "gloo", "21,401,403,5001,6001,7001,5201,8001,9001,10001"), (3, "gloo", "21,402,5002,5102,7001,5301,9001,10002"),
                                                 (2, "gloo", -1), (3, "gloo", -1), (2, "gloo", 3000), (3, "gloo", 3000)])
 def test_sharded_matches_unsharded(world, backend, seed):
     """(1, "nccl"): the local / reduce / finish route over RCCL with device buffers, one rank -- the plumbing bench.py --gpus N uses.
@@ -23,6 +23,7 @@ def test_sharded_matches_unsharded(world, backend, seed):
     seed 51xx: the same under NLLS_FLAG_PRESHARDED, where each rank sees only its own part of the camera graph (the union is taken collectively).
     seed 52xx: a pre-sharded upload whose reduced rows differ in layout between ranks (points listed before the cameras) is refused on every rank.
     seed 7001: a deadline (maxtime) only rank 0 crosses -- all ranks leave the loop in the same iteration (no rank left in a collective).
+    seed 100xx: problems that do not shard (dense systems) run as REPLICAS -- whole on every rank, no collective, the unsharded result (round 5; refused before).
     seed 9001: a bundle adjustment with three dynamic-size variables beside it (round 4: dynamic-size blocks in a block-sparse system, also under sharding).
     seed 8001 / 5301: a 24 x 24 camera grid with permuted labels -- the reduced system goes to the tile-sparse solver (solve_mode 3); the nested dissection at upload
     must give every rank the same tiles (5301: pre-sharded, from the union of the ranks' camera graphs).
