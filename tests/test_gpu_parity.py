@@ -658,12 +658,12 @@ def test_folded_sweep_switch(fold, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"NLLS_DENSE_T64": "1"}, {"NLLS_DENSE_T128_MIN": "1"}, {"NLLS_ELIM_TILED": "1"}, {"NLLS_BCR_CHROWS_SLOTS": "0"},
                                  {"NLLS_DENSE_STEP_BACKWARD": "1"}, {"NLLS_BCR_LEVEL_BACKWARD": "1"}, {"NLLS_ELIM_SPLIT": "1"}, {"NLLS_POST_SPLIT": "1"},
-                                 {"NLLS_HEAVY_MAX_ENTRIES": "256"}])
+                                 {"NLLS_HEAVY_MAX_ENTRIES": "256"}, {"NLLS_SUPERNODE_PIECE": "128"}, {"NLLS_SUPERNODE_PIECE": "5"}])
 def test_ab_switches_select_paths_that_still_match_the_oracle(env, monkeypatch):
     """The environment switches read by nlls_create (the register-tiled elimination instead of the matrix-core one, the
     64 x 64-tile dense update instead of the 128 x 128 one, the 128 x 128 one from the first pass on, three X rows per panel workgroup at every
     level of the block cyclic reduction, one backward launch per block / per level instead of the one-launch substitutions, the assembly in three
-    launches, the trial's retraction and step statistics in a launch of their own) select kernels or launch shapes no default run of this size reaches:
+    launches, the trial's retraction and step statistics in a launch of their own, the runs of eliminated blocks never cut / cut into pieces of five members) select kernels or launch shapes no default run of this size reaches:
     the same parity as every other path -- band mode and the dense reduced solve (NLLS_FLAG_NO_BAND) of a camera chain, 2100 reduced dof."""
     for k, v in env.items(): monkeypatch.setenv(k, v)
     p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(350, 7000, 10.0 / 350, seed=77, robust=N.HuberKernel(0.02)), 1e-3, 1e-3)
