@@ -840,7 +840,25 @@ __global__ __launch_bounds__(64 * NT) void bcr_backward_kernel(BcrBackArgs a) {
     if (root) {
         if (nbd > 0) {
             // corner = cp[0] - sum_i cp[1 + i], blocks in index order (fixed order: reproducible)
-            for (int e = tid; e < 256; e += NTH) { double v = g.ws[g.ocp + e]; for (int i = 0; i < g.N; ++i) v -= g.ws[g.ocp + (size_t)(1 + i) * 256 + e]; Cl[e] = v; }
+            // (round 5: the N blocks' shares dealt over the lanes -- each entry of rows 0 .. nbd, the rows read below, as `parts` partial sums formed side by side and combined in a
+            //  fixed order: reproducible.  One thread per entry stepping through the N shares was a chain of N dependent loads on the path every other block of the backward pass
+            //  waits for: 28 us at BASELINE config 5 -- the adaptive kernel's variable is the border -- where six levels without a border take ~18.)
+            {
+                const int ne = 16 * nbr; int parts = NTH / ne; if (parts > 8) parts = 8; if (parts * ne > NT * 64) parts = (NT * 64) / ne;     // (the partial sums go through `red`: NT * 64 doubles, not in use yet)
+                if (parts >= 2) {
+                    const int e = tid % ne, pt = tid / ne;
+                    if (pt < parts) {
+                        double v0 = 0.0, v1 = 0.0; int i = pt;
+                        for (; i + parts < g.N; i += 2 * parts) { v0 += g.ws[g.ocp + (size_t)(1 + i) * 256 + e]; v1 += g.ws[g.ocp + (size_t)(1 + i + parts) * 256 + e]; }
+                        if (i < g.N) v0 += g.ws[g.ocp + (size_t)(1 + i) * 256 + e];
+                        red[pt * ne + e] = v0 + v1;
+                    }
+                    __syncthreads();
+                    if (tid < ne) { double v = g.ws[g.ocp + tid]; for (int q = 0; q < parts; ++q) v -= red[q * ne + tid]; Cl[tid] = v; }
+                } else {
+                    for (int e = tid; e < 256; e += NTH) { double v = g.ws[g.ocp + e]; for (int i = 0; i < g.N; ++i) v -= g.ws[g.ocp + (size_t)(1 + i) * 256 + e]; Cl[e] = v; }
+                }
+            }
             __syncthreads();
             if (tid == 0) {                        // LDL' of the nbd x nbd corner with the rhs row riding along (Cl[row][col])
                 for (int j = 0; j < nbd; ++j) {
