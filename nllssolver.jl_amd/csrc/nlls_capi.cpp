@@ -183,6 +183,7 @@ int nlls_get_bsm_index(const nlls_ctx* ctx, int64_t* colptr, int64_t* rowval, in
 int nlls_set_variables(nlls_ctx* ctx, int32_t which, const double* packed) {
     NEED_READY(); if (!valid_set(which) || !packed) return NLLS_ERR_INVALID_ARG;
     spec_note_write(ctx, which);
+    if (which == NLLS_VARS_CURRENT) ctx->sweeps_since_set = 0;         // (a new starting point: its first trial gets no look-ahead sweep, see nlls_sweep_gradhess)
     HIPCHK(hipMemcpyAsync(vars_ptr(ctx, which), packed, sizeof(double) * ctx->info.var_storage, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
@@ -218,7 +219,10 @@ static int ensure_reduced_summed(nlls_ctx* ctx) {
 }
 int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
     NEED_READY();
-    ctx->spec_armed = true;                                                  // (a sweep the caller asks for: the look-ahead may try again behind the next trial)
+    // (a sweep the caller asks for: the look-ahead may try again behind the next trial -- but not behind the FIRST trial from a new starting point: the initial damping
+    //  (1e-6 of the largest diagonal entry, src/iterators.jl:131-137) is the one guess of the loop that is routinely rejected -- five times in a row at BASELINE config 5 --,
+    //  and a look-ahead behind it is a sweep thrown away plus the current point swept again)
+    ctx->spec_armed = ctx->sweeps_since_set >= 1; ctx->sweeps_since_set++;
     if (ctx->spec_pending) {
         const bool hit = !cost_out && !ctx->spec_stale && ctx->grad_phys == ctx->vars_slot[NLLS_VARS_CURRENT];
         ctx->spec_pending = false; ctx->spec_stale = false;

@@ -232,6 +232,7 @@ struct nlls_ctx {
     int grad_phys = -1;                      // physical variable slot A and b are the linearisation of
     bool spec_on = true, spec_pending = false, spec_stale = false, spec_armed = true;   // spec_on: NLLS_NO_LOOKAHEAD_SWEEP unset; pending: A, b belong to grad_phys, not (yet) to CURRENT; stale: that slot was written since; armed: the last look-ahead was used (a miss disarms until the next real sweep)
     int64_t spec_hits = 0, spec_misses = 0;  // nlls_get_solve_stats
+    int64_t sweeps_since_set = 0;            // gradient sweeps the caller has asked for since nlls_set_variables(CURRENT)
     bool tail_zero_for_lookahead = false, heavy_rows_zeroed = false;   // the look-ahead sweep's zero fill in the trial's finishing launch (trial_finish_kernel)
     // the small dense system (fewer than 64 unknowns, nothing eliminated, one rank: curve fits, Rosenbrock): the sweep leaves one image of [A | b] per workgroup in
     // dense_slab and ONE gathering launch sums them (no zero fill, no atomics on HBM, no mirror launch); an LM trial is one single-workgroup launch for

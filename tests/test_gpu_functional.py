@@ -188,7 +188,8 @@ def test_lookahead_sweep_is_transparent(floor, monkeypatch):
     assert s1["lookahead_hits"] == 0 and s1["lookahead_misses"] == 0
     rejected = r0[-1][3] - len(r0)                                      # damped solves beyond one per iteration
     # a rejected trial throws its look-ahead away -- at most once per iteration (the look-ahead then stays off until the next sweep the loop asks for)
-    assert s0["lookahead_hits"] >= len(r0) - 1 - s0["lookahead_misses"] and s0["lookahead_misses"] <= rejected and (s0["lookahead_misses"] > 0) == (rejected > 0), (s0, rejected)
+    # (the first trial from a new starting point gets no look-ahead: one hit fewer than iterations - 1)
+    assert s0["lookahead_hits"] >= len(r0) - 2 - s0["lookahead_misses"] and s0["lookahead_misses"] <= rejected and (s0["lookahead_misses"] > 0) == (rejected > 0), (s0, rejected)
     assert (rejected == 0) == floor, rejected
 
 
