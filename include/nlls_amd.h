@@ -171,6 +171,9 @@ typedef struct nlls_info {
 
 /* variable-set ids for the on-device copies of problem.variables / varnext / varbest
  * (src/problem.jl:9-12) */
+#define NLLS_FLAG_MATERIALIZE    0x800 /* never the matrix-free LM trial (round 6): nlls_lm_trial then eliminates from the materialised A.data as rounds 1-5 did.  Default: two-slot
+                                       * Schur problems whose eliminated blocks all take the fast path (bundle adjustment) evaluate their cost blocks inside the elimination and the
+                                       * back-substitution launches; A.data in the reference's layout is then formed on demand only (nlls_get_bsm_data, nlls_solve, ...). */
 #define NLLS_VARS_CURRENT 0
 #define NLLS_VARS_NEXT    1
 #define NLLS_VARS_BEST    2
@@ -270,8 +273,16 @@ int  nlls_solve(nlls_ctx* ctx, double* x_out);
  * [14] half bandwidth (dof) the caller's order would have given (-1: not computed), [15] 1: the dense LDL' (solve_mode 1) is restricted to the band of the
  * re-ordered reduced system and the border strip ("windowed": O(n w^2) work in dense storage, for bands too wide for the band kernels).
  * Tile-sparse solver (solve_mode 3): [16] tiles of 128 unknowns, [17] levels of the tile elimination tree (the dependent chain of the factorisation),
- * [18] lower tiles stored (fill included), [19] kernel launches per reduced solve, [20] 128^3 tile products per factorisation (updates + panels). */
+ * [18] lower tiles stored (fill included), [19] kernel launches per reduced solve, [20] 128^3 tile products per factorisation (updates + panels).
+ * [21], [22] look-ahead sweeps used / thrown away; [23] matrix-free LM trials, [24] gradient sweeps of the reduced rows only, [25] full accumulate sweeps since the upload. */
 int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
+/* Run-time switches of a context (A/B measurements, parity tests through both paths on ONE upload):
+ *   NLLS_OPT_MATERIALIZE  value != 0: nlls_lm_trial eliminates from the materialised A.data (the round-5 path) although the structure qualifies for the
+ *                         matrix-free trial; 0 (default): matrix-free where nlls_upload_structure found it applicable (NLLS_FLAG_MATERIALIZE: never).
+ *   NLLS_OPT_LOOKAHEAD    value == 0: no look-ahead sweep behind an LM trial (the environment's NLLS_NO_LOOKAHEAD_SWEEP=1). */
+#define NLLS_OPT_MATERIALIZE 1
+#define NLLS_OPT_LOOKAHEAD   2
+int  nlls_set_option(nlls_ctx* ctx, int32_t option, int64_t value);
 int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
 int  nlls_get_step(nlls_ctx* ctx, double* x_out);
 int  nlls_step_maxabs(nlls_ctx* ctx, double* out);                /* maximum(abs, linsystem.x) */

@@ -19,6 +19,8 @@ FLAG_PRESHARDED = 128
 FLAG_NO_REORDER = 256
 FLAG_NO_TILE_SPARSE = 512
 FLAG_NO_PIVOT_FLOOR = 1024
+FLAG_MATERIALIZE = 2048
+OPT_MATERIALIZE, OPT_LOOKAHEAD = 1, 2
 VARS_CURRENT, VARS_NEXT, VARS_BEST = 0, 1, 2
 
 # every symbol include/nlls_amd.h declares (checked by tests/test_capi_symbols.py)
@@ -29,7 +31,7 @@ nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_qua
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
 nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_profile_sweep_dispatch nlls_solve_finish_replicated nlls_get_variables_owned nlls_lm_iterations
-nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl nlls_comm_post_flag nlls_comm_agreed_flag nlls_comm_info nlls_get_memory_info nlls_flush_cache nlls_check_analytic""".split()
+nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl nlls_comm_post_flag nlls_comm_agreed_flag nlls_comm_info nlls_get_memory_info nlls_flush_cache nlls_check_analytic nlls_set_option""".split()
 
 
 class LmOptions(C.Structure):          # nlls_lm_options
@@ -120,6 +122,7 @@ def lib():
         L.nlls_solve_finish_replicated.argtypes = [vp]; L.nlls_get_variables_owned.argtypes = [vp, i32, vp]
         L.nlls_set_allreduce.argtypes = [vp, vp, vp]; L.nlls_comm_unique_id.argtypes = [vp]; L.nlls_comm_init_rccl.argtypes = [vp, vp]
         L.nlls_get_memory_info.argtypes = [vp, vp, i32]; L.nlls_flush_cache.argtypes = [vp, i64]; L.nlls_check_analytic.argtypes = [vp, vp, i32]
+        L.nlls_set_option.argtypes = [vp, i32, i64]
         L.nlls_comm_post_flag.argtypes = [vp, dbl]; L.nlls_comm_agreed_flag.argtypes = [vp, dbl, vp]; L.nlls_comm_info.argtypes = [vp, vp, i32]
         _lib = L
     return _lib
@@ -317,14 +320,18 @@ class Context:
         out = np.zeros(4, np.int64); self._chk(self.L.nlls_comm_info(self.h, _p(out), 4))
         return dict(nranks=int(out[0]), rank=int(out[1]), device=int(out[2]), transport={0: "none", 1: "rccl", 2: "caller-installed all-reduce"}[int(out[3])])
 
+    def set_option(self, option, value):
+        """nlls_set_option: OPT_MATERIALIZE (1: nlls_lm_trial eliminates from the materialised A.data, 0: matrix-free where it applies), OPT_LOOKAHEAD"""
+        self._chk(self.L.nlls_set_option(self.h, int(option), int(value)))
+
     def solve_stats(self):
-        out = np.zeros(23, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 23))
+        out = np.zeros(26, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 26))
         return dict(status=int(out[0]), band_factor_cycles=int(out[1]), band_backward_cycles=int(out[2]), solve_mode=int(out[3]),
                     elim_supernodes=int(out[4]), bandwidth=int(out[5]), bcr_mfma_issued=int(out[6]), bcr_launches=int(out[7]), bcr_levels=int(out[8]),
                     band_dof=int(out[9]), dropped_pivots=int(out[10]), reduced_row_sums=int(out[11]), lazy_trials=int(out[12]),
                     reordered=int(out[13]), bandwidth_caller_order=int(out[14]), dense_window=int(out[15]),
                     tsp_tiles=int(out[16]), tsp_levels=int(out[17]), tsp_lower_tiles=int(out[18]), tsp_launches=int(out[19]), tsp_products=int(out[20]),
-                    lookahead_hits=int(out[21]), lookahead_misses=int(out[22]))
+                    lookahead_hits=int(out[21]), lookahead_misses=int(out[22]), mf_trials=int(out[23]), reduced_sweeps=int(out[24]), full_sweeps=int(out[25]))
 
     def set_step(self, x):
         x = np.ascontiguousarray(x, np.float64); assert x.size == self.info.ndof

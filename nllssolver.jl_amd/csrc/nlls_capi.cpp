@@ -16,7 +16,7 @@ int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(wha
 #define NEED_READY() do { if (!ctx) return NLLS_ERR_INVALID_ARG; if (!ctx->ready) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_upload_structure has not succeeded"); (void)hipSetDevice(ctx->device); } while (0)
 #define NEED_GRAD_LAZY() do { NEED_READY(); if (!ctx->have_grad) return fail(ctx, NLLS_ERR_NOT_READY, "nlls_sweep_gradhess has not been run"); } while (0)
 // (... and with the reduced rows summed over ranks: every entry point but the LM trial itself reads them as if one GPU had swept all cost blocks)
-#define NEED_GRAD() do { NEED_GRAD_LAZY(); TRY(ensure_grad_current(ctx)); TRY(ensure_reduced_summed(ctx)); } while (0)
+#define NEED_GRAD() do { NEED_GRAD_LAZY(); TRY(ensure_grad(ctx, 2)); TRY(ensure_reduced_summed(ctx)); } while (0)
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != NLLS_OK) return rc_; } while (0)
 
 // copy `count` scalars starting at `slot` to the pinned mirror and wait
@@ -29,17 +29,31 @@ bool valid_set(int w) { return w >= 0 && w < 3; }
 // Look-ahead sweep (nlls_ctx::spec_pending): A and b may hold the linearisation at the last trial's point instead of the current one.  Whoever needs them for the
 // CURRENT point comes through here: after the swap of an accepted trial they simply ARE the current point's (a hit); otherwise the current point is swept again (a miss:
 // one accumulate launch, the damping kept) and the look-ahead stays off until the next sweep the caller asks for.
-int ensure_grad_current(nlls_ctx* ctx) {
-    if (!ctx->spec_pending) return NLLS_OK;
-    ctx->spec_pending = false;
-    if (!ctx->spec_stale && ctx->grad_phys == ctx->vars_slot[NLLS_VARS_CURRENT]) { ctx->spec_hits++; return NLLS_OK; }
-    ctx->spec_misses++; ctx->spec_armed = false; ctx->spec_stale = false;
-    const double lam = ctx->lambda; const bool solved = ctx->solved;
-    TRY(enqueue_sweep_gradhess(ctx, false));
-    ctx->lambda = lam; ctx->solved = false; (void)solved;
+// `level` (round 6, nlls_ctx::grad_level): 1 -- the reduced rows suffice (the matrix-free LM trial); 2 -- all of A.data and b.  A linearisation that holds less than is asked for
+// is swept (again) here, at CURRENT: the matrix-free trial never forms the eliminated rows, and nlls_sweep_gradhess(ctx, NULL) defers its sweep to the first call that says
+// which level it needs.
+int ensure_grad(nlls_ctx* ctx, int level) {
+    if (ctx->spec_pending) {
+        ctx->spec_pending = false;
+        if (!ctx->spec_stale && ctx->grad_phys == ctx->vars_slot[NLLS_VARS_CURRENT]) ctx->spec_hits++;
+        else { ctx->spec_misses++; ctx->spec_armed = false; ctx->grad_level = 0; }
+        ctx->spec_stale = false;
+    }
+    if (ctx->grad_level >= level && ctx->grad_phys == ctx->vars_slot[NLLS_VARS_CURRENT]) return NLLS_OK;
+    const double lam = ctx->lambda;
+    TRY(enqueue_sweep_gradhess(ctx, false, NLLS_VARS_CURRENT, level == 1 ? 1 : 0));
+    ctx->lambda = lam; ctx->solved = false;
     return NLLS_OK;
 }
-void spec_note_write(nlls_ctx* ctx, int32_t which) { if (ctx->spec_pending && ctx->vars_slot[which] == ctx->grad_phys) ctx->spec_stale = true; }
+int ensure_grad_current(nlls_ctx* ctx) { return ensure_grad(ctx, 2); }
+// a variable set is about to be written: a look-ahead sweep of it is stale, and so is a linearisation at it that is not (fully) formed yet
+void spec_note_write(nlls_ctx* ctx, int32_t which) {
+    if (ctx->vars_slot[which] != ctx->grad_phys) return;
+    if (ctx->spec_pending) ctx->spec_stale = true;
+    else if (ctx->grad_level < 2) ctx->grad_level = 0;          // (what is formed on demand would be formed at the NEW values: the caller sweeps again after writing CURRENT -- every iterator does)
+}
+// is this trial matrix-free?  (nlls_ctx::mf_ok: the structure qualifies; mf_on: not switched off; the trial starts at CURRENT, one rank, no collective route)
+bool mf_trial(const nlls_ctx* ctx, int32_t from) { return ctx->mf_ok && ctx->mf_on && from == NLLS_VARS_CURRENT && ctx->nranks == 1 && !ctx->reduce_fn && ctx->info.is_sparse && !ctx->tiny_dense; }
 }  // namespace
 
 extern "C" {
@@ -58,6 +72,7 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
     if (!c) return NLLS_ERR_HIP;
     c->device = dev; c->num_cus = prop.multiProcessorCount;
     { const char* e = getenv("NLLS_NO_LOOKAHEAD_SWEEP"); if (e && e[0] == '1') c->spec_on = false; }
+    { const char* e = getenv("NLLS_MATERIALIZE"); if (e && e[0] == '1') c->mf_on = false; }
     { const char* e = getenv("NLLS_TINY_DENSE"); if (e && e[0] == '0') c->tiny_dense_on = false; }
     { const char* e = getenv("NLLS_TINY_FIN_ROLE"); if (e && e[0] == '0') c->tiny_fin_role = false; }             // (A/B: the trial's finishing reduction always in a launch of its own)
     { const char* e = getenv("NLLS_ELIM_TILED"); if (e && e[0] == '1') c->elim_mfma = false; }
@@ -229,6 +244,13 @@ int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
         if (hit) { ctx->spec_hits++; ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; ctx->reduced_summed = true; return NLLS_OK; }   // already enqueued behind the trial
         ctx->spec_misses++;
     }
+    // Matrix-free LM trial (nlls_ctx::mf_ok): between two iterations nothing is enqueued here -- the first call that needs the linearisation says how much of it
+    // (ensure_grad: nlls_lm_trial the reduced rows, everything else all of A.data and b), and it is formed then, at CURRENT.
+    if (!cost_out && mf_trial(ctx, NLLS_VARS_CURRENT)) {
+        ctx->grad_level = 0; ctx->grad_phys = ctx->vars_slot[NLLS_VARS_CURRENT];
+        ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; ctx->reduced_summed = true; ctx->tE_valid = false; ctx->step_cached = false;
+        return NLLS_OK;
+    }
     // cost_out == NULL: the caller does not want the cost (the outer loop between iterations, src/optimize.jl:167-170
     // discards it) -- the sweep is then only enqueued: no partial-sum kernel, no synchronisation
     if (ctx->reduce_fn) {
@@ -315,7 +337,8 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
 // solve!, negate!, update!(to, from, x), cost(to).  Same kernels, same order as the separate entry points.
 int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, double* cost_out) {
     NEED_GRAD_LAZY(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
-    TRY(ensure_grad_current(ctx));                 // (a trial right behind a REJECTED one: the look-ahead sweep of that trial's point is in A and b)
+    const bool mf = mf_trial(ctx, from);           // matrix-free: the eliminated rows of A.data are neither needed nor formed (nlls_mf.hip)
+    TRY(ensure_grad(ctx, mf ? 1 : 2));             // (a trial right behind a REJECTED one: the look-ahead sweep of that trial's point is in A and b)
     const bool collective = ctx->reduce_fn != nullptr && ctx->info.is_sparse && !ctx->replicated;
     if (!collective) TRY(ensure_reduced_summed(ctx));
     if (ctx->nranks != 1 && !collective) return fail(ctx, NLLS_ERR_UNSUPPORTED, "nlls_lm_trial under nlls_set_shard needs an all-reduce (nlls_comm_init_rccl / nlls_set_allreduce), or the *_local / *_finish pairs");
@@ -345,12 +368,13 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         TRY(enqueue_tiny_trial_finish_pending(ctx));      // (no accumulate launch took the finishing reduction along)
     } else {
     ctx->trial_to = to; ctx->trial_from = from;    // (the back-substitution launch may take the retraction with it: enqueue_solve_finish)
-    { const int rc = enqueue_solve(ctx); ctx->trial_to = ctx->trial_from = -1; TRY(rc); }
+    ctx->mf_use = mf; if (mf) ctx->mf_trials++;
+    { const int rc = enqueue_solve(ctx); ctx->trial_to = ctx->trial_from = -1; ctx->mf_use = false; TRY(rc); }
     const bool la = ctx->spec_on && ctx->spec_armed && ctx->nranks == 1 && ctx->info.is_sparse && from == NLLS_VARS_CURRENT;
     ctx->tail_zero_for_lookahead = la; ctx->heavy_rows_zeroed = false;
     { const int rc = enqueue_lm_trial_tail(ctx, to, from); ctx->tail_zero_for_lookahead = false; TRY(rc); }     // step statistics + quadratic form (+ retraction) and the cost sweep, one finishing launch
     // the look-ahead sweep: the gradient sweep of the trial point, enqueued behind the finishing launch (the host reads the trial's scalars while it runs)
-    if (la) { const int rc = enqueue_sweep_gradhess(ctx, false, to); ctx->heavy_rows_zeroed = false; TRY(rc); ctx->spec_pending = true; ctx->spec_stale = false; }
+    if (la) { const int rc = enqueue_sweep_gradhess(ctx, false, to, mf ? 1 : 0); ctx->heavy_rows_zeroed = false; TRY(rc); ctx->spec_pending = true; ctx->spec_stale = false; }
     }
     // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
     if ((!ctx->info.is_sparse && !ctx->tiny_dense) || !ctx->h_scalars_dev) {
@@ -474,6 +498,7 @@ int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices
     HIPCHK(d_groups.upload(gbuf));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_grad = false; ctx->solved = false; ctx->step_cached = false; ctx->tE_valid = false;   // the variables change under the linear system
+    spec_note_write(ctx, NLLS_VARS_CURRENT); ctx->spec_pending = false; ctx->spec_stale = false; ctx->grad_level = 0;   // (... and under a look-ahead sweep of this very set: its A and b are of the point before the relaxation)
     if (nloc > 0) TRY(enqueue_optimize_singles(ctx, nloc, d_sel.p, d_cptr.p, d_cgroup.p, d_cidx.p, d_cslot.p, d_groups.p, iterator, maxiters, maxfails, reldcost, absdcost, dstep, d_iters.p));
     if (!sharded) {
         if (iters_out) HIPCHK(hipMemcpyAsync(iters_out, d_iters.p, sizeof(int64_t) * nsel, hipMemcpyDeviceToHost, ctx->stream));      // (unsharded: nloc == nsel, the caller's order)
@@ -495,17 +520,26 @@ int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices
     if (iters_out) for (int64_t i = 0; i < nsel; ++i) iters_out[i] = (int64_t)hit[(size_t)i];
     return NLLS_OK;
 }
+int nlls_set_option(nlls_ctx* ctx, int32_t option, int64_t value) {
+    if (!ctx) return NLLS_ERR_INVALID_ARG;
+    switch (option) {
+    case NLLS_OPT_MATERIALIZE: ctx->mf_on = value == 0; return NLLS_OK;          // (takes effect with the next nlls_lm_trial / nlls_sweep_gradhess; what A and b hold is tracked either way)
+    case NLLS_OPT_LOOKAHEAD:   ctx->spec_on = value != 0; return NLLS_OK;
+    }
+    return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_set_option: unknown option");
+}
 int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
     NEED_READY(); if (!out || n < 1) return NLLS_ERR_INVALID_ARG;
     int32_t status[16] = {0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    const int64_t vals[23] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
+    const int64_t vals[26] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
                               ctx->bcr.ready ? ctx->bcr.mfma_issued : 0, ctx->bcr.ready ? ctx->bcr.launches : 0, ctx->bcr.ready ? (int64_t)ctx->bcr.levels.size() : 0, ctx->n_band,
                               status[4] /* pivots the floor of the last undamped band solve dropped */, ctx->n_stage0, ctx->n_lazy_trials, ctx->red_reordered, ctx->bw_caller, ctx->dense_window ? 1 : 0,
                               ctx->tsp.ready ? ctx->tsp.nt : 0, ctx->tsp.ready ? (int64_t)ctx->tsp.levels.size() : 0, ctx->tsp.ready ? ctx->tsp.nslots : 0, ctx->tsp.ready ? ctx->tsp.launches : 0, ctx->tsp.ready ? ctx->tsp.products : 0,
-                              ctx->spec_hits, ctx->spec_misses /* look-ahead sweeps used / thrown away */};
-    for (int i = 0; i < n && i < 23; ++i) out[i] = vals[i];
+                              ctx->spec_hits, ctx->spec_misses /* look-ahead sweeps used / thrown away */,
+                              ctx->mf_trials, ctx->mf_reduced_sweeps, ctx->full_sweeps /* matrix-free LM trials, sweeps of the reduced rows only, full accumulate sweeps since the upload */};
+    for (int i = 0; i < n && i < 26; ++i) out[i] = vals[i];
     return NLLS_OK;
 }
 int nlls_set_step(nlls_ctx* ctx, const double* x) {
@@ -534,7 +568,7 @@ int nlls_step_norm(nlls_ctx* ctx, double* out) {
 int nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out) {
     NEED_GRAD_LAZY();
     if (ctx->step_cached) { if (xHx_out) *xHx_out = ctx->c_xAx + ctx->lambda * ctx->c_xx; if (gx_out) *gx_out = ctx->c_gx; return NLLS_OK; }   // damping may have changed since
-    TRY(ensure_grad_current(ctx)); TRY(ensure_reduced_summed(ctx));
+    TRY(ensure_grad(ctx, 2)); TRY(ensure_reduced_summed(ctx));
     TRY(enqueue_quadform(ctx, ctx->x.p, 4)); TRY(comm_reduce(ctx, ctx->scalars.p + 4, 2, NLLS_REDUCE_SUM)); TRY(fetch_scalars(ctx, 4, 2));
     if (xHx_out) *xHx_out = ctx->h_scalars[4]; if (gx_out) *gx_out = ctx->h_scalars[5];
     return NLLS_OK;
@@ -549,7 +583,7 @@ int nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from) {
 //   nlls_sweep_cost / nlls_quadform / nlls_max_abs_diag / nlls_grad_* return this rank's PARTIAL values (the caller
 //   sums, or takes the max of, them over ranks); the *_local / *_finish pairs bracket the buffer reductions.
 int nlls_sweep_gradhess_local(nlls_ctx* ctx) {
-    NEED_READY(); TRY(enqueue_sweep_gradhess(ctx));
+    NEED_READY(); ctx->spec_pending = false; ctx->spec_stale = false; TRY(enqueue_sweep_gradhess(ctx));
     ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; ctx->reduced_summed = true;     // (the caller sums the reduce buffer)
     if (ctx->nranks > 1) TRY(enqueue_pack_reduce0(ctx));
     return NLLS_OK;                                  // enqueue only: the reduce buffer is complete in stream order
@@ -627,11 +661,11 @@ static int time_loop(nlls_ctx* ctx, int reps, float* ms_avg, int (*fn)(nlls_ctx*
 }
 
 int nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
-    NEED_READY(); int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c); });
+    NEED_READY(); ctx->spec_pending = false; ctx->spec_stale = false; int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c); });
     ctx->have_grad = true; ctx->reduced_summed = true; return rc;
 }
 int nlls_time_sweep_accumulate(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
-    NEED_READY(); int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c, false); });
+    NEED_READY(); ctx->spec_pending = false; ctx->spec_stale = false; int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c, false); });
     ctx->have_grad = true; ctx->reduced_summed = true; return rc;
 }
 int nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg) {

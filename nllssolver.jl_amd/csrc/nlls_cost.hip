@@ -374,6 +374,8 @@ static int launch_cost(nlls_ctx* c, const Group& G, const double* vars, int64_t&
         int grid = (int)std::min<int64_t>((G.ncost + TPB - 1) / TPB, cost_grid_max);
         const bool shared = G.cost_list >= 0 && c->info.is_sparse;
         const double* data = shared ? G.lists[G.cost_list].data.p : G.data.p; const uint32_t* voff = shared ? G.lists[G.cost_list].voff.p : G.voff.p;
+        // (matrix-free LM trial: the blocks in elimination order are what the loop's other two launches stream -- the cost sweep reads the same 24 bytes per block)
+        if (c->mf_ok && c->mf_on && G.mf_data.p && G.mf_voff.p) { data = G.mf_data.p; voff = G.mf_voff.p; }
         if (post && taken && !*taken) {      // the first launch of the sweep takes the statistics roles along
             hipLaunchKernelGGL((cost_kernel<KIND, true>), dim3(grid + post->np + post->np3 + post->np2), dim3(TPB), 0, c->stream, vars, data, voff, (const uint32_t*)nullptr, G.ncost, G.rk, c->partials.p + pbase, grid, *post);
             *taken = true;

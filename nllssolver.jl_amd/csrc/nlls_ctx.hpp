@@ -125,6 +125,10 @@ struct Group {
     // loop (cost sweep of the accepted trial, then the gradient sweep) they are read from the memory-side cache, and the cost-order arrays
     // (another 24 bytes per block) stay out of the loop's working set.  -1: none (cost order).  The sum is taken in list order: a fixed order.
     int cost_list = -1;
+    // matrix-free LM trial (round 6, nlls_mf.hip): the group's blocks in ELIMINATION order -- supernode by supernode (launch order), member by member, column block by column
+    // block of [E] -- so that lane l of a wavefront's batch finds its block at obs0 + first member * ncb + l.  Same record form as an entry list (data + one storage offset per slot):
+    // the cost sweep of an LM trial reads these arrays too (the loop's working set holds the blocks once)
+    DevBuf<double> mf_data; DevBuf<uint32_t> mf_voff;
 };
 
 // ---- Schur / solve structures ---------------------------------------------------------------------
@@ -138,7 +142,7 @@ struct ElimDesc {
     uint32_t v0, nmem;       // first member (index into the elimination arrays), members
     uint32_t nd, rc_off;     // columns of [E] (neighbour dof), offset of their reduced columns in d_elim_rc
     int64_t dg0;             // A.data offset of the first member's diagonal block
-    uint32_t eb0, pad;       // b offset of the first member
+    uint32_t eb0, obs0;      // b offset of the first member; first record of the supernode in Group::mf_data / mf_voff (matrix-free trial)
 };
 struct SchurNbr {            // one off-diagonal block touching an eliminated block
     int64_t off;             // offset in A.data
@@ -243,6 +247,18 @@ struct nlls_ctx {
     // always a launch of its own, A/B)
     nlls::DenseFin dense_fin{}; bool dense_fin_pending = false, tiny_fin_role = true;
     bool have_grad = false;
+    // Matrix-free LM trial (round 6; nlls_mf.hip).  Two-slot Schur problems whose eliminated blocks all sit on the fast path: nlls_lm_trial evaluates the cost blocks of every
+    // supernode inside the elimination launch and again inside the back-substitution launch -- the point rows of A.data (151 of its 151.5 MB at BASELINE config 4) are never
+    // written or read by the loop.  What stays materialised is the reduced rows (camera diagonal blocks, their part of b: what `grad_level` 1 means) -- the gradient sweep between
+    // two iterations shrinks to the reduced slot's pass; b's eliminated part is written by the elimination launch itself.  A.data in the reference's layout is formed on demand:
+    // every entry point that reads it (nlls_get_bsm_data, nlls_solve, nlls_max_abs_diag, ...) sweeps in full first (ensure_grad level 2).  NLLS_FLAG_MATERIALIZE / NLLS_MATERIALIZE=1 /
+    // nlls_set_option(NLLS_OPT_MATERIALIZE): the round-5 path.
+    bool mf_ok = false, mf_on = true; int mf_group = -1, mf_ps = -1;     // eligibility (build_mf), run-time switch, the cost group and its eliminated slot
+    int grad_level = 0;                      // what A and b hold of the linearisation at grad_phys: 0 nothing, 1 the reduced rows, 2 everything
+    bool mf_step = false;                    // the last solve was matrix-free: the quadratic form's share of the eliminated rows is in mf_q
+    nlls::DevBuf<double> mf_q; size_t mf_lds = 0; uint32_t mf_ecap = 0, mf_wsz = 0; bool mf_use = false;    // per-supernode partials of the step's quadratic form; dynamic LDS of the two launches
+    int64_t mf_trials = 0, mf_reduced_sweeps = 0, full_sweeps = 0;   // diagnostics (nlls_get_solve_stats [23..25])
+    std::vector<int64_t> h_erow; std::vector<int64_t> h_eptr; std::vector<int64_t> h_enbr_block; std::vector<nlls::ElimDesc> h_elim_desc; std::vector<uint32_t> h_fast_voff;   // host copies kept between build_schur and build_mf
 
     // ---- sharding ------------------------------------------------------------------------------------
     bool replicate_xr = false;               // the step's reduced part is written on every rank (sharded LM trial without the stage-2 reduction)

@@ -27,7 +27,7 @@ int enqueue_fixedcost(nlls_ctx* c, const Group& G, const double* vars, int64_t& 
 int enqueue_dyn_gradhess(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase);   // dynamic-size residual blocks (dense system): accumulate
 int enqueue_reduce_partials(nlls_ctx* c, int64_t n);
 int enqueue_check_analytic(nlls_ctx* c, double* d_out, int64_t* nblocks_out);   // closed-form block maths against the dual-number statement (nlls_check_analytic)
-int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost = true, int which = NLLS_VARS_CURRENT);   // which: the variable set to linearise at (the look-ahead sweep of an LM trial: NLLS_VARS_NEXT)
+int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost = true, int which = NLLS_VARS_CURRENT, int mode = 0);   // mode 1: the reduced rows only (the matrix-free trial's gradient sweep: nlls_ctx::grad_level 1)   // which: the variable set to linearise at (the look-ahead sweep of an LM trial: NLLS_VARS_NEXT)
 // vector helpers (nlls_sweep.hip)
 int enqueue_retract(nlls_ctx* c, int to, int from);
 int enqueue_step_stats(nlls_ctx* c);          // scalars[1] = max|x|, scalars[2] = x'x
@@ -93,6 +93,13 @@ int enqueue_reduced_solve(nlls_ctx* c);   // the factorisation + backward pass o
 int enqueue_pack_reduce0(nlls_ctx* c);      // [cost | reduced rows | reduced b] -> redbuf
 int enqueue_unpack_reduce0(nlls_ctx* c, bool with_cost = true);
 
+
+// the matrix-free LM trial (nlls_mf.hip; nlls_ctx::mf_ok)
+struct BsfRetract;
+int enqueue_mf_solve_local(nlls_ctx* c);
+int enqueue_mf_backsub(nlls_ctx* c, const BsfRetract& rt, int write_red, double* zptr, int64_t zcount, unsigned nextra, unsigned nrestwg);
+size_t mf_lds_bytes(uint32_t ecap, int dp); uint32_t mf_wave_doubles(uint32_t ecap, int dp); int mf_batch_max();
+int build_mf(nlls_ctx* c, int32_t ngroups, const nlls_cost_group* groups, const uint64_t* bi, int32_t flags);   // (nlls_structure.cpp)
 
 // collectives (nlls_comm.cpp)
 int comm_reduce(nlls_ctx* c, double* dev_ptr, int64_t count, int op);                 // no-op without an installed all-reduce

@@ -16,10 +16,10 @@
 
 #include "nlls_wave.hpp"
 #include "nlls_post.hpp"
+#include "nlls_slayout.hpp"
 
 namespace nlls {
 
-constexpr int NB = 64;          // Cholesky panel width
 constexpr int LDT = 80;         // LDS leading dimension of a 64-row operand tile (80 = 16 mod 32: conflict-free ds_read_b64)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -29,37 +29,6 @@ NLLS_DEV double wsum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
-
-// ---------------------------------------------------------------------------------------------------
-// reduced system storage.  S is addressed by its lower triangle (i >= j) in reduced order
-// [banded part (n_band dof) | border dof (nbd) | rhs row]; row n (= n_band + nbd) carries the right-hand side.
-//   dense: col-major, ld = npad                         (general systems; MFMA blocked LDL')
-//   band : column j of the banded part holds H = bw+1+nbd+1 entries [S(j..j+bw, j) | S(border, j) | s(j)],
-//          followed by the (nbd+1)^2 border corner        (narrow-band systems; persistent-workgroup LDL')
-//   tile-sparse: the lower tiles of the filled tile pattern, 128 x 128 column-major each, in a nested-dissection order of its own (nlls_tsp.hip):
-//          tsp[0, n) = position of a reduced unknown in that order, tsp[n + I npad + J] = slot of tile (I, J), I >= J  (npad = number of tiles)
-// ---------------------------------------------------------------------------------------------------
-// The tile-sparse addressing is a TYPE of its own (SLayoutT<true>: one more pointer, two dependent loads per entry): every kernel that assembles [S | s] is
-// instantiated for both, and the band / dense instantiations are byte for byte what they were without it (with the branch inside one struct the elimination
-// launch of BASELINE config 4 was measured 4 us slower -- registers, not the branch).
-struct SLayoutNoMap {}; struct SLayoutMap { const int32_t* tsp; };
-template <bool TSP>
-struct SLayoutT : std::conditional_t<TSP, SLayoutMap, SLayoutNoMap> {
-    double* S; int mode; int n, npad, n_band, bw, nbd, H;
-    NLLS_DEV double* at(int i, int j) const {   // i >= j
-        if constexpr (TSP) { int pi = this->tsp[i], pj = this->tsp[j]; if (pi < pj) { const int t = pi; pi = pj; pj = t; }      // (the tile order is not the reduced order: the entry lives at (max, min) of the POSITIONS)
-            return S + (size_t)this->tsp[n + (pi >> 7) * npad + (pj >> 7)] * (128 * 128) + (pi & 127) + 128 * (pj & 127); }
-        if (mode != SOLVE_BAND) return S + (size_t)i + (size_t)npad * j;
-        if (i < n_band) return S + (size_t)j * H + (i - j);
-        if (j < n_band) return S + (size_t)j * H + bw + 1 + (i - n_band);
-        return S + (size_t)n_band * H + (i - n_band) + (size_t)(nbd + 1) * (j - n_band);
-    }
-    // entry i of the reduced right-hand side while the system is assembled: the factorisations carry it as row n of S
-    // (band and dense layouts); only the one-wave solver of tiny systems reads it from the vector s
-    NLLS_DEV double* rhs(double* s, int i) const { if constexpr (TSP) return s + i; else return mode == SOLVE_SMALL ? s + i : at(n, i); }
-};
-using SLayout = SLayoutT<false>;
-template <bool T> NLLS_HD constexpr bool LAY_IS_TSP(const SLayoutT<T>&) { return T; }
 
 // identity on the padding of the dense layout; the rhs as row n: factoring the bordered matrix
 // [[S, s], [s', c]] leaves z = D^-1 L^-1 s in row n of the factor, so no separate forward substitution is needed.
@@ -264,8 +233,6 @@ NLLS_DEV double row_shr_add(double v) {
 // members from the step it has just formed (Euclidean variables of DV entries: checked at upload), workgroups behind the others retract every
 // other variable from the reduced solution itself (x_R = -xr: the scatter of this very launch is not visible to them) -- the cost sweep is then the
 // next launch, and the step statistics ride in ITS launch (nlls_post.hpp): no launch of their own for either.
-struct BsfRetract { int on, nrest; const uint32_t* fast_voff; const uint32_t* rest_var; const int32_t* rest_red;
-                    const int32_t* vkind; const int32_t* vdim; const uint32_t* voff; const double* vfrom; double* vto; };
 template <int DV>
 __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                                 const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
@@ -275,19 +242,7 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
     constexpr int MAXC = (72 + 15) / 16;                      // columns per lane (nd <= 72)
     __shared__ uint32_t rc[80];
     const int lane = threadIdx.x, l = lane & 15, gsub = lane >> 4;
-    if (blockIdx.x >= ngroups + nextra) {                     // (only with rt.on) one thread per variable that is no member of a fast supernode
-        const int j = (int)(blockIdx.x - ngroups - nextra) * 64 + lane; if (j >= rt.nrest) return;
-        const uint32_t i = rt.rest_var[j]; const int r0 = rt.rest_red[j]; const int k = rt.vkind[i], d = rt.vdim[i]; const uint32_t o = rt.voff[i];
-        if (r0 < 0) { const int st = var_storage(k, d); for (int q = 0; q < st; ++q) rt.vto[o + q] = rt.vfrom[o + q]; return; }      // fixed: copied
-        retract_var_fn(k, d, o, rt.vfrom, rt.vto, [&](int q) { return write_red ? -xr[r0 + q] : 0.0; });     // (no staging array: it lived in scratch memory, 1040 bytes per lane of this launch)
-        return;
-    }
-    if (blockIdx.x >= ngroups) {                              // the workgroups behind the supernodes scatter the reduced part: x_R = -s
-        for (int i = (blockIdx.x - ngroups) * 64 + lane; i < nred; i += nextra * 64) x[red_boff[i]] = write_red ? -xr[i] : 0.0;
-        // ... and leave the reduced system's storage zero-filled for the next solve (nothing reads S any more)
-        for (int64_t i = (int64_t)(blockIdx.x - ngroups) * 64 + lane; i < nzero; i += (int64_t)nextra * 64) Szero[i] = 0.0;
-        return;
-    }
+    if (blockIdx.x >= ngroups) { backsub_rest_roles(blockIdx.x - ngroups, nextra, lane, xr, x, red_boff, nred, write_red, Szero, nzero, rt); return; }
     const ElimDesc d = desc[blockIdx.x];                       // uniform: one scalar load
     const uint32_t v0 = d.v0, v1 = d.v0 + d.nmem; const int nd = (int)d.nd;
     for (int c2 = lane; c2 < nd; c2 += 64) rc[c2] = rcflat[d.rc_off + c2];
@@ -686,30 +641,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 //  * the workgroups behind the supernodes ADD the reduced-reduced blocks (+ lambda on their diagonals) and the reduced right-hand side into
 //    [S | s] -- the storage is zero when the launch starts (the previous solve's back-substitution leaves it so), and sums commute with the
 //    supernodes' atomic adds, so the order inside the launch does not matter.
-struct PrepArgs { const uint32_t* red_boff; const SchurCopy* copies; double lambda; int ninit; uint32_t nfast; int* status; };
 template <int DV, class LAY = SLayout>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_all_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
                                                               double* __restrict__ Cinv, LAY L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa) {
-    if (blockIdx.x >= pa.nfast) {
-        const int w = (int)(blockIdx.x - pa.nfast);
-        if (w == 0 && threadIdx.x == 0) pa.status[4] = 0;                       // (pivots dropped by the floor: only the panels of this solve add to it)
-        if (w < pa.ninit) {
-            const int i = w * 256 + threadIdx.x;
-            if (i < L.n) { atomicAdd(L.rhs(s, i), b[pa.red_boff[i]]); return; }
-            if (!LAY_IS_TSP(L) && L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
-            return;
-        }
-        const SchurCopy cp = pa.copies[w - pa.ninit];
-        for (int e = threadIdx.x; e < cp.rows * cp.cols; e += 256) {
-            const int i = e % cp.rows, j = e / cp.rows;
-            double v = A[cp.off + e];
-            if (cp.r == cp.c) { if (i < j) continue; if (i == j) v += pa.lambda; atomicAdd(L.at(cp.r + i, cp.c + j), v); }
-            else if (cp.r > cp.c) atomicAdd(L.at(cp.r + i, cp.c + j), v);
-            else atomicAdd(L.at(cp.c + j, cp.r + i), v);
-        }
-        return;
-    }
+    if (blockIdx.x >= pa.nfast) { schur_prep_roles(A, b, L, s, pa, (int)(blockIdx.x - pa.nfast)); return; }
     {   // the members' inverse diagonal blocks (schur_cinv_kernel's arithmetic, same bits)
         const ElimDesc d = desc[blockIdx.x];
         const int64_t dstride = (int64_t)DV * d.nd + DV * DV;
@@ -1503,9 +1439,10 @@ __global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) { post
 // out[1] = max|x| (NaN if any entry is), out[2] = x'x, out[4] = x'(H + lambda I)x, out[5] = g'x, out[8] = x'Hx, out[9] = (masked) x'x,
 // out[10] = factorisation status
 NLLS_DEV void post_solve_finish_body(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
-                                     double lambda, double* __restrict__ out, const int* __restrict__ status, double (*red)[4]) {
+                                     double lambda, double* __restrict__ out, const int* __restrict__ status, double (*red)[4], const double* __restrict__ mfq = nullptr, int nmfq = 0) {
     double a = 0, m = 0, nan = 0, ss = 0, vv = 0, bv = 0;
     for (int i = threadIdx.x; i < np; i += 256) a += partials[i];
+    for (int i = threadIdx.x; i < nmfq; i += 256) a += mfq[i];      // (matrix-free step: the eliminated rows' share of x'Hx, one partial per supernode)
     for (int i = threadIdx.x; i < np2; i += 256) { m = fmax(m, part2[5 * i]); nan = fmax(nan, part2[5 * i + 1]); ss += part2[5 * i + 2]; vv += part2[5 * i + 3]; bv += part2[5 * i + 4]; }
     a = wsum(a); ss = wsum(ss); vv = wsum(vv); bv = wsum(bv);
 #pragma unroll
@@ -1522,9 +1459,9 @@ NLLS_DEV void post_solve_finish_body(const double* __restrict__ partials, int np
     }
 }
 __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
-                                                                double lambda, double* __restrict__ out, const int* __restrict__ status) {
+                                                                double lambda, double* __restrict__ out, const int* __restrict__ status, const double* __restrict__ mfq, int nmfq) {
     __shared__ double red[6][4];
-    post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red);
+    post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red, mfq, nmfq);
 }
 // the two one-workgroup reductions that end an LM trial in ONE launch: workgroup 0 sums the cost partials (the same order as
 // reduce_partials_kernel: the totals are bit-identical), workgroup 1 finishes the step statistics
@@ -1533,7 +1470,7 @@ __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __
 struct ZeroRanges { double* A; const int64_t* off; const uint32_t* len; double* b; const uint32_t* boff; const uint32_t* blen; int n; };
 __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restrict__ cpart, int64_t ncp, const double* __restrict__ partials, int np,
                                                            const double* __restrict__ part2, int np2, double lambda, double* __restrict__ out, const int* __restrict__ status,
-                                                           double* __restrict__ host_out, double seq, ZeroRanges zr) {
+                                                           double* __restrict__ host_out, double seq, ZeroRanges zr, const double* __restrict__ mfq, int nmfq) {
     __shared__ double red[6][4];
     if (blockIdx.x >= 2) {
         const int r = (int)blockIdx.x - 2;
@@ -1544,7 +1481,7 @@ __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restr
         return;
     }
     if (blockIdx.x == 0) reduce_partials_body(cpart, ncp, out, &red[0][0]);
-    else post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red);
+    else post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red, mfq, nmfq);
     // the scalars also go straight to the pinned host mirror (device-visible, coherent host memory): no copy command behind this launch.
     // Each workgroup then publishes the trial's sequence number: the host spins on the two numbers instead of sleeping in a stream
     // synchronisation (its wake-up costs more than the kernels of this size it waits for).
@@ -1692,7 +1629,8 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
 
 // the arguments of the step-statistics roles (nlls_post.hpp) for the step of the last solve; retract_to >= 0: with the retraction role
 PostSolveArgs post_solve_args(nlls_ctx* c, int retract_to, int retract_from) {
-    const bool reuse = c->tE_valid && c->n_fast_members > 0;
+    const bool mf = c->mf_step;                                 // matrix-free step: the eliminated rows' share of x'Hx is in mf_q (mf_backsub_kernel), summed by the finishing launch
+    const bool reuse = mf || (c->tE_valid && c->n_fast_members > 0);
     PostSolveArgs a{};
     const bool lazy = c->nranks > 1 && !c->reduced_summed;      // the reduced rows of A.data and b hold this rank's share only: they count on every rank
     a.A = c->A.p; a.blk = reuse ? (lazy ? c->d_blk_slow_lazy.p : c->d_blk_slow.p) : c->d_blk.p; a.nblk = reuse ? (lazy ? c->nblk_slow_lazy : c->nblk_slow) : c->nblk;
@@ -1700,7 +1638,7 @@ PostSolveArgs post_solve_args(nlls_ctx* c, int retract_to, int retract_from) {
     a.ediag = c->d_elim_diag.p; a.eboff = c->d_elim_boff.p; a.members = c->n_fast_members == (int64_t)c->d_elim_diag.n ? (const uint32_t*)nullptr : c->d_fast_members.p; a.nm = c->n_fast_members; a.tE = c->tE.p;
     a.x = c->x.p; a.b = c->b.p; a.dofmask = c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr; a.dofmask_b = lazy ? c->d_dof_mask_lazy.p : (const double*)nullptr; a.ndof = c->info.ndof;
     a.np = (int)std::max<int64_t>(1, std::min<int64_t>((a.nblk * QF_COLS + 255) / 256, 768));
-    a.np3 = reuse ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
+    a.np3 = (reuse && !mf) ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
     a.np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 512));      // (5 partials each, behind the quadratic form's at 1024: ends at 3584 < TRIAL_COST_POFS)
     a.partials = c->partials.p; a.part2 = c->partials.p + 1024;
     a.nretract = 0;
@@ -1727,7 +1665,8 @@ int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from, bool finis
     if (c->fast_dv == 3) hipLaunchKernelGGL((post_solve_kernel<3>), grid, dim3(256), 0, c->stream, a);
     else if (c->fast_dv == 2) hipLaunchKernelGGL((post_solve_kernel<2>), grid, dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((post_solve_kernel<1>), grid, dim3(256), 0, c->stream, a);
-    if (finish) hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p, c->d_status.p);
+    if (finish) hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p, c->d_status.p,
+                                   c->mf_step ? c->mf_q.p : (const double*)nullptr, c->mf_step ? (int)c->n_fast_groups : 0);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
@@ -1749,17 +1688,9 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
     ZeroRanges zr{};
     if (c->tail_zero_for_lookahead && c->nzero > 0) { zr = ZeroRanges{c->A.p, c->d_zero_off.p, c->d_zero_len.p, c->b.p, c->d_zero_b_off.p, c->d_zero_b_len.p, (int)c->nzero}; c->heavy_rows_zeroed = true; }
     hipLaunchKernelGGL(trial_finish_kernel, dim3(2 + (unsigned)zr.n), dim3(256), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->partials.p, c->ps_np, c->partials.p + 1024, c->ps_np2,
-                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq), zr);
+                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq), zr, c->mf_step ? c->mf_q.p : (const double*)nullptr, c->mf_step ? (int)c->n_fast_groups : 0);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
-}
-
-template <bool TSP = false>
-static SLayoutT<TSP> make_layout(nlls_ctx* c) {
-    SLayoutT<TSP> L{}; L.S = c->S.p; L.mode = c->solve_mode; L.n = (int)c->nred; L.npad = c->dense_pad128 ? (((int)c->nred + 1 + 127) / 128) * 128 : (((int)c->nred + 1 + NB - 1) / NB) * NB;
-    L.n_band = (int)c->n_band; L.bw = c->bw; L.nbd = c->nbd; L.H = c->band_H;
-    if constexpr (TSP) { L.npad = c->tsp.nt; L.tsp = c->tsp.d_map.p; }
-    return L;
 }
 
 // local phase: assemble this rank's share of [S | s] (rank 0 also contributes the reduced-reduced blocks,
@@ -1768,6 +1699,7 @@ template <bool TSP>
 static int enqueue_solve_local_t(nlls_ctx* c) {
     using LAY = SLayoutT<TSP>;
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
+    if (c->mf_use) return enqueue_mf_solve_local(c);               // the matrix-free trial: the supernodes evaluate their cost blocks themselves (nlls_mf.hip)
     const LAY L = make_layout<TSP>(c); const int npad = TSP ? 0 : L.npad;
     // lazy stage 0 (collective route, reduced rows not summed over ranks): EVERY rank adds its share of the reduced-reduced blocks and of b_R to its
     // share of [S | s] -- the one sum over ranks that follows completes both; the damping is rank 0's
@@ -1995,6 +1927,12 @@ int enqueue_solve_finish(nlls_ctx* c) {
             rt.vkind = c->d_var_kind.p; rt.vdim = c->d_var_dim.p; rt.voff = c->d_var_off.p; rt.vfrom = vars_ptr(c, c->trial_from); rt.vto = vars_ptr(c, c->trial_to);
             nrestwg = (unsigned)((rt.nrest + 63) / 64); c->retract_done = true;
         }
+        if (c->mf_use) {
+            const int rc = enqueue_mf_backsub(c, rt, write_red, zptr, zcount, nextra, nrestwg); if (rc != NLLS_OK) return rc;
+            c->tE_valid = false; c->mf_step = true; c->S_zeroed = zero_S;
+            return NLLS_OK;
+        }
+        c->mf_step = false;
 #define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + nextra + nrestwg), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, \
                 c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red, zptr, zcount, nextra, rt)
         if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; c->S_zeroed = zero_S; }

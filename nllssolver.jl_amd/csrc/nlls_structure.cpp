@@ -60,11 +60,12 @@ void hot_set(nlls_ctx* c, std::vector<HotItem>& v) {
             hot(v, E.fslot); hot(v, E.ftiles); hot(v, E.frowx); }
         if (G.fold) { hot(v, G.frows); hot(v, G.fcons); hot(v, G.fslab); }
         if (G.cost_list < 0 || !c->info.is_sparse) { hot(v, G.data); hot(v, G.voff); }
+        hot(v, G.mf_data); hot(v, G.mf_voff);
         hot(v, G.fixedcost); hot(v, G.dense.data); hot(v, G.dense.voff); hot(v, G.dense.brow);
     }
     hot(v, c->d_var_kind); hot(v, c->d_var_dim); hot(v, c->d_var_off); hot(v, c->d_var_boff); hot(v, c->d_diag_off); hot(v, c->d_blocksizes);
     hot(v, c->d_zero_off); hot(v, c->d_zero_len); hot(v, c->d_zero_b_off); hot(v, c->d_zero_b_len); hot(v, c->partials); hot(v, c->scalars);
-    hot(v, c->S); hot(v, c->Cinv); hot(v, c->tE); hot(v, c->d_status); hot(v, c->d_copy); hot(v, c->d_red_boff); hot(v, c->d_blk_slow);
+    hot(v, c->S); hot(v, c->Cinv); hot(v, c->tE); hot(v, c->mf_q); hot(v, c->d_status); hot(v, c->d_copy); hot(v, c->d_red_boff); hot(v, c->d_blk_slow);
     hot(v, c->d_elim_desc); hot(v, c->d_elim_rc); hot(v, c->d_elim_diag); hot(v, c->d_elim_boff); hot(v, c->d_elim_dim); hot(v, c->d_fast_members); hot(v, c->d_fast_groups);
     if (c->bcr.ready) { hot(v, c->bcr.ws); hot(v, c->bcr.d_upd); hot(v, c->bcr.d_elim); } else hot(v, c->Lwork);
 }
@@ -205,6 +206,7 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
     c->rank = c->shard_rank; c->nranks = c->shard_nranks; c->replicated = false;      // what nlls_set_shard asked for (a problem that does not shard falls back to replicas below)
     c->presharded = (flags & NLLS_FLAG_PRESHARDED) != 0 && c->nranks > 1;
     c->ready = false; c->solved = false; c->have_grad = false; c->lambda = 0; c->reduced_summed = true; c->n_stage0 = 0; c->n_lazy_trials = 0;
+    c->spec_pending = false; c->spec_stale = false; c->spec_armed = true; c->grad_phys = -1; c->grad_level = 0; c->sweeps_since_set = 0; c->dense_fin_pending = false; c->heavy_rows_zeroed = false; c->tail_zero_for_lookahead = false;   // (a re-upload starts from a clean look-ahead state)
     { std::vector<HotItem> v; hot_set(c, v); for (HotItem& it : v) if (!*it.owned) { *it.pp = nullptr; *it.owned = true; } }   // what lived in the previous upload's arena is gone with it
     c->arena.release(); c->arena_pre.release();     // ... so release it NOW: a re-upload would otherwise hold two arenas (and every buffer once more) at its peak
     c->groups.clear();
@@ -587,9 +589,65 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
       c->local_nnz_data = sparse ? lw : nnz_data; c->local_ndof = ld; }
     int rc = build_schur(c, flags);
     if (rc != NLLS_OK) return rc;
+    rc = build_mf(c, ngroups, groups, bi, flags);
+    if (rc != NLLS_OK) return rc;
     rc = compact_hot_set(c);
     if (rc != NLLS_OK) return rc;
     c->ready = true;
+    return NLLS_OK;
+}
+
+
+// ---- the matrix-free LM trial's block list (nlls_mf.hip) ------------------------------------------------------------------
+// Eligible: one rank, ONE cost group of a two-slot residual kind, one slot's variables all eliminated on the fast path (Euclidean, at most three unknowns), the other
+// slot's all reduced, no fixed variable, exactly one block per (eliminated block, neighbour) pair -- i.e. the member's blocks ARE the column blocks of its [E], one each.
+// Leaves c->mf_ok false (and nothing else changed) whenever the problem does not qualify: nlls_lm_trial then takes the materialised path.
+int build_mf(nlls_ctx* c, int32_t ngroups, const nlls_cost_group* groups, const uint64_t* bi, int32_t flags) {
+    c->mf_ok = false; c->mf_group = -1; c->mf_ps = -1; c->mf_step = false; c->mf_use = false; c->mf_q.release();
+    for (Group& G : c->groups) { G.mf_data.release(); G.mf_voff.release(); }
+    { const char* e = getenv("NLLS_MATERIALIZE"); c->mf_on = !(e && e[0] == '1'); }
+    if ((flags & NLLS_FLAG_MATERIALIZE) || ngroups != 1 || c->nranks != 1 || !c->info.is_sparse) return NLLS_OK;
+    const nlls_cost_group& in = groups[0]; ResDesc d;
+    if (!res_desc(in.res_kind, d) || is_dyn_kind(in.res_kind) || d.ndeps != 2 || d.adaptive || d.nres <= 0) return NLLS_OK;
+    if (c->n_fast_groups == 0 || c->n_slow_groups != 0 || c->n_fast_members != (int64_t)c->h_erow.size() || !c->fast_all_euclid || c->elim_slab) return NLLS_OK;
+    if (c->solve_mode == SOLVE_SMALL || c->solve_mode == SOLVE_TSPARSE || c->h_elim_desc.size() != (size_t)c->n_fast_groups || in.ncost <= 0 || in.ncost > 0xFFFFFFF0ll) return NLLS_OK;
+    Group& G = c->groups[0];
+    if (G.nfixedcost != 0) return NLLS_OK;
+    const int64_t nb = c->info.nblocks;
+    int ps = -1;
+    { const uint64_t b0 = bi[in.varind[0] - 1], b1 = bi[in.varind[1] - 1]; if (!b0 || !b1) return NLLS_OK; ps = c->is_elim[b0 - 1] ? 0 : 1; }
+    const int cs = 1 - ps; const int dp = var_dof(d.sk[ps], d.sd[ps]), dc = var_dof(d.sk[cs], d.sd[cs]);
+    if (dp != c->fast_dv || dp < 1 || dp > 3 || dc < 1) return NLLS_OK;
+    // the blocks of every eliminated block row, counting sort by that row
+    std::vector<int64_t> cnt(nb + 1, 0);
+    for (int64_t k = 0; k < in.ncost; ++k) { const uint64_t bp = bi[in.varind[k * 2 + ps] - 1], bc = bi[in.varind[k * 2 + cs] - 1];
+        if (!bp || !bc || !c->is_elim[bp - 1] || c->is_elim[bc - 1]) return NLLS_OK;
+        cnt[bp]++; }
+    std::vector<int64_t> pos(nb + 1, 0); for (int64_t r = 0; r < nb; ++r) pos[r + 1] = pos[r] + cnt[r + 1];
+    std::vector<int64_t> byrow((size_t)in.ncost); { std::vector<int64_t> cur(pos.begin(), pos.end() - 1); for (int64_t k = 0; k < in.ncost; ++k) byrow[cur[bi[in.varind[k * 2 + ps] - 1] - 1]++] = k; }
+    std::vector<double> hd; std::vector<uint32_t> hv; hd.reserve((size_t)in.ncost * d.ndata); hv.reserve((size_t)in.ncost * 2);
+    std::vector<ElimDesc> desc = c->h_elim_desc; uint32_t ecap = 0; int64_t nobs = 0;
+    const int bmax = mf_batch_max();
+    for (ElimDesc& e : desc) {
+        const int nd = (int)e.nd; if (nd % dc || nd + 1 > 80 || nd / dc > 64 || nd / dc < 1 || e.nmem > 128) return NLLS_OK;
+        const int ncb = nd / dc; e.obs0 = (uint32_t)nobs;
+        const int B = std::min(64 / ncb, bmax), TR = (nd + 1 + 15) / 16; ecap = std::max<uint32_t>(ecap, (uint32_t)(B * dp * 16 * TR));
+        for (uint32_t m = 0; m < e.nmem; ++m) { const uint32_t v = e.v0 + m; const int64_t row = c->h_erow[v];
+            const int64_t q0 = c->h_eptr[v], q1 = c->h_eptr[v + 1];
+            if (q1 - q0 != ncb || pos[row + 1] - pos[row] != ncb) return NLLS_OK;
+            for (int64_t q = q0; q < q1; ++q) { const int64_t nbk = c->h_enbr_block[q]; if (nbk < 0 || c->blocksizes[nbk] != dc) return NLLS_OK;
+                int64_t found = -1;
+                for (int64_t t = pos[row]; t < pos[row + 1]; ++t) { const int64_t k = byrow[t]; if ((int64_t)bi[in.varind[k * 2 + cs] - 1] - 1 == nbk) { if (found >= 0) return NLLS_OK; found = k; } }
+                if (found < 0) return NLLS_OK;
+                for (int q2 = 0; q2 < d.ndata; ++q2) hd.push_back(in.data[found * d.ndata + q2]);
+                hv.push_back(c->var_off[in.varind[found * 2] - 1]); hv.push_back(c->var_off[in.varind[found * 2 + 1] - 1]); ++nobs; } }
+    }
+    if (nobs != in.ncost) return NLLS_OK;
+    HIPCHK(G.mf_data.upload(hd)); HIPCHK(G.mf_voff.upload(hv)); HIPCHK(c->d_elim_desc.upload(desc)); HIPCHK(c->mf_q.alloc((size_t)c->n_fast_groups));
+    c->h_elim_desc = desc;
+    c->mf_ecap = ecap; c->mf_wsz = mf_wave_doubles(ecap, dp); c->mf_lds = mf_lds_bytes(ecap, dp);
+    if (c->mf_lds > (size_t)150 * 1024) return NLLS_OK;
+    c->mf_ok = true; c->mf_group = 0; c->mf_ps = ps;
     return NLLS_OK;
 }
 
@@ -685,6 +743,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     // (a re-upload -- or the retry without Schur elimination after an unsupported shape -- must not see the previous
     // attempt's supernode lists: the solve dispatches on these counters)
     c->n_fast_groups = 0; c->n_slow_groups = 0; c->n_fast_members = 0; c->n_fast_narrow = 0; c->n_fast_n60 = 0; c->fast_dv = 0;
+    c->h_elim_desc.clear(); c->h_erow.clear(); c->h_eptr.clear(); c->h_enbr_block.clear(); c->mf_ok = false; c->mf_step = false; c->mf_use = false;
     c->tE_valid = false; c->S_zeroed = false; c->status_known_zero = false; c->step_cached = false; c->bcr.release();
     c->elim_slab = false; c->slab.release(); c->d_slab_off.release(); c->d_slab_groups.release(); c->d_gjobs.release(); c->d_gcons.release(); c->n_gjobs = 0;
     // (the solve also dispatches on the SIZE of these lists: an upload without elimination must not inherit them)
@@ -923,7 +982,11 @@ int build_schur(nlls_ctx* c, int32_t flags) {
           if (rcflat.empty()) rcflat.push_back(0);
           // (rounds 3-4 could fold the tiny supernodes at every step of the visibility window into a large neighbour -- ElimPre, NLLS_ELIM_FOLD: parity-green, 316 against 294 us
           //  per solve: the tiny workgroups were filling slots the large ones leave idle.  Out of the library since round 5; last in the tree at commit 6e015b8.)
-          if (hipSuccess != c->d_elim_desc.upload(desc) || hipSuccess != c->d_elim_rc.upload(rcflat)) return fail(c, NLLS_ERR_HIP, "supernode descriptor upload"); }
+          if (hipSuccess != c->d_elim_desc.upload(desc) || hipSuccess != c->d_elim_rc.upload(rcflat)) return fail(c, NLLS_ERR_HIP, "supernode descriptor upload");
+          // (host copies for build_mf: the matrix-free trial's block list follows the supernodes' launch order)
+          c->h_elim_desc = desc; c->h_erow = erow; c->h_eptr = eptr;
+          { std::vector<int64_t> blk_of_red((size_t)c->nred, -1); for (int64_t k = 0; k < nb; ++k) if (!c->is_elim[k] && red_of[k] >= 0) blk_of_red[(size_t)red_of[k]] = k;
+            c->h_enbr_block.resize(enbr.size()); for (size_t i = 0; i < enbr.size(); ++i) c->h_enbr_block[i] = enbr[i].rcol < blk_of_red.size() ? blk_of_red[enbr[i].rcol] : -1; } }
         if (hipSuccess != c->d_fast_groups.upload(fastg) || hipSuccess != c->d_slow_groups.upload(slowg) || hipSuccess != c->d_slow_blocks.upload(slowb) ||
             hipSuccess != c->Cinv.alloc(std::max<size_t>(1, ediag.size() * (size_t)std::max(1, fast_dv * fast_dv)))) return fail(c, NLLS_ERR_HIP, "group list upload");
         if (hipSuccess != c->d_elim_ptr.upload(eptr) || hipSuccess != c->d_elim_nbr.upload(enbr) || hipSuccess != c->d_elim_diag.upload(ediag) ||

@@ -791,8 +791,14 @@ static bool launch_gh_fold(nlls_ctx* c, const Group& G, const double* vars, int6
     }
     return true;
 }
+// the reduced slot's pass alone (the gradient sweep of the matrix-free LM trial, nlls_ctx::grad_level 1: the eliminated rows of A.data are never formed)
 template <int KIND>
-static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+static void launch_gh_reduced(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase) {
+    if constexpr (Res<KIND>::NDEPS == 2) { if (c->mf_ps == 0) launch_gh_slot<KIND, 1>(c, G, vars, pbase); else launch_gh_slot<KIND, 0>(c, G, vars, pbase); }
+}
+template <int KIND>
+static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& pbase, int mode = 0) {
+    if (mode == 1) { launch_gh_reduced<KIND>(c, G, vars, pbase); return NLLS_OK; }
     if (c->info.is_sparse) {
         // (three-slot kinds whose lists do not qualify for the folded sweep take one launch per role: rounds 2-4's one-launch form of that, gh_fused3_kernel -- every block
         //  evaluated once per ROLE, 244 registers -- went with the fold: 104 against 55 us at BASELINE config 5; last in the tree at commit 6e015b8)
@@ -812,7 +818,9 @@ static int launch_gh(nlls_ctx* c, const Group& G, const double* vars, int64_t& p
     return enqueue_fixedcost(c, G, vars, pbase);
 }
 
-int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost, int which) {
+int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost, int which, int mode) {
+    if (mode == 1 && (!c->mf_ok || want_cost)) mode = 0;
+    c->grad_level = mode == 1 ? 1 : 2; if (mode == 1) c->mf_reduced_sweeps++; else c->full_sweeps++;
     c->tE_valid = false; c->step_cached = false;  // A and b change: what the last solve kept of them is stale
     c->grad_phys = c->vars_slot[which];           // the variable set (physical slot) A and b are the linearisation of
     const double* vars = vars_ptr(c, which); int64_t pbase = 0;
@@ -827,17 +835,17 @@ int enqueue_sweep_gradhess(nlls_ctx* c, bool want_cost, int which) {
     } else if (c->nzero > 0) {
         hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)c->nzero), dim3(64), 0, c->stream, c->A.p, c->d_zero_off.p, c->d_zero_len.p, c->b.p, c->d_zero_b_off.p, c->d_zero_b_len.p);
     }
-    const bool prof = c->prof_sweep && !c->prof_ev.empty();
+    const bool prof = c->prof_sweep && !c->prof_ev.empty() && mode == 0;      // (the in-situ profile is of the full accumulate launch)
     const size_t pslot = prof ? (size_t)(c->prof_count % (int64_t)(c->prof_ev.size() / 2)) : 0;
     // profiling: a problem of ONE cost group whose sweep is one fused (or folded) launch hands the event pair to that launch (hipExtLaunchKernelGGL: the
     // dispatch's own begin / end timestamps); anything else is bracketed by recorded events, which also hold the dispatch latency in front
     c->prof_e0 = c->prof_e1 = nullptr; c->prof_taken = false;
-    if (prof && c->groups.size() == 1 && c->info.is_sparse) { c->prof_e0 = c->prof_ev[2 * pslot]; c->prof_e1 = c->prof_ev[2 * pslot + 1]; }
+    if (prof && c->groups.size() == 1 && c->info.is_sparse && mode == 0) { c->prof_e0 = c->prof_ev[2 * pslot]; c->prof_e1 = c->prof_ev[2 * pslot + 1]; }
     else if (prof) (void)hipEventRecord(c->prof_ev[2 * pslot], c->stream);
     for (const Group& G : c->groups) {
         if (is_dyn_kind(G.res_kind)) { enqueue_dyn_gradhess(c, G, vars, pbase); enqueue_fixedcost(c, G, vars, pbase); continue; }   // (into the dense system, or the variable's diagonal block of a block-sparse one)
         switch (G.res_kind) {
-#define X(K) case K: launch_gh<K>(c, G, vars, pbase); break;
+#define X(K) case K: launch_gh<K>(c, G, vars, pbase, mode); break;
             NLLS_FOR_EACH_RES(X)
 #undef X
         }
