@@ -144,6 +144,12 @@ struct ElimDesc {
     int64_t dg0;             // A.data offset of the first member's diagonal block
     uint32_t eb0, obs0;      // b offset of the first member; first record of the supernode in Group::mf_data / mf_voff (matrix-free trial)
 };
+struct MfDesc {              // a supernode of the matrix-free trial (nlls_mf.hip), launch order: those of several batches first
+    uint32_t v0, nmem, nd, rc_off;   // as ElimDesc
+    uint32_t eb0, obs0;              // b offset of the first member; first record in Group::mf_data / mf_voff
+    uint32_t B, slab;                // members per batch; offset of the supernode's share in nlls_ctx::slab (GatherCon offsets point into it)
+    //                                  B: members per batch (one lane per cost block: at most 64 / blocks per member, chosen so that the four wavefronts get equal shares)
+};
 struct SchurNbr {            // one off-diagonal block touching an eliminated block
     int64_t off;             // offset in A.data
     uint32_t rcol;           // dof offset of the neighbour in the reduced system
@@ -256,7 +262,7 @@ struct nlls_ctx {
     bool mf_ok = false, mf_on = true; int mf_group = -1, mf_ps = -1;     // eligibility (build_mf), run-time switch, the cost group and its eliminated slot
     int grad_level = 0;                      // what A and b hold of the linearisation at grad_phys: 0 nothing, 1 the reduced rows, 2 everything
     bool mf_step = false;                    // the last solve was matrix-free: the quadratic form's share of the eliminated rows is in mf_q
-    nlls::DevBuf<double> mf_q; size_t mf_lds = 0; uint32_t mf_ecap = 0, mf_wsz = 0; bool mf_use = false;    // per-supernode partials of the step's quadratic form; dynamic LDS of the two launches
+    nlls::DevBuf<double> mf_q; nlls::DevBuf<nlls::MfDesc> d_mf_desc; int64_t mf_nbig = 0; size_t mf_lds = 0; uint32_t mf_ecap = 0, mf_wsz = 0; bool mf_use = false;    // per-supernode partials of the step's quadratic form; dynamic LDS of the two launches
     int64_t mf_trials = 0, mf_reduced_sweeps = 0, full_sweeps = 0;   // diagnostics (nlls_get_solve_stats [23..25])
     std::vector<int64_t> h_erow; std::vector<int64_t> h_eptr; std::vector<int64_t> h_enbr_block; std::vector<nlls::ElimDesc> h_elim_desc; std::vector<uint32_t> h_fast_voff;   // host copies kept between build_schur and build_mf
 
@@ -326,6 +332,7 @@ struct nlls_ctx {
     int solve_mode = 0, band_CH = 0, band_H = 0, band_SEG = 0, band_NSEG = 0;
     bool band_blocked = true;                // blocked (MFMA) band factorisation when the bandwidth allows
     bool band_twisted = true;               // factor the band from both ends at once (two workgroups) when the layout allows
+    bool gather_ready = false, tiles_zeroed = false; std::vector<uint32_t> h_slab_off;   // the gather index (d_gjobs / d_gcons / slab) exists; the tiles the gather writes into are zero
     bool elim_slab = false;                 // slab + gather assembly straight into the block cyclic reduction's tiles (single rank, fast-path supernodes only)
     nlls::DevBuf<double> slab; nlls::DevBuf<uint32_t> d_slab_off, d_slab_groups; int64_t n_slab60 = 0, n_slabnar = 0, n_slabwide = 0; nlls::DevBuf<nlls::GatherJob> d_gjobs; nlls::DevBuf<nlls::GatherCon> d_gcons; int64_t n_gjobs = 0;
     nlls::TspSolver tsp;                    // tile-sparse LDL' of a reduced system that is neither a narrow band nor small (nlls_tsp.hip)

@@ -52,13 +52,13 @@ template <class LAY>
 NLLS_DEV void schur_prep_roles(const double* __restrict__ A, const double* __restrict__ b, const LAY& L, double* __restrict__ s, const PrepArgs& pa, int w) {
     if (w == 0 && threadIdx.x == 0) pa.status[4] = 0;                       // (pivots dropped by the floor: only the panels of this solve add to it)
     if (w < pa.ninit) {
-        const int i = w * 256 + threadIdx.x;
+        const int i = w * (int)blockDim.x + threadIdx.x;      // (ninit counts workgroups of the launch's own size)
         if (i < L.n) { atomicAdd(L.rhs(s, i), b[pa.red_boff[i]]); return; }
         if (!LAY_IS_TSP(L) && L.mode != SOLVE_BAND && i < L.npad) { s[i] = 0.0; L.S[(size_t)i + (size_t)L.npad * i] = (i == L.n) ? 1e300 : 1.0; }
         return;
     }
     const SchurCopy cp = pa.copies[w - pa.ninit];
-    for (int e = threadIdx.x; e < cp.rows * cp.cols; e += 256) {
+    for (int e = threadIdx.x; e < cp.rows * cp.cols; e += (int)blockDim.x) {
         const int i = e % cp.rows, j = e / cp.rows;
         double v = A[cp.off + e];
         if (cp.r == cp.c) { if (i < j) continue; if (i == j) v += pa.lambda; atomicAdd(L.at(cp.r + i, cp.c + j), v); }

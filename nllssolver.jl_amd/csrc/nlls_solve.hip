@@ -1693,6 +1693,18 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
     return NLLS_OK;
 }
 
+// the supernodes' slabs -> the tiles of the block cyclic reduction (the tiles outside the pattern must be zero: the previous solve's back-substitution, or a memset here)
+int enqueue_gather(nlls_ctx* c) {
+    if (!c->gather_ready || !c->bcr.ready) { c->err = "gather index missing"; return NLLS_ERR_NOT_READY; }
+    const BcrGeom& g = c->bcr.geom;
+    if (!c->tiles_zeroed) HIPCHK(hipMemsetAsync(g.ws + g.oD, 0, sizeof(double) * (g.oBR + (size_t)g.N * g.NT * 256 - g.oD), c->stream));
+    c->tiles_zeroed = false;
+    GatherArgs ga{c->d_gjobs.p, c->d_gcons.p, c->n_gjobs, c->slab.p, c->A.p, c->b.p, c->Cinv.p, c->fast_dv, c->lambda, c->bcr.geom, c->d_status.p};
+    hipLaunchKernelGGL(schur_gather_kernel, dim3((unsigned)((c->n_gjobs + 3) / 4)), dim3(256), 0, c->stream, ga);
+    HIPCHK(hipGetLastError());
+    return NLLS_OK;
+}
+
 // local phase: assemble this rank's share of [S | s] (rank 0 also contributes the reduced-reduced blocks,
 // lambda*I and b_R); under sharding the buffer is then summed over ranks
 template <bool TSP>
@@ -1722,10 +1734,7 @@ static int enqueue_solve_local_t(nlls_ctx* c) {
         HIPCHK(hipMemsetAsync(c->d_status.p, 0, sizeof(int32_t) * 5, c->stream));
         if (c->fast_dv == 3) LAUNCH_SLAB(3); else if (c->fast_dv == 2) LAUNCH_SLAB(2); else LAUNCH_SLAB(1);
 #undef LAUNCH_SLAB
-        GatherArgs ga{c->d_gjobs.p, c->d_gcons.p, c->n_gjobs, c->slab.p, c->A.p, c->b.p, c->Cinv.p, c->fast_dv, c->lambda, c->bcr.geom, c->d_status.p};
-        hipLaunchKernelGGL(schur_gather_kernel, dim3((unsigned)((c->n_gjobs + 3) / 4)), dim3(256), 0, c->stream, ga);
-        HIPCHK(hipGetLastError());
-        return NLLS_OK;
+        return enqueue_gather(c);
     }
     const bool one_prepare = lead && c->info.is_sparse && c->ncopy > 0;      // status reset, s and the reduced-reduced blocks in one launch
     // ONE launch for the whole assembly (schur_elim_all_kernel): every eliminated block on the fast path with both kinds of supernode present, one rank,
@@ -1821,7 +1830,9 @@ int enqueue_reduced_solve(nlls_ctx* c) {
         // gauge directions are rounding noise of either sign, the step along them noise / noise, and whether the trial is accepted a coin toss: at BASELINE config 4
         // 29-31 damped solves for 20 iterations (the oracle's LDL': 24) against 20 with the rule, ending at the oracle's cost to 12 digits.
         const double pivot_floor = c->lambda == 0.0 ? 1e-11 : c->damped_floor;
-        if (c->bcr.enqueue(c->stream, c->elim_slab ? (const double*)nullptr : c->S.p, c->s_ptr(), c->d_status.p, pivot_floor) != NLLS_OK) return herr(c, hipGetLastError(), "block cyclic reduction launch");
+        const bool tiles_direct = c->elim_slab || c->mf_use;          // (slab + gather assembly: the tiles are in place, no conversion from band storage)
+        if (!tiles_direct) c->tiles_zeroed = false;
+        if (c->bcr.enqueue(c->stream, tiles_direct ? (const double*)nullptr : c->S.p, c->s_ptr(), c->d_status.p, pivot_floor) != NLLS_OK) return herr(c, hipGetLastError(), "block cyclic reduction launch");
     } else if (band) {
         // bands wider than block cyclic reduction takes (more than 80 columns), and NLLS_FLAG_NO_BCR: the chain kernels of round 1 (nlls_chain.hip)
         const int rc = enqueue_chain_solve(c, L.n_band, L.bw, L.nbd, L.H); if (rc != NLLS_OK) return rc;
@@ -1918,7 +1929,8 @@ int enqueue_solve_finish(nlls_ctx* c) {
         const unsigned nextra = zero_S ? 160 : 32;
         // what the spare workgroups zero-fill for the next solve: the band storage of S, or (slab + gather assembly) the tiles the gather writes into
         double* zptr = c->S.p; int64_t zcount = zero_S ? (int64_t)c->s_elems : (int64_t)0;
-        if (c->elim_slab) { const BcrGeom& g = c->bcr.geom; zptr = g.ws + g.oD; zcount = (int64_t)(g.oBR + (size_t)g.N * g.NT * 256 - g.oD); }
+        const bool tiles_direct = c->elim_slab || c->mf_use;
+        if (tiles_direct) { const BcrGeom& g = c->bcr.geom; zptr = g.ws + g.oD; zcount = (int64_t)(g.oBR + (size_t)g.N * g.NT * 256 - g.oD); }
         // an LM trial (nlls_lm_trial sets trial_to / trial_from): the retraction in this launch
         BsfRetract rt{}; unsigned nrestwg = 0;
         c->retract_done = false;
@@ -1929,13 +1941,13 @@ int enqueue_solve_finish(nlls_ctx* c) {
         }
         if (c->mf_use) {
             const int rc = enqueue_mf_backsub(c, rt, write_red, zptr, zcount, nextra, nrestwg); if (rc != NLLS_OK) return rc;
-            c->tE_valid = false; c->mf_step = true; c->S_zeroed = zero_S;
+            c->tE_valid = false; c->mf_step = true; c->tiles_zeroed = true;
             return NLLS_OK;
         }
         c->mf_step = false;
 #define LAUNCH_BSF(DV) hipLaunchKernelGGL((schur_backsub_fast_kernel<DV>), dim3((unsigned)c->n_fast_groups + nextra + nrestwg), dim3(64), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, \
                 c->Cinv.p, c->s_ptr(), c->x.p, c->tE.p, (uint32_t)c->n_fast_groups, c->d_red_boff.p, n, write_red, zptr, zcount, nextra, rt)
-        if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; c->S_zeroed = zero_S; }
+        if (c->n_fast_groups > 0) { if (c->fast_dv == 3) LAUNCH_BSF(3); else if (c->fast_dv == 2) LAUNCH_BSF(2); else if (c->fast_dv == 1) LAUNCH_BSF(1); c->tE_valid = true; if (tiles_direct) c->tiles_zeroed = true; else c->S_zeroed = zero_S; }
         else c->retract_done = false;
 #undef LAUNCH_BSF
     }

@@ -65,7 +65,7 @@ void hot_set(nlls_ctx* c, std::vector<HotItem>& v) {
     }
     hot(v, c->d_var_kind); hot(v, c->d_var_dim); hot(v, c->d_var_off); hot(v, c->d_var_boff); hot(v, c->d_diag_off); hot(v, c->d_blocksizes);
     hot(v, c->d_zero_off); hot(v, c->d_zero_len); hot(v, c->d_zero_b_off); hot(v, c->d_zero_b_len); hot(v, c->partials); hot(v, c->scalars);
-    hot(v, c->S); hot(v, c->Cinv); hot(v, c->tE); hot(v, c->mf_q); hot(v, c->d_status); hot(v, c->d_copy); hot(v, c->d_red_boff); hot(v, c->d_blk_slow);
+    hot(v, c->S); hot(v, c->Cinv); hot(v, c->tE); hot(v, c->mf_q); hot(v, c->d_mf_desc); hot(v, c->d_status); hot(v, c->d_copy); hot(v, c->d_red_boff); hot(v, c->d_blk_slow);
     hot(v, c->d_elim_desc); hot(v, c->d_elim_rc); hot(v, c->d_elim_diag); hot(v, c->d_elim_boff); hot(v, c->d_elim_dim); hot(v, c->d_fast_members); hot(v, c->d_fast_groups);
     if (c->bcr.ready) { hot(v, c->bcr.ws); hot(v, c->bcr.d_upd); hot(v, c->bcr.d_elim); } else hot(v, c->Lwork);
 }
@@ -603,13 +603,15 @@ int build_structure(nlls_ctx* c, int64_t nvar, const int32_t* var_kind, const in
 // slot's all reduced, no fixed variable, exactly one block per (eliminated block, neighbour) pair -- i.e. the member's blocks ARE the column blocks of its [E], one each.
 // Leaves c->mf_ok false (and nothing else changed) whenever the problem does not qualify: nlls_lm_trial then takes the materialised path.
 int build_mf(nlls_ctx* c, int32_t ngroups, const nlls_cost_group* groups, const uint64_t* bi, int32_t flags) {
-    c->mf_ok = false; c->mf_group = -1; c->mf_ps = -1; c->mf_step = false; c->mf_use = false; c->mf_q.release();
+    c->mf_ok = false; c->mf_group = -1; c->mf_ps = -1; c->mf_step = false; c->mf_use = false; c->mf_q.release(); c->d_mf_desc.release(); c->mf_nbig = 0;
     for (Group& G : c->groups) { G.mf_data.release(); G.mf_voff.release(); }
     { const char* e = getenv("NLLS_MATERIALIZE"); c->mf_on = !(e && e[0] == '1'); }
-    if ((flags & NLLS_FLAG_MATERIALIZE) || ngroups != 1 || c->nranks != 1 || !c->info.is_sparse) return NLLS_OK;
+    // (the gather index of build_schur was built for this trial: without it -- or when the problem turns out not to qualify below -- it goes again, unless the flag asked for it)
+    struct Drop { nlls_ctx* c; bool keep; ~Drop() { if (!c->mf_ok && !keep) { c->gather_ready = false; c->slab.release(); c->d_slab_off.release(); c->d_slab_groups.release(); c->d_gjobs.release(); c->d_gcons.release(); c->n_gjobs = 0; } } } drop{c, (flags & NLLS_FLAG_DETERMINISTIC) != 0};
+    if ((flags & NLLS_FLAG_MATERIALIZE) || ngroups != 1 || c->nranks != 1 || !c->info.is_sparse || !c->gather_ready || c->h_slab_off.size() != c->h_elim_desc.size()) return NLLS_OK;
     const nlls_cost_group& in = groups[0]; ResDesc d;
     if (!res_desc(in.res_kind, d) || is_dyn_kind(in.res_kind) || d.ndeps != 2 || d.adaptive || d.nres <= 0) return NLLS_OK;
-    if (c->n_fast_groups == 0 || c->n_slow_groups != 0 || c->n_fast_members != (int64_t)c->h_erow.size() || !c->fast_all_euclid || c->elim_slab) return NLLS_OK;
+    if (c->n_fast_groups == 0 || c->n_slow_groups != 0 || c->n_fast_members != (int64_t)c->h_erow.size() || !c->fast_all_euclid) return NLLS_OK;
     if (c->solve_mode == SOLVE_SMALL || c->solve_mode == SOLVE_TSPARSE || c->h_elim_desc.size() != (size_t)c->n_fast_groups || in.ncost <= 0 || in.ncost > 0xFFFFFFF0ll) return NLLS_OK;
     Group& G = c->groups[0];
     if (G.nfixedcost != 0) return NLLS_OK;
@@ -626,12 +628,19 @@ int build_mf(nlls_ctx* c, int32_t ngroups, const nlls_cost_group* groups, const 
     std::vector<int64_t> pos(nb + 1, 0); for (int64_t r = 0; r < nb; ++r) pos[r + 1] = pos[r] + cnt[r + 1];
     std::vector<int64_t> byrow((size_t)in.ncost); { std::vector<int64_t> cur(pos.begin(), pos.end() - 1); for (int64_t k = 0; k < in.ncost; ++k) byrow[cur[bi[in.varind[k * 2 + ps] - 1] - 1]++] = k; }
     std::vector<double> hd; std::vector<uint32_t> hv; hd.reserve((size_t)in.ncost * d.ndata); hv.reserve((size_t)in.ncost * 2);
-    std::vector<ElimDesc> desc = c->h_elim_desc; uint32_t ecap = 0; int64_t nobs = 0;
-    const int bmax = mf_batch_max();
-    for (ElimDesc& e : desc) {
-        const int nd = (int)e.nd; if (nd % dc || nd + 1 > 80 || nd / dc > 64 || nd / dc < 1 || e.nmem > 128) return NLLS_OK;
-        const int ncb = nd / dc; e.obs0 = (uint32_t)nobs;
-        const int B = std::min(64 / ncb, bmax), TR = (nd + 1 + 15) / 16; ecap = std::max<uint32_t>(ecap, (uint32_t)(B * dp * 16 * TR));
+    // launch order: the supernodes of several batches (one workgroup each), then those of ONE batch (one wavefront each).  Members per batch B <= 64 / (blocks per member):
+    // the value that gives the four wavefronts the shortest longest share -- rounds x (fixed work per batch ~ four members' + B)
+    std::vector<MfDesc> desc; desc.reserve(c->h_elim_desc.size()); uint32_t ecap = 0, imgmax = 0; int64_t nobs = 0;
+    const int bmax = mf_batch_max(), nw = mf_elim_waves();
+    for (int pass = 0; pass < 2; ++pass) for (size_t ei = 0; ei < c->h_elim_desc.size(); ++ei) { const ElimDesc& e0 = c->h_elim_desc[ei];
+        const int nd = (int)e0.nd; if (nd % dc || nd + 1 > 80 || nd / dc > 64 || nd / dc < 1 || e0.nmem > 128 || e0.nmem < 1) return NLLS_OK;
+        const int ncb = nd / dc, bcap = std::min(64 / ncb, bmax);
+        const bool tiny = (int)e0.nmem <= bcap; if (tiny != (pass == 1)) continue;
+        int B = bcap;
+        if (!tiny) { int64_t best = -1; for (int b2 = 1; b2 <= bcap; ++b2) { const int64_t nbt = ((int64_t)e0.nmem + b2 - 1) / b2, rounds = (nbt + nw - 1) / nw, cost = rounds * (4 + b2); if (best < 0 || cost <= best) { best = cost; B = b2; } } }
+        MfDesc e{e0.v0, e0.nmem, e0.nd, e0.rc_off, e0.eb0, (uint32_t)nobs, (uint32_t)B, c->h_slab_off[ei]};
+        imgmax = std::max<uint32_t>(imgmax, (uint32_t)(ncb * (ncb + 1) / 2 * dc * dc + nd + 4));
+        const int TR = (nd + 1 + 15) / 16; ecap = std::max<uint32_t>(ecap, (uint32_t)(B * dp * 16 * TR));
         for (uint32_t m = 0; m < e.nmem; ++m) { const uint32_t v = e.v0 + m; const int64_t row = c->h_erow[v];
             const int64_t q0 = c->h_eptr[v], q1 = c->h_eptr[v + 1];
             if (q1 - q0 != ncb || pos[row + 1] - pos[row] != ncb) return NLLS_OK;
@@ -641,11 +650,12 @@ int build_mf(nlls_ctx* c, int32_t ngroups, const nlls_cost_group* groups, const 
                 if (found < 0) return NLLS_OK;
                 for (int q2 = 0; q2 < d.ndata; ++q2) hd.push_back(in.data[found * d.ndata + q2]);
                 hv.push_back(c->var_off[in.varind[found * 2] - 1]); hv.push_back(c->var_off[in.varind[found * 2 + 1] - 1]); ++nobs; } }
+        desc.push_back(e);
+        if (pass == 0) c->mf_nbig = (int64_t)desc.size();
     }
     if (nobs != in.ncost) return NLLS_OK;
-    HIPCHK(G.mf_data.upload(hd)); HIPCHK(G.mf_voff.upload(hv)); HIPCHK(c->d_elim_desc.upload(desc)); HIPCHK(c->mf_q.alloc((size_t)c->n_fast_groups));
-    c->h_elim_desc = desc;
-    c->mf_ecap = ecap; c->mf_wsz = mf_wave_doubles(ecap, dp); c->mf_lds = mf_lds_bytes(ecap, dp);
+    HIPCHK(G.mf_data.upload(hd)); HIPCHK(G.mf_voff.upload(hv)); HIPCHK(c->d_mf_desc.upload(desc)); HIPCHK(c->mf_q.alloc((size_t)c->n_fast_groups));
+    c->mf_ecap = ecap; c->mf_wsz = std::max(mf_wave_doubles(ecap, dp), (imgmax + 1) & ~1u); c->mf_lds = sizeof(double) * (size_t)c->mf_wsz * mf_elim_waves();      // (a wavefront's region also stages its supernode's share in slab layout)
     if (c->mf_lds > (size_t)150 * 1024) return NLLS_OK;
     c->mf_ok = true; c->mf_group = 0; c->mf_ps = ps;
     return NLLS_OK;
@@ -745,7 +755,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
     c->n_fast_groups = 0; c->n_slow_groups = 0; c->n_fast_members = 0; c->n_fast_narrow = 0; c->n_fast_n60 = 0; c->fast_dv = 0;
     c->h_elim_desc.clear(); c->h_erow.clear(); c->h_eptr.clear(); c->h_enbr_block.clear(); c->mf_ok = false; c->mf_step = false; c->mf_use = false;
     c->tE_valid = false; c->S_zeroed = false; c->status_known_zero = false; c->step_cached = false; c->bcr.release();
-    c->elim_slab = false; c->slab.release(); c->d_slab_off.release(); c->d_slab_groups.release(); c->d_gjobs.release(); c->d_gcons.release(); c->n_gjobs = 0;
+    c->elim_slab = false; c->gather_ready = false; c->h_slab_off.clear(); c->tiles_zeroed = false; c->slab.release(); c->d_slab_off.release(); c->d_slab_groups.release(); c->d_gjobs.release(); c->d_gcons.release(); c->n_gjobs = 0;
     // (the solve also dispatches on the SIZE of these lists: an upload without elimination must not inherit them)
     c->d_elim_ptr.release(); c->d_elim_nbr.release(); c->d_elim_diag.release(); c->d_elim_boff.release(); c->d_elim_dim.release(); c->d_elim_group.release();
     c->d_fast_groups.release(); c->d_elim_desc.release(); c->d_elim_rc.release(); c->d_slow_groups.release(); c->d_slow_blocks.release(); c->d_fast_members.release(); c->Cinv.release(); c->tE.release();
@@ -1109,7 +1119,11 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         }
         // ---- slab + gather assembly (NLLS_FLAG_DETERMINISTIC: no atomics, x is bit-reproducible; 15 % slower than the atomic flush at
         //      config 4): single rank, every eliminated block on the fast path
-        if (c->bcr.ready && c->nranks == 1 && (flags & NLLS_FLAG_DETERMINISTIC) && c->n_fast_groups > 0 && c->n_slow_groups == 0 && I0.is_sparse) {
+        // (round 6: the matrix-free LM trial assembles the tiles this way BY DEFAULT -- its supernodes leave their shares in the slabs with plain stores, the memory side took
+        //  45 us per trial for the 4.1 M atomics of the flush at BASELINE config 4 -- so the index is built whenever that trial may apply; elim_slab, i.e. the MATERIALISED
+        //  elimination through slabs, stays the flag's)
+        c->gather_ready = false; c->h_slab_off.clear();
+        if (c->bcr.ready && c->nranks == 1 && ((flags & NLLS_FLAG_DETERMINISTIC) || !(flags & NLLS_FLAG_MATERIALIZE)) && c->n_fast_groups > 0 && c->n_slow_groups == 0 && I0.is_sparse) {
             struct Key { uint32_t r, c; bool operator<(const Key& o) const { return r != o.r ? r < o.r : c < o.c; } };
             std::map<Key, std::vector<GatherCon>> pairs; std::map<uint32_t, std::vector<GatherCon>> rhs;
             std::vector<uint32_t> slab_off, slab_groups; uint64_t off = 0; bool ok = (uint64_t)I0.nnz_data < ((uint64_t)1 << 32) && (uint64_t)I0.ndof < ((uint64_t)1 << 32);
@@ -1173,7 +1187,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 { GatherJob j{}; j.copy_off = -1; j.kind = 2; jobs.push_back(j); }
                 if (hipSuccess != c->slab.alloc((size_t)std::max<uint64_t>(off, 4)) || hipSuccess != c->d_slab_off.upload(slab_off) || hipSuccess != c->d_slab_groups.upload(slab_groups) || hipSuccess != c->d_gjobs.upload(jobs) ||
                     hipSuccess != c->d_gcons.upload(cons)) return fail(c, NLLS_ERR_HIP, "gather index upload");
-                c->n_gjobs = (int64_t)jobs.size(); c->elim_slab = true;
+                c->n_gjobs = (int64_t)jobs.size(); c->elim_slab = (flags & NLLS_FLAG_DETERMINISTIC) != 0; c->gather_ready = true; c->h_slab_off = slab_off;
             }
         }
     } else {
