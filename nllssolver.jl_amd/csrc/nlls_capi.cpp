@@ -266,7 +266,10 @@ int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
         TRY(fetch_scalars(ctx, 0, 1)); *cost_out = ctx->h_scalars[0];
         return NLLS_OK;
     }
-    TRY(enqueue_sweep_gradhess(ctx, cost_out != nullptr));
+    // (where the matrix-free trial applies the cost is ITS sum of the blocks -- the one nlls_sweep_cost and every trial report: one fixed sum, bit for bit the same everywhere)
+    const bool mfcost = cost_out && mf_trial(ctx, NLLS_VARS_CURRENT);
+    TRY(enqueue_sweep_gradhess(ctx, cost_out != nullptr && !mfcost));
+    if (mfcost) TRY(enqueue_mf_sweep_cost(ctx, NLLS_VARS_CURRENT));
     ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; ctx->reduced_summed = true;
     if (!cost_out) return NLLS_OK;
     TRY(fetch_scalars(ctx, 0, 1));
@@ -275,6 +278,8 @@ int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
 }
 int nlls_sweep_cost(nlls_ctx* ctx, int32_t which, double* cost_out) {
     NEED_READY(); if (!valid_set(which)) return NLLS_ERR_INVALID_ARG;
+    // (where the matrix-free trial applies, every cost is ONE fixed sum -- the trial's: cost(problem) == result.bestcost bit for bit)
+    if (mf_trial(ctx, NLLS_VARS_CURRENT)) TRY(enqueue_mf_sweep_cost(ctx, which)); else
     TRY(enqueue_sweep_cost(ctx, which));
     TRY(comm_reduce(ctx, ctx->scalars.p, 1, NLLS_REDUCE_SUM));       // (collective mode: the ranks' partial costs)
     TRY(fetch_scalars(ctx, 0, 1));
@@ -372,9 +377,12 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     { const int rc = enqueue_solve(ctx); ctx->trial_to = ctx->trial_from = -1; ctx->mf_use = false; TRY(rc); }
     const bool la = ctx->spec_on && ctx->spec_armed && ctx->nranks == 1 && ctx->info.is_sparse && from == NLLS_VARS_CURRENT;
     ctx->tail_zero_for_lookahead = la; ctx->heavy_rows_zeroed = false;
-    { const int rc = enqueue_lm_trial_tail(ctx, to, from); ctx->tail_zero_for_lookahead = false; TRY(rc); }     // step statistics + quadratic form (+ retraction) and the cost sweep, one finishing launch
+    // (matrix-free trial with a look-ahead sweep behind it: the trial's finishing workgroup rides in that sweep's launch -- nlls_sweep.hip -- unless rows have to be zeroed in between)
+    ctx->mf_fin_defer = mf && la && ctx->nzero == 0; ctx->mf_fin_pending = false;
+    { const int rc = enqueue_lm_trial_tail(ctx, to, from); ctx->tail_zero_for_lookahead = false; ctx->mf_fin_defer = false; TRY(rc); }     // step statistics + quadratic form (+ retraction) and the cost sweep, one finishing launch
     // the look-ahead sweep: the gradient sweep of the trial point, enqueued behind the finishing launch (the host reads the trial's scalars while it runs)
     if (la) { const int rc = enqueue_sweep_gradhess(ctx, false, to, mf ? 1 : 0); ctx->heavy_rows_zeroed = false; TRY(rc); ctx->spec_pending = true; ctx->spec_stale = false; }
+    if (ctx->mf_fin_pending) TRY(enqueue_mf_trial_finish_now(ctx));      // (no launch of the sweep took the finishing workgroup along)
     }
     // (sparse systems: the finishing launch has written the scalars -- in [10] the factorisation status -- to the pinned host mirror itself)
     if ((!ctx->info.is_sparse && !ctx->tiny_dense) || !ctx->h_scalars_dev) {

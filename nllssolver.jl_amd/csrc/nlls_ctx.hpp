@@ -261,8 +261,9 @@ struct nlls_ctx {
     // nlls_set_option(NLLS_OPT_MATERIALIZE): the round-5 path.
     bool mf_ok = false, mf_on = true; int mf_group = -1, mf_ps = -1;     // eligibility (build_mf), run-time switch, the cost group and its eliminated slot
     int grad_level = 0;                      // what A and b hold of the linearisation at grad_phys: 0 nothing, 1 the reduced rows, 2 everything
-    bool mf_step = false;                    // the last solve was matrix-free: the quadratic form's share of the eliminated rows is in mf_q
-    nlls::DevBuf<double> mf_q; nlls::DevBuf<nlls::MfDesc> d_mf_desc; int64_t mf_nbig = 0; size_t mf_lds = 0; uint32_t mf_ecap = 0, mf_wsz = 0; bool mf_use = false;    // per-supernode partials of the step's quadratic form; dynamic LDS of the two launches
+    bool mf_step = false;                    // the last solve was matrix-free: its back-substitution launch has left the trial's cost and the step statistics as rows of partials in mf_q (mf_rows of them)
+    nlls::DevBuf<double> mf_q; int mf_rows = 0; bool mf_fin_defer = false, mf_fin_pending = false;   // (the finishing workgroup may ride in the look-ahead sweep's launch)
+    nlls::DevBuf<nlls::MfDesc> d_mf_desc; int64_t mf_nbig = 0; size_t mf_lds = 0; uint32_t mf_ecap = 0, mf_wsz = 0; bool mf_use = false;    // per-supernode partials of the step's quadratic form; dynamic LDS of the two launches
     int64_t mf_trials = 0, mf_reduced_sweeps = 0, full_sweeps = 0;   // diagnostics (nlls_get_solve_stats [23..25])
     std::vector<int64_t> h_erow; std::vector<int64_t> h_eptr; std::vector<int64_t> h_enbr_block; std::vector<nlls::ElimDesc> h_elim_desc; std::vector<uint32_t> h_fast_voff;   // host copies kept between build_schur and build_mf
 

@@ -501,6 +501,24 @@ NLLS_DEV double block_cost(const double* __restrict__ vars, const uint32_t* voff
     else return 0.5 * robustify_fixed(rk, s);
 }
 
+// ... the same from variable storage already in registers (one row per getvars() slot, kernel included): the matrix-free trial's back-substitution forms the trial
+// point's variables itself and takes their cost in the same pass
+template <int KIND>
+NLLS_DEV double block_cost_st(const double (*st)[MAXST], const double* data, const RobustSpec& rk) {
+    using R = Res<KIND>; using I = ResInfo<KIND>;
+    double sv[I::NS > 0 ? I::NS : 1][MAXST];
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+        (var_load<R::SK[S + R::ADAPT], R::SD[S + R::ADAPT], double>(st[S + R::ADAPT], -1, sv[S]), ...);
+    }(std::make_integer_sequence<int, I::NS>{});
+    double r[R::M]; R::template eval<double>(data, sv, r);
+    if constexpr (is_cost_kind<KIND>) return r[0];
+    double s = 0;
+#pragma unroll
+    for (int m = 0; m < R::M; ++m) s += r[m] * r[m];
+    if constexpr (R::ADAPT) return 0.5 * cg_robustify(st[0], s);
+    else return 0.5 * robustify_fixed(rk, s);
+}
+
 // Everything the accumulate kernels need from one block, with ALL variables treated as free
 // (the reference's varflags specialisations only drop rows/columns of g and H; the kept entries
 // are identical -- src/residual.jl:57-111).

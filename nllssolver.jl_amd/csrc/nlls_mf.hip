@@ -18,23 +18,9 @@
 
 #include "nlls_wave.hpp"
 #include "nlls_slayout.hpp"
+#include "nlls_mf.hpp"
 
 namespace nlls {
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-constexpr int MF_NW = 4;            // wavefronts per workgroup of the back-substitution
-constexpr int MF_ENW = 2;           // wavefronts per supernode of the elimination, each taking every other batch of members (four: two workgroups per CU, and a workgroup's atomic flush -- its slot
-                                    // held until the memory side has taken 1891 atomics -- left the CU half idle: 132 us; two: four workgroups per CU, every large supernode of BASELINE config 4 resident at once)
-constexpr int MF_BMAX = 8;          // members per batch at most (one lane per cost block: 64 / blocks per member, capped)
-constexpr int MF_TRMAX = 5;         // tile rows of [E | b]: nd + 1 <= 80
-constexpr int MF_SLOTS = 40;        // members one wavefront handles at most (128 members per supernode)
-// one supernode of the matrix-free trial, in launch order (nlls_ctx::d_mf_desc): everything a workgroup needs to start on it comes with one uniform load
-// (struct MfDesc: nlls_ctx.hpp -- v0, nmem, nd, rc_off, eb0, obs0, B = members per batch)
-
-// a wavefront's own LDS traffic: writes of some lanes, then reads by others.  The LDS pipe serves one wavefront's instructions in order; the compiler must not
-// move them across this point, and the counter wait covers the returned data
-NLLS_DEV void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
-NLLS_DEV double mf_rcp(double d) { const double r = __builtin_amdgcn_rcp(d); const double e = fma(-d, r, 1.0); return fma(r, fma(e, e, e), r); }   // v_rcp_f64 (2^-24) + one cubic step: 1.1e-16
 
 struct MfArgs {
     const double* vars; const double* odata; const uint32_t* ovoff;      // the blocks in elimination order (Group::mf_data / mf_voff)
@@ -286,126 +272,6 @@ __global__ __launch_bounds__(64 * MF_ENW) __attribute__((amdgpu_waves_per_eu(2, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
-// back-substitution: x_v = -(C_v + lambda I)^-1 (b_v - E_v s), s = the reduced system's solution (x_R = -s), E_v s = sum over the member's blocks of H_pc s_c
-// ---------------------------------------------------------------------------------------------------------------------------------------------------
-struct MfBackArgs {
-    const double* vars; const double* odata; const uint32_t* ovoff; RobustSpec rk;
-    const MfDesc* desc; const uint32_t* rcflat; const double* Cinv; const double* b; const double* xr; double* x; double* q;
-    uint32_t ngroups; const uint32_t* red_boff; int nred, write_red; double* Szero; int64_t nzero; uint32_t nextra; BsfRetract rt;
-};
-template <int KIND, int PS>
-__global__ __launch_bounds__(64 * MF_NW) void mf_backsub_kernel(MfBackArgs a) {
-    using R = Res<KIND>; using I = ResInfo<KIND>;
-    constexpr int CS = 1 - PS, DP = I::dof(PS), DC = I::dof(CS);
-    __shared__ double red[MF_NW][64 * DP], xpw[MF_NW][MF_BMAX * DP], stage[MF_NW][MF_SLOTS][2 * DP]; __shared__ uint32_t stpv[MF_NW][MF_SLOTS]; __shared__ double qred[MF_NW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (blockIdx.x >= a.ngroups) { backsub_rest_roles((blockIdx.x - a.ngroups) * MF_NW + wave, a.nextra, lane, a.xr, a.x, a.red_boff, a.nred, a.write_red, a.Szero, a.nzero, a.rt); return; }
-    const MfDesc d = a.desc[blockIdx.x];
-    const int nd = (int)d.nd, nmem = (int)d.nmem, ncb = nd / DC;
-    const int B = (int)d.B;
-    const int ml = lane / ncb, j = lane - ml * ncb; const bool lane_in = ml < B;
-    const double* __restrict__ vars = a.vars; const double* __restrict__ odata = a.odata; const uint32_t* __restrict__ ovoff = a.ovoff; const RobustSpec rk = a.rk;
-    const uint32_t obs0 = d.obs0, v0 = d.v0, eb0 = d.eb0;
-    // the reduced solution under this lane's column block: the same for every batch
-    double sc[DC];
-    { const int jj = lane_in ? j : 0;
-#pragma unroll
-      for (int c2 = 0; c2 < DC; ++c2) sc[c2] = a.xr[a.rcflat[d.rc_off + DC * jj + c2]]; }
-    using St = double[2][MAXST];
-    struct Rec { double dd[R::NDATA]; uint32_t vo[2]; };
-    auto load_rec = [&](int mb, Rec& r) {
-        const bool on = lane_in && mb + ml < nmem;
-        const size_t e = (size_t)obs0 + (on ? (size_t)(mb + ml) * ncb + j : 0);
-#pragma unroll
-        for (int q = 0; q < R::NDATA; ++q) r.dd[q] = odata[e * R::NDATA + q];
-        r.vo[0] = ovoff[e * 2]; r.vo[1] = ovoff[e * 2 + 1];
-    };
-    Rec r0, r1; St s0, s1;
-    load_rec(wave * B, r0);
-    BlockGH<KIND>::load(vars, r0.vo, s0);
-    double qacc = 0.0; int slot0 = 0;
-#pragma unroll 1
-    for (int mb = wave * B; mb < nmem; mb += MF_NW * B, slot0 += B) {
-        const int nlive = min(B, nmem - mb);
-        const bool active = lane_in && ml < nlive, head = active && j == 0;
-        load_rec(mb + MF_NW * B, r1);
-        // the member's right-hand side and inverse block, by its first lane: requested now, used behind the sum
-        double bv[DP], ci[DP * DP];
-        { const size_t m = (size_t)(mb + (head ? ml : 0));
-#pragma unroll
-          for (int k = 0; k < DP; ++k) bv[k] = a.b[eb0 + m * DP + k];
-#pragma unroll
-          for (int q = 0; q < DP * DP; ++q) ci[q] = a.Cinv[((size_t)v0 + m) * (DP * DP) + q]; }
-        BlockGH<KIND> G; G.compute_st(s0, r0.dd, rk, false);
-        double ts[DP];
-#pragma unroll
-        for (int k = 0; k < DP; ++k) { double t = 0.0;
-#pragma unroll
-            for (int c2 = 0; c2 < DC; ++c2) t = fma(h_elem<KIND, PS, CS>(G, k, c2), sc[c2], t);
-            ts[k] = t; }
-        if (active) {
-#pragma unroll
-            for (int k = 0; k < DP; ++k) red[wave][lane * DP + k] = ts[k]; }
-        BlockGH<KIND>::load(vars, r1.vo, s1);
-        wave_lds_sync();
-        if (head) {
-            double accv[DP];
-#pragma unroll
-            for (int k = 0; k < DP; ++k) accv[k] = 0.0;
-            for (int t = 0; t < ncb; ++t)
-#pragma unroll
-                for (int k = 0; k < DP; ++k) accv[k] += red[wave][(lane + t) * DP + k];
-            double xp[DP];
-#pragma unroll
-            for (int i = 0; i < DP; ++i) { double t = 0.0;
-#pragma unroll
-                for (int k = 0; k < DP; ++k) t = fma(ci[i + DP * k], bv[k] - accv[k], t);
-                xp[i] = -t; }
-#pragma unroll
-            for (int k = 0; k < DP; ++k) { xpw[wave][ml * DP + k] = xp[k]; stage[wave][slot0 + ml][k] = xp[k]; stage[wave][slot0 + ml][DP + k] = s0[PS][k] + xp[k]; }   // the retraction of a Euclidean block (src/variable.jl:5)
-            stpv[wave][slot0 + ml] = r0.vo[PS];
-        }
-        wave_lds_sync();
-        if (active) {
-            // the member rows' share of x'Hx:  2 x_v'(E_v x_R) + x_v' C_v x_v  with  E_v x_R = -E_v s  (what quadform_points_body takes from A.data and tE)
-            double xp[DP];
-#pragma unroll
-            for (int k = 0; k < DP; ++k) xp[k] = xpw[wave][ml * DP + k];
-            double qv = 0.0;
-#pragma unroll
-            for (int k = 0; k < DP; ++k) { qv = fma(-2.0 * xp[k], ts[k], qv);
-#pragma unroll
-                for (int l2 = 0; l2 < DP; ++l2) qv = fma(xp[k] * h_elem<KIND, PS, PS>(G, k, l2), xp[l2], qv); }
-            qacc += qv;
-        }
-        wave_lds_sync();
-        r0 = r1;
-#pragma unroll
-        for (int q = 0; q < MAXST; ++q) { s0[0][q] = s1[0][q]; s0[1][q] = s1[1][q]; }
-    }
-    // results leave behind the loop: a store between the loads would make every wait a full vmcnt(0) (finding 3)
-    {
-        const int nb_all = (nmem + B - 1) / B;                        // batches of the supernode; this wavefront took wave, wave + 4, ...
-        for (int sl = lane; sl < MF_SLOTS; sl += 64) {
-            const int bi = sl / B, mi = sl - bi * B; const int batch = wave + MF_NW * bi; const int m = batch * B + mi;
-            if (batch >= nb_all || m >= nmem) continue;
-#pragma unroll
-            for (int k = 0; k < DP; ++k) a.x[eb0 + (size_t)m * DP + k] = stage[wave][sl][k];
-            if (a.rt.on) { const uint32_t pv = stpv[wave][sl];
-#pragma unroll
-                for (int k = 0; k < DP; ++k) a.rt.vto[pv + k] = stage[wave][sl][DP + k]; }
-        }
-    }
-    qacc = wave_sum_dpp63(qacc);
-    if (lane == 63) qred[wave] = qacc;
-    __syncthreads();
-    if (tid == 0) { double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < MF_NW; ++w) t += qred[w];
-        a.q[blockIdx.x] = t; }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
 static int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(what) + ": " + hipGetErrorString(e); return NLLS_ERR_HIP; }
@@ -424,19 +290,6 @@ static int launch_mf_elim(nlls_ctx* c, const Group& G) {
         return NLLS_OK;
     } else { c->err = "matrix-free trial: kind not eligible"; return NLLS_ERR_UNSUPPORTED; }
 }
-template <int KIND, int PS>
-static int launch_mf_backsub(nlls_ctx* c, const Group& G, const BsfRetract& rt, int write_red, double* zptr, int64_t zcount, unsigned nextra, unsigned nrestwg) {
-    if constexpr (Res<KIND>::NDEPS == 2 && Res<KIND>::ADAPT == 0 && !is_cost_kind<KIND> && ResInfo<KIND>::dof(PS < 2 ? PS : 0) <= 3) {
-        MfBackArgs a{}; a.vars = vars_ptr(c, NLLS_VARS_CURRENT); a.odata = G.mf_data.p; a.ovoff = G.mf_voff.p; a.rk = G.rk; a.desc = c->d_mf_desc.p; a.rcflat = c->d_elim_rc.p;
-        a.Cinv = c->Cinv.p; a.b = c->b.p; a.xr = c->s_ptr(); a.x = c->x.p; a.q = c->mf_q.p; a.ngroups = (uint32_t)c->n_fast_groups; a.red_boff = c->d_red_boff.p; a.nred = (int)c->nred; a.write_red = write_red;
-        a.Szero = zptr; a.nzero = zcount; a.nextra = nextra; a.rt = rt;
-        const unsigned rest = (nextra + nrestwg + MF_NW - 1) / MF_NW;
-        hipLaunchKernelGGL((mf_backsub_kernel<KIND, PS>), dim3((unsigned)c->n_fast_groups + rest), dim3(64 * MF_NW), 0, c->stream, a);
-        HIPCHK(hipGetLastError());
-        return NLLS_OK;
-    } else { c->err = "matrix-free trial: kind not eligible"; return NLLS_ERR_UNSUPPORTED; }
-}
-
 // the assembly of the reduced system of a matrix-free trial: the supernodes' launch (their shares into the slabs), then the gather (schur_gather_kernel: the shares of every
 // block pair summed in a fixed order + the reduced-reduced blocks + lambda, straight into the block cyclic reduction's tiles)
 int enqueue_mf_solve_local(nlls_ctx* c) {
@@ -452,15 +305,6 @@ int enqueue_mf_solve_local(nlls_ctx* c) {
     }
     if (rc != NLLS_OK) return rc;
     return enqueue_gather(c);
-}
-int enqueue_mf_backsub(nlls_ctx* c, const BsfRetract& rt, int write_red, double* zptr, int64_t zcount, unsigned nextra, unsigned nrestwg) {
-    const Group& G = c->groups[c->mf_group];
-    switch (G.res_kind) {
-#define X(K) case K: return c->mf_ps == 0 ? launch_mf_backsub<K, 0>(c, G, rt, write_red, zptr, zcount, nextra, nrestwg) : launch_mf_backsub<K, 1>(c, G, rt, write_red, zptr, zcount, nextra, nrestwg);
-        NLLS_FOR_EACH_RES(X)
-#undef X
-    }
-    return NLLS_ERR_UNSUPPORTED;
 }
 // (nlls_structure.cpp sizes the launches' LDS with this)
 uint32_t mf_wave_doubles(uint32_t ecap, int dp) { return mf_wave_lds(ecap, dp); }

@@ -16,7 +16,7 @@ constexpr int QF_COLS = 8;      // threads per block of the quadratic form (one 
 // One thread per (block, column): the column's entries and the entries of v it multiplies are requested at once (a loop over a run-time number of
 // rows waits for every load before it issues the next: 36 dependent round trips for a 6 x 6 block, the longest chain of the whole launch).
 __device__ __forceinline__ void quadform_blocks_body(const double* __restrict__ A, const SchurCopy* __restrict__ blk, int64_t nblk,
-                                                     const double* __restrict__ v, const uint8_t* __restrict__ mask, double* __restrict__ partials, int bid, int nb) {
+                                                     const double* __restrict__ v, const uint8_t* __restrict__ mask, double* __restrict__ partials, int bid, int nb, double* __restrict__ out_one = nullptr) {
     __shared__ double red[4];
     constexpr int MB = QF_COLS;
     double acc = 0;
@@ -43,7 +43,7 @@ __device__ __forceinline__ void quadform_blocks_body(const double* __restrict__ 
     acc = post_wsum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partials[bid] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) { const double t = red[0] + red[1] + red[2] + red[3]; if (out_one) *out_one = t; else partials[bid] = t; }
 }
 // rows of fast-path members, for the step x of the last solve: x' A x restricted to row v is
 //   2 x_v' (E_v x_R) + x_v' C_v x_v,   E_v x_R = -E_v s  -- and E_v s is what schur_backsub_fast_kernel left in tE

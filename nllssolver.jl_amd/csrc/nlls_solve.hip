@@ -1439,10 +1439,9 @@ __global__ __launch_bounds__(256) void post_solve_kernel(PostSolveArgs a) { post
 // out[1] = max|x| (NaN if any entry is), out[2] = x'x, out[4] = x'(H + lambda I)x, out[5] = g'x, out[8] = x'Hx, out[9] = (masked) x'x,
 // out[10] = factorisation status
 NLLS_DEV void post_solve_finish_body(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
-                                     double lambda, double* __restrict__ out, const int* __restrict__ status, double (*red)[4], const double* __restrict__ mfq = nullptr, int nmfq = 0) {
+                                     double lambda, double* __restrict__ out, const int* __restrict__ status, double (*red)[4]) {
     double a = 0, m = 0, nan = 0, ss = 0, vv = 0, bv = 0;
     for (int i = threadIdx.x; i < np; i += 256) a += partials[i];
-    for (int i = threadIdx.x; i < nmfq; i += 256) a += mfq[i];      // (matrix-free step: the eliminated rows' share of x'Hx, one partial per supernode)
     for (int i = threadIdx.x; i < np2; i += 256) { m = fmax(m, part2[5 * i]); nan = fmax(nan, part2[5 * i + 1]); ss += part2[5 * i + 2]; vv += part2[5 * i + 3]; bv += part2[5 * i + 4]; }
     a = wsum(a); ss = wsum(ss); vv = wsum(vv); bv = wsum(bv);
 #pragma unroll
@@ -1459,9 +1458,9 @@ NLLS_DEV void post_solve_finish_body(const double* __restrict__ partials, int np
     }
 }
 __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __restrict__ partials, int np, const double* __restrict__ part2, int np2,
-                                                                double lambda, double* __restrict__ out, const int* __restrict__ status, const double* __restrict__ mfq, int nmfq) {
+                                                                double lambda, double* __restrict__ out, const int* __restrict__ status) {
     __shared__ double red[6][4];
-    post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red, mfq, nmfq);
+    post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red);
 }
 // the two one-workgroup reductions that end an LM trial in ONE launch: workgroup 0 sums the cost partials (the same order as
 // reduce_partials_kernel: the totals are bit-identical), workgroup 1 finishes the step statistics
@@ -1470,7 +1469,7 @@ __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __
 struct ZeroRanges { double* A; const int64_t* off; const uint32_t* len; double* b; const uint32_t* boff; const uint32_t* blen; int n; };
 __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restrict__ cpart, int64_t ncp, const double* __restrict__ partials, int np,
                                                            const double* __restrict__ part2, int np2, double lambda, double* __restrict__ out, const int* __restrict__ status,
-                                                           double* __restrict__ host_out, double seq, ZeroRanges zr, const double* __restrict__ mfq, int nmfq) {
+                                                           double* __restrict__ host_out, double seq, ZeroRanges zr) {
     __shared__ double red[6][4];
     if (blockIdx.x >= 2) {
         const int r = (int)blockIdx.x - 2;
@@ -1481,7 +1480,7 @@ __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restr
         return;
     }
     if (blockIdx.x == 0) reduce_partials_body(cpart, ncp, out, &red[0][0]);
-    else post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red, mfq, nmfq);
+    else post_solve_finish_body(partials, np, part2, np2, lambda, out, status, red);
     // the scalars also go straight to the pinned host mirror (device-visible, coherent host memory): no copy command behind this launch.
     // Each workgroup then publishes the trial's sequence number: the host spins on the two numbers instead of sleeping in a stream
     // synchronisation (its wake-up costs more than the kernels of this size it waits for).
@@ -1629,8 +1628,7 @@ int enqueue_quadform(nlls_ctx* c, const double* d_vec, int out_slot) {
 
 // the arguments of the step-statistics roles (nlls_post.hpp) for the step of the last solve; retract_to >= 0: with the retraction role
 PostSolveArgs post_solve_args(nlls_ctx* c, int retract_to, int retract_from) {
-    const bool mf = c->mf_step;                                 // matrix-free step: the eliminated rows' share of x'Hx is in mf_q (mf_backsub_kernel), summed by the finishing launch
-    const bool reuse = mf || (c->tE_valid && c->n_fast_members > 0);
+    const bool reuse = c->tE_valid && c->n_fast_members > 0;
     PostSolveArgs a{};
     const bool lazy = c->nranks > 1 && !c->reduced_summed;      // the reduced rows of A.data and b hold this rank's share only: they count on every rank
     a.A = c->A.p; a.blk = reuse ? (lazy ? c->d_blk_slow_lazy.p : c->d_blk_slow.p) : c->d_blk.p; a.nblk = reuse ? (lazy ? c->nblk_slow_lazy : c->nblk_slow) : c->nblk;
@@ -1638,7 +1636,7 @@ PostSolveArgs post_solve_args(nlls_ctx* c, int retract_to, int retract_from) {
     a.ediag = c->d_elim_diag.p; a.eboff = c->d_elim_boff.p; a.members = c->n_fast_members == (int64_t)c->d_elim_diag.n ? (const uint32_t*)nullptr : c->d_fast_members.p; a.nm = c->n_fast_members; a.tE = c->tE.p;
     a.x = c->x.p; a.b = c->b.p; a.dofmask = c->nranks > 1 ? c->d_dof_mask.p : (const double*)nullptr; a.dofmask_b = lazy ? c->d_dof_mask_lazy.p : (const double*)nullptr; a.ndof = c->info.ndof;
     a.np = (int)std::max<int64_t>(1, std::min<int64_t>((a.nblk * QF_COLS + 255) / 256, 768));
-    a.np3 = (reuse && !mf) ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
+    a.np3 = reuse ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
     a.np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 512));      // (5 partials each, behind the quadratic form's at 1024: ends at 3584 < TRIAL_COST_POFS)
     a.partials = c->partials.p; a.part2 = c->partials.p + 1024;
     a.nretract = 0;
@@ -1665,13 +1663,14 @@ int enqueue_post_solve(nlls_ctx* c, int retract_to, int retract_from, bool finis
     if (c->fast_dv == 3) hipLaunchKernelGGL((post_solve_kernel<3>), grid, dim3(256), 0, c->stream, a);
     else if (c->fast_dv == 2) hipLaunchKernelGGL((post_solve_kernel<2>), grid, dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((post_solve_kernel<1>), grid, dim3(256), 0, c->stream, a);
-    if (finish) hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p, c->d_status.p,
-                                   c->mf_step ? c->mf_q.p : (const double*)nullptr, c->mf_step ? (int)c->n_fast_groups : 0);
+    if (finish) hipLaunchKernelGGL(post_solve_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->partials.p, a.np + a.np3, a.part2, a.np2, c->lambda, c->scalars.p, c->d_status.p);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
 // what follows the solve in an LM trial (src/iterators.jl:155-163)
 int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
+    // (matrix-free trial: the back-substitution launch has retracted, taken the trial point's cost and left the step statistics -- one finishing launch sums its rows)
+    if (c->mf_step) { c->retract_done = false; return enqueue_mf_trial_finish(c); }
     if (!c->info.is_sparse) { int rc = enqueue_post_solve(c, to, from); if (rc != NLLS_OK) return rc; return enqueue_sweep_cost(c, to); }
     int rc; int64_t ncp = 0;
     if (c->retract_done) {
@@ -1688,7 +1687,7 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
     ZeroRanges zr{};
     if (c->tail_zero_for_lookahead && c->nzero > 0) { zr = ZeroRanges{c->A.p, c->d_zero_off.p, c->d_zero_len.p, c->b.p, c->d_zero_b_off.p, c->d_zero_b_len.p, (int)c->nzero}; c->heavy_rows_zeroed = true; }
     hipLaunchKernelGGL(trial_finish_kernel, dim3(2 + (unsigned)zr.n), dim3(256), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->partials.p, c->ps_np, c->partials.p + 1024, c->ps_np2,
-                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq), zr, c->mf_step ? c->mf_q.p : (const double*)nullptr, c->mf_step ? (int)c->n_fast_groups : 0);
+                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq), zr);
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
@@ -1934,12 +1933,13 @@ int enqueue_solve_finish(nlls_ctx* c) {
         // an LM trial (nlls_lm_trial sets trial_to / trial_from): the retraction in this launch
         BsfRetract rt{}; unsigned nrestwg = 0;
         c->retract_done = false;
-        if (c->trial_to >= 0 && c->post_fuse && c->fast_all_euclid && c->nranks == 1 && nslow == 0 && c->info.is_sparse && c->n_fast_groups > 0 && c->info.nvar > 0) {
+        if (c->trial_to >= 0 && (c->post_fuse || c->mf_use) && c->fast_all_euclid && c->nranks == 1 && nslow == 0 && c->info.is_sparse && c->n_fast_groups > 0 && c->info.nvar > 0) {
             rt.on = 1; rt.nrest = (int)c->d_rest_var.n; rt.fast_voff = c->d_fast_voff.p; rt.rest_var = c->d_rest_var.p; rt.rest_red = c->d_rest_red.p;
             rt.vkind = c->d_var_kind.p; rt.vdim = c->d_var_dim.p; rt.voff = c->d_var_off.p; rt.vfrom = vars_ptr(c, c->trial_from); rt.vto = vars_ptr(c, c->trial_to);
             nrestwg = (unsigned)((rt.nrest + 63) / 64); c->retract_done = true;
         }
         if (c->mf_use) {
+            if (!rt.on) { c->err = "matrix-free trial without the fused retraction"; return NLLS_ERR_NOT_READY; }
             const int rc = enqueue_mf_backsub(c, rt, write_red, zptr, zcount, nextra, nrestwg); if (rc != NLLS_OK) return rc;
             c->tE_valid = false; c->mf_step = true; c->tiles_zeroed = true;
             return NLLS_OK;

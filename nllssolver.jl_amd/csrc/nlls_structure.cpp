@@ -654,7 +654,7 @@ int build_mf(nlls_ctx* c, int32_t ngroups, const nlls_cost_group* groups, const 
         if (pass == 0) c->mf_nbig = (int64_t)desc.size();
     }
     if (nobs != in.ncost) return NLLS_OK;
-    HIPCHK(G.mf_data.upload(hd)); HIPCHK(G.mf_voff.upload(hv)); HIPCHK(c->d_mf_desc.upload(desc)); HIPCHK(c->mf_q.alloc((size_t)c->n_fast_groups));
+    HIPCHK(G.mf_data.upload(hd)); HIPCHK(G.mf_voff.upload(hv)); HIPCHK(c->d_mf_desc.upload(desc)); HIPCHK(c->mf_q.alloc(mf_part_doubles(c->n_fast_groups, (160 + (int64_t)c->var_kind.size() / 64 + 8) / 4 + 2)));
     c->mf_ecap = ecap; c->mf_wsz = std::max(mf_wave_doubles(ecap, dp), (imgmax + 1) & ~1u); c->mf_lds = sizeof(double) * (size_t)c->mf_wsz * mf_elim_waves();      // (a wavefront's region also stages its supernode's share in slab layout)
     if (c->mf_lds > (size_t)150 * 1024) return NLLS_OK;
     c->mf_ok = true; c->mf_group = 0; c->mf_ps = ps;

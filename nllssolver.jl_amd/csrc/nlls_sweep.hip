@@ -22,6 +22,7 @@
 #include <hip/hip_ext.h>
 
 #include "nlls_wave.hpp"
+#include "nlls_mf.hpp"
 
 namespace nlls {
 
@@ -335,6 +336,14 @@ template <int KIND, int SLOT>
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void gh_heavy_kernel(GhArgs g, uint32_t heavy_img) {
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
     gh_heavy_body<KIND, SLOT, 3>(g, blockIdx.x, heavy_img, dyn_lds);
+}
+// the heavy tiles of a list with the finishing workgroup of a matrix-free LM trial in front (nlls_mf.hpp): the look-ahead sweep of the trial point's reduced rows carries the
+// trial's last reduction -- first in the grid, the host is waiting for it -- instead of standing behind a launch of its own
+template <int KIND, int SLOT>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void gh_heavy_fin_kernel(GhArgs g, uint32_t heavy_img, MfFin fin) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    if (blockIdx.x == 0) { __shared__ double red[6][4]; mf_finish_body(fin, red); return; }
+    gh_heavy_body<KIND, SLOT, 3>(g, blockIdx.x - 1, heavy_img, dyn_lds);
 }
 // One launch for a cost group whose entry lists split cleanly into one list of light tiles (bundle adjustment: the point
 // rows) and one of heavy tiles (the camera rows): the heavy workgroups come first in the grid and are compute / latency
@@ -730,7 +739,12 @@ static void launch_gh_slot(nlls_ctx* c, const Group& G, const double* vars, int6
                                gh_args<KIND>(c, G, E, vars, false, c->partials.p + pbase));
             pbase += E.nlight;
         }
-        if (E.nheavy > 0) {
+        if (E.nheavy > 0 && c->mf_fin_pending && c->nzero == 0) {      // (a matrix-free trial's finishing workgroup rides in front: nlls_lm_trial deferred it)
+            c->mf_fin_pending = false;
+            hipLaunchKernelGGL((gh_heavy_fin_kernel<KIND, SLOT>), dim3(1 + (unsigned)((E.nheavy + HROWS - 1) / HROWS)), dim3(TPB), gh_heavy_lds(E.heavy_lds) * sizeof(double), c->stream,
+                               gh_args<KIND>(c, G, E, vars, true, c->partials.p + pbase), E.heavy_lds, mf_fin_args(c));
+            pbase += E.nheavy;
+        } else if (E.nheavy > 0) {
             hipLaunchKernelGGL((gh_heavy_kernel<KIND, SLOT>), dim3((unsigned)((E.nheavy + HROWS - 1) / HROWS)), dim3(TPB), gh_heavy_lds(E.heavy_lds) * sizeof(double), c->stream,
                                gh_args<KIND>(c, G, E, vars, true, c->partials.p + pbase), E.heavy_lds);
             pbase += E.nheavy;
