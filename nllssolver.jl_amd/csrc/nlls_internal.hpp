@@ -101,7 +101,7 @@ int enqueue_mf_backsub(nlls_ctx* c, const BsfRetract& rt, int write_red, double*
 int enqueue_mf_trial_finish(nlls_ctx* c); int enqueue_mf_trial_finish_now(nlls_ctx* c); struct MfFin; MfFin mf_fin_args(nlls_ctx* c); size_t mf_part_doubles(int64_t nsupernodes, int64_t nrest_wg_max);
 int enqueue_mf_sweep_cost(nlls_ctx* c, int which);   // cost(vars[which]) summed as the matrix-free trial sums its cost
 int enqueue_gather(nlls_ctx* c);   // (nlls_solve.hip) schur_gather_kernel: slabs -> the block cyclic reduction's tiles
-uint32_t mf_wave_doubles(uint32_t ecap, int dp); int mf_batch_max(); int mf_elim_waves();
+uint32_t mf_wave_doubles(uint32_t ecap, int dp); int mf_batch_max(); int mf_elim_waves(); uint32_t mf_slab_doubles(int B, int dp, int tr);
 int build_mf(nlls_ctx* c, int32_t ngroups, const nlls_cost_group* groups, const uint64_t* bi, int32_t flags);   // (nlls_structure.cpp)
 
 // collectives (nlls_comm.cpp)

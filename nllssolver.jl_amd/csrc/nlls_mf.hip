@@ -32,14 +32,27 @@ struct MfArgs {
     uint32_t nbig, ntiny;                                                // supernodes of several batches (one workgroup each) come first, then those of ONE batch (one wavefront each)
     int dbg;
 };
-// per-wavefront LDS: [E slab: B x DP x LDC | red: 64 x NRED | sums: BMAX x NRED | cinv: BMAX x DP^2]; at least the supernode's share in slab layout (nlls_ctx::mf_wsz)
-NLLS_HD uint32_t mf_wave_lds(uint32_t ecap, int dp) { const uint32_t nred = (uint32_t)(dp * (dp + 1) / 2 + dp); return (ecap + 64 * nred + MF_BMAX * (nred + (uint32_t)(dp * dp)) + 1) & ~1u; }
+// per-wavefront LDS: [E slab: B x (DP + 1) x LDC | red: 64 x NRED | sums: BMAX x NRED | cinv: BMAX x (DP + 1) x DP]; at least the supernode's share in slab layout (nlls_ctx::mf_wsz).
+// Row DP of a member's slab and of its inverse block is ZERO: the lanes of the instruction's fourth k-slot (DP = 3) read their operands there like the others -- no selects in the member loop
+// (forty v_cndmask per member stood in front of its ten matrix-core instructions)
+// LDS strides of the slab: a row of [E | b] is 16 TR doubles + 8 (the four k-rows of a member then start 16 banks apart: the lanes of the four k-slots read their A operands
+// in ONE instruction -- with rows a multiple of 64 doubles apart all four hit the same banks: 117 instead of 83 us), a member (DP + 1) rows + 1 (the members' blocks a bank pair apart: the
+// evaluation's stores of one instruction come from up to eight members)
+#ifndef MF_ROWPAD
+#define MF_ROWPAD 8
+#endif
+#ifndef MF_MEMPAD
+#define MF_MEMPAD 2      /* even: with an ODD member stride the launch took 115 instead of 82 us at BASELINE config 4 */
+#endif
+NLLS_HD constexpr int mf_row_stride(int tr) { return 16 * tr + MF_ROWPAD; }
+NLLS_HD constexpr int mf_member_stride(int dp, int tr) { return (dp + 1) * mf_row_stride(tr) + MF_MEMPAD; }
+NLLS_HD uint32_t mf_wave_lds(uint32_t ecap, int dp) { const uint32_t nred = (uint32_t)(dp * (dp + 1) / 2 + dp); return (ecap + 64 * nred + MF_BMAX * (nred + (uint32_t)((dp + 1) * dp)) + 1) & ~1u; }
 
 // All batches first, first + stride, ... of one supernode, by ONE wavefront: evaluation, slab, (C + lambda I)^-1, and the members' rank-DP updates summed into acc.
 template <int KIND, int PS, int TRK>
 __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d, double* __restrict__ Ew, int first, int stride, double4_t (&acc)[TRK * (TRK + 1) / 2]) {
     using R = Res<KIND>; using I = ResInfo<KIND>;
-    constexpr int CS = 1 - PS, DP = I::dof(PS), DC = I::dof(CS), NSYM = DP * (DP + 1) / 2, NRED = NSYM + DP, LDC = 16 * TRK;
+    constexpr int CS = 1 - PS, DP = I::dof(PS), DC = I::dof(CS), NSYM = DP * (DP + 1) / 2, NRED = NSYM + DP, LDC = mf_row_stride(TRK), MST = mf_member_stride(DP, TRK);
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int nd = (int)d.nd, nmem = (int)d.nmem, ncb = nd / DC, B = (int)d.B;
     double* const red = Ew + a.ecap; double* const sums = red + 64 * NRED; double* const cinvw = sums + MF_BMAX * NRED;
@@ -48,7 +61,7 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
     const double* __restrict__ vars = a.vars; const double* __restrict__ odata = a.odata; const uint32_t* __restrict__ ovoff = a.ovoff;
     const RobustSpec rk = a.rk; const double lambda = a.lambda; const int dbg = a.dbg;
     const uint32_t obs0 = d.obs0, v0 = d.v0, eb0 = d.eb0;
-    const bool kslot = lk < DP; const int kk = kslot ? lk : 0;
+    const int kk = lk < DP ? lk : DP;                    // (lanes of a k-slot the block does not have: the zero row)
     using St = double[2][MAXST];
     struct Rec { double dd[R::NDATA]; uint32_t vo[2]; };
     auto load_rec = [&](int mb, Rec& r) {                             // unconditional, clamped (a predicated load becomes copy + vmcnt(0))
@@ -69,7 +82,7 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
         {
             BlockGH<KIND> G; G.compute_st(s0, r0.dd, rk, false);
             if (active && !(dbg & 4)) {
-                double* er = Ew + (size_t)(ml * DP) * LDC + DC * j;
+                double* er = Ew + (size_t)ml * MST + DC * j;
 #pragma unroll
                 for (int k = 0; k < DP; ++k)
 #pragma unroll
@@ -88,8 +101,11 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
         // C_v (lower triangle) and b_v: component q of member m2 summed over the member's lanes
         for (int idx = lane; idx < nlive * NRED; idx += 64) {
             const int m2 = idx / NRED, q = idx - m2 * NRED; const double* rr = red + (size_t)(m2 * ncb) * NRED + q;
-            double sum = 0.0; for (int t = 0; t < ncb; ++t) sum += rr[t * NRED];
-            sums[idx] = sum;
+            // (four values requested together: one wait per four, not one per value -- a run-time loop of single dependent LDS reads was a chain of ncb round trips)
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0; int t = 0;
+            for (; t + 4 <= ncb; t += 4) { const double v0 = rr[t * NRED], v1 = rr[(t + 1) * NRED], v2 = rr[(t + 2) * NRED], v3 = rr[(t + 3) * NRED]; s0 += v0; s1 += v1; s2 += v2; s3 += v3; }
+            for (; t < ncb; ++t) s0 += rr[t * NRED];
+            sums[idx] = (s0 + s1) + (s2 + s3);
         }
         wave_lds_sync();
         // (C_v + lambda I)^-1 by LDL' (the arithmetic of schur_cinv_kernel; the pivots' reciprocals by v_rcp_f64 + one cubic step), one lane per member
@@ -131,30 +147,28 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
 #pragma unroll
                     for (int k = r2 + 1; k < DP; ++k) t -= C[k + DP * r2] * y[k]; y[r2] = t; }
 #pragma unroll
-                for (int r2 = 0; r2 < DP; ++r2) { cinvw[lane * (DP * DP) + r2 + DP * c2] = y[r2]; a.Cinv[vi * (DP * DP) + r2 + DP * c2] = y[r2]; }
+                for (int r2 = 0; r2 < DP; ++r2) { cinvw[lane * ((DP + 1) * DP) + r2 * DP + c2] = y[r2]; a.Cinv[vi * (DP * DP) + r2 + DP * c2] = y[r2]; }     // (LDS: row r2 of the inverse contiguous)
             }
 #pragma unroll
-            for (int r2 = 0; r2 < DP; ++r2) { const double bv = sm[NSYM + r2]; a.b[eb0 + (size_t)(mb + lane) * DP + r2] = bv; Ew[(size_t)(lane * DP + r2) * LDC + nd] = bv; }   // the right-hand side rides as column nd
+            for (int r2 = 0; r2 < DP; ++r2) { const double bv = sm[NSYM + r2]; a.b[eb0 + (size_t)(mb + lane) * DP + r2] = bv; Ew[(size_t)lane * MST + r2 * LDC + nd] = bv; }   // the right-hand side rides as column nd
         }
         wave_lds_sync();
         // per member: S_supernode += E' (C + lambda I)^-1 [E | b] on the matrix cores -- tile (Rr, Cc) is one instruction whose A operand is lane (i, k) <- e_{16 Rr + i}[k]
         // and whose B operand is lane (j, k) <- y_{16 Cc + j}[k], y = (C + lambda I)^-1 e; both read from the slab (row k of E is contiguous: sixteen lanes, sixteen doubles).
 #pragma unroll 1
         for (int m2 = 0; m2 < ((dbg & 1) ? 0 : nlive); ++m2) {
-            const double* em = Ew + (size_t)(m2 * DP) * LDC + li;
+            const double* em = Ew + (size_t)m2 * MST + li;
             double cr[DP];
 #pragma unroll
-            for (int q = 0; q < DP; ++q) cr[q] = cinvw[m2 * (DP * DP) + kk + DP * q];
+            for (int q = 0; q < DP; ++q) cr[q] = cinvw[m2 * ((DP + 1) * DP) + kk * DP + q];
             double aop[TRK], bop[TRK];
 #pragma unroll
             for (int r2 = 0; r2 < TRK; ++r2) {
-                double e[DP];
+                aop[r2] = em[kk * LDC + 16 * r2];
+                double y = 0.0;
 #pragma unroll
-                for (int q = 0; q < DP; ++q) e[q] = em[q * LDC + 16 * r2];
-                double av = 0.0, y = 0.0;
-#pragma unroll
-                for (int q = 0; q < DP; ++q) { if (q == kk) av = e[q]; y = fma(cr[q], e[q], y); }
-                aop[r2] = kslot ? av : 0.0; bop[r2] = kslot ? y : 0.0;
+                for (int q = 0; q < DP; ++q) y = fma(cr[q], em[q * LDC + 16 * r2], y);
+                bop[r2] = y;
             }
 #pragma unroll
             for (int Rr = 0; Rr < TRK; ++Rr)
@@ -178,7 +192,8 @@ __device__ __forceinline__ void mf_elim_big(const MfArgs& a, uint32_t bidx, doub
     const int nd = (int)d.nd, nmem = (int)d.nmem, B = (int)d.B, ncb = nd / DC;
     const int TR = (nd + 1 + 15) >> 4;
     double* const Ew = lds + (size_t)wave * a.wsz;
-    for (int i = lane; i < B * DP * 16 * TR; i += 64) Ew[i] = 0.0;      // (the padding columns behind nd stay zero for the whole launch)
+    for (int i = lane; i < B * mf_member_stride(DP, TR); i += 64) Ew[i] = 0.0;      // (the padding columns behind nd and the members' zero rows stay zero for the whole launch)
+    { double* const cz = Ew + a.ecap + 64 * (DP * (DP + 1) / 2 + DP) + MF_BMAX * (DP * (DP + 1) / 2 + DP); for (int i = lane; i < MF_BMAX * (DP + 1) * DP; i += 64) cz[i] = 0.0; }
     wave_lds_sync();
     const int nbatch = (nmem + B - 1) / B, nact = min(nbatch, MF_ENW);   // wavefronts that have a batch at all
     auto members = [&](auto TRc) {
@@ -232,7 +247,8 @@ __device__ __forceinline__ void mf_elim_tiny(const MfArgs& a, uint32_t sidx, dou
     const int nd = (int)d.nd, B = (int)d.B, ncb = nd / DC;
     const int TR = (nd + 1 + 15) >> 4;
     double* const Ew = lds + (size_t)wave * a.wsz;
-    for (int i = lane; i < B * DP * 16 * TR; i += 64) Ew[i] = 0.0;
+    for (int i = lane; i < B * mf_member_stride(DP, TR); i += 64) Ew[i] = 0.0;
+    { double* const cz = Ew + a.ecap + 64 * (DP * (DP + 1) / 2 + DP) + MF_BMAX * (DP * (DP + 1) / 2 + DP); for (int i = lane; i < MF_BMAX * (DP + 1) * DP; i += 64) cz[i] = 0.0; }
     wave_lds_sync();
     auto members = [&](auto TRc) {
         constexpr int TRK = decltype(TRc)::value;
@@ -310,5 +326,6 @@ int enqueue_mf_solve_local(nlls_ctx* c) {
 uint32_t mf_wave_doubles(uint32_t ecap, int dp) { return mf_wave_lds(ecap, dp); }
 int mf_elim_waves() { return MF_ENW; }
 int mf_batch_max() { return MF_BMAX; }
+uint32_t mf_slab_doubles(int B, int dp, int tr) { return (uint32_t)(B * mf_member_stride(dp, tr)); }
 
 }  // namespace nlls

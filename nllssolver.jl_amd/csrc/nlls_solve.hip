@@ -1558,31 +1558,40 @@ __global__ __launch_bounds__(256) void schur_gather_kernel(GatherArgs a) {
         return;
     }
     const int rows = J.rows, ne = rows * J.cols;
-    for (int e = lane; e < ne; e += 64) {
-        const int b2 = e / rows, a2 = e - b2 * rows;
+    // (every lane walks the same loops -- the shares' descriptors travel by read-lane from the lane that loaded them --; a lane without an element of its own reads element 0 and stores nothing)
+    for (int e0 = 0; e0 < ne; e0 += 64) {
+        const int e = e0 + lane; const bool inr = e < ne; const int ee = inr ? e : 0;
+        const int b2 = ee / rows, a2 = ee - b2 * rows;
         const bool diag = J.kind == 0 && J.r0 == J.c0;
-        if (diag && a2 < b2) continue;                        // diagonal block: the lower triangle (mirrored by the store)
+        const bool live = inr && !(diag && a2 < b2);             // diagonal block: the lower triangle (mirrored by the store)
         double v = 0.0;
         if (J.kind == 0) { if (J.copy_off >= 0) v = J.copy_trans ? a.A[J.copy_off + b2 + (int)J.cols * a2] : a.A[J.copy_off + a2 + rows * b2]; if (diag && a2 == b2) v += a.lambda; }
         else v = a.b[J.boff + a2];
-        // shares, four at a time: the descriptors (uniform loads) and then the four values are in flight together
-        for (uint32_t c0 = J.cbeg; c0 < J.cend; c0 += 4) {
-            GatherCon k[4]; double t[4];
+        // shares: the descriptors of up to 64 of them come with ONE coalesced load (lane u takes share u) and reach every lane through read-lanes; the values are then requested
+        // eight at a time, all in flight together (round 6: four at a time behind uniform descriptor loads was a chain of dependent round trips, 16.7 us at BASELINE config 4)
+        for (uint32_t c0 = J.cbeg; c0 < J.cend; c0 += 64) {
+            const uint32_t nc = min(64u, J.cend - c0);
+            const GatherCon mine = a.cons[c0 + ((uint32_t)lane < nc ? (uint32_t)lane : 0u)];
+            for (uint32_t u0 = 0; u0 < nc; u0 += 8) {
+                double t[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) k[u] = a.cons[c0 + u < J.cend ? c0 + u : J.cend - 1];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (k[u].ld) t[u] = k[u].aux ? a.slab[k[u].off + b2 + k[u].ld * a2] : a.slab[k[u].off + a2 + k[u].ld * b2];   // aux: the share lies above the diagonal of S in reduced order -- its transpose is wanted
-                else {                                          // a member of a small supernode: e_a' (C_v + lambda I)^-1 e_b on the fly
-                    const int dv = a.dv; const double* ea = a.A + k[u].off + (size_t)dv * a2; const double* eb = J.kind == 0 ? a.A + k[u].aux + (size_t)dv * b2 : a.b + k[u].aux;
-                    const double* ci = a.Cinv + k[u].cinv; double s2 = 0.0;
-                    for (int m = 0; m < dv; ++m) { double r2 = 0.0; for (int n2 = 0; n2 < dv; ++n2) r2 = fma(ci[m + dv * n2], eb[n2], r2); s2 = fma(ea[m], r2, s2); }
-                    t[u] = s2;
+                for (int u = 0; u < 8; ++u) {
+                    const int src = (int)min(u0 + (uint32_t)u, nc - 1);
+                    GatherCon k; k.off = (uint32_t)__builtin_amdgcn_readlane((int)mine.off, src); k.ld = (uint32_t)__builtin_amdgcn_readlane((int)mine.ld, src);
+                    k.aux = (uint32_t)__builtin_amdgcn_readlane((int)mine.aux, src); k.cinv = (uint32_t)__builtin_amdgcn_readlane((int)mine.cinv, src);
+                    if (k.ld) t[u] = k.aux ? a.slab[k.off + b2 + k.ld * a2] : a.slab[k.off + a2 + k.ld * b2];   // aux: the share lies above the diagonal of S in reduced order -- its transpose is wanted
+                    else {                                          // a member of a small supernode: e_a' (C_v + lambda I)^-1 e_b on the fly
+                        const int dv = a.dv; const double* ea = a.A + k.off + (size_t)dv * a2; const double* eb = J.kind == 0 ? a.A + k.aux + (size_t)dv * b2 : a.b + k.aux;
+                        const double* ci = a.Cinv + k.cinv; double s2 = 0.0;
+                        for (int m = 0; m < dv; ++m) { double r2 = 0.0; for (int n2 = 0; n2 < dv; ++n2) r2 = fma(ci[m + dv * n2], eb[n2], r2); s2 = fma(ea[m], r2, s2); }
+                        t[u] = s2;
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (c0 + u < J.cend) v -= t[u];
+                for (int u = 0; u < 8; ++u) if (u0 + (uint32_t)u < nc) v -= t[u];
+            }
         }
+        if (!live) continue;
         if (J.kind == 0) gather_store(g, (int)J.r0 + a2, (int)J.c0 + b2, v);
         else {                                                 // the rhs row: row nbd of the border / rhs tiles
             const int r = (int)J.r0 + a2, NT = g.NT, bsz = 16 * NT;

@@ -634,13 +634,16 @@ int build_mf(nlls_ctx* c, int32_t ngroups, const nlls_cost_group* groups, const 
     const int bmax = mf_batch_max(), nw = mf_elim_waves();
     for (int pass = 0; pass < 2; ++pass) for (size_t ei = 0; ei < c->h_elim_desc.size(); ++ei) { const ElimDesc& e0 = c->h_elim_desc[ei];
         const int nd = (int)e0.nd; if (nd % dc || nd + 1 > 80 || nd / dc > 64 || nd / dc < 1 || e0.nmem > 128 || e0.nmem < 1) return NLLS_OK;
-        const int ncb = nd / dc, bcap = std::min(64 / ncb, bmax);
+        // (members per batch: one lane per cost block, at most MF_BMAX, and -- four workgroups per CU -- a slab that leaves the wavefront's LDS region within 2446 doubles: with
+        //  2514 the launch held three workgroups per CU and took 120 instead of 83 us at BASELINE config 4)
+        const int ncb = nd / dc, TR0 = (nd + 1 + 15) / 16;
+        const int bcap = std::max(1, std::min({64 / ncb, bmax, (int)((2446 - (int)mf_wave_doubles(0, dp)) / (int)mf_slab_doubles(1, dp, TR0))}));
         const bool tiny = (int)e0.nmem <= bcap; if (tiny != (pass == 1)) continue;
-        int B = bcap;
-        if (!tiny) { int64_t best = -1; for (int b2 = 1; b2 <= bcap; ++b2) { const int64_t nbt = ((int64_t)e0.nmem + b2 - 1) / b2, rounds = (nbt + nw - 1) / nw, cost = rounds * (4 + b2); if (best < 0 || cost <= best) { best = cost; B = b2; } } }
+        int B = tiny ? (int)e0.nmem : bcap;      // (a supernode of one batch: the batch is its members)
+        if (!tiny) { int64_t best = -1; for (int b2 = 1; b2 <= bcap; ++b2) { const int64_t nbt = ((int64_t)e0.nmem + b2 - 1) / b2, rounds = (nbt + nw - 1) / nw, cost = rounds * (4 + b2); if (best < 0 || cost < best) { best = cost; B = b2; } } }
         MfDesc e{e0.v0, e0.nmem, e0.nd, e0.rc_off, e0.eb0, (uint32_t)nobs, (uint32_t)B, c->h_slab_off[ei]};
         imgmax = std::max<uint32_t>(imgmax, (uint32_t)(ncb * (ncb + 1) / 2 * dc * dc + nd + 4));
-        const int TR = (nd + 1 + 15) / 16; ecap = std::max<uint32_t>(ecap, (uint32_t)(B * dp * 16 * TR));
+        const int TR = (nd + 1 + 15) / 16; ecap = std::max<uint32_t>(ecap, mf_slab_doubles(B, dp, TR));
         for (uint32_t m = 0; m < e.nmem; ++m) { const uint32_t v = e.v0 + m; const int64_t row = c->h_erow[v];
             const int64_t q0 = c->h_eptr[v], q1 = c->h_eptr[v + 1];
             if (q1 - q0 != ncb || pos[row + 1] - pos[row] != ncb) return NLLS_OK;
