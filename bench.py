@@ -24,6 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HBM_ACHIEVABLE_GBS = 6290.0    # MI355X_MICROARCH.md: the copy rate measured on the chip
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix = fp64 vector peak: one v_mfma_f64_16x16x4_f64 (2048 flop) per 64 cycles per SIMD
                                # (tools/microbench/mfma_rate.hip), 1024 SIMDs, 2.4 GHz
@@ -34,7 +35,7 @@ def sweep_code_hash():
     counters it holds, and a stale file is refused (roofline.traffic = null) instead of being quoted."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("nlls_sweep.hip", "nlls_wave.hpp", "nlls_kinds.hpp", "nlls_structure.cpp"):
+    for f in ("nlls_sweep.hip", "nlls_wave.hpp", "nlls_kinds.hpp", "nlls_structure.cpp"):      # (the MATERIALISING accumulate sweep: the kernel `roofline` describes)
         h.update(open(os.path.join(ROOT, "nllssolver.jl_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -50,6 +51,16 @@ CONFIGS = {
     "ba_grid_40x40": (40, 40, 6),
     "ba_grid_100x100": (100, 100, 3),
 }
+
+
+def loop_code_hash():
+    """Hash of everything an LM iteration's kernels are built from: profiles/pmc_iter.json (HBM bytes per LM iteration, both paths) is quoted only for the build it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(os.path.join(ROOT, "nllssolver.jl_amd", "csrc"))):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(open(os.path.join(ROOT, "nllssolver.jl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes_per_sweep(nobs, var_storage, nnz_data, ndof, M=2, ndeps=2):
@@ -136,6 +147,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ba_1kx100k", choices=sorted(CONFIGS))
+    ap.add_argument("--path", default="default", choices=["default", "materialise"],
+                    help="default: the matrix-free LM trial where the structure qualifies (two-slot Schur problems: the eliminated rows of A.data are never formed); "
+                         "materialise: every trial eliminates from the materialised A.data (NLLS_OPT_MATERIALIZE), the path of rounds 1-5")
     ap.add_argument("--solver", default="default", choices=["default", "dense", "chain", "deterministic", "windowed", "nofloor"],
                     help="reduced-system solver: block cyclic reduction of the band (default), the dense MFMA LDL' (NLLS_FLAG_NO_BAND), "
                          "the round-1 twisted chain kernels (NLLS_FLAG_NO_BCR), or the atomics-free assembly (NLLS_FLAG_DETERMINISTIC)")
@@ -219,6 +233,8 @@ def main():
 
     ls = ShardedLS(problem, np.ones(problem.nvariables, bool), flags=flags, device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged, force_collectives=force_dist)
     info = ls.info
+    if args.path == "materialise":
+        ls.ctx.set_option(_capi.OPT_MATERIALIZE, 1)
     # never terminate early inside the timed region: exactly K outer iterations
     # (the adaptive-kernel costs are negative log-likelihoods: 'dcost < bestcost * reldcost', src/optimize.jl:152, then needs reldcost = +inf to stay off)
     options = N.NLLSOptions(maxiters=10 ** 9, reldcost=np.inf if args.workload == "ba_so3_500x50k" else -np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
@@ -264,8 +280,22 @@ def main():
             os._exit(17)
         loop_r, elapsed_r = timed_loop(ls, problem, start_vars, profile=(rep == max(1, args.repeats) - 1))
         runs.append((elapsed_r, loop_r))
+    stats_loop = ls.ctx.solve_stats()
+    mf_loop = world == 1 and args.path == "default" and stats_loop.get("mf_trials", 0) > 0      # did the timed loop run matrix-free trials?
+    # `roofline` describes the MATERIALISING accumulate launch (north_star names it).  Where the timed loop ran matrix-free it holds no such launch: one more loop of the same K
+    # iterations with NLLS_OPT_MATERIALIZE set -- the round-5 path on the same upload -- gives the launch's in-situ duration, and the materialised rate to hold the default against
+    materialised = None
+    if mf_loop:
+        ls.ctx.profile_sweep(False, read=True)
+        ls.ctx.set_option(_capi.OPT_MATERIALIZE, 1)
+        mruns = [timed_loop(ls, problem, start_vars, profile=(r == 2))[::-1] for r in range(3)]      # (elapsed, loop)
+        me, ml_ = sorted(mruns, key=lambda t: t[0])[1]
+        materialised = {"value": round(args.steps / me, 3), "unit": "LM iters/s", "ms_per_step": round(1e3 * me / args.steps, 4), "linear_solves": int(ml_.data.linearsolvers), "final_cost": ml_.data.bestcost,
+                        "runs": [round(args.steps / e, 1) for e, _ in mruns], "what": "the same K iterations from the same start with NLLS_OPT_MATERIALIZE: accumulate sweep -> A.data, elimination and back-substitution read it (rounds 1-5)"}
     insitu = ls.ctx.profile_sweep(False, read=True)       # (avg, min, max ms, samples) of the accumulate launches inside the (last) timed loop: the kernel's own first-start .. last-end stamps
     insitu_disp = ls.ctx.profile_sweep_dispatch()         # ... the same launches by their dispatch timestamps (begin .. end as a kernel trace reports them)
+    if mf_loop:
+        ls.ctx.set_option(_capi.OPT_MATERIALIZE, 0)
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
     elapsed, loop = runs[order[len(order) // 2]]           # the median run is the one reported
     data = loop.data
@@ -352,10 +382,12 @@ def main():
     roofline["infinity_cache_resident"] = bool(mem["working_set_bytes"] <= 256 * 2 ** 20)
     if world == 1 and info.is_sparse:
         flush_bytes = 512 * 2 ** 20
+        ls.ctx.set_option(_capi.OPT_MATERIALIZE, 1)          # (the full accumulate launch: with the matrix-free trial enabled nlls_sweep_gradhess(ctx, NULL) enqueues nothing)
         ls.ctx.profile_sweep(True)
         for _ in range(12):
             ls.ctx.flush_cache(flush_bytes); ls.ctx.sweep_gradhess(want_cost=False)
         cold = ls.ctx.profile_sweep(False, read=True); cold_disp = ls.ctx.profile_sweep_dispatch()
+        ls.ctx.set_option(_capi.OPT_MATERIALIZE, 1 if args.path == "materialise" else 0)
         cold_q = cold_disp if cold_disp and cold_disp[3] >= 3 and cold_disp[0] > 0 else cold
         if cold_q and cold_q[3] >= 3:
             ach_c = alg_bytes / (cold_q[0] * 1e-3) / 1e9
@@ -364,6 +396,24 @@ def main():
                                 "timing": ("dispatch timestamps" if cold_q is cold_disp else "execution span of the launch (kernel stamps)") + ", each launch behind a 512 MiB device-to-device copy of foreign data",
                                 "kernel_span_ms": round(cold[0], 4) if cold and cold[3] >= 3 else None}
             roofline["frac_cold"] = roofline["cold"]["frac"]
+            roofline["frac_hbm"] = roofline["cold"]["frac"]                                             # the launch with its data coming from HBM: the figure to hold against "of peak HBM"
+            roofline["cold"]["frac_of_achievable"] = round(ach_c / HBM_ACHIEVABLE_GBS, 4)
+    # which regime `frac` is in, in the numbers themselves: `frac` = the launch inside the LM loop (its working set may sit in the 256 MiB memory-side cache: infinity_cache_resident),
+    # `frac_hbm` (= frac_cold) = the same launch behind 512 MiB of foreign traffic, and both against the copy rate the guide measured (6.29 TB/s) beside the 8 TB/s specification
+    roofline["frac_of_achievable"] = round(achieved_q / HBM_ACHIEVABLE_GBS, 4)
+    roofline["achievable_peak"] = HBM_ACHIEVABLE_GBS
+    roofline["regime"] = ("in-loop figure: working set %.1f MiB %s the 256 MiB memory-side cache; frac_hbm is the HBM-resident figure" % (mem["working_set_bytes"] / 2 ** 20, "inside" if roofline["infinity_cache_resident"] else "beyond"))
+    roofline["timed_loop_path"] = "matrix-free LM trial (no accumulate launch in the loop: `frac` is taken from a second, materialising loop of the same iterations)" if mf_loop else "materialising (the accumulate launch is the timed loop's own)"
+    # HBM bytes of ONE LM iteration, both paths (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/lm_iters.py, all kernels of the loop: tools/pmc_iter.sh -> profiles/pmc_iter.json)
+    hbm_iter = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_iter.json"))).get(args.workload)
+        if rec and rec.get("loop_code_hash") == loop_code_hash():
+            hbm_iter = {k: rec[k] for k in ("matrix_free", "materialised", "note") if k in rec}
+        elif rec:
+            hbm_iter = {"refused": "profiles/pmc_iter.json was collected on a different build (re-run tools/pmc_iter.sh)"}
+    except Exception:
+        hbm_iter = None
     # ---- roofline of the reduced solve (north_star: MFMA utilisation on the reduced solve against chip peak)
     roofline_solve = None
     if world == 1 and info.nreduced_dof > 0 and reduced_ms > 0:
@@ -476,6 +526,9 @@ def main():
                    # (tests/golden/oracle_trials.json, tools/oracle_trials.py), not a run on this box
                    **oracle_loop_fixture(args.workload, args.steps)},
             "spread": spread,
+            "lm_path": ("matrix-free LM trial: the cost blocks are evaluated inside the Schur elimination and the back-substitution, the eliminated rows of A.data are never formed (nlls_mf.hip)" if mf_loop
+                        else "materialised: accumulate sweep -> A.data -> elimination"),
+            "materialised": materialised, "hbm_bytes_per_lm_iteration": hbm_iter,
             "roofline": roofline, "roofline_solve": roofline_solve, "roofline_solve_dense": roofline_solve_dense, "cpu_baseline": cpu,
         }
         if world > 1 or force_dist:

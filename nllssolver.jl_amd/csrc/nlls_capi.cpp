@@ -8,6 +8,7 @@
 using namespace nlls;
 
 namespace {
+constexpr int32_t NLLS_MAX_GRAPH_NODES = 1 << 27;      // nlls_rcm_order / nlls_nd_tiles: nodes of a reduced-system graph
 int fail(nlls_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
 int herr(nlls_ctx* c, hipError_t e, const char* what) { c->err = std::string(what) + ": " + hipGetErrorString(e); return NLLS_ERR_HIP; }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return herr(ctx, e_, #expr); } while (0)
@@ -58,7 +59,7 @@ bool mf_trial(const nlls_ctx* ctx, int32_t from) { return ctx->mf_ok && ctx->mf_
 
 extern "C" {
 
-int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
+int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) { NLLS_API_BEGIN
     if (!out) return NLLS_ERR_INVALID_ARG;
     *out = nullptr;
     int count = 0;
@@ -88,9 +89,10 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) {
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return NLLS_ERR_HIP; }
     *out = c;
     return NLLS_OK;
+    NLLS_API_END(nullptr)
 }
 
-int nlls_ctx_destroy(nlls_ctx* ctx) {
+int nlls_ctx_destroy(nlls_ctx* ctx) { NLLS_API_BEGIN
     if (!ctx) return NLLS_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -104,48 +106,55 @@ int nlls_ctx_destroy(nlls_ctx* ctx) {
     delete ctx;
     if (s) (void)hipStreamDestroy(s);
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 
 const char* nlls_last_error(const nlls_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int nlls_set_stream(nlls_ctx* ctx, void* hip_stream) {
+int nlls_set_stream(nlls_ctx* ctx, void* hip_stream) { NLLS_API_BEGIN
     if (!ctx) return NLLS_ERR_INVALID_ARG;
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
     if (hip_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     else { if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return NLLS_ERR_HIP; ctx->own_stream = true; }
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 
-int nlls_set_shard(nlls_ctx* ctx, int32_t rank, int32_t nranks) {
+int nlls_set_shard(nlls_ctx* ctx, int32_t rank, int32_t nranks) { NLLS_API_BEGIN
     if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return NLLS_ERR_INVALID_ARG;
     ctx->rank = ctx->shard_rank = rank; ctx->nranks = ctx->shard_nranks = nranks; ctx->replicated = false; ctx->ready = false;
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 
-int nlls_var_storage(int32_t k, int32_t d) { return var_storage(k, d); }
-int nlls_var_dof(int32_t k, int32_t d) { return var_dof(k, d); }
-int nlls_res_ndeps(int32_t k) { ResDesc d; return res_desc(k, d) ? d.ndeps : NLLS_ERR_UNSUPPORTED; }
-int nlls_res_nres(int32_t k) { ResDesc d; return res_desc(k, d) ? d.nres : NLLS_ERR_UNSUPPORTED; }
-int nlls_res_ndata(int32_t k) { ResDesc d; return res_desc(k, d) ? d.ndata : NLLS_ERR_UNSUPPORTED; }
-int nlls_res_slot_kind(int32_t k, int32_t slot, int32_t* vk, int32_t* vd) {
+int nlls_var_storage(int32_t k, int32_t d) { NLLS_API_BEGIN return var_storage(k, d); NLLS_API_END(nullptr) }
+int nlls_var_dof(int32_t k, int32_t d) { NLLS_API_BEGIN return var_dof(k, d); NLLS_API_END(nullptr) }
+int nlls_res_ndeps(int32_t k) { NLLS_API_BEGIN ResDesc d; return res_desc(k, d) ? d.ndeps : NLLS_ERR_UNSUPPORTED; NLLS_API_END(nullptr) }
+int nlls_res_nres(int32_t k) { NLLS_API_BEGIN ResDesc d; return res_desc(k, d) ? d.nres : NLLS_ERR_UNSUPPORTED; NLLS_API_END(nullptr) }
+int nlls_res_ndata(int32_t k) { NLLS_API_BEGIN ResDesc d; return res_desc(k, d) ? d.ndata : NLLS_ERR_UNSUPPORTED; NLLS_API_END(nullptr) }
+int nlls_res_slot_kind(int32_t k, int32_t slot, int32_t* vk, int32_t* vd) { NLLS_API_BEGIN
     ResDesc d; if (!res_desc(k, d)) return NLLS_ERR_UNSUPPORTED;
     if (slot < 0 || slot >= d.ndeps) return NLLS_ERR_INVALID_ARG;
     if (vk) *vk = d.sk[slot]; if (vd) *vd = d.sd[slot];
     return NLLS_OK;
+    NLLS_API_END(nullptr)
 }
-int nlls_rcm_order(int32_t n, const int64_t* adjptr, const int32_t* adj, int32_t* perm_out) {
+int nlls_rcm_order(int32_t n, const int64_t* adjptr, const int32_t* adj, int32_t* perm_out) { NLLS_API_BEGIN
     if (n < 0 || (n > 0 && (!adjptr || !perm_out))) return NLLS_ERR_INVALID_ARG;
+    if (n > NLLS_MAX_GRAPH_NODES) return NLLS_ERR_INVALID_ARG;          // (a size no reduced system has: refused before any work vector is sized by it)
     std::vector<std::vector<int32_t>> a((size_t)n);
     for (int32_t i = 0; i < n; ++i) { if (adjptr[i + 1] < adjptr[i]) return NLLS_ERR_INVALID_ARG;
         for (int64_t q = adjptr[i]; q < adjptr[i + 1]; ++q) { if (adj[q] < 0 || adj[q] >= n || adj[q] == i) return NLLS_ERR_INVALID_ARG; a[i].push_back(adj[q]); } }
     const std::vector<int32_t> p = nlls::rcm_order(a);
     for (int32_t i = 0; i < n; ++i) perm_out[i] = p[i];
     return NLLS_OK;
+    NLLS_API_END(nullptr)
 }
 
 int nlls_nd_tiles(int32_t n, int32_t nborder, const int64_t* adjptr, const int32_t* adj, const int32_t* dof, int32_t* tile_of, int32_t* row_in_tile,
                   int32_t max_tiles, int32_t* parent, int32_t* level, int64_t* colptr, int64_t max_rows, int32_t* rows) {
+    if (n > NLLS_MAX_GRAPH_NODES || nborder > NLLS_MAX_GRAPH_NODES) return NLLS_ERR_INVALID_ARG;
     if (n < 0 || nborder < 0 || (n > 0 && !adjptr) || (n + nborder > 0 && (!dof || !tile_of || !row_in_tile)) || !parent || !level || !colptr || (max_rows > 0 && !rows)) return NLLS_ERR_INVALID_ARG;
     std::vector<std::vector<int32_t>> a((size_t)n);
     for (int32_t i = 0; i < n; ++i) { if (adjptr[i + 1] < adjptr[i]) return NLLS_ERR_INVALID_ARG;
@@ -177,14 +186,16 @@ int nlls_upload_structure(nlls_ctx* ctx, int64_t nvar, const int32_t* var_kind, 
         return rc;
     }
     catch (const std::exception& e) { return fail(ctx, NLLS_ERR_HIP, std::string("host exception: ") + e.what()); }
+    catch (...) { return nlls::api_exception(ctx, "unknown C++ exception"); }
 }
 
-int nlls_get_info(const nlls_ctx* ctx, nlls_info* out) {
+int nlls_get_info(const nlls_ctx* ctx, nlls_info* out) { NLLS_API_BEGIN
     if (!ctx || !out || !ctx->ready) return ctx ? NLLS_ERR_NOT_READY : NLLS_ERR_INVALID_ARG;
     *out = ctx->info; return NLLS_OK;
+    NLLS_API_END(const_cast<nlls_ctx*>(ctx))
 }
 
-int nlls_get_bsm_index(const nlls_ctx* ctx, int64_t* colptr, int64_t* rowval, int64_t* nzval, int64_t* boffsets) {
+int nlls_get_bsm_index(const nlls_ctx* ctx, int64_t* colptr, int64_t* rowval, int64_t* nzval, int64_t* boffsets) { NLLS_API_BEGIN
     if (!ctx || !ctx->ready) return ctx ? NLLS_ERR_NOT_READY : NLLS_ERR_INVALID_ARG;
     if (ctx->info.is_sparse) {
         if (colptr) for (size_t i = 0; i < ctx->it_colptr.size(); ++i) colptr[i] = ctx->it_colptr[i] + 1;
@@ -193,31 +204,36 @@ int nlls_get_bsm_index(const nlls_ctx* ctx, int64_t* colptr, int64_t* rowval, in
     }
     if (boffsets) for (int64_t i = 0; i < ctx->info.nblocks; ++i) boffsets[i] = ctx->boffsets[i] + 1;
     return NLLS_OK;
+    NLLS_API_END(const_cast<nlls_ctx*>(ctx))
 }
 
-int nlls_set_variables(nlls_ctx* ctx, int32_t which, const double* packed) {
+int nlls_set_variables(nlls_ctx* ctx, int32_t which, const double* packed) { NLLS_API_BEGIN
     NEED_READY(); if (!valid_set(which) || !packed) return NLLS_ERR_INVALID_ARG;
     spec_note_write(ctx, which);
     if (which == NLLS_VARS_CURRENT) ctx->sweeps_since_set = 0;         // (a new starting point: its first trial gets no look-ahead sweep, see nlls_sweep_gradhess)
     HIPCHK(hipMemcpyAsync(vars_ptr(ctx, which), packed, sizeof(double) * ctx->info.var_storage, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_get_variables(nlls_ctx* ctx, int32_t which, double* packed) {
+int nlls_get_variables(nlls_ctx* ctx, int32_t which, double* packed) { NLLS_API_BEGIN
     NEED_READY(); if (!valid_set(which) || !packed) return NLLS_ERR_INVALID_ARG;
     HIPCHK(hipMemcpyAsync(packed, vars_ptr(ctx, which), sizeof(double) * ctx->info.var_storage, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_swap_variables(nlls_ctx* ctx, int32_t a, int32_t b) {
+int nlls_swap_variables(nlls_ctx* ctx, int32_t a, int32_t b) { NLLS_API_BEGIN
     NEED_READY(); if (!valid_set(a) || !valid_set(b)) return NLLS_ERR_INVALID_ARG;
     std::swap(ctx->vars_slot[a], ctx->vars_slot[b]); return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_copy_variables(nlls_ctx* ctx, int32_t dst, int32_t src) {
+int nlls_copy_variables(nlls_ctx* ctx, int32_t dst, int32_t src) { NLLS_API_BEGIN
     NEED_READY(); if (!valid_set(dst) || !valid_set(src)) return NLLS_ERR_INVALID_ARG;
     if (dst != src) spec_note_write(ctx, dst);
     if (dst != src) HIPCHK(hipMemcpyAsync(vars_ptr(ctx, dst), vars_ptr(ctx, src), sizeof(double) * ctx->info.var_storage, hipMemcpyDeviceToDevice, ctx->stream));
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 
 // Lazy stage 0 (collective route): nlls_sweep_gradhess(ctx, NULL) leaves the reduced rows of A.data and b as this rank's share -- all an LM trial
@@ -232,7 +248,7 @@ static int ensure_reduced_summed(nlls_ctx* ctx) {
     TRY(enqueue_pack_reduce0(ctx)); TRY(comm_reduce(ctx, ctx->redbuf.p, ctx->redbuf_len, NLLS_REDUCE_SUM)); TRY(enqueue_unpack_reduce0(ctx, false));
     return NLLS_OK;
 }
-int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
+int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) { NLLS_API_BEGIN
     NEED_READY();
     // (a sweep the caller asks for: the look-ahead may try again behind the next trial -- but not behind the FIRST trial from a new starting point: the initial damping
     //  (1e-6 of the largest diagonal entry, src/iterators.jl:131-137) is the one guess of the loop that is routinely rejected -- five times in a row at BASELINE config 5 --,
@@ -275,8 +291,9 @@ int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) {
     TRY(fetch_scalars(ctx, 0, 1));
     *cost_out = ctx->h_scalars[0];
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_sweep_cost(nlls_ctx* ctx, int32_t which, double* cost_out) {
+int nlls_sweep_cost(nlls_ctx* ctx, int32_t which, double* cost_out) { NLLS_API_BEGIN
     NEED_READY(); if (!valid_set(which)) return NLLS_ERR_INVALID_ARG;
     // (where the matrix-free trial applies, every cost is ONE fixed sum -- the trial's: cost(problem) == result.bestcost bit for bit)
     if (mf_trial(ctx, NLLS_VARS_CURRENT)) TRY(enqueue_mf_sweep_cost(ctx, which)); else
@@ -285,31 +302,37 @@ int nlls_sweep_cost(nlls_ctx* ctx, int32_t which, double* cost_out) {
     TRY(fetch_scalars(ctx, 0, 1));
     if (cost_out) *cost_out = ctx->h_scalars[0];
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 
-int nlls_get_grad(nlls_ctx* ctx, double* b_out) {
+int nlls_get_grad(nlls_ctx* ctx, double* b_out) { NLLS_API_BEGIN
     NEED_GRAD(); if (!b_out) return NLLS_ERR_INVALID_ARG;
     HIPCHK(hipMemcpyAsync(b_out, ctx->b.p, sizeof(double) * ctx->info.ndof, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_get_bsm_data(nlls_ctx* ctx, double* data_out) {
+int nlls_get_bsm_data(nlls_ctx* ctx, double* data_out) { NLLS_API_BEGIN
     NEED_GRAD(); if (!data_out) return NLLS_ERR_INVALID_ARG;
     HIPCHK(hipMemcpyAsync(data_out, ctx->A.p, sizeof(double) * ctx->info.nnz_data, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_max_abs_diag(nlls_ctx* ctx, double* out) {
+int nlls_max_abs_diag(nlls_ctx* ctx, double* out) { NLLS_API_BEGIN
     NEED_GRAD(); TRY(enqueue_max_abs_diag(ctx)); TRY(comm_reduce(ctx, ctx->scalars.p + 3, 1, NLLS_REDUCE_MAX)); TRY(fetch_scalars(ctx, 3, 1));
     if (out) *out = ctx->h_scalars[3]; return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_grad_sqnorm(nlls_ctx* ctx, double* out) {
+int nlls_grad_sqnorm(nlls_ctx* ctx, double* out) { NLLS_API_BEGIN
     NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->b.p, 6)); TRY(comm_reduce(ctx, ctx->scalars.p + 6, 2, NLLS_REDUCE_SUM)); TRY(fetch_scalars(ctx, 6, 2));
     if (out) *out = ctx->h_scalars[7]; return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_grad_quadform(nlls_ctx* ctx, double* out) {
+int nlls_grad_quadform(nlls_ctx* ctx, double* out) { NLLS_API_BEGIN
     NEED_GRAD(); TRY(enqueue_quadform(ctx, ctx->b.p, 6)); TRY(comm_reduce(ctx, ctx->scalars.p + 6, 2, NLLS_REDUCE_SUM)); TRY(fetch_scalars(ctx, 6, 2));
     if (out) *out = ctx->h_scalars[6]; return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 
 // what a non-zero factorisation status means: a bad pivot (NLLS_ERR_NOT_SPD: the iterators damp more and retry) or a hand-off inside a one-launch backward pass that
@@ -318,9 +341,9 @@ static int status_error(nlls_ctx* ctx, int32_t st, const char* what) {
     if (st == 0x40000000) return fail(ctx, NLLS_ERR_HIP, "a hand-off between workgroups of the one-launch backward substitution timed out (0.5 s): not a pivot failure -- NLLS_BCR_LEVEL_BACKWARD=1 / NLLS_DENSE_STEP_BACKWARD=1 select the per-level launches");
     return fail(ctx, NLLS_ERR_NOT_SPD, std::string(what) + " (code " + std::to_string(st) + ")");
 }
-int nlls_damp(nlls_ctx* ctx, double delta) { NEED_GRAD_LAZY(); ctx->lambda += delta; return NLLS_OK; }
+int nlls_damp(nlls_ctx* ctx, double delta) { NLLS_API_BEGIN NEED_GRAD_LAZY(); ctx->lambda += delta; return NLLS_OK; NLLS_API_END(ctx) }
 
-int nlls_solve(nlls_ctx* ctx, double* x_out) {
+int nlls_solve(nlls_ctx* ctx, double* x_out) { NLLS_API_BEGIN
     NEED_GRAD();
     TRY(enqueue_solve(ctx));
     // what the iterators ask about the step next -- max |x|, |x|, x'Hx, g'x (src/optimize.jl:149, src/iterators.jl:160-163) --
@@ -337,10 +360,11 @@ int nlls_solve(nlls_ctx* ctx, double* x_out) {
     if (precompute) { status[0] = (int32_t)ctx->h_scalars[10]; ctx->step_cached = true; ctx->c_maxabs = ctx->h_scalars[1]; ctx->c_sumsq = ctx->h_scalars[2]; ctx->c_gx = ctx->h_scalars[5]; ctx->c_xAx = ctx->h_scalars[8]; ctx->c_xx = ctx->h_scalars[9]; }
     if (status[0] != 0) return status_error(ctx, status[0], "factorisation met a non-positive pivot");
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 // One Levenberg-Marquardt trial in one call and one synchronisation (src/iterators.jl:149-157): uniformscaling!(H, dlambda),
 // solve!, negate!, update!(to, from, x), cost(to).  Same kernels, same order as the separate entry points.
-int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, double* cost_out) {
+int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, double* cost_out) { NLLS_API_BEGIN
     NEED_GRAD_LAZY(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
     const bool mf = mf_trial(ctx, from);           // matrix-free: the eliminated rows of A.data are neither needed nor formed (nlls_mf.hip)
     TRY(ensure_grad(ctx, mf ? 1 : 2));             // (a trial right behind a REJECTED one: the look-ahead sweep of that trial's point is in A and b)
@@ -411,12 +435,13 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
     if (status[0] != 0) return status_error(ctx, status[0], "factorisation met a non-positive pivot");
     if (cost_out) *cost_out = ctx->h_scalars[0];
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 // The part of one Levenberg-Marquardt trial that follows the solve (src/iterators.jl:155-163), for sharded runs: with the
 // step x complete on this rank (after the stage-2 reduction) -- update!(to, from, x), cost(to), fast_bAb(H, x), dot(g, x),
 // maximum(abs, x), |x|^2 -- in one enqueue and one synchronisation.  out = [cost, x'Hx, g'x, max|x|, |x|^2]; under
 // nlls_set_shard the first three are this rank's PARTIAL sums (the caller adds them over ranks), the last two are global.
-int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
+int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) { NLLS_API_BEGIN
     NEED_GRAD(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
     TRY(enqueue_lm_trial_tail(ctx, to, from));     // step statistics + quadratic form + retraction in one launch, the cost sweep, one finishing launch
     if (!out) return NLLS_OK;                      // enqueue only: the eleven scalars stay on the device (reduce buffer 3) for a device-side gather
@@ -432,16 +457,18 @@ int nlls_trial_local(nlls_ctx* ctx, int32_t to, int32_t from, double* out) {
     }
     if ((int32_t)ctx->h_scalars[10] != 0) return status_error(ctx, (int32_t)ctx->h_scalars[10], "factorisation met a zero pivot");
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 // nlls_solve_finish_async for a sharded LM trial: the reduced part of the step stays on every rank (no stage-2 reduction afterwards)
-int nlls_solve_finish_replicated(nlls_ctx* ctx) {
+int nlls_solve_finish_replicated(nlls_ctx* ctx) { NLLS_API_BEGIN
     NEED_GRAD(); ctx->replicate_xr = true; const int rc = enqueue_solve_finish(ctx); ctx->replicate_xr = false;
     if (rc != NLLS_OK) return rc;
     ctx->solved = true; ctx->step_cached = false; return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 // this rank's share of a variable set: its own eliminated blocks' variables, on rank 0 also everything else; zeros elsewhere --
 // the sum over ranks is the complete set (what a sharded optimisation hands back at the end)
-int nlls_get_variables_owned(nlls_ctx* ctx, int32_t which, double* packed) {
+int nlls_get_variables_owned(nlls_ctx* ctx, int32_t which, double* packed) { NLLS_API_BEGIN
     TRY(nlls_get_variables(ctx, which, packed));
     if (ctx->nranks == 1) return NLLS_OK;
     for (int64_t i = 0; i < ctx->info.nvar; ++i) {
@@ -451,6 +478,7 @@ int nlls_get_variables_owned(nlls_ctx* ctx, int32_t which, double* packed) {
         if (owner != ctx->rank) for (uint32_t q = ctx->var_off[i]; q < ctx->var_off[i + 1]; ++q) packed[q] = 0.0;
     }
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 // optimizesingles!(problem, options, indices)  src/optimize.jl:60-76,183-205
 int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices, const int64_t* cptr, const int32_t* cgroup, const int64_t* cindex,
@@ -528,15 +556,16 @@ int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices
     if (iters_out) for (int64_t i = 0; i < nsel; ++i) iters_out[i] = (int64_t)hit[(size_t)i];
     return NLLS_OK;
 }
-int nlls_set_option(nlls_ctx* ctx, int32_t option, int64_t value) {
+int nlls_set_option(nlls_ctx* ctx, int32_t option, int64_t value) { NLLS_API_BEGIN
     if (!ctx) return NLLS_ERR_INVALID_ARG;
     switch (option) {
     case NLLS_OPT_MATERIALIZE: ctx->mf_on = value == 0; return NLLS_OK;          // (takes effect with the next nlls_lm_trial / nlls_sweep_gradhess; what A and b hold is tracked either way)
     case NLLS_OPT_LOOKAHEAD:   ctx->spec_on = value != 0; return NLLS_OK;
     }
     return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_set_option: unknown option");
+    NLLS_API_END(ctx)
 }
-int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
+int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) { NLLS_API_BEGIN
     NEED_READY(); if (!out || n < 1) return NLLS_ERR_INVALID_ARG;
     int32_t status[16] = {0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
@@ -549,66 +578,76 @@ int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) {
                               ctx->mf_trials, ctx->mf_reduced_sweeps, ctx->full_sweeps /* matrix-free LM trials, sweeps of the reduced rows only, full accumulate sweeps since the upload */};
     for (int i = 0; i < n && i < 26; ++i) out[i] = vals[i];
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_set_step(nlls_ctx* ctx, const double* x) {
+int nlls_set_step(nlls_ctx* ctx, const double* x) { NLLS_API_BEGIN
     NEED_READY(); if (!x) return NLLS_ERR_INVALID_ARG;
     ctx->tE_valid = false; ctx->step_cached = false;   // the step is no longer the one the last solve produced
     HIPCHK(hipMemcpyAsync(ctx->x.p, x, sizeof(double) * ctx->info.ndof, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_get_step(nlls_ctx* ctx, double* x_out) {
+int nlls_get_step(nlls_ctx* ctx, double* x_out) { NLLS_API_BEGIN
     NEED_READY(); if (!x_out) return NLLS_ERR_INVALID_ARG;
     HIPCHK(hipMemcpyAsync(x_out, ctx->x.p, sizeof(double) * ctx->info.ndof, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_step_maxabs(nlls_ctx* ctx, double* out) {
+int nlls_step_maxabs(nlls_ctx* ctx, double* out) { NLLS_API_BEGIN
     NEED_READY(); if (ctx->step_cached) { if (out) *out = ctx->c_maxabs; return NLLS_OK; }
     TRY(enqueue_step_stats(ctx)); TRY(fetch_scalars(ctx, 1, 2));
     if (out) *out = ctx->h_scalars[1]; return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_step_norm(nlls_ctx* ctx, double* out) {
+int nlls_step_norm(nlls_ctx* ctx, double* out) { NLLS_API_BEGIN
     NEED_READY(); if (ctx->step_cached) { if (out) *out = std::sqrt(ctx->c_sumsq); return NLLS_OK; }
     TRY(enqueue_step_stats(ctx)); TRY(fetch_scalars(ctx, 1, 2));
     if (out) *out = std::sqrt(ctx->h_scalars[2]); return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out) {
+int nlls_quadform(nlls_ctx* ctx, double* xHx_out, double* gx_out) { NLLS_API_BEGIN
     NEED_GRAD_LAZY();
     if (ctx->step_cached) { if (xHx_out) *xHx_out = ctx->c_xAx + ctx->lambda * ctx->c_xx; if (gx_out) *gx_out = ctx->c_gx; return NLLS_OK; }   // damping may have changed since
     TRY(ensure_grad(ctx, 2)); TRY(ensure_reduced_summed(ctx));
     TRY(enqueue_quadform(ctx, ctx->x.p, 4)); TRY(comm_reduce(ctx, ctx->scalars.p + 4, 2, NLLS_REDUCE_SUM)); TRY(fetch_scalars(ctx, 4, 2));
     if (xHx_out) *xHx_out = ctx->h_scalars[4]; if (gx_out) *gx_out = ctx->h_scalars[5];
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from) {
+int nlls_retract(nlls_ctx* ctx, int32_t to, int32_t from) { NLLS_API_BEGIN
     NEED_READY(); if (!valid_set(to) || !valid_set(from) || to == from) return NLLS_ERR_INVALID_ARG;
     spec_note_write(ctx, to);
     return enqueue_retract(ctx, to, from);
+    NLLS_API_END(ctx)
 }
 
 // ---- multi-GPU: local phases + reduce buffers.  Under nlls_set_shard(rank, nranks > 1):
 //   nlls_sweep_cost / nlls_quadform / nlls_max_abs_diag / nlls_grad_* return this rank's PARTIAL values (the caller
 //   sums, or takes the max of, them over ranks); the *_local / *_finish pairs bracket the buffer reductions.
-int nlls_sweep_gradhess_local(nlls_ctx* ctx) {
+int nlls_sweep_gradhess_local(nlls_ctx* ctx) { NLLS_API_BEGIN
     NEED_READY(); ctx->spec_pending = false; ctx->spec_stale = false; TRY(enqueue_sweep_gradhess(ctx));
     ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false; ctx->reduced_summed = true;     // (the caller sums the reduce buffer)
     if (ctx->nranks > 1) TRY(enqueue_pack_reduce0(ctx));
     return NLLS_OK;                                  // enqueue only: the reduce buffer is complete in stream order
+    NLLS_API_END(ctx)
 }
-int nlls_sweep_gradhess_finish(nlls_ctx* ctx, double* cost_out) {
+int nlls_sweep_gradhess_finish(nlls_ctx* ctx, double* cost_out) { NLLS_API_BEGIN
     NEED_GRAD();
     if (ctx->nranks > 1) TRY(enqueue_unpack_reduce0(ctx));
     if (!cost_out) return NLLS_OK;                   // cost not wanted (src/optimize.jl:169 discards it): no synchronisation
     TRY(fetch_scalars(ctx, 0, 1)); *cost_out = ctx->h_scalars[0]; return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_sweep_cost_local(nlls_ctx* ctx, int32_t which) { NEED_READY(); if (!valid_set(which)) return NLLS_ERR_INVALID_ARG; return enqueue_sweep_cost(ctx, which); }
-int nlls_sweep_cost_finish(nlls_ctx* ctx, double* cost_out) { NEED_READY(); TRY(fetch_scalars(ctx, 0, 1)); if (cost_out) *cost_out = ctx->h_scalars[0]; return NLLS_OK; }
-int nlls_solve_local(nlls_ctx* ctx) {
+int nlls_sweep_cost_local(nlls_ctx* ctx, int32_t which) { NLLS_API_BEGIN NEED_READY(); if (!valid_set(which)) return NLLS_ERR_INVALID_ARG; return enqueue_sweep_cost(ctx, which); NLLS_API_END(ctx) }
+int nlls_sweep_cost_finish(nlls_ctx* ctx, double* cost_out) { NLLS_API_BEGIN NEED_READY(); TRY(fetch_scalars(ctx, 0, 1)); if (cost_out) *cost_out = ctx->h_scalars[0]; return NLLS_OK; NLLS_API_END(ctx) }
+int nlls_solve_local(nlls_ctx* ctx) { NLLS_API_BEGIN
     NEED_GRAD(); TRY(enqueue_solve_local(ctx));
     return NLLS_OK;                                  // enqueue only, as above
+    NLLS_API_END(ctx)
 }
-int nlls_solve_finish(nlls_ctx* ctx, double* x_out) {
+int nlls_solve_finish(nlls_ctx* ctx, double* x_out) { NLLS_API_BEGIN
     NEED_GRAD(); TRY(enqueue_solve_finish(ctx));
     int32_t status[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
@@ -617,11 +656,13 @@ int nlls_solve_finish(nlls_ctx* ctx, double* x_out) {
     ctx->solved = true;
     if (status[0] != 0) return status_error(ctx, status[0], "factorisation met a zero pivot");
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_solve_finish_async(nlls_ctx* ctx) {          // enqueue only: the status comes home with nlls_trial_local's scalars
+int nlls_solve_finish_async(nlls_ctx* ctx) { NLLS_API_BEGIN           // enqueue only: the status comes home with nlls_trial_local's scalars
     NEED_GRAD(); TRY(enqueue_solve_finish(ctx)); ctx->solved = true; ctx->step_cached = false; return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count) {
+int nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t* count) { NLLS_API_BEGIN
     NEED_READY(); if (!dev_ptr || !count) return NLLS_ERR_INVALID_ARG;
     if (stage == 0) { *dev_ptr = ctx->redbuf.p; *count = ctx->redbuf_len; return NLLS_OK; }                                   // after sweep_gradhess_local
     if (stage == 1) { *dev_ptr = ctx->S.p; *count = (int64_t)ctx->s_elems + ctx->nred; return NLLS_OK; }                      // after solve_local: [S | s]
@@ -630,14 +671,16 @@ int nlls_get_reduce_buffer(nlls_ctx* ctx, int32_t stage, void** dev_ptr, int64_t
     // [1] max|x|, [9] |x|^2 over this rank's share of the step, [10] factorisation status
     if (stage == 3) { *dev_ptr = ctx->scalars.p; *count = 11; return NLLS_OK; }
     return fail(ctx, NLLS_ERR_INVALID_ARG, "unknown reduce stage");
+    NLLS_API_END(ctx)
 }
-int nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count, int64_t* own_offset, int64_t* own_count) {
+int nlls_get_step_shard(nlls_ctx* ctx, void** dev_ptr_x, int64_t* reduced_count, int64_t* own_offset, int64_t* own_count) { NLLS_API_BEGIN
     NEED_READY();
     if (dev_ptr_x) *dev_ptr_x = ctx->x.p; if (reduced_count) *reduced_count = ctx->nred;
     if (own_offset) *own_offset = 0; if (own_count) *own_count = ctx->info.ndof;
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_get_grad_owned(nlls_ctx* ctx, double* b_out) {
+int nlls_get_grad_owned(nlls_ctx* ctx, double* b_out) { NLLS_API_BEGIN
     TRY(nlls_get_grad(ctx, b_out));
     if (ctx->nranks > 1) {
         std::vector<double> mask((size_t)ctx->info.ndof);
@@ -645,12 +688,14 @@ int nlls_get_grad_owned(nlls_ctx* ctx, double* b_out) {
         for (size_t i = 0; i < mask.size(); ++i) if (mask[i] == 0.0) b_out[i] = 0.0;
     }
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_get_shard_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
+int nlls_get_shard_info(nlls_ctx* ctx, int64_t* out, int32_t n) { NLLS_API_BEGIN
     NEED_READY(); if (!out || n < 1) return NLLS_ERR_INVALID_ARG;
     const int64_t vals[6] = {ctx->rank, ctx->nranks, ctx->local_ncost, ctx->local_nnz_data, ctx->local_ndof, ctx->replicated ? ctx->shard_nranks : 0};
     for (int i = 0; i < n && i < 6; ++i) out[i] = vals[i];
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 
 // ---- timing helpers: HIP events on the context's stream around `reps` back-to-back enqueues -------------
@@ -668,27 +713,32 @@ static int time_loop(nlls_ctx* ctx, int reps, float* ms_avg, int (*fn)(nlls_ctx*
     return NLLS_OK;
 }
 
-int nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+int nlls_time_sweep_gradhess(nlls_ctx* ctx, int32_t reps, float* ms_avg) { NLLS_API_BEGIN
     NEED_READY(); ctx->spec_pending = false; ctx->spec_stale = false; int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c); });
     ctx->have_grad = true; ctx->reduced_summed = true; return rc;
+    NLLS_API_END(ctx)
 }
-int nlls_time_sweep_accumulate(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+int nlls_time_sweep_accumulate(nlls_ctx* ctx, int32_t reps, float* ms_avg) { NLLS_API_BEGIN
     NEED_READY(); ctx->spec_pending = false; ctx->spec_stale = false; int rc = time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_gradhess(c, false); });
     ctx->have_grad = true; ctx->reduced_summed = true; return rc;
+    NLLS_API_END(ctx)
 }
-int nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+int nlls_time_sweep_cost(nlls_ctx* ctx, int32_t reps, float* ms_avg) { NLLS_API_BEGIN
     NEED_READY(); return time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_sweep_cost(c, NLLS_VARS_CURRENT); });
+    NLLS_API_END(ctx)
 }
-int nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+int nlls_time_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) { NLLS_API_BEGIN
     NEED_GRAD(); return time_loop(ctx, reps, ms_avg, [](nlls_ctx* c) { return enqueue_solve(c); });
+    NLLS_API_END(ctx)
 }
-int nlls_get_memory_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
+int nlls_get_memory_info(nlls_ctx* ctx, int64_t* out, int32_t n) { NLLS_API_BEGIN
     NEED_READY(); if (!out || n < 4) return NLLS_ERR_INVALID_ARG;
     out[0] = ctx->hot_bytes; out[1] = (int64_t)ctx->arena.n; out[2] = (int64_t)sizeof(double) * ctx->info.nnz_data; out[3] = (int64_t)sizeof(double) * ((int64_t)ctx->s_elems + ctx->nred);
     if (n >= 5) out[4] = (int64_t)sizeof(double) * ((ctx->solve_mode == SOLVE_TSPARSE ? ctx->tsp.nslots_assembled * (int64_t)TSP_TE : (int64_t)ctx->s_elems) + ctx->nred);   // what a sharded trial sums over ranks
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_check_analytic(nlls_ctx* ctx, double* out, int32_t n) {
+int nlls_check_analytic(nlls_ctx* ctx, double* out, int32_t n) { NLLS_API_BEGIN
     NEED_READY(); if (!out || n < 7) return NLLS_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     int64_t nb = 0; TRY(enqueue_check_analytic(ctx, nullptr, &nb));
@@ -700,16 +750,18 @@ int nlls_check_analytic(nlls_ctx* ctx, double* out, int32_t n) {
     HIPCHK(hipMemcpyAsync(h.data(), d.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int64_t b = 0; b < nb; ++b) for (int q = 0; q < 7; ++q) { const double v = h[(size_t)b * 8 + q]; if (!(v <= out[q])) out[q] = v; }   // (a NaN difference comes through)
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_flush_cache(nlls_ctx* ctx, int64_t bytes) {
+int nlls_flush_cache(nlls_ctx* ctx, int64_t bytes) { NLLS_API_BEGIN
     if (!ctx || bytes <= 0 || bytes > ((int64_t)8 << 30)) return NLLS_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     const size_t half = ((size_t)bytes / 2 + 255) & ~(size_t)255;
     if (ctx->flushbuf.n < 2 * half) { HIPCHK(ctx->flushbuf.alloc(2 * half)); HIPCHK(hipMemsetAsync(ctx->flushbuf.p, 1, 2 * half, ctx->stream)); }
     HIPCHK(hipMemcpyAsync(ctx->flushbuf.p + half, ctx->flushbuf.p, half, hipMemcpyDeviceToDevice, ctx->stream));
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples) {
+int nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples) { NLLS_API_BEGIN
     if (!ctx) return NLLS_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     if (ms_avg || ms_min || ms_max || nsamples) {            // read what has been recorded so far (synchronises the stream)
@@ -742,9 +794,10 @@ int nlls_profile_sweep(nlls_ctx* ctx, int32_t on, float* ms_avg, float* ms_min, 
     if (on && ctx->prof_ev.empty()) { ctx->prof_ev.resize(128); for (auto& e : ctx->prof_ev) if (hipEventCreate(&e) != hipSuccess) return NLLS_ERR_HIP; }
     ctx->prof_sweep = on != 0; if (on) ctx->prof_count = 0;
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 // the event pairs alone: begin .. end of the accumulate dispatch(es) as the command processor stamped them -- what rocprofv3 --kernel-trace reports per dispatch
-int nlls_profile_sweep_dispatch(nlls_ctx* ctx, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples) {
+int nlls_profile_sweep_dispatch(nlls_ctx* ctx, float* ms_avg, float* ms_min, float* ms_max, int64_t* nsamples) { NLLS_API_BEGIN
     if (!ctx) return NLLS_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -753,8 +806,9 @@ int nlls_profile_sweep_dispatch(nlls_ctx* ctx, float* ms_avg, float* ms_min, flo
     for (int64_t i = 0; i < n; ++i) { float ms = 0.f; if (hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) != hipSuccess) { (void)hipGetLastError(); continue; } sum += ms; mn = std::min(mn, ms); mx = std::max(mx, ms); ++ok; }
     if (ms_avg) *ms_avg = ok ? (float)(sum / ok) : 0.f; if (ms_min) *ms_min = ok ? mn : 0.f; if (ms_max) *ms_max = mx; if (nsamples) *nsamples = ok;
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
+int nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) { NLLS_API_BEGIN
     NEED_GRAD();
     if (ctx->nred == 0 || ctx->elim_slab) { if (ms_avg) *ms_avg = 0.f; return NLLS_OK; }   // (slab + gather assembly: the tiles are consumed in place)
     if (ctx->solve_mode == SOLVE_BAND && ctx->bcr.ready) {
@@ -771,6 +825,7 @@ int nlls_time_reduced_solve(nlls_ctx* ctx, int32_t reps, float* ms_avg) {
     ctx->S_zeroed = false; ctx->solved = false;
     if (ms_avg) *ms_avg = ms_both > ms_asm ? ms_both - ms_asm : 0.f;
     return rc;
+    NLLS_API_END(ctx)
 }
 
 }  // extern "C"

@@ -94,20 +94,22 @@ void comm_release(nlls_ctx* c) {
 }  // namespace nlls
 
 extern "C" {
-int nlls_set_allreduce(nlls_ctx* ctx, nlls_allreduce_fn fn, void* user) {
+int nlls_set_allreduce(nlls_ctx* ctx, nlls_allreduce_fn fn, void* user) { NLLS_API_BEGIN
     if (!ctx) return NLLS_ERR_INVALID_ARG;
     comm_release(ctx);
     ctx->reduce_fn = fn; ctx->reduce_user = fn ? user : nullptr;
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_comm_unique_id(void* id128) {
+int nlls_comm_unique_id(void* id128) { NLLS_API_BEGIN
     if (!id128) return NLLS_ERR_INVALID_ARG;
     if (!rccl().load()) return NLLS_ERR_UNSUPPORTED;
     ncclUniqueId id; if (rccl().get_unique_id(&id) != ncclSuccess) return NLLS_ERR_HIP;
     memcpy(id128, &id, 128);
     return NLLS_OK;
+    NLLS_API_END(nullptr)
 }
-int nlls_comm_init_rccl(nlls_ctx* ctx, const void* id128) {
+int nlls_comm_init_rccl(nlls_ctx* ctx, const void* id128) { NLLS_API_BEGIN
     if (!ctx || !id128) return NLLS_ERR_INVALID_ARG;
     if (!rccl().load()) return fail(ctx, NLLS_ERR_UNSUPPORTED, rccl().err);
     (void)hipSetDevice(ctx->device);
@@ -118,20 +120,23 @@ int nlls_comm_init_rccl(nlls_ctx* ctx, const void* id128) {
     if (r != ncclSuccess) return fail(ctx, NLLS_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().error_string(r));
     ctx->rccl_comm = comm; ctx->reduce_fn = rccl_allreduce; ctx->reduce_user = ctx;
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_comm_post_flag(nlls_ctx* ctx, double value) {
+int nlls_comm_post_flag(nlls_ctx* ctx, double value) { NLLS_API_BEGIN
     if (!ctx || !(value >= 0.0)) return NLLS_ERR_INVALID_ARG;
     ctx->comm_posted = value; ctx->comm_gathered = false;      // (a new iteration: the answer must come from a trial that follows this post)
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_comm_agreed_flag(nlls_ctx* ctx, double local_value, double* out) {
+int nlls_comm_agreed_flag(nlls_ctx* ctx, double local_value, double* out) { NLLS_API_BEGIN
     if (!ctx || !out) return NLLS_ERR_INVALID_ARG;
     // the agreed value only when the last trial really gathered it: with an all-reduce installed on a DENSE system (or before the first trial) nothing
     // writes comm_agreed, and answering 0 would silently disable the caller's deadline (advisor, round 4)
     *out = (ctx->reduce_fn && ctx->comm_gathered) ? ctx->comm_agreed : local_value;
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
-int nlls_comm_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
+int nlls_comm_info(nlls_ctx* ctx, int64_t* out, int32_t n) { NLLS_API_BEGIN
     if (!ctx || !out || n < 4) return NLLS_ERR_INVALID_ARG;
     out[0] = 1; out[1] = 0; out[2] = ctx->device; out[3] = 0;
     if (ctx->rccl_comm && rccl().lib && rccl().comm_count && rccl().comm_user_rank) {
@@ -142,5 +147,6 @@ int nlls_comm_info(nlls_ctx* ctx, int64_t* out, int32_t n) {
         out[0] = cnt; out[1] = rk; out[2] = dev; out[3] = 1;
     } else if (ctx->reduce_fn) { out[0] = ctx->nranks; out[1] = ctx->rank; out[3] = 2; }
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 }

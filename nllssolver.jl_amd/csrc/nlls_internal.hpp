@@ -1,13 +1,24 @@
 // nlls_internal.hpp -- declarations shared by the translation units of libnlls_amd.so
 #pragma once
 
+#include <exception>
+#include <new>
+
 #include "nlls_ctx.hpp"
 
 #define NLLS_FOR_EACH_RES(X) \
     X(NLLS_RES_BA_AFFINE) X(NLLS_RES_ROSENBROCK_A) X(NLLS_RES_ROSENBROCK_B) X(NLLS_RES_ROSENBROCK_2D) \
     X(NLLS_RES_CURVE_EXP4) X(NLLS_RES_ADAPTIVE_MEAN) X(NLLS_RES_BA_SO3) X(NLLS_RES_BA_SO3_ADAPTIVE) X(NLLS_RES_LINEAR3) X(NLLS_COST_LINEAR3) X(NLLS_RES_SCALE_MIX) NLLS_USER_RES(X)
 
+// Every extern "C" entry point runs between these two (nothing may throw or longjmp across the ccall boundary): a C++ exception -- std::bad_alloc of a host-side
+// work vector, above all -- becomes NLLS_ERR_HIP with the message in nlls_last_error.
+#define NLLS_API_BEGIN try {
+#define NLLS_API_END(C) } catch (const std::bad_alloc&) { return nlls::api_exception(C, "out of host memory (std::bad_alloc)"); } \
+    catch (const std::exception& e_) { return nlls::api_exception(C, e_.what()); } catch (...) { return nlls::api_exception(C, "unknown C++ exception"); }
+
 namespace nlls {
+
+inline int api_exception(nlls_ctx* c, const char* what) { if (c) { try { c->err = std::string("host exception: ") + what; } catch (...) {} } return NLLS_ERR_HIP; }
 
 struct ResDesc { int ndeps, nres, ndata, adaptive; int sk[MAX_SLOTS], sd[MAX_SLOTS]; };
 bool res_desc(int kind, ResDesc& d);

@@ -13,7 +13,13 @@
 #include <limits>
 #include <vector>
 
+#include <exception>
+
 #include "../../include/nlls_amd.h"
+
+// (this file sees the public header only: the boundary guard of nlls_internal.hpp, restated -- no exception leaves nlls_lm_iterations)
+#define NLLS_API_BEGIN try {
+#define NLLS_API_END(C) } catch (...) { return NLLS_ERR_HIP; }
 
 namespace {
 int64_t monotonic_ns() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
@@ -66,7 +72,7 @@ int iterate_levmar(nlls_ctx* ctx, const nlls_lm_options* opt, nlls_lm_state* st,
 }
 }  // namespace
 
-extern "C" int nlls_lm_iterations(nlls_ctx* ctx, const nlls_lm_options* opt, nlls_lm_state* st, int64_t niter) {
+extern "C" int nlls_lm_iterations(nlls_ctx* ctx, const nlls_lm_options* opt, nlls_lm_state* st, int64_t niter) { NLLS_API_BEGIN
     if (!ctx || !opt || !st) return NLLS_ERR_INVALID_ARG;
     const bool timed = opt->stoptime_ns > 0;
     for (int64_t it = 0; it < niter; ++it) {
@@ -108,4 +114,5 @@ extern "C" int nlls_lm_iterations(nlls_ctx* ctx, const nlls_lm_options* opt, nll
         st->gradientcomputations++;
     }
     return NLLS_OK;
+    NLLS_API_END(ctx)
 }

@@ -47,6 +47,9 @@ constexpr uint32_t HEAVY_MAX_ENTRIES_DEFAULT = 1024;   // entries per heavy tile
 // group whose cost sweep reads a light entry list instead (Group::cost_list), voff / dest of compact heavy lists (one word per tile is
 // read), the per-block neighbour records of the generic elimination, the all-blocks list of the quadratic form (the loop uses the short
 // one), the chain / dense solvers' workspace when block cyclic reduction solves the band.
+// (round 6: the matrix-free trial's own buffers -- Group::mf_data / mf_voff, the slabs, its descriptors and partials, 60 MB at BASELINE config 4 -- stay OUTSIDE: the arena is the
+// working set of the MATERIALISING loop, 250 of the cache's 256 MB; with them inside it was 275 MB and the accumulate launch of that loop went from 45 to 51 us.  The matrix-free loop's
+// own working set is 100 MB: wherever its buffers lie, it fits.)
 namespace {
 struct HotItem { void** pp; size_t bytes; bool* owned; };
 template <class T> void hot(std::vector<HotItem>& v, DevBuf<T>& b) { if (b.p && b.n) v.push_back(HotItem{reinterpret_cast<void**>(&b.p), b.n * sizeof(T), &b.owned}); }
@@ -60,12 +63,11 @@ void hot_set(nlls_ctx* c, std::vector<HotItem>& v) {
             hot(v, E.fslot); hot(v, E.ftiles); hot(v, E.frowx); }
         if (G.fold) { hot(v, G.frows); hot(v, G.fcons); hot(v, G.fslab); }
         if (G.cost_list < 0 || !c->info.is_sparse) { hot(v, G.data); hot(v, G.voff); }
-        hot(v, G.mf_data); hot(v, G.mf_voff);
         hot(v, G.fixedcost); hot(v, G.dense.data); hot(v, G.dense.voff); hot(v, G.dense.brow);
     }
     hot(v, c->d_var_kind); hot(v, c->d_var_dim); hot(v, c->d_var_off); hot(v, c->d_var_boff); hot(v, c->d_diag_off); hot(v, c->d_blocksizes);
     hot(v, c->d_zero_off); hot(v, c->d_zero_len); hot(v, c->d_zero_b_off); hot(v, c->d_zero_b_len); hot(v, c->partials); hot(v, c->scalars);
-    hot(v, c->S); hot(v, c->Cinv); hot(v, c->tE); hot(v, c->mf_q); hot(v, c->d_mf_desc); hot(v, c->d_status); hot(v, c->d_copy); hot(v, c->d_red_boff); hot(v, c->d_blk_slow);
+    hot(v, c->S); hot(v, c->Cinv); hot(v, c->tE); hot(v, c->d_status); hot(v, c->d_copy); hot(v, c->d_red_boff); hot(v, c->d_blk_slow);
     hot(v, c->d_elim_desc); hot(v, c->d_elim_rc); hot(v, c->d_elim_diag); hot(v, c->d_elim_boff); hot(v, c->d_elim_dim); hot(v, c->d_fast_members); hot(v, c->d_fast_groups);
     if (c->bcr.ready) { hot(v, c->bcr.ws); hot(v, c->bcr.d_upd); hot(v, c->bcr.d_elim); } else hot(v, c->Lwork);
 }

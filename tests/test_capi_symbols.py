@@ -39,6 +39,29 @@ def test_static_helpers_match_registry():
         assert L.nlls_var_storage(kind, dim) == K.var_storage(kind, dim) and L.nlls_var_dof(kind, dim) == K.var_dof(kind, dim)
 
 
+def test_entry_points_never_throw_across_the_boundary():
+    """nothing throws or longjmps across the ccall boundary.  Every extern "C" body of csrc/nlls_capi.cpp, nlls_lm.cpp and nlls_comm.cpp sits between NLLS_API_BEGIN /
+    NLLS_API_END (a C++ exception becomes NLLS_ERR_HIP + nlls_last_error), and a graph size no reduced system has is refused before a work vector is sized by it: an error code
+    comes back, not std::terminate."""
+    import ctypes as C
+    L = _capi.lib()
+    n = 2 ** 31 - 1
+    adjptr = np.zeros(2, np.int64); adj = np.zeros(1, np.int32); perm = np.zeros(1, np.int32)
+    assert L.nlls_rcm_order(n, _capi._p(adjptr), _capi._p(adj), _capi._p(perm)) == _capi.ERR_INVALID_ARG
+    one = np.zeros(4, np.int32); col = np.zeros(4, np.int64)
+    assert L.nlls_nd_tiles(n, 0, _capi._p(adjptr), _capi._p(adj), _capi._p(one), _capi._p(one), _capi._p(one), 1, _capi._p(one), _capi._p(one), _capi._p(col), 0, None) == _capi.ERR_INVALID_ARG
+    assert L.nlls_rcm_order(-1, None, None, None) == _capi.ERR_INVALID_ARG
+    # the guard pair is on every entry point that returns a status (a source check: the macro pair cannot be observed from outside without exhausting the host's memory)
+    import re
+    for f in ("nlls_capi.cpp", "nlls_lm.cpp", "nlls_comm.cpp"):
+        src = open(os.path.join(ROOT, "nllssolver.jl_amd", "csrc", f)).read()
+        heads = re.findall(r"^(?:extern \"C\" )?int\s+(nlls_\w+)\([^\n]*\)\s*\{([^\n]*)$", src, flags=re.M)
+        assert heads, f
+        for name, rest in heads:
+            assert "NLLS_API_BEGIN" in rest or name == "nlls_upload_structure", (f, name)      # (nlls_upload_structure carries its try / catch written out)
+    assert src.count("NLLS_API_BEGIN") >= 1
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

@@ -80,6 +80,24 @@ def check_problem(problem, unfixed=None, flags=0, lam_scale=1e-6, expect_sparse=
     xHx2, gx2 = ctx.quadform()
     assert np.isclose(xHx2, xHx, rtol=1e-8) and np.isclose(gx2, gx, rtol=1e-8), (xHx2, xHx, gx2, gx)
     assert np.isclose(ctx.step_maxabs(), np.max(np.abs(x_gpu)), rtol=1e-8)
+    # ---- BOTH paths of the trial (round 6).  Where nlls_upload_structure found the matrix-free trial applicable, the call above WAS matrix-free (the cost blocks evaluated inside the
+    # elimination and the back-substitution, A.data's eliminated rows never read): the same trial once more with NLLS_OPT_MATERIALIZE -- the round-5 kernels on the materialised A.data --
+    # must give the same step, point, cost and statistics; and against the oracle's x the matrix-free step holds the tolerance of the materialised one.
+    st = ctx.solve_stats(); x_trial = ctx.get_step()
+    assert rel(x_trial, ols.x) < RTOL_X, f"trial step vs oracle {rel(x_trial, ols.x)}"
+    if st["mf_trials"] > 0:
+        v_mf = ctx.get_variables(_capi.VARS_NEXT)
+        ctx.set_option(_capi.OPT_MATERIALIZE, 1)
+        ctx.set_variables(np.zeros_like(v_gpu), _capi.VARS_NEXT)
+        c_mat = ctx.lm_trial(0.0)
+        assert ctx.solve_stats()["mf_trials"] == st["mf_trials"]                 # (this one was not matrix-free)
+        assert np.isclose(c_trial, c_mat, rtol=1e-9, atol=1e-13 * abs(c_gpu)), (c_trial, c_mat)      # (a noise-free problem's trial cost is a cancellation: the tolerance of the comparison above)
+        assert rel(x_trial, ctx.get_step()) < 1e-9 and rel(v_mf, ctx.get_variables(_capi.VARS_NEXT)) < 1e-11
+        xHx3, gx3 = ctx.quadform()
+        assert np.isclose(xHx3, xHx2, rtol=1e-9) and np.isclose(gx3, gx2, rtol=1e-9)
+        ctx.set_option(_capi.OPT_MATERIALIZE, 0)
+        # A.data and b on demand behind a matrix-free trial: what the first sweep left (the linearisation point has not moved)
+        assert rel(ctx.get_bsm_data(), A_ora) < RTOL and rel(ctx.get_grad(), ols.b) < RTOL
     ctx.close()
     return info
 
@@ -670,3 +688,77 @@ def test_ab_switches_select_paths_that_still_match_the_oracle(env, monkeypatch):
     for flags in (0, _capi.FLAG_NO_BAND):
         info = check_problem(p, flags=flags, lam_scale=1e-4)
         assert info.has_schur and info.nreduced_dof == 2100 and info.solve_mode == (1 if flags else 2)
+
+
+def _ba(ncam, npts, prop, seed, robust=None):
+    return synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, prop, seed=seed, robust=robust, outlier_frac=0.05 if robust else 0.0, outlier_sigma=0.05), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("ncam,npts,prop,robust", [(120, 3000, 0.06, None), (100, 10000, 0.1, "huber"), (200, 8000, 0.04, "huber2o"), (64, 2000, 0.2, "gm")])
+def test_matrix_free_trial_against_the_materialised_one_and_the_oracle(ncam, npts, prop, robust):
+    """nlls_mf.hip / nlls_mfb.hip (round 6): an LM trial that evaluates the cost blocks inside the Schur elimination and the back-substitution instead of reading the eliminated rows of
+    A.data -- against the SAME trial through the materialised kernels (NLLS_OPT_MATERIALIZE on one upload) and against the oracle's full sparse LDL' (src/linearsolver.jl:28-32): step
+    1e-7 (oracle) / 1e-9 (materialised), trial point, trial cost, x'Hx, g'x, max |x|.  The matrix-free assembly uses no atomics: two calls give the SAME BITS.  A rejected trial (more
+    damping from the same point) and an accepted one (swap, next trial) go through the look-ahead of the reduced rows."""
+    rk = {None: None, "huber": N.HuberKernel(0.01), "huber2o": N.Huber2oKernel(0.02), "gm": N.GemanMcclureKernel(0.05)}[robust]
+    p = _ba(ncam, npts, prop, 11, rk)
+    bi = np.arange(1, p.nvariables + 1, dtype=np.uint64)
+    op = oracle_problem(p); ols = op.linear_system(bi); ols.costgradhess()
+    ctx = _capi.Context(); info = ctx.upload(p.var_kind, p.var_dim, bi, p.groups())
+    assert info.has_schur and info.solve_mode in (1, 2)
+    ctx.set_variables(p.variables); c0 = ctx.sweep_gradhess()
+    assert ctx.sweep_cost() == c0                                     # one fixed sum for every cost of the path
+    lam = ols.max_abs_diag() * 1e-6
+    res = {}
+    for name, mat in (("mat", 1), ("mf", 0), ("mf2", 0)):
+        ctx.set_option(_capi.OPT_MATERIALIZE, mat)
+        if name != "mf2":                                             # (mf2: the SAME linearisation once more -- the accumulate sweep's LDS atomics are not bit-reproducible from sweep to sweep, the trial is)
+            ctx.set_variables(p.variables); ctx.sweep_gradhess()
+        n0 = ctx.solve_stats()["mf_trials"]
+        ct = ctx.lm_trial(lam if name != "mf2" else 0.0)
+        assert (ctx.solve_stats()["mf_trials"] - n0) == (0 if mat else 1), "the structure should qualify for the matrix-free trial"
+        res[name] = (ct, ctx.get_step(), ctx.get_variables(_capi.VARS_NEXT), ctx.quadform(), ctx.step_maxabs(), ctx.step_norm())
+    assert ols.solve(lam) == 0
+    assert rel(res["mf"][1], ols.x) < RTOL_X and rel(res["mat"][1], ols.x) < RTOL_X
+    assert rel(res["mf"][1], res["mat"][1]) < 1e-9 and rel(res["mf"][2], res["mat"][2]) < 1e-11
+    assert np.isclose(res["mf"][0], res["mat"][0], rtol=1e-9, atol=1e-13 * abs(c0)) and np.allclose(res["mf"][3], res["mat"][3], rtol=1e-9) and np.isclose(res["mf"][4], res["mat"][4], rtol=1e-9)
+    assert res["mf"][0] == res["mf2"][0] and np.array_equal(res["mf"][1], res["mf2"][1]) and np.array_equal(res["mf"][2], res["mf2"][2])      # bit-reproducible
+    assert ctx.sweep_cost(_capi.VARS_NEXT) == res["mf2"][0]           # cost(trial point) == the trial's own cost, bit for bit
+    # a rejected trial (ten times the damping from the same point), then the accepted path: swap, sweep(NULL), next trial -- against the same sequence materialised
+    seq = {}
+    for name, mat in (("mf", 0), ("mat", 1)):
+        ctx.set_option(_capi.OPT_MATERIALIZE, mat)
+        ctx.set_variables(p.variables); ctx.sweep_gradhess()
+        a = ctx.lm_trial(lam); b = ctx.lm_trial(9 * lam)               # (damping accumulates: 10 lam)
+        ctx.damp(-10 * lam); ctx.swap_variables(_capi.VARS_CURRENT, _capi.VARS_NEXT); ctx.sweep_gradhess(want_cost=False)
+        c2 = ctx.lm_trial(lam)
+        seq[name] = (a, b, c2, ctx.get_step())
+    assert np.allclose(seq["mf"][:3], seq["mat"][:3], rtol=1e-9, atol=1e-13 * abs(c0)) and rel(seq["mf"][3], seq["mat"][3]) < 1e-8
+    ctx.close()
+
+
+def test_optimize_singles_invalidates_a_lookahead_sweep():
+    """Advisor (round 5): nlls_optimize_singles rewrites CURRENT in place; a look-ahead sweep of that very set (enqueued behind the last trial) must not be taken for the
+    linearisation at the relaxed point.  LM trial + accept + optimize_singles + sweep(NULL) + trial: the same with and without the look-ahead (NLLS_OPT_LOOKAHEAD)."""
+    p = _ba(60, 1500, 0.12, 5, N.HuberKernel(0.02))
+    bi = np.arange(1, p.nvariables + 1, dtype=np.uint64)
+    out = {}
+    for la in (1, 0):
+        for mat in (0, 1):
+            ctx = _capi.Context(); ctx.upload(p.var_kind, p.var_dim, bi, p.groups())
+            ctx.set_option(_capi.OPT_LOOKAHEAD, la); ctx.set_option(_capi.OPT_MATERIALIZE, mat)
+            ctx.set_variables(p.variables); ctx.sweep_gradhess(); lam = 1e-5 * ctx.max_abs_diag()
+            ctx.copy_variables(_capi.VARS_NEXT, _capi.VARS_CURRENT)
+            ctx.sweep_gradhess(want_cost=False); ctx.lm_trial(lam)            # (the second sweep of the set arms the look-ahead)
+            ctx.damp(-lam); ctx.swap_variables(_capi.VARS_CURRENT, _capi.VARS_NEXT)
+            pts = np.arange(61, 61 + 1500, dtype=np.int64)                       # every point on its own (src/optimize.jl:60-76)
+            # the points' cost lists: block k of the one group touches point varind[k, 1]
+            (g,) = p.groups(); vi = np.asarray(g["varind"]); order = np.argsort(vi[:, 1], kind="stable"); cnt = np.bincount(vi[:, 1] - 61, minlength=1500)
+            cptr = np.concatenate([[0], np.cumsum(cnt)])
+            ctx.optimize_singles(pts, cptr, np.zeros(len(order), np.int32), order.astype(np.int64), np.ones(len(order), np.int32), maxiters=3)
+            ctx.sweep_gradhess(want_cost=False)
+            c = ctx.lm_trial(lam)
+            out[(la, mat)] = (c, ctx.get_step()); ctx.close()
+    for mat in (0, 1):
+        assert np.isclose(out[(1, mat)][0], out[(0, mat)][0], rtol=1e-10), (mat, out[(1, mat)][0], out[(0, mat)][0])
+        assert rel(out[(1, mat)][1], out[(0, mat)][1]) < 1e-8
