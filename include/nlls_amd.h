@@ -280,6 +280,8 @@ int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
  *   NLLS_OPT_MATERIALIZE  value != 0: nlls_lm_trial eliminates from the materialised A.data (the round-5 path) although the structure qualifies for the
  *                         matrix-free trial; 0 (default): matrix-free where nlls_upload_structure found it applicable (NLLS_FLAG_MATERIALIZE: never).
  *   NLLS_OPT_LOOKAHEAD    value == 0: no look-ahead sweep behind an LM trial (the environment's NLLS_NO_LOOKAHEAD_SWEEP=1). */
+/* Device-timed NLLSResult buckets since the upload, nanoseconds: out[0] gradient, [1] cost, [2] solver, [3] trials counted (single-GPU sparse trials; others leave them untouched). */
+int  nlls_get_time_buckets(nlls_ctx* ctx, int64_t* out, int32_t n);
 #define NLLS_OPT_MATERIALIZE 1
 #define NLLS_OPT_LOOKAHEAD   2
 int  nlls_set_option(nlls_ctx* ctx, int32_t option, int64_t value);
@@ -323,6 +325,11 @@ typedef struct nlls_lm_state {
     int64_t iternum, fails, have_best, converged;
     int64_t linearsolvers, costcomputations, gradientcomputations, singulartrials;
     int64_t timesolver_ns, timegradient_ns;
+    int64_t timecost_ns;            /* (round 6, appended) NLLSResult.timecost (src/structs.jl:43, src/iterators.jl:157).  The three buckets are DEVICE times where the trials' launches
+                                     * time themselves (nlls_get_time_buckets): solver = start of the assembly launch .. start of the cost launch, cost = .. end of the finishing
+                                     * workgroup, gradient = end of a trial .. start of the next (the sweep between them and the host's turn-around).  Matrix-free trial: the cost
+                                     * blocks are evaluated INSIDE the assembly and back-substitution launches, so their evaluation is booked under solver, and cost is the finishing
+                                     * workgroup alone. */
 } nlls_lm_state;
 int  nlls_lm_iterations(nlls_ctx* ctx, const nlls_lm_options* options, nlls_lm_state* state, int64_t niter);
 /* One Levenberg-Marquardt trial (src/iterators.jl:149-157) in one call and one synchronisation:

@@ -31,7 +31,7 @@ nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_qua
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
 nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_profile_sweep_dispatch nlls_solve_finish_replicated nlls_get_variables_owned nlls_lm_iterations
-nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl nlls_comm_post_flag nlls_comm_agreed_flag nlls_comm_info nlls_get_memory_info nlls_flush_cache nlls_check_analytic nlls_set_option""".split()
+nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl nlls_comm_post_flag nlls_comm_agreed_flag nlls_comm_info nlls_get_memory_info nlls_flush_cache nlls_check_analytic nlls_set_option nlls_get_time_buckets""".split()
 
 
 class LmOptions(C.Structure):          # nlls_lm_options
@@ -42,7 +42,7 @@ class LmOptions(C.Structure):          # nlls_lm_options
 class LmState(C.Structure):            # nlls_lm_state
     _fields_ = [("lambda_", C.c_double), ("bestcost", C.c_double), ("cost", C.c_double), ("iternum", C.c_int64), ("fails", C.c_int64),
                 ("have_best", C.c_int64), ("converged", C.c_int64), ("linearsolvers", C.c_int64), ("costcomputations", C.c_int64),
-                ("gradientcomputations", C.c_int64), ("singulartrials", C.c_int64), ("timesolver_ns", C.c_int64), ("timegradient_ns", C.c_int64)]
+                ("gradientcomputations", C.c_int64), ("singulartrials", C.c_int64), ("timesolver_ns", C.c_int64), ("timegradient_ns", C.c_int64), ("timecost_ns", C.c_int64)]
 
 
 class NllsError(RuntimeError):
@@ -122,7 +122,7 @@ def lib():
         L.nlls_solve_finish_replicated.argtypes = [vp]; L.nlls_get_variables_owned.argtypes = [vp, i32, vp]
         L.nlls_set_allreduce.argtypes = [vp, vp, vp]; L.nlls_comm_unique_id.argtypes = [vp]; L.nlls_comm_init_rccl.argtypes = [vp, vp]
         L.nlls_get_memory_info.argtypes = [vp, vp, i32]; L.nlls_flush_cache.argtypes = [vp, i64]; L.nlls_check_analytic.argtypes = [vp, vp, i32]
-        L.nlls_set_option.argtypes = [vp, i32, i64]
+        L.nlls_set_option.argtypes = [vp, i32, i64]; L.nlls_get_time_buckets.argtypes = [vp, vp, i32]
         L.nlls_comm_post_flag.argtypes = [vp, dbl]; L.nlls_comm_agreed_flag.argtypes = [vp, dbl, vp]; L.nlls_comm_info.argtypes = [vp, vp, i32]
         _lib = L
     return _lib
@@ -323,6 +323,11 @@ class Context:
     def set_option(self, option, value):
         """nlls_set_option: OPT_MATERIALIZE (1: nlls_lm_trial eliminates from the materialised A.data, 0: matrix-free where it applies), OPT_LOOKAHEAD"""
         self._chk(self.L.nlls_set_option(self.h, int(option), int(value)))
+
+    def time_buckets(self):
+        """device-timed NLLSResult buckets since the upload: seconds (gradient, cost, solver) and the trials counted"""
+        out = np.zeros(4, np.int64); self._chk(self.L.nlls_get_time_buckets(self.h, _p(out), 4))
+        return dict(timegradient=out[0] * 1e-9, timecost=out[1] * 1e-9, timesolver=out[2] * 1e-9, trials=int(out[3]))
 
     def solve_stats(self):
         out = np.zeros(26, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 26))

@@ -72,6 +72,7 @@ int nlls_ctx_create(const int32_t* device_ids, int32_t ndev, nlls_ctx** out) { N
     nlls_ctx* c = new (std::nothrow) nlls_ctx();
     if (!c) return NLLS_ERR_HIP;
     c->device = dev; c->num_cus = prop.multiProcessorCount;
+    { int khz = 100000; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000; c->tb_ns_per_tick = 1e6 / (double)khz; }
     { const char* e = getenv("NLLS_NO_LOOKAHEAD_SWEEP"); if (e && e[0] == '1') c->spec_on = false; }
     { const char* e = getenv("NLLS_MATERIALIZE"); if (e && e[0] == '1') c->mf_on = false; }
     { const char* e = getenv("NLLS_TINY_DENSE"); if (e && e[0] == '0') c->tiny_dense_on = false; }
@@ -210,7 +211,7 @@ int nlls_get_bsm_index(const nlls_ctx* ctx, int64_t* colptr, int64_t* rowval, in
 int nlls_set_variables(nlls_ctx* ctx, int32_t which, const double* packed) { NLLS_API_BEGIN
     NEED_READY(); if (!valid_set(which) || !packed) return NLLS_ERR_INVALID_ARG;
     spec_note_write(ctx, which);
-    if (which == NLLS_VARS_CURRENT) ctx->sweeps_since_set = 0;         // (a new starting point: its first trial gets no look-ahead sweep, see nlls_sweep_gradhess)
+    if (which == NLLS_VARS_CURRENT) { ctx->sweeps_since_set = 0; ctx->tb_prev_end = 0.0; }         // (a new starting point: its first trial gets no look-ahead sweep, see nlls_sweep_gradhess)
     HIPCHK(hipMemcpyAsync(vars_ptr(ctx, which), packed, sizeof(double) * ctx->info.var_storage, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NLLS_OK;
@@ -396,6 +397,7 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         if (la) { TRY(enqueue_sweep_gradhess(ctx, false, to)); ctx->spec_pending = true; ctx->spec_stale = false; }
         TRY(enqueue_tiny_trial_finish_pending(ctx));      // (no accumulate launch took the finishing reduction along)
     } else {
+    { double* st = ctx->h_scalars + 40; st[0] = st[1] = st[2] = st[3] = 0.0; }       // (the launches of this trial stamp them: device-timed buckets)
     ctx->trial_to = to; ctx->trial_from = from;    // (the back-substitution launch may take the retraction with it: enqueue_solve_finish)
     ctx->mf_use = mf; if (mf) ctx->mf_trials++;
     { const int rc = enqueue_solve(ctx); ctx->trial_to = ctx->trial_from = -1; ctx->mf_use = false; TRY(rc); }
@@ -425,6 +427,15 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    {   // device-timed buckets (nlls_ctx::tb_*): only a trial whose launches all stamped (the sparse single-GPU routes) counts
+        const double* st = ctx->h_scalars + 40;
+        if (!collective && st[0] > 0.0 && st[2] >= st[0] && st[3] >= st[2]) {
+            const double k = ctx->tb_ns_per_tick;
+            ctx->tb_solver_ns += (int64_t)((st[2] - st[0]) * k); ctx->tb_cost_ns += (int64_t)((st[3] - st[2]) * k); ctx->tb_trials++;
+            if (ctx->tb_prev_end > 0.0 && st[0] >= ctx->tb_prev_end) ctx->tb_grad_ns += (int64_t)((st[0] - ctx->tb_prev_end) * k);
+            ctx->tb_prev_end = st[3];
+        }
     }
     const int32_t status[1] = {(int32_t)ctx->h_scalars[10]};
     ctx->comm_gathered = collective;
@@ -555,6 +566,13 @@ int nlls_optimize_singles(nlls_ctx* ctx, int64_t nsel, const int64_t* varindices
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (iters_out) for (int64_t i = 0; i < nsel; ++i) iters_out[i] = (int64_t)hit[(size_t)i];
     return NLLS_OK;
+}
+int nlls_get_time_buckets(nlls_ctx* ctx, int64_t* out, int32_t n) { NLLS_API_BEGIN
+    if (!ctx || !out || n < 1) return NLLS_ERR_INVALID_ARG;
+    const int64_t v[4] = {ctx->tb_grad_ns, ctx->tb_cost_ns, ctx->tb_solver_ns, ctx->tb_trials};
+    for (int i = 0; i < n && i < 4; ++i) out[i] = v[i];
+    return NLLS_OK;
+    NLLS_API_END(ctx)
 }
 int nlls_set_option(nlls_ctx* ctx, int32_t option, int64_t value) { NLLS_API_BEGIN
     if (!ctx) return NLLS_ERR_INVALID_ARG;

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(TPB) void cost_kernel(const double* __restrict__ va
     // (the roles come FIRST in the grid: their chains of dependent loads are the longer ones, and the cost blocks alone fill every wave slot of the chip --
     //  behind them the roles would only start when the sweep is over)
     int bid = (int)blockIdx.x;
-    if constexpr (POST) { const int npost = (int)gridDim.x - cgrid; if (bid < npost) { post_roles_any(post, bid); return; } bid -= npost; }
+    if constexpr (POST) { if (blockIdx.x == 0 && threadIdx.x == 0) time_stamp(post.stamps, 2);
+        const int npost = (int)gridDim.x - cgrid; if (bid < npost) { post_roles_any(post, bid); return; } bid -= npost; }
     __shared__ double red[TPB / 64];
     double acc = 0;
     for (int64_t i = (int64_t)bid * TPB + threadIdx.x; i < n; i += (int64_t)cgrid * TPB) {

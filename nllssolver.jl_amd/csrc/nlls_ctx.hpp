@@ -253,6 +253,12 @@ struct nlls_ctx {
     // always a launch of its own, A/B)
     nlls::DenseFin dense_fin{}; bool dense_fin_pending = false, tiny_fin_role = true;
     bool have_grad = false;
+    // Device-timed NLLSResult buckets (round 6; src/structs.jl:37-50, filled at src/iterators.jl:152,157): the launches of an LM trial leave the constant clock (100 MHz) in the pinned
+    // mirror -- h_scalars[40] start of the assembly launch, [41] of the back-substitution, [42] start of the cost launch (matrix-free trial: of the finishing workgroup; the cost rides in
+    // the back-substitution), [43] end of the finishing workgroup -- one thread each, off every critical path.  nlls_lm_trial turns them into nanoseconds: solver [40]..[42], cost
+    // [42]..[43], gradient = end of the previous trial .. [40] (the sweep between two trials and the host's turn-around).  nlls_get_time_buckets; nlls_lm_iterations reports them.
+    int64_t tb_grad_ns = 0, tb_cost_ns = 0, tb_solver_ns = 0, tb_trials = 0; double tb_prev_end = 0.0, tb_ns_per_tick = 10.0;
+    double* stamp_ptr() const { return h_scalars_dev ? h_scalars_dev + 40 : nullptr; }
     // Matrix-free LM trial (round 6; nlls_mf.hip).  Two-slot Schur problems whose eliminated blocks all sit on the fast path: nlls_lm_trial evaluates the cost blocks of every
     // supernode inside the elimination launch and again inside the back-substitution launch -- the point rows of A.data (151 of its 151.5 MB at BASELINE config 4) are never
     // written or read by the loop.  What stays materialised is the reduced rows (camera diagonal blocks, their part of b: what `grad_level` 1 means) -- the gradient sweep between

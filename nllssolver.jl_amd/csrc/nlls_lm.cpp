@@ -74,6 +74,13 @@ int iterate_levmar(nlls_ctx* ctx, const nlls_lm_options* opt, nlls_lm_state* st,
 
 extern "C" int nlls_lm_iterations(nlls_ctx* ctx, const nlls_lm_options* opt, nlls_lm_state* st, int64_t niter) { NLLS_API_BEGIN
     if (!ctx || !opt || !st) return NLLS_ERR_INVALID_ARG;
+    // the time buckets of NLLSResult (src/structs.jl:42-44): where the trials' launches time themselves on the device (nlls_get_time_buckets) those figures replace this loop's
+    // host timers -- which only see enqueues -- when the call returns
+    int64_t tb0[4] = {0, 0, 0, 0}; const bool have_tb = nlls_get_time_buckets(ctx, tb0, 4) == NLLS_OK;
+    const int64_t ts0 = st->timesolver_ns, tg0 = st->timegradient_ns, tc0 = st->timecost_ns;
+    struct Fill { nlls_ctx* ctx; nlls_lm_state* st; const int64_t* tb0; bool have; int64_t ts0, tg0, tc0;
+        ~Fill() { int64_t tb1[4]; if (!have || nlls_get_time_buckets(ctx, tb1, 4) != NLLS_OK || tb1[3] == tb0[3]) return;
+                  st->timegradient_ns = tg0 + (tb1[0] - tb0[0]); st->timecost_ns = tc0 + (tb1[1] - tb0[1]); st->timesolver_ns = ts0 + (tb1[2] - tb0[2]); } } fill{ctx, st, tb0, have_tb, ts0, tg0, tc0};
     const bool timed = opt->stoptime_ns > 0;
     for (int64_t it = 0; it < niter; ++it) {
         // the deadline under sharding: every rank has its own clock -- each posts what ITS clock says now, the flags ride in the scalar gather of this

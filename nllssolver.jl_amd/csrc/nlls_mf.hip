@@ -29,6 +29,7 @@ struct MfArgs {
     double* Cinv; double* b; double* slab;                               // per member: (C_v + lambda I)^-1 and b_v (b's eliminated part); per supernode: its share of [S | s]
     double lambda; int* status;
     uint32_t wsz, ecap;                                                  // doubles of LDS per wavefront, of which the E slab
+    double* stamps;                                                      // nlls_ctx::stamp_ptr (device-timed buckets)
     uint32_t nbig, ntiny;                                                // supernodes of several batches (one workgroup each) come first, then those of ONE batch (one wavefront each)
     int dbg;
 };
@@ -283,6 +284,7 @@ __device__ __forceinline__ void mf_elim_tiny(const MfArgs& a, uint32_t sidx, dou
 template <int KIND, int PS, class LAY>
 __global__ __launch_bounds__(64 * MF_ENW) __attribute__((amdgpu_waves_per_eu(2, 2))) void mf_elim_kernel(MfArgs a) {
     extern __shared__ __attribute__((aligned(16))) double mf_lds[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) time_stamp(a.stamps, 0);
     if (blockIdx.x < a.nbig) { mf_elim_big<KIND, PS, LAY>(a, blockIdx.x, mf_lds); return; }
     const uint32_t t = (blockIdx.x - a.nbig) * MF_ENW + (threadIdx.x >> 6); if (t < a.ntiny) mf_elim_tiny<KIND, PS, LAY>(a, a.nbig + t, mf_lds);
 }
@@ -298,7 +300,7 @@ static int launch_mf_elim(nlls_ctx* c, const Group& G) {
     if constexpr (Res<KIND>::NDEPS == 2 && Res<KIND>::ADAPT == 0 && !is_cost_kind<KIND> && ResInfo<KIND>::dof(PS < 2 ? PS : 0) <= 3) {
         const unsigned nsn = (unsigned)c->mf_nbig + (unsigned)((c->n_fast_groups - c->mf_nbig + MF_ENW - 1) / MF_ENW);
         MfArgs a{}; a.vars = vars_ptr(c, NLLS_VARS_CURRENT); a.odata = G.mf_data.p; a.ovoff = G.mf_voff.p; a.rk = G.rk; a.desc = c->d_mf_desc.p; a.rcflat = c->d_elim_rc.p; a.nbig = (uint32_t)c->mf_nbig; a.ntiny = (uint32_t)(c->n_fast_groups - c->mf_nbig);
-        a.Cinv = c->Cinv.p; a.b = c->b.p; a.slab = c->slab.p; a.lambda = c->lambda; a.status = c->d_status.p; a.wsz = c->mf_wsz; a.ecap = c->mf_ecap; { static const int dbg = [] { const char* e = getenv("NLLS_MF_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+        a.stamps = c->stamp_ptr(); a.Cinv = c->Cinv.p; a.b = c->b.p; a.slab = c->slab.p; a.lambda = c->lambda; a.status = c->d_status.p; a.wsz = c->mf_wsz; a.ecap = c->mf_ecap; { static const int dbg = [] { const char* e = getenv("NLLS_MF_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
         static size_t granted = 0;
         if (c->mf_lds > 64 * 1024 && c->mf_lds > granted) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf_elim_kernel<KIND, PS, SLayout>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->mf_lds)); granted = c->mf_lds; }
         hipLaunchKernelGGL((mf_elim_kernel<KIND, PS, SLayout>), dim3(nsn), dim3(64 * MF_ENW), c->mf_lds, c->stream, a);

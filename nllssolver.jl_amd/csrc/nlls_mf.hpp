@@ -36,8 +36,9 @@ NLLS_DEV double mfb_wave_sum(double v) {
 // ONE workgroup of 256 threads sums the rows of partials (fixed order: the totals are bit-reproducible) into the trial's scalars -- out[0] cost, [1] max|x| (NaN if any entry
 // is), [2] x'x, [4] x'(H + lambda I)x, [5] g'x, [8] x'Hx, [9] x'x, [10] factorisation status: what trial_finish_kernel leaves -- and publishes them to the pinned host mirror
 // with the trial's sequence number (the host spins on it)
-struct MfFin { const double* part; int nrows; double lambda; double* out; const int* status; double* host_out; double seq; };
+struct MfFin { const double* part; int nrows; double lambda; double* out; const int* status; double* host_out; double seq; double* stamps; };
 NLLS_DEV void mf_finish_body(const MfFin& f, double (*red)[4]) {
+    if (threadIdx.x == 0) time_stamp(f.stamps, 2);
     double q = 0, cost = 0, mx = 0, nan = 0, ss = 0, bx = 0;
     for (int i = threadIdx.x; i < f.nrows; i += 256) { const double* r = f.part + (size_t)i * MF_PW; q += r[0]; cost += r[1]; mx = fmax(mx, r[2]); nan = fmax(nan, r[3]); ss += r[4]; bx += r[5]; }
     q = mfb_wave_sum(q); cost = mfb_wave_sum(cost); ss = mfb_wave_sum(ss); bx = mfb_wave_sum(bx); mx = mfb_wave_max(mx); nan = mfb_wave_max(nan);
@@ -50,6 +51,7 @@ NLLS_DEV void mf_finish_body(const MfFin& f, double (*red)[4]) {
         double* out = f.out;
         out[0] = cost; out[1] = nan > 0 ? __longlong_as_double(0x7ff8000000000000LL) : mx; out[2] = ss;
         out[4] = q + f.lambda * ss; out[5] = bx; out[8] = q; out[9] = ss; out[10] = (double)f.status[0];
+        time_stamp(f.stamps, 3);
         if (f.host_out) {
             double* h = f.host_out;
             h[0] = out[0]; h[1] = out[1]; h[2] = out[2]; h[4] = out[4]; h[5] = out[5]; h[8] = out[8]; h[9] = out[9]; h[10] = out[10];

@@ -27,6 +27,7 @@ struct MfBackArgs {
     const double* vars; const double* odata; const uint32_t* ovoff; RobustSpec rk;
     const MfDesc* desc; const uint32_t* rcflat; const double* Cinv; const double* b; const double* xr; double* x; double* part;
     uint32_t ngroups; const uint32_t* red_boff; int nred, write_red; double* Szero; int64_t nzero; uint32_t nextra, nrest_wg; BsfRetract rt;
+    double* stamps;
     const double* A; const SchurCopy* copies; int64_t ncopy; int npq, nps;      // the reduced blocks' share of the statistics: npq workgroups for x_R' B x_R, nps for max / |x|^2 / g'x over the reduced unknowns
 };
 
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(64 * MF_NW) __attribute__((amdgpu_waves_per_eu(3, 3
     __shared__ double red[MF_NW][64 * DP], xpw[MF_NW][MF_BMAX * DP], stage[MF_NW][MF_SLOTS][2 * DP]; __shared__ uint32_t stpv[MF_NW][MF_SLOTS]; __shared__ double rowred[6][MF_NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double* const row = a.part + (size_t)blockIdx.x * MF_PW;
+    if (blockIdx.x == 0 && tid == 0) time_stamp(a.stamps, 1);
     if (blockIdx.x >= a.ngroups) {
         const uint32_t w = blockIdx.x - a.ngroups;
         if (w < a.nrest_wg) {                                  // x_R = -s scattered, S / the tiles zero-filled for the next solve, the other variables retracted (64-thread roles)
@@ -268,7 +270,7 @@ static int launch_mf_backsub(nlls_ctx* c, const Group& G, const BsfRetract& rt, 
     if constexpr (Res<KIND>::NDEPS == 2 && Res<KIND>::ADAPT == 0 && !is_cost_kind<KIND> && ResInfo<KIND>::dof(PS < 2 ? PS : 0) <= 3) {
         MfBackArgs a{}; a.vars = vars_ptr(c, NLLS_VARS_CURRENT); a.odata = G.mf_data.p; a.ovoff = G.mf_voff.p; a.rk = G.rk; a.desc = c->d_mf_desc.p; a.rcflat = c->d_elim_rc.p;
         a.Cinv = c->Cinv.p; a.b = c->b.p; a.xr = c->s_ptr(); a.x = c->x.p; a.part = c->mf_q.p; a.ngroups = (uint32_t)c->n_fast_groups; a.red_boff = c->d_red_boff.p; a.nred = (int)c->nred; a.write_red = write_red;
-        a.Szero = zptr; a.nzero = zcount; a.nextra = nextra; a.rt = rt;
+        a.Szero = zptr; a.nzero = zcount; a.nextra = nextra; a.rt = rt; a.stamps = c->stamp_ptr();
         a.nrest_wg = (nextra + nrestwg + MF_NW - 1) / MF_NW;
         a.A = c->A.p; a.copies = c->d_copy.p; a.ncopy = c->ncopy;
         a.npq = (int)std::max<int64_t>(1, std::min<int64_t>((c->ncopy * QF_COLS + 255) / 256, 64)); a.nps = (int)std::max<int64_t>(1, std::min<int64_t>((c->nred + 255) / 256, 32));
@@ -295,7 +297,7 @@ int enqueue_mf_backsub(nlls_ctx* c, const BsfRetract& rt, int write_red, double*
 }
 // the end of the trial whose back-substitution launch has left the rows of partials (nlls_ctx::mf_rows): one finishing workgroup, nothing else -- as a launch of its own, or
 // (nlls_ctx::mf_fin_defer) as the first workgroup of the look-ahead sweep's launch behind it (nlls_sweep.hip takes mf_fin_pending along)
-MfFin mf_fin_args(nlls_ctx* c) { return MfFin{c->mf_q.p, c->mf_rows, c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)c->trial_seq}; }
+MfFin mf_fin_args(nlls_ctx* c) { return MfFin{c->mf_q.p, c->mf_rows, c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)c->trial_seq, c->stamp_ptr()}; }
 int enqueue_mf_trial_finish(nlls_ctx* c) {
     ++c->trial_seq;
     if (c->mf_fin_defer) { c->mf_fin_pending = true; return NLLS_OK; }

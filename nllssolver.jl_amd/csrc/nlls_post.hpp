@@ -77,6 +77,7 @@ __device__ __forceinline__ void quadform_points_body(const double* __restrict__ 
 struct PostSolveArgs { const double* A; const SchurCopy* blk; int64_t nblk; const uint8_t* blkmask; const int64_t* ediag; const uint32_t* eboff;
                        const uint32_t* members; int64_t nm; const double* tE; const double* x; const double* b; const double* dofmask; const double* dofmask_b; int64_t ndof;
                        double* partials; double* part2; int np, np3, np2;
+                       double* stamps;                         /* nlls_ctx::stamp_ptr: the launch that carries these roles stamps the start of the trial's cost sweep */
                        int dv;                                 /* block size of the fast-path members (the run-time switch of post_roles_any) */
                        int nretract; const int32_t* vkind; const int32_t* vdim; const uint32_t* voff; const uint32_t* vboff; int64_t nvar; const double* vfrom; double* vto; };
 // the roles of one virtual workgroup bid (256 threads) of [0, np + np3 + np2 (+ nretract)): blocks of H outside the fast-path rows, the fast-path rows

@@ -47,7 +47,7 @@ inline SLayoutT<TSP> make_layout(nlls_ctx* c) {
 }
 
 // the workgroups behind the supernodes of the one-launch assembly: status reset, s += b_R, the reduced-reduced blocks (+ lambda on their diagonals) added into S
-struct PrepArgs { const uint32_t* red_boff; const SchurCopy* copies; double lambda; int ninit; uint32_t nfast; int* status; };
+struct PrepArgs { const uint32_t* red_boff; const SchurCopy* copies; double lambda; int ninit; uint32_t nfast; int* status; double* stamps; };
 template <class LAY>
 NLLS_DEV void schur_prep_roles(const double* __restrict__ A, const double* __restrict__ b, const LAY& L, double* __restrict__ s, const PrepArgs& pa, int w) {
     if (w == 0 && threadIdx.x == 0) pa.status[4] = 0;                       // (pivots dropped by the floor: only the panels of this solve add to it)
@@ -71,7 +71,7 @@ NLLS_DEV void schur_prep_roles(const double* __restrict__ A, const double* __res
 // members from the step it has just formed (Euclidean variables of DV entries: checked at upload), workgroups behind the others retract every
 // other variable from the reduced solution itself (x_R = -xr: the scatter of this very launch is not visible to them) -- the cost sweep is then the
 // next launch, and the step statistics ride in ITS launch (nlls_post.hpp): no launch of their own for either.
-struct BsfRetract { int on, nrest; const uint32_t* fast_voff; const uint32_t* rest_var; const int32_t* rest_red;
+struct BsfRetract { double* stamps; int on, nrest; const uint32_t* fast_voff; const uint32_t* rest_var; const int32_t* rest_red;
                     const int32_t* vkind; const int32_t* vdim; const uint32_t* voff; const double* vfrom; double* vto; };
 
 // the workgroups behind the supernodes of a back-substitution launch (64 threads each; bid counts from the first of them): [0, nextra) scatter the reduced part of the step

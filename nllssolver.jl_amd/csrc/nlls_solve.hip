@@ -242,6 +242,7 @@ __global__ __launch_bounds__(64) void schur_backsub_fast_kernel(const double* __
     constexpr int MAXC = (72 + 15) / 16;                      // columns per lane (nd <= 72)
     __shared__ uint32_t rc[80];
     const int lane = threadIdx.x, l = lane & 15, gsub = lane >> 4;
+    if (blockIdx.x == 0 && lane == 0) time_stamp(rt.stamps, 1);
     if (blockIdx.x >= ngroups) { backsub_rest_roles(blockIdx.x - ngroups, nextra, lane, xr, x, red_boff, nred, write_red, Szero, nzero, rt); return; }
     const ElimDesc d = desc[blockIdx.x];                       // uniform: one scalar load
     const uint32_t v0 = d.v0, v1 = d.v0 + d.nmem; const int nd = (int)d.nd;
@@ -645,6 +646,7 @@ template <int DV, class LAY = SLayout>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void schur_elim_all_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               const ElimDesc* __restrict__ desc, const uint32_t* __restrict__ rcflat,
                                                               double* __restrict__ Cinv, LAY L, double* __restrict__ s, uint32_t nnarrow, PrepArgs pa) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) time_stamp(pa.stamps, 0);
     if (blockIdx.x >= pa.nfast) { schur_prep_roles(A, b, L, s, pa, (int)(blockIdx.x - pa.nfast)); return; }
     {   // the members' inverse diagonal blocks (schur_cinv_kernel's arithmetic, same bits)
         const ElimDesc d = desc[blockIdx.x];
@@ -1469,7 +1471,7 @@ __global__ __launch_bounds__(256) void post_solve_finish_kernel(const double* __
 struct ZeroRanges { double* A; const int64_t* off; const uint32_t* len; double* b; const uint32_t* boff; const uint32_t* blen; int n; };
 __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restrict__ cpart, int64_t ncp, const double* __restrict__ partials, int np,
                                                            const double* __restrict__ part2, int np2, double lambda, double* __restrict__ out, const int* __restrict__ status,
-                                                           double* __restrict__ host_out, double seq, ZeroRanges zr) {
+                                                           double* __restrict__ host_out, double seq, ZeroRanges zr, double* __restrict__ stamps) {
     __shared__ double red[6][4];
     if (blockIdx.x >= 2) {
         const int r = (int)blockIdx.x - 2;
@@ -1487,6 +1489,7 @@ __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restr
     if (host_out && threadIdx.x == 0) {
         if (blockIdx.x == 0) host_out[0] = out[0];
         else { host_out[1] = out[1]; host_out[2] = out[2]; host_out[4] = out[4]; host_out[5] = out[5]; host_out[8] = out[8]; host_out[9] = out[9]; host_out[10] = out[10]; }
+        if (blockIdx.x == 1) time_stamp(stamps, 3);
         __threadfence_system();
         reinterpret_cast<volatile double*>(host_out)[32 + blockIdx.x] = seq;
     }
@@ -1648,6 +1651,7 @@ PostSolveArgs post_solve_args(nlls_ctx* c, int retract_to, int retract_from) {
     a.np3 = reuse ? (int)std::max<int64_t>(1, std::min<int64_t>((c->n_fast_members + 255) / 256, 256)) : 0;
     a.np2 = (int)std::max<int64_t>(1, std::min<int64_t>((c->info.ndof + 255) / 256, 512));      // (5 partials each, behind the quadratic form's at 1024: ends at 3584 < TRIAL_COST_POFS)
     a.partials = c->partials.p; a.part2 = c->partials.p + 1024;
+    a.stamps = c->stamp_ptr();
     a.nretract = 0;
     if (retract_to >= 0 && c->info.nvar > 0) {
         a.nretract = (int)((c->info.nvar + 255) / 256); a.vkind = c->d_var_kind.p; a.vdim = c->d_var_dim.p; a.voff = c->d_var_off.p; a.vboff = c->d_var_boff.p;
@@ -1696,7 +1700,7 @@ int enqueue_lm_trial_tail(nlls_ctx* c, int to, int from) {
     ZeroRanges zr{};
     if (c->tail_zero_for_lookahead && c->nzero > 0) { zr = ZeroRanges{c->A.p, c->d_zero_off.p, c->d_zero_len.p, c->b.p, c->d_zero_b_off.p, c->d_zero_b_len.p, (int)c->nzero}; c->heavy_rows_zeroed = true; }
     hipLaunchKernelGGL(trial_finish_kernel, dim3(2 + (unsigned)zr.n), dim3(256), 0, c->stream, c->partials.p + TRIAL_COST_POFS, ncp, c->partials.p, c->ps_np, c->partials.p + 1024, c->ps_np2,
-                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq), zr);
+                       c->lambda, c->scalars.p, c->d_status.p, c->h_scalars_dev, (double)(++c->trial_seq), zr, c->stamp_ptr());
     HIPCHK(hipGetLastError());
     return NLLS_OK;
 }
@@ -1756,7 +1760,7 @@ static int enqueue_solve_local_t(nlls_ctx* c) {
         if (!c->S_zeroed) HIPCHK(hipMemsetAsync(c->S.p, 0, sizeof(double) * (c->s_elems + (size_t)((band || TSP) ? n : npad)), c->stream));
         c->S_zeroed = false;
         const int ninit = (std::max(npad, n) + 255) / 256;
-        PrepArgs pa{c->d_red_boff.p, c->d_copy.p, c->lambda, ninit, (uint32_t)c->n_fast_groups, c->d_status.p};
+        PrepArgs pa{c->d_red_boff.p, c->d_copy.p, c->lambda, ninit, (uint32_t)c->n_fast_groups, c->d_status.p, c->stamp_ptr()};
         const dim3 grid((unsigned)(c->n_fast_groups + ninit + c->ncopy));
 #define LAUNCH_ALL(DV) hipLaunchKernelGGL((schur_elim_all_kernel<DV, LAY>), grid, dim3(256), 0, c->stream, c->A.p, c->b.p, c->d_elim_desc.p, c->d_elim_rc.p, c->Cinv.p, L, c->s_ptr(), (uint32_t)nfast_narrow, pa)
         if (c->fast_dv == 3) LAUNCH_ALL(3); else if (c->fast_dv == 2) LAUNCH_ALL(2); else LAUNCH_ALL(1);
@@ -1940,7 +1944,7 @@ int enqueue_solve_finish(nlls_ctx* c) {
         const bool tiles_direct = c->elim_slab || c->mf_use;
         if (tiles_direct) { const BcrGeom& g = c->bcr.geom; zptr = g.ws + g.oD; zcount = (int64_t)(g.oBR + (size_t)g.N * g.NT * 256 - g.oD); }
         // an LM trial (nlls_lm_trial sets trial_to / trial_from): the retraction in this launch
-        BsfRetract rt{}; unsigned nrestwg = 0;
+        BsfRetract rt{}; unsigned nrestwg = 0; rt.stamps = c->stamp_ptr();
         c->retract_done = false;
         if (c->trial_to >= 0 && (c->post_fuse || c->mf_use) && c->fast_all_euclid && c->nranks == 1 && nslow == 0 && c->info.is_sparse && c->n_fast_groups > 0 && c->info.nvar > 0) {
             rt.on = 1; rt.nrest = (int)c->d_rest_var.n; rt.fast_voff = c->d_fast_voff.p; rt.rest_var = c->d_rest_var.p; rt.rest_red = c->d_rest_red.p;

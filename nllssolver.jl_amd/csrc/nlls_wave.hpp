@@ -5,6 +5,8 @@
 namespace nlls {
 
 constexpr int TPB = 256;
+// one thread of a launch leaves the constant clock in the pinned host mirror (nlls_ctx::stamp_ptr: the device-timed NLLSResult buckets); nullptr: nothing
+NLLS_DEV void time_stamp(double* __restrict__ stamps, int k) { if (stamps) stamps[k] = (double)wall_clock64(); }
 
 template <int N, class F>
 NLLS_DEV void static_for(F&& f) {

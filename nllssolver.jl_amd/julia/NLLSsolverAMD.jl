@@ -307,6 +307,7 @@ mutable struct LmState
     iternum::Int64; fails::Int64; have_best::Int64; converged::Int64
     linearsolvers::Int64; costcomputations::Int64; gradientcomputations::Int64; singulartrials::Int64
     timesolver_ns::Int64; timegradient_ns::Int64
+    timecost_ns::Int64                     # (round 6, appended: device-timed buckets, nlls_get_time_buckets)
 end
 
 function NLLSsolver.optimizeinternal!(problem::NLLSProblem, options::NLLSOptions, data::NLLSInternal{MultiVariateLSgpu}, iteratedata::NLLSsolver.LevMarData, callback)
@@ -324,12 +325,12 @@ function NLLSsolver.optimizeinternal!(problem::NLLSProblem, options::NLLSOptions
         big = typemax(Int64) >> 1
         opts = Ref(LmOptions(options.reldcost, options.absdcost, options.dstep, min(Int64(options.maxfails), big), min(Int64(options.maxiters), big),
                              min(Int64(data.starttime + options.maxtime), big)))           # Base.time_ns() is CLOCK_MONOTONIC, as the library's clock
-        st = LmState(iteratedata.lambda, cost, cost, 0, 0, 0, 0, data.linearsolvers, data.costcomputations, data.gradientcomputations, 0, 0, 0)
+        st = LmState(iteratedata.lambda, cost, cost, 0, 0, 0, 0, data.linearsolvers, data.costcomputations, data.gradientcomputations, 0, 0, 0, 0)
         GC.@preserve st check(ls.ctx, ccall((:nlls_lm_iterations, lib), Cint, (Ptr{Cvoid}, Ptr{LmOptions}, Ptr{LmState}, Int64), ls.ctx, opts,
                                             Ptr{LmState}(pointer_from_objref(st)), big))
         iteratedata.lambda = st.lambda; data.bestcost = st.bestcost; data.iternum = st.iternum; data.converged = st.converged
         data.linearsolvers = st.linearsolvers; data.costcomputations = st.costcomputations; data.gradientcomputations = st.gradientcomputations
-        data.timesolver += st.timesolver_ns; data.timegradient += st.timegradient_ns
+        data.timesolver += st.timesolver_ns; data.timegradient += st.timegradient_ns; data.timecost += st.timecost_ns
         !(st.bestcost >= st.cost) && NLLSsolver.updatefrombest!(problem, data)
         fetchvariables!(problem, ls, VARS_CURRENT); ls.resident = false
         data.timetotal += Base.time_ns() - data.starttime

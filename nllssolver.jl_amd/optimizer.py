@@ -150,7 +150,7 @@ class OuterLoop:
         st.lambda_, st.bestcost, st.cost = float(self.iteratedata.lambda_), float(data.bestcost), float(self.cost)
         st.iternum, st.fails, st.have_best = int(data.iternum), int(self.fails), int(self.have_best)
         st.linearsolvers, st.costcomputations, st.gradientcomputations, st.singulartrials = data.linearsolvers, data.costcomputations, data.gradientcomputations, data.singulartrials
-        st.timesolver_ns = st.timegradient_ns = 0
+        st.timesolver_ns = st.timegradient_ns = st.timecost_ns = 0
         ls._x = None
         try:
             ls.ctx.lm_iterations(opt, st, n)
@@ -158,7 +158,7 @@ class OuterLoop:
             self.iteratedata.lambda_ = st.lambda_
             data.bestcost, self.cost, data.iternum, self.fails, self.have_best = st.bestcost, st.cost, st.iternum, st.fails, bool(st.have_best)
             data.linearsolvers, data.costcomputations, data.gradientcomputations, data.singulartrials = st.linearsolvers, st.costcomputations, st.gradientcomputations, st.singulartrials
-            data.timesolver += st.timesolver_ns; data.timegradient += st.timegradient_ns
+            data.timesolver += st.timesolver_ns; data.timegradient += st.timegradient_ns; data.timecost += st.timecost_ns      # (device times where the trials' launches time themselves: nlls_get_time_buckets)
             data.converged = st.converged
         return int(st.converged)
 

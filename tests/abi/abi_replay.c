@@ -28,7 +28,7 @@ _Static_assert(offsetof(nlls_info, var_storage) == 56 && offsetof(nlls_info, nre
 _Static_assert(offsetof(nlls_info, nborder_dof) == 104, "NllsInfo last field");
 /* struct LmOptions / mutable struct LmState of the shim (the library's own LM loop, nlls_lm_iterations) */
 _Static_assert(sizeof(nlls_lm_options) == 48 && offsetof(nlls_lm_options, maxfails) == 24 && offsetof(nlls_lm_options, stoptime_ns) == 40, "LmOptions: 3 x Float64 + 3 x Int64");
-_Static_assert(sizeof(nlls_lm_state) == 104 && offsetof(nlls_lm_state, iternum) == 24 && offsetof(nlls_lm_state, converged) == 48, "LmState head");
+_Static_assert(sizeof(nlls_lm_state) == 112 && offsetof(nlls_lm_state, timecost_ns) == 104 && offsetof(nlls_lm_state, iternum) == 24 && offsetof(nlls_lm_state, converged) == 48, "LmState head");
 _Static_assert(offsetof(nlls_lm_state, linearsolvers) == 56 && offsetof(nlls_lm_state, singulartrials) == 80 && offsetof(nlls_lm_state, timegradient_ns) == 96, "LmState tail");
 
 /* ---- the entry points the shim ccalls, with the argument types it passes ---- */

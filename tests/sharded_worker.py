@@ -56,9 +56,10 @@ def scenario(rank, world, dist, staged, seed):
     rng = np.random.default_rng(seed)
     ncr = int(rng.integers(12, 90))             # (sharding partitions by eliminated block: stay within what the Schur kernels take)
     shape = (40, 2000, 0.15) if seed == 21 else (90, 3000, 0.08) if shuffled else (ncr, int(rng.integers(300, 4000)), float(rng.uniform(4.0, 10.0)) / ncr)
-    config3 = seed == 3000                       # BASELINE config 3 at full size, checked against the ORACLE (not only the unsharded device)
+    config4 = seed == 4000                       # BASELINE config 4 at full size (1k cameras x 100k points x 1M residual blocks: the configuration north_star shards), against the ORACLE
+    config3 = seed == 3000 or config4            # BASELINE config 3 at full size, checked against the ORACLE (not only the unsharded device)
     if config3:
-        shape = (100, 10000, 0.1)
+        shape = (1000, 100000, 0.01) if config4 else (100, 10000, 0.1)
     shuf = (lambda q: synthetic.shuffle_camera_labels(q, shape[0], seed)) if shuffled else (lambda q: q)
     mkp = lambda: synthetic.perturb_ba_problem(shuf(synthetic.create_ba_problem(*shape, seed=1 if config3 else seed, robust=N.HuberKernel(0.01 if config3 else 0.05),
                                                                                 outlier_frac=0.05, outlier_sigma=0.05)), 1e-3, 1e-3)
@@ -172,6 +173,12 @@ def scenario(rank, world, dist, staged, seed):
     if config3:
         ores = oracle_problem(mkp()).optimize(maxiters=4)
         assert np.isclose(ores.bestcost, cs, rtol=1e-8), (ores.bestcost, cs)
+    if config4:     # (no dogleg leg at this size: the single steps, the LM loops -- host and library -- and the oracle's loop are what this scenario is for)
+        for o in (ref, sh, ref2, sh2):
+            o.close()
+        dist.barrier(); dist.destroy_process_group()
+        print(f"rank {rank}: sharded == unsharded (BASELINE config 4 at full size against the oracle, cost {cs:.6e}, owned {info['local_ncost']} of {p.ncosts()} cost blocks)")
+        return
     if grid:        # (no dogleg leg: its undamped steps on this gauge-free problem need the pivot floor only the band solver has)
         for o in (ref, sh, ref2, sh2):
             o.close()

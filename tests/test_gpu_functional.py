@@ -669,3 +669,29 @@ def test_nonsquared_cost_static_and_dynamic_on_device(seed):
         p = mk()
         N.optimize(p, N.NLLSOptions(iterator=it))
         assert np.allclose(p.variables[:3], solution, rtol=tol, atol=tol) and np.allclose(p.variables[3:], solution, rtol=tol, atol=tol)
+
+
+def test_device_timed_result_buckets():
+    """NLLSResult.timecost / timegradient / timesolver (src/structs.jl:37-50, filled at src/iterators.jl:152,157) from the DEVICE: the launches of an LM trial stamp the constant
+    clock themselves (nlls_get_time_buckets), the library's loop reports the three buckets -- they tile the loop's timeline, so their sum is its wall time (15 %), on BASELINE
+    config 3 through both trial paths."""
+    import time
+    from nllssolver_jl_amd import iterators as It, optimizer as Opt
+    from nllssolver_jl_amd.dist import ShardedLS
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(100, 10000, 0.1, seed=1, robust=N.HuberKernel(0.01), outlier_frac=0.05, outlier_sigma=0.05), 1e-3, 1e-3)
+    for mat in (0, 1):
+        ls = ShardedLS(p, np.ones(p.nvariables, bool), flags=0, device=0, rank=0, world=1, dist=None, host_staged=False)
+        ls.ctx.set_option(_capi.OPT_MATERIALIZE, mat)
+        options = N.NLLSOptions(maxiters=10 ** 9, reldcost=-np.inf, absdcost=-np.inf, dstep=-1.0, maxfails=10 ** 9, maxtime=1e6)
+        ls.ctx.set_variables(p.variables, _capi.VARS_CURRENT); ls.ctx.copy_variables(_capi.VARS_NEXT, _capi.VARS_CURRENT)
+        data = Opt.NLLSInternal(ls, time.perf_counter_ns())
+        loop = Opt.OuterLoop(p, options, data, It.LevMarData(), It.iterate_levmar, N.nullcallback); loop.start()
+        loop.iterations(3)                                           # (warm: the first trial of a run has no look-ahead, and the clocks of a cold process are slow)
+        b0 = ls.ctx.time_buckets(); t0 = time.perf_counter()
+        loop.iterations(40)
+        wall = time.perf_counter() - t0; b1 = ls.ctx.time_buckets()
+        tg, tc, ts = (b1[k] - b0[k] for k in ("timegradient", "timecost", "timesolver"))
+        assert b1["trials"] - b0["trials"] >= 40 and tg > 0 and tc > 0 and ts > 0, (b0, b1)
+        assert abs((tg + tc + ts) - wall) < 0.15 * wall, (mat, tg, tc, ts, wall)
+        assert data.timesolver > 0 and data.timecost > 0 and data.timegradient > 0      # (nanoseconds, as the loop reports them: nlls_lm_state)
+        ls.close()

@@ -13,11 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # (a string of seeds = several scenarios in ONE process group: most of a scenario's two seconds is the start of its ranks)
 @pytest.mark.parametrize("world,backend,seed", [(1, "nccl", 21), (2, "gloo", "21,401,403,5001,6001,7001,5201,8001,9001,10001"), (3, "gloo", "21,402,5002,5102,7001,5301,9001,10002"),
-                                                (2, "gloo", -1), (3, "gloo", -1), (2, "gloo", 3000), (3, "gloo", 3000)])
+                                                (2, "gloo", -1), (3, "gloo", -1), (2, "gloo", 3000), (3, "gloo", 3000), (2, "gloo", 4000), (3, "gloo", 4000)])
 def test_sharded_matches_unsharded(world, backend, seed):
     """(1, "nccl"): the local / reduce / finish route over RCCL with device buffers, one rank -- the plumbing bench.py --gpus N uses.
     seed 3000: BASELINE config 3 at full size (100 cameras x 10k points, ~100k residual blocks) against the CPU oracle: cost, gradient,
     damped step and four Levenberg-Marquardt iterations.
+    seed 4000: BASELINE config 4 at full size (1k cameras x 100k points x 1M residual blocks -- the configuration north_star shards over 1 / 2 / 4 / 8 GPUs) against the CPU oracle: cost 1e-11,
+    gradient 1e-10, damped step 1e-7, four Levenberg-Marquardt iterations 1e-8 (host loop and the library's own), as seed 3000 does for config 3.
     seed -1: a zero pivot only one rank sees must be raised on every rank (no rank left behind in a collective).
     seed >= 6000: the cameras' labels permuted -- every rank re-orders the reduced system at upload (reverse Cuthill-McKee) and must arrive at the same order;
     seed 51xx: the same under NLLS_FLAG_PRESHARDED, where each rank sees only its own part of the camera graph (the union is taken collectively).
@@ -34,7 +36,7 @@ def test_sharded_matches_unsharded(world, backend, seed):
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port, backend, str(seed)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
-    deadline = time.monotonic() + 150 + 20 * len(seeds)          # all ranks share one deadline: a rank that died leaves the others in a collective
+    deadline = time.monotonic() + 150 + 20 * len(seeds) + (400 if 4000 in seeds else 0)          # all ranks share one deadline: a rank that died leaves the others in a collective
     for p in procs:
         try:
             out, _ = p.communicate(timeout=max(1.0, deadline - time.monotonic()))
