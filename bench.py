@@ -471,6 +471,36 @@ def main():
                                     "achieved": round(uf / (dms * 1e-3) / 1e12, 3), "frac": round(uf / (dms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
         dls.close()
 
+    # ---- where an iteration of the SHARDED loop goes, measured (N > 1, and one rank through the collective route): stream events at the phase boundaries of the collective
+    # trial (NLLS_OPT_PHASE_EVENTS), one more loop of the same K iterations, outside the timed region -- beside `predicted`, so that the first multi-GPU run diagnoses itself
+    phases = None
+    if (world > 1 or force_dist) and info.is_sparse:
+        ls.ctx.set_option(_capi.OPT_PHASE_EVENTS, 1)
+        lp, pe = timed_loop(ls, problem, start_vars)
+        ph = ls.ctx.phase_times(); ls.ctx.set_option(_capi.OPT_PHASE_EVENTS, 0)
+        trials_per_it = lp.data.linearsolvers / max(1, args.steps)
+        phases = {"per_trial_us": {k: round(v, 1) for k, v in ph.items() if k.endswith("_us") and k != "gradient_sweep_us"}, "gradient_sweep_us": round(ph["gradient_sweep_us"], 1),
+                  "trials_counted": ph["trials"], "sweeps_counted": ph["sweeps"], "trials_per_iteration": round(trials_per_it, 3),
+                  "sum_per_iteration_us": round(trials_per_it * sum(v for k, v in ph.items() if k.endswith("_us") and k != "gradient_sweep_us") + ph["gradient_sweep_us"], 1),
+                  "ms_per_step_of_this_loop": round(1e3 * pe / args.steps, 4),
+                  "how": "hipEventRecord on the library's stream at the phase boundaries of nlls_lm_trial (collective route) and around the gradient sweep; rank 0's figures; the all-reduce phase "
+                         "contains the wait for the slowest rank; the events themselves cost a marker packet each (this loop is not the timed one)"}
+
+    # ---- strong-scaling leg (N > 1 only): the TEN-times workload (10k cameras x 1M points x 10M residual blocks) split over the ranks -- there about 70 % of an iteration divides by N
+    # (sweep, elimination, back-substitution of 10M blocks against a reduced solve that grows only with the cameras); every rank generates and uploads only its share (NLLS_FLAG_PRESHARDED)
+    strong = None
+    if world > 1 and args.workload == "ba_1kx100k" and not os.environ.get("NLLS_BENCH_NO_STRONG"):
+        sc, sp, spr = CONFIGS["ba_10kx1M"]
+        sproblem = synthetic.create_ba_problem_shard(sc, sp, spr, rank, world, seed=1, robust=N.HuberKernel(0.01), outlier_frac=0.05, outlier_sigma=0.05, pointnoise=1e-3, posenoise=1e-3)
+        sls = ShardedLS(sproblem, np.ones(sproblem.nvariables, bool), flags=flags, device=local_rank, rank=rank, world=world, dist=dist, host_staged=host_staged, presharded=True)
+        sloop, selapsed = timed_loop(sls, sproblem, sproblem.variables.copy())
+        scounts = [None] * world; dist.all_gather_object(scounts, int(sproblem.ncosts())); stotal = int(sum(scounts))
+        strong = {"scaling": "strong", "workload": f"ba_10kx1M: {sc} cameras x {sp} points ({stotal} residual blocks) split by point over {world} ranks",
+                  "value": round(args.steps / selapsed, 3), "unit": "LM iters/s", "ms_per_step": round(1e3 * selapsed / args.steps, 4), "residual_blocks_per_s": round(stotal * args.steps / selapsed, 1),
+                  "lm_trials_per_s": round(sloop.data.linearsolvers / selapsed, 1), "local_residual_blocks": int(sls.local_nobs), "start_cost": sloop.data.startcost, "final_cost": sloop.data.bestcost,
+                  "one_gpu_reference": "profiles/r06_bench_ba_10kx1M.json (python bench.py --workload ba_10kx1M on one MI355X)"}
+        sls.close()
+
     # ---- weak-scaling leg (N > 1 only): N x 100k points against the SAME cameras, sharded by point -- per-rank sweeps, elimination and
     # back-substitution stay those of the one-GPU problem, the replicated reduced system keeps its size; what grows is the data volume
     weak = None
@@ -535,6 +565,10 @@ def main():
             out["rccl"] = ls.ctx.comm_info()        # what the library's communicator reports (ncclCommCount / ncclCommUserRank), not the environment
         if weak:
             out["weak_scaling"] = weak
+        if strong:
+            out["strong_scaling_10x"] = strong
+        if phases:
+            out["phases_measured"] = phases
         if world > 1 and args.workload == "ba_1kx100k":
             out["predicted"] = predicted_scaling(world)
         sys.stdout.flush(); os.dup2(saved_stdout, 1)

@@ -279,11 +279,16 @@ int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
 /* Run-time switches of a context (A/B measurements, parity tests through both paths on ONE upload):
  *   NLLS_OPT_MATERIALIZE  value != 0: nlls_lm_trial eliminates from the materialised A.data (the round-5 path) although the structure qualifies for the
  *                         matrix-free trial; 0 (default): matrix-free where nlls_upload_structure found it applicable (NLLS_FLAG_MATERIALIZE: never).
- *   NLLS_OPT_LOOKAHEAD    value == 0: no look-ahead sweep behind an LM trial (the environment's NLLS_NO_LOOKAHEAD_SWEEP=1). */
+ *   NLLS_OPT_LOOKAHEAD    value == 0: no look-ahead sweep behind an LM trial (the environment's NLLS_NO_LOOKAHEAD_SWEEP=1).
+ *   NLLS_OPT_PHASE_EVENTS see below. */
 /* Device-timed NLLSResult buckets since the upload, nanoseconds: out[0] gradient, [1] cost, [2] solver, [3] trials counted (single-GPU sparse trials; others leave them untouched). */
 int  nlls_get_time_buckets(nlls_ctx* ctx, int64_t* out, int32_t n);
 #define NLLS_OPT_MATERIALIZE 1
 #define NLLS_OPT_LOOKAHEAD   2
+#define NLLS_OPT_PHASE_EVENTS 3   /* value != 0: the COLLECTIVE nlls_lm_trial records stream events at its phase boundaries (resets the sums); nlls_get_phase_times reads them */
+/* out[0..4]: milliseconds summed over the trials since NLLS_OPT_PHASE_EVENTS was set -- [0] this rank's assembly of [S | s] (elimination), [1] the all-reduce of [S | s] (wait included),
+ * [2] the reduced solve (every rank), [3] back-substitution + retraction, [4] trial tail (statistics, cost sweep, the scalars' gather); [5] gradient sweeps (ms summed), [6] trials, [7] sweeps counted. */
+int  nlls_get_phase_times(nlls_ctx* ctx, double* out, int32_t n);
 int  nlls_set_option(nlls_ctx* ctx, int32_t option, int64_t value);
 int  nlls_set_step(nlls_ctx* ctx, const double* x);               /* host-formed steps (dogleg, GD) */
 int  nlls_get_step(nlls_ctx* ctx, double* x_out);

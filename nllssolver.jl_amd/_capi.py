@@ -20,7 +20,7 @@ FLAG_NO_REORDER = 256
 FLAG_NO_TILE_SPARSE = 512
 FLAG_NO_PIVOT_FLOOR = 1024
 FLAG_MATERIALIZE = 2048
-OPT_MATERIALIZE, OPT_LOOKAHEAD = 1, 2
+OPT_MATERIALIZE, OPT_LOOKAHEAD, OPT_PHASE_EVENTS = 1, 2, 3
 VARS_CURRENT, VARS_NEXT, VARS_BEST = 0, 1, 2
 
 # every symbol include/nlls_amd.h declares (checked by tests/test_capi_symbols.py)
@@ -31,7 +31,7 @@ nlls_get_grad nlls_get_bsm_data nlls_max_abs_diag nlls_grad_sqnorm nlls_grad_qua
 nlls_get_step nlls_step_maxabs nlls_step_norm nlls_quadform nlls_retract nlls_sweep_gradhess_local
 nlls_sweep_gradhess_finish nlls_sweep_cost_local nlls_sweep_cost_finish nlls_solve_local nlls_solve_finish
 nlls_get_reduce_buffer nlls_get_step_shard nlls_get_shard_info nlls_get_grad_owned nlls_trial_local nlls_solve_finish_async nlls_lm_trial nlls_optimize_singles nlls_time_sweep_gradhess nlls_time_sweep_accumulate nlls_time_sweep_cost nlls_time_solve nlls_time_reduced_solve nlls_profile_sweep nlls_profile_sweep_dispatch nlls_solve_finish_replicated nlls_get_variables_owned nlls_lm_iterations
-nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl nlls_comm_post_flag nlls_comm_agreed_flag nlls_comm_info nlls_get_memory_info nlls_flush_cache nlls_check_analytic nlls_set_option nlls_get_time_buckets""".split()
+nlls_set_allreduce nlls_comm_unique_id nlls_comm_init_rccl nlls_comm_post_flag nlls_comm_agreed_flag nlls_comm_info nlls_get_memory_info nlls_flush_cache nlls_check_analytic nlls_set_option nlls_get_time_buckets nlls_get_phase_times""".split()
 
 
 class LmOptions(C.Structure):          # nlls_lm_options
@@ -122,7 +122,7 @@ def lib():
         L.nlls_solve_finish_replicated.argtypes = [vp]; L.nlls_get_variables_owned.argtypes = [vp, i32, vp]
         L.nlls_set_allreduce.argtypes = [vp, vp, vp]; L.nlls_comm_unique_id.argtypes = [vp]; L.nlls_comm_init_rccl.argtypes = [vp, vp]
         L.nlls_get_memory_info.argtypes = [vp, vp, i32]; L.nlls_flush_cache.argtypes = [vp, i64]; L.nlls_check_analytic.argtypes = [vp, vp, i32]
-        L.nlls_set_option.argtypes = [vp, i32, i64]; L.nlls_get_time_buckets.argtypes = [vp, vp, i32]
+        L.nlls_set_option.argtypes = [vp, i32, i64]; L.nlls_get_time_buckets.argtypes = [vp, vp, i32]; L.nlls_get_phase_times.argtypes = [vp, vp, i32]
         L.nlls_comm_post_flag.argtypes = [vp, dbl]; L.nlls_comm_agreed_flag.argtypes = [vp, dbl, vp]; L.nlls_comm_info.argtypes = [vp, vp, i32]
         _lib = L
     return _lib
@@ -323,6 +323,12 @@ class Context:
     def set_option(self, option, value):
         """nlls_set_option: OPT_MATERIALIZE (1: nlls_lm_trial eliminates from the materialised A.data, 0: matrix-free where it applies), OPT_LOOKAHEAD"""
         self._chk(self.L.nlls_set_option(self.h, int(option), int(value)))
+
+    def phase_times(self):
+        """nlls_get_phase_times: microseconds per collective trial by phase (stream events; NLLS_OPT_PHASE_EVENTS) and per gradient sweep"""
+        out = np.zeros(8); self._chk(self.L.nlls_get_phase_times(self.h, _p(out), 8)); nt, ns = max(out[6], 1.0), max(out[7], 1.0)
+        return dict(trials=int(out[6]), sweeps=int(out[7]), elimination_us=1e3 * out[0] / nt, allreduce_S_us=1e3 * out[1] / nt, reduced_solve_us=1e3 * out[2] / nt,
+                    backsub_retraction_us=1e3 * out[3] / nt, trial_tail_us=1e3 * out[4] / nt, gradient_sweep_us=1e3 * out[5] / ns)
 
     def time_buckets(self):
         """device-timed NLLSResult buckets since the upload: seconds (gradient, cost, solver) and the trials counted"""

@@ -53,6 +53,8 @@ void spec_note_write(nlls_ctx* ctx, int32_t which) {
     if (ctx->spec_pending) ctx->spec_stale = true;
     else if (ctx->grad_level < 2) ctx->grad_level = 0;          // (what is formed on demand would be formed at the NEW values: the caller sweeps again after writing CURRENT -- every iterator does)
 }
+// phase events (nlls_ctx::phase_on): record event k on the stream
+void phase_mark(nlls_ctx* ctx, int k) { if (ctx->phase_on && (size_t)k < ctx->phase_ev.size()) (void)hipEventRecord(ctx->phase_ev[k], ctx->stream); }
 // is this trial matrix-free?  (nlls_ctx::mf_ok: the structure qualifies; mf_on: not switched off; the trial starts at CURRENT, one rank, no collective route)
 bool mf_trial(const nlls_ctx* ctx, int32_t from) { return ctx->mf_ok && ctx->mf_on && from == NLLS_VARS_CURRENT && ctx->nranks == 1 && !ctx->reduce_fn && ctx->info.is_sparse && !ctx->tiny_dense; }
 }  // namespace
@@ -101,6 +103,7 @@ int nlls_ctx_destroy(nlls_ctx* ctx) { NLLS_API_BEGIN
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (auto& e : ctx->phase_ev) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     hipStream_t s = ctx->own_stream ? ctx->stream : nullptr;
@@ -273,7 +276,12 @@ int nlls_sweep_gradhess(nlls_ctx* ctx, double* cost_out) { NLLS_API_BEGIN
     if (ctx->reduce_fn) {
         // collective (include/nlls_amd.h): this rank's blocks, then ONE sum over ranks of [cost | reduced rows of A.data | reduced part of b]
         const bool lazy = !cost_out && ctx->lazy_stage0 && ctx->info.is_sparse && !ctx->elim_slab;
+        if (ctx->phase_on && ctx->phase_ev.size() >= 8) {      // (the previous sweep's pair has long completed: the trials between synchronise)
+            float ms = 0.f; if (ctx->phase_sweeps >= 0 && hipEventElapsedTime(&ms, ctx->phase_ev[6], ctx->phase_ev[7]) == hipSuccess) { ctx->phase_ms[5] += ms; ctx->phase_sweeps++; } else (void)hipGetLastError();
+            (void)hipEventRecord(ctx->phase_ev[6], ctx->stream);
+        }
         TRY(enqueue_sweep_gradhess(ctx, !lazy));
+        if (ctx->phase_on && ctx->phase_ev.size() >= 8) (void)hipEventRecord(ctx->phase_ev[7], ctx->stream);
         ctx->lambda = 0.0; ctx->have_grad = true; ctx->solved = false;
         ctx->reduced_summed = !lazy;
         if (lazy) return NLLS_OK;                                            // nothing is summed now: ensure_reduced_summed, or never
@@ -379,18 +387,23 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
         // every rank (each then holds the reduced part of the step: x is never summed), own back-substitution, retraction, own cost blocks,
         // and one gather of the ranks' scalars -- combined on the device and published to the host mirror as the single-GPU trial does
         if (ctx->nranks > 1 && !ctx->reduced_summed) ctx->n_lazy_trials++;
+        phase_mark(ctx, 0);
         TRY(enqueue_solve_local(ctx));
+        phase_mark(ctx, 1);
         if (ctx->solve_mode == SOLVE_TSPARSE && ctx->tsp.nslots_assembled < ctx->tsp.nslots) {
             // tile-sparse layout [assembled tiles | fill tiles | strips | s]: the fill tiles and the strips are zero on every rank until the factorisation -- the assembled
             // prefix and s are what is summed (two collectives: on the 100 x 100 camera grid most of the volume was zeros)
             TRY(comm_reduce(ctx, ctx->S.p, ctx->tsp.nslots_assembled * (int64_t)TSP_TE, NLLS_REDUCE_SUM));
             TRY(comm_reduce(ctx, ctx->S.p + ctx->s_elems, ctx->nred, NLLS_REDUCE_SUM));
         } else TRY(comm_reduce(ctx, ctx->S.p, (int64_t)ctx->s_elems + ctx->nred, NLLS_REDUCE_SUM));
+        phase_mark(ctx, 2);
         if (ctx->nranks == 1) { ctx->trial_to = to; ctx->trial_from = from; }      // (one rank through the route: the same launches as the unsharded trial)
         ctx->replicate_xr = true; int rc = enqueue_solve_finish(ctx); ctx->replicate_xr = false; ctx->trial_to = ctx->trial_from = -1; TRY(rc);
+        phase_mark(ctx, 4);
         double* const mirror = ctx->h_scalars_dev; ctx->h_scalars_dev = nullptr;           // (the rank's own scalars are not what the host waits for)
         rc = enqueue_lm_trial_tail(ctx, to, from); ctx->h_scalars_dev = mirror; TRY(rc);
         TRY(comm_gather_trial_scalars(ctx, (double)ctx->trial_seq));
+        phase_mark(ctx, 5);
     } else if (ctx->tiny_dense) {
         const bool la = ctx->spec_on && ctx->spec_armed && from == NLLS_VARS_CURRENT;
         TRY(enqueue_tiny_dense_trial(ctx, to, from, la && ctx->tiny_fin_role));
@@ -435,6 +448,13 @@ int nlls_lm_trial(nlls_ctx* ctx, double dlambda, int32_t to, int32_t from, doubl
             ctx->tb_solver_ns += (int64_t)((st[2] - st[0]) * k); ctx->tb_cost_ns += (int64_t)((st[3] - st[2]) * k); ctx->tb_trials++;
             if (ctx->tb_prev_end > 0.0 && st[0] >= ctx->tb_prev_end) ctx->tb_grad_ns += (int64_t)((st[0] - ctx->tb_prev_end) * k);
             ctx->tb_prev_end = st[3];
+        }
+    }
+    if (collective && ctx->phase_on && ctx->phase_ev.size() >= 6) {      // (the trial has ended: every event has completed)
+        if (hipEventSynchronize(ctx->phase_ev[5]) == hipSuccess) {
+            float ms = 0.f; bool ok = true; double d[5];
+            for (int k = 0; k < 5 && ok; ++k) { ok = hipEventElapsedTime(&ms, ctx->phase_ev[k], ctx->phase_ev[k + 1]) == hipSuccess; d[k] = ms; }
+            if (ok) { for (int k = 0; k < 5; ++k) ctx->phase_ms[k] += d[k]; ctx->phase_trials++; } else (void)hipGetLastError();
         }
     }
     const int32_t status[1] = {(int32_t)ctx->h_scalars[10]};
@@ -574,11 +594,23 @@ int nlls_get_time_buckets(nlls_ctx* ctx, int64_t* out, int32_t n) { NLLS_API_BEG
     return NLLS_OK;
     NLLS_API_END(ctx)
 }
+int nlls_get_phase_times(nlls_ctx* ctx, double* out, int32_t n) { NLLS_API_BEGIN
+    if (!ctx || !out || n < 1) return NLLS_ERR_INVALID_ARG;
+    const double v[8] = {ctx->phase_ms[0], ctx->phase_ms[1], ctx->phase_ms[2], ctx->phase_ms[3], ctx->phase_ms[4], ctx->phase_ms[5], (double)ctx->phase_trials, (double)ctx->phase_sweeps};
+    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+    return NLLS_OK;
+    NLLS_API_END(ctx)
+}
 int nlls_set_option(nlls_ctx* ctx, int32_t option, int64_t value) { NLLS_API_BEGIN
     if (!ctx) return NLLS_ERR_INVALID_ARG;
     switch (option) {
     case NLLS_OPT_MATERIALIZE: ctx->mf_on = value == 0; return NLLS_OK;          // (takes effect with the next nlls_lm_trial / nlls_sweep_gradhess; what A and b hold is tracked either way)
     case NLLS_OPT_LOOKAHEAD:   ctx->spec_on = value != 0; return NLLS_OK;
+    case NLLS_OPT_PHASE_EVENTS:
+        ctx->phase_on = value != 0; (void)hipSetDevice(ctx->device);
+        if (ctx->phase_on && ctx->phase_ev.empty()) { ctx->phase_ev.resize(8); for (auto& e : ctx->phase_ev) if (hipEventCreate(&e) != hipSuccess) return NLLS_ERR_HIP; }
+        if (ctx->phase_on) { for (double& v : ctx->phase_ms) v = 0.0; ctx->phase_trials = ctx->phase_sweeps = 0; }
+        return NLLS_OK;
     }
     return fail(ctx, NLLS_ERR_INVALID_ARG, "nlls_set_option: unknown option");
     NLLS_API_END(ctx)

@@ -258,6 +258,9 @@ struct nlls_ctx {
     // the back-substitution), [43] end of the finishing workgroup -- one thread each, off every critical path.  nlls_lm_trial turns them into nanoseconds: solver [40]..[42], cost
     // [42]..[43], gradient = end of the previous trial .. [40] (the sweep between two trials and the host's turn-around).  nlls_get_time_buckets; nlls_lm_iterations reports them.
     int64_t tb_grad_ns = 0, tb_cost_ns = 0, tb_solver_ns = 0, tb_trials = 0; double tb_prev_end = 0.0, tb_ns_per_tick = 10.0;
+    // Phase timing of the COLLECTIVE trial (NLLS_OPT_PHASE_EVENTS; bench.py --gpus N): events recorded on the stream at the phase boundaries of nlls_lm_trial -- local assembly,
+    // the [S | s] all-reduce, reduced solve, back-substitution, trial tail -- and around the gradient sweep; off by default (an event is a marker packet on the queue)
+    bool phase_on = false; std::vector<hipEvent_t> phase_ev; double phase_ms[6] = {0, 0, 0, 0, 0, 0}; int64_t phase_trials = 0, phase_sweeps = 0;
     double* stamp_ptr() const { return h_scalars_dev ? h_scalars_dev + 40 : nullptr; }
     // Matrix-free LM trial (round 6; nlls_mf.hip).  Two-slot Schur problems whose eliminated blocks all sit on the fast path: nlls_lm_trial evaluates the cost blocks of every
     // supernode inside the elimination launch and again inside the back-substitution launch -- the point rows of A.data (151 of its 151.5 MB at BASELINE config 4) are never

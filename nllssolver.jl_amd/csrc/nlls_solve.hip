@@ -1922,6 +1922,7 @@ int enqueue_solve_finish(nlls_ctx* c) {
     c->retract_done = false;
     const int n = (int)c->nred; if (n == 0) return NLLS_OK;
     { const int rc = enqueue_reduced_solve(c); if (rc != NLLS_OK) return rc; }
+    if (c->phase_on && c->phase_ev.size() >= 6) (void)hipEventRecord(c->phase_ev[3], c->stream);      // (phase timing: the reduced solve ends)
     // x = -solution (folded into the fast back-substitution launch when there is one)
     // (replicate_xr: a sharded LM trial keeps the reduced part of the step on every rank -- each retracts the cameras and its own
     //  points itself, no all-reduce of x)

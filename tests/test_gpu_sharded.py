@@ -68,6 +68,10 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["config"]["sharding"] == "by point over 2 ranks"
     assert out["lm"]["final_cost"] < out["lm"]["start_cost"] and out["value"] > 0
+    # the N > 1 line diagnoses itself: measured microseconds per phase of the collective trial beside the prediction, and the strong-scaling leg on the ten-times workload
+    ph = out["phases_measured"]
+    assert ph["trials_counted"] >= 4 and all(ph["per_trial_us"][k] > 0 for k in ("elimination_us", "allreduce_S_us", "reduced_solve_us", "backsub_retraction_us", "trial_tail_us")), ph
+    assert ph["gradient_sweep_us"] > 0 and 0.3 * 1e3 * ph["ms_per_step_of_this_loop"] < ph["sum_per_iteration_us"] < 1.5 * 1e3 * ph["ms_per_step_of_this_loop"], ph
     assert out["rccl"]["nranks"] == 2 and out["rccl"]["rank"] == 0 and out["spread"]["runs"] >= 3 and len(out["spread"]["trials_per_run"]) == out["spread"]["runs"]
 
 
