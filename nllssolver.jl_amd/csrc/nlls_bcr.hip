@@ -1076,10 +1076,10 @@ bool BcrSolver::supports(int64_t n_band, int bw, int nbd) {
     return bw >= 1 && (bw + 15) / 16 <= BCR_MAXNT && nbd <= 15 && n_band >= 1 && n_band < (int64_t)1 << 30;
 }
 
-int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* err) {
+int BcrSolver::build(int64_t n_band_, int bw_, int nbd_, int H_, std::string* err, int nt) {
     release();
     n_band = (int)n_band_; bw = bw_; nbd = nbd_; H = H_;
-    NT = std::max(1, (bw + 15) / 16); const int b = 16 * NT; N = (n_band + b - 1) / b;
+    NT = nt > 0 ? nt : std::max(1, (bw + 15) / 16); const int b = 16 * NT; N = (n_band + b - 1) / b;
     const int ND = NT * (NT + 1) / 2, NO = NT * (NT - 1) / 2, RXT = 2 * NT + 1;
     size_t off = 0;
     auto take = [&](size_t doubles) { const size_t o = off; off += (doubles + 31) & ~(size_t)31; return o; };

@@ -38,7 +38,7 @@ struct BcrSolver {
     int64_t mfma_issued = 0;                      // v_mfma_f64_16x16x4_f64 instructions one solve issues (all workgroups, redundant factorisations included)
 
     static bool supports(int64_t n_band, int bw, int nbd);
-    int build(int64_t n_band, int bw, int nbd, int H, std::string* err);
+    int build(int64_t n_band, int bw, int nbd, int H, std::string* err, int nt = 0);   // nt > 0: tiles per block chosen by the caller (blocks of 16 nt < bw unknowns that the STRUCTURE keeps block tridiagonal)
     // Sb: band storage [S | corner] as assembled by the Schur elimination (SLayout, mode SOLVE_BAND); xr: n_band + nbd unknowns out
     // pivot_floor > 0 (undamped Newton / dogleg steps on a gauge-free problem: S is singular): a pivot that has lost more than that
     // fraction of its original diagonal entry is treated as infinite -- its unknown comes out 0 instead of (rounding) / (rounding)

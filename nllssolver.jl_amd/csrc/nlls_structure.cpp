@@ -878,12 +878,17 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         c->nred = ro; c->nbd = (int)(ro - c->n_band);
     }
     int64_t bw = 0;   // half bandwidth (in dof) of the non-border part of S
+    // bt_bad[NT]: blocks of 16 NT unknowns do NOT make the band part of S block TRIDIAGONAL (some coupled pair of unknowns lies two blocks apart).  Blocks of at least bw
+    // unknowns always do; a smaller block may as well -- cameras of 6 unknowns that share points with ten neighbours: bw = 65, and no coupling crosses two blocks of 64 --
+    // and the block cyclic reduction's dependent chain is (tiles per block) x (levels): it takes the cheapest block size the STRUCTURE allows (choose_bcr_nt below)
+    double bt_bad[6] = {0, 0, 0, 0, 0, 0};
+    auto bt_note = [&](int64_t lo, int64_t hi) { for (int t = 1; t <= 5; ++t) if (hi / (16 * t) - lo / (16 * t) > 1) bt_bad[t] = 1.0; };
     if (c->nranks > 1) for (int64_t v = 0; v < nb; ++v) if (c->is_elim[v]) {   // all ranks must agree on the layout of S
         int64_t lo = -1, hi = -1;
         auto upd = [&](int64_t u) { const int64_t r0 = red_of[u]; if (r0 < c->n_band) { lo = lo < 0 ? r0 : std::min(lo, r0); hi = std::max(hi, r0 + c->blocksizes[u] - 1); } };
         for (int64_t q = c->it_colptr[v]; q < c->it_colptr[v + 1]; ++q) if (c->it_rowval[q] != v) upd(c->it_rowval[q]);
         for (int64_t q = tptr[v]; q < tptr[v + 1]; ++q) if (trow[q] != v) upd(trow[q]);
-        if (lo >= 0) bw = std::max(bw, hi - lo);
+        if (lo >= 0) { bw = std::max(bw, hi - lo); bt_note(lo, hi); }
     }
     std::vector<int64_t> eptr; std::vector<SchurNbr> enbr; std::vector<int64_t> ediag; std::vector<uint32_t> eboff; std::vector<uint16_t> edim; std::vector<uint32_t> egroup;
     std::vector<int64_t> erow;                 // block row of each (local) eliminated member
@@ -907,7 +912,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
               else std::sort(nl.begin(), nl.end(), [](const SchurNbr& a, const SchurNbr& b) { return a.rcol < b.rcol; }); }
             int nd = 0; int64_t lo = -1, hi = -1;
             for (auto& n : nl) { nd += n.dim; if ((int64_t)n.rcol < c->n_band) { lo = lo < 0 ? (int64_t)n.rcol : std::min<int64_t>(lo, n.rcol); hi = std::max<int64_t>(hi, (int64_t)n.rcol + n.dim - 1); } }   // (any order: the columns are in MEMORY order)
-            if (lo >= 0) bw = std::max(bw, hi - lo);
+            if (lo >= 0) { bw = std::max(bw, hi - lo); bt_note(lo, hi); }
             c->max_nbr_dof = std::max(c->max_nbr_dof, nd); c->max_elim_dim = std::max(c->max_elim_dim, (int)c->blocksizes[v]);
             // supernode: same neighbour columns and own size as the previous eliminated block
             bool same = !edim.empty() && glen < sn_cap && prev.size() == nl.size() && edim.back() == (uint16_t)c->blocksizes[v];
@@ -1015,8 +1020,9 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             // S is addressed by its lower triangle in REDUCED order: transpose the block if the border reordering flipped it
             SchurCopy cp{c->it_nzval[q], (uint32_t)red_of[row], (uint32_t)red_of[col], (uint16_t)c->blocksizes[row], (uint16_t)c->blocksizes[col]};
             copies.push_back(cp);
-            if (red_of[row] < c->n_band && red_of[col] < c->n_band && row != col) bw = std::max<int64_t>(bw, std::llabs(red_of[row] - red_of[col]) + std::max(c->blocksizes[row], c->blocksizes[col]) - 1);
-            if (row == col) bw = std::max<int64_t>(bw, c->blocksizes[row] - 1);
+            if (red_of[row] < c->n_band && red_of[col] < c->n_band && row != col) { bw = std::max<int64_t>(bw, std::llabs(red_of[row] - red_of[col]) + std::max(c->blocksizes[row], c->blocksizes[col]) - 1);
+                bt_note(std::min(red_of[row], red_of[col]), std::max(red_of[row] + c->blocksizes[row], red_of[col] + c->blocksizes[col]) - 1); }
+            if (row == col) { bw = std::max<int64_t>(bw, c->blocksizes[row] - 1); if (red_of[row] < c->n_band) bt_note(red_of[row], red_of[row] + c->blocksizes[row] - 1); }
         } }
     c->ncopy = (int64_t)copies.size();
     if ((flags & NLLS_FLAG_PRESHARDED) && c->nranks > 1) {
@@ -1032,16 +1038,16 @@ int build_schur(nlls_ctx* c, int32_t flags) {
               int64_t len = 0; if (I0.is_sparse) for (int64_t q = c->it_colptr[k]; q < c->it_colptr[k + 1]; ++q) len += (int64_t)c->blocksizes[k] * c->blocksizes[c->it_rowval[q]];
               mix((uint64_t)len); }
           seghash = (double)(hsh >> 12); }
-        double h[16] = {(double)bw, (double)c->nbd, (double)c->n_band, (double)c->nred, -(double)c->nbd, -(double)c->n_band, -(double)c->nred, 0.0,
-                        (double)c->redbuf_len, -(double)c->redbuf_len, (double)c->ncopy, -(double)c->ncopy, seghash, -seghash, 0.0, 0.0};
-        DevBuf<double> dh; HIPCHK(dh.alloc(16));
+        double h[20] = {(double)bw, (double)c->nbd, (double)c->n_band, (double)c->nred, -(double)c->nbd, -(double)c->n_band, -(double)c->nred, 0.0,
+                        (double)c->redbuf_len, -(double)c->redbuf_len, (double)c->ncopy, -(double)c->ncopy, seghash, -seghash, 0.0, 0.0, bt_bad[1], bt_bad[2], bt_bad[3], bt_bad[4]};   // (bt_bad: a block size one rank's couplings rule out is ruled out)
+        DevBuf<double> dh; HIPCHK(dh.alloc(20));
         HIPCHK(hipMemcpyAsync(dh.p, h, sizeof h, hipMemcpyHostToDevice, c->stream));
-        { const int rc = comm_reduce(c, dh.p, 16, NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
+        { const int rc = comm_reduce(c, dh.p, 20, NLLS_REDUCE_MAX); if (rc != NLLS_OK) return rc; }
         HIPCHK(hipMemcpyAsync(h, dh.p, sizeof h, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
         if (h[1] != -h[4] || h[2] != -h[5] || h[3] != -h[6]) return fail(c, NLLS_ERR_INVALID_ARG, "NLLS_FLAG_PRESHARDED: the ranks' reduced systems differ in size or border (the reduced variables must be the same on every rank)");
         if (h[8] != -h[9] || h[10] != -h[11] || h[12] != -h[13]) return fail(c, NLLS_ERR_INVALID_ARG, "NLLS_FLAG_PRESHARDED: the ranks' reduced rows differ in layout (stage-0 buffer length, reduced-reduced block list or segment lengths): "
                                                                                       "every rank must hold the same reduced variables in the same order, each coupled to the same stored blocks -- list the reduced variables before the eliminated ones");
-        bw = (int64_t)h[0];
+        bw = (int64_t)h[0]; for (int t = 1; t <= 4; ++t) bt_bad[t] = h[15 + t];
     }
     { std::vector<SchurCopy> blks;
       if (I0.is_sparse) for (int64_t row = 0; row < nb; ++row) for (int64_t q = c->it_colptr[row]; q < c->it_colptr[row + 1]; ++q) { int64_t col = c->it_rowval[q];
@@ -1119,7 +1125,14 @@ int build_schur(nlls_ctx* c, int32_t flags) {
         if (hipSuccess != c->S.alloc(sz + (size_t)n + 64) || hipSuccess != c->Lwork.alloc(std::max(sz, tsz)) || hipSuccess != c->d_status.alloc(96)) return fail(c, NLLS_ERR_HIP, "band system alloc");
         // block cyclic reduction (nlls_bcr.hip) is the band solver whenever it supports the shape; the chain kernels stay as fallbacks
         if (!(flags & NLLS_FLAG_NO_BCR) && BcrSolver::supports(c->n_band, (int)bw, c->nbd)) {
-            std::string e; const int rc = c->bcr.build(c->n_band, (int)bw, c->nbd, c->band_H, &e);
+            // tiles per block: the cheapest dependent chain, NT x levels (levels = ceil(log2(N + 1)) for N blocks), among the block sizes the structure allows
+            // (NLLS_BCR_NT_FULL=1: always ceil(bw / 16), rounds 2-5)
+            const int nt_full = std::max(1, ((int)bw + 15) / 16); int nt_best = nt_full;
+            if (!getenv("NLLS_BCR_NT_FULL")) {
+                auto chain = [&](int t) { const int64_t N = (c->n_band + 16 * t - 1) / (16 * t); int lv = 0; while (((int64_t)1 << lv) < N + 1) ++lv; return (int64_t)t * lv; };
+                for (int t = nt_full - 1; t >= 1; --t) if (bt_bad[t] == 0.0 && chain(t) < chain(nt_best)) nt_best = t;
+            }
+            std::string e; const int rc = c->bcr.build(c->n_band, (int)bw, c->nbd, c->band_H, &e, nt_best);
             if (rc != NLLS_OK) return fail(c, rc, e.c_str());
         }
         // ---- slab + gather assembly (NLLS_FLAG_DETERMINISTIC: no atomics, x is bit-reproducible; 15 % slower than the atomic flush at
