@@ -274,7 +274,8 @@ int  nlls_solve(nlls_ctx* ctx, double* x_out);
  * re-ordered reduced system and the border strip ("windowed": O(n w^2) work in dense storage, for bands too wide for the band kernels).
  * Tile-sparse solver (solve_mode 3): [16] tiles of 128 unknowns, [17] levels of the tile elimination tree (the dependent chain of the factorisation),
  * [18] lower tiles stored (fill included), [19] kernel launches per reduced solve, [20] 128^3 tile products per factorisation (updates + panels).
- * [21], [22] look-ahead sweeps used / thrown away; [23] matrix-free LM trials, [24] gradient sweeps of the reduced rows only, [25] full accumulate sweeps since the upload. */
+ * [21], [22] look-ahead sweeps used / thrown away; [23] matrix-free LM trials, [24] gradient sweeps of the reduced rows only, [25] full accumulate sweeps since the upload;
+ * [26] unknowns per block of the block cyclic reduction (the smallest multiple of 16 that keeps the band block tridiagonal: may be below the bandwidth [5]). */
 int  nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n);
 /* Run-time switches of a context (A/B measurements, parity tests through both paths on ONE upload):
  *   NLLS_OPT_MATERIALIZE  value != 0: nlls_lm_trial eliminates from the materialised A.data (the round-5 path) although the structure qualifies for the

@@ -336,13 +336,13 @@ class Context:
         return dict(timegradient=out[0] * 1e-9, timecost=out[1] * 1e-9, timesolver=out[2] * 1e-9, trials=int(out[3]))
 
     def solve_stats(self):
-        out = np.zeros(26, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 26))
+        out = np.zeros(27, np.int64); self._chk(self.L.nlls_get_solve_stats(self.h, _p(out), 27))
         return dict(status=int(out[0]), band_factor_cycles=int(out[1]), band_backward_cycles=int(out[2]), solve_mode=int(out[3]),
                     elim_supernodes=int(out[4]), bandwidth=int(out[5]), bcr_mfma_issued=int(out[6]), bcr_launches=int(out[7]), bcr_levels=int(out[8]),
                     band_dof=int(out[9]), dropped_pivots=int(out[10]), reduced_row_sums=int(out[11]), lazy_trials=int(out[12]),
                     reordered=int(out[13]), bandwidth_caller_order=int(out[14]), dense_window=int(out[15]),
                     tsp_tiles=int(out[16]), tsp_levels=int(out[17]), tsp_lower_tiles=int(out[18]), tsp_launches=int(out[19]), tsp_products=int(out[20]),
-                    lookahead_hits=int(out[21]), lookahead_misses=int(out[22]), mf_trials=int(out[23]), reduced_sweeps=int(out[24]), full_sweeps=int(out[25]))
+                    lookahead_hits=int(out[21]), lookahead_misses=int(out[22]), mf_trials=int(out[23]), reduced_sweeps=int(out[24]), full_sweeps=int(out[25]), bcr_block=int(out[26]))
 
     def set_step(self, x):
         x = np.ascontiguousarray(x, np.float64); assert x.size == self.info.ndof

@@ -620,13 +620,14 @@ int nlls_get_solve_stats(nlls_ctx* ctx, int64_t* out, int32_t n) { NLLS_API_BEGI
     int32_t status[16] = {0};
     HIPCHK(hipMemcpyAsync(status, ctx->d_status.p, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    const int64_t vals[26] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
+    const int64_t vals[27] = {status[0], (int64_t)status[2] << 10, (int64_t)status[3] << 10, ctx->solve_mode, ctx->nelim_groups, ctx->bw,
                               ctx->bcr.ready ? ctx->bcr.mfma_issued : 0, ctx->bcr.ready ? ctx->bcr.launches : 0, ctx->bcr.ready ? (int64_t)ctx->bcr.levels.size() : 0, ctx->n_band,
                               status[4] /* pivots the floor of the last undamped band solve dropped */, ctx->n_stage0, ctx->n_lazy_trials, ctx->red_reordered, ctx->bw_caller, ctx->dense_window ? 1 : 0,
                               ctx->tsp.ready ? ctx->tsp.nt : 0, ctx->tsp.ready ? (int64_t)ctx->tsp.levels.size() : 0, ctx->tsp.ready ? ctx->tsp.nslots : 0, ctx->tsp.ready ? ctx->tsp.launches : 0, ctx->tsp.ready ? ctx->tsp.products : 0,
                               ctx->spec_hits, ctx->spec_misses /* look-ahead sweeps used / thrown away */,
-                              ctx->mf_trials, ctx->mf_reduced_sweeps, ctx->full_sweeps /* matrix-free LM trials, sweeps of the reduced rows only, full accumulate sweeps since the upload */};
-    for (int i = 0; i < n && i < 26; ++i) out[i] = vals[i];
+                              ctx->mf_trials, ctx->mf_reduced_sweeps, ctx->full_sweeps /* matrix-free LM trials, sweeps of the reduced rows only, full accumulate sweeps since the upload */,
+                              ctx->bcr.ready ? 16 * ctx->bcr.NT : 0 /* unknowns per block of the block cyclic reduction */};
+    for (int i = 0; i < n && i < 27; ++i) out[i] = vals[i];
     return NLLS_OK;
     NLLS_API_END(ctx)
 }

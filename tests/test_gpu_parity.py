@@ -558,6 +558,28 @@ def test_block_cyclic_reduction_shapes(ncam, npts, cpp, adaptive, seed):
     assert info.solve_mode == 2
 
 
+@pytest.mark.parametrize("ncam,npts,cpp,seed,block", [(130, 3000, 10.5, 921, 64), (333, 7000, 10.5, 922, 64), (130, 3000, 11.5, 923, 80), (150, 3000, 7.9, 924, None)])
+def test_block_size_of_the_cyclic_reduction_comes_from_the_structure(ncam, npts, cpp, seed, block, monkeypatch):
+    """Round 6: the blocks of the block cyclic reduction are the smallest multiple of 16 unknowns that keeps the band part of S block TRIDIAGONAL -- found from the coupled
+    pairs themselves, not from the bandwidth (cameras of 6 unknowns that share points with ten neighbours: bandwidth 65, and no coupling crosses two blocks of 64; with eleven
+    neighbours some do, and the blocks stay at 80).  x of both block sizes against the oracle (check_problem) and against each other."""
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(ncam, npts, cpp / ncam, seed=seed), 1e-3, 1e-3)
+    info = check_problem(p, expect_sparse=1, expect_schur=1)
+    assert info.solve_mode == 2
+    bi = np.arange(1, p.nvariables + 1, dtype=np.uint64); xs = {}
+    for full in (0, 1):
+        if full: monkeypatch.setenv("NLLS_BCR_NT_FULL", "1")
+        ctx = _capi.Context(); ctx.upload(p.var_kind, p.var_dim, bi, p.groups(), 0)
+        st = ctx.solve_stats(); bw = st["bandwidth"]
+        if full: assert st["bcr_block"] == 16 * ((bw + 15) // 16)
+        elif block is not None: assert st["bcr_block"] == block, (st["bcr_block"], bw)
+        assert st["bcr_block"] <= 16 * ((bw + 15) // 16)
+        ctx.set_variables(p.variables); ctx.sweep_gradhess(); ctx.damp(1e-4 * ctx.max_abs_diag())
+        xs[full] = ctx.solve(want_x=True).copy(); ctx.close()
+    monkeypatch.delenv("NLLS_BCR_NT_FULL")
+    assert rel(xs[0], xs[1]) < 1e-10
+
+
 @pytest.mark.parametrize("ncam,npts,cpp,seed", [(130, 3000, 10.5, 951), (96, 2000, 5.2, 952), (300, 9000, 10.5, 953)])
 def test_deterministic_flag_is_bit_reproducible(ncam, npts, cpp, seed):
     """NLLS_FLAG_DETERMINISTIC: the reduced system is assembled from per-supernode slabs by an ordered gather (no atomics) and
