@@ -114,6 +114,45 @@ __device__ __forceinline__ void chain_blocked2(bdouble4_t& A, bdouble4_t& Bt, in
         }
     }
 }
+// V == 9: a REAL all-vector rank-1 update of the tile and of its inverse (no matrix-core instruction at all): row k of the symmetric tile sits in register k / 4 of the sixteen lanes
+// with lk = k % 4; every lane fetches its column's entry T[k][li] and its four rows' entries T[k][lk + 4 r] (= T[lk + 4 r][k]) through the LDS crossbar (ds_bpermute_b32 x 2 per
+// double: 12 per pivot with the inverse's row), then four FMAs per accumulator.  Same arithmetic per entry as the MFMA form (one product, one fused add).
+__device__ __forceinline__ void chain_valu(bdouble4_t& A, bdouble4_t& Bt, int li, int lk) {
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        const int q = k & 3, r0 = k >> 2;
+        const double w = A[r0], bt = Bt[r0];
+        const double dk = rl(w, 16 * q + k);
+        const double colv = bperm(w, 4 * (16 * q + li)), colb = bperm(bt, 4 * (16 * q + li));
+        double rowv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowv[r] = bperm(w, 4 * (16 * q + lk + 4 * r));
+        double rdk = __builtin_amdgcn_rcp(dk); rdk = refine(dk, rdk);
+        const double ca = li > k ? colv * -rdk : 0.0, cb = colb * -rdk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const double a = lk + 4 * r > k ? rowv[r] : 0.0; A[r] = fma(a, ca, A[r]); Bt[r] = fma(a, cb, Bt[r]); }
+    }
+}
+// V == 10: hybrid -- the tile's update on the matrix core, the inverse's on the vector side (its operands through the LDS crossbar: 10 ds_bpermute per pivot)
+__device__ __forceinline__ void chain_hybrid(bdouble4_t& A, bdouble4_t& Bt, int li, int lk) {
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        const int q = k & 3, r0 = k >> 2;
+        const double w = A[r0], bt = Bt[r0];
+        const double dk = rl(w, 16 * q + k);
+        const double colb = bperm(bt, 4 * (16 * q + li));
+        double rowv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowv[r] = bperm(w, 4 * (16 * q + lk + 4 * r));
+        double rdk = __builtin_amdgcn_rcp(dk); rdk = refine(dk, rdk);
+        const bool rowq = lk == q;
+        const double am = (rowq && li > k) ? w : 0.0;
+        A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
+        const double cb = colb * -rdk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const double a = lk + 4 * r > k ? rowv[r] : 0.0; Bt[r] = fma(a, cb, Bt[r]); }
+    }
+}
 template <int V>
 __global__ void k(const double* T, double* out, long long* cyc, int reps) {
     const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
@@ -123,7 +162,7 @@ __global__ void k(const double* T, double* out, long long* cyc, int reps) {
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < reps; ++it) {
         bdouble4_t A = A0, Bt = B0; A[0] += acc * 1e-300;        // (a dependence from one repetition to the next)
-        if constexpr (V == 6) chain_deferred(A, Bt, li, lk); else if constexpr (V == 7) chain_blocked(A, Bt, li, lk); else if constexpr (V == 8) chain_blocked2(A, Bt, li, lk); else chain<V>(A, Bt, li, lk);
+        if constexpr (V == 6) chain_deferred(A, Bt, li, lk); else if constexpr (V == 9) chain_valu(A, Bt, li, lk); else if constexpr (V == 10) chain_hybrid(A, Bt, li, lk); else if constexpr (V == 7) chain_blocked(A, Bt, li, lk); else if constexpr (V == 8) chain_blocked2(A, Bt, li, lk); else chain<V>(A, Bt, li, lk);
         acc += A[3] + Bt[3];
     }
     const long long t1 = __builtin_readcyclecounter();
@@ -133,21 +172,26 @@ template <int V>
 __global__ void dump(const double* T, double* outA, double* outB) {
     const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
     bdouble4_t A, B; for (int r = 0; r < 4; ++r) { A[r] = T[(lk + 4 * r) * 16 + li]; B[r] = (lk + 4 * r == li) ? 1.0 : 0.0; }
-    if constexpr (V == 7) chain_blocked(A, B, li, lk); else if constexpr (V == 8) chain_blocked2(A, B, li, lk); else chain<0>(A, B, li, lk);
+    if constexpr (V == 7) chain_blocked(A, B, li, lk); else if constexpr (V == 8) chain_blocked2(A, B, li, lk); else if constexpr (V == 9) chain_valu(A, B, li, lk); else chain<0>(A, B, li, lk);
     for (int r = 0; r < 4; ++r) { outA[(lk + 4 * r) * 16 + li] = A[r]; outB[(lk + 4 * r) * 16 + li] = B[r]; }
 }
 int main() {
     double h[256]; for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) h[i * 16 + j] = (i == j ? 20.0 : 0.0) + 1.0 / (1 + i + j);
     double *T, *out; long long* cyc; hipMalloc(&T, sizeof h); hipMalloc(&out, 64 * 8); hipMalloc(&cyc, 8); hipMemcpy(T, h, sizeof h, hipMemcpyHostToDevice);
-    const int reps = 2000; const char* names[] = {"full chain (as in the library)", "without the inverse's MFMA", "raw v_rcp_f64 (no refinement)", "no v_rcp_f64 (constant)", "no MFMA (vector FMAs)", "pivot by ds_bpermute instead of v_readlane", "the inverse's MFMA deferred behind the next read-lane", "four pivots per MFMA (in-group elimination on the vector side)", "... the group's columns fetched once, eliminated in every row group"};
+    const int reps = 2000; const char* names[] = {"full chain (as in the library)", "without the inverse's MFMA", "raw v_rcp_f64 (no refinement)", "no v_rcp_f64 (constant)", "no MFMA (vector FMAs)", "pivot by ds_bpermute instead of v_readlane", "the inverse's MFMA deferred behind the next read-lane", "four pivots per MFMA (in-group elimination on the vector side)", "... the group's columns fetched once, eliminated in every row group", "ALL-VECTOR rank-1 updates (12 ds_bpermute + 8 FMA per pivot, no MFMA)", "hybrid: tile on the matrix core, inverse on the vector side (10 ds_bpermute + 4 FMA)"};
     auto run = [&](auto kern, int v) { long long c = 0; for (int w = 0; w < 2; ++w) { hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, 0, T, out, cyc, reps); hipDeviceSynchronize(); } hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
         printf("%-48s %8.1f shader-clock cycles per pivot\n", names[v], (double)c / reps / 15.0); };
-    run(k<0>, 0); run(k<1>, 1); run(k<2>, 2); run(k<3>, 3); run(k<4>, 4); run(k<5>, 5); run(k<6>, 6); run(k<7>, 7); run(k<8>, 8);
+    run(k<0>, 0); run(k<1>, 1); run(k<2>, 2); run(k<3>, 3); run(k<4>, 4); run(k<5>, 5); run(k<6>, 6); run(k<7>, 7); run(k<8>, 8); run(k<9>, 9); run(k<10>, 10);
     { double *dA, *dB; hipMalloc(&dA, 256 * 8); hipMalloc(&dB, 256 * 8); double a0[256], b0[256], a7[256], b7[256];
       hipLaunchKernelGGL(dump<0>, dim3(1), dim3(64), 0, 0, T, dA, dB); hipMemcpy(a0, dA, sizeof a0, hipMemcpyDeviceToHost); hipMemcpy(b0, dB, sizeof b0, hipMemcpyDeviceToHost);
       hipLaunchKernelGGL(dump<8>, dim3(1), dim3(64), 0, 0, T, dA, dB); hipMemcpy(a7, dA, sizeof a7, hipMemcpyDeviceToHost); hipMemcpy(b7, dB, sizeof b7, hipMemcpyDeviceToHost);
       double ea = 0, eb = 0, eal = 0; for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { const double da = fabs(a0[i * 16 + j] - a7[i * 16 + j]) / (fabs(a0[i * 16 + j]) + 1e-300), db = fabs(b0[i * 16 + j] - b7[i * 16 + j]) / (fabs(b0[i * 16 + j]) + 1e-300); if (da > ea) ea = da; if (i >= j && da > eal) eal = da; if (db > eb && fabs(b0[i * 16 + j]) > 1e-300) eb = db; }
       printf("blocked against the library chain: max rel diff of the factored tile %.2e (lower triangle %.2e), of the inverse %.2e\n", ea, eal, eb); }
+    { double *dA, *dB; hipMalloc(&dA, 256 * 8); hipMalloc(&dB, 256 * 8); double a0[256], b0[256], a9[256], b9[256];
+      hipLaunchKernelGGL(dump<0>, dim3(1), dim3(64), 0, 0, T, dA, dB); hipMemcpy(a0, dA, sizeof a0, hipMemcpyDeviceToHost); hipMemcpy(b0, dB, sizeof b0, hipMemcpyDeviceToHost);
+      hipLaunchKernelGGL(dump<9>, dim3(1), dim3(64), 0, 0, T, dA, dB); hipMemcpy(a9, dA, sizeof a9, hipMemcpyDeviceToHost); hipMemcpy(b9, dB, sizeof b9, hipMemcpyDeviceToHost);
+      int same = 1; for (int i = 0; i < 256; ++i) same &= (a0[i] == a9[i]) && (b0[i] == b9[i]);
+      printf("all-vector == library chain, bit for bit: %s\n", same ? "yes" : "NO"); }
     { double o0[64], o6[64]; hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, T, out, cyc, 1); hipMemcpy(o0, out, sizeof o0, hipMemcpyDeviceToHost); hipLaunchKernelGGL(k<6>, dim3(1), dim3(64), 0, 0, T, out, cyc, 1); hipMemcpy(o6, out, sizeof o6, hipMemcpyDeviceToHost);
       int same = 1; for (int i = 0; i < 64; ++i) same &= o0[i] == o6[i]; printf("deferred == library chain, bit for bit: %s\n", same ? "yes" : "NO"); }
     return 0;
