@@ -31,7 +31,6 @@ struct MfArgs {
     uint32_t wsz, ecap;                                                  // doubles of LDS per wavefront, of which the E slab
     double* stamps;                                                      // nlls_ctx::stamp_ptr (device-timed buckets)
     uint32_t nbig, ntiny;                                                // supernodes of several batches (one workgroup each) come first, then those of ONE batch (one wavefront each)
-    int dbg;
 };
 // per-wavefront LDS: [E slab: B x (DP + 1) x LDC | red: 64 x NRED | sums: BMAX x NRED | cinv: BMAX x (DP + 1) x DP]; at least the supernode's share in slab layout (nlls_ctx::mf_wsz).
 // Row DP of a member's slab and of its inverse block is ZERO: the lanes of the instruction's fourth k-slot (DP = 3) read their operands there like the others -- no selects in the member loop
@@ -60,7 +59,7 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
     const int ml = lane / ncb, j = lane - ml * ncb;       // this lane's block inside a batch: member ml of the batch, column block j of [E]
     const bool lane_in = ml < B;
     const double* __restrict__ vars = a.vars; const double* __restrict__ odata = a.odata; const uint32_t* __restrict__ ovoff = a.ovoff;
-    const RobustSpec rk = a.rk; const double lambda = a.lambda; const int dbg = a.dbg;
+    const RobustSpec rk = a.rk; const double lambda = a.lambda;
     const uint32_t obs0 = d.obs0, v0 = d.v0, eb0 = d.eb0;
     const int kk = lk < DP ? lk : DP;                    // (lanes of a k-slot the block does not have: the zero row)
     using St = double[2][MAXST];
@@ -82,7 +81,7 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
         load_rec(mb + stride * B, r1);                                // the next batch's records: in flight through this batch's evaluation
         {
             BlockGH<KIND> G; G.compute_st(s0, r0.dd, rk, false);
-            if (active && !(dbg & 4)) {
+            if (active) {
                 double* er = Ew + (size_t)ml * MST + DC * j;
 #pragma unroll
                 for (int k = 0; k < DP; ++k)
@@ -110,7 +109,7 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
         }
         wave_lds_sync();
         // (C_v + lambda I)^-1 by LDL' (the arithmetic of schur_cinv_kernel; the pivots' reciprocals by v_rcp_f64 + one cubic step), one lane per member
-        if (lane < nlive && !(dbg & 2)) {
+        if (lane < nlive) {
             const double* sm = sums + lane * NRED;
             double C[DP * DP], id[DP];
             { int q = 0;
@@ -157,7 +156,7 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
         // per member: S_supernode += E' (C + lambda I)^-1 [E | b] on the matrix cores -- tile (Rr, Cc) is one instruction whose A operand is lane (i, k) <- e_{16 Rr + i}[k]
         // and whose B operand is lane (j, k) <- y_{16 Cc + j}[k], y = (C + lambda I)^-1 e; both read from the slab (row k of E is contiguous: sixteen lanes, sixteen doubles).
 #pragma unroll 1
-        for (int m2 = 0; m2 < ((dbg & 1) ? 0 : nlive); ++m2) {
+        for (int m2 = 0; m2 < nlive; ++m2) {
             const double* em = Ew + (size_t)m2 * MST + li;
             double cr[DP];
 #pragma unroll
@@ -203,7 +202,6 @@ __device__ __forceinline__ void mf_elim_big(const MfArgs& a, uint32_t bidx, doub
 #pragma unroll
         for (int t = 0; t < TRK * (TRK + 1) / 2; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
         mf_wave_batches<KIND, PS, TRK>(a, d, Ew, wave, MF_ENW, acc);
-        if (a.dbg & 16) return;
         // The wavefronts' tiles meet in LDS in the layout of the supernode's SLAB (build_schur: one column-major block per pair of neighbour blocks a >= b in list order -- of a
         // diagonal pair the lower triangle --, then the right-hand side) in the place of the wavefronts' regions, and leave with plain coalesced stores: schur_gather_kernel
         // sums the supernodes' shares of every block pair of S in a fixed order, straight into the block cyclic reduction's tiles.  No atomics on HBM: the reduced system
@@ -225,9 +223,8 @@ __device__ __forceinline__ void mf_elim_big(const MfArgs& a, uint32_t bidx, doub
         };
         if (wave == 0) each([](double* p, double v) { *p = v; });
         __syncthreads();
-        if (wave > 0 && wave < nact && !(a.dbg & 32)) each([](double* p, double v) { atomicAdd(p, v); });
+        if (wave > 0 && wave < nact) each([](double* p, double v) { atomicAdd(p, v); });
         if (nact > 1) __syncthreads();
-        if (a.dbg & 64) return;
         { double* __restrict__ out = a.slab + d.slab; const int len = npair * (DC * DC) + nd;
           for (int i = tid; i < len; i += 64 * MF_ENW) out[i] = img[i]; }
     };
@@ -257,7 +254,6 @@ __device__ __forceinline__ void mf_elim_tiny(const MfArgs& a, uint32_t sidx, dou
 #pragma unroll
         for (int t = 0; t < TRK * (TRK + 1) / 2; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
         mf_wave_batches<KIND, PS, TRK>(a, d, Ew, 0, 1, acc);
-        if (a.dbg & (16 | 64)) return;
         // the wavefront's own region takes its tiles in slab layout (mf_elim_big), then they leave with coalesced stores
         double* const img = Ew; const int npair = ncb * (ncb + 1) / 2; double* const irhs = img + npair * (DC * DC);
 #pragma unroll
@@ -300,7 +296,7 @@ static int launch_mf_elim(nlls_ctx* c, const Group& G) {
     if constexpr (Res<KIND>::NDEPS == 2 && Res<KIND>::ADAPT == 0 && !is_cost_kind<KIND> && ResInfo<KIND>::dof(PS < 2 ? PS : 0) <= 3) {
         const unsigned nsn = (unsigned)c->mf_nbig + (unsigned)((c->n_fast_groups - c->mf_nbig + MF_ENW - 1) / MF_ENW);
         MfArgs a{}; a.vars = vars_ptr(c, NLLS_VARS_CURRENT); a.odata = G.mf_data.p; a.ovoff = G.mf_voff.p; a.rk = G.rk; a.desc = c->d_mf_desc.p; a.rcflat = c->d_elim_rc.p; a.nbig = (uint32_t)c->mf_nbig; a.ntiny = (uint32_t)(c->n_fast_groups - c->mf_nbig);
-        a.stamps = c->stamp_ptr(); a.Cinv = c->Cinv.p; a.b = c->b.p; a.slab = c->slab.p; a.lambda = c->lambda; a.status = c->d_status.p; a.wsz = c->mf_wsz; a.ecap = c->mf_ecap; { static const int dbg = [] { const char* e = getenv("NLLS_MF_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+        a.stamps = c->stamp_ptr(); a.Cinv = c->Cinv.p; a.b = c->b.p; a.slab = c->slab.p; a.lambda = c->lambda; a.status = c->d_status.p; a.wsz = c->mf_wsz; a.ecap = c->mf_ecap;
         static size_t granted = 0;
         if (c->mf_lds > 64 * 1024 && c->mf_lds > granted) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf_elim_kernel<KIND, PS, SLayout>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->mf_lds)); granted = c->mf_lds; }
         hipLaunchKernelGGL((mf_elim_kernel<KIND, PS, SLayout>), dim3(nsn), dim3(64 * MF_ENW), c->mf_lds, c->stream, a);

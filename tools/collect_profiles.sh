@@ -18,6 +18,10 @@ done
 for w in ba_100x10k ba_so3_500x50k ba_1kx100k; do cp "$(last "$o/${t}_valu_$w/*/*counter_collection.csv")" $p/${t}_pmc_issue_sweep_$w.csv; done
 for k in band dense; do f="$(last "$o/${t}_mfma_$k/*/*counter_collection.csv")"; [ -n "$f" ] && cp "$f" $p/${t}_pmc_mfma_$k.csv; done
 cp $o/${t}_pmc_traffic.json $p/pmc_traffic.json; cp $o/${t}_pmc_mfma.json $p/pmc_mfma.json
+[ -f $o/${t}_pmc_iter.json ] && cp $o/${t}_pmc_iter.json $p/pmc_iter.json
+for w in ba_1kx100k ba_100x10k; do for x in fetch_mf fetch_mat write_mf write_mat; do f="$(last "$o/${t}_iter_${x}_$w/*/*counter_collection.csv")"; [ -n "$f" ] && cp "$f" $p/${t}_pmc_iter_${x}_$w.csv; done; done
+[ -f $o/${t}_bench_materialised.json ] && cp $o/${t}_bench_materialised.json $p/${t}_bench_materialised.json
+f="$(last "$o/${t}_stats_materialised/*/*kernel_stats.csv")"; [ -n "$f" ] && cp "$f" $p/${t}_kernel_stats_materialised.csv
 for w in ba_grid_40x40 ba_grid_100x100 ba_grid_40x40_windowed; do [ -f $o/${t}_bench_$w.json ] && cp $o/${t}_bench_$w.json $p/${t}_bench_$w.json; done
 f="$(last "$o/${t}_stats_ba_grid_40x40/*/*kernel_stats.csv")"; [ -n "$f" ] && cp "$f" $p/${t}_kernel_stats_ba_grid_40x40.csv
 [ -f $o/${t}_tsp_try.json ] && cp $o/${t}_tsp_try.json $p/${t}_tsp_try.json

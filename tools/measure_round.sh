@@ -14,11 +14,16 @@ for w in ba_1kx100k ba_100x10k ba_so3_500x50k; do
   rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_valu_$w -- python tools/sweep_only.py --workload $w --reps 3 > /dev/null 2> gpurun_out/${tag}_valu_$w.err || exit 14
 done
 cp profiles/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.json
+# HBM bytes of ONE LM iteration, matrix-free and materialised (every kernel of the loop): profiles/pmc_iter.json, quoted by bench.py as hbm_bytes_per_lm_iteration
+for w in ba_1kx100k ba_100x10k; do bash tools/pmc_iter.sh ${tag} $w > gpurun_out/${tag}_pmc_iter_$w.txt 2>&1 || exit 19; done
 # hardware counters under the matrix-core figures (f64 MFMA instructions, matrix-pipe busy cycles): profiles/pmc_mfma.json, checked by bench.py against the launcher's count
 bash tools/pmc_mfma.sh ${tag} > gpurun_out/${tag}_pmc_mfma.txt 2>&1 || exit 10
 cp profiles/pmc_mfma.json gpurun_out/${tag}_pmc_mfma.json
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
 for w in ba_100x10k curvefit_10k ba_so3_500x50k ba_10kx1M; do python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_$w.json 2> gpurun_out/${tag}_bench_$w.err || exit 6; done
+# the same loop through the MATERIALISING kernels (rounds 1-5: accumulate sweep -> A.data -> elimination), bench line and kernel trace
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --path materialise > gpurun_out/${tag}_bench_materialised.json 2> gpurun_out/${tag}_bench_materialised.err || exit 20
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_materialised -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --path materialise > /dev/null 2> gpurun_out/${tag}_stats_materialised.err || exit 21
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --shuffle-cameras 7 > gpurun_out/${tag}_bench_shuffled.json 2> gpurun_out/${tag}_bench_shuffled.err || exit 15
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --solver nofloor > gpurun_out/${tag}_bench_nofloor.json 2> gpurun_out/${tag}_bench_nofloor.err || exit 16
 python bench.py --solver dense --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_dense.json 2> gpurun_out/${tag}_bench_dense.err || exit 7
