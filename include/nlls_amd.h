@@ -93,7 +93,7 @@ typedef struct nlls_ctx nlls_ctx;
 /* USER residual kinds (round 5).  The reference takes any Julia function as a residual and differentiates it with ForwardDiff (/root/reference/src/autodiff.jl:81-93,
  * README.md:36-46); a HIP kernel cannot call those, so the registry above is closed at run time -- but not at BUILD time: ids 100 .. 107 are reserved for kinds a user
  * header adds.  Such a header (nllssolver.jl_amd/csrc/Makefile: `make user USER_KINDS=/abs/path/kinds.hpp LIB=libmine.so OBJDIR=build_mine`) specialises
- * nlls::Res<NLLS_RES_USERk> -- NDEPS (<= 4 slots), M, NDATA, the slots' variable kinds SK / dimensions SD, and ONE templated eval<T>(data, variables, r), generic in the
+ * nlls::Res<NLLS_RES_USERk> -- NDEPS (<= MAX_SLOTS = 10 slots, the reference's MAX_ARGS), M, NDATA, the slots' variable kinds SK / dimensions SD, and ONE templated eval<T>(data, variables, r), generic in the
  * scalar type exactly like the reference's computeresidual -- and lists its kinds in NLLS_USER_RES(X).  Everything else follows from that: the Jacobian w.r.t. the tangent of
  * update() by dual numbers, the accumulate kernels, the cost sweep, optimizesingles, the Schur path.  tests/user_kinds/radial_ba.hpp is a worked example (an affine camera
  * with one radial distortion coefficient), built by __graft_entry__.build() and exercised on the GPU by tests/test_gpu_userkind.py. */

@@ -132,6 +132,7 @@ int nlls_comm_agreed_flag(nlls_ctx* ctx, double local_value, double* out) { NLLS
     if (!ctx || !out) return NLLS_ERR_INVALID_ARG;
     // the agreed value only when the last trial really gathered it: with an all-reduce installed on a DENSE system (or before the first trial) nothing
     // writes comm_agreed, and answering 0 would silently disable the caller's deadline (advisor, round 4)
+    // (replicas -- dense systems, systems without an eliminated set under nlls_set_shard -- enter no collective: nothing waits on a peer, each replica keeps its own deadline)
     *out = (ctx->reduce_fn && ctx->comm_gathered) ? ctx->comm_agreed : local_value;
     return NLLS_OK;
     NLLS_API_END(ctx)
