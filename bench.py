@@ -115,10 +115,11 @@ def self_launch(n, deadline_s=None):
 
 def predicted_scaling(world):
     """The scaling model of DESIGN.md 5 for `bench.py --gpus N` on BASELINE config 4, printed WITH the measured line so that the first multi-GPU run falsifies it on the spot
-    (no multi-GPU node has been available to this build in five rounds: every number here is a prediction from one-GPU measurements, not a measurement)."""
-    # one LM iteration on one MI355X (round 5: one damped solve per iteration), in us -- from profiles/r05_kernel_stats.csv
-    divides = {"accumulate sweep": 46.0, "Schur elimination": 80.0, "back-substitution + retraction": 27.0, "cost sweep + step statistics": 12.0}
-    replicated = {"block cyclic reduction of the reduced system (every rank)": 170.0, "convert + finish launches": 10.0, "host turn-around + launch gaps": 20.0}
+    (no multi-GPU node has been available to this build in six rounds: every number here is a prediction from one-GPU measurements, not a measurement)."""
+    # one LM iteration of the MATERIALISED trial -- the kernels of the collective route -- on one MI355X (round 6: one damped solve per iteration, 324 us), in us:
+    # profiles/r06*_kernel_stats_materialised.csv
+    divides = {"accumulate sweep": 44.0, "Schur elimination": 83.0, "back-substitution + retraction": 28.0, "cost sweep + step statistics": 14.0}
+    replicated = {"block cyclic reduction of the reduced system (every rank)": 150.0, "convert + finish launches": 10.0, "host turn-around + launch gaps": 10.0}
     allreduce = {2: 40.0, 4: 50.0, 8: 60.0}.get(world, 40.0 + 10.0 * max(0, world.bit_length() - 2))      # [S | s], 3.4 MB, ring over point-to-point xGMI links: latency-dominated
     route = 9.0                                                                                            # pack / combine launches + the trial's 128-byte gather (measured with one rank: DESIGN.md 5)
     d, r = sum(divides.values()), sum(replicated.values())
