@@ -158,7 +158,7 @@ def main():
                     help="permute the cameras' labels (seeded) before the upload: the reference generator numbers neighbouring cameras consecutively, "
                          "real image collections do not -- the reduced camera system is then re-ordered at upload (reverse Cuthill-McKee)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=10, help="LM iterations of the CPU oracle behind cpu_baseline (about 12 s of one core at BASELINE config 4)")
     ap.add_argument("--repeats", type=int, default=7, help="the (W warm-up + K timed) loop is run this many times from the same start; value = the MEDIAN run")
     ap.add_argument("--die-rank", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: this rank exits non-zero in the middle of the timed loop
     args = ap.parse_args()
