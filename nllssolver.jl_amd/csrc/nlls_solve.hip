@@ -1581,14 +1581,8 @@ __global__ __launch_bounds__(256) void schur_gather_kernel(GatherArgs a) {
                 for (int u = 0; u < 8; ++u) {
                     const int src = (int)min(u0 + (uint32_t)u, nc - 1);
                     GatherCon k; k.off = (uint32_t)__builtin_amdgcn_readlane((int)mine.off, src); k.ld = (uint32_t)__builtin_amdgcn_readlane((int)mine.ld, src);
-                    k.aux = (uint32_t)__builtin_amdgcn_readlane((int)mine.aux, src); k.cinv = (uint32_t)__builtin_amdgcn_readlane((int)mine.cinv, src);
-                    if (k.ld) t[u] = k.aux ? a.slab[k.off + b2 + k.ld * a2] : a.slab[k.off + a2 + k.ld * b2];   // aux: the share lies above the diagonal of S in reduced order -- its transpose is wanted
-                    else {                                          // a member of a small supernode: e_a' (C_v + lambda I)^-1 e_b on the fly
-                        const int dv = a.dv; const double* ea = a.A + k.off + (size_t)dv * a2; const double* eb = J.kind == 0 ? a.A + k.aux + (size_t)dv * b2 : a.b + k.aux;
-                        const double* ci = a.Cinv + k.cinv; double s2 = 0.0;
-                        for (int m = 0; m < dv; ++m) { double r2 = 0.0; for (int n2 = 0; n2 < dv; ++n2) r2 = fma(ci[m + dv * n2], eb[n2], r2); s2 = fma(ea[m], r2, s2); }
-                        t[u] = s2;
-                    }
+                    k.aux = (uint32_t)__builtin_amdgcn_readlane((int)mine.aux, src); k.cinv = 0;
+                    t[u] = k.aux ? a.slab[k.off + b2 + k.ld * a2] : a.slab[k.off + a2 + k.ld * b2];   // aux: the share lies above the diagonal of S in reduced order -- its transpose is wanted
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (u0 + (uint32_t)u < nc) v -= t[u];

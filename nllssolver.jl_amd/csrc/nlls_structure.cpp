@@ -1146,8 +1146,7 @@ int build_schur(nlls_ctx* c, int32_t flags) {
             std::map<Key, std::vector<GatherCon>> pairs; std::map<uint32_t, std::vector<GatherCon>> rhs;
             std::vector<uint32_t> slab_off, slab_groups; uint64_t off = 0; bool ok = (uint64_t)I0.nnz_data < ((uint64_t)1 << 32) && (uint64_t)I0.ndof < ((uint64_t)1 << 32);
             int64_t cls_count[3] = {0, 0, 0};
-            constexpr uint32_t SMALL_SUPERNODE = 0;      // members: up to here a supernode's share is formed inside the gather, member by member (measured: only pays for supernodes that are rare; the 1-2 member supernodes of config 4 are not -- 0 = off)
-            const int dv = c->fast_dv;
+            // (shares formed INSIDE the gather, member by member, for the one- and two-member supernodes: measured twice -- rounds 4 and 6, notes/r06.md -- and slower; out of the library)
             for (size_t pos = 0; ok && pos < fastg_all.size(); ++pos) {
                 const uint32_t gi = fastg_all[pos];
                 const uint32_t v0 = egroup[gi], v1 = egroup[gi + 1];
@@ -1155,17 +1154,6 @@ int build_schur(nlls_ctx* c, int32_t flags) {
                 if (nl.size() > 16) { ok = false; break; }
                 // (the columns of a supernode are in MEMORY order, the reduced order may be any permutation of it: a share whose list pair (a >= b) lies
                 //  above the diagonal of S is flagged and read transposed by the gather)
-                if (v1 - v0 <= SMALL_SUPERNODE) {
-                    for (uint32_t v = v0; v < v1; ++v) {
-                        const SchurNbr* nv = enbr.data() + eptr[v];
-                        for (size_t a = 0; a < nl.size(); ++a) {
-                            for (size_t b2 = 0; b2 <= a; ++b2) { const bool tr = nl[a].rcol < nl[b2].rcol; const size_t hi2 = tr ? b2 : a, lo2 = tr ? a : b2;
-                                pairs[Key{nl[hi2].rcol, nl[lo2].rcol}].push_back(GatherCon{(uint32_t)nv[hi2].off, 0, (uint32_t)nv[lo2].off, (uint32_t)((uint64_t)v * dv * dv)}); }
-                            rhs[nl[a].rcol].push_back(GatherCon{(uint32_t)nv[a].off, 0, eboff[v], (uint32_t)((uint64_t)v * dv * dv)});
-                        }
-                    }
-                    continue;
-                }
                 const int cls = (int64_t)pos < c->n_fast_n60 ? 0 : ((int64_t)pos < c->n_fast_narrow ? 1 : 2);
                 cls_count[cls]++; slab_groups.push_back(gi);
                 slab_off.push_back((uint32_t)off);
