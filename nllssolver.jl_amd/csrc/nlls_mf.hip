@@ -32,9 +32,10 @@ struct MfArgs {
     double* stamps;                                                      // nlls_ctx::stamp_ptr (device-timed buckets)
     uint32_t nbig, ntiny;                                                // supernodes of several batches (one workgroup each) come first, then those of ONE batch (one wavefront each)
 };
-// per-wavefront LDS: [E slab: B x (DP + 1) x LDC | red: 64 x NRED | sums: BMAX x NRED | cinv: BMAX x (DP + 1) x DP]; at least the supernode's share in slab layout (nlls_ctx::mf_wsz).
-// Row DP of a member's slab and of its inverse block is ZERO: the lanes of the instruction's fourth k-slot (DP = 3) read their operands there like the others -- no selects in the member loop
-// (forty v_cndmask per member stood in front of its ten matrix-core instructions)
+// per-wavefront LDS: [E slab: B x DP x LDC, then ONE zero row | red: 64 x NRED | sums: BMAX x NRED | cinv: BMAX x (DP + 1) x DP]; at least the supernode's share in slab layout (nlls_ctx::mf_wsz).
+// The matrix-core loop takes FOUR rows of the batch per instruction, across members; the k-slots behind the batch's last row read their A operand from the ZERO row behind the members'
+// rows and their B operand through the zero row DP of an inverse block -- like the others, no selects on the operands.  (Round 6, late: a zero row PER MEMBER was a quarter of the slab
+// and of the matrix-core time.)
 // LDS strides of the slab: a row of [E | b] is 16 TR doubles + 8 (the four k-rows of a member then start 16 banks apart: the lanes of the four k-slots read their A operands
 // in ONE instruction -- with rows a multiple of 64 doubles apart all four hit the same banks: 117 instead of 83 us), a member (DP + 1) rows + 1 (the members' blocks a bank pair apart: the
 // evaluation's stores of one instruction come from up to eight members)
@@ -45,7 +46,7 @@ struct MfArgs {
 #define MF_MEMPAD 2      /* even: with an ODD member stride the launch took 115 instead of 82 us at BASELINE config 4 */
 #endif
 NLLS_HD constexpr int mf_row_stride(int tr) { return 16 * tr + MF_ROWPAD; }
-NLLS_HD constexpr int mf_member_stride(int dp, int tr) { return (dp + 1) * mf_row_stride(tr) + MF_MEMPAD; }
+NLLS_HD constexpr int mf_member_stride(int dp, int tr) { return dp * mf_row_stride(tr) + MF_MEMPAD; }
 NLLS_HD uint32_t mf_wave_lds(uint32_t ecap, int dp) { const uint32_t nred = (uint32_t)(dp * (dp + 1) / 2 + dp); return (ecap + 64 * nred + MF_BMAX * (nred + (uint32_t)((dp + 1) * dp)) + 1) & ~1u; }
 
 // All batches first, first + stride, ... of one supernode, by ONE wavefront: evaluation, slab, (C + lambda I)^-1, and the members' rank-DP updates summed into acc.
@@ -61,7 +62,7 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
     const double* __restrict__ vars = a.vars; const double* __restrict__ odata = a.odata; const uint32_t* __restrict__ ovoff = a.ovoff;
     const RobustSpec rk = a.rk; const double lambda = a.lambda;
     const uint32_t obs0 = d.obs0, v0 = d.v0, eb0 = d.eb0;
-    const int kk = lk < DP ? lk : DP;                    // (lanes of a k-slot the block does not have: the zero row)
+    const double* const zrow = Ew + (size_t)B * MST + li;                      // the slab's one zero row (rows behind the batch's last in the matrix-core loop)
     using St = double[2][MAXST];
     struct Rec { double dd[R::NDATA]; uint32_t vo[2]; };
     auto load_rec = [&](int mb, Rec& r) {                             // unconditional, clamped (a predicated load becomes copy + vmcnt(0))
@@ -153,18 +154,23 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
             for (int r2 = 0; r2 < DP; ++r2) { const double bv = sm[NSYM + r2]; a.b[eb0 + (size_t)(mb + lane) * DP + r2] = bv; Ew[(size_t)lane * MST + r2 * LDC + nd] = bv; }   // the right-hand side rides as column nd
         }
         wave_lds_sync();
-        // per member: S_supernode += E' (C + lambda I)^-1 [E | b] on the matrix cores -- tile (Rr, Cc) is one instruction whose A operand is lane (i, k) <- e_{16 Rr + i}[k]
-        // and whose B operand is lane (j, k) <- y_{16 Cc + j}[k], y = (C + lambda I)^-1 e; both read from the slab (row k of E is contiguous: sixteen lanes, sixteen doubles).
+        // S_supernode += E' (C + lambda I)^-1 [E | b] on the matrix cores, FOUR ROWS of [E | b] per step: the k-slots of v_mfma_f64_16x16x4_f64 take rows rho = 4 t + lk of the batch's
+        // DP nlive rows -- whichever members they belong to (a member's DP = 3 rows used three of the four slots: a quarter of the matrix-core time multiplied zeros) --: tile (Rr, Cc)
+        // is one instruction whose A operand is lane (i, k) <- e_rho[16 Rr + i] and whose B operand is lane (j, k) <- y_rho[16 Cc + j], y = (C_m + lambda I)^-1 e of the row's member m;
+        // both read from the slab (a row of E is contiguous: sixteen lanes, sixteen doubles).  Rows behind the last: the slab's zero row and the inverse block's zero row.
+        const int nrow = nlive * DP;
 #pragma unroll 1
-        for (int m2 = 0; m2 < nlive; ++m2) {
-            const double* em = Ew + (size_t)m2 * MST + li;
+        for (int t0 = 0; t0 < nrow; t0 += 4) {
+            const int rho = t0 + lk; const bool on = rho < nrow; const int m2 = on ? rho / DP : 0, q2 = rho - m2 * DP;
+            const double* em = Ew + (size_t)m2 * MST + li; const double* ea = on ? em + q2 * LDC : zrow;
+            const double* cw = cinvw + (on ? m2 * ((DP + 1) * DP) + q2 * DP : DP * DP);
             double cr[DP];
 #pragma unroll
-            for (int q = 0; q < DP; ++q) cr[q] = cinvw[m2 * ((DP + 1) * DP) + kk * DP + q];
+            for (int q = 0; q < DP; ++q) cr[q] = cw[q];
             double aop[TRK], bop[TRK];
 #pragma unroll
             for (int r2 = 0; r2 < TRK; ++r2) {
-                aop[r2] = em[kk * LDC + 16 * r2];
+                aop[r2] = ea[16 * r2];
                 double y = 0.0;
 #pragma unroll
                 for (int q = 0; q < DP; ++q) y = fma(cr[q], em[q * LDC + 16 * r2], y);
@@ -192,7 +198,7 @@ __device__ __forceinline__ void mf_elim_big(const MfArgs& a, uint32_t bidx, doub
     const int nd = (int)d.nd, nmem = (int)d.nmem, B = (int)d.B, ncb = nd / DC;
     const int TR = (nd + 1 + 15) >> 4;
     double* const Ew = lds + (size_t)wave * a.wsz;
-    for (int i = lane; i < B * mf_member_stride(DP, TR); i += 64) Ew[i] = 0.0;      // (the padding columns behind nd and the members' zero rows stay zero for the whole launch)
+    for (int i = lane; i < B * mf_member_stride(DP, TR) + mf_row_stride(TR); i += 64) Ew[i] = 0.0;      // (the padding columns behind nd and the zero row stay zero for the whole launch)
     { double* const cz = Ew + a.ecap + 64 * (DP * (DP + 1) / 2 + DP) + MF_BMAX * (DP * (DP + 1) / 2 + DP); for (int i = lane; i < MF_BMAX * (DP + 1) * DP; i += 64) cz[i] = 0.0; }
     wave_lds_sync();
     const int nbatch = (nmem + B - 1) / B, nact = min(nbatch, MF_ENW);   // wavefronts that have a batch at all
@@ -245,7 +251,7 @@ __device__ __forceinline__ void mf_elim_tiny(const MfArgs& a, uint32_t sidx, dou
     const int nd = (int)d.nd, B = (int)d.B, ncb = nd / DC;
     const int TR = (nd + 1 + 15) >> 4;
     double* const Ew = lds + (size_t)wave * a.wsz;
-    for (int i = lane; i < B * mf_member_stride(DP, TR); i += 64) Ew[i] = 0.0;
+    for (int i = lane; i < B * mf_member_stride(DP, TR) + mf_row_stride(TR); i += 64) Ew[i] = 0.0;
     { double* const cz = Ew + a.ecap + 64 * (DP * (DP + 1) / 2 + DP) + MF_BMAX * (DP * (DP + 1) / 2 + DP); for (int i = lane; i < MF_BMAX * (DP + 1) * DP; i += 64) cz[i] = 0.0; }
     wave_lds_sync();
     auto members = [&](auto TRc) {
@@ -324,6 +330,6 @@ int enqueue_mf_solve_local(nlls_ctx* c) {
 uint32_t mf_wave_doubles(uint32_t ecap, int dp) { return mf_wave_lds(ecap, dp); }
 int mf_elim_waves() { return MF_ENW; }
 int mf_batch_max() { return MF_BMAX; }
-uint32_t mf_slab_doubles(int B, int dp, int tr) { return (uint32_t)(B * mf_member_stride(dp, tr)); }
+uint32_t mf_slab_doubles(int B, int dp, int tr) { return (uint32_t)(B * mf_member_stride(dp, tr) + mf_row_stride(tr)); }      // the members' rows + the zero row
 
 }  // namespace nlls

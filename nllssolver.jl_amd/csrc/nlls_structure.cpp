@@ -639,7 +639,8 @@ int build_mf(nlls_ctx* c, int32_t ngroups, const nlls_cost_group* groups, const 
         // (members per batch: one lane per cost block, at most MF_BMAX, and -- four workgroups per CU -- a slab that leaves the wavefront's LDS region within 2446 doubles: with
         //  2514 the launch held three workgroups per CU and took 120 instead of 83 us at BASELINE config 4)
         const int ncb = nd / dc, TR0 = (nd + 1 + 15) / 16;
-        const int bcap = std::max(1, std::min({64 / ncb, bmax, (int)((2446 - (int)mf_wave_doubles(0, dp)) / (int)mf_slab_doubles(1, dp, TR0))}));
+        int bfit = 1; while (bfit < bmax && mf_wave_doubles(mf_slab_doubles(bfit + 1, dp, TR0), dp) <= 2446u) ++bfit;
+        const int bcap = std::max(1, std::min({64 / ncb, bmax, bfit}));
         const bool tiny = (int)e0.nmem <= bcap; if (tiny != (pass == 1)) continue;
         int B = tiny ? (int)e0.nmem : bcap;      // (a supernode of one batch: the batch is its members)
         if (!tiny) { int64_t best = -1; for (int b2 = 1; b2 <= bcap; ++b2) { const int64_t nbt = ((int64_t)e0.nmem + b2 - 1) / b2, rounds = (nbt + nw - 1) / nw, cost = rounds * (4 + b2); if (best < 0 || cost < best) { best = cost; B = b2; } } }
