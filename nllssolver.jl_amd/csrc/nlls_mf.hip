@@ -80,14 +80,14 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
         const int nlive = min(B, nmem - mb);
         const bool active = lane_in && ml < nlive;
         load_rec(mb + stride * B, r1);                                // the next batch's records: in flight through this batch's evaluation
+        double ev[DP][DC];                                            // this lane's block of E: in registers until the member's factor L is known (it leaves for the slab as L^-1 e)
         {
             BlockGH<KIND> G; G.compute_st(s0, r0.dd, rk, false);
+#pragma unroll
+            for (int k = 0; k < DP; ++k)
+#pragma unroll
+                for (int c2 = 0; c2 < DC; ++c2) ev[k][c2] = h_elem<KIND, PS, CS>(G, k, c2);
             if (active) {
-                double* er = Ew + (size_t)ml * MST + DC * j;
-#pragma unroll
-                for (int k = 0; k < DP; ++k)
-#pragma unroll
-                    for (int c2 = 0; c2 < DC; ++c2) er[k * LDC + c2] = h_elem<KIND, PS, CS>(G, k, c2);
                 double* rr = red + lane * NRED; int q = 0;
 #pragma unroll
                 for (int c2 = 0; c2 < DP; ++c2)
@@ -148,34 +148,55 @@ __device__ __forceinline__ void mf_wave_batches(const MfArgs& a, const MfDesc& d
 #pragma unroll
                     for (int k = r2 + 1; k < DP; ++k) t -= C[k + DP * r2] * y[k]; y[r2] = t; }
 #pragma unroll
-                for (int r2 = 0; r2 < DP; ++r2) { cinvw[lane * ((DP + 1) * DP) + r2 * DP + c2] = y[r2]; a.Cinv[vi * (DP * DP) + r2 + DP * c2] = y[r2]; }     // (LDS: row r2 of the inverse contiguous)
+                for (int r2 = 0; r2 < DP; ++r2) a.Cinv[vi * (DP * DP) + r2 + DP * c2] = y[r2];
             }
+            // the member's factor for the wave: unit lower L (row-wise, below the diagonal) and 1 / D -- the matrix-core loop forms E' C^-1 E as (L^-1 E)' D^-1 (L^-1 E): both operands
+            // from the SAME rows f = L^-1 e, the B operand one multiplication by 1 / d (with y = C^-1 e as B operand every k-slot read DP rows and did DP FMAs per tile column)
+            { double* lw = cinvw + lane * ((DP + 1) * DP); int q = 0;
 #pragma unroll
-            for (int r2 = 0; r2 < DP; ++r2) { const double bv = sm[NSYM + r2]; a.b[eb0 + (size_t)(mb + lane) * DP + r2] = bv; Ew[(size_t)lane * MST + r2 * LDC + nd] = bv; }   // the right-hand side rides as column nd
+              for (int r2 = 1; r2 < DP; ++r2)
+#pragma unroll
+                  for (int c2 = 0; c2 < r2; ++c2) lw[q++] = C[r2 + DP * c2];
+#pragma unroll
+              for (int r2 = 0; r2 < DP; ++r2) lw[NSYM - DP + r2] = id[r2]; }
+            double fb[DP];
+#pragma unroll
+            for (int r2 = 0; r2 < DP; ++r2) { const double bv = sm[NSYM + r2]; a.b[eb0 + (size_t)(mb + lane) * DP + r2] = bv; double t = bv;
+#pragma unroll
+                for (int k = 0; k < r2; ++k) t -= C[r2 + DP * k] * fb[k];
+                fb[r2] = t; Ew[(size_t)lane * MST + r2 * LDC + nd] = t; }   // the right-hand side rides as column nd (forward-substituted like the rows of E)
+        }
+        wave_lds_sync();
+        if (active) {                                                 // f = L^-1 e of this lane's block, into the slab
+            const double* lw = cinvw + ml * ((DP + 1) * DP);
+            double lv[NSYM - DP > 0 ? NSYM - DP : 1];
+#pragma unroll
+            for (int q = 0; q < NSYM - DP; ++q) lv[q] = lw[q];
+            double* er = Ew + (size_t)ml * MST + DC * j;
+#pragma unroll
+            for (int c2 = 0; c2 < DC; ++c2) {
+                double f[DP];
+#pragma unroll
+                for (int r2 = 0; r2 < DP; ++r2) { double t = ev[r2][c2];
+#pragma unroll
+                    for (int k = 0; k < r2; ++k) t -= lv[r2 * (r2 - 1) / 2 + k] * f[k];
+                    f[r2] = t; er[r2 * LDC + c2] = t; }
+            }
         }
         wave_lds_sync();
         // S_supernode += E' (C + lambda I)^-1 [E | b] on the matrix cores, FOUR ROWS of [E | b] per step: the k-slots of v_mfma_f64_16x16x4_f64 take rows rho = 4 t + lk of the batch's
         // DP nlive rows -- whichever members they belong to (a member's DP = 3 rows used three of the four slots: a quarter of the matrix-core time multiplied zeros) --: tile (Rr, Cc)
-        // is one instruction whose A operand is lane (i, k) <- e_rho[16 Rr + i] and whose B operand is lane (j, k) <- y_rho[16 Cc + j], y = (C_m + lambda I)^-1 e of the row's member m;
-        // both read from the slab (a row of E is contiguous: sixteen lanes, sixteen doubles).  Rows behind the last: the slab's zero row and the inverse block's zero row.
+        // is one instruction whose A operand is lane (i, k) <- f_rho[16 Rr + i] and whose B operand is lane (j, k) <- f_rho[16 Cc + j] / d_rho, f = L_m^-1 [e | b] of the row's member m
+        // (C_m + lambda I = L D L'); read from the slab (a row is contiguous: sixteen lanes, sixteen doubles).  Rows behind the last: the slab's zero row.
         const int nrow = nlive * DP;
 #pragma unroll 1
         for (int t0 = 0; t0 < nrow; t0 += 4) {
             const int rho = t0 + lk; const bool on = rho < nrow; const int m2 = on ? rho / DP : 0, q2 = rho - m2 * DP;
-            const double* em = Ew + (size_t)m2 * MST + li; const double* ea = on ? em + q2 * LDC : zrow;
-            const double* cw = cinvw + (on ? m2 * ((DP + 1) * DP) + q2 * DP : DP * DP);
-            double cr[DP];
-#pragma unroll
-            for (int q = 0; q < DP; ++q) cr[q] = cw[q];
+            const double* ea = on ? Ew + (size_t)m2 * MST + q2 * LDC + li : zrow;
+            const double dinv = cinvw[(on ? m2 * ((DP + 1) * DP) + q2 : 0) + NSYM - DP];
             double aop[TRK], bop[TRK];
 #pragma unroll
-            for (int r2 = 0; r2 < TRK; ++r2) {
-                aop[r2] = ea[16 * r2];
-                double y = 0.0;
-#pragma unroll
-                for (int q = 0; q < DP; ++q) y = fma(cr[q], em[q * LDC + 16 * r2], y);
-                bop[r2] = y;
-            }
+            for (int r2 = 0; r2 < TRK; ++r2) { aop[r2] = ea[16 * r2]; bop[r2] = aop[r2] * dinv; }
 #pragma unroll
             for (int Rr = 0; Rr < TRK; ++Rr)
 #pragma unroll
