@@ -26,18 +26,18 @@ struct MfArgs {
     const double* vars; const double* odata; const uint32_t* ovoff;      // the blocks in elimination order (Group::mf_data / mf_voff)
     RobustSpec rk;
     const MfDesc* desc; const uint32_t* rcflat;
-    double* Cinv; double* b; double* slab;                               // per member: (C_v + lambda I)^-1 and b_v (b's eliminated part); per supernode: its share of [S | s]
+    double* Cinv; double* b; double* slab;                               // per member: (C_v + lambda I)^-1 (for the back-substitution) and b_v (b's eliminated part); per supernode: its share of [S | s]
     double lambda; int* status;
     uint32_t wsz, ecap;                                                  // doubles of LDS per wavefront, of which the E slab
     double* stamps;                                                      // nlls_ctx::stamp_ptr (device-timed buckets)
     uint32_t nbig, ntiny;                                                // supernodes of several batches (one workgroup each) come first, then those of ONE batch (one wavefront each)
 };
-// per-wavefront LDS: [E slab: B x DP x LDC, then ONE zero row | red: 64 x NRED | sums: BMAX x NRED | cinv: BMAX x (DP + 1) x DP]; at least the supernode's share in slab layout (nlls_ctx::mf_wsz).
-// The matrix-core loop takes FOUR rows of the batch per instruction, across members; the k-slots behind the batch's last row read their A operand from the ZERO row behind the members'
-// rows and their B operand through the zero row DP of an inverse block -- like the others, no selects on the operands.  (Round 6, late: a zero row PER MEMBER was a quarter of the slab
-// and of the matrix-core time.)
-// LDS strides of the slab: a row of [E | b] is 16 TR doubles + 8 (the four k-rows of a member then start 16 banks apart: the lanes of the four k-slots read their A operands
-// in ONE instruction -- with rows a multiple of 64 doubles apart all four hit the same banks: 117 instead of 83 us), a member (DP + 1) rows + 1 (the members' blocks a bank pair apart: the
+// per-wavefront LDS: [slab: B x DP x LDC rows of L^-1 [E | b], then ONE zero row | red: 64 x NRED | sums: BMAX x NRED | factors: BMAX x (DP + 1) x DP (per member: L below the diagonal, then 1 / D)];
+// at least the supernode's share in slab layout (nlls_ctx::mf_wsz).
+// The matrix-core loop takes FOUR rows of the batch per instruction, across members; the k-slots behind the batch's last row read the ZERO row behind the members' rows -- like the
+// others, no selects on the operands.  (Round 6, late: a zero row PER MEMBER was a quarter of the slab and of the matrix-core time.)
+// LDS strides of the slab: a row is 16 TR doubles + 8 (consecutive rows then start 16 banks apart: the lanes of the four k-slots read their A operands in ONE instruction -- with rows a
+// multiple of 64 doubles apart all four hit the same banks: 117 instead of 83 us), a member DP rows + 2 (EVEN: with an odd member stride the launch took 115 instead of 82 us; the
 // evaluation's stores of one instruction come from up to eight members)
 #ifndef MF_ROWPAD
 #define MF_ROWPAD 8
