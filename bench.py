@@ -499,7 +499,7 @@ def main():
         strong = {"scaling": "strong", "workload": f"ba_10kx1M: {sc} cameras x {sp} points ({stotal} residual blocks) split by point over {world} ranks",
                   "value": round(args.steps / selapsed, 3), "unit": "LM iters/s", "ms_per_step": round(1e3 * selapsed / args.steps, 4), "residual_blocks_per_s": round(stotal * args.steps / selapsed, 1),
                   "lm_trials_per_s": round(sloop.data.linearsolvers / selapsed, 1), "local_residual_blocks": int(sls.local_nobs), "start_cost": sloop.data.startcost, "final_cost": sloop.data.bestcost,
-                  "one_gpu_reference": "profiles/r06c_bench_ba_10kx1M.json (python bench.py --workload ba_10kx1M on one MI355X: 675 LM iterations/s, matrix-free)"}
+                  "one_gpu_reference": "profiles/r06e_bench_ba_10kx1M.json (python bench.py --workload ba_10kx1M on one MI355X: 695 LM iterations/s, matrix-free)"}
         sls.close()
 
     # ---- weak-scaling leg (N > 1 only): N x 100k points against the SAME cameras, sharded by point -- per-rank sweeps, elimination and
