@@ -695,3 +695,29 @@ def test_device_timed_result_buckets():
         assert abs((tg + tc + ts) - wall) < 0.15 * wall, (mat, tg, tc, ts, wall)
         assert data.timesolver > 0 and data.timecost > 0 and data.timegradient > 0      # (nanoseconds, as the loop reports them: nlls_lm_state)
         ls.close()
+
+@pytest.mark.gpu
+def test_zero_point_block_raises_on_both_trial_paths():
+    """An eliminated block whose diagonal block is exactly zero (a point seen by one camera whose pose is all zeros: its Jacobian vanishes): the undamped trial must come
+    back with NLLS_ERR_NOT_SPD -- matrix-free (the block's LDL' inside mf_elim_kernel) and materialised (schur_elim_all_kernel's) alike, as the sharded route does on every
+    rank (tests/sharded_worker.py: singular_point_block) --, and a damped trial on the same context must go through afterwards, the same on both paths."""
+    p = synthetic.perturb_ba_problem(synthetic.create_ba_problem(130, 3000, 10.5 / 130, seed=5), 1e-3, 1e-3)
+    g = next(iter(p.costs.values())); vi, da = g.arrays()
+    last = p.nvariables
+    keep = vi[:, 1] != last
+    g.set_arrays(np.concatenate([vi[keep], [[1, last]]]), np.concatenate([da[keep], [[0.0, 0.0]]]))
+    p.variables[:6] = 0.0
+    bi = np.arange(1, p.nvariables + 1, dtype=np.uint64)
+    costs = {}
+    for mat in (0, 1):
+        ctx = _capi.Context(); ctx.upload(p.var_kind, p.var_dim, bi, p.groups(), 0); ctx.set_option(_capi.OPT_MATERIALIZE, mat)
+        ctx.set_variables(p.variables); ctx.sweep_gradhess()
+        n0 = ctx.solve_stats()["mf_trials"]
+        with pytest.raises(_capi.NllsError) as e:
+            ctx.lm_trial(0.0)
+        assert e.value.code == _capi.ERR_NOT_SPD
+        assert ctx.solve_stats()["mf_trials"] - n0 == (0 if mat else 1)
+        costs[mat] = ctx.lm_trial(1e-3 * ctx.max_abs_diag())                  # damped: C_v + lambda I is regular
+        assert np.isfinite(costs[mat])
+        ctx.close()
+    assert np.isclose(costs[0], costs[1], rtol=1e-9)
