@@ -153,6 +153,26 @@ __device__ __forceinline__ void chain_hybrid(bdouble4_t& A, bdouble4_t& Bt, int 
         for (int r = 0; r < 4; ++r) { const double a = lk + 4 * r > k ? rowv[r] : 0.0; Bt[r] = fma(a, cb, Bt[r]); }
     }
 }
+// V == 11: the library's chain ROLLED over the four pivots of a register group (the register A[r] of pivot k = 4 r + q must be a compile-time choice, the lane group q need not):
+// four pivot bodies of code instead of fifteen -- a kernel launched once per level starts with a cold instruction cache, and the chain is the first thing wave 0 runs
+__device__ __forceinline__ void chain_rolled(bdouble4_t& A, bdouble4_t& Bt, int li, int lk) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll 1
+        for (int q = 0; q < (r == 3 ? 3 : 4); ++q) {
+            const int k = 4 * r + q;
+            const double w = A[r], bt = Bt[r];
+            const double dk = rl(w, 16 * q + k);
+            double rdk = __builtin_amdgcn_rcp(dk);
+            const bool rowq = lk == q;
+            const double am = (rowq && li > k) ? w : 0.0;
+            const double bm = rowq ? bt : 0.0;
+            rdk = refine(dk, rdk);
+            A = __builtin_amdgcn_mfma_f64_16x16x4f64(am, am * -rdk, A, 0, 0, 0);
+            Bt = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm * -rdk, Bt, 0, 0, 0);
+        }
+    }
+}
 template <int V>
 __global__ void k(const double* T, double* out, long long* cyc, int reps) {
     const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
@@ -162,7 +182,7 @@ __global__ void k(const double* T, double* out, long long* cyc, int reps) {
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < reps; ++it) {
         bdouble4_t A = A0, Bt = B0; A[0] += acc * 1e-300;        // (a dependence from one repetition to the next)
-        if constexpr (V == 6) chain_deferred(A, Bt, li, lk); else if constexpr (V == 9) chain_valu(A, Bt, li, lk); else if constexpr (V == 10) chain_hybrid(A, Bt, li, lk); else if constexpr (V == 7) chain_blocked(A, Bt, li, lk); else if constexpr (V == 8) chain_blocked2(A, Bt, li, lk); else chain<V>(A, Bt, li, lk);
+        if constexpr (V == 6) chain_deferred(A, Bt, li, lk); else if constexpr (V == 9) chain_valu(A, Bt, li, lk); else if constexpr (V == 10) chain_hybrid(A, Bt, li, lk); else if constexpr (V == 11) chain_rolled(A, Bt, li, lk); else if constexpr (V == 7) chain_blocked(A, Bt, li, lk); else if constexpr (V == 8) chain_blocked2(A, Bt, li, lk); else chain<V>(A, Bt, li, lk);
         acc += A[3] + Bt[3];
     }
     const long long t1 = __builtin_readcyclecounter();
@@ -178,10 +198,10 @@ __global__ void dump(const double* T, double* outA, double* outB) {
 int main() {
     double h[256]; for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) h[i * 16 + j] = (i == j ? 20.0 : 0.0) + 1.0 / (1 + i + j);
     double *T, *out; long long* cyc; hipMalloc(&T, sizeof h); hipMalloc(&out, 64 * 8); hipMalloc(&cyc, 8); hipMemcpy(T, h, sizeof h, hipMemcpyHostToDevice);
-    const int reps = 2000; const char* names[] = {"full chain (as in the library)", "without the inverse's MFMA", "raw v_rcp_f64 (no refinement)", "no v_rcp_f64 (constant)", "no MFMA (vector FMAs)", "pivot by ds_bpermute instead of v_readlane", "the inverse's MFMA deferred behind the next read-lane", "four pivots per MFMA (in-group elimination on the vector side)", "... the group's columns fetched once, eliminated in every row group", "ALL-VECTOR rank-1 updates (12 ds_bpermute + 8 FMA per pivot, no MFMA)", "hybrid: tile on the matrix core, inverse on the vector side (10 ds_bpermute + 4 FMA)"};
+    const int reps = 2000; const char* names[] = {"full chain (as in the library)", "without the inverse's MFMA", "raw v_rcp_f64 (no refinement)", "no v_rcp_f64 (constant)", "no MFMA (vector FMAs)", "pivot by ds_bpermute instead of v_readlane", "the inverse's MFMA deferred behind the next read-lane", "four pivots per MFMA (in-group elimination on the vector side)", "... the group's columns fetched once, eliminated in every row group", "ALL-VECTOR rank-1 updates (12 ds_bpermute + 8 FMA per pivot, no MFMA)", "hybrid: tile on the matrix core, inverse on the vector side (10 ds_bpermute + 4 FMA)", "library chain rolled over the four pivots of a register group (4 bodies of code, not 15)"};
     auto run = [&](auto kern, int v) { long long c = 0; for (int w = 0; w < 2; ++w) { hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, 0, T, out, cyc, reps); hipDeviceSynchronize(); } hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
         printf("%-48s %8.1f shader-clock cycles per pivot\n", names[v], (double)c / reps / 15.0); };
-    run(k<0>, 0); run(k<1>, 1); run(k<2>, 2); run(k<3>, 3); run(k<4>, 4); run(k<5>, 5); run(k<6>, 6); run(k<7>, 7); run(k<8>, 8); run(k<9>, 9); run(k<10>, 10);
+    run(k<0>, 0); run(k<1>, 1); run(k<2>, 2); run(k<3>, 3); run(k<4>, 4); run(k<5>, 5); run(k<6>, 6); run(k<7>, 7); run(k<8>, 8); run(k<9>, 9); run(k<10>, 10); run(k<11>, 11);
     { double *dA, *dB; hipMalloc(&dA, 256 * 8); hipMalloc(&dB, 256 * 8); double a0[256], b0[256], a7[256], b7[256];
       hipLaunchKernelGGL(dump<0>, dim3(1), dim3(64), 0, 0, T, dA, dB); hipMemcpy(a0, dA, sizeof a0, hipMemcpyDeviceToHost); hipMemcpy(b0, dB, sizeof b0, hipMemcpyDeviceToHost);
       hipLaunchKernelGGL(dump<8>, dim3(1), dim3(64), 0, 0, T, dA, dB); hipMemcpy(a7, dA, sizeof a7, hipMemcpyDeviceToHost); hipMemcpy(b7, dB, sizeof b7, hipMemcpyDeviceToHost);
@@ -192,6 +212,9 @@ int main() {
       hipLaunchKernelGGL(dump<9>, dim3(1), dim3(64), 0, 0, T, dA, dB); hipMemcpy(a9, dA, sizeof a9, hipMemcpyDeviceToHost); hipMemcpy(b9, dB, sizeof b9, hipMemcpyDeviceToHost);
       int same = 1; for (int i = 0; i < 256; ++i) same &= (a0[i] == a9[i]) && (b0[i] == b9[i]);
       printf("all-vector == library chain, bit for bit: %s\n", same ? "yes" : "NO"); }
+    { double o0[64], o11[64]; hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, T, out, cyc, 1); hipMemcpy(o0, out, sizeof o0, hipMemcpyDeviceToHost); long long c0 = 0, c11 = 0; hipMemcpy(&c0, cyc, 8, hipMemcpyDeviceToHost);
+      hipLaunchKernelGGL(k<11>, dim3(1), dim3(64), 0, 0, T, out, cyc, 1); hipMemcpy(o11, out, sizeof o11, hipMemcpyDeviceToHost); hipMemcpy(&c11, cyc, 8, hipMemcpyDeviceToHost);
+      int same = 1; for (int i = 0; i < 64; ++i) same &= o0[i] == o11[i]; printf("rolled == library chain, bit for bit: %s;  ONE chain in a fresh launch (cold instruction cache): library %lld cycles, rolled %lld\n", same ? "yes" : "NO", c0, c11); }
     { double o0[64], o6[64]; hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, T, out, cyc, 1); hipMemcpy(o0, out, sizeof o0, hipMemcpyDeviceToHost); hipLaunchKernelGGL(k<6>, dim3(1), dim3(64), 0, 0, T, out, cyc, 1); hipMemcpy(o6, out, sizeof o6, hipMemcpyDeviceToHost);
       int same = 1; for (int i = 0; i < 64; ++i) same &= o0[i] == o6[i]; printf("deferred == library chain, bit for bit: %s\n", same ? "yes" : "NO"); }
     return 0;
